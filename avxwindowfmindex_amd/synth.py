@@ -1,0 +1,107 @@
+"""Seeded synthetic texts and query sets, numpy side.
+
+splitmix64 is counter based: the i-th output of a stream seeded with ``s`` is
+``mix(s + (i+1)*GOLDEN)``, so every character can be generated independently
+(the HIP generators in csrc/awfm_synth.hip compute exactly the same values).
+
+  text char i          = alphabet[ mix(seed + (i+1)*G) % |A| ]
+  query j stream state = q_j = mix(seed_q + j)            ("hashed once")
+  random query j       : char c = alphabet[ mix(q_j + (c+1)*G) % |A| ]
+  planted query j      : offset = mix(q_j + G) % (n-L+1), chars = text[offset:offset+L]
+  mixed length j       : L = lo + mix(q_j + 2^63 + G) % (hi-lo+1)
+"""
+import numpy as np
+
+GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+DNA_ALPHABET = b"acgt"
+AMINO_ALPHABET = b"acdefghiklmnpqrstvwy"
+
+
+def mix64(z):
+    z = np.asarray(z, dtype=np.uint64).copy()
+    with np.errstate(over="ignore"):
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+def stream(seed, start, count):
+    """outputs start..start+count-1 of the splitmix64 stream seeded with ``seed``"""
+    with np.errstate(over="ignore"):
+        idx = np.arange(start + 1, start + count + 1, dtype=np.uint64)
+        return mix64(np.uint64(seed) + idx * GOLDEN)
+
+
+def text(seed, n, alphabet=DNA_ALPHABET, start=0):
+    lut = np.frombuffer(alphabet, dtype=np.uint8)
+    return lut[(stream(seed, start, n) % np.uint64(len(alphabet))).astype(np.int64)]
+
+
+def _qstate(seed_q, first, count):
+    with np.errstate(over="ignore"):
+        return mix64(np.uint64(seed_q) + np.arange(first, first + count, dtype=np.uint64))
+
+
+def random_queries(seed_q, count, length, alphabet=DNA_ALPHABET, first=0):
+    """uint8[count, length] of uniform random k-mers (query ids first..first+count-1)"""
+    lut = np.frombuffer(alphabet, dtype=np.uint8)
+    q = _qstate(seed_q, first, count)[:, None]
+    with np.errstate(over="ignore"):
+        c = (np.arange(1, length + 1, dtype=np.uint64) * GOLDEN)[None, :]
+        z = mix64(q + c)
+    return lut[(z % np.uint64(len(alphabet))).astype(np.int64)]
+
+
+def planted_offsets(seed_q, count, length, n, first=0):
+    q = _qstate(seed_q, first, count)
+    with np.errstate(over="ignore"):
+        return mix64(q + GOLDEN) % np.uint64(n - length + 1)
+
+
+def planted_queries(seed_q, count, length, txt, first=0):
+    off = planted_offsets(seed_q, count, length, len(txt), first).astype(np.int64)
+    return txt[off[:, None] + np.arange(length, dtype=np.int64)[None, :]]
+
+
+def mixed_lengths(seed_q, count, lo=8, hi=30, first=0):
+    q = _qstate(seed_q, first, count)
+    with np.errstate(over="ignore"):
+        return (np.uint64(lo) + mix64(q + np.uint64(1 << 63) + GOLDEN) % np.uint64(hi - lo + 1)).astype(np.int64)
+
+
+def mixed_queries(seed_q, count, txt, alphabet=DNA_ALPHABET, lo=8, hi=30, first=0):
+    """CSR (chars uint8, offsets uint64): even ids random, odd ids planted, lengths lo..hi"""
+    lens = mixed_lengths(seed_q, count, lo, hi, first)
+    offsets = np.zeros(count + 1, dtype=np.uint64)
+    np.cumsum(lens, out=offsets[1:])
+    chars = np.empty(int(offsets[-1]), dtype=np.uint8)
+    rnd = random_queries(seed_q, count, hi, alphabet, first)
+    n = len(txt)
+    q = _qstate(seed_q, first, count)
+    with np.errstate(over="ignore"):
+        draw = mix64(q + GOLDEN)
+    for j in range(count):
+        L = int(lens[j])
+        o = int(offsets[j])
+        if (first + j) % 2 == 0:
+            chars[o:o + L] = rnd[j, :L]
+        else:
+            s = int(draw[j] % np.uint64(n - L + 1))
+            chars[o:o + L] = txt[s:s + L]
+    return chars, offsets
+
+
+def fixed_csr(q2d):
+    """uint8[count, L] -> CSR (chars, offsets)"""
+    count, L = q2d.shape
+    return np.ascontiguousarray(q2d).reshape(-1), (np.arange(count + 1, dtype=np.uint64) * np.uint64(L))
+
+
+def fnv1a(arr, h=0xCBF29CE484222325):
+    """FNV-1a-64 of the array's bytes (slow pure-python; use for small arrays)"""
+    for b in np.ascontiguousarray(arr).view(np.uint8).reshape(-1).tolist():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
