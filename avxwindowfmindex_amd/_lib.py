@@ -1,0 +1,138 @@
+"""ctypes loader and struct mirrors for libawfmindex_amd.so (include/AwFmIndex.h, include/awfm_gpu.h)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libawfmindex_amd.so")
+_LIB = None
+
+AwFmAlphabetAmino, AwFmAlphabetDna, AwFmAlphabetRna = 1, 2, 3
+AwFmSuccess, AwFmFileReadOkay, AwFmFileWriteOkay = 1, 2, 3
+AwFmGeneralFailure = -1
+AwFmFileReadFail = -11
+
+# every symbol the two public headers declare
+API_SYMBOLS = [
+    "awFmCreateIndex", "awFmCreateIndexFromFasta", "awFmDeallocIndex", "awFmWriteIndexToFile",
+    "awFmReadIndexFromFile", "awFmCreateKmerSearchList", "awFmDeallocKmerSearchList", "awFmParallelSearchLocate",
+    "awFmParallelSearchCount", "awFmFindSearchRangeForString", "awFmReadSequenceFromFile",
+    "awFmCreateInitialQueryRange", "awFmCreateInitialQueryRangeFromChar",
+    "awFmNucleotideIterativeStepBackwardSearch", "awFmAminoIterativeStepBackwardSearch",
+    "awFmFindDatabaseHitPositions", "awFmFindDatabaseHitPositionSingle",
+    "awFmGetLocalSequencePositionFromIndexPosition", "awFmNucleotideBacktraceReturnPreviousLetterIndex",
+    "awFmAminoBacktraceReturnPreviousLetterIndex", "awFmGetHeaderStringFromSequenceNumber", "awFmSearchRangeLength",
+    "awFmReturnCodeIsFailure", "awFmReturnCodeIsSuccess", "awFmGetNumSequences",
+]
+GPU_SYMBOLS = [
+    "awfmGpuDeviceCount", "awfmGpuLastError", "awfmGpuIndexCreate", "awfmGpuIndexDestroy", "awfmGpuIndexAcquire",
+    "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuSearch",
+    "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
+]
+
+
+class AwFmIndexConfiguration(C.Structure):
+    _fields_ = [("suffixArrayCompressionRatio", C.c_uint8), ("kmerLengthInSeedTable", C.c_uint8),
+                ("alphabetType", C.c_int), ("keepSuffixArrayInMemory", C.c_bool), ("storeOriginalSequence", C.c_bool)]
+
+
+class AwFmCompressedSuffixArray(C.Structure):
+    _fields_ = [("valueBitWidth", C.c_uint8), ("values", C.POINTER(C.c_uint8)), ("compressedByteLength", C.c_uint64)]
+
+
+class AwFmSearchRange(C.Structure):
+    _fields_ = [("startPtr", C.c_uint64), ("endPtr", C.c_uint64)]
+
+
+class AwFmIndex(C.Structure):
+    _fields_ = [("versionNumber", C.c_uint32), ("featureFlags", C.c_uint32), ("bwtLength", C.c_uint64),
+                ("bwtBlockList", C.c_void_p), ("prefixSums", C.POINTER(C.c_uint64)),
+                ("kmerSeedTable", C.POINTER(AwFmSearchRange)), ("fileHandle", C.c_void_p),
+                ("config", AwFmIndexConfiguration), ("fileDescriptor", C.c_int), ("suffixArrayFileOffset", C.c_size_t),
+                ("sequenceFileOffset", C.c_size_t), ("fastaVector", C.c_void_p),
+                ("suffixArray", AwFmCompressedSuffixArray)]
+
+
+class AwFmKmerSearchData(C.Structure):
+    _fields_ = [("kmerString", C.c_void_p), ("kmerLength", C.c_uint64), ("positionList", C.POINTER(C.c_uint64)),
+                ("count", C.c_uint32), ("capacity", C.c_uint32)]
+
+
+class AwFmKmerSearchList(C.Structure):
+    _fields_ = [("capacity", C.c_size_t), ("count", C.c_size_t), ("kmerSearchData", C.POINTER(AwFmKmerSearchData))]
+
+
+def build(force=False):
+    """compile libawfmindex_amd.so in-tree (hipcc --offload-arch=gfx950 + gcc)"""
+    src = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", src, "-s", "clean"])
+    subprocess.check_call(["make", "-C", src, "-s", "-j4"])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libawfmindex_amd.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+            "there is no fallback implementation")
+    try:  # share torch's HIP runtime when torch is in the process (same SONAME libamdhip64.so.7)
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    IP, LP = C.POINTER(AwFmIndex), C.POINTER(AwFmKmerSearchList)
+    RP = C.POINTER(AwFmSearchRange)
+    vp, u64 = C.c_void_p, C.c_uint64
+    sig = {
+        "awFmCreateIndex": (C.c_int, [C.POINTER(IP), C.POINTER(AwFmIndexConfiguration), vp, C.c_size_t, C.c_char_p]),
+        "awFmCreateIndexFromFasta": (C.c_int, [C.POINTER(IP), C.POINTER(AwFmIndexConfiguration), C.c_char_p, C.c_char_p]),
+        "awFmDeallocIndex": (None, [IP]),
+        "awFmWriteIndexToFile": (C.c_int, [IP, vp, u64, C.c_char_p]),
+        "awFmReadIndexFromFile": (C.c_int, [C.POINTER(IP), C.c_char_p, C.c_bool]),
+        "awFmCreateKmerSearchList": (LP, [C.c_size_t]),
+        "awFmDeallocKmerSearchList": (None, [LP]),
+        "awFmParallelSearchLocate": (C.c_int, [IP, LP, C.c_uint32]),
+        "awFmParallelSearchCount": (None, [IP, LP, C.c_uint32]),
+        "awFmFindSearchRangeForString": (AwFmSearchRange, [IP, C.c_char_p, C.c_size_t]),
+        "awFmReadSequenceFromFile": (C.c_int, [IP, C.c_size_t, C.c_size_t, C.c_char_p]),
+        "awFmCreateInitialQueryRange": (AwFmSearchRange, [IP, C.c_char_p, u64]),
+        "awFmCreateInitialQueryRangeFromChar": (AwFmSearchRange, [IP, C.c_char]),
+        "awFmNucleotideIterativeStepBackwardSearch": (None, [IP, RP, C.c_uint8]),
+        "awFmAminoIterativeStepBackwardSearch": (None, [IP, RP, C.c_uint8]),
+        "awFmFindDatabaseHitPositions": (C.POINTER(u64), [IP, RP, C.POINTER(C.c_int)]),
+        "awFmFindDatabaseHitPositionSingle": (u64, [IP, u64, C.POINTER(C.c_int)]),
+        "awFmNucleotideBacktraceReturnPreviousLetterIndex": (C.c_uint8, [IP, C.POINTER(u64)]),
+        "awFmAminoBacktraceReturnPreviousLetterIndex": (C.c_uint8, [IP, C.POINTER(u64)]),
+        "awFmSearchRangeLength": (C.c_size_t, [RP]),
+        "awFmReturnCodeIsFailure": (C.c_bool, [C.c_int]),
+        "awFmReturnCodeIsSuccess": (C.c_bool, [C.c_int]),
+        "awFmGetNumSequences": (C.c_uint32, [IP]),
+        "awfmGpuDeviceCount": (C.c_int, []),
+        "awfmGpuLastError": (C.c_char_p, []),
+        "awfmGpuIndexCreate": (C.c_int, [IP, C.c_int, C.POINTER(vp)]),
+        "awfmGpuIndexDestroy": (None, [vp]),
+        "awfmGpuIndexAcquire": (vp, [IP]),
+        "awfmGpuIndexRelease": (None, [IP]),
+        "awfmGpuIndexDeviceBytes": (u64, [vp]),
+        "awfmGpuIndexDevice": (C.c_int, [vp]),
+        "awfmGpuIndexSetKernel": (None, [vp, C.c_int]),
+        "awfmGpuSearch": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
+        "awfmGpuScanScratchBytes": (u64, [u64]),
+        "awfmGpuHitOffsets": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),
+        "awfmGpuLocate": (C.c_int, [vp, vp, vp, u64, u64, vp, vp]),
+        "awfmGpuCountHost": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp]),
+        "awfmGpuLocateHost": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, C.POINTER(C.POINTER(u64))]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    L.free = C.CDLL(None).free
+    L.free.argtypes = [vp]
+    L.free.restype = None
+    _LIB = L
+    return L

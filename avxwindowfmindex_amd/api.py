@@ -1,0 +1,245 @@
+"""Python mirror of the AwFmIndex.h interface, calling libawfmindex_amd.so through its C ABI.
+
+Names and argument meaning follow the reference API (src/AwFmIndex.h) so tests read
+like the reference's own: create_index -> awFmCreateIndex, KmerSearchList ->
+awFmCreateKmerSearchList, parallel_search_count / parallel_search_locate ->
+awFmParallelSearchCount / awFmParallelSearchLocate.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import (AwFmAlphabetAmino, AwFmAlphabetDna, AwFmAlphabetRna, AwFmFileReadOkay, AwFmFileWriteOkay,  # noqa: F401
+                   AwFmSuccess)
+
+
+class AwFmError(RuntimeError):
+    def __init__(self, what, rc):
+        msg = _lib.lib().awfmGpuLastError().decode(errors="replace")
+        super().__init__(f"{what} failed with AwFmReturnCode {rc}" + (f": {msg}" if msg else ""))
+        self.rc = rc
+
+
+def _check(what, rc, ok=(AwFmSuccess, AwFmFileReadOkay, AwFmFileWriteOkay)):
+    if rc not in ok:
+        raise AwFmError(what, rc)
+    return rc
+
+
+class Index:
+    """struct AwFmIndex* owner"""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    @property
+    def c(self):
+        return self.ptr.contents
+
+    @property
+    def bwt_length(self):
+        return int(self.c.bwtLength)
+
+    @property
+    def is_amino(self):
+        return self.c.config.alphabetType == AwFmAlphabetAmino
+
+    @property
+    def num_blocks(self):
+        return 1 + (self.bwt_length - 1) // 256
+
+    # host arrays in reference layout (views, valid while the index lives)
+    def blocks(self):
+        nbytes = self.num_blocks * (352 if self.is_amino else 160)
+        return np.ctypeslib.as_array(C.cast(self.c.bwtBlockList, C.POINTER(C.c_uint8)), shape=(nbytes,))
+
+    def prefix_sums(self):
+        return np.ctypeslib.as_array(self.c.prefixSums, shape=((20 if self.is_amino else 4) + 2,))
+
+    def seed_table(self):
+        n = (20 if self.is_amino else 4) ** int(self.c.config.kmerLengthInSeedTable)
+        return np.ctypeslib.as_array(C.cast(self.c.kmerSeedTable, C.POINTER(C.c_uint64)), shape=(n, 2))
+
+    def packed_sa(self):
+        sa = self.c.suffixArray
+        if not sa.values:
+            return None
+        return np.ctypeslib.as_array(sa.values, shape=(int(sa.compressedByteLength),))
+
+    def find_search_range_for_string(self, kmer):
+        r = _lib.lib().awFmFindSearchRangeForString(self.ptr, bytes(kmer), len(kmer))
+        return int(r.startPtr), int(r.endPtr)
+
+    def dealloc(self):
+        if self.ptr:
+            _lib.lib().awFmDeallocIndex(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.dealloc()
+        except Exception:
+            pass
+
+
+def create_index(sequence, alphabet=AwFmAlphabetDna, sa_ratio=8, seed_k=8, keep_sa_in_memory=True,
+                 store_sequence=False, file_src=None):
+    """awFmCreateIndex (ref src/AwFmIndex.h:164-169)"""
+    L = _lib.lib()
+    cfg = _lib.AwFmIndexConfiguration(sa_ratio, seed_k, alphabet, keep_sa_in_memory, store_sequence)
+    seq = np.frombuffer(bytes(sequence), dtype=np.uint8) if not isinstance(sequence, np.ndarray) else sequence
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    holder = seq if seq.size else np.zeros(1, np.uint8)
+    if file_src is None:
+        file_src = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"awfm_{os.getpid()}_{id(seq):x}.awfmi")
+    out = C.POINTER(_lib.AwFmIndex)()
+    rc = L.awFmCreateIndex(C.byref(out), C.byref(cfg), holder.ctypes.data, seq.size, file_src.encode())
+    _check("awFmCreateIndex", rc, ok=(AwFmFileWriteOkay,))
+    ix = Index(out)
+    ix.file_src = file_src
+    return ix
+
+
+def read_index_from_file(file_src, keep_sa_in_memory=True):
+    """awFmReadIndexFromFile (ref src/AwFmIndex.h:260-262)"""
+    out = C.POINTER(_lib.AwFmIndex)()
+    rc = _lib.lib().awFmReadIndexFromFile(C.byref(out), file_src.encode(), keep_sa_in_memory)
+    _check("awFmReadIndexFromFile", rc, ok=(AwFmFileReadOkay,))
+    ix = Index(out)
+    ix.file_src = file_src
+    return ix
+
+
+class KmerSearchList:
+    """struct AwFmKmerSearchList* owner; fill() sets kmerString/kmerLength like the reference tests do"""
+
+    def __init__(self, capacity):
+        self.ptr = _lib.lib().awFmCreateKmerSearchList(capacity)
+        if not self.ptr:
+            raise MemoryError("awFmCreateKmerSearchList")
+        self._keep = None
+
+    def fill(self, kmers):
+        lst = self.ptr.contents
+        assert len(kmers) <= lst.capacity
+        bufs = [C.create_string_buffer(bytes(k), len(k)) if len(k) else C.create_string_buffer(1) for k in kmers]
+        for i, (k, b) in enumerate(zip(kmers, bufs)):
+            lst.kmerSearchData[i].kmerString = C.addressof(b)
+            lst.kmerSearchData[i].kmerLength = len(k)
+        lst.count = len(kmers)
+        self._keep = bufs
+
+    def counts(self):
+        lst = self.ptr.contents
+        return np.array([lst.kmerSearchData[i].count for i in range(lst.count)], dtype=np.uint32)
+
+    def capacities(self):
+        lst = self.ptr.contents
+        return np.array([lst.kmerSearchData[i].capacity for i in range(lst.count)], dtype=np.uint32)
+
+    def positions(self, i):
+        d = self.ptr.contents.kmerSearchData[i]
+        return np.array([d.positionList[j] for j in range(d.count)], dtype=np.uint64)
+
+    def dealloc(self):
+        if self.ptr:
+            _lib.lib().awFmDeallocKmerSearchList(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.dealloc()
+        except Exception:
+            pass
+
+
+def parallel_search_count(index, search_list, num_threads=4):
+    """awFmParallelSearchCount (ref src/AwFmIndex.h:400-403); returns nothing, like the reference"""
+    _lib.lib().awFmParallelSearchCount(index.ptr, search_list.ptr, num_threads)
+
+
+def parallel_search_locate(index, search_list, num_threads=4):
+    """awFmParallelSearchLocate (ref src/AwFmIndex.h:364-367); returns the AwFmReturnCode"""
+    return _lib.lib().awFmParallelSearchLocate(index.ptr, search_list.ptr, num_threads)
+
+
+class GpuIndex:
+    """AwFmGpuIndex* owner: the device image plus the flat batch API of include/awfm_gpu.h"""
+
+    def __init__(self, index, device=-1):
+        L = _lib.lib()
+        if L.awfmGpuDeviceCount() <= 0:
+            raise RuntimeError("no HIP device: the search path is GPU only (no CPU fallback)")
+        h = C.c_void_p()
+        _check("awfmGpuIndexCreate", L.awfmGpuIndexCreate(index.ptr, device, C.byref(h)))
+        self.handle = h
+        self.index = index
+
+    @property
+    def device_bytes(self):
+        return int(_lib.lib().awfmGpuIndexDeviceBytes(self.handle))
+
+    def set_kernel(self, kernel):
+        _lib.lib().awfmGpuIndexSetKernel(self.handle, kernel)
+
+    # host-buffer calls -------------------------------------------------
+    def count_host(self, chars, offsets=None, fixed_length=0):
+        chars = np.ascontiguousarray(chars, dtype=np.uint8)
+        n = (len(offsets) - 1) if offsets is not None else chars.size // fixed_length
+        ranges = np.zeros((n, 2), np.uint64)
+        counts = np.zeros(n, np.uint32)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64) if offsets is not None else None
+        holder = chars if chars.size else np.zeros(1, np.uint8)
+        rc = _lib.lib().awfmGpuCountHost(self.handle, holder.ctypes.data, off.ctypes.data if off is not None else None,
+                                         fixed_length, n, ranges.ctypes.data, counts.ctypes.data)
+        _check("awfmGpuCountHost", rc)
+        return ranges, counts
+
+    def locate_host(self, chars, offsets=None, fixed_length=0):
+        L = _lib.lib()
+        chars = np.ascontiguousarray(chars, dtype=np.uint8)
+        n = (len(offsets) - 1) if offsets is not None else chars.size // fixed_length
+        ranges = np.zeros((n, 2), np.uint64)
+        hit_off = np.zeros(n + 1, np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64) if offsets is not None else None
+        holder = chars if chars.size else np.zeros(1, np.uint8)
+        pos_ptr = C.POINTER(C.c_uint64)()
+        rc = L.awfmGpuLocateHost(self.handle, holder.ctypes.data, off.ctypes.data if off is not None else None,
+                                 fixed_length, n, ranges.ctypes.data, hit_off.ctypes.data, C.byref(pos_ptr))
+        _check("awfmGpuLocateHost", rc)
+        total = int(hit_off[n])
+        pos = np.ctypeslib.as_array(pos_ptr, shape=(total,)).copy() if total else np.zeros(0, np.uint64)
+        L.free(C.cast(pos_ptr, C.c_void_p))
+        return ranges, hit_off, pos
+
+    # device-pointer calls (addresses as ints, e.g. torch tensor.data_ptr()) -------------
+    def search(self, d_chars, d_offsets, fixed_length, n, d_ranges, d_counts, stream=0):
+        _check("awfmGpuSearch", _lib.lib().awfmGpuSearch(self.handle, d_chars, d_offsets or None, fixed_length, n,
+                                                         d_ranges or None, d_counts or None, stream or None))
+
+    def hit_offsets(self, d_ranges, n, d_hit_offsets, d_scratch, stream=0):
+        total = C.c_uint64(0)
+        _check("awfmGpuHitOffsets", _lib.lib().awfmGpuHitOffsets(self.handle, d_ranges, n, d_hit_offsets, d_scratch,
+                                                                 C.byref(total), stream or None))
+        return int(total.value)
+
+    def locate(self, d_ranges, d_hit_offsets, n, total_hits, d_positions, stream=0):
+        _check("awfmGpuLocate", _lib.lib().awfmGpuLocate(self.handle, d_ranges, d_hit_offsets, n, total_hits,
+                                                         d_positions, stream or None))
+
+    @staticmethod
+    def scan_scratch_bytes(n):
+        return int(_lib.lib().awfmGpuScanScratchBytes(n))
+
+    def destroy(self):
+        if self.handle:
+            _lib.lib().awfmGpuIndexDestroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -1,0 +1,108 @@
+/*
+ * awfm_gpu.h -- C ABI of the HIP (gfx950) side of libawfmindex_amd.so.
+ *
+ * This is the thin shim the host C code (and any FFI: ctypes, cgo, JNI ...)
+ * calls.  Plain pointers and sizes only; `stream` arguments are hipStream_t
+ * passed as void* (NULL = the null stream).  Pointers prefixed `d` are device
+ * addresses (hipMalloc or any allocator that shares the HIP context, e.g. a
+ * torch tensor's data_ptr()); all others are host addresses.
+ *
+ * What each entry point replaces in the reference:
+ *   awfmGpuSearch          seed + extend phases of awFmParallelSearchCount /
+ *                          awFmParallelSearchLocate
+ *                          (ref src/AwFmParallelSearch.c:159-220, :222-313) on top of
+ *                          the rank primitives (ref src/AwFmOccurrence.c:8-135,
+ *                          src/AwFmSimdConfig.c:89-114, src/AwFmSearch.c:42-159,
+ *                          :485-520, src/AwFmKmerTable.c:4-51)
+ *   awfmGpuHitOffsets      the per-query sizing of setPositionListCount
+ *                          (ref src/AwFmParallelSearch.c:327-328, :367-387) as
+ *                          one exclusive scan
+ *   awfmGpuLocate          parallelSearchTracebackPositionLists
+ *                          (ref src/AwFmParallelSearch.c:315-365): LF walk
+ *                          (ref src/AwFmSearch.c:369-427, src/AwFmOccurrence.c:170-217)
+ *                          + sampled-SA read (ref src/AwFmSuffixArray.c:114-142, :179-191)
+ *   awfmGpuCountHost /     the whole of awFmParallelSearchCount / ...Locate
+ *   awfmGpuLocateHost      for host-resident flat query buffers
+ *   awfmGpuIndexCreate     the reference has no analogue: it builds the
+ *                          device image (re-laid-out BWT blocks, seed table,
+ *                          sampled SA) of a host AwFmIndex.
+ *
+ * Results are bit-identical to the reference semantics:
+ * a query stops at the first invalid range and keeps it; hits are listed in
+ * BWT order sp, sp+1, ..., ep.
+ */
+#ifndef AWFM_GPU_H
+#define AWFM_GPU_H
+
+#include "AwFmIndex.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct AwFmGpuIndex AwFmGpuIndex; /* opaque device image of one index on one GPU */
+
+/* kernel variants (for measurement; AWFM_GPU_KERNEL_AUTO picks the default) */
+enum AwFmGpuKernel {
+  AWFM_GPU_KERNEL_AUTO = 0,
+  AWFM_GPU_KERNEL_GROUP8 = 1, /* 8 lanes cooperate on one query: one 128-B line per load instruction */
+  AWFM_GPU_KERNEL_LANE = 2    /* one query per lane, each lane walks its own block */
+};
+
+/* ---- runtime ---- */
+int awfmGpuDeviceCount(void);           /* 0 when no usable HIP device */
+const char *awfmGpuLastError(void);     /* thread-local text of the last failure, "" if none */
+
+/* ---- device image ---- */
+/* Builds the device image of `index` on GPU `device` (-1: current device or
+ * $AWFM_GPU_DEVICE).  When the index has no in-memory sampled SA
+ * (keepSuffixArrayInMemory == false) it is staged from index->fileDescriptor. */
+enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device, AwFmGpuIndex **out);
+void awfmGpuIndexDestroy(AwFmGpuIndex *g);
+/* Side table used by awFmParallelSearch*: image for a host index, created on first use. */
+AwFmGpuIndex *awfmGpuIndexAcquire(const struct AwFmIndex *index);
+/* Drops the side-table entry (called by awFmDeallocIndex). */
+void awfmGpuIndexRelease(const struct AwFmIndex *index);
+uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g);
+int awfmGpuIndexDevice(const AwFmGpuIndex *g);
+/* Selects the search kernel variant for this image (default AUTO). */
+void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel);
+
+/* ---- flat batch API on device buffers ---- */
+/* Queries: dChars = concatenated ASCII k-mers; either dOffsets (numQueries+1
+ * CSR offsets into dChars) or, with dOffsets == NULL, fixedLength characters
+ * per query.  Outputs (each may be NULL): dRanges[numQueries] = final {sp,ep},
+ * dCounts[numQueries] = range length truncated to u32
+ * (ref src/AwFmIndexStruct.c:126-130).  Asynchronous on `stream`. */
+enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                  uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
+                                  uint32_t *dCounts, void *stream);
+
+/* dHitOffsets[numQueries+1] = exclusive scan of the range lengths; the total is
+ * also copied to *totalHits (host) -- this call synchronises `stream`.
+ * dScratch must hold awfmGpuScanScratchBytes(numQueries) bytes. */
+uint64_t awfmGpuScanScratchBytes(uint64_t numQueries);
+enum AwFmReturnCode awfmGpuHitOffsets(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges, uint64_t numQueries,
+                                      uint64_t *dHitOffsets, void *dScratch, uint64_t *totalHits, void *stream);
+
+/* dPositions[dHitOffsets[i] + h] = text position of hit h (BWT order) of query i.
+ * Asynchronous on `stream`. */
+enum AwFmReturnCode awfmGpuLocate(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges,
+                                  const uint64_t *dHitOffsets, uint64_t numQueries, uint64_t totalHits,
+                                  uint64_t *dPositions, void *stream);
+
+/* ---- flat batch API on host buffers (upload, kernels, download) ---- */
+/* ranges / counts may be NULL. */
+enum AwFmReturnCode awfmGpuCountHost(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
+                                     uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
+                                     uint32_t *counts);
+/* hitOffsets[numQueries+1] is filled; *positions is a malloc'ed array of
+ * hitOffsets[numQueries] entries that the caller frees. */
+enum AwFmReturnCode awfmGpuLocateHost(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
+                                      uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
+                                      uint64_t *hitOffsets, uint64_t **positions);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+    O.build()
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def awfm():
+    """the product library through its C ABI; built in-tree if missing (never falls back to anything else)"""
+    from avxwindowfmindex_amd import _lib, api
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    _lib.lib()
+    return api
+
+
+@pytest.fixture(scope="session")
+def require_gpu(awfm):
+    from avxwindowfmindex_amd import _lib
+    n = _lib.lib().awfmGpuDeviceCount()
+    assert n > 0, "GPU test selected but no HIP device is visible: the HIP path must run, there is no fallback"
+    return n

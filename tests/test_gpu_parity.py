@@ -1,0 +1,163 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, bit for bit.
+
+Mirrors the properties of the reference's test/parallelSearch/parallelSearchTest.c:45-456,
+test/inMemorySaTest/inMemorySaTest.c:29-266 and test/searchTest/searchTest.c:124-200, with
+seeded inputs and exact {sp,ep}/hit-order comparison instead of order-insensitive checks.
+"""
+import numpy as np
+import pytest
+
+from avxwindowfmindex_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed_queries(seed, count, txt, alphabet, lo, hi, ambiguity=None, upper=False):
+    chars, offsets = synth.mixed_queries(seed, count, txt, alphabet, lo, hi)
+    chars = chars.copy()
+    rng = np.random.default_rng(seed)
+    if ambiguity is not None and chars.size:
+        hit = rng.random(chars.size) < 0.01
+        chars[hit] = ambiguity
+    if upper and chars.size:
+        up = rng.random(chars.size) < 0.3
+        chars[up] = chars[up] & 0xDF
+    return chars, offsets
+
+
+def _check_against_oracle(O, awfm, txt, alpha, oalpha, ratio, seed_k, chars, offsets):
+    ix = awfm.create_index(txt, alpha, ratio, seed_k)
+    oi = O.Index.wrap(oalpha, ratio, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                      ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    ranges, counts = g.count_host(chars, offsets)
+    assert np.array_equal(ranges[:, 0], sp), "sp differs"
+    assert np.array_equal(ranges[:, 1], ep), "ep differs"
+    assert np.array_equal(counts, cnt), "count differs"
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    r2, ho2, pos2 = g.locate_host(chars, offsets)
+    assert np.array_equal(r2, ranges)
+    assert np.array_equal(ho2, hit_off), "hit offsets differ"
+    assert np.array_equal(pos2, pos), "positions differ (BWT order)"
+    g.destroy()
+    ix.dealloc()
+    return int(hit_off[-1])
+
+
+@pytest.mark.parametrize("n,ratio,seed_k", [(29, 1, 3), (4096, 3, 4), (65536, 8, 8), (300000, 16, 6), (100000, 255, 5)])
+def test_dna_parity(oracle, awfm, require_gpu, n, ratio, seed_k):
+    txt = synth.text(n + 7, n, synth.DNA_ALPHABET).copy()
+    if n > 100:
+        txt[10:14] = ord("n")  # ambiguity run in the text (sanitised to 'x')
+        txt[n // 2] = ord("N")
+    chars, offsets = _mixed_queries(1000 + n, 4000, txt, synth.DNA_ALPHABET, 1, min(40, n), ambiguity=ord("x"),
+                                    upper=True)
+    hits = _check_against_oracle(oracle, awfm, txt, awfm.AwFmAlphabetDna, oracle.DNA, ratio, seed_k, chars, offsets)
+    assert hits > 0
+
+
+@pytest.mark.parametrize("n,ratio,seed_k", [(31, 1, 1), (5000, 3, 2), (60000, 8, 3), (200000, 16, 4)])
+def test_amino_parity(oracle, awfm, require_gpu, n, ratio, seed_k):
+    txt = synth.text(n + 3, n, synth.AMINO_ALPHABET).copy()
+    if n > 100:
+        txt[20:23] = ord("x")  # sanitised to 'z'
+        txt[n // 3] = ord("b")
+    chars, offsets = _mixed_queries(2000 + n, 4000, txt, synth.AMINO_ALPHABET, 1, min(25, n), ambiguity=ord("z"))
+    hits = _check_against_oracle(oracle, awfm, txt, awfm.AwFmAlphabetAmino, oracle.AMINO, ratio, seed_k, chars,
+                                 offsets)
+    assert hits > 0
+
+
+def test_fixed_length_and_empty_batch(oracle, awfm, require_gpu):
+    txt = synth.text(5, 50000)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    q = np.concatenate([synth.random_queries(9, 3000, 12), synth.planted_queries(10, 3000, 12, txt)])
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    ranges, counts = g.count_host(chars, None, fixed_length=12)
+    assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep) and np.array_equal(counts, cnt)
+    # empty batch is a no-op
+    r0, c0 = g.count_host(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert r0.shape == (0, 2) and c0.size == 0
+    # zero-length k-mers (documented UB in the reference) come back as empty ranges
+    r1, c1 = g.count_host(np.frombuffer(b"acgt", np.uint8), np.array([0, 0, 4, 4], np.uint64))
+    assert c1[0] == 0 and c1[2] == 0 and c1[1] == oi.search_list([b"acgt"])[2][0]
+    g.destroy()
+    ix.dealloc()
+
+
+def test_repetitive_text_many_hits(oracle, awfm, require_gpu):
+    """long position lists (wave-cooperative expansion) and long LF chains, sentinel wrap included"""
+    txt = np.frombuffer((b"acgtacgtaa" * 3000) + b"ttttttttttttttttttttt", np.uint8)
+    for ratio in (1, 7, 200):
+        ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, 4)
+        oi = oracle.Index.wrap(oracle.DNA, ratio, 4, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                               ix.packed_sa())
+        g = awfm.GpuIndex(ix)
+        kmers = [b"a", b"acgt", b"acgtacgtaaacgt", b"tttt", b"gta", b"cccc", txt[:30].tobytes(), b"t" * 21, b"x"]
+        chars, offsets = oracle.pack_queries(kmers)
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+        hit_off, pos, _ = oi.batch_locate(sp, ep)
+        ranges, ho, p = g.locate_host(chars, offsets)
+        assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep)
+        assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
+        assert int(hit_off[-1]) > 10000
+        g.destroy()
+        ix.dealloc()
+
+
+def test_drop_in_aos_api(oracle, awfm, require_gpu):
+    """awFmCreateKmerSearchList / awFmParallelSearchCount / awFmParallelSearchLocate exactly as a
+    reference user calls them (ref test/parallelSearch/parallelSearchTest.c:105-214)"""
+    txt = synth.text(77, 8000).copy()
+    txt[100] = ord("x")
+    raw = txt.tobytes()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 9)
+    chars, offsets = synth.mixed_queries(78, 1500, txt, synth.DNA_ALPHABET, 7, 36)
+    kmers = [chars[int(offsets[i]):int(offsets[i + 1])].tobytes() for i in range(1500)]
+    for threads in (1, 4):
+        lst = awfm.KmerSearchList(1600)
+        lst.fill(kmers)
+        awfm.parallel_search_count(ix, lst, threads)
+        counts = lst.counts()
+        rc = awfm.parallel_search_locate(ix, lst, threads)
+        assert rc == awfm.AwFmSuccess
+        assert np.array_equal(lst.counts(), counts)
+        caps = lst.capacities()
+        assert np.all(caps >= counts) and np.all(caps[counts <= 4] == 4)
+        for i in range(0, 1500, 7):
+            k = kmers[i]
+            expect = sorted(p for p in range(len(raw) - len(k) + 1) if raw[p:p + len(k)] == k)
+            assert sorted(lst.positions(i).tolist()) == expect
+            assert counts[i] == len(expect)
+        lst.dealloc()
+    ix.dealloc()
+
+
+def test_sa_staged_from_file(oracle, awfm, require_gpu, tmp_path):
+    """keepSuffixArrayInMemory=false: the device image stages the sampled SA from the .awfmi file"""
+    txt = synth.text(91, 30000)
+    path = str(tmp_path / "ondisk.awfmi")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 5, 6, keep_sa_in_memory=False, file_src=path)
+    assert ix.packed_sa() is None
+    oi = oracle.Index.from_text(txt.tobytes(), oracle.DNA, 5, 6)
+    q = synth.planted_queries(92, 2000, 15, txt)
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, _, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    g = awfm.GpuIndex(ix)
+    _, ho, p = g.locate_host(chars, offsets)
+    assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
+    g.destroy()
+    ix.dealloc()
+    # and through a re-read index
+    ix2 = awfm.read_index_from_file(path, keep_sa_in_memory=False)
+    g2 = awfm.GpuIndex(ix2)
+    _, ho2, p2 = g2.locate_host(chars, offsets)
+    assert np.array_equal(ho2, hit_off) and np.array_equal(p2, pos)
+    g2.destroy()
+    ix2.dealloc()
