@@ -102,6 +102,28 @@ def create_index(sequence, alphabet=AwFmAlphabetDna, sa_ratio=8, seed_k=8, keep_
     return ix
 
 
+def gpu_create_index(sequence, alphabet=AwFmAlphabetDna, sa_ratio=8, seed_k=8, keep_sa_in_memory=True,
+                     store_sequence=False, file_src=None, device=-1, on_device_length=None):
+    """awfmGpuCreateIndex: same arrays as create_index, built on the GPU.  `sequence` is bytes / a numpy
+    array, or a device address (int) together with on_device_length."""
+    L = _lib.lib()
+    cfg = _lib.AwFmIndexConfiguration(sa_ratio, seed_k, alphabet, keep_sa_in_memory, store_sequence)
+    out = C.POINTER(_lib.AwFmIndex)()
+    if on_device_length is not None:
+        rc = L.awfmGpuCreateIndex(C.byref(out), C.byref(cfg), int(sequence), on_device_length, 1,
+                                  file_src.encode() if file_src else None, device)
+    else:
+        seq = np.frombuffer(bytes(sequence), dtype=np.uint8) if not isinstance(sequence, np.ndarray) else sequence
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        holder = seq if seq.size else np.zeros(1, np.uint8)
+        rc = L.awfmGpuCreateIndex(C.byref(out), C.byref(cfg), holder.ctypes.data, seq.size, 0,
+                                  file_src.encode() if file_src else None, device)
+    _check("awfmGpuCreateIndex", rc, ok=(AwFmFileWriteOkay,))
+    ix = Index(out)
+    ix.file_src = file_src
+    return ix
+
+
 def read_index_from_file(file_src, keep_sa_in_memory=True):
     """awFmReadIndexFromFile (ref src/AwFmIndex.h:260-262)"""
     out = C.POINTER(_lib.AwFmIndex)()
@@ -168,13 +190,22 @@ def parallel_search_locate(index, search_list, num_threads=4):
 class GpuIndex:
     """AwFmGpuIndex* owner: the device image plus the flat batch API of include/awfm_gpu.h"""
 
-    def __init__(self, index, device=-1):
+    def __init__(self, index, device=-1, acquire=False):
+        """acquire=True reuses (or lazily creates) the image registered for `index` -- the one
+        awFmParallelSearch* uses, e.g. the image a GPU-built index already has; it is then owned by the index"""
         L = _lib.lib()
         if L.awfmGpuDeviceCount() <= 0:
             raise RuntimeError("no HIP device: the search path is GPU only (no CPU fallback)")
-        h = C.c_void_p()
-        _check("awfmGpuIndexCreate", L.awfmGpuIndexCreate(index.ptr, device, C.byref(h)))
-        self.handle = h
+        self.owned = not acquire
+        if acquire:
+            h = L.awfmGpuIndexAcquire(index.ptr)
+            if not h:
+                raise AwFmError("awfmGpuIndexAcquire", -1)
+            self.handle = C.c_void_p(h)
+        else:
+            h = C.c_void_p()
+            _check("awfmGpuIndexCreate", L.awfmGpuIndexCreate(index.ptr, device, C.byref(h)))
+            self.handle = h
         self.index = index
 
     @property
@@ -235,7 +266,8 @@ class GpuIndex:
 
     def destroy(self):
         if self.handle:
-            _lib.lib().awfmGpuIndexDestroy(self.handle)
+            if self.owned:
+                _lib.lib().awfmGpuIndexDestroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -1,0 +1,751 @@
+/*
+ * awfm_gpu_build.hip -- index construction on the GPU.
+ *
+ * Produces exactly the arrays awFmCreateIndex produces on the host
+ * (ref src/AwFmCreate.c:31-137, :281-450; src/AwFmSuffixArray.c:58-112) -- the
+ * suffix array of a text is unique, everything after it is arithmetic -- but
+ * sized for a 3.1 Gbp text in seconds:
+ *   1. sanitise + '$' on the device;
+ *   2. suffix array: every suffix gets a 64-bit key of its first 64/b
+ *      characters (b bits per dense character code), (key, position) pairs are
+ *      radix sorted (rocPRIM onesweep), and suffixes whose keys tie are refined
+ *      by prefix doubling (Larsson-Sadakane) on the tied subset only, using the
+ *      inverse suffix array as rank;
+ *   3. BWT bit planes by wave ballots, per-block letter counts, exclusive scans
+ *      -> reference-layout blocks and prefix sums;
+ *   4. device-layout blocks (awfm_device.h), seed table level by level with the
+ *      same blind backward step the host DFS uses, sampled SA bit-packing;
+ *   5. download of the reference-layout arrays into a host AwFmIndex; the
+ *      device image is kept and registered for awFmParallelSearch*.
+ * Limits: bwtLength <= 2^32 - 2 (32-bit suffix positions on the device).
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "awfm_device.h"
+
+namespace {
+
+#define BUILD_TRY(call)                         \
+  do {                                          \
+    hipError_t err__ = (call);                  \
+    if (err__ != hipSuccess) {                  \
+      awfmGpuSetHipError(#call, err__);         \
+      return false;                             \
+    }                                           \
+  } while (0)
+
+struct DeviceBuffer {
+  void *p = nullptr;
+  ~DeviceBuffer() { reset(); }
+  bool alloc(size_t bytes) {
+    reset();
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+      awfmGpuSetHipError("hipMalloc (index build)", e);
+      p = nullptr;
+      return false;
+    }
+    return true;
+  }
+  void reset() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+  }
+  void *release() {
+    void *r = p;
+    p = nullptr;
+    return r;
+  }
+  template <class T>
+  T *as() const {
+    return (T *)p;
+  }
+};
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+inline unsigned gridOf(u64 n, unsigned block = 256) { return (unsigned)((n + block - 1) / block); }
+
+/* ---- text ---- */
+
+/* ref src/AwFmCreate.c:452-466 + src/AwFmLetter.c:24-42, :69-79; writes the '$' terminator too */
+__global__ void sanitizeKernel(const unsigned char *__restrict__ raw, u64 n, int amino, unsigned char *__restrict__ out) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > n) return;
+  if (i == n) {
+    out[i] = '$';
+    return;
+  }
+  const unsigned c = raw[i];
+  const unsigned l = c | 0x20u;
+  unsigned r;
+  if (amino)
+    r = (l == 'b' || l == 'x' || c == 0) ? 'z' : c;
+  else
+    r = (l == 'a' || l == 'c' || l == 'g' || l == 't' || l == 'u' || l == '$') ? l : 'x';
+  out[i] = (unsigned char)r;
+}
+
+__global__ void byteHistogramKernel(const unsigned char *__restrict__ text, u64 n, u64 *__restrict__ hist) {
+  __shared__ unsigned local[256];
+  local[threadIdx.x] = 0;
+  __syncthreads();
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) atomicAdd(&local[text[i]], 1u);
+  __syncthreads();
+  if (local[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (u64)local[threadIdx.x]);
+}
+
+/* key(i) = dense codes of text[i..i+perKey) packed MSB first, 0 past the end */
+constexpr int kKeyTile = 1024;
+__global__ void __launch_bounds__(256)
+    suffixKeyKernel(const unsigned char *__restrict__ text, u64 n, const unsigned char *__restrict__ codeTable,
+                    unsigned bits, unsigned perKey, u64 *__restrict__ keys, u32 *__restrict__ positions) {
+  __shared__ unsigned char sCode[256];
+  __shared__ unsigned char sText[kKeyTile + 64];
+  sCode[threadIdx.x] = codeTable[threadIdx.x];
+  __syncthreads();
+  const u64 base = (u64)blockIdx.x * kKeyTile;
+  for (unsigned t = threadIdx.x; t < kKeyTile + 64; t += 256) {
+    const u64 i = base + t;
+    sText[t] = i < n ? sCode[text[i]] : 0;
+  }
+  __syncthreads();
+  for (unsigned t = threadIdx.x; t < kKeyTile; t += 256) {
+    const u64 i = base + t;
+    if (i >= n) break;
+    u64 key = 0;
+    for (unsigned c = 0; c < perKey; c++) key = (key << bits) | sText[t + c];
+    keys[i] = key;
+    positions[i] = (u32)i;
+  }
+}
+
+/* ---- suffix array refinement ---- */
+
+__global__ void tiedFlagKernel(const u64 *__restrict__ keys, u64 n, unsigned char *__restrict__ tied) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const u64 k = keys[i];
+  tied[i] = (i > 0 && keys[i - 1] == k) || (i + 1 < n && keys[i + 1] == k);
+}
+
+__global__ void inverseSaKernel(const u32 *__restrict__ sa, u64 n, u32 *__restrict__ rank) {
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rank[sa[i]] = (u32)i;
+}
+
+/* compact state of the tied suffixes: slot (SA index), val (text position), headSlot candidates */
+__global__ void tiedInitKernel(const u64 *__restrict__ keys, const u32 *__restrict__ sa, const u32 *__restrict__ slot,
+                               u64 t, u32 *__restrict__ val, u32 *__restrict__ headSlot) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= t) return;
+  const u32 s = slot[j];
+  val[j] = sa[s];
+  const bool head = s == 0 || keys[s] != keys[s - 1];
+  headSlot[j] = head ? s : 0u;
+}
+
+__global__ void setRankKernel(const u32 *__restrict__ val, const u32 *__restrict__ grp, u64 t, u32 *__restrict__ rank) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < t) rank[val[j]] = grp[j];
+}
+
+__global__ void doublingKeyKernel(const u32 *__restrict__ val, const u32 *__restrict__ grp, const u32 *__restrict__ rank,
+                                  u64 t, u64 n, u64 h, u64 *__restrict__ key2) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= t) return;
+  const u64 next = (u64)val[j] + h;
+  const u64 second = next < n ? (u64)rank[next] + 1ull : 0ull;
+  key2[j] = ((u64)grp[j] << 32) | second;
+}
+
+/* after sorting (key2,val): write the new order into the SA, derive the new group heads */
+__global__ void doublingApplyKernel(const u64 *__restrict__ key2, const u32 *__restrict__ val,
+                                    const u32 *__restrict__ slot, u64 t, u32 *__restrict__ sa,
+                                    u32 *__restrict__ headSlot) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= t) return;
+  sa[slot[j]] = val[j];
+  const bool head = j == 0 || key2[j] != key2[j - 1];
+  headSlot[j] = head ? slot[j] : 0u;
+}
+
+/* keep[j] = still tied after this round */
+__global__ void stillTiedKernel(const u64 *__restrict__ key2, u64 t, unsigned char *__restrict__ keep) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= t) return;
+  const u64 k = key2[j];
+  keep[j] = (j > 0 && key2[j - 1] == k) || (j + 1 < t && key2[j + 1] == k);
+}
+
+__global__ void compactTriplesKernel(const unsigned char *__restrict__ keep, const u32 *__restrict__ dest, u64 t,
+                                     const u32 *__restrict__ slotIn, const u32 *__restrict__ valIn,
+                                     const u32 *__restrict__ grpIn, u32 *__restrict__ slotOut,
+                                     u32 *__restrict__ valOut, u32 *__restrict__ grpOut) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= t || !keep[j]) return;
+  const u32 d = dest[j];
+  slotOut[d] = slotIn[j];
+  valOut[d] = valIn[j];
+  grpOut[d] = grpIn[j];
+}
+
+__global__ void flagsToU32Kernel(const unsigned char *__restrict__ flags, u64 t, u32 *__restrict__ out) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < t) out[j] = flags[j];
+}
+
+struct MaxOp {
+  __host__ __device__ u32 operator()(u32 a, u32 b) const { return a > b ? a : b; }
+};
+
+/* ---- BWT blocks ---- */
+
+/* one 256-thread workgroup per BWT block: bit planes by wave ballots
+ * (ref src/AwFmCreate.c:291-336, :350-395) and the block's letter histogram */
+template <bool AMINO>
+__global__ void __launch_bounds__(256)
+    bwtBlockKernel(const unsigned char *__restrict__ text, const u32 *__restrict__ sa, u64 n, u64 numBlocks,
+                   u64 *__restrict__ refBlocks, u64 *__restrict__ blockCounts, u64 *__restrict__ sentinelPos) {
+  constexpr unsigned kPlanes = AMINO ? 5 : 3;
+  constexpr unsigned kLetters = AMINO ? 22 : 6;
+  constexpr unsigned kWords = AMINO ? 44 : 20; /* u64 words per reference block */
+  __shared__ unsigned sCount[4][24];
+  const u64 blk = blockIdx.x;
+  const u64 i = blk * 256ull + threadIdx.x;
+  const bool valid = i < n;
+  unsigned letter = 0xFFu, code = 0;
+  if (valid) {
+    const u32 p = sa[i];
+    if (p == 0) {
+      letter = AMINO ? 21u : 5u;
+      *sentinelPos = i;
+    } else {
+      const unsigned c = text[p - 1];
+      letter = AMINO ? (c == '$' ? 21u : (unsigned)kAminoTables.letterOfAscii[c & 31u]) : nucLetterIndex(c);
+    }
+    if (AMINO) {
+      /* index -> code, ref src/AwFmLetter.c:81-87 */
+      const unsigned char codes[22] = {0x0C, 0x17, 0x03, 0x06, 0x1E, 0x1A, 0x1B, 0x19, 0x15, 0x1C, 0x1D,
+                                       0x08, 0x09, 0x04, 0x13, 0x0A, 0x05, 0x16, 0x01, 0x02, 0x1F, 0x00};
+      code = codes[letter];
+    } else {
+      code = (0x421356u >> (4u * letter)) & 7u; /* {6,5,3,1,2,4}, ref src/AwFmLetter.c:44-47 */
+    }
+  }
+  const unsigned wave = threadIdx.x >> 6;
+  u64 *dst = refBlocks + blk * kWords;
+#pragma unroll
+  for (unsigned j = 0; j < kPlanes; j++) {
+    const u64 word = __ballot((code >> j) & 1u);
+    if ((threadIdx.x & 63u) == 0) dst[4 * j + wave] = word;
+  }
+  for (unsigned l = 0; l < kLetters; l++) {
+    const u64 m = __ballot(letter == l);
+    if ((threadIdx.x & 63u) == 0) sCount[wave][l] = (unsigned)__popcll(m);
+  }
+  __syncthreads();
+  if (threadIdx.x < kLetters)
+    blockCounts[(u64)threadIdx.x * numBlocks + blk] =
+        (u64)sCount[0][threadIdx.x] + sCount[1][threadIdx.x] + sCount[2][threadIdx.x] + sCount[3][threadIdx.x];
+}
+
+/* base occurrences = exclusive scan of the per-block counts, copied into the block headers
+ * (ref src/AwFmCreate.c:304-313, :361-370); the two pad counters are zero */
+template <bool AMINO>
+__global__ void baseOccurrenceKernel(const u64 *__restrict__ scanned, u64 numBlocks, u64 *__restrict__ refBlocks) {
+  constexpr unsigned kLetters = AMINO ? 22 : 6;
+  constexpr unsigned kCounters = AMINO ? 24 : 8;
+  constexpr unsigned kWords = AMINO ? 44 : 20;
+  constexpr unsigned kFirst = AMINO ? 20 : 12;
+  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  const u64 blk = t / kCounters;
+  const unsigned c = (unsigned)(t % kCounters);
+  if (blk >= numBlocks) return;
+  refBlocks[blk * kWords + kFirst + c] = c < kLetters ? scanned[(u64)c * numBlocks + blk] : 0ull;
+}
+
+/* ---- seed table ---- */
+
+/* level L+1 from level L: entry e = a * |A|^L + parent, range = blind backward step of the
+ * parent's range with letter a -- no validity check (ref src/AwFmCreate.c:419-450) */
+template <bool AMINO>
+__global__ void __launch_bounds__(kThreads)
+    seedLevelKernel(const DevIndex ix, const ulonglong2 *__restrict__ parentLevel, u64 parentLen, u64 outLen,
+                    ulonglong2 *__restrict__ out) {
+  __shared__ u64 sC[24];
+  __shared__ AminoShared sAmino;
+  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  if (AMINO && threadIdx.x < 32) {
+    sAmino.letterOfAscii[threadIdx.x] = kAminoTables.letterOfAscii[threadIdx.x];
+    sAmino.letterOfCode[threadIdx.x] = kAminoTables.letterOfCode[threadIdx.x];
+    if (threadIdx.x < 24) sAmino.planeMask[threadIdx.x] = kAminoTables.planeMask[threadIdx.x];
+  }
+  __syncthreads();
+  const unsigned g = threadIdx.x & 7u;
+  const u64 numGroups = (u64)gridDim.x * kGroupsPerBlock;
+  for (u64 e = ((u64)blockIdx.x * kThreads + threadIdx.x) >> 3; e < outLen; e += numGroups) {
+    const unsigned a = (unsigned)(e / parentLen);
+    const ulonglong2 r = parentLevel[e % parentLen];
+    u64 sp = r.x, ep = r.y;
+    if (AMINO)
+      aminoStep(ix, sC, sAmino, a, sp, ep, g);
+    else
+      nucStep(ix, sC, a, sp, ep, g);
+    if (g == 0) out[e] = make_ulonglong2(sp, ep);
+  }
+}
+
+/* ---- sampled SA ---- */
+
+/* 64-bit word j of the little-endian bit stream of samples SA[s*ratio], `width` bits each
+ * (ref src/AwFmSuffixArray.c:58-112) */
+__global__ void packSampledSaKernel(const u32 *__restrict__ sa, u64 samples, unsigned ratio, unsigned width,
+                                    u64 words, u64 *__restrict__ out) {
+  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= words) return;
+  const u64 firstBit = j * 64ull;
+  u64 word = 0;
+  for (u64 s = firstBit / width; s < samples && s * width < firstBit + 64ull; s++) {
+    const u64 v = sa[s * ratio];
+    const long long shift = (long long)(s * width) - (long long)firstBit;
+    word |= shift >= 0 ? v << shift : v >> (-shift);
+  }
+  out[j] = word;
+}
+
+/* ---- rocPRIM wrappers ---- */
+
+bool sortPairs(u64 *keysIn, u64 *keysOut, u32 *valsIn, u32 *valsOut, u64 n, unsigned endBit, DeviceBuffer &temp,
+               size_t &tempBytes) {
+  size_t need = 0;
+  BUILD_TRY(rocprim::radix_sort_pairs(nullptr, need, keysIn, keysOut, valsIn, valsOut, (size_t)n, 0u, endBit,
+                                      (hipStream_t)0));
+  if (need > tempBytes) {
+    if (!temp.alloc(need)) return false;
+    tempBytes = need;
+  }
+  BUILD_TRY(rocprim::radix_sort_pairs(temp.p, need, keysIn, keysOut, valsIn, valsOut, (size_t)n, 0u, endBit,
+                                      (hipStream_t)0));
+  return true;
+}
+
+bool maxScanU32(const u32 *in, u32 *out, u64 n, DeviceBuffer &temp, size_t &tempBytes) {
+  size_t need = 0;
+  BUILD_TRY(rocprim::inclusive_scan(nullptr, need, in, out, (size_t)n, MaxOp(), (hipStream_t)0));
+  if (need > tempBytes) {
+    if (!temp.alloc(need)) return false;
+    tempBytes = need;
+  }
+  BUILD_TRY(rocprim::inclusive_scan(temp.p, need, in, out, (size_t)n, MaxOp(), (hipStream_t)0));
+  return true;
+}
+
+bool exclusiveSumU32(const u32 *in, u32 *out, u64 n, DeviceBuffer &temp, size_t &tempBytes) {
+  size_t need = 0;
+  BUILD_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0u, (size_t)n, rocprim::plus<u32>(), (hipStream_t)0));
+  if (need > tempBytes) {
+    if (!temp.alloc(need)) return false;
+    tempBytes = need;
+  }
+  BUILD_TRY(rocprim::exclusive_scan(temp.p, need, in, out, 0u, (size_t)n, rocprim::plus<u32>(), (hipStream_t)0));
+  return true;
+}
+
+bool exclusiveSumU64(const u64 *in, u64 *out, u64 n, DeviceBuffer &temp, size_t &tempBytes) {
+  size_t need = 0;
+  BUILD_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0ull, (size_t)n, rocprim::plus<u64>(), (hipStream_t)0));
+  if (need > tempBytes) {
+    if (!temp.alloc(need)) return false;
+    tempBytes = need;
+  }
+  BUILD_TRY(rocprim::exclusive_scan(temp.p, need, in, out, 0ull, (size_t)n, rocprim::plus<u64>(), (hipStream_t)0));
+  return true;
+}
+
+/* indices i in [0,n) with flags[i] != 0 -> out, count -> *countHost */
+bool selectFlagged(const unsigned char *flags, u64 n, u32 *out, u64 *countHost, DeviceBuffer &temp, size_t &tempBytes) {
+  DeviceBuffer dCount;
+  if (!dCount.alloc(sizeof(u64))) return false;
+  rocprim::counting_iterator<u32> ids(0u);
+  size_t need = 0;
+  BUILD_TRY(rocprim::select(nullptr, need, ids, flags, out, dCount.as<u64>(), (size_t)n, (hipStream_t)0));
+  if (need > tempBytes) {
+    if (!temp.alloc(need)) return false;
+    tempBytes = need;
+  }
+  BUILD_TRY(rocprim::select(temp.p, need, ids, flags, out, dCount.as<u64>(), (size_t)n, (hipStream_t)0));
+  BUILD_TRY(hipMemcpy(countHost, dCount.p, sizeof(u64), hipMemcpyDeviceToHost));
+  return true;
+}
+
+/* suffix array of dText[0..n) into dSa (u32); dText ends with the unique '$' */
+bool buildSuffixArray(const unsigned char *dText, u64 n, u32 *dSa, bool verbose) {
+  /* dense codes from the byte histogram */
+  DeviceBuffer dHist, dCode;
+  if (!dHist.alloc(256 * sizeof(u64)) || !dCode.alloc(256)) return false;
+  BUILD_TRY(hipMemset(dHist.p, 0, 256 * sizeof(u64)));
+  hipLaunchKernelGGL(byteHistogramKernel, dim3(2048), dim3(256), 0, 0, dText, n, dHist.as<u64>());
+  u64 hist[256];
+  BUILD_TRY(hipMemcpy(hist, dHist.p, sizeof hist, hipMemcpyDeviceToHost));
+  unsigned char code[256];
+  unsigned distinct = 0;
+  for (int c = 0; c < 256; c++) code[c] = hist[c] ? (unsigned char)++distinct : 0;
+  unsigned bits = 1;
+  while ((1u << bits) <= distinct) bits++;
+  const unsigned perKey = 64 / bits;
+  BUILD_TRY(hipMemcpy(dCode.p, code, 256, hipMemcpyHostToDevice));
+
+  DeviceBuffer temp;
+  size_t tempBytes = 0;
+  DeviceBuffer dSlot;
+  u64 tied = 0;
+  DeviceBuffer dRank;
+  {
+    DeviceBuffer keysA, keysB, valsB;
+    if (!keysA.alloc(n * 8) || !keysB.alloc(n * 8) || !valsB.alloc(n * 4)) return false;
+    hipLaunchKernelGGL(suffixKeyKernel, dim3(gridOf(n, kKeyTile)), dim3(256), 0, 0, dText, n, dCode.as<unsigned char>(),
+                       bits, perKey, keysA.as<u64>(), valsB.as<u32>());
+    BUILD_TRY(hipGetLastError());
+    if (!sortPairs(keysA.as<u64>(), keysB.as<u64>(), valsB.as<u32>(), dSa, n, bits * perKey, temp, tempBytes))
+      return false;
+    keysA.reset();
+    valsB.reset();
+    /* which suffixes still tie on their first perKey characters */
+    DeviceBuffer dTied;
+    if (!dTied.alloc(n)) return false;
+    hipLaunchKernelGGL(tiedFlagKernel, dim3(gridOf(n)), dim3(256), 0, 0, keysB.as<u64>(), n, dTied.as<unsigned char>());
+    BUILD_TRY(hipGetLastError());
+    /* select needs an output as large as the worst case only if everything ties; size it by a count first */
+    DeviceBuffer dFlag32;
+    {
+      /* count = sum of flags via select's own counter: run select into a full-size buffer lazily */
+      if (!dSlot.alloc(n * 4)) return false;
+      if (!selectFlagged(dTied.as<unsigned char>(), n, dSlot.as<u32>(), &tied, temp, tempBytes)) return false;
+    }
+    if (verbose) fprintf(stderr, "[awfm build] %llu suffixes, %u bits/char, %u chars/key, %llu tied after the key sort\n",
+                         n, bits, perKey, tied);
+    if (tied == 0) return true;
+    if (!dRank.alloc(n * 4)) return false;
+    hipLaunchKernelGGL(inverseSaKernel, dim3(gridOf(n)), dim3(256), 0, 0, dSa, n, dRank.as<u32>());
+    BUILD_TRY(hipGetLastError());
+    /* compact tied state, group heads from the sorted keys */
+    DeviceBuffer dVal, dHead, dGrp;
+    if (!dVal.alloc(tied * 4) || !dHead.alloc(tied * 4) || !dGrp.alloc(tied * 4)) return false;
+    hipLaunchKernelGGL(tiedInitKernel, dim3(gridOf(tied)), dim3(256), 0, 0, keysB.as<u64>(), dSa, dSlot.as<u32>(), tied,
+                       dVal.as<u32>(), dHead.as<u32>());
+    BUILD_TRY(hipGetLastError());
+    keysB.reset();
+    dTied.reset();
+    if (!maxScanU32(dHead.as<u32>(), dGrp.as<u32>(), tied, temp, tempBytes)) return false;
+    hipLaunchKernelGGL(setRankKernel, dim3(gridOf(tied)), dim3(256), 0, 0, dVal.as<u32>(), dGrp.as<u32>(), tied,
+                       dRank.as<u32>());
+    BUILD_TRY(hipGetLastError());
+
+    /* prefix doubling on the tied subset */
+    DeviceBuffer key2A, key2B, valOut, keep, dest, slot2, val2, grp2;
+    u64 t = tied;
+    DeviceBuffer curSlot, curVal, curGrp;
+    curSlot.p = dSlot.release();
+    curVal.p = dVal.release();
+    curGrp.p = dGrp.release();
+    for (u64 h = perKey; t > 0; h *= 2) {
+      if (!key2A.alloc(t * 8) || !key2B.alloc(t * 8) || !valOut.alloc(t * 4) || !keep.alloc(t) || !dest.alloc(t * 4))
+        return false;
+      hipLaunchKernelGGL(doublingKeyKernel, dim3(gridOf(t)), dim3(256), 0, 0, curVal.as<u32>(), curGrp.as<u32>(),
+                         dRank.as<u32>(), t, n, h, key2A.as<u64>());
+      BUILD_TRY(hipGetLastError());
+      if (!sortPairs(key2A.as<u64>(), key2B.as<u64>(), curVal.as<u32>(), valOut.as<u32>(), t, 64, temp, tempBytes))
+        return false;
+      hipLaunchKernelGGL(doublingApplyKernel, dim3(gridOf(t)), dim3(256), 0, 0, key2B.as<u64>(), valOut.as<u32>(),
+                         curSlot.as<u32>(), t, dSa, dHead.as<u32>());
+      BUILD_TRY(hipGetLastError());
+      if (!maxScanU32(dHead.as<u32>(), curGrp.as<u32>(), t, temp, tempBytes)) return false;
+      hipLaunchKernelGGL(setRankKernel, dim3(gridOf(t)), dim3(256), 0, 0, valOut.as<u32>(), curGrp.as<u32>(), t,
+                         dRank.as<u32>());
+      hipLaunchKernelGGL(stillTiedKernel, dim3(gridOf(t)), dim3(256), 0, 0, key2B.as<u64>(), t, keep.as<unsigned char>());
+      BUILD_TRY(hipGetLastError());
+      /* compaction: exclusive sum of keep flags */
+      DeviceBuffer keep32;
+      if (!keep32.alloc(t * 4)) return false;
+      hipLaunchKernelGGL(flagsToU32Kernel, dim3(gridOf(t)), dim3(256), 0, 0, keep.as<unsigned char>(), t, keep32.as<u32>());
+      if (!exclusiveSumU32(keep32.as<u32>(), dest.as<u32>(), t, temp, tempBytes)) return false;
+      u32 lastDest = 0;
+      unsigned char lastKeep = 0;
+      BUILD_TRY(hipMemcpy(&lastDest, dest.as<u32>() + (t - 1), 4, hipMemcpyDeviceToHost));
+      BUILD_TRY(hipMemcpy(&lastKeep, keep.as<unsigned char>() + (t - 1), 1, hipMemcpyDeviceToHost));
+      const u64 newT = (u64)lastDest + lastKeep;
+      if (verbose) fprintf(stderr, "[awfm build]   doubling h=%llu: %llu tied -> %llu\n", h, t, newT);
+      if (newT == 0) break;
+      if (!slot2.alloc(newT * 4) || !val2.alloc(newT * 4) || !grp2.alloc(newT * 4)) return false;
+      hipLaunchKernelGGL(compactTriplesKernel, dim3(gridOf(t)), dim3(256), 0, 0, keep.as<unsigned char>(), dest.as<u32>(),
+                         t, curSlot.as<u32>(), valOut.as<u32>(), curGrp.as<u32>(), slot2.as<u32>(), val2.as<u32>(),
+                         grp2.as<u32>());
+      BUILD_TRY(hipGetLastError());
+      BUILD_TRY(hipDeviceSynchronize());
+      curSlot.reset();
+      curVal.reset();
+      curGrp.reset();
+      curSlot.p = slot2.release();
+      curVal.p = val2.release();
+      curGrp.p = grp2.release();
+      if (!dHead.alloc(newT * 4)) return false;
+      t = newT;
+    }
+  }
+  BUILD_TRY(hipDeviceSynchronize());
+  return true;
+}
+
+}  // namespace
+
+extern "C" enum AwFmReturnCode awfmGpuCreateIndex(struct AwFmIndex **index, const struct AwFmIndexConfiguration *config,
+                                                  const uint8_t *sequence, uint64_t sequenceLength,
+                                                  int sequenceOnDevice, const char *fileSrc, int device) {
+  if (!index || !config || !sequence) {
+    awfmGpuSetError("awfmGpuCreateIndex: null argument");
+    return AwFmNullPtrError;
+  }
+  *index = nullptr;
+  if (awfmGpuDeviceCount() <= 0) {
+    awfmGpuSetError("awfmGpuCreateIndex: no HIP device available");
+    return AwFmGeneralFailure;
+  }
+  const u64 n = sequenceLength + 1; /* bwtLength */
+  if (n > 0xFFFFFFFEull) {
+    awfmGpuSetError("awfmGpuCreateIndex: the GPU builder handles bwtLength <= 2^32-2");
+    return AwFmUnsupportedVersionError;
+  }
+  if (config->suffixArrayCompressionRatio == 0) {
+    awfmGpuSetError("awfmGpuCreateIndex: suffixArrayCompressionRatio must be >= 1");
+    return AwFmGeneralFailure;
+  }
+  if (device < 0) {
+    const char *env = getenv("AWFM_GPU_DEVICE");
+    if (env && *env)
+      device = atoi(env);
+    else if (hipGetDevice(&device) != hipSuccess)
+      device = 0;
+  }
+  DeviceGuard guard(device);
+  if (!guard.ok) {
+    awfmGpuSetError("awfmGpuCreateIndex: hipSetDevice failed");
+    return AwFmGeneralFailure;
+  }
+  const bool verbose = getenv("AWFM_VERBOSE") != nullptr;
+  const bool amino = config->alphabetType == AwFmAlphabetAmino;
+  const u64 numBlocks = awfmNumBlocks(n);
+  const unsigned refWords = amino ? 44 : 20;
+  const unsigned letters = amino ? 22 : 6;
+  const unsigned card = amino ? 20 : 4;
+  const unsigned K = config->kmerLengthInSeedTable;
+  const u64 seedLen = awfmKmerTableLength(config->alphabetType, K);
+
+  struct AwFmIndex *ix = awfmIndexAlloc(config, n);
+  if (!ix) {
+    awfmGpuSetError("awfmGpuCreateIndex: host allocation failed");
+    return AwFmAllocationFailure;
+  }
+  ix->versionNumber = AWFM_VERSION_NUMBER;
+  ix->featureFlags = 0;
+  auto failWith = [&](enum AwFmReturnCode rc) {
+    awFmDeallocIndex(ix);
+    return rc;
+  };
+#define STEP(expr)                                \
+  do {                                            \
+    if (!(expr)) return failWith(AwFmGeneralFailure); \
+  } while (0)
+#define STEP_HIP(call)                            \
+  do {                                            \
+    hipError_t e__ = (call);                      \
+    if (e__ != hipSuccess) {                      \
+      awfmGpuSetHipError(#call, e__);             \
+      return failWith(AwFmGeneralFailure);        \
+    }                                             \
+  } while (0)
+
+  /* 1. text */
+  DeviceBuffer dText, dRaw;
+  STEP(dText.alloc(n + 64));
+  const unsigned char *rawDev = sequence;
+  if (!sequenceOnDevice) {
+    STEP(dRaw.alloc(sequenceLength));
+    STEP_HIP(hipMemcpy(dRaw.p, sequence, sequenceLength, hipMemcpyHostToDevice));
+    rawDev = dRaw.as<unsigned char>();
+  }
+  hipLaunchKernelGGL(sanitizeKernel, dim3(gridOf(n)), dim3(256), 0, 0, rawDev, (u64)sequenceLength, amino ? 1 : 0,
+                     dText.as<unsigned char>());
+  STEP_HIP(hipGetLastError());
+  dRaw.reset();
+
+  /* 2. suffix array */
+  DeviceBuffer dSa;
+  STEP(dSa.alloc(n * 4));
+  STEP(buildSuffixArray(dText.as<unsigned char>(), n, dSa.as<u32>(), verbose));
+
+  /* 3. reference-layout blocks */
+  DeviceBuffer dRef, dCounts, dScanned, dSentinel, temp;
+  size_t tempBytes = 0;
+  STEP(dRef.alloc(numBlocks * refWords * 8));
+  STEP(dCounts.alloc((u64)letters * numBlocks * 8));
+  STEP(dScanned.alloc((u64)letters * numBlocks * 8));
+  STEP(dSentinel.alloc(8));
+  STEP_HIP(hipMemset(dSentinel.p, 0, 8));
+  if (amino)
+    hipLaunchKernelGGL(bwtBlockKernel<true>, dim3((unsigned)numBlocks), dim3(256), 0, 0, dText.as<unsigned char>(),
+                       dSa.as<u32>(), n, numBlocks, dRef.as<u64>(), dCounts.as<u64>(), dSentinel.as<u64>());
+  else
+    hipLaunchKernelGGL(bwtBlockKernel<false>, dim3((unsigned)numBlocks), dim3(256), 0, 0, dText.as<unsigned char>(),
+                       dSa.as<u32>(), n, numBlocks, dRef.as<u64>(), dCounts.as<u64>(), dSentinel.as<u64>());
+  STEP_HIP(hipGetLastError());
+  u64 totals[24] = {0};
+  for (unsigned l = 0; l < letters; l++) {
+    STEP(exclusiveSumU64(dCounts.as<u64>() + (u64)l * numBlocks, dScanned.as<u64>() + (u64)l * numBlocks, numBlocks, temp,
+                         tempBytes));
+    u64 lastScan = 0, lastCount = 0;
+    STEP_HIP(hipMemcpy(&lastScan, dScanned.as<u64>() + (u64)l * numBlocks + (numBlocks - 1), 8, hipMemcpyDeviceToHost));
+    STEP_HIP(hipMemcpy(&lastCount, dCounts.as<u64>() + (u64)l * numBlocks + (numBlocks - 1), 8, hipMemcpyDeviceToHost));
+    totals[l] = lastScan + lastCount;
+  }
+  {
+    const u64 threads = numBlocks * (amino ? 24 : 8);
+    if (amino)
+      hipLaunchKernelGGL(baseOccurrenceKernel<true>, dim3(gridOf(threads)), dim3(256), 0, 0, dScanned.as<u64>(), numBlocks,
+                         dRef.as<u64>());
+    else
+      hipLaunchKernelGGL(baseOccurrenceKernel<false>, dim3(gridOf(threads)), dim3(256), 0, 0, dScanned.as<u64>(),
+                         numBlocks, dRef.as<u64>());
+    STEP_HIP(hipGetLastError());
+  }
+  dCounts.reset();
+  dScanned.reset();
+  dText.reset();
+  u64 sentinelPos = 0;
+  STEP_HIP(hipMemcpy(&sentinelPos, dSentinel.p, 8, hipMemcpyDeviceToHost));
+  /* prefix sums (ref src/AwFmCreate.c:338-344) */
+  ix->prefixSums[0] = 1;
+  for (unsigned i = 1; i < card + 2; i++) ix->prefixSums[i] = ix->prefixSums[i - 1] + totals[i - 1];
+
+  /* 4. device image: blocks, prefix sums, seed table, packed SA */
+  DeviceBuffer dBlocks, dPrefix, dSeedA, dSeedB, dPacked;
+  STEP(dBlocks.alloc(numBlocks * (amino ? 256ull : 128ull)));
+  {
+    DeviceBuffer dIgnored;
+    STEP(dIgnored.alloc(8));
+    const u64 threads = numBlocks * 8;
+    if (amino)
+      hipLaunchKernelGGL(relayoutAminoKernel, dim3(gridOf(threads)), dim3(256), 0, 0, dRef.as<u64>(), numBlocks, n,
+                         dBlocks.as<uint4>(), dIgnored.as<u64>());
+    else
+      hipLaunchKernelGGL(relayoutNucKernel, dim3(gridOf(threads)), dim3(256), 0, 0, dRef.as<u64>(), numBlocks, n,
+                         dBlocks.as<uint4>(), dIgnored.as<u64>());
+    STEP_HIP(hipGetLastError());
+    STEP_HIP(hipDeviceSynchronize());
+  }
+  {
+    u64 prefix[24] = {0};
+    memcpy(prefix, ix->prefixSums, (card + 2) * sizeof(u64));
+    STEP(dPrefix.alloc(sizeof prefix));
+    STEP_HIP(hipMemcpy(dPrefix.p, prefix, sizeof prefix, hipMemcpyHostToDevice));
+  }
+  DevIndex dev{};
+  dev.blocks = dBlocks.as<uint4>();
+  dev.prefixSums = dPrefix.as<u64>();
+  dev.bwtLength = n;
+  dev.sentinelPos = sentinelPos;
+  dev.seedK = K;
+  STEP(dSeedA.alloc(seedLen * 16));
+  if (K == 0) {
+    STEP_HIP(hipMemset(dSeedA.p, 0, 16));
+  } else {
+    STEP(dSeedB.alloc(seedLen * 16));
+    std::vector<u64> level1(2 * card);
+    for (unsigned a = 0; a < card; a++) {
+      level1[2 * a] = ix->prefixSums[a];
+      level1[2 * a + 1] = ix->prefixSums[a + 1] - 1;
+    }
+    /* ping-pong so that the last level lands in dSeedA */
+    DeviceBuffer *cur = (K % 2 == 1) ? &dSeedA : &dSeedB;
+    DeviceBuffer *nxt = (K % 2 == 1) ? &dSeedB : &dSeedA;
+    STEP_HIP(hipMemcpy(cur->p, level1.data(), level1.size() * 8, hipMemcpyHostToDevice));
+    u64 len = card;
+    for (unsigned L = 1; L < K; L++) {
+      const u64 outLen = len * card;
+      const u64 blocks = (outLen + kGroupsPerBlock - 1) / kGroupsPerBlock;
+      const unsigned grid = (unsigned)(blocks < 2048 * 4 ? blocks : 2048 * 4);
+      if (amino)
+        hipLaunchKernelGGL(seedLevelKernel<true>, dim3(grid), dim3(kThreads), 0, 0, dev, cur->as<ulonglong2>(), len, outLen,
+                           nxt->as<ulonglong2>());
+      else
+        hipLaunchKernelGGL(seedLevelKernel<false>, dim3(grid), dim3(kThreads), 0, 0, dev, cur->as<ulonglong2>(), len,
+                           outLen, nxt->as<ulonglong2>());
+      STEP_HIP(hipGetLastError());
+      std::swap(cur, nxt);
+      len = outLen;
+    }
+    STEP_HIP(hipDeviceSynchronize());
+    if (cur != &dSeedA) { /* cannot happen with the parity choice above, kept as a guard */
+      awfmGpuSetError("awfmGpuCreateIndex: seed table ping-pong parity");
+      return failWith(AwFmGeneralFailure);
+    }
+    dSeedB.reset();
+  }
+  ix->suffixArray.valueBitWidth = awfmSaWidth(n);
+  ix->suffixArray.compressedByteLength = awfmSaPackedBytes(n, config->suffixArrayCompressionRatio);
+  const u64 saWords = (ix->suffixArray.compressedByteLength + 7) / 8 + 2;
+  STEP(dPacked.alloc(saWords * 8));
+  hipLaunchKernelGGL(packSampledSaKernel, dim3(gridOf(saWords)), dim3(256), 0, 0, dSa.as<u32>(),
+                     awfmSaSampleCount(n, config->suffixArrayCompressionRatio),
+                     (unsigned)config->suffixArrayCompressionRatio, (unsigned)ix->suffixArray.valueBitWidth, saWords,
+                     dPacked.as<u64>());
+  STEP_HIP(hipGetLastError());
+  STEP_HIP(hipDeviceSynchronize());
+  dSa.reset();
+
+  /* 5. download the reference-layout arrays */
+  STEP_HIP(hipMemcpy(ix->bwtBlockList.asNucleotide, dRef.p, numBlocks * refWords * 8, hipMemcpyDeviceToHost));
+  dRef.reset();
+  STEP_HIP(hipMemcpy(ix->kmerSeedTable, dSeedA.p, seedLen * 16, hipMemcpyDeviceToHost));
+  ix->suffixArray.values = (uint8_t *)malloc(ix->suffixArray.compressedByteLength);
+  if (!ix->suffixArray.values) {
+    awfmGpuSetError("awfmGpuCreateIndex: host allocation failed");
+    return failWith(AwFmAllocationFailure);
+  }
+  STEP_HIP(hipMemcpy(ix->suffixArray.values, dPacked.p, ix->suffixArray.compressedByteLength, hipMemcpyDeviceToHost));
+  ix->suffixArrayFileOffset = awfmSuffixArrayFileOffset(ix);
+  ix->sequenceFileOffset = awfmSequenceFileOffset(ix);
+
+  /* keep the device image for awFmParallelSearch* */
+  const uint64_t deviceBytes = numBlocks * (amino ? 256ull : 128ull) + seedLen * 16 + saWords * 8;
+  AwFmGpuIndex *g = awfmGpuIndexAdopt(ix, device, dBlocks.release(), dSeedA.release(), dPacked.release(), dPrefix.release(),
+                                      sentinelPos, deviceBytes);
+  awfmGpuIndexRegister(ix, g);
+
+  enum AwFmReturnCode rc = AwFmFileWriteOkay;
+  if (fileSrc) {
+    if (config->storeOriginalSequence && sequenceOnDevice) {
+      std::vector<uint8_t> hostSeq(sequenceLength ? sequenceLength : 1);
+      STEP_HIP(hipMemcpy(hostSeq.data(), sequence, sequenceLength, hipMemcpyDeviceToHost));
+      rc = awFmWriteIndexToFile(ix, hostSeq.data(), sequenceLength, fileSrc);
+    } else {
+      static const uint8_t none = 0;
+      rc = awFmWriteIndexToFile(ix, sequenceOnDevice ? &none : sequence, sequenceLength, fileSrc);
+    }
+  }
+  if (!config->keepSuffixArrayInMemory && fileSrc) { /* ref src/AwFmCreate.c:128-131 */
+    free(ix->suffixArray.values);
+    ix->suffixArray.values = nullptr;
+  }
+#undef STEP
+#undef STEP_HIP
+  *index = ix;
+  return rc;
+}

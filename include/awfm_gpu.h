@@ -68,6 +68,16 @@ int awfmGpuIndexDevice(const AwFmGpuIndex *g);
 /* Selects the search kernel variant for this image (default AUTO). */
 void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel);
 
+/* ---- index construction on the GPU ---- */
+/* Same contract and byte-identical arrays as awFmCreateIndex (ref src/AwFmCreate.c:31-137), built on
+ * the device: suffix sort (radix + prefix doubling), BWT bit planes, base counts, seed table, sampled
+ * SA.  `sequence` is a host pointer, or a device pointer when sequenceOnDevice != 0.  fileSrc may be
+ * NULL (no .awfmi file is written; an extension over the reference).  The device image stays
+ * resident and is the one awFmParallelSearch* will use.  Needs bwtLength <= 2^32-2. */
+enum AwFmReturnCode awfmGpuCreateIndex(struct AwFmIndex **index, const struct AwFmIndexConfiguration *config,
+                                       const uint8_t *sequence, uint64_t sequenceLength, int sequenceOnDevice,
+                                       const char *fileSrc, int device);
+
 /* ---- flat batch API on device buffers ---- */
 /* Queries: dChars = concatenated ASCII k-mers; either dOffsets (numQueries+1
  * CSR offsets into dChars) or, with dOffsets == NULL, fixedLength characters
@@ -101,6 +111,17 @@ enum AwFmReturnCode awfmGpuCountHost(AwFmGpuIndex *g, const uint8_t *chars, cons
 enum AwFmReturnCode awfmGpuLocateHost(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
                                       uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
                                       uint64_t *hitOffsets, uint64_t **positions);
+
+/* ---- seeded synthetic inputs on the device (bench and full-size tests) ---- */
+/* text characters start..start+count-1 of the stream `seed`; amino != 0 selects the 20-letter alphabet */
+enum AwFmReturnCode awfmGpuSynthText(uint8_t *dOut, uint64_t start, uint64_t count, uint64_t seed, int amino,
+                                     void *stream);
+/* `count` uniform random k-mers (query ids first..first+count-1) of `length` characters, row-major */
+enum AwFmReturnCode awfmGpuSynthRandomQueries(uint8_t *dOut, uint64_t first, uint64_t count, uint32_t length,
+                                              uint64_t seedQ, int amino, void *stream);
+/* `count` k-mers copied from the (unsanitised) device text at seeded uniform offsets */
+enum AwFmReturnCode awfmGpuSynthPlantedQueries(uint8_t *dOut, uint64_t first, uint64_t count, uint32_t length,
+                                               uint64_t seedQ, const uint8_t *dText, uint64_t textLength, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,103 @@
+"""GPU index construction and device-side synthetic generators against their host twins.
+
+The arrays an index is made of (blocks, prefix sums, seed table, packed sampled SA) must be byte
+identical whichever builder made them (ref test/createTests/AwFmCreationTest.c:151-295,
+test/bwtTest/bwtTest.c:95-213, test/kmerSeedTableTests/kmerSeedTableTests.c:203-228 pin them against
+brute force; the host builder is pinned to the oracle's in tests/test_host_lib.py).
+"""
+import numpy as np
+import pytest
+
+from avxwindowfmindex_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_arrays(a, b):
+    assert a.bwt_length == b.bwt_length
+    assert np.array_equal(a.prefix_sums(), b.prefix_sums()), "prefix sums"
+    assert np.array_equal(a.blocks(), b.blocks()), "BWT blocks"
+    assert np.array_equal(a.seed_table(), b.seed_table()), "seed table"
+    assert np.array_equal(a.packed_sa(), b.packed_sa()), "packed sampled SA"
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 29, 255, 256, 257, 4096, 100003, 1 << 20])
+def test_dna_build_matches_host(awfm, require_gpu, n):
+    txt = synth.text(40 + n, n).copy()
+    if n > 100:
+        txt[7:12] = ord("N")
+        txt[n // 2] = ord("x")
+    for ratio, k in ((1, 1), (8, 6), (3, 3)):
+        host = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, k)
+        dev = awfm.gpu_create_index(txt, awfm.AwFmAlphabetDna, ratio, k)
+        _same_arrays(host, dev)
+        host.dealloc()
+        dev.dealloc()
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 256, 5000, 300001])
+def test_amino_build_matches_host(awfm, require_gpu, n):
+    txt = synth.text(50 + n, n, synth.AMINO_ALPHABET).copy()
+    if n > 100:
+        txt[3:6] = ord("x")
+        txt[n // 2] = ord("b")
+    for ratio, k in ((1, 1), (8, 3), (5, 2)):
+        host = awfm.create_index(txt, awfm.AwFmAlphabetAmino, ratio, k)
+        dev = awfm.gpu_create_index(txt, awfm.AwFmAlphabetAmino, ratio, k)
+        _same_arrays(host, dev)
+        host.dealloc()
+        dev.dealloc()
+
+
+def test_repetitive_texts_need_doubling_rounds(awfm, require_gpu):
+    cases = [b"a" * 5000, b"acgt" * 4000 + b"a", (b"acgtacgtaa" * 3000) + b"t" * 300,
+             bytes(synth.text(3, 2000)) * 40]
+    for raw in cases:
+        txt = np.frombuffer(raw, np.uint8)
+        host = awfm.create_index(txt, awfm.AwFmAlphabetDna, 4, 4)
+        dev = awfm.gpu_create_index(txt, awfm.AwFmAlphabetDna, 4, 4)
+        _same_arrays(host, dev)
+        host.dealloc()
+        dev.dealloc()
+
+
+def test_gpu_built_index_searches_with_its_resident_image(oracle, awfm, require_gpu, tmp_path):
+    txt = synth.text(61, 400000)
+    path = str(tmp_path / "gpu_built.awfmi")
+    ix = awfm.gpu_create_index(txt, awfm.AwFmAlphabetDna, 8, 8, file_src=path)
+    g = awfm.GpuIndex(ix, acquire=True)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    q = np.concatenate([synth.random_queries(62, 3000, 15), synth.planted_queries(63, 3000, 15, txt)])
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, _, _ = oi.batch_search(chars, offsets)
+    ho, pos, _ = oi.batch_locate(sp, ep)
+    r, ho2, pos2 = g.locate_host(chars, offsets)
+    assert np.array_equal(r[:, 0], sp) and np.array_equal(r[:, 1], ep)
+    assert np.array_equal(ho2, ho) and np.array_equal(pos2, pos)
+    # the file the GPU builder wrote loads back to the same arrays
+    back = awfm.read_index_from_file(path)
+    _same_arrays(ix, back)
+    back.dealloc()
+    ix.dealloc()
+
+
+def test_device_generators_match_numpy(awfm, require_gpu):
+    import torch
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    n = 100000
+    for amino, alphabet in ((0, synth.DNA_ALPHABET), (1, synth.AMINO_ALPHABET)):
+        d = torch.empty(n, dtype=torch.uint8, device="cuda")
+        assert L.awfmGpuSynthText(d.data_ptr(), 0, n, 11, amino, None) == 1
+        torch.cuda.synchronize()
+        txt = synth.text(11, n, alphabet)
+        assert np.array_equal(d.cpu().numpy(), txt)
+        part = torch.empty(1000, dtype=torch.uint8, device="cuda")
+        assert L.awfmGpuSynthText(part.data_ptr(), 5000, 1000, 11, amino, None) == 1
+        assert np.array_equal(part.cpu().numpy(), txt[5000:6000])
+        q = torch.empty(2000 * 21, dtype=torch.uint8, device="cuda")
+        assert L.awfmGpuSynthRandomQueries(q.data_ptr(), 100, 2000, 21, 12, amino, None) == 1
+        assert np.array_equal(q.cpu().numpy().reshape(2000, 21), synth.random_queries(12, 2000, 21, alphabet, first=100))
+        assert L.awfmGpuSynthPlantedQueries(q.data_ptr(), 100, 2000, 21, 13, d.data_ptr(), n, None) == 1
+        assert np.array_equal(q.cpu().numpy().reshape(2000, 21), synth.planted_queries(13, 2000, 21, txt, first=100))
