@@ -28,7 +28,7 @@ GPU_SYMBOLS = [
     "awfmGpuDeviceCount", "awfmGpuLastError", "awfmGpuIndexCreate", "awfmGpuIndexDestroy", "awfmGpuIndexAcquire",
     "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuSearch",
     "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
-    "awfmGpuCreateIndex", "awfmGpuSynthText", "awfmGpuSynthRandomQueries", "awfmGpuSynthPlantedQueries",
+    "awfmGpuCreateIndex", "awfmGpuSearchTally", "awfmGpuSynthText", "awfmGpuSynthRandomQueries", "awfmGpuSynthPlantedQueries",
 ]
 
 
@@ -129,6 +129,7 @@ def lib():
         "awfmGpuLocateHost": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, C.POINTER(C.POINTER(u64))]),
         "awfmGpuCreateIndex": (C.c_int, [C.POINTER(IP), C.POINTER(AwFmIndexConfiguration), vp, u64, C.c_int,
                                          C.c_char_p, C.c_int]),
+        "awfmGpuSearchTally": (C.c_int, [vp, vp, vp, C.c_uint32, u64, C.POINTER(u64 * 4)]),
         "awfmGpuSynthText": (C.c_int, [vp, u64, u64, u64, C.c_int, vp]),
         "awfmGpuSynthRandomQueries": (C.c_int, [vp, u64, u64, C.c_uint32, u64, C.c_int, vp]),
         "awfmGpuSynthPlantedQueries": (C.c_int, [vp, u64, u64, C.c_uint32, u64, vp, u64, vp]),

@@ -250,6 +250,13 @@ class GpuIndex:
         _check("awfmGpuSearch", _lib.lib().awfmGpuSearch(self.handle, d_chars, d_offsets or None, fixed_length, n,
                                                          d_ranges or None, d_counts or None, stream or None))
 
+    def search_tally(self, d_chars, d_offsets, fixed_length, n):
+        """{seeded, steps, blocks, chars} of the instrumented search kernel"""
+        out = (C.c_uint64 * 4)()
+        _check("awfmGpuSearchTally", _lib.lib().awfmGpuSearchTally(self.handle, d_chars, d_offsets or None, fixed_length,
+                                                                   n, C.byref(out)))
+        return {"seeded": int(out[0]), "steps": int(out[1]), "blocks": int(out[2]), "chars": int(out[3])}
+
     def hit_offsets(self, d_ranges, n, d_hit_offsets, d_scratch, stream=0):
         total = C.c_uint64(0)
         _check("awfmGpuHitOffsets", _lib.lib().awfmGpuHitOffsets(self.handle, d_ranges, n, d_hit_offsets, d_scratch,

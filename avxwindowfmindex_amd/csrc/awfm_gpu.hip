@@ -46,12 +46,14 @@ namespace {
  * (ref src/AwFmParallelSearch.c:222-313, src/AwFmKmerTable.c:4-51, src/AwFmSearch.c:485-520).
  * The non-seeded search over the last min(len,k) characters followed by the
  * extension loop is one right-to-left walk that stops at the first invalid range. */
-template <bool AMINO>
+template <bool AMINO, bool TALLY>
 __global__ void __launch_bounds__(kThreads)
     searchGroup8Kernel(const DevIndex ix, const unsigned char *__restrict__ chars,
                        const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
                        const unsigned long long numQueries, ulonglong2 *__restrict__ ranges,
-                       unsigned *__restrict__ counts) {
+                       unsigned *__restrict__ counts, unsigned long long *__restrict__ tally) {
+  /* TALLY build only: work counters for the roofline's algorithmic bytes */
+  unsigned long long tSeeded = 0, tSteps = 0, tBlocks = 0, tChars = 0;
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sPow[32];
   __shared__ AminoShared sAmino;
@@ -102,6 +104,7 @@ __global__ void __launch_bounds__(kThreads)
         const unsigned long long ballot = __ballot(ambiguous);
         seeded = ((ballot >> (lane & 56u)) & 0xFFull) == 0ull;
         if (seeded && index < ix.seedLen) {
+          if (TALLY) tSeeded++;
           const ulonglong2 r = ix.seed[index];
           sp = r.x;
           ep = r.y;
@@ -118,8 +121,13 @@ __global__ void __launch_bounds__(kThreads)
         pos = (long long)len - 2;
       }
     }
+    if (TALLY) tChars += len;
     while (pos >= 0 && sp <= ep) {
       const unsigned c = kmer[pos];
+      if (TALLY) {
+        tSteps++;
+        tBlocks += ((sp - 1ull) >> 8) == (ep >> 8) ? 1ull : 2ull;
+      }
       if (AMINO)
         aminoStep(ix, sC, sAmino, aminoLetterIndex(sAmino, c), sp, ep, g);
       else
@@ -130,6 +138,12 @@ __global__ void __launch_bounds__(kThreads)
       if (ranges) ranges[q] = make_ulonglong2(sp, ep);
       if (counts) counts[q] = sp <= ep ? (unsigned)(ep - sp + 1ull) : 0u;
     }
+  }
+  if (TALLY && g == 0) { /* one lane per group carries the group's counters */
+    atomicAdd(&tally[0], tSeeded);
+    atomicAdd(&tally[1], tSteps);
+    atomicAdd(&tally[2], tBlocks);
+    atomicAdd(&tally[3], tChars);
   }
 }
 
@@ -580,14 +594,47 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
   const unsigned grid = gridFor(numQueries, g);
   hipStream_t s = (hipStream_t)stream;
   if (g->amino)
-    hipLaunchKernelGGL(searchGroup8Kernel<true>, dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
+    hipLaunchKernelGGL((searchGroup8Kernel<true, false>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
                        (const unsigned long long *)dOffsets, fixedLength, (unsigned long long)numQueries,
-                       (ulonglong2 *)dRanges, dCounts);
+                       (ulonglong2 *)dRanges, dCounts, (unsigned long long *)nullptr);
   else
-    hipLaunchKernelGGL(searchGroup8Kernel<false>, dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
+    hipLaunchKernelGGL((searchGroup8Kernel<false, false>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
                        (const unsigned long long *)dOffsets, fixedLength, (unsigned long long)numQueries,
-                       (ulonglong2 *)dRanges, dCounts);
+                       (ulonglong2 *)dRanges, dCounts, (unsigned long long *)nullptr);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  return AwFmSuccess;
+}
+
+/* Instrumented run of the search kernel: tallyOut = {seeded queries, backward steps, distinct
+ * blocks over those steps, query characters}.  Synchronous; not for timing. */
+enum AwFmReturnCode awfmGpuSearchTally(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                       uint32_t fixedLength, uint64_t numQueries, uint64_t tallyOut[4]) {
+  if (!g || !dChars || !tallyOut || (!dOffsets && fixedLength == 0)) {
+    setError("awfmGpuSearchTally: null argument");
+    return AwFmNullPtrError;
+  }
+  DeviceGuard guard(g->device);
+  unsigned long long *dTally = nullptr;
+  AWFM_HIP_TRY(hipMalloc((void **)&dTally, 32), AwFmAllocationFailure);
+  hipError_t e = hipMemset(dTally, 0, 32);
+  if (e == hipSuccess && numQueries) {
+    const unsigned grid = gridFor(numQueries, g);
+    if (g->amino)
+      hipLaunchKernelGGL((searchGroup8Kernel<true, true>), dim3(grid), dim3(kThreads), 0, 0, g->dev, dChars,
+                         (const unsigned long long *)dOffsets, fixedLength, (unsigned long long)numQueries,
+                         (ulonglong2 *)nullptr, (unsigned *)nullptr, dTally);
+    else
+      hipLaunchKernelGGL((searchGroup8Kernel<false, true>), dim3(grid), dim3(kThreads), 0, 0, g->dev, dChars,
+                         (const unsigned long long *)dOffsets, fixedLength, (unsigned long long)numQueries,
+                         (ulonglong2 *)nullptr, (unsigned *)nullptr, dTally);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(tallyOut, dTally, 32, hipMemcpyDeviceToHost);
+  (void)hipFree(dTally);
+  if (e != hipSuccess) {
+    setError("awfmGpuSearchTally", e);
+    return AwFmGeneralFailure;
+  }
   return AwFmSuccess;
 }
 

@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py -- Mkmers/s located on a GRCh38-sized synthetic nucleotide FM-index, MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic k-mers already resident in HBM:
+search kernel (seed lookup + backward search) -> hit-offset scan -> expand + LF-walk/SA kernels,
+i.e. the device side of awFmParallelSearchLocate (ref src/AwFmParallelSearch.c:95-157).
+
+Workload (BASELINE.json configs[2]): 100 M uniform random 21-mers, locate, index of a 3.1 Gbp
+uniform synthetic text, SA compression 8, seed table k=12, one index replica per GPU, the query
+batch sharded over the ranks with no collective (weak scaling: every rank has its own 100 M batch).
+`--workload planted` runs the secondary case (k-mers drawn from the text, >=1 hit each).
+
+The JSON line also carries
+  roofline     -- dominant kernel (searchGroup8Kernel): algorithmic bytes (SURVEY.md 8d,
+                  bytes_count = L + 16 t + 104 D + 16 per query, D/t/L tallied on the device by an
+                  instrumented run of the same kernel) / mean kernel time from HIP events on the
+                  launch stream, against the 8 TB/s HBM peak;
+  cpu_baseline -- the CPU oracle (a port of the reference's OpenMP 8-query lock-step driver) timed
+                  on this box's host cores on a bounded sample of the same queries, after checking
+                  that its results equal the GPU's on that sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+RANK_BYTES_DNA, RANK_BYTES_AMINO = 104, 168  # planes + one count of the reference block
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=5)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--workload", choices=["random", "planted"], default="random")
+    p.add_argument("--mode", choices=["locate", "count"], default="locate")
+    p.add_argument("--text-len", type=int, default=3_100_000_000)
+    p.add_argument("--queries", type=int, default=100_000_000, help="k-mers per GPU per step")
+    p.add_argument("--kmer", type=int, default=21)
+    p.add_argument("--seed-k", type=int, default=12)
+    p.add_argument("--sa-ratio", type=int, default=8)
+    p.add_argument("--alphabet", choices=["dna", "amino"], default="dna")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    p.add_argument("--no-cpu", action="store_true")
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from avxwindowfmindex_amd import _lib, api
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    L = _lib.lib()
+    amino = args.alphabet == "amino"
+    alpha = api.AwFmAlphabetAmino if amino else api.AwFmAlphabetDna
+    n, Q, K = args.text_len, args.queries, args.kmer
+    text_seed, query_seed = (4, 104) if amino else (2, 102 if args.workload == "random" else 103)
+
+    # ---- index replica on this GPU (text generated and indexed on the device) ----
+    t0 = time.time()
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, text_seed, int(amino), None) == 1
+    torch.cuda.synchronize()
+    ix = api.gpu_create_index(d_text.data_ptr(), alpha, args.sa_ratio, args.seed_k, on_device_length=n,
+                              device=dev.index)
+    g = api.GpuIndex(ix, acquire=True)
+    build_s = time.time() - t0
+
+    # ---- this rank's query shard, resident in HBM ----
+    first = rank * Q
+    d_chars = torch.empty(Q * K, dtype=torch.uint8, device=dev)
+    if args.workload == "random":
+        assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr(), first, Q, K, query_seed, int(amino), None) == 1
+    else:
+        assert L.awfmGpuSynthPlantedQueries(d_chars.data_ptr(), first, Q, K, query_seed, d_text.data_ptr(), n, None) == 1
+    torch.cuda.synchronize()
+    if args.mode == "count" or args.workload == "random":
+        del d_text  # planted k-mers are already copied out; free 3.1 GB
+        torch.cuda.empty_cache()
+
+    d_ranges = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+    d_counts = torch.empty(Q, dtype=torch.int32, device=dev)
+    d_hit_off = torch.empty(Q + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.empty(api.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    state = {"positions": None, "hits": 0}
+
+    def ensure_positions(total):
+        if state["positions"] is None or state["positions"].numel() < max(total, 1):
+            state["positions"] = torch.empty(max(total, 1) + total // 8, dtype=torch.int64, device=dev)
+
+    search_events = []
+
+    def step(record):
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        g.search(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr(), stream)
+        if record:
+            e1.record()
+            search_events.append((e0, e1))
+        if args.mode == "locate":
+            total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
+            ensure_positions(total)
+            g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, state["positions"].data_ptr(), stream)
+            state["hits"] = total
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = world * Q / (elapsed / args.steps) / 1e6  # Mkmers/s over all ranks
+    search_ms = float(np.mean([a.elapsed_time(b) for a, b in search_events]))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel: algorithmic bytes / measured kernel time ----
+    tally = g.search_tally(d_chars.data_ptr(), 0, K, Q)
+    rank_bytes = RANK_BYTES_AMINO if amino else RANK_BYTES_DNA
+    alg_bytes = tally["chars"] + 16 * tally["seeded"] + rank_bytes * tally["blocks"] + 16 * Q
+    achieved = alg_bytes / (search_ms * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "searchGroup8Kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel_ms": round(search_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
+        "per_query": {"steps": round(tally["steps"] / Q, 4), "distinct_blocks": round(tally["blocks"] / Q, 4),
+                      "seeded": round(tally["seeded"] / Q, 4), "bytes": round(alg_bytes / Q, 1)},
+        "upper_bound_variant_GBs": round((tally["chars"] + 16 * tally["seeded"] + rank_bytes * 2 * tally["steps"]
+                                          + 16 * Q) / (search_ms * 1e-3) / 1e9, 1),
+    }
+
+    # ---- CPU baseline: the oracle on this box's host cores, bounded sample, parity-gated ----
+    cpu = None
+    if not args.no_cpu:
+        from oracle import oracle as O
+        oalpha = O.AMINO if amino else O.DNA
+        oi = O.Index.wrap(oalpha, args.sa_ratio, args.seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(),
+                          ix.seed_table(), ix.packed_sa())
+        cores = os.cpu_count() or 1
+
+        def run_sample(m):
+            chars = d_chars[: m * K].cpu().numpy()
+            offsets = np.arange(m + 1, dtype=np.uint64) * np.uint64(K)
+            t0 = time.perf_counter()
+            sp, ep, cnt, tl = oi.batch_search(chars, offsets, threads=cores)
+            if args.mode == "locate":
+                ho, pos, tl2 = oi.batch_locate(sp, ep, threads=cores)
+            dt = time.perf_counter() - t0
+            # parity gate on the sample: ranges and (for locate) hit positions in BWT order
+            gr = d_ranges[: 2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)
+            assert np.array_equal(gr[:, 0], sp) and np.array_equal(gr[:, 1], ep), "GPU ranges differ from the oracle"
+            if args.mode == "locate":
+                gho = d_hit_off[: m + 1].cpu().numpy().view(np.uint64)
+                assert np.array_equal(gho, ho), "GPU hit offsets differ from the oracle"
+                gp = state["positions"][: int(ho[-1])].cpu().numpy().view(np.uint64)
+                assert np.array_equal(gp, pos), "GPU positions differ from the oracle"
+            return dt, tl
+
+        # grow the sample until it costs about --cpu-seconds of wall time (thread start-up and first-touch
+        # page faults dominate tiny samples)
+        m = min(Q, 200_000)
+        dt, tl = run_sample(m)
+        for _ in range(4):
+            if dt >= args.cpu_seconds / 2 or m >= Q or m >= 50_000_000:
+                break
+            m = int(min(Q, 50_000_000, max(2 * m, m * args.cpu_seconds / max(dt, 1e-3))))
+            dt, tl = run_sample(m)
+        cpu = {"value": round(m / dt / 1e6, 3), "unit": "Mkmers/s", "cores": cores, "kind": "port",
+               "sample": f"first {m} of the {Q} {args.workload} {K}-mers of rank 0, {args.mode}, same index, "
+                         f"{dt:.1f} s wall, results equal to the GPU's",
+               "per_query": {"steps": round(tl["steps"] / m, 4), "distinct_blocks": round(tl["blocks"] / m, 4)}}
+
+    out = {
+        "metric": "Mkmers/sec located, GRCh38 nucleotide index" if not amino else "Mkmers/sec located, amino index",
+        "value": round(value, 2), "unit": "Mkmers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"{Q / 1e6:g} M {args.workload} {K}-mers per GPU, {args.mode}, "
+                               f"{n / 1e9:g} Gbp uniform synthetic {args.alphabet} text (GRCh38-sized), "
+                               f"SA ratio {args.sa_ratio}, seed table k={args.seed_k}",
+                   "parallelism": f"index replica per GPU, query batch sharded over {world} rank(s), no collective",
+                   "hits_per_step_rank0": int(state["hits"]), "index_build_s": round(build_s, 2),
+                   "device_image_bytes": g.device_bytes},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -88,6 +88,12 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
                                   uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
                                   uint32_t *dCounts, void *stream);
 
+/* Instrumented run of the same kernel for the roofline accounting: tallyOut =
+ * {queries that used the seed table, backward steps executed, distinct blocks over those steps,
+ * query characters}.  Synchronous, not for timing. */
+enum AwFmReturnCode awfmGpuSearchTally(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                       uint32_t fixedLength, uint64_t numQueries, uint64_t tallyOut[4]);
+
 /* dHitOffsets[numQueries+1] = exclusive scan of the range lengths; the total is
  * also copied to *totalHits (host) -- this call synchronises `stream`.
  * dScratch must hold awfmGpuScanScratchBytes(numQueries) bytes. */
