@@ -338,7 +338,12 @@ std::vector<std::pair<const AwFmIndex *, AwFmGpuIndex *>> imageTable;
 
 unsigned gridFor(uint64_t groups, const AwFmGpuIndex *g) {
   const uint64_t blocks = (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
-  const uint64_t cap = (uint64_t)g->numCUs * 8; /* 8 x 256-thread blocks = 32 waves per CU */
+  uint64_t perCU = 8; /* 8 x 256-thread blocks = 32 waves per CU */
+  if (const char *env = getenv("AWFM_GPU_BLOCKS_PER_CU")) { /* measurement knob */
+    const int v = atoi(env);
+    if (v >= 1 && v <= 64) perCU = (uint64_t)v;
+  }
+  const uint64_t cap = (uint64_t)g->numCUs * perCU;
   return (unsigned)(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
 
