@@ -93,16 +93,21 @@ __device__ __forceinline__ unsigned sliceMask(unsigned p, unsigned piece) {
 
 /* ---- nucleotide ---- */
 
-/* ref src/AwFmLetter.c:4-22 */
+/* 1 when (c | 0x20) is one of a,c,g,t,u; branch-free */
+__device__ __forceinline__ unsigned nucIsAcgtu(unsigned c) {
+  const unsigned d = (c | 0x20u) - 'a';
+  return (d < 21u ? 1u : 0u) & (0x180045u >> (d & 31u)); /* bits a=0 c=2 g=6 t=19 u=20 */
+}
+/* ref src/AwFmLetter.c:4-22: a0 c1 g2 t/u3 '$'5 else 4; branch-free: for a,c,g,t,u the code bits
+ * (c>>1)&3 are 0,1,3,2,2 and x^(x>>1) maps them to 0,1,2,3,3 */
 __device__ __forceinline__ unsigned nucLetterIndex(unsigned c) {
-  const unsigned l = c | 0x20u;
-  return l == 'a' ? 0u : l == 'c' ? 1u : l == 'g' ? 2u : (l == 't' || l == 'u') ? 3u : l == '$' ? 5u : 4u;
+  const unsigned y = (c >> 1) & 3u;
+  const unsigned acgt = y ^ (y >> 1);
+  const unsigned other = (c | 0x20u) == '$' ? 5u : 4u;
+  return (nucIsAcgtu(c) & 1u) ? acgt : other;
 }
-/* ref src/AwFmLetter.c:98-125 */
-__device__ __forceinline__ bool nucIsAmbiguous(unsigned c) {
-  const unsigned l = (c >= 'A' && c <= 'Z') ? (c | 0x20u) : c;
-  return !(l == 'a' || l == 'c' || l == 'g' || l == 't' || l == 'u');
-}
+/* ref src/AwFmLetter.c:98-125 (tolower(c) is one of acgtu exactly when c|0x20 is) */
+__device__ __forceinline__ bool nucIsAmbiguous(unsigned c) { return (nucIsAcgtu(c) & 1u) == 0u; }
 
 struct PlaneSel3 {
   unsigned x0, x1, x2; /* all-ones where the plane must be 0 */
@@ -143,23 +148,33 @@ __device__ __forceinline__ unsigned long long nucBase(const uint4 &pc, unsigned 
   return before - acgt - (sentinelPos < before ? 1ull : 0ull);
 }
 
-/* one backward step for the group's query (ref src/AwFmSearch.c:42-103) */
-__device__ __forceinline__ void nucStep(const DevIndex &ix, const unsigned long long *sC, unsigned letter,
-                                        unsigned long long &sp, unsigned long long &ep, unsigned g) {
+/* rank arithmetic of one backward step once the two pieces are in registers
+ * (ref src/AwFmSearch.c:42-103); pc1 == pc0 when sp-1 and ep share a block */
+__device__ __forceinline__ void nucStepFromPieces(const DevIndex &ix, const unsigned long long *sC, unsigned letter,
+                                                  const uint4 &pc0, const uint4 &pc1, unsigned long long &sp,
+                                                  unsigned long long &ep, unsigned g) {
   const unsigned long long q0 = sp - 1ull, q1 = ep;
-  const unsigned long long blk0 = q0 >> 8, blk1 = q1 >> 8;
-  const uint4 pc0 = ix.blocks[blk0 * 8ull + g];
-  uint4 pc1 = pc0;
-  if (blk1 != blk0) pc1 = ix.blocks[blk1 * 8ull + g];
   const PlaneSel3 sel = nucPlaneSel(letter);
   const unsigned n0 = __popc(nucOccSlice(pc0, sel) & sliceMask((unsigned)q0 & 255u, g));
   const unsigned n1 = __popc(nucOccSlice(pc1, sel) & sliceMask((unsigned)q1 & 255u, g));
   const unsigned packed = groupSum8(n0 | (n1 << 16));
-  const unsigned long long base0 = nucBase(pc0, letter, blk0, ix.sentinelPos, g);
-  const unsigned long long base1 = nucBase(pc1, letter, blk1, ix.sentinelPos, g);
+  const unsigned long long base0 = nucBase(pc0, letter, q0 >> 8, ix.sentinelPos, g);
+  const unsigned long long base1 = nucBase(pc1, letter, q1 >> 8, ix.sentinelPos, g);
   const unsigned long long c = sC[letter];
   sp = c + base0 + (packed & 0xFFFFu);
   ep = c + base1 + (packed >> 16) - 1ull;
+}
+
+/* one backward step for the group's query: loads + rank */
+__device__ __forceinline__ void nucStep(const DevIndex &ix, const unsigned long long *sC, unsigned letter,
+                                        unsigned long long &sp, unsigned long long &ep, unsigned g) {
+  const unsigned long long blk0 = (sp - 1ull) >> 8, blk1 = ep >> 8;
+  /* both loads are issued before either is consumed (copying pc0 into pc1 first would serialise them) */
+  const uint4 pc0 = ix.blocks[blk0 * 8ull + g];
+  uint4 other = make_uint4(0u, 0u, 0u, 0u);
+  if (blk1 != blk0) other = ix.blocks[blk1 * 8ull + g];
+  const uint4 pc1 = blk1 != blk0 ? other : pc0;
+  nucStepFromPieces(ix, sC, letter, pc0, pc1, sp, ep, g);
 }
 
 /* ---- amino ---- */
@@ -190,8 +205,8 @@ __device__ __forceinline__ unsigned aminoLetterIndex(const AminoShared &t, unsig
   return c == '$' ? 21u : (unsigned)t.letterOfAscii[c & 31u];
 }
 __device__ __forceinline__ bool aminoIsAmbiguous(unsigned c) {
-  const unsigned l = (c >= 'A' && c <= 'Z') ? (c | 0x20u) : c;
-  return l == 'z' || l == 'x' || l == 'b';
+  const unsigned l = c | 0x20u; /* equals tolower(c) whenever the result is z, x or b */
+  return ((l == 'z') | (l == 'x') | (l == 'b')) != 0;
 }
 
 /* An amino piece is two 16-B loads kept as plain uint4 values: lo = {b0,b1,b2,b3},
@@ -219,19 +234,12 @@ __device__ __forceinline__ unsigned long long aminoBase(const uint4 &hi, unsigne
   return (unsigned)__shfl((int)mine, (int)(letter / 3u), 8);
 }
 
-/* ref src/AwFmSearch.c:105-159 */
-__device__ __forceinline__ void aminoStep(const DevIndex &ix, const unsigned long long *sC, const AminoShared &t,
-                                          unsigned letter, unsigned long long &sp, unsigned long long &ep,
-                                          unsigned g) {
+/* rank arithmetic of one amino backward step from loaded pieces (ref src/AwFmSearch.c:105-159) */
+__device__ __forceinline__ void aminoStepFromPieces(const unsigned long long *sC, const AminoShared &t, unsigned letter,
+                                                    const uint4 &lo0, const uint4 &hi0, const uint4 &lo1,
+                                                    const uint4 &hi1, unsigned long long &sp, unsigned long long &ep,
+                                                    unsigned g) {
   const unsigned long long q0 = sp - 1ull, q1 = ep;
-  const unsigned long long blk0 = q0 >> 8, blk1 = q1 >> 8;
-  const uint4 lo0 = ix.blocks[blk0 * 16ull + 2u * g];
-  const uint4 hi0 = ix.blocks[blk0 * 16ull + 2u * g + 1u];
-  uint4 lo1 = lo0, hi1 = hi0;
-  if (blk1 != blk0) {
-    lo1 = ix.blocks[blk1 * 16ull + 2u * g];
-    hi1 = ix.blocks[blk1 * 16ull + 2u * g + 1u];
-  }
   const unsigned pm = t.planeMask[letter < 24u ? letter : 23u];
   const unsigned ones = pm & 0xFFu, zeros = pm >> 8;
   const unsigned n0 = __popc(aminoOccSlice(lo0, hi0, ones, zeros) & sliceMask((unsigned)q0 & 255u, g));
@@ -240,6 +248,21 @@ __device__ __forceinline__ void aminoStep(const DevIndex &ix, const unsigned lon
   const unsigned long long c = sC[letter];
   sp = c + aminoBase(hi0, letter) + (packed & 0xFFFFu);
   ep = c + aminoBase(hi1, letter) + (packed >> 16) - 1ull;
+}
+
+__device__ __forceinline__ void aminoStep(const DevIndex &ix, const unsigned long long *sC, const AminoShared &t,
+                                          unsigned letter, unsigned long long &sp, unsigned long long &ep,
+                                          unsigned g) {
+  const unsigned long long blk0 = (sp - 1ull) >> 8, blk1 = ep >> 8;
+  const uint4 lo0 = ix.blocks[blk0 * 16ull + 2u * g];
+  const uint4 hi0 = ix.blocks[blk0 * 16ull + 2u * g + 1u];
+  uint4 otherLo = make_uint4(0u, 0u, 0u, 0u), otherHi = otherLo;
+  if (blk1 != blk0) {
+    otherLo = ix.blocks[blk1 * 16ull + 2u * g];
+    otherHi = ix.blocks[blk1 * 16ull + 2u * g + 1u];
+  }
+  const uint4 lo1 = blk1 != blk0 ? otherLo : lo0, hi1 = blk1 != blk0 ? otherHi : hi0;
+  aminoStepFromPieces(sC, t, letter, lo0, hi0, lo1, hi1, sp, ep, g);
 }
 
 

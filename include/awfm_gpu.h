@@ -45,8 +45,13 @@ typedef struct AwFmGpuIndex AwFmGpuIndex; /* opaque device image of one index on
 /* kernel variants (for measurement; AWFM_GPU_KERNEL_AUTO picks the default) */
 enum AwFmGpuKernel {
   AWFM_GPU_KERNEL_AUTO = 0,
-  AWFM_GPU_KERNEL_GROUP8 = 1, /* 8 lanes cooperate on one query: one 128-B line per load instruction */
-  AWFM_GPU_KERNEL_LANE = 2    /* one query per lane, each lane walks its own block */
+  AWFM_GPU_KERNEL_GROUP8 = 1, /* 8 lanes per query, one query per group at a time, lock-step per wave */
+  AWFM_GPU_KERNEL_PIPE1 = 2,  /* 8 lanes per query, refilled slots: 1, 2 or 4 queries in flight per group */
+  AWFM_GPU_KERNEL_PIPE2 = 3,
+  AWFM_GPU_KERNEL_PIPE4 = 4,
+  AWFM_GPU_KERNEL_LOCK1 = 5,  /* 8 lanes per query, k-mer window in registers, 1, 2 or 4 queries per group in lock step */
+  AWFM_GPU_KERNEL_LOCK2 = 6,
+  AWFM_GPU_KERNEL_LOCK4 = 7
 };
 
 /* ---- runtime ---- */
