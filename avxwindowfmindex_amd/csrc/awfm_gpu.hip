@@ -33,656 +33,13 @@
 #include <vector>
 
 #include "awfm_device.h"
+#include "awfm_search_kernel.h"
 
 static thread_local std::string tlsError;
 void awfmGpuSetError(const char *what) { tlsError = what; }
 void awfmGpuSetHipError(const char *what, hipError_t e) { tlsError = std::string(what) + ": " + hipGetErrorString(e); }
 
 namespace {
-
-/* ------------------------------------------------------------------ search kernel */
-
-/* Seed + extend for one query per 8-lane group
- * (ref src/AwFmParallelSearch.c:222-313, src/AwFmKmerTable.c:4-51, src/AwFmSearch.c:485-520).
- * The non-seeded search over the last min(len,k) characters followed by the
- * extension loop is one right-to-left walk that stops at the first invalid range. */
-template <bool AMINO, bool TALLY>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
-    searchGroup8Kernel(const DevIndex ix, const unsigned char *__restrict__ chars,
-                       const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
-                       const unsigned long long numQueries, ulonglong2 *__restrict__ ranges,
-                       unsigned *__restrict__ counts, unsigned long long *__restrict__ tally) {
-  /* TALLY build only: work counters for the roofline's algorithmic bytes */
-  unsigned long long tSeeded = 0, tSteps = 0, tBlocks = 0, tChars = 0;
-  __shared__ unsigned long long sC[24];
-  __shared__ unsigned sPow[32];
-  __shared__ AminoShared sAmino;
-  const unsigned card = AMINO ? 20u : 4u;
-  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
-  if (threadIdx.x < 32) {
-    /* weight of seed character i: card^(k-1-i) (ref src/AwFmKmerTable.c:26-32) */
-    unsigned w = 1;
-    for (unsigned e = threadIdx.x + 1; e < ix.seedK; e++) w *= card;
-    sPow[threadIdx.x] = w;
-    if (AMINO) {
-      sAmino.letterOfAscii[threadIdx.x] = kAminoTables.letterOfAscii[threadIdx.x];
-      sAmino.letterOfCode[threadIdx.x] = kAminoTables.letterOfCode[threadIdx.x];
-      if (threadIdx.x < 24) sAmino.planeMask[threadIdx.x] = kAminoTables.planeMask[threadIdx.x];
-    }
-  }
-  __syncthreads();
-
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned g = threadIdx.x & 7u;
-  const unsigned long long numGroups = (unsigned long long)gridDim.x * kGroupsPerBlock;
-  const unsigned K = ix.seedK;
-
-  for (unsigned long long q = ((unsigned long long)blockIdx.x * kThreads + threadIdx.x) >> 3; q < numQueries;
-       q += numGroups) {
-    unsigned long long off, len;
-    if (offsets) {
-      off = offsets[q];
-      len = offsets[q + 1] - off;
-    } else {
-      off = q * fixedLength;
-      len = fixedLength;
-    }
-    const unsigned char *kmer = chars + off;
-    unsigned long long sp = 1, ep = 0;
-    long long pos = -1;
-    if (len != 0) {
-      bool seeded = false;
-      if (K != 0 && len >= K) { /* ref src/AwFmKmerTable.c:4-19 */
-        unsigned index = 0;
-        bool ambiguous = false;
-        for (unsigned i = g; i < K; i += 8) {
-          const unsigned c = kmer[len - K + i];
-          ambiguous |= AMINO ? aminoIsAmbiguous(c) : nucIsAmbiguous(c);
-          index += (AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c)) * sPow[i];
-        }
-        index = groupSum8(index);
-        const unsigned long long ballot = __ballot(ambiguous);
-        seeded = ((ballot >> (lane & 56u)) & 0xFFull) == 0ull;
-        if (seeded && index < ix.seedLen) {
-          if (TALLY) tSeeded++;
-          const ulonglong2 r = ix.seed[index];
-          sp = r.x;
-          ep = r.y;
-          pos = (long long)(len - K) - 1;
-        } else {
-          seeded = false;
-        }
-      }
-      if (!seeded) { /* ref src/AwFmSearch.c:485-502 */
-        const unsigned c = kmer[len - 1];
-        const unsigned a = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
-        sp = sC[a];
-        ep = sC[a + 1] - 1ull;
-        pos = (long long)len - 2;
-      }
-    }
-    if (TALLY) tChars += len;
-    while (pos >= 0 && sp <= ep) {
-      const unsigned c = kmer[pos];
-      if (TALLY) {
-        tSteps++;
-        tBlocks += ((sp - 1ull) >> 8) == (ep >> 8) ? 1ull : 2ull;
-      }
-      if (AMINO)
-        aminoStep(ix, sC, sAmino, aminoLetterIndex(sAmino, c), sp, ep, g);
-      else
-        nucStep(ix, sC, nucLetterIndex(c), sp, ep, g);
-      pos--;
-    }
-    if (g == 0) {
-      if (ranges) ranges[q] = make_ulonglong2(sp, ep);
-      if (counts) counts[q] = sp <= ep ? (unsigned)(ep - sp + 1ull) : 0u;
-    }
-  }
-  if (TALLY && g == 0) { /* one lane per group carries the group's counters */
-    atomicAdd(&tally[0], tSeeded);
-    atomicAdd(&tally[1], tSteps);
-    atomicAdd(&tally[2], tBlocks);
-    atomicAdd(&tally[3], tChars);
-  }
-}
-
-/* ------------------------------------------------------------------ pipelined search kernel */
-
-/*
- * Same semantics as searchGroup8Kernel, restructured for memory-level parallelism: every 8-lane group
- * keeps U queries in flight ("slots").  The outer loop visits the slots round-robin; a visit consumes
- * the slot's pending load (seed-table entry or BWT pieces), and immediately issues the next one, so a
- * wave has up to 8*U dependent chains outstanding instead of 8, and a slot that finishes is refilled
- * at once (no lock-step tail: queries of different depth do not wait for each other).  The last 32
- * characters of each k-mer live in registers (4 bytes per lane, prefetched one query ahead), so a step
- * issues only its block loads.
- */
-/* length of a query from its {start, end} offsets; uses all four loaded dwords, so no register of the
- * pair is dead (and re-used, which would need a wait) while the load is still in flight */
-__device__ __forceinline__ unsigned pairLength(const ulonglong2 &o) {
-  const unsigned long long d = o.y - o.x;
-  return d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)d;
-}
-
-/* ------------------------------------------------------------------ lock-step search kernel */
-
-/*
- * The production search kernel.  Every 8-lane group runs U queries at a time in lock step:
- *   - the last 32 characters of each k-mer are held in registers (4 bytes per lane, two aligned dword
- *     loads + v_alignbyte), prefetched one batch ahead, so neither the seed lookup nor a step waits for
- *     query characters;
- *   - seed index and ambiguity test are computed from the window without branches, the U seed-table
- *     reads are in flight together, then every step issues the block loads of all U queries (both
- *     blocks of a query when sp-1 and ep fall into different blocks) before any of them is consumed.
- * Semantics: ref src/AwFmParallelSearch.c:222-313, src/AwFmKmerTable.c:4-51, src/AwFmSearch.c:485-520;
- * a query stops at the first invalid range and keeps it.
- */
-template <bool AMINO, int U, bool CSR, bool TALLY>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
-    searchLockstepKernel(const DevIndex ix, const unsigned char *__restrict__ chars,
-                         const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
-                         const unsigned long long numQueries, ulonglong2 *__restrict__ ranges,
-                         unsigned *__restrict__ counts, unsigned long long *__restrict__ tally) {
-  __shared__ unsigned long long sC[24];
-  __shared__ unsigned sPow[32];
-  __shared__ AminoShared sAmino;
-  const unsigned card = AMINO ? 20u : 4u;
-  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
-  if (threadIdx.x < 32) {
-    unsigned w = 1;
-    for (unsigned e = threadIdx.x + 1; e < ix.seedK; e++) w *= card;
-    sPow[threadIdx.x] = w;
-    if (AMINO) {
-      sAmino.letterOfAscii[threadIdx.x] = kAminoTables.letterOfAscii[threadIdx.x];
-      sAmino.letterOfCode[threadIdx.x] = kAminoTables.letterOfCode[threadIdx.x];
-      if (threadIdx.x < 24) sAmino.planeMask[threadIdx.x] = kAminoTables.planeMask[threadIdx.x];
-    }
-  }
-  __syncthreads();
-
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned g = threadIdx.x & 7u;
-  const unsigned long long numGroups = (unsigned long long)gridDim.x * kGroupsPerBlock;
-  const unsigned long long groupId = ((unsigned long long)blockIdx.x * kThreads + threadIdx.x) >> 3;
-  const unsigned K = ix.seedK;
-  const unsigned long long charsEnd = CSR ? offsets[numQueries] : numQueries * (unsigned long long)fixedLength;
-  const unsigned charsMisalign = (unsigned)((unsigned long long)chars & 3ull);
-  const unsigned char *charsAligned = chars - charsMisalign; /* stays a global-address-space pointer */
-  const unsigned long long charsLast = (charsEnd + charsMisalign - 1ull) & ~3ull;
-  const unsigned long long batchStride = numGroups * (unsigned long long)U;
-
-  unsigned long long tSeeded = 0, tSteps = 0, tBlocks = 0, tChars = 0;
-
-  /* prefetched batch: raw {start,end} offsets and raw window dwords of its U queries */
-  ulonglong2 nOff[U];
-  unsigned nLo[U], nHi[U];
-  ulonglong2 fOff[U]; /* CSR only: offsets of the batch after the prefetched one */
-
-  auto queryOffsets = [&](unsigned long long q) -> ulonglong2 {
-    if (CSR) {
-      const unsigned long long *o = offsets + q;
-      return make_ulonglong2(o[0], o[1]);
-    }
-    return make_ulonglong2(q * fixedLength, q * fixedLength + fixedLength);
-  };
-  auto requestWindow = [&](const ulonglong2 &o, unsigned &lo, unsigned &hi) {
-    const unsigned L = pairLength(o);
-    const unsigned wb = L > 32u ? L - 32u : 0u;
-    const unsigned long long addr = o.x + wb + 4u * g + charsMisalign;
-    unsigned long long loOff = addr & ~3ull, hiOff = loOff + 4ull;
-    loOff = loOff < charsLast ? loOff : charsLast;
-    hiOff = hiOff < charsLast ? hiOff : charsLast;
-    lo = *(const unsigned *)(charsAligned + loOff);
-    hi = *(const unsigned *)(charsAligned + hiOff);
-  };
-
-  /* prologue: first batch's windows (and, CSR, the second batch's offsets) */
-  unsigned long long q0 = groupId * (unsigned long long)U;
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    nOff[u] = make_ulonglong2(0ull, 0ull);
-    nLo[u] = nHi[u] = 0u;
-    fOff[u] = make_ulonglong2(0ull, 0ull);
-    if (q0 + u < numQueries) {
-      nOff[u] = queryOffsets(q0 + u);
-      requestWindow(nOff[u], nLo[u], nHi[u]);
-    }
-    if (CSR && q0 + batchStride + u < numQueries) fOff[u] = queryOffsets(q0 + batchStride + u);
-  }
-
-  for (; q0 < numQueries; q0 += batchStride) {
-    unsigned long long sp[U], ep[U], base[U];
-    unsigned len[U], win[U];
-    int pos[U];
-    bool valid[U];
-    /* ---- the prefetched batch becomes current ---- */
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      valid[u] = q0 + u < numQueries;
-      base[u] = nOff[u].x;
-      len[u] = valid[u] ? pairLength(nOff[u]) : 0u;
-      const unsigned wb = len[u] > 32u ? len[u] - 32u : 0u;
-      win[u] = __builtin_amdgcn_alignbyte(nHi[u], nLo[u], (unsigned)(nOff[u].x + wb + 4u * g + charsMisalign) & 3u);
-      sp[u] = 1;
-      ep[u] = 0;
-      pos[u] = -1;
-      if (TALLY) tChars += len[u];
-    }
-    /* ---- prefetch the next batch (windows; CSR: also the offsets of the one after) ---- */
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const unsigned long long qn = q0 + batchStride + u;
-      if (qn < numQueries) {
-        nOff[u] = CSR ? fOff[u] : queryOffsets(qn);
-        requestWindow(nOff[u], nLo[u], nHi[u]);
-      }
-      if (CSR && qn + batchStride < numQueries) fOff[u] = queryOffsets(qn + batchStride);
-    }
-    /* ---- seeds (ref src/AwFmKmerTable.c:4-51) or non-seeded start (ref src/AwFmSearch.c:485-502) ---- */
-    ulonglong2 seedEntry[U];
-    bool seeded[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const unsigned L = len[u];
-      seeded[u] = false;
-      seedEntry[u] = make_ulonglong2(1ull, 0ull);
-      unsigned index = 0;
-      bool ambiguous = false;
-      const bool tryTable = K != 0 && K <= 32u && L >= K;
-      if (tryTable) {
-        const unsigned wb = L > 32u ? L - 32u : 0u;
-#pragma unroll
-        for (unsigned b = 0; b < 4; b++) {
-          const unsigned i = wb + 4u * g + b;  /* index in the query */
-          const int j = (int)i - (int)(L - K); /* index in the seed */
-          const unsigned c = (win[u] >> (8u * b)) & 0xFFu;
-          const bool inSeed = i < L && j >= 0;
-          const bool amb = AMINO ? aminoIsAmbiguous(c) : nucIsAmbiguous(c);
-          const unsigned letter = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
-          ambiguous |= inSeed && amb;
-          index += inSeed ? letter * sPow[j & 31] : 0u;
-        }
-      }
-      index = groupSum8(index);
-      const unsigned long long ballot = __ballot(ambiguous);
-      seeded[u] = tryTable && ((ballot >> (lane & 56u)) & 0xFFull) == 0ull && index < ix.seedLen;
-      if (seeded[u]) seedEntry[u] = ix.seed[index];
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const unsigned L = len[u];
-      if (seeded[u]) {
-        if (TALLY) tSeeded++;
-        sp[u] = seedEntry[u].x;
-        ep[u] = seedEntry[u].y;
-        pos[u] = (int)(L - K) - 1;
-      } else if (L != 0) {
-        const unsigned wb = L > 32u ? L - 32u : 0u;
-        const unsigned rel = L - 1u - wb;
-        const unsigned w = (unsigned)__shfl((int)win[u], (int)(rel >> 2), 8);
-        const unsigned c = (w >> (8u * (rel & 3u))) & 0xFFu;
-        const unsigned a = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
-        sp[u] = sC[a];
-        ep[u] = sC[a + 1] - 1ull;
-        pos[u] = (int)L - 2;
-      }
-    }
-    /* ---- lock-step extension (ref src/AwFmParallelSearch.c:273-313) ---- */
-    for (;;) {
-      bool active[U], anyActive = false;
-      uint4 p0a[U], p1a[U], p0b[U], p1b[U];
-      bool same[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        active[u] = pos[u] >= 0 && sp[u] <= ep[u];
-        anyActive |= active[u];
-        const unsigned long long blk0 = (sp[u] - 1ull) >> 8, blk1 = ep[u] >> 8;
-        same[u] = blk0 == blk1;
-        p0a[u] = p1a[u] = p0b[u] = p1b[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (active[u]) {
-          if (AMINO) {
-            p0a[u] = ix.blocks[blk0 * 16ull + 2u * g];
-            p0b[u] = ix.blocks[blk0 * 16ull + 2u * g + 1u];
-          } else {
-            p0a[u] = ix.blocks[blk0 * 8ull + g];
-          }
-        }
-        if (active[u] && !same[u]) {
-          if (AMINO) {
-            p1a[u] = ix.blocks[blk1 * 16ull + 2u * g];
-            p1b[u] = ix.blocks[blk1 * 16ull + 2u * g + 1u];
-          } else {
-            p1a[u] = ix.blocks[blk1 * 8ull + g];
-          }
-        }
-      }
-      if (!anyActive) break;
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        if (!active[u]) continue;
-        /* character pos[u] of the query: from the register window, or (k-mers longer than 32) from memory */
-        const unsigned wb = len[u] > 32u ? len[u] - 32u : 0u;
-        unsigned c;
-        if (__builtin_expect((unsigned)pos[u] >= wb, 1)) {
-          const unsigned rel = (unsigned)pos[u] - wb;
-          const unsigned w = (unsigned)__shfl((int)win[u], (int)(rel >> 2), 8);
-          c = (w >> (8u * (rel & 3u))) & 0xFFu;
-        } else {
-          c = chars[base[u] + (unsigned)pos[u]];
-        }
-        if (TALLY) {
-          tSteps++;
-          tBlocks += same[u] ? 1ull : 2ull;
-        }
-        if (AMINO) {
-          const uint4 l1 = same[u] ? p0a[u] : p1a[u], h1 = same[u] ? p0b[u] : p1b[u];
-          aminoStepFromPieces(sC, sAmino, aminoLetterIndex(sAmino, c), p0a[u], p0b[u], l1, h1, sp[u], ep[u], g);
-        } else {
-          const uint4 l1 = same[u] ? p0a[u] : p1a[u];
-          nucStepFromPieces(ix, sC, nucLetterIndex(c), p0a[u], l1, sp[u], ep[u], g);
-        }
-        pos[u]--;
-      }
-    }
-    /* ---- results ---- */
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (g == 0 && valid[u]) {
-        if (ranges) ranges[q0 + u] = make_ulonglong2(sp[u], ep[u]);
-        if (counts) counts[q0 + u] = sp[u] <= ep[u] ? (unsigned)(ep[u] - sp[u] + 1ull) : 0u;
-      }
-    }
-  }
-  if (TALLY && g == 0) {
-    atomicAdd(&tally[0], tSeeded);
-    atomicAdd(&tally[1], tSteps);
-    atomicAdd(&tally[2], tBlocks);
-    atomicAdd(&tally[3], tChars);
-  }
-}
-
-template <bool AMINO, int U, bool CSR>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
-    searchPipeKernel(const DevIndex ix, const unsigned char *__restrict__ chars,
-                     const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
-                     const unsigned long long numQueries, ulonglong2 *__restrict__ ranges,
-                     unsigned *__restrict__ counts) {
-  __shared__ unsigned long long sC[24];
-  __shared__ unsigned sPow[32];
-  __shared__ AminoShared sAmino;
-  const unsigned card = AMINO ? 20u : 4u;
-  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
-  if (threadIdx.x < 32) {
-    unsigned w = 1;
-    for (unsigned e = threadIdx.x + 1; e < ix.seedK; e++) w *= card;
-    sPow[threadIdx.x] = w;
-    if (AMINO) {
-      sAmino.letterOfAscii[threadIdx.x] = kAminoTables.letterOfAscii[threadIdx.x];
-      sAmino.letterOfCode[threadIdx.x] = kAminoTables.letterOfCode[threadIdx.x];
-      if (threadIdx.x < 24) sAmino.planeMask[threadIdx.x] = kAminoTables.planeMask[threadIdx.x];
-    }
-  }
-  __syncthreads();
-
-  const unsigned lane = threadIdx.x & 63u;
-  const unsigned g = threadIdx.x & 7u;
-  const unsigned long long numGroups = (unsigned long long)gridDim.x * kGroupsPerBlock;
-  const unsigned long long groupId = ((unsigned long long)blockIdx.x * kThreads + threadIdx.x) >> 3;
-  const unsigned K = ix.seedK;
-  const unsigned long long qStride = numGroups * (unsigned long long)U;
-  const unsigned long long charsEnd = CSR ? offsets[numQueries] : numQueries * (unsigned long long)fixedLength;
-  /* window loads are aligned dwords; offsets are clamped to the last dword that still holds a query byte */
-  const unsigned charsMisalign = (unsigned)((unsigned long long)chars & 3ull);
-  const unsigned char *charsAligned = chars - charsMisalign; /* stays a global-address-space pointer */
-  const unsigned long long charsLast = (charsEnd + charsMisalign - 1ull) & ~3ull;
-
-  enum : int { kIdle = 0, kSeedPending = 1, kStepPending = 2, kDead = 3 };
-  /* current query of each slot */
-  unsigned long long sp[U], ep[U], qid[U], base[U];
-  unsigned len[U], win[U];
-  int pos[U], phase[U];
-  uint4 p0a[U], p1a[U], p0b[U], p1b[U]; /* block(sp-1): a (+b for amino); block(ep): likewise; p0a also takes the seed entry */
-  bool sameBlock[U];
-  /* prefetched next query of each slot; raw load results: nothing is computed from a load until it is consumed */
-  unsigned long long nQid[U];
-  ulonglong2 nOff[U]; /* {start, end} byte offsets of the prefetched query, kept exactly as loaded */
-  unsigned nLo[U], nHi[U];
-  unsigned tLo[U], tHi[U]; /* CSR only: landing registers of a window request, copied to nLo/nHi after the drain */
-  int nStage[U]; /* 0 no more queries; fixed length: 2 window requested (usable after the next drain);
-                    CSR: 1 offsets requested, 2 window requested into tLo/tHi, 3 window in nLo/nHi */
-
-  /* Every load below has exactly ONE site per slot (address and predicate are computed first), so a
-   * register that is the destination of an in-flight load is never copied at a control-flow merge --
-   * such a copy would force a wait in the middle of the issue phase. */
-
-  /* window addresses of the prefetched query (known offset/length) */
-  auto windowOffsets = [&](int u, unsigned long long &loOff, unsigned long long &hiOff) {
-    const unsigned nLen = pairLength(nOff[u]);
-    const unsigned wb = nLen > 32u ? nLen - 32u : 0u;
-    const unsigned long long addr = nOff[u].x + wb + 4u * g + charsMisalign;
-    loOff = addr & ~3ull;
-    hiOff = loOff + 4ull;
-    loOff = loOff < charsLast ? loOff : charsLast;
-    hiOff = hiOff < charsLast ? hiOff : charsLast;
-  };
-  auto windowShift = [&](int u) -> unsigned {
-    const unsigned nLen = pairLength(nOff[u]);
-    const unsigned wb = nLen > 32u ? nLen - 32u : 0u;
-    return (unsigned)(nOff[u].x + wb + 4u * g + charsMisalign) & 3u;
-  };
-  /* character i of the current query of slot u (i inside the register window, else straight from memory) */
-  auto charAt = [&](int u, unsigned i) -> unsigned {
-    const unsigned wb = len[u] > 32u ? len[u] - 32u : 0u;
-    unsigned c;
-    if (__builtin_expect(i >= wb, 1)) {
-      const unsigned rel = i - wb;
-      const unsigned w = (unsigned)__shfl((int)win[u], (int)(rel >> 2), 8);
-      c = (w >> (8u * (rel & 3u))) & 0xFFu;
-    } else {
-      c = chars[base[u] + i];
-    }
-    return c;
-  };
-
-  /* prologue: slot u starts with query groupId + u*numGroups "prefetched", then the loop's finish path
-   * makes it current */
-#pragma unroll
-  for (int u = 0; u < U; u++) {
-    const unsigned long long q = groupId + (unsigned long long)u * numGroups;
-    nQid[u] = q;
-    nStage[u] = 0;
-    nOff[u] = make_ulonglong2(0ull, 0ull);
-    nLo[u] = nHi[u] = 0;
-    if (q < numQueries) {
-      if (CSR)
-        nOff[u] = make_ulonglong2(offsets[q], offsets[q + 1]);
-      else
-        nOff[u] = make_ulonglong2(q * fixedLength, q * fixedLength + fixedLength);
-      unsigned long long loOff, hiOff;
-      windowOffsets(u, loOff, hiOff);
-      nLo[u] = *(const unsigned *)(charsAligned + loOff);
-      nHi[u] = *(const unsigned *)(charsAligned + hiOff);
-      nStage[u] = CSR ? 3 : 2;
-    }
-    tLo[u] = tHi[u] = 0;
-    /* an already-finished dummy query that writes nothing: the first visit starts the real one */
-    sp[u] = 1;
-    ep[u] = 0;
-    pos[u] = -1;
-    qid[u] = ~0ull;
-    base[u] = 0;
-    len[u] = 0;
-    win[u] = 0;
-    phase[u] = kIdle;
-    sameBlock[u] = true;
-  }
-
-  for (;;) {
-    /* one explicit drain per iteration: everything the previous issue phase requested has been in flight
-     * together; stating the wait here keeps hipcc from sinking a consumer (and a conservative vmcnt(0))
-     * in between the loads of the next issue phase */
-    __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */
-
-    /* ---- consume phase ---- */
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (phase[u] == kStepPending) {
-        const unsigned c = charAt(u, (unsigned)pos[u]);
-        if (AMINO) {
-          const uint4 l1 = sameBlock[u] ? p0a[u] : p1a[u], h1 = sameBlock[u] ? p0b[u] : p1b[u];
-          aminoStepFromPieces(sC, sAmino, aminoLetterIndex(sAmino, c), p0a[u], p0b[u], l1, h1, sp[u], ep[u], g);
-        } else {
-          const uint4 l1 = sameBlock[u] ? p0a[u] : p1a[u];
-          nucStepFromPieces(ix, sC, nucLetterIndex(c), p0a[u], l1, sp[u], ep[u], g);
-        }
-        pos[u]--;
-      } else if (phase[u] == kSeedPending) {
-        sp[u] = ((unsigned long long)p0a[u].y << 32) | p0a[u].x;
-        ep[u] = ((unsigned long long)p0a[u].w << 32) | p0a[u].z;
-      }
-    }
-
-    if (CSR) {
-      /* windows requested last iteration have landed: publish them; offsets requested last iteration have
-       * landed: request their windows (into the landing registers) */
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        if (nStage[u] == 2) {
-          nLo[u] = tLo[u];
-          nHi[u] = tHi[u];
-          nStage[u] = 3;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        if (nStage[u] == 1) {
-          unsigned long long loOff, hiOff;
-          windowOffsets(u, loOff, hiOff);
-          tLo[u] = *(const unsigned *)(charsAligned + loOff);
-          tHi[u] = *(const unsigned *)(charsAligned + hiOff);
-          nStage[u] = 2;
-        }
-      }
-    }
-
-    /* ---- issue phase ---- */
-    bool anyAlive = false;
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      if (phase[u] == kDead) continue;
-      anyAlive = true;
-      bool wantSeed = false, wantPrefetch = false, wantOffsets = false;
-      unsigned seedIndex = 0;
-      const bool wantStep = pos[u] >= 0 && sp[u] <= ep[u];
-      if (!wantStep) {
-        /* the query is finished: store its result, make the prefetched query current
-         * (seed lookup or non-seeded start, ref src/AwFmParallelSearch.c:222-271) */
-        if (g == 0 && qid[u] != ~0ull) {
-          if (ranges) ranges[qid[u]] = make_ulonglong2(sp[u], ep[u]);
-          if (counts) counts[qid[u]] = sp[u] <= ep[u] ? (unsigned)(ep[u] - sp[u] + 1ull) : 0u;
-        }
-        if (nStage[u] == 0) {
-          phase[u] = kDead;
-        } else if (CSR && nStage[u] != 3) {
-          /* the successor's window is still on its way (the finished query lasted a single iteration):
-           * idle this iteration as an already-stored dummy and retry after the next drain */
-          qid[u] = ~0ull;
-          phase[u] = kIdle;
-        } else {
-          qid[u] = nQid[u];
-          base[u] = nOff[u].x;
-          const unsigned L = pairLength(nOff[u]);
-          len[u] = L;
-          win[u] = __builtin_amdgcn_alignbyte(nHi[u], nLo[u], windowShift(u));
-          sp[u] = 1;
-          ep[u] = 0;
-          pos[u] = -1;
-          phase[u] = kIdle;
-          /* the query after it */
-          const unsigned long long q2 = qid[u] + qStride;
-          nQid[u] = q2;
-          nStage[u] = 0;
-          if (q2 < numQueries) {
-            if (CSR) {
-              wantOffsets = true;
-              nStage[u] = 1;
-            } else {
-              wantPrefetch = true;
-              nStage[u] = 2;
-            }
-          }
-          if (L != 0) {
-            bool seeded = false;
-            if (K != 0 && K <= 32u && L >= K) { /* ref src/AwFmKmerTable.c:4-19 */
-              const unsigned wb = L > 32u ? L - 32u : 0u;
-              unsigned index = 0;
-              bool ambiguous = false;
-#pragma unroll
-              for (unsigned b = 0; b < 4; b++) {
-                const unsigned i = wb + 4u * g + b;  /* index in the query */
-                const int j = (int)i - (int)(L - K); /* index in the seed */
-                const unsigned c = (win[u] >> (8u * b)) & 0xFFu;
-                const bool inSeed = i < L && j >= 0;
-                const bool amb = AMINO ? aminoIsAmbiguous(c) : nucIsAmbiguous(c);
-                const unsigned letter = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
-                ambiguous |= inSeed && amb;
-                index += inSeed ? letter * sPow[j & 31] : 0u;
-              }
-              index = groupSum8(index);
-              const unsigned long long ballot = __ballot(ambiguous);
-              seeded = ((ballot >> (lane & 56u)) & 0xFFull) == 0ull && index < ix.seedLen;
-              if (seeded) {
-                wantSeed = true;
-                seedIndex = index;
-                pos[u] = (int)(L - K) - 1;
-                phase[u] = kSeedPending;
-              }
-            }
-            if (!seeded) { /* ref src/AwFmSearch.c:485-502 */
-              const unsigned c = charAt(u, L - 1u);
-              const unsigned a = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
-              sp[u] = sC[a];
-              ep[u] = sC[a + 1] - 1ull;
-              pos[u] = (int)L - 2;
-            }
-          }
-        }
-      }
-      /* the loads of this slot, one site each */
-      const unsigned long long blk0 = (sp[u] - 1ull) >> 8, blk1 = ep[u] >> 8;
-      if (wantStep) {
-        sameBlock[u] = blk0 == blk1;
-        phase[u] = kStepPending;
-      }
-      const uint4 *addrA = AMINO ? ix.blocks + (blk0 * 16ull + 2u * g) : ix.blocks + (blk0 * 8ull + g);
-      if (wantSeed) addrA = (const uint4 *)(ix.seed + seedIndex);
-      if (wantStep || wantSeed) p0a[u] = *addrA;
-      if (AMINO) {
-        if (wantStep) p0b[u] = ix.blocks[blk0 * 16ull + 2u * g + 1u];
-        if (wantStep && !sameBlock[u]) {
-          p1a[u] = ix.blocks[blk1 * 16ull + 2u * g];
-          p1b[u] = ix.blocks[blk1 * 16ull + 2u * g + 1u];
-        }
-      } else {
-        if (wantStep && !sameBlock[u]) p1a[u] = ix.blocks[blk1 * 8ull + g];
-      }
-      if (CSR && wantOffsets) {
-        /* offsets[q], offsets[q+1] as one 16-byte pair; the pair may be only 8-byte aligned */
-        const unsigned long long *o = offsets + nQid[u];
-        nOff[u] = make_ulonglong2(o[0], o[1]);
-      }
-      if (!CSR && wantPrefetch) {
-        nOff[u] = make_ulonglong2(nQid[u] * fixedLength, nQid[u] * fixedLength + fixedLength);
-        unsigned long long loOff, hiOff;
-        windowOffsets(u, loOff, hiOff);
-        nLo[u] = *(const unsigned *)(charsAligned + loOff);
-        nHi[u] = *(const unsigned *)(charsAligned + hiOff);
-      }
-    }
-    if (!anyAlive) break;
-  }
-}
 
 /* ------------------------------------------------------------------ locate kernels */
 
@@ -877,7 +234,7 @@ std::vector<std::pair<const AwFmIndex *, AwFmGpuIndex *>> imageTable;
  * (blocksPerCU from the occupancy query for that kernel); a larger grid would run as a second,
  * under-filled round.  AWFM_GPU_BLOCKS_PER_CU overrides (measurement knob). */
 template <class Kernel>
-unsigned gridFor(uint64_t groups, const AwFmGpuIndex *g, Kernel kernel) {
+unsigned gridFor(uint64_t groups, const AwFmGpuIndex *g, Kernel kernel, unsigned groupsPerBlock = kGroupsPerBlock) {
   int perCU = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kThreads, 0) != hipSuccess || perCU < 1) perCU = 4;
   if (perCU > 8) perCU = 8;
@@ -885,7 +242,7 @@ unsigned gridFor(uint64_t groups, const AwFmGpuIndex *g, Kernel kernel) {
     const int v = atoi(env);
     if (v >= 1 && v <= 64) perCU = v;
   }
-  const uint64_t blocks = (groups + kGroupsPerBlock - 1) / kGroupsPerBlock;
+  const uint64_t blocks = (groups + groupsPerBlock - 1) / groupsPerBlock;
   const uint64_t cap = (uint64_t)g->numCUs * (uint64_t)perCU;
   return (unsigned)(blocks < cap ? (blocks ? blocks : 1) : cap);
 }
@@ -923,6 +280,59 @@ void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned long 
   }
   d.saWidth = index->suffixArray.valueBitWidth;
   d.seedK = index->config.kmerLengthInSeedTable;
+}
+}  // namespace
+
+namespace {
+/* lanes that cooperate on one query: image setting, else $AWFM_GPU_KERNEL (g8|g4|g2|g1), else the default */
+int lanesPerQuery(const AwFmGpuIndex *g) {
+  int lanes = 8;
+  switch (g->kernel) {
+    case AWFM_GPU_KERNEL_GROUP8: lanes = 8; break;
+    case AWFM_GPU_KERNEL_GROUP4: lanes = 4; break;
+    case AWFM_GPU_KERNEL_GROUP2: lanes = 2; break;
+    case AWFM_GPU_KERNEL_GROUP1: lanes = 1; break;
+    default:
+      lanes = 2; /* measured on MI355X, GRCh38-sized index, 100 M random 21-mers: g8 19.6 ms, g4 16.0, g2 15.4, g1 17.7 */
+      if (const char *env = getenv("AWFM_GPU_KERNEL")) { /* measurement knob */
+        if (!strcmp(env, "g8")) lanes = 8;
+        else if (!strcmp(env, "g4")) lanes = 4;
+        else if (!strcmp(env, "g2")) lanes = 2;
+        else if (!strcmp(env, "g1")) lanes = 1;
+      }
+  }
+  if (g->amino && lanes < 4) lanes = 4; /* amino pieces are 32 B: 4 lanes already hold 64 registers of block data */
+  return lanes;
+}
+
+template <bool AMINO, int G, bool CSR, bool TALLY>
+void launchSearchKernel(const AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
+                        uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts,
+                        unsigned long long *dTally) {
+  const unsigned grid = gridFor(nq, g, searchKernel<AMINO, G, CSR, TALLY>, kThreads / G);
+  hipLaunchKernelGGL((searchKernel<AMINO, G, CSR, TALLY>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars, off,
+                     fixedLength, nq, rng, dCounts, dTally);
+}
+
+template <bool TALLY>
+void launchSearch(const AwFmGpuIndex *g, int lanes, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
+                  uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts,
+                  unsigned long long *dTally) {
+#define AWFM_GO(AM, GG)                                                                                       \
+  do {                                                                                                        \
+    if (off) launchSearchKernel<AM, GG, true, TALLY>(g, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);  \
+    else launchSearchKernel<AM, GG, false, TALLY>(g, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);     \
+  } while (0)
+  if (g->amino) {
+    if (lanes == 8) AWFM_GO(true, 8);
+    else AWFM_GO(true, 4);
+  } else {
+    if (lanes == 8) AWFM_GO(false, 8);
+    else if (lanes == 4) AWFM_GO(false, 4);
+    else if (lanes == 2) AWFM_GO(false, 2);
+    else AWFM_GO(false, 1);
+  }
+#undef AWFM_GO
 }
 }  // namespace
 
@@ -1140,59 +550,9 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
   }
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
-  int kernel = (int)g->kernel;
-  if (kernel == AWFM_GPU_KERNEL_AUTO) {
-    kernel = AWFM_GPU_KERNEL_LOCK1;
-    if (const char *env = getenv("AWFM_GPU_KERNEL")) { /* measurement knob */
-      static const struct { const char *name; int id; } names[] = {
-          {"group8", AWFM_GPU_KERNEL_GROUP8}, {"pipe1", AWFM_GPU_KERNEL_PIPE1}, {"pipe2", AWFM_GPU_KERNEL_PIPE2},
-          {"pipe4", AWFM_GPU_KERNEL_PIPE4},   {"lock1", AWFM_GPU_KERNEL_LOCK1}, {"lock2", AWFM_GPU_KERNEL_LOCK2},
-          {"lock4", AWFM_GPU_KERNEL_LOCK4}};
-      for (const auto &e : names)
-        if (!strcmp(env, e.name)) kernel = e.id;
-    }
-  }
-  if (g->dev.seedK > 32u) kernel = AWFM_GPU_KERNEL_GROUP8; /* the register window holds 32 characters */
-  const unsigned long long *off = (const unsigned long long *)dOffsets;
-  const unsigned long long nq = numQueries;
-  ulonglong2 *rng = (ulonglong2 *)dRanges;
-  unsigned long long *noTally = nullptr;
-#define AWFM_LAUNCH_PIPE2(AM, UU, CS)                                                                      \
-  hipLaunchKernelGGL((searchPipeKernel<AM, UU, CS>),                                                        \
-                     dim3(gridFor((nq + UU - 1) / UU, g, searchPipeKernel<AM, UU, CS>)), dim3(kThreads), 0, s, \
-                     g->dev, dChars, off, fixedLength, nq, rng, dCounts)
-#define AWFM_LAUNCH_LOCK2(AM, UU, CS)                                                                          \
-  hipLaunchKernelGGL((searchLockstepKernel<AM, UU, CS, false>),                                                 \
-                     dim3(gridFor((nq + UU - 1) / UU, g, searchLockstepKernel<AM, UU, CS, false>)), dim3(kThreads), 0, \
-                     s, g->dev, dChars, off, fixedLength, nq, rng, dCounts, noTally)
-#define AWFM_LAUNCH(KIND, UU)                               \
-  do {                                                      \
-    if (g->amino) {                                         \
-      if (off) AWFM_LAUNCH_##KIND##2(true, UU, true);       \
-      else AWFM_LAUNCH_##KIND##2(true, UU, false);          \
-    } else {                                                \
-      if (off) AWFM_LAUNCH_##KIND##2(false, UU, true);      \
-      else AWFM_LAUNCH_##KIND##2(false, UU, false);         \
-    }                                                       \
-  } while (0)
-  switch (kernel) {
-    case AWFM_GPU_KERNEL_PIPE1: AWFM_LAUNCH(PIPE, 1); break;
-    case AWFM_GPU_KERNEL_PIPE2: AWFM_LAUNCH(PIPE, 2); break;
-    case AWFM_GPU_KERNEL_PIPE4: AWFM_LAUNCH(PIPE, 4); break;
-    case AWFM_GPU_KERNEL_LOCK1: AWFM_LAUNCH(LOCK, 1); break;
-    case AWFM_GPU_KERNEL_LOCK2: AWFM_LAUNCH(LOCK, 2); break;
-    case AWFM_GPU_KERNEL_LOCK4: AWFM_LAUNCH(LOCK, 4); break;
-    default:
-      if (g->amino)
-        hipLaunchKernelGGL((searchGroup8Kernel<true, false>), dim3(gridFor(nq, g, searchGroup8Kernel<true, false>)),
-                           dim3(kThreads), 0, s, g->dev, dChars, off, fixedLength, nq, rng, dCounts, noTally);
-      else
-        hipLaunchKernelGGL((searchGroup8Kernel<false, false>), dim3(gridFor(nq, g, searchGroup8Kernel<false, false>)),
-                           dim3(kThreads), 0, s, g->dev, dChars, off, fixedLength, nq, rng, dCounts, noTally);
-  }
-#undef AWFM_LAUNCH
-#undef AWFM_LAUNCH_PIPE2
-#undef AWFM_LAUNCH_LOCK2
+  const int lanes = lanesPerQuery(g);
+  launchSearch<false>(g, lanes, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries,
+                      (ulonglong2 *)dRanges, dCounts, nullptr);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
 }
@@ -1210,14 +570,8 @@ enum AwFmReturnCode awfmGpuSearchTally(AwFmGpuIndex *g, const uint8_t *dChars, c
   AWFM_HIP_TRY(hipMalloc((void **)&dTally, 32), AwFmAllocationFailure);
   hipError_t e = hipMemset(dTally, 0, 32);
   if (e == hipSuccess && numQueries) {
-    if (g->amino)
-      hipLaunchKernelGGL((searchGroup8Kernel<true, true>), dim3(gridFor(numQueries, g, searchGroup8Kernel<true, true>)), dim3(kThreads), 0, 0, g->dev, dChars,
-                         (const unsigned long long *)dOffsets, fixedLength, (unsigned long long)numQueries,
-                         (ulonglong2 *)nullptr, (unsigned *)nullptr, dTally);
-    else
-      hipLaunchKernelGGL((searchGroup8Kernel<false, true>), dim3(gridFor(numQueries, g, searchGroup8Kernel<false, true>)), dim3(kThreads), 0, 0, g->dev, dChars,
-                         (const unsigned long long *)dOffsets, fixedLength, (unsigned long long)numQueries,
-                         (ulonglong2 *)nullptr, (unsigned *)nullptr, dTally);
+    launchSearch<true>(g, lanesPerQuery(g), (hipStream_t)0, dChars, (const unsigned long long *)dOffsets, fixedLength,
+                       numQueries, nullptr, nullptr, dTally);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(tallyOut, dTally, 32, hipMemcpyDeviceToHost);

@@ -1,0 +1,338 @@
+/*
+ * awfm_search_kernel.h -- the batched backward-search kernel (seed lookup + extension).
+ *
+ * One query is owned by a group of G lanes (G = 8, 4, 2 or 1).  A BWT block of the device image is
+ * 8 pieces (awfm_device.h); lane j of the group loads pieces j*S .. j*S+S-1 (S = 8/G, 16*S contiguous
+ * bytes, so the group always reads whole 128-B lines), ranks its own 32*S positions with XOR/OR/AND +
+ * popcount, and the partial counts are summed over the group with DPP adds.  Smaller G means more
+ * queries per wave (64/G) -- more dependent chains in flight and fewer redundant per-query
+ * instructions per lane -- at the price of S load instructions per block instead of one.
+ *
+ * The last 32 characters of a k-mer live in registers (4*S bytes per lane, aligned dword loads +
+ * v_alignbyte), prefetched one query ahead; seed index and ambiguity test are computed from the
+ * window without branches; both blocks of a step are requested before either is consumed.
+ *
+ * Semantics (bit-exact with the reference): ref src/AwFmParallelSearch.c:222-313,
+ * src/AwFmKmerTable.c:4-51, src/AwFmSearch.c:42-159, :485-520 -- the non-seeded search over the last
+ * min(len,k) characters followed by the extension loop is one right-to-left walk that stops at the
+ * first invalid range and keeps it.
+ */
+#ifndef AWFM_SEARCH_KERNEL_H
+#define AWFM_SEARCH_KERNEL_H
+
+#include "awfm_device.h"
+
+namespace {
+
+/* sum over the G lanes of a group (G a power of two <= 8); every lane gets the total */
+template <int G>
+__device__ __forceinline__ unsigned groupSum(unsigned v) {
+  if (G >= 2) v += dppMove<0xB1>(v);  /* quad_perm [1,0,3,2] */
+  if (G >= 4) v += dppMove<0x4E>(v);  /* quad_perm [2,3,0,1] */
+  if (G >= 8) v += dppMove<0x141>(v); /* row_half_mirror */
+  return v;
+}
+
+template <int G>
+__device__ __forceinline__ unsigned long long groupSum64(unsigned long long v) {
+  if (G >= 2) {
+    const unsigned lo = dppMove<0xB1>((unsigned)v), hi = dppMove<0xB1>((unsigned)(v >> 32));
+    v += ((unsigned long long)hi << 32) | lo;
+  }
+  if (G >= 4) {
+    const unsigned lo = dppMove<0x4E>((unsigned)v), hi = dppMove<0x4E>((unsigned)(v >> 32));
+    v += ((unsigned long long)hi << 32) | lo;
+  }
+  if (G >= 8) {
+    const unsigned lo = dppMove<0x141>((unsigned)v), hi = dppMove<0x141>((unsigned)(v >> 32));
+    v += ((unsigned long long)hi << 32) | lo;
+  }
+  return v;
+}
+
+template <int G>
+__device__ __forceinline__ unsigned groupShfl(unsigned v, unsigned srcLaneInGroup) {
+  if (G == 1) return v;
+  return (unsigned)__shfl((int)v, (int)srcLaneInGroup, G);
+}
+
+/* length of a query from its {start, end} offsets; uses all four loaded dwords, so no register of the
+ * pair is dead (and re-used, which would need a wait) while the load is still in flight */
+__device__ __forceinline__ unsigned pairLength(const ulonglong2 &o) {
+  const unsigned long long d = o.y - o.x;
+  return d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)d;
+}
+
+/* 32-bit base count `slot` (0..2) of an amino piece's second half, picked with shifts (a select chain
+ * on vector components makes hipcc spill the vector to LDS for dynamic indexing) */
+__device__ __forceinline__ unsigned aminoCountWord(const uint4 &hi, unsigned slot) {
+  const unsigned long long c01 = ((unsigned long long)hi.z << 32) | hi.y;
+  const unsigned long long c2x = hi.w;
+  return (unsigned)((slot == 2u ? c2x : c01) >> (slot == 1u ? 32u : 0u));
+}
+
+template <bool AMINO, int G, bool CSR, bool TALLY>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
+    searchKernel(const DevIndex ix, const unsigned char *__restrict__ chars,
+                 const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
+                 const unsigned long long numQueries, ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts,
+                 unsigned long long *__restrict__ tally) {
+  constexpr int S = 8 / G;          /* pieces (and window dwords) per lane */
+  constexpr int V = AMINO ? 2 : 1;  /* uint4 per piece */
+  constexpr int kGroups = kThreads / G;
+  __shared__ unsigned long long sC[24];
+  __shared__ unsigned sPow[32];
+  __shared__ AminoShared sAmino;
+  const unsigned card = AMINO ? 20u : 4u;
+  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  if (threadIdx.x < 32) {
+    /* weight of seed character j: card^(k-1-j) (ref src/AwFmKmerTable.c:26-32) */
+    unsigned w = 1;
+    for (unsigned e = threadIdx.x + 1; e < ix.seedK; e++) w *= card;
+    sPow[threadIdx.x] = w;
+    if (AMINO) {
+      sAmino.letterOfAscii[threadIdx.x] = kAminoTables.letterOfAscii[threadIdx.x];
+      sAmino.letterOfCode[threadIdx.x] = kAminoTables.letterOfCode[threadIdx.x];
+      if (threadIdx.x < 24) sAmino.planeMask[threadIdx.x] = kAminoTables.planeMask[threadIdx.x];
+    }
+  }
+  __syncthreads();
+
+  const unsigned lane = threadIdx.x & 63u;
+  const unsigned gl = threadIdx.x % G; /* lane within the group */
+  const unsigned firstPiece = gl * S;
+  const unsigned long long numGroups = (unsigned long long)gridDim.x * kGroups;
+  const unsigned long long groupId = ((unsigned long long)blockIdx.x * kThreads + threadIdx.x) / G;
+  const unsigned K = ix.seedK;
+  const unsigned long long charsEnd = CSR ? offsets[numQueries] : numQueries * (unsigned long long)fixedLength;
+  /* window loads are aligned dwords; offsets are clamped to the last dword that still holds a query byte */
+  const unsigned charsMisalign = (unsigned)((unsigned long long)chars & 3ull);
+  const unsigned char *charsAligned = chars - charsMisalign; /* stays a global-address-space pointer */
+  const unsigned long long charsLast = (charsEnd + charsMisalign - 1ull) & ~3ull;
+
+  unsigned long long tSeeded = 0, tSteps = 0, tBlocks = 0, tChars = 0;
+
+  /* prefetched query: raw {start,end} offsets and raw window dwords (S+1 aligned dwords cover 4*S bytes) */
+  ulonglong2 nOff = make_ulonglong2(0ull, 0ull);
+  unsigned nRaw[S + 1];
+  ulonglong2 fOff = make_ulonglong2(0ull, 0ull); /* CSR only: offsets of the query after the prefetched one */
+
+  auto queryOffsets = [&](unsigned long long q) -> ulonglong2 {
+    if (CSR) {
+      const unsigned long long *o = offsets + q;
+      return make_ulonglong2(o[0], o[1]);
+    }
+    return make_ulonglong2(q * fixedLength, q * fixedLength + fixedLength);
+  };
+  auto windowStart = [&](const ulonglong2 &o) -> unsigned long long { /* byte address (+misalign) of this lane's part */
+    const unsigned L = pairLength(o);
+    const unsigned wb = L > 32u ? L - 32u : 0u;
+    return o.x + wb + 4u * firstPiece + charsMisalign;
+  };
+  auto requestWindow = [&](const ulonglong2 &o) {
+    const unsigned long long first = windowStart(o) & ~3ull;
+#pragma unroll
+    for (int w = 0; w <= S; w++) {
+      unsigned long long at = first + 4ull * w;
+      at = at < charsLast ? at : charsLast;
+      nRaw[w] = *(const unsigned *)(charsAligned + at);
+    }
+  };
+
+  unsigned long long q = groupId;
+#pragma unroll
+  for (int w = 0; w <= S; w++) nRaw[w] = 0u;
+  if (q < numQueries) {
+    nOff = queryOffsets(q);
+    requestWindow(nOff);
+  }
+  if (CSR && q + numGroups < numQueries) fOff = queryOffsets(q + numGroups);
+
+  for (; q < numQueries; q += numGroups) {
+    /* ---- the prefetched query becomes current ---- */
+    const unsigned long long base = nOff.x;
+    const unsigned len = pairLength(nOff);
+    const unsigned wb = len > 32u ? len - 32u : 0u;
+    unsigned win[S];
+    {
+      const unsigned shift = (unsigned)windowStart(nOff) & 3u;
+#pragma unroll
+      for (int w = 0; w < S; w++) win[w] = __builtin_amdgcn_alignbyte(nRaw[w + 1], nRaw[w], shift);
+    }
+    if (TALLY) tChars += len;
+    /* ---- prefetch the next query's window (CSR: and the offsets of the one after) ---- */
+    {
+      const unsigned long long qn = q + numGroups;
+      if (qn < numQueries) {
+        nOff = CSR ? fOff : queryOffsets(qn);
+        requestWindow(nOff);
+      }
+      if (CSR && qn + numGroups < numQueries) fOff = queryOffsets(qn + numGroups);
+    }
+    /* character i (>= wb) of the query out of the register window */
+    auto windowChar = [&](unsigned i) -> unsigned {
+      const unsigned rel = i - wb;         /* 0..31 */
+      const unsigned word = rel >> 2;      /* 0..7: lane word/S, register word%S */
+      unsigned mine = win[0];
+#pragma unroll
+      for (int w = 1; w < S; w++) mine = (word % S) == (unsigned)w ? win[w] : mine;
+      const unsigned v = groupShfl<G>(mine, word / S);
+      return (v >> (8u * (rel & 3u))) & 0xFFu;
+    };
+
+    unsigned long long sp = 1, ep = 0;
+    int pos = -1;
+    if (len != 0) {
+      /* ---- seed (ref src/AwFmKmerTable.c:4-51) ---- */
+      bool seeded = false;
+      const bool tryTable = K != 0 && K <= 32u && len >= K;
+      unsigned index = 0;
+      bool ambiguous = false;
+      if (tryTable) {
+#pragma unroll
+        for (int w = 0; w < S; w++) {
+#pragma unroll
+          for (unsigned b = 0; b < 4; b++) {
+            const unsigned i = wb + 4u * (firstPiece + w) + b; /* index in the query */
+            const int j = (int)i - (int)(len - K);             /* index in the seed */
+            const unsigned c = (win[w] >> (8u * b)) & 0xFFu;
+            const bool inSeed = i < len && j >= 0;
+            const bool amb = AMINO ? aminoIsAmbiguous(c) : nucIsAmbiguous(c);
+            const unsigned letter = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
+            ambiguous |= inSeed && amb;
+            index += inSeed ? letter * sPow[j & 31] : 0u;
+          }
+        }
+      }
+      index = groupSum<G>(index);
+      const unsigned long long ballot = __ballot(ambiguous);
+      const unsigned groupBits = (unsigned)(ballot >> (lane & ~(unsigned)(G - 1))) & ((1u << G) - 1u);
+      seeded = tryTable && groupBits == 0u && index < ix.seedLen;
+      if (seeded) {
+        if (TALLY) tSeeded++;
+        const ulonglong2 r = ix.seed[index];
+        sp = r.x;
+        ep = r.y;
+        pos = (int)(len - K) - 1;
+      } else { /* ref src/AwFmSearch.c:485-502 */
+        const unsigned c = windowChar(len - 1u);
+        const unsigned a = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
+        sp = sC[a];
+        ep = sC[a + 1] - 1ull;
+        pos = (int)len - 2;
+      }
+    }
+
+    /* ---- extension (ref src/AwFmParallelSearch.c:273-313; one step = ref src/AwFmSearch.c:42-159) ---- */
+    while (pos >= 0 && sp <= ep) {
+      const unsigned long long q0 = sp - 1ull, q1 = ep;
+      const unsigned long long blk0 = q0 >> 8, blk1 = q1 >> 8;
+      const bool same = blk0 == blk1;
+      uint4 p0[S][V], p1[S][V];
+#pragma unroll
+      for (int s = 0; s < S; s++)
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+          p0[s][v] = ix.blocks[(blk0 * 8ull + firstPiece + s) * V + v];
+          p1[s][v] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      if (!same) {
+#pragma unroll
+        for (int s = 0; s < S; s++)
+#pragma unroll
+          for (int v = 0; v < V; v++) p1[s][v] = ix.blocks[(blk1 * 8ull + firstPiece + s) * V + v];
+      }
+      unsigned c;
+      if (__builtin_expect((unsigned)pos >= wb, 1))
+        c = windowChar((unsigned)pos);
+      else
+        c = chars[base + (unsigned)pos]; /* k-mers longer than the 32-character window */
+      if (TALLY) {
+        tSteps++;
+        tBlocks += same ? 1ull : 2ull;
+      }
+      const unsigned letter = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
+      const unsigned local0 = (unsigned)q0 & 255u, local1 = (unsigned)q1 & 255u;
+      unsigned n0 = 0, n1 = 0;
+      unsigned long long base0, base1;
+      if (AMINO) {
+        const unsigned pm = sAmino.planeMask[letter < 24u ? letter : 23u];
+        const unsigned ones = pm & 0xFFu, zeros = pm >> 8;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          const uint4 l1 = same ? p0[s][0] : p1[s][0], h1 = same ? p0[s][V - 1] : p1[s][V - 1];
+          n0 += __popc(aminoOccSlice(p0[s][0], p0[s][V - 1], ones, zeros) & sliceMask(local0, firstPiece + s));
+          n1 += __popc(aminoOccSlice(l1, h1, ones, zeros) & sliceMask(local1, firstPiece + s));
+        }
+        /* count of letter a: slot a%3 of piece a/3 (32-bit) */
+        const unsigned piece = letter / 3u, slot = letter % 3u;
+        unsigned mine0 = 0, mine1 = 0;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          const uint4 h0 = p0[s][V - 1], h1 = same ? p0[s][V - 1] : p1[s][V - 1];
+          const unsigned w0 = aminoCountWord(h0, slot), w1 = aminoCountWord(h1, slot);
+          mine0 = (piece % S) == (unsigned)s ? w0 : mine0;
+          mine1 = (piece % S) == (unsigned)s ? w1 : mine1;
+        }
+        base0 = groupShfl<G>(mine0, piece / S);
+        base1 = groupShfl<G>(mine1, piece / S);
+      } else {
+        const PlaneSel3 sel = nucPlaneSel(letter);
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          const uint4 o1 = same ? p0[s][0] : p1[s][0];
+          n0 += __popc(nucOccSlice(p0[s][0], sel) & sliceMask(local0, firstPiece + s));
+          n1 += __popc(nucOccSlice(o1, sel) & sliceMask(local1, firstPiece + s));
+        }
+        if (letter < 4u) {
+          /* count words 2a (low) and 2a+1 (high) of the block, i.e. piece 2a / 2a+1 */
+          const unsigned kLo = 2u * letter, kHi = kLo + 1u;
+          unsigned lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+#pragma unroll
+          for (int s = 0; s < S; s++) {
+            const unsigned w0 = p0[s][0].w, w1 = same ? p0[s][0].w : p1[s][0].w;
+            lo0 = (kLo % S) == (unsigned)s ? w0 : lo0;
+            hi0 = (kHi % S) == (unsigned)s ? w0 : hi0;
+            lo1 = (kLo % S) == (unsigned)s ? w1 : lo1;
+            hi1 = (kHi % S) == (unsigned)s ? w1 : hi1;
+          }
+          base0 = ((unsigned long long)groupShfl<G>(hi0, kHi / S) << 32) | groupShfl<G>(lo0, kLo / S);
+          base1 = ((unsigned long long)groupShfl<G>(hi1, kHi / S) << 32) | groupShfl<G>(lo1, kLo / S);
+        } else {
+          /* X: positions before the block that are not A,C,G,T or the sentinel */
+          unsigned long long part0 = 0, part1 = 0;
+#pragma unroll
+          for (int s = 0; s < S; s++) {
+            const unsigned w0 = p0[s][0].w, w1 = same ? p0[s][0].w : p1[s][0].w;
+            const bool high = ((firstPiece + s) & 1u) != 0u;
+            part0 += high ? ((unsigned long long)w0 << 32) : (unsigned long long)w0;
+            part1 += high ? ((unsigned long long)w1 << 32) : (unsigned long long)w1;
+          }
+          const unsigned long long before0 = blk0 * 256ull, before1 = blk1 * 256ull;
+          base0 = before0 - groupSum64<G>(part0) - (ix.sentinelPos < before0 ? 1ull : 0ull);
+          base1 = before1 - groupSum64<G>(part1) - (ix.sentinelPos < before1 ? 1ull : 0ull);
+        }
+      }
+      const unsigned packed = groupSum<G>(n0 | (n1 << 16));
+      const unsigned long long cLetter = sC[letter];
+      sp = cLetter + base0 + (packed & 0xFFFFu);
+      ep = cLetter + base1 + (packed >> 16) - 1ull;
+      pos--;
+    }
+
+    if (gl == 0) {
+      if (ranges) ranges[q] = make_ulonglong2(sp, ep);
+      if (counts) counts[q] = sp <= ep ? (unsigned)(ep - sp + 1ull) : 0u;
+    }
+  }
+  if (TALLY && gl == 0) { /* one lane per group carries the group's counters */
+    atomicAdd(&tally[0], tSeeded);
+    atomicAdd(&tally[1], tSteps);
+    atomicAdd(&tally[2], tBlocks);
+    atomicAdd(&tally[3], tChars);
+  }
+}
+
+}  // namespace
+
+#endif

@@ -42,16 +42,13 @@ extern "C" {
 
 typedef struct AwFmGpuIndex AwFmGpuIndex; /* opaque device image of one index on one GPU */
 
-/* kernel variants (for measurement; AWFM_GPU_KERNEL_AUTO picks the default) */
+/* search kernel variants: how many lanes cooperate on one query (AUTO picks the default) */
 enum AwFmGpuKernel {
   AWFM_GPU_KERNEL_AUTO = 0,
-  AWFM_GPU_KERNEL_GROUP8 = 1, /* 8 lanes per query, one query per group at a time, lock-step per wave */
-  AWFM_GPU_KERNEL_PIPE1 = 2,  /* 8 lanes per query, refilled slots: 1, 2 or 4 queries in flight per group */
-  AWFM_GPU_KERNEL_PIPE2 = 3,
-  AWFM_GPU_KERNEL_PIPE4 = 4,
-  AWFM_GPU_KERNEL_LOCK1 = 5,  /* 8 lanes per query, k-mer window in registers, 1, 2 or 4 queries per group in lock step */
-  AWFM_GPU_KERNEL_LOCK2 = 6,
-  AWFM_GPU_KERNEL_LOCK4 = 7
+  AWFM_GPU_KERNEL_GROUP8 = 1, /* 8 lanes x 16 B: one load instruction per 128-B block, 8 queries per wave */
+  AWFM_GPU_KERNEL_GROUP4 = 2, /* 4 lanes x 32 B, 16 queries per wave */
+  AWFM_GPU_KERNEL_GROUP2 = 3, /* 2 lanes x 64 B, 32 queries per wave (nucleotide only) */
+  AWFM_GPU_KERNEL_GROUP1 = 4  /* 1 lane x 128 B, 64 queries per wave (nucleotide only) */
 };
 
 /* ---- runtime ---- */
