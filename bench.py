@@ -56,15 +56,10 @@ def main():
     import torch
     import torch.distributed as dist
     from avxwindowfmindex_amd import _lib, api
+    from avxwindowfmindex_amd import dist as shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
+    rank, world = shard.init("nccl")
+    if world == 1:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
     L = _lib.lib()
@@ -84,7 +79,7 @@ def main():
     build_s = time.time() - t0
 
     # ---- this rank's query shard, resident in HBM ----
-    first = rank * Q
+    first, _ = shard.shard_bounds(Q * world, world, rank)  # weak scaling: the global batch is Q*world k-mers
     d_chars = torch.empty(Q * K, dtype=torch.uint8, device=dev)
     if args.workload == "random":
         assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr(), first, Q, K, query_seed, int(amino), None) == 1
@@ -123,9 +118,7 @@ def main():
             state["hits"] = total
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard.barrier(world, torch.cuda.synchronize)
 
     for _ in range(args.warmup):
         step(False)
@@ -135,10 +128,7 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, world, dev)
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * Q / (elapsed / args.steps) / 1e6  # Mkmers/s over all ranks
     search_ms = float(np.mean([a.elapsed_time(b) for a, b in search_events]))

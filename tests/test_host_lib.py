@@ -1,0 +1,200 @@
+"""CPU-side tests of libawfmindex_amd.so: exported symbols, struct ABI, host builder, .awfmi file,
+single-query API, search-list ownership -- no GPU compute.
+
+Reference behaviour mirrored: test/createTests/AwFmCreationTest.c, test/fileTests/AwFmFileTests.c:32-381,
+test/searchTest/searchTest.c:124-200, test/staticLibTest, src/AwFmParallelSearch.c:36-93.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from avxwindowfmindex_amd import synth
+
+
+def test_library_exports_every_declared_symbol(awfm):
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    missing = [s for s in _lib.API_SYMBOLS + _lib.GPU_SYMBOLS if not hasattr(L, s)]
+    assert not missing
+    # every function declared in the two public headers is in the lists the loader checks
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    declared = set()
+    for h in ("include/AwFmIndex.h", "include/awfm_gpu.h"):
+        src = open(os.path.join(root, h)).read()
+        declared |= set(re.findall(r"\b(awFm[A-Z]\w+|awfmGpu\w+)\s*\(", src))
+    assert declared <= set(_lib.API_SYMBOLS + _lib.GPU_SYMBOLS), declared - set(_lib.API_SYMBOLS + _lib.GPU_SYMBOLS)
+
+
+def test_struct_abi_matches_reference_layout(awfm):
+    """LP64 sizes/offsets of the reference structs (probed from the compiled reference)"""
+    from avxwindowfmindex_amd import _lib
+    assert C.sizeof(_lib.AwFmKmerSearchData) == 32
+    assert _lib.AwFmKmerSearchData.positionList.offset == 16 and _lib.AwFmKmerSearchData.count.offset == 24
+    assert _lib.AwFmKmerSearchData.capacity.offset == 28
+    assert C.sizeof(_lib.AwFmKmerSearchList) == 24 and C.sizeof(_lib.AwFmSearchRange) == 16
+    assert C.sizeof(_lib.AwFmIndexConfiguration) == 12
+    assert _lib.AwFmIndexConfiguration.alphabetType.offset == 4
+    assert _lib.AwFmIndexConfiguration.keepSuffixArrayInMemory.offset == 8
+    assert C.sizeof(_lib.AwFmIndex) == 112
+
+
+@pytest.mark.parametrize("alphabet_name", ["dna", "amino"])
+def test_host_builder_is_byte_identical_to_the_oracle(oracle, awfm, alphabet_name):
+    amino = alphabet_name == "amino"
+    alpha, oalpha = (awfm.AwFmAlphabetAmino, oracle.AMINO) if amino else (awfm.AwFmAlphabetDna, oracle.DNA)
+    letters = synth.AMINO_ALPHABET if amino else synth.DNA_ALPHABET
+    for n in (0, 1, 29, 255, 256, 257, 5000, 70000):
+        for ratio, k in ((1, 1), (3, 2), (8, 2 if amino else 6)):
+            raw = synth.text(n + 1, n, letters).copy()
+            if n > 100:
+                raw[5:9] = ord("x")
+                raw[50] = ord("N")
+            ix = awfm.create_index(raw, alpha, ratio, k)
+            oi = oracle.Index.from_text(raw.tobytes(), oalpha, ratio, k)
+            assert np.array_equal(ix.blocks(), oi.blocks())
+            assert np.array_equal(ix.prefix_sums(), oi.prefix_sums())
+            assert np.array_equal(ix.seed_table(), oi.seed_table())
+            assert np.array_equal(ix.packed_sa(), oi.packed_sa())
+            ix.dealloc()
+
+
+def test_host_builder_on_repetitive_texts(oracle, awfm):
+    for raw in (b"a" * 3000, b"acgt" * 2000 + b"a", b"acgtacgtaa" * 1500 + b"t" * 100, b"$acg$t"):
+        ix = awfm.create_index(np.frombuffer(raw, np.uint8), awfm.AwFmAlphabetDna, 4, 3)
+        oi = oracle.Index.from_text(raw, oracle.DNA, 4, 3)
+        assert np.array_equal(ix.blocks(), oi.blocks()) and np.array_equal(ix.packed_sa(), oi.packed_sa())
+        assert np.array_equal(ix.seed_table(), oi.seed_table())
+        ix.dealloc()
+
+
+def test_awfmi_file_round_trip_and_layout(awfm, tmp_path):
+    """ref src/AwFmFile.c:20-193: magic, header fields, section sizes; read-back equals what was written"""
+    raw = synth.text(3, 29)
+    for store in (False, True):
+        path = str(tmp_path / f"toy_{int(store)}.awfmi")
+        ix = awfm.create_index(raw, awfm.AwFmAlphabetDna, 8, 3, store_sequence=store, file_src=path)
+        blob = open(path, "rb").read()
+        # 10 magic + 12 header + 8 bwtLength + 1 block*160 + 6*8 prefix sums + 64*16 seed table (+29 sequence)
+        # + packed SA: ceil(4 samples * 5 bits / 8) + 8 pad (1275 bytes for a 29-bp text)
+        assert len(blob) == 10 + 12 + 8 + 160 + 48 + 1024 + (29 if store else 0) + 3 + 8
+        assert blob[:10] == b"AwFmIndex\n"
+        assert int.from_bytes(blob[10:14], "little") == 8 and blob[18] == 8 and blob[19] == 3 and blob[20] == 2
+        assert blob[21] == int(store) and int.from_bytes(blob[22:30], "little") == 30
+        if store:
+            assert blob[30 + 160 + 48 + 1024:][:29] == raw.tobytes()
+        for keep in (True, False):
+            back = awfm.read_index_from_file(path, keep_sa_in_memory=keep)
+            assert back.bwt_length == 30
+            assert np.array_equal(back.blocks(), ix.blocks()) and np.array_equal(back.prefix_sums(), ix.prefix_sums())
+            assert np.array_equal(back.seed_table(), ix.seed_table())
+            if keep:
+                assert np.array_equal(back.packed_sa(), ix.packed_sa())
+            else:
+                assert back.packed_sa() is None
+            if store:
+                from avxwindowfmindex_amd import _lib
+                buf = C.create_string_buffer(11)
+                assert _lib.lib().awFmReadSequenceFromFile(back.ptr, 5, 10, buf) == awfm.AwFmFileReadOkay
+                assert buf.value == raw.tobytes()[5:15]
+            back.dealloc()
+        ix.dealloc()
+    from avxwindowfmindex_amd import _lib
+    out = C.POINTER(_lib.AwFmIndex)()
+    assert _lib.lib().awFmReadIndexFromFile(C.byref(out), str(tmp_path / "missing.awfmi").encode(), True) == -10
+    bad = tmp_path / "bad.awfmi"
+    bad.write_bytes(b"NotAnIndex" + bytes(100))
+    assert _lib.lib().awFmReadIndexFromFile(C.byref(out), str(bad).encode(), True) == -9
+
+
+@pytest.mark.parametrize("alphabet_name", ["dna", "amino"])
+def test_single_query_api_matches_oracle(oracle, awfm, alphabet_name, tmp_path):
+    """awFmFindSearchRangeForString, step, backtrace, hit positions (in memory and from the file)"""
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    amino = alphabet_name == "amino"
+    alpha, oalpha = (awfm.AwFmAlphabetAmino, oracle.AMINO) if amino else (awfm.AwFmAlphabetDna, oracle.DNA)
+    letters = synth.AMINO_ALPHABET if amino else synth.DNA_ALPHABET
+    raw = synth.text(17, 6000, letters).copy()
+    raw[40:43] = ord("x")
+    oi = oracle.Index.from_text(raw.tobytes(), oalpha, 7, 2)
+    for keep in (True, False):
+        ix = awfm.create_index(raw, alpha, 7, 2, keep_sa_in_memory=keep, file_src=str(tmp_path / f"s{int(keep)}.awfmi"))
+        chars, offsets = synth.mixed_queries(18, 400, raw, letters, 1, 10)
+        for j in range(400):
+            kmer = bytes(chars[int(offsets[j]):int(offsets[j + 1])])
+            assert ix.find_search_range_for_string(kmer) == oi.range_for_string(kmer)
+        rng = np.random.default_rng(4)
+        for _ in range(200):
+            p = int(rng.integers(0, 6001))
+            pos = C.c_uint64(p)
+            f = L.awFmAminoBacktraceReturnPreviousLetterIndex if amino else L.awFmNucleotideBacktraceReturnPreviousLetterIndex
+            letter = f(ix.ptr, C.byref(pos))
+            if oi.letter_at(p) == (21 if amino else 5):
+                assert letter == 0 and pos.value == p
+            else:
+                assert letter == oi.letter_at(p) and pos.value == oi.lf(p)
+            rc = C.c_int(0)
+            assert L.awFmFindDatabaseHitPositionSingle(ix.ptr, p, C.byref(rc)) == oi.locate_one(p)
+            assert rc.value == awfm.AwFmFileReadOkay
+        r = _lib.AwFmSearchRange(*oi.range_for_string(raw[100:103].tobytes()))
+        rc = C.c_int(0)
+        ptr = L.awFmFindDatabaseHitPositions(ix.ptr, C.byref(r), C.byref(rc))
+        n = L.awFmSearchRangeLength(C.byref(r))
+        got = [ptr[i] for i in range(n)]
+        L.free(C.cast(ptr, C.c_void_p))
+        assert got == [oi.locate_one(p) for p in range(r.startPtr, r.endPtr + 1)] and rc.value == awfm.AwFmFileReadOkay
+        empty = _lib.AwFmSearchRange(5, 4)
+        assert not L.awFmFindDatabaseHitPositions(ix.ptr, C.byref(empty), C.byref(rc)) and rc.value == -1
+        step = L.awFmAminoIterativeStepBackwardSearch if amino else L.awFmNucleotideIterativeStepBackwardSearch
+        rr = L.awFmCreateInitialQueryRangeFromChar(ix.ptr, bytes([letters[2]]))
+        step(ix.ptr, C.byref(rr), 1)
+        assert (rr.startPtr, rr.endPtr) == oi.step(int(oi.prefix_sums()[2]), int(oi.prefix_sums()[3]) - 1, 1)
+        ix.dealloc()
+
+
+def test_search_list_ownership_and_return_codes(awfm):
+    """ref src/AwFmParallelSearch.c:36-93: 4-slot malloc'ed position lists, strings never owned"""
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    lst = awfm.KmerSearchList(100)
+    c = lst.ptr.contents
+    assert c.capacity == 100 and c.count == 0
+    assert all(c.kmerSearchData[i].capacity == 4 and c.kmerSearchData[i].count == 0 and
+               bool(c.kmerSearchData[i].positionList) and not c.kmerSearchData[i].kmerString for i in range(100))
+    lst.fill([b"acgt", b"gg"])
+    assert lst.ptr.contents.count == 2 and lst.ptr.contents.kmerSearchData[1].kmerLength == 2
+    lst.dealloc()
+    assert L.awFmReturnCodeIsFailure(-11) and not L.awFmReturnCodeIsFailure(3)
+    assert L.awFmReturnCodeIsSuccess(1) and not L.awFmReturnCodeIsSuccess(-1)
+    r = _lib.AwFmSearchRange(7, 9)
+    assert L.awFmSearchRangeLength(C.byref(r)) == 3
+    r = _lib.AwFmSearchRange(10, 9)
+    assert L.awFmSearchRangeLength(C.byref(r)) == 0
+    out = C.POINTER(_lib.AwFmIndex)()
+    cfg = _lib.AwFmIndexConfiguration(8, 4, 2, True, False)
+    assert L.awFmCreateIndex(C.byref(out), None, None, 0, b"x") == -4
+    assert L.awFmCreateIndexFromFasta(C.byref(out), C.byref(cfg), b"a.fa", b"a.awfmi") == -2
+
+
+def test_batch_search_fails_loudly_without_a_gpu(awfm):
+    """the hot path has no CPU fallback: without a device Locate returns a failure code and Count
+    leaves the list untouched"""
+    from avxwindowfmindex_amd import _lib
+    if _lib.lib().awfmGpuDeviceCount() > 0:
+        pytest.skip("a GPU is visible here")
+    raw = synth.text(5, 2000)
+    ix = awfm.create_index(raw, awfm.AwFmAlphabetDna, 8, 4)
+    lst = awfm.KmerSearchList(8)
+    lst.fill([raw[10:20].tobytes()])
+    lst.ptr.contents.kmerSearchData[0].count = 77
+    awfm.parallel_search_count(ix, lst, 2)
+    assert lst.counts()[0] == 77
+    assert awfm.parallel_search_locate(ix, lst, 2) == -1
+    assert b"no HIP device" in _lib.lib().awfmGpuLastError()
+    with pytest.raises(RuntimeError):
+        awfm.GpuIndex(ix)
+    lst.dealloc()
+    ix.dealloc()

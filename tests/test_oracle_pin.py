@@ -1,0 +1,208 @@
+"""Pins the CPU oracle (oracle/awfm_oracle.c) before anything is compared with it.
+
+The reference cannot be compiled here (its FastaVector / libdivsufsort submodules are empty), so the
+oracle is pinned against (a) the known answers the reference's own tests hold and (b) the brute-force
+properties those tests check, restated with seeded inputs:
+  test/occurrenceTests/occurrenceTests.c:48-113   masked popcount known answers + random vectors
+  test/letterTest/AwFmLetterTest.c:16-324         letter tables
+  test/suffixArrayCompressionTests/saTest.c:28-117 sampled-SA codec round trip and bit width
+  test/bwtTest/bwtTest.c:95-213                   every BWT position holds the letter before SA[i]
+  test/createTests/AwFmCreationTest.c:151-231     prefix sums, seed-table range length == brute count
+  test/kmerSeedTableTests/kmerSeedTableTests.c:203-228 every seed entry == SA interval
+  test/searchTest/searchTest.c:124-200            SA[sp..ep] == set of matching text positions
+  test/backtraceTest/backtraceTest.c:78-175       LF lands on the SA slot of text position - 1
+  test/parallelSearch/parallelSearchTest.c:45-456 batch count / locate vs strncmp scan
+  test/inMemorySaTest/inMemorySaTest.c:29-266     locate with ratio 1, huge ratio, sentinel wrap
+An SA interval is a pure function of text and pattern, so the brute-force suffix array pins {sp,ep}
+and the hit order bit for bit; a naive rank over the naive BWT pins the first-invalid range.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from avxwindowfmindex_amd import synth
+
+
+def naive_sa(text: bytes):
+    return sorted(range(len(text)), key=lambda i: text[i:])
+
+
+def sanitize(raw: bytes, O, alphabet):
+    L = O.lib()
+    f = L.orc_amino_sanitize if alphabet == O.AMINO else L.orc_nuc_sanitize
+    return bytes(f(c) for c in raw) + b"$"
+
+
+def letter_index(O, alphabet, c):
+    L = O.lib()
+    return L.orc_amino_ascii_to_index(c) if alphabet == O.AMINO else L.orc_nuc_ascii_to_index(c)
+
+
+def naive_search(O, alphabet, text, sa, prefix_sums, kmer):
+    """reference semantics on naive structures: right-to-left, stop at the first invalid range"""
+    bwt = [letter_index(O, alphabet, text[p - 1]) if p else (21 if alphabet == O.AMINO else 5) for p in sa]
+    a = letter_index(O, alphabet, kmer[-1])
+    sp, ep = int(prefix_sums[a]), int(prefix_sums[a + 1]) - 1
+    for c in reversed(kmer[:-1]):
+        if sp > ep:
+            break
+        a = letter_index(O, alphabet, c)
+        occ = lambda q: sum(1 for x in bwt[: q + 1] if x == a)  # noqa: E731
+        sp, ep = int(prefix_sums[a]) + occ(sp - 1), int(prefix_sums[a]) + occ(ep) - 1
+    return sp, ep
+
+
+def test_masked_popcount_known_answers(oracle):
+    L = oracle.lib()
+    def pop(byte, p=255):
+        v = (C.c_uint8 * 32)(*([byte] * 32))
+        return L.orc_masked_popcount(v, p)
+    # ref test/occurrenceTests/occurrenceTests.c:48-102
+    assert pop(0x00) == 0 and pop(0xFF) == 256 and pop(0x7F) == 224 and pop(0xF7) == 224
+    assert pop(0x77) == 192 and pop(0x0F) == 128 and pop(0xF0) == 128
+    rng = np.random.default_rng(1)
+    for _ in range(2000):  # :104-113, plus every prefix length
+        bits = rng.integers(0, 2, 256, dtype=np.uint8)
+        vec = np.packbits(bits, bitorder="little")
+        v = (C.c_uint8 * 32)(*vec.tolist())
+        p = int(rng.integers(0, 256))
+        assert L.orc_masked_popcount(v, 255) == int(bits.sum())
+        assert L.orc_masked_popcount(v, p) == int(bits[: p + 1].sum())
+
+
+def test_letter_tables(oracle):
+    L = oracle.lib()
+    # ref src/AwFmLetter.c:4-22 / test/letterTest: case-insensitive, u == t, everything else ambiguous
+    for ch, idx in ((b"a", 0), (b"c", 1), (b"g", 2), (b"t", 3), (b"u", 3), (b"A", 0), (b"T", 3), (b"$", 5), (b"n", 4), (b"x", 4)):
+        assert L.orc_nuc_ascii_to_index(ch[0]) == idx
+    amino = b"acdefghiklmnpqrstvwy"
+    for i, ch in enumerate(amino):
+        assert L.orc_amino_ascii_to_index(ch) == i and L.orc_amino_ascii_to_index(ch & 0xDF) == i
+    for ch in b"bjouxz":
+        assert L.orc_amino_ascii_to_index(ch) == 20
+    assert L.orc_amino_ascii_to_index(ord("$")) == 21
+    # code <-> index round trips on valid codes (ref src/AwFmLetter.c:44-53, :81-96)
+    for i in range(6):
+        assert L.orc_nuc_code_to_index(L.orc_nuc_index_to_code(i)) == i
+    for i in range(22):
+        assert L.orc_amino_code_to_index(L.orc_amino_index_to_code(i)) == i
+    assert len({L.orc_amino_index_to_code(i) for i in range(22)}) == 22
+    assert L.orc_nuc_sanitize(ord("N")) == ord("x") and L.orc_nuc_sanitize(ord("G")) == ord("g")
+    assert L.orc_amino_sanitize(ord("B")) == ord("z") and L.orc_amino_sanitize(0) == ord("z")
+    assert L.orc_amino_sanitize(ord("K")) == ord("K")  # case is preserved (ref src/AwFmLetter.c:69-79)
+
+
+def test_sa_codec_round_trip(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(2)
+    for length in list(range(4, 70)) + [255, 256, 257, 1023] + rng.integers(1024, 1 << 19, 20).tolist():
+        width = L.orc_sa_width(length)
+        assert width == max(1, int(length - 1).bit_length())  # ref test/.../saTest.c:44-52
+        for ratio in (1, 3, 8):
+            full = rng.permutation(length).astype(np.uint64)
+            out = np.zeros(L.orc_sa_packed_bytes(length, ratio), np.uint8)
+            L.orc_sa_pack(full.ctypes.data_as(C.POINTER(C.c_uint64)), length, ratio, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+            n = L.orc_sa_num_samples(length, ratio)
+            assert n == (length + ratio - 1) // ratio
+            got = [L.orc_sa_get(out.ctypes.data_as(C.POINTER(C.c_uint8)), width, i) for i in range(n)]
+            assert got == full[::ratio].tolist()
+
+
+@pytest.mark.parametrize("alphabet_name,n,seed_k,ratio", [("dna", 700, 3, 1), ("dna", 3000, 4, 8), ("dna", 1200, 5, 200),
+                                                         ("amino", 900, 1, 1), ("amino", 4000, 2, 8)])
+def test_index_and_search_against_brute_force(oracle, alphabet_name, n, seed_k, ratio):
+    O = oracle
+    alphabet = O.AMINO if alphabet_name == "amino" else O.DNA
+    letters = synth.AMINO_ALPHABET if alphabet == O.AMINO else synth.DNA_ALPHABET
+    raw = synth.text(100 + n, n, letters).copy()
+    raw[5:9] = ord("x")  # ambiguity run (stays x for DNA, becomes z for amino)
+    raw[n // 2] = ord("N") if alphabet == O.DNA else ord("b")
+    ix = O.Index.from_text(raw.tobytes(), alphabet, ratio, seed_k)
+    text = sanitize(raw.tobytes(), O, alphabet)
+    sa = naive_sa(text)
+    assert ix.full_sa().tolist() == sa
+    # BWT letters (bwtTest), prefix sums (createTests), LF (backtraceTest)
+    sentinel = 21 if alphabet == O.AMINO else 5
+    counts = np.zeros(22, np.int64)
+    for i, p in enumerate(sa):
+        expect = letter_index(O, alphabet, text[p - 1]) if p else sentinel
+        assert ix.letter_at(i) == expect
+        counts[expect] += 1
+    card = 20 if alphabet == O.AMINO else 4
+    ps = ix.prefix_sums()
+    assert ps[0] == 1 and all(ps[i] == 1 + counts[:i].sum() for i in range(1, card + 2))
+    inv = {p: i for i, p in enumerate(sa)}
+    for i in range(0, len(sa), 7):
+        p = sa[i]
+        assert ix.lf(i) == (inv[p - 1] if p else 0)
+    # every seed-table entry of a present k-mer is its SA interval (kmerSeedTableTests)
+    table = ix.seed_table()
+    for e in range(0, len(table), max(1, len(table) // 200)):
+        digits, x = [], e
+        for _ in range(seed_k):
+            digits.append(x % card)
+            x //= card
+        kmer = bytes(letters[d] for d in reversed(digits))
+        hits = [i for i, p in enumerate(sa) if text[p:p + seed_k] == kmer]
+        if hits:
+            assert (int(table[e][0]), int(table[e][1])) == (hits[0], hits[-1])
+        else:
+            assert table[e][0] == table[e][1] + 1  # blind stepping leaves an empty range
+    # searches: SA interval for present k-mers, first-invalid range for absent ones, hits in BWT order
+    chars, offsets = synth.mixed_queries(7 + n, 300, raw, letters, 1, 14)
+    sp, ep, cnt, _ = ix.batch_search(chars, offsets)
+    hit_off, pos, _ = ix.batch_locate(sp, ep)
+    for j in range(300):
+        kmer = bytes(chars[int(offsets[j]):int(offsets[j + 1])])
+        san = sanitize(kmer, O, alphabet)[:-1]
+        hits = [i for i, p in enumerate(sa) if text[p:p + len(san)] == san]
+        unseeded = ix.range_for_string(kmer)
+        if hits:
+            assert (int(sp[j]), int(ep[j])) == (hits[0], hits[-1]) == unseeded
+            assert cnt[j] == len(hits)
+            assert pos[int(hit_off[j]):int(hit_off[j + 1])].tolist() == [sa[i] for i in hits]
+        else:
+            assert cnt[j] == 0 and sp[j] > ep[j]
+            # a query shorter than the seed length, or with an ambiguous seed, walks exactly like the
+            # naive right-to-left search; a seeded one starts from the (blindly stepped) table entry
+            if len(kmer) < seed_k:
+                assert (int(sp[j]), int(ep[j])) == naive_search(O, alphabet, text, sa, ps, san)
+                assert unseeded == (int(sp[j]), int(ep[j]))
+
+
+def test_locate_with_extreme_ratios_and_sentinel_wrap(oracle):
+    """ref test/inMemorySaTest/inMemorySaTest.c: ratio 1, ratio = n-1 (two samples), 8-mers from the text"""
+    raw = synth.text(9, 600)
+    text = raw.tobytes() + b"$"
+    sa = naive_sa(text)
+    for ratio in (1, 16, 255):
+        ix = oracle.Index.from_text(raw.tobytes(), oracle.DNA, ratio, 4)
+        q = synth.planted_queries(10, 100, 8, raw)
+        sp, ep, cnt, _ = ix.search_list([bytes(r) for r in q] + [raw[:8].tobytes()])
+        hit_off, pos, tally = ix.batch_locate(sp, ep)
+        for j in range(len(sp)):
+            assert pos[int(hit_off[j]):int(hit_off[j + 1])].tolist() == sa[int(sp[j]):int(ep[j]) + 1]
+        assert cnt.min() >= 1
+        if ratio == 255:
+            assert tally["lfSteps"] > 10 * tally["hits"]
+
+
+def test_word_rank_equals_bytewise_definition(oracle):
+    """the oracle's 64-bit-word rank against masked_popcount(occurrence vector) on a real block"""
+    L = oracle.lib()
+    for alphabet, letters, nletters in ((oracle.DNA, synth.DNA_ALPHABET, 5), (oracle.AMINO, synth.AMINO_ALPHABET, 21)):
+        raw = synth.text(77, 2000, letters).copy()
+        raw[100:110] = ord("x")
+        ix = oracle.Index.from_text(raw.tobytes(), alphabet, 8, 2)
+        blocks = ix.blocks()
+        planes = 5 if alphabet == oracle.AMINO else 3
+        bb = 352 if alphabet == oracle.AMINO else 160
+        rng = np.random.default_rng(3)
+        for _ in range(400):
+            q = int(rng.integers(0, 2001))
+            a = int(rng.integers(0, nletters))
+            vec = (C.c_uint8 * 32)()
+            L.orc_occ_vector(ix.ptr, q // 256, a, vec)
+            base = int(np.frombuffer(blocks[(q // 256) * bb + 32 * planes + 8 * a:][:8].tobytes(), np.uint64)[0])
+            assert ix.occ(a, q) == base + L.orc_masked_popcount(vec, q % 256)
