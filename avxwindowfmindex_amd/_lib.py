@@ -29,6 +29,7 @@ GPU_SYMBOLS = [
     "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuSearch",
     "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
     "awfmGpuCreateIndex", "awfmGpuSearchTally", "awfmGpuSynthText", "awfmGpuSynthRandomQueries", "awfmGpuSynthPlantedQueries",
+    "awfmGpuSynthMixedLengths", "awfmGpuSynthMixedQueries",
 ]
 
 
@@ -133,6 +134,8 @@ def lib():
         "awfmGpuSynthText": (C.c_int, [vp, u64, u64, u64, C.c_int, vp]),
         "awfmGpuSynthRandomQueries": (C.c_int, [vp, u64, u64, C.c_uint32, u64, C.c_int, vp]),
         "awfmGpuSynthPlantedQueries": (C.c_int, [vp, u64, u64, C.c_uint32, u64, vp, u64, vp]),
+        "awfmGpuSynthMixedLengths": (C.c_int, [vp, u64, u64, C.c_uint32, C.c_uint32, u64, vp]),
+        "awfmGpuSynthMixedQueries": (C.c_int, [vp, vp, u64, u64, u64, vp, u64, C.c_int, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

@@ -34,6 +34,7 @@
 
 #include "awfm_device.h"
 #include "awfm_search_kernel.h"
+#include "awfm_locate_kernel.h"
 
 static thread_local std::string tlsError;
 void awfmGpuSetError(const char *what) { tlsError = what; }
@@ -135,90 +136,6 @@ __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const un
     for (unsigned long long h = lane; h < c; h += 64ull) positions[s + h] = p + h;
   }
 }
-
-/* sampled SA value i from the little-endian bit stream (ref src/AwFmSuffixArray.c:22-39, :114-142) */
-__device__ __forceinline__ unsigned long long sampledSaValue(const DevIndex &ix, unsigned long long i) {
-  const unsigned long long bit = i * ix.saWidth; /* bwtLength*width < 2^64 for any index that fits memory */
-  const unsigned long long word = bit >> 6;
-  const unsigned shift = (unsigned)bit & 63u;
-  const unsigned long long lo = ix.sa[word];
-  unsigned long long v = lo >> shift;
-  if (shift + ix.saWidth > 64u) v |= ix.sa[word + 1ull] << (64u - shift);
-  return ix.saWidth >= 64u ? v : v & ((1ull << ix.saWidth) - 1ull);
-}
-
-/* LF walk to a sampled position + SA read, one hit per 8-lane group, in place
- * (ref src/AwFmParallelSearch.c:338-361, src/AwFmSearch.c:369-427,
- *  src/AwFmOccurrence.c:170-217, src/AwFmSuffixArray.c:179-191) */
-template <bool AMINO>
-__global__ void __launch_bounds__(kThreads)
-    locateGroup8Kernel(const DevIndex ix, unsigned long long totalHits, unsigned long long *__restrict__ positions) {
-  __shared__ unsigned long long sC[24];
-  __shared__ AminoShared sAmino;
-  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
-  if (AMINO && threadIdx.x < 32) {
-    sAmino.letterOfAscii[threadIdx.x] = kAminoTables.letterOfAscii[threadIdx.x];
-    sAmino.letterOfCode[threadIdx.x] = kAminoTables.letterOfCode[threadIdx.x];
-    if (threadIdx.x < 24) sAmino.planeMask[threadIdx.x] = kAminoTables.planeMask[threadIdx.x];
-  }
-  __syncthreads();
-  const unsigned g = threadIdx.x & 7u;
-  const unsigned long long numGroups = (unsigned long long)gridDim.x * kGroupsPerBlock;
-  const bool pow2 = ix.saShift != 0xFFFFFFFFu;
-  const unsigned long long ratio = ix.saRatio;
-
-  for (unsigned long long t = ((unsigned long long)blockIdx.x * kThreads + threadIdx.x) >> 3; t < totalHits;
-       t += numGroups) {
-    unsigned long long p = positions[t];
-    unsigned long long offset = 0;
-    for (;;) {
-      const bool sampled = pow2 ? (p & (ratio - 1ull)) == 0ull : (p % ratio) == 0ull; /* ref src/AwFmIndexStruct.c:88-91 */
-      if (sampled || offset > ix.bwtLength) break; /* the bound only trips on a corrupt index */
-      const unsigned long long blk = p >> 8;
-      const unsigned local = (unsigned)p & 255u;
-      const unsigned bit = local & 31u, owner = local >> 5;
-      unsigned letter;
-      unsigned long long next;
-      if (AMINO) {
-        const uint4 lo = ix.blocks[blk * 16ull + 2u * g];
-        const uint4 hi = ix.blocks[blk * 16ull + 2u * g + 1u];
-        const unsigned myCode = ((lo.x >> bit) & 1u) | (((lo.y >> bit) & 1u) << 1) | (((lo.z >> bit) & 1u) << 2) |
-                                (((lo.w >> bit) & 1u) << 3) | (((hi.x >> bit) & 1u) << 4);
-        const unsigned code = (unsigned)__shfl((int)myCode, (int)owner, 8);
-        letter = sAmino.letterOfCode[code];
-        if (letter == 21u) {
-          next = 0;
-        } else {
-          const unsigned pm = sAmino.planeMask[letter];
-          const unsigned n = groupSum8(__popc(aminoOccSlice(lo, hi, pm & 0xFFu, pm >> 8) & sliceMask(local, g)));
-          next = sC[letter] + aminoBase(hi, letter) + n - 1ull;
-        }
-      } else {
-        const uint4 pc = ix.blocks[blk * 8ull + g];
-        const unsigned myCode = ((pc.x >> bit) & 1u) | (((pc.y >> bit) & 1u) << 1) | (((pc.z >> bit) & 1u) << 2);
-        const unsigned code = (unsigned)__shfl((int)myCode, (int)owner, 8);
-        letter = (0x00152435u >> (4u * code)) & 7u; /* code -> index {5,3,4,2,5,1,0,0}, ref src/AwFmLetter.c:49-53 */
-        if (letter == 5u) {
-          next = 0;
-        } else {
-          const PlaneSel3 sel = nucPlaneSel(letter);
-          const unsigned n = groupSum8(__popc(nucOccSlice(pc, sel) & sliceMask(local, g)));
-          next = sC[letter] + nucBase(pc, letter, blk, ix.sentinelPos, g) + n - 1ull;
-        }
-      }
-      p = next;
-      offset++;
-    }
-    if (g == 0) {
-      const unsigned long long sample = pow2 ? p >> ix.saShift : p / ratio;
-      unsigned long long v = sampledSaValue(ix, sample) + offset;
-      if (v >= ix.bwtLength) v -= ix.bwtLength;
-      if (v >= ix.bwtLength) v %= ix.bwtLength;
-      positions[t] = v;
-    }
-  }
-}
-
 
 }  // namespace
 
@@ -662,12 +579,31 @@ enum AwFmReturnCode awfmGpuLocate(AwFmGpuIndex *g, const struct AwFmSearchRange 
                      (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets,
                      (unsigned long long)numQueries, (unsigned long long *)dPositions);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-  if (g->amino)
-    hipLaunchKernelGGL(locateGroup8Kernel<true>, dim3(gridFor(totalHits, g, locateGroup8Kernel<true>)), dim3(kThreads), 0, s, g->dev,
-                       (unsigned long long)totalHits, (unsigned long long *)dPositions);
-  else
-    hipLaunchKernelGGL(locateGroup8Kernel<false>, dim3(gridFor(totalHits, g, locateGroup8Kernel<false>)), dim3(kThreads), 0, s, g->dev,
-                       (unsigned long long)totalHits, (unsigned long long *)dPositions);
+  {
+    int lanes = lanesPerQuery(g);
+    if (const char *env = getenv("AWFM_GPU_LOCATE_KERNEL")) { /* measurement knob: g8 | g4 | g2 | g1 */
+      if (!strcmp(env, "g8")) lanes = 8;
+      else if (!strcmp(env, "g4")) lanes = 4;
+      else if (!strcmp(env, "g2")) lanes = 2;
+      else if (!strcmp(env, "g1")) lanes = 1;
+    }
+    if (g->amino && lanes < 4) lanes = 4;
+    unsigned long long *pos = (unsigned long long *)dPositions;
+    const unsigned long long th = totalHits;
+#define AWFM_LOC(AM, GG)                                                                                   \
+  hipLaunchKernelGGL((locateKernel<AM, GG>), dim3(gridFor(th, g, locateKernel<AM, GG>, kThreads / GG)), \
+                     dim3(kThreads), 0, s, g->dev, th, pos)
+    if (g->amino) {
+      if (lanes == 8) AWFM_LOC(true, 8);
+      else AWFM_LOC(true, 4);
+    } else {
+      if (lanes == 8) AWFM_LOC(false, 8);
+      else if (lanes == 4) AWFM_LOC(false, 4);
+      else if (lanes == 2) AWFM_LOC(false, 2);
+      else AWFM_LOC(false, 1);
+    }
+#undef AWFM_LOC
+  }
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
 }

@@ -50,9 +50,51 @@ __global__ void synthPlantedQueriesKernel(unsigned char *out, u64 first, u64 cou
     out[t] = text[offset + c];
   }
 }
+/* mixed-length set: L_j = lo + mix(q_j + 2^63 + G) % (hi-lo+1); even ids random, odd ids planted */
+__global__ void synthMixedLengthsKernel(u64 *lengths, u64 first, u64 count, unsigned lo, unsigned hi, u64 seedQ) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+    const u64 q = mix64(seedQ + first + j);
+    lengths[j] = lo + mix64(q + (1ull << 63) + kGolden) % (u64)(hi - lo + 1u);
+  }
+}
+
+__global__ void synthMixedQueriesKernel(unsigned char *out, const u64 *offsets, u64 first, u64 count, u64 seedQ,
+                                        const unsigned char *text, u64 n, int amino) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+    const u64 q = mix64(seedQ + first + j);
+    const u64 o = offsets[j], L = offsets[j + 1] - o;
+    if (((first + j) & 1ull) == 0ull) {
+      for (u64 c = 0; c < L; c++) out[o + c] = letterOf(mix64(q + (c + 1ull) * kGolden), amino);
+    } else {
+      const u64 s = mix64(q + kGolden) % (n - L + 1ull);
+      for (u64 c = 0; c < L; c++) out[o + c] = text[s + c];
+    }
+  }
+}
 }  // namespace
 
 extern "C" {
+
+enum AwFmReturnCode awfmGpuSynthMixedLengths(uint64_t *dLengths, uint64_t first, uint64_t count, uint32_t lo,
+                                             uint32_t hi, uint64_t seedQ, void *stream) {
+  if (!dLengths || hi < lo) return AwFmNullPtrError;
+  if (count == 0) return AwFmSuccess;
+  hipLaunchKernelGGL(synthMixedLengthsKernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, (u64 *)dLengths, (u64)first,
+                     (u64)count, lo, hi, (u64)seedQ);
+  return hipGetLastError() == hipSuccess ? AwFmSuccess : AwFmGeneralFailure;
+}
+
+enum AwFmReturnCode awfmGpuSynthMixedQueries(uint8_t *dOut, const uint64_t *dOffsets, uint64_t first, uint64_t count,
+                                             uint64_t seedQ, const uint8_t *dText, uint64_t textLength, int amino,
+                                             void *stream) {
+  if (!dOut || !dOffsets || !dText) return AwFmNullPtrError;
+  if (count == 0) return AwFmSuccess;
+  hipLaunchKernelGGL(synthMixedQueriesKernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, dOut, (const u64 *)dOffsets,
+                     (u64)first, (u64)count, (u64)seedQ, dText, (u64)textLength, amino);
+  return hipGetLastError() == hipSuccess ? AwFmSuccess : AwFmGeneralFailure;
+}
 
 enum AwFmReturnCode awfmGpuSynthText(uint8_t *dOut, uint64_t start, uint64_t count, uint64_t seed, int amino,
                                      void *stream) {

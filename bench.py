@@ -37,7 +37,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--workload", choices=["random", "planted"], default="random")
+    p.add_argument("--workload", choices=["random", "planted", "mixed"], default="random")
     p.add_argument("--mode", choices=["locate", "count"], default="locate")
     p.add_argument("--text-len", type=int, default=3_100_000_000)
     p.add_argument("--queries", type=int, default=100_000_000, help="k-mers per GPU per step")
@@ -66,7 +66,10 @@ def main():
     amino = args.alphabet == "amino"
     alpha = api.AwFmAlphabetAmino if amino else api.AwFmAlphabetDna
     n, Q, K = args.text_len, args.queries, args.kmer
-    text_seed, query_seed = (4, 104) if amino else (2, 102 if args.workload == "random" else 103)
+    if args.workload == "mixed":
+        args.mode = "count"  # 8..11-mers have ~10^4..10^5 hits each: the hit list of 10^8 of them does not fit any memory
+    text_seed = 4 if amino else 2
+    query_seed = 104 if amino else {"random": 102, "planted": 103, "mixed": 105}[args.workload]
 
     # ---- index replica on this GPU (text generated and indexed on the device) ----
     t0 = time.time()
@@ -80,13 +83,29 @@ def main():
 
     # ---- this rank's query shard, resident in HBM ----
     first, _ = shard.shard_bounds(Q * world, world, rank)  # weak scaling: the global batch is Q*world k-mers
-    d_chars = torch.empty(Q * K, dtype=torch.uint8, device=dev)
-    if args.workload == "random":
+    d_offsets = None  # CSR offsets (mixed lengths only); fixed-length batches pass the length instead
+    if args.workload == "mixed":
+        d_len = torch.empty(Q, dtype=torch.int64, device=dev)
+        assert L.awfmGpuSynthMixedLengths(d_len.data_ptr(), first, Q, 8, 30, query_seed, None) == 1
+        d_offsets = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(d_len, 0, out=d_offsets[1:])
+        total_chars = int(d_offsets[-1].item())
+        del d_len
+        d_chars = torch.empty(total_chars, dtype=torch.uint8, device=dev)
+        assert L.awfmGpuSynthMixedQueries(d_chars.data_ptr(), d_offsets.data_ptr(), first, Q, query_seed,
+                                          d_text.data_ptr(), n, int(amino), None) == 1
+        K = 0
+    else:
+        d_chars = torch.empty(Q * K, dtype=torch.uint8, device=dev)
+    if args.workload == "mixed":
+        pass
+    elif args.workload == "random":
         assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr(), first, Q, K, query_seed, int(amino), None) == 1
     else:
         assert L.awfmGpuSynthPlantedQueries(d_chars.data_ptr(), first, Q, K, query_seed, d_text.data_ptr(), n, None) == 1
     torch.cuda.synchronize()
-    if args.mode == "count" or args.workload == "random":
+    off_ptr = d_offsets.data_ptr() if d_offsets is not None else 0
+    if True:
         del d_text  # planted k-mers are already copied out; free 3.1 GB
         torch.cuda.empty_cache()
 
@@ -102,19 +121,26 @@ def main():
             state["positions"] = torch.empty(max(total, 1) + total // 8, dtype=torch.int64, device=dev)
 
     search_events = []
+    locate_events = []
 
     def step(record):
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        g.search(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr(), stream)
+        g.search(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr(), d_counts.data_ptr(), stream)
         if record:
             e1.record()
             search_events.append((e0, e1))
         if args.mode == "locate":
             total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
             ensure_positions(total)
+            if record:
+                e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e2.record()
             g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, state["positions"].data_ptr(), stream)
+            if record:
+                e3.record()
+                locate_events.append((e2, e3))
             state["hits"] = total
 
     def barrier():
@@ -132,19 +158,21 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * Q / (elapsed / args.steps) / 1e6  # Mkmers/s over all ranks
     search_ms = float(np.mean([a.elapsed_time(b) for a, b in search_events]))
+    locate_ms = float(np.mean([a.elapsed_time(b) for a, b in locate_events])) if locate_events else 0.0
 
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    kdesc = "8..30-mers" if args.workload == "mixed" else f"{K}-mers"
     # ---- roofline of the dominant kernel: algorithmic bytes / measured kernel time ----
-    tally = g.search_tally(d_chars.data_ptr(), 0, K, Q)
+    tally = g.search_tally(d_chars.data_ptr(), off_ptr, K, Q)
     rank_bytes = RANK_BYTES_AMINO if amino else RANK_BYTES_DNA
     alg_bytes = tally["chars"] + 16 * tally["seeded"] + rank_bytes * tally["blocks"] + 16 * Q
     achieved = alg_bytes / (search_ms * 1e-3) / 1e9
     roofline = {
-        "bound": "hbm", "kernel": "searchGroup8Kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": "searchKernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
         "kernel_ms": round(search_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
         "per_query": {"steps": round(tally["steps"] / Q, 4), "distinct_blocks": round(tally["blocks"] / Q, 4),
@@ -163,8 +191,12 @@ def main():
         cores = os.cpu_count() or 1
 
         def run_sample(m):
-            chars = d_chars[: m * K].cpu().numpy()
-            offsets = np.arange(m + 1, dtype=np.uint64) * np.uint64(K)
+            if d_offsets is not None:
+                offsets = d_offsets[: m + 1].cpu().numpy().view(np.uint64)
+                chars = d_chars[: int(offsets[-1])].cpu().numpy()
+            else:
+                chars = d_chars[: m * K].cpu().numpy()
+                offsets = np.arange(m + 1, dtype=np.uint64) * np.uint64(K)
             t0 = time.perf_counter()
             sp, ep, cnt, tl = oi.batch_search(chars, offsets, threads=cores)
             if args.mode == "locate":
@@ -190,7 +222,7 @@ def main():
             m = int(min(Q, 50_000_000, max(2 * m, m * args.cpu_seconds / max(dt, 1e-3))))
             dt, tl = run_sample(m)
         cpu = {"value": round(m / dt / 1e6, 3), "unit": "Mkmers/s", "cores": cores, "kind": "port",
-               "sample": f"first {m} of the {Q} {args.workload} {K}-mers of rank 0, {args.mode}, same index, "
+               "sample": f"first {m} of the {Q} {args.workload} {kdesc} of rank 0, {args.mode}, same index, "
                          f"{dt:.1f} s wall, results equal to the GPU's",
                "per_query": {"steps": round(tl["steps"] / m, 4), "distinct_blocks": round(tl["blocks"] / m, 4)}}
 
@@ -199,11 +231,12 @@ def main():
         "value": round(value, 2), "unit": "Mkmers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"{Q / 1e6:g} M {args.workload} {K}-mers per GPU, {args.mode}, "
+        "config": {"workload": f"{Q / 1e6:g} M {args.workload} {kdesc} per GPU, {args.mode}, "
                                f"{n / 1e9:g} Gbp uniform synthetic {args.alphabet} text (GRCh38-sized), "
                                f"SA ratio {args.sa_ratio}, seed table k={args.seed_k}",
                    "parallelism": f"index replica per GPU, query batch sharded over {world} rank(s), no collective",
-                   "hits_per_step_rank0": int(state["hits"]), "index_build_s": round(build_s, 2),
+                   "hits_per_step_rank0": int(state["hits"]), "locate_kernels_ms": round(locate_ms, 3),
+                   "index_build_s": round(build_s, 2),
                    "device_image_bytes": g.device_bytes},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -131,6 +131,14 @@ enum AwFmReturnCode awfmGpuSynthRandomQueries(uint8_t *dOut, uint64_t first, uin
 enum AwFmReturnCode awfmGpuSynthPlantedQueries(uint8_t *dOut, uint64_t first, uint64_t count, uint32_t length,
                                                uint64_t seedQ, const uint8_t *dText, uint64_t textLength, void *stream);
 
+/* mixed-length set: lengths lo..hi, even ids random, odd ids copied from the text.
+ * Lengths first; the caller turns them into count+1 exclusive-scan offsets; then the characters. */
+enum AwFmReturnCode awfmGpuSynthMixedLengths(uint64_t *dLengths, uint64_t first, uint64_t count, uint32_t lo,
+                                             uint32_t hi, uint64_t seedQ, void *stream);
+enum AwFmReturnCode awfmGpuSynthMixedQueries(uint8_t *dOut, const uint64_t *dOffsets, uint64_t first, uint64_t count,
+                                             uint64_t seedQ, const uint8_t *dText, uint64_t textLength, int amino,
+                                             void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -101,3 +101,21 @@ def test_device_generators_match_numpy(awfm, require_gpu):
         assert np.array_equal(q.cpu().numpy().reshape(2000, 21), synth.random_queries(12, 2000, 21, alphabet, first=100))
         assert L.awfmGpuSynthPlantedQueries(q.data_ptr(), 100, 2000, 21, 13, d.data_ptr(), n, None) == 1
         assert np.array_equal(q.cpu().numpy().reshape(2000, 21), synth.planted_queries(13, 2000, 21, txt, first=100))
+
+
+def test_device_mixed_generator_matches_numpy(awfm, require_gpu):
+    import torch
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    n, count = 50000, 3000
+    txt = synth.text(15, n)
+    d_text = torch.from_numpy(txt.copy()).cuda()
+    chars, offsets = synth.mixed_queries(16, count, txt, synth.DNA_ALPHABET, 8, 30, first=40)
+    d_len = torch.empty(count, dtype=torch.int64, device="cuda")
+    assert L.awfmGpuSynthMixedLengths(d_len.data_ptr(), 40, count, 8, 30, 16, None) == 1
+    d_off = torch.zeros(count + 1, dtype=torch.int64, device="cuda")
+    torch.cumsum(d_len, 0, out=d_off[1:])
+    assert np.array_equal(d_off.cpu().numpy().view(np.uint64), offsets)
+    d_chars = torch.empty(int(d_off[-1].item()), dtype=torch.uint8, device="cuda")
+    assert L.awfmGpuSynthMixedQueries(d_chars.data_ptr(), d_off.data_ptr(), 40, count, 16, d_text.data_ptr(), n, 0, None) == 1
+    assert np.array_equal(d_chars.cpu().numpy(), chars)
