@@ -186,28 +186,62 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
       /* ---- seed (ref src/AwFmKmerTable.c:4-51) ---- */
       bool seeded = false;
       const bool tryTable = K != 0 && K <= 32u && len >= K;
-      unsigned index = 0;
-      bool ambiguous = false;
-      if (tryTable) {
+      unsigned long long index = 0;
+      bool ambiguousGroup = false; /* group-uniform */
+      if (AMINO) {
+        unsigned partial = 0;
+        bool ambiguous = false;
+        if (tryTable) {
 #pragma unroll
-        for (int w = 0; w < S; w++) {
+          for (int w = 0; w < S; w++) {
 #pragma unroll
-          for (unsigned b = 0; b < 4; b++) {
-            const unsigned i = wb + 4u * (firstPiece + w) + b; /* index in the query */
-            const int j = (int)i - (int)(len - K);             /* index in the seed */
-            const unsigned c = (win[w] >> (8u * b)) & 0xFFu;
-            const bool inSeed = i < len && j >= 0;
-            const bool amb = AMINO ? aminoIsAmbiguous(c) : nucIsAmbiguous(c);
-            const unsigned letter = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
-            ambiguous |= inSeed && amb;
-            index += inSeed ? letter * sPow[j & 31] : 0u;
+            for (unsigned b = 0; b < 4; b++) {
+              const unsigned i = wb + 4u * (firstPiece + w) + b; /* index in the query */
+              const int j = (int)i - (int)(len - K);             /* index in the seed */
+              const unsigned c = (win[w] >> (8u * b)) & 0xFFu;
+              const bool inSeed = i < len && j >= 0;
+              ambiguous |= inSeed && aminoIsAmbiguous(c);
+              partial += inSeed ? aminoLetterIndex(sAmino, c) * sPow[j & 31] : 0u;
+            }
           }
         }
+        index = groupSum<G>(partial);
+        const unsigned long long ballot = __ballot(ambiguous);
+        ambiguousGroup = ((unsigned)(ballot >> (lane & ~(unsigned)(G - 1))) & ((1u << G) - 1u)) != 0u;
+      } else {
+        /* Nucleotide: with 4 letters the table index is simply the 2-bit letter codes of the last K
+         * characters concatenated, first character most significant.  Decode the window 4 characters at a
+         * time (SWAR): for a,c,g,t,u the bits (c>>1)&3 are 0,1,3,2,2 and x^(x>>1) maps them to 0,1,2,3,3;
+         * a byte is a valid letter iff re-encoding its code gives the byte back (u matches t up to bit 0). */
+        unsigned long long codes = 0; /* this lane's 4*S characters, 2 bits each, first character on top */
+        unsigned bad = 0;             /* bit i: character i of this lane's part is not a,c,g,t,u */
+#pragma unroll
+        for (int w = 0; w < S; w++) {
+          const unsigned word = win[w];
+          unsigned t = (word >> 1) & 0x03030303u;
+          t ^= (t >> 1) & 0x01010101u;
+          const unsigned b0 = t & 0x01010101u, b1 = (t >> 1) & 0x01010101u, b01 = b0 & b1;
+          const unsigned expect = 0x61616161u + (b0 << 1) + b1 * 6u + b01 * 11u; /* 'a','c','g','t' */
+          unsigned diff = ((word | 0x20202020u) ^ expect) & ~b01;
+          diff |= diff >> 4;
+          diff |= diff >> 2;
+          diff |= diff >> 1;
+          diff &= 0x01010101u;
+          const unsigned badBits = (diff & 1u) | ((diff >> 7) & 2u) | ((diff >> 14) & 4u) | ((diff >> 21) & 8u);
+          const unsigned packed = ((t & 3u) << 6) | ((t >> 4) & 0x30u) | ((t >> 14) & 0x0Cu) | (t >> 24);
+          codes = (codes << 8) | packed;
+          bad |= badBits << (4 * w);
+        }
+        /* window-wide: 64-bit code string (character 0 of the window in bits 63..62) and 32-bit bad mask */
+        const unsigned long long allCodes = groupSum64<G>(codes << (64 - 8 * S * ((int)gl + 1)));
+        const unsigned allBad = groupSum<G>(bad << (4 * S * gl));
+        const unsigned e = len - wb; /* characters of the query inside the window: 1..32, >= K when tryTable */
+        const unsigned long long kMask = K >= 32u ? ~0ull : ((1ull << (2u * K)) - 1ull);
+        index = (e >= 32u ? allCodes : (allCodes >> (2u * (32u - e)))) & kMask;
+        const unsigned long long seedChars = (K >= 32u ? 0xFFFFFFFFull : ((1ull << K) - 1ull)) << (tryTable ? e - K : 0u);
+        ambiguousGroup = ((unsigned long long)allBad & seedChars) != 0ull;
       }
-      index = groupSum<G>(index);
-      const unsigned long long ballot = __ballot(ambiguous);
-      const unsigned groupBits = (unsigned)(ballot >> (lane & ~(unsigned)(G - 1))) & ((1u << G) - 1u);
-      seeded = tryTable && groupBits == 0u && index < ix.seedLen;
+      seeded = tryTable && !ambiguousGroup && index < ix.seedLen;
       if (seeded) {
         if (TALLY) tSeeded++;
         const ulonglong2 r = ix.seed[index];
