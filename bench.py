@@ -171,9 +171,17 @@ def main():
     rank_bytes = RANK_BYTES_AMINO if amino else RANK_BYTES_DNA
     alg_bytes = tally["chars"] + 16 * tally["seeded"] + rank_bytes * tally["blocks"] + 16 * Q
     achieved = alg_bytes / (search_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes of scripts/profile_bench.sh (profiles/r1/traffic_default.json),
+    # valid for the default workload only
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1", "traffic_default.json")
+    is_default = (args.workload == "random" and not amino and n == 3_100_000_000 and Q == 100_000_000 and K == 21
+                  and args.seed_k == 12 and args.sa_ratio == 8)
+    if is_default and os.path.exists(tpath):
+        traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
     roofline = {
         "bound": "hbm", "kernel": "searchKernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "kernel_ms": round(search_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
         "per_query": {"steps": round(tally["steps"] / Q, 4), "distinct_blocks": round(tally["blocks"] / Q, 4),
                       "seeded": round(tally["seeded"] / Q, 4), "bytes": round(alg_bytes / Q, 1)},
