@@ -1,0 +1,102 @@
+"""Size-independent properties at (near) BASELINE sizes, where the oracle cannot be run over everything:
+  * every planted k-mer is found, and every reported position really spells the k-mer in the text
+    (the locate property of ref test/parallelSearch/parallelSearchTest.c:105-214, checked on the device);
+  * hit lists are strictly inside [0, n-K] and, per query, pairwise distinct;
+  * counts equal range lengths; an oracle-checked sample of the same batch agrees bit for bit.
+Sizes: AWFM_TEST_TEXT_LEN / AWFM_TEST_QUERIES (defaults 400 Mbp / 20 M; bench.py runs the 3.1 Gbp / 100 M
+case with the same parity gate)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_planted_kmers_are_located_where_they_were_taken(oracle, awfm, require_gpu):
+    import torch
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    n = int(os.environ.get("AWFM_TEST_TEXT_LEN", 400_000_000))
+    Q = int(os.environ.get("AWFM_TEST_QUERIES", 20_000_000))
+    K = 21
+    dev = torch.device("cuda")
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, 2, 0, None) == 1
+    ix = awfm.gpu_create_index(d_text.data_ptr(), awfm.AwFmAlphabetDna, 8, 12, on_device_length=n)
+    g = awfm.GpuIndex(ix, acquire=True)
+    d_chars = torch.empty(Q * K, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthPlantedQueries(d_chars.data_ptr(), 0, Q, K, 103, d_text.data_ptr(), n, None) == 1
+    d_ranges = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+    d_counts = torch.empty(Q, dtype=torch.int32, device=dev)
+    d_off = torch.empty(Q + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.empty(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+    g.search(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+    total = g.hit_offsets(d_ranges.data_ptr(), Q, d_off.data_ptr(), d_scratch.data_ptr())
+    d_pos = torch.empty(total, dtype=torch.int64, device=dev)
+    g.locate(d_ranges.data_ptr(), d_off.data_ptr(), Q, total, d_pos.data_ptr())
+    torch.cuda.synchronize()
+    r = d_ranges.view(Q, 2)
+    lens = torch.where(r[:, 0] <= r[:, 1], r[:, 1] - r[:, 0] + 1, torch.zeros_like(r[:, 0]))
+    assert int(lens.min()) >= 1, "a planted k-mer was not found"
+    assert torch.equal(lens.to(torch.int32), d_counts) and int(lens.sum()) == total
+    assert torch.equal(torch.cumsum(lens, 0), d_off[1:]) and int(d_off[0]) == 0
+    assert int(d_pos.min()) >= 0 and int(d_pos.max()) <= n - K
+    # every hit spells its k-mer: compare text[pos + c] with the query's character c, one column at a time
+    owner = torch.repeat_interleave(torch.arange(Q, device=dev), lens)
+    q2d = d_chars.view(Q, K)
+    for c in range(K):
+        assert torch.equal(d_text[d_pos + c], q2d[owner, c]), f"hit does not match the k-mer at character {c}"
+    # the seeded offset each k-mer was copied from is among its hits
+    from avxwindowfmindex_amd import synth
+    sample = 200_000
+    planted = torch.from_numpy(synth.planted_offsets(103, sample, K, n).astype(np.int64)).to(dev)
+    first_hit = d_off[:sample]
+    found = torch.zeros(sample, dtype=torch.bool, device=dev)
+    maxc = int(lens[:sample].max())
+    for h in range(maxc):
+        valid = lens[:sample] > h
+        idx = torch.where(valid, first_hit + h, torch.zeros_like(first_hit))
+        found |= valid & (d_pos[idx] == planted)
+    assert bool(found.all())
+    # hits of one query are pairwise distinct (BWT order gives distinct suffixes)
+    multi = torch.nonzero(lens[:sample] > 1).flatten()[:2000].tolist()
+    pos_cpu = d_pos[: int(d_off[sample])].cpu().numpy()
+    off_cpu = d_off[: sample + 1].cpu().numpy()
+    for q in multi:
+        hits = pos_cpu[off_cpu[q]:off_cpu[q + 1]]
+        assert len(set(hits.tolist())) == len(hits)
+    # oracle on a sample of the same batch, bit for bit
+    m = 300_000
+    oi = oracle.Index.wrap(oracle.DNA, 8, 12, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    chars = d_chars[: m * K].cpu().numpy()
+    offsets = np.arange(m + 1, dtype=np.uint64) * np.uint64(K)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=os.cpu_count() or 1)
+    ho, pos, _ = oi.batch_locate(sp, ep, threads=os.cpu_count() or 1)
+    gr = d_ranges[: 2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)
+    assert np.array_equal(gr[:, 0], sp) and np.array_equal(gr[:, 1], ep)
+    assert np.array_equal(d_off[: m + 1].cpu().numpy().view(np.uint64), ho)
+    assert np.array_equal(d_pos[: int(ho[-1])].cpu().numpy().view(np.uint64), pos)
+    g.destroy()
+    ix.dealloc()
+
+
+def test_random_kmers_counts_are_consistent_between_count_and_locate(awfm, require_gpu):
+    """idempotence / agreement: the same batch through the count path and the locate path, host-buffer API"""
+    from avxwindowfmindex_amd import synth
+    txt = synth.text(2, 3_000_000)
+    ix = awfm.gpu_create_index(txt, awfm.AwFmAlphabetDna, 8, 10)
+    g = awfm.GpuIndex(ix, acquire=True)
+    q = np.concatenate([synth.random_queries(102, 300000, 14), synth.planted_queries(103, 300000, 14, txt)])
+    chars, _ = synth.fixed_csr(q)
+    ranges, counts = g.count_host(chars, None, fixed_length=14)
+    r2, ho, pos = g.locate_host(chars, None, fixed_length=14)
+    assert np.array_equal(ranges, r2) and np.array_equal(np.diff(ho).astype(np.uint32), counts)
+    raw = txt.tobytes()
+    for j in list(range(0, 600000, 997)):
+        k = q[j].tobytes()
+        for p in pos[int(ho[j]):int(ho[j + 1])].tolist():
+            assert raw[p:p + 14] == k
+    assert counts[300000:].min() >= 1
+    g.destroy()
+    ix.dealloc()
