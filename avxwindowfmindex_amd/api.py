@@ -212,6 +212,10 @@ class GpuIndex:
     def device_bytes(self):
         return int(_lib.lib().awfmGpuIndexDeviceBytes(self.handle))
 
+    def set_deep_seed(self, deep_k):
+        """device-only deeper seed table (nucleotide); 0 drops it"""
+        _check("awfmGpuIndexSetDeepSeed", _lib.lib().awfmGpuIndexSetDeepSeed(self.handle, deep_k))
+
     def set_kernel(self, kernel):
         _lib.lib().awfmGpuIndexSetKernel(self.handle, kernel)
 

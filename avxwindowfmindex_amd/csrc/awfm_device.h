@@ -44,6 +44,11 @@ struct DevIndex {
   unsigned int saShift; /* log2(saRatio) when it is a power of two, else 0xFFFFFFFF */
   unsigned int saWidth;
   unsigned int seedK;
+  /* optional device-only deeper seed table (nucleotide): entry of a deepK-mer = the range the reference
+   * algorithm reaches after the seed lookup and (deepK - seedK) extension steps that stop at the first
+   * invalid range; NULL when not built */
+  const ulonglong2 *deepSeed;
+  unsigned int deepK;
 };
 
 constexpr int kThreads = 256;
@@ -328,6 +333,8 @@ struct AwFmGpuIndex {
   void *dSeed = nullptr;
   void *dSa = nullptr;
   void *dPrefix = nullptr;
+  void *dDeepSeed = nullptr;
+  uint64_t deepSeedBytes = 0;
   uint64_t deviceBytes = 0;
   uint64_t numBlocks = 0;
   AwFmGpuKernel kernel = AWFM_GPU_KERNEL_AUTO;
@@ -356,6 +363,8 @@ struct DeviceGuard {
 AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSeed, void *dSa,
                                 void *dPrefix, unsigned long long sentinelPos, uint64_t deviceBytes);
 void awfmGpuIndexRegister(const struct AwFmIndex *index, AwFmGpuIndex *g);
+/* awfm_gpu_build.hip: level-wise construction of the deeper seed table into a new device buffer */
+bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut);
 void awfmGpuSetError(const char *what);
 void awfmGpuSetHipError(const char *what, hipError_t e);
 

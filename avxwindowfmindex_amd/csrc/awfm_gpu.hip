@@ -197,6 +197,8 @@ void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned long 
   }
   d.saWidth = index->suffixArray.valueBitWidth;
   d.seedK = index->config.kmerLengthInSeedTable;
+  d.deepSeed = nullptr;
+  d.deepK = 0;
 }
 }  // namespace
 
@@ -405,6 +407,10 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
 #undef TRY_OR_FAIL
 
   fillDevIndex(g, index, sentinelPos);
+  if (const char *env = getenv("AWFM_GPU_DEEP_SEED_K")) {
+    const int deepK = atoi(env);
+    if (deepK > 0 && !amino && awfmGpuIndexSetDeepSeed(g, (unsigned)deepK) != AwFmSuccess) return fail(AwFmGeneralFailure);
+  }
   *out = g;
   return AwFmSuccess;
 }
@@ -417,6 +423,7 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
     if (g->dSeed) (void)hipFree(g->dSeed);
     if (g->dSa) (void)hipFree(g->dSa);
     if (g->dPrefix) (void)hipFree(g->dPrefix);
+    if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
     if (g->dWork) (void)hipFree(g->dWork);
     if (g->hostStage) (void)hipHostFree(g->hostStage);
   }
@@ -447,7 +454,31 @@ void awfmGpuIndexRelease(const struct AwFmIndex *index) {
   awfmGpuIndexDestroy(g);
 }
 
-uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g) { return g ? g->deviceBytes : 0; }
+uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g) { return g ? g->deviceBytes + g->deepSeedBytes : 0; }
+
+enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK) {
+  if (!g) {
+    setError("awfmGpuIndexSetDeepSeed: null image");
+    return AwFmNullPtrError;
+  }
+  DeviceGuard guard(g->device);
+  std::lock_guard<std::mutex> lock(g->workMutex);
+  (void)hipDeviceSynchronize();
+  if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
+  g->dDeepSeed = nullptr;
+  g->deepSeedBytes = 0;
+  g->dev.deepSeed = nullptr;
+  g->dev.deepK = 0;
+  if (deepK == 0) return AwFmSuccess;
+  void *table = nullptr;
+  uint64_t bytes = 0;
+  if (!awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes)) return AwFmGeneralFailure;
+  g->dDeepSeed = table;
+  g->deepSeedBytes = bytes;
+  g->dev.deepSeed = (const ulonglong2 *)table;
+  g->dev.deepK = deepK;
+  return AwFmSuccess;
+}
 int awfmGpuIndexDevice(const AwFmGpuIndex *g) { return g ? g->device : -1; }
 void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel) {
   if (g) g->kernel = kernel;
@@ -487,8 +518,14 @@ enum AwFmReturnCode awfmGpuSearchTally(AwFmGpuIndex *g, const uint8_t *dChars, c
   AWFM_HIP_TRY(hipMalloc((void **)&dTally, 32), AwFmAllocationFailure);
   hipError_t e = hipMemset(dTally, 0, 32);
   if (e == hipSuccess && numQueries) {
+    /* the tally prices the reference algorithm (index seed table), so the device-only deeper
+     * table is switched off for this launch */
+    DevIndex saved = g->dev;
+    g->dev.deepSeed = nullptr;
+    g->dev.deepK = 0;
     launchSearch<true>(g, lanesPerQuery(g), (hipStream_t)0, dChars, (const unsigned long long *)dOffsets, fixedLength,
                        numQueries, nullptr, nullptr, dTally);
+    g->dev = saved;
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(tallyOut, dTally, 32, hipMemcpyDeviceToHost);

@@ -276,7 +276,7 @@ __global__ void baseOccurrenceKernel(const u64 *__restrict__ scanned, u64 numBlo
 
 /* level L+1 from level L: entry e = a * |A|^L + parent, range = blind backward step of the
  * parent's range with letter a -- no validity check (ref src/AwFmCreate.c:419-450) */
-template <bool AMINO>
+template <bool AMINO, bool STOP_AT_INVALID = false>
 __global__ void __launch_bounds__(kThreads)
     seedLevelKernel(const DevIndex ix, const ulonglong2 *__restrict__ parentLevel, u64 parentLen, u64 outLen,
                     ulonglong2 *__restrict__ out) {
@@ -295,10 +295,14 @@ __global__ void __launch_bounds__(kThreads)
     const unsigned a = (unsigned)(e / parentLen);
     const ulonglong2 r = parentLevel[e % parentLen];
     u64 sp = r.x, ep = r.y;
-    if (AMINO)
-      aminoStep(ix, sC, sAmino, a, sp, ep, g);
-    else
-      nucStep(ix, sC, a, sp, ep, g);
+    /* STOP_AT_INVALID (deeper device table): a query stops at its first invalid range and keeps it
+     * (ref src/AwFmParallelSearch.c:293-294), so an invalid parent is inherited unchanged */
+    if (!STOP_AT_INVALID || sp <= ep) {
+      if (AMINO)
+        aminoStep(ix, sC, sAmino, a, sp, ep, g);
+      else
+        nucStep(ix, sC, a, sp, ep, g);
+    }
     if (g == 0) out[e] = make_ulonglong2(sp, ep);
   }
 }
@@ -505,6 +509,40 @@ bool buildSuffixArray(const unsigned char *dText, u64 n, u32 *dSa, bool verbose)
 }
 
 }  // namespace
+
+/* Deeper seed table for the device image: level seedK is the index's own table; level L+1 extends
+ * every level-L entry by one more (prepended) letter with the search path's stop-at-first-invalid rule. */
+bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut) {
+  *tableOut = nullptr;
+  *bytesOut = 0;
+  const unsigned K = g->dev.seedK;
+  if (g->amino || deepK <= K || deepK > 16 || K == 0) {
+    awfmGpuSetError("deep seed table: nucleotide images only, seedK < deepK <= 16");
+    return false;
+  }
+  DeviceGuard guard(g->device);
+  u64 len = 1;
+  for (unsigned i = 0; i < K; i++) len *= 4;
+  DeviceBuffer cur, nxt;
+  const ulonglong2 *parent = g->dev.seed;
+  for (unsigned L = K; L < deepK; L++) {
+    const u64 outLen = len * 4;
+    if (!nxt.alloc(outLen * 16)) return false;
+    const u64 blocks = (outLen + kGroupsPerBlock - 1) / kGroupsPerBlock;
+    const unsigned grid = (unsigned)(blocks < 2048 * 4 ? blocks : 2048 * 4);
+    hipLaunchKernelGGL((seedLevelKernel<false, true>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen,
+                       nxt.as<ulonglong2>());
+    BUILD_TRY(hipGetLastError());
+    BUILD_TRY(hipDeviceSynchronize());
+    cur.reset();
+    cur.p = nxt.release();
+    parent = cur.as<ulonglong2>();
+    len = outLen;
+  }
+  *bytesOut = len * 16;
+  *tableOut = cur.release();
+  return true;
+}
 
 extern "C" enum AwFmReturnCode awfmGpuCreateIndex(struct AwFmIndex **index, const struct AwFmIndexConfiguration *config,
                                                   const uint8_t *sequence, uint64_t sequenceLength,

@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
     int pos = -1;
     if (len != 0) {
       /* ---- seed (ref src/AwFmKmerTable.c:4-51) ---- */
-      bool seeded = false;
+      bool seeded = false, deep = false;
       const bool tryTable = K != 0 && K <= 32u && len >= K;
       unsigned long long index = 0;
       bool ambiguousGroup = false; /* group-uniform */
@@ -236,19 +236,32 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
         const unsigned long long allCodes = groupSum64<G>(codes << (64 - 8 * S * ((int)gl + 1)));
         const unsigned allBad = groupSum<G>(bad << (4 * S * gl));
         const unsigned e = len - wb; /* characters of the query inside the window: 1..32, >= K when tryTable */
+        const unsigned long long tail = e >= 32u ? allCodes : (allCodes >> (2u * (32u - e)));
         const unsigned long long kMask = K >= 32u ? ~0ull : ((1ull << (2u * K)) - 1ull);
-        index = (e >= 32u ? allCodes : (allCodes >> (2u * (32u - e)))) & kMask;
+        index = tail & kMask;
         const unsigned long long seedChars = (K >= 32u ? 0xFFFFFFFFull : ((1ull << K) - 1ull)) << (tryTable ? e - K : 0u);
         ambiguousGroup = ((unsigned long long)allBad & seedChars) != 0ull;
+        /* device-only deeper table: same answer as the seed entry followed by deepK-K extension steps */
+        const unsigned DK = ix.deepK;
+        if (DK != 0u && len >= DK) {
+          const unsigned long long deepChars = ((1ull << DK) - 1ull) << (e - DK);
+          if (((unsigned long long)allBad & deepChars) == 0ull) {
+            const ulonglong2 r = ix.deepSeed[tail & ((1ull << (2u * DK)) - 1ull)];
+            sp = r.x;
+            ep = r.y;
+            pos = (int)(len - DK) - 1;
+            deep = true;
+          }
+        }
       }
-      seeded = tryTable && !ambiguousGroup && index < ix.seedLen;
+      seeded = !deep && tryTable && !ambiguousGroup && index < ix.seedLen;
       if (seeded) {
         if (TALLY) tSeeded++;
         const ulonglong2 r = ix.seed[index];
         sp = r.x;
         ep = r.y;
         pos = (int)(len - K) - 1;
-      } else { /* ref src/AwFmSearch.c:485-502 */
+      } else if (!deep) { /* ref src/AwFmSearch.c:485-502 */
         const unsigned c = windowChar(len - 1u);
         const unsigned a = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
         sp = sC[a];

@@ -47,6 +47,8 @@ def parse():
     p.add_argument("--alphabet", choices=["dna", "amino"], default="dna")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--device-seed-k", type=int, default=0,
+                   help="optional device-only deeper seed table (same results, fewer block reads); 0 = the index's own table")
     return p.parse_args()
 
 
@@ -80,6 +82,12 @@ def main():
                               device=dev.index)
     g = api.GpuIndex(ix, acquire=True)
     build_s = time.time() - t0
+    deep_s = 0.0
+    if args.device_seed_k:
+        t1 = time.time()
+        g.set_deep_seed(args.device_seed_k)
+        torch.cuda.synchronize()
+        deep_s = time.time() - t1
 
     # ---- this rank's query shard, resident in HBM ----
     first, _ = shard.shard_bounds(Q * world, world, rank)  # weak scaling: the global batch is Q*world k-mers
@@ -175,7 +183,7 @@ def main():
     # valid for the default workload only
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r1", "traffic_default.json")
-    is_default = (args.workload == "random" and not amino and n == 3_100_000_000 and Q == 100_000_000 and K == 21
+    is_default = (not args.device_seed_k and args.workload == "random" and not amino and n == 3_100_000_000 and Q == 100_000_000 and K == 21
                   and args.seed_k == 12 and args.sa_ratio == 8)
     if is_default and os.path.exists(tpath):
         traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
@@ -245,7 +253,8 @@ def main():
                    "parallelism": f"index replica per GPU, query batch sharded over {world} rank(s), no collective",
                    "hits_per_step_rank0": int(state["hits"]), "locate_kernels_ms": round(locate_ms, 3),
                    "index_build_s": round(build_s, 2),
-                   "device_image_bytes": g.device_bytes},
+                   "device_image_bytes": g.device_bytes, "device_seed_k": args.device_seed_k or args.seed_k,
+                   "device_seed_build_s": round(deep_s, 2)},
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

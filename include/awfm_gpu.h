@@ -67,6 +67,13 @@ AwFmGpuIndex *awfmGpuIndexAcquire(const struct AwFmIndex *index);
 void awfmGpuIndexRelease(const struct AwFmIndex *index);
 uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g);
 int awfmGpuIndexDevice(const AwFmGpuIndex *g);
+/* Optional, nucleotide images: builds a device-only seed table of depth deepK (seedK < deepK <= 16,
+ * 4^deepK x 16 bytes of HBM: 4.3 GB at 14, 69 GB at 16) whose entries equal what the reference algorithm
+ * reaches after the seed lookup plus deepK-seedK extension steps (stopping at the first invalid range), so
+ * results stay bit-identical while those steps' block reads disappear.  deepK = 0 drops it.  The host
+ * index, its seed table and the .awfmi file are untouched.  Also read from $AWFM_GPU_DEEP_SEED_K when an
+ * image is created. */
+enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK);
 /* Selects the search kernel variant for this image (default AUTO). */
 void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel);
 

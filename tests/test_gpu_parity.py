@@ -161,3 +161,30 @@ def test_sa_staged_from_file(oracle, awfm, require_gpu, tmp_path):
     assert np.array_equal(ho2, hit_off) and np.array_equal(p2, pos)
     g2.destroy()
     ix2.dealloc()
+
+
+@pytest.mark.parametrize("seed_k,deep_k", [(3, 5), (6, 9), (8, 12)])
+def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, require_gpu, seed_k, deep_k):
+    """the optional device-only deeper seed table must not change a single range or position, including
+    queries shorter than it, ambiguity letters inside/outside the deep suffix and absent k-mers"""
+    n = 250000
+    txt = synth.text(300 + deep_k, n).copy()
+    txt[1000:1004] = ord("n")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, seed_k)
+    oi = oracle.Index.wrap(oracle.DNA, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    chars, offsets = _mixed_queries(400 + deep_k, 6000, txt, synth.DNA_ALPHABET, 1, 40, ambiguity=ord("x"), upper=True)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    g = awfm.GpuIndex(ix)
+    before = g.device_bytes
+    g.set_deep_seed(deep_k)
+    assert g.device_bytes == before + 16 * 4 ** deep_k
+    ranges, ho, p = g.locate_host(chars, offsets)
+    assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep)
+    assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
+    g.set_deep_seed(0)
+    ranges2, counts2 = g.count_host(chars, offsets)
+    assert np.array_equal(ranges2, ranges) and np.array_equal(counts2, cnt) and g.device_bytes == before
+    g.destroy()
+    ix.dealloc()
