@@ -216,6 +216,10 @@ class GpuIndex:
         """device-only deeper seed table (nucleotide); 0 drops it"""
         _check("awfmGpuIndexSetDeepSeed", _lib.lib().awfmGpuIndexSetDeepSeed(self.handle, deep_k))
 
+    def set_dense_sa(self, enable=True):
+        """device-only full suffix array (32-bit entries) so that a locate is a single gather"""
+        _check("awfmGpuIndexSetDenseSa", _lib.lib().awfmGpuIndexSetDenseSa(self.handle, int(bool(enable))))
+
     def set_kernel(self, kernel):
         _lib.lib().awfmGpuIndexSetKernel(self.handle, kernel)
 

@@ -335,6 +335,8 @@ struct AwFmGpuIndex {
   void *dPrefix = nullptr;
   void *dDeepSeed = nullptr;
   uint64_t deepSeedBytes = 0;
+  void *dDenseSa = nullptr; /* optional full suffix array, 32-bit entries */
+  uint64_t denseSaBytes = 0;
   uint64_t deviceBytes = 0;
   uint64_t numBlocks = 0;
   AwFmGpuKernel kernel = AWFM_GPU_KERNEL_AUTO;

@@ -112,6 +112,24 @@ __global__ void __launch_bounds__(kScanThreads)
   if (writeTotal && base <= n - 1 && n - 1 < base + kScanItems) out[n] = running;
 }
 
+/* dense device SA construction helpers */
+__global__ void iotaKernel(unsigned long long *out, unsigned long long first, unsigned long long count) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = first + i;
+}
+__global__ void narrowKernel(const unsigned long long *in, unsigned long long count, unsigned *out) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) out[i] = (unsigned)in[i];
+}
+/* positions[t] = denseSa[positions[t]]: the whole backtrace as one gather (hits of a query are consecutive
+ * BWT positions, so the reads are contiguous per query) */
+__global__ void denseSaGatherKernel(const unsigned *__restrict__ dense, unsigned long long totalHits,
+                                    unsigned long long *__restrict__ positions) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < totalHits; t += stride)
+    positions[t] = dense[positions[t]];
+}
+
 /* dPositions[hitOffsets[i] + h] = sp_i + h (the BWT positions to trace back) */
 __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const unsigned long long *__restrict__ hitOffsets,
                                  unsigned long long n, unsigned long long *__restrict__ positions) {
@@ -203,6 +221,8 @@ void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned long 
 }  // namespace
 
 namespace {
+enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions,
+                                 hipStream_t s);
 /* lanes that cooperate on one query: image setting, else $AWFM_GPU_KERNEL (g8|g4|g2|g1), else the default */
 int lanesPerQuery(const AwFmGpuIndex *g) {
   int lanes = 8;
@@ -424,6 +444,7 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
     if (g->dSa) (void)hipFree(g->dSa);
     if (g->dPrefix) (void)hipFree(g->dPrefix);
     if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
+    if (g->dDenseSa) (void)hipFree(g->dDenseSa);
     if (g->dWork) (void)hipFree(g->dWork);
     if (g->hostStage) (void)hipHostFree(g->hostStage);
   }
@@ -454,7 +475,9 @@ void awfmGpuIndexRelease(const struct AwFmIndex *index) {
   awfmGpuIndexDestroy(g);
 }
 
-uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g) { return g ? g->deviceBytes + g->deepSeedBytes : 0; }
+uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g) {
+  return g ? g->deviceBytes + g->deepSeedBytes + g->denseSaBytes : 0;
+}
 
 enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK) {
   if (!g) {
@@ -616,6 +639,19 @@ enum AwFmReturnCode awfmGpuLocate(AwFmGpuIndex *g, const struct AwFmSearchRange 
                      (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets,
                      (unsigned long long)numQueries, (unsigned long long *)dPositions);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  if (g->dDenseSa) {
+    hipLaunchKernelGGL(denseSaGatherKernel, dim3((unsigned)(g->numCUs * 8)), dim3(256), 0, s, (const unsigned *)g->dDenseSa,
+                       (unsigned long long)totalHits, (unsigned long long *)dPositions);
+    AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+    return AwFmSuccess;
+  }
+  return launchLocate(g, totalHits, (unsigned long long *)dPositions, s);
+}
+
+namespace {
+/* LF-walk + sampled-SA kernel over `totalHits` BWT positions stored in dPositions (in place) */
+enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions,
+                                 hipStream_t s) {
   {
     int lanes = lanesPerQuery(g);
     if (const char *env = getenv("AWFM_GPU_LOCATE_KERNEL")) { /* measurement knob: g8 | g4 | g2 | g1 */
@@ -625,7 +661,7 @@ enum AwFmReturnCode awfmGpuLocate(AwFmGpuIndex *g, const struct AwFmSearchRange 
       else if (!strcmp(env, "g1")) lanes = 1;
     }
     if (g->amino && lanes < 4) lanes = 4;
-    unsigned long long *pos = (unsigned long long *)dPositions;
+    unsigned long long *pos = dPositions;
     const unsigned long long th = totalHits;
 #define AWFM_LOC(AM, GG)                                                                                   \
   hipLaunchKernelGGL((locateKernel<AM, GG>), dim3(gridFor(th, g, locateKernel<AM, GG>, kThreads / GG)), \
@@ -642,6 +678,55 @@ enum AwFmReturnCode awfmGpuLocate(AwFmGpuIndex *g, const struct AwFmSearchRange 
 #undef AWFM_LOC
   }
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  return AwFmSuccess;
+}
+}  // namespace
+
+/* Optional: the full suffix array on the device (32-bit entries), computed once with the LF-walk kernel
+ * from the sampled SA, so that a locate becomes one gather.  enable = 0 drops it. */
+enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable) {
+  if (!g) {
+    setError("awfmGpuIndexSetDenseSa: null image");
+    return AwFmNullPtrError;
+  }
+  DeviceGuard guard(g->device);
+  std::lock_guard<std::mutex> lock(g->workMutex);
+  (void)hipDeviceSynchronize();
+  if (g->dDenseSa) (void)hipFree(g->dDenseSa);
+  g->dDenseSa = nullptr;
+  g->denseSaBytes = 0;
+  if (!enable) return AwFmSuccess;
+  const unsigned long long n = g->dev.bwtLength;
+  if (n >= (1ull << 32)) {
+    setError("awfmGpuIndexSetDenseSa: 32-bit entries need bwtLength < 2^32");
+    return AwFmUnsupportedVersionError;
+  }
+  unsigned *dense = nullptr;
+  unsigned long long *chunkBuf = nullptr;
+  const unsigned long long chunk = n < (1ull << 28) ? n : (1ull << 28);
+  AWFM_HIP_TRY(hipMalloc((void **)&dense, n * 4), AwFmAllocationFailure);
+  if (hipMalloc((void **)&chunkBuf, chunk * 8) != hipSuccess) {
+    (void)hipFree(dense);
+    setError("awfmGpuIndexSetDenseSa: hipMalloc of the work buffer failed");
+    return AwFmAllocationFailure;
+  }
+  enum AwFmReturnCode rc = AwFmSuccess;
+  for (unsigned long long first = 0; first < n && rc == AwFmSuccess; first += chunk) {
+    const unsigned long long count = n - first < chunk ? n - first : chunk;
+    hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, first, count);
+    rc = launchLocate(g, count, chunkBuf, (hipStream_t)0);
+    hipLaunchKernelGGL(narrowKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, count, dense + first);
+    if (hipGetLastError() != hipSuccess) rc = AwFmGeneralFailure;
+  }
+  if (hipDeviceSynchronize() != hipSuccess) rc = AwFmGeneralFailure;
+  (void)hipFree(chunkBuf);
+  if (rc != AwFmSuccess) {
+    (void)hipFree(dense);
+    setError("awfmGpuIndexSetDenseSa: construction failed");
+    return rc;
+  }
+  g->dDenseSa = dense;
+  g->denseSaBytes = n * 4;
   return AwFmSuccess;
 }
 

@@ -47,6 +47,8 @@ def parse():
     p.add_argument("--alphabet", choices=["dna", "amino"], default="dna")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--device-dense-sa", action="store_true",
+                   help="optional device-only full suffix array (same positions, a locate becomes one gather)")
     p.add_argument("--device-seed-k", type=int, default=0,
                    help="optional device-only deeper seed table (same results, fewer block reads); 0 = the index's own table")
     return p.parse_args()
@@ -88,6 +90,12 @@ def main():
         g.set_deep_seed(args.device_seed_k)
         torch.cuda.synchronize()
         deep_s = time.time() - t1
+    dense_s = 0.0
+    if args.device_dense_sa:
+        t1 = time.time()
+        g.set_dense_sa(True)
+        torch.cuda.synchronize()
+        dense_s = time.time() - t1
 
     # ---- this rank's query shard, resident in HBM ----
     first, _ = shard.shard_bounds(Q * world, world, rank)  # weak scaling: the global batch is Q*world k-mers
@@ -254,7 +262,8 @@ def main():
                    "hits_per_step_rank0": int(state["hits"]), "locate_kernels_ms": round(locate_ms, 3),
                    "index_build_s": round(build_s, 2),
                    "device_image_bytes": g.device_bytes, "device_seed_k": args.device_seed_k or args.seed_k,
-                   "device_seed_build_s": round(deep_s, 2)},
+                   "device_seed_build_s": round(deep_s, 2), "device_dense_sa": bool(args.device_dense_sa),
+                   "device_dense_sa_build_s": round(dense_s, 2)},
         "roofline": roofline,
         "cpu_baseline": cpu,
     }

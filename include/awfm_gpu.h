@@ -74,6 +74,11 @@ int awfmGpuIndexDevice(const AwFmGpuIndex *g);
  * index, its seed table and the .awfmi file are untouched.  Also read from $AWFM_GPU_DEEP_SEED_K when an
  * image is created. */
 enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK);
+/* Optional: keeps the full suffix array on the device (32-bit entries, 4 x bwtLength bytes: 12.4 GB for a
+ * GRCh38-sized index), reconstructed once from the sampled SA with the LF-walk kernel, so that locating a
+ * hit is one read instead of a chain of about ratio-1 dependent block reads.  Positions are bit-identical.
+ * enable = 0 drops it.  Needs bwtLength < 2^32. */
+enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable);
 /* Selects the search kernel variant for this image (default AUTO). */
 void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel);
 

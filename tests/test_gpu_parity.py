@@ -188,3 +188,27 @@ def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, requir
     assert np.array_equal(ranges2, ranges) and np.array_equal(counts2, cnt) and g.device_bytes == before
     g.destroy()
     ix.dealloc()
+
+
+@pytest.mark.parametrize("alphabet_name,ratio", [("dna", 8), ("dna", 255), ("amino", 5)])
+def test_device_dense_sa_keeps_positions_bit_identical(oracle, awfm, require_gpu, alphabet_name, ratio):
+    amino = alphabet_name == "amino"
+    letters = synth.AMINO_ALPHABET if amino else synth.DNA_ALPHABET
+    alpha, oalpha = (awfm.AwFmAlphabetAmino, oracle.AMINO) if amino else (awfm.AwFmAlphabetDna, oracle.DNA)
+    txt = synth.text(500 + ratio, 120000, letters)
+    ix = awfm.create_index(txt, alpha, ratio, 3)
+    oi = oracle.Index.from_text(txt.tobytes(), oalpha, ratio, 3)
+    chars, offsets = _mixed_queries(501, 4000, txt, letters, 2, 20)
+    sp, ep, _, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    g = awfm.GpuIndex(ix)
+    before = g.device_bytes
+    g.set_dense_sa(True)
+    assert g.device_bytes == before + 4 * ix.bwt_length
+    _, ho, p = g.locate_host(chars, offsets)
+    assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
+    g.set_dense_sa(False)
+    _, ho2, p2 = g.locate_host(chars, offsets)
+    assert np.array_equal(ho2, hit_off) and np.array_equal(p2, pos) and g.device_bytes == before
+    g.destroy()
+    ix.dealloc()
