@@ -4,7 +4,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libawfmindex_amd.so")
+LIB_PATH = os.environ.get("AWFM_LIB_PATH") or os.path.join(_HERE, "libawfmindex_amd.so")  # override: A/B builds
 _LIB = None
 
 AwFmAlphabetAmino, AwFmAlphabetDna, AwFmAlphabetRna = 1, 2, 3

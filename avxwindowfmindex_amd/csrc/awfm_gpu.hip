@@ -232,7 +232,7 @@ int lanesPerQuery(const AwFmGpuIndex *g) {
     case AWFM_GPU_KERNEL_GROUP2: lanes = 2; break;
     case AWFM_GPU_KERNEL_GROUP1: lanes = 1; break;
     default:
-      lanes = 2; /* measured on MI355X, GRCh38-sized index, 100 M random 21-mers: g8 19.6 ms, g4 16.0, g2 15.4, g1 17.7 */
+      lanes = 4; /* measured on MI355X, GRCh38-sized index, 100 M random 21-mers: g8 18.6 ms, g4 14.2, g2 14.5, g1 16.5 */
       if (const char *env = getenv("AWFM_GPU_KERNEL")) { /* measurement knob */
         if (!strcmp(env, "g8")) lanes = 8;
         else if (!strcmp(env, "g4")) lanes = 4;
@@ -244,13 +244,25 @@ int lanesPerQuery(const AwFmGpuIndex *g) {
   return lanes;
 }
 
+template <bool AMINO, int G, bool CSR, bool TALLY, bool NARROW>
+void launchSearchKernelN(const AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
+                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts,
+                         unsigned long long *dTally) {
+  const unsigned grid = gridFor(nq, g, searchKernel<AMINO, G, CSR, TALLY, NARROW>, kThreads / G);
+  hipLaunchKernelGGL((searchKernel<AMINO, G, CSR, TALLY, NARROW>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars, off,
+                     fixedLength, nq, rng, dCounts, dTally);
+}
+
 template <bool AMINO, int G, bool CSR, bool TALLY>
 void launchSearchKernel(const AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts,
                         unsigned long long *dTally) {
-  const unsigned grid = gridFor(nq, g, searchKernel<AMINO, G, CSR, TALLY>, kThreads / G);
-  hipLaunchKernelGGL((searchKernel<AMINO, G, CSR, TALLY>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars, off,
-                     fixedLength, nq, rng, dCounts, dTally);
+  /* amino images always have bwtLength < 2^32 (32-bit base counts) */
+  if (AMINO || g->dev.bwtLength < (1ull << 32))
+    launchSearchKernelN<AMINO, G, CSR, TALLY, true>(g, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);
+  else
+    launchSearchKernelN<AMINO, G, CSR, TALLY, AMINO ? true : false>(g, s, dChars, off, fixedLength, nq, rng, dCounts,
+                                                                    dTally);
 }
 
 template <bool TALLY>

@@ -71,7 +71,20 @@ __device__ __forceinline__ unsigned aminoCountWord(const uint4 &hi, unsigned slo
   return (unsigned)((slot == 2u ? c2x : c01) >> (slot == 1u ? 32u : 0u));
 }
 
-template <bool AMINO, int G, bool CSR, bool TALLY>
+/* one 16-byte piece of a BWT block (default cache policy: a non-temporal load measured 25 % slower) */
+__device__ __forceinline__ uint4 loadBlockPiece(const uint4 *p) { return *p; }
+
+/* BWT positions are 32-bit when bwtLength < 2^32 (NARROW): half the integer work of the range arithmetic */
+template <bool NARROW>
+struct PositionType {
+  typedef unsigned long long type;
+};
+template <>
+struct PositionType<true> {
+  typedef unsigned type;
+};
+
+template <bool AMINO, int G, bool CSR, bool TALLY, bool NARROW>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
     searchKernel(const DevIndex ix, const unsigned char *__restrict__ chars,
                  const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
@@ -80,6 +93,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
   constexpr int S = 8 / G;          /* pieces (and window dwords) per lane */
   constexpr int V = AMINO ? 2 : 1;  /* uint4 per piece */
   constexpr int kGroups = kThreads / G;
+  typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sPow[32];
   __shared__ AminoShared sAmino;
@@ -180,7 +194,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
       return (v >> (8u * (rel & 3u))) & 0xFFu;
     };
 
-    unsigned long long sp = 1, ep = 0;
+    pos_t sp = 1, ep = 0;
     int pos = -1;
     if (len != 0) {
       /* ---- seed (ref src/AwFmKmerTable.c:4-51) ---- */
@@ -247,8 +261,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
           const unsigned long long deepChars = ((1ull << DK) - 1ull) << (e - DK);
           if (((unsigned long long)allBad & deepChars) == 0ull) {
             const ulonglong2 r = ix.deepSeed[tail & ((1ull << (2u * DK)) - 1ull)];
-            sp = r.x;
-            ep = r.y;
+            sp = (pos_t)r.x;
+            ep = (pos_t)r.y;
             pos = (int)(len - DK) - 1;
             deep = true;
           }
@@ -258,36 +272,36 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
       if (seeded) {
         if (TALLY) tSeeded++;
         const ulonglong2 r = ix.seed[index];
-        sp = r.x;
-        ep = r.y;
+        sp = (pos_t)r.x;
+        ep = (pos_t)r.y;
         pos = (int)(len - K) - 1;
       } else if (!deep) { /* ref src/AwFmSearch.c:485-502 */
         const unsigned c = windowChar(len - 1u);
         const unsigned a = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
-        sp = sC[a];
-        ep = sC[a + 1] - 1ull;
+        sp = (pos_t)sC[a];
+        ep = (pos_t)(sC[a + 1] - 1ull);
         pos = (int)len - 2;
       }
     }
 
     /* ---- extension (ref src/AwFmParallelSearch.c:273-313; one step = ref src/AwFmSearch.c:42-159) ---- */
     while (pos >= 0 && sp <= ep) {
-      const unsigned long long q0 = sp - 1ull, q1 = ep;
+      const pos_t q0 = sp - 1, q1 = ep;
       const unsigned long long blk0 = q0 >> 8, blk1 = q1 >> 8;
-      const bool same = blk0 == blk1;
+      const bool same = (q0 >> 8) == (q1 >> 8);
       uint4 p0[S][V], p1[S][V];
 #pragma unroll
       for (int s = 0; s < S; s++)
 #pragma unroll
         for (int v = 0; v < V; v++) {
-          p0[s][v] = ix.blocks[(blk0 * 8ull + firstPiece + s) * V + v];
+          p0[s][v] = loadBlockPiece(ix.blocks + (blk0 * 8ull + firstPiece + s) * V + v);
           p1[s][v] = make_uint4(0u, 0u, 0u, 0u);
         }
       if (!same) {
 #pragma unroll
         for (int s = 0; s < S; s++)
 #pragma unroll
-          for (int v = 0; v < V; v++) p1[s][v] = ix.blocks[(blk1 * 8ull + firstPiece + s) * V + v];
+          for (int v = 0; v < V; v++) p1[s][v] = loadBlockPiece(ix.blocks + (blk1 * 8ull + firstPiece + s) * V + v);
       }
       unsigned c;
       if (__builtin_expect((unsigned)pos >= wb, 1))
@@ -301,7 +315,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
       const unsigned letter = AMINO ? aminoLetterIndex(sAmino, c) : nucLetterIndex(c);
       const unsigned local0 = (unsigned)q0 & 255u, local1 = (unsigned)q1 & 255u;
       unsigned n0 = 0, n1 = 0;
-      unsigned long long base0, base1;
+      pos_t base0, base1;
       if (AMINO) {
         const unsigned pm = sAmino.planeMask[letter < 24u ? letter : 23u];
         const unsigned ones = pm & 0xFFu, zeros = pm >> 8;
@@ -343,8 +357,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
             lo1 = (kLo % S) == (unsigned)s ? w1 : lo1;
             hi1 = (kHi % S) == (unsigned)s ? w1 : hi1;
           }
-          base0 = ((unsigned long long)groupShfl<G>(hi0, kHi / S) << 32) | groupShfl<G>(lo0, kLo / S);
-          base1 = ((unsigned long long)groupShfl<G>(hi1, kHi / S) << 32) | groupShfl<G>(lo1, kLo / S);
+          if (NARROW) { /* counts < 2^32: the high words are zero */
+            base0 = (pos_t)groupShfl<G>(lo0, kLo / S);
+            base1 = (pos_t)groupShfl<G>(lo1, kLo / S);
+          } else {
+            base0 = (pos_t)(((unsigned long long)groupShfl<G>(hi0, kHi / S) << 32) | groupShfl<G>(lo0, kLo / S));
+            base1 = (pos_t)(((unsigned long long)groupShfl<G>(hi1, kHi / S) << 32) | groupShfl<G>(lo1, kLo / S));
+          }
         } else {
           /* X: positions before the block that are not A,C,G,T or the sentinel */
           unsigned long long part0 = 0, part1 = 0;
@@ -356,20 +375,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
             part1 += high ? ((unsigned long long)w1 << 32) : (unsigned long long)w1;
           }
           const unsigned long long before0 = blk0 * 256ull, before1 = blk1 * 256ull;
-          base0 = before0 - groupSum64<G>(part0) - (ix.sentinelPos < before0 ? 1ull : 0ull);
-          base1 = before1 - groupSum64<G>(part1) - (ix.sentinelPos < before1 ? 1ull : 0ull);
+          base0 = (pos_t)(before0 - groupSum64<G>(part0) - (ix.sentinelPos < before0 ? 1ull : 0ull));
+          base1 = (pos_t)(before1 - groupSum64<G>(part1) - (ix.sentinelPos < before1 ? 1ull : 0ull));
         }
       }
       const unsigned packed = groupSum<G>(n0 | (n1 << 16));
-      const unsigned long long cLetter = sC[letter];
-      sp = cLetter + base0 + (packed & 0xFFFFu);
-      ep = cLetter + base1 + (packed >> 16) - 1ull;
+      const pos_t cLetter = (pos_t)sC[letter];
+      sp = cLetter + base0 + (pos_t)(packed & 0xFFFFu);
+      ep = cLetter + base1 + (pos_t)(packed >> 16) - (pos_t)1;
       pos--;
     }
 
     if (gl == 0) {
-      if (ranges) ranges[q] = make_ulonglong2(sp, ep);
-      if (counts) counts[q] = sp <= ep ? (unsigned)(ep - sp + 1ull) : 0u;
+      if (ranges) ranges[q] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
+      if (counts) counts[q] = sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u;
     }
   }
   if (TALLY && gl == 0) { /* one lane per group carries the group's counters */
