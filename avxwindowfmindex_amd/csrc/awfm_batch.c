@@ -67,25 +67,29 @@ static void packChars(void *p, uint64_t begin, uint64_t end, unsigned tid) {
     memcpy(c->chars + c->offsets[i], c->data[i].kmerString, c->data[i].kmerLength);
 }
 
-static bool packQueries(const struct AwFmKmerSearchList *list, uint64_t n, unsigned threads, uint8_t **charsOut,
-                        uint64_t **offsetsOut) {
-  uint64_t *offsets = malloc((n + 1) * sizeof(uint64_t));
+/* Packs the k-mers into page-locked staging buffers of the image.  When every k-mer has the same length
+ * the offsets array is dropped (*offsetsOut = NULL, *fixedOut = that length). */
+static bool packQueries(AwFmGpuIndex *g, const struct AwFmKmerSearchList *list, uint64_t n, unsigned threads,
+                        uint8_t **charsOut, uint64_t **offsetsOut, uint32_t *fixedOut) {
+  uint64_t *offsets = awfmGpuPinnedBuffer(g, 1, (n + 1) * sizeof(uint64_t));
   if (!offsets) return false;
   uint64_t total = 0;
+  const uint64_t firstLength = list->kmerSearchData[0].kmerLength;
+  bool uniform = firstLength != 0 && firstLength <= 0xFFFFFFFFull;
   for (uint64_t i = 0; i < n; i++) {
+    const uint64_t len = list->kmerSearchData[i].kmerLength;
     offsets[i] = total;
-    total += list->kmerSearchData[i].kmerLength;
+    total += len;
+    uniform &= len == firstLength;
   }
   offsets[n] = total;
-  uint8_t *chars = malloc(total ? total : 1);
-  if (!chars) {
-    free(offsets);
-    return false;
-  }
+  uint8_t *chars = awfmGpuPinnedBuffer(g, 0, total ? total : 1);
+  if (!chars) return false;
   struct packCtx ctx = {list->kmerSearchData, offsets, chars};
   awfmParallelFor(threads, n, packChars, &ctx);
   *charsOut = chars;
-  *offsetsOut = offsets;
+  *offsetsOut = uniform ? NULL : offsets;
+  *fixedOut = uniform ? (uint32_t)firstLength : 0;
   return true;
 }
 
@@ -110,24 +114,24 @@ void awFmParallelSearchCount(const struct AwFmIndex *_RESTRICT_ const index,
     fprintf(stderr, "awFmParallelSearchCount: no device image: %s\n", awfmGpuLastError());
     return;
   }
+  awfmGpuAosLock(g);
   uint8_t *chars = NULL;
   uint64_t *offsets = NULL;
-  uint32_t *counts = malloc(n * sizeof(uint32_t));
-  if (!counts || !packQueries(searchList, n, numThreads, &chars, &offsets)) {
-    fprintf(stderr, "awFmParallelSearchCount: host allocation failed\n");
-    free(counts);
+  uint32_t fixedLength = 0;
+  uint32_t *counts = awfmGpuPinnedBuffer(g, 2, n * sizeof(uint32_t));
+  if (!counts || !packQueries(g, searchList, n, numThreads, &chars, &offsets, &fixedLength)) {
+    fprintf(stderr, "awFmParallelSearchCount: host staging allocation failed: %s\n", awfmGpuLastError());
+    awfmGpuAosUnlock(g);
     return;
   }
-  const enum AwFmReturnCode rc = awfmGpuCountHost(g, chars, offsets, 0, n, NULL, counts);
+  const enum AwFmReturnCode rc = awfmGpuCountHost(g, chars, offsets, fixedLength, n, NULL, counts);
   if (rc == AwFmSuccess) {
     struct countCtx ctx = {searchList->kmerSearchData, counts};
     awfmParallelFor(numThreads, n, scatterCounts, &ctx);
   } else {
     fprintf(stderr, "awFmParallelSearchCount: GPU search failed (%d): %s\n", (int)rc, awfmGpuLastError());
   }
-  free(chars);
-  free(offsets);
-  free(counts);
+  awfmGpuAosUnlock(g);
 }
 
 struct locateCtx {
@@ -172,15 +176,17 @@ enum AwFmReturnCode awFmParallelSearchLocate(const struct AwFmIndex *_RESTRICT_ 
     fprintf(stderr, "awFmParallelSearchLocate: no device image: %s\n", awfmGpuLastError());
     return AwFmGeneralFailure;
   }
+  awfmGpuAosLock(g);
   uint8_t *chars = NULL;
   uint64_t *offsets = NULL;
-  uint64_t *hitOffsets = malloc((n + 1) * sizeof(uint64_t));
+  uint32_t fixedLength = 0;
+  uint64_t *hitOffsets = awfmGpuPinnedBuffer(g, 2, (n + 1) * sizeof(uint64_t));
   uint64_t *positions = NULL;
-  if (!hitOffsets || !packQueries(searchList, n, numThreads, &chars, &offsets)) {
-    free(hitOffsets);
+  if (!hitOffsets || !packQueries(g, searchList, n, numThreads, &chars, &offsets, &fixedLength)) {
+    awfmGpuAosUnlock(g);
     return AwFmAllocationFailure;
   }
-  enum AwFmReturnCode rc = awfmGpuLocateHost(g, chars, offsets, 0, n, NULL, hitOffsets, &positions);
+  enum AwFmReturnCode rc = awfmGpuLocateHost(g, chars, offsets, fixedLength, n, NULL, hitOffsets, &positions);
   if (rc == AwFmSuccess) {
     struct locateCtx ctx = {searchList->kmerSearchData, hitOffsets, positions, 0};
     awfmParallelFor(numThreads, n, scatterPositions, &ctx);
@@ -188,9 +194,7 @@ enum AwFmReturnCode awFmParallelSearchLocate(const struct AwFmIndex *_RESTRICT_ 
   } else {
     fprintf(stderr, "awFmParallelSearchLocate: GPU search failed (%d): %s\n", (int)rc, awfmGpuLastError());
   }
-  free(chars);
-  free(offsets);
-  free(hitOffsets);
   free(positions);
+  awfmGpuAosUnlock(g);
   return rc;
 }

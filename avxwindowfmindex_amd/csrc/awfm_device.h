@@ -345,7 +345,9 @@ struct AwFmGpuIndex {
   std::mutex workMutex;
   void *dWork = nullptr;
   size_t workBytes = 0;
-  void *hostStage = nullptr; /* pinned staging for small D2H results */
+  std::mutex aosMutex;       /* serialises the AoS entry points (they share the pinned buffers) */
+  void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t pinnedBytes[4] = {0, 0, 0, 0};
 };
 
 /* RAII hipSetDevice */

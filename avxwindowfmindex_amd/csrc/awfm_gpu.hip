@@ -458,7 +458,8 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
     if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
     if (g->dDenseSa) (void)hipFree(g->dDenseSa);
     if (g->dWork) (void)hipFree(g->dWork);
-    if (g->hostStage) (void)hipHostFree(g->hostStage);
+    for (int i = 0; i < 4; i++)
+      if (g->pinned[i]) (void)hipHostFree(g->pinned[i]);
   }
   delete g;
 }
@@ -485,6 +486,29 @@ void awfmGpuIndexRelease(const struct AwFmIndex *index) {
       }
   }
   awfmGpuIndexDestroy(g);
+}
+
+void *awfmGpuPinnedBuffer(AwFmGpuIndex *g, int slot, uint64_t bytes) {
+  if (!g || slot < 0 || slot > 3) return nullptr;
+  if (bytes <= g->pinnedBytes[slot]) return g->pinned[slot];
+  DeviceGuard guard(g->device);
+  if (g->pinned[slot]) (void)hipHostFree(g->pinned[slot]);
+  g->pinned[slot] = nullptr;
+  g->pinnedBytes[slot] = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  if (hipHostMalloc(&g->pinned[slot], want, hipHostMallocDefault) != hipSuccess) {
+    setError("awfmGpuPinnedBuffer: hipHostMalloc failed");
+    g->pinned[slot] = nullptr;
+    return nullptr;
+  }
+  g->pinnedBytes[slot] = want;
+  return g->pinned[slot];
+}
+void awfmGpuAosLock(AwFmGpuIndex *g) {
+  if (g) g->aosMutex.lock();
+}
+void awfmGpuAosUnlock(AwFmGpuIndex *g) {
+  if (g) g->aosMutex.unlock();
 }
 
 uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g) {

@@ -121,6 +121,13 @@ enum AwFmReturnCode awfmGpuLocate(AwFmGpuIndex *g, const struct AwFmSearchRange 
                                   const uint64_t *dHitOffsets, uint64_t numQueries, uint64_t totalHits,
                                   uint64_t *dPositions, void *stream);
 
+/* ---- pinned staging for the drop-in AoS entry points ---- */
+/* A grow-only page-locked host buffer cached in the image (slot 0..3); valid until the next call for the
+ * same slot.  awfmGpuAosLock/Unlock serialise the AoS entry points that share these buffers. */
+void *awfmGpuPinnedBuffer(AwFmGpuIndex *g, int slot, uint64_t bytes);
+void awfmGpuAosLock(AwFmGpuIndex *g);
+void awfmGpuAosUnlock(AwFmGpuIndex *g);
+
 /* ---- flat batch API on host buffers (upload, kernels, download) ---- */
 /* ranges / counts may be NULL. */
 enum AwFmReturnCode awfmGpuCountHost(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
