@@ -366,7 +366,7 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
   const uint64_t seedLen = awfmKmerTableLength(index->config.alphabetType, index->config.kmerLengthInSeedTable);
   const size_t seedBytes = seedLen * sizeof(struct AwFmSearchRange);
   const size_t saBytes = index->suffixArray.compressedByteLength;
-  const size_t saAlloc = alignUp(saBytes, 8) + 16;
+  const size_t saAlloc = alignUp(saBytes, 16) + 256; /* the locate kernel reads a 128-byte window at a sample */
 
   auto fail = [&](enum AwFmReturnCode rc) {
     awfmGpuIndexDestroy(g);
@@ -699,9 +699,22 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     if (g->amino && lanes < 4) lanes = 4;
     unsigned long long *pos = dPositions;
     const unsigned long long th = totalHits;
-#define AWFM_LOC(AM, GG)                                                                                   \
-  hipLaunchKernelGGL((locateKernel<AM, GG>), dim3(gridFor(th, g, locateKernel<AM, GG>, kThreads / GG)), \
+    if (g->dev.bwtLength / g->dev.saRatio >= (1ull << 40)) {
+      setError("awfmGpuLocate: more than 2^40 suffix-array samples are not supported");
+      return AwFmUnsupportedVersionError;
+    }
+    const bool pow2 = g->dev.saShift != 0xFFFFFFFFu;
+    const bool narrow = g->amino || g->dev.bwtLength < (1ull << 32);
+#define AWFM_LOC3(AM, GG, P2, NR)                                                                                  \
+  hipLaunchKernelGGL((walkKernel<AM, GG, P2, NR>), dim3(gridFor(th, g, walkKernel<AM, GG, P2, NR>, kThreads / GG)), \
                      dim3(kThreads), 0, s, g->dev, th, pos)
+#define AWFM_LOC(AM, GG)                                      \
+  do {                                                        \
+    if (pow2 && narrow) AWFM_LOC3(AM, GG, true, true);        \
+    else if (pow2) AWFM_LOC3(AM, GG, true, AM);               \
+    else if (narrow) AWFM_LOC3(AM, GG, false, true);          \
+    else AWFM_LOC3(AM, GG, false, AM);                        \
+  } while (0)
     if (g->amino) {
       if (lanes == 8) AWFM_LOC(true, 8);
       else AWFM_LOC(true, 4);
@@ -712,6 +725,9 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
       else AWFM_LOC(false, 1);
     }
 #undef AWFM_LOC
+#undef AWFM_LOC3
+    AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+    hipLaunchKernelGGL(finishKernel, dim3((unsigned)(g->numCUs * 8)), dim3(256), 0, s, g->dev, th, pos);
   }
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;

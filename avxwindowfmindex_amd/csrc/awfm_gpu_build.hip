@@ -738,7 +738,7 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndex(struct AwFmIndex **index, cons
   }
   ix->suffixArray.valueBitWidth = awfmSaWidth(n);
   ix->suffixArray.compressedByteLength = awfmSaPackedBytes(n, config->suffixArrayCompressionRatio);
-  const u64 saWords = (ix->suffixArray.compressedByteLength + 7) / 8 + 2;
+  const u64 saWords = (ix->suffixArray.compressedByteLength + 15) / 16 * 2 + 32; /* +256 B: 128-byte window reads */
   STEP(dPacked.alloc(saWords * 8));
   hipLaunchKernelGGL(packSampledSaKernel, dim3(gridOf(saWords)), dim3(256), 0, 0, dSa.as<u32>(),
                      awfmSaSampleCount(n, config->suffixArrayCompressionRatio),
