@@ -25,7 +25,7 @@ API_SYMBOLS = [
     "awFmReturnCodeIsFailure", "awFmReturnCodeIsSuccess", "awFmGetNumSequences",
 ]
 GPU_SYMBOLS = [
-    "awfmGpuDeviceCount", "awfmGpuLastError", "awfmGpuIndexCreate", "awfmGpuIndexDestroy", "awfmGpuIndexAcquire",
+    "awfmGpuDeviceCount", "awfmGpuLastError", "awfmGpuIndexCreate", "awfmGpuIndexDestroy", "awfmGpuIndexAcquire", "awfmGpuIndexAcquireAll",
     "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuIndexSetDeepSeed", "awfmGpuIndexSetDenseSa", "awfmGpuPinnedBuffer", "awfmGpuAosLock",
     "awfmGpuAosUnlock", "awfmGpuSearch",
     "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
@@ -119,6 +119,7 @@ def lib():
         "awfmGpuIndexCreate": (C.c_int, [IP, C.c_int, C.POINTER(vp)]),
         "awfmGpuIndexDestroy": (None, [vp]),
         "awfmGpuIndexAcquire": (vp, [IP]),
+        "awfmGpuIndexAcquireAll": (C.c_int, [IP, C.POINTER(vp), C.c_int]),
         "awfmGpuIndexRelease": (None, [IP]),
         "awfmGpuIndexDeviceBytes": (u64, [vp]),
         "awfmGpuIndexDevice": (C.c_int, [vp]),

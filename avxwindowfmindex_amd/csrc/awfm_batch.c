@@ -53,9 +53,13 @@ void awFmDeallocKmerSearchList(struct AwFmKmerSearchList *_RESTRICT_ const searc
   free(searchList);
 }
 
+#include <pthread.h>
+
+#define AWFM_MAX_IMAGES 16
+
 /* ---- pack: AoS k-mers -> flat chars + CSR offsets ---- */
 struct packCtx {
-  const struct AwFmKmerSearchData *data;
+  const struct AwFmKmerSearchData *data; /* first query of the shard */
   uint64_t *offsets;
   uint8_t *chars;
 };
@@ -67,17 +71,17 @@ static void packChars(void *p, uint64_t begin, uint64_t end, unsigned tid) {
     memcpy(c->chars + c->offsets[i], c->data[i].kmerString, c->data[i].kmerLength);
 }
 
-/* Packs the k-mers into page-locked staging buffers of the image.  When every k-mer has the same length
- * the offsets array is dropped (*offsetsOut = NULL, *fixedOut = that length). */
-static bool packQueries(AwFmGpuIndex *g, const struct AwFmKmerSearchList *list, uint64_t n, unsigned threads,
+/* Packs n k-mers starting at data[0] into page-locked staging buffers of the image.  When every k-mer has
+ * the same length the offsets array is dropped (*offsetsOut = NULL, *fixedOut = that length). */
+static bool packQueries(AwFmGpuIndex *g, const struct AwFmKmerSearchData *data, uint64_t n, unsigned threads,
                         uint8_t **charsOut, uint64_t **offsetsOut, uint32_t *fixedOut) {
   uint64_t *offsets = awfmGpuPinnedBuffer(g, 1, (n + 1) * sizeof(uint64_t));
   if (!offsets) return false;
   uint64_t total = 0;
-  const uint64_t firstLength = list->kmerSearchData[0].kmerLength;
+  const uint64_t firstLength = data[0].kmerLength;
   bool uniform = firstLength != 0 && firstLength <= 0xFFFFFFFFull;
   for (uint64_t i = 0; i < n; i++) {
-    const uint64_t len = list->kmerSearchData[i].kmerLength;
+    const uint64_t len = data[i].kmerLength;
     offsets[i] = total;
     total += len;
     uniform &= len == firstLength;
@@ -85,7 +89,7 @@ static bool packQueries(AwFmGpuIndex *g, const struct AwFmKmerSearchList *list, 
   offsets[n] = total;
   uint8_t *chars = awfmGpuPinnedBuffer(g, 0, total ? total : 1);
   if (!chars) return false;
-  struct packCtx ctx = {list->kmerSearchData, offsets, chars};
+  struct packCtx ctx = {data, offsets, chars};
   awfmParallelFor(threads, n, packChars, &ctx);
   *charsOut = chars;
   *offsetsOut = uniform ? NULL : offsets;
@@ -102,36 +106,6 @@ static void scatterCounts(void *p, uint64_t begin, uint64_t end, unsigned tid) {
   (void)tid;
   struct countCtx *c = p;
   for (uint64_t i = begin; i < end; i++) c->data[i].count = c->counts[i];
-}
-
-/* ref src/AwFmParallelSearch.c:159-220 */
-void awFmParallelSearchCount(const struct AwFmIndex *_RESTRICT_ const index,
-                             struct AwFmKmerSearchList *_RESTRICT_ const searchList, uint32_t numThreads) {
-  const uint64_t n = (uint32_t)searchList->count; /* the reference reads the count as uint32_t, :164 */
-  if (n == 0) return;
-  AwFmGpuIndex *g = awfmGpuIndexAcquire(index);
-  if (!g) {
-    fprintf(stderr, "awFmParallelSearchCount: no device image: %s\n", awfmGpuLastError());
-    return;
-  }
-  awfmGpuAosLock(g);
-  uint8_t *chars = NULL;
-  uint64_t *offsets = NULL;
-  uint32_t fixedLength = 0;
-  uint32_t *counts = awfmGpuPinnedBuffer(g, 2, n * sizeof(uint32_t));
-  if (!counts || !packQueries(g, searchList, n, numThreads, &chars, &offsets, &fixedLength)) {
-    fprintf(stderr, "awFmParallelSearchCount: host staging allocation failed: %s\n", awfmGpuLastError());
-    awfmGpuAosUnlock(g);
-    return;
-  }
-  const enum AwFmReturnCode rc = awfmGpuCountHost(g, chars, offsets, fixedLength, n, NULL, counts);
-  if (rc == AwFmSuccess) {
-    struct countCtx ctx = {searchList->kmerSearchData, counts};
-    awfmParallelFor(numThreads, n, scatterCounts, &ctx);
-  } else {
-    fprintf(stderr, "awFmParallelSearchCount: GPU search failed (%d): %s\n", (int)rc, awfmGpuLastError());
-  }
-  awfmGpuAosUnlock(g);
 }
 
 struct locateCtx {
@@ -165,36 +139,94 @@ static void scatterPositions(void *p, uint64_t begin, uint64_t end, unsigned tid
   }
 }
 
-/* ref src/AwFmParallelSearch.c:95-157 */
-enum AwFmReturnCode awFmParallelSearchLocate(const struct AwFmIndex *_RESTRICT_ const index,
-                                             struct AwFmKmerSearchList *_RESTRICT_ const searchList,
-                                             uint32_t numThreads) {
-  const uint64_t n = (uint32_t)searchList->count; /* :100 */
-  if (n == 0) return AwFmSuccess;
-  AwFmGpuIndex *g = awfmGpuIndexAcquire(index);
-  if (!g) {
-    fprintf(stderr, "awFmParallelSearchLocate: no device image: %s\n", awfmGpuLastError());
-    return AwFmGeneralFailure;
-  }
+/* ---- one contiguous shard of the list on one device image ---- */
+struct shardJob {
+  AwFmGpuIndex *image;
+  struct AwFmKmerSearchData *data; /* first query of the shard */
+  uint64_t n;
+  unsigned threads;
+  bool locate;
+  enum AwFmReturnCode rc;
+};
+
+static void *runShard(void *p) {
+  struct shardJob *job = p;
+  AwFmGpuIndex *g = job->image;
+  job->rc = AwFmSuccess;
+  if (job->n == 0) return NULL;
   awfmGpuAosLock(g);
   uint8_t *chars = NULL;
   uint64_t *offsets = NULL;
   uint32_t fixedLength = 0;
-  uint64_t *hitOffsets = awfmGpuPinnedBuffer(g, 2, (n + 1) * sizeof(uint64_t));
-  uint64_t *positions = NULL;
-  if (!hitOffsets || !packQueries(g, searchList, n, numThreads, &chars, &offsets, &fixedLength)) {
-    awfmGpuAosUnlock(g);
-    return AwFmAllocationFailure;
-  }
-  enum AwFmReturnCode rc = awfmGpuLocateHost(g, chars, offsets, fixedLength, n, NULL, hitOffsets, &positions);
-  if (rc == AwFmSuccess) {
-    struct locateCtx ctx = {searchList->kmerSearchData, hitOffsets, positions, 0};
-    awfmParallelFor(numThreads, n, scatterPositions, &ctx);
-    if (ctx.failed) rc = AwFmAllocationFailure;
+  void *out = awfmGpuPinnedBuffer(g, 2, (job->n + 1) * sizeof(uint64_t)); /* counts (u32) or hit offsets (u64) */
+  if (!out || !packQueries(g, job->data, job->n, job->threads, &chars, &offsets, &fixedLength)) {
+    job->rc = AwFmAllocationFailure;
+  } else if (!job->locate) {
+    job->rc = awfmGpuCountHost(g, chars, offsets, fixedLength, job->n, NULL, out);
+    if (job->rc == AwFmSuccess) {
+      struct countCtx ctx = {job->data, out};
+      awfmParallelFor(job->threads, job->n, scatterCounts, &ctx);
+    }
   } else {
-    fprintf(stderr, "awFmParallelSearchLocate: GPU search failed (%d): %s\n", (int)rc, awfmGpuLastError());
+    uint64_t *positions = NULL;
+    job->rc = awfmGpuLocateHost(g, chars, offsets, fixedLength, job->n, NULL, out, &positions);
+    if (job->rc == AwFmSuccess) {
+      struct locateCtx ctx = {job->data, out, positions, 0};
+      awfmParallelFor(job->threads, job->n, scatterPositions, &ctx);
+      if (ctx.failed) job->rc = AwFmAllocationFailure;
+    }
+    free(positions);
   }
-  free(positions);
   awfmGpuAosUnlock(g);
+  return NULL;
+}
+
+/* Shards the list contiguously over the images of $AWFM_GPU_DEVICES (one host thread per device; the
+ * shards are independent, there is no exchange: ref src/AwFmParallelSearch.c:103-129 treats 8-query
+ * blocks the same way).  Returns the first failure. */
+static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKmerSearchList *list, uint32_t numThreads,
+                                    bool locate, const char *who) {
+  const uint64_t n = (uint32_t)list->count; /* the reference reads the count as uint32_t (:100, :164) */
+  if (n == 0) return AwFmSuccess;
+  AwFmGpuIndex *images[AWFM_MAX_IMAGES];
+  const int numImages = awfmGpuIndexAcquireAll(index, images, AWFM_MAX_IMAGES);
+  if (numImages <= 0) {
+    fprintf(stderr, "%s: no device image: %s\n", who, awfmGpuLastError());
+    return AwFmGeneralFailure;
+  }
+  struct shardJob jobs[AWFM_MAX_IMAGES];
+  pthread_t threads[AWFM_MAX_IMAGES];
+  bool spawned[AWFM_MAX_IMAGES] = {false};
+  const uint64_t per = (n + (uint64_t)numImages - 1) / (uint64_t)numImages;
+  const unsigned threadsPerShard = numThreads / (unsigned)numImages > 0 ? numThreads / (unsigned)numImages : 1;
+  for (int i = 0; i < numImages; i++) {
+    const uint64_t begin = per * (uint64_t)i < n ? per * (uint64_t)i : n;
+    const uint64_t end = begin + per < n ? begin + per : n;
+    jobs[i] = (struct shardJob){images[i], list->kmerSearchData + begin, end - begin, threadsPerShard, locate, AwFmSuccess};
+  }
+  for (int i = 1; i < numImages; i++) spawned[i] = pthread_create(&threads[i], NULL, runShard, &jobs[i]) == 0;
+  runShard(&jobs[0]);
+  enum AwFmReturnCode rc = jobs[0].rc;
+  for (int i = 1; i < numImages; i++) {
+    if (spawned[i])
+      pthread_join(threads[i], NULL);
+    else
+      runShard(&jobs[i]);
+    if (rc == AwFmSuccess && jobs[i].rc != AwFmSuccess) rc = jobs[i].rc;
+  }
+  if (rc != AwFmSuccess) fprintf(stderr, "%s: GPU search failed (%d): %s\n", who, (int)rc, awfmGpuLastError());
   return rc;
+}
+
+/* ref src/AwFmParallelSearch.c:159-220 */
+void awFmParallelSearchCount(const struct AwFmIndex *_RESTRICT_ const index,
+                             struct AwFmKmerSearchList *_RESTRICT_ const searchList, uint32_t numThreads) {
+  (void)runBatch(index, searchList, numThreads, false, "awFmParallelSearchCount");
+}
+
+/* ref src/AwFmParallelSearch.c:95-157 */
+enum AwFmReturnCode awFmParallelSearchLocate(const struct AwFmIndex *_RESTRICT_ const index,
+                                             struct AwFmKmerSearchList *_RESTRICT_ const searchList,
+                                             uint32_t numThreads) {
+  return runBatch(index, searchList, numThreads, true, "awFmParallelSearchLocate");
 }

@@ -162,7 +162,12 @@ __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const un
 namespace {
 
 std::mutex tableMutex;
-std::vector<std::pair<const AwFmIndex *, AwFmGpuIndex *>> imageTable;
+struct ImageEntry {
+  const AwFmIndex *index;
+  int slot; /* position in the $AWFM_GPU_DEVICES list; 0 = the image awfmGpuIndexAcquire returns */
+  AwFmGpuIndex *image;
+};
+std::vector<ImageEntry> imageTable;
 
 
 /* Persistent grid: the kernels stride over the work, so the grid is exactly what is resident
@@ -307,7 +312,7 @@ AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void 
 
 void awfmGpuIndexRegister(const struct AwFmIndex *index, AwFmGpuIndex *g) {
   std::lock_guard<std::mutex> lock(tableMutex);
-  imageTable.emplace_back(index, g);
+  imageTable.push_back({index, 0, g});
 }
 
 extern "C" {
@@ -464,28 +469,62 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
   delete g;
 }
 
-AwFmGpuIndex *awfmGpuIndexAcquire(const struct AwFmIndex *index) {
+/* device ordinals the AoS entry points shard over: $AWFM_GPU_DEVICES = "all" or a comma list
+ * (repeats allowed); unset = one image on the default device (-1) */
+static int aosDevices(int *devs, int maxOut) {
+  int n = 0;
+  const char *env = getenv("AWFM_GPU_DEVICES");
+  if (env && !strcmp(env, "all")) {
+    const int count = awfmGpuDeviceCount();
+    for (int d = 0; d < count && n < maxOut; d++) devs[n++] = d;
+  } else if (env && *env) {
+    for (const char *c = env; *c && n < maxOut;) {
+      devs[n++] = atoi(c);
+      while (*c && *c != ',') c++;
+      if (*c == ',') c++;
+    }
+  }
+  if (n == 0) devs[n++] = -1;
+  return n;
+}
+
+int awfmGpuIndexAcquireAll(const struct AwFmIndex *index, AwFmGpuIndex **out, int maxOut) {
+  int devs[64];
+  const int numDevs = aosDevices(devs, 64);
   std::lock_guard<std::mutex> lock(tableMutex);
-  for (auto &e : imageTable)
-    if (e.first == index) return e.second;
+  int n = 0;
+  for (int slot = 0; slot < numDevs && n < maxOut; slot++) {
+    AwFmGpuIndex *g = nullptr;
+    for (auto &e : imageTable)
+      if (e.index == index && e.slot == slot) g = e.image;
+    if (!g) {
+      if (awfmGpuIndexCreate(index, devs[slot], &g) != AwFmSuccess) return n;
+      imageTable.push_back({index, slot, g});
+    }
+    out[n++] = g;
+  }
+  return n;
+}
+
+AwFmGpuIndex *awfmGpuIndexAcquire(const struct AwFmIndex *index) {
   AwFmGpuIndex *g = nullptr;
-  if (awfmGpuIndexCreate(index, -1, &g) != AwFmSuccess) return nullptr;
-  imageTable.emplace_back(index, g);
-  return g;
+  return awfmGpuIndexAcquireAll(index, &g, 1) == 1 ? g : nullptr;
 }
 
 void awfmGpuIndexRelease(const struct AwFmIndex *index) {
-  AwFmGpuIndex *g = nullptr;
+  std::vector<AwFmGpuIndex *> doomed;
   {
     std::lock_guard<std::mutex> lock(tableMutex);
-    for (size_t i = 0; i < imageTable.size(); i++)
-      if (imageTable[i].first == index) {
-        g = imageTable[i].second;
+    for (size_t i = 0; i < imageTable.size();) {
+      if (imageTable[i].index == index) {
+        doomed.push_back(imageTable[i].image);
         imageTable.erase(imageTable.begin() + (long)i);
-        break;
+      } else {
+        i++;
       }
+    }
   }
-  awfmGpuIndexDestroy(g);
+  for (AwFmGpuIndex *g : doomed) awfmGpuIndexDestroy(g);
 }
 
 void *awfmGpuPinnedBuffer(AwFmGpuIndex *g, int slot, uint64_t bytes) {

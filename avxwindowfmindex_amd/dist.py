@@ -39,6 +39,8 @@ def init(backend):
 
 def barrier(world, sync=None):
     import torch.distributed as dist
+    if sync is not None:
+        sync()
     if world > 1:
         dist.barrier()
     if sync is not None:

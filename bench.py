@@ -47,6 +47,8 @@ def parse():
     p.add_argument("--alphabet", choices=["dna", "amino"], default="dna")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (gloo: several ranks on one GPU, testing)")
+    p.add_argument("--force-device", type=int, default=-1, help="testing: every rank uses this GPU")
     p.add_argument("--device-dense-sa", action="store_true",
                    help="optional device-only full suffix array (same positions, a locate becomes one gather)")
     p.add_argument("--device-seed-k", type=int, default=0,
@@ -62,9 +64,11 @@ def main():
     from avxwindowfmindex_amd import _lib, api
     from avxwindowfmindex_amd import dist as shard
 
-    rank, world = shard.init("nccl")
-    if world == 1:
-        torch.cuda.set_device(0)
+    if args.force_device >= 0:
+        os.environ["LOCAL_RANK"] = str(args.force_device)
+    rank, world = shard.init(args.dist_backend)
+    if world == 1 or args.dist_backend != "nccl":
+        torch.cuda.set_device(max(args.force_device, 0) if world > 1 else 0)
     dev = torch.device("cuda", torch.cuda.current_device())
     L = _lib.lib()
     amino = args.alphabet == "amino"
@@ -170,7 +174,7 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t_start
-    elapsed = shard.max_over_ranks(elapsed, world, dev)
+    elapsed = shard.max_over_ranks(elapsed, world, dev if args.dist_backend == "nccl" else "cpu")
     ms_per_step = elapsed * 1e3 / args.steps
     value = world * Q / (elapsed / args.steps) / 1e6  # Mkmers/s over all ranks
     search_ms = float(np.mean([a.elapsed_time(b) for a, b in search_events]))

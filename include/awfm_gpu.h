@@ -63,7 +63,11 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
 void awfmGpuIndexDestroy(AwFmGpuIndex *g);
 /* Side table used by awFmParallelSearch*: image for a host index, created on first use. */
 AwFmGpuIndex *awfmGpuIndexAcquire(const struct AwFmIndex *index);
-/* Drops the side-table entry (called by awFmDeallocIndex). */
+/* Images of a host index on every device of $AWFM_GPU_DEVICES ("all" or a comma list of ordinals; unset: the
+ * one default image), created on first use; awFmParallelSearch* shard a batch over them.  Returns how
+ * many images were written to out[0..maxOut). */
+int awfmGpuIndexAcquireAll(const struct AwFmIndex *index, AwFmGpuIndex **out, int maxOut);
+/* Drops the side-table entries of the index (called by awFmDeallocIndex). */
 void awfmGpuIndexRelease(const struct AwFmIndex *index);
 uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g);
 int awfmGpuIndexDevice(const AwFmGpuIndex *g);

@@ -212,3 +212,54 @@ def test_device_dense_sa_keeps_positions_bit_identical(oracle, awfm, require_gpu
     assert np.array_equal(ho2, hit_off) and np.array_equal(p2, pos) and g.device_bytes == before
     g.destroy()
     ix.dealloc()
+
+
+def test_drop_in_api_shards_over_device_images(oracle, awfm, require_gpu, monkeypatch):
+    """AWFM_GPU_DEVICES lists the devices awFmParallelSearch* shard a batch over (one host thread and one
+    index replica per entry, contiguous shards, no exchange).  With one GPU on the box the list names it
+    three times: three images, three shards, results identical to the unsharded run."""
+    txt = synth.text(88, 120000)
+    chars, offsets = synth.mixed_queries(89, 5003, txt, synth.DNA_ALPHABET, 3, 30)
+    kmers = [chars[int(offsets[i]):int(offsets[i + 1])].tobytes() for i in range(5003)]
+    oi = oracle.Index.from_text(txt.tobytes(), oracle.DNA, 8, 7)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    monkeypatch.setenv("AWFM_GPU_DEVICES", "0,0,0")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 7)
+    lst = awfm.KmerSearchList(5003)
+    lst.fill(kmers)
+    awfm.parallel_search_count(ix, lst, 6)
+    assert np.array_equal(lst.counts(), cnt)
+    assert awfm.parallel_search_locate(ix, lst, 6) == awfm.AwFmSuccess
+    assert np.array_equal(lst.counts(), cnt)
+    for i in range(0, 5003, 11):
+        assert np.array_equal(lst.positions(i), pos[int(hit_off[i]):int(hit_off[i + 1])])
+    from avxwindowfmindex_amd import _lib
+    import ctypes as C
+    imgs = (C.c_void_p * 8)()
+    assert _lib.lib().awfmGpuIndexAcquireAll(ix.ptr, imgs, 8) == 3 and len({imgs[0], imgs[1], imgs[2]}) == 3
+    lst.dealloc()
+    ix.dealloc()
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4])  # AWFM_GPU_KERNEL_GROUP8 / 4 / 2 / 1 lanes per query
+@pytest.mark.parametrize("alphabet_name", ["dna", "amino"])
+def test_every_kernel_variant_is_bit_exact(oracle, awfm, require_gpu, kernel, alphabet_name):
+    amino = alphabet_name == "amino"
+    letters = synth.AMINO_ALPHABET if amino else synth.DNA_ALPHABET
+    alpha, oalpha = (awfm.AwFmAlphabetAmino, oracle.AMINO) if amino else (awfm.AwFmAlphabetDna, oracle.DNA)
+    txt = synth.text(700 + kernel, 90000, letters).copy()
+    txt[50:54] = ord("x")
+    k = 3 if amino else 7
+    ix = awfm.create_index(txt, alpha, 6, k)
+    oi = oracle.Index.from_text(txt.tobytes(), oalpha, 6, k)
+    chars, offsets = _mixed_queries(701, 5000, txt, letters, 1, 45, ambiguity=ord("z" if amino else "x"), upper=not amino)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    g = awfm.GpuIndex(ix)
+    g.set_kernel(kernel)
+    ranges, ho, p = g.locate_host(chars, offsets)
+    assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep)
+    assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
+    g.destroy()
+    ix.dealloc()
