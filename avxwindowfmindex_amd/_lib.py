@@ -110,6 +110,9 @@ def lib():
         "awFmFindDatabaseHitPositionSingle": (u64, [IP, u64, C.POINTER(C.c_int)]),
         "awFmNucleotideBacktraceReturnPreviousLetterIndex": (C.c_uint8, [IP, C.POINTER(u64)]),
         "awFmAminoBacktraceReturnPreviousLetterIndex": (C.c_uint8, [IP, C.POINTER(u64)]),
+        "awFmGetLocalSequencePositionFromIndexPosition": (C.c_int, [IP, C.c_size_t, C.POINTER(C.c_size_t),
+                                                                   C.POINTER(C.c_size_t)]),
+        "awFmGetHeaderStringFromSequenceNumber": (C.c_int, [IP, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t)]),
         "awFmSearchRangeLength": (C.c_size_t, [RP]),
         "awFmReturnCodeIsFailure": (C.c_bool, [C.c_int]),
         "awFmReturnCodeIsSuccess": (C.c_bool, [C.c_int]),

@@ -72,6 +72,20 @@ class Index:
         r = _lib.lib().awFmFindSearchRangeForString(self.ptr, bytes(kmer), len(kmer))
         return int(r.startPtr), int(r.endPtr)
 
+    def local_position(self, global_position):
+        """awFmGetLocalSequencePositionFromIndexPosition -> (sequence number, position in it)"""
+        seq, loc = C.c_size_t(0), C.c_size_t(0)
+        rc = _lib.lib().awFmGetLocalSequencePositionFromIndexPosition(self.ptr, global_position, C.byref(seq), C.byref(loc))
+        _check("awFmGetLocalSequencePositionFromIndexPosition", rc)
+        return int(seq.value), int(loc.value)
+
+    def header(self, sequence_number):
+        """awFmGetHeaderStringFromSequenceNumber"""
+        buf, n = C.c_char_p(), C.c_size_t(0)
+        rc = _lib.lib().awFmGetHeaderStringFromSequenceNumber(self.ptr, sequence_number, C.byref(buf), C.byref(n))
+        _check("awFmGetHeaderStringFromSequenceNumber", rc)
+        return C.string_at(buf, n.value)
+
     def dealloc(self):
         if self.ptr:
             _lib.lib().awFmDeallocIndex(self.ptr)
@@ -119,6 +133,20 @@ def gpu_create_index(sequence, alphabet=AwFmAlphabetDna, sa_ratio=8, seed_k=8, k
         rc = L.awfmGpuCreateIndex(C.byref(out), C.byref(cfg), holder.ctypes.data, seq.size, 0,
                                   file_src.encode() if file_src else None, device)
     _check("awfmGpuCreateIndex", rc, ok=(AwFmFileWriteOkay,))
+    ix = Index(out)
+    ix.file_src = file_src
+    return ix
+
+
+def create_index_from_fasta(fasta_src, alphabet=AwFmAlphabetDna, sa_ratio=8, seed_k=8, keep_sa_in_memory=True,
+                            store_sequence=False, file_src=None):
+    """awFmCreateIndexFromFasta (ref src/AwFmIndex.h:196-200)"""
+    cfg = _lib.AwFmIndexConfiguration(sa_ratio, seed_k, alphabet, keep_sa_in_memory, store_sequence)
+    if file_src is None:
+        file_src = fasta_src + ".awfmi"
+    out = C.POINTER(_lib.AwFmIndex)()
+    rc = _lib.lib().awFmCreateIndexFromFasta(C.byref(out), C.byref(cfg), fasta_src.encode(), file_src.encode())
+    _check("awFmCreateIndexFromFasta", rc, ok=(AwFmFileWriteOkay,))
     ix = Index(out)
     ix.file_src = file_src
     return ix

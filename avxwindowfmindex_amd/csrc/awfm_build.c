@@ -100,6 +100,14 @@ enum AwFmReturnCode awFmCreateIndex(struct AwFmIndex *_RESTRICT_ *index,
                                     struct AwFmIndexConfiguration *_RESTRICT_ const config,
                                     const uint8_t *_RESTRICT_ const sequence, const size_t sequenceLength,
                                     const char *_RESTRICT_ const fileSrc) {
+  return awfmCreateIndexWithFasta((struct AwFmIndex **)index, config, sequence, sequenceLength, fileSrc, NULL);
+}
+
+/* the build shared by awFmCreateIndex and awFmCreateIndexFromFasta (ref src/AwFmCreate.c:31-137, :140-279);
+ * takes ownership of fastaVector on success */
+enum AwFmReturnCode awfmCreateIndexWithFasta(struct AwFmIndex **index, const struct AwFmIndexConfiguration *config,
+                                             const uint8_t *sequence, size_t sequenceLength, const char *fileSrc,
+                                             struct FastaVector *fastaVector) {
   if (!config || !sequence || !fileSrc) return AwFmNullPtrError;
   *index = NULL;
   const bool amino = config->alphabetType == AwFmAlphabetAmino;
@@ -120,7 +128,7 @@ enum AwFmReturnCode awFmCreateIndex(struct AwFmIndex *_RESTRICT_ *index,
     return AwFmAllocationFailure;
   }
   ix->versionNumber = AWFM_VERSION_NUMBER;
-  ix->featureFlags = 0;
+  ix->featureFlags = fastaVector ? (1u << AWFM_FEATURE_BIT_FASTA_VECTOR) : 0u;
 
   if (awfmSuffixSort(text, saLength, sa) != 0) {
     free(text);
@@ -146,7 +154,9 @@ enum AwFmReturnCode awFmCreateIndex(struct AwFmIndex *_RESTRICT_ *index,
   ix->suffixArrayFileOffset = awfmSuffixArrayFileOffset(ix);
   ix->sequenceFileOffset = awfmSequenceFileOffset(ix);
 
+  ix->fastaVector = fastaVector; /* the trailer of the file is written from it */
   const enum AwFmReturnCode rc = awFmWriteIndexToFile(ix, sequence, sequenceLength, fileSrc);
+  if (awFmReturnCodeIsFailure(rc)) ix->fastaVector = NULL; /* the caller keeps ownership on failure */
 
   if (!config->keepSuffixArrayInMemory) { /* ref src/AwFmCreate.c:128-131 */
     free(ix->suffixArray.values);
@@ -154,13 +164,4 @@ enum AwFmReturnCode awFmCreateIndex(struct AwFmIndex *_RESTRICT_ *index,
   }
   *index = ix;
   return rc;
-}
-
-/* ref src/AwFmCreate.c:140-279: FASTA parsing/metadata (FastaVector) is out of scope */
-enum AwFmReturnCode awFmCreateIndexFromFasta(struct AwFmIndex *_RESTRICT_ *index,
-                                             struct AwFmIndexConfiguration *_RESTRICT_ const config,
-                                             const char *fastaSrc, const char *_RESTRICT_ const indexFileSrc) {
-  if (!config || !fastaSrc || !indexFileSrc) return AwFmNullPtrError;
-  *index = NULL;
-  return AwFmUnsupportedVersionError;
 }

@@ -27,6 +27,35 @@ size_t awfmSuffixArrayFileOffset(const struct AwFmIndex *ix) {
 static bool put(FILE *f, const void *p, size_t bytes) { return bytes == 0 || fwrite(p, 1, bytes, f) == bytes; }
 static bool get(FILE *f, void *p, size_t bytes) { return bytes == 0 || fread(p, 1, bytes, f) == bytes; }
 
+/* FASTA trailer (ref src/AwFmFile.c:157-187): header length, record count, header characters, records */
+static bool putFastaTrailer(FILE *f, const struct AwFmIndex *index) {
+  const struct FastaVector *fv = index->fastaVector;
+  if (!fv || (index->featureFlags & (1u << AWFM_FEATURE_BIT_FASTA_VECTOR)) == 0) return true;
+  return put(f, &fv->headerLength, sizeof(size_t)) && put(f, &fv->numRecords, sizeof(size_t)) &&
+         put(f, fv->headers, fv->headerLength) && put(f, fv->records, fv->numRecords * sizeof(struct AwfmFastaRecord));
+}
+
+/* ref src/AwFmFile.c:360-440 */
+static bool getFastaTrailer(FILE *f, struct AwFmIndex *ix) {
+  if ((ix->featureFlags & (1u << AWFM_FEATURE_BIT_FASTA_VECTOR)) == 0) return true;
+  if (fseek(f, (long)(ix->suffixArrayFileOffset + ix->suffixArray.compressedByteLength), SEEK_SET) != 0) return false;
+  struct FastaVector *fv = calloc(1, sizeof *fv);
+  if (!fv) return false;
+  bool ok = get(f, &fv->headerLength, sizeof(size_t)) && get(f, &fv->numRecords, sizeof(size_t));
+  if (ok) {
+    fv->headers = malloc(fv->headerLength ? fv->headerLength : 1);
+    fv->records = malloc((fv->numRecords ? fv->numRecords : 1) * sizeof(struct AwfmFastaRecord));
+    ok = fv->headers && fv->records && get(f, fv->headers, fv->headerLength) &&
+         get(f, fv->records, fv->numRecords * sizeof(struct AwfmFastaRecord));
+  }
+  if (!ok) {
+    awfmFastaVectorFree(fv);
+    return false;
+  }
+  ix->fastaVector = fv;
+  return true;
+}
+
 /* ref src/AwFmFile.c:20-193 */
 enum AwFmReturnCode awFmWriteIndexToFile(struct AwFmIndex *_RESTRICT_ const index,
                                          const uint8_t *_RESTRICT_ const sequence, const uint64_t sequenceLength,
@@ -49,7 +78,7 @@ enum AwFmReturnCode awFmWriteIndexToFile(struct AwFmIndex *_RESTRICT_ const inde
           awfmKmerTableLength(index->config.alphabetType, index->config.kmerLengthInSeedTable) *
               sizeof(struct AwFmSearchRange)) &&
       (!index->config.storeOriginalSequence || put(f, sequence, sequenceLength)) &&
-      put(f, index->suffixArray.values, index->suffixArray.compressedByteLength);
+      put(f, index->suffixArray.values, index->suffixArray.compressedByteLength) && putFastaTrailer(f, index);
   if (!ok) {
     fclose(f);
     index->fileHandle = NULL;
@@ -60,7 +89,7 @@ enum AwFmReturnCode awFmWriteIndexToFile(struct AwFmIndex *_RESTRICT_ const inde
   return AwFmFileWriteOkay;
 }
 
-/* ref src/AwFmFile.c:195-449 (the FastaVector trailer, if present, is skipped) */
+/* ref src/AwFmFile.c:195-449 (with the FASTA trailer when the feature flag is set) */
 enum AwFmReturnCode awFmReadIndexFromFile(struct AwFmIndex *_RESTRICT_ *_RESTRICT_ index, const char *fileSrc,
                                           const bool keepSuffixArrayInMemory) {
   if (!fileSrc) return AwFmNoFileSrcGiven;
@@ -121,6 +150,10 @@ enum AwFmReturnCode awFmReadIndexFromFile(struct AwFmIndex *_RESTRICT_ *_RESTRIC
       awFmDeallocIndex(ix);
       return AwFmFileReadFail;
     }
+  }
+  if (!getFastaTrailer(f, ix)) {
+    awFmDeallocIndex(ix);
+    return AwFmFileReadFail;
   }
   *index = ix;
   return AwFmFileReadOkay;

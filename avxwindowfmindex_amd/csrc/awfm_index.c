@@ -39,6 +39,7 @@ void awFmDeallocIndex(struct AwFmIndex *index) {
   free(index->prefixSums);
   free(index->kmerSeedTable);
   free(index->suffixArray.values);
+  awfmFastaVectorFree(index->fastaVector);
   free(index);
 }
 
@@ -50,9 +51,3 @@ size_t awFmSearchRangeLength(const struct AwFmSearchRange *_RESTRICT_ const rang
 /* ref src/AwFmIndexStruct.c:141-147 */
 bool awFmReturnCodeIsFailure(const enum AwFmReturnCode rc) { return rc < 0; }
 bool awFmReturnCodeIsSuccess(const enum AwFmReturnCode rc) { return rc >= 0; }
-
-/* ref src/AwFmIndexStruct.c:149-155: no FASTA metadata in this library */
-uint32_t awFmGetNumSequences(const struct AwFmIndex *_RESTRICT_ const index) {
-  (void)index;
-  return 1;
-}

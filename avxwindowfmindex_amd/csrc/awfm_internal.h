@@ -13,9 +13,28 @@
 #define AWFM_FEATURE_BIT_FASTA_VECTOR 0 /* ref src/AwFmIndexStruct.h:10 */
 #define AWFM_SA_PAD_BYTES 8             /* ref src/AwFmSuffixArray.c:9 */
 
+/* record table of a multi-FASTA index (this library's own definition of the type the reference header
+ * only names; ref src/AwFmIndex.h:107) */
+struct AwfmFastaRecord {
+  size_t headerEndPosition;   /* end of this record's header in the concatenated header string */
+  size_t sequenceEndPosition; /* end of this record's residues in the concatenated text (terminator excluded) */
+};
+struct FastaVector {
+  char *headers;
+  size_t headerLength;
+  struct AwfmFastaRecord *records;
+  size_t numRecords;
+};
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* ---- awfm_fasta.c / awfm_build.c ---- */
+void awfmFastaVectorFree(struct FastaVector *fv);
+enum AwFmReturnCode awfmCreateIndexWithFasta(struct AwFmIndex **index, const struct AwFmIndexConfiguration *config,
+                                             const uint8_t *sequence, size_t sequenceLength, const char *fileSrc,
+                                             struct FastaVector *fastaVector);
 
 /* ---- awfm_letters.c (ref src/AwFmLetter.c) ---- */
 uint8_t awfmNucAsciiToIndex(uint8_t c);

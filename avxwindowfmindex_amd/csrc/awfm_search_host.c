@@ -183,24 +183,3 @@ uint64_t *awFmFindDatabaseHitPositions(const struct AwFmIndex *_RESTRICT_ const 
   *fileAccessResult = AwFmFileReadOkay;
   return positions;
 }
-
-/* FASTA metadata is not carried by this library (ref src/AwFmSearch.c:284-315) */
-enum AwFmReturnCode awFmGetLocalSequencePositionFromIndexPosition(const struct AwFmIndex *_RESTRICT_ const index,
-                                                                  size_t globalPosition, size_t *sequenceNumber,
-                                                                  size_t *localSequencePosition) {
-  (void)index;
-  (void)globalPosition;
-  (void)sequenceNumber;
-  (void)localSequencePosition;
-  return AwFmUnsupportedVersionError;
-}
-
-enum AwFmReturnCode awFmGetHeaderStringFromSequenceNumber(const struct AwFmIndex *_RESTRICT_ const index,
-                                                          size_t sequenceNumber, char **headerBuffer,
-                                                          size_t *headerLength) {
-  (void)index;
-  (void)sequenceNumber;
-  (void)headerBuffer;
-  (void)headerLength;
-  return AwFmUnsupportedVersionError;
-}

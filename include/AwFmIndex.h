@@ -8,6 +8,8 @@
  * declaration it replaces.  Differences, all ABI-neutral:
  *   - FastaVector.h / <immintrin.h> are not included; `struct FastaVector` is
  *     opaque and the 256-bit plane type is a 32-byte aligned uint64_t[4].
+ *   - `struct FastaVector` is this library's own record table (the reference's comes from a
+ *     submodule that is not part of its tree); only its pointer appears in the ABI.
  *   - awFmParallelSearchCount / awFmParallelSearchLocate run on the GPU
  *     (HIP, gfx950).  There is no CPU fallback: without a usable device Locate
  *     returns AwFmGeneralFailure and Count leaves the list untouched and
@@ -163,9 +165,10 @@ enum AwFmReturnCode awFmCreateIndex(struct AwFmIndex *_RESTRICT_ *index,
                                     const uint8_t *_RESTRICT_ const sequence, const size_t sequenceLength,
                                     const char *_RESTRICT_ const fileSrc);
 
-/* ref src/AwFmIndex.h:196-200 / src/AwFmCreate.c:140-279.  FASTA bookkeeping
- * (FastaVector) is out of scope for this library: returns
- * AwFmUnsupportedVersionError. */
+/* ref src/AwFmIndex.h:196-200 / src/AwFmCreate.c:140-279.  The records of a multi-FASTA
+ * file are indexed as one text with a terminator after every record (it becomes the
+ * ambiguity letter, so no k-mer matches across records); headers and record boundaries
+ * are kept for the two lookups below and stored in the .awfmi trailer. */
 enum AwFmReturnCode awFmCreateIndexFromFasta(struct AwFmIndex *_RESTRICT_ *index,
                                              struct AwFmIndexConfiguration *_RESTRICT_ const config,
                                              const char *fastaSrc, const char *_RESTRICT_ const indexFileSrc);
@@ -238,8 +241,8 @@ uint64_t awFmFindDatabaseHitPositionSingle(const struct AwFmIndex *_RESTRICT_ co
                                            const uint64_t bwtPosition,
                                            enum AwFmReturnCode *_RESTRICT_ fileAccessResult);
 
-/* ref src/AwFmIndex.h:602-604 / src/AwFmSearch.c:284-301: needs FastaVector
- * metadata, which this library does not carry: AwFmUnsupportedVersionError */
+/* ref src/AwFmIndex.h:602-604 / src/AwFmSearch.c:284-301: AwFmUnsupportedVersionError for an
+ * index that was not built from FASTA, AwFmIllegalPositionError outside every record */
 enum AwFmReturnCode awFmGetLocalSequencePositionFromIndexPosition(const struct AwFmIndex *_RESTRICT_ const index,
                                                                   size_t globalPosition, size_t *sequenceNumber,
                                                                   size_t *localSequencePosition);
@@ -252,7 +255,8 @@ uint8_t awFmNucleotideBacktraceReturnPreviousLetterIndex(const struct AwFmIndex 
 uint8_t awFmAminoBacktraceReturnPreviousLetterIndex(const struct AwFmIndex *_RESTRICT_ const index,
                                                     uint64_t *bwtPosition);
 
-/* ref src/AwFmIndex.h:662-664 / src/AwFmSearch.c:303-315: AwFmUnsupportedVersionError */
+/* ref src/AwFmIndex.h:662-664 / src/AwFmSearch.c:303-315: *headerBuffer points into the index
+ * (not NUL terminated) */
 enum AwFmReturnCode awFmGetHeaderStringFromSequenceNumber(const struct AwFmIndex *_RESTRICT_ const index,
                                                           size_t sequenceNumber, char **headerBuffer,
                                                           size_t *headerLength);
@@ -264,7 +268,7 @@ size_t awFmSearchRangeLength(const struct AwFmSearchRange *_RESTRICT_ const rang
 bool awFmReturnCodeIsFailure(const enum AwFmReturnCode rc);
 bool awFmReturnCodeIsSuccess(const enum AwFmReturnCode rc);
 
-/* ref src/AwFmIndex.h:720 / src/AwFmIndexStruct.c:149-155: 1 without FASTA metadata */
+/* ref src/AwFmIndex.h:720 / src/AwFmIndexStruct.c:149-155: 1 for an index not built from FASTA */
 uint32_t awFmGetNumSequences(const struct AwFmIndex *_RESTRICT_ const index);
 
 #ifdef __cplusplus

@@ -176,7 +176,7 @@ def test_search_list_ownership_and_return_codes(awfm):
     out = C.POINTER(_lib.AwFmIndex)()
     cfg = _lib.AwFmIndexConfiguration(8, 4, 2, True, False)
     assert L.awFmCreateIndex(C.byref(out), None, None, 0, b"x") == -4
-    assert L.awFmCreateIndexFromFasta(C.byref(out), C.byref(cfg), b"a.fa", b"a.awfmi") == -2
+    assert L.awFmCreateIndexFromFasta(C.byref(out), C.byref(cfg), b"/nonexistent/a.fa", b"a.awfmi") == -10  # AwFmFileOpenFail
 
 
 def test_batch_search_fails_loudly_without_a_gpu(awfm):
