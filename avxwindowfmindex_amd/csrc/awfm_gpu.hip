@@ -44,30 +44,31 @@ namespace {
 
 /* ------------------------------------------------------------------ locate kernels */
 
-/* dLengths[i] = range length (ref src/AwFmIndexStruct.c:126-130) */
-__global__ void rangeLengthKernel(const ulonglong2 *__restrict__ ranges, unsigned long long n,
-                                  unsigned long long *__restrict__ lengths) {
-  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) {
-    const ulonglong2 r = ranges[i];
-    lengths[i] = r.x <= r.y ? r.y - r.x + 1ull : 0ull;
-  }
-}
-
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 4;
 constexpr int kScanTile = kScanThreads * kScanItems;
 
 /* per-tile sums */
+/* element i of a scan input: a plain u64 array, or the length of range i (ref src/AwFmIndexStruct.c:126-130) */
+template <bool FROM_RANGES>
+__device__ __forceinline__ unsigned long long scanInput(const void *in, unsigned long long i) {
+  if (FROM_RANGES) {
+    const ulonglong2 r = ((const ulonglong2 *)in)[i];
+    return r.x <= r.y ? r.y - r.x + 1ull : 0ull;
+  }
+  return ((const unsigned long long *)in)[i];
+}
+
+template <bool FROM_RANGES>
 __global__ void __launch_bounds__(kScanThreads)
-    scanReduceKernel(const unsigned long long *__restrict__ in, unsigned long long n,
+    scanReduceKernel(const void *__restrict__ in, unsigned long long n,
                      unsigned long long *__restrict__ tileSums) {
   __shared__ unsigned long long sWave[kScanThreads / 64];
   const unsigned long long base = (unsigned long long)blockIdx.x * kScanTile;
   unsigned long long v = 0;
   for (int k = 0; k < kScanItems; k++) {
     const unsigned long long i = base + (unsigned long long)k * kScanThreads + threadIdx.x;
-    if (i < n) v += in[i];
+    if (i < n) v += scanInput<FROM_RANGES>(in, i);
   }
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
   if ((threadIdx.x & 63) == 0) sWave[threadIdx.x >> 6] = v;
@@ -81,8 +82,9 @@ __global__ void __launch_bounds__(kScanThreads)
 
 /* exclusive scan of one tile given the tile's offset (tileOffsets may be NULL for a single tile);
  * also writes the grand total to out[n] when writeTotal */
+template <bool FROM_RANGES>
 __global__ void __launch_bounds__(kScanThreads)
-    scanTileKernel(const unsigned long long *__restrict__ in, unsigned long long n,
+    scanTileKernel(const void *__restrict__ in, unsigned long long n,
                    const unsigned long long *__restrict__ tileOffsets, unsigned long long *__restrict__ out,
                    int writeTotal) {
   __shared__ unsigned long long sWave[kScanThreads / 64];
@@ -90,7 +92,7 @@ __global__ void __launch_bounds__(kScanThreads)
   unsigned long long vals[kScanItems];
   unsigned long long sum = 0;
   for (int k = 0; k < kScanItems; k++) {
-    vals[k] = base + k < n ? in[base + k] : 0ull;
+    vals[k] = base + k < n ? scanInput<FROM_RANGES>(in, base + k) : 0ull;
     sum += vals[k];
   }
   /* inclusive scan of the per-thread sums inside the wave */
@@ -635,9 +637,9 @@ enum AwFmReturnCode awfmGpuSearchTally(AwFmGpuIndex *g, const uint8_t *dChars, c
   return AwFmSuccess;
 }
 
-/* scratch: range lengths (n) + tile sums per level */
+/* scratch: tile sums (and their scanned offsets) per level */
 uint64_t awfmGpuScanScratchBytes(uint64_t numQueries) {
-  uint64_t words = numQueries + 1;
+  uint64_t words = 4;
   uint64_t level = numQueries;
   while (level > (uint64_t)kScanTile) {
     level = (level + kScanTile - 1) / kScanTile;
@@ -648,26 +650,30 @@ uint64_t awfmGpuScanScratchBytes(uint64_t numQueries) {
 
 namespace {
 /* exclusive scan of in[0..n) into out[0..n] (out[n] = total), recursive over tiles */
-enum AwFmReturnCode scanRecursive(const unsigned long long *in, uint64_t n, unsigned long long *out,
-                                  unsigned long long *scratch, hipStream_t s) {
+extern "C++" {
+template <bool FROM_RANGES>
+enum AwFmReturnCode scanRecursive(const void *in, uint64_t n, unsigned long long *out, unsigned long long *scratch,
+                                  hipStream_t s) {
   const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
   if (tiles <= 1) {
-    hipLaunchKernelGGL(scanTileKernel, dim3(1), dim3(kScanThreads), 0, s, in, (unsigned long long)n,
+    hipLaunchKernelGGL(scanTileKernel<FROM_RANGES>, dim3(1), dim3(kScanThreads), 0, s, in, (unsigned long long)n,
                        (const unsigned long long *)nullptr, out, 1);
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
   }
   unsigned long long *sums = scratch;
   unsigned long long *offs = scratch + tiles;
-  hipLaunchKernelGGL(scanReduceKernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, (unsigned long long)n, sums);
+  hipLaunchKernelGGL(scanReduceKernel<FROM_RANGES>, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in,
+                     (unsigned long long)n, sums);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-  const enum AwFmReturnCode rc = scanRecursive(sums, tiles, offs, scratch + 2 * tiles + 2, s);
+  const enum AwFmReturnCode rc = scanRecursive<false>(sums, tiles, offs, scratch + 2 * tiles + 2, s);
   if (rc != AwFmSuccess) return rc;
-  hipLaunchKernelGGL(scanTileKernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in, (unsigned long long)n,
-                     (const unsigned long long *)offs, out, 1);
+  hipLaunchKernelGGL(scanTileKernel<FROM_RANGES>, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, in,
+                     (unsigned long long)n, (const unsigned long long *)offs, out, 1);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
 }
+}  // extern "C++"
 }  // namespace
 
 enum AwFmReturnCode awfmGpuHitOffsets(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges, uint64_t numQueries,
@@ -684,12 +690,9 @@ enum AwFmReturnCode awfmGpuHitOffsets(AwFmGpuIndex *g, const struct AwFmSearchRa
     AWFM_HIP_TRY(hipStreamSynchronize(s), AwFmGeneralFailure);
     return AwFmSuccess;
   }
-  unsigned long long *lengths = (unsigned long long *)dScratch;
-  hipLaunchKernelGGL(rangeLengthKernel, dim3((unsigned)((numQueries + 255) / 256)), dim3(256), 0, s,
-                     (const ulonglong2 *)dRanges, (unsigned long long)numQueries, lengths);
-  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  /* the scan reads the ranges directly (lengths are formed on the fly) */
   const enum AwFmReturnCode rc =
-      scanRecursive(lengths, numQueries, (unsigned long long *)dHitOffsets, lengths + numQueries + 1, s);
+      scanRecursive<true>(dRanges, numQueries, (unsigned long long *)dHitOffsets, (unsigned long long *)dScratch, s);
   if (rc != AwFmSuccess) return rc;
   AWFM_HIP_TRY(hipMemcpyAsync(totalHits, dHitOffsets + numQueries, 8, hipMemcpyDeviceToHost, s), AwFmGeneralFailure);
   AWFM_HIP_TRY(hipStreamSynchronize(s), AwFmGeneralFailure);

@@ -147,7 +147,8 @@ def main():
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        g.search(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr(), d_counts.data_ptr(), stream)
+        g.search(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr(),
+                 d_counts.data_ptr() if args.mode == "count" else 0, stream)  # locate needs the ranges only
         if record:
             e1.record()
             search_events.append((e0, e1))
@@ -260,7 +261,8 @@ def main():
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {"workload": f"{Q / 1e6:g} M {args.workload} {kdesc} per GPU, {args.mode}, "
-                               f"{n / 1e9:g} Gbp uniform synthetic {args.alphabet} text (GRCh38-sized), "
+                               f"{n / 1e9:g} G{'res' if amino else 'bp'} uniform synthetic {args.alphabet} text"
+                               f"{' (GRCh38-sized)' if n >= 3_000_000_000 and not amino else ''}, "
                                f"SA ratio {args.sa_ratio}, seed table k={args.seed_k}",
                    "parallelism": f"index replica per GPU, query batch sharded over {world} rank(s), no collective",
                    "hits_per_step_rank0": int(state["hits"]), "locate_kernels_ms": round(locate_ms, 3),
