@@ -100,3 +100,41 @@ def test_random_kmers_counts_are_consistent_between_count_and_locate(awfm, requi
     assert counts[300000:].min() >= 1
     g.destroy()
     ix.dealloc()
+
+
+def test_batches_beyond_4_gib_of_query_characters(oracle, awfm, require_gpu):
+    """byte offsets into the query buffer exceed 2^32 (fixed-length and CSR): the tail of the batch is
+    compared with the oracle"""
+    import torch
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    n, K = 50_000_000, 21
+    Q = (1 << 32) // K + 3_000_000  # ~207.5 M k-mers, 4.36 GB of characters
+    dev = torch.device("cuda")
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, 6, 0, None) == 1
+    ix = awfm.gpu_create_index(d_text.data_ptr(), awfm.AwFmAlphabetDna, 8, 10, on_device_length=n)
+    g = awfm.GpuIndex(ix, acquire=True)
+    d_chars = torch.empty(Q * K, dtype=torch.uint8, device=dev)
+    half = Q // 2
+    assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr(), 0, half, K, 106, 0, None) == 1
+    assert L.awfmGpuSynthPlantedQueries(d_chars.data_ptr() + half * K, half, Q - half, K, 107, d_text.data_ptr(), n, None) == 1
+    d_ranges = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+    g.search(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), 0)
+    torch.cuda.synchronize()
+    fixed = d_ranges.clone()
+    d_offsets = torch.arange(Q + 1, dtype=torch.int64, device=dev) * K
+    d_ranges.zero_()
+    g.search(d_chars.data_ptr(), d_offsets.data_ptr(), 0, Q, d_ranges.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert torch.equal(fixed, d_ranges), "CSR and fixed-length addressing disagree"
+    m = 200_000  # the last m k-mers: their bytes start beyond 4 GiB
+    assert (Q - m) * K > (1 << 32)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 10, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    chars = d_chars[(Q - m) * K:].cpu().numpy()
+    sp, ep, _, _ = oi.batch_search(chars, np.arange(m + 1, dtype=np.uint64) * np.uint64(K), threads=8)
+    tail = d_ranges[2 * (Q - m):].cpu().numpy().view(np.uint64).reshape(m, 2)
+    assert np.array_equal(tail[:, 0], sp) and np.array_equal(tail[:, 1], ep)
+    assert int((tail[:, 0] <= tail[:, 1]).sum()) == m  # the second half is planted
+    g.destroy()
+    ix.dealloc()
