@@ -74,6 +74,19 @@ __device__ __forceinline__ unsigned aminoCountWord(const uint4 &hi, unsigned slo
 /* one 16-byte piece of a BWT block (default cache policy: a non-temporal load measured 25 % slower) */
 __device__ __forceinline__ uint4 loadBlockPiece(const uint4 *p) { return *p; }
 
+/* a piece as one 128-bit register tuple */
+typedef unsigned Piece __attribute__((ext_vector_type(4)));
+
+/* occurrence bits of letter code (c1,c0) in a nucleotide piece, c0m/c1m = the code bits as all-ones masks.
+ * With planes x,y,z: a (00) = y&z, c (01) = x&z, g (10) = x&y, t (11) = x&~y&~z (the literals of ref
+ * src/AwFmOccurrence.c:18-31), i.e. (x | a) & ((y ^ t) | c) & ((z ^ t) | g) with one v_bitop3 per factor. */
+__device__ __forceinline__ unsigned nucOccFast(const Piece &pc, unsigned c0m, unsigned c1m) {
+  const unsigned t0 = __builtin_amdgcn_bitop3_b32(pc.x, c0m, c1m, 0xF1); /* x | (~c0 & ~c1) */
+  const unsigned t1 = __builtin_amdgcn_bitop3_b32(pc.y, c0m, c1m, 0x7C); /* (y ^ (c0 & c1)) | (c0 & ~c1) */
+  const unsigned t2 = __builtin_amdgcn_bitop3_b32(pc.z, c0m, c1m, 0x7A); /* (z ^ (c0 & c1)) | (~c0 & c1) */
+  return t0 & t1 & t2;
+}
+
 /* BWT positions are 32-bit when bwtLength < 2^32 (NARROW): half the integer work of the range arithmetic */
 template <bool NARROW>
 struct PositionType {
@@ -85,7 +98,7 @@ struct PositionType<true> {
 };
 
 template <bool AMINO, int G, bool CSR, bool TALLY, bool NARROW>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 4 && !TALLY && !CSR && !AMINO ? 8 : 2, 8)))
     searchKernel(const DevIndex ix, const unsigned char *__restrict__ chars,
                  const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
                  const unsigned long long numQueries, ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts,
@@ -97,8 +110,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sPow[32];
   __shared__ AminoShared sAmino;
+  /* nucleotide fast step: sMask[local * 8 + piece] = bits of piece `piece` at positions <= local */
+  __shared__ unsigned sMask[AMINO ? 8 : 256 * 8];
   const unsigned card = AMINO ? 20u : 4u;
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  if (!AMINO) {
+    for (unsigned e = threadIdx.x; e < 256u * 8u; e += kThreads) sMask[e] = sliceMask(e >> 3, e & 7u);
+  }
   if (threadIdx.x < 32) {
     /* weight of seed character j: card^(k-1-j) (ref src/AwFmKmerTable.c:26-32) */
     unsigned w = 1;
@@ -196,6 +214,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
 
     pos_t sp = 1, ep = 0;
     int pos = -1;
+    unsigned long long winCodes = 0; /* nucleotide: 2-bit codes of the window, character 0 in bits 63..62 */
+    unsigned winBad = 0;             /* nucleotide: bit i set when window character i is not a,c,g,t,u */
     if (len != 0) {
       /* ---- seed (ref src/AwFmKmerTable.c:4-51) ---- */
       bool seeded = false, deep = false;
@@ -249,6 +269,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
         /* window-wide: 64-bit code string (character 0 of the window in bits 63..62) and 32-bit bad mask */
         const unsigned long long allCodes = groupSum64<G>(codes << (64 - 8 * S * ((int)gl + 1)));
         const unsigned allBad = groupSum<G>(bad << (4 * S * gl));
+        winCodes = allCodes;
+        winBad = allBad;
         const unsigned e = len - wb; /* characters of the query inside the window: 1..32, >= K when tryTable */
         const unsigned long long tail = e >= 32u ? allCodes : (allCodes >> (2u * (32u - e)));
         const unsigned long long kMask = K >= 32u ? ~0ull : ((1ull << (2u * K)) - 1ull);
@@ -285,7 +307,90 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
     }
 
     /* ---- extension (ref src/AwFmParallelSearch.c:273-313; one step = ref src/AwFmSearch.c:42-159) ---- */
+    /* nucleotide: the window's codes from the seed decode serve the extension too.  `rem` has the code of
+     * character `pos` in bits 1..0 (the one before it in bits 3..2, ...), `badTop` its validity in bit 31. */
+    unsigned long long rem = 0;
+    unsigned badTop = 0;
+    if (!AMINO) {
+      const unsigned r = (unsigned)(pos - (int)wb) & 31u; /* only used while pos >= wb */
+      rem = winCodes >> (62u - 2u * r);
+      badTop = winBad << (31u - r);
+    }
     while (pos >= 0 && sp <= ep) {
+      if (!AMINO && __builtin_expect(pos >= (int)wb && (int)badTop >= 0, 1)) {
+        /* ---- fast step: a,c,g,t/u inside the register window.  Everything that does not depend on
+         * the block (letter, plane selectors, position masks from the LDS table, C[a]) is computed
+         * between issuing the loads and the first use of their data. ---- */
+        const pos_t q0 = sp - 1, q1 = ep;
+        const unsigned long long blk0 = q0 >> 8, blk1 = q1 >> 8;
+        const bool same = blk0 == blk1;
+        Piece p0[S], p1[S];
+        {
+          const Piece *a0 = (const Piece *)(ix.blocks + (blk0 * 8ull + firstPiece));
+#pragma unroll
+          for (int s = 0; s < S; s++) p0[s] = a0[s];
+        }
+        /* p1 starts as "whatever the registers hold" (no instruction); lanes with one block never use it */
+#pragma unroll
+        for (int s = 0; s < S; s++) asm volatile("" : "=v"(p1[s]));
+        if (!same) {
+          const Piece *a1 = (const Piece *)(ix.blocks + (blk1 * 8ull + firstPiece));
+#pragma unroll
+          for (int s = 0; s < S; s++) p1[s] = a1[s];
+        }
+        if (TALLY) {
+          tSteps++;
+          tBlocks += same ? 1ull : 2ull;
+        }
+        const unsigned letter = (unsigned)rem & 3u;
+        const unsigned c0m = 0u - (letter & 1u), c1m = 0u - (letter >> 1);
+        const unsigned *m0 = sMask + (((unsigned)q0 & 255u) * 8u + firstPiece);
+        const unsigned *m1 = sMask + (((unsigned)q1 & 255u) * 8u + firstPiece);
+        unsigned mask0[S], mask1[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          mask0[s] = m0[s];
+          mask1[s] = m1[s];
+        }
+        const pos_t cLetter = (pos_t)sC[letter];
+        const unsigned sameMask = same ? ~0u : 0u;
+        unsigned n0 = 0, n1 = 0;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          const unsigned occ0 = nucOccFast(p0[s], c0m, c1m), occ1 = nucOccFast(p1[s], c0m, c1m);
+          n0 += __popc(occ0 & mask0[s]);
+          n1 += __popc(__builtin_amdgcn_bitop3_b32(occ0, occ1, sameMask, 0xE4) & mask1[s]); /* same ? occ0 : occ1 */
+        }
+        /* keep every loaded register allocated until here: a dead component (an unused count word) would be
+         * re-used for the values above while the load is in flight, which costs a full wait before them */
+#pragma unroll
+        for (int s = 0; s < S; s++) asm volatile("" ::"v"(p0[s]), "v"(p1[s]));
+        const unsigned kLo = 2u * letter, kHi = kLo + 1u;
+        unsigned lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+          lo0 = (kLo % S) == (unsigned)s ? p0[s].w : lo0;
+          hi0 = (kHi % S) == (unsigned)s ? p0[s].w : hi0;
+          lo1 = (kLo % S) == (unsigned)s ? p1[s].w : lo1;
+          hi1 = (kHi % S) == (unsigned)s ? p1[s].w : hi1;
+        }
+        pos_t base0, base1;
+        if (NARROW) { /* counts < 2^32: the high words are zero */
+          base0 = (pos_t)groupShfl<G>(lo0, kLo / S);
+          base1 = (pos_t)groupShfl<G>(lo1, kLo / S);
+        } else {
+          base0 = (pos_t)(((unsigned long long)groupShfl<G>(hi0, kHi / S) << 32) | groupShfl<G>(lo0, kLo / S));
+          base1 = (pos_t)(((unsigned long long)groupShfl<G>(hi1, kHi / S) << 32) | groupShfl<G>(lo1, kLo / S));
+        }
+        base1 = same ? base0 : base1;
+        const unsigned packed = groupSum<G>(n0 | (n1 << 16));
+        sp = cLetter + base0 + (pos_t)(packed & 0xFFFFu);
+        ep = cLetter + base1 + (pos_t)(packed >> 16) - (pos_t)1;
+        pos--;
+        rem >>= 2;
+        badTop <<= 1;
+        continue;
+      }
       const pos_t q0 = sp - 1, q1 = ep;
       const unsigned long long blk0 = q0 >> 8, blk1 = q1 >> 8;
       const bool same = (q0 >> 8) == (q1 >> 8);
@@ -384,6 +489,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
       sp = cLetter + base0 + (pos_t)(packed & 0xFFFFu);
       ep = cLetter + base1 + (pos_t)(packed >> 16) - (pos_t)1;
       pos--;
+      rem >>= 2;
+      badTop <<= 1;
     }
 
     if (gl == 0) {
