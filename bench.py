@@ -11,7 +11,7 @@ batch sharded over the ranks with no collective (weak scaling: every rank has it
 `--workload planted` runs the secondary case (k-mers drawn from the text, >=1 hit each).
 
 The JSON line also carries
-  roofline     -- dominant kernel (searchGroup8Kernel): algorithmic bytes (SURVEY.md 8d,
+  roofline     -- dominant kernel (searchKernel): algorithmic bytes (SURVEY.md 8d,
                   bytes_count = L + 16 t + 104 D + 16 per query, D/t/L tallied on the device by an
                   instrumented run of the same kernel) / mean kernel time from HIP events on the
                   launch stream, against the 8 TB/s HBM peak;
@@ -39,10 +39,10 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", choices=["random", "planted", "mixed"], default="random")
     p.add_argument("--mode", choices=["locate", "count"], default="locate")
-    p.add_argument("--text-len", type=int, default=3_100_000_000)
-    p.add_argument("--queries", type=int, default=100_000_000, help="k-mers per GPU per step")
-    p.add_argument("--kmer", type=int, default=21)
-    p.add_argument("--seed-k", type=int, default=12)
+    p.add_argument("--text-len", type=int, default=None, help="default 3.1e9 (dna) / 2e8 (amino)")
+    p.add_argument("--queries", type=int, default=None, help="k-mers per GPU per step; default 1e8 (dna) / 5e7 (amino)")
+    p.add_argument("--kmer", type=int, default=None, help="default 21 (dna) / 10 (amino)")
+    p.add_argument("--seed-k", type=int, default=None, help="default 12 (dna) / 5 (amino)")
     p.add_argument("--sa-ratio", type=int, default=8)
     p.add_argument("--alphabet", choices=["dna", "amino"], default="dna")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
@@ -73,6 +73,11 @@ def main():
     L = _lib.lib()
     amino = args.alphabet == "amino"
     alpha = api.AwFmAlphabetAmino if amino else api.AwFmAlphabetDna
+    # BASELINE.json configs[2] (dna, the headline) / configs[3] (amino, Swiss-Prot-sized)
+    for name, dna_default, amino_default in (("text_len", 3_100_000_000, 200_000_000), ("queries", 100_000_000, 50_000_000),
+                                             ("kmer", 21, 10), ("seed_k", 12, 5)):
+        if getattr(args, name) is None:
+            setattr(args, name, amino_default if amino else dna_default)
     n, Q, K = args.text_len, args.queries, args.kmer
     if args.workload == "mixed":
         args.mode = "count"  # 8..11-mers have ~10^4..10^5 hits each: the hit list of 10^8 of them does not fit any memory
@@ -125,9 +130,8 @@ def main():
         assert L.awfmGpuSynthPlantedQueries(d_chars.data_ptr(), first, Q, K, query_seed, d_text.data_ptr(), n, None) == 1
     torch.cuda.synchronize()
     off_ptr = d_offsets.data_ptr() if d_offsets is not None else 0
-    if True:
-        del d_text  # planted k-mers are already copied out; free 3.1 GB
-        torch.cuda.empty_cache()
+    del d_text  # planted k-mers are already copied out; free 3.1 GB
+    torch.cuda.empty_cache()
 
     d_ranges = torch.empty(Q * 2, dtype=torch.int64, device=dev)
     d_counts = torch.empty(Q, dtype=torch.int32, device=dev)

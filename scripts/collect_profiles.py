@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Condense a scripts/profile_bench.sh run (gpurun_out/prof_<tag>) into the files kept under profiles/:
+kernel_stats_<name>_bench.csv (rocprofv3 --kernel-trace --stats), pmc_summary_<name>_bench.json (mean counter values per
+kernel) and traffic_<name>.json (HBM bytes per launch of the search kernel, MI355X_MICROARCH.md rules).
+
+usage: scripts/collect_profiles.py gpurun_out/prof_<tag> profiles/r1 <name> "<workload text>"
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, dst, name, workload = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+os.makedirs(dst, exist_ok=True)
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"kernel_stats_{name}_bench.csv"))
+summary = collections.defaultdict(dict)
+for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        kernel = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+        acc[(kernel, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for (kernel, counter), v in acc.items():
+        summary[kernel][counter] = {"dispatches": len(v), "mean": sum(v) / len(v)}
+json.dump(summary, open(os.path.join(dst, f"pmc_summary_{name}_bench.json"), "w"), indent=1, sort_keys=True)
+# the timed search kernel: most dispatches among the searchKernel instances (the tally launch runs once)
+search = [k for k in summary if k.startswith("searchKernel") and "FETCH_SIZE" in summary[k]]
+if search:
+    k = max(search, key=lambda x: summary[x]["FETCH_SIZE"]["dispatches"])
+    fetch_kb, write_kb = summary[k]["FETCH_SIZE"]["mean"], summary[k].get("WRITE_SIZE", {"mean": 0.0})["mean"]
+    miss = summary[k].get("TCC_MISS_sum", {"mean": None})["mean"]
+    json.dump({
+        "kernel": k, "workload": workload, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "TCC_MISS_sum": miss,
+        "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
+        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (scripts/profile_bench.sh); on "
+                  "gfx950 FETCH_SIZE counts each 128-B read request as 64 B for 16-B-per-lane loads "
+                  "(MI355X_MICROARCH.md, HBM), so reads = 2 x FETCH_SIZE; cross-check: TCC_MISS_sum x 128 B; "
+                  "WRITE_SIZE is exact",
+    }, open(os.path.join(dst, f"traffic_{name}.json"), "w"), indent=1)
+    print(k, "traffic GB/launch", (2 * fetch_kb + write_kb) * 1024 / 1e9, "TCC_MISS x128 GB", (miss or 0) * 128 / 1e9)
+for line in open(os.path.join(src, "bench_trace.log")):
+    if line.startswith("{"):
+        open(os.path.join(dst, f"bench_{name}_under_rocprofv3.json"), "w").write(line)
