@@ -198,3 +198,31 @@ def test_batch_search_fails_loudly_without_a_gpu(awfm):
         awfm.GpuIndex(ix)
     lst.dealloc()
     ix.dealloc()
+
+
+def test_reference_shared_library_program_relinks_unchanged(awfm, tmp_path):
+    """oracle/_ref/sharedLibTest is the reference's own test/sharedLibTest/awfmiTest.c (it includes nothing but
+    "AwFmIndex.h"), compiled where it lies against include/AwFmIndex.h and libawfmindex_amd.so by
+    oracle/Makefile.  It builds an index from its fixture test.fa and must report success; the file it writes
+    is then read back through this library."""
+    import subprocess
+    from avxwindowfmindex_amd import _lib
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "sharedLibTest")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/sharedLibTest is only built where /root/reference is mounted")
+    # contents of the reference's fixture test/sharedLibTest/test.fa (data: one record)
+    record = b"test1sequencedataagasfnlawebrfilqawhbefrilahwbseflikhabsdlfikhbas"
+    (tmp_path / "test.fa").write_bytes(b">test 1 header\n" + record + b"\n")
+    out = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "createIndex successful" in out.stdout, out.stdout + out.stderr
+    ix = awfm.read_index_from_file(str(tmp_path / "output.awfmi"))
+    L = _lib.lib()
+    assert L.awFmGetNumSequences(ix.ptr) == 1 and ix.header(0) == b"test 1 header"
+    assert ix.bwt_length == len(record) + 2  # the record, its terminator and the sentinel
+    # the program's configuration is a DNA index (ratio 2, k 2): of the record's letters only a, c, g, t/u are
+    # themselves, everything else is the ambiguity letter
+    sp, ep = ix.find_search_range_for_string(b"ataaga")
+    assert ep - sp + 1 == 1
+    sp, ep = ix.find_search_range_for_string(b"gata")
+    assert sp > ep
+    ix.dealloc()
