@@ -2,8 +2,9 @@
 #include <string.h>
 #include "awfm_internal.h"
 
-/* ref src/AwFmSuffixArray.c:12-18 */
-uint8_t awfmSaWidth(uint64_t saLength) { return (uint8_t)(64 - __builtin_clzll(saLength - 1)); }
+/* ref src/AwFmSuffixArray.c:12-18; the reference evaluates clz(0) for a one-entry suffix array (empty text),
+ * which is undefined: one bit is used there */
+uint8_t awfmSaWidth(uint64_t saLength) { return saLength <= 1 ? 1 : (uint8_t)(64 - __builtin_clzll(saLength - 1)); }
 
 /* ref src/AwFmSuffixArray.c:144-147 */
 uint64_t awfmSaSampleCount(uint64_t bwtLength, uint64_t ratio) { return (bwtLength + ratio - 1) / ratio; }

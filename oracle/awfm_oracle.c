@@ -212,7 +212,9 @@ void orc_range_for_string(const OrcIndex *ix, const char *kmer, uint64_t len, ui
 /* ------------------------------------------------------------- sampled SA */
 
 /* src/AwFmSuffixArray.c:12-18: width = 64 - clz(saLength-1) */
-uint8_t orc_sa_width(uint64_t saLength) { return (uint8_t)(64 - __builtin_clzll(saLength - 1)); }
+uint8_t orc_sa_width(uint64_t saLength) {
+  return saLength <= 1 ? 1 : (uint8_t)(64 - __builtin_clzll(saLength - 1)); /* clz(0) is undefined: one bit */
+}
 
 /* src/AwFmSuffixArray.c:144-147 */
 uint64_t orc_sa_num_samples(uint64_t bwtLength, uint64_t ratio) { return (bwtLength + ratio - 1) / ratio; }
