@@ -13,13 +13,9 @@
  *   The reference layout (ref src/AwFmIndex.h:55-65: 160 / 352 B blocks) always
  *   straddles two 128-B lines per rank; here a rank reads exactly 1 (2) lines.
  *
- * Search kernel ("group8"): 8 lanes cooperate on one query; one
- * global_load_dwordx4 per lane fetches a whole block as one fully used 128-B
- * request, every lane ranks its own 32 positions with AND/XOR/popcount and the
- * eight partial counts are summed with DPP adds (no LDS traffic, no bank
- * conflicts).  A wave therefore has 8 queries x 2 blocks = up to 16 lines in
- * flight per step; occupancy (32 waves/CU) supplies the rest of the memory
- * level parallelism.
+ * Kernels: searchKernel (awfm_search_kernel.h: seed lookup + backward search, G lanes per query),
+ * walkKernel/finishKernel (awfm_locate_kernel.h: LF walk to a sampled position, sampled-SA read), and here the
+ * hit-offset scan, hit expansion, dense-SA helpers and the layout conversion launches.
  *
  * Semantics restated from the reference (see include/awfm_gpu.h for the map):
  * a query stops at the first invalid range and keeps it; hits are in BWT order.
@@ -139,10 +135,9 @@ __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const un
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long start = 0, count = 0, sp = 0;
   if (i < n) {
-    const ulonglong2 r = ranges[i];
-    sp = r.x;
     start = hitOffsets[i];
     count = hitOffsets[i + 1] - start;
+    if (count) sp = ranges[i].x; /* batches with few hits: the ranges are not read at all */
   }
   const bool isLong = count > 32ull;
   if (!isLong)
@@ -690,7 +685,8 @@ enum AwFmReturnCode awfmGpuHitOffsets(AwFmGpuIndex *g, const struct AwFmSearchRa
     AWFM_HIP_TRY(hipStreamSynchronize(s), AwFmGeneralFailure);
     return AwFmSuccess;
   }
-  /* the scan reads the ranges directly (lengths are formed on the fly) */
+  /* the scan reads the ranges directly (lengths are formed on the fly).  rocPRIM's one-pass look-back scan over
+   * the same input measured 0.65 ms per 10^8 queries against 0.76 ms for these two passes: not worth a dependency */
   const enum AwFmReturnCode rc =
       scanRecursive<true>(dRanges, numQueries, (unsigned long long *)dHitOffsets, (unsigned long long *)dScratch, s);
   if (rc != AwFmSuccess) return rc;
