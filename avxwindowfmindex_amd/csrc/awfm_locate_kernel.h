@@ -1,8 +1,9 @@
 /*
  * awfm_locate_kernel.h -- suffix-array backtrace: BWT position of a hit -> text position, two kernels.
  *
- * walkKernel: one hit per group of G lanes (same piece ownership as the search kernel: lane j holds
- *   pieces j*S..j*S+S-1 of a block, S = 8/G).  Per LF step the group reads the block of the current BWT
+ * walkKernel: one hit at a time per group of G lanes (same piece ownership as the search kernel: lane j holds
+ *   pieces j*S..j*S+S-1 of a block, S = 8/G); a group takes its hits in batches of 4*G consecutive entries,
+ *   read and written as whole lines.  Per LF step the group reads the block of the current BWT
  *   position as whole 128-B lines, extracts the letter stored there (the owning lane builds the code from
  *   its plane words, the group gets it by ds_bpermute), ranks that letter up to the position and continues
  *   at C[a] + Occ(a,p) - 1 until the position is sampled.  Persistent with refill: a group that reaches a
@@ -72,25 +73,92 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
   const pos_t ratio = (pos_t)ix.saRatio;
   const unsigned long long maxSteps = (1ull << kWalkStepBits) - 1ull;
 
-  unsigned long long t = ((unsigned long long)blockIdx.x * kThreads + threadIdx.x) / G;
-  bool alive = t < totalHits;
-  pos_t p = alive ? (pos_t)positions[t] : (pos_t)0;
-  unsigned long long nextP = t + numGroups < totalHits ? positions[t + numGroups] : 0ull;
+  /* A group works through batches of 4*G consecutive hits (lane j holds hits 4j..4j+3 of the batch, 32 B):
+   * one coalesced read brings a batch in, the hand-over values replace the BWT positions in the registers,
+   * one coalesced write takes the batch out.  (One hit per refill, 8 bytes at a time, cost an extra
+   * partial-line read and a read-modify-write per hit: the L2 lines do not survive between the refills.) */
+  constexpr unsigned kPerLane = 4u, kBatch = kPerLane * G;
+  const unsigned long long batchStride = numGroups * kBatch;
+  const bool aligned = ((unsigned long long)positions & 15ull) == 0ull;
+  /* (the four entries of a lane are named scalars: hipcc moves a small array that is indexed in any
+   * non-constant way to LDS) */
+  struct Four {
+    unsigned long long a, b, c, d;
+  };
+  auto loadBatch = [&](unsigned long long base) -> Four {
+    const unsigned long long first = base + kPerLane * gl;
+    Four r;
+    if (aligned && first + kPerLane <= totalHits) {
+      const ulonglong2 lo = *(const ulonglong2 *)(positions + first), hi = *(const ulonglong2 *)(positions + first + 2);
+      r.a = lo.x;
+      r.b = lo.y;
+      r.c = hi.x;
+      r.d = hi.y;
+    } else {
+      r.a = first < totalHits ? positions[first] : 0ull;
+      r.b = first + 1 < totalHits ? positions[first + 1] : 0ull;
+      r.c = first + 2 < totalHits ? positions[first + 2] : 0ull;
+      r.d = first + 3 < totalHits ? positions[first + 3] : 0ull;
+    }
+    return r;
+  };
+  auto storeBatch = [&](unsigned long long base, const Four &v) {
+    const unsigned long long first = base + kPerLane * gl;
+    if (aligned && first + kPerLane <= totalHits) {
+      *(ulonglong2 *)(positions + first) = make_ulonglong2(v.a, v.b);
+      *(ulonglong2 *)(positions + first + 2) = make_ulonglong2(v.c, v.d);
+    } else {
+      if (first < totalHits) positions[first] = v.a;
+      if (first + 1 < totalHits) positions[first + 1] = v.b;
+      if (first + 2 < totalHits) positions[first + 2] = v.c;
+      if (first + 3 < totalHits) positions[first + 3] = v.d;
+    }
+  };
+  /* hit j of the batch, for every lane of the group (32-bit positions travel as one word) */
+  auto pick = [&](const Four &v, unsigned j) -> pos_t {
+    const unsigned k = j % kPerLane;
+    const unsigned long long mine = k == 0u ? v.a : (k == 1u ? v.b : (k == 2u ? v.c : v.d));
+    const unsigned lo = groupShfl<G>((unsigned)mine, j / kPerLane);
+    if (NARROW) return (pos_t)lo;
+    return (pos_t)(((unsigned long long)groupShfl<G>((unsigned)(mine >> 32), j / kPerLane) << 32) | lo);
+  };
+
+  unsigned long long batchBase = (((unsigned long long)blockIdx.x * kThreads + threadIdx.x) / G) * kBatch;
+  bool alive = batchBase < totalHits;
+  Four slot = {0ull, 0ull, 0ull, 0ull}, nslot = {0ull, 0ull, 0ull, 0ull};
+  unsigned cnt = 0, j = 0;
+  if (alive) {
+    slot = loadBatch(batchBase);
+    cnt = totalHits - batchBase < kBatch ? (unsigned)(totalHits - batchBase) : kBatch;
+  }
+  if (batchBase + batchStride < totalHits) nslot = loadBatch(batchBase + batchStride);
+  pos_t p = pick(slot, 0u);
   unsigned steps = 0;
   while (alive) {
     bool sampled = POW2 ? (p & (ratio - 1)) == 0 : (p % ratio) == 0; /* ref src/AwFmIndexStruct.c:88-91 */
     if (sampled || steps >= maxSteps) {
       /* hand the hit over (or, after 2^23-1 steps, which only a corrupt index reaches, finish it here) */
-      if (gl == 0) {
-        const unsigned long long sample = POW2 ? (unsigned long long)(p >> ix.saShift) : (unsigned long long)(p / ratio);
-        positions[t] = sampled ? (kWalkTag | ((unsigned long long)steps << 40) | (sample & kWalkSampleMask))
-                               : finishPosition(ix, sample, steps);
+      const unsigned long long sample = POW2 ? (unsigned long long)(p >> ix.saShift) : (unsigned long long)(p / ratio);
+      const unsigned long long result = sampled ? (kWalkTag | ((unsigned long long)steps << 40) | (sample & kWalkSampleMask))
+                                                : finishPosition(ix, sample, steps);
+      const bool owner = gl == j / kPerLane;
+      const unsigned k = j % kPerLane;
+      slot.a = owner && k == 0u ? result : slot.a;
+      slot.b = owner && k == 1u ? result : slot.b;
+      slot.c = owner && k == 2u ? result : slot.c;
+      slot.d = owner && k == 3u ? result : slot.d;
+      j++;
+      if (j == cnt) {
+        storeBatch(batchBase, slot);
+        batchBase += batchStride;
+        alive = batchBase < totalHits;
+        slot = nslot;
+        cnt = !alive ? 0u : (totalHits - batchBase < kBatch ? (unsigned)(totalHits - batchBase) : kBatch);
+        j = 0;
+        if (batchBase + batchStride < totalHits) nslot = loadBatch(batchBase + batchStride);
       }
-      t += numGroups;
-      alive = t < totalHits;
-      p = (pos_t)nextP;
+      p = pick(slot, j);
       steps = 0;
-      if (t + numGroups < totalHits) nextP = positions[t + numGroups];
       sampled = POW2 ? (p & (ratio - 1)) == 0 : (p % ratio) == 0;
     }
     const bool walk = alive && !sampled; /* a refilled hit that is sampled right away is handed over next iteration */
