@@ -26,7 +26,7 @@ API_SYMBOLS = [
 ]
 GPU_SYMBOLS = [
     "awfmGpuDeviceCount", "awfmGpuLastError", "awfmGpuIndexCreate", "awfmGpuIndexDestroy", "awfmGpuIndexAcquire", "awfmGpuIndexAcquireAll",
-    "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuIndexSetDeepSeed", "awfmGpuIndexSetDenseSa", "awfmGpuPinnedBuffer", "awfmGpuAosLock",
+    "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuIndexSetDeepSeed", "awfmGpuIndexSetDenseSa", "awfmGpuPinnedBuffer", "awfmGpuLocateHostPinned", "awfmGpuAosLock",
     "awfmGpuAosUnlock", "awfmGpuSearch",
     "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
     "awfmGpuCreateIndex", "awfmGpuSearchTally", "awfmGpuSynthText", "awfmGpuSynthRandomQueries", "awfmGpuSynthPlantedQueries",

@@ -58,42 +58,80 @@ void awFmDeallocKmerSearchList(struct AwFmKmerSearchList *_RESTRICT_ const searc
 #define AWFM_MAX_IMAGES 16
 
 /* ---- pack: AoS k-mers -> flat chars + CSR offsets ---- */
+#define AWFM_MAX_PACK_THREADS 64 /* awfmParallelFor never uses more */
+
 struct packCtx {
   const struct AwFmKmerSearchData *data; /* first query of the shard */
-  uint64_t *offsets;
+  uint64_t firstLength;
+  /* pass 1 (per chunk of awfmParallelFor, indexed by tid): characters in the chunk, all lengths == firstLength */
+  uint64_t chunkChars[AWFM_MAX_PACK_THREADS];
+  bool chunkUniform[AWFM_MAX_PACK_THREADS];
+  bool chunkUsed[AWFM_MAX_PACK_THREADS];
+  /* pass 2 */
+  uint64_t chunkStart[AWFM_MAX_PACK_THREADS]; /* character offset of the chunk's first query */
+  uint64_t *offsets;                          /* NULL when every k-mer has firstLength characters */
   uint8_t *chars;
 };
 
-static void packChars(void *p, uint64_t begin, uint64_t end, unsigned tid) {
-  (void)tid;
+static void packMeasure(void *p, uint64_t begin, uint64_t end, unsigned tid) {
   struct packCtx *c = p;
-  for (uint64_t i = begin; i < end; i++)
-    memcpy(c->chars + c->offsets[i], c->data[i].kmerString, c->data[i].kmerLength);
+  uint64_t total = 0;
+  bool uniform = true;
+  for (uint64_t i = begin; i < end; i++) {
+    const uint64_t len = c->data[i].kmerLength;
+    total += len;
+    uniform &= len == c->firstLength;
+  }
+  c->chunkChars[tid] = total;
+  c->chunkUniform[tid] = uniform;
+  c->chunkUsed[tid] = true;
 }
 
-/* Packs n k-mers starting at data[0] into page-locked staging buffers of the image.  When every k-mer has
- * the same length the offsets array is dropped (*offsetsOut = NULL, *fixedOut = that length). */
+static void packChars(void *p, uint64_t begin, uint64_t end, unsigned tid) {
+  struct packCtx *c = p;
+  if (!c->offsets) {
+    const uint64_t len = c->firstLength;
+    for (uint64_t i = begin; i < end; i++) memcpy(c->chars + i * len, c->data[i].kmerString, len);
+    return;
+  }
+  uint64_t at = c->chunkStart[tid];
+  for (uint64_t i = begin; i < end; i++) {
+    const uint64_t len = c->data[i].kmerLength;
+    c->offsets[i] = at;
+    memcpy(c->chars + at, c->data[i].kmerString, len);
+    at += len;
+  }
+}
+
+/* Packs n k-mers starting at data[0] into page-locked staging buffers of the image, with `threads` host threads
+ * (lengths are summed per chunk first, so that every chunk knows where its characters go).  When every k-mer
+ * has the same length the offsets array is dropped (*offsetsOut = NULL, *fixedOut = that length). */
 static bool packQueries(AwFmGpuIndex *g, const struct AwFmKmerSearchData *data, uint64_t n, unsigned threads,
                         uint8_t **charsOut, uint64_t **offsetsOut, uint32_t *fixedOut) {
-  uint64_t *offsets = awfmGpuPinnedBuffer(g, 1, (n + 1) * sizeof(uint64_t));
-  if (!offsets) return false;
+  struct packCtx ctx;
+  memset(&ctx, 0, sizeof ctx);
+  ctx.data = data;
+  ctx.firstLength = data[0].kmerLength;
+  awfmParallelFor(threads, n, packMeasure, &ctx);
   uint64_t total = 0;
-  const uint64_t firstLength = data[0].kmerLength;
-  bool uniform = firstLength != 0 && firstLength <= 0xFFFFFFFFull;
-  for (uint64_t i = 0; i < n; i++) {
-    const uint64_t len = data[i].kmerLength;
-    offsets[i] = total;
-    total += len;
-    uniform &= len == firstLength;
+  bool uniform = ctx.firstLength != 0 && ctx.firstLength <= 0xFFFFFFFFull;
+  for (unsigned t = 0; t < AWFM_MAX_PACK_THREADS; t++) { /* chunks are in query order; a run may use fewer */
+    ctx.chunkStart[t] = total;
+    if (!ctx.chunkUsed[t]) continue;
+    total += ctx.chunkChars[t];
+    uniform &= ctx.chunkUniform[t];
   }
-  offsets[n] = total;
-  uint8_t *chars = awfmGpuPinnedBuffer(g, 0, total ? total : 1);
-  if (!chars) return false;
-  struct packCtx ctx = {data, offsets, chars};
+  if (!uniform) {
+    ctx.offsets = awfmGpuPinnedBuffer(g, 1, (n + 1) * sizeof(uint64_t));
+    if (!ctx.offsets) return false;
+    ctx.offsets[n] = total;
+  }
+  ctx.chars = awfmGpuPinnedBuffer(g, 0, total ? total : 1);
+  if (!ctx.chars) return false;
   awfmParallelFor(threads, n, packChars, &ctx);
-  *charsOut = chars;
-  *offsetsOut = uniform ? NULL : offsets;
-  *fixedOut = uniform ? (uint32_t)firstLength : 0;
+  *charsOut = ctx.chars;
+  *offsetsOut = ctx.offsets;
+  *fixedOut = uniform ? (uint32_t)ctx.firstLength : 0;
   return true;
 }
 
@@ -147,6 +185,7 @@ struct shardJob {
   unsigned threads;
   bool locate;
   enum AwFmReturnCode rc;
+  char error[256]; /* awfmGpuLastError() of the thread that ran the shard (the message is thread-local) */
 };
 
 static void *runShard(void *p) {
@@ -168,15 +207,15 @@ static void *runShard(void *p) {
       awfmParallelFor(job->threads, job->n, scatterCounts, &ctx);
     }
   } else {
-    uint64_t *positions = NULL;
-    job->rc = awfmGpuLocateHost(g, chars, offsets, fixedLength, job->n, NULL, out, &positions);
+    const uint64_t *positions = NULL; /* page-locked staging of the image, valid while the AoS lock is held */
+    job->rc = awfmGpuLocateHostPinned(g, chars, offsets, fixedLength, job->n, out, &positions);
     if (job->rc == AwFmSuccess) {
       struct locateCtx ctx = {job->data, out, positions, 0};
       awfmParallelFor(job->threads, job->n, scatterPositions, &ctx);
       if (ctx.failed) job->rc = AwFmAllocationFailure;
     }
-    free(positions);
   }
+  if (job->rc != AwFmSuccess) snprintf(job->error, sizeof job->error, "%s", awfmGpuLastError());
   awfmGpuAosUnlock(g);
   return NULL;
 }
@@ -202,20 +241,22 @@ static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKm
   for (int i = 0; i < numImages; i++) {
     const uint64_t begin = per * (uint64_t)i < n ? per * (uint64_t)i : n;
     const uint64_t end = begin + per < n ? begin + per : n;
-    jobs[i] = (struct shardJob){images[i], list->kmerSearchData + begin, end - begin, threadsPerShard, locate, AwFmSuccess};
+    jobs[i] = (struct shardJob){images[i], list->kmerSearchData + begin, end - begin, threadsPerShard, locate, AwFmSuccess, {0}};
   }
   for (int i = 1; i < numImages; i++) spawned[i] = pthread_create(&threads[i], NULL, runShard, &jobs[i]) == 0;
   runShard(&jobs[0]);
-  enum AwFmReturnCode rc = jobs[0].rc;
+  int firstFailed = jobs[0].rc != AwFmSuccess ? 0 : -1;
   for (int i = 1; i < numImages; i++) {
     if (spawned[i])
       pthread_join(threads[i], NULL);
     else
       runShard(&jobs[i]);
-    if (rc == AwFmSuccess && jobs[i].rc != AwFmSuccess) rc = jobs[i].rc;
+    if (firstFailed < 0 && jobs[i].rc != AwFmSuccess) firstFailed = i;
   }
-  if (rc != AwFmSuccess) fprintf(stderr, "%s: GPU search failed (%d): %s\n", who, (int)rc, awfmGpuLastError());
-  return rc;
+  if (firstFailed < 0) return AwFmSuccess;
+  fprintf(stderr, "%s: GPU search failed (%d) on image %d: %s\n", who, (int)jobs[firstFailed].rc, firstFailed,
+          jobs[firstFailed].error);
+  return jobs[firstFailed].rc;
 }
 
 /* ref src/AwFmParallelSearch.c:159-220 */

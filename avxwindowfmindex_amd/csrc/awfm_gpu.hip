@@ -874,9 +874,11 @@ enum AwFmReturnCode awfmGpuCountHost(AwFmGpuIndex *g, const uint8_t *chars, cons
   return AwFmSuccess;
 }
 
-enum AwFmReturnCode awfmGpuLocateHost(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
+/* pinnedOut: the positions land in page-locked slot 3 of the image (no malloc, full-rate copy) instead of a
+ * malloc'ed array */
+static enum AwFmReturnCode locateHost(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
                                       uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
-                                      uint64_t *hitOffsets, uint64_t **positions) {
+                                      uint64_t *hitOffsets, uint64_t **positions, bool pinnedOut) {
   if (!g || !chars || !hitOffsets || !positions) {
     setError("awfmGpuLocateHost: null argument");
     return AwFmNullPtrError;
@@ -915,7 +917,8 @@ enum AwFmReturnCode awfmGpuLocateHost(AwFmGpuIndex *g, const uint8_t *chars, con
       return rc;
     }
   }
-  uint64_t *hostPositions = (uint64_t *)malloc((totalHits ? totalHits : 1) * 8);
+  uint64_t *hostPositions = pinnedOut ? (uint64_t *)awfmGpuPinnedBuffer(g, 3, (totalHits ? totalHits : 1) * 8)
+                                      : (uint64_t *)malloc((totalHits ? totalHits : 1) * 8);
   if (!hostPositions) {
     if (dPositions) (void)hipFree(dPositions);
     setError("awfmGpuLocateHost: host allocation failed");
@@ -927,12 +930,28 @@ enum AwFmReturnCode awfmGpuLocateHost(AwFmGpuIndex *g, const uint8_t *chars, con
   if (e == hipSuccess && ranges) e = hipMemcpy(ranges, dRanges, numQueries * 16, hipMemcpyDeviceToHost);
   if (dPositions) (void)hipFree(dPositions);
   if (e != hipSuccess) {
-    free(hostPositions);
+    if (!pinnedOut) free(hostPositions);
     setError("awfmGpuLocateHost: download failed", e);
     return AwFmGeneralFailure;
   }
   *positions = hostPositions;
   return AwFmSuccess;
+}
+
+
+enum AwFmReturnCode awfmGpuLocateHost(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
+                                      uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
+                                      uint64_t *hitOffsets, uint64_t **positions) {
+  return locateHost(g, chars, offsets, fixedLength, numQueries, ranges, hitOffsets, positions, false);
+}
+
+enum AwFmReturnCode awfmGpuLocateHostPinned(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
+                                            uint32_t fixedLength, uint64_t numQueries, uint64_t *hitOffsets,
+                                            const uint64_t **positions) {
+  uint64_t *out = nullptr;
+  const enum AwFmReturnCode rc = locateHost(g, chars, offsets, fixedLength, numQueries, nullptr, hitOffsets, &out, true);
+  if (positions) *positions = out;
+  return rc;
 }
 
 }  // extern "C"

@@ -143,6 +143,13 @@ enum AwFmReturnCode awfmGpuLocateHost(AwFmGpuIndex *g, const uint8_t *chars, con
                                       uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
                                       uint64_t *hitOffsets, uint64_t **positions);
 
+/* Same, for the drop-in AoS entry points: *positions points into page-locked slot 3 of the image (valid until
+ * the next call for that slot; hold awfmGpuAosLock), so the download runs at the full PCIe rate and nothing
+ * is malloc'ed. */
+enum AwFmReturnCode awfmGpuLocateHostPinned(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
+                                            uint32_t fixedLength, uint64_t numQueries, uint64_t *hitOffsets,
+                                            const uint64_t **positions);
+
 /* ---- seeded synthetic inputs on the device (bench and full-size tests) ---- */
 /* text characters start..start+count-1 of the stream `seed`; amino != 0 selects the 20-letter alphabet */
 enum AwFmReturnCode awfmGpuSynthText(uint8_t *dOut, uint64_t start, uint64_t count, uint64_t seed, int amino,

@@ -263,3 +263,31 @@ def test_every_kernel_variant_is_bit_exact(oracle, awfm, require_gpu, kernel, al
     assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
     g.destroy()
     ix.dealloc()
+
+
+def test_drop_in_aos_api_large_lists_are_packed_in_parallel(oracle, awfm, require_gpu):
+    """lists beyond the serial threshold (4096 k-mers) with 8 host threads: mixed lengths with empty k-mers
+    (CSR path) and a uniform-length list (fixed-length path); counts and every position list against the oracle"""
+    txt = synth.text(91, 120000)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 4, 7)
+    oi = oracle.Index.wrap(oracle.DNA, 4, 7, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    n = 20000
+    chars, offsets = synth.mixed_queries(92, n, txt, synth.DNA_ALPHABET, 5, 33)
+    mixed = [chars[int(offsets[i]):int(offsets[i + 1])].tobytes() for i in range(n)]
+    for i in range(0, n, 997):
+        mixed[i] = b""  # empty k-mers inside several chunks, and as the first entry
+    uniform = [bytes(q) for q in np.concatenate([synth.random_queries(93, n // 2, 13), synth.planted_queries(94, n // 2, 13, txt)])]
+    for kmers in (mixed, uniform):
+        sp, ep, cnt, _ = oi.search_list(kmers)
+        hit_off, pos, _ = oi.batch_locate(sp, ep)
+        lst = awfm.KmerSearchList(n)
+        lst.fill(kmers)
+        awfm.parallel_search_count(ix, lst, 8)
+        assert np.array_equal(lst.counts(), cnt)
+        assert awfm.parallel_search_locate(ix, lst, 8) == awfm.AwFmSuccess
+        assert np.array_equal(lst.counts(), cnt)
+        for i in range(0, n, 13):
+            assert np.array_equal(lst.positions(i), pos[int(hit_off[i]):int(hit_off[i + 1])]), f"k-mer {i}"
+        lst.dealloc()
+    ix.dealloc()
