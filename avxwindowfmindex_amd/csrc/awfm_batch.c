@@ -56,6 +56,7 @@ void awFmDeallocKmerSearchList(struct AwFmKmerSearchList *_RESTRICT_ const searc
 #include <pthread.h>
 
 #define AWFM_MAX_IMAGES 16
+#define AWFM_MIN_SHARDED_LIST 65536u
 
 /* ---- pack: AoS k-mers -> flat chars + CSR offsets ---- */
 #define AWFM_MAX_PACK_THREADS 64 /* awfmParallelFor never uses more */
@@ -228,7 +229,11 @@ static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKm
   const uint64_t n = (uint32_t)list->count; /* the reference reads the count as uint32_t (:100, :164) */
   if (n == 0) return AwFmSuccess;
   AwFmGpuIndex *images[AWFM_MAX_IMAGES];
-  const int numImages = awfmGpuIndexAcquireAll(index, images, AWFM_MAX_IMAGES);
+  /* without an explicit device list a small batch is one shard: splitting it over the two default lanes
+   * would only add launches */
+  const char *deviceList = getenv("AWFM_GPU_DEVICES");
+  const bool oneShard = !(deviceList && *deviceList) && n < AWFM_MIN_SHARDED_LIST;
+  const int numImages = awfmGpuIndexAcquireAll(index, images, oneShard ? 1 : AWFM_MAX_IMAGES);
   if (numImages <= 0) {
     fprintf(stderr, "%s: no device image: %s\n", who, awfmGpuLastError());
     return AwFmGeneralFailure;

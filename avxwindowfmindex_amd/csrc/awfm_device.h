@@ -326,6 +326,10 @@ __global__ void relayoutAminoKernel(const unsigned long long *__restrict__ ref, 
 }  // namespace
 
 struct AwFmGpuIndex {
+  /* a lane: a second host-side handle on the device image of `shares` (same device buffers, own staging
+   * buffers and locks), so that two host threads can overlap their pack/scatter with each other's transfers
+   * and kernels without a second copy of the index; owns none of the device arrays */
+  AwFmGpuIndex *shares = nullptr;
   int device = 0;
   bool amino = false;
   DevIndex dev{};

@@ -453,12 +453,14 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
   if (!g) return;
   {
     DeviceGuard guard(g->device);
-    if (g->dBlocks) (void)hipFree(g->dBlocks);
-    if (g->dSeed) (void)hipFree(g->dSeed);
-    if (g->dSa) (void)hipFree(g->dSa);
-    if (g->dPrefix) (void)hipFree(g->dPrefix);
-    if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
-    if (g->dDenseSa) (void)hipFree(g->dDenseSa);
+    if (!g->shares) { /* a lane owns only its staging */
+      if (g->dBlocks) (void)hipFree(g->dBlocks);
+      if (g->dSeed) (void)hipFree(g->dSeed);
+      if (g->dSa) (void)hipFree(g->dSa);
+      if (g->dPrefix) (void)hipFree(g->dPrefix);
+      if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
+      if (g->dDenseSa) (void)hipFree(g->dDenseSa);
+    }
     if (g->dWork) (void)hipFree(g->dWork);
     for (int i = 0; i < 4; i++)
       if (g->pinned[i]) (void)hipHostFree(g->pinned[i]);
@@ -466,8 +468,9 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
   delete g;
 }
 
-/* device ordinals the AoS entry points shard over: $AWFM_GPU_DEVICES = "all" or a comma list
- * (repeats allowed); unset = one image on the default device (-1) */
+/* device ordinals the AoS entry points shard over: $AWFM_GPU_DEVICES = "all" or a comma list (a device named
+ * again gets a lane on its image); unset = the default device (-1) with two lanes, so that one half of a
+ * batch is packed / scattered on the host while the other half is on the PCIe bus or in the kernels */
 static int aosDevices(int *devs, int maxOut) {
   int n = 0;
   const char *env = getenv("AWFM_GPU_DEVICES");
@@ -481,8 +484,38 @@ static int aosDevices(int *devs, int maxOut) {
       if (*c == ',') c++;
     }
   }
-  if (n == 0) devs[n++] = -1;
+  if (n == 0) {
+    devs[n++] = -1;
+    if (maxOut > 1) devs[n++] = -1;
+  }
   return n;
+}
+
+/* the lanes of a primary image (call with tableMutex NOT held) */
+static std::vector<AwFmGpuIndex *> lanesOf(const AwFmGpuIndex *primary) {
+  std::vector<AwFmGpuIndex *> lanes;
+  std::lock_guard<std::mutex> lock(tableMutex);
+  for (auto &e : imageTable)
+    if (e.image->shares == primary) lanes.push_back(e.image);
+  return lanes;
+}
+
+static AwFmGpuIndex *makeLane(AwFmGpuIndex *primary) {
+  AwFmGpuIndex *g = new AwFmGpuIndex();
+  g->shares = primary;
+  g->device = primary->device;
+  g->amino = primary->amino;
+  g->dev = primary->dev;
+  g->dBlocks = primary->dBlocks;
+  g->dSeed = primary->dSeed;
+  g->dSa = primary->dSa;
+  g->dPrefix = primary->dPrefix;
+  g->dDeepSeed = primary->dDeepSeed;
+  g->dDenseSa = primary->dDenseSa;
+  g->numBlocks = primary->numBlocks;
+  g->kernel = primary->kernel;
+  g->numCUs = primary->numCUs;
+  return g;
 }
 
 int awfmGpuIndexAcquireAll(const struct AwFmIndex *index, AwFmGpuIndex **out, int maxOut) {
@@ -495,7 +528,17 @@ int awfmGpuIndexAcquireAll(const struct AwFmIndex *index, AwFmGpuIndex **out, in
     for (auto &e : imageTable)
       if (e.index == index && e.slot == slot) g = e.image;
     if (!g) {
-      if (awfmGpuIndexCreate(index, devs[slot], &g) != AwFmSuccess) return n;
+      /* a device named again gets a lane on the image it already has */
+      AwFmGpuIndex *primary = nullptr;
+      for (int earlier = 0; earlier < slot && !primary; earlier++)
+        if (devs[earlier] == devs[slot])
+          for (auto &e : imageTable)
+            if (e.index == index && e.slot == earlier) primary = e.image->shares ? e.image->shares : e.image;
+      if (primary) {
+        g = makeLane(primary);
+      } else if (awfmGpuIndexCreate(index, devs[slot], &g) != AwFmSuccess) {
+        return n;
+      }
       imageTable.push_back({index, slot, g});
     }
     out[n++] = g;
@@ -521,7 +564,10 @@ void awfmGpuIndexRelease(const struct AwFmIndex *index) {
       }
     }
   }
-  for (AwFmGpuIndex *g : doomed) awfmGpuIndexDestroy(g);
+  for (AwFmGpuIndex *g : doomed)
+    if (g->shares) awfmGpuIndexDestroy(g); /* lanes first: they point into their primary */
+  for (AwFmGpuIndex *g : doomed)
+    if (!g->shares) awfmGpuIndexDestroy(g);
 }
 
 void *awfmGpuPinnedBuffer(AwFmGpuIndex *g, int slot, uint64_t bytes) {
@@ -551,12 +597,36 @@ uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g) {
   return g ? g->deviceBytes + g->deepSeedBytes + g->denseSaBytes : 0;
 }
 
+namespace {
+/* holds the work and AoS locks of every lane of a primary image for the lifetime of the object */
+struct LaneLocks {
+  std::vector<AwFmGpuIndex *> lanes;
+  explicit LaneLocks(const AwFmGpuIndex *primary) : lanes(lanesOf(primary)) {
+    for (AwFmGpuIndex *lane : lanes) {
+      lane->aosMutex.lock();
+      lane->workMutex.lock();
+    }
+  }
+  ~LaneLocks() {
+    for (AwFmGpuIndex *lane : lanes) {
+      lane->workMutex.unlock();
+      lane->aosMutex.unlock();
+    }
+  }
+};
+}  // namespace
+
 enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK) {
   if (!g) {
     setError("awfmGpuIndexSetDeepSeed: null image");
     return AwFmNullPtrError;
   }
+  if (g->shares) {
+    setError("awfmGpuIndexSetDeepSeed: set it on the primary image, not on a lane");
+    return AwFmIllegalPositionError;
+  }
   DeviceGuard guard(g->device);
+  LaneLocks lanes(g); /* nobody searches through a lane while the table is replaced */
   std::lock_guard<std::mutex> lock(g->workMutex);
   (void)hipDeviceSynchronize();
   if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
@@ -564,15 +634,25 @@ enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK) {
   g->deepSeedBytes = 0;
   g->dev.deepSeed = nullptr;
   g->dev.deepK = 0;
-  if (deepK == 0) return AwFmSuccess;
-  void *table = nullptr;
-  uint64_t bytes = 0;
-  if (!awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes)) return AwFmGeneralFailure;
-  g->dDeepSeed = table;
-  g->deepSeedBytes = bytes;
-  g->dev.deepSeed = (const ulonglong2 *)table;
-  g->dev.deepK = deepK;
-  return AwFmSuccess;
+  enum AwFmReturnCode rc = AwFmSuccess;
+  if (deepK != 0) {
+    void *table = nullptr;
+    uint64_t bytes = 0;
+    if (awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes)) {
+      g->dDeepSeed = table;
+      g->deepSeedBytes = bytes;
+      g->dev.deepSeed = (const ulonglong2 *)table;
+      g->dev.deepK = deepK;
+    } else {
+      rc = AwFmGeneralFailure;
+    }
+  }
+  for (AwFmGpuIndex *lane : lanes.lanes) {
+    lane->dDeepSeed = g->dDeepSeed;
+    lane->dev.deepSeed = g->dev.deepSeed;
+    lane->dev.deepK = g->dev.deepK;
+  }
+  return rc;
 }
 int awfmGpuIndexDevice(const AwFmGpuIndex *g) { return g ? g->device : -1; }
 void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel) {
@@ -779,12 +859,18 @@ enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable) {
     setError("awfmGpuIndexSetDenseSa: null image");
     return AwFmNullPtrError;
   }
+  if (g->shares) {
+    setError("awfmGpuIndexSetDenseSa: set it on the primary image, not on a lane");
+    return AwFmIllegalPositionError;
+  }
   DeviceGuard guard(g->device);
+  LaneLocks lanes(g);
   std::lock_guard<std::mutex> lock(g->workMutex);
   (void)hipDeviceSynchronize();
   if (g->dDenseSa) (void)hipFree(g->dDenseSa);
   g->dDenseSa = nullptr;
   g->denseSaBytes = 0;
+  for (AwFmGpuIndex *lane : lanes.lanes) lane->dDenseSa = nullptr;
   if (!enable) return AwFmSuccess;
   const unsigned long long n = g->dev.bwtLength;
   if (n >= (1ull << 32)) {
@@ -817,6 +903,7 @@ enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable) {
   }
   g->dDenseSa = dense;
   g->denseSaBytes = n * 4;
+  for (AwFmGpuIndex *lane : lanes.lanes) lane->dDenseSa = dense;
   return AwFmSuccess;
 }
 

@@ -63,9 +63,11 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
 void awfmGpuIndexDestroy(AwFmGpuIndex *g);
 /* Side table used by awFmParallelSearch*: image for a host index, created on first use. */
 AwFmGpuIndex *awfmGpuIndexAcquire(const struct AwFmIndex *index);
-/* Images of a host index on every device of $AWFM_GPU_DEVICES ("all" or a comma list of ordinals; unset: the
- * one default image), created on first use; awFmParallelSearch* shard a batch over them.  Returns how
- * many images were written to out[0..maxOut). */
+/* Handles on the device images of a host index for every entry of $AWFM_GPU_DEVICES ("all" or a comma list of
+ * ordinals), created on first use; awFmParallelSearch* shard a batch over them, one host thread each.  A device
+ * named again gets a lane: a handle with its own staging buffers and locks on the image that device already
+ * has (no second copy of the index), so that its shard overlaps the other's transfers and kernels.  Unset:
+ * the default device with two lanes.  Returns how many handles were written to out[0..maxOut). */
 int awfmGpuIndexAcquireAll(const struct AwFmIndex *index, AwFmGpuIndex **out, int maxOut);
 /* Drops the side-table entries of the index (called by awFmDeallocIndex). */
 void awfmGpuIndexRelease(const struct AwFmIndex *index);

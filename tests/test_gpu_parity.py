@@ -215,9 +215,11 @@ def test_device_dense_sa_keeps_positions_bit_identical(oracle, awfm, require_gpu
 
 
 def test_drop_in_api_shards_over_device_images(oracle, awfm, require_gpu, monkeypatch):
-    """AWFM_GPU_DEVICES lists the devices awFmParallelSearch* shard a batch over (one host thread and one
-    index replica per entry, contiguous shards, no exchange).  With one GPU on the box the list names it
-    three times: three images, three shards, results identical to the unsharded run."""
+    """AWFM_GPU_DEVICES lists the devices awFmParallelSearch* shard a batch over (one host thread per entry,
+    contiguous shards, no exchange; one index replica per distinct device, a device named again gets a lane
+    with its own staging on the replica it already has).  With one GPU on the box the list names it three
+    times: one image + two lanes, three shards, results identical to the unsharded run, also after the
+    device-only accelerators are switched on and off on the primary image."""
     txt = synth.text(88, 120000)
     chars, offsets = synth.mixed_queries(89, 5003, txt, synth.DNA_ALPHABET, 3, 30)
     kmers = [chars[int(offsets[i]):int(offsets[i + 1])].tobytes() for i in range(5003)]
@@ -237,7 +239,20 @@ def test_drop_in_api_shards_over_device_images(oracle, awfm, require_gpu, monkey
     from avxwindowfmindex_amd import _lib
     import ctypes as C
     imgs = (C.c_void_p * 8)()
-    assert _lib.lib().awfmGpuIndexAcquireAll(ix.ptr, imgs, 8) == 3 and len({imgs[0], imgs[1], imgs[2]}) == 3
+    L = _lib.lib()
+    assert L.awfmGpuIndexAcquireAll(ix.ptr, imgs, 8) == 3 and len({imgs[0], imgs[1], imgs[2]}) == 3
+    L.awfmGpuIndexDeviceBytes.restype = C.c_uint64
+    assert L.awfmGpuIndexDeviceBytes(C.c_void_p(imgs[0])) > 0
+    assert L.awfmGpuIndexDeviceBytes(C.c_void_p(imgs[1])) == 0 and L.awfmGpuIndexDeviceBytes(C.c_void_p(imgs[2])) == 0
+    # accelerators are set on the primary and reach the lanes; a lane refuses them
+    assert L.awfmGpuIndexSetDeepSeed(C.c_void_p(imgs[1]), 9) < 0
+    for deep_k, dense in ((9, 1), (0, 0)):
+        assert L.awfmGpuIndexSetDeepSeed(C.c_void_p(imgs[0]), deep_k) == awfm.AwFmSuccess
+        assert L.awfmGpuIndexSetDenseSa(C.c_void_p(imgs[0]), dense) == awfm.AwFmSuccess
+        assert awfm.parallel_search_locate(ix, lst, 6) == awfm.AwFmSuccess
+        assert np.array_equal(lst.counts(), cnt)
+        for i in range(0, 5003, 11):
+            assert np.array_equal(lst.positions(i), pos[int(hit_off[i]):int(hit_off[i + 1])])
     lst.dealloc()
     ix.dealloc()
 
