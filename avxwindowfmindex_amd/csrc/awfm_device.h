@@ -349,6 +349,8 @@ struct AwFmGpuIndex {
   std::mutex workMutex;
   void *dWork = nullptr;
   size_t workBytes = 0;
+  void *dHits = nullptr; /* positions of the host-buffer locate calls, grow-only like dWork */
+  size_t hitsBytes = 0;
   std::mutex aosMutex;       /* serialises the AoS entry points (they share the pinned buffers) */
   void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pinnedBytes[4] = {0, 0, 0, 0};

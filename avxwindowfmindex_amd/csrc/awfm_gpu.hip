@@ -462,6 +462,7 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
       if (g->dDenseSa) (void)hipFree(g->dDenseSa);
     }
     if (g->dWork) (void)hipFree(g->dWork);
+    if (g->dHits) (void)hipFree(g->dHits);
     for (int i = 0; i < 4; i++)
       if (g->pinned[i]) (void)hipHostFree(g->pinned[i]);
   }
@@ -949,15 +950,20 @@ enum AwFmReturnCode awfmGpuCountHost(AwFmGpuIndex *g, const uint8_t *chars, cons
   enum AwFmReturnCode rc = ensureWork(g, l.total);
   if (rc != AwFmSuccess) return rc;
   uint8_t *w = (uint8_t *)g->dWork;
-  AWFM_HIP_TRY(hipMemcpy(w + l.chars, chars, totalChars, hipMemcpyHostToDevice), AwFmGeneralFailure);
+  /* the calling thread's own stream: two host lanes (or two user threads with two images) overlap one's
+   * transfers with the other's kernels */
+  hipStream_t s = hipStreamPerThread;
+  AWFM_HIP_TRY(hipMemcpyAsync(w + l.chars, chars, totalChars, hipMemcpyHostToDevice, s), AwFmGeneralFailure);
   if (offsets)
-    AWFM_HIP_TRY(hipMemcpy(w + l.offsets, offsets, (numQueries + 1) * 8, hipMemcpyHostToDevice), AwFmGeneralFailure);
+    AWFM_HIP_TRY(hipMemcpyAsync(w + l.offsets, offsets, (numQueries + 1) * 8, hipMemcpyHostToDevice, s), AwFmGeneralFailure);
   rc = awfmGpuSearch(g, w + l.chars, offsets ? (const uint64_t *)(w + l.offsets) : nullptr, fixedLength, numQueries,
-                     (struct AwFmSearchRange *)(w + l.ranges), (uint32_t *)(w + l.counts), nullptr);
+                     (struct AwFmSearchRange *)(w + l.ranges), (uint32_t *)(w + l.counts), s);
   if (rc != AwFmSuccess) return rc;
-  AWFM_HIP_TRY(hipDeviceSynchronize(), AwFmGeneralFailure);
-  if (ranges) AWFM_HIP_TRY(hipMemcpy(ranges, w + l.ranges, numQueries * 16, hipMemcpyDeviceToHost), AwFmGeneralFailure);
-  if (counts) AWFM_HIP_TRY(hipMemcpy(counts, w + l.counts, numQueries * 4, hipMemcpyDeviceToHost), AwFmGeneralFailure);
+  if (ranges)
+    AWFM_HIP_TRY(hipMemcpyAsync(ranges, w + l.ranges, numQueries * 16, hipMemcpyDeviceToHost, s), AwFmGeneralFailure);
+  if (counts)
+    AWFM_HIP_TRY(hipMemcpyAsync(counts, w + l.counts, numQueries * 4, hipMemcpyDeviceToHost, s), AwFmGeneralFailure);
+  AWFM_HIP_TRY(hipStreamSynchronize(s), AwFmGeneralFailure);
   return AwFmSuccess;
 }
 
@@ -980,42 +986,47 @@ static enum AwFmReturnCode locateHost(AwFmGpuIndex *g, const uint8_t *chars, con
   enum AwFmReturnCode rc = ensureWork(g, l.total);
   if (rc != AwFmSuccess) return rc;
   uint8_t *w = (uint8_t *)g->dWork;
-  AWFM_HIP_TRY(hipMemcpy(w + l.chars, chars, totalChars, hipMemcpyHostToDevice), AwFmGeneralFailure);
+  hipStream_t s = hipStreamPerThread; /* see awfmGpuCountHost */
+  AWFM_HIP_TRY(hipMemcpyAsync(w + l.chars, chars, totalChars, hipMemcpyHostToDevice, s), AwFmGeneralFailure);
   if (offsets)
-    AWFM_HIP_TRY(hipMemcpy(w + l.offsets, offsets, (numQueries + 1) * 8, hipMemcpyHostToDevice), AwFmGeneralFailure);
+    AWFM_HIP_TRY(hipMemcpyAsync(w + l.offsets, offsets, (numQueries + 1) * 8, hipMemcpyHostToDevice, s), AwFmGeneralFailure);
   struct AwFmSearchRange *dRanges = (struct AwFmSearchRange *)(w + l.ranges);
   uint64_t *dHitOffsets = (uint64_t *)(w + l.hitOffsets);
   rc = awfmGpuSearch(g, w + l.chars, offsets ? (const uint64_t *)(w + l.offsets) : nullptr, fixedLength, numQueries,
-                     dRanges, nullptr, nullptr);
+                     dRanges, nullptr, s);
   if (rc != AwFmSuccess) return rc;
   uint64_t totalHits = 0;
-  rc = awfmGpuHitOffsets(g, dRanges, numQueries, dHitOffsets, w + l.scratch, &totalHits, nullptr);
+  rc = awfmGpuHitOffsets(g, dRanges, numQueries, dHitOffsets, w + l.scratch, &totalHits, s);
   if (rc != AwFmSuccess) return rc;
   uint64_t *dPositions = nullptr;
   if (totalHits) {
-    AWFM_HIP_TRY(hipMalloc((void **)&dPositions, totalHits * 8), AwFmAllocationFailure);
-    rc = awfmGpuLocate(g, dRanges, dHitOffsets, numQueries, totalHits, dPositions, nullptr);
-    if (rc == AwFmSuccess && hipDeviceSynchronize() != hipSuccess) {
+    if (totalHits * 8 > g->hitsBytes) { /* grow-only, so that a steady stream of batches never allocates */
+      if (g->dHits) (void)hipFree(g->dHits);
+      g->dHits = nullptr;
+      g->hitsBytes = 0;
+      const size_t want = totalHits * 8 + totalHits * 2 + 4096;
+      AWFM_HIP_TRY(hipMalloc(&g->dHits, want), AwFmAllocationFailure);
+      g->hitsBytes = want;
+    }
+    dPositions = (uint64_t *)g->dHits;
+    rc = awfmGpuLocate(g, dRanges, dHitOffsets, numQueries, totalHits, dPositions, s);
+    if (rc == AwFmSuccess && hipStreamSynchronize(s) != hipSuccess) {
       setError("awfmGpuLocateHost: locate kernels failed", hipGetLastError());
       rc = AwFmGeneralFailure;
     }
-    if (rc != AwFmSuccess) {
-      (void)hipFree(dPositions);
-      return rc;
-    }
+    if (rc != AwFmSuccess) return rc;
   }
   uint64_t *hostPositions = pinnedOut ? (uint64_t *)awfmGpuPinnedBuffer(g, 3, (totalHits ? totalHits : 1) * 8)
                                       : (uint64_t *)malloc((totalHits ? totalHits : 1) * 8);
   if (!hostPositions) {
-    if (dPositions) (void)hipFree(dPositions);
     setError("awfmGpuLocateHost: host allocation failed");
     return AwFmAllocationFailure;
   }
   hipError_t e = hipSuccess;
-  if (totalHits) e = hipMemcpy(hostPositions, dPositions, totalHits * 8, hipMemcpyDeviceToHost);
-  if (e == hipSuccess) e = hipMemcpy(hitOffsets, dHitOffsets, (numQueries + 1) * 8, hipMemcpyDeviceToHost);
-  if (e == hipSuccess && ranges) e = hipMemcpy(ranges, dRanges, numQueries * 16, hipMemcpyDeviceToHost);
-  if (dPositions) (void)hipFree(dPositions);
+  if (totalHits) e = hipMemcpyAsync(hostPositions, dPositions, totalHits * 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipMemcpyAsync(hitOffsets, dHitOffsets, (numQueries + 1) * 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess && ranges) e = hipMemcpyAsync(ranges, dRanges, numQueries * 16, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {
     if (!pinnedOut) free(hostPositions);
     setError("awfmGpuLocateHost: download failed", e);
