@@ -306,3 +306,42 @@ def test_drop_in_aos_api_large_lists_are_packed_in_parallel(oracle, awfm, requir
             assert np.array_equal(lst.positions(i), pos[int(hit_off[i]):int(hit_off[i + 1])]), f"k-mer {i}"
         lst.dealloc()
     ix.dealloc()
+
+
+@pytest.mark.parametrize("alphabet_name", ["dna", "amino"])
+def test_flat_locate_with_any_position_buffer_alignment_and_hit_count(oracle, awfm, require_gpu, alphabet_name):
+    """the walk kernel moves hits in 128-byte batches when the position buffer is 16-byte aligned and one by one
+    otherwise; hit totals that are not a multiple of a batch exercise the tail of both paths"""
+    import torch
+    amino = alphabet_name == "amino"
+    alphabet = synth.AMINO_ALPHABET if amino else synth.DNA_ALPHABET
+    alpha, oalpha = (awfm.AwFmAlphabetAmino, oracle.AMINO) if amino else (awfm.AwFmAlphabetDna, oracle.DNA)
+    k_seed, ratio = (2, 5) if amino else (6, 7)
+    txt = synth.text(33, 90000, alphabet)
+    ix = awfm.create_index(txt, alpha, ratio, k_seed)
+    oi = oracle.Index.wrap(oalpha, ratio, k_seed, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    dev = torch.device("cuda")
+    for count in (1, 7, 16, 17, 1000, 4097):
+        K = 4 if amino else 9
+        q = synth.planted_queries(300 + count, count, K, txt)
+        chars, offsets = synth.fixed_csr(q)
+        sp, ep, _, _ = oi.batch_search(chars, offsets)
+        hit_off, pos, _ = oi.batch_locate(sp, ep)
+        d_chars = torch.from_numpy(chars).to(dev)
+        d_ranges = torch.zeros(count * 2, dtype=torch.int64, device=dev)
+        g.search(d_chars.data_ptr(), 0, K, count, d_ranges.data_ptr(), 0)
+        d_hit_off = torch.zeros(count + 1, dtype=torch.int64, device=dev)
+        d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(count), dtype=torch.uint8, device=dev)
+        total = g.hit_offsets(d_ranges.data_ptr(), count, d_hit_off.data_ptr(), d_scratch.data_ptr())
+        assert total == len(pos)
+        for shift in (0, 1):  # 16-byte aligned, then only 8-byte aligned
+            d_pos = torch.zeros(total + 4, dtype=torch.int64, device=dev)
+            g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), count, total, d_pos.data_ptr() + 8 * shift)
+            torch.cuda.synchronize()
+            got = d_pos[shift:shift + total].cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, pos), f"{count} k-mers, buffer shift {shift}"
+            assert int(d_pos[shift + total]) == 0  # nothing written past the end
+    g.destroy()
+    ix.dealloc()
