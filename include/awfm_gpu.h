@@ -135,7 +135,9 @@ void awfmGpuAosLock(AwFmGpuIndex *g);
 void awfmGpuAosUnlock(AwFmGpuIndex *g);
 
 /* ---- flat batch API on host buffers (upload, kernels, download) ---- */
-/* ranges / counts may be NULL. */
+/* Synchronous for the caller; the work is issued on the calling thread's own stream (hipStreamPerThread), so
+ * several host threads (or the two lanes of the AoS entry points) overlap on the device.
+ * ranges / counts may be NULL. */
 enum AwFmReturnCode awfmGpuCountHost(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
                                      uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
                                      uint32_t *counts);
