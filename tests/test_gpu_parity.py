@@ -345,3 +345,33 @@ def test_flat_locate_with_any_position_buffer_alignment_and_hit_count(oracle, aw
             assert int(d_pos[shift + total]) == 0  # nothing written past the end
     g.destroy()
     ix.dealloc()
+
+
+def test_drop_in_aos_api_two_default_lanes(oracle, awfm, require_gpu, monkeypatch):
+    """lists of 65536 k-mers and more are split over two host lanes on the one default image (no device list in
+    the environment): counts and position lists against the oracle, twice in a row (staging buffers re-used)"""
+    monkeypatch.delenv("AWFM_GPU_DEVICES", raising=False)
+    txt = synth.text(95, 300000)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    n = 70001
+    q = np.concatenate([synth.random_queries(96, n // 2, 15), synth.planted_queries(97, n - n // 2, 15, txt)])
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+    hit_off, pos, _ = oi.batch_locate(sp, ep, threads=4)
+    lst = awfm.KmerSearchList(n)
+    lst.fill([bytes(r) for r in q])
+    for _ in range(2):
+        awfm.parallel_search_count(ix, lst, 8)
+        assert np.array_equal(lst.counts(), cnt)
+        assert awfm.parallel_search_locate(ix, lst, 8) == awfm.AwFmSuccess
+        assert np.array_equal(lst.counts(), cnt)
+        for i in list(range(0, n, 97)) + [n // 2 - 1, n // 2, n - 1]:
+            assert np.array_equal(lst.positions(i), pos[int(hit_off[i]):int(hit_off[i + 1])]), f"k-mer {i}"
+    from avxwindowfmindex_amd import _lib
+    import ctypes as C
+    imgs = (C.c_void_p * 4)()
+    assert _lib.lib().awfmGpuIndexAcquireAll(ix.ptr, imgs, 4) == 2 and imgs[0] != imgs[1]
+    lst.dealloc()
+    ix.dealloc()
