@@ -9,6 +9,8 @@
 #include <string.h>
 #include "awfm_internal.h"
 
+#define AWFM_GPU_BUILD_MIN_LENGTH (1ull << 20)
+
 /* Fill the blocks from the suffix array: BWT[i] = text[SA[i]-1], '$' when
  * SA[i]==0; each block starts with a copy of the running letter counts
  * (ref src/AwFmCreate.c:291-336, :350-395).  Also derives the prefix sums
@@ -112,6 +114,19 @@ enum AwFmReturnCode awfmCreateIndexWithFasta(struct AwFmIndex **index, const str
   *index = NULL;
   const bool amino = config->alphabetType == AwFmAlphabetAmino;
   const uint64_t saLength = (uint64_t)sequenceLength + 1;
+
+  /* Texts of a megabase and more are built on the GPU when there is one (suffix sort, BWT planes, seed table and
+   * SA packing in seconds for a 3.1 Gbp genome; the arrays and the file are byte-identical to this builder's,
+   * tests/test_gpu_build.py).  $AWFM_HOST_BUILD=1 keeps the build on the host; so does any failure of the GPU
+   * build (no device, not enough device memory, more than 2^32-2 positions). */
+  if (sequenceLength >= AWFM_GPU_BUILD_MIN_LENGTH && saLength <= 0xFFFFFFFEull && config->suffixArrayCompressionRatio != 0) {
+    const char *hostOnly = getenv("AWFM_HOST_BUILD");
+    if (!(hostOnly && *hostOnly && *hostOnly != '0') && awfmGpuDeviceCount() > 0) {
+      const enum AwFmReturnCode rc =
+          awfmGpuCreateIndexWithFasta(index, config, sequence, sequenceLength, 0, fileSrc, -1, fastaVector);
+      if (*index) return rc; /* built (rc is the file write status, as below) */
+    }
+  }
 
   /* sanitized copy + '$' (ref src/AwFmCreate.c:53-66, :452-466) */
   uint8_t *text = malloc(saLength);

@@ -547,6 +547,16 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
 extern "C" enum AwFmReturnCode awfmGpuCreateIndex(struct AwFmIndex **index, const struct AwFmIndexConfiguration *config,
                                                   const uint8_t *sequence, uint64_t sequenceLength,
                                                   int sequenceOnDevice, const char *fileSrc, int device) {
+  return awfmGpuCreateIndexWithFasta(index, config, sequence, sequenceLength, sequenceOnDevice, fileSrc, device, nullptr);
+}
+
+/* fastaVector (may be NULL): record table of an index built from FASTA; owned by the index on success, left to
+ * the caller on failure (the contract of awfmCreateIndexWithFasta) */
+extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **index,
+                                                           const struct AwFmIndexConfiguration *config,
+                                                           const uint8_t *sequence, uint64_t sequenceLength,
+                                                           int sequenceOnDevice, const char *fileSrc, int device,
+                                                           struct FastaVector *fastaVector) {
   if (!index || !config || !sequence) {
     awfmGpuSetError("awfmGpuCreateIndex: null argument");
     return AwFmNullPtrError;
@@ -592,9 +602,9 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndex(struct AwFmIndex **index, cons
     return AwFmAllocationFailure;
   }
   ix->versionNumber = AWFM_VERSION_NUMBER;
-  ix->featureFlags = 0;
+  ix->featureFlags = fastaVector ? (1u << AWFM_FEATURE_BIT_FASTA_VECTOR) : 0u;
   auto failWith = [&](enum AwFmReturnCode rc) {
-    awFmDeallocIndex(ix);
+    awFmDeallocIndex(ix); /* ix->fastaVector is still NULL: the caller keeps the record table */
     return rc;
   };
 #define STEP(expr)                                \
@@ -768,6 +778,7 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndex(struct AwFmIndex **index, cons
   awfmGpuIndexRegister(ix, g);
 
   enum AwFmReturnCode rc = AwFmFileWriteOkay;
+  ix->fastaVector = fastaVector; /* the trailer of the file is written from it */
   if (fileSrc) {
     if (config->storeOriginalSequence && sequenceOnDevice) {
       std::vector<uint8_t> hostSeq(sequenceLength ? sequenceLength : 1);
@@ -778,6 +789,7 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndex(struct AwFmIndex **index, cons
       rc = awFmWriteIndexToFile(ix, sequenceOnDevice ? &none : sequence, sequenceLength, fileSrc);
     }
   }
+  if (awFmReturnCodeIsFailure(rc)) ix->fastaVector = nullptr; /* the caller keeps ownership on failure */
   if (!config->keepSuffixArrayInMemory && fileSrc) { /* ref src/AwFmCreate.c:128-131 */
     free(ix->suffixArray.values);
     ix->suffixArray.values = nullptr;

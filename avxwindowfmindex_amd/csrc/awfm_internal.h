@@ -35,6 +35,11 @@ void awfmFastaVectorFree(struct FastaVector *fv);
 enum AwFmReturnCode awfmCreateIndexWithFasta(struct AwFmIndex **index, const struct AwFmIndexConfiguration *config,
                                              const uint8_t *sequence, size_t sequenceLength, const char *fileSrc,
                                              struct FastaVector *fastaVector);
+/* the same build on the GPU (awfm_gpu_build.hip): byte-identical arrays; sequence is a host pointer unless
+ * sequenceOnDevice; fails (negative code, awfmGpuLastError) without a device or beyond 2^32-2 positions */
+enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **index, const struct AwFmIndexConfiguration *config,
+                                                const uint8_t *sequence, uint64_t sequenceLength, int sequenceOnDevice,
+                                                const char *fileSrc, int device, struct FastaVector *fastaVector);
 
 /* ---- awfm_letters.c (ref src/AwFmLetter.c) ---- */
 uint8_t awfmNucAsciiToIndex(uint8_t c);

@@ -13,6 +13,16 @@ from avxwindowfmindex_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+def _host_build(awfm, *args, **kwargs):
+    """awFmCreateIndex kept on the host builder (texts of 2^20 characters and more go to the GPU builder otherwise)"""
+    import os
+    os.environ["AWFM_HOST_BUILD"] = "1"
+    try:
+        return awfm.create_index(*args, **kwargs)
+    finally:
+        del os.environ["AWFM_HOST_BUILD"]
+
+
 def _same_arrays(a, b):
     assert a.bwt_length == b.bwt_length
     assert np.array_equal(a.prefix_sums(), b.prefix_sums()), "prefix sums"
@@ -28,7 +38,7 @@ def test_dna_build_matches_host(awfm, require_gpu, n):
         txt[7:12] = ord("N")
         txt[n // 2] = ord("x")
     for ratio, k in ((1, 1), (8, 6), (3, 3)):
-        host = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, k)
+        host = _host_build(awfm, txt, awfm.AwFmAlphabetDna, ratio, k)
         dev = awfm.gpu_create_index(txt, awfm.AwFmAlphabetDna, ratio, k)
         _same_arrays(host, dev)
         host.dealloc()
@@ -42,7 +52,7 @@ def test_amino_build_matches_host(awfm, require_gpu, n):
         txt[3:6] = ord("x")
         txt[n // 2] = ord("b")
     for ratio, k in ((1, 1), (8, 3), (5, 2)):
-        host = awfm.create_index(txt, awfm.AwFmAlphabetAmino, ratio, k)
+        host = _host_build(awfm, txt, awfm.AwFmAlphabetAmino, ratio, k)
         dev = awfm.gpu_create_index(txt, awfm.AwFmAlphabetAmino, ratio, k)
         _same_arrays(host, dev)
         host.dealloc()
@@ -54,7 +64,7 @@ def test_repetitive_texts_need_doubling_rounds(awfm, require_gpu):
              bytes(synth.text(3, 2000)) * 40]
     for raw in cases:
         txt = np.frombuffer(raw, np.uint8)
-        host = awfm.create_index(txt, awfm.AwFmAlphabetDna, 4, 4)
+        host = _host_build(awfm, txt, awfm.AwFmAlphabetDna, 4, 4)
         dev = awfm.gpu_create_index(txt, awfm.AwFmAlphabetDna, 4, 4)
         _same_arrays(host, dev)
         host.dealloc()
@@ -119,3 +129,50 @@ def test_device_mixed_generator_matches_numpy(awfm, require_gpu):
     d_chars = torch.empty(int(d_off[-1].item()), dtype=torch.uint8, device="cuda")
     assert L.awfmGpuSynthMixedQueries(d_chars.data_ptr(), d_off.data_ptr(), 40, count, 16, d_text.data_ptr(), n, 0, None) == 1
     assert np.array_equal(d_chars.cpu().numpy(), chars)
+
+
+def test_drop_in_create_index_goes_to_the_gpu_builder_and_writes_the_same_file(awfm, require_gpu, tmp_path, monkeypatch):
+    """awFmCreateIndex / awFmCreateIndexFromFasta of a text of 2^20 characters and more are built on the GPU: the
+    arrays AND the .awfmi file are byte-identical to the host builder's ($AWFM_HOST_BUILD=1), with the sequence
+    stored or not, the SA kept in memory or not, from a plain text and from a multi-record FASTA file"""
+    from avxwindowfmindex_amd import _lib
+    n = (1 << 20) + 12345
+    txt = synth.text(71, n).copy()
+    txt[1000:1100] = ord("N")
+    for keep_sa, store_seq in ((True, False), (False, True)):
+        files = {}
+        for where in ("gpu", "host"):
+            if where == "host":
+                monkeypatch.setenv("AWFM_HOST_BUILD", "1")
+            else:
+                monkeypatch.delenv("AWFM_HOST_BUILD", raising=False)
+            f = str(tmp_path / f"{where}_{int(keep_sa)}{int(store_seq)}.awfmi")
+            ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 7, keep_sa_in_memory=keep_sa, store_sequence=store_seq,
+                                   file_src=f)
+            # the GPU build leaves its device image registered for the batch search; the host build has none yet
+            files[where] = (open(f, "rb").read(), ix.blocks().copy(), ix.seed_table().copy(), ix.prefix_sums().copy())
+            ix.dealloc()
+        assert files["gpu"][0] == files["host"][0], "index files differ"
+        for a, b in zip(files["gpu"][1:], files["host"][1:]):
+            assert np.array_equal(a, b)
+    # FASTA: three records, wrapped lines
+    recs = [synth.text(80 + i, 400000 + 1000 * i).tobytes() for i in range(3)]
+    fa = tmp_path / "big.fa"
+    with open(fa, "wb") as out:
+        for i, r in enumerate(recs):
+            out.write(b">record %d some description\n" % i)
+            for at in range(0, len(r), 70):
+                out.write(r[at:at + 70] + b"\n")
+    blobs = {}
+    for where in ("gpu", "host"):
+        if where == "host":
+            monkeypatch.setenv("AWFM_HOST_BUILD", "1")
+        else:
+            monkeypatch.delenv("AWFM_HOST_BUILD", raising=False)
+        f = str(tmp_path / f"fa_{where}.awfmi")
+        ix = awfm.create_index_from_fasta(str(fa), awfm.AwFmAlphabetDna, 8, 6, file_src=f)
+        assert _lib.lib().awFmGetNumSequences(ix.ptr) == 3 and ix.header(2) == b"record 2 some description"
+        assert ix.local_position(len(recs[0]) + 1 + 5) == (1, 5)
+        blobs[where] = open(f, "rb").read()
+        ix.dealloc()
+    assert blobs["gpu"] == blobs["host"], "FASTA index files differ"
