@@ -1,0 +1,57 @@
+"""Compile-time guard for the two kernels the headline depends on: the default search kernel and the default
+walk kernel must keep 8 waves per SIMD (<= 64 VGPRs), spill nothing, and keep their LDS footprint (the code is
+cross-compiled for gfx950 with hipcc; no GPU needed)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "avxwindowfmindex_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def kernel_metadata(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not installed")
+    out = tmp_path_factory.mktemp("isa") / "awfm_gpu.s"
+    subprocess.check_call([HIPCC, "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + CSRC, "-Wno-unused-function", "-S", "--cuda-device-only", "-o", str(out),
+                           os.path.join(CSRC, "awfm_gpu.hip")], stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    meta = {}
+    for m in re.finditer(r"\.group_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.name:\s+(\S+)\n(?:.*\n)*?"
+                         r"\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n"
+                         r"\s+\.vgpr_spill_count:\s+(\d+)", text):
+        meta[m.group(2)] = {"lds": int(m.group(1)), "scratch": int(m.group(3)), "vgpr": int(m.group(4)),
+                            "spill": int(m.group(5))}
+    assert meta, "no kernel metadata found in the assembly"
+    return meta
+
+
+def _one(meta, pattern):
+    names = [n for n in meta if re.search(pattern, n)]
+    assert len(names) == 1, (pattern, names)
+    return meta[names[0]]
+
+
+def test_default_search_kernel_keeps_full_occupancy(kernel_metadata):
+    # searchKernel<AMINO=false, G=4, CSR=false, TALLY=false, NARROW=true>
+    k = _one(kernel_metadata, r"searchKernelILb0ELi4ELb0ELb0ELb1E")
+    assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0
+    assert k["lds"] <= 16 * 1024  # 8 workgroups of 256 threads per CU must fit the 160 KB of LDS
+
+
+def test_default_walk_kernel_keeps_full_occupancy(kernel_metadata):
+    # walkKernel<AMINO=false, G=4, POW2=true, NARROW=true>
+    k = _one(kernel_metadata, r"walkKernelILb0ELi4ELb1ELb1E")
+    assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0
+    assert k["lds"] <= 1024  # small arrays that are indexed dynamically get moved to LDS by hipcc: must not happen
+
+
+def test_no_search_or_walk_variant_uses_scratch(kernel_metadata):
+    bad = {n: v for n, v in kernel_metadata.items() if ("searchKernel" in n or "walkKernel" in n) and v["scratch"]}
+    assert not bad, bad
