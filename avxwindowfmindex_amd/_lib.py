@@ -27,7 +27,7 @@ API_SYMBOLS = [
 GPU_SYMBOLS = [
     "awfmGpuDeviceCount", "awfmGpuLastError", "awfmGpuIndexCreate", "awfmGpuIndexDestroy", "awfmGpuIndexAcquire", "awfmGpuIndexAcquireAll",
     "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuIndexSetDeepSeed", "awfmGpuIndexSetDenseSa", "awfmGpuPinnedBuffer", "awfmGpuLocateHostPinned", "awfmGpuAosLock",
-    "awfmGpuAosUnlock", "awfmGpuSearch",
+    "awfmGpuAosUnlock", "awfmGpuSearch", "awfmGpuSearchHits", "awfmGpuIndexSetOrdered", "awfmGpuSearchHitsIsOrdered", "awfmGpuLastOrderedKernelMs",
     "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
     "awfmGpuCreateIndex", "awfmGpuSearchTally", "awfmGpuSynthText", "awfmGpuSynthRandomQueries", "awfmGpuSynthPlantedQueries",
     "awfmGpuSynthMixedLengths", "awfmGpuSynthMixedQueries",
@@ -127,9 +127,13 @@ def lib():
         "awfmGpuIndexDeviceBytes": (u64, [vp]),
         "awfmGpuIndexDevice": (C.c_int, [vp]),
         "awfmGpuIndexSetKernel": (None, [vp, C.c_int]),
+        "awfmGpuIndexSetOrdered": (None, [vp, C.c_int]),
+        "awfmGpuSearchHitsIsOrdered": (C.c_int, [vp, C.c_int, C.c_uint32, u64]),
+        "awfmGpuLastOrderedKernelMs": (C.c_double, [vp]),
         "awfmGpuIndexSetDeepSeed": (C.c_int, [vp, C.c_uint]),
         "awfmGpuIndexSetDenseSa": (C.c_int, [vp, C.c_int]),
         "awfmGpuSearch": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
+        "awfmGpuSearchHits": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuScanScratchBytes": (u64, [u64]),
         "awfmGpuHitOffsets": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),
         "awfmGpuLocate": (C.c_int, [vp, vp, vp, u64, u64, vp, vp]),

@@ -286,6 +286,21 @@ class GpuIndex:
         _check("awfmGpuSearch", _lib.lib().awfmGpuSearch(self.handle, d_chars, d_offsets or None, fixed_length, n,
                                                          d_ranges or None, d_counts or None, stream or None))
 
+    def search_hits(self, d_chars, d_offsets, fixed_length, n, d_ranges, d_counts, stream=0):
+        """awfmGpuSearchHits: like search(), but a query without hits only gets count 0 and some empty range"""
+        _check("awfmGpuSearchHits", _lib.lib().awfmGpuSearchHits(self.handle, d_chars, d_offsets or None, fixed_length,
+                                                                 n, d_ranges or None, d_counts or None, stream or None))
+
+    def search_hits_is_ordered(self, has_offsets, fixed_length, n):
+        return bool(_lib.lib().awfmGpuSearchHitsIsOrdered(self.handle, int(bool(has_offsets)), fixed_length, n))
+
+    def last_ordered_kernel_ms(self):
+        return float(_lib.lib().awfmGpuLastOrderedKernelMs(self.handle))
+
+    def set_ordered(self, mode):
+        """-1 automatic, 0 never, 1 always: search_hits() of fixed-length nucleotide batches in seed order"""
+        _lib.lib().awfmGpuIndexSetOrdered(self.handle, mode)
+
     def search_tally(self, d_chars, d_offsets, fixed_length, n):
         """{seeded, steps, blocks, chars} of the instrumented search kernel"""
         out = (C.c_uint64 * 4)()

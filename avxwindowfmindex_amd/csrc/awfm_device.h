@@ -51,6 +51,13 @@ struct DevIndex {
   unsigned int deepK;
 };
 
+/* a nucleotide query prepared for the ordered search path (awfm_ordered_kernel.h) */
+struct QueryRec {
+  unsigned long long codes; /* 2-bit letter codes of the k-mer, last character in bits 1..0 */
+  unsigned int index;       /* query number in the batch */
+  unsigned int length;      /* characters (1..32), or 0xFFFFFFFF: left to the general kernel */
+};
+
 constexpr int kThreads = 256;
 constexpr int kGroupsPerBlock = kThreads / 8;
 
@@ -351,6 +358,16 @@ struct AwFmGpuIndex {
   size_t workBytes = 0;
   void *dHits = nullptr; /* positions of the host-buffer locate calls, grow-only like dWork */
   size_t hitsBytes = 0;
+  /* ordered search path (awfm_gpu_ordered.hip): grow-only scratch shared by all searches on this image;
+   * the event orders its re-use across streams */
+  int orderMode = -1; /* -1 auto, 0 off, 1 on */
+  std::mutex orderMutex;
+  void *dOrder = nullptr;
+  size_t orderBytes = 0;
+  hipEvent_t orderEvent = nullptr;
+  bool orderEventRecorded = false;
+  hipEvent_t orderTiming[2] = {nullptr, nullptr}; /* around orderedSearchKernel when $AWFM_GPU_TIME_ORDERED is set */
+  bool orderTimed = false;
   std::mutex aosMutex;       /* serialises the AoS entry points (they share the pinned buffers) */
   void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pinnedBytes[4] = {0, 0, 0, 0};
@@ -368,6 +385,10 @@ struct DeviceGuard {
     if (previous >= 0) (void)hipSetDevice(previous);
   }
 };
+
+/* ordered hits-only search; 1 = searched, 0 = does not apply, <0 = -AwFmReturnCode (awfm_gpu_ordered.hip) */
+int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength,
+                         unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts);
 
 /* adopts device buffers that already hold a complete image (used by the GPU builder) */
 AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSeed, void *dSa,

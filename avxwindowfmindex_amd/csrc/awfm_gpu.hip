@@ -463,6 +463,10 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
     }
     if (g->dWork) (void)hipFree(g->dWork);
     if (g->dHits) (void)hipFree(g->dHits);
+    if (g->dOrder) (void)hipFree(g->dOrder);
+    if (g->orderEvent) (void)hipEventDestroy(g->orderEvent);
+    for (int i = 0; i < 2; i++)
+      if (g->orderTiming[i]) (void)hipEventDestroy(g->orderTiming[i]);
     for (int i = 0; i < 4; i++)
       if (g->pinned[i]) (void)hipHostFree(g->pinned[i]);
   }
@@ -679,6 +683,34 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
                       (ulonglong2 *)dRanges, dCounts, nullptr);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
+}
+
+/* Hits-only search (include/awfm_gpu.h): ordered path when it applies, else the general kernel, whose exact
+ * empty ranges satisfy the contract as well */
+enum AwFmReturnCode awfmGpuSearchHits(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                      uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
+                                      uint32_t *dCounts, void *stream) {
+  if (!g) {
+    setError("awfmGpuSearchHits: null image");
+    return AwFmNullPtrError;
+  }
+  if (numQueries == 0) return AwFmSuccess;
+  if (!dChars || (!dOffsets && fixedLength == 0)) {
+    setError("awfmGpuSearchHits: queries need dChars and either dOffsets or fixedLength");
+    return AwFmNullPtrError;
+  }
+  if (!dOffsets && (g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) {
+    DeviceGuard guard(g->device);
+    const int ordered = awfmGpuOrderedSearch(g, (hipStream_t)stream, dChars, fixedLength, numQueries,
+                                             (ulonglong2 *)dRanges, dCounts);
+    if (ordered < 0) return (enum AwFmReturnCode)(-ordered);
+    if (ordered > 0) return AwFmSuccess;
+  }
+  return awfmGpuSearch(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream);
+}
+
+void awfmGpuIndexSetOrdered(AwFmGpuIndex *g, int mode) {
+  if (g) g->orderMode = mode < 0 ? -1 : (mode != 0);
 }
 
 /* Instrumented run of the search kernel: tallyOut = {seeded queries, backward steps, distinct

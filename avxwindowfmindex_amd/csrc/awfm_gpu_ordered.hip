@@ -1,0 +1,197 @@
+/*
+ * awfm_gpu_ordered.hip -- host side of the ordered hits-only search (awfm_ordered_kernel.h): decides whether a
+ * batch takes it, owns its scratch memory in the device image, and launches
+ *   fillNoHitKernel -> encodeQueriesKernel -> rocprim::radix_sort_pairs -> orderedSearchKernel -> searchKernel<INDIRECT>
+ * on the caller's stream.  Called by awfmGpuSearchHits (awfm_gpu.hip); nothing here synchronises with the host
+ * except a scratch (re)allocation.
+ */
+#include <cstring>
+#include <cstdio>
+#include <cstdlib>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "awfm_ordered_kernel.h"
+
+namespace {
+
+inline size_t alignUp256(size_t v) { return (v + 255) / 256 * 256; }
+
+struct OrderScratch {
+  size_t keysIn, keysOut, recsIn, recsOut, generalCount, sortTemp, total;
+};
+
+OrderScratch scratchLayout(uint64_t n, size_t sortTempBytes) {
+  OrderScratch l;
+  size_t at = 0;
+  l.generalCount = at; /* word 0: the count; words 64, 128, ...: the per-XCD ticket counters */
+  at += 4096;
+  l.keysIn = at;
+  at += alignUp256(n * sizeof(unsigned short));
+  l.keysOut = at;
+  at += alignUp256(n * sizeof(unsigned short));
+  l.recsIn = at;
+  at += alignUp256(n * sizeof(QueryRec));
+  l.recsOut = at;
+  at += alignUp256(n * sizeof(QueryRec));
+  l.sortTemp = at;
+  at += alignUp256(sortTempBytes ? sortTempBytes : 256);
+  l.total = at;
+  return l;
+}
+
+template <class Kernel>
+unsigned residentGrid(const AwFmGpuIndex *g, Kernel kernel) {
+  int perCU = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kThreads, 0) != hipSuccess || perCU < 1) perCU = 4;
+  if (perCU > 8) perCU = 8;
+  if (const char *env = getenv("AWFM_GPU_BLOCKS_PER_CU")) {
+    const int v = atoi(env);
+    if (v >= 1 && v <= 64) perCU = v;
+  }
+  return (unsigned)g->numCUs * (unsigned)perCU;
+}
+
+template <bool NARROW>
+enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t len, unsigned depth,
+                                  const ulonglong2 *table, unsigned long long nq, const QueryRec *recs,
+                                  const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts) {
+  {
+    unsigned grid = residentGrid(g, orderedSearchKernel<4, NARROW>);
+    const unsigned long long blocks = (nq + kThreads / 4 - 1) / (kThreads / 4);
+    if (blocks < grid) grid = (unsigned)blocks;
+    if (grid >= 8u) grid &= ~7u; /* a multiple of the 8 XCDs, so that every XCD gets the same number of workgroups */
+    /* measurement hook (bench.py): HIP events around the dominant kernel on its launch stream */
+    const bool timed = getenv("AWFM_GPU_TIME_ORDERED") != nullptr;
+    if (timed && !g->orderTiming[0]) {
+      AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[0]), AwFmGeneralFailure);
+      AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[1]), AwFmGeneralFailure);
+    }
+    if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[0], s), AwFmGeneralFailure);
+    hipLaunchKernelGGL((orderedSearchKernel<4, NARROW>), dim3(grid ? grid : 1u), dim3(kThreads), 0, s, g->dev, recs, nq,
+                       generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64, getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0);
+    AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+    if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[1], s), AwFmGeneralFailure);
+    g->orderTimed = timed;
+  }
+  /* the queries the fast path left out (ambiguity characters; normally none): general kernel over the tail */
+  const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, NARROW, true>);
+  hipLaunchKernelGGL((searchKernel<false, 4, false, false, NARROW, true>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
+                     (const unsigned long long *)nullptr, len, nq, rng, dCounts, (unsigned long long *)nullptr, recs, nq,
+                     generalCount);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  return AwFmSuccess;
+}
+
+}  // namespace
+
+/* does a fixed-length batch of nq k-mers take the ordered path on this image?  depth/table: where its search starts */
+static bool orderedApplies(const AwFmGpuIndex *g, uint32_t fixedLength, unsigned long long nq, unsigned *depthOut,
+                           const ulonglong2 **tableOut) {
+  if (g->amino || fixedLength == 0 || fixedLength > 32 || nq >= 0xFFFFFFFFull) return false;
+  /* the table the search starts from: the deeper device-only one when it is built and the k-mers reach it */
+  const bool deep = g->dev.deepK != 0 && fixedLength >= g->dev.deepK;
+  const unsigned depth = deep ? g->dev.deepK : g->dev.seedK;
+  if (depth == 0 || depth >= 32 || fixedLength < depth) return false;
+  if (depthOut) *depthOut = depth;
+  if (tableOut) *tableOut = deep ? g->dev.deepSeed : g->dev.seed;
+  int mode = g->orderMode; /* -1 auto, 0 off, 1 on */
+  if (mode < 0) {
+    if (const char *env = getenv("AWFM_GPU_ORDERED")) mode = atoi(env) != 0;
+  }
+  if (mode < 0) {
+    /* worth its sort only when the batch is large and the image far exceeds the L2s */
+    mode = nq >= (1ull << 21) && g->dev.bwtLength >= (1ull << 27);
+  }
+  return mode != 0;
+}
+
+/* milliseconds orderedSearchKernel took in the last awfmGpuSearchHits on this image that ran with
+ * $AWFM_GPU_TIME_ORDERED set (waits for it); negative when there is none */
+extern "C" double awfmGpuLastOrderedKernelMs(AwFmGpuIndex *g) {
+  if (!g) return -1.0;
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  if (!g->orderTimed || !g->orderTiming[0]) return -1.0;
+  float ms = 0.0f;
+  if (hipEventSynchronize(g->orderTiming[1]) != hipSuccess ||
+      hipEventElapsedTime(&ms, g->orderTiming[0], g->orderTiming[1]) != hipSuccess)
+    return -1.0;
+  return (double)ms;
+}
+
+extern "C" int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets, uint32_t fixedLength, uint64_t numQueries) {
+  if (!g || hasOffsets) return 0;
+  if (!(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) return 0;
+  return orderedApplies(g, fixedLength, numQueries, nullptr, nullptr) ? 1 : 0;
+}
+
+/* 1: the batch was searched; 0: the ordered path does not apply (caller runs the general kernel); <0: -AwFmReturnCode */
+int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength,
+                         unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts) {
+  unsigned depth = 0;
+  const ulonglong2 *table = nullptr;
+  if (!orderedApplies(g, fixedLength, nq, &depth, &table)) return 0;
+
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  unsigned short *nullKeys = nullptr;
+  QueryRec *nullRecs = nullptr;
+  size_t sortTemp = 0;
+  if (rocprim::radix_sort_pairs(nullptr, sortTemp, nullKeys, nullKeys, nullRecs, nullRecs, (size_t)nq, 0u, kOrderKeyBits,
+                                s) != hipSuccess) {
+    setError("awfmGpuSearchHits: radix sort sizing failed");
+    return -(int)AwFmGeneralFailure;
+  }
+  const OrderScratch l = scratchLayout(nq, sortTemp);
+  if (l.total > g->orderBytes) {
+    /* hipFree waits for every stream of the device, so nothing still reads the old scratch */
+    if (g->dOrder) (void)hipFree(g->dOrder);
+    g->dOrder = nullptr;
+    g->orderBytes = 0;
+    const size_t want = l.total + l.total / 8;
+    if (hipMalloc(&g->dOrder, want) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0; /* no room for the scratch: the general kernel needs none */
+    }
+    g->orderBytes = want;
+  }
+  if (!g->orderEvent && hipEventCreateWithFlags(&g->orderEvent, hipEventDisableTiming) != hipSuccess) {
+    setError("awfmGpuSearchHits: hipEventCreate failed");
+    return -(int)AwFmGeneralFailure;
+  }
+  /* the scratch is shared by all searches on this image: order them across streams */
+  if (g->orderEventRecorded && hipStreamWaitEvent(s, g->orderEvent, 0) != hipSuccess) {
+    setError("awfmGpuSearchHits: hipStreamWaitEvent failed");
+    return -(int)AwFmGeneralFailure;
+  }
+  uint8_t *w = (uint8_t *)g->dOrder;
+  unsigned *generalCount = (unsigned *)(w + l.generalCount);
+  unsigned short *keysIn = (unsigned short *)(w + l.keysIn), *keysOut = (unsigned short *)(w + l.keysOut);
+  QueryRec *recsIn = (QueryRec *)(w + l.recsIn), *recsOut = (QueryRec *)(w + l.recsOut);
+#define ORDER_TRY(call)                     \
+  do {                                      \
+    hipError_t e__ = (call);                \
+    if (e__ != hipSuccess) {                \
+      setError(#call, e__);                 \
+      return -(int)AwFmGeneralFailure;      \
+    }                                       \
+  } while (0)
+  ORDER_TRY(hipMemsetAsync(generalCount, 0, 4096, s)); /* the count and the eight per-XCD ticket counters */
+  hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s, rng, dCounts, nq);
+  ORDER_TRY(hipGetLastError());
+  hipLaunchKernelGGL(encodeQueriesKernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, dChars, fixedLength, depth,
+                     nq, keysIn, recsIn, generalCount);
+  ORDER_TRY(hipGetLastError());
+  size_t tempBytes = sortTemp;
+  ORDER_TRY(rocprim::radix_sort_pairs(w + l.sortTemp, tempBytes, keysIn, keysOut, recsIn, recsOut, (size_t)nq, 0u,
+                                      kOrderKeyBits, s));
+  const enum AwFmReturnCode rc =
+      g->dev.bwtLength < (1ull << 32)
+          ? launchOrdered<true>(g, s, dChars, fixedLength, depth, table, nq, recsOut, generalCount, rng, dCounts)
+          : launchOrdered<false>(g, s, dChars, fixedLength, depth, table, nq, recsOut, generalCount, rng, dCounts);
+  if (rc != AwFmSuccess) return -(int)rc;
+  ORDER_TRY(hipEventRecord(g->orderEvent, s));
+  g->orderEventRecorded = true;
+#undef ORDER_TRY
+  return 1;
+}

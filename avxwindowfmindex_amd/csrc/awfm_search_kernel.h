@@ -97,12 +97,95 @@ struct PositionType<true> {
   typedef unsigned type;
 };
 
-template <bool AMINO, int G, bool CSR, bool TALLY, bool NARROW>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 4 && !TALLY && !CSR && !AMINO ? 8 : 2, 8)))
+/*
+ * One backward step of a nucleotide query whose next letter is a,c,g or t/u (`letter` 0..3), by the G lanes
+ * of its group.  Everything that does not depend on the block (plane selectors, position masks from the LDS
+ * table sMask[local * 8 + piece], C[a]) is computed between issuing the loads and the first use of their
+ * data; both blocks are requested before anything waits.  Returns whether sp-1 and ep share a block.
+ * ref src/AwFmSearch.c:42-159, src/AwFmOccurrence.c:18-31, :170-217.
+ */
+template <int G, bool NARROW>
+__device__ __forceinline__ bool nucFastStep(const DevIndex &ix, const unsigned long long *sC, const unsigned *sMask,
+                                            unsigned firstPiece, unsigned letter,
+                                            typename PositionType<NARROW>::type &sp,
+                                            typename PositionType<NARROW>::type &ep) {
+  constexpr int S = 8 / G;
+  typedef typename PositionType<NARROW>::type pos_t;
+  const pos_t q0 = sp - 1, q1 = ep;
+  const unsigned long long blk0 = q0 >> 8, blk1 = q1 >> 8;
+  const bool same = blk0 == blk1;
+  Piece p0[S], p1[S];
+  {
+    const Piece *a0 = (const Piece *)(ix.blocks + (blk0 * 8ull + firstPiece));
+#pragma unroll
+    for (int s = 0; s < S; s++) p0[s] = a0[s];
+  }
+  /* p1 starts as "whatever the registers hold" (no instruction); lanes with one block never use it */
+#pragma unroll
+  for (int s = 0; s < S; s++) asm volatile("" : "=v"(p1[s]));
+  if (!same) {
+    const Piece *a1 = (const Piece *)(ix.blocks + (blk1 * 8ull + firstPiece));
+#pragma unroll
+    for (int s = 0; s < S; s++) p1[s] = a1[s];
+  }
+  const unsigned c0m = 0u - (letter & 1u), c1m = 0u - (letter >> 1);
+  const unsigned *m0 = sMask + (((unsigned)q0 & 255u) * 8u + firstPiece);
+  const unsigned *m1 = sMask + (((unsigned)q1 & 255u) * 8u + firstPiece);
+  unsigned mask0[S], mask1[S];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    mask0[s] = m0[s];
+    mask1[s] = m1[s];
+  }
+  const pos_t cLetter = (pos_t)sC[letter];
+  const unsigned sameMask = same ? ~0u : 0u;
+  unsigned n0 = 0, n1 = 0;
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    const unsigned occ0 = nucOccFast(p0[s], c0m, c1m), occ1 = nucOccFast(p1[s], c0m, c1m);
+    n0 += __popc(occ0 & mask0[s]);
+    n1 += __popc(__builtin_amdgcn_bitop3_b32(occ0, occ1, sameMask, 0xE4) & mask1[s]); /* same ? occ0 : occ1 */
+  }
+  /* keep every loaded register allocated until here: a dead component (an unused count word) would be
+   * re-used for the values above while the load is in flight, which costs a full wait before them */
+#pragma unroll
+  for (int s = 0; s < S; s++) asm volatile("" ::"v"(p0[s]), "v"(p1[s]));
+  const unsigned kLo = 2u * letter, kHi = kLo + 1u;
+  unsigned lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    lo0 = (kLo % S) == (unsigned)s ? p0[s].w : lo0;
+    hi0 = (kHi % S) == (unsigned)s ? p0[s].w : hi0;
+    lo1 = (kLo % S) == (unsigned)s ? p1[s].w : lo1;
+    hi1 = (kHi % S) == (unsigned)s ? p1[s].w : hi1;
+  }
+  pos_t base0, base1;
+  if (NARROW) { /* counts < 2^32: the high words are zero */
+    base0 = (pos_t)groupShfl<G>(lo0, kLo / S);
+    base1 = (pos_t)groupShfl<G>(lo1, kLo / S);
+  } else {
+    base0 = (pos_t)(((unsigned long long)groupShfl<G>(hi0, kHi / S) << 32) | groupShfl<G>(lo0, kLo / S));
+    base1 = (pos_t)(((unsigned long long)groupShfl<G>(hi1, kHi / S) << 32) | groupShfl<G>(lo1, kLo / S));
+  }
+  base1 = same ? base0 : base1;
+  const unsigned packed = groupSum<G>(n0 | (n1 << 16));
+  sp = cLetter + base0 + (pos_t)(packed & 0xFFFFu);
+  ep = cLetter + base1 + (pos_t)(packed >> 16) - (pos_t)1;
+  return same;
+}
+
+/*
+ * INDIRECT: the kernel searches only the queries listed in the tail of an ordered record array (the ones the
+ * ordered path, awfm_ordered_kernel.h, leaves to this kernel): record i of the tail is
+ * subset[subsetTotal - *subsetCount + i], its .index the query number.
+ */
+template <bool AMINO, int G, bool CSR, bool TALLY, bool NARROW, bool INDIRECT = false>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 4 && !TALLY && !CSR && !AMINO && !INDIRECT ? 8 : 2, 8)))
     searchKernel(const DevIndex ix, const unsigned char *__restrict__ chars,
                  const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
                  const unsigned long long numQueries, ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts,
-                 unsigned long long *__restrict__ tally) {
+                 unsigned long long *__restrict__ tally, const QueryRec *__restrict__ subset = nullptr,
+                 const unsigned long long subsetTotal = 0, const unsigned *__restrict__ subsetCount = nullptr) {
   constexpr int S = 8 / G;          /* pieces (and window dwords) per lane */
   constexpr int V = AMINO ? 2 : 1;  /* uint4 per piece */
   constexpr int kGroups = kThreads / G;
@@ -171,16 +254,22 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
     }
   };
 
+  /* INDIRECT: i-th listed query -> query number; otherwise the identity */
+  const unsigned long long listed = INDIRECT ? (unsigned long long)*subsetCount : numQueries;
+  const QueryRec *subsetTail = INDIRECT ? subset + (subsetTotal - listed) : nullptr;
+  auto queryNumber = [&](unsigned long long i) -> unsigned long long {
+    return INDIRECT ? (unsigned long long)subsetTail[i].index : i;
+  };
   unsigned long long q = groupId;
 #pragma unroll
   for (int w = 0; w <= S; w++) nRaw[w] = 0u;
-  if (q < numQueries) {
-    nOff = queryOffsets(q);
+  if (q < listed) {
+    nOff = queryOffsets(queryNumber(q));
     requestWindow(nOff);
   }
-  if (CSR && q + numGroups < numQueries) fOff = queryOffsets(q + numGroups);
+  if (CSR && q + numGroups < listed) fOff = queryOffsets(queryNumber(q + numGroups));
 
-  for (; q < numQueries; q += numGroups) {
+  for (; q < listed; q += numGroups) {
     /* ---- the prefetched query becomes current ---- */
     const unsigned long long base = nOff.x;
     const unsigned len = pairLength(nOff);
@@ -195,11 +284,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
     /* ---- prefetch the next query's window (CSR: and the offsets of the one after) ---- */
     {
       const unsigned long long qn = q + numGroups;
-      if (qn < numQueries) {
-        nOff = CSR ? fOff : queryOffsets(qn);
+      if (qn < listed) {
+        nOff = CSR ? fOff : queryOffsets(queryNumber(qn));
         requestWindow(nOff);
       }
-      if (CSR && qn + numGroups < numQueries) fOff = queryOffsets(qn + numGroups);
+      if (CSR && qn + numGroups < listed) fOff = queryOffsets(queryNumber(qn + numGroups));
     }
     /* character i (>= wb) of the query out of the register window */
     auto windowChar = [&](unsigned i) -> unsigned {
@@ -321,71 +410,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
         /* ---- fast step: a,c,g,t/u inside the register window.  Everything that does not depend on
          * the block (letter, plane selectors, position masks from the LDS table, C[a]) is computed
          * between issuing the loads and the first use of their data. ---- */
-        const pos_t q0 = sp - 1, q1 = ep;
-        const unsigned long long blk0 = q0 >> 8, blk1 = q1 >> 8;
-        const bool same = blk0 == blk1;
-        Piece p0[S], p1[S];
-        {
-          const Piece *a0 = (const Piece *)(ix.blocks + (blk0 * 8ull + firstPiece));
-#pragma unroll
-          for (int s = 0; s < S; s++) p0[s] = a0[s];
-        }
-        /* p1 starts as "whatever the registers hold" (no instruction); lanes with one block never use it */
-#pragma unroll
-        for (int s = 0; s < S; s++) asm volatile("" : "=v"(p1[s]));
-        if (!same) {
-          const Piece *a1 = (const Piece *)(ix.blocks + (blk1 * 8ull + firstPiece));
-#pragma unroll
-          for (int s = 0; s < S; s++) p1[s] = a1[s];
-        }
+        const bool same = nucFastStep<G, NARROW>(ix, sC, sMask, firstPiece, (unsigned)rem & 3u, sp, ep);
         if (TALLY) {
           tSteps++;
           tBlocks += same ? 1ull : 2ull;
         }
-        const unsigned letter = (unsigned)rem & 3u;
-        const unsigned c0m = 0u - (letter & 1u), c1m = 0u - (letter >> 1);
-        const unsigned *m0 = sMask + (((unsigned)q0 & 255u) * 8u + firstPiece);
-        const unsigned *m1 = sMask + (((unsigned)q1 & 255u) * 8u + firstPiece);
-        unsigned mask0[S], mask1[S];
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-          mask0[s] = m0[s];
-          mask1[s] = m1[s];
-        }
-        const pos_t cLetter = (pos_t)sC[letter];
-        const unsigned sameMask = same ? ~0u : 0u;
-        unsigned n0 = 0, n1 = 0;
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-          const unsigned occ0 = nucOccFast(p0[s], c0m, c1m), occ1 = nucOccFast(p1[s], c0m, c1m);
-          n0 += __popc(occ0 & mask0[s]);
-          n1 += __popc(__builtin_amdgcn_bitop3_b32(occ0, occ1, sameMask, 0xE4) & mask1[s]); /* same ? occ0 : occ1 */
-        }
-        /* keep every loaded register allocated until here: a dead component (an unused count word) would be
-         * re-used for the values above while the load is in flight, which costs a full wait before them */
-#pragma unroll
-        for (int s = 0; s < S; s++) asm volatile("" ::"v"(p0[s]), "v"(p1[s]));
-        const unsigned kLo = 2u * letter, kHi = kLo + 1u;
-        unsigned lo0 = 0, hi0 = 0, lo1 = 0, hi1 = 0;
-#pragma unroll
-        for (int s = 0; s < S; s++) {
-          lo0 = (kLo % S) == (unsigned)s ? p0[s].w : lo0;
-          hi0 = (kHi % S) == (unsigned)s ? p0[s].w : hi0;
-          lo1 = (kLo % S) == (unsigned)s ? p1[s].w : lo1;
-          hi1 = (kHi % S) == (unsigned)s ? p1[s].w : hi1;
-        }
-        pos_t base0, base1;
-        if (NARROW) { /* counts < 2^32: the high words are zero */
-          base0 = (pos_t)groupShfl<G>(lo0, kLo / S);
-          base1 = (pos_t)groupShfl<G>(lo1, kLo / S);
-        } else {
-          base0 = (pos_t)(((unsigned long long)groupShfl<G>(hi0, kHi / S) << 32) | groupShfl<G>(lo0, kLo / S));
-          base1 = (pos_t)(((unsigned long long)groupShfl<G>(hi1, kHi / S) << 32) | groupShfl<G>(lo1, kLo / S));
-        }
-        base1 = same ? base0 : base1;
-        const unsigned packed = groupSum<G>(n0 | (n1 << 16));
-        sp = cLetter + base0 + (pos_t)(packed & 0xFFFFu);
-        ep = cLetter + base1 + (pos_t)(packed >> 16) - (pos_t)1;
         pos--;
         rem >>= 2;
         badTop <<= 1;
@@ -494,8 +523,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
     }
 
     if (gl == 0) {
-      if (ranges) ranges[q] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
-      if (counts) counts[q] = sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u;
+      const unsigned long long out = queryNumber(q);
+      if (ranges) ranges[out] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
+      if (counts) counts[out] = sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u;
     }
   }
   if (TALLY && gl == 0) { /* one lane per group carries the group's counters */

@@ -27,9 +27,33 @@ for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), 
     for (kernel, counter), v in acc.items():
         summary[kernel][counter] = {"dispatches": len(v), "mean": sum(v) / len(v)}
 json.dump(summary, open(os.path.join(dst, f"pmc_summary_{name}_bench.json"), "w"), indent=1, sort_keys=True)
-# the timed search kernel: most dispatches among the searchKernel instances (the tally launch runs once)
+# HBM bytes per search call.  Ordered path (awfmGpuSearchHits): every kernel of the call -- the "no hit" fill, the
+# encoding, the radix sort of (u16 key, record) pairs, orderedSearchKernel and the general kernel over the tail;
+# otherwise the one searchKernel instance that is launched per step (the tally launch runs once).
+def total(kernel, counter):
+    c = summary[kernel].get(counter)
+    return c["mean"] * c["dispatches"] if c else 0.0
+
+
+ordered = [k for k in summary if k.startswith("orderedSearchKernel") and "FETCH_SIZE" in summary[k]]
+if ordered:
+    calls = summary[ordered[0]]["FETCH_SIZE"]["dispatches"]
+    parts = [k for k in summary if k.startswith(("orderedSearchKernel", "fillNoHitKernel", "encodeQueriesKernel"))
+             or ("radix_sort" in k and "unsigned short" in k) or (k.startswith("searchKernel") and k.rstrip(">").endswith("true, true"))]
+    per_kernel = {k: {"read_bytes": 128 * total(k, "TCC_MISS_sum") / calls, "write_bytes": 1024 * total(k, "WRITE_SIZE") / calls,
+                      "launches_per_call": summary[k]["FETCH_SIZE"]["dispatches"] / calls} for k in parts}
+    hbm = sum(v["read_bytes"] + v["write_bytes"] for v in per_kernel.values())
+    json.dump({
+        "kernel": "awfmGpuSearchHits (ordered path): " + ", ".join(sorted(k.split("<")[0] for k in parts)),
+        "workload": workload, "per_kernel": per_kernel, "hbm_bytes_per_launch": int(hbm),
+        "method": "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum and --pmc WRITE_SIZE in separate passes "
+                  "(scripts/profile_bench.sh), summed over every kernel of one awfmGpuSearchHits call; reads = TCC_MISS_sum "
+                  "x 128 B (the L2 fills whole lines; for the search kernels this equals 2 x FETCH_SIZE, "
+                  "MI355X_MICROARCH.md HBM), writes = WRITE_SIZE",
+    }, open(os.path.join(dst, f"traffic_{name}.json"), "w"), indent=1)
+    print("ordered search call: HBM GB", hbm / 1e9, {k.split("<")[0]: round((v["read_bytes"] + v["write_bytes"]) / 1e9, 2) for k, v in per_kernel.items()})
 search = [k for k in summary if k.startswith("searchKernel") and "FETCH_SIZE" in summary[k]]
-if search:
+if search and not ordered:
     k = max(search, key=lambda x: summary[x]["FETCH_SIZE"]["dispatches"])
     fetch_kb, write_kb = summary[k]["FETCH_SIZE"]["mean"], summary[k].get("WRITE_SIZE", {"mean": 0.0})["mean"]
     miss = summary[k].get("TCC_MISS_sum", {"mean": None})["mean"]

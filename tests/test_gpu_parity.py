@@ -375,3 +375,121 @@ def test_drop_in_aos_api_two_default_lanes(oracle, awfm, require_gpu, monkeypatc
     assert _lib.lib().awfmGpuIndexAcquireAll(ix.ptr, imgs, 4) == 2 and imgs[0] != imgs[1]
     lst.dealloc()
     ix.dealloc()
+
+
+def _check_hits_contract(ranges, counts, sp, ep, cnt):
+    """awfmGpuSearchHits: exact range and count for queries with hits, count 0 and an empty range otherwise"""
+    hit = cnt > 0
+    assert np.array_equal(counts, cnt), "counts differ"
+    assert np.array_equal(ranges[hit, 0], sp[hit]) and np.array_equal(ranges[hit, 1], ep[hit]), "ranges of hits differ"
+    assert np.all(ranges[~hit, 0] > ranges[~hit, 1]), "a query without hits must have an empty range"
+
+
+@pytest.mark.parametrize("n,ratio,seed_k,deep_k,K", [(300000, 8, 8, 0, 21), (300000, 5, 8, 0, 8), (200000, 8, 6, 9, 32),
+                                                     (200000, 8, 6, 9, 7), (4096, 3, 4, 0, 13), (100000, 8, 1, 0, 5),
+                                                     (150000, 8, 10, 11, 11)])
+def test_ordered_hits_only_search_is_exact_on_hits(oracle, awfm, require_gpu, n, ratio, seed_k, deep_k, K):
+    """awfmGpuSearchHits with the ordered path forced on (fixed-length DNA batches): ambiguity characters and upper
+    case included, query buffer at every byte alignment, ranges only / counts only / both, then the locate
+    pipeline on top of the hits-only ranges"""
+    import torch
+    txt = synth.text(n + 13, n, synth.DNA_ALPHABET).copy()
+    txt[10:14] = ord("n")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, seed_k)
+    oi = oracle.Index.wrap(oracle.DNA, ratio, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    if deep_k:
+        g.set_deep_seed(deep_k)
+    Q = 30011
+    q = np.concatenate([synth.random_queries(5, Q // 2, K), synth.planted_queries(6, Q - Q // 2, K, txt)]).copy()
+    rng = np.random.default_rng(n + K)
+    flat = q.reshape(-1)
+    flat[rng.random(flat.size) < 0.002] = ord("x")      # ambiguity characters: those k-mers go to the general kernel
+    up = rng.random(flat.size) < 0.3
+    flat[up] = flat[up] & 0xDF
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    assert cnt.sum() > 0
+    dev = torch.device("cuda")
+    for mis in range(4):
+        buf = torch.zeros(chars.size + 64, dtype=torch.uint8, device=dev)
+        buf[mis:mis + chars.size] = torch.from_numpy(chars).to(dev)
+        d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
+        d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+        g.search_hits(buf.data_ptr() + mis, 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+        torch.cuda.synchronize()
+        r = d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2)
+        _check_hits_contract(r, d_counts.cpu().numpy().view(np.uint32), sp, ep, cnt)
+    d_ranges2 = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
+    g.search_hits(buf.data_ptr() + 3, 0, K, Q, d_ranges2.data_ptr(), 0)      # ranges only
+    d_counts2 = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+    g.search_hits(buf.data_ptr() + 3, 0, K, Q, 0, d_counts2.data_ptr())      # counts only
+    torch.cuda.synchronize()
+    assert torch.equal(d_ranges2, d_ranges) and torch.equal(d_counts2, d_counts)
+    # locate on top of the hits-only ranges
+    d_hit_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+    total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr())
+    assert total == len(pos) and np.array_equal(d_hit_off.cpu().numpy().view(np.uint64), hit_off)
+    d_pos = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+    g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, d_pos.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pos[:total].cpu().numpy().view(np.uint64), pos)
+    g.destroy()
+    ix.dealloc()
+
+
+def test_hits_only_search_falls_back_to_the_general_kernel(oracle, awfm, require_gpu):
+    """batches the ordered path does not cover (CSR offsets, k-mers shorter than the seed or longer than 32
+    characters, amino indices) still honour the hits-only contract"""
+    import torch
+    dev = torch.device("cuda")
+    txt = synth.text(17, 150000)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    chars, offsets = synth.mixed_queries(18, 9000, txt, synth.DNA_ALPHABET, 1, 40)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    d_chars, d_off = torch.from_numpy(chars).to(dev), torch.from_numpy(offsets.view(np.int64)).to(dev)
+    d_ranges = torch.zeros(9000 * 2, dtype=torch.int64, device=dev)
+    d_counts = torch.zeros(9000, dtype=torch.int32, device=dev)
+    g.search_hits(d_chars.data_ptr(), d_off.data_ptr(), 0, 9000, d_ranges.data_ptr(), d_counts.data_ptr())
+    torch.cuda.synchronize()
+    _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(-1, 2), d_counts.cpu().numpy().view(np.uint32),
+                         sp, ep, cnt)
+    for K in (5, 36):
+        q = np.concatenate([synth.random_queries(19, 2000, K), synth.planted_queries(20, 2000, K, txt)])
+        c, o = synth.fixed_csr(q)
+        sp, ep, cnt, _ = oi.batch_search(c, o)
+        d_c = torch.from_numpy(c).to(dev)
+        d_ranges = torch.zeros(4000 * 2, dtype=torch.int64, device=dev)
+        d_counts = torch.zeros(4000, dtype=torch.int32, device=dev)
+        g.search_hits(d_c.data_ptr(), 0, K, 4000, d_ranges.data_ptr(), d_counts.data_ptr())
+        torch.cuda.synchronize()
+        _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(-1, 2),
+                             d_counts.cpu().numpy().view(np.uint32), sp, ep, cnt)
+    g.destroy()
+    ix.dealloc()
+    atxt = synth.text(21, 60000, synth.AMINO_ALPHABET)
+    aix = awfm.create_index(atxt, awfm.AwFmAlphabetAmino, 8, 3)
+    aoi = oracle.Index.wrap(oracle.AMINO, 8, 3, aix.bwt_length, aix.blocks(), aix.prefix_sums(), aix.seed_table(),
+                            aix.packed_sa())
+    ag = awfm.GpuIndex(aix)
+    ag.set_ordered(1)
+    q = np.concatenate([synth.random_queries(22, 2000, 6, synth.AMINO_ALPHABET), synth.planted_queries(23, 2000, 6, atxt)])
+    c, o = synth.fixed_csr(q)
+    sp, ep, cnt, _ = aoi.batch_search(c, o)
+    d_c = torch.from_numpy(c).to(dev)
+    d_ranges = torch.zeros(4000 * 2, dtype=torch.int64, device=dev)
+    d_counts = torch.zeros(4000, dtype=torch.int32, device=dev)
+    ag.search_hits(d_c.data_ptr(), 0, 6, 4000, d_ranges.data_ptr(), d_counts.data_ptr())
+    torch.cuda.synchronize()
+    _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(-1, 2), d_counts.cpu().numpy().view(np.uint32),
+                         sp, ep, cnt)
+    ag.destroy()
+    aix.dealloc()
