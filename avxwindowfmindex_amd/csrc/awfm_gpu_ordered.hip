@@ -8,6 +8,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -22,19 +23,19 @@ struct OrderScratch {
   size_t keysIn, keysOut, recsIn, recsOut, generalCount, sortTemp, total;
 };
 
-OrderScratch scratchLayout(uint64_t n, size_t sortTempBytes) {
+OrderScratch scratchLayout(uint64_t n, size_t recordBytes, size_t sortTempBytes) {
   OrderScratch l;
   size_t at = 0;
-  l.generalCount = at; /* word 0: the count; words 64, 128, ...: the per-XCD ticket counters */
-  at += 4096;
+  l.generalCount = at; /* word 0: the count; words 64, 128, ...: the ticket counters (8 XCDs x 4 waves) */
+  at += 16384;
   l.keysIn = at;
   at += alignUp256(n * sizeof(unsigned short));
   l.keysOut = at;
   at += alignUp256(n * sizeof(unsigned short));
   l.recsIn = at;
-  at += alignUp256(n * sizeof(QueryRec));
+  at += alignUp256(n * recordBytes);
   l.recsOut = at;
-  at += alignUp256(n * sizeof(QueryRec));
+  at += alignUp256(n * recordBytes);
   l.sortTemp = at;
   at += alignUp256(sortTempBytes ? sortTempBytes : 256);
   l.total = at;
@@ -53,33 +54,50 @@ unsigned residentGrid(const AwFmGpuIndex *g, Kernel kernel) {
   return (unsigned)g->numCUs * (unsigned)perCU;
 }
 
-template <bool NARROW>
+template <int G, bool NARROW, bool COMPACT>
+enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t len, unsigned depth, const ulonglong2 *table,
+                                        unsigned long long nq, const void *recs, const unsigned short *keys,
+                                        const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts) {
+  unsigned grid = residentGrid(g, orderedSearchKernel<G, NARROW, COMPACT>);
+  const unsigned long long blocks = (nq + kThreads / G - 1) / (kThreads / G);
+  if (blocks < grid) grid = (unsigned)blocks;
+  if (grid >= 8u) grid &= ~7u; /* a multiple of the 8 XCDs, so that every XCD gets the same number of workgroups */
+  /* measurement hook (bench.py): HIP events around the dominant kernel on its launch stream */
+  const bool timed = getenv("AWFM_GPU_TIME_ORDERED") != nullptr;
+  if (timed && !g->orderTiming[0]) {
+    AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[0]), AwFmGeneralFailure);
+    AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[1]), AwFmGeneralFailure);
+  }
+  if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[0], s), AwFmGeneralFailure);
+  hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT>), dim3(grid ? grid : 1u), dim3(kThreads), 0, s, g->dev, recs,
+                     keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
+                     getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[1], s), AwFmGeneralFailure);
+  g->orderTimed = timed;
+  return AwFmSuccess;
+}
+
+template <bool NARROW, bool COMPACT>
 enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t len, unsigned depth,
-                                  const ulonglong2 *table, unsigned long long nq, const QueryRec *recs,
-                                  const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts) {
+                                  const ulonglong2 *table, unsigned long long nq, const void *recs,
+                                  const unsigned short *keys, const unsigned *generalCount, ulonglong2 *rng,
+                                  uint32_t *dCounts) {
   {
-    unsigned grid = residentGrid(g, orderedSearchKernel<4, NARROW>);
-    const unsigned long long blocks = (nq + kThreads / 4 - 1) / (kThreads / 4);
-    if (blocks < grid) grid = (unsigned)blocks;
-    if (grid >= 8u) grid &= ~7u; /* a multiple of the 8 XCDs, so that every XCD gets the same number of workgroups */
-    /* measurement hook (bench.py): HIP events around the dominant kernel on its launch stream */
-    const bool timed = getenv("AWFM_GPU_TIME_ORDERED") != nullptr;
-    if (timed && !g->orderTiming[0]) {
-      AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[0]), AwFmGeneralFailure);
-      AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[1]), AwFmGeneralFailure);
-    }
-    if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[0], s), AwFmGeneralFailure);
-    hipLaunchKernelGGL((orderedSearchKernel<4, NARROW>), dim3(grid ? grid : 1u), dim3(kThreads), 0, s, g->dev, recs, nq,
-                       generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64, getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0);
-    AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-    if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[1], s), AwFmGeneralFailure);
-    g->orderTimed = timed;
+    const char *lanes = getenv("AWFM_GPU_ORDERED_LANES"); /* measurement knob: 2 | 4 | 8 lanes per query (default 4) */
+    const int G = lanes ? atoi(lanes) : 4;
+    enum AwFmReturnCode rc;
+    if (G == 2) rc = launchOrderedKernel<2, NARROW, COMPACT>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
+    else if (G == 8) rc = launchOrderedKernel<8, NARROW, COMPACT>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
+    else rc = launchOrderedKernel<4, NARROW, COMPACT>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
+    if (rc != AwFmSuccess) return rc;
   }
   /* the queries the fast path left out (ambiguity characters; normally none): general kernel over the tail */
   const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, NARROW, true>);
   hipLaunchKernelGGL((searchKernel<false, 4, false, false, NARROW, true>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
-                     (const unsigned long long *)nullptr, len, nq, rng, dCounts, (unsigned long long *)nullptr, recs, nq,
-                     generalCount);
+                     (const unsigned long long *)nullptr, len, nq, rng, dCounts, (unsigned long long *)nullptr,
+                     (const unsigned char *)recs, COMPACT ? 8u : (unsigned)sizeof(QueryRec),
+                     COMPACT ? 0u : (unsigned)offsetof(QueryRec, index), nq, generalCount);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
 }
@@ -134,15 +152,22 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   if (!orderedApplies(g, fixedLength, nq, &depth, &table)) return 0;
 
   std::lock_guard<std::mutex> lock(g->orderMutex);
+  const bool compact = orderCompact(fixedLength, depth) && !getenv("AWFM_GPU_ORDERED_WIDE"); /* 8-byte records */
   unsigned short *nullKeys = nullptr;
-  QueryRec *nullRecs = nullptr;
   size_t sortTemp = 0;
-  if (rocprim::radix_sort_pairs(nullptr, sortTemp, nullKeys, nullKeys, nullRecs, nullRecs, (size_t)nq, 0u, kOrderKeyBits,
-                                s) != hipSuccess) {
+  hipError_t sized;
+  if (compact) {
+    unsigned long long *nullRecs = nullptr;
+    sized = rocprim::radix_sort_pairs(nullptr, sortTemp, nullKeys, nullKeys, nullRecs, nullRecs, (size_t)nq, 0u, kOrderKeyBits, s);
+  } else {
+    QueryRec *nullRecs = nullptr;
+    sized = rocprim::radix_sort_pairs(nullptr, sortTemp, nullKeys, nullKeys, nullRecs, nullRecs, (size_t)nq, 0u, kOrderKeyBits, s);
+  }
+  if (sized != hipSuccess) {
     setError("awfmGpuSearchHits: radix sort sizing failed");
     return -(int)AwFmGeneralFailure;
   }
-  const OrderScratch l = scratchLayout(nq, sortTemp);
+  const OrderScratch l = scratchLayout(nq, compact ? 8 : sizeof(QueryRec), sortTemp);
   if (l.total > g->orderBytes) {
     /* hipFree waits for every stream of the device, so nothing still reads the old scratch */
     if (g->dOrder) (void)hipFree(g->dOrder);
@@ -167,7 +192,7 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   uint8_t *w = (uint8_t *)g->dOrder;
   unsigned *generalCount = (unsigned *)(w + l.generalCount);
   unsigned short *keysIn = (unsigned short *)(w + l.keysIn), *keysOut = (unsigned short *)(w + l.keysOut);
-  QueryRec *recsIn = (QueryRec *)(w + l.recsIn), *recsOut = (QueryRec *)(w + l.recsOut);
+  void *recsIn = w + l.recsIn, *recsOut = w + l.recsOut;
 #define ORDER_TRY(call)                     \
   do {                                      \
     hipError_t e__ = (call);                \
@@ -176,19 +201,30 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
       return -(int)AwFmGeneralFailure;      \
     }                                       \
   } while (0)
-  ORDER_TRY(hipMemsetAsync(generalCount, 0, 4096, s)); /* the count and the eight per-XCD ticket counters */
+  ORDER_TRY(hipMemsetAsync(generalCount, 0, 16384, s)); /* the count and the ticket counters */
   hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s, rng, dCounts, nq);
   ORDER_TRY(hipGetLastError());
-  hipLaunchKernelGGL(encodeQueriesKernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, dChars, fixedLength, depth,
-                     nq, keysIn, recsIn, generalCount);
-  ORDER_TRY(hipGetLastError());
+  const unsigned encodeGrid = (unsigned)((nq + 255) / 256);
   size_t tempBytes = sortTemp;
-  ORDER_TRY(rocprim::radix_sort_pairs(w + l.sortTemp, tempBytes, keysIn, keysOut, recsIn, recsOut, (size_t)nq, 0u,
-                                      kOrderKeyBits, s));
-  const enum AwFmReturnCode rc =
-      g->dev.bwtLength < (1ull << 32)
-          ? launchOrdered<true>(g, s, dChars, fixedLength, depth, table, nq, recsOut, generalCount, rng, dCounts)
-          : launchOrdered<false>(g, s, dChars, fixedLength, depth, table, nq, recsOut, generalCount, rng, dCounts);
+  if (compact) {
+    hipLaunchKernelGGL(encodeQueriesKernel<true>, dim3(encodeGrid), dim3(256), 0, s, dChars, fixedLength, depth, nq, keysIn,
+                       recsIn, generalCount);
+    ORDER_TRY(hipGetLastError());
+    ORDER_TRY(rocprim::radix_sort_pairs(w + l.sortTemp, tempBytes, keysIn, keysOut, (unsigned long long *)recsIn,
+                                        (unsigned long long *)recsOut, (size_t)nq, 0u, kOrderKeyBits, s));
+  } else {
+    hipLaunchKernelGGL(encodeQueriesKernel<false>, dim3(encodeGrid), dim3(256), 0, s, dChars, fixedLength, depth, nq, keysIn,
+                       recsIn, generalCount);
+    ORDER_TRY(hipGetLastError());
+    ORDER_TRY(rocprim::radix_sort_pairs(w + l.sortTemp, tempBytes, keysIn, keysOut, (QueryRec *)recsIn, (QueryRec *)recsOut,
+                                        (size_t)nq, 0u, kOrderKeyBits, s));
+  }
+  const bool narrow = g->dev.bwtLength < (1ull << 32);
+  enum AwFmReturnCode rc;
+  if (narrow && compact) rc = launchOrdered<true, true>(g, s, dChars, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts);
+  else if (narrow) rc = launchOrdered<true, false>(g, s, dChars, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts);
+  else if (compact) rc = launchOrdered<false, true>(g, s, dChars, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts);
+  else rc = launchOrdered<false, false>(g, s, dChars, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts);
   if (rc != AwFmSuccess) return -(int)rc;
   ORDER_TRY(hipEventRecord(g->orderEvent, s));
   g->orderEventRecorded = true;

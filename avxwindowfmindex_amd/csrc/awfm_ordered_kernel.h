@@ -52,6 +52,41 @@ __device__ __forceinline__ void decodeWord(unsigned word, unsigned &packed, unsi
   packed = ((t & 3u) << 6) | ((t >> 4) & 0x30u) | ((t >> 14) & 0x0Cu) | (t >> 24);
 }
 
+/*
+ * Sort key and record.  The key is the leading keyBits = min(15, 2*depth) bits of the table index (the low
+ * 2*depth bits of the code string), left-aligned in 15 bits.  A 16-byte QueryRec carries the whole code string.
+ * When the rest of the code string -- everything but those key bits, 2*len - keyBits bits -- fits 32 bits
+ * (k-mers of up to 23 characters), the record is 8 bytes instead: rest in the high word, query number in the
+ * low word; the sort then moves 10 bytes per query instead of 18, and the search rebuilds the codes from the
+ * sorted key and the rest.
+ */
+struct OrderFormat {
+  unsigned depth;    /* characters the table lookup consumes */
+  unsigned keyBits;  /* min(15, 2*depth) */
+  unsigned lowBits;  /* 2*depth - keyBits: table-index bits below the key */
+};
+__host__ __device__ inline OrderFormat orderFormat(unsigned depth) {
+  OrderFormat f;
+  f.depth = depth;
+  f.keyBits = 2u * depth < 15u ? 2u * depth : 15u;
+  f.lowBits = 2u * depth - f.keyBits;
+  return f;
+}
+__host__ __device__ inline bool orderCompact(unsigned len, unsigned depth) { return 2u * len - orderFormat(depth).keyBits <= 32u; }
+__device__ __forceinline__ unsigned orderKey(const OrderFormat &f, unsigned long long codes) {
+  const unsigned long long index = codes & ((1ull << (2u * f.depth)) - 1ull);
+  return (unsigned)(index >> f.lowBits) << (15u - f.keyBits);
+}
+__device__ __forceinline__ unsigned orderRest(const OrderFormat &f, unsigned long long codes) {
+  const unsigned long long low = codes & ((1ull << f.lowBits) - 1ull);
+  return (unsigned)(((codes >> (2u * f.depth)) << f.lowBits) | low);
+}
+__device__ __forceinline__ unsigned long long orderCodes(const OrderFormat &f, unsigned key, unsigned rest) {
+  const unsigned long long low = (unsigned long long)rest & ((1ull << f.lowBits) - 1ull);
+  const unsigned long long index = ((unsigned long long)(key >> (15u - f.keyBits)) << f.lowBits) | low;
+  return ((unsigned long long)(rest >> f.lowBits) << (2u * f.depth)) | index;
+}
+
 /* "no hit" everywhere: the ordered search only stores the queries that have hits */
 __global__ void __launch_bounds__(256)
     fillNoHitKernel(ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts, const unsigned long long n) {
@@ -62,11 +97,13 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-/* fixed-length batch, depth <= len <= 32: record + key per query; depth = the table the search starts from */
+/* fixed-length batch, depth <= len <= 32: record + key per query; depth = the table the search starts from;
+ * recs: QueryRec[numQueries], or unsigned long long[numQueries] when COMPACT */
+template <bool COMPACT>
 __global__ void __launch_bounds__(256)
     encodeQueriesKernel(const unsigned char *__restrict__ chars, const unsigned len, const unsigned depth,
                         const unsigned long long numQueries, unsigned short *__restrict__ keys,
-                        QueryRec *__restrict__ recs, unsigned *__restrict__ generalCount) {
+                        void *__restrict__ recs, unsigned *__restrict__ generalCount) {
   const unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
   const bool live = t < numQueries;
   unsigned long long codes = 0;
@@ -92,17 +129,17 @@ __global__ void __launch_bounds__(256)
   }
   const bool fast = live && bad == 0u;
   if (live) {
-    unsigned key = kOrderGeneralKey;
-    if (fast) {
-      const unsigned long long index = codes & ((1ull << (2u * depth)) - 1ull);
-      key = 2u * depth >= 15u ? (unsigned)(index >> (2u * depth - 15u)) : (unsigned)(index << (15u - 2u * depth));
+    const OrderFormat f = orderFormat(depth);
+    keys[t] = (unsigned short)(fast ? orderKey(f, codes) : kOrderGeneralKey);
+    if (COMPACT) {
+      ((unsigned long long *)recs)[t] = ((unsigned long long)(fast ? orderRest(f, codes) : 0u) << 32) | (unsigned)t;
+    } else {
+      QueryRec r;
+      r.codes = codes;
+      r.index = (unsigned)t;
+      r.length = fast ? len : 0xFFFFFFFFu;
+      ((QueryRec *)recs)[t] = r;
     }
-    keys[t] = (unsigned short)key;
-    QueryRec r;
-    r.codes = codes;
-    r.index = (unsigned)t;
-    r.length = fast ? len : 0xFFFFFFFFu;
-    recs[t] = r;
   }
   const unsigned long long general = __ballot(live && !fast);
   if ((threadIdx.x & 63u) == 0u && general != 0ull) atomicAdd(generalCount, (unsigned)__popcll(general));
@@ -113,14 +150,14 @@ __global__ void __launch_bounds__(256)
  * comes from a 16-byte record (read one iteration ahead) and only a non-empty final range is stored, under the
  * original query number.
  */
-template <int G, bool NARROW>
+template <int G, bool NARROW, bool COMPACT>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 4 ? 8 : 2, 8)))
-    orderedSearchKernel(const DevIndex ix, const QueryRec *__restrict__ recs, const unsigned long long numRecs,
+    orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
+                        const unsigned long long numRecs,
                         const unsigned *__restrict__ generalCount, const unsigned len, const unsigned depth,
                         const ulonglong2 *__restrict__ table, ulonglong2 *__restrict__ ranges,
                         unsigned *__restrict__ counts, unsigned *__restrict__ tickets, const int xcdMap = 0) {
   constexpr int S = 8 / G;
-  constexpr int kGroups = kThreads / G;
   typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sMask[256 * 8];
@@ -128,6 +165,13 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
   for (unsigned e = threadIdx.x; e < 256u * 8u; e += kThreads) sMask[e] = sliceMask(e >> 3, e & 7u);
   __syncthreads();
 
+  const OrderFormat format = orderFormat(depth);
+  /* a record as loaded, two 64-bit words: {codes, query number | length << 32}, or COMPACT {8-byte record, sorted
+   * key}; it is taken apart one iteration later, so nothing waits for the loads here */
+  auto readRecord = [&](unsigned long long at) -> ulonglong2 {
+    if (!COMPACT) return *(const ulonglong2 *)((const QueryRec *)recs + at);
+    return make_ulonglong2(((const unsigned long long *)recs)[at], (unsigned long long)keys[at]);
+  };
   const unsigned gl = threadIdx.x % G;
   const unsigned firstPiece = gl * S;
   /* the records the fast path covers come first in the order; each XCD takes a contiguous eighth of them */
@@ -140,33 +184,35 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
   const unsigned long long begin = share * xcd;
   const unsigned long long end = begin + share < covered ? begin + share : covered;
   (void)blockInXcd;
-  /* The workgroups of an XCD take chunks of kGroups consecutive records from a per-XCD ticket counter instead
-   * of a fixed stride: free-running workgroups drift apart, and with a fixed stride the records in flight on an
-   * XCD would then span many more buckets than its L2 holds the blocks of.  The ticket for the next chunk is
-   * drawn one iteration ahead, so its latency and the record read hide behind the current chunk. */
-  __shared__ unsigned sTicket[2];
-  unsigned *ticket = tickets + xcd * 64u; /* one counter per XCD, 256 bytes apart */
-  unsigned parity = 0;
-  if (threadIdx.x == 0) {
-    sTicket[0] = atomicAdd(ticket, 1u);
-    sTicket[1] = atomicAdd(ticket, 1u);
-  }
-  __syncthreads();
-  unsigned long long q = begin + (unsigned long long)sTicket[0] * kGroups + threadIdx.x / G;
-  unsigned long long qNext = begin + (unsigned long long)sTicket[1] * kGroups + threadIdx.x / G;
+  /* The waves of an XCD take chunks of 64/G consecutive records from ticket counters instead of a fixed stride:
+   * free-running waves drift apart, and with a fixed stride the records in flight on an XCD would then span
+   * many more buckets than its L2 holds the blocks of (8.7 ms with the stride, 5.8 ms with tickets).  Wave w of
+   * a workgroup draws from counter w of its XCD and takes chunk 4*ticket + w, so a counter sees a quarter of the
+   * traffic and no barrier ties the waves of a workgroup together.  A ticket is drawn two chunks ahead and read
+   * at the end of an iteration, so its latency and the record read hide behind the current chunk. */
+  constexpr unsigned kWaves = kThreads / 64, kChunk = 64 / G;
+  const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  unsigned *ticket = tickets + (xcd * kWaves + wave) * 64u; /* 256 bytes apart */
+  auto chunkBase = [&](unsigned t) -> unsigned long long {
+    return begin + ((unsigned long long)t * kWaves + wave) * kChunk;
+  };
+  unsigned drawn = 0;
+  if (lane == 0) drawn = atomicAdd(ticket, 1u);
+  unsigned long long base = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
+  if (lane == 0) drawn = atomicAdd(ticket, 1u);
+  unsigned long long baseNext = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
 
   const unsigned long long tableMask = (1ull << (2u * depth)) - 1ull;
   ulonglong2 raw = make_ulonglong2(0ull, 0ull); /* the prefetched record as two 64-bit words */
-  if (q < end) raw = *(const ulonglong2 *)(recs + q);
-  /* every thread of the workgroup leaves the loop in the same iteration: chunks are whole, q - threadIdx.x / G is uniform */
-  while (q - threadIdx.x / G < end) {
+  if (base + lane / G < end) raw = readRecord(base + lane / G);
+  while (base < end) { /* wave-uniform */
+    const unsigned long long q = base + lane / G;
     const bool live = q < end;
-    const unsigned long long codes = raw.x;
-    const unsigned index = (unsigned)raw.y;
-    /* draw the ticket after next, fetch the next chunk's record */
-    __syncthreads(); /* sTicket[parity] (the current chunk) has been read by everyone */
-    if (threadIdx.x == 0) sTicket[parity] = atomicAdd(ticket, 1u);
-    if (qNext < end) raw = *(const ulonglong2 *)(recs + qNext);
+    const unsigned long long codes = COMPACT ? orderCodes(format, (unsigned)raw.y, (unsigned)(raw.x >> 32)) : raw.x;
+    const unsigned index = COMPACT ? (unsigned)raw.x : (unsigned)raw.y;
+    /* draw the ticket after next (consumed at the bottom), fetch the next chunk's record */
+    if (lane == 0) drawn = atomicAdd(ticket, 1u);
+    if (baseNext + lane / G < end) raw = readRecord(baseNext + lane / G);
     /* ---- seed (ref src/AwFmKmerTable.c:4-51): the index table, or the deeper device-only one ---- */
     pos_t sp = 1, ep = 0;
     int pos = -1;
@@ -188,10 +234,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
       if (ranges) ranges[index] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
       if (counts) counts[index] = (unsigned)(ep - sp + (pos_t)1);
     }
-    __syncthreads(); /* the ticket drawn at the top of this iteration is visible */
-    q = qNext;
-    qNext = begin + (unsigned long long)sTicket[parity] * kGroups + threadIdx.x / G;
-    parity ^= 1u;
+    base = baseNext;
+    baseNext = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
   }
 }
 

@@ -176,15 +176,17 @@ __device__ __forceinline__ bool nucFastStep(const DevIndex &ix, const unsigned l
 
 /*
  * INDIRECT: the kernel searches only the queries listed in the tail of an ordered record array (the ones the
- * ordered path, awfm_ordered_kernel.h, leaves to this kernel): record i of the tail is
- * subset[subsetTotal - *subsetCount + i], its .index the query number.
+ * ordered path, awfm_ordered_kernel.h, leaves to this kernel): record i of the tail is record
+ * subsetTotal - *subsetCount + i of `subset` (records of subsetStride bytes), its first 32-bit word at byte
+ * subsetIndexAt the query number.
  */
 template <bool AMINO, int G, bool CSR, bool TALLY, bool NARROW, bool INDIRECT = false>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 4 && !TALLY && !CSR && !AMINO && !INDIRECT ? 8 : 2, 8)))
     searchKernel(const DevIndex ix, const unsigned char *__restrict__ chars,
                  const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
                  const unsigned long long numQueries, ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts,
-                 unsigned long long *__restrict__ tally, const QueryRec *__restrict__ subset = nullptr,
+                 unsigned long long *__restrict__ tally, const unsigned char *__restrict__ subset = nullptr,
+                 const unsigned subsetStride = 0, const unsigned subsetIndexAt = 0,
                  const unsigned long long subsetTotal = 0, const unsigned *__restrict__ subsetCount = nullptr) {
   constexpr int S = 8 / G;          /* pieces (and window dwords) per lane */
   constexpr int V = AMINO ? 2 : 1;  /* uint4 per piece */
@@ -256,9 +258,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
 
   /* INDIRECT: i-th listed query -> query number; otherwise the identity */
   const unsigned long long listed = INDIRECT ? (unsigned long long)*subsetCount : numQueries;
-  const QueryRec *subsetTail = INDIRECT ? subset + (subsetTotal - listed) : nullptr;
+  const unsigned char *subsetTail = INDIRECT ? subset + (subsetTotal - listed) * subsetStride + subsetIndexAt : nullptr;
   auto queryNumber = [&](unsigned long long i) -> unsigned long long {
-    return INDIRECT ? (unsigned long long)subsetTail[i].index : i;
+    return INDIRECT ? (unsigned long long)*(const unsigned *)(subsetTail + i * subsetStride) : i;
   };
   unsigned long long q = groupId;
 #pragma unroll
