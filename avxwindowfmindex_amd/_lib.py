@@ -28,7 +28,7 @@ GPU_SYMBOLS = [
     "awfmGpuDeviceCount", "awfmGpuLastError", "awfmGpuIndexCreate", "awfmGpuIndexDestroy", "awfmGpuIndexAcquire", "awfmGpuIndexAcquireAll",
     "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuIndexSetDeepSeed", "awfmGpuIndexSetDenseSa", "awfmGpuPinnedBuffer", "awfmGpuLocateHostPinned", "awfmGpuAosLock",
     "awfmGpuAosUnlock", "awfmGpuSearch", "awfmGpuSearchHits", "awfmGpuIndexSetOrdered", "awfmGpuSearchHitsIsOrdered", "awfmGpuLastOrderedKernelMs",
-    "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
+    "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuHitOffsetsFromCounts", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
     "awfmGpuCreateIndex", "awfmGpuSearchTally", "awfmGpuSynthText", "awfmGpuSynthRandomQueries", "awfmGpuSynthPlantedQueries",
     "awfmGpuSynthMixedLengths", "awfmGpuSynthMixedQueries",
 ]
@@ -136,6 +136,7 @@ def lib():
         "awfmGpuSearchHits": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuScanScratchBytes": (u64, [u64]),
         "awfmGpuHitOffsets": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),
+        "awfmGpuHitOffsetsFromCounts": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),
         "awfmGpuLocate": (C.c_int, [vp, vp, vp, u64, u64, vp, vp]),
         "awfmGpuCountHost": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp]),
         "awfmGpuLocateHost": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, C.POINTER(C.POINTER(u64))]),

@@ -314,6 +314,12 @@ class GpuIndex:
                                                                  C.byref(total), stream or None))
         return int(total.value)
 
+    def hit_offsets_from_counts(self, d_counts, n, d_hit_offsets, d_scratch, stream=0):
+        total = C.c_uint64(0)
+        _check("awfmGpuHitOffsetsFromCounts", _lib.lib().awfmGpuHitOffsetsFromCounts(
+            self.handle, d_counts, n, d_hit_offsets, d_scratch, C.byref(total), stream or None))
+        return int(total.value)
+
     def locate(self, d_ranges, d_hit_offsets, n, total_hits, d_positions, stream=0):
         _check("awfmGpuLocate", _lib.lib().awfmGpuLocate(self.handle, d_ranges, d_hit_offsets, n, total_hits,
                                                          d_positions, stream or None))

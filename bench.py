@@ -147,6 +147,7 @@ def main():
     search_events = []
     locate_events = []
     ordered_ms = []
+    narrow_counts = ix.bwt_length < (1 << 32)  # 32-bit counts are exact: hit offsets can be scanned from them
     ordered = g.search_hits_is_ordered(d_offsets is not None, K, Q)
     if ordered:
         os.environ["AWFM_GPU_TIME_ORDERED"] = "1"  # HIP events around orderedSearchKernel inside the library
@@ -158,14 +159,17 @@ def main():
         # counting and locating need the hits only (what awFmParallelSearchCount/Locate report): large
         # fixed-length batches are searched in seed order, the others by the general kernel
         g.search_hits(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr(),
-                      d_counts.data_ptr() if args.mode == "count" else 0, stream)  # locate needs the ranges only
+                      d_counts.data_ptr() if (args.mode == "count" or narrow_counts) else 0, stream)
         if record:
             e1.record()
             search_events.append((e0, e1))
             if ordered:
                 ordered_ms.append(g.last_ordered_kernel_ms())  # waits for that kernel only
         if args.mode == "locate":
-            total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
+            if narrow_counts:  # the scan reads 4-byte counts instead of 16-byte ranges
+                total = g.hit_offsets_from_counts(d_counts.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
+            else:
+                total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
             ensure_positions(total)
             if record:
                 e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -141,6 +141,10 @@ enum AwFmReturnCode awfmGpuSearchTally(AwFmGpuIndex *g, const uint8_t *dChars, c
 uint64_t awfmGpuScanScratchBytes(uint64_t numQueries);
 enum AwFmReturnCode awfmGpuHitOffsets(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges, uint64_t numQueries,
                                       uint64_t *dHitOffsets, void *dScratch, uint64_t *totalHits, void *stream);
+/* The same from the 32-bit counts awfmGpuSearch / awfmGpuSearchHits wrote (a quarter of the bytes of the
+ * ranges); exact, hence allowed, only for images below 2^32 positions. */
+enum AwFmReturnCode awfmGpuHitOffsetsFromCounts(AwFmGpuIndex *g, const uint32_t *dCounts, uint64_t numQueries,
+                                                uint64_t *dHitOffsets, void *dScratch, uint64_t *totalHits, void *stream);
 
 /* dPositions[dHitOffsets[i] + h] = text position of hit h (BWT order) of query i.
  * Asynchronous on `stream`. */

@@ -434,6 +434,9 @@ def test_ordered_hits_only_search_is_exact_on_hits(oracle, awfm, require_gpu, n,
     d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
     total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr())
     assert total == len(pos) and np.array_equal(d_hit_off.cpu().numpy().view(np.uint64), hit_off)
+    d_hit_off2 = torch.zeros(Q + 1, dtype=torch.int64, device=dev)  # the same offsets scanned from the 32-bit counts
+    assert g.hit_offsets_from_counts(d_counts.data_ptr(), Q, d_hit_off2.data_ptr(), d_scratch.data_ptr()) == total
+    assert torch.equal(d_hit_off2, d_hit_off)
     d_pos = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
     g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, d_pos.data_ptr())
     torch.cuda.synchronize()
