@@ -166,11 +166,23 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
   __syncthreads();
 
   const OrderFormat format = orderFormat(depth);
-  /* a record as loaded, two 64-bit words: {codes, query number | length << 32}, or COMPACT {8-byte record, sorted
-   * key}; it is taken apart one iteration later, so nothing waits for the loads here */
-  auto readRecord = [&](unsigned long long at) -> ulonglong2 {
-    if (!COMPACT) return *(const ulonglong2 *)((const QueryRec *)recs + at);
-    return make_ulonglong2(((const unsigned long long *)recs)[at], (unsigned long long)keys[at]);
+  /* A record as loaded: {codes, query number | length << 32} (16 bytes), or COMPACT the 8-byte record plus the
+   * aligned dword that holds its sorted 16-bit key.  Every loaded value lands in the register it is later read
+   * from (no widening, no copy: either would be waited for right after the load) and is taken apart one
+   * iteration later. */
+  struct Raw {
+    unsigned long long a, b; /* wide: the two words; COMPACT: a = record */
+    unsigned keyWord;        /* COMPACT */
+  };
+  auto readRecord = [&](unsigned long long at, Raw &r) {
+    if (COMPACT) {
+      r.a = ((const unsigned long long *)recs)[at];
+      r.keyWord = ((const unsigned *)keys)[at >> 1];
+    } else {
+      const ulonglong2 w = *(const ulonglong2 *)((const QueryRec *)recs + at);
+      r.a = w.x;
+      r.b = w.y;
+    }
   };
   const unsigned gl = threadIdx.x % G;
   const unsigned firstPiece = gl * S;
@@ -203,16 +215,20 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
   unsigned long long baseNext = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
 
   const unsigned long long tableMask = (1ull << (2u * depth)) - 1ull;
-  ulonglong2 raw = make_ulonglong2(0ull, 0ull); /* the prefetched record as two 64-bit words */
-  if (base + lane / G < end) raw = readRecord(base + lane / G);
+  Raw raw = {0ull, 0ull, 0u}; /* the prefetched record */
+  if (base + lane / G < end) readRecord(base + lane / G, raw);
   while (base < end) { /* wave-uniform */
     const unsigned long long q = base + lane / G;
     const bool live = q < end;
-    const unsigned long long codes = COMPACT ? orderCodes(format, (unsigned)raw.y, (unsigned)(raw.x >> 32)) : raw.x;
-    const unsigned index = COMPACT ? (unsigned)raw.x : (unsigned)raw.y;
+    /* the record fetched an iteration ago is taken apart BEFORE anything new is issued: a wait placed after the
+     * atomic below would also wait for that atomic */
+    asm volatile("" : "+v"(raw.a), "+v"(raw.b), "+v"(raw.keyWord)::"memory");
+    const unsigned key = (raw.keyWord >> (16u * (unsigned)(q & 1ull))) & 0xFFFFu;
+    const unsigned long long codes = COMPACT ? orderCodes(format, key, (unsigned)(raw.a >> 32)) : raw.a;
+    const unsigned index = COMPACT ? (unsigned)raw.a : (unsigned)raw.b;
     /* draw the ticket after next (consumed at the bottom), fetch the next chunk's record */
     if (lane == 0) drawn = atomicAdd(ticket, 1u);
-    if (baseNext + lane / G < end) raw = readRecord(baseNext + lane / G);
+    if (baseNext + lane / G < end) readRecord(baseNext + lane / G, raw);
     /* ---- seed (ref src/AwFmKmerTable.c:4-51): the index table, or the deeper device-only one ---- */
     pos_t sp = 1, ep = 0;
     int pos = -1;
