@@ -1017,8 +1017,11 @@ enum AwFmReturnCode awfmGpuCountHost(AwFmGpuIndex *g, const uint8_t *chars, cons
   AWFM_HIP_TRY(hipMemcpyAsync(w + l.chars, chars, totalChars, hipMemcpyHostToDevice, s), AwFmGeneralFailure);
   if (offsets)
     AWFM_HIP_TRY(hipMemcpyAsync(w + l.offsets, offsets, (numQueries + 1) * 8, hipMemcpyHostToDevice, s), AwFmGeneralFailure);
-  rc = awfmGpuSearch(g, w + l.chars, offsets ? (const uint64_t *)(w + l.offsets) : nullptr, fixedLength, numQueries,
-                     (struct AwFmSearchRange *)(w + l.ranges), (uint32_t *)(w + l.counts), s);
+  /* a caller that does not ask for the ranges only needs the hits (the AoS entry points): ordered search if it applies */
+  rc = (ranges ? awfmGpuSearch : awfmGpuSearchHits)(g, w + l.chars, offsets ? (const uint64_t *)(w + l.offsets) : nullptr,
+                                                    fixedLength, numQueries,
+                                                    ranges ? (struct AwFmSearchRange *)(w + l.ranges) : nullptr,
+                                                    (uint32_t *)(w + l.counts), s);
   if (rc != AwFmSuccess) return rc;
   if (ranges)
     AWFM_HIP_TRY(hipMemcpyAsync(ranges, w + l.ranges, numQueries * 16, hipMemcpyDeviceToHost, s), AwFmGeneralFailure);
@@ -1053,8 +1056,8 @@ static enum AwFmReturnCode locateHost(AwFmGpuIndex *g, const uint8_t *chars, con
     AWFM_HIP_TRY(hipMemcpyAsync(w + l.offsets, offsets, (numQueries + 1) * 8, hipMemcpyHostToDevice, s), AwFmGeneralFailure);
   struct AwFmSearchRange *dRanges = (struct AwFmSearchRange *)(w + l.ranges);
   uint64_t *dHitOffsets = (uint64_t *)(w + l.hitOffsets);
-  rc = awfmGpuSearch(g, w + l.chars, offsets ? (const uint64_t *)(w + l.offsets) : nullptr, fixedLength, numQueries,
-                     dRanges, nullptr, s);
+  rc = (ranges ? awfmGpuSearch : awfmGpuSearchHits)(g, w + l.chars, offsets ? (const uint64_t *)(w + l.offsets) : nullptr,
+                                                    fixedLength, numQueries, dRanges, nullptr, s);
   if (rc != AwFmSuccess) return rc;
   uint64_t totalHits = 0;
   rc = awfmGpuHitOffsets(g, dRanges, numQueries, dHitOffsets, w + l.scratch, &totalHits, s);

@@ -496,3 +496,28 @@ def test_hits_only_search_falls_back_to_the_general_kernel(oracle, awfm, require
                          sp, ep, cnt)
     ag.destroy()
     aix.dealloc()
+
+
+def test_drop_in_aos_api_uses_the_ordered_search_when_forced(oracle, awfm, require_gpu, monkeypatch):
+    """AWFM_GPU_ORDERED=1: the AoS entry points (which only report hits) search uniform-length lists in seed order"""
+    monkeypatch.setenv("AWFM_GPU_ORDERED", "1")
+    txt = synth.text(98, 200000)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    n = 30000
+    q = np.concatenate([synth.random_queries(99, n // 2, 17), synth.planted_queries(100, n - n // 2, 17, txt)]).copy()
+    q[7, 5] = ord("N")
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    lst = awfm.KmerSearchList(n)
+    lst.fill([bytes(r) for r in q])
+    awfm.parallel_search_count(ix, lst, 4)
+    assert np.array_equal(lst.counts(), cnt)
+    assert awfm.parallel_search_locate(ix, lst, 4) == awfm.AwFmSuccess
+    assert np.array_equal(lst.counts(), cnt)
+    for i in range(0, n, 29):
+        assert np.array_equal(lst.positions(i), pos[int(hit_off[i]):int(hit_off[i + 1])]), f"k-mer {i}"
+    lst.dealloc()
+    ix.dealloc()
