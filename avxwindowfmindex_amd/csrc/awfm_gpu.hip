@@ -702,10 +702,10 @@ enum AwFmReturnCode awfmGpuSearchHits(AwFmGpuIndex *g, const uint8_t *dChars, co
     setError("awfmGpuSearchHits: queries need dChars and either dOffsets or fixedLength");
     return AwFmNullPtrError;
   }
-  if (!dOffsets && (g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) {
+  if (g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4) {
     DeviceGuard guard(g->device);
-    const int ordered = awfmGpuOrderedSearch(g, (hipStream_t)stream, dChars, fixedLength, numQueries,
-                                             (ulonglong2 *)dRanges, dCounts);
+    const int ordered = awfmGpuOrderedSearch(g, (hipStream_t)stream, dChars, (const unsigned long long *)dOffsets, fixedLength,
+                                             numQueries, (ulonglong2 *)dRanges, dCounts);
     if (ordered < 0) return (enum AwFmReturnCode)(-ordered);
     if (ordered > 0) return AwFmSuccess;
   }

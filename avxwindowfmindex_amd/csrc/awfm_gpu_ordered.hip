@@ -54,11 +54,11 @@ unsigned residentGrid(const AwFmGpuIndex *g, Kernel kernel) {
   return (unsigned)g->numCUs * (unsigned)perCU;
 }
 
-template <int G, bool NARROW, bool COMPACT>
+template <int G, bool NARROW, bool COMPACT, bool VARLEN>
 enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t len, unsigned depth, const ulonglong2 *table,
                                         unsigned long long nq, const void *recs, const unsigned short *keys,
                                         const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts) {
-  unsigned grid = residentGrid(g, orderedSearchKernel<G, NARROW, COMPACT>);
+  unsigned grid = residentGrid(g, orderedSearchKernel<G, NARROW, COMPACT, VARLEN>);
   const unsigned long long blocks = (nq + kThreads / G - 1) / (kThreads / G);
   if (blocks < grid) grid = (unsigned)blocks;
   if (grid >= 8u) grid &= ~7u; /* a multiple of the 8 XCDs, so that every XCD gets the same number of workgroups */
@@ -69,7 +69,7 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
     AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[1]), AwFmGeneralFailure);
   }
   if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[0], s), AwFmGeneralFailure);
-  hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT>), dim3(grid ? grid : 1u), dim3(kThreads), 0, s, g->dev, recs,
+  hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN>), dim3(grid ? grid : 1u), dim3(kThreads), 0, s, g->dev, recs,
                      keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
                      getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
@@ -78,42 +78,47 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
   return AwFmSuccess;
 }
 
-template <bool NARROW, bool COMPACT>
-enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t len, unsigned depth,
-                                  const ulonglong2 *table, unsigned long long nq, const void *recs,
-                                  const unsigned short *keys, const unsigned *generalCount, ulonglong2 *rng,
-                                  uint32_t *dCounts) {
+template <bool NARROW, bool COMPACT, bool VARLEN>
+enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
+                                  uint32_t len, unsigned depth, const ulonglong2 *table, unsigned long long nq,
+                                  const void *recs, const unsigned short *keys, const unsigned *generalCount,
+                                  ulonglong2 *rng, uint32_t *dCounts) {
   {
     const char *lanes = getenv("AWFM_GPU_ORDERED_LANES"); /* measurement knob: 2 | 4 | 8 lanes per query (default 4) */
     const int G = lanes ? atoi(lanes) : 4;
     enum AwFmReturnCode rc;
-    if (G == 2) rc = launchOrderedKernel<2, NARROW, COMPACT>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
-    else if (G == 8) rc = launchOrderedKernel<8, NARROW, COMPACT>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
-    else rc = launchOrderedKernel<4, NARROW, COMPACT>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
+    if (G == 2) rc = launchOrderedKernel<2, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
+    else if (G == 8) rc = launchOrderedKernel<8, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
+    else rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
     if (rc != AwFmSuccess) return rc;
   }
-  /* the queries the fast path left out (ambiguity characters; normally none): general kernel over the tail */
-  const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, NARROW, true>);
-  hipLaunchKernelGGL((searchKernel<false, 4, false, false, NARROW, true>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
-                     (const unsigned long long *)nullptr, len, nq, rng, dCounts, (unsigned long long *)nullptr,
-                     (const unsigned char *)recs, COMPACT ? 8u : (unsigned)sizeof(QueryRec),
-                     COMPACT ? 0u : (unsigned)offsetof(QueryRec, index), nq, generalCount);
+  /* the queries the fast path left out (ambiguity characters, empty or longer than 32; normally none): general
+   * kernel over the tail of the order */
+  const unsigned grid = residentGrid(g, searchKernel<false, 4, VARLEN, false, NARROW, true>);
+  hipLaunchKernelGGL((searchKernel<false, 4, VARLEN, false, NARROW, true>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
+                     off, len, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)recs,
+                     COMPACT ? 8u : (unsigned)sizeof(QueryRec), COMPACT ? 0u : (unsigned)offsetof(QueryRec, index), nq,
+                     generalCount);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
 }
 
 }  // namespace
 
-/* does a fixed-length batch of nq k-mers take the ordered path on this image?  depth/table: where its search starts */
-static bool orderedApplies(const AwFmGpuIndex *g, uint32_t fixedLength, unsigned long long nq, unsigned *depthOut,
-                           const ulonglong2 **tableOut) {
-  if (g->amino || fixedLength == 0 || fixedLength > 32 || nq >= 0xFFFFFFFFull) return false;
-  /* the table the search starts from: the deeper device-only one when it is built and the k-mers reach it */
-  const bool deep = g->dev.deepK != 0 && fixedLength >= g->dev.deepK;
-  const unsigned depth = deep ? g->dev.deepK : g->dev.seedK;
-  if (depth == 0 || depth >= 32 || fixedLength < depth) return false;
-  if (depthOut) *depthOut = depth;
-  if (tableOut) *tableOut = deep ? g->dev.deepSeed : g->dev.seed;
+/* does a batch of nq k-mers (fixed length, or CSR when hasOffsets) take the ordered path on this image?
+ * depth/table: where the search of a fixed-length batch starts */
+static bool orderedApplies(const AwFmGpuIndex *g, bool hasOffsets, uint32_t fixedLength, unsigned long long nq,
+                           unsigned *depthOut, const ulonglong2 **tableOut) {
+  if (g->amino || nq >= 0xFFFFFFFFull || g->dev.seedK == 0 || g->dev.seedK >= 32 || g->dev.deepK >= 32) return false;
+  if (!hasOffsets) {
+    if (fixedLength == 0 || fixedLength > 32) return false;
+    /* the table the search starts from: the deeper device-only one when it is built and the k-mers reach it */
+    const bool deep = g->dev.deepK != 0 && fixedLength >= g->dev.deepK;
+    const unsigned depth = deep ? g->dev.deepK : g->dev.seedK;
+    if (fixedLength < depth) return false; /* shorter than the seed: the general kernel */
+    if (depthOut) *depthOut = depth;
+    if (tableOut) *tableOut = deep ? g->dev.deepSeed : g->dev.seed;
+  }
   int mode = g->orderMode; /* -1 auto, 0 off, 1 on */
   if (mode < 0) {
     if (const char *env = getenv("AWFM_GPU_ORDERED")) mode = atoi(env) != 0;
@@ -139,20 +144,21 @@ extern "C" double awfmGpuLastOrderedKernelMs(AwFmGpuIndex *g) {
 }
 
 extern "C" int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets, uint32_t fixedLength, uint64_t numQueries) {
-  if (!g || hasOffsets) return 0;
+  if (!g) return 0;
   if (!(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) return 0;
-  return orderedApplies(g, fixedLength, numQueries, nullptr, nullptr) ? 1 : 0;
+  return orderedApplies(g, hasOffsets != 0, fixedLength, numQueries, nullptr, nullptr) ? 1 : 0;
 }
 
 /* 1: the batch was searched; 0: the ordered path does not apply (caller runs the general kernel); <0: -AwFmReturnCode */
-int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength,
-                         unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts) {
+int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
+                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts) {
   unsigned depth = 0;
   const ulonglong2 *table = nullptr;
-  if (!orderedApplies(g, fixedLength, nq, &depth, &table)) return 0;
+  if (!orderedApplies(g, off != nullptr, fixedLength, nq, &depth, &table)) return 0;
 
   std::lock_guard<std::mutex> lock(g->orderMutex);
-  const bool compact = orderCompact(fixedLength, depth) && !getenv("AWFM_GPU_ORDERED_WIDE"); /* 8-byte records */
+  /* 8-byte records: fixed-length batches of short enough k-mers */
+  const bool compact = !off && orderCompact(fixedLength, depth) && !getenv("AWFM_GPU_ORDERED_WIDE");
   unsigned short *nullKeys = nullptr;
   size_t sortTemp = 0;
   hipError_t sized;
@@ -205,26 +211,33 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s, rng, dCounts, nq);
   ORDER_TRY(hipGetLastError());
   const unsigned encodeGrid = (unsigned)((nq + 255) / 256);
+  const unsigned seedK = g->dev.seedK, deepK = g->dev.deepK;
   size_t tempBytes = sortTemp;
   if (compact) {
-    hipLaunchKernelGGL(encodeQueriesKernel<true>, dim3(encodeGrid), dim3(256), 0, s, dChars, fixedLength, depth, nq, keysIn,
-                       recsIn, generalCount);
+    hipLaunchKernelGGL((encodeQueriesKernel<true, false>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
+                       seedK, deepK, nq, keysIn, recsIn, generalCount);
     ORDER_TRY(hipGetLastError());
     ORDER_TRY(rocprim::radix_sort_pairs(w + l.sortTemp, tempBytes, keysIn, keysOut, (unsigned long long *)recsIn,
                                         (unsigned long long *)recsOut, (size_t)nq, 0u, kOrderKeyBits, s));
   } else {
-    hipLaunchKernelGGL(encodeQueriesKernel<false>, dim3(encodeGrid), dim3(256), 0, s, dChars, fixedLength, depth, nq, keysIn,
-                       recsIn, generalCount);
+    if (off)
+      hipLaunchKernelGGL((encodeQueriesKernel<false, true>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
+                         seedK, deepK, nq, keysIn, recsIn, generalCount);
+    else
+      hipLaunchKernelGGL((encodeQueriesKernel<false, false>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
+                         seedK, deepK, nq, keysIn, recsIn, generalCount);
     ORDER_TRY(hipGetLastError());
     ORDER_TRY(rocprim::radix_sort_pairs(w + l.sortTemp, tempBytes, keysIn, keysOut, (QueryRec *)recsIn, (QueryRec *)recsOut,
                                         (size_t)nq, 0u, kOrderKeyBits, s));
   }
   const bool narrow = g->dev.bwtLength < (1ull << 32);
   enum AwFmReturnCode rc;
-  if (narrow && compact) rc = launchOrdered<true, true>(g, s, dChars, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts);
-  else if (narrow) rc = launchOrdered<true, false>(g, s, dChars, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts);
-  else if (compact) rc = launchOrdered<false, true>(g, s, dChars, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts);
-  else rc = launchOrdered<false, false>(g, s, dChars, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts);
+#define ORDER_GO(NR, CP, VL) \
+  launchOrdered<NR, CP, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts)
+  if (off) rc = narrow ? ORDER_GO(true, false, true) : ORDER_GO(false, false, true);
+  else if (compact) rc = narrow ? ORDER_GO(true, true, false) : ORDER_GO(false, true, false);
+  else rc = narrow ? ORDER_GO(true, false, false) : ORDER_GO(false, false, false);
+#undef ORDER_GO
   if (rc != AwFmSuccess) return -(int)rc;
   ORDER_TRY(hipEventRecord(g->orderEvent, s));
   g->orderEventRecorded = true;

@@ -97,20 +97,42 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-/* fixed-length batch, depth <= len <= 32: record + key per query; depth = the table the search starts from;
- * recs: QueryRec[numQueries], or unsigned long long[numQueries] when COMPACT */
-template <bool COMPACT>
+/* where the search of a k-mer of `len` characters starts: the deeper device-only table, the index's seed table,
+ * or (0) the letter range of its last character (ref src/AwFmSearch.c:485-520: k-mers shorter than the seed) */
+__host__ __device__ inline unsigned orderStartDepth(unsigned len, unsigned seedK, unsigned deepK) {
+  if (deepK != 0u && len >= deepK) return deepK;
+  return len >= seedK ? seedK : 0u;
+}
+
+/* Record + key per query.  Fixed-length batch (VARLEN false): every k-mer has fixedLen characters and starts at
+ * table depth fixedDepth; recs is QueryRec[numQueries], or unsigned long long[numQueries] when COMPACT.  CSR batch
+ * (VARLEN): lengths from the offsets, the start depth per k-mer (orderStartDepth), 16-byte records; the key of a
+ * k-mer that starts below a table is the leading bits of the k-mer itself, which is where its letter-range
+ * search ends up in the BWT.  K-mers the ordered kernel does not cover (ambiguity characters, no characters,
+ * more than 32) get the general key. */
+template <bool COMPACT, bool VARLEN>
 __global__ void __launch_bounds__(256)
-    encodeQueriesKernel(const unsigned char *__restrict__ chars, const unsigned len, const unsigned depth,
+    encodeQueriesKernel(const unsigned char *__restrict__ chars, const unsigned long long *__restrict__ offsets,
+                        const unsigned fixedLen, const unsigned fixedDepth, const unsigned seedK, const unsigned deepK,
                         const unsigned long long numQueries, unsigned short *__restrict__ keys,
                         void *__restrict__ recs, unsigned *__restrict__ generalCount) {
   const unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
   const bool live = t < numQueries;
-  unsigned long long codes = 0;
-  unsigned bad = 0;
+  unsigned long long codes = 0, start = 0;
+  unsigned bad = 0, len = fixedLen;
   if (live) {
+    if (VARLEN) {
+      start = offsets[t];
+      const unsigned long long l = offsets[t + 1] - start;
+      len = l > 33ull ? 33u : (unsigned)l;
+    } else {
+      start = t * fixedLen;
+    }
+  }
+  const bool inRange = live && len >= 1u && len <= 32u;
+  if (inRange) {
     /* aligned dwords that hold the query's bytes; a dword is only read when it contains one of them */
-    const unsigned long long at = (unsigned long long)chars + t * len;
+    const unsigned long long at = (unsigned long long)chars + start;
     const unsigned *first = (const unsigned *)(at & ~3ull);
     const unsigned shift = (unsigned)at & 3u;
     const unsigned numDwords = (shift + len + 3u) >> 2;
@@ -127,12 +149,25 @@ __global__ void __launch_bounds__(256)
     codes >>= 2u * (32u - len); /* character 0 was in bits 63..62: now the last character is in bits 1..0 */
     bad &= len >= 32u ? ~0u : ((1u << len) - 1u);
   }
-  const bool fast = live && bad == 0u;
+  const bool fast = inRange && bad == 0u;
   if (live) {
-    const OrderFormat f = orderFormat(depth);
-    keys[t] = (unsigned short)(fast ? orderKey(f, codes) : kOrderGeneralKey);
+    unsigned key = kOrderGeneralKey;
+    if (fast) {
+      if (VARLEN) {
+        /* leading 15 bits of the string the search starts from: the last `depth` characters, or the whole
+         * k-mer when it starts from a letter range */
+        const unsigned depth = orderStartDepth(len, seedK, deepK);
+        const unsigned span = depth ? depth : len; /* characters of that string, 1..32 */
+        const unsigned long long str = span >= 32u ? codes : (codes & ((1ull << (2u * span)) - 1ull));
+        key = 2u * span >= 15u ? (unsigned)(str >> (2u * span - 15u)) : (unsigned)(str << (15u - 2u * span));
+      } else {
+        key = orderKey(orderFormat(fixedDepth), codes);
+      }
+    }
+    keys[t] = (unsigned short)key;
     if (COMPACT) {
-      ((unsigned long long *)recs)[t] = ((unsigned long long)(fast ? orderRest(f, codes) : 0u) << 32) | (unsigned)t;
+      ((unsigned long long *)recs)[t] =
+          ((unsigned long long)(fast ? orderRest(orderFormat(fixedDepth), codes) : 0u) << 32) | (unsigned)t;
     } else {
       QueryRec r;
       r.codes = codes;
@@ -150,7 +185,7 @@ __global__ void __launch_bounds__(256)
  * comes from a 16-byte record (read one iteration ahead) and only a non-empty final range is stored, under the
  * original query number.
  */
-template <int G, bool NARROW, bool COMPACT>
+template <int G, bool NARROW, bool COMPACT, bool VARLEN>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 4 ? 8 : 2, 8)))
     orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
                         const unsigned long long numRecs,
@@ -226,19 +261,42 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
     const unsigned key = (raw.keyWord >> (16u * (unsigned)(q & 1ull))) & 0xFFFFu;
     const unsigned long long codes = COMPACT ? orderCodes(format, key, (unsigned)(raw.a >> 32)) : raw.a;
     const unsigned index = COMPACT ? (unsigned)raw.a : (unsigned)raw.b;
+    const unsigned myLen = VARLEN ? (unsigned)(raw.b >> 32) : len; /* before `raw` is overwritten by the prefetch */
     /* draw the ticket after next (consumed at the bottom), fetch the next chunk's record */
     if (lane == 0) drawn = atomicAdd(ticket, 1u);
     if (baseNext + lane / G < end) readRecord(baseNext + lane / G, raw);
     /* ---- seed (ref src/AwFmKmerTable.c:4-51): the index table, or the deeper device-only one ---- */
     pos_t sp = 1, ep = 0;
     int pos = -1;
-    if (live) {
-      const ulonglong2 r = table[codes & tableMask];
-      sp = (pos_t)r.x;
-      ep = (pos_t)r.y;
-      pos = (int)(len - depth) - 1;
+    unsigned long long rem;
+    if (!VARLEN) {
+      if (live) {
+        const ulonglong2 r = table[codes & tableMask];
+        sp = (pos_t)r.x;
+        ep = (pos_t)r.y;
+        pos = (int)(len - depth) - 1;
+      }
+      rem = codes >> (2u * depth); /* code of character `pos` in bits 1..0 */
+    } else {
+      /* per-query length (in the record) and start: deeper table, seed table, or the letter range of the last
+       * character (ref src/AwFmSearch.c:485-502) */
+      const unsigned myDepth = orderStartDepth(myLen, ix.seedK, ix.deepK);
+      if (live) {
+        if (myDepth != 0u) {
+          const ulonglong2 *from = myDepth == ix.seedK ? ix.seed : ix.deepSeed;
+          const ulonglong2 r = from[codes & ((1ull << (2u * myDepth)) - 1ull)];
+          sp = (pos_t)r.x;
+          ep = (pos_t)r.y;
+          pos = (int)(myLen - myDepth) - 1;
+        } else {
+          const unsigned a = (unsigned)codes & 3u;
+          sp = (pos_t)sC[a];
+          ep = (pos_t)(sC[a + 1] - 1ull);
+          pos = (int)myLen - 2;
+        }
+      }
+      rem = codes >> (myDepth != 0u ? 2u * myDepth : 2u);
     }
-    unsigned long long rem = codes >> (2u * depth); /* code of character `pos` in bits 1..0 */
 
     /* ---- extension (ref src/AwFmParallelSearch.c:273-313) ---- */
     while (pos >= 0 && sp <= ep) {

@@ -521,3 +521,101 @@ def test_drop_in_aos_api_uses_the_ordered_search_when_forced(oracle, awfm, requi
         assert np.array_equal(lst.positions(i), pos[int(hit_off[i]):int(hit_off[i + 1])]), f"k-mer {i}"
     lst.dealloc()
     ix.dealloc()
+
+
+@pytest.mark.parametrize("n,ratio,seed_k,deep_k", [(300000, 8, 8, 0), (200000, 8, 6, 9), (4096, 3, 4, 0), (100000, 8, 1, 0),
+                                                   (150000, 8, 10, 11), (250000, 7, 12, 0)])
+def test_ordered_hits_only_search_of_mixed_length_batches(oracle, awfm, require_gpu, n, ratio, seed_k, deep_k):
+    """CSR batches through the ordered path (forced on): lengths 0..40, so k-mers start from the deeper table, the
+    seed table or a letter range (shorter than the seed), and empty / over-long / ambiguous ones go to the general
+    kernel; counts, hit ranges, hit offsets and positions against the oracle"""
+    import torch
+    txt = synth.text(n + 17, n, synth.DNA_ALPHABET).copy()
+    txt[20:24] = ord("n")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, seed_k)
+    oi = oracle.Index.wrap(oracle.DNA, ratio, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    if deep_k:
+        g.set_deep_seed(deep_k)
+    Q = 25013
+    chars, offsets = _mixed_queries(4000 + n, Q, txt, synth.DNA_ALPHABET, 0, min(40, n), ambiguity=ord("x"), upper=True)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(np.concatenate([chars, np.zeros(8, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
+    d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+    assert g.search_hits_is_ordered(True, 0, Q)
+    g.search_hits(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+    torch.cuda.synchronize()
+    _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2), d_counts.cpu().numpy().view(np.uint32),
+                         sp, ep, cnt)
+    d_hit_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+    total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr())
+    assert total == len(pos) and np.array_equal(d_hit_off.cpu().numpy().view(np.uint64), hit_off)
+    d_pos = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+    g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, d_pos.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pos[:total].cpu().numpy().view(np.uint64), pos)
+    g.destroy()
+    ix.dealloc()
+
+
+def test_ordered_search_when_every_wave_takes_many_chunks(oracle, awfm, require_gpu):
+    """batches large enough that every wave of the ordered kernel draws several tickets (its record prefetch runs
+    ahead of the k-mer being searched): 600 000 mixed-length and 600 000 fixed-length k-mers, device generators,
+    counts / hit ranges / hit offsets / positions against the oracle"""
+    import torch
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda")
+    n, Q = 3_000_000, 600_000
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, 9, 0, None) == 1
+    ix = awfm.gpu_create_index(d_text.data_ptr(), awfm.AwFmAlphabetDna, 8, 9, on_device_length=n)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 9, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix, acquire=True)
+    g.set_ordered(1)
+    d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+    for mixed in (True, False):
+        if mixed:
+            d_len = torch.empty(Q, dtype=torch.int64, device=dev)
+            assert L.awfmGpuSynthMixedLengths(d_len.data_ptr(), 0, Q, 5, 32, 205, None) == 1
+            d_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(d_len, 0, out=d_off[1:])
+            d_chars = torch.empty(int(d_off[-1]) + 8, dtype=torch.uint8, device=dev)
+            assert L.awfmGpuSynthMixedQueries(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, 205, d_text.data_ptr(), n, 0, None) == 1
+            off_ptr, K = d_off.data_ptr(), 0
+            offsets = d_off.cpu().numpy().view(np.uint64)
+            chars = d_chars[: int(offsets[-1])].cpu().numpy()
+        else:
+            K = 19
+            d_chars = torch.empty(Q * K + 8, dtype=torch.uint8, device=dev)
+            assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr(), 0, Q // 2, K, 206, 0, None) == 1
+            assert L.awfmGpuSynthPlantedQueries(d_chars.data_ptr() + (Q // 2) * K, Q // 2, Q - Q // 2, K, 207,
+                                                d_text.data_ptr(), n, None) == 1
+            off_ptr = 0
+            chars = d_chars[: Q * K].cpu().numpy()
+            offsets = np.arange(Q + 1, dtype=np.uint64) * np.uint64(K)
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=8)
+        hit_off, pos, _ = oi.batch_locate(sp, ep, threads=8)
+        d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
+        d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+        assert g.search_hits_is_ordered(mixed, K, Q)
+        g.search_hits(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+        torch.cuda.synchronize()
+        _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2), d_counts.cpu().numpy().view(np.uint32),
+                             sp, ep, cnt)
+        d_hit_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+        total = g.hit_offsets_from_counts(d_counts.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr())
+        assert total == len(pos) and np.array_equal(d_hit_off.cpu().numpy().view(np.uint64), hit_off)
+        d_pos = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+        g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, d_pos.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_pos[:total].cpu().numpy().view(np.uint64), pos)
+    g.destroy()
+    ix.dealloc()
