@@ -17,11 +17,13 @@ HIPCC = "/opt/rocm/bin/hipcc"
 def kernel_metadata(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
-    out = tmp_path_factory.mktemp("isa") / "awfm_gpu.s"
-    subprocess.check_call([HIPCC, "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
-                           "-I" + CSRC, "-Wno-unused-function", "-S", "--cuda-device-only", "-o", str(out),
-                           os.path.join(CSRC, "awfm_gpu.hip")], stderr=subprocess.DEVNULL)
-    text = out.read_text()
+    text = ""
+    for source in ("awfm_gpu.hip", "awfm_gpu_ordered.hip"):
+        out = tmp_path_factory.mktemp("isa") / (source + ".s")
+        subprocess.check_call([HIPCC, "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + CSRC, "-Wno-unused-function", "-S", "--cuda-device-only", "-o", str(out),
+                               os.path.join(CSRC, source)], stderr=subprocess.DEVNULL)
+        text += out.read_text()
     meta = {}
     for m in re.finditer(r"\.group_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.name:\s+(\S+)\n(?:.*\n)*?"
                          r"\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)\n"
@@ -39,8 +41,8 @@ def _one(meta, pattern):
 
 
 def test_default_search_kernel_keeps_full_occupancy(kernel_metadata):
-    # searchKernel<AMINO=false, G=4, CSR=false, TALLY=false, NARROW=true>
-    k = _one(kernel_metadata, r"searchKernelILb0ELi4ELb0ELb0ELb1E")
+    # searchKernel<AMINO=false, G=4, CSR=false, TALLY=false, NARROW=true, INDIRECT=false>
+    k = _one(kernel_metadata, r"[0-9]searchKernelILb0ELi4ELb0ELb0ELb1ELb0EE")
     assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0
     assert k["lds"] <= 16 * 1024  # 8 workgroups of 256 threads per CU must fit the 160 KB of LDS
 
@@ -52,6 +54,15 @@ def test_default_walk_kernel_keeps_full_occupancy(kernel_metadata):
     assert k["lds"] <= 1024  # small arrays that are indexed dynamically get moved to LDS by hipcc: must not happen
 
 
+def test_ordered_search_kernels_keep_full_occupancy(kernel_metadata):
+    # orderedSearchKernel<G=4, NARROW=true, COMPACT, VARLEN>: the 8-byte-record, the 16-byte-record and the CSR variant
+    for variant in ("Lb1ELb1ELb0E", "Lb1ELb0ELb0E", "Lb1ELb0ELb1E"):
+        k = _one(kernel_metadata, r"orderedSearchKernelILi4E" + variant)
+        assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0, variant
+        assert k["lds"] <= 16 * 1024
+
+
 def test_no_search_or_walk_variant_uses_scratch(kernel_metadata):
-    bad = {n: v for n, v in kernel_metadata.items() if ("searchKernel" in n or "walkKernel" in n) and v["scratch"]}
+    bad = {n: v for n, v in kernel_metadata.items()
+           if ("searchKernel" in n or "walkKernel" in n or "orderedSearchKernel" in n) and v["scratch"]}
     assert not bad, bad
