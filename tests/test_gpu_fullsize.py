@@ -138,3 +138,46 @@ def test_batches_beyond_4_gib_of_query_characters(oracle, awfm, require_gpu):
     assert int((tail[:, 0] <= tail[:, 1]).sum()) == m  # the second half is planted
     g.destroy()
     ix.dealloc()
+
+
+def test_hits_only_search_takes_the_ordered_path_by_itself_and_agrees_with_the_general_kernel(oracle, awfm, require_gpu):
+    """automatic mode: 4.2 M k-mers against a 150 Mbp index cross both thresholds (2^21 queries, 2^27 positions);
+    every one of them is compared with awfmGpuSearch on the device, a sample with the oracle"""
+    import torch
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    n, K, Q = 150_000_000, 21, 4_200_000
+    dev = torch.device("cuda")
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, 8, 0, None) == 1
+    ix = awfm.gpu_create_index(d_text.data_ptr(), awfm.AwFmAlphabetDna, 8, 11, on_device_length=n)
+    g = awfm.GpuIndex(ix, acquire=True)
+    d_chars = torch.empty(Q * K + 8, dtype=torch.uint8, device=dev)
+    half = Q // 2
+    assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr(), 0, half, K, 108, 0, None) == 1
+    assert L.awfmGpuSynthPlantedQueries(d_chars.data_ptr() + half * K, half, Q - half, K, 109, d_text.data_ptr(), n, None) == 1
+    del d_text
+    assert g.search_hits_is_ordered(False, K, Q) and not g.search_hits_is_ordered(False, K, 1000)
+    exact = torch.zeros(Q * 2, dtype=torch.int64, device=dev)
+    hits = torch.full((Q * 2,), 5, dtype=torch.int64, device=dev)
+    counts = torch.full((Q,), 5, dtype=torch.int32, device=dev)
+    g.search(d_chars.data_ptr(), 0, K, Q, exact.data_ptr(), 0)
+    g.search_hits(d_chars.data_ptr(), 0, K, Q, hits.data_ptr(), counts.data_ptr())
+    torch.cuda.synchronize()
+    a, b = exact.view(Q, 2), hits.view(Q, 2)
+    has = a[:, 0] <= a[:, 1]
+    assert int(has.sum()) >= Q - half
+    assert torch.equal(a[has], b[has]), "ranges of k-mers with hits differ between the two kernels"
+    assert bool((b[~has, 0] > b[~has, 1]).all())
+    assert torch.equal(counts.to(torch.int64), torch.where(has, a[:, 1] - a[:, 0] + 1, torch.zeros_like(a[:, 0])))
+    m = 100_000  # the last m k-mers (planted) and the first m (random) against the oracle
+    oi = oracle.Index.wrap(oracle.DNA, 8, 11, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    for lo in (0, Q - m):
+        chars = d_chars[lo * K:(lo + m) * K].cpu().numpy()
+        sp, ep, cnt, _ = oi.batch_search(chars, np.arange(m + 1, dtype=np.uint64) * np.uint64(K), threads=8)
+        got = hits[2 * lo:2 * (lo + m)].cpu().numpy().view(np.uint64).reshape(m, 2)
+        hit = cnt > 0
+        assert np.array_equal(got[hit, 0], sp[hit]) and np.array_equal(got[hit, 1], ep[hit])
+        assert np.array_equal(counts[lo:lo + m].cpu().numpy().view(np.uint32), cnt)
+    g.destroy()
+    ix.dealloc()
