@@ -138,7 +138,7 @@ def main():
     d_hit_off = torch.empty(Q + 1, dtype=torch.int64, device=dev)
     d_scratch = torch.empty(api.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    state = {"positions": None, "hits": 0}
+    state = {"positions": None, "hits": 0, "sparse": True}
 
     def ensure_positions(total):
         if state["positions"] is None or state["positions"].numel() < max(total, 1):
@@ -158,15 +158,16 @@ def main():
             e0.record()
         # counting and locating need the hits only (what awFmParallelSearchCount/Locate report): large
         # fixed-length batches are searched in seed order, the others by the general kernel
+        use_counts = narrow_counts and state["sparse"]
         g.search_hits(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr(),
-                      d_counts.data_ptr() if (args.mode == "count" or narrow_counts) else 0, stream)
+                      d_counts.data_ptr() if (args.mode == "count" or use_counts) else 0, stream)
         if record:
             e1.record()
             search_events.append((e0, e1))
             if ordered:
                 ordered_ms.append(g.last_ordered_kernel_ms())  # waits for that kernel only
         if args.mode == "locate":
-            if narrow_counts:  # the scan reads 4-byte counts instead of 16-byte ranges
+            if use_counts:  # the scan reads 4-byte counts instead of 16-byte ranges
                 total = g.hit_offsets_from_counts(d_counts.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
             else:
                 total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
@@ -179,6 +180,9 @@ def main():
                 e3.record()
                 locate_events.append((e2, e3))
             state["hits"] = total
+            # when most k-mers have hits, a second per-query result (the count) costs a scattered store each in
+            # the ordered search, more than scanning the ranges does: decided from the previous step's hit total
+            state["sparse"] = total < Q // 4
 
     def barrier():
         shard.barrier(world, torch.cuda.synchronize)
