@@ -2,8 +2,9 @@
 """bench.py -- Mkmers/s located on a GRCh38-sized synthetic nucleotide FM-index, MI355X.
 
 One "step" = one pass of the hot path over one batch of synthetic k-mers already resident in HBM:
-search kernel (seed lookup + backward search) -> hit-offset scan -> expand + LF-walk/SA kernels,
-i.e. the device side of awFmParallelSearchLocate (ref src/AwFmParallelSearch.c:95-157).
+search (awfmGpuSearchHits: seed lookup + backward search; large fixed-length batches in seed order,
+DESIGN.md 4a) -> hit-offset scan -> expand + LF-walk/SA kernels, i.e. the device side of
+awFmParallelSearchLocate (ref src/AwFmParallelSearch.c:95-157).
 
 Workload (BASELINE.json configs[2]): 100 M uniform random 21-mers, locate, index of a 3.1 Gbp
 uniform synthetic text, SA compression 8, seed table k=12, one index replica per GPU, the query
@@ -11,10 +12,10 @@ batch sharded over the ranks with no collective (weak scaling: every rank has it
 `--workload planted` runs the secondary case (k-mers drawn from the text, >=1 hit each).
 
 The JSON line also carries
-  roofline     -- dominant kernel (searchKernel): algorithmic bytes (SURVEY.md 8d,
-                  bytes_count = L + 16 t + 104 D + 16 per query, D/t/L tallied on the device by an
-                  instrumented run of the same kernel) / mean kernel time from HIP events on the
-                  launch stream, against the 8 TB/s HBM peak;
+  roofline     -- the search call (all of its kernels; the dominant one is timed separately):
+                  algorithmic bytes (bytes_count = L + 16 t + 104 D + 16 per query,
+                  D/t/L tallied on the device by an instrumented run of the general kernel) / mean
+                  time from HIP events on the launch stream, against the 8 TB/s HBM peak;
   cpu_baseline -- the CPU oracle (a port of the reference's OpenMP 8-query lock-step driver) timed
                   on this box's host cores on a bounded sample of the same queries, after checking
                   that its results equal the GPU's on that sample.
