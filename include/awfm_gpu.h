@@ -111,8 +111,8 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
 /* Hits-only variant of awfmGpuSearch, for callers that go on to count or locate (what
  * awFmParallelSearchCount/Locate report: ref src/AwFmParallelSearch.c:159-220, :315-365): queries with hits get
  * exactly the range and count awfmGpuSearch gives them; a query WITHOUT hits gets count 0 and some empty range
- * (sp > ep), not necessarily the one the stepping ended in.  That freedom lets large nucleotide batches (>= 2^21
- * k-mers against >= 2^27 positions, fixed length or CSR; $AWFM_GPU_ORDERED=0|1 or awfmGpuIndexSetOrdered override)
+ * (sp > ep), not necessarily the one the stepping ended in.  That freedom lets large nucleotide batches (>= 2^23
+ * k-mers against >= 2^28 positions, fixed length or CSR; $AWFM_GPU_ORDERED=0|1 or awfmGpuIndexSetOrdered override)
  * be searched in seed order: the k-mers are packed into 8- or 16-byte records, sorted by the leading bits of the
  * string their search starts from (rocPRIM, 16-bit key), searched in that order so that neighbouring queries read
  * neighbouring blocks out of the L2, and only the non-empty results are stored under their query numbers over a

@@ -141,12 +141,12 @@ def test_batches_beyond_4_gib_of_query_characters(oracle, awfm, require_gpu):
 
 
 def test_hits_only_search_takes_the_ordered_path_by_itself_and_agrees_with_the_general_kernel(oracle, awfm, require_gpu):
-    """automatic mode: 4.2 M k-mers against a 150 Mbp index cross both thresholds (2^21 queries, 2^27 positions);
+    """automatic mode: 8.5 M k-mers against a 280 Mbp index cross both thresholds (2^23 queries, 2^28 positions);
     every one of them is compared with awfmGpuSearch on the device, a sample with the oracle"""
     import torch
     from avxwindowfmindex_amd import _lib
     L = _lib.lib()
-    n, K, Q = 150_000_000, 21, 4_200_000
+    n, K, Q = 280_000_000, 21, 8_500_000
     dev = torch.device("cuda")
     d_text = torch.empty(n, dtype=torch.uint8, device=dev)
     assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, 8, 0, None) == 1
