@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the ordered hits-only search against the general kernel, all on the GPU: random index
+sizes, seed depths, deeper tables, fixed and mixed k-mer lengths, ambiguity characters, buffer alignments.
+usage: scripts/fuzz_ordered.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+from avxwindowfmindex_amd import _lib, api  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+L = _lib.lib()
+dev = torch.device("cuda")
+t_end = time.time() + budget
+rounds = 0
+while time.time() < t_end:
+    n = int(rng.integers(200_000, 40_000_000))
+    seed_k = int(rng.integers(2, 13))
+    while 4 ** seed_k > 8 * n:
+        seed_k -= 1
+    deep_k = int(seed_k + rng.integers(1, 4)) if rng.random() < 0.4 else 0
+    ratio = int(rng.choice([1, 3, 8, 16, 255]))
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, int(rng.integers(1, 1 << 30)), 0, None) == 1
+    if rng.random() < 0.5:  # an ambiguity run in the text
+        at = int(rng.integers(0, n - 100))
+        d_text[at:at + int(rng.integers(1, 90))] = ord("n")
+    ix = api.gpu_create_index(d_text.data_ptr(), api.AwFmAlphabetDna, ratio, seed_k, on_device_length=n)
+    g = api.GpuIndex(ix, acquire=True)
+    g.set_ordered(1)
+    if deep_k and 4 ** deep_k * 16 < 2 << 30:
+        g.set_deep_seed(deep_k)
+    else:
+        deep_k = 0
+    for _ in range(3):
+        Q = int(rng.integers(50_000, 3_000_000))
+        qseed = int(rng.integers(1, 1 << 30))
+        mis = int(rng.integers(0, 4))
+        if rng.random() < 0.5:
+            lo, hi = sorted(int(x) for x in rng.integers(1, 41, size=2))
+            d_len = torch.empty(Q, dtype=torch.int64, device=dev)
+            assert L.awfmGpuSynthMixedLengths(d_len.data_ptr(), 0, Q, lo, hi, qseed, None) == 1
+            d_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(d_len, 0, out=d_off[1:])
+            total = int(d_off[-1])
+            buf = torch.zeros(total + 16, dtype=torch.uint8, device=dev)
+            d_off += mis  # offsets relative to an aligned base: shifts every k-mer by `mis` bytes
+            assert L.awfmGpuSynthMixedQueries(buf.data_ptr(), d_off.data_ptr(), 0, Q, qseed, d_text.data_ptr(), n, 0, None) == 1
+            chars_ptr, off_ptr, K, desc = buf.data_ptr(), d_off.data_ptr(), 0, f"csr {lo}..{hi}"
+            nchars = total + mis
+        else:
+            K = int(rng.integers(1, 36))
+            buf = torch.zeros(Q * K + 16, dtype=torch.uint8, device=dev)
+            half = Q // 2
+            assert L.awfmGpuSynthRandomQueries(buf.data_ptr() + mis, 0, half, K, qseed, 0, None) == 1
+            if K <= n:
+                assert L.awfmGpuSynthPlantedQueries(buf.data_ptr() + mis + half * K, half, Q - half, K, qseed + 1,
+                                                    d_text.data_ptr(), n, None) == 1
+            chars_ptr, off_ptr, desc = buf.data_ptr() + mis, 0, f"fixed {K}"
+            nchars = Q * K + mis
+        if rng.random() < 0.5:  # ambiguity characters and upper case in the queries
+            where = torch.rand(nchars, device=dev)
+            buf[:nchars][where < 0.001] = ord("x")
+            up = (where > 0.7) & (buf[:nchars] >= ord("a"))
+            buf[:nchars][up] -= 32
+        exact = torch.zeros(Q * 2, dtype=torch.int64, device=dev)
+        hits = torch.full((Q * 2,), 9, dtype=torch.int64, device=dev)
+        counts = torch.full((Q,), 9, dtype=torch.int32, device=dev)
+        g.search(chars_ptr, off_ptr, K, Q, exact.data_ptr(), 0)
+        g.search_hits(chars_ptr, off_ptr, K, Q, hits.data_ptr(), counts.data_ptr())
+        torch.cuda.synchronize()
+        a, b = exact.view(Q, 2), hits.view(Q, 2)
+        has = a[:, 0] <= a[:, 1]
+        expect = torch.where(has, a[:, 1] - a[:, 0] + 1, torch.zeros_like(a[:, 0])).clamp(max=0xFFFFFFFF)
+        ok = (torch.equal(a[has], b[has]) and bool((b[~has, 0] > b[~has, 1]).all())
+              and torch.equal(counts.to(torch.int64) & 0xFFFFFFFF, expect))
+        tag = f"n={n} k={seed_k} deep={deep_k} ratio={ratio} Q={Q} {desc} mis={mis} ordered={g.search_hits_is_ordered(off_ptr != 0, K, Q)}"
+        if not ok:
+            print("MISMATCH", tag, flush=True)
+            sys.exit(1)
+        if os.environ.get("FUZZ_VERBOSE"):
+            print(tag, "hits", int(has.sum()), flush=True)
+        rounds += 1
+    g.destroy()
+    ix.dealloc()
+    del d_text
+print(f"fuzz ok: {rounds} batches", flush=True)

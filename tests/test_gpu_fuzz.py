@@ -1,0 +1,17 @@
+"""A few seconds of scripts/fuzz_ordered.py: the ordered hits-only search against the general kernel over random
+index sizes, seed depths, deeper tables, fixed and mixed k-mer lengths, ambiguity characters and alignments."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12])
+def test_ordered_search_differential_fuzz(require_gpu, seed):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_ordered.py"), "6", str(seed)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fuzz ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
