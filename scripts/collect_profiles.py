@@ -41,15 +41,20 @@ if ordered:
     parts = [k for k in summary if k.startswith(("orderedSearchKernel", "fillNoHitKernel", "encodeQueriesKernel"))
              or ("radix_sort" in k and "unsigned short" in k) or (k.startswith("searchKernel") and k.rstrip(">").endswith("true, true"))]
     per_kernel = {k: {"read_bytes": 128 * total(k, "TCC_MISS_sum") / calls, "write_bytes": 1024 * total(k, "WRITE_SIZE") / calls,
+                      "FETCH_SIZE_bytes_raw": 1024 * total(k, "FETCH_SIZE") / calls,
                       "launches_per_call": summary[k]["FETCH_SIZE"]["dispatches"] / calls} for k in parts}
     hbm = sum(v["read_bytes"] + v["write_bytes"] for v in per_kernel.values())
     json.dump({
         "kernel": "awfmGpuSearchHits (ordered path): " + ", ".join(sorted(k.split("<")[0] for k in parts)),
         "workload": workload, "per_kernel": per_kernel, "hbm_bytes_per_launch": int(hbm),
         "method": "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum and --pmc WRITE_SIZE in separate passes "
-                  "(scripts/profile_bench.sh), summed over every kernel of one awfmGpuSearchHits call; reads = TCC_MISS_sum "
-                  "x 128 B (the L2 fills whole lines; for the search kernels this equals 2 x FETCH_SIZE, "
-                  "MI355X_MICROARCH.md HBM), writes = WRITE_SIZE",
+                  "(scripts/profile_bench.sh), summed over every kernel of one awfmGpuSearchHits call.  Reads = "
+                  "TCC_MISS_sum x 128 B (the L2 fills whole lines).  MI355X_MICROARCH.md (HBM): FETCH_SIZE counts a "
+                  "128-B request as 64 B for 16-B-per-lane loads and is uncalibrated for other widths; the kernels of "
+                  "this call mix widths (4-, 8- and 16-byte loads), so the line count is used for all of them and the raw "
+                  "FETCH_SIZE is kept beside it (for orderedSearchKernel, 16 B per lane on its block reads, 2 x "
+                  "FETCH_SIZE and the line count agree to a few percent).  Writes = WRITE_SIZE (exact for streaming "
+                  "stores)",
     }, open(os.path.join(dst, f"traffic_{name}.json"), "w"), indent=1)
     print("ordered search call: HBM GB", hbm / 1e9, {k.split("<")[0]: round((v["read_bytes"] + v["write_bytes"]) / 1e9, 2) for k, v in per_kernel.items()})
 search = [k for k in summary if k.startswith("searchKernel") and "FETCH_SIZE" in summary[k]]
