@@ -40,21 +40,19 @@ if ordered:
     calls = summary[ordered[0]]["FETCH_SIZE"]["dispatches"]
     parts = [k for k in summary if k.startswith(("orderedSearchKernel", "fillNoHitKernel", "encodeQueriesKernel"))
              or ("radix_sort" in k and "unsigned short" in k) or (k.startswith("searchKernel") and k.rstrip(">").endswith("true, true"))]
-    per_kernel = {k: {"read_bytes": 128 * total(k, "TCC_MISS_sum") / calls, "write_bytes": 1024 * total(k, "WRITE_SIZE") / calls,
-                      "FETCH_SIZE_bytes_raw": 1024 * total(k, "FETCH_SIZE") / calls,
+    per_kernel = {k: {"read_bytes": 2 * 1024 * total(k, "FETCH_SIZE") / calls, "write_bytes": 1024 * total(k, "WRITE_SIZE") / calls,
+                      "TCC_MISS_lines_x128": 128 * total(k, "TCC_MISS_sum") / calls,
                       "launches_per_call": summary[k]["FETCH_SIZE"]["dispatches"] / calls} for k in parts}
     hbm = sum(v["read_bytes"] + v["write_bytes"] for v in per_kernel.values())
     json.dump({
         "kernel": "awfmGpuSearchHits (ordered path): " + ", ".join(sorted(k.split("<")[0] for k in parts)),
         "workload": workload, "per_kernel": per_kernel, "hbm_bytes_per_launch": int(hbm),
-        "method": "rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum and --pmc WRITE_SIZE in separate passes "
-                  "(scripts/profile_bench.sh), summed over every kernel of one awfmGpuSearchHits call.  Reads = "
-                  "TCC_MISS_sum x 128 B (the L2 fills whole lines).  MI355X_MICROARCH.md (HBM): FETCH_SIZE counts a "
-                  "128-B request as 64 B for 16-B-per-lane loads and is uncalibrated for other widths; the kernels of "
-                  "this call mix widths (4-, 8- and 16-byte loads), so the line count is used for all of them and the raw "
-                  "FETCH_SIZE is kept beside it (for orderedSearchKernel, 16 B per lane on its block reads, 2 x "
-                  "FETCH_SIZE and the line count agree to a few percent).  Writes = WRITE_SIZE (exact for streaming "
-                  "stores)",
+        "method": "rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc TCC_HIT_sum TCC_MISS_sum in separate passes "
+                  "(scripts/profile_bench.sh), summed over every kernel of one awfmGpuSearchHits call.  Reads = 2 x FETCH_SIZE: "
+                  "on gfx950 FETCH_SIZE tallies each 128-B request at 64 B (MI355X_MICROARCH.md, HBM); the rule is "
+                  "calibrated here on encodeQueriesKernel, whose 2.1 GB of k-mer characters (dword loads) read as 1.05 GB "
+                  "of FETCH_SIZE.  Writes = WRITE_SIZE.  TCC_MISS_sum x 128 B is kept as a cross-check; it also counts "
+                  "the write-allocate misses of the stores (fillNoHitKernel: 2.0 GB of 'misses', no reads).",
     }, open(os.path.join(dst, f"traffic_{name}.json"), "w"), indent=1)
     print("ordered search call: HBM GB", hbm / 1e9, {k.split("<")[0]: round((v["read_bytes"] + v["write_bytes"]) / 1e9, 2) for k, v in per_kernel.items()})
 search = [k for k in summary if k.startswith("searchKernel") and "FETCH_SIZE" in summary[k]]
