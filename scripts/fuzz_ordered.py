@@ -82,6 +82,24 @@ while time.time() < t_end:
         if not ok:
             print("MISMATCH", tag, flush=True)
             sys.exit(1)
+        if rounds % 4 == 0 and int(expect.sum()) < 50_000_000:
+            # the locate pipeline on top of both: hit offsets (from ranges / from counts) and positions must agree
+            scratch = torch.zeros(api.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+            off_a = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+            off_b = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+            total_a = g.hit_offsets(exact.data_ptr(), Q, off_a.data_ptr(), scratch.data_ptr())
+            if ix.bwt_length < (1 << 32) and bool((expect < 0xFFFFFFFF).all()):
+                total_b = g.hit_offsets_from_counts(counts.data_ptr(), Q, off_b.data_ptr(), scratch.data_ptr())
+            else:
+                total_b = g.hit_offsets(hits.data_ptr(), Q, off_b.data_ptr(), scratch.data_ptr())
+            pos_a = torch.zeros(max(total_a, 1), dtype=torch.int64, device=dev)
+            pos_b = torch.zeros(max(total_b, 1), dtype=torch.int64, device=dev)
+            g.locate(exact.data_ptr(), off_a.data_ptr(), Q, total_a, pos_a.data_ptr())
+            g.locate(hits.data_ptr(), off_b.data_ptr(), Q, total_b, pos_b.data_ptr())
+            torch.cuda.synchronize()
+            if not (total_a == total_b and torch.equal(off_a, off_b) and torch.equal(pos_a, pos_b)):
+                print("LOCATE MISMATCH", tag, flush=True)
+                sys.exit(1)
         if os.environ.get("FUZZ_VERBOSE"):
             print(tag, "hits", int(has.sum()), flush=True)
         rounds += 1
