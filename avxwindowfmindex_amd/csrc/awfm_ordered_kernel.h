@@ -1,5 +1,5 @@
 /*
- * awfm_ordered_kernel.h -- the ordered, hits-only search of large fixed-length nucleotide batches
+ * awfm_ordered_kernel.h -- the ordered, hits-only search of large nucleotide batches, fixed-length or CSR
  * (awfmGpuSearchHits).
  *
  * The backward search of a batch of unrelated k-mers reads BWT blocks at random: every step of every query is
@@ -7,15 +7,18 @@
  * whatever the kernel does.  The order of the queries inside a batch is not part of the
  * result, so this path picks the order that makes those reads local:
  *
- *   1. encodeQueriesKernel: one thread per query packs the k-mer into 2-bit codes (a 16-byte record) and derives
- *      a 16-bit key = the leading bits of its seed-table index.  Queries with ambiguity characters get key
- *      0x8000 and are searched by the general kernel afterwards (searchKernel<INDIRECT>).
+ *   1. encodeQueriesKernel: one thread per query packs the k-mer into 2-bit codes (a 16-byte record, or 8 bytes
+ *      for fixed-length k-mers of up to 23 characters) and derives a 16-bit key = the leading bits of the string
+ *      its search starts from (its table index; the k-mer itself when it is shorter than the seed).  Queries with
+ *      ambiguity characters, no characters or more than 32 get key 0x8000 and are searched by the general kernel
+ *      afterwards (searchKernel<INDIRECT>).
  *   2. rocPRIM radix sort of (key, record): two 8-bit passes.
- *   3. orderedSearchKernel: the same seed lookup and the same backward steps as searchKernel (nucFastStep) over
- *      the records in key order.  Neighbours in that order start in neighbouring seed entries and, step after
+ *   3. orderedSearchKernel: the same table lookup and the same backward steps as searchKernel (nucFastStep) over
+ *      the records in key order.  Neighbours in that order start in neighbouring table entries and, step after
  *      step, land in neighbouring blocks (the range of cP lies in the c-section of the BWT in the order of P),
- *      so most block reads hit the L2.  Each XCD has its own L2: workgroup b runs on XCD b % 8, and every XCD
- *      walks one contiguous eighth of the order.
+ *      so most block reads hit the L2.  Each XCD has its own L2: workgroup b runs on XCD b % 8, every XCD walks
+ *      one contiguous eighth of the order, and its waves take consecutive chunks from ticket counters so that
+ *      what is in flight stays within what the L2 holds.
  *
  * Putting results back under the original query numbers is a scatter of one partial line per query, which costs
  * as much as the ordering saves -- unless it is sparse.  This path therefore reports HITS: the
