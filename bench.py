@@ -160,7 +160,7 @@ def main():
         # counting and locating need the hits only (what awFmParallelSearchCount/Locate report): large
         # fixed-length batches are searched in seed order, the others by the general kernel
         use_counts = narrow_counts and state["sparse"]
-        g.search_hits(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr(),
+        g.search_hits(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr() if args.mode == "locate" else 0,
                       d_counts.data_ptr() if (args.mode == "count" or use_counts) else 0, stream)
         if record:
             e1.record()
@@ -271,12 +271,13 @@ def main():
                 ho, pos, tl2 = oi.batch_locate(sp, ep, threads=threads)
             dt = time.perf_counter() - t0
             # parity gate on the sample: ranges and (for locate) hit positions in BWT order
-            gr = d_ranges[: 2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)
-            hit = cnt > 0  # hits-only contract: exact ranges for queries with hits, an empty range otherwise
-            assert np.array_equal(gr[hit, 0], sp[hit]) and np.array_equal(gr[hit, 1], ep[hit]), "GPU ranges differ from the oracle"
-            assert np.all(gr[~hit, 0] > gr[~hit, 1]), "GPU reports hits the oracle does not have"
-            if args.mode == "count":
+            if args.mode == "count":  # counting asks for the counts only
                 assert np.array_equal(d_counts[:m].cpu().numpy().view(np.uint32), cnt), "GPU counts differ from the oracle"
+            else:
+                gr = d_ranges[: 2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)
+                hit = cnt > 0  # hits-only contract: exact ranges for queries with hits, an empty range otherwise
+                assert np.array_equal(gr[hit, 0], sp[hit]) and np.array_equal(gr[hit, 1], ep[hit]), "GPU ranges differ from the oracle"
+                assert np.all(gr[~hit, 0] > gr[~hit, 1]), "GPU reports hits the oracle does not have"
             if args.mode == "locate":
                 gho = d_hit_off[: m + 1].cpu().numpy().view(np.uint64)
                 assert np.array_equal(gho, ho), "GPU hit offsets differ from the oracle"
