@@ -320,7 +320,8 @@ def main():
                    "index_build_s": round(build_s, 2),
                    "device_image_bytes": g.device_bytes, "device_seed_k": args.device_seed_k or args.seed_k,
                    "device_seed_build_s": round(deep_s, 2), "device_dense_sa": bool(args.device_dense_sa),
-                   "device_dense_sa_build_s": round(dense_s, 2)},
+                   "device_dense_sa_build_s": round(dense_s, 2),
+                   "search_path": "awfmGpuSearchHits, seed order" if ordered else "awfmGpuSearchHits, general kernel"},
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
