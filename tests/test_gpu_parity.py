@@ -619,3 +619,46 @@ def test_ordered_search_when_every_wave_takes_many_chunks(oracle, awfm, require_
         assert np.array_equal(d_pos[:total].cpu().numpy().view(np.uint64), pos)
     g.destroy()
     ix.dealloc()
+
+
+def test_rna_alphabet_and_u_for_t(oracle, awfm, require_gpu):
+    """AwFmAlphabetRna indices (ref src/AwFmIndex.h:30-34, src/AwFmLetter.c:4-22: u and t are the same letter):
+    text and queries written with u, t or a mix give the ranges and positions of the oracle's RNA index, through
+    the general kernel and through the ordered path"""
+    import torch
+    txt = synth.text(41, 200000).copy()
+    rna = txt.copy()
+    rna[rna == ord("t")] = ord("u")
+    rna[::7][rna[::7] == ord("u")] = ord("U")  # some upper case (a text that mixes t and u sorts them as two bytes
+    # in the reference too, src/AwFmLetter.c:33-36: not a consistent index, not tested)
+    ix = awfm.create_index(rna, awfm.AwFmAlphabetRna, 8, 7)
+    oi = oracle.Index.wrap(oracle.RNA, 8, 7, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    ref = oracle.Index.from_text(txt.tobytes(), oracle.DNA, 8, 7)  # the same text as DNA: identical arrays
+    assert np.array_equal(ix.blocks(), ref.blocks()) and np.array_equal(ix.seed_table(), ref.seed_table())
+    g = awfm.GpuIndex(ix)
+    Q, K = 20000, 15
+    q = np.concatenate([synth.random_queries(42, Q // 2, K), synth.planted_queries(43, Q - Q // 2, K, txt)]).copy()
+    flat = q.reshape(-1)
+    rng = np.random.default_rng(44)
+    sel = (flat == ord("t")) & (rng.random(flat.size) < 0.6)
+    flat[sel] = ord("u")
+    sel = (flat == ord("u")) & (rng.random(flat.size) < 0.3)
+    flat[sel] = ord("U")
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    assert cnt.sum() >= Q // 2
+    ranges, hoff, positions = g.locate_host(chars, offsets)
+    assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep)
+    assert np.array_equal(hoff, hit_off) and np.array_equal(positions, pos)
+    g.set_ordered(1)
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(chars).to(dev)
+    d_ranges = torch.zeros(Q * 2, dtype=torch.int64, device=dev)
+    d_counts = torch.zeros(Q, dtype=torch.int32, device=dev)
+    g.search_hits(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+    torch.cuda.synchronize()
+    _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2), d_counts.cpu().numpy().view(np.uint32),
+                         sp, ep, cnt)
+    g.destroy()
+    ix.dealloc()
