@@ -40,8 +40,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", choices=["random", "planted", "mixed"], default="random")
     p.add_argument("--mode", choices=["locate", "count"], default="locate")
-    p.add_argument("--text-len", type=int, default=None, help="default 3.1e9 (dna) / 2e8 (amino)")
-    p.add_argument("--queries", type=int, default=None, help="k-mers per GPU per step; default 1e8 (dna) / 5e7 (amino)")
+    count = lambda v: int(float(v))  # noqa: E731  ("3e6" is accepted)
+    p.add_argument("--text-len", type=count, default=None, help="default 3.1e9 (dna) / 2e8 (amino)")
+    p.add_argument("--queries", type=count, default=None, help="k-mers per GPU per step; default 1e8 (dna) / 5e7 (amino)")
     p.add_argument("--kmer", type=int, default=None, help="default 21 (dna) / 10 (amino)")
     p.add_argument("--seed-k", type=int, default=None, help="default 12 (dna) / 5 (amino)")
     p.add_argument("--sa-ratio", type=int, default=8)
@@ -54,11 +55,46 @@ def parse():
                    help="optional device-only full suffix array (same positions, a locate becomes one gather)")
     p.add_argument("--device-seed-k", type=int, default=0,
                    help="optional device-only deeper seed table (same results, fewer block reads); 0 = the index's own table")
+    p.add_argument("--dump-dir", default=None,
+                   help="testing: every rank writes its shard's counts / hit offsets / positions to <dir>/rank<r>.npz")
     return p.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without an outer torchrun: this process starts the N ranks itself.
+
+    The parent never touches the GPU (no HIP call, no torch.cuda call before or after the spawn): it only
+    starts one child per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON
+    line and fails if any rank failed.  Ranks are independent (index replica per GPU, contiguous query
+    shards, ref src/AwFmParallelSearch.c:103-129: 8-query blocks are independent), so nothing else is shared."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(codes):
+        sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
+        sys.exit(1)
+    lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    if not lines or json.loads(lines[-1]).get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: rank 0 did not report n_gpus == --gpus\n")
+        sys.exit(1)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)  # before anything that could initialise the GPU in this process
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -68,6 +104,8 @@ def main():
     if args.force_device >= 0:
         os.environ["LOCAL_RANK"] = str(args.force_device)
     rank, world = shard.init(args.dist_backend)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: the line would misreport n_gpus")
     if world == 1 or args.dist_backend != "nccl":
         torch.cuda.set_device(max(args.force_device, 0) if world > 1 else 0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -201,6 +239,17 @@ def main():
     value = world * Q / (elapsed / args.steps) / 1e6  # Mkmers/s over all ranks
     search_ms = float(np.mean([a.elapsed_time(b) for a, b in search_events]))
     locate_ms = float(np.mean([a.elapsed_time(b) for a, b in locate_events])) if locate_events else 0.0
+
+    if args.dump_dir:  # testing: this rank's shard results, for a check against the oracle outside the bench
+        os.makedirs(args.dump_dir, exist_ok=True)
+        dump = {"first": np.uint64(first), "queries": np.uint64(Q)}
+        if args.mode == "count":
+            dump["counts"] = d_counts.cpu().numpy().view(np.uint32)
+        else:
+            dump["ranges"] = d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2)
+            dump["hit_offsets"] = d_hit_off.cpu().numpy().view(np.uint64)
+            dump["positions"] = state["positions"][: state["hits"]].cpu().numpy().view(np.uint64)
+        np.savez(os.path.join(args.dump_dir, f"rank{rank}.npz"), **dump)
 
     if rank != 0:
         if world > 1:
