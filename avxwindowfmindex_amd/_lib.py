@@ -26,7 +26,7 @@ API_SYMBOLS = [
 ]
 GPU_SYMBOLS = [
     "awfmGpuDeviceCount", "awfmGpuLastError", "awfmGpuIndexCreate", "awfmGpuIndexDestroy", "awfmGpuIndexAcquire", "awfmGpuIndexAcquireAll",
-    "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuIndexSetDeepSeed", "awfmGpuIndexSetDenseSa", "awfmGpuPinnedBuffer", "awfmGpuLocateHostPinned", "awfmGpuAosLock",
+    "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuIndexSetWide", "awfmGpuIndexIsWide", "awfmGpuLastBatchStatus", "awfmGpuIndexSetDeepSeed", "awfmGpuIndexSetDenseSa", "awfmGpuPinnedBuffer", "awfmGpuLocateHostPinned", "awfmGpuAosLock",
     "awfmGpuAosUnlock", "awfmGpuSearch", "awfmGpuSearchHits", "awfmGpuIndexSetOrdered", "awfmGpuSearchHitsIsOrdered", "awfmGpuLastOrderedKernelMs",
     "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuHitOffsetsFromCounts", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
     "awfmGpuCreateIndex", "awfmGpuSearchTally", "awfmGpuSynthText", "awfmGpuSynthRandomQueries", "awfmGpuSynthPlantedQueries",
@@ -127,6 +127,9 @@ def lib():
         "awfmGpuIndexDeviceBytes": (u64, [vp]),
         "awfmGpuIndexDevice": (C.c_int, [vp]),
         "awfmGpuIndexSetKernel": (None, [vp, C.c_int]),
+        "awfmGpuIndexSetWide": (None, [vp, C.c_int]),
+        "awfmGpuIndexIsWide": (C.c_int, [vp]),
+        "awfmGpuLastBatchStatus": (C.c_int, []),
         "awfmGpuIndexSetOrdered": (None, [vp, C.c_int]),
         "awfmGpuSearchHitsIsOrdered": (C.c_int, [vp, C.c_int, C.c_uint32, u64]),
         "awfmGpuLastOrderedKernelMs": (C.c_double, [vp]),

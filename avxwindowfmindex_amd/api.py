@@ -251,6 +251,14 @@ class GpuIndex:
     def set_kernel(self, kernel):
         _lib.lib().awfmGpuIndexSetKernel(self.handle, kernel)
 
+    def set_wide(self, wide=True):
+        """64-bit BWT positions in the kernels although bwtLength < 2^32 (testing)"""
+        _lib.lib().awfmGpuIndexSetWide(self.handle, int(bool(wide)))
+
+    @property
+    def is_wide(self):
+        return bool(_lib.lib().awfmGpuIndexIsWide(self.handle))
+
     # host-buffer calls -------------------------------------------------
     def count_host(self, chars, offsets=None, fixed_length=0):
         chars = np.ascontiguousarray(chars, dtype=np.uint8)

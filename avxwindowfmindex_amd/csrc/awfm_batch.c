@@ -178,6 +178,13 @@ static void scatterPositions(void *p, uint64_t begin, uint64_t end, unsigned tid
   }
 }
 
+/* A shard that failed reports no hits: there is no CPU search path to fall back to, awFmParallelSearchCount
+ * returns void (ref src/AwFmIndex.h:400-403), and a caller must never read the counts of an earlier search as
+ * the answer of this one.  The failure itself goes to stderr and to awfmGpuLastBatchStatus(). */
+static void invalidateCounts(struct AwFmKmerSearchData *data, uint64_t n) {
+  for (uint64_t i = 0; i < n; i++) data[i].count = 0;
+}
+
 /* ---- one contiguous shard of the list on one device image ---- */
 struct shardJob {
   AwFmGpuIndex *image;
@@ -216,7 +223,10 @@ static void *runShard(void *p) {
       if (ctx.failed) job->rc = AwFmAllocationFailure;
     }
   }
-  if (job->rc != AwFmSuccess) snprintf(job->error, sizeof job->error, "%s", awfmGpuLastError());
+  if (job->rc != AwFmSuccess) {
+    snprintf(job->error, sizeof job->error, "%s", awfmGpuLastError());
+    invalidateCounts(job->data, job->n);
+  }
   awfmGpuAosUnlock(g);
   return NULL;
 }
@@ -236,6 +246,7 @@ static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKm
   const int numImages = awfmGpuIndexAcquireAll(index, images, oneShard ? 1 : AWFM_MAX_IMAGES);
   if (numImages <= 0) {
     fprintf(stderr, "%s: no device image: %s\n", who, awfmGpuLastError());
+    invalidateCounts(list->kmerSearchData, n);
     return AwFmGeneralFailure;
   }
   struct shardJob jobs[AWFM_MAX_IMAGES];
@@ -264,15 +275,19 @@ static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKm
   return jobs[firstFailed].rc;
 }
 
+static _Thread_local enum AwFmReturnCode lastBatchStatus = AwFmSuccess;
+/* return code of the calling thread's last awFmParallelSearchCount / awFmParallelSearchLocate */
+enum AwFmReturnCode awfmGpuLastBatchStatus(void) { return lastBatchStatus; }
+
 /* ref src/AwFmParallelSearch.c:159-220 */
 void awFmParallelSearchCount(const struct AwFmIndex *_RESTRICT_ const index,
                              struct AwFmKmerSearchList *_RESTRICT_ const searchList, uint32_t numThreads) {
-  (void)runBatch(index, searchList, numThreads, false, "awFmParallelSearchCount");
+  lastBatchStatus = runBatch(index, searchList, numThreads, false, "awFmParallelSearchCount");
 }
 
 /* ref src/AwFmParallelSearch.c:95-157 */
 enum AwFmReturnCode awFmParallelSearchLocate(const struct AwFmIndex *_RESTRICT_ const index,
                                              struct AwFmKmerSearchList *_RESTRICT_ const searchList,
                                              uint32_t numThreads) {
-  return runBatch(index, searchList, numThreads, true, "awFmParallelSearchLocate");
+  return lastBatchStatus = runBatch(index, searchList, numThreads, true, "awFmParallelSearchLocate");
 }

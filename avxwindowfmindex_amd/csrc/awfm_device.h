@@ -351,6 +351,8 @@ struct AwFmGpuIndex {
   uint64_t deviceBytes = 0;
   uint64_t numBlocks = 0;
   AwFmGpuKernel kernel = AWFM_GPU_KERNEL_AUTO;
+  /* testing: run the 64-bit-position kernels although bwtLength < 2^32 (awfmGpuIndexSetWide, $AWFM_GPU_FORCE_WIDE) */
+  bool forceWide = false;
   int numCUs = 256;
   /* grow-only workspace for the host-buffer entry points */
   std::mutex workMutex;
@@ -372,6 +374,10 @@ struct AwFmGpuIndex {
   void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pinnedBytes[4] = {0, 0, 0, 0};
 };
+
+/* 32-bit BWT positions in the kernels: exact whenever bwtLength < 2^32 (ref src/AwFmIndex.h:88-91 is 64-bit
+ * throughout; the NARROW = false instantiations are that arithmetic) */
+inline bool awfmImageNarrow(const AwFmGpuIndex *g) { return !g->forceWide && g->dev.bwtLength < (1ull << 32); }
 
 /* RAII hipSetDevice */
 struct DeviceGuard {

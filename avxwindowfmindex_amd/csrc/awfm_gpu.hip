@@ -164,7 +164,8 @@ namespace {
 std::mutex tableMutex;
 struct ImageEntry {
   const AwFmIndex *index;
-  int slot; /* position in the $AWFM_GPU_DEVICES list; 0 = the image awfmGpuIndexAcquire returns */
+  int device; /* HIP ordinal the image lives on */
+  int lane;   /* 0 = the image itself; n = the n-th extra handle on it (a device named again in $AWFM_GPU_DEVICES) */
   AwFmGpuIndex *image;
 };
 std::vector<ImageEntry> imageTable;
@@ -249,35 +250,37 @@ int lanesPerQuery(const AwFmGpuIndex *g) {
   return lanes;
 }
 
+/* `dev`: the image view the kernel gets -- g->dev, or a copy with a field changed for this launch only (the tally
+ * prices the reference algorithm without the deeper table) so that the shared image is never edited */
 template <bool AMINO, int G, bool CSR, bool TALLY, bool NARROW>
-void launchSearchKernelN(const AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
-                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts,
-                         unsigned long long *dTally) {
+void launchSearchKernelN(const AwFmGpuIndex *g, const DevIndex &dev, hipStream_t s, const uint8_t *dChars,
+                         const unsigned long long *off, uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng,
+                         uint32_t *dCounts, unsigned long long *dTally) {
   const unsigned grid = gridFor(nq, g, searchKernel<AMINO, G, CSR, TALLY, NARROW>, kThreads / G);
-  hipLaunchKernelGGL((searchKernel<AMINO, G, CSR, TALLY, NARROW>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars, off,
+  hipLaunchKernelGGL((searchKernel<AMINO, G, CSR, TALLY, NARROW>), dim3(grid), dim3(kThreads), 0, s, dev, dChars, off,
                      fixedLength, nq, rng, dCounts, dTally);
 }
 
 template <bool AMINO, int G, bool CSR, bool TALLY>
-void launchSearchKernel(const AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
-                        uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts,
-                        unsigned long long *dTally) {
+void launchSearchKernel(const AwFmGpuIndex *g, const DevIndex &dev, hipStream_t s, const uint8_t *dChars,
+                        const unsigned long long *off, uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng,
+                        uint32_t *dCounts, unsigned long long *dTally) {
   /* amino images always have bwtLength < 2^32 (32-bit base counts) */
-  if (AMINO || g->dev.bwtLength < (1ull << 32))
-    launchSearchKernelN<AMINO, G, CSR, TALLY, true>(g, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);
+  if (AMINO || awfmImageNarrow(g))
+    launchSearchKernelN<AMINO, G, CSR, TALLY, true>(g, dev, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);
   else
-    launchSearchKernelN<AMINO, G, CSR, TALLY, AMINO ? true : false>(g, s, dChars, off, fixedLength, nq, rng, dCounts,
-                                                                    dTally);
+    launchSearchKernelN<AMINO, G, CSR, TALLY, AMINO ? true : false>(g, dev, s, dChars, off, fixedLength, nq, rng,
+                                                                    dCounts, dTally);
 }
 
 template <bool TALLY>
-void launchSearch(const AwFmGpuIndex *g, int lanes, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
-                  uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts,
-                  unsigned long long *dTally) {
-#define AWFM_GO(AM, GG)                                                                                       \
-  do {                                                                                                        \
-    if (off) launchSearchKernel<AM, GG, true, TALLY>(g, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);  \
-    else launchSearchKernel<AM, GG, false, TALLY>(g, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);     \
+void launchSearch(const AwFmGpuIndex *g, const DevIndex &dev, int lanes, hipStream_t s, const uint8_t *dChars,
+                  const unsigned long long *off, uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng,
+                  uint32_t *dCounts, unsigned long long *dTally) {
+#define AWFM_GO(AM, GG)                                                                                            \
+  do {                                                                                                             \
+    if (off) launchSearchKernel<AM, GG, true, TALLY>(g, dev, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);  \
+    else launchSearchKernel<AM, GG, false, TALLY>(g, dev, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);     \
   } while (0)
   if (g->amino) {
     if (lanes == 8) AWFM_GO(true, 8);
@@ -291,6 +294,10 @@ void launchSearch(const AwFmGpuIndex *g, int lanes, hipStream_t s, const uint8_t
 #undef AWFM_GO
 }
 }  // namespace
+
+extern "C" {
+static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g);
+}
 
 AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSeed, void *dSa,
                                 void *dPrefix, unsigned long long sentinelPos, uint64_t deviceBytes) {
@@ -307,12 +314,14 @@ AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void 
   g->dPrefix = dPrefix;
   g->deviceBytes = deviceBytes;
   fillDevIndex(g, index, sentinelPos);
+  if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
+  (void)applyDeepSeedFromEnv(g); /* optional accelerator: on failure the image simply has no deeper table */
   return g;
 }
 
 void awfmGpuIndexRegister(const struct AwFmIndex *index, AwFmGpuIndex *g) {
   std::lock_guard<std::mutex> lock(tableMutex);
-  imageTable.push_back({index, 0, g});
+  imageTable.push_back({index, g->device, 0, g});
 }
 
 extern "C" {
@@ -444,10 +453,8 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
 #undef TRY_OR_FAIL
 
   fillDevIndex(g, index, sentinelPos);
-  if (const char *env = getenv("AWFM_GPU_DEEP_SEED_K")) {
-    const int deepK = atoi(env);
-    if (deepK > 0 && !amino && awfmGpuIndexSetDeepSeed(g, (unsigned)deepK) != AwFmSuccess) return fail(AwFmGeneralFailure);
-  }
+  if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
+  if (applyDeepSeedFromEnv(g) != AwFmSuccess) return fail(AwFmGeneralFailure);
   *out = g;
   return AwFmSuccess;
 }
@@ -522,6 +529,7 @@ static AwFmGpuIndex *makeLane(AwFmGpuIndex *primary) {
   g->dDenseSa = primary->dDenseSa;
   g->numBlocks = primary->numBlocks;
   g->kernel = primary->kernel;
+  g->forceWide = primary->forceWide;
   g->numCUs = primary->numCUs;
   return g;
 }
@@ -529,25 +537,33 @@ static AwFmGpuIndex *makeLane(AwFmGpuIndex *primary) {
 int awfmGpuIndexAcquireAll(const struct AwFmIndex *index, AwFmGpuIndex **out, int maxOut) {
   int devs[64];
   const int numDevs = aosDevices(devs, 64);
+  /* -1 = the default device: $AWFM_GPU_DEVICE, else the calling thread's current device.  Entries are keyed by
+   * the resolved ordinal, so a list that changes between calls never hands out another device's image. */
+  int fallback = 0;
+  if (const char *env = getenv("AWFM_GPU_DEVICE"); env && *env) fallback = atoi(env);
+  else if (hipGetDevice(&fallback) != hipSuccess) fallback = 0;
+  for (int i = 0; i < numDevs; i++)
+    if (devs[i] < 0) devs[i] = fallback;
   std::lock_guard<std::mutex> lock(tableMutex);
+  auto find = [&](int device, int lane) -> AwFmGpuIndex * {
+    for (auto &e : imageTable)
+      if (e.index == index && e.device == device && e.lane == lane) return e.image;
+    return nullptr;
+  };
   int n = 0;
   for (int slot = 0; slot < numDevs && n < maxOut; slot++) {
-    AwFmGpuIndex *g = nullptr;
-    for (auto &e : imageTable)
-      if (e.index == index && e.slot == slot) g = e.image;
+    int lane = 0; /* how often this device was named before */
+    for (int earlier = 0; earlier < slot; earlier++) lane += devs[earlier] == devs[slot];
+    AwFmGpuIndex *g = find(devs[slot], lane);
     if (!g) {
-      /* a device named again gets a lane on the image it already has */
-      AwFmGpuIndex *primary = nullptr;
-      for (int earlier = 0; earlier < slot && !primary; earlier++)
-        if (devs[earlier] == devs[slot])
-          for (auto &e : imageTable)
-            if (e.index == index && e.slot == earlier) primary = e.image->shares ? e.image->shares : e.image;
-      if (primary) {
+      if (lane > 0) { /* a device named again gets a lane on the image it already has */
+        AwFmGpuIndex *primary = find(devs[slot], 0);
+        if (!primary) return n;
         g = makeLane(primary);
       } else if (awfmGpuIndexCreate(index, devs[slot], &g) != AwFmSuccess) {
         return n;
       }
-      imageTable.push_back({index, slot, g});
+      imageTable.push_back({index, devs[slot], lane, g});
     }
     out[n++] = g;
   }
@@ -624,6 +640,10 @@ struct LaneLocks {
 };
 }  // namespace
 
+/* replaces the deeper table of a primary image and of the given lanes; the caller holds whatever locks the image
+ * needs (none for an image nobody else has a pointer to yet) */
+static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const std::vector<AwFmGpuIndex *> &laneList);
+
 enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK) {
   if (!g) {
     setError("awfmGpuIndexSetDeepSeed: null image");
@@ -636,6 +656,10 @@ enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK) {
   DeviceGuard guard(g->device);
   LaneLocks lanes(g); /* nobody searches through a lane while the table is replaced */
   std::lock_guard<std::mutex> lock(g->workMutex);
+  return applyDeepSeed(g, deepK, lanes.lanes);
+}
+
+static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const std::vector<AwFmGpuIndex *> &laneList) {
   (void)hipDeviceSynchronize();
   if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
   g->dDeepSeed = nullptr;
@@ -655,16 +679,35 @@ enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK) {
       rc = AwFmGeneralFailure;
     }
   }
-  for (AwFmGpuIndex *lane : lanes.lanes) {
+  for (AwFmGpuIndex *lane : laneList) {
     lane->dDeepSeed = g->dDeepSeed;
     lane->dev.deepSeed = g->dev.deepSeed;
     lane->dev.deepK = g->dev.deepK;
   }
   return rc;
 }
+
+/* $AWFM_GPU_DEEP_SEED_K on an image that was just created or adopted: nobody else holds it and it has no lanes,
+ * so no lock is taken -- awfmGpuIndexAcquireAll creates images while it holds the table lock, and the public
+ * setter would ask for that lock again through lanesOf() */
+static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
+  const char *env = getenv("AWFM_GPU_DEEP_SEED_K");
+  if (!env || g->amino) return AwFmSuccess;
+  const int deepK = atoi(env);
+  if (deepK <= 0 || (unsigned)deepK <= g->dev.seedK) return AwFmSuccess; /* nothing deeper than the index's own table */
+  DeviceGuard guard(g->device);
+  return applyDeepSeed(g, (unsigned)deepK, {});
+}
 int awfmGpuIndexDevice(const AwFmGpuIndex *g) { return g ? g->device : -1; }
 void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel) {
   if (g) g->kernel = kernel;
+}
+int awfmGpuIndexIsWide(const AwFmGpuIndex *g) { return g && !awfmImageNarrow(g) ? 1 : 0; }
+void awfmGpuIndexSetWide(AwFmGpuIndex *g, int wide) {
+  if (!g) return;
+  g->forceWide = wide != 0;
+  if (!g->shares)
+    for (AwFmGpuIndex *lane : lanesOf(g)) lane->forceWide = g->forceWide;
 }
 
 enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
@@ -682,7 +725,7 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
   const int lanes = lanesPerQuery(g);
-  launchSearch<false>(g, lanes, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries,
+  launchSearch<false>(g, g->dev, lanes, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries,
                       (ulonglong2 *)dRanges, dCounts, nullptr);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
@@ -729,14 +772,14 @@ enum AwFmReturnCode awfmGpuSearchTally(AwFmGpuIndex *g, const uint8_t *dChars, c
   AWFM_HIP_TRY(hipMalloc((void **)&dTally, 32), AwFmAllocationFailure);
   hipError_t e = hipMemset(dTally, 0, 32);
   if (e == hipSuccess && numQueries) {
-    /* the tally prices the reference algorithm (index seed table), so the device-only deeper
-     * table is switched off for this launch */
-    DevIndex saved = g->dev;
-    g->dev.deepSeed = nullptr;
-    g->dev.deepK = 0;
-    launchSearch<true>(g, lanesPerQuery(g), (hipStream_t)0, dChars, (const unsigned long long *)dOffsets, fixedLength,
-                       numQueries, nullptr, nullptr, dTally);
-    g->dev = saved;
+    /* the tally prices the reference algorithm (index seed table), so this launch gets a copy of
+     * the image view without the device-only deeper table; the image itself is not touched (other threads may
+     * be searching through it) */
+    DevIndex plain = g->dev;
+    plain.deepSeed = nullptr;
+    plain.deepK = 0;
+    launchSearch<true>(g, plain, lanesPerQuery(g), (hipStream_t)0, dChars, (const unsigned long long *)dOffsets,
+                       fixedLength, numQueries, nullptr, nullptr, dTally);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(tallyOut, dTally, 32, hipMemcpyDeviceToHost);
@@ -884,7 +927,7 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
       return AwFmUnsupportedVersionError;
     }
     const bool pow2 = g->dev.saShift != 0xFFFFFFFFu;
-    const bool narrow = g->amino || g->dev.bwtLength < (1ull << 32);
+    const bool narrow = g->amino || awfmImageNarrow(g);
 #define AWFM_LOC3(AM, GG, P2, NR)                                                                                  \
   hipLaunchKernelGGL((walkKernel<AM, GG, P2, NR>), dim3(gridFor(th, g, walkKernel<AM, GG, P2, NR>, kThreads / GG)), \
                      dim3(kThreads), 0, s, g->dev, th, pos)

@@ -231,7 +231,7 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
     ORDER_TRY(rocprim::radix_sort_pairs(w + l.sortTemp, tempBytes, keysIn, keysOut, (QueryRec *)recsIn, (QueryRec *)recsOut,
                                         (size_t)nq, 0u, kOrderKeyBits, s));
   }
-  const bool narrow = g->dev.bwtLength < (1ull << 32);
+  const bool narrow = awfmImageNarrow(g);
   enum AwFmReturnCode rc;
 #define ORDER_GO(NR, CP, VL) \
   launchOrdered<NR, CP, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts)

@@ -54,6 +54,11 @@ enum AwFmGpuKernel {
 /* ---- runtime ---- */
 int awfmGpuDeviceCount(void);           /* 0 when no usable HIP device */
 const char *awfmGpuLastError(void);     /* thread-local text of the last failure, "" if none */
+/* Return code of the calling thread's last awFmParallelSearchCount / awFmParallelSearchLocate.  Count returns void in
+ * the reference API (ref src/AwFmIndex.h:400-403) and there is no CPU search path here, so a failed call (no device,
+ * allocation or kernel failure) sets the `count` of every k-mer of the failed shard(s) to 0, prints the reason to
+ * stderr, and leaves its code here. */
+enum AwFmReturnCode awfmGpuLastBatchStatus(void);
 
 /* ---- device image ---- */
 /* Builds the device image of `index` on GPU `device` (-1: current device or
@@ -87,6 +92,12 @@ enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK);
 enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable);
 /* Selects the search kernel variant for this image (default AUTO). */
 void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel);
+/* The kernels keep BWT positions in 32 bits whenever bwtLength < 2^32 and in 64 bits otherwise (the reference is
+ * 64-bit throughout: ref src/AwFmIndex.h:88-91, src/AwFmSuffixArray.c:114-142).  wide != 0 selects the 64-bit
+ * instantiations on any image -- same results, used by the parity tests to cover the code indices of 2^32 or more
+ * positions run; also read from $AWFM_GPU_FORCE_WIDE when an image is created. */
+void awfmGpuIndexSetWide(AwFmGpuIndex *g, int wide);
+int awfmGpuIndexIsWide(const AwFmGpuIndex *g); /* 1 when searches on this image run the 64-bit instantiations */
 
 /* ---- index construction on the GPU ---- */
 /* Same contract and byte-identical arrays as awFmCreateIndex (ref src/AwFmCreate.c:31-137), built on

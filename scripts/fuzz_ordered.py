@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Differential fuzz of the ordered hits-only search against the general kernel, all on the GPU: random index
 sizes, seed depths, deeper tables, fixed and mixed k-mer lengths, ambiguity characters, buffer alignments.
+With FUZZ_WIDE=1 the side under test (hits-only search, second locate) runs the 64-bit-position instantiations
+while the general kernel it is compared with keeps 32-bit positions.
 usage: scripts/fuzz_ordered.py [seconds] [seed]"""
 import os
 import sys
@@ -15,6 +17,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 L = _lib.lib()
 dev = torch.device("cuda")
+fuzz_wide = os.environ.get("FUZZ_WIDE") == "1"
 t_end = time.time() + budget
 rounds = 0
 while time.time() < t_end:
@@ -71,8 +74,12 @@ while time.time() < t_end:
         hits = torch.full((Q * 2,), 9, dtype=torch.int64, device=dev)
         counts = torch.full((Q,), 9, dtype=torch.int32, device=dev)
         g.search(chars_ptr, off_ptr, K, Q, exact.data_ptr(), 0)
+        torch.cuda.synchronize()
+        g.set_wide(fuzz_wide)
+        assert g.is_wide == fuzz_wide
         g.search_hits(chars_ptr, off_ptr, K, Q, hits.data_ptr(), counts.data_ptr())
         torch.cuda.synchronize()
+        g.set_wide(False)
         a, b = exact.view(Q, 2), hits.view(Q, 2)
         has = a[:, 0] <= a[:, 1]
         expect = torch.where(has, a[:, 1] - a[:, 0] + 1, torch.zeros_like(a[:, 0])).clamp(max=0xFFFFFFFF)
@@ -95,8 +102,11 @@ while time.time() < t_end:
             pos_a = torch.zeros(max(total_a, 1), dtype=torch.int64, device=dev)
             pos_b = torch.zeros(max(total_b, 1), dtype=torch.int64, device=dev)
             g.locate(exact.data_ptr(), off_a.data_ptr(), Q, total_a, pos_a.data_ptr())
+            torch.cuda.synchronize()
+            g.set_wide(fuzz_wide)
             g.locate(hits.data_ptr(), off_b.data_ptr(), Q, total_b, pos_b.data_ptr())
             torch.cuda.synchronize()
+            g.set_wide(False)
             if not (total_a == total_b and torch.equal(off_a, off_b) and torch.equal(pos_a, pos_b)):
                 print("LOCATE MISMATCH", tag, flush=True)
                 sys.exit(1)

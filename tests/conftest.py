@@ -36,3 +36,12 @@ def require_gpu(awfm):
     n = _lib.lib().awfmGpuDeviceCount()
     assert n > 0, "GPU test selected but no HIP device is visible: the HIP path must run, there is no fallback"
     return n
+
+
+@pytest.fixture(params=[False, True], ids=["narrow", "wide"])
+def wide(request, monkeypatch):
+    """runs a GPU test twice: with 32-bit BWT positions in the kernels (what an index below 2^32 positions gets)
+    and with the 64-bit instantiations forced on the same small index ($AWFM_GPU_FORCE_WIDE is read when a device
+    image is created), i.e. the code a >= 2^32-position index runs (ref src/AwFmIndex.h:88-91)"""
+    monkeypatch.setenv("AWFM_GPU_FORCE_WIDE", "1" if request.param else "0")
+    return request.param

@@ -4,6 +4,8 @@ Mirrors the properties of the reference's test/parallelSearch/parallelSearchTest
 test/inMemorySaTest/inMemorySaTest.c:29-266 and test/searchTest/searchTest.c:124-200, with
 seeded inputs and exact {sp,ep}/hit-order comparison instead of order-insensitive checks.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -30,6 +32,8 @@ def _check_against_oracle(O, awfm, txt, alpha, oalpha, ratio, seed_k, chars, off
     oi = O.Index.wrap(oalpha, ratio, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
                       ix.packed_sa())
     g = awfm.GpuIndex(ix)
+    if alpha != awfm.AwFmAlphabetAmino:  # the `wide` fixture really selected the 64-bit instantiations
+        assert g.is_wide == (os.environ.get("AWFM_GPU_FORCE_WIDE", "0") == "1")
     sp, ep, cnt, _ = oi.batch_search(chars, offsets)
     ranges, counts = g.count_host(chars, offsets)
     assert np.array_equal(ranges[:, 0], sp), "sp differs"
@@ -46,7 +50,7 @@ def _check_against_oracle(O, awfm, txt, alpha, oalpha, ratio, seed_k, chars, off
 
 
 @pytest.mark.parametrize("n,ratio,seed_k", [(29, 1, 3), (4096, 3, 4), (65536, 8, 8), (300000, 16, 6), (100000, 255, 5)])
-def test_dna_parity(oracle, awfm, require_gpu, n, ratio, seed_k):
+def test_dna_parity(oracle, awfm, require_gpu, wide, n, ratio, seed_k):
     txt = synth.text(n + 7, n, synth.DNA_ALPHABET).copy()
     if n > 100:
         txt[10:14] = ord("n")  # ambiguity run in the text (sanitised to 'x')
@@ -90,7 +94,7 @@ def test_fixed_length_and_empty_batch(oracle, awfm, require_gpu):
     ix.dealloc()
 
 
-def test_repetitive_text_many_hits(oracle, awfm, require_gpu):
+def test_repetitive_text_many_hits(oracle, awfm, require_gpu, wide):
     """long position lists (wave-cooperative expansion) and long LF chains, sentinel wrap included"""
     txt = np.frombuffer((b"acgtacgtaa" * 3000) + b"ttttttttttttttttttttt", np.uint8)
     for ratio in (1, 7, 200):
@@ -164,7 +168,7 @@ def test_sa_staged_from_file(oracle, awfm, require_gpu, tmp_path):
 
 
 @pytest.mark.parametrize("seed_k,deep_k", [(3, 5), (6, 9), (8, 12)])
-def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, require_gpu, seed_k, deep_k):
+def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, require_gpu, wide, seed_k, deep_k):
     """the optional device-only deeper seed table must not change a single range or position, including
     queries shorter than it, ambiguity letters inside/outside the deep suffix and absent k-mers"""
     n = 250000
@@ -191,7 +195,7 @@ def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, requir
 
 
 @pytest.mark.parametrize("alphabet_name,ratio", [("dna", 8), ("dna", 255), ("amino", 5)])
-def test_device_dense_sa_keeps_positions_bit_identical(oracle, awfm, require_gpu, alphabet_name, ratio):
+def test_device_dense_sa_keeps_positions_bit_identical(oracle, awfm, require_gpu, wide, alphabet_name, ratio):
     amino = alphabet_name == "amino"
     letters = synth.AMINO_ALPHABET if amino else synth.DNA_ALPHABET
     alpha, oalpha = (awfm.AwFmAlphabetAmino, oracle.AMINO) if amino else (awfm.AwFmAlphabetDna, oracle.DNA)
@@ -259,7 +263,7 @@ def test_drop_in_api_shards_over_device_images(oracle, awfm, require_gpu, monkey
 
 @pytest.mark.parametrize("kernel", [1, 2, 3, 4])  # AWFM_GPU_KERNEL_GROUP8 / 4 / 2 / 1 lanes per query
 @pytest.mark.parametrize("alphabet_name", ["dna", "amino"])
-def test_every_kernel_variant_is_bit_exact(oracle, awfm, require_gpu, kernel, alphabet_name):
+def test_every_kernel_variant_is_bit_exact(oracle, awfm, require_gpu, wide, kernel, alphabet_name):
     amino = alphabet_name == "amino"
     letters = synth.AMINO_ALPHABET if amino else synth.DNA_ALPHABET
     alpha, oalpha = (awfm.AwFmAlphabetAmino, oracle.AMINO) if amino else (awfm.AwFmAlphabetDna, oracle.DNA)
@@ -309,7 +313,7 @@ def test_drop_in_aos_api_large_lists_are_packed_in_parallel(oracle, awfm, requir
 
 
 @pytest.mark.parametrize("alphabet_name", ["dna", "amino"])
-def test_flat_locate_with_any_position_buffer_alignment_and_hit_count(oracle, awfm, require_gpu, alphabet_name):
+def test_flat_locate_with_any_position_buffer_alignment_and_hit_count(oracle, awfm, require_gpu, wide, alphabet_name):
     """the walk kernel moves hits in 128-byte batches when the position buffer is 16-byte aligned and one by one
     otherwise; hit totals that are not a multiple of a batch exercise the tail of both paths"""
     import torch
@@ -388,7 +392,7 @@ def _check_hits_contract(ranges, counts, sp, ep, cnt):
 @pytest.mark.parametrize("n,ratio,seed_k,deep_k,K", [(300000, 8, 8, 0, 21), (300000, 5, 8, 0, 8), (200000, 8, 6, 9, 32),
                                                      (200000, 8, 6, 9, 7), (4096, 3, 4, 0, 13), (100000, 8, 1, 0, 5),
                                                      (150000, 8, 10, 11, 11)])
-def test_ordered_hits_only_search_is_exact_on_hits(oracle, awfm, require_gpu, n, ratio, seed_k, deep_k, K):
+def test_ordered_hits_only_search_is_exact_on_hits(oracle, awfm, require_gpu, wide, n, ratio, seed_k, deep_k, K):
     """awfmGpuSearchHits with the ordered path forced on (fixed-length DNA batches): ambiguity characters and upper
     case included, query buffer at every byte alignment, ranges only / counts only / both, then the locate
     pipeline on top of the hits-only ranges"""
@@ -525,7 +529,7 @@ def test_drop_in_aos_api_uses_the_ordered_search_when_forced(oracle, awfm, requi
 
 @pytest.mark.parametrize("n,ratio,seed_k,deep_k", [(300000, 8, 8, 0), (200000, 8, 6, 9), (4096, 3, 4, 0), (100000, 8, 1, 0),
                                                    (150000, 8, 10, 11), (250000, 7, 12, 0)])
-def test_ordered_hits_only_search_of_mixed_length_batches(oracle, awfm, require_gpu, n, ratio, seed_k, deep_k):
+def test_ordered_hits_only_search_of_mixed_length_batches(oracle, awfm, require_gpu, wide, n, ratio, seed_k, deep_k):
     """CSR batches through the ordered path (forced on): lengths 0..40, so k-mers start from the deeper table, the
     seed table or a letter range (shorter than the seed), and empty / over-long / ambiguous ones go to the general
     kernel; counts, hit ranges, hit offsets and positions against the oracle"""
@@ -565,7 +569,7 @@ def test_ordered_hits_only_search_of_mixed_length_batches(oracle, awfm, require_
     ix.dealloc()
 
 
-def test_ordered_search_when_every_wave_takes_many_chunks(oracle, awfm, require_gpu):
+def test_ordered_search_when_every_wave_takes_many_chunks(oracle, awfm, require_gpu, wide):
     """batches large enough that every wave of the ordered kernel draws several tickets (its record prefetch runs
     ahead of the k-mer being searched): 600 000 mixed-length and 600 000 fixed-length k-mers, device generators,
     counts / hit ranges / hit offsets / positions against the oracle"""
@@ -621,7 +625,7 @@ def test_ordered_search_when_every_wave_takes_many_chunks(oracle, awfm, require_
     ix.dealloc()
 
 
-def test_rna_alphabet_and_u_for_t(oracle, awfm, require_gpu):
+def test_rna_alphabet_and_u_for_t(oracle, awfm, require_gpu, wide):
     """AwFmAlphabetRna indices (ref src/AwFmIndex.h:30-34, src/AwFmLetter.c:4-22: u and t are the same letter):
     text and queries written with u, t or a mix give the ranges and positions of the oracle's RNA index, through
     the general kernel and through the ordered path"""
@@ -661,4 +665,53 @@ def test_rna_alphabet_and_u_for_t(oracle, awfm, require_gpu):
     _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2), d_counts.cpu().numpy().view(np.uint32),
                          sp, ep, cnt)
     g.destroy()
+    ix.dealloc()
+
+
+@pytest.mark.timeout(300)
+def test_deep_seed_env_knob_through_the_drop_in_api(oracle, awfm, require_gpu, monkeypatch, tmp_path):
+    """$AWFM_GPU_DEEP_SEED_K is read when a device image is created.  awFmParallelSearchLocate creates that image
+    lazily while it holds the image-table lock (an index loaded with awFmReadIndexFromFile has none yet): this used
+    to self-deadlock.  The knob also applies to the image a GPU-built index adopts, and a device list that changes
+    between calls gets that device's own image (entries are keyed by device, not by list position)."""
+    import ctypes as C
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    txt = synth.text(91, 150000)
+    chars, offsets = synth.mixed_queries(92, 4001, txt, synth.DNA_ALPHABET, 5, 30)
+    kmers = [chars[int(offsets[i]):int(offsets[i + 1])].tobytes() for i in range(4001)]
+    oi = oracle.Index.from_text(txt.tobytes(), oracle.DNA, 8, 6)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    path = str(tmp_path / "deep.awfmi")
+    awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 6, file_src=path).dealloc()
+    monkeypatch.setenv("AWFM_GPU_DEEP_SEED_K", "9")
+
+    def check(ix):
+        lst = awfm.KmerSearchList(4001)
+        lst.fill(kmers)
+        assert awfm.parallel_search_locate(ix, lst, 4) == awfm.AwFmSuccess
+        assert L.awfmGpuLastBatchStatus() == awfm.AwFmSuccess
+        assert np.array_equal(lst.counts(), cnt)
+        for i in range(0, 4001, 13):
+            assert np.array_equal(lst.positions(i), pos[int(hit_off[i]):int(hit_off[i + 1])])
+        lst.dealloc()
+        img = L.awfmGpuIndexAcquire(ix.ptr)
+        plain = awfm.GpuIndex(ix)  # a second image of the same index, created without going through the table
+        deep_bytes = 4 ** 9 * 16
+        assert L.awfmGpuIndexDeviceBytes(C.c_void_p(img)) >= deep_bytes  # the table was really built
+        plain.destroy()
+
+    ix = awfm.read_index_from_file(path)
+    check(ix)
+    # the same index, now asked for with an explicit device list: device 0's image (and a lane on it)
+    monkeypatch.setenv("AWFM_GPU_DEVICES", "0,0")
+    check(ix)
+    imgs = (C.c_void_p * 4)()
+    assert L.awfmGpuIndexAcquireAll(ix.ptr, imgs, 4) == 2 and imgs[0] != imgs[1]
+    assert L.awfmGpuIndexDevice(C.c_void_p(imgs[0])) == 0 and L.awfmGpuIndexDevice(C.c_void_p(imgs[1])) == 0
+    ix.dealloc()
+    monkeypatch.delenv("AWFM_GPU_DEVICES")
+    ix = awfm.gpu_create_index(txt, awfm.AwFmAlphabetDna, 8, 6)  # the builder's adopted image gets the table too
+    check(ix)
     ix.dealloc()

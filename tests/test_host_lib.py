@@ -180,8 +180,8 @@ def test_search_list_ownership_and_return_codes(awfm):
 
 
 def test_batch_search_fails_loudly_without_a_gpu(awfm):
-    """the hot path has no CPU fallback: without a device Locate returns a failure code and Count
-    leaves the list untouched"""
+    """the hot path has no CPU fallback: without a device Locate returns a failure code, Count leaves its code in
+    awfmGpuLastBatchStatus(), and neither leaves a stale count behind (a failed search reports no hits)"""
     from avxwindowfmindex_amd import _lib
     if _lib.lib().awfmGpuDeviceCount() > 0:
         pytest.skip("a GPU is visible here")
@@ -191,8 +191,11 @@ def test_batch_search_fails_loudly_without_a_gpu(awfm):
     lst.fill([raw[10:20].tobytes()])
     lst.ptr.contents.kmerSearchData[0].count = 77
     awfm.parallel_search_count(ix, lst, 2)
-    assert lst.counts()[0] == 77
+    assert lst.counts()[0] == 0
+    assert _lib.lib().awfmGpuLastBatchStatus() == _lib.AwFmGeneralFailure
+    lst.ptr.contents.kmerSearchData[0].count = 77
     assert awfm.parallel_search_locate(ix, lst, 2) == -1
+    assert lst.counts()[0] == 0
     assert b"no HIP device" in _lib.lib().awfmGpuLastError()
     with pytest.raises(RuntimeError):
         awfm.GpuIndex(ix)
