@@ -1,0 +1,324 @@
+"""Every BASELINE.json configuration at its own workload, on the GPU, through the C ABI.
+
+  cfg 1  1 M random 12-mers against a 1 Mbp index, seed table k = 12 (pure table look-ups) and k = 8 (4 steps):
+         ALL of it against the oracle, plus committed digests of the results (the oracle itself is pinned on this
+         configuration by brute force in tests/test_oracle_pin.py::test_cfg1_counts_and_positions_by_brute_force)
+  cfg 2  100 M random 21-mers counted against a 3.1 Gbp (GRCh38-sized) index
+  cfg 3  (a) the same batch located; (b) 100 M planted 21-mers located (the workload that really backtraces)
+  cfg 4  50 M random 10-mers against a 200 M-residue amino index, seed table k = 5, counted and located,
+         plus planted 10-mers located
+  cfg 5  100 M mixed-length 8..30-mers (half random, half planted) counted against the 3.1 Gbp index
+
+At these sizes the oracle cannot run over everything, so each test checks (i) size-independent properties over the
+WHOLE batch on the device -- every reported position spells its k-mer in the text, every planted k-mer is found at
+the offset it was taken from, counts == range lengths == hit-offset differences, the hits-only (seed-order) path
+agrees with the general kernel for every k-mer -- and (ii) the oracle bit for bit on a sample of >= 10^5 k-mers
+taken from both ends of the batch.  Inputs come from the seeded device generators, the index
+from the GPU builder (byte-identical to the host builder: tests/test_gpu_build.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from avxwindowfmindex_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+GRCH38 = int(os.environ.get("AWFM_TEST_GRCH38_LEN", 3_100_000_000))
+BATCH = int(os.environ.get("AWFM_TEST_BATCH", 100_000_000))
+SAMPLE = 100_000
+
+
+class _Big:
+    """an index replica with its text kept on the device"""
+
+    def __init__(self, awfm, oracle, n, text_seed, amino, ratio, seed_k):
+        import torch
+        from avxwindowfmindex_amd import _lib
+        self.torch, self.L, self.awfm, self.n, self.amino, self.seed_k, self.ratio = torch, _lib.lib(), awfm, n, amino, seed_k, ratio
+        self.dev = torch.device("cuda")
+        self.text = torch.empty(n, dtype=torch.uint8, device=self.dev)
+        assert self.L.awfmGpuSynthText(self.text.data_ptr(), 0, n, text_seed, int(amino), None) == 1
+        alpha = awfm.AwFmAlphabetAmino if amino else awfm.AwFmAlphabetDna
+        self.ix = awfm.gpu_create_index(self.text.data_ptr(), alpha, ratio, seed_k, on_device_length=n)
+        self.g = awfm.GpuIndex(self.ix, acquire=True)
+        ix = self.ix
+        self.oracle = oracle.Index.wrap(oracle.AMINO if amino else oracle.DNA, ratio, seed_k, ix.bwt_length, ix.blocks(),
+                                        ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+
+    def close(self):
+        self.g.destroy()
+        self.ix.dealloc()
+        del self.text
+        self.torch.cuda.empty_cache()
+
+    # ---- helpers over device batches ----
+    def buffers(self, Q):
+        t = self.torch
+        return (t.empty(Q * 2, dtype=t.int64, device=self.dev), t.empty(Q, dtype=t.int32, device=self.dev),
+                t.empty(Q + 1, dtype=t.int64, device=self.dev),
+                t.empty(self.awfm.GpuIndex.scan_scratch_bytes(Q), dtype=t.uint8, device=self.dev))
+
+    def lengths(self, ranges, Q):
+        t = self.torch
+        r = ranges.view(Q, 2)
+        return t.where(r[:, 0] <= r[:, 1], r[:, 1] - r[:, 0] + 1, t.zeros_like(r[:, 0]))
+
+    def check_positions_spell(self, d_chars, d_offsets, K, Q, lens, d_pos):
+        """text[pos + c] == k-mer[c] for every hit of every k-mer (fixed length K, or CSR with d_offsets)"""
+        t = self.torch
+        owner = t.repeat_interleave(t.arange(Q, device=self.dev), lens)
+        if d_offsets is None:
+            q2d = d_chars[: Q * K].view(Q, K)
+            for c in range(K):
+                assert t.equal(self.text[d_pos + c], q2d[owner, c]), f"a hit does not spell its k-mer at character {c}"
+        else:
+            start, klen = d_offsets[:-1][owner], (d_offsets[1:] - d_offsets[:-1])[owner]
+            for c in range(int(klen.max())):
+                m = klen > c
+                assert t.equal(self.text[d_pos[m] + c], d_chars[start[m] + c]), f"a hit does not spell its k-mer at character {c}"
+
+    def check_sample_against_oracle(self, d_chars, d_offsets, K, Q, ranges, counts, hit_off, d_pos, exact_ranges):
+        """first and last SAMPLE k-mers: ranges (exact, or the hits-only contract), counts, hit offsets, positions"""
+        for lo in (0, Q - SAMPLE):
+            if d_offsets is None:
+                chars = d_chars[lo * K:(lo + SAMPLE) * K].cpu().numpy()
+                offsets = np.arange(SAMPLE + 1, dtype=np.uint64) * np.uint64(K)
+            else:
+                o = d_offsets[lo:lo + SAMPLE + 1].cpu().numpy().view(np.uint64)
+                chars = d_chars[int(o[0]):int(o[-1])].cpu().numpy()
+                offsets = o - o[0]
+            sp, ep, cnt, _ = self.oracle.batch_search(chars, offsets, threads=os.cpu_count() or 1)
+            hit = cnt > 0
+            if ranges is not None:
+                got = ranges[2 * lo:2 * (lo + SAMPLE)].cpu().numpy().view(np.uint64).reshape(SAMPLE, 2)
+                if exact_ranges:
+                    assert np.array_equal(got[:, 0], sp) and np.array_equal(got[:, 1], ep), "ranges differ from the oracle"
+                else:
+                    assert np.array_equal(got[hit, 0], sp[hit]) and np.array_equal(got[hit, 1], ep[hit])
+                    assert np.all(got[~hit, 0] > got[~hit, 1])
+            if counts is not None:
+                assert np.array_equal(counts[lo:lo + SAMPLE].cpu().numpy().view(np.uint32), cnt), "counts differ from the oracle"
+            if hit_off is not None:
+                ho, pos, _ = self.oracle.batch_locate(sp, ep, threads=os.cpu_count() or 1)
+                gho = hit_off[lo:lo + SAMPLE + 1].cpu().numpy().view(np.uint64)
+                assert np.array_equal(gho - gho[0], ho), "hit offsets differ from the oracle"
+                gp = d_pos[int(gho[0]):int(gho[-1])].cpu().numpy().view(np.uint64)
+                assert np.array_equal(gp, pos), "positions (BWT order) differ from the oracle"
+
+
+@pytest.fixture(scope="module")
+def grch38(awfm, oracle, require_gpu):
+    big = _Big(awfm, oracle, GRCH38, 2, False, 8, 12)
+    yield big
+    big.close()
+
+
+def _random_batch(big, Q, K, seed, first=0):
+    d = big.torch.empty(Q * K + 8, dtype=big.torch.uint8, device=big.dev)
+    assert big.L.awfmGpuSynthRandomQueries(d.data_ptr(), first, Q, K, seed, int(big.amino), None) == 1
+    return d
+
+
+def _planted_batch(big, Q, K, seed, first=0):
+    d = big.torch.empty(Q * K + 8, dtype=big.torch.uint8, device=big.dev)
+    assert big.L.awfmGpuSynthPlantedQueries(d.data_ptr(), first, Q, K, seed, big.text.data_ptr(), big.n, None) == 1
+    return d
+
+
+def test_cfg2_and_cfg3a_random_21mers_counted_and_located(grch38):
+    """cfg 2 (count) and cfg 3a (locate) share the batch: 100 M uniform random 21-mers, seed 102"""
+    big, t, Q, K = grch38, grch38.torch, BATCH, 21
+    d_chars = _random_batch(big, Q, K, 102)
+    ranges, counts, hit_off, scratch = big.buffers(Q)
+    assert big.g.search_hits_is_ordered(False, K, Q) == (Q >= 1 << 23 and big.n >= 1 << 28)
+    # cfg 2: counts only, the way awFmParallelSearchCount asks (hits-only search, seed order at this size)
+    big.g.search_hits(d_chars.data_ptr(), 0, K, Q, 0, counts.data_ptr())
+    # every k-mer again through the general kernel (exact ranges)
+    big.g.search(d_chars.data_ptr(), 0, K, Q, ranges.data_ptr(), 0)
+    t.cuda.synchronize()
+    lens = big.lengths(ranges, Q)
+    assert t.equal(lens.to(t.int32), counts), "hits-only counts differ from the general kernel's range lengths"
+    total_hits = int(lens.sum())
+    if (GRCH38, BATCH) == (3_100_000_000, 100_000_000):
+        assert total_hits == 70542  # known answer of this seeded workload (bench.py's oracle-gated run, BENCH_r01)
+    big.check_sample_against_oracle(d_chars, None, K, Q, ranges, counts, None, None, exact_ranges=True)
+    # cfg 3a: locate through the hits-only ranges
+    hits = t.full((Q * 2,), 7, dtype=t.int64, device=big.dev)
+    big.g.search_hits(d_chars.data_ptr(), 0, K, Q, hits.data_ptr(), counts.data_ptr())
+    total = big.g.hit_offsets_from_counts(counts.data_ptr(), Q, hit_off.data_ptr(), scratch.data_ptr())
+    assert total == total_hits
+    d_pos = t.empty(max(total, 1), dtype=t.int64, device=big.dev)
+    big.g.locate(hits.data_ptr(), hit_off.data_ptr(), Q, total, d_pos.data_ptr())
+    t.cuda.synchronize()
+    assert t.equal(t.cumsum(lens, 0), hit_off[1:]) and int(hit_off[0]) == 0
+    assert int(d_pos[:total].min()) >= 0 and int(d_pos[:total].max()) <= big.n - K
+    big.check_positions_spell(d_chars, None, K, Q, lens, d_pos[:total])
+    big.check_sample_against_oracle(d_chars, None, K, Q, hits, counts, hit_off, d_pos, exact_ranges=False)
+
+
+def test_cfg3b_planted_21mers_located(grch38):
+    """every k-mer occurs: 9 backward steps each and about 7 LF steps per hit -- the case that exercises the backtrace
+    (ref src/AwFmParallelSearch.c:315-365; the reference's own harness samples its k-mers from the text too)"""
+    big, t, Q, K = grch38, grch38.torch, BATCH, 21
+    d_chars = _planted_batch(big, Q, K, 103)
+    ranges, counts, hit_off, scratch = big.buffers(Q)
+    big.g.search_hits(d_chars.data_ptr(), 0, K, Q, ranges.data_ptr(), 0)
+    total = big.g.hit_offsets(ranges.data_ptr(), Q, hit_off.data_ptr(), scratch.data_ptr())
+    d_pos = t.empty(total, dtype=t.int64, device=big.dev)
+    big.g.locate(ranges.data_ptr(), hit_off.data_ptr(), Q, total, d_pos.data_ptr())
+    t.cuda.synchronize()
+    lens = big.lengths(ranges, Q)
+    assert int(lens.min()) >= 1, "a planted k-mer was not found"
+    assert int(lens.sum()) == total and t.equal(t.cumsum(lens, 0), hit_off[1:])
+    assert int(d_pos.min()) >= 0 and int(d_pos.max()) <= big.n - K
+    big.check_positions_spell(d_chars, None, K, Q, lens, d_pos)
+    # the offset each k-mer was copied from is one of its hits (all of them: planted offsets regenerated on the host
+    # for a slice, compared on the device)
+    m = 2_000_000
+    planted = t.from_numpy(synth.planted_offsets(103, m, K, big.n).astype(np.int64)).to(big.dev)
+    found = t.zeros(m, dtype=t.bool, device=big.dev)
+    for h in range(int(lens[:m].max())):
+        valid = lens[:m] > h
+        idx = t.where(valid, hit_off[:m] + h, t.zeros_like(hit_off[:m]))
+        found |= valid & (d_pos[idx] == planted)
+    assert bool(found.all())
+    # the same k-mers through the general kernel: identical ranges everywhere (every k-mer has hits)
+    exact = t.empty(Q * 2, dtype=t.int64, device=big.dev)
+    big.g.search(d_chars.data_ptr(), 0, K, Q, exact.data_ptr(), 0)
+    t.cuda.synchronize()
+    assert t.equal(exact, ranges)
+    big.check_sample_against_oracle(d_chars, None, K, Q, ranges, None, hit_off, d_pos, exact_ranges=True)
+
+
+def test_cfg5_mixed_length_8_to_30mers_counted(grch38):
+    """divergent depth: 8..11-mers walk wide ranges from a letter range (no seed), 12..30-mers take 0..18 steps;
+    even ids random, odd ids planted"""
+    big, t, Q = grch38, grch38.torch, BATCH
+    d_len = t.empty(Q, dtype=t.int64, device=big.dev)
+    assert big.L.awfmGpuSynthMixedLengths(d_len.data_ptr(), 0, Q, 8, 30, 105, None) == 1
+    d_off = t.zeros(Q + 1, dtype=t.int64, device=big.dev)
+    t.cumsum(d_len, 0, out=d_off[1:])
+    assert int(d_len.min()) == 8 and int(d_len.max()) == 30
+    d_chars = t.empty(int(d_off[-1]) + 8, dtype=t.uint8, device=big.dev)
+    assert big.L.awfmGpuSynthMixedQueries(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, 105, big.text.data_ptr(), big.n, 0, None) == 1
+    ranges, counts, _, _ = big.buffers(Q)
+    hits_counts = t.full((Q,), 9, dtype=t.int32, device=big.dev)
+    big.g.search(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, ranges.data_ptr(), counts.data_ptr())
+    big.g.search_hits(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, 0, hits_counts.data_ptr())
+    t.cuda.synchronize()
+    lens = big.lengths(ranges, Q)
+    assert t.equal((lens & 0xFFFFFFFF).to(t.int32), counts) and t.equal(counts, hits_counts)
+    assert int(lens[1::2].min()) >= 1, "a planted k-mer was not found"
+    # an 8-mer occurs about n/4^8 times; anything absent has count 0
+    short = d_len == 8
+    assert float(lens[short].float().mean()) == pytest.approx(big.n / 4 ** 8, rel=0.05)
+    big.check_sample_against_oracle(d_chars, d_off, 0, Q, ranges, hits_counts, None, None, exact_ranges=True)
+
+
+def test_cfg4_amino_10mers_counted_and_located(awfm, oracle, require_gpu):
+    """Swiss-Prot-sized: 200 M residues over the 20 letters, seed table k = 5, 50 M random 10-mers (nearly all absent:
+    20^10 >> 2*10^8), plus planted 10-mers so that the amino LF walk runs at size"""
+    n = int(os.environ.get("AWFM_TEST_AMINO_LEN", 200_000_000))
+    Q, K = int(os.environ.get("AWFM_TEST_AMINO_BATCH", 50_000_000)), 10
+    big = _Big(awfm, oracle, n, 4, True, 8, 5)
+    t = big.torch
+    try:
+        d_chars = _random_batch(big, Q, K, 104)
+        ranges, counts, hit_off, scratch = big.buffers(Q)
+        big.g.search(d_chars.data_ptr(), 0, K, Q, ranges.data_ptr(), counts.data_ptr())
+        hits = t.full((Q * 2,), 7, dtype=t.int64, device=big.dev)
+        hcounts = t.full((Q,), 7, dtype=t.int32, device=big.dev)
+        big.g.search_hits(d_chars.data_ptr(), 0, K, Q, hits.data_ptr(), hcounts.data_ptr())
+        total = big.g.hit_offsets(ranges.data_ptr(), Q, hit_off.data_ptr(), scratch.data_ptr())
+        d_pos = t.empty(max(total, 1), dtype=t.int64, device=big.dev)
+        big.g.locate(ranges.data_ptr(), hit_off.data_ptr(), Q, total, d_pos.data_ptr())
+        t.cuda.synchronize()
+        lens = big.lengths(ranges, Q)
+        assert t.equal(lens.to(t.int32), counts) and t.equal(counts, hcounts) and int(lens.sum()) == total
+        has = lens > 0
+        assert t.equal(hits.view(Q, 2)[has], ranges.view(Q, 2)[has])
+        big.check_positions_spell(d_chars, None, K, Q, lens, d_pos[:total])
+        big.check_sample_against_oracle(d_chars, None, K, Q, ranges, counts, hit_off, d_pos, exact_ranges=True)
+        # planted 10-mers: every one is found where it was taken from, every hit spells it
+        Qp = Q // 5
+        d_chars = _planted_batch(big, Qp, K, 114)
+        big.g.search(d_chars.data_ptr(), 0, K, Qp, ranges.data_ptr(), counts.data_ptr())
+        total = big.g.hit_offsets(ranges.data_ptr(), Qp, hit_off.data_ptr(), scratch.data_ptr())
+        d_pos = t.empty(total, dtype=t.int64, device=big.dev)
+        big.g.locate(ranges.data_ptr(), hit_off.data_ptr(), Qp, total, d_pos.data_ptr())
+        t.cuda.synchronize()
+        lens = big.lengths(ranges[: 2 * Qp], Qp)
+        assert int(lens.min()) >= 1 and int(lens.sum()) == total
+        big.check_positions_spell(d_chars, None, K, Qp, lens, d_pos)
+        m = 1_000_000
+        planted = t.from_numpy(synth.planted_offsets(114, m, K, n).astype(np.int64)).to(big.dev)
+        found = t.zeros(m, dtype=t.bool, device=big.dev)
+        for h in range(int(lens[:m].max())):
+            valid = lens[:m] > h
+            idx = t.where(valid, hit_off[:m] + h, t.zeros_like(hit_off[:m]))
+            found |= valid & (d_pos[idx] == planted)
+        assert bool(found.all())
+        big.check_sample_against_oracle(d_chars, None, K, Qp, ranges, counts, hit_off, d_pos, exact_ranges=True)
+    finally:
+        big.close()
+
+
+# cfg 1: results of the CPU oracle on this seeded workload (scripts/cfg1_known_answers.py prints them); the counts
+# and the positions are the same for both seed depths, the final ranges of ABSENT 12-mers are not: with k = 12 they
+# are the blindly stepped table entries, with k = 8 the range the stepping stopped at
+CFG1 = {"present": 57758, "hits": 59556, "counts_fnv": 0x60B4BCE94F3A97A5, "positions_fnv": 0xFD5ED662ABC742EC,
+        "ranges_fnv": {12: 0x875F88CE60453C82, 8: 0xC79E9B59573DFD80}}
+
+
+@pytest.mark.parametrize("seed_k", [12, 8])
+def test_cfg1_one_million_12mers_against_1mbp(oracle, awfm, require_gpu, seed_k):
+    """the reference's CPU-runnable configuration, on every GPU entry point, all 10^6 k-mers against the oracle"""
+    txt = synth.text(1, 1_000_000)
+    q = synth.random_queries(101, 1_000_000, 12)
+    chars, offsets = synth.fixed_csr(q)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, seed_k)
+    oi = oracle.Index.wrap(oracle.DNA, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=8)
+    ho, pos, _ = oi.batch_locate(sp, ep, threads=8)
+    assert (int((cnt > 0).sum()), int(cnt.sum())) == (CFG1["present"], CFG1["hits"])
+    g = awfm.GpuIndex(ix)
+    # host-buffer entry points (general kernel, exact ranges: awfmGpuSearch)
+    ranges, counts = g.count_host(chars, None, fixed_length=12)
+    assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep) and np.array_equal(counts, cnt)
+    assert oracle.fnv1a(counts) == CFG1["counts_fnv"] and oracle.fnv1a(ranges) == CFG1["ranges_fnv"][seed_k]
+    r2, ho2, pos2 = g.locate_host(chars, None, fixed_length=12)
+    assert np.array_equal(r2, ranges) and np.array_equal(ho2, ho) and np.array_equal(pos2, pos)
+    assert oracle.fnv1a(pos2) == CFG1["positions_fnv"]
+    # device entry points, hits-only search in seed order forced on this small batch, then scan + locate
+    import torch
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(chars).to(dev)
+    d_ranges = torch.full((2_000_000,), 3, dtype=torch.int64, device=dev)
+    d_counts = torch.full((1_000_000,), 3, dtype=torch.int32, device=dev)
+    d_off = torch.empty(1_000_001, dtype=torch.int64, device=dev)
+    d_scratch = torch.empty(awfm.GpuIndex.scan_scratch_bytes(1_000_000), dtype=torch.uint8, device=dev)
+    g.set_ordered(1)
+    assert g.search_hits_is_ordered(False, 12, 1_000_000)
+    g.search_hits(d_chars.data_ptr(), 0, 12, 1_000_000, d_ranges.data_ptr(), d_counts.data_ptr())
+    total = g.hit_offsets_from_counts(d_counts.data_ptr(), 1_000_000, d_off.data_ptr(), d_scratch.data_ptr())
+    d_pos = torch.empty(total, dtype=torch.int64, device=dev)
+    g.locate(d_ranges.data_ptr(), d_off.data_ptr(), 1_000_000, total, d_pos.data_ptr())
+    torch.cuda.synchronize()
+    got = d_ranges.cpu().numpy().view(np.uint64).reshape(-1, 2)
+    hit = cnt > 0
+    assert np.array_equal(got[hit, 0], sp[hit]) and np.array_equal(got[hit, 1], ep[hit]) and np.all(got[~hit, 0] > got[~hit, 1])
+    assert oracle.fnv1a(d_counts.cpu().numpy()) == CFG1["counts_fnv"]
+    assert np.array_equal(d_off.cpu().numpy().view(np.uint64), ho) and oracle.fnv1a(d_pos.cpu().numpy()) == CFG1["positions_fnv"]
+    # the drop-in AoS entry points on a slice (python fills the list one k-mer at a time)
+    m = 20_000
+    lst = awfm.KmerSearchList(m)
+    lst.fill([q[i].tobytes() for i in range(m)])
+    awfm.parallel_search_count(ix, lst, 4)
+    assert np.array_equal(lst.counts(), cnt[:m])
+    assert awfm.parallel_search_locate(ix, lst, 4) == awfm.AwFmSuccess
+    for i in np.nonzero(cnt[:m])[0].tolist():
+        assert np.array_equal(lst.positions(i), pos[int(ho[i]):int(ho[i + 1])])
+    lst.dealloc()
+    g.destroy()
+    ix.dealloc()

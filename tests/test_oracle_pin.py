@@ -206,3 +206,143 @@ def test_word_rank_equals_bytewise_definition(oracle):
             L.orc_occ_vector(ix.ptr, q // 256, a, vec)
             base = int(np.frombuffer(blocks[(q // 256) * bb + 32 * planes + 8 * a:][:8].tobytes(), np.uint64)[0])
             assert ix.occ(a, q) == base + L.orc_masked_popcount(vec, q % 256)
+
+
+class _Naive:
+    """the reference's batch-search semantics on naive structures only (sorted suffixes, a python BWT, cumulative
+    letter counts): nothing here comes from the oracle, so whatever agrees with it is pinned independently"""
+
+    def __init__(self, O, alphabet, raw, seed_k):
+        self.O, self.alphabet, self.K = O, alphabet, seed_k
+        self.card = 20 if alphabet == O.AMINO else 4
+        self.text = sanitize(raw, O, alphabet)
+        self.sa = naive_sa(self.text)
+        sentinel = 21 if alphabet == O.AMINO else 5
+        bwt = np.array([letter_index(O, alphabet, self.text[p - 1]) if p else sentinel for p in self.sa], dtype=np.int64)
+        n = len(bwt)
+        # occ[a][q + 1] = occurrences of letter a in bwt[0..q]
+        self.occ = np.zeros((22, n + 1), dtype=np.int64)
+        for a in range(22):
+            np.cumsum(bwt == a, out=self.occ[a, 1:])
+        counts = self.occ[:, n]
+        self.C = [1 + int(counts[:i].sum()) for i in range(self.card + 2)]  # ref src/AwFmCreate.c:338-344: C[0] = 1
+
+    def step(self, sp, ep, a):
+        """ref src/AwFmSearch.c:42-103, applied whether or not the range is valid"""
+        return self.C[a] + int(self.occ[a, sp]), self.C[a] + int(self.occ[a, ep + 1]) - 1  # Occ(a, sp-1), Occ(a, ep)
+
+    def seed_table(self):
+        """ref src/AwFmCreate.c:407-450: depth-first from each last letter, prepending letters with no validity
+        check; entry index = letters of the k-mer as base-|A| digits, first letter most significant"""
+        table = np.zeros((self.card ** self.K, 2), dtype=np.uint64)
+
+        def recurse(sp, ep, length, index, multiplier):
+            if length == self.K:
+                table[index] = (sp, ep)
+                return
+            for e in range(self.card):
+                nsp, nep = self.step(sp, ep, e)
+                recurse(nsp, nep, length + 1, index + e * multiplier, multiplier * self.card)
+
+        for i in range(self.card):
+            recurse(self.C[i], self.C[i + 1] - 1, 1, i, self.card)
+        return table
+
+    def batch_range(self, table, kmer):
+        """ref src/AwFmParallelSearch.c:222-313 for one k-mer"""
+        O, L, K = self.O, len(kmer), self.K
+        li = [letter_index(O, self.alphabet, c) for c in kmer]
+        ambiguous = [bool(O.lib().orc_letter_is_ambiguous(c, self.alphabet)) for c in kmer]
+        if L >= K and not any(ambiguous[L - K:]):  # ref src/AwFmKmerTable.c:4-51
+            index = 0
+            for a in li[L - K:]:
+                index = index * self.card + a
+            sp, ep = int(table[index][0]), int(table[index][1])
+        else:  # ref src/AwFmSearch.c:485-520 over the last min(L, K) characters
+            part = li[max(0, L - K):]
+            sp, ep = self.C[part[-1]], self.C[part[-1] + 1] - 1
+            for a in reversed(part[:-1]):
+                if sp > ep:
+                    break
+                sp, ep = self.step(sp, ep, a)
+        j = 1
+        while L >= K + j and sp <= ep:  # ref src/AwFmParallelSearch.c:273-313
+            sp, ep = self.step(sp, ep, li[L - (K + j)])
+            j += 1
+        return sp, ep
+
+
+@pytest.mark.parametrize("alphabet_name,n,seed_k", [("dna", 3000, 7), ("dna", 900, 6), ("amino", 4000, 3), ("amino", 300, 2)])
+def test_whole_seed_table_and_absent_seeded_kmers_against_naive_structures(oracle, alphabet_name, n, seed_k):
+    """The seed table holds, for an ABSENT k-mer, whatever empty range blind stepping produced, and a seeded query
+    that ends up absent keeps the first invalid range after that entry.  Both are pinned here without the oracle:
+    the whole table is rebuilt by blind stepping over a python BWT (most entries of the 6-mer / 3-mer tables are of
+    absent k-mers), and every query's final {sp, ep} -- present or absent, seeded or not -- is recomputed on the
+    naive structures.  This is exactly what awfmGpuSearch promises bit for bit."""
+    O = oracle
+    alphabet = O.AMINO if alphabet_name == "amino" else O.DNA
+    letters = synth.AMINO_ALPHABET if alphabet == O.AMINO else synth.DNA_ALPHABET
+    raw = synth.text(300 + n, n, letters).copy()
+    raw[7:10] = ord("x")
+    ix = O.Index.from_text(raw.tobytes(), alphabet, 4, seed_k)
+    naive = _Naive(O, alphabet, raw.tobytes(), seed_k)
+    table = naive.seed_table()
+    got = ix.seed_table()
+    assert np.array_equal(got, table), "seed table differs from blind stepping over the naive BWT"
+    absent_entries = int((table[:, 0] > table[:, 1]).sum())
+    assert absent_entries > len(table) // 4
+    # queries: random (mostly absent once longer than log_|A| n), planted, with ambiguity letters inside and outside
+    # the seed, shorter than the seed, upper case
+    chars, offsets = synth.mixed_queries(11 + n, 600, raw, letters, 1, seed_k + 9)
+    chars = chars.copy()
+    rng = np.random.default_rng(5)
+    for at in rng.integers(0, len(chars), size=40):
+        chars[at] = ord("x") if alphabet == O.DNA else ord("b")
+    for at in rng.integers(0, len(chars), size=200):
+        if chars[at] >= ord("a"):
+            chars[at] -= 32
+    sp, ep, cnt, _ = ix.batch_search(chars, offsets)
+    seeded_absent = 0
+    for j in range(600):
+        kmer = bytes(chars[int(offsets[j]):int(offsets[j + 1])])
+        expect = naive.batch_range(table, kmer)
+        assert (int(sp[j]), int(ep[j])) == expect, f"query {j} {kmer!r}"
+        assert int(cnt[j]) == (expect[1] - expect[0] + 1 if expect[0] <= expect[1] else 0)
+        seeded_absent += len(kmer) >= seed_k and expect[0] > expect[1]
+    assert seeded_absent > 100
+
+
+def test_cfg1_counts_and_positions_by_brute_force(oracle):
+    """BASELINE configs[0]: 1 M random 12-mers against the 1 Mbp text, ALL of them.  A 12-mer is a 24-bit integer,
+    so its occurrences are found by sorting the text's 12-mers -- no FM-index involved.  The oracle's counts and
+    position sets must equal that; the digests committed in tests/test_gpu_configs.py::CFG1 are then what the GPU
+    has to reproduce."""
+    O = oracle
+    from tests.test_gpu_configs import CFG1
+    txt = synth.text(1, 1_000_000)
+    q = synth.random_queries(101, 1_000_000, 12)
+    code = np.zeros(256, np.int64)
+    for i, c in enumerate(b"acgt"):
+        code[c] = i
+    t = code[txt]
+    n = len(t) - 11
+    text_keys = np.zeros(n, np.int64)
+    for c in range(12):
+        text_keys = text_keys * 4 + t[c:c + n]
+    order = np.argsort(text_keys, kind="stable")  # positions in increasing order within a key
+    sorted_keys = text_keys[order]
+    qk = np.zeros(len(q), np.int64)
+    for c in range(12):
+        qk = qk * 4 + code[q[:, c]]
+    lo, hi = np.searchsorted(sorted_keys, qk, "left"), np.searchsorted(sorted_keys, qk, "right")
+    brute_counts = (hi - lo).astype(np.uint32)
+    assert (int((brute_counts > 0).sum()), int(brute_counts.sum())) == (CFG1["present"], CFG1["hits"])
+    chars, offsets = synth.fixed_csr(q)
+    oi = O.Index.from_text(txt.tobytes(), O.DNA, 8, 8)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=8)
+    assert np.array_equal(cnt, brute_counts)
+    assert O.fnv1a(cnt) == CFG1["counts_fnv"]
+    ho, pos, _ = oi.batch_locate(sp, ep, threads=8)
+    assert O.fnv1a(pos) == CFG1["positions_fnv"]
+    for j in np.nonzero(brute_counts)[0].tolist():
+        assert sorted(pos[int(ho[j]):int(ho[j + 1])].tolist()) == order[lo[j]:hi[j]].tolist()
