@@ -1,8 +1,29 @@
 /*
  * awfm_device.h -- device-side building blocks shared by awfm_gpu.hip (search /
  * locate) and awfm_gpu_build.hip (index construction): the kernel-argument view
- * of the device image, the 8-lane group rank/step primitives and the layout
- * conversion kernels.  C++/HIP only; the C ABI is include/awfm_gpu.h.
+ * of the device image, the rank/step primitives on the device block layouts and the
+ * layout conversion kernels.  C++/HIP only; the C ABI is include/awfm_gpu.h.
+ *
+ * Device block layouts (the host AwFmIndex keeps the reference's 160-B / 352-B blocks of 256 positions,
+ * ref src/AwFmIndex.h:55-65; the device image is re-laid-out once per index):
+ *
+ *   A device block covers 128 BWT positions as 4 slices of 32 positions, for both alphabets.
+ *
+ *   nucleotide block = 64 B.  Slice k is one 16-B piece {b0, b1, b2, count}: the three bit-plane words of positions
+ *     32k..32k+31 and the 32-bit count of letter k (a, c, g, t) before the block, relative to the block's
+ *     superblock of 2^32 positions.  A rank reads one 64-B granule, a lane of a 4-lane group holds one piece per
+ *     block, and an index of fewer than 2^32 positions has a single superblock with base 0.  The X count is
+ *     derived: positions before the block minus A+C+G+T minus the sentinel; '$' is never ranked.
+ *
+ *   amino block = 128 B = one line.  Slice k is two 16-B pieces {b0,b1,b2,b3} {b4, c01, c23, c45}: the five plane
+ *     words and six 16-bit counts (letters 6k..6k+5; 21 letters including z) relative to the block's superblock
+ *     of 2^16 positions (512 blocks).
+ *
+ *   super: absolute 64-bit base counts at superblock starts -- nucleotide super[4*sb + a] (at most 64 superblocks,
+ *     copied to LDS by the kernels of images of 2^32 or more positions), amino super[24*sb + a] (24 words per 2^16
+ *     positions: 0.6 MB for a Swiss-Prot-sized index, read beside the block).
+ *
+ * Occ is a function of the BWT only, so the block granularity changes no result, only which bytes a rank reads.
  */
 #ifndef AWFM_DEVICE_H
 #define AWFM_DEVICE_H
@@ -31,6 +52,14 @@ inline void setError(const char *what) { awfmGpuSetError(what); }
     }                                                   \
   } while (0)
 
+constexpr unsigned kBlockShift = 7;       /* 128 positions per device block */
+constexpr unsigned kBlockMask = 127;
+constexpr unsigned kSlices = 4;           /* 32-position slices per device block */
+constexpr unsigned kNucSuperShift = 32;   /* positions per nucleotide superblock: 2^32 */
+constexpr unsigned kMaxNucSuper = 64;     /* nucleotide images of up to 2^38 positions */
+constexpr unsigned kAminoSuperShift = 16; /* positions per amino superblock: 2^16 */
+constexpr unsigned kAminoSuperStride = 24;
+
 /* kernel-argument view of the device image */
 struct DevIndex {
   const uint4 *blocks;
@@ -40,6 +69,8 @@ struct DevIndex {
   unsigned long long sentinelPos; /* BWT position holding '$' */
   unsigned long long seedLen;
   const unsigned long long *prefixSums; /* 24 words in device memory */
+  const unsigned long long *super;      /* base counts at superblock starts (layouts above) */
+  unsigned int numSuper;
   unsigned int saRatio;
   unsigned int saShift; /* log2(saRatio) when it is a power of two, else 0xFFFFFFFF */
   unsigned int saWidth;
@@ -59,51 +90,73 @@ struct QueryRec {
 };
 
 constexpr int kThreads = 256;
-constexpr int kGroupsPerBlock = kThreads / 8;
 
-/* ------------------------------------------------------------------ device helpers */
+/* BWT positions are 32-bit when bwtLength < 2^32 (NARROW): half the integer work of the range arithmetic */
+template <bool NARROW>
+struct PositionType {
+  typedef unsigned long long type;
+};
+template <>
+struct PositionType<true> {
+  typedef unsigned type;
+};
+
+/* ------------------------------------------------------------------ lane-group helpers */
 
 template <int CTRL>
 __device__ __forceinline__ unsigned dppMove(unsigned v) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
 }
 
-/* sum over the 8 lanes of a group; every lane gets the total */
-__device__ __forceinline__ unsigned groupSum8(unsigned v) {
-  v += dppMove<0xB1>(v);  /* quad_perm [1,0,3,2] */
-  v += dppMove<0x4E>(v);  /* quad_perm [2,3,0,1] */
-  v += dppMove<0x141>(v); /* row_half_mirror: lane i <- lane 7-i of its half row */
+/* sum over the G lanes of a group (G a power of two <= 8); every lane gets the total */
+template <int G>
+__device__ __forceinline__ unsigned groupSum(unsigned v) {
+  if (G >= 2) v += dppMove<0xB1>(v);  /* quad_perm [1,0,3,2] */
+  if (G >= 4) v += dppMove<0x4E>(v);  /* quad_perm [2,3,0,1] */
+  if (G >= 8) v += dppMove<0x141>(v); /* row_half_mirror */
   return v;
 }
 
-__device__ __forceinline__ unsigned long long groupSum8u64(unsigned long long v) {
-#pragma unroll
-  for (int stage = 0; stage < 3; stage++) {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32), olo, ohi;
-    if (stage == 0) {
-      olo = dppMove<0xB1>(lo);
-      ohi = dppMove<0xB1>(hi);
-    } else if (stage == 1) {
-      olo = dppMove<0x4E>(lo);
-      ohi = dppMove<0x4E>(hi);
-    } else {
-      olo = dppMove<0x141>(lo);
-      ohi = dppMove<0x141>(hi);
-    }
-    v += ((unsigned long long)ohi << 32) | olo;
+template <int G>
+__device__ __forceinline__ unsigned long long groupSum64(unsigned long long v) {
+  if (G >= 2) {
+    const unsigned lo = dppMove<0xB1>((unsigned)v), hi = dppMove<0xB1>((unsigned)(v >> 32));
+    v += ((unsigned long long)hi << 32) | lo;
+  }
+  if (G >= 4) {
+    const unsigned lo = dppMove<0x4E>((unsigned)v), hi = dppMove<0x4E>((unsigned)(v >> 32));
+    v += ((unsigned long long)hi << 32) | lo;
+  }
+  if (G >= 8) {
+    const unsigned lo = dppMove<0x141>((unsigned)v), hi = dppMove<0x141>((unsigned)(v >> 32));
+    v += ((unsigned long long)hi << 32) | lo;
   }
   return v;
 }
 
-/* bits 0..(p - 32*piece) of a 32-position slice, clamped: the slice's share of
+template <int G>
+__device__ __forceinline__ unsigned groupShfl(unsigned v, unsigned srcLaneInGroup) {
+  if (G == 1) return v;
+  return (unsigned)__shfl((int)v, (int)srcLaneInGroup, G);
+}
+
+/* bits 0..(p - 32*slice) of a 32-position slice, clamped: the slice's share of
  * the inclusive prefix mask of ref src/AwFmSimdConfig.c:89-114 */
-__device__ __forceinline__ unsigned sliceMask(unsigned p, unsigned piece) {
-  int bits = (int)p - (int)(piece * 32) + 1;
+__device__ __forceinline__ unsigned sliceMask(unsigned p, unsigned slice) {
+  int bits = (int)p - (int)(slice * 32) + 1;
   bits = bits < 0 ? 0 : (bits > 32 ? 32 : bits);
   return (unsigned)((1ull << bits) - 1ull);
 }
 
-/* ---- nucleotide ---- */
+/* position-mask table in LDS: sMask[local * 4 + slice] = bits of slice `slice` at positions <= local */
+__device__ __forceinline__ void stageMaskTable(unsigned *sMask) {
+  for (unsigned e = threadIdx.x; e < (kBlockMask + 1u) * kSlices; e += blockDim.x) sMask[e] = sliceMask(e >> 2, e & 3u);
+}
+
+/* ------------------------------------------------------------------ nucleotide */
+
+/* a 16-byte piece as one 128-bit register tuple */
+typedef unsigned Piece __attribute__((ext_vector_type(4)));
 
 /* 1 when (c | 0x20) is one of a,c,g,t,u; branch-free */
 __device__ __forceinline__ unsigned nucIsAcgtu(unsigned c) {
@@ -141,55 +194,174 @@ __device__ __forceinline__ PlaneSel3 nucPlaneSel(unsigned letter) {
   return s;
 }
 
-__device__ __forceinline__ unsigned nucOccSlice(const uint4 &pc, const PlaneSel3 &s) {
+__device__ __forceinline__ unsigned nucOccSlice(const Piece &pc, const PlaneSel3 &s) {
   return ((pc.x ^ s.x0) | s.d0) & ((pc.y ^ s.x1) | s.d1) & ((pc.z ^ s.x2) | s.d2);
 }
 
-/* base count of `letter` before block `blk` from the count words spread over the group */
-__device__ __forceinline__ unsigned long long nucBase(const uint4 &pc, unsigned letter, unsigned long long blk,
-                                                      unsigned long long sentinelPos, unsigned g) {
-  if (letter < 4u) {
-    const unsigned lo = (unsigned)__shfl((int)pc.w, (int)(2u * letter), 8);
-    const unsigned hi = (unsigned)__shfl((int)pc.w, (int)(2u * letter + 1u), 8);
-    return ((unsigned long long)hi << 32) | lo;
+/* occurrence bits of letter code (c1,c0) in a nucleotide piece, c0m/c1m = the code bits as all-ones masks.
+ * With planes x,y,z: a (00) = y&z, c (01) = x&z, g (10) = x&y, t (11) = x&~y&~z (the literals of ref
+ * src/AwFmOccurrence.c:18-31), i.e. (x | a) & ((y ^ t) | c) & ((z ^ t) | g) with one v_bitop3 per factor. */
+__device__ __forceinline__ unsigned nucOccFast(const Piece &pc, unsigned c0m, unsigned c1m) {
+  const unsigned t0 = __builtin_amdgcn_bitop3_b32(pc.x, c0m, c1m, 0xF1); /* x | (~c0 & ~c1) */
+  const unsigned t1 = __builtin_amdgcn_bitop3_b32(pc.y, c0m, c1m, 0x7C); /* (y ^ (c0 & c1)) | (c0 & ~c1) */
+  const unsigned t2 = __builtin_amdgcn_bitop3_b32(pc.z, c0m, c1m, 0x7A); /* (z ^ (c0 & c1)) | (~c0 & c1) */
+  return t0 & t1 & t2;
+}
+
+/* nucleotide superblock bases in LDS: only images of 2^32 or more positions have more than the all-zero entry */
+template <bool NARROW>
+__device__ __forceinline__ void nucStageSuper(const DevIndex &ix, unsigned long long *sSuper) {
+  if (!NARROW)
+    for (unsigned e = threadIdx.x; e < kMaxNucSuper * 4u; e += blockDim.x) sSuper[e] = e < ix.numSuper * 4u ? ix.super[e] : 0ull;
+}
+
+/*
+ * One backward step of a nucleotide query whose next letter is a,c,g or t/u (`letter` 0..3), by the G lanes
+ * of its group; lane j holds slices j*S..j*S+S-1 (S = 4/G) of a block.  Everything that does not depend on the
+ * block (plane selectors, position masks from the LDS table sMask[local * 4 + slice], C[a]) is computed between
+ * issuing the loads and the first use of their data; both blocks are requested before anything waits: the second
+ * block's registers start as an "undefined" asm definition and are loaded under the branch, the select happens on
+ * the rank results, and an empty asm use keeps every loaded register allocated until the rank is done (a dead
+ * component would be re-used for the values computed in the shadow of the load, at the price of a full wait).
+ * ref src/AwFmSearch.c:42-159, src/AwFmOccurrence.c:18-31, :170-217.
+ */
+template <int G, bool NARROW>
+__device__ __forceinline__ void nucFastStep(const DevIndex &ix, const unsigned long long *sC, const unsigned long long *sSuper,
+                                            const unsigned *sMask, unsigned firstSlice, unsigned letter,
+                                            typename PositionType<NARROW>::type &sp,
+                                            typename PositionType<NARROW>::type &ep) {
+  constexpr int S = (int)kSlices / G;
+  typedef typename PositionType<NARROW>::type pos_t;
+  const pos_t q0 = sp - 1, q1 = ep;
+  const unsigned long long blk0 = q0 >> kBlockShift, blk1 = q1 >> kBlockShift;
+  const bool same = blk0 == blk1;
+  Piece p0[S], p1[S];
+  {
+    const Piece *a0 = (const Piece *)(ix.blocks + (blk0 * kSlices + firstSlice));
+#pragma unroll
+    for (int s = 0; s < S; s++) p0[s] = a0[s];
   }
-  /* X (or anything else): everything before the block that is not A,C,G,T,$ */
-  const unsigned long long part = (g & 1u) ? ((unsigned long long)pc.w << 32) : (unsigned long long)pc.w;
-  const unsigned long long acgt = groupSum8u64(part);
-  const unsigned long long before = blk * 256ull;
-  return before - acgt - (sentinelPos < before ? 1ull : 0ull);
+#pragma unroll
+  for (int s = 0; s < S; s++) asm volatile("" : "=v"(p1[s]));
+  if (!same) {
+    const Piece *a1 = (const Piece *)(ix.blocks + (blk1 * kSlices + firstSlice));
+#pragma unroll
+    for (int s = 0; s < S; s++) p1[s] = a1[s];
+  }
+  const unsigned c0m = 0u - (letter & 1u), c1m = 0u - (letter >> 1);
+  const unsigned *m0 = sMask + (((unsigned)q0 & kBlockMask) * kSlices + firstSlice);
+  const unsigned *m1 = sMask + (((unsigned)q1 & kBlockMask) * kSlices + firstSlice);
+  unsigned mask0[S], mask1[S];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    mask0[s] = m0[s];
+    mask1[s] = m1[s];
+  }
+  pos_t cLetter = (pos_t)sC[letter];
+  pos_t super1 = 0;
+  if (!NARROW) { /* 64-bit bases of the superblocks of q0 and q1 (they may differ) */
+    const unsigned long long s0 = sSuper[(unsigned)((unsigned long long)q0 >> kNucSuperShift) * 4u + letter];
+    const unsigned long long s1 = sSuper[(unsigned)((unsigned long long)q1 >> kNucSuperShift) * 4u + letter];
+    cLetter += (pos_t)s0;
+    super1 = (pos_t)(s1 - s0);
+  }
+  const unsigned sameMask = same ? ~0u : 0u;
+  unsigned n0 = 0, n1 = 0;
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    const unsigned occ0 = nucOccFast(p0[s], c0m, c1m), occ1 = nucOccFast(p1[s], c0m, c1m);
+    n0 += __popc(occ0 & mask0[s]);
+    n1 += __popc(__builtin_amdgcn_bitop3_b32(occ0, occ1, sameMask, 0xE4) & mask1[s]); /* same ? occ0 : occ1 */
+  }
+#pragma unroll
+  for (int s = 0; s < S; s++) asm volatile("" ::"v"(p0[s]), "v"(p1[s]));
+  /* count word of letter a: slice a, i.e. lane a / S, register a % S */
+  unsigned c0 = 0, c1 = 0;
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    c0 = (letter % S) == (unsigned)s ? p0[s].w : c0;
+    c1 = (letter % S) == (unsigned)s ? p1[s].w : c1;
+  }
+  const unsigned base0 = groupShfl<G>(c0, letter / S);
+  unsigned base1 = groupShfl<G>(c1, letter / S);
+  base1 = same ? base0 : base1;
+  const unsigned packed = groupSum<G>(n0 | (n1 << 16));
+  sp = cLetter + (pos_t)base0 + (pos_t)(packed & 0xFFFFu);
+  ep = cLetter + super1 + (pos_t)base1 + (pos_t)(packed >> 16) - (pos_t)1;
 }
 
-/* rank arithmetic of one backward step once the two pieces are in registers
- * (ref src/AwFmSearch.c:42-103); pc1 == pc0 when sp-1 and ep share a block */
-__device__ __forceinline__ void nucStepFromPieces(const DevIndex &ix, const unsigned long long *sC, unsigned letter,
-                                                  const uint4 &pc0, const uint4 &pc1, unsigned long long &sp,
-                                                  unsigned long long &ep, unsigned g) {
-  const unsigned long long q0 = sp - 1ull, q1 = ep;
+/* count of `letter` (0..3, or anything else = X: everything before the block that is not a,c,g,t or '$') before
+ * block `blk`, from the count words spread over the group */
+template <int G, bool NARROW>
+__device__ __forceinline__ typename PositionType<NARROW>::type nucBaseAny(const DevIndex &ix, const unsigned long long *sSuper,
+                                                                         const Piece *p, unsigned letter,
+                                                                         unsigned long long blk) {
+  constexpr int S = (int)kSlices / G;
+  typedef typename PositionType<NARROW>::type pos_t;
+  const unsigned sb = NARROW ? 0u : (unsigned)(blk >> (kNucSuperShift - kBlockShift));
+  unsigned mine = 0;
+  unsigned long long part = 0;
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    mine = (letter % S) == (unsigned)s ? p[s].w : mine;
+    part += p[s].w;
+  }
+  if (letter < 4u) {
+    const pos_t rel = (pos_t)groupShfl<G>(mine, letter / S);
+    return NARROW ? rel : rel + (pos_t)sSuper[sb * 4u + letter];
+  }
+  unsigned long long acgt = groupSum64<G>(part);
+  if (!NARROW) acgt += sSuper[sb * 4u] + sSuper[sb * 4u + 1u] + sSuper[sb * 4u + 2u] + sSuper[sb * 4u + 3u];
+  const unsigned long long before = blk << kBlockShift;
+  return (pos_t)(before - acgt - (ix.sentinelPos < before ? 1ull : 0ull));
+}
+
+/* one backward step with any letter index (0..3, 4 = X; ref src/AwFmSearch.c:42-103): loads + rank */
+template <int G, bool NARROW>
+__device__ __forceinline__ void nucStepAny(const DevIndex &ix, const unsigned long long *sC, const unsigned long long *sSuper,
+                                           unsigned firstSlice, unsigned letter,
+                                           typename PositionType<NARROW>::type &sp,
+                                           typename PositionType<NARROW>::type &ep) {
+  constexpr int S = (int)kSlices / G;
+  typedef typename PositionType<NARROW>::type pos_t;
+  const pos_t q0 = sp - 1, q1 = ep;
+  const unsigned long long blk0 = q0 >> kBlockShift, blk1 = q1 >> kBlockShift;
+  const bool same = blk0 == blk1;
+  Piece p0[S], p1[S];
+  {
+    const Piece *a0 = (const Piece *)(ix.blocks + (blk0 * kSlices + firstSlice));
+#pragma unroll
+    for (int s = 0; s < S; s++) p0[s] = a0[s];
+  }
+#pragma unroll
+  for (int s = 0; s < S; s++) asm volatile("" : "=v"(p1[s]));
+  if (!same) {
+    const Piece *a1 = (const Piece *)(ix.blocks + (blk1 * kSlices + firstSlice));
+#pragma unroll
+    for (int s = 0; s < S; s++) p1[s] = a1[s];
+  }
   const PlaneSel3 sel = nucPlaneSel(letter);
-  const unsigned n0 = __popc(nucOccSlice(pc0, sel) & sliceMask((unsigned)q0 & 255u, g));
-  const unsigned n1 = __popc(nucOccSlice(pc1, sel) & sliceMask((unsigned)q1 & 255u, g));
-  const unsigned packed = groupSum8(n0 | (n1 << 16));
-  const unsigned long long base0 = nucBase(pc0, letter, q0 >> 8, ix.sentinelPos, g);
-  const unsigned long long base1 = nucBase(pc1, letter, q1 >> 8, ix.sentinelPos, g);
-  const unsigned long long c = sC[letter];
-  sp = c + base0 + (packed & 0xFFFFu);
-  ep = c + base1 + (packed >> 16) - 1ull;
+  const unsigned local0 = (unsigned)q0 & kBlockMask, local1 = (unsigned)q1 & kBlockMask;
+  const unsigned sameMask = same ? ~0u : 0u;
+  unsigned n0 = 0, n1 = 0;
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    const unsigned occ0 = nucOccSlice(p0[s], sel), occ1 = nucOccSlice(p1[s], sel);
+    n0 += __popc(occ0 & sliceMask(local0, firstSlice + s));
+    n1 += __popc(__builtin_amdgcn_bitop3_b32(occ0, occ1, sameMask, 0xE4) & sliceMask(local1, firstSlice + s));
+  }
+#pragma unroll
+  for (int s = 0; s < S; s++) asm volatile("" ::"v"(p0[s]), "v"(p1[s]));
+  const pos_t base0 = nucBaseAny<G, NARROW>(ix, sSuper, p0, letter, blk0);
+  pos_t base1 = nucBaseAny<G, NARROW>(ix, sSuper, p1, letter, blk1);
+  base1 = same ? base0 : base1;
+  const unsigned packed = groupSum<G>(n0 | (n1 << 16));
+  const pos_t cLetter = (pos_t)sC[letter];
+  sp = cLetter + base0 + (pos_t)(packed & 0xFFFFu);
+  ep = cLetter + base1 + (pos_t)(packed >> 16) - (pos_t)1;
 }
 
-/* one backward step for the group's query: loads + rank */
-__device__ __forceinline__ void nucStep(const DevIndex &ix, const unsigned long long *sC, unsigned letter,
-                                        unsigned long long &sp, unsigned long long &ep, unsigned g) {
-  const unsigned long long blk0 = (sp - 1ull) >> 8, blk1 = ep >> 8;
-  /* both loads are issued before either is consumed (copying pc0 into pc1 first would serialise them) */
-  const uint4 pc0 = ix.blocks[blk0 * 8ull + g];
-  uint4 other = make_uint4(0u, 0u, 0u, 0u);
-  if (blk1 != blk0) other = ix.blocks[blk1 * 8ull + g];
-  const uint4 pc1 = blk1 != blk0 ? other : pc0;
-  nucStepFromPieces(ix, sC, letter, pc0, pc1, sp, ep, g);
-}
-
-/* ---- amino ---- */
+/* ------------------------------------------------------------------ amino */
 
 struct AminoTables {
   unsigned char letterOfAscii[32]; /* ref src/AwFmLetter.c:55-67 */
@@ -213,6 +385,14 @@ struct AminoShared {
   unsigned short planeMask[24];
 };
 
+__device__ __forceinline__ void aminoStageTables(AminoShared &t) {
+  if (threadIdx.x < 32) {
+    t.letterOfAscii[threadIdx.x] = kAminoTables.letterOfAscii[threadIdx.x];
+    t.letterOfCode[threadIdx.x] = kAminoTables.letterOfCode[threadIdx.x];
+    if (threadIdx.x < 24) t.planeMask[threadIdx.x] = kAminoTables.planeMask[threadIdx.x];
+  }
+}
+
 __device__ __forceinline__ unsigned aminoLetterIndex(const AminoShared &t, unsigned c) {
   return c == '$' ? 21u : (unsigned)t.letterOfAscii[c & 31u];
 }
@@ -221,114 +401,199 @@ __device__ __forceinline__ bool aminoIsAmbiguous(unsigned c) {
   return ((l == 'z') | (l == 'x') | (l == 'b')) != 0;
 }
 
-/* An amino piece is two 16-B loads kept as plain uint4 values: lo = {b0,b1,b2,b3},
- * hi = {b4,c0,c1,c2} (plane words of this lane's 32 positions, then the base
- * counts of letters 3k, 3k+1, 3k+2). */
 __device__ __forceinline__ unsigned aminoLiteral(unsigned plane, unsigned ones, unsigned zeros, unsigned j) {
   const unsigned x = 0u - ((zeros >> j) & 1u);
   const unsigned d = (((ones | zeros) >> j) & 1u) - 1u;
   return (plane ^ x) | d;
 }
 
-__device__ __forceinline__ unsigned aminoOccSlice(const uint4 &lo, const uint4 &hi, unsigned ones, unsigned zeros) {
+/* occurrence bits of a letter in one amino slice: lo = {b0,b1,b2,b3}, hi = {b4, c01, c23, c45} */
+__device__ __forceinline__ unsigned aminoOccSlice(const Piece &lo, const Piece &hi, unsigned ones, unsigned zeros) {
   return aminoLiteral(lo.x, ones, zeros, 0) & aminoLiteral(lo.y, ones, zeros, 1) &
          aminoLiteral(lo.z, ones, zeros, 2) & aminoLiteral(lo.w, ones, zeros, 3) &
          aminoLiteral(hi.x, ones, zeros, 4);
 }
 
-__device__ __forceinline__ unsigned long long aminoBase(const uint4 &hi, unsigned letter) {
-  /* pick count word 1+letter%3 of `hi` with shifts (a select chain on vector
-   * components makes hipcc spill the vector to LDS for dynamic indexing) */
-  const unsigned slot = letter % 3u;
-  const unsigned long long c01 = ((unsigned long long)hi.z << 32) | hi.y;
-  const unsigned long long c2x = hi.w;
-  const unsigned mine = (unsigned)((slot == 2u ? c2x : c01) >> (slot == 1u ? 32u : 0u));
-  return (unsigned)__shfl((int)mine, (int)(letter / 3u), 8);
+/* 16-bit count `sub` (0..5) of a slice's second piece, picked with shifts (a select chain on vector components
+ * indexed dynamically makes hipcc move the vector to scratch) */
+__device__ __forceinline__ unsigned aminoCount16(const Piece &hi, unsigned sub) {
+  const unsigned long long c03 = ((unsigned long long)hi.z << 32) | hi.y;
+  const unsigned long long c45 = hi.w;
+  return (unsigned)((sub >= 4u ? c45 : c03) >> (16u * (sub & 3u))) & 0xFFFFu;
 }
 
-/* rank arithmetic of one amino backward step from loaded pieces (ref src/AwFmSearch.c:105-159) */
-__device__ __forceinline__ void aminoStepFromPieces(const unsigned long long *sC, const AminoShared &t, unsigned letter,
-                                                    const uint4 &lo0, const uint4 &hi0, const uint4 &lo1,
-                                                    const uint4 &hi1, unsigned long long &sp, unsigned long long &ep,
-                                                    unsigned g) {
-  const unsigned long long q0 = sp - 1ull, q1 = ep;
-  const unsigned pm = t.planeMask[letter < 24u ? letter : 23u];
-  const unsigned ones = pm & 0xFFu, zeros = pm >> 8;
-  const unsigned n0 = __popc(aminoOccSlice(lo0, hi0, ones, zeros) & sliceMask((unsigned)q0 & 255u, g));
-  const unsigned n1 = __popc(aminoOccSlice(lo1, hi1, ones, zeros) & sliceMask((unsigned)q1 & 255u, g));
-  const unsigned packed = groupSum8(n0 | (n1 << 16));
-  const unsigned long long c = sC[letter];
-  sp = c + aminoBase(hi0, letter) + (packed & 0xFFFFu);
-  ep = c + aminoBase(hi1, letter) + (packed >> 16) - 1ull;
-}
-
-__device__ __forceinline__ void aminoStep(const DevIndex &ix, const unsigned long long *sC, const AminoShared &t,
-                                          unsigned letter, unsigned long long &sp, unsigned long long &ep,
-                                          unsigned g) {
-  const unsigned long long blk0 = (sp - 1ull) >> 8, blk1 = ep >> 8;
-  const uint4 lo0 = ix.blocks[blk0 * 16ull + 2u * g];
-  const uint4 hi0 = ix.blocks[blk0 * 16ull + 2u * g + 1u];
-  uint4 otherLo = make_uint4(0u, 0u, 0u, 0u), otherHi = otherLo;
-  if (blk1 != blk0) {
-    otherLo = ix.blocks[blk1 * 16ull + 2u * g];
-    otherHi = ix.blocks[blk1 * 16ull + 2u * g + 1u];
+/* one backward step of an amino query by the G lanes of its group (G = 4 or 2); lane j holds slices j*S..j*S+S-1,
+ * two pieces each.  ref src/AwFmSearch.c:105-159, src/AwFmOccurrence.c:52-135.  The superblock bases are read
+ * beside the blocks (one address for the lanes of a group); loads and rank are arranged as in nucFastStep. */
+template <int G, bool NARROW>
+__device__ __forceinline__ void aminoStepAny(const DevIndex &ix, const unsigned long long *sC, const AminoShared &t,
+                                             const unsigned *sMask, unsigned firstSlice, unsigned letter,
+                                             typename PositionType<NARROW>::type &sp,
+                                             typename PositionType<NARROW>::type &ep) {
+  constexpr int S = (int)kSlices / G;
+  typedef typename PositionType<NARROW>::type pos_t;
+  const pos_t q0 = sp - 1, q1 = ep;
+  const unsigned long long blk0 = q0 >> kBlockShift, blk1 = q1 >> kBlockShift;
+  const bool same = blk0 == blk1;
+  const unsigned safe = letter < 24u ? letter : 23u;
+  Piece p0[S][2], p1[S][2];
+  {
+    const Piece *a0 = (const Piece *)(ix.blocks + (blk0 * kSlices + firstSlice) * 2ull);
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      p0[s][0] = a0[2 * s];
+      p0[s][1] = a0[2 * s + 1];
+    }
   }
-  const uint4 lo1 = blk1 != blk0 ? otherLo : lo0, hi1 = blk1 != blk0 ? otherHi : hi0;
-  aminoStepFromPieces(sC, t, letter, lo0, hi0, lo1, hi1, sp, ep, g);
+  const unsigned long long super0 = ix.super[(unsigned long long)(q0 >> kAminoSuperShift) * kAminoSuperStride + safe];
+#pragma unroll
+  for (int s = 0; s < S; s++) asm volatile("" : "=v"(p1[s][0]), "=v"(p1[s][1]));
+  unsigned long long super1;
+  asm volatile("" : "=v"(super1));
+  if (!same) {
+    const Piece *a1 = (const Piece *)(ix.blocks + (blk1 * kSlices + firstSlice) * 2ull);
+#pragma unroll
+    for (int s = 0; s < S; s++) {
+      p1[s][0] = a1[2 * s];
+      p1[s][1] = a1[2 * s + 1];
+    }
+    super1 = ix.super[(unsigned long long)(q1 >> kAminoSuperShift) * kAminoSuperStride + safe];
+  }
+  const unsigned pm = t.planeMask[safe];
+  const unsigned ones = pm & 0xFFu, zeros = pm >> 8;
+  const unsigned *m0 = sMask + (((unsigned)q0 & kBlockMask) * kSlices + firstSlice);
+  const unsigned *m1 = sMask + (((unsigned)q1 & kBlockMask) * kSlices + firstSlice);
+  unsigned mask0[S], mask1[S];
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    mask0[s] = m0[s];
+    mask1[s] = m1[s];
+  }
+  const pos_t cLetter = (pos_t)sC[safe];
+  const unsigned sameMask = same ? ~0u : 0u;
+  const unsigned slice = safe / 6u, sub = safe % 6u; /* where the letter's 16-bit count lives */
+  unsigned n0 = 0, n1 = 0, c0 = 0, c1 = 0;
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    const unsigned occ0 = aminoOccSlice(p0[s][0], p0[s][1], ones, zeros), occ1 = aminoOccSlice(p1[s][0], p1[s][1], ones, zeros);
+    n0 += __popc(occ0 & mask0[s]);
+    n1 += __popc(__builtin_amdgcn_bitop3_b32(occ0, occ1, sameMask, 0xE4) & mask1[s]);
+    const unsigned w0 = aminoCount16(p0[s][1], sub), w1 = aminoCount16(p1[s][1], sub);
+    c0 = (slice % S) == (unsigned)s ? w0 : c0;
+    c1 = (slice % S) == (unsigned)s ? w1 : c1;
+  }
+#pragma unroll
+  for (int s = 0; s < S; s++) asm volatile("" ::"v"(p0[s][0]), "v"(p0[s][1]), "v"(p1[s][0]), "v"(p1[s][1]));
+  asm volatile("" ::"v"(super1));
+  const pos_t base0 = (pos_t)super0 + (pos_t)groupShfl<G>(c0, slice / S);
+  pos_t base1 = (pos_t)super1 + (pos_t)groupShfl<G>(c1, slice / S);
+  base1 = same ? base0 : base1;
+  const unsigned packed = groupSum<G>(n0 | (n1 << 16));
+  sp = cLetter + base0 + (pos_t)(packed & 0xFFFFu);
+  ep = cLetter + base1 + (pos_t)(packed >> 16) - (pos_t)1;
 }
-
 
 /* ------------------------------------------------------------------ image build kernels */
 
-/* reference-layout blocks -> device layout; also finds the sentinel's BWT position */
-__global__ void relayoutNucKernel(const unsigned long long *__restrict__ ref, unsigned long long numBlocks,
-                                  unsigned long long bwtLength, uint4 *__restrict__ out,
-                                  unsigned long long *__restrict__ sentinelPos) {
+/* absolute base counts at superblock starts, from the reference-layout blocks (ref src/AwFmIndex.h:55-65: 160-B
+ * blocks = planes [3][4] + counts [8] as 64-bit words; 352-B blocks = planes [5][4] + counts [24]) */
+__global__ void gatherSuperKernel(const unsigned long long *__restrict__ ref, unsigned long long numRefBlocks, int amino,
+                                  unsigned numSuper, unsigned long long *__restrict__ super) {
+  const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned stride = amino ? kAminoSuperStride : 4u;
+  if (t >= numSuper * stride) return;
+  const unsigned sb = t / stride, a = t % stride;
+  const unsigned long long refBlk = ((unsigned long long)sb << (amino ? kAminoSuperShift : kNucSuperShift)) >> 8;
+  unsigned long long v = 0;
+  if (refBlk < numRefBlocks && a < (amino ? 21u : 4u)) v = amino ? ref[refBlk * 44ull + 20u + a] : ref[refBlk * 20ull + 12u + a];
+  super[t] = v;
+}
+
+/* reference-layout blocks -> device layout; also finds the sentinel's BWT position.  One thread per slice. */
+__global__ void relayoutNucKernel(const unsigned long long *__restrict__ ref, unsigned long long numRefBlocks,
+                                  unsigned long long bwtLength, const unsigned long long *__restrict__ super,
+                                  uint4 *__restrict__ out, unsigned long long *__restrict__ sentinelPos) {
   const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long blk = t >> 3;
-  const unsigned k = (unsigned)t & 7u;
-  if (blk >= numBlocks) return;
-  const unsigned long long *src = ref + blk * 20ull; /* 160 B = 20 words: planes [3][4], counts [8] */
-  const unsigned half = (k & 1u) * 32u;
-  const unsigned b0 = (unsigned)(src[0 + (k >> 1)] >> half);
-  const unsigned b1 = (unsigned)(src[4 + (k >> 1)] >> half);
-  const unsigned b2 = (unsigned)(src[8 + (k >> 1)] >> half);
-  const unsigned cw = (unsigned)(src[12 + (k >> 1)] >> half);
-  out[blk * 8ull + k] = make_uint4(b0, b1, b2, cw);
-  unsigned sentinelBits = b2 & ~b1 & ~b0; /* code 100b, ref src/AwFmLetter.c:44-47 */
+  const unsigned long long blk = t >> 2; /* device block */
+  const unsigned k = (unsigned)t & 3u;   /* slice = letter whose count this piece carries */
+  const unsigned long long refBlk = blk >> 1;
+  if (refBlk >= numRefBlocks) return;
+  const unsigned half = (unsigned)blk & 1u;
+  const unsigned long long *src = ref + refBlk * 20ull;
+  auto planeWord = [&](unsigned plane, unsigned w) -> unsigned { /* 32-bit word w (0..7) of a 256-bit plane */
+    return (unsigned)(src[4u * plane + (w >> 1)] >> ((w & 1u) * 32u));
+  };
+  const unsigned w = 4u * half + k;
+  const unsigned b0 = planeWord(0, w), b1 = planeWord(1, w), b2 = planeWord(2, w);
+  unsigned long long count = src[12u + k]; /* letter k before the 256-position block */
+  if (half) {
+    const PlaneSel3 sel = nucPlaneSel(k);
+    for (unsigned j = 0; j < 4; j++) {
+      Piece pc;
+      pc.x = planeWord(0, j);
+      pc.y = planeWord(1, j);
+      pc.z = planeWord(2, j);
+      pc.w = 0;
+      count += __popc(nucOccSlice(pc, sel));
+    }
+  }
+  count -= super[(blk >> (kNucSuperShift - kBlockShift)) * 4ull + k];
+  out[blk * kSlices + k] = make_uint4(b0, b1, b2, (unsigned)count);
+  const unsigned sentinelBits = b2 & ~b1 & ~b0; /* code 100b, ref src/AwFmLetter.c:44-47 */
   if (sentinelBits) {
-    const unsigned long long pos = blk * 256ull + k * 32u + (unsigned)(__ffs((int)sentinelBits) - 1);
+    const unsigned long long pos = (blk << kBlockShift) + k * 32u + (unsigned)(__ffs((int)sentinelBits) - 1);
     if (pos < bwtLength) *sentinelPos = pos;
   }
 }
 
-__global__ void relayoutAminoKernel(const unsigned long long *__restrict__ ref, unsigned long long numBlocks,
-                                    unsigned long long bwtLength, uint4 *__restrict__ out,
-                                    unsigned long long *__restrict__ sentinelPos) {
+__global__ void relayoutAminoKernel(const unsigned long long *__restrict__ ref, unsigned long long numRefBlocks,
+                                    unsigned long long bwtLength, const unsigned long long *__restrict__ super,
+                                    uint4 *__restrict__ out, unsigned long long *__restrict__ sentinelPos) {
   const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long blk = t >> 3;
-  const unsigned k = (unsigned)t & 7u;
-  if (blk >= numBlocks) return;
-  const unsigned long long *src = ref + blk * 44ull; /* 352 B = 44 words: planes [5][4], counts [24] */
-  const unsigned half = (k & 1u) * 32u;
+  const unsigned long long blk = t >> 2;
+  const unsigned k = (unsigned)t & 3u;
+  const unsigned long long refBlk = blk >> 1;
+  if (refBlk >= numRefBlocks) return;
+  const unsigned half = (unsigned)blk & 1u;
+  const unsigned long long *src = ref + refBlk * 44ull;
+  auto planeWord = [&](unsigned plane, unsigned w) -> unsigned {
+    return (unsigned)(src[4u * plane + (w >> 1)] >> ((w & 1u) * 32u));
+  };
   unsigned b[5];
-  for (int j = 0; j < 5; j++) b[j] = (unsigned)(src[4 * j + (k >> 1)] >> half);
-  unsigned c[3];
-  for (unsigned s = 0; s < 3; s++) {
-    const unsigned letter = 3u * k + s;
-    c[s] = letter < 21u ? (unsigned)src[20 + letter] : 0u;
+  for (unsigned j = 0; j < 5; j++) b[j] = planeWord(j, 4u * half + k);
+  unsigned c16[6];
+  for (unsigned s = 0; s < 6; s++) {
+    const unsigned letter = 6u * k + s;
+    unsigned long long count = 0;
+    if (letter < 21u) {
+      count = src[20u + letter];
+      if (half) {
+        const unsigned pm = kAminoTables.planeMask[letter];
+        for (unsigned j = 0; j < 4; j++) {
+          Piece lo, hi;
+          lo.x = planeWord(0, j);
+          lo.y = planeWord(1, j);
+          lo.z = planeWord(2, j);
+          lo.w = planeWord(3, j);
+          hi.x = planeWord(4, j);
+          hi.y = hi.z = hi.w = 0;
+          count += __popc(aminoOccSlice(lo, hi, pm & 0xFFu, pm >> 8));
+        }
+      }
+      count -= super[(blk >> (kAminoSuperShift - kBlockShift)) * kAminoSuperStride + letter];
+    }
+    c16[s] = (unsigned)count & 0xFFFFu;
   }
-  out[blk * 16ull + 2u * k] = make_uint4(b[0], b[1], b[2], b[3]);
-  out[blk * 16ull + 2u * k + 1u] = make_uint4(b[4], c[0], c[1], c[2]);
+  out[(blk * kSlices + k) * 2ull] = make_uint4(b[0], b[1], b[2], b[3]);
+  out[(blk * kSlices + k) * 2ull + 1ull] = make_uint4(b[4], c16[0] | (c16[1] << 16), c16[2] | (c16[3] << 16), c16[4] | (c16[5] << 16));
   unsigned sentinelBits = ~(b[0] | b[1] | b[2] | b[3] | b[4]); /* code 00000 */
   while (sentinelBits) {
     const unsigned bit = (unsigned)(__ffs((int)sentinelBits) - 1);
     sentinelBits &= sentinelBits - 1u;
-    const unsigned long long pos = blk * 256ull + k * 32u + bit;
+    const unsigned long long pos = (blk << kBlockShift) + k * 32u + bit;
     if (pos < bwtLength) *sentinelPos = pos;
   }
 }
-
 
 }  // namespace
 
@@ -341,6 +606,7 @@ struct AwFmGpuIndex {
   bool amino = false;
   DevIndex dev{};
   void *dBlocks = nullptr;
+  void *dSuper = nullptr;
   void *dSeed = nullptr;
   void *dSa = nullptr;
   void *dPrefix = nullptr;
@@ -349,7 +615,7 @@ struct AwFmGpuIndex {
   void *dDenseSa = nullptr; /* optional full suffix array, 32-bit entries */
   uint64_t denseSaBytes = 0;
   uint64_t deviceBytes = 0;
-  uint64_t numBlocks = 0;
+  uint64_t numBlocks = 0; /* device blocks (128 positions each) */
   AwFmGpuKernel kernel = AWFM_GPU_KERNEL_AUTO;
   /* testing: run the 64-bit-position kernels although bwtLength < 2^32 (awfmGpuIndexSetWide, $AWFM_GPU_FORCE_WIDE) */
   bool forceWide = false;
@@ -375,6 +641,16 @@ struct AwFmGpuIndex {
   size_t pinnedBytes[4] = {0, 0, 0, 0};
 };
 
+/* sizes of the device block array and of the superblock table of an index */
+inline uint64_t awfmDeviceBlocks(uint64_t bwtLength) { return 2 * awfmNumBlocks(bwtLength); }
+inline uint64_t awfmDeviceBlockBytes(bool amino) { return amino ? 128 : 64; }
+inline uint64_t awfmNumSuper(uint64_t bwtLength, bool amino) {
+  return ((bwtLength - 1) >> (amino ? kAminoSuperShift : kNucSuperShift)) + 1;
+}
+inline uint64_t awfmSuperBytes(uint64_t bwtLength, bool amino) {
+  return awfmNumSuper(bwtLength, amino) * (amino ? kAminoSuperStride : 4u) * 8u;
+}
+
 /* 32-bit BWT positions in the kernels: exact whenever bwtLength < 2^32 (ref src/AwFmIndex.h:88-91 is 64-bit
  * throughout; the NARROW = false instantiations are that arithmetic) */
 inline bool awfmImageNarrow(const AwFmGpuIndex *g) { return !g->forceWide && g->dev.bwtLength < (1ull << 32); }
@@ -392,13 +668,19 @@ struct DeviceGuard {
   }
 };
 
+/* blocks + superblock table of the device image from reference-layout blocks already on the device (current device,
+ * null stream).  dBlocks / dSuper are allocated by the caller: awfmDeviceBlocks x awfmDeviceBlockBytes, awfmSuperBytes.
+ * Synchronous; false with awfmGpuLastError set on failure. */
+bool awfmGpuRelayout(const void *dRefBlocks, uint64_t bwtLength, bool amino, void *dBlocks, void *dSuper,
+                     unsigned long long *sentinelPosOut);
+
 /* ordered hits-only search; 1 = searched, 0 = does not apply, <0 = -AwFmReturnCode (awfm_gpu_ordered.hip) */
 int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                          uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts);
 
 /* adopts device buffers that already hold a complete image (used by the GPU builder) */
-AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSeed, void *dSa,
-                                void *dPrefix, unsigned long long sentinelPos, uint64_t deviceBytes);
+AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSuper, void *dSeed,
+                                void *dSa, void *dPrefix, unsigned long long sentinelPos, uint64_t deviceBytes);
 void awfmGpuIndexRegister(const struct AwFmIndex *index, AwFmGpuIndex *g);
 /* awfm_gpu_build.hip: level-wise construction of the deeper seed table into a new device buffer */
 bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut);

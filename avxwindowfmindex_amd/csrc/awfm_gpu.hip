@@ -1,17 +1,11 @@
 /*
  * awfm_gpu.hip -- HIP (gfx950 / CDNA4) side of libawfmindex_amd.so.
  *
- * Device image ("re-laid-out windowed BWT"):
- *   nucleotide block = 128 B = one HBM line = 8 pieces of 16 B; piece k holds,
- *     for BWT positions 32k..32k+31 of the block, the three plane words
- *     {b0,b1,b2} and one 32-bit word of the A/C/G/T base counts
- *     (word 2a = low half, 2a+1 = high half of count[a]).  The X count is
- *     derived: positions before the block minus A+C+G+T minus the sentinel.
- *   amino block = 256 B = 8 pieces of 32 B; piece k holds the five plane words
- *     and three 32-bit base counts (slot 3k+s = letter 3k+s, 21 letters incl. Z);
- *     needs bwtLength < 2^32.
- *   The reference layout (ref src/AwFmIndex.h:55-65: 160 / 352 B blocks) always
- *   straddles two 128-B lines per rank; here a rank reads exactly 1 (2) lines.
+ * Device image ("re-laid-out windowed BWT", awfm_device.h): blocks of 128 BWT positions -- nucleotide 64 B (three
+ * plane words + one 32-bit base count per 32-position slice), amino 128 B (five plane words + six 16-bit base counts
+ * per slice) -- with 64-bit base counts kept per superblock (2^32 / 2^16 positions).  The reference layout
+ * (ref src/AwFmIndex.h:55-65: 160 / 352 B blocks of 256 positions) straddles two (three to four) 128-B lines per
+ * rank; here a rank reads one 64-B granule (one line).
  *
  * Kernels: searchKernel (awfm_search_kernel.h: seed lookup + backward search, G lanes per query),
  * walkKernel/finishKernel (awfm_locate_kernel.h: LF walk to a sampled position, sampled-SA read), and here the
@@ -175,7 +169,7 @@ std::vector<ImageEntry> imageTable;
  * (blocksPerCU from the occupancy query for that kernel); a larger grid would run as a second,
  * under-filled round.  AWFM_GPU_BLOCKS_PER_CU overrides (measurement knob). */
 template <class Kernel>
-unsigned gridFor(uint64_t groups, const AwFmGpuIndex *g, Kernel kernel, unsigned groupsPerBlock = kGroupsPerBlock) {
+unsigned gridFor(uint64_t groups, const AwFmGpuIndex *g, Kernel kernel, unsigned groupsPerBlock) {
   int perCU = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kThreads, 0) != hipSuccess || perCU < 1) perCU = 4;
   if (perCU > 8) perCU = 8;
@@ -207,6 +201,8 @@ namespace {
 void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned long long sentinelPos) {
   DevIndex &d = g->dev;
   d.blocks = (const uint4 *)g->dBlocks;
+  d.super = (const unsigned long long *)g->dSuper;
+  d.numSuper = (unsigned)awfmNumSuper(index->bwtLength, index->config.alphabetType == AwFmAlphabetAmino);
   d.seed = (const ulonglong2 *)g->dSeed;
   d.sa = (const unsigned long long *)g->dSa;
   d.bwtLength = index->bwtLength;
@@ -229,24 +225,29 @@ void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned long 
 namespace {
 enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions,
                                  hipStream_t s);
-/* lanes that cooperate on one query: image setting, else $AWFM_GPU_KERNEL (g8|g4|g2|g1), else the default */
+/* lanes that cooperate on one query: image setting, else $AWFM_GPU_KERNEL (g4|g2|g1), else the default.  A device
+ * block has 4 slices, so 4 lanes is the widest group (GROUP8 of the enum maps to it); amino slices are 32 B, 2 lanes
+ * per query already hold 64 registers of block data */
 int lanesPerQuery(const AwFmGpuIndex *g) {
-  int lanes = 8;
+  int lanes = 4;
   switch (g->kernel) {
-    case AWFM_GPU_KERNEL_GROUP8: lanes = 8; break;
+    case AWFM_GPU_KERNEL_GROUP8:
     case AWFM_GPU_KERNEL_GROUP4: lanes = 4; break;
     case AWFM_GPU_KERNEL_GROUP2: lanes = 2; break;
     case AWFM_GPU_KERNEL_GROUP1: lanes = 1; break;
     default:
-      lanes = 4; /* measured on MI355X, GRCh38-sized index, 100 M random 21-mers: g8 18.6 ms, g4 14.2, g2 14.5, g1 16.5 */
+      /* measured on MI355X (scripts/ab_layout.sh): 10^8 random 21-mers against the GRCh38-sized index, general
+       * kernel: g4 13.2-13.7 ms, g2 13.0-13.4, g1 13.9 (within the box-to-box spread: the kernel runs at the rate the
+       * chip delivers random granules; g4 keeps 8 waves per SIMD without spilling); 5*10^7 amino 10-mers: g4 3.91 ms,
+       * g2 3.72 */
+      lanes = g->amino ? 2 : 4;
       if (const char *env = getenv("AWFM_GPU_KERNEL")) { /* measurement knob */
-        if (!strcmp(env, "g8")) lanes = 8;
-        else if (!strcmp(env, "g4")) lanes = 4;
+        if (!strcmp(env, "g8") || !strcmp(env, "g4")) lanes = 4;
         else if (!strcmp(env, "g2")) lanes = 2;
         else if (!strcmp(env, "g1")) lanes = 1;
       }
   }
-  if (g->amino && lanes < 4) lanes = 4; /* amino pieces are 32 B: 4 lanes already hold 64 registers of block data */
+  if (g->amino && lanes < 2) lanes = 2;
   return lanes;
 }
 
@@ -265,12 +266,10 @@ template <bool AMINO, int G, bool CSR, bool TALLY>
 void launchSearchKernel(const AwFmGpuIndex *g, const DevIndex &dev, hipStream_t s, const uint8_t *dChars,
                         const unsigned long long *off, uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng,
                         uint32_t *dCounts, unsigned long long *dTally) {
-  /* amino images always have bwtLength < 2^32 (32-bit base counts) */
-  if (AMINO || awfmImageNarrow(g))
+  if (awfmImageNarrow(g))
     launchSearchKernelN<AMINO, G, CSR, TALLY, true>(g, dev, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);
   else
-    launchSearchKernelN<AMINO, G, CSR, TALLY, AMINO ? true : false>(g, dev, s, dChars, off, fixedLength, nq, rng,
-                                                                    dCounts, dTally);
+    launchSearchKernelN<AMINO, G, CSR, TALLY, false>(g, dev, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);
 }
 
 template <bool TALLY>
@@ -283,11 +282,10 @@ void launchSearch(const AwFmGpuIndex *g, const DevIndex &dev, int lanes, hipStre
     else launchSearchKernel<AM, GG, false, TALLY>(g, dev, s, dChars, off, fixedLength, nq, rng, dCounts, dTally);     \
   } while (0)
   if (g->amino) {
-    if (lanes == 8) AWFM_GO(true, 8);
-    else AWFM_GO(true, 4);
+    if (lanes == 4) AWFM_GO(true, 4);
+    else AWFM_GO(true, 2);
   } else {
-    if (lanes == 8) AWFM_GO(false, 8);
-    else if (lanes == 4) AWFM_GO(false, 4);
+    if (lanes == 4) AWFM_GO(false, 4);
     else if (lanes == 2) AWFM_GO(false, 2);
     else AWFM_GO(false, 1);
   }
@@ -299,16 +297,17 @@ extern "C" {
 static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g);
 }
 
-AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSeed, void *dSa,
-                                void *dPrefix, unsigned long long sentinelPos, uint64_t deviceBytes) {
+AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSuper, void *dSeed,
+                                void *dSa, void *dPrefix, unsigned long long sentinelPos, uint64_t deviceBytes) {
   AwFmGpuIndex *g = new AwFmGpuIndex();
   g->device = device;
   g->amino = index->config.alphabetType == AwFmAlphabetAmino;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     g->numCUs = prop.multiProcessorCount;
-  g->numBlocks = awfmNumBlocks(index->bwtLength);
+  g->numBlocks = awfmDeviceBlocks(index->bwtLength);
   g->dBlocks = dBlocks;
+  g->dSuper = dSuper;
   g->dSeed = dSeed;
   g->dSa = dSa;
   g->dPrefix = dPrefix;
@@ -322,6 +321,38 @@ AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void 
 void awfmGpuIndexRegister(const struct AwFmIndex *index, AwFmGpuIndex *g) {
   std::lock_guard<std::mutex> lock(tableMutex);
   imageTable.push_back({index, g->device, 0, g});
+}
+
+bool awfmGpuRelayout(const void *dRefBlocks, uint64_t bwtLength, bool amino, void *dBlocks, void *dSuper,
+                     unsigned long long *sentinelPosOut) {
+  const uint64_t numRef = awfmNumBlocks(bwtLength);
+  const unsigned numSuper = (unsigned)awfmNumSuper(bwtLength, amino);
+  unsigned long long *dSentinel = nullptr;
+  hipError_t e = hipMalloc((void **)&dSentinel, 8);
+  if (e == hipSuccess) e = hipMemset(dSentinel, 0, 8);
+  if (e == hipSuccess) {
+    const unsigned words = numSuper * (amino ? kAminoSuperStride : 4u);
+    hipLaunchKernelGGL(gatherSuperKernel, dim3((words + 255) / 256), dim3(256), 0, 0, (const unsigned long long *)dRefBlocks,
+                       (unsigned long long)numRef, amino ? 1 : 0, numSuper, (unsigned long long *)dSuper);
+    const uint64_t threads = numRef * 2 * kSlices;
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    if (amino)
+      hipLaunchKernelGGL(relayoutAminoKernel, dim3(grid), dim3(256), 0, 0, (const unsigned long long *)dRefBlocks,
+                         (unsigned long long)numRef, (unsigned long long)bwtLength, (const unsigned long long *)dSuper,
+                         (uint4 *)dBlocks, dSentinel);
+    else
+      hipLaunchKernelGGL(relayoutNucKernel, dim3(grid), dim3(256), 0, 0, (const unsigned long long *)dRefBlocks,
+                         (unsigned long long)numRef, (unsigned long long)bwtLength, (const unsigned long long *)dSuper,
+                         (uint4 *)dBlocks, dSentinel);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(sentinelPosOut, dSentinel, 8, hipMemcpyDeviceToHost);
+  if (dSentinel) (void)hipFree(dSentinel);
+  if (e != hipSuccess) {
+    setError("awfmGpuRelayout", e);
+    return false;
+  }
+  return true;
 }
 
 extern "C" {
@@ -358,8 +389,8 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
     return AwFmGeneralFailure;
   }
   const bool amino = index->config.alphabetType == AwFmAlphabetAmino;
-  if (amino && index->bwtLength >= (1ull << 32)) {
-    setError("awfmGpuIndexCreate: amino device layout holds 32-bit base counts; bwtLength must be < 2^32");
+  if (!amino && awfmNumSuper(index->bwtLength, false) > kMaxNucSuper) {
+    setError("awfmGpuIndexCreate: nucleotide device images hold at most 2^38 positions");
     return AwFmUnsupportedVersionError;
   }
   if (index->config.suffixArrayCompressionRatio == 0) {
@@ -373,10 +404,10 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     g->numCUs = prop.multiProcessorCount;
-  const uint64_t numBlocks = awfmNumBlocks(index->bwtLength);
-  g->numBlocks = numBlocks;
-  const size_t refBytes = numBlocks * awfmBlockBytes(index->config.alphabetType);
-  const size_t devBlockBytes = numBlocks * (amino ? 256ull : 128ull);
+  g->numBlocks = awfmDeviceBlocks(index->bwtLength);
+  const size_t refBytes = awfmNumBlocks(index->bwtLength) * awfmBlockBytes(index->config.alphabetType);
+  const size_t devBlockBytes = g->numBlocks * awfmDeviceBlockBytes(amino);
+  const size_t superBytes = awfmSuperBytes(index->bwtLength, amino);
   const uint64_t seedLen = awfmKmerTableLength(index->config.alphabetType, index->config.kmerLengthInSeedTable);
   const size_t seedBytes = seedLen * sizeof(struct AwFmSearchRange);
   const size_t saBytes = index->suffixArray.compressedByteLength;
@@ -387,46 +418,31 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
     return rc;
   };
   void *dRef = nullptr;
-  unsigned long long *dSentinel = nullptr;
 #define TRY_OR_FAIL(call, rc)                 \
   do {                                        \
     hipError_t e__ = (call);                  \
     if (e__ != hipSuccess) {                  \
       setError(#call, e__);                   \
       if (dRef) (void)hipFree(dRef);          \
-      if (dSentinel) (void)hipFree(dSentinel);\
       return fail(rc);                        \
     }                                         \
   } while (0)
 
   TRY_OR_FAIL(hipMalloc(&g->dBlocks, devBlockBytes), AwFmAllocationFailure);
+  TRY_OR_FAIL(hipMalloc(&g->dSuper, superBytes), AwFmAllocationFailure);
   TRY_OR_FAIL(hipMalloc(&g->dSeed, seedBytes ? seedBytes : 16), AwFmAllocationFailure);
   TRY_OR_FAIL(hipMalloc(&g->dSa, saAlloc), AwFmAllocationFailure);
   TRY_OR_FAIL(hipMalloc(&dRef, refBytes), AwFmAllocationFailure);
-  TRY_OR_FAIL(hipMalloc((void **)&dSentinel, 8), AwFmAllocationFailure);
-  g->deviceBytes = devBlockBytes + seedBytes + saAlloc;
+  g->deviceBytes = devBlockBytes + superBytes + seedBytes + saAlloc;
 
   TRY_OR_FAIL(hipMemcpy(dRef, index->bwtBlockList.asNucleotide, refBytes, hipMemcpyHostToDevice), AwFmGeneralFailure);
-  TRY_OR_FAIL(hipMemset(dSentinel, 0, 8), AwFmGeneralFailure);
-  {
-    const uint64_t threads = numBlocks * 8;
-    const unsigned grid = (unsigned)((threads + 255) / 256);
-    if (amino)
-      hipLaunchKernelGGL(relayoutAminoKernel, dim3(grid), dim3(256), 0, 0, (const unsigned long long *)dRef,
-                         (unsigned long long)numBlocks, (unsigned long long)index->bwtLength, (uint4 *)g->dBlocks,
-                         dSentinel);
-    else
-      hipLaunchKernelGGL(relayoutNucKernel, dim3(grid), dim3(256), 0, 0, (const unsigned long long *)dRef,
-                         (unsigned long long)numBlocks, (unsigned long long)index->bwtLength, (uint4 *)g->dBlocks,
-                         dSentinel);
-    TRY_OR_FAIL(hipGetLastError(), AwFmGeneralFailure);
-  }
   unsigned long long sentinelPos = 0;
-  TRY_OR_FAIL(hipMemcpy(&sentinelPos, dSentinel, 8, hipMemcpyDeviceToHost), AwFmGeneralFailure);
+  if (!awfmGpuRelayout(dRef, index->bwtLength, amino, g->dBlocks, g->dSuper, &sentinelPos)) {
+    (void)hipFree(dRef);
+    return fail(AwFmGeneralFailure);
+  }
   (void)hipFree(dRef);
   dRef = nullptr;
-  (void)hipFree(dSentinel);
-  dSentinel = nullptr;
 
   TRY_OR_FAIL(hipMemcpy(g->dSeed, index->kmerSeedTable, seedBytes, hipMemcpyHostToDevice), AwFmGeneralFailure);
   {
@@ -465,6 +481,7 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
     DeviceGuard guard(g->device);
     if (!g->shares) { /* a lane owns only its staging */
       if (g->dBlocks) (void)hipFree(g->dBlocks);
+      if (g->dSuper) (void)hipFree(g->dSuper);
       if (g->dSeed) (void)hipFree(g->dSeed);
       if (g->dSa) (void)hipFree(g->dSa);
       if (g->dPrefix) (void)hipFree(g->dPrefix);
@@ -522,6 +539,7 @@ static AwFmGpuIndex *makeLane(AwFmGpuIndex *primary) {
   g->amino = primary->amino;
   g->dev = primary->dev;
   g->dBlocks = primary->dBlocks;
+  g->dSuper = primary->dSuper;
   g->dSeed = primary->dSeed;
   g->dSa = primary->dSa;
   g->dPrefix = primary->dPrefix;
@@ -860,7 +878,7 @@ enum AwFmReturnCode awfmGpuHitOffsetsFromCounts(AwFmGpuIndex *g, const uint32_t 
     setError("awfmGpuHitOffsetsFromCounts: null argument");
     return AwFmNullPtrError;
   }
-  if (!g->amino && g->dev.bwtLength >= (1ull << 32)) {
+  if (g->dev.bwtLength >= (1ull << 32)) {
     setError("awfmGpuHitOffsetsFromCounts: 32-bit counts are exact only for images below 2^32 positions; use awfmGpuHitOffsets");
     return AwFmUnsupportedVersionError;
   }
@@ -912,14 +930,17 @@ namespace {
 enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions,
                                  hipStream_t s) {
   {
-    int lanes = lanesPerQuery(g);
-    if (const char *env = getenv("AWFM_GPU_LOCATE_KERNEL")) { /* measurement knob: g8 | g4 | g2 | g1 */
-      if (!strcmp(env, "g8")) lanes = 8;
+    /* the walk runs at the rate the chip delivers random granules whatever the group width (17.2 / 17.5 / 18.3 ms
+     * for g4 / g2 / g1 on 1.0007*10^8 hits); four lanes keep the fewest instructions per step */
+    int lanes = g->kernel == AWFM_GPU_KERNEL_AUTO ? 4 : lanesPerQuery(g);
+    if (const char *env = getenv("AWFM_GPU_LOCATE_KERNEL")) { /* measurement knob: g4 | g2 | g1 */
+      if (!strcmp(env, "g8")) lanes = 4;
       else if (!strcmp(env, "g4")) lanes = 4;
       else if (!strcmp(env, "g2")) lanes = 2;
       else if (!strcmp(env, "g1")) lanes = 1;
     }
-    if (g->amino && lanes < 4) lanes = 4;
+    if (lanes > 4) lanes = 4;
+    if (g->amino && lanes < 2) lanes = 2;
     unsigned long long *pos = dPositions;
     const unsigned long long th = totalHits;
     if (g->dev.bwtLength / g->dev.saRatio >= (1ull << 40)) {
@@ -927,23 +948,22 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
       return AwFmUnsupportedVersionError;
     }
     const bool pow2 = g->dev.saShift != 0xFFFFFFFFu;
-    const bool narrow = g->amino || awfmImageNarrow(g);
+    const bool narrow = awfmImageNarrow(g);
 #define AWFM_LOC3(AM, GG, P2, NR)                                                                                  \
   hipLaunchKernelGGL((walkKernel<AM, GG, P2, NR>), dim3(gridFor(th, g, walkKernel<AM, GG, P2, NR>, kThreads / GG)), \
                      dim3(kThreads), 0, s, g->dev, th, pos)
 #define AWFM_LOC(AM, GG)                                      \
   do {                                                        \
     if (pow2 && narrow) AWFM_LOC3(AM, GG, true, true);        \
-    else if (pow2) AWFM_LOC3(AM, GG, true, AM);               \
+    else if (pow2) AWFM_LOC3(AM, GG, true, false);            \
     else if (narrow) AWFM_LOC3(AM, GG, false, true);          \
-    else AWFM_LOC3(AM, GG, false, AM);                        \
+    else AWFM_LOC3(AM, GG, false, false);                     \
   } while (0)
     if (g->amino) {
-      if (lanes == 8) AWFM_LOC(true, 8);
-      else AWFM_LOC(true, 4);
+      if (lanes == 4) AWFM_LOC(true, 4);
+      else AWFM_LOC(true, 2);
     } else {
-      if (lanes == 8) AWFM_LOC(false, 8);
-      else if (lanes == 4) AWFM_LOC(false, 4);
+      if (lanes == 4) AWFM_LOC(false, 4);
       else if (lanes == 2) AWFM_LOC(false, 2);
       else AWFM_LOC(false, 1);
     }

@@ -30,6 +30,9 @@
 
 namespace {
 
+constexpr unsigned kSeedGroupsPerBlock = kThreads / 4; /* seedLevelKernel: 4 lanes per table entry */
+
+
 #define BUILD_TRY(call)                         \
   do {                                          \
     hipError_t err__ = (call);                  \
@@ -280,18 +283,19 @@ template <bool AMINO, bool STOP_AT_INVALID = false>
 __global__ void __launch_bounds__(kThreads)
     seedLevelKernel(const DevIndex ix, const ulonglong2 *__restrict__ parentLevel, u64 parentLen, u64 outLen,
                     ulonglong2 *__restrict__ out) {
+  constexpr int G = 4; /* one slice of a block per lane */
   __shared__ u64 sC[24];
   __shared__ AminoShared sAmino;
+  __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
+  __shared__ u64 sSuper[AMINO ? 1 : kMaxNucSuper * 4];
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
-  if (AMINO && threadIdx.x < 32) {
-    sAmino.letterOfAscii[threadIdx.x] = kAminoTables.letterOfAscii[threadIdx.x];
-    sAmino.letterOfCode[threadIdx.x] = kAminoTables.letterOfCode[threadIdx.x];
-    if (threadIdx.x < 24) sAmino.planeMask[threadIdx.x] = kAminoTables.planeMask[threadIdx.x];
-  }
+  if (AMINO) aminoStageTables(sAmino);
+  stageMaskTable(sMask);
+  if (!AMINO) nucStageSuper<false>(ix, sSuper);
   __syncthreads();
-  const unsigned g = threadIdx.x & 7u;
-  const u64 numGroups = (u64)gridDim.x * kGroupsPerBlock;
-  for (u64 e = ((u64)blockIdx.x * kThreads + threadIdx.x) >> 3; e < outLen; e += numGroups) {
+  const unsigned g = threadIdx.x % G;
+  const u64 numGroups = (u64)gridDim.x * kSeedGroupsPerBlock;
+  for (u64 e = ((u64)blockIdx.x * kThreads + threadIdx.x) / G; e < outLen; e += numGroups) {
     const unsigned a = (unsigned)(e / parentLen);
     const ulonglong2 r = parentLevel[e % parentLen];
     u64 sp = r.x, ep = r.y;
@@ -299,9 +303,9 @@ __global__ void __launch_bounds__(kThreads)
      * (ref src/AwFmParallelSearch.c:293-294), so an invalid parent is inherited unchanged */
     if (!STOP_AT_INVALID || sp <= ep) {
       if (AMINO)
-        aminoStep(ix, sC, sAmino, a, sp, ep, g);
+        aminoStepAny<G, false>(ix, sC, sAmino, sMask, g, a, sp, ep);
       else
-        nucStep(ix, sC, a, sp, ep, g);
+        nucStepAny<G, false>(ix, sC, sSuper, g, a, sp, ep);
     }
     if (g == 0) out[e] = make_ulonglong2(sp, ep);
   }
@@ -528,7 +532,7 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
   for (unsigned L = K; L < deepK; L++) {
     const u64 outLen = len * 4;
     if (!nxt.alloc(outLen * 16)) return false;
-    const u64 blocks = (outLen + kGroupsPerBlock - 1) / kGroupsPerBlock;
+    const u64 blocks = (outLen + kSeedGroupsPerBlock - 1) / kSeedGroupsPerBlock;
     const unsigned grid = (unsigned)(blocks < 2048 * 4 ? blocks : 2048 * 4);
     hipLaunchKernelGGL((seedLevelKernel<false, true>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen,
                        nxt.as<ulonglong2>());
@@ -682,21 +686,13 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
   ix->prefixSums[0] = 1;
   for (unsigned i = 1; i < card + 2; i++) ix->prefixSums[i] = ix->prefixSums[i - 1] + totals[i - 1];
 
-  /* 4. device image: blocks, prefix sums, seed table, packed SA */
-  DeviceBuffer dBlocks, dPrefix, dSeedA, dSeedB, dPacked;
-  STEP(dBlocks.alloc(numBlocks * (amino ? 256ull : 128ull)));
+  /* 4. device image: blocks + superblock bases, prefix sums, seed table, packed SA */
+  DeviceBuffer dBlocks, dSuper, dPrefix, dSeedA, dSeedB, dPacked;
+  STEP(dBlocks.alloc(awfmDeviceBlocks(n) * awfmDeviceBlockBytes(amino)));
+  STEP(dSuper.alloc(awfmSuperBytes(n, amino)));
   {
-    DeviceBuffer dIgnored;
-    STEP(dIgnored.alloc(8));
-    const u64 threads = numBlocks * 8;
-    if (amino)
-      hipLaunchKernelGGL(relayoutAminoKernel, dim3(gridOf(threads)), dim3(256), 0, 0, dRef.as<u64>(), numBlocks, n,
-                         dBlocks.as<uint4>(), dIgnored.as<u64>());
-    else
-      hipLaunchKernelGGL(relayoutNucKernel, dim3(gridOf(threads)), dim3(256), 0, 0, dRef.as<u64>(), numBlocks, n,
-                         dBlocks.as<uint4>(), dIgnored.as<u64>());
-    STEP_HIP(hipGetLastError());
-    STEP_HIP(hipDeviceSynchronize());
+    unsigned long long again = 0; /* the sentinel's position is known from the BWT pass already */
+    STEP(awfmGpuRelayout(dRef.p, n, amino, dBlocks.p, dSuper.p, &again));
   }
   {
     u64 prefix[24] = {0};
@@ -706,6 +702,8 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
   }
   DevIndex dev{};
   dev.blocks = dBlocks.as<uint4>();
+  dev.super = dSuper.as<u64>();
+  dev.numSuper = (unsigned)awfmNumSuper(n, amino);
   dev.prefixSums = dPrefix.as<u64>();
   dev.bwtLength = n;
   dev.sentinelPos = sentinelPos;
@@ -727,7 +725,7 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
     u64 len = card;
     for (unsigned L = 1; L < K; L++) {
       const u64 outLen = len * card;
-      const u64 blocks = (outLen + kGroupsPerBlock - 1) / kGroupsPerBlock;
+      const u64 blocks = (outLen + kSeedGroupsPerBlock - 1) / kSeedGroupsPerBlock;
       const unsigned grid = (unsigned)(blocks < 2048 * 4 ? blocks : 2048 * 4);
       if (amino)
         hipLaunchKernelGGL(seedLevelKernel<true>, dim3(grid), dim3(kThreads), 0, 0, dev, cur->as<ulonglong2>(), len, outLen,
@@ -772,9 +770,9 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
   ix->sequenceFileOffset = awfmSequenceFileOffset(ix);
 
   /* keep the device image for awFmParallelSearch* */
-  const uint64_t deviceBytes = numBlocks * (amino ? 256ull : 128ull) + seedLen * 16 + saWords * 8;
-  AwFmGpuIndex *g = awfmGpuIndexAdopt(ix, device, dBlocks.release(), dSeedA.release(), dPacked.release(), dPrefix.release(),
-                                      sentinelPos, deviceBytes);
+  const uint64_t deviceBytes = awfmDeviceBlocks(n) * awfmDeviceBlockBytes(amino) + awfmSuperBytes(n, amino) + seedLen * 16 + saWords * 8;
+  AwFmGpuIndex *g = awfmGpuIndexAdopt(ix, device, dBlocks.release(), dSuper.release(), dSeedA.release(), dPacked.release(),
+                                      dPrefix.release(), sentinelPos, deviceBytes);
   awfmGpuIndexRegister(ix, g);
 
   enum AwFmReturnCode rc = AwFmFileWriteOkay;

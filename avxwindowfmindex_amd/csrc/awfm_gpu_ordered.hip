@@ -84,11 +84,11 @@ enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t 
                                   const void *recs, const unsigned short *keys, const unsigned *generalCount,
                                   ulonglong2 *rng, uint32_t *dCounts) {
   {
-    const char *lanes = getenv("AWFM_GPU_ORDERED_LANES"); /* measurement knob: 2 | 4 | 8 lanes per query (default 4) */
+    const char *lanes = getenv("AWFM_GPU_ORDERED_LANES"); /* measurement knob: 1 | 2 | 4 lanes per query (default 4) */
     const int G = lanes ? atoi(lanes) : 4;
     enum AwFmReturnCode rc;
     if (G == 2) rc = launchOrderedKernel<2, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
-    else if (G == 8) rc = launchOrderedKernel<8, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
+    else if (G == 1) rc = launchOrderedKernel<1, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
     else rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
     if (rc != AwFmSuccess) return rc;
   }

@@ -1,11 +1,11 @@
 /*
  * awfm_locate_kernel.h -- suffix-array backtrace: BWT position of a hit -> text position, two kernels.
  *
- * walkKernel: one hit at a time per group of G lanes (same piece ownership as the search kernel: lane j holds
- *   pieces j*S..j*S+S-1 of a block, S = 8/G); a group takes its hits in batches of 4*G consecutive entries,
+ * walkKernel: one hit at a time per group of G lanes (same slice ownership as the search kernel: lane j holds
+ *   slices j*S..j*S+S-1 of a block, S = 4/G); a group takes its hits in batches of 4*G consecutive entries,
  *   read and written as whole lines.  Per LF step the group reads the block of the current BWT
- *   position as whole 128-B lines, extracts the letter stored there (the owning lane builds the code from
- *   its plane words, the group gets it by ds_bpermute), ranks that letter up to the position and continues
+ *   position (one 64-B granule, amino one 128-B line), extracts the letter stored there (the owning lane builds
+ *   the code from its plane words, the group gets it by ds_bpermute), ranks that letter up to the position and continues
  *   at C[a] + Occ(a,p) - 1 until the position is sampled.  Persistent with refill: a group that reaches a
  *   sampled position stores {sample index, steps walked} in place and continues with its next hit in the
  *   same iteration, so every iteration is exactly one dependent block read per group and no lane waits
@@ -54,21 +54,19 @@ __device__ __forceinline__ unsigned long long finishPosition(const DevIndex &ix,
 template <bool AMINO, int G, bool POW2, bool NARROW>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
     walkKernel(const DevIndex ix, unsigned long long totalHits, unsigned long long *__restrict__ positions) {
-  constexpr int S = 8 / G;
+  constexpr int S = (int)kSlices / G;
   constexpr int V = AMINO ? 2 : 1;
   constexpr int kGroups = kThreads / G;
   typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
   __shared__ AminoShared sAmino;
+  __shared__ unsigned long long sSuper[!AMINO && !NARROW ? kMaxNucSuper * 4 : 1];
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
-  if (AMINO && threadIdx.x < 32) {
-    sAmino.letterOfAscii[threadIdx.x] = kAminoTables.letterOfAscii[threadIdx.x];
-    sAmino.letterOfCode[threadIdx.x] = kAminoTables.letterOfCode[threadIdx.x];
-    if (threadIdx.x < 24) sAmino.planeMask[threadIdx.x] = kAminoTables.planeMask[threadIdx.x];
-  }
+  if (AMINO) aminoStageTables(sAmino);
+  if (!AMINO) nucStageSuper<NARROW>(ix, sSuper);
   __syncthreads();
   const unsigned gl = threadIdx.x % G;
-  const unsigned firstPiece = gl * S;
+  const unsigned firstSlice = gl * S;
   const unsigned long long numGroups = (unsigned long long)gridDim.x * kGroups;
   const pos_t ratio = (pos_t)ix.saRatio;
   const unsigned long long maxSteps = (1ull << kWalkStepBits) - 1ull;
@@ -162,75 +160,62 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
       sampled = POW2 ? (p & (ratio - 1)) == 0 : (p % ratio) == 0;
     }
     const bool walk = alive && !sampled; /* a refilled hit that is sampled right away is handed over next iteration */
-    const unsigned long long blk = (unsigned long long)(p >> 8);
-    const unsigned local = (unsigned)p & 255u;
-    uint4 pc[S][V];
+    const unsigned long long blk = (unsigned long long)(p >> kBlockShift);
+    const unsigned local = (unsigned)p & kBlockMask;
+    Piece pc[S][V];
 #pragma unroll
     for (int s = 0; s < S; s++)
 #pragma unroll
-      for (int v = 0; v < V; v++) pc[s][v] = make_uint4(0u, 0u, 0u, 0u);
+      for (int v = 0; v < V; v++) pc[s][v] = (Piece)(0u);
     if (walk) {
+      const Piece *at = (const Piece *)(ix.blocks + (blk * kSlices + firstSlice) * V);
 #pragma unroll
       for (int s = 0; s < S; s++)
 #pragma unroll
-        for (int v = 0; v < V; v++) pc[s][v] = ix.blocks[(blk * 8ull + firstPiece + s) * V + v];
+        for (int v = 0; v < V; v++) pc[s][v] = at[s * V + v];
     }
     __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): the single drain of the iteration */
     if (walk) {
-      const unsigned bit = local & 31u, ownerPiece = local >> 5;
-      /* letter stored at p: code bits from the owning piece */
+      const unsigned bit = local & 31u, ownerSlice = local >> 5;
+      /* letter stored at p: code bits from the owning slice */
       unsigned myCode = 0;
 #pragma unroll
       for (int s = 0; s < S; s++) {
         unsigned code = ((pc[s][0].x >> bit) & 1u) | (((pc[s][0].y >> bit) & 1u) << 1) | (((pc[s][0].z >> bit) & 1u) << 2);
         if (AMINO) code |= (((pc[s][0].w >> bit) & 1u) << 3) | (((pc[s][V - 1].x >> bit) & 1u) << 4);
-        myCode = (ownerPiece % S) == (unsigned)s ? code : myCode;
+        myCode = (ownerSlice % S) == (unsigned)s ? code : myCode;
       }
-      const unsigned code = groupShfl<G>(myCode, ownerPiece / S);
+      const unsigned code = groupShfl<G>(myCode, ownerSlice / S);
       pos_t next;
       if (AMINO) {
         const unsigned letter = sAmino.letterOfCode[code];
         const unsigned safe = letter < 21u ? letter : 0u;
+        /* the superblock base of the letter just read: a second, dependent read, but into a table that stays in
+         * the L2 (24 words per 2^16 positions) */
+        const unsigned long long super = ix.super[(unsigned long long)(p >> kAminoSuperShift) * kAminoSuperStride + safe];
         const unsigned pm = sAmino.planeMask[safe];
         const unsigned ones = pm & 0xFFu, zeros = pm >> 8;
         unsigned n = 0, mine = 0;
-        const unsigned piece = safe / 3u, slot = safe % 3u;
+        const unsigned slice = safe / 6u, sub = safe % 6u;
 #pragma unroll
         for (int s = 0; s < S; s++) {
-          n += __popc(aminoOccSlice(pc[s][0], pc[s][V - 1], ones, zeros) & sliceMask(local, firstPiece + s));
-          mine = (piece % S) == (unsigned)s ? aminoCountWord(pc[s][V - 1], slot) : mine;
+          n += __popc(aminoOccSlice(pc[s][0], pc[s][V - 1], ones, zeros) & sliceMask(local, firstSlice + s));
+          mine = (slice % S) == (unsigned)s ? aminoCount16(pc[s][V - 1], sub) : mine;
         }
-        next = (pos_t)sC[safe] + (pos_t)groupShfl<G>(mine, piece / S) + (pos_t)groupSum<G>(n) - (pos_t)1;
+        next = (pos_t)sC[safe] + (pos_t)super + (pos_t)groupShfl<G>(mine, slice / S) + (pos_t)groupSum<G>(n) - (pos_t)1;
         if (letter == 21u) next = 0; /* sentinel: ref src/AwFmSearch.c:414-416 */
       } else {
         const unsigned letter = (0x00152435u >> (4u * code)) & 7u; /* code -> index {5,3,4,2,5,1,0,0}, ref src/AwFmLetter.c:49-53 */
         const unsigned safe = letter < 5u ? letter : 0u;
         const PlaneSel3 sel = nucPlaneSel(safe);
         unsigned n = 0;
+        Piece mine[S];
 #pragma unroll
-        for (int s = 0; s < S; s++) n += __popc(nucOccSlice(pc[s][0], sel) & sliceMask(local, firstPiece + s));
-        pos_t base;
-        if (safe < 4u) {
-          const unsigned kLo = 2u * safe, kHi = kLo + 1u;
-          unsigned lo = 0, hi = 0;
-#pragma unroll
-          for (int s = 0; s < S; s++) {
-            lo = (kLo % S) == (unsigned)s ? pc[s][0].w : lo;
-            hi = (kHi % S) == (unsigned)s ? pc[s][0].w : hi;
-          }
-          if (NARROW)
-            base = (pos_t)groupShfl<G>(lo, kLo / S);
-          else
-            base = (pos_t)(((unsigned long long)groupShfl<G>(hi, kHi / S) << 32) | groupShfl<G>(lo, kLo / S));
-        } else {
-          unsigned long long part = 0;
-#pragma unroll
-          for (int s = 0; s < S; s++)
-            part += ((firstPiece + s) & 1u) ? ((unsigned long long)pc[s][0].w << 32) : (unsigned long long)pc[s][0].w;
-          const unsigned long long before = blk * 256ull;
-          base = (pos_t)(before - groupSum64<G>(part) - (ix.sentinelPos < before ? 1ull : 0ull));
+        for (int s = 0; s < S; s++) {
+          mine[s] = pc[s][0];
+          n += __popc(nucOccSlice(pc[s][0], sel) & sliceMask(local, firstSlice + s));
         }
-        next = (pos_t)sC[safe] + base + (pos_t)groupSum<G>(n) - (pos_t)1;
+        next = (pos_t)sC[safe] + nucBaseAny<G, NARROW>(ix, sSuper, mine, safe, blk) + (pos_t)groupSum<G>(n) - (pos_t)1;
         if (letter == 5u) next = 0; /* sentinel: ref src/AwFmSearch.c:384-386 */
       }
       p = next;

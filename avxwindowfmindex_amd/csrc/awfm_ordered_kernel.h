@@ -189,18 +189,20 @@ __global__ void __launch_bounds__(256)
  * original query number.
  */
 template <int G, bool NARROW, bool COMPACT, bool VARLEN>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 4 ? 8 : 2, 8)))
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? 8 : 2, 8)))
     orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
                         const unsigned long long numRecs,
                         const unsigned *__restrict__ generalCount, const unsigned len, const unsigned depth,
                         const ulonglong2 *__restrict__ table, ulonglong2 *__restrict__ ranges,
                         unsigned *__restrict__ counts, unsigned *__restrict__ tickets, const int xcdMap = 0) {
-  constexpr int S = 8 / G;
+  constexpr int S = (int)kSlices / G;
   typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
-  __shared__ unsigned sMask[256 * 8];
+  __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
+  __shared__ unsigned long long sSuper[!NARROW ? kMaxNucSuper * 4 : 1];
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
-  for (unsigned e = threadIdx.x; e < 256u * 8u; e += kThreads) sMask[e] = sliceMask(e >> 3, e & 7u);
+  stageMaskTable(sMask);
+  nucStageSuper<NARROW>(ix, sSuper);
   __syncthreads();
 
   const OrderFormat format = orderFormat(depth);
@@ -223,7 +225,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
     }
   };
   const unsigned gl = threadIdx.x % G;
-  const unsigned firstPiece = gl * S;
+  const unsigned firstSlice = gl * S;
   /* the records the fast path covers come first in the order; each XCD takes a contiguous eighth of them */
   const unsigned long long covered = numRecs - (unsigned long long)*generalCount;
   const unsigned xcds = (gridDim.x & 7u) == 0u && xcdMap != 2 ? 8u : 1u;
@@ -303,7 +305,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
 
     /* ---- extension (ref src/AwFmParallelSearch.c:273-313) ---- */
     while (pos >= 0 && sp <= ep) {
-      nucFastStep<G, NARROW>(ix, sC, sMask, firstPiece, (unsigned)rem & 3u, sp, ep);
+      nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
       pos--;
       rem >>= 2;
     }
