@@ -30,6 +30,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 
@@ -55,7 +57,7 @@ inline void setError(const char *what) { awfmGpuSetError(what); }
 constexpr unsigned kBlockShift = 7;       /* 128 positions per device block */
 constexpr unsigned kBlockMask = 127;
 constexpr unsigned kSlices = 4;           /* 32-position slices per device block */
-constexpr unsigned kNucSuperShift = 32;   /* positions per nucleotide superblock: 2^32 */
+constexpr unsigned kNucSuperShift = 32;   /* positions per nucleotide superblock: 2^32 ($AWFM_GPU_NUC_SUPER_SHIFT: tests) */
 constexpr unsigned kMaxNucSuper = 64;     /* nucleotide images of up to 2^38 positions */
 constexpr unsigned kAminoSuperShift = 16; /* positions per amino superblock: 2^16 */
 constexpr unsigned kAminoSuperStride = 24;
@@ -71,6 +73,7 @@ struct DevIndex {
   const unsigned long long *prefixSums; /* 24 words in device memory */
   const unsigned long long *super;      /* base counts at superblock starts (layouts above) */
   unsigned int numSuper;
+  unsigned int nucSuperShift; /* log2 of the positions per nucleotide superblock: 32 (smaller only in tests) */
   unsigned int saRatio;
   unsigned int saShift; /* log2(saRatio) when it is a power of two, else 0xFFFFFFFF */
   unsigned int saWidth;
@@ -260,8 +263,8 @@ __device__ __forceinline__ void nucFastStep(const DevIndex &ix, const unsigned l
   pos_t cLetter = (pos_t)sC[letter];
   pos_t super1 = 0;
   if (!NARROW) { /* 64-bit bases of the superblocks of q0 and q1 (they may differ) */
-    const unsigned long long s0 = sSuper[(unsigned)((unsigned long long)q0 >> kNucSuperShift) * 4u + letter];
-    const unsigned long long s1 = sSuper[(unsigned)((unsigned long long)q1 >> kNucSuperShift) * 4u + letter];
+    const unsigned long long s0 = sSuper[(unsigned)((unsigned long long)q0 >> ix.nucSuperShift) * 4u + letter];
+    const unsigned long long s1 = sSuper[(unsigned)((unsigned long long)q1 >> ix.nucSuperShift) * 4u + letter];
     cLetter += (pos_t)s0;
     super1 = (pos_t)(s1 - s0);
   }
@@ -298,7 +301,7 @@ __device__ __forceinline__ typename PositionType<NARROW>::type nucBaseAny(const 
                                                                          unsigned long long blk) {
   constexpr int S = (int)kSlices / G;
   typedef typename PositionType<NARROW>::type pos_t;
-  const unsigned sb = NARROW ? 0u : (unsigned)(blk >> (kNucSuperShift - kBlockShift));
+  const unsigned sb = NARROW ? 0u : (unsigned)(blk >> (ix.nucSuperShift - kBlockShift));
   unsigned mine = 0;
   unsigned long long part = 0;
 #pragma unroll
@@ -498,12 +501,12 @@ __device__ __forceinline__ void aminoStepAny(const DevIndex &ix, const unsigned 
 /* absolute base counts at superblock starts, from the reference-layout blocks (ref src/AwFmIndex.h:55-65: 160-B
  * blocks = planes [3][4] + counts [8] as 64-bit words; 352-B blocks = planes [5][4] + counts [24]) */
 __global__ void gatherSuperKernel(const unsigned long long *__restrict__ ref, unsigned long long numRefBlocks, int amino,
-                                  unsigned numSuper, unsigned long long *__restrict__ super) {
+                                  unsigned superShift, unsigned numSuper, unsigned long long *__restrict__ super) {
   const unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned stride = amino ? kAminoSuperStride : 4u;
   if (t >= numSuper * stride) return;
   const unsigned sb = t / stride, a = t % stride;
-  const unsigned long long refBlk = ((unsigned long long)sb << (amino ? kAminoSuperShift : kNucSuperShift)) >> 8;
+  const unsigned long long refBlk = ((unsigned long long)sb << superShift) >> 8;
   unsigned long long v = 0;
   if (refBlk < numRefBlocks && a < (amino ? 21u : 4u)) v = amino ? ref[refBlk * 44ull + 20u + a] : ref[refBlk * 20ull + 12u + a];
   super[t] = v;
@@ -511,8 +514,9 @@ __global__ void gatherSuperKernel(const unsigned long long *__restrict__ ref, un
 
 /* reference-layout blocks -> device layout; also finds the sentinel's BWT position.  One thread per slice. */
 __global__ void relayoutNucKernel(const unsigned long long *__restrict__ ref, unsigned long long numRefBlocks,
-                                  unsigned long long bwtLength, const unsigned long long *__restrict__ super,
-                                  uint4 *__restrict__ out, unsigned long long *__restrict__ sentinelPos) {
+                                  unsigned long long bwtLength, unsigned superShift,
+                                  const unsigned long long *__restrict__ super, uint4 *__restrict__ out,
+                                  unsigned long long *__restrict__ sentinelPos) {
   const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned long long blk = t >> 2; /* device block */
   const unsigned k = (unsigned)t & 3u;   /* slice = letter whose count this piece carries */
@@ -537,7 +541,7 @@ __global__ void relayoutNucKernel(const unsigned long long *__restrict__ ref, un
       count += __popc(nucOccSlice(pc, sel));
     }
   }
-  count -= super[(blk >> (kNucSuperShift - kBlockShift)) * 4ull + k];
+  count -= super[(blk >> (superShift - kBlockShift)) * 4ull + k];
   out[blk * kSlices + k] = make_uint4(b0, b1, b2, (unsigned)count);
   const unsigned sentinelBits = b2 & ~b1 & ~b0; /* code 100b, ref src/AwFmLetter.c:44-47 */
   if (sentinelBits) {
@@ -644,16 +648,36 @@ struct AwFmGpuIndex {
 /* sizes of the device block array and of the superblock table of an index */
 inline uint64_t awfmDeviceBlocks(uint64_t bwtLength) { return 2 * awfmNumBlocks(bwtLength); }
 inline uint64_t awfmDeviceBlockBytes(bool amino) { return amino ? 128 : 64; }
-inline uint64_t awfmNumSuper(uint64_t bwtLength, bool amino) {
-  return ((bwtLength - 1) >> (amino ? kAminoSuperShift : kNucSuperShift)) + 1;
+/* log2 of the positions per superblock.  Nucleotide: 32.  $AWFM_GPU_NUC_SUPER_SHIFT = 13..31, or "auto" (the
+ * smallest shift >= 13 that gives at most 48 superblocks), makes them smaller so that the parity tests reach the
+ * several-superblock arithmetic an index of 2^32 or more positions runs -- such an image always uses the 64-bit
+ * kernels, the only ones that read the superblock bases. */
+inline unsigned awfmSuperShift(bool amino, uint64_t bwtLength) {
+  if (amino) return kAminoSuperShift;
+  if (const char *env = getenv("AWFM_GPU_NUC_SUPER_SHIFT")) {
+    if (!strcmp(env, "auto")) {
+      unsigned shift = 13;
+      while (((bwtLength - 1) >> shift) + 1 > 48) shift++;
+      return shift < kNucSuperShift ? shift : kNucSuperShift;
+    }
+    const int v = atoi(env);
+    if (v >= 13 && v < (int)kNucSuperShift) return (unsigned)v;
+  }
+  return kNucSuperShift;
 }
-inline uint64_t awfmSuperBytes(uint64_t bwtLength, bool amino) {
-  return awfmNumSuper(bwtLength, amino) * (amino ? kAminoSuperStride : 4u) * 8u;
+inline uint64_t awfmNumSuper(uint64_t bwtLength, bool amino, unsigned superShift) {
+  (void)amino;
+  return ((bwtLength - 1) >> superShift) + 1;
+}
+inline uint64_t awfmSuperBytes(uint64_t bwtLength, bool amino, unsigned superShift) {
+  return awfmNumSuper(bwtLength, amino, superShift) * (amino ? kAminoSuperStride : 4u) * 8u;
 }
 
 /* 32-bit BWT positions in the kernels: exact whenever bwtLength < 2^32 (ref src/AwFmIndex.h:88-91 is 64-bit
  * throughout; the NARROW = false instantiations are that arithmetic) */
-inline bool awfmImageNarrow(const AwFmGpuIndex *g) { return !g->forceWide && g->dev.bwtLength < (1ull << 32); }
+inline bool awfmImageNarrow(const AwFmGpuIndex *g) {
+  return !g->forceWide && g->dev.bwtLength < (1ull << 32) && (g->amino || g->dev.numSuper == 1);
+}
 
 /* RAII hipSetDevice */
 struct DeviceGuard {
@@ -671,16 +695,16 @@ struct DeviceGuard {
 /* blocks + superblock table of the device image from reference-layout blocks already on the device (current device,
  * null stream).  dBlocks / dSuper are allocated by the caller: awfmDeviceBlocks x awfmDeviceBlockBytes, awfmSuperBytes.
  * Synchronous; false with awfmGpuLastError set on failure. */
-bool awfmGpuRelayout(const void *dRefBlocks, uint64_t bwtLength, bool amino, void *dBlocks, void *dSuper,
-                     unsigned long long *sentinelPosOut);
+bool awfmGpuRelayout(const void *dRefBlocks, uint64_t bwtLength, bool amino, unsigned superShift, void *dBlocks,
+                     void *dSuper, unsigned long long *sentinelPosOut);
 
 /* ordered hits-only search; 1 = searched, 0 = does not apply, <0 = -AwFmReturnCode (awfm_gpu_ordered.hip) */
 int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                          uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts);
 
 /* adopts device buffers that already hold a complete image (used by the GPU builder) */
-AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSuper, void *dSeed,
-                                void *dSa, void *dPrefix, unsigned long long sentinelPos, uint64_t deviceBytes);
+AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSuper, unsigned superShift,
+                                void *dSeed, void *dSa, void *dPrefix, unsigned long long sentinelPos, uint64_t deviceBytes);
 void awfmGpuIndexRegister(const struct AwFmIndex *index, AwFmGpuIndex *g);
 /* awfm_gpu_build.hip: level-wise construction of the deeper seed table into a new device buffer */
 bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut);

@@ -198,11 +198,12 @@ inline size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 }  // namespace
 
 namespace {
-void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned long long sentinelPos) {
+void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned superShift, unsigned long long sentinelPos) {
   DevIndex &d = g->dev;
   d.blocks = (const uint4 *)g->dBlocks;
   d.super = (const unsigned long long *)g->dSuper;
-  d.numSuper = (unsigned)awfmNumSuper(index->bwtLength, index->config.alphabetType == AwFmAlphabetAmino);
+  d.numSuper = (unsigned)awfmNumSuper(index->bwtLength, index->config.alphabetType == AwFmAlphabetAmino, superShift);
+  d.nucSuperShift = superShift;
   d.seed = (const ulonglong2 *)g->dSeed;
   d.sa = (const unsigned long long *)g->dSa;
   d.bwtLength = index->bwtLength;
@@ -297,8 +298,8 @@ extern "C" {
 static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g);
 }
 
-AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSuper, void *dSeed,
-                                void *dSa, void *dPrefix, unsigned long long sentinelPos, uint64_t deviceBytes) {
+AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSuper, unsigned superShift,
+                                void *dSeed, void *dSa, void *dPrefix, unsigned long long sentinelPos, uint64_t deviceBytes) {
   AwFmGpuIndex *g = new AwFmGpuIndex();
   g->device = device;
   g->amino = index->config.alphabetType == AwFmAlphabetAmino;
@@ -312,7 +313,7 @@ AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void 
   g->dSa = dSa;
   g->dPrefix = dPrefix;
   g->deviceBytes = deviceBytes;
-  fillDevIndex(g, index, sentinelPos);
+  fillDevIndex(g, index, superShift, sentinelPos);
   if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
   (void)applyDeepSeedFromEnv(g); /* optional accelerator: on failure the image simply has no deeper table */
   return g;
@@ -323,17 +324,17 @@ void awfmGpuIndexRegister(const struct AwFmIndex *index, AwFmGpuIndex *g) {
   imageTable.push_back({index, g->device, 0, g});
 }
 
-bool awfmGpuRelayout(const void *dRefBlocks, uint64_t bwtLength, bool amino, void *dBlocks, void *dSuper,
-                     unsigned long long *sentinelPosOut) {
+bool awfmGpuRelayout(const void *dRefBlocks, uint64_t bwtLength, bool amino, unsigned superShift, void *dBlocks,
+                     void *dSuper, unsigned long long *sentinelPosOut) {
   const uint64_t numRef = awfmNumBlocks(bwtLength);
-  const unsigned numSuper = (unsigned)awfmNumSuper(bwtLength, amino);
+  const unsigned numSuper = (unsigned)awfmNumSuper(bwtLength, amino, superShift);
   unsigned long long *dSentinel = nullptr;
   hipError_t e = hipMalloc((void **)&dSentinel, 8);
   if (e == hipSuccess) e = hipMemset(dSentinel, 0, 8);
   if (e == hipSuccess) {
     const unsigned words = numSuper * (amino ? kAminoSuperStride : 4u);
     hipLaunchKernelGGL(gatherSuperKernel, dim3((words + 255) / 256), dim3(256), 0, 0, (const unsigned long long *)dRefBlocks,
-                       (unsigned long long)numRef, amino ? 1 : 0, numSuper, (unsigned long long *)dSuper);
+                       (unsigned long long)numRef, amino ? 1 : 0, superShift, numSuper, (unsigned long long *)dSuper);
     const uint64_t threads = numRef * 2 * kSlices;
     const unsigned grid = (unsigned)((threads + 255) / 256);
     if (amino)
@@ -342,8 +343,8 @@ bool awfmGpuRelayout(const void *dRefBlocks, uint64_t bwtLength, bool amino, voi
                          (uint4 *)dBlocks, dSentinel);
     else
       hipLaunchKernelGGL(relayoutNucKernel, dim3(grid), dim3(256), 0, 0, (const unsigned long long *)dRefBlocks,
-                         (unsigned long long)numRef, (unsigned long long)bwtLength, (const unsigned long long *)dSuper,
-                         (uint4 *)dBlocks, dSentinel);
+                         (unsigned long long)numRef, (unsigned long long)bwtLength, superShift,
+                         (const unsigned long long *)dSuper, (uint4 *)dBlocks, dSentinel);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipMemcpy(sentinelPosOut, dSentinel, 8, hipMemcpyDeviceToHost);
@@ -389,8 +390,9 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
     return AwFmGeneralFailure;
   }
   const bool amino = index->config.alphabetType == AwFmAlphabetAmino;
-  if (!amino && awfmNumSuper(index->bwtLength, false) > kMaxNucSuper) {
-    setError("awfmGpuIndexCreate: nucleotide device images hold at most 2^38 positions");
+  const unsigned superShift = awfmSuperShift(amino, index->bwtLength);
+  if (!amino && awfmNumSuper(index->bwtLength, false, superShift) > kMaxNucSuper) {
+    setError("awfmGpuIndexCreate: nucleotide device images hold at most 64 superblocks (2^38 positions)");
     return AwFmUnsupportedVersionError;
   }
   if (index->config.suffixArrayCompressionRatio == 0) {
@@ -407,7 +409,7 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
   g->numBlocks = awfmDeviceBlocks(index->bwtLength);
   const size_t refBytes = awfmNumBlocks(index->bwtLength) * awfmBlockBytes(index->config.alphabetType);
   const size_t devBlockBytes = g->numBlocks * awfmDeviceBlockBytes(amino);
-  const size_t superBytes = awfmSuperBytes(index->bwtLength, amino);
+  const size_t superBytes = awfmSuperBytes(index->bwtLength, amino, superShift);
   const uint64_t seedLen = awfmKmerTableLength(index->config.alphabetType, index->config.kmerLengthInSeedTable);
   const size_t seedBytes = seedLen * sizeof(struct AwFmSearchRange);
   const size_t saBytes = index->suffixArray.compressedByteLength;
@@ -437,7 +439,7 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
 
   TRY_OR_FAIL(hipMemcpy(dRef, index->bwtBlockList.asNucleotide, refBytes, hipMemcpyHostToDevice), AwFmGeneralFailure);
   unsigned long long sentinelPos = 0;
-  if (!awfmGpuRelayout(dRef, index->bwtLength, amino, g->dBlocks, g->dSuper, &sentinelPos)) {
+  if (!awfmGpuRelayout(dRef, index->bwtLength, amino, superShift, g->dBlocks, g->dSuper, &sentinelPos)) {
     (void)hipFree(dRef);
     return fail(AwFmGeneralFailure);
   }
@@ -468,7 +470,7 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
   }
 #undef TRY_OR_FAIL
 
-  fillDevIndex(g, index, sentinelPos);
+  fillDevIndex(g, index, superShift, sentinelPos);
   if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
   if (applyDeepSeedFromEnv(g) != AwFmSuccess) return fail(AwFmGeneralFailure);
   *out = g;

@@ -688,11 +688,16 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
 
   /* 4. device image: blocks + superblock bases, prefix sums, seed table, packed SA */
   DeviceBuffer dBlocks, dSuper, dPrefix, dSeedA, dSeedB, dPacked;
+  const unsigned superShift = awfmSuperShift(amino, n);
+  if (!amino && awfmNumSuper(n, false, superShift) > kMaxNucSuper) {
+    awfmGpuSetError("awfmGpuCreateIndex: nucleotide device images hold at most 64 superblocks");
+    return failWith(AwFmUnsupportedVersionError);
+  }
   STEP(dBlocks.alloc(awfmDeviceBlocks(n) * awfmDeviceBlockBytes(amino)));
-  STEP(dSuper.alloc(awfmSuperBytes(n, amino)));
+  STEP(dSuper.alloc(awfmSuperBytes(n, amino, superShift)));
   {
     unsigned long long again = 0; /* the sentinel's position is known from the BWT pass already */
-    STEP(awfmGpuRelayout(dRef.p, n, amino, dBlocks.p, dSuper.p, &again));
+    STEP(awfmGpuRelayout(dRef.p, n, amino, superShift, dBlocks.p, dSuper.p, &again));
   }
   {
     u64 prefix[24] = {0};
@@ -703,7 +708,8 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
   DevIndex dev{};
   dev.blocks = dBlocks.as<uint4>();
   dev.super = dSuper.as<u64>();
-  dev.numSuper = (unsigned)awfmNumSuper(n, amino);
+  dev.numSuper = (unsigned)awfmNumSuper(n, amino, superShift);
+  dev.nucSuperShift = superShift;
   dev.prefixSums = dPrefix.as<u64>();
   dev.bwtLength = n;
   dev.sentinelPos = sentinelPos;
@@ -770,8 +776,8 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
   ix->sequenceFileOffset = awfmSequenceFileOffset(ix);
 
   /* keep the device image for awFmParallelSearch* */
-  const uint64_t deviceBytes = awfmDeviceBlocks(n) * awfmDeviceBlockBytes(amino) + awfmSuperBytes(n, amino) + seedLen * 16 + saWords * 8;
-  AwFmGpuIndex *g = awfmGpuIndexAdopt(ix, device, dBlocks.release(), dSuper.release(), dSeedA.release(), dPacked.release(),
+  const uint64_t deviceBytes = awfmDeviceBlocks(n) * awfmDeviceBlockBytes(amino) + awfmSuperBytes(n, amino, superShift) + seedLen * 16 + saWords * 8;
+  AwFmGpuIndex *g = awfmGpuIndexAdopt(ix, device, dBlocks.release(), dSuper.release(), superShift, dSeedA.release(), dPacked.release(),
                                       dPrefix.release(), sentinelPos, deviceBytes);
   awfmGpuIndexRegister(ix, g);
 

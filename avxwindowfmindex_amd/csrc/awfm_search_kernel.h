@@ -38,7 +38,7 @@ __device__ __forceinline__ unsigned pairLength(const ulonglong2 &o) {
  * subsetIndexAt the query number.
  */
 template <bool AMINO, int G, bool CSR, bool TALLY, bool NARROW, bool INDIRECT = false>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 4 && !TALLY && !CSR && !AMINO && !INDIRECT ? 8 : 2, 8)))
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 4 && !TALLY && !CSR && !AMINO && !INDIRECT ? (NARROW ? 8 : 6) : 2, 8)))
     searchKernel(const DevIndex ix, const unsigned char *__restrict__ chars,
                  const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
                  const unsigned long long numQueries, ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts,

@@ -38,10 +38,14 @@ def require_gpu(awfm):
     return n
 
 
-@pytest.fixture(params=[False, True], ids=["narrow", "wide"])
+@pytest.fixture(params=["narrow", "wide", "wide-superblocks"])
 def wide(request, monkeypatch):
-    """runs a GPU test twice: with 32-bit BWT positions in the kernels (what an index below 2^32 positions gets)
-    and with the 64-bit instantiations forced on the same small index ($AWFM_GPU_FORCE_WIDE is read when a device
-    image is created), i.e. the code a >= 2^32-position index runs (ref src/AwFmIndex.h:88-91)"""
-    monkeypatch.setenv("AWFM_GPU_FORCE_WIDE", "1" if request.param else "0")
-    return request.param
+    """runs a GPU test three times: with 32-bit BWT positions in the kernels (what an index below 2^32 positions
+    gets); with the 64-bit instantiations forced on the same small index ($AWFM_GPU_FORCE_WIDE is read when a device
+    image is created); and with nucleotide superblocks of a few thousand positions instead of 2^32 on top of that
+    ($AWFM_GPU_NUC_SUPER_SHIFT=auto: up to 48 superblocks), i.e. the code and the base-count arithmetic an index of
+    2^32 or more positions runs (ref src/AwFmIndex.h:88-91 is 64-bit throughout)"""
+    monkeypatch.setenv("AWFM_GPU_FORCE_WIDE", "0" if request.param == "narrow" else "1")
+    if request.param == "wide-superblocks":
+        monkeypatch.setenv("AWFM_GPU_NUC_SUPER_SHIFT", "auto")
+    return request.param != "narrow"

@@ -32,8 +32,7 @@ def _check_against_oracle(O, awfm, txt, alpha, oalpha, ratio, seed_k, chars, off
     oi = O.Index.wrap(oalpha, ratio, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
                       ix.packed_sa())
     g = awfm.GpuIndex(ix)
-    if alpha != awfm.AwFmAlphabetAmino:  # the `wide` fixture really selected the 64-bit instantiations
-        assert g.is_wide == (os.environ.get("AWFM_GPU_FORCE_WIDE", "0") == "1")
+    assert g.is_wide == (os.environ.get("AWFM_GPU_FORCE_WIDE", "0") == "1")  # the `wide` fixture really took effect
     sp, ep, cnt, _ = oi.batch_search(chars, offsets)
     ranges, counts = g.count_host(chars, offsets)
     assert np.array_equal(ranges[:, 0], sp), "sp differs"
