@@ -31,7 +31,12 @@ GPU_SYMBOLS = [
     "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuHitOffsetsFromCounts", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
     "awfmGpuCreateIndex", "awfmGpuSearchTally", "awfmGpuSynthText", "awfmGpuSynthRandomQueries", "awfmGpuSynthPlantedQueries",
     "awfmGpuSynthMixedLengths", "awfmGpuSynthMixedQueries",
+    "awfmPackKmers", "awfmGpuPackKmers", "awfmGpuUnpackKmers", "awfmGpuHostAlloc", "awfmGpuHostFree", "awfmGpuStreamPacked",
+    "awfmGpuStreamChars", "awfmGpuCountPackedHost", "awfmGpuLocatePackedHost", "awfmGpuIndexSetPairImage", "awfmGpuIndexHasPairImage",
+    "awfmGpuSearchHitsPacked",
 ]
+# int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
+CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
 
 
 class AwFmIndexConfiguration(C.Structure):
@@ -135,6 +140,8 @@ def lib():
         "awfmGpuLastOrderedKernelMs": (C.c_double, [vp]),
         "awfmGpuIndexSetDeepSeed": (C.c_int, [vp, C.c_uint]),
         "awfmGpuIndexSetDenseSa": (C.c_int, [vp, C.c_int]),
+        "awfmGpuIndexSetPairImage": (C.c_int, [vp, C.c_int]),
+        "awfmGpuIndexHasPairImage": (C.c_int, [vp]),
         "awfmGpuSearch": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuSearchHits": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuScanScratchBytes": (u64, [u64]),
@@ -151,6 +158,16 @@ def lib():
         "awfmGpuSynthPlantedQueries": (C.c_int, [vp, u64, u64, C.c_uint32, u64, vp, u64, vp]),
         "awfmGpuSynthMixedLengths": (C.c_int, [vp, u64, u64, C.c_uint32, C.c_uint32, u64, vp]),
         "awfmGpuSynthMixedQueries": (C.c_int, [vp, vp, u64, u64, u64, vp, u64, C.c_int, vp]),
+        "awfmPackKmers": (C.c_int, [C.c_int, vp, C.c_uint32, u64, vp, C.POINTER(u64)]),
+        "awfmGpuPackKmers": (C.c_int, [vp, vp, C.c_uint32, u64, vp, C.POINTER(u64), vp]),
+        "awfmGpuUnpackKmers": (C.c_int, [vp, vp, C.c_uint32, u64, vp, vp]),
+        "awfmGpuSearchHitsPacked": (C.c_int, [vp, vp, C.c_uint32, u64, vp, vp, vp, vp]),
+        "awfmGpuHostAlloc": (vp, [u64]),
+        "awfmGpuHostFree": (None, [vp]),
+        "awfmGpuStreamPacked": (C.c_int, [vp, vp, C.c_uint32, u64, u64, C.c_int, C.c_uint, CHUNK_SINK, vp]),
+        "awfmGpuStreamChars": (C.c_int, [vp, vp, C.c_uint32, u64, u64, C.c_int, C.c_uint, CHUNK_SINK, vp]),
+        "awfmGpuCountPackedHost": (C.c_int, [vp, vp, C.c_uint32, u64, vp]),
+        "awfmGpuLocatePackedHost": (C.c_int, [vp, vp, C.c_uint32, u64, vp, C.POINTER(C.POINTER(u64)), C.POINTER(u64)]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)

@@ -215,6 +215,20 @@ def parallel_search_locate(index, search_list, num_threads=4):
     return _lib.lib().awFmParallelSearchLocate(index.ptr, search_list.ptr, num_threads)
 
 
+def pack_kmers(kmers, alphabet=AwFmAlphabetDna):
+    """awfmPackKmers: uint8[n, L] fixed-length ASCII k-mers -> uint64[n] packed words (2 bits per nucleotide, 5 bits
+    per amino acid, first character most significant).  Raises on a k-mer the packing cannot express."""
+    kmers = np.ascontiguousarray(kmers, dtype=np.uint8)
+    n, length = kmers.shape
+    out = np.zeros(n, np.uint64)
+    bad = C.c_uint64(0)
+    holder = kmers if kmers.size else np.zeros(1, np.uint8)
+    rc = _lib.lib().awfmPackKmers(alphabet, holder.ctypes.data, length, n, out.ctypes.data, C.byref(bad))
+    if rc != AwFmSuccess:
+        raise ValueError(f"awfmPackKmers: k-mer {bad.value} cannot be packed (rc {rc})")
+    return out
+
+
 class GpuIndex:
     """AwFmGpuIndex* owner: the device image plus the flat batch API of include/awfm_gpu.h"""
 
@@ -247,6 +261,14 @@ class GpuIndex:
     def set_dense_sa(self, enable=True):
         """device-only full suffix array (32-bit entries) so that a locate is a single gather"""
         _check("awfmGpuIndexSetDenseSa", _lib.lib().awfmGpuIndexSetDenseSa(self.handle, int(bool(enable))))
+
+    def set_pair_image(self, enable=True):
+        """device-only pair image (two steps per block read); built by default with nucleotide images"""
+        _check("awfmGpuIndexSetPairImage", _lib.lib().awfmGpuIndexSetPairImage(self.handle, int(bool(enable))))
+
+    @property
+    def has_pair_image(self):
+        return bool(_lib.lib().awfmGpuIndexHasPairImage(self.handle))
 
     def set_kernel(self, kernel):
         _lib.lib().awfmGpuIndexSetKernel(self.handle, kernel)
@@ -289,6 +311,63 @@ class GpuIndex:
         L.free(C.cast(pos_ptr, C.c_void_p))
         return ranges, hit_off, pos
 
+    # chunked pipeline on host buffers (awfm_gpu_stream.hip) ---------------------------
+    def stream(self, kmers, kmer_length, locate=True, chunk=0, packed=True, threads=4, sink=None):
+        """awfmGpuStreamPacked / awfmGpuStreamChars over a host array (numpy uint64[n] packed words, or uint8[n*L]
+        ASCII; or an (address, n) pair for page-locked memory).  Without a sink the chunks are gathered:
+        returns (counts uint32[n], positions uint64[total] or None)."""
+        L = _lib.lib()
+        if isinstance(kmers, tuple):
+            address, n = kmers
+        else:
+            kmers = np.ascontiguousarray(kmers, dtype=np.uint64 if packed else np.uint8)
+            n = kmers.size if packed else kmers.size // kmer_length
+            address = kmers.ctypes.data if kmers.size else None
+        counts = np.zeros(n, np.uint32)
+        parts = []
+
+        def gather(user, first, m, c, p, total):
+            counts[first:first + m] = np.ctypeslib.as_array(c, shape=(m,))
+            if locate and total:
+                parts.append(np.ctypeslib.as_array(p, shape=(total,)).copy())
+            return 0
+
+        cb = _lib.CHUNK_SINK(sink or gather)
+        fn = L.awfmGpuStreamPacked if packed else L.awfmGpuStreamChars
+        _check(fn.__name__, fn(self.handle, address, kmer_length, n, chunk, int(bool(locate)), threads, cb, None))
+        if sink is not None:
+            return None
+        return counts, (np.concatenate(parts) if parts else np.zeros(0, np.uint64)) if locate else None
+
+    def count_packed_host(self, packed, kmer_length):
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        counts = np.zeros(packed.size, np.uint32)
+        _check("awfmGpuCountPackedHost", _lib.lib().awfmGpuCountPackedHost(
+            self.handle, packed.ctypes.data if packed.size else None, kmer_length, packed.size, counts.ctypes.data))
+        return counts
+
+    def locate_packed_host(self, packed, kmer_length):
+        L = _lib.lib()
+        packed = np.ascontiguousarray(packed, dtype=np.uint64)
+        counts = np.zeros(packed.size, np.uint32)
+        pos_ptr, total = C.POINTER(C.c_uint64)(), C.c_uint64(0)
+        _check("awfmGpuLocatePackedHost", L.awfmGpuLocatePackedHost(
+            self.handle, packed.ctypes.data if packed.size else None, kmer_length, packed.size, counts.ctypes.data,
+            C.byref(pos_ptr), C.byref(total)))
+        pos = np.ctypeslib.as_array(pos_ptr, shape=(total.value,)).copy() if total.value else np.zeros(0, np.uint64)
+        L.free(C.cast(pos_ptr, C.c_void_p))
+        return counts, pos
+
+    def pack_device(self, d_chars, kmer_length, n, d_packed, stream=0):
+        """awfmGpuPackKmers on device buffers; returns how many k-mers could not be expressed"""
+        bad = C.c_uint64(0)
+        _check("awfmGpuPackKmers", _lib.lib().awfmGpuPackKmers(self.handle, d_chars, kmer_length, n, d_packed, C.byref(bad),
+                                                               stream or None))
+        return int(bad.value)
+
+    def unpack_device(self, d_packed, kmer_length, n, d_chars, stream=0):
+        _check("awfmGpuUnpackKmers", _lib.lib().awfmGpuUnpackKmers(self.handle, d_packed, kmer_length, n, d_chars, stream or None))
+
     # device-pointer calls (addresses as ints, e.g. torch tensor.data_ptr()) -------------
     def search(self, d_chars, d_offsets, fixed_length, n, d_ranges, d_counts, stream=0):
         _check("awfmGpuSearch", _lib.lib().awfmGpuSearch(self.handle, d_chars, d_offsets or None, fixed_length, n,
@@ -298,6 +377,11 @@ class GpuIndex:
         """awfmGpuSearchHits: like search(), but a query without hits only gets count 0 and some empty range"""
         _check("awfmGpuSearchHits", _lib.lib().awfmGpuSearchHits(self.handle, d_chars, d_offsets or None, fixed_length,
                                                                  n, d_ranges or None, d_counts or None, stream or None))
+
+    def search_hits_packed(self, d_packed, kmer_length, n, d_ranges, d_counts, d_chars_scratch=0, stream=0):
+        """awfmGpuSearchHitsPacked: hits-only search of bit-packed k-mers resident on the device"""
+        _check("awfmGpuSearchHitsPacked", _lib.lib().awfmGpuSearchHitsPacked(
+            self.handle, d_packed, kmer_length, n, d_ranges or None, d_counts or None, d_chars_scratch or None, stream or None))
 
     def search_hits_is_ordered(self, has_offsets, fixed_length, n):
         return bool(_lib.lib().awfmGpuSearchHitsIsOrdered(self.handle, int(bool(has_offsets)), fixed_length, n))

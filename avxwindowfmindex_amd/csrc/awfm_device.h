@@ -61,6 +61,8 @@ constexpr unsigned kNucSuperShift = 32;   /* positions per nucleotide superblock
 constexpr unsigned kMaxNucSuper = 64;     /* nucleotide images of up to 2^38 positions */
 constexpr unsigned kAminoSuperShift = 16; /* positions per amino superblock: 2^16 */
 constexpr unsigned kAminoSuperStride = 24;
+constexpr unsigned kPairSuperShift = 23;  /* positions per superblock of the pair image: 2^23 (23-bit relative counts) */
+constexpr unsigned kPairCountMask = 0xFFFFFFu;
 
 /* kernel-argument view of the device image */
 struct DevIndex {
@@ -83,6 +85,15 @@ struct DevIndex {
    * invalid range; NULL when not built */
   const ulonglong2 *deepSeed;
   unsigned int deepK;
+  /* optional device-only pair image (nucleotide; awfm_pair.h): two backward / LF steps per block read; NULL when
+   * not built.  pairSuper32 is the 32-bit copy of the superblock bases the kernels of images below 2^32 positions
+   * keep in LDS. */
+  const uint4 *pairBlocks;
+  const unsigned long long *pairSuper;
+  const unsigned int *pairSuper32;
+  const unsigned long long *pairC; /* 16 words: first BWT position of the suffixes that start with the pair */
+  unsigned int numPairSuper;
+  unsigned int pairSuperInLds; /* set per launch: the kernel was given numPairSuper * 64 bytes of dynamic LDS for pairSuper32 */
 };
 
 /* a nucleotide query prepared for the ordered search path (awfm_ordered_kernel.h) */
@@ -618,6 +629,8 @@ struct AwFmGpuIndex {
   uint64_t deepSeedBytes = 0;
   void *dDenseSa = nullptr; /* optional full suffix array, 32-bit entries */
   uint64_t denseSaBytes = 0;
+  void *dPairBlocks = nullptr, *dPairSuper = nullptr, *dPairSuper32 = nullptr, *dPairC = nullptr; /* pair image */
+  uint64_t pairBytes = 0;
   uint64_t deviceBytes = 0;
   uint64_t numBlocks = 0; /* device blocks (128 positions each) */
   AwFmGpuKernel kernel = AWFM_GPU_KERNEL_AUTO;
@@ -643,6 +656,10 @@ struct AwFmGpuIndex {
   std::mutex aosMutex;       /* serialises the AoS entry points (they share the pinned buffers) */
   void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pinnedBytes[4] = {0, 0, 0, 0};
+  /* chunked host-buffer pipeline (awfm_gpu_stream.hip): three slots of device buffers + page-locked staging,
+   * created on first use, one batch at a time */
+  std::mutex streamMutex;
+  struct AwFmGpuStreamState *streamState = nullptr;
 };
 
 /* sizes of the device block array and of the superblock table of an index */
@@ -679,6 +696,13 @@ inline bool awfmImageNarrow(const AwFmGpuIndex *g) {
   return !g->forceWide && g->dev.bwtLength < (1ull << 32) && (g->amino || g->dev.numSuper == 1);
 }
 
+/* where the kernels that use the pair image keep its 32-bit superblock bases (64 B per 2^23 positions): in dynamic LDS,
+ * or read from memory beside the blocks.  $AWFM_GPU_PAIR_SUPER=lds|global (measurement knob) */
+inline bool awfmPairSuperInLds(const AwFmGpuIndex *g) {
+  if (const char *env = getenv("AWFM_GPU_PAIR_SUPER")) return !strcmp(env, "lds");
+  return g->dev.numPairSuper * 64u <= 32768u; /* measured: 4.46 ms from LDS against 4.91 ms from memory (10^8 random 21-mers) */
+}
+
 /* RAII hipSetDevice */
 struct DeviceGuard {
   int previous = -1;
@@ -699,13 +723,24 @@ bool awfmGpuRelayout(const void *dRefBlocks, uint64_t bwtLength, bool amino, uns
                      void *dSuper, unsigned long long *sentinelPosOut);
 
 /* ordered hits-only search; 1 = searched, 0 = does not apply, <0 = -AwFmReturnCode (awfm_gpu_ordered.hip) */
+/* packed: dChars is one 64-bit word per fixed-length k-mer (2-bit codes) instead of ASCII */
 int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
-                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts);
+                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed = false);
 
 /* adopts device buffers that already hold a complete image (used by the GPU builder) */
 AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSuper, unsigned superShift,
                                 void *dSeed, void *dSa, void *dPrefix, unsigned long long sentinelPos, uint64_t deviceBytes);
 void awfmGpuIndexRegister(const struct AwFmIndex *index, AwFmGpuIndex *g);
+/* awfm_gpu_pair.hip: builds (enable) or drops the pair image of a primary nucleotide image; the caller holds whatever
+ * locks the image needs and copies the view into its lanes */
+enum AwFmReturnCode awfmGpuApplyPairImage(AwFmGpuIndex *g, bool enable);
+/* awfm_gpu_stream.hip: drops the pipeline slots of an image (called by awfmGpuIndexDestroy) */
+void awfmGpuStreamStateFree(AwFmGpuIndex *g);
+/* hit offsets of a chunk without a host wait: exclusive scan of the 32-bit counts (dCounts != NULL) or of the range
+ * lengths into dHitOffsets[0..n], the total also copied to *pinnedTotal (page-locked) on the stream */
+enum AwFmReturnCode awfmGpuHitOffsetsAsync(AwFmGpuIndex *g, const uint32_t *dCounts, const struct AwFmSearchRange *dRanges,
+                                           uint64_t numQueries, uint64_t *dHitOffsets, void *dScratch,
+                                           unsigned long long *pinnedTotal, hipStream_t s);
 /* awfm_gpu_build.hip: level-wise construction of the deeper seed table into a new device buffer */
 bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut);
 void awfmGpuSetError(const char *what);

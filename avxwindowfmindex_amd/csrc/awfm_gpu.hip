@@ -169,9 +169,10 @@ std::vector<ImageEntry> imageTable;
  * (blocksPerCU from the occupancy query for that kernel); a larger grid would run as a second,
  * under-filled round.  AWFM_GPU_BLOCKS_PER_CU overrides (measurement knob). */
 template <class Kernel>
-unsigned gridFor(uint64_t groups, const AwFmGpuIndex *g, Kernel kernel, unsigned groupsPerBlock) {
+unsigned gridFor(uint64_t groups, const AwFmGpuIndex *g, Kernel kernel, unsigned groupsPerBlock, size_t dynamicLds = 0,
+                 int threads = kThreads) {
   int perCU = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kThreads, 0) != hipSuccess || perCU < 1) perCU = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, threads, dynamicLds) != hipSuccess || perCU < 1) perCU = 4;
   if (perCU > 8) perCU = 8;
   if (const char *env = getenv("AWFM_GPU_BLOCKS_PER_CU")) {
     const int v = atoi(env);
@@ -220,6 +221,12 @@ void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned super
   d.seedK = index->config.kmerLengthInSeedTable;
   d.deepSeed = nullptr;
   d.deepK = 0;
+  d.pairBlocks = nullptr;
+  d.pairSuper = nullptr;
+  d.pairSuper32 = nullptr;
+  d.pairC = nullptr;
+  d.numPairSuper = 0;
+  d.pairSuperInLds = 0;
 }
 }  // namespace
 
@@ -296,6 +303,7 @@ void launchSearch(const AwFmGpuIndex *g, const DevIndex &dev, int lanes, hipStre
 
 extern "C" {
 static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g);
+static enum AwFmReturnCode applyPairFromEnv(AwFmGpuIndex *g);
 }
 
 AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSuper, unsigned superShift,
@@ -316,6 +324,7 @@ AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void 
   fillDevIndex(g, index, superShift, sentinelPos);
   if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
   (void)applyDeepSeedFromEnv(g); /* optional accelerator: on failure the image simply has no deeper table */
+  (void)applyPairFromEnv(g);
   return g;
 }
 
@@ -473,6 +482,7 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
   fillDevIndex(g, index, superShift, sentinelPos);
   if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
   if (applyDeepSeedFromEnv(g) != AwFmSuccess) return fail(AwFmGeneralFailure);
+  (void)applyPairFromEnv(g); /* without it (no memory left) searches simply take one step per read */
   *out = g;
   return AwFmSuccess;
 }
@@ -481,6 +491,7 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
   if (!g) return;
   {
     DeviceGuard guard(g->device);
+    awfmGpuStreamStateFree(g);
     if (!g->shares) { /* a lane owns only its staging */
       if (g->dBlocks) (void)hipFree(g->dBlocks);
       if (g->dSuper) (void)hipFree(g->dSuper);
@@ -489,6 +500,9 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
       if (g->dPrefix) (void)hipFree(g->dPrefix);
       if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
       if (g->dDenseSa) (void)hipFree(g->dDenseSa);
+      void *pairOwned[] = {g->dPairBlocks, g->dPairSuper, g->dPairSuper32, g->dPairC};
+      for (void *p : pairOwned)
+        if (p) (void)hipFree(p);
     }
     if (g->dWork) (void)hipFree(g->dWork);
     if (g->dHits) (void)hipFree(g->dHits);
@@ -638,7 +652,7 @@ void awfmGpuAosUnlock(AwFmGpuIndex *g) {
 }
 
 uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g) {
-  return g ? g->deviceBytes + g->deepSeedBytes + g->denseSaBytes : 0;
+  return g ? g->deviceBytes + g->deepSeedBytes + g->denseSaBytes + g->pairBytes : 0;
 }
 
 namespace {
@@ -718,6 +732,44 @@ static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
   DeviceGuard guard(g->device);
   return applyDeepSeed(g, (unsigned)deepK, {});
 }
+/* Pair image (awfm_pair.h) of a nucleotide image that was just created or adopted (nobody else holds it, no lanes, so
+ * no lock): built unless $AWFM_GPU_PAIR=0.  It doubles the block bytes of the image (128 B per 128 positions beside
+ * the 64 B of the one-letter blocks) and halves the dependent block reads of hits-only searches and of the LF walk. */
+static enum AwFmReturnCode applyPairFromEnv(AwFmGpuIndex *g) {
+  if (g->amino) return AwFmSuccess;
+  if (const char *env = getenv("AWFM_GPU_PAIR"))
+    if (atoi(env) == 0) return AwFmSuccess;
+  DeviceGuard guard(g->device);
+  const enum AwFmReturnCode rc = awfmGpuApplyPairImage(g, true);
+  if (rc != AwFmSuccess) (void)awfmGpuApplyPairImage(g, false);
+  return rc;
+}
+
+enum AwFmReturnCode awfmGpuIndexSetPairImage(AwFmGpuIndex *g, int enable) {
+  if (!g) {
+    setError("awfmGpuIndexSetPairImage: null image");
+    return AwFmNullPtrError;
+  }
+  if (g->shares) {
+    setError("awfmGpuIndexSetPairImage: set it on the primary image, not on a lane");
+    return AwFmIllegalPositionError;
+  }
+  DeviceGuard guard(g->device);
+  LaneLocks lanes(g); /* nobody searches through a lane while the image changes */
+  std::lock_guard<std::mutex> lock(g->workMutex);
+  const enum AwFmReturnCode rc = awfmGpuApplyPairImage(g, enable != 0);
+  if (rc != AwFmSuccess) (void)awfmGpuApplyPairImage(g, false);
+  for (AwFmGpuIndex *lane : lanes.lanes) {
+    lane->dev.pairBlocks = g->dev.pairBlocks;
+    lane->dev.pairSuper = g->dev.pairSuper;
+    lane->dev.pairSuper32 = g->dev.pairSuper32;
+    lane->dev.pairC = g->dev.pairC;
+    lane->dev.numPairSuper = g->dev.numPairSuper;
+  }
+  return rc;
+}
+int awfmGpuIndexHasPairImage(const AwFmGpuIndex *g) { return g && g->dev.pairBlocks ? 1 : 0; }
+
 int awfmGpuIndexDevice(const AwFmGpuIndex *g) { return g ? g->device : -1; }
 void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel) {
   if (g) g->kernel = kernel;
@@ -900,6 +952,25 @@ enum AwFmReturnCode awfmGpuHitOffsetsFromCounts(AwFmGpuIndex *g, const uint32_t 
   return AwFmSuccess;
 }
 
+}  // extern "C"
+
+enum AwFmReturnCode awfmGpuHitOffsetsAsync(AwFmGpuIndex *g, const uint32_t *dCounts, const struct AwFmSearchRange *dRanges,
+                                           uint64_t numQueries, uint64_t *dHitOffsets, void *dScratch,
+                                           unsigned long long *pinnedTotal, hipStream_t s) {
+  if (!g || (!dCounts && !dRanges) || !dHitOffsets || !dScratch || !pinnedTotal || numQueries == 0) {
+    setError("awfmGpuHitOffsetsAsync: null argument");
+    return AwFmNullPtrError;
+  }
+  const enum AwFmReturnCode rc =
+      dCounts ? scanRecursive<kScanU32>(dCounts, numQueries, (unsigned long long *)dHitOffsets, (unsigned long long *)dScratch, s)
+              : scanRecursive<kScanRanges>(dRanges, numQueries, (unsigned long long *)dHitOffsets, (unsigned long long *)dScratch, s);
+  if (rc != AwFmSuccess) return rc;
+  AWFM_HIP_TRY(hipMemcpyAsync(pinnedTotal, dHitOffsets + numQueries, 8, hipMemcpyDeviceToHost, s), AwFmGeneralFailure);
+  return AwFmSuccess;
+}
+
+extern "C" {
+
 enum AwFmReturnCode awfmGpuLocate(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges,
                                   const uint64_t *dHitOffsets, uint64_t numQueries, uint64_t totalHits,
                                   uint64_t *dPositions, void *stream) {
@@ -951,6 +1022,17 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     }
     const bool pow2 = g->dev.saShift != 0xFFFFFFFFu;
     const bool narrow = awfmImageNarrow(g);
+    /* two LF steps per block read where the image has its pair blocks (awfm_pair.h); their 32-bit superblock bases are
+     * dynamic LDS */
+    const bool pair = !g->amino && lanes == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_LOCATE_NO_PAIR");
+    const bool superInLds = pair && narrow && awfmPairSuperInLds(g);
+    const size_t pairLds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
+    DevIndex pairDev = g->dev;
+    pairDev.pairSuperInLds = superInLds ? 1u : 0u;
+#define AWFM_LOCP(P2, NR)                                                                                                    \
+  hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true>),                                                                   \
+                     dim3(gridFor(th, g, walkKernel<false, 4, P2, NR, true>, walkThreads(true) / 4, pairLds, walkThreads(true))), \
+                     dim3(walkThreads(true)), pairLds, s, pairDev, th, pos)
 #define AWFM_LOC3(AM, GG, P2, NR)                                                                                  \
   hipLaunchKernelGGL((walkKernel<AM, GG, P2, NR>), dim3(gridFor(th, g, walkKernel<AM, GG, P2, NR>, kThreads / GG)), \
                      dim3(kThreads), 0, s, g->dev, th, pos)
@@ -961,7 +1043,12 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     else if (narrow) AWFM_LOC3(AM, GG, false, true);          \
     else AWFM_LOC3(AM, GG, false, false);                     \
   } while (0)
-    if (g->amino) {
+    if (pair) {
+      if (pow2 && narrow) AWFM_LOCP(true, true);
+      else if (pow2) AWFM_LOCP(true, false);
+      else if (narrow) AWFM_LOCP(false, true);
+      else AWFM_LOCP(false, false);
+    } else if (g->amino) {
       if (lanes == 4) AWFM_LOC(true, 4);
       else AWFM_LOC(true, 2);
     } else {
@@ -971,6 +1058,7 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     }
 #undef AWFM_LOC
 #undef AWFM_LOC3
+#undef AWFM_LOCP
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     hipLaunchKernelGGL(finishKernel, dim3((unsigned)(g->numCUs * 8)), dim3(256), 0, s, g->dev, th, pos);
   }

@@ -18,6 +18,7 @@
 namespace {
 
 inline size_t alignUp256(size_t v) { return (v + 255) / 256 * 256; }
+constexpr size_t kOrderCounterBytes = 32768; /* 256 B for the count + 8 XCDs x 8 waves x 256 B of ticket counters */
 
 struct OrderScratch {
   size_t keysIn, keysOut, recsIn, recsOut, generalCount, sortTemp, total;
@@ -26,8 +27,8 @@ struct OrderScratch {
 OrderScratch scratchLayout(uint64_t n, size_t recordBytes, size_t sortTempBytes) {
   OrderScratch l;
   size_t at = 0;
-  l.generalCount = at; /* word 0: the count; words 64, 128, ...: the ticket counters (8 XCDs x 4 waves) */
-  at += 16384;
+  l.generalCount = at; /* word 0: the count; words 64, 128, ...: the ticket counters (8 XCDs x up to 8 waves) */
+  at += kOrderCounterBytes;
   l.keysIn = at;
   at += alignUp256(n * sizeof(unsigned short));
   l.keysOut = at;
@@ -43,9 +44,9 @@ OrderScratch scratchLayout(uint64_t n, size_t recordBytes, size_t sortTempBytes)
 }
 
 template <class Kernel>
-unsigned residentGrid(const AwFmGpuIndex *g, Kernel kernel) {
+unsigned residentGrid(const AwFmGpuIndex *g, Kernel kernel, size_t dynamicLds = 0, int threads = kThreads) {
   int perCU = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, kThreads, 0) != hipSuccess || perCU < 1) perCU = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, threads, dynamicLds) != hipSuccess || perCU < 1) perCU = 4;
   if (perCU > 8) perCU = 8;
   if (const char *env = getenv("AWFM_GPU_BLOCKS_PER_CU")) {
     const int v = atoi(env);
@@ -54,12 +55,18 @@ unsigned residentGrid(const AwFmGpuIndex *g, Kernel kernel) {
   return (unsigned)g->numCUs * (unsigned)perCU;
 }
 
-template <int G, bool NARROW, bool COMPACT, bool VARLEN>
+template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false>
 enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t len, unsigned depth, const ulonglong2 *table,
                                         unsigned long long nq, const void *recs, const unsigned short *keys,
                                         const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts) {
-  unsigned grid = residentGrid(g, orderedSearchKernel<G, NARROW, COMPACT, VARLEN>);
-  const unsigned long long blocks = (nq + kThreads / G - 1) / (kThreads / G);
+  /* dynamic LDS: the 32-bit superblock bases of the pair image (images below 2^32 positions) */
+  const bool superInLds = PAIR && NARROW && awfmPairSuperInLds(g);
+  const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
+  DevIndex dev = g->dev;
+  dev.pairSuperInLds = superInLds ? 1u : 0u;
+  constexpr int threads = orderedThreads(PAIR);
+  unsigned grid = residentGrid(g, orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR>, lds, threads);
+  const unsigned long long blocks = (nq + threads / G - 1) / (threads / G);
   if (blocks < grid) grid = (unsigned)blocks;
   if (grid >= 8u) grid &= ~7u; /* a multiple of the 8 XCDs, so that every XCD gets the same number of workgroups */
   /* measurement hook (bench.py): HIP events around the dominant kernel on its launch stream */
@@ -69,7 +76,7 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
     AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[1]), AwFmGeneralFailure);
   }
   if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[0], s), AwFmGeneralFailure);
-  hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN>), dim3(grid ? grid : 1u), dim3(kThreads), 0, s, g->dev, recs,
+  hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR>), dim3(grid ? grid : 1u), dim3(threads), lds, s, dev, recs,
                      keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
                      getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
@@ -82,16 +89,19 @@ template <bool NARROW, bool COMPACT, bool VARLEN>
 enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                                   uint32_t len, unsigned depth, const ulonglong2 *table, unsigned long long nq,
                                   const void *recs, const unsigned short *keys, const unsigned *generalCount,
-                                  ulonglong2 *rng, uint32_t *dCounts) {
+                                  ulonglong2 *rng, uint32_t *dCounts, bool packed = false) {
   {
     const char *lanes = getenv("AWFM_GPU_ORDERED_LANES"); /* measurement knob: 1 | 2 | 4 lanes per query (default 4) */
     const int G = lanes ? atoi(lanes) : 4;
     enum AwFmReturnCode rc;
-    if (G == 2) rc = launchOrderedKernel<2, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
+    if (G == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR"))
+      rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN, true>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
+    else if (G == 2) rc = launchOrderedKernel<2, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
     else if (G == 1) rc = launchOrderedKernel<1, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
     else rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
     if (rc != AwFmSuccess) return rc;
   }
+  if (packed) return AwFmSuccess; /* bit-packed k-mers: every one of them is covered */
   /* the queries the fast path left out (ambiguity characters, empty or longer than 32; normally none): general
    * kernel over the tail of the order */
   const unsigned grid = residentGrid(g, searchKernel<false, 4, VARLEN, false, NARROW, true>);
@@ -152,9 +162,10 @@ extern "C" int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets,
 
 /* 1: the batch was searched; 0: the ordered path does not apply (caller runs the general kernel); <0: -AwFmReturnCode */
 int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
-                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts) {
+                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed) {
   unsigned depth = 0;
   const ulonglong2 *table = nullptr;
+  if (packed && off) return 0;
   if (!orderedApplies(g, off != nullptr, fixedLength, nq, &depth, &table)) return 0;
 
   std::lock_guard<std::mutex> lock(g->orderMutex);
@@ -208,15 +219,19 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
       return -(int)AwFmGeneralFailure;      \
     }                                       \
   } while (0)
-  ORDER_TRY(hipMemsetAsync(generalCount, 0, 16384, s)); /* the count and the ticket counters */
+  ORDER_TRY(hipMemsetAsync(generalCount, 0, kOrderCounterBytes, s)); /* the count and the ticket counters */
   hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s, rng, dCounts, nq);
   ORDER_TRY(hipGetLastError());
   const unsigned encodeGrid = (unsigned)((nq + 255) / 256);
   const unsigned seedK = g->dev.seedK, deepK = g->dev.deepK;
   size_t tempBytes = sortTemp;
   if (compact) {
-    hipLaunchKernelGGL((encodeQueriesKernel<true, false>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
-                       seedK, deepK, nq, keysIn, recsIn, generalCount);
+    if (packed)
+      hipLaunchKernelGGL((encodeQueriesKernel<true, false, true>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength,
+                         depth, seedK, deepK, nq, keysIn, recsIn, generalCount);
+    else
+      hipLaunchKernelGGL((encodeQueriesKernel<true, false>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
+                         seedK, deepK, nq, keysIn, recsIn, generalCount);
     ORDER_TRY(hipGetLastError());
     ORDER_TRY(rocprim::radix_sort_pairs(w + l.sortTemp, tempBytes, keysIn, keysOut, (unsigned long long *)recsIn,
                                         (unsigned long long *)recsOut, (size_t)nq, 0u, kOrderKeyBits, s));
@@ -224,6 +239,9 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
     if (off)
       hipLaunchKernelGGL((encodeQueriesKernel<false, true>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
                          seedK, deepK, nq, keysIn, recsIn, generalCount);
+    else if (packed)
+      hipLaunchKernelGGL((encodeQueriesKernel<false, false, true>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength,
+                         depth, seedK, deepK, nq, keysIn, recsIn, generalCount);
     else
       hipLaunchKernelGGL((encodeQueriesKernel<false, false>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
                          seedK, deepK, nq, keysIn, recsIn, generalCount);
@@ -234,7 +252,7 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   const bool narrow = awfmImageNarrow(g);
   enum AwFmReturnCode rc;
 #define ORDER_GO(NR, CP, VL) \
-  launchOrdered<NR, CP, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts)
+  launchOrdered<NR, CP, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts, packed)
   if (off) rc = narrow ? ORDER_GO(true, false, true) : ORDER_GO(false, false, true);
   else if (compact) rc = narrow ? ORDER_GO(true, true, false) : ORDER_GO(false, true, false);
   else rc = narrow ? ORDER_GO(true, false, false) : ORDER_GO(false, false, false);

@@ -1,0 +1,588 @@
+/*
+ * awfm_gpu_stream.hip -- the flat host-buffer batch API as a chunked, overlapped pipeline, with bit-packed k-mers.
+ *
+ * The reference hands a batch over as an array of structs (one kmerString pointer and one malloc'ed positionList
+ * per k-mer, ref src/AwFmParallelSearch.c:36-93, :367-387); packing that into something a device can read and
+ * scattering the answers back costs more host time than the search costs device time.  This entry point takes the
+ * batch flat instead: one 64-bit word per k-mer (2 bits per nucleotide, 5 bits per amino acid), or fixed-length
+ * ASCII, in one host array; results come back chunk by chunk through a callback, as 32-bit counts and one flat
+ * array of positions (the hits of k-mer i of the chunk follow those of k-mer i-1, in BWT order).
+ *
+ * Pipeline: the batch is cut into chunks of chunkKmers; three slots of device buffers and page-locked staging, each with
+ * its own stream.  For chunk t the calling thread
+ *   A(t)   enqueues the upload of the k-mers, search -> hit-offset scan -> total to the host,
+ *   B(t-1) waits for that total, enqueues expand + LF walk + sample read and the copies back,
+ *   C(t-2) waits for the copies and calls the sink,
+ * in that order in one loop, so that the upload of chunk t, the kernels of t-1 and the download of t-2 are all in flight
+ * and the sink runs on the host while the device works on the next two chunks.  What overlaps in practice (rocprofv3,
+ * MI355X, ROCm 7.2): host-to-device copies run on the DMA engines beside the kernels; device-to-host copies are executed
+ * as a shader copy (__amd_rocclr_copyBuffer) whatever the API variant or size, and a shader copy does not get onto the
+ * chip while a persistent search or walk kernel holds every CU -- so the downloads mostly alternate with the kernels:
+ * a batch costs about kernels + downloads (10^8 planted 21-mers: 26 ms + 1.2 GB / 55 GB/s), uploads and the host side
+ * are hidden.
+ *
+ * Device side of a chunk: awfmGpuSearchHits (ordered path for large nucleotide chunks) -> scan -> awfmGpuLocate,
+ * i.e. exactly the kernels of the device-buffer API; results are those of ref src/AwFmParallelSearch.c:95-365.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+
+#include "awfm_device.h"
+
+namespace {
+
+typedef unsigned long long u64;
+
+__constant__ unsigned char kUnpackDna[4] = {'a', 'c', 'g', 't'};
+/* letter index -> ASCII (ref src/AwFmLetter.c:55-67 maps the other way); 20.. = ambiguity */
+__constant__ unsigned char kUnpackAmino[32] = {'a', 'c', 'd', 'e', 'f', 'g', 'h', 'i', 'k', 'l', 'm', 'n', 'p', 'q', 'r', 's',
+                                               't', 'v', 'w', 'y', 'x', 'x', 'x', 'x', 'x', 'x', 'x', 'x', 'x', 'x', 'x', 'x'};
+
+/* packed words -> ASCII k-mers, one thread per character (coalesced byte stores; the word is read once per wave
+ * and a few times per cache line) */
+__global__ void __launch_bounds__(256)
+    unpackKmersKernel(const u64 *__restrict__ packed, unsigned len, u64 n, int amino, unsigned char *__restrict__ chars) {
+  /* a workgroup takes tiles of 256 k-mers (256 * len contiguous bytes); inside a tile the indices are small, so the
+   * division by the runtime length is a 32-bit multiply-high (exact for values below 2^13 and len <= 32) */
+  const unsigned bits = amino ? 5u : 2u;
+  const unsigned magic = len > 1u ? (unsigned)((0x100000000ull + len - 1u) / len) : 0u;
+  const u64 tiles = (n + 255ull) / 256ull;
+  for (u64 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const u64 first = tile * 256ull;
+    const unsigned inTile = n - first < 256ull ? (unsigned)(n - first) : 256u;
+    for (unsigned i = threadIdx.x; i < inTile * len; i += 256u) {
+      const unsigned j = len > 1u ? __umulhi(i, magic) : i, c = i - j * len;
+      const unsigned code = (unsigned)(packed[first + j] >> (bits * (len - 1u - c))) & (amino ? 31u : 3u);
+      chars[first * len + i] = amino ? kUnpackAmino[code] : kUnpackDna[code];
+    }
+  }
+}
+
+/* ASCII k-mers -> packed words, one thread per k-mer; bad[0] counts k-mers with a character the packing cannot
+ * express (those get the all-ones word) */
+__global__ void __launch_bounds__(256)
+    packKmersKernel(const unsigned char *__restrict__ chars, unsigned len, u64 n, int amino, u64 *__restrict__ packed,
+                    u64 *__restrict__ bad) {
+  const u64 j = (u64)blockIdx.x * 256ull + threadIdx.x;
+  if (j >= n) return;
+  u64 w = 0;
+  bool ok = true;
+  for (unsigned c = 0; c < len; c++) {
+    const unsigned ch = chars[j * len + c];
+    if (amino) {
+      const unsigned a = ch == '$' ? 21u : (unsigned)kAminoTables.letterOfAscii[ch & 31u]; /* as the ASCII API maps it */
+      ok &= a < 20u;
+      w = (w << 5) | (a & 31u);
+    } else {
+      ok &= (nucIsAcgtu(ch) & 1u) != 0u;
+      w = (w << 2) | (nucLetterIndex(ch) & 3u);
+    }
+  }
+  packed[j] = ok ? w : ~0ull;
+  if (!ok) atomicAdd(bad, 1ull);
+}
+
+struct StreamSlot {
+  hipEvent_t uploaded = nullptr, searched = nullptr, located = nullptr, done = nullptr, doneB = nullptr;
+  /* device */
+  void *dIn = nullptr;       /* packed words or ASCII as uploaded */
+  void *dChars = nullptr;    /* ASCII the search reads (packed input only) */
+  void *dRanges = nullptr, *dCounts = nullptr, *dHitOffsets = nullptr, *dScratch = nullptr;
+  size_t capKmers = 0, capChars = 0;
+  void *dPositions = nullptr;
+  size_t capPositions = 0;
+  /* page-locked host */
+  void *hIn = nullptr;
+  size_t hInBytes = 0;
+  uint32_t *hCounts = nullptr;
+  u64 *hTotal = nullptr;
+  u64 *hPositions = nullptr;
+  size_t hCapPositions = 0;
+  /* the chunk in the slot */
+  u64 first = 0, n = 0, total = 0;
+};
+
+}  // namespace
+
+constexpr int kStreamSlots = 3; /* chunk t uploads and searches, t-1 walks and downloads, t-2 is with the caller */
+
+struct AwFmGpuStreamState {
+  /* downloads: one stream per slot and a second one for the upper half of a large copy -- a single stream moves
+   * device-to-host bytes at well under half the rate the link gives several (measured: 10^8 planted 21-mers, 1.2 GB
+   * back, 69 ms through one download stream against 36 ms) */
+  hipStream_t copyIn = nullptr, compute = nullptr, copyOut[kStreamSlots] = {}, copyOutB = nullptr;
+  hipStream_t slotStream[kStreamSlots] = {}; /* $AWFM_GPU_STREAM_MODE=slots: everything of a chunk on its slot's stream */
+  StreamSlot slot[kStreamSlots];
+};
+
+namespace {
+
+void freeSlot(StreamSlot &s) {
+  void *dev[] = {s.dIn, s.dChars, s.dRanges, s.dCounts, s.dHitOffsets, s.dScratch, s.dPositions};
+  for (void *p : dev)
+    if (p) (void)hipFree(p);
+  void *host[] = {s.hIn, s.hCounts, s.hTotal, s.hPositions};
+  for (void *p : host)
+    if (p) (void)hipHostFree(p);
+  hipEvent_t events[] = {s.uploaded, s.searched, s.located, s.done, s.doneB};
+  for (hipEvent_t e : events)
+    if (e) (void)hipEventDestroy(e);
+  s = StreamSlot();
+}
+
+#define STREAM_TRY(call)                   \
+  do {                                     \
+    hipError_t e__ = (call);               \
+    if (e__ != hipSuccess) {               \
+      setError(#call, e__);                \
+      return AwFmGeneralFailure;           \
+    }                                      \
+  } while (0)
+
+/* (re)allocations happen while nothing of this slot is in flight: its previous chunk was handed to the sink */
+enum AwFmReturnCode ensureSlot(StreamSlot &s, size_t kmers, size_t inBytesPerKmer, size_t charsPerKmer, bool locate,
+                               bool stageInput) {
+  if (!s.done) {
+    STREAM_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
+    STREAM_TRY(hipEventCreateWithFlags(&s.searched, hipEventDisableTiming));
+    STREAM_TRY(hipEventCreateWithFlags(&s.located, hipEventDisableTiming));
+    STREAM_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    STREAM_TRY(hipEventCreateWithFlags(&s.doneB, hipEventDisableTiming));
+    STREAM_TRY(hipHostMalloc((void **)&s.hTotal, 64, hipHostMallocDefault));
+  }
+  const size_t chars = kmers * charsPerKmer;
+  if (kmers > s.capKmers || chars > s.capChars) {
+    void **dev[] = {&s.dIn, &s.dChars, &s.dRanges, &s.dCounts, &s.dHitOffsets, &s.dScratch};
+    for (void **p : dev) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    if (s.hCounts) (void)hipHostFree(s.hCounts);
+    s.hCounts = nullptr;
+    s.capKmers = s.capChars = 0;
+    const size_t inBytes = kmers * (inBytesPerKmer > 8 ? inBytesPerKmer : 8);
+    STREAM_TRY(hipMalloc(&s.dIn, inBytes + 256));
+    STREAM_TRY(hipMalloc(&s.dChars, chars + 256));
+    STREAM_TRY(hipMalloc(&s.dRanges, kmers * 16 + 256));
+    STREAM_TRY(hipMalloc(&s.dCounts, kmers * 4 + 256));
+    STREAM_TRY(hipMalloc(&s.dHitOffsets, (kmers + 1) * 8 + 256));
+    STREAM_TRY(hipMalloc(&s.dScratch, awfmGpuScanScratchBytes(kmers) + 256));
+    STREAM_TRY(hipHostMalloc((void **)&s.hCounts, kmers * 4 + 256, hipHostMallocDefault));
+    s.capKmers = kmers;
+    s.capChars = chars;
+  }
+  (void)locate;
+  if (stageInput && kmers * inBytesPerKmer > s.hInBytes) {
+    if (s.hIn) (void)hipHostFree(s.hIn);
+    s.hIn = nullptr;
+    s.hInBytes = 0;
+    STREAM_TRY(hipHostMalloc(&s.hIn, kmers * inBytesPerKmer + 256, hipHostMallocDefault));
+    s.hInBytes = kmers * inBytesPerKmer;
+  }
+  return AwFmSuccess;
+}
+
+enum AwFmReturnCode ensurePositions(StreamSlot &s, u64 total) {
+  if (total > s.capPositions) {
+    if (s.dPositions) (void)hipFree(s.dPositions);
+    s.dPositions = nullptr;
+    s.capPositions = 0;
+    const size_t want = total + total / 4 + 1024;
+    hipError_t e = hipMalloc(&s.dPositions, want * 8);
+    if (e != hipSuccess) {
+      setError("awfmGpuStream: hipMalloc of the positions of a chunk failed (use smaller chunks)", e);
+      return AwFmAllocationFailure;
+    }
+    s.capPositions = want;
+  }
+  if (total > s.hCapPositions) {
+    if (s.hPositions) (void)hipHostFree(s.hPositions);
+    s.hPositions = nullptr;
+    s.hCapPositions = 0;
+    const size_t want = total + total / 4 + 1024;
+    hipError_t e = hipHostMalloc((void **)&s.hPositions, want * 8, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      setError("awfmGpuStream: hipHostMalloc of the positions of a chunk failed (use smaller chunks)", e);
+      return AwFmAllocationFailure;
+    }
+    s.hCapPositions = want;
+  }
+  return AwFmSuccess;
+}
+
+struct CopyCtx {
+  const uint8_t *src;
+  uint8_t *dst;
+};
+void copyRange(void *p, uint64_t begin, uint64_t end, unsigned tid) {
+  (void)tid;
+  const CopyCtx *c = (const CopyCtx *)p;
+  memcpy(c->dst + begin, c->src + begin, end - begin);
+}
+
+/* is this host pointer page-locked memory HIP knows (hipHostMalloc / hipHostRegister)?  Then the DMA engine reads
+ * it directly; anything else goes through the slot's staging buffer first. */
+bool isPinned(const void *p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
+}  // namespace
+
+void awfmGpuStreamStateFree(AwFmGpuIndex *g) {
+  if (!g || !g->streamState) return;
+  AwFmGpuStreamState &state = *g->streamState;
+  hipStream_t streams[] = {state.copyIn, state.compute, state.copyOut[0], state.copyOut[1], state.copyOut[2], state.copyOutB,
+                           state.slotStream[0], state.slotStream[1], state.slotStream[2]};
+  for (hipStream_t s : streams)
+    if (s) {
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamDestroy(s);
+    }
+  for (StreamSlot &s : g->streamState->slot) freeSlot(s);
+  delete g->streamState;
+  g->streamState = nullptr;
+}
+
+extern "C" {
+
+void *awfmGpuHostAlloc(uint64_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    setError("awfmGpuHostAlloc: hipHostMalloc failed");
+    return nullptr;
+  }
+  return p;
+}
+void awfmGpuHostFree(void *p) {
+  if (p) (void)hipHostFree(p);
+}
+
+enum AwFmReturnCode awfmGpuUnpackKmers(AwFmGpuIndex *g, const uint64_t *dPacked, uint32_t kmerLength, uint64_t numKmers,
+                                       uint8_t *dChars, void *stream) {
+  if (!g || !dPacked || !dChars) {
+    setError("awfmGpuUnpackKmers: null argument");
+    return AwFmNullPtrError;
+  }
+  if (kmerLength == 0 || kmerLength > (g->amino ? 12u : 32u)) {
+    setError("awfmGpuUnpackKmers: a packed k-mer holds 1..32 nucleotides or 1..12 amino acids");
+    return AwFmIllegalPositionError;
+  }
+  if (numKmers == 0) return AwFmSuccess;
+  DeviceGuard guard(g->device);
+  hipLaunchKernelGGL(unpackKmersKernel, dim3((unsigned)g->numCUs * 16u), dim3(256), 0, (hipStream_t)stream, (const u64 *)dPacked,
+                     kmerLength, (u64)numKmers, g->amino ? 1 : 0, dChars);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  return AwFmSuccess;
+}
+
+enum AwFmReturnCode awfmGpuPackKmers(AwFmGpuIndex *g, const uint8_t *dChars, uint32_t kmerLength, uint64_t numKmers,
+                                     uint64_t *dPacked, uint64_t *numUnpackable, void *stream) {
+  if (!g || !dPacked || !dChars) {
+    setError("awfmGpuPackKmers: null argument");
+    return AwFmNullPtrError;
+  }
+  if (kmerLength == 0 || kmerLength > (g->amino ? 12u : 32u)) {
+    setError("awfmGpuPackKmers: a packed k-mer holds 1..32 nucleotides or 1..12 amino acids");
+    return AwFmIllegalPositionError;
+  }
+  if (numUnpackable) *numUnpackable = 0;
+  if (numKmers == 0) return AwFmSuccess;
+  DeviceGuard guard(g->device);
+  hipStream_t s = (hipStream_t)stream;
+  u64 *dBad = nullptr;
+  AWFM_HIP_TRY(hipMalloc((void **)&dBad, 8), AwFmAllocationFailure);
+  hipError_t e = hipMemsetAsync(dBad, 0, 8, s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(packKmersKernel, dim3((unsigned)((numKmers + 255) / 256)), dim3(256), 0, s, dChars, kmerLength,
+                       (u64)numKmers, g->amino ? 1 : 0, (u64 *)dPacked, dBad);
+    e = hipGetLastError();
+  }
+  u64 bad = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&bad, dBad, 8, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(dBad);
+  if (e != hipSuccess) {
+    setError("awfmGpuPackKmers", e);
+    return AwFmGeneralFailure;
+  }
+  if (numUnpackable) *numUnpackable = bad;
+  return AwFmSuccess;
+}
+
+/* Hits-only search of bit-packed k-mers resident on the device: nucleotide batches the seed-order path takes are
+ * searched straight from the packed words (they are its record format); anything else is unpacked into dCharsScratch
+ * (kmerLength bytes per k-mer) and searched as ASCII. */
+enum AwFmReturnCode awfmGpuSearchHitsPacked(AwFmGpuIndex *g, const uint64_t *dPacked, uint32_t kmerLength, uint64_t numKmers,
+                                            struct AwFmSearchRange *dRanges, uint32_t *dCounts, uint8_t *dCharsScratch,
+                                            void *stream) {
+  if (!g || (!dPacked && numKmers)) {
+    setError("awfmGpuSearchHitsPacked: null argument");
+    return AwFmNullPtrError;
+  }
+  if (kmerLength == 0 || kmerLength > (g->amino ? 12u : 32u)) {
+    setError("awfmGpuSearchHitsPacked: a packed k-mer holds 1..32 nucleotides or 1..12 amino acids");
+    return AwFmIllegalPositionError;
+  }
+  if (numKmers == 0) return AwFmSuccess;
+  if (!g->amino && (g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) {
+    DeviceGuard guard(g->device);
+    const int ordered = awfmGpuOrderedSearch(g, (hipStream_t)stream, (const uint8_t *)dPacked, nullptr, kmerLength, numKmers,
+                                             (ulonglong2 *)dRanges, dCounts, true);
+    if (ordered < 0) return (enum AwFmReturnCode)(-ordered);
+    if (ordered > 0) return AwFmSuccess;
+  }
+  if (!dCharsScratch) {
+    setError("awfmGpuSearchHitsPacked: this batch is searched as ASCII and needs dCharsScratch");
+    return AwFmNullPtrError;
+  }
+  const enum AwFmReturnCode rc = awfmGpuUnpackKmers(g, dPacked, kmerLength, numKmers, dCharsScratch, stream);
+  if (rc != AwFmSuccess) return rc;
+  return awfmGpuSearchHits(g, dCharsScratch, nullptr, kmerLength, numKmers, dRanges, dCounts, stream);
+}
+
+/* the pipeline; packed != 0: `input` is one 64-bit word per k-mer, else kmerLength ASCII characters per k-mer */
+static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int packed, uint32_t kmerLength,
+                                       uint64_t numKmers, uint64_t chunkKmers, int locate, unsigned hostThreads,
+                                       AwFmGpuChunkSink sink, void *user) {
+  if (!g || (!input && numKmers) || !sink) {
+    setError("awfmGpuStream: null argument");
+    return AwFmNullPtrError;
+  }
+  if (kmerLength == 0 || (packed && kmerLength > (g->amino ? 12u : 32u))) {
+    setError("awfmGpuStream: a packed k-mer holds 1..32 nucleotides or 1..12 amino acids");
+    return AwFmIllegalPositionError;
+  }
+  if (numKmers == 0) return AwFmSuccess;
+  if (g->shares) g = g->shares; /* lanes have no pipeline of their own */
+  if (chunkKmers == 0) chunkKmers = 1ull << 24;
+  if (chunkKmers > numKmers) chunkKmers = numKmers;
+  if (chunkKmers >= 0xFFFFFFFFull) chunkKmers = 0xFFFFFFFEull;
+  if (hostThreads == 0) hostThreads = 4;
+  DeviceGuard guard(g->device);
+  std::lock_guard<std::mutex> lock(g->streamMutex);
+  if (!g->streamState) g->streamState = new AwFmGpuStreamState();
+  AwFmGpuStreamState &st = *g->streamState;
+  StreamSlot *slots = st.slot;
+  if (!st.compute) {
+    STREAM_TRY(hipStreamCreateWithFlags(&st.copyIn, hipStreamNonBlocking));
+    STREAM_TRY(hipStreamCreateWithFlags(&st.compute, hipStreamNonBlocking));
+    for (int i = 0; i < kStreamSlots; i++) STREAM_TRY(hipStreamCreateWithFlags(&st.copyOut[i], hipStreamNonBlocking));
+    STREAM_TRY(hipStreamCreateWithFlags(&st.copyOutB, hipStreamNonBlocking));
+    for (int i = 0; i < kStreamSlots; i++) STREAM_TRY(hipStreamCreateWithFlags(&st.slotStream[i], hipStreamNonBlocking));
+  }
+  /* $AWFM_GPU_STREAM_MODE=split: one upload stream, one kernel stream, download streams; default: everything of a
+   * chunk on its slot's own stream (measured, 10^8 planted 21-mers located: 43-58 ms against 60 ms; random ones 23-25
+   * against 22.8 ms) */
+  const char *modeEnv = getenv("AWFM_GPU_STREAM_MODE");
+  const bool perSlot = !(modeEnv && !strcmp(modeEnv, "split"));
+  const size_t inBytesPerKmer = packed ? 8 : kmerLength;
+  const bool stage = !isPinned(input);
+  const bool narrowCounts = g->dev.bwtLength < (1ull << 32);
+  const u64 numChunks = (numKmers + chunkKmers - 1) / chunkKmers;
+  enum AwFmReturnCode rc = AwFmSuccess;
+  auto drain = [&]() {
+    (void)hipStreamSynchronize(st.copyIn);
+    (void)hipStreamSynchronize(st.compute);
+    for (int i = 0; i < kStreamSlots; i++) (void)hipStreamSynchronize(st.copyOut[i]);
+    (void)hipStreamSynchronize(st.copyOutB);
+    for (int i = 0; i < kStreamSlots; i++) (void)hipStreamSynchronize(st.slotStream[i]);
+  };
+#define STEP_TRY(call)                    \
+  do {                                    \
+    hipError_t e__ = (call);              \
+    if (e__ != hipSuccess) {              \
+      setError(#call, e__);               \
+      drain();                            \
+      return AwFmGeneralFailure;          \
+    }                                     \
+  } while (0)
+#define STEP_RC(call)          \
+  do {                         \
+    rc = (call);               \
+    if (rc != AwFmSuccess) {   \
+      drain();                 \
+      return rc;               \
+    }                          \
+  } while (0)
+
+  const bool trace = getenv("AWFM_GPU_STREAM_TRACE") != nullptr; /* host-side timeline of the loop on stderr */
+  struct timespec ts0;
+  clock_gettime(CLOCK_MONOTONIC, &ts0);
+  auto now = [&]() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (ts.tv_sec - ts0.tv_sec) * 1e3 + (ts.tv_nsec - ts0.tv_nsec) * 1e-6;
+  };
+  const u64 lag = 2; /* a deeper loop (four slots, the sink three chunks behind) measured no faster */
+  for (u64 t = 0; t < numChunks + lag; t++) {
+    if (trace) fprintf(stderr, "[stream] t=%llu start %.2f ms\n", (unsigned long long)t, now());
+    if (t < numChunks) { /* ---- A(t): upload; search, scan ---- */
+      StreamSlot &s = slots[t % kStreamSlots];
+      s.first = t * chunkKmers;
+      s.n = numKmers - s.first < chunkKmers ? numKmers - s.first : chunkKmers;
+      s.total = 0;
+      STEP_RC(ensureSlot(s, chunkKmers, inBytesPerKmer, kmerLength, locate != 0, stage));
+      const uint8_t *src = (const uint8_t *)input + s.first * inBytesPerKmer;
+      const size_t bytes = s.n * inBytesPerKmer;
+      if (stage) {
+        CopyCtx ctx = {src, (uint8_t *)s.hIn};
+        awfmParallelFor(hostThreads, bytes, copyRange, &ctx);
+        src = (const uint8_t *)s.hIn;
+      }
+      hipStream_t in = perSlot ? st.slotStream[t % kStreamSlots] : st.copyIn, comp = perSlot ? st.slotStream[t % kStreamSlots] : st.compute;
+      STEP_TRY(hipMemcpyAsync(s.dIn, src, bytes, hipMemcpyHostToDevice, in));
+      STEP_TRY(hipEventRecord(s.uploaded, in));
+      STEP_TRY(hipStreamWaitEvent(comp, s.uploaded, 0));
+      if (packed)
+        STEP_RC(awfmGpuSearchHitsPacked(g, (const uint64_t *)s.dIn, kmerLength, s.n,
+                                        locate ? (struct AwFmSearchRange *)s.dRanges : nullptr, (uint32_t *)s.dCounts,
+                                        (uint8_t *)s.dChars, comp));
+      else
+        STEP_RC(awfmGpuSearchHits(g, (const uint8_t *)s.dIn, nullptr, kmerLength, s.n,
+                                  locate ? (struct AwFmSearchRange *)s.dRanges : nullptr, (uint32_t *)s.dCounts, comp));
+      if (locate)
+        STEP_RC(awfmGpuHitOffsetsAsync(g, narrowCounts ? (const uint32_t *)s.dCounts : nullptr,
+                                       (const struct AwFmSearchRange *)s.dRanges, s.n, (uint64_t *)s.dHitOffsets, s.dScratch,
+                                       s.hTotal, comp));
+      STEP_TRY(hipEventRecord(s.searched, comp));
+    }
+    if (t >= 1 && t - 1 < numChunks) { /* ---- B(t-1): locate; download ---- */
+      StreamSlot &s = slots[(t - 1) % kStreamSlots];
+      hipStream_t out = perSlot ? st.slotStream[(t - 1) % kStreamSlots] : st.copyOut[(t - 1) % kStreamSlots];
+      hipStream_t comp = perSlot ? st.slotStream[(t - 1) % kStreamSlots] : st.compute;
+      bool split = false;
+      if (locate) {
+        STEP_TRY(hipEventSynchronize(s.searched));
+        if (trace) fprintf(stderr, "[stream] t=%llu searched(%llu) seen %.2f ms\n", (unsigned long long)t, (unsigned long long)(t - 1), now());
+        s.total = *s.hTotal;
+        if (s.total) {
+          STEP_RC(ensurePositions(s, s.total));
+          STEP_RC(awfmGpuLocate(g, (const struct AwFmSearchRange *)s.dRanges, (const uint64_t *)s.dHitOffsets, s.n, s.total,
+                                (uint64_t *)s.dPositions, comp));
+        }
+        STEP_TRY(hipEventRecord(s.located, comp));
+        if (getenv("AWFM_GPU_STREAM_HOSTWAIT")) STEP_TRY(hipEventSynchronize(s.located));
+        else STEP_TRY(hipStreamWaitEvent(out, s.located, 0));
+        split = !perSlot && s.total >= (1ull << 20);
+        const u64 lower = split ? s.total / 2 : s.total;
+        if (lower) STEP_TRY(hipMemcpyAsync(s.hPositions, s.dPositions, lower * 8, hipMemcpyDeviceToHost, out));
+        if (split) {
+          STEP_TRY(hipStreamWaitEvent(st.copyOutB, s.located, 0));
+          STEP_TRY(hipMemcpyAsync(s.hPositions + lower, (const u64 *)s.dPositions + lower, (s.total - lower) * 8,
+                                  hipMemcpyDeviceToHost, st.copyOutB));
+          STEP_TRY(hipEventRecord(s.doneB, st.copyOutB));
+          STEP_TRY(hipStreamWaitEvent(out, s.doneB, 0)); /* `done` covers both halves */
+        }
+      } else {
+        STEP_TRY(hipStreamWaitEvent(out, s.searched, 0));
+      }
+      STEP_TRY(hipMemcpyAsync(s.hCounts, s.dCounts, s.n * 4, hipMemcpyDeviceToHost, out));
+      STEP_TRY(hipEventRecord(s.done, out));
+    }
+    if (t >= lag) { /* ---- C(t-lag): hand the chunk to the caller ---- */
+      StreamSlot &s = slots[(t - lag) % kStreamSlots];
+      STEP_TRY(hipEventSynchronize(s.done));
+      if (trace) fprintf(stderr, "[stream] t=%llu done(%llu) seen %.2f ms\n", (unsigned long long)t, (unsigned long long)(t - lag), now());
+      if (sink(user, s.first, s.n, s.hCounts, locate ? (const uint64_t *)s.hPositions : nullptr, s.total) != 0) {
+        setError("awfmGpuStream: the sink asked to stop");
+        drain();
+        return AwFmGeneralFailure;
+      }
+    }
+  }
+#undef STEP_TRY
+#undef STEP_RC
+  return rc;
+}
+
+enum AwFmReturnCode awfmGpuStreamPacked(AwFmGpuIndex *g, const uint64_t *packedKmers, uint32_t kmerLength,
+                                        uint64_t numKmers, uint64_t chunkKmers, int locate, unsigned hostThreads,
+                                        AwFmGpuChunkSink sink, void *user) {
+  return streamBatch(g, packedKmers, 1, kmerLength, numKmers, chunkKmers, locate, hostThreads, sink, user);
+}
+
+enum AwFmReturnCode awfmGpuStreamChars(AwFmGpuIndex *g, const uint8_t *chars, uint32_t kmerLength, uint64_t numKmers,
+                                       uint64_t chunkKmers, int locate, unsigned hostThreads, AwFmGpuChunkSink sink,
+                                       void *user) {
+  return streamBatch(g, chars, 0, kmerLength, numKmers, chunkKmers, locate, hostThreads, sink, user);
+}
+
+/* ---- whole-batch convenience on top of the pipeline: results gathered into caller arrays ---- */
+struct GatherCtx {
+  uint32_t *counts;
+  uint64_t *positions;
+  uint64_t capacity, used;
+  unsigned threads;
+  int failed;
+};
+static int gatherSink(void *user, uint64_t first, uint64_t n, const uint32_t *counts, const uint64_t *positions,
+                      uint64_t numPositions) {
+  GatherCtx *c = (GatherCtx *)user;
+  {
+    CopyCtx ctx = {(const uint8_t *)counts, (uint8_t *)(c->counts + first)};
+    awfmParallelFor(c->threads, n * 4, copyRange, &ctx);
+  }
+  if (positions && numPositions) {
+    if (c->used + numPositions > c->capacity) {
+      const uint64_t want = (c->used + numPositions) * 2;
+      uint64_t *grown = (uint64_t *)realloc(c->positions, want * 8);
+      if (!grown) {
+        c->failed = 1;
+        return 1;
+      }
+      c->positions = grown;
+      c->capacity = want;
+    }
+    CopyCtx ctx = {(const uint8_t *)positions, (uint8_t *)(c->positions + c->used)};
+    awfmParallelFor(c->threads, numPositions * 8, copyRange, &ctx);
+    c->used += numPositions;
+  }
+  return 0;
+}
+
+enum AwFmReturnCode awfmGpuCountPackedHost(AwFmGpuIndex *g, const uint64_t *packedKmers, uint32_t kmerLength,
+                                           uint64_t numKmers, uint32_t *counts) {
+  if (!counts && numKmers) {
+    setError("awfmGpuCountPackedHost: null argument");
+    return AwFmNullPtrError;
+  }
+  GatherCtx ctx = {counts, nullptr, 0, 0, 4, 0};
+  return awfmGpuStreamPacked(g, packedKmers, kmerLength, numKmers, 0, 0, 4, gatherSink, &ctx);
+}
+
+enum AwFmReturnCode awfmGpuLocatePackedHost(AwFmGpuIndex *g, const uint64_t *packedKmers, uint32_t kmerLength,
+                                            uint64_t numKmers, uint32_t *counts, uint64_t **positions,
+                                            uint64_t *numPositions) {
+  if ((!counts && numKmers) || !positions || !numPositions) {
+    setError("awfmGpuLocatePackedHost: null argument");
+    return AwFmNullPtrError;
+  }
+  *positions = nullptr;
+  *numPositions = 0;
+  GatherCtx ctx = {counts, (uint64_t *)malloc(8 * (numKmers + 16)), numKmers + 16, 0, 4, 0};
+  if (!ctx.positions) {
+    setError("awfmGpuLocatePackedHost: host allocation failed");
+    return AwFmAllocationFailure;
+  }
+  const enum AwFmReturnCode rc = awfmGpuStreamPacked(g, packedKmers, kmerLength, numKmers, 0, 1, 4, gatherSink, &ctx);
+  if (rc != AwFmSuccess || ctx.failed) {
+    free(ctx.positions);
+    if (ctx.failed) setError("awfmGpuLocatePackedHost: host allocation failed");
+    return ctx.failed ? AwFmAllocationFailure : rc;
+  }
+  *positions = ctx.positions;
+  *numPositions = ctx.used;
+  return AwFmSuccess;
+}
+
+}  // extern "C"

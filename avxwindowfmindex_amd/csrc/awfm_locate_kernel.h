@@ -22,6 +22,7 @@
 #define AWFM_LOCATE_KERNEL_H
 
 #include "awfm_search_kernel.h"
+#include "awfm_pair.h"
 
 namespace {
 
@@ -51,19 +52,29 @@ __device__ __forceinline__ unsigned long long finishPosition(const DevIndex &ix,
   return v;
 }
 
-template <bool AMINO, int G, bool POW2, bool NARROW>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
+/* workgroup size: 512 threads for the pair variant, whose LDS copy of the pair image's superblock bases (24 KB for a
+ * GRCh38-sized index) would otherwise limit a CU to 6 workgroups of 256 */
+constexpr int walkThreads(bool pair) { return pair ? 512 : kThreads; }
+
+template <bool AMINO, int G, bool POW2, bool NARROW, bool PAIR = false>
+__global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80)))
     walkKernel(const DevIndex ix, unsigned long long totalHits, unsigned long long *__restrict__ positions) {
+  static_assert(!PAIR || (!AMINO && G == 4), "pair steps: nucleotide images, 4 lanes per hit");
   constexpr int S = (int)kSlices / G;
   constexpr int V = AMINO ? 2 : 1;
-  constexpr int kGroups = kThreads / G;
+  constexpr int kGroups = walkThreads(PAIR) / G;
   typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
   __shared__ AminoShared sAmino;
   __shared__ unsigned long long sSuper[!AMINO && !NARROW ? kMaxNucSuper * 4 : 1];
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  /* PAIR: two LF steps per block read through the pair image (awfm_pair.h) wherever the position's block is not
+   * flagged and the position in between is not a sampled one */
+  __shared__ unsigned long long sPairC[PAIR ? 16 : 1];
+  extern __shared__ unsigned sPairSuper[];
   if (AMINO) aminoStageTables(sAmino);
   if (!AMINO) nucStageSuper<NARROW>(ix, sSuper);
+  if (PAIR) pairStageTables<NARROW>(ix, sPairC, sPairSuper);
   __syncthreads();
   const unsigned gl = threadIdx.x % G;
   const unsigned firstSlice = gl * S;
@@ -121,7 +132,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
     return (pos_t)(((unsigned long long)groupShfl<G>((unsigned)(mine >> 32), j / kPerLane) << 32) | lo);
   };
 
-  unsigned long long batchBase = (((unsigned long long)blockIdx.x * kThreads + threadIdx.x) / G) * kBatch;
+  unsigned long long batchBase = (((unsigned long long)blockIdx.x * walkThreads(PAIR) + threadIdx.x) / G) * kBatch;
   bool alive = batchBase < totalHits;
   Four slot = {0ull, 0ull, 0ull, 0ull}, nslot = {0ull, 0ull, 0ull, 0ull};
   unsigned cnt = 0, j = 0;
@@ -159,7 +170,36 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
       steps = 0;
       sampled = POW2 ? (p & (ratio - 1)) == 0 : (p % ratio) == 0;
     }
-    const bool walk = alive && !sampled; /* a refilled hit that is sampled right away is handed over next iteration */
+    bool walk = alive && !sampled; /* a refilled hit that is sampled right away is handed over next iteration */
+    if (PAIR) {
+      const unsigned long long pblk = (unsigned long long)(p >> kBlockShift);
+      const unsigned plocal = (unsigned)p & kBlockMask;
+      Piece pl = (Piece)(0u), ph = (Piece)(0u);
+      if (walk) {
+        const Piece *at = (const Piece *)(ix.pairBlocks + (pblk * 8ull + 2u * gl));
+        pl = at[0];
+        ph = at[1];
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */
+      if (walk) {
+        const unsigned bit = plocal & 31u, ownerSlice = plocal >> 5;
+        /* pair code at p and "LF(p) is sampled", from the lane that owns p's slice */
+        const unsigned mine = ((pl.x >> bit) & 1u) | (((pl.y >> bit) & 1u) << 1) | (((pl.z >> bit) & 1u) << 2) |
+                              (((pl.w >> bit) & 1u) << 3) | (((ph.x >> bit) & 1u) << 4);
+        const unsigned got = groupShfl<G>(mine, ownerSlice);
+        const unsigned pi = got & 15u;
+        const bool single = ((ph.w >> 31) | (got >> 4)) != 0u; /* flagged block, or the walk must look at LF(p) */
+        const unsigned n = __popc(pairOccSlice(pl, 0u - (pi & 1u), 0u - ((pi >> 1) & 1u), 0u - ((pi >> 2) & 1u), 0u - (pi >> 3)) &
+                                  sliceMask(plocal, gl));
+        const unsigned base = groupShfl<G>(pairCount24(ph, pi & 3u), pi >> 2);
+        const unsigned total = groupSum<G>(n);
+        if (!single) {
+          p = (pos_t)sPairC[pi] + pairSuperBase<NARROW>(ix, sPairSuper, (unsigned long long)p, pi) + (pos_t)base + (pos_t)total - (pos_t)1;
+          steps += 2;
+          walk = false;
+        }
+      }
+    }
     const unsigned long long blk = (unsigned long long)(p >> kBlockShift);
     const unsigned local = (unsigned)p & kBlockMask;
     Piece pc[S][V];

@@ -33,6 +33,7 @@
 #define AWFM_ORDERED_KERNEL_H
 
 #include "awfm_search_kernel.h"
+#include "awfm_pair.h"
 
 namespace {
 
@@ -113,7 +114,9 @@ __host__ __device__ inline unsigned orderStartDepth(unsigned len, unsigned seedK
  * k-mer that starts below a table is the leading bits of the k-mer itself, which is where its letter-range
  * search ends up in the BWT.  K-mers the ordered kernel does not cover (ambiguity characters, no characters,
  * more than 32) get the general key. */
-template <bool COMPACT, bool VARLEN>
+/* PACKED: `chars` is one 64-bit word per k-mer (2-bit codes, last character in bits 1..0: the record's own format;
+ * include/awfm_gpu.h), fixed length: nothing to decode, and no k-mer is left to the general kernel */
+template <bool COMPACT, bool VARLEN, bool PACKED = false>
 __global__ void __launch_bounds__(256)
     encodeQueriesKernel(const unsigned char *__restrict__ chars, const unsigned long long *__restrict__ offsets,
                         const unsigned fixedLen, const unsigned fixedDepth, const unsigned seedK, const unsigned deepK,
@@ -133,7 +136,12 @@ __global__ void __launch_bounds__(256)
     }
   }
   const bool inRange = live && len >= 1u && len <= 32u;
-  if (inRange) {
+  if (PACKED) {
+    if (inRange) {
+      const unsigned long long word = ((const unsigned long long *)chars)[t];
+      codes = len >= 32u ? word : (word & ((1ull << (2u * len)) - 1ull));
+    }
+  } else if (inRange) {
     /* aligned dwords that hold the query's bytes; a dword is only read when it contains one of them */
     const unsigned long long at = (unsigned long long)chars + start;
     const unsigned *first = (const unsigned *)(at & ~3ull);
@@ -188,8 +196,13 @@ __global__ void __launch_bounds__(256)
  * comes from a 16-byte record (read one iteration ahead) and only a non-empty final range is stored, under the
  * original query number.
  */
-template <int G, bool NARROW, bool COMPACT, bool VARLEN>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? 8 : 2, 8)))
+/* workgroup size: the pair variant keeps the 32-bit superblock bases of the pair image in LDS (64 B per 2^23 positions:
+ * 24 KB for a GRCh38-sized index), so it runs as 4 workgroups of 512 threads per CU instead of 8 of 256 -- the same 8
+ * waves per SIMD with half the copies of the table */
+constexpr int orderedThreads(bool pair) { return pair ? 256 : kThreads; }
+
+template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false>
+__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? 8 : 2, 8)))
     orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
                         const unsigned long long numRecs,
                         const unsigned *__restrict__ generalCount, const unsigned len, const unsigned depth,
@@ -200,9 +213,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
   __shared__ unsigned long long sSuper[!NARROW ? kMaxNucSuper * 4 : 1];
+  /* PAIR (G = 4): two steps per block read through the pair image (awfm_pair.h); its superblock bases are dynamic LDS */
+  __shared__ unsigned long long sPairC[PAIR ? 16 : 1];
+  extern __shared__ unsigned sPairSuper[];
+  static_assert(!PAIR || G == 4, "pair steps are written for 4 lanes per query");
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   stageMaskTable(sMask);
   nucStageSuper<NARROW>(ix, sSuper);
+  if (PAIR) pairStageTables<NARROW>(ix, sPairC, sPairSuper);
   __syncthreads();
 
   const OrderFormat format = orderFormat(depth);
@@ -242,7 +260,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
    * a workgroup draws from counter w of its XCD and takes chunk 4*ticket + w, so a counter sees a quarter of the
    * traffic and no barrier ties the waves of a workgroup together.  A ticket is drawn two chunks ahead and read
    * at the end of an iteration, so its latency and the record read hide behind the current chunk. */
-  constexpr unsigned kWaves = kThreads / 64, kChunk = 64 / G;
+  constexpr unsigned kWaves = orderedThreads(PAIR) / 64, kChunk = 64 / G;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   unsigned *ticket = tickets + (xcd * kWaves + wave) * 64u; /* 256 bytes apart */
   auto chunkBase = [&](unsigned t) -> unsigned long long {
@@ -304,10 +322,35 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
     }
 
     /* ---- extension (ref src/AwFmParallelSearch.c:273-313) ---- */
-    while (pos >= 0 && sp <= ep) {
-      nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
-      pos--;
-      rem >>= 2;
+    if (PAIR) {
+      /* two characters per block read.  Only hits are reported, so it does not matter at which of the two steps a
+       * range without hits became empty.  An odd step is taken alone: first in a mixed-length batch (one divergent
+       * round), last in a fixed-length one (where it is wave-uniform and few k-mers are still alive). */
+      if (VARLEN && pos >= 0 && sp <= ep && (pos & 1) == 0) {
+        nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+        pos--;
+        rem >>= 2;
+      }
+      while (pos >= 1 && sp <= ep) {
+        const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
+        if (pairSearchStep<NARROW>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep)) {
+          /* a block with an ambiguity letter or the sentinel: letter by letter through the one-letter image */
+          nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
+          if (sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
+        }
+        pos -= 2;
+        rem >>= 4;
+      }
+      if (!VARLEN && pos == 0 && sp <= ep) {
+        nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+        pos--;
+      }
+    } else {
+      while (pos >= 0 && sp <= ep) {
+        nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+        pos--;
+        rem >>= 2;
+      }
     }
     if (live && gl == 0 && sp <= ep) {
       if (ranges) ranges[index] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);

@@ -49,6 +49,9 @@ def parse():
     p.add_argument("--alphabet", choices=["dna", "amino"], default="dna")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--no-e2e", action="store_true", help="skip the host-inclusive end_to_end leg")
+    p.add_argument("--e2e-aos-queries", type=count, default=10_000_000,
+                   help="k-mers of the batch that also go through the drop-in AoS entry point (0: skip)")
     p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (gloo: several ranks on one GPU, testing)")
     p.add_argument("--force-device", type=int, default=-1, help="testing: every rank uses this GPU")
     p.add_argument("--device-dense-sa", action="store_true",
@@ -89,6 +92,85 @@ def launch_ranks(args):
     if not lines or json.loads(lines[-1]).get("n_gpus") != args.gpus:
         sys.stderr.write("bench.py: rank 0 did not report n_gpus == --gpus\n")
         sys.exit(1)
+
+
+def end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, amino, dev):
+    """wall-clock rates with the batch in HOST memory at the start and the results in host memory at the end"""
+    import ctypes as C
+    import numpy as np
+    import torch
+    locate = args.mode == "locate"
+    out = {"unit": "Mkmers/s", "mode": args.mode}
+    # the batch, bit-packed, in page-locked host memory (packed on the device from the resident ASCII batch)
+    d_packed = torch.empty(Q, dtype=torch.int64, device=dev)
+    bad = g.pack_device(d_chars.data_ptr(), K, Q, d_packed.data_ptr())
+    assert bad == 0, "synthetic k-mers are plain letters"
+    address = L.awfmGpuHostAlloc(Q * 8)
+    assert address
+    host_packed = np.ctypeslib.as_array(C.cast(address, C.POINTER(C.c_uint64)), shape=(Q,))
+    host_packed[:] = d_packed.cpu().numpy().view(np.uint64)
+    del d_packed
+    seen = {"kmers": 0, "hits": 0, "chunks": 0}
+
+    def tally_sink(user, first, m, counts, positions, total):
+        seen["kmers"] += m
+        seen["hits"] += total
+        seen["chunks"] += 1
+        return 0
+
+    def run_stream():
+        seen.update(kmers=0, hits=0, chunks=0)
+        t0 = time.perf_counter()
+        g.stream((address, Q), K, locate=locate, chunk=0, sink=tally_sink)
+        return time.perf_counter() - t0
+
+    run_stream()  # first call allocates the pipeline's device buffers and page-locked staging
+    times = [run_stream() for _ in range(3)]
+    assert seen["kmers"] == Q and (not locate or seen["hits"] == state["hits"]), "pipeline lost k-mers or hits"
+    # parity at full size: the pipeline's counts / positions against the device-buffer API's results of the timed steps
+    counts, positions = g.stream((address, Q), K, locate=locate, chunk=0)
+    if locate:
+        ho = d_hit_off.cpu().numpy().view(np.uint64)
+        assert np.array_equal(counts, np.diff(ho).astype(np.uint32)), "pipeline counts differ from the device API's"
+        assert np.array_equal(positions, state["positions"][: state["hits"]].cpu().numpy().view(np.uint64)), \
+            "pipeline positions differ from the device API's"
+    else:
+        assert np.array_equal(counts, d_counts.cpu().numpy().view(np.uint32)), "pipeline counts differ from the device API's"
+    del counts, positions
+    best = min(times)
+    out["flat_packed_pipeline"] = {
+        "value": round(Q / best / 1e6, 1), "ms": round(best * 1e3, 2), "kmers": Q, "chunks": seen["chunks"],
+        "entry_point": "awfmGpuStreamPacked", "input": "8 B/k-mer packed words in page-locked host memory",
+        "output": "4 B/k-mer counts" + (" + 8 B/hit positions" if locate else "") + " in page-locked staging, per chunk",
+        "pcie_bytes": {"h2d": Q * 8, "d2h": Q * 4 + (seen["hits"] * 8 if locate else 0)},
+        "checked": "counts and positions equal the device-buffer API's for the whole batch"}
+    L.awfmGpuHostFree(address)
+    # the drop-in AoS entry point on a prefix of the batch (one kmerString pointer in, one positionList out per k-mer)
+    m = min(Q, args.e2e_aos_queries)
+    if m:
+        chars = np.ascontiguousarray(d_chars[: m * K].cpu().numpy())
+        lst = api.KmerSearchList(m)
+        data = lst.ptr.contents.kmerSearchData
+        arr = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint64)), shape=(m, 4))
+        arr[:, 0] = chars.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(K)
+        arr[:, 1] = K
+        lst.ptr.contents.count = m
+        threads = min(32, 2 * (os.cpu_count() or 1))
+        fn = (lambda: api.parallel_search_locate(ix, lst, threads)) if locate else (lambda: api.parallel_search_count(ix, lst, threads))
+        fn()
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        got = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint32)), shape=(m, 8))[:, 6]
+        if locate:
+            ho = d_hit_off[: m + 1].cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, np.diff(ho).astype(np.uint32)), "AoS counts differ from the device API's"
+        else:
+            assert np.array_equal(got, d_counts[:m].cpu().numpy().view(np.uint32)), "AoS counts differ from the device API's"
+        out["aos_drop_in"] = {"value": round(m / dt / 1e6, 1), "ms": round(dt * 1e3, 2), "kmers": m, "host_threads": threads,
+                              "entry_point": "awFmParallelSearchLocate" if locate else "awFmParallelSearchCount"}
+        lst.dealloc()
+    return out
 
 
 def main():
@@ -349,11 +431,24 @@ def main():
                 break
             m = int(min(Q, 50_000_000, max(2 * m, m * args.cpu_seconds / max(dt, 1e-3))))
             dt, tl = run_sample(m)
-        cpu = {"value": round(m / dt / 1e6, 3), "unit": "Mkmers/s", "cores": cores, "kind": "port",
+        # SURVEY.md 8d also asks for the 1-thread and 8-thread figures of the same port
+        fixed = {}
+        for t, mt in ((1, 2_000_000), (8, 8_000_000)):
+            mt = min(Q, mt)
+            dtt, _ = run_sample(mt, t)
+            fixed[f"threads_{t}"] = {"value": round(mt / dtt / 1e6, 3), "sample": mt}
+        cpu = {"value": round(m / dt / 1e6, 3), "unit": "Mkmers/s", "cores": cores, "kind": "port", **fixed,
                "sample": f"first {m} of the {Q} {args.workload} {kdesc} of rank 0, {args.mode}, same index, "
                          f"{dt:.1f} s wall on {cores} threads ({granted} CPUs granted of {os.cpu_count()}), "
                          f"results equal to the GPU's",
                "per_query": {"steps": round(tl["steps"] / m, 4), "distinct_blocks": round(tl["blocks"] / m, 4)}}
+
+    # ---- host-inclusive rates (never `value`): the same batch from host memory through the flat packed pipeline
+    # (awfmGpuStreamPacked: chunked upload / kernels / download) and a prefix of it through the drop-in
+    # AoS entry point (awFmParallelSearchCount/Locate, ref src/AwFmParallelSearch.c:95-220), wall clock, rank 0 ----
+    e2e = None
+    if not args.no_e2e and world == 1 and d_offsets is None and K <= (12 if amino else 32):
+        e2e = end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, amino, dev)
 
     out = {
         "metric": "Mkmers/sec located, GRCh38 nucleotide index" if not amino else "Mkmers/sec located, amino index",
@@ -373,6 +468,7 @@ def main():
                    "search_path": "awfmGpuSearchHits, seed order" if ordered else "awfmGpuSearchHits, general kernel"},
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "end_to_end": e2e,
     }
     print(json.dumps(out), flush=True)
     if world > 1:

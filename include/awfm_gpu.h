@@ -90,6 +90,15 @@ enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK);
  * hit is one read instead of a chain of about ratio-1 dependent block reads.  Positions are bit-identical.
  * enable = 0 drops it.  Needs bwtLength < 2^32. */
 enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable);
+/* Nucleotide images carry, beside the one-letter blocks, a pair image: for every BWT position the pair of its two
+ * preceding text characters, in 128-byte blocks of 128 positions with 16 base counts, so that two backward steps (two
+ * LF steps) are one rank over a 16-letter sequence and one block read (csrc/awfm_pair.h).  Hits-only searches
+ * (awfmGpuSearchHits in seed order) and the LF walk of awfmGpuLocate use it; results are those of the letter-by-letter
+ * steps (ref src/AwFmSearch.c:42-103, :369-427), bit for bit.  Built with every nucleotide image unless
+ * $AWFM_GPU_PAIR=0; enable = 0 drops it (the image then takes one step per read), enable != 0 rebuilds it.  It adds
+ * 1 byte per BWT position of device memory; the host index and the .awfmi file are untouched. */
+enum AwFmReturnCode awfmGpuIndexSetPairImage(AwFmGpuIndex *g, int enable);
+int awfmGpuIndexHasPairImage(const AwFmGpuIndex *g);
 /* Selects the search kernel variant for this image (default AUTO). */
 void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel);
 /* The kernels keep BWT positions in 32 bits whenever bwtLength < 2^32 and in 64 bits otherwise (the reference is
@@ -189,6 +198,59 @@ enum AwFmReturnCode awfmGpuLocateHost(AwFmGpuIndex *g, const uint8_t *chars, con
 enum AwFmReturnCode awfmGpuLocateHostPinned(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
                                             uint32_t fixedLength, uint64_t numQueries, uint64_t *hitOffsets,
                                             const uint64_t **positions);
+
+/* ---- packed k-mers and the chunked host-buffer pipeline (awfm_gpu_stream.hip) ----
+ * The reference's batch is an array of structs: a kmerString pointer in and a malloc'ed positionList out per
+ * k-mer (ref src/AwFmParallelSearch.c:36-93, :367-387).  These entry points take the batch flat and bit-packed
+ * and return it flat, cut into chunks whose upload, kernels and download overlap.
+ *
+ * Packed k-mer: one 64-bit word per k-mer of kmerLength characters, first character most significant, last
+ * character in the lowest bits; nucleotide 2 bits per character (a 0, c 1, g 2, t/u 3; kmerLength <= 32), amino
+ * 5 bits per character = the letter index of ref src/AwFmLetter.c:55-67 (a 0, c 1, d 2, ... y 19; 20..31 search
+ * as the ambiguity letter x; kmerLength <= 12).  Nucleotide ambiguity characters cannot be expressed: batches
+ * that contain them go through the ASCII entry points. */
+/* host-side packing of n fixed-length ASCII k-mers; returns AwFmIllegalPositionError and the number of the first
+ * k-mer that cannot be expressed in *firstUnpackable (may be NULL) */
+enum AwFmReturnCode awfmPackKmers(enum AwFmAlphabetType alphabet, const uint8_t *chars, uint32_t kmerLength,
+                                  uint64_t numKmers, uint64_t *packedOut, uint64_t *firstUnpackable);
+/* the same on device buffers (k-mers that cannot be expressed become the all-ones word and are counted), and back */
+enum AwFmReturnCode awfmGpuPackKmers(AwFmGpuIndex *g, const uint8_t *dChars, uint32_t kmerLength, uint64_t numKmers,
+                                     uint64_t *dPacked, uint64_t *numUnpackable, void *stream);
+enum AwFmReturnCode awfmGpuUnpackKmers(AwFmGpuIndex *g, const uint64_t *dPacked, uint32_t kmerLength, uint64_t numKmers,
+                                       uint8_t *dChars, void *stream);
+/* awfmGpuSearchHits for bit-packed k-mers resident on the device.  Nucleotide batches that take the seed-order path are
+ * searched straight from the packed words; other batches are unpacked into dCharsScratch (kmerLength bytes per k-mer;
+ * may be NULL when the caller knows awfmGpuSearchHitsIsOrdered) and searched as ASCII.  Same outputs and contract. */
+enum AwFmReturnCode awfmGpuSearchHitsPacked(AwFmGpuIndex *g, const uint64_t *dPacked, uint32_t kmerLength, uint64_t numKmers,
+                                            struct AwFmSearchRange *dRanges, uint32_t *dCounts, uint8_t *dCharsScratch,
+                                            void *stream);
+/* page-locked host memory: batches handed over in it are read by the DMA engine directly, anything else is first
+ * copied into the pipeline's own staging by hostThreads threads */
+void *awfmGpuHostAlloc(uint64_t bytes);
+void awfmGpuHostFree(void *p);
+/* Receives the results of k-mers firstKmer .. firstKmer+numKmers-1: counts[i] hits of k-mer firstKmer+i (the
+ * reference's uint32 count, ref src/AwFmIndex.h:112-118), and -- locate -- numPositions text positions, the
+ * hits of k-mer firstKmer+i starting where those of firstKmer+i-1 end, each list in BWT order (what
+ * awFmParallelSearchLocate puts into positionList).  The arrays are page-locked staging of the pipeline, valid until
+ * the sink returns; chunks arrive in order; a non-zero return stops the batch. */
+typedef int (*AwFmGpuChunkSink)(void *user, uint64_t firstKmer, uint64_t numKmers, const uint32_t *counts,
+                                const uint64_t *positions, uint64_t numPositions);
+/* Counts (locate == 0) or locates numKmers packed host-resident k-mers in chunks of chunkKmers (0: 2^24) through
+ * three pipeline slots: while the sink consumes chunk t-2 on the calling thread, chunk t-1 is in the kernels and
+ * chunk t on its way to the device.  One batch at a time per image. */
+enum AwFmReturnCode awfmGpuStreamPacked(AwFmGpuIndex *g, const uint64_t *packedKmers, uint32_t kmerLength,
+                                        uint64_t numKmers, uint64_t chunkKmers, int locate, unsigned hostThreads,
+                                        AwFmGpuChunkSink sink, void *user);
+/* the same pipeline for fixed-length ASCII k-mers (any character the ASCII API accepts) */
+enum AwFmReturnCode awfmGpuStreamChars(AwFmGpuIndex *g, const uint8_t *chars, uint32_t kmerLength, uint64_t numKmers,
+                                       uint64_t chunkKmers, int locate, unsigned hostThreads, AwFmGpuChunkSink sink,
+                                       void *user);
+/* whole batch into caller arrays: counts[numKmers]; *positions is malloc'ed (caller frees), *numPositions entries */
+enum AwFmReturnCode awfmGpuCountPackedHost(AwFmGpuIndex *g, const uint64_t *packedKmers, uint32_t kmerLength,
+                                           uint64_t numKmers, uint32_t *counts);
+enum AwFmReturnCode awfmGpuLocatePackedHost(AwFmGpuIndex *g, const uint64_t *packedKmers, uint32_t kmerLength,
+                                            uint64_t numKmers, uint32_t *counts, uint64_t **positions,
+                                            uint64_t *numPositions);
 
 /* ---- seeded synthetic inputs on the device (bench and full-size tests) ---- */
 /* text characters start..start+count-1 of the stream `seed`; amino != 0 selects the 20-letter alphabet */

@@ -69,6 +69,41 @@ if search and not ordered:
                   "WRITE_SIZE is exact",
     }, open(os.path.join(dst, f"traffic_{name}.json"), "w"), indent=1)
     print(k, "traffic GB/launch", (2 * fetch_kb + write_kb) * 1024 / 1e9, "TCC_MISS x128 GB", (miss or 0) * 128 / 1e9)
+# counters of the dominant kernel, condensed for bench.py's roofline record (guide: wave64 VALU issue = 2 cycles on a
+# SIMD-32; GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_WAVE_CYCLES / SQ_WAIT_ANY count in units of 4 cycles)
+def kernel_avg_ns(prefix):
+    if not stats:
+        return None
+    for r in csv.DictReader(open(stats[0])):
+        nm = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        if nm.startswith(prefix):
+            return float(r["AverageNs"])
+    return None
+
+
+dominant = (ordered or search or [None])[0]
+if dominant:
+    c = {k: v["mean"] for k, v in summary[dominant].items()}
+    ns = kernel_avg_ns(dominant.split("<")[0])
+    out = {"kernel": dominant, "workload": workload, "avg_ns_kernel_trace": ns, "raw": c}
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        out["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if "GRBM_GUI_ACTIVE" in c:
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+        out["cycles_per_xcd"] = cycles
+        if ns:
+            out["clock_ghz_under_profiler"] = cycles / ns
+        if "SQ_INSTS_VALU" in c:
+            out["valu_issue_frac"] = c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cycles)  # 256 CUs x 4 SIMDs
+    if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+        out["wave_wait_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+    if "FETCH_SIZE" in c:  # FETCH_SIZE = TCC_EA0_RDREQ x 64 B: exact for 64-B requests (block reads), half for 128-B streams
+        out["hbm_read_bytes_min"] = c["FETCH_SIZE"] * 1024.0
+        out["hbm_read_bytes_max"] = 2.0 * c["FETCH_SIZE"] * 1024.0
+    if "WRITE_SIZE" in c:
+        out["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024.0
+    json.dump(out, open(os.path.join(dst, f"counters_{name}.json"), "w"), indent=1, sort_keys=True)
+    print("dominant kernel", dominant, {k: v for k, v in out.items() if k not in ("raw", "kernel", "workload")})
 for line in open(os.path.join(src, "bench_trace.log")):
     if line.startswith("{"):
         open(os.path.join(dst, f"bench_{name}_under_rocprofv3.json"), "w").write(line)

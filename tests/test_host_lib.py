@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(awfm):
     declared = set()
     for h in ("include/AwFmIndex.h", "include/awfm_gpu.h"):
         src = open(os.path.join(root, h)).read()
-        declared |= set(re.findall(r"\b(awFm[A-Z]\w+|awfmGpu\w+)\s*\(", src))
+        declared |= set(re.findall(r"\b(awFm[A-Z]\w+|awfmGpu\w+|awfmPack\w+)\s*\(", src))
     assert declared <= set(_lib.API_SYMBOLS + _lib.GPU_SYMBOLS), declared - set(_lib.API_SYMBOLS + _lib.GPU_SYMBOLS)
 
 
@@ -229,3 +229,36 @@ def test_reference_shared_library_program_relinks_unchanged(awfm, tmp_path):
     sp, ep = ix.find_search_range_for_string(b"gata")
     assert sp > ep
     ix.dealloc()
+
+
+def test_pack_kmers_layout_and_rejections(awfm):
+    """awfmPackKmers: first character most significant, 2 bits per nucleotide (the letter indices of ref
+    src/AwFmLetter.c:4-22) / 5 bits per amino acid (ref src/AwFmLetter.c:55-67); what cannot be expressed is refused"""
+    q = synth.random_queries(2, 2000, 21).copy()
+    q[::3] &= 0xDF  # upper case packs like lower case
+    ts = np.argwhere(q == ord("t"))[::2]
+    q[ts[:, 0], ts[:, 1]] = ord("u")
+    lut = np.zeros(256, np.uint64)
+    for ch, v in ((b"c", 1), (b"g", 2), (b"t", 3), (b"u", 3)):
+        lut[ch[0]] = lut[ch[0] & 0xDF] = v
+    expect = np.zeros(len(q), np.uint64)
+    for c in range(21):
+        expect = (expect << np.uint64(2)) | lut[q[:, c]]
+    assert np.array_equal(awfm.pack_kmers(q), expect)
+    assert awfm.pack_kmers(np.frombuffer(b"t" * 32, np.uint8).reshape(1, 32))[0] == np.uint64(2**64 - 1)
+    qa = synth.random_queries(3, 2000, 12, synth.AMINO_ALPHABET)
+    index_of = np.zeros(256, np.uint64)
+    for i, ch in enumerate(synth.AMINO_ALPHABET):
+        index_of[ch] = i
+    expect = np.zeros(len(qa), np.uint64)
+    for c in range(12):
+        expect = (expect << np.uint64(5)) | index_of[qa[:, c]]
+    assert np.array_equal(awfm.pack_kmers(qa, awfm.AwFmAlphabetAmino), expect)
+    for bad, alphabet in ((b"acgn", awfm.AwFmAlphabetDna), (b"ac$t", awfm.AwFmAlphabetDna), (b"acdx", awfm.AwFmAlphabetAmino),
+                          (b"acdb", awfm.AwFmAlphabetAmino)):
+        with pytest.raises(ValueError):
+            awfm.pack_kmers(np.frombuffer(bad, np.uint8).reshape(1, 4), alphabet)
+    with pytest.raises(ValueError):  # more characters than a word holds
+        awfm.pack_kmers(np.full((1, 33), ord("a"), np.uint8))
+    with pytest.raises(ValueError):
+        awfm.pack_kmers(np.full((1, 13), ord("a"), np.uint8), awfm.AwFmAlphabetAmino)

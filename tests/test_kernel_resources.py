@@ -48,18 +48,21 @@ def test_default_search_kernel_keeps_full_occupancy(kernel_metadata):
 
 
 def test_default_walk_kernel_keeps_full_occupancy(kernel_metadata):
-    # walkKernel<AMINO=false, G=4, POW2=true, NARROW=true>
-    k = _one(kernel_metadata, r"walkKernelILb0ELi4ELb1ELb1E")
-    assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0
-    assert k["lds"] <= 1024  # small arrays that are indexed dynamically get moved to LDS by hipcc: must not happen
+    # walkKernel<AMINO=false, G=4, POW2=true, NARROW=true, PAIR>: one LF step per read, and two (the default)
+    for pair in ("Lb0E", "Lb1E"):
+        k = _one(kernel_metadata, r"walkKernelILb0ELi4ELb1ELb1E" + pair)
+        assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0, pair
+        assert k["lds"] <= 1024  # small arrays that are indexed dynamically get moved to LDS by hipcc: must not happen
 
 
 def test_ordered_search_kernels_keep_full_occupancy(kernel_metadata):
-    # orderedSearchKernel<G=4, NARROW=true, COMPACT, VARLEN>: the 8-byte-record, the 16-byte-record and the CSR variant
+    # orderedSearchKernel<G=4, NARROW=true, COMPACT, VARLEN, PAIR>: the 8-byte-record, the 16-byte-record and the CSR
+    # variant, with one step per block read and with two (pair image, the default)
     for variant in ("Lb1ELb1ELb0E", "Lb1ELb0ELb0E", "Lb1ELb0ELb1E"):
-        k = _one(kernel_metadata, r"orderedSearchKernelILi4E" + variant)
-        assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0, variant
-        assert k["lds"] <= 16 * 1024
+        for pair in ("Lb0E", "Lb1E"):
+            k = _one(kernel_metadata, r"orderedSearchKernelILi4E" + variant + pair)
+            assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0, variant + pair
+            assert k["lds"] <= 16 * 1024  # static; the pair variant adds 64 B per 2^23 positions of dynamic LDS
 
 
 def test_no_search_or_walk_variant_uses_scratch(kernel_metadata):
