@@ -114,6 +114,9 @@ __host__ __device__ inline unsigned orderStartDepth(unsigned len, unsigned seedK
  * k-mer that starts below a table is the leading bits of the k-mer itself, which is where its letter-range
  * search ends up in the BWT.  K-mers the ordered kernel does not cover (ambiguity characters, no characters,
  * more than 32) get the general key. */
+/* (Staging a workgroup's 256 * fixedLen contiguous bytes through LDS with coalesced dword loads, with or without the
+ * "no hit" fill folded in, was measured slower than these per-thread unaligned-stride reads: search call 6.87-6.93
+ * against 6.54-6.70 ms per 10^8 21-mers in a same-box A/B -- the L1 already serves the overlapping dwords.) */
 /* PACKED: `chars` is one 64-bit word per k-mer (2-bit codes, last character in bits 1..0: the record's own format;
  * include/awfm_gpu.h), fixed length: nothing to decode, and no k-mer is left to the general kernel */
 template <bool COMPACT, bool VARLEN, bool PACKED = false>

@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-python -m pytest tests/test_gpu_stream.py -x -q 2>&1 | tail -2
-for lag in 2 3; do for m in split slots; do
- echo "== lag $lag mode $m planted"; AWFM_GPU_STREAM_LAG=$lag AWFM_GPU_STREAM_MODE=$m python scripts/stream_probe.py 3.1e9 1e8 planted 2>&1 | grep "^run [123]"
+source scripts/ab_lib.sh
+for i in 1 2; do for v in A B C; do
+run enc${v}${i}_count AWFM_LIB_PATH=$PWD/avxwindowfmindex_amd/libawfm_$v.so -- --no-e2e --mode count
 done; done

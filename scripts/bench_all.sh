@@ -1,20 +1,25 @@
 #!/bin/bash
 # every bench.py configuration quoted in DESIGN.md, one JSON line each -> gpurun_out/bench_<tag>/bench_<name>.json
-TAG=${1:-r1}
+TAG=${1:-r2}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/bench_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
-run() { name=$1; shift; python3 bench.py "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/bench_$name.json"; }
-run default
-run count --mode count
-run planted --workload planted
-run mixed --workload mixed
-run amino --alphabet amino
-run deep14 --device-seed-k 14 --no-cpu
-run deep16_dense --device-seed-k 16 --device-dense-sa --no-cpu
-run planted_dense --workload planted --device-dense-sa --no-cpu
-run planted_deep16_dense --workload planted --device-seed-k 16 --device-dense-sa --no-cpu
+run() { # name [ENV=..]... -- bench args
+  name=$1; shift
+  envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  env "${envs[@]}" python3 bench.py "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/bench_$name.json"
+}
+run default --
+run count -- --mode count
+run planted -- --workload planted
+run mixed -- --workload mixed
+run amino -- --alphabet amino
+run general AWFM_GPU_ORDERED=0 -- --mode count --no-cpu --no-e2e
+run nopair_default AWFM_GPU_PAIR=0 -- --no-cpu --no-e2e
+run nopair_planted AWFM_GPU_PAIR=0 -- --workload planted --no-cpu --no-e2e
+run deep14 -- --device-seed-k 14 --no-cpu --no-e2e
+run planted_dense -- --workload planted --device-dense-sa --no-cpu --no-e2e
 python3 - "$OUT" <<'PY'
 import glob, json, os, sys
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):

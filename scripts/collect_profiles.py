@@ -15,11 +15,17 @@ import sys
 
 src, dst, name, workload = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+def newest(paths):
+    """gpurun_out accumulates the files of every profiling call for a tag: keep the latest run of each pass"""
+    return sorted(paths, key=os.path.getmtime)[-1:]
+
+
+stats = newest(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"kernel_stats_{name}_bench.csv"))
 summary = collections.defaultdict(dict)
-for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+passes = sorted(glob.glob(os.path.join(src, "pmc_*")))
+for f in [g for d in passes for g in newest(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))]:
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         kernel = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
@@ -35,12 +41,31 @@ def total(kernel, counter):
     return c["mean"] * c["dispatches"] if c else 0.0
 
 
+def fetch_factor(kernel):
+    """FETCH_SIZE = TCC_EA0_RDREQ x 64 B.  The L2 asks memory for 64 B when a 64-B granule of a line is touched (the
+    one-letter blocks of the search and walk kernels: their TCC_MISS count equals the number of distinct 64-B blocks,
+    not half of it) and for 128 B when a whole line streams in -- the case MI355X_MICROARCH.md describes ("exactly half
+    of the bytes of a wide coalesced streaming read"), calibrated here on encodeQueriesKernel (2.1 GB of characters
+    read, 1.05 GB of FETCH_SIZE).  So: x1 for kernels whose reads are 64-B blocks, x2 for everything else (streams,
+    and the 128-B blocks of the pair image)."""
+    name = kernel.split("<")[0]
+    args = kernel[kernel.find("<") + 1:kernel.rfind(">")].replace(" ", "").split(",") if "<" in kernel else []
+    if name == "orderedSearchKernel":
+        return 2 if len(args) >= 5 and args[4] == "true" else 1
+    if name == "walkKernel":
+        return 2 if (len(args) >= 5 and args[4] == "true") or args[0] == "true" else 1  # pair image / amino: 128-B blocks
+    if name == "searchKernel":
+        return 2 if args and args[0] == "true" else 1
+    return 2
+
+
 ordered = [k for k in summary if k.startswith("orderedSearchKernel") and "FETCH_SIZE" in summary[k]]
 if ordered:
     calls = summary[ordered[0]]["FETCH_SIZE"]["dispatches"]
     parts = [k for k in summary if k.startswith(("orderedSearchKernel", "fillNoHitKernel", "encodeQueriesKernel"))
              or ("radix_sort" in k and "unsigned short" in k) or (k.startswith("searchKernel") and k.rstrip(">").endswith("true, true"))]
-    per_kernel = {k: {"read_bytes": 2 * 1024 * total(k, "FETCH_SIZE") / calls, "write_bytes": 1024 * total(k, "WRITE_SIZE") / calls,
+    per_kernel = {k: {"read_bytes": fetch_factor(k) * 1024 * total(k, "FETCH_SIZE") / calls, "fetch_factor": fetch_factor(k),
+                      "write_bytes": 1024 * total(k, "WRITE_SIZE") / calls,
                       "TCC_MISS_lines_x128": 128 * total(k, "TCC_MISS_sum") / calls,
                       "launches_per_call": summary[k]["FETCH_SIZE"]["dispatches"] / calls} for k in parts}
     hbm = sum(v["read_bytes"] + v["write_bytes"] for v in per_kernel.values())
@@ -48,11 +73,12 @@ if ordered:
         "kernel": "awfmGpuSearchHits (ordered path): " + ", ".join(sorted(k.split("<")[0] for k in parts)),
         "workload": workload, "per_kernel": per_kernel, "hbm_bytes_per_launch": int(hbm),
         "method": "rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc TCC_HIT_sum TCC_MISS_sum in separate passes "
-                  "(scripts/profile_bench.sh), summed over every kernel of one awfmGpuSearchHits call.  Reads = 2 x FETCH_SIZE: "
-                  "on gfx950 FETCH_SIZE tallies each 128-B request at 64 B (MI355X_MICROARCH.md, HBM); the rule is "
-                  "calibrated here on encodeQueriesKernel, whose 2.1 GB of k-mer characters (dword loads) read as 1.05 GB "
-                  "of FETCH_SIZE.  Writes = WRITE_SIZE.  TCC_MISS_sum x 128 B is kept as a cross-check; it also counts "
-                  "the write-allocate misses of the stores (fillNoHitKernel: 2.0 GB of 'misses', no reads).",
+                  "(scripts/profile_bench.sh), summed over every kernel of one awfmGpuSearchHits call.  Reads = fetch_factor x "
+                  "FETCH_SIZE: on gfx950 FETCH_SIZE tallies each read request at 64 B (MI355X_MICROARCH.md, HBM), which is "
+                  "half of a streamed 128-B line (calibrated on encodeQueriesKernel: 2.1 GB of k-mer characters read as "
+                  "1.05 GB of FETCH_SIZE) but all of a 64-B block granule (kernels on the one-letter blocks: factor 1).  "
+                  "Writes = WRITE_SIZE.  TCC_MISS_sum x 128 B is kept as a cross-check; it also counts the write-allocate "
+                  "misses of the stores.",
     }, open(os.path.join(dst, f"traffic_{name}.json"), "w"), indent=1)
     print("ordered search call: HBM GB", hbm / 1e9, {k.split("<")[0]: round((v["read_bytes"] + v["write_bytes"]) / 1e9, 2) for k, v in per_kernel.items()})
 search = [k for k in summary if k.startswith("searchKernel") and "FETCH_SIZE" in summary[k]]
@@ -97,13 +123,26 @@ if dominant:
             out["valu_issue_frac"] = c["SQ_INSTS_VALU"] * 2.0 / (1024.0 * cycles)  # 256 CUs x 4 SIMDs
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
         out["wave_wait_frac"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
-    if "FETCH_SIZE" in c:  # FETCH_SIZE = TCC_EA0_RDREQ x 64 B: exact for 64-B requests (block reads), half for 128-B streams
-        out["hbm_read_bytes_min"] = c["FETCH_SIZE"] * 1024.0
-        out["hbm_read_bytes_max"] = 2.0 * c["FETCH_SIZE"] * 1024.0
+    if "FETCH_SIZE" in c:
+        out["hbm_read_bytes"] = fetch_factor(dominant) * c["FETCH_SIZE"] * 1024.0
+        if ns:
+            out["hbm_read_GBs"] = out["hbm_read_bytes"] / ns
     if "WRITE_SIZE" in c:
         out["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024.0
     json.dump(out, open(os.path.join(dst, f"counters_{name}.json"), "w"), indent=1, sort_keys=True)
     print("dominant kernel", dominant, {k: v for k, v in out.items() if k not in ("raw", "kernel", "workload")})
+# every kernel of the run: bytes and time per launch (for the locate kernels of the planted workload)
+table = {}
+for k in summary:
+    if "FETCH_SIZE" in summary[k]:
+        table[k.split("(")[0][:90]] = {
+            "launches": summary[k]["FETCH_SIZE"]["dispatches"],
+            "read_bytes_per_launch": fetch_factor(k) * 1024 * summary[k]["FETCH_SIZE"]["mean"],
+            "write_bytes_per_launch": 1024 * summary[k].get("WRITE_SIZE", {"mean": 0.0})["mean"],
+            "l2_hit_rate": (summary[k]["TCC_HIT_sum"]["mean"] / max(1.0, summary[k]["TCC_HIT_sum"]["mean"] + summary[k]["TCC_MISS_sum"]["mean"]))
+            if "TCC_HIT_sum" in summary[k] else None,
+            "avg_ns_kernel_trace": kernel_avg_ns(k.split("<")[0])}
+json.dump(table, open(os.path.join(dst, f"kernels_{name}.json"), "w"), indent=1, sort_keys=True)
 for line in open(os.path.join(src, "bench_trace.log")):
     if line.startswith("{"):
         open(os.path.join(dst, f"bench_{name}_under_rocprofv3.json"), "w").write(line)
