@@ -33,7 +33,7 @@ GPU_SYMBOLS = [
     "awfmGpuSynthMixedLengths", "awfmGpuSynthMixedQueries",
     "awfmPackKmers", "awfmGpuPackKmers", "awfmGpuUnpackKmers", "awfmGpuHostAlloc", "awfmGpuHostFree", "awfmGpuStreamPacked",
     "awfmGpuStreamChars", "awfmGpuCountPackedHost", "awfmGpuLocatePackedHost", "awfmGpuIndexSetPairImage", "awfmGpuIndexHasPairImage",
-    "awfmGpuSearchHitsPacked",
+    "awfmGpuSearchHitsPacked", "awfmGpuLocateTo",
 ]
 # int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
 CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
@@ -148,6 +148,7 @@ def lib():
         "awfmGpuHitOffsets": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),
         "awfmGpuHitOffsetsFromCounts": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),
         "awfmGpuLocate": (C.c_int, [vp, vp, vp, u64, u64, vp, vp]),
+        "awfmGpuLocateTo": (C.c_int, [vp, vp, vp, u64, u64, vp, vp, vp]),
         "awfmGpuCountHost": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp]),
         "awfmGpuLocateHost": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, C.POINTER(C.POINTER(u64))]),
         "awfmGpuCreateIndex": (C.c_int, [C.POINTER(IP), C.POINTER(AwFmIndexConfiguration), vp, u64, C.c_int,

@@ -119,10 +119,10 @@ __global__ void narrowKernel(const unsigned long long *in, unsigned long long co
 /* positions[t] = denseSa[positions[t]]: the whole backtrace as one gather (hits of a query are consecutive
  * BWT positions, so the reads are contiguous per query) */
 __global__ void denseSaGatherKernel(const unsigned *__restrict__ dense, unsigned long long totalHits,
-                                    unsigned long long *__restrict__ positions) {
+                                    const unsigned long long *positions, unsigned long long *out) {
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < totalHits; t += stride)
-    positions[t] = dense[positions[t]];
+    out[t] = dense[positions[t]];
 }
 
 /* dPositions[hitOffsets[i] + h] = sp_i + h (the BWT positions to trace back) */
@@ -232,7 +232,7 @@ void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned super
 
 namespace {
 enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions,
-                                 hipStream_t s);
+                                 hipStream_t s, unsigned long long *out = nullptr);
 /* lanes that cooperate on one query: image setting, else $AWFM_GPU_KERNEL (g4|g2|g1), else the default.  A device
  * block has 4 slices, so 4 lanes is the widest group (GROUP8 of the enum maps to it); amino slices are 32 B, 2 lanes
  * per query already hold 64 registers of block data */
@@ -974,12 +974,18 @@ extern "C" {
 enum AwFmReturnCode awfmGpuLocate(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges,
                                   const uint64_t *dHitOffsets, uint64_t numQueries, uint64_t totalHits,
                                   uint64_t *dPositions, void *stream) {
+  return awfmGpuLocateTo(g, dRanges, dHitOffsets, numQueries, totalHits, dPositions, dPositions, stream);
+}
+
+enum AwFmReturnCode awfmGpuLocateTo(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges,
+                                    const uint64_t *dHitOffsets, uint64_t numQueries, uint64_t totalHits,
+                                    uint64_t *dPositions, uint64_t *outPositions, void *stream) {
   if (!g) {
     setError("awfmGpuLocate: null image");
     return AwFmNullPtrError;
   }
   if (numQueries == 0 || totalHits == 0) return AwFmSuccess;
-  if (!dRanges || !dHitOffsets || !dPositions) {
+  if (!dRanges || !dHitOffsets || !dPositions || !outPositions) {
     setError("awfmGpuLocate: null argument");
     return AwFmNullPtrError;
   }
@@ -991,17 +997,17 @@ enum AwFmReturnCode awfmGpuLocate(AwFmGpuIndex *g, const struct AwFmSearchRange 
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   if (g->dDenseSa) {
     hipLaunchKernelGGL(denseSaGatherKernel, dim3((unsigned)(g->numCUs * 8)), dim3(256), 0, s, (const unsigned *)g->dDenseSa,
-                       (unsigned long long)totalHits, (unsigned long long *)dPositions);
+                       (unsigned long long)totalHits, (const unsigned long long *)dPositions, (unsigned long long *)outPositions);
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
   }
-  return launchLocate(g, totalHits, (unsigned long long *)dPositions, s);
+  return launchLocate(g, totalHits, (unsigned long long *)dPositions, s, (unsigned long long *)outPositions);
 }
 
 namespace {
 /* LF-walk + sampled-SA kernel over `totalHits` BWT positions stored in dPositions (in place) */
 enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions,
-                                 hipStream_t s) {
+                                 hipStream_t s, unsigned long long *out) {
   {
     /* the walk runs at the rate the chip delivers random granules whatever the group width (17.2 / 17.5 / 18.3 ms
      * for g4 / g2 / g1 on 1.0007*10^8 hits); four lanes keep the fewest instructions per step */
@@ -1060,7 +1066,10 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
 #undef AWFM_LOC3
 #undef AWFM_LOCP
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-    hipLaunchKernelGGL(finishKernel, dim3((unsigned)(g->numCUs * 8)), dim3(256), 0, s, g->dev, th, pos);
+    /* out-of-place: the final positions go to `out` (page-locked host memory in the pipeline): a smaller grid, so that
+     * a kernel paced by the PCIe writes leaves the chip to whatever runs beside it */
+    const unsigned finishGrid = out && out != pos ? (unsigned)g->numCUs * (getenv("AWFM_GPU_FINISH_BLOCKS") ? (unsigned)atoi(getenv("AWFM_GPU_FINISH_BLOCKS")) : 2u) : (unsigned)g->numCUs * 8u;
+    hipLaunchKernelGGL(finishKernel, dim3(finishGrid), dim3(256), 0, s, g->dev, th, (const unsigned long long *)pos, out ? out : pos);
   }
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;

@@ -267,11 +267,16 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
 }
 
 /* second half: the bit-packed sample of every handed-over hit */
-__global__ void finishKernel(const DevIndex ix, unsigned long long totalHits, unsigned long long *__restrict__ positions) {
+/* out == positions: in place.  Otherwise every entry is written to `out`, which may be page-locked host memory (the
+ * pipeline of awfm_gpu_stream.hip lets the kernel that produces the positions deliver them: sequential 8-byte stores) */
+__global__ void finishKernel(const DevIndex ix, unsigned long long totalHits, const unsigned long long *positions,
+                             unsigned long long *out) {
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const bool inPlace = out == positions;
   for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < totalHits; t += stride) {
     const unsigned long long v = positions[t];
-    if (v & kWalkTag) positions[t] = finishPosition(ix, v & kWalkSampleMask, (v >> 40) & ((1ull << kWalkStepBits) - 1ull));
+    if (v & kWalkTag) out[t] = finishPosition(ix, v & kWalkSampleMask, (v >> 40) & ((1ull << kWalkStepBits) - 1ull));
+    else if (!inPlace) out[t] = v;
   }
 }
 

@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-e2e", action="store_true", help="skip the host-inclusive end_to_end leg")
+    p.add_argument("--no-secondary", action="store_true", help="skip the planted (every k-mer has a hit) line of the default run")
     p.add_argument("--e2e-aos-queries", type=count, default=10_000_000,
                    help="k-mers of the batch that also go through the drop-in AoS entry point (0: skip)")
     p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (gloo: several ranks on one GPU, testing)")
@@ -251,6 +252,13 @@ def main():
         assert L.awfmGpuSynthPlantedQueries(d_chars.data_ptr(), first, Q, K, query_seed, d_text.data_ptr(), n, None) == 1
     torch.cuda.synchronize()
     off_ptr = d_offsets.data_ptr() if d_offsets is not None else 0
+    # the default run also reports the dense-hit case (every k-mer located, ~7 LF steps per hit) beside the headline:
+    # its k-mers are drawn from the text now, searched after everything else
+    d_planted = None
+    if args.workload == "random" and not amino and world == 1 and not args.no_secondary and args.mode == "locate":
+        d_planted = torch.empty(Q * K, dtype=torch.uint8, device=dev)
+        assert L.awfmGpuSynthPlantedQueries(d_planted.data_ptr(), first, Q, K, 103, d_text.data_ptr(), n, None) == 1
+        torch.cuda.synchronize()
     del d_text  # planted k-mers are already copied out; free 3.1 GB
     torch.cuda.empty_cache()
 
@@ -477,6 +485,42 @@ def main():
     if not args.no_e2e and world == 1 and d_offsets is None and K <= (12 if amino else 32):
         e2e = end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, amino, dev)
 
+    # ---- secondary: the same index, 10^8 k-mers drawn from the text (BASELINE config 3b), same step, 3 timed steps ----
+    secondary = None
+    if d_planted is not None:
+        from avxwindowfmindex_amd import synth
+
+        def planted_step():
+            g.search_hits(d_planted.data_ptr(), 0, K, Q, d_ranges.data_ptr(), 0, stream)
+            total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
+            ensure_positions(total)
+            g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, state["positions"].data_ptr(), stream)
+            return total
+
+        planted_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            hits = planted_step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        # every planted k-mer must come back at its planting offset (checked on the first 10^6: a k-mer with one hit has
+        # exactly that position, one with several has it among them)
+        m = min(Q, 1_000_000)
+        planted_at = synth.planted_offsets(103, m, K, n, first=first)
+        ho = d_hit_off[: m + 1].cpu().numpy().view(np.uint64)
+        pos = state["positions"][: int(ho[m])].cpu().numpy().view(np.uint64)
+        cnt = np.diff(ho)
+        assert cnt.min() >= 1, "a planted k-mer was not found"
+        one = cnt == 1
+        assert np.array_equal(pos[ho[:-1][one]], planted_at[one]), "a planted k-mer was located somewhere else"
+        for i in np.flatnonzero(~one)[:1000]:
+            assert planted_at[i] in pos[ho[i]:ho[i + 1]], "a planted k-mer's own offset is missing from its hit list"
+        secondary = {"workload": f"{Q / 1e6:g} M planted {K}-mers (every k-mer has >= 1 hit), locate, same index",
+                     "value": round(Q / dt / 1e6, 2), "unit": "Mkmers/s", "ms_per_step": round(dt * 1e3, 3), "steps": 3,
+                     "hits_per_step": int(hits), "checked": f"first {m} k-mers located at their planting offsets"}
+        del d_planted
+
     out = {
         "metric": "Mkmers/sec located, GRCh38 nucleotide index" if not amino else "Mkmers/sec located, amino index",
         "value": round(value, 2), "unit": "Mkmers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -496,6 +540,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "end_to_end": e2e,
+        "secondary": secondary,
     }
     print(json.dumps(out), flush=True)
     if world > 1:

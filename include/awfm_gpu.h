@@ -172,6 +172,13 @@ enum AwFmReturnCode awfmGpuLocate(AwFmGpuIndex *g, const struct AwFmSearchRange 
                                   const uint64_t *dHitOffsets, uint64_t numQueries, uint64_t totalHits,
                                   uint64_t *dPositions, void *stream);
 
+/* The same with the final positions written to outPositions instead of over dPositions (which stays the work array of
+ * the walk): outPositions may be any memory the device can store to, e.g. page-locked host memory (awfmGpuHostAlloc),
+ * in which case the kernel that produces the positions also delivers them and no device-to-host copy is needed. */
+enum AwFmReturnCode awfmGpuLocateTo(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges,
+                                    const uint64_t *dHitOffsets, uint64_t numQueries, uint64_t totalHits,
+                                    uint64_t *dPositions, uint64_t *outPositions, void *stream);
+
 /* ---- pinned staging for the drop-in AoS entry points ---- */
 /* A grow-only page-locked host buffer cached in the image (slot 0..3); valid until the next call for the
  * same slot.  awfmGpuAosLock/Unlock serialise the AoS entry points that share these buffers. */

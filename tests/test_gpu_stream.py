@@ -181,3 +181,38 @@ def test_device_resident_packed_search(oracle, awfm, require_gpu, wide, ordered)
             g.search_hits_packed(d_packed.data_ptr(), K, Q, d_ranges.data_ptr(), d_counts.data_ptr(), 0)
     g.destroy()
     ix.dealloc()
+
+
+def test_locate_into_page_locked_host_memory(oracle, awfm, require_gpu, monkeypatch):
+    """awfmGpuLocateTo: the kernel that produces the positions stores them where the caller reads them (page-locked host
+    memory), the walk's work array stays on the device; and the pipeline's variant of it ($AWFM_GPU_STREAM_DIRECT)"""
+    import torch
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    n, K, Q = 150_000, 18, 9_000
+    txt = synth.text(111, n)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 7)
+    g = awfm.GpuIndex(ix)
+    kmers = synth.planted_queries(112, Q, K, txt)
+    cnt, pos = _oracle_answers(oracle, oracle.DNA, ix, 8, 7, kmers)
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(kmers.reshape(-1).copy()).to(dev)
+    d_ranges = torch.zeros(Q * 2, dtype=torch.int64, device=dev)
+    g.search(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), 0)
+    d_hit_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+    total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr())
+    assert total == len(pos)
+    d_work = torch.zeros(total, dtype=torch.int64, device=dev)
+    address = L.awfmGpuHostAlloc(total * 8)
+    rc = L.awfmGpuLocateTo(g.handle, d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, d_work.data_ptr(), address, None)
+    assert rc == 1
+    torch.cuda.synchronize()
+    got = np.ctypeslib.as_array(C.cast(address, C.POINTER(C.c_uint64)), shape=(total,)).copy()
+    assert np.array_equal(got, pos)
+    L.awfmGpuHostFree(address)
+    monkeypatch.setenv("AWFM_GPU_STREAM_DIRECT", "1")
+    counts, positions = g.stream(awfm.pack_kmers(kmers), K, locate=True, chunk=2000)
+    assert np.array_equal(counts, cnt) and np.array_equal(positions, pos)
+    g.destroy()
+    ix.dealloc()
