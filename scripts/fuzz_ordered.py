@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the ordered hits-only search against the general kernel, all on the GPU: random index
-sizes, seed depths, deeper tables, fixed and mixed k-mer lengths, ambiguity characters, buffer alignments.
+"""Differential fuzz of the ordered hits-only search (pair steps) against the general kernel (letter by letter), and of
+the pair-step LF walk against the one-letter walk, all on the GPU: random index sizes, seed depths, deeper tables,
+fixed and mixed k-mer lengths, ambiguity characters and runs (flagged pair blocks), buffer alignments.
 With FUZZ_WIDE=1 the side under test (hits-only search, second locate) runs the 64-bit-position instantiations
 while the general kernel it is compared with keeps 32-bit positions.
 usage: scripts/fuzz_ordered.py [seconds] [seed]"""
@@ -29,9 +30,10 @@ while time.time() < t_end:
     ratio = int(rng.choice([1, 3, 8, 16, 255]))
     d_text = torch.empty(n, dtype=torch.uint8, device=dev)
     assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, int(rng.integers(1, 1 << 30)), 0, None) == 1
-    if rng.random() < 0.5:  # an ambiguity run in the text
-        at = int(rng.integers(0, n - 100))
-        d_text[at:at + int(rng.integers(1, 90))] = ord("n")
+    if rng.random() < 0.5:  # ambiguity runs in the text: their blocks, and those their LF images fall into, are flagged
+        for _ in range(int(rng.integers(1, 30))):
+            at = int(rng.integers(0, n - 100))
+            d_text[at:at + int(rng.integers(1, 90))] = ord("n")
     ix = api.gpu_create_index(d_text.data_ptr(), api.AwFmAlphabetDna, ratio, seed_k, on_device_length=n)
     g = api.GpuIndex(ix, acquire=True)
     g.set_ordered(1)
@@ -101,8 +103,10 @@ while time.time() < t_end:
                 total_b = g.hit_offsets(hits.data_ptr(), Q, off_b.data_ptr(), scratch.data_ptr())
             pos_a = torch.zeros(max(total_a, 1), dtype=torch.int64, device=dev)
             pos_b = torch.zeros(max(total_b, 1), dtype=torch.int64, device=dev)
+            os.environ["AWFM_GPU_LOCATE_NO_PAIR"] = "1"  # side A: one LF step per block read
             g.locate(exact.data_ptr(), off_a.data_ptr(), Q, total_a, pos_a.data_ptr())
             torch.cuda.synchronize()
+            del os.environ["AWFM_GPU_LOCATE_NO_PAIR"]
             g.set_wide(fuzz_wide)
             g.locate(hits.data_ptr(), off_b.data_ptr(), Q, total_b, pos_b.data_ptr())
             torch.cuda.synchronize()
