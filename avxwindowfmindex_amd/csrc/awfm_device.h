@@ -63,6 +63,7 @@ constexpr unsigned kAminoSuperShift = 16; /* positions per amino superblock: 2^1
 constexpr unsigned kAminoSuperStride = 24;
 constexpr unsigned kPairSuperShift = 23;  /* positions per superblock of the pair image: 2^23 (23-bit relative counts) */
 constexpr unsigned kPairCountMask = 0xFFFFFFu;
+constexpr unsigned kPairSuperStride = 20; /* words per superblock of the pair image: 16 pairs, then the letters a,c,g,t */
 
 /* kernel-argument view of the device image */
 struct DevIndex {
@@ -87,7 +88,7 @@ struct DevIndex {
   unsigned int deepK;
   /* optional device-only pair image (nucleotide; awfm_pair.h): two backward / LF steps per block read; NULL when
    * not built.  pairSuper32 is the 32-bit copy of the superblock bases the kernels of images below 2^32 positions
-   * keep in LDS. */
+   * keep in LDS (kPairSuperStride words per superblock). */
   const uint4 *pairBlocks;
   const unsigned long long *pairSuper;
   const unsigned int *pairSuper32;
@@ -700,7 +701,7 @@ inline bool awfmImageNarrow(const AwFmGpuIndex *g) {
  * or read from memory beside the blocks.  $AWFM_GPU_PAIR_SUPER=lds|global (measurement knob) */
 inline bool awfmPairSuperInLds(const AwFmGpuIndex *g) {
   if (const char *env = getenv("AWFM_GPU_PAIR_SUPER")) return !strcmp(env, "lds");
-  return g->dev.numPairSuper * 64u <= 32768u; /* measured: 4.46 ms from LDS against 4.91 ms from memory (10^8 random 21-mers) */
+  return g->dev.numPairSuper * (kPairSuperStride * 4u) <= 32768u; /* measured: 4.46 ms from LDS against 4.91 ms from memory (10^8 random 21-mers) */
 }
 
 /* RAII hipSetDevice */

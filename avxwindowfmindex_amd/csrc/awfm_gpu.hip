@@ -1032,7 +1032,7 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
      * dynamic LDS */
     const bool pair = !g->amino && lanes == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_LOCATE_NO_PAIR");
     const bool superInLds = pair && narrow && awfmPairSuperInLds(g);
-    const size_t pairLds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
+    const size_t pairLds = superInLds ? (size_t)g->dev.numPairSuper * (kPairSuperStride * 4u) : 0u;
     DevIndex pairDev = g->dev;
     pairDev.pairSuperInLds = superInLds ? 1u : 0u;
 #define AWFM_LOCP(P2, NR)                                                                                                    \

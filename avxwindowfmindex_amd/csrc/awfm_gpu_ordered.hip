@@ -61,7 +61,7 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
                                         const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts) {
   /* dynamic LDS: the 32-bit superblock bases of the pair image (images below 2^32 positions) */
   const bool superInLds = PAIR && NARROW && awfmPairSuperInLds(g);
-  const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
+  const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u; /* the 16 pair bases of every superblock */
   DevIndex dev = g->dev;
   dev.pairSuperInLds = superInLds ? 1u : 0u;
   constexpr int threads = orderedThreads(PAIR);

@@ -69,9 +69,8 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
   __shared__ unsigned long long sSuper[!AMINO && !NARROW ? kMaxNucSuper * 4 : 1];
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   /* PAIR: two LF steps per block read through the pair image (awfm_pair.h) wherever the position's block is not
-   * flagged and the position in between is not a sampled one; otherwise the same iteration goes on to a single step
-   * through the one-letter image (deferring that step to the next iteration, so that every iteration has one wait,
-   * was measured slower in a same-box A/B: walk + finish + expand 15.1 against 14.0 ms per 10^8 hits) */
+   * flagged; a flagged block's position goes on, in the same iteration, to a single step through the one-letter
+   * image */
   __shared__ unsigned long long sPairC[PAIR ? 16 : 1];
   extern __shared__ unsigned sPairSuper[];
   if (AMINO) aminoStageTables(sAmino);
@@ -174,6 +173,9 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
     }
     bool walk = alive && !sampled; /* a refilled hit that is sampled right away is handed over next iteration */
     if (PAIR) {
+      /* The pair block of p gives both LF(p) (its low code bits are the letters, one count per letter) and LF(LF(p)):
+       * the hit moves two steps unless the position in between is a sampled one, where it moves one and ends there in
+       * the next iteration.  Flagged blocks (ambiguity letter or sentinel around) go on to the one-letter step below. */
       const unsigned long long pblk = (unsigned long long)(p >> kBlockShift);
       const unsigned plocal = (unsigned)p & kBlockMask;
       Piece pl = (Piece)(0u), ph = (Piece)(0u);
@@ -183,23 +185,26 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
         ph = at[1];
       }
       __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */
-      if (walk) {
+      if (walk && (ph.w >> 31) == 0u) {
         const unsigned bit = plocal & 31u, ownerSlice = plocal >> 5;
-        /* pair code at p and "LF(p) is sampled", from the lane that owns p's slice */
-        const unsigned mine = ((pl.x >> bit) & 1u) | (((pl.y >> bit) & 1u) << 1) | (((pl.z >> bit) & 1u) << 2) |
-                              (((pl.w >> bit) & 1u) << 3) | (((ph.x >> bit) & 1u) << 4);
-        const unsigned got = groupShfl<G>(mine, ownerSlice);
-        const unsigned pi = got & 15u;
-        const bool single = ((ph.w >> 31) | (got >> 4)) != 0u; /* flagged block, or the walk must look at LF(p) */
-        const unsigned n = __popc(pairOccSlice(pl, 0u - (pi & 1u), 0u - ((pi >> 1) & 1u), 0u - ((pi >> 2) & 1u), 0u - (pi >> 3)) &
-                                  sliceMask(plocal, gl));
-        const unsigned base = groupShfl<G>(pairCount24(ph, pi & 3u), pi >> 2);
-        const unsigned total = groupSum<G>(n);
-        if (!single) {
-          p = (pos_t)sPairC[pi] + pairSuperBase<NARROW>(ix, sPairSuper, (unsigned long long)p, pi) + (pos_t)base + (pos_t)total - (pos_t)1;
-          steps += 2;
-          walk = false;
-        }
+        const unsigned mine = ((pl.x >> bit) & 1u) | (((pl.y >> bit) & 1u) << 1) | (((pl.z >> bit) & 1u) << 2) | (((pl.w >> bit) & 1u) << 3);
+        const unsigned pi = groupShfl<G>(mine, ownerSlice) & 15u; /* pair code at p */
+        const unsigned c2 = pi & 3u;                            /* the letter at p */
+        const unsigned mask = sliceMask(plocal, gl);
+        const unsigned m0 = 0u - (pi & 1u), m1 = 0u - ((pi >> 1) & 1u), m2 = 0u - ((pi >> 2) & 1u), m3 = 0u - (pi >> 3);
+        const unsigned sameLetter = ~((pl.x ^ m0) | (pl.y ^ m1));
+        const unsigned nLetter = __popc(sameLetter & mask), nPair = __popc(sameLetter & ~((pl.z ^ m2) | (pl.w ^ m3)) & mask);
+        const unsigned totals = groupSum<G>(nLetter | (nPair << 16));
+        const unsigned letterBase = groupShfl<G>(ph.x & kPairCountMask, c2);
+        const unsigned pairBase = groupShfl<G>(pairCount24(ph, pi & 3u), pi >> 2);
+        const pos_t one = (pos_t)sC[c2] + pairSuperBase<NARROW>(ix, sPairSuper, (unsigned long long)p, 16u + c2) + (pos_t)letterBase +
+                          (pos_t)(totals & 0xFFFFu) - (pos_t)1; /* LF(p), ref src/AwFmSearch.c:369-392 */
+        const pos_t two = (pos_t)sPairC[pi] + pairSuperBase<NARROW>(ix, sPairSuper, (unsigned long long)p, pi) + (pos_t)pairBase +
+                          (pos_t)(totals >> 16) - (pos_t)1; /* LF(LF(p)) */
+        const bool stop = POW2 ? (one & (ratio - 1)) == 0 : (one % ratio) == 0;
+        p = stop ? one : two;
+        steps += stop ? 1u : 2u;
+        walk = false;
       }
     }
     const unsigned long long blk = (unsigned long long)(p >> kBlockShift);

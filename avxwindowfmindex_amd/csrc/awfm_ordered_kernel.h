@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   stageMaskTable(sMask);
   nucStageSuper<NARROW>(ix, sSuper);
-  if (PAIR) pairStageTables<NARROW>(ix, sPairC, sPairSuper);
+  if (PAIR) pairStageTables<NARROW, 16u>(ix, sPairC, sPairSuper);
   __syncthreads();
 
   const OrderFormat format = orderFormat(depth);

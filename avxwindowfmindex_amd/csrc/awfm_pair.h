@@ -13,14 +13,17 @@
  *
  * Pair block = 128 B = one line per 128 BWT positions; slice k (positions 32k..32k+31) is two 16-B pieces:
  *   {b0, b1, b2, b3}   bit j of b_i = bit i of pair(128 blk + 32 k + j)
- *   {s1, w0, w1, w2}   bit j of s1 = "LF(position) is a sampled SA position" (the walk must stop there: it then takes
- *                      a single step through the one-letter image); w0..w2 = four 24-bit counts of the pairs 4k..4k+3
- *                      (c1 = k, c2 = 0..3) before the block, relative to the block's superblock of 2^23 positions
- *                      (bits 24 i .. 24 i + 23); bit 95, the top bit of the last count (counts stay below 2^23), is
- *                      set in every slice of a block that holds a position whose pair is not two of a,c,g,t
- *                      (ambiguity letter or sentinel at the position or at its LF image): such blocks are stepped
- *                      through the one-letter image, a letter at a time.
- * pairSuper[16 sb + pair] = absolute count at the start of superblock sb (64-bit; a 32-bit copy for LDS).
+ *   {l, w0, w1, w2}    l = 24-bit count of letter k (a,c,g,t) before the block: in a block without a flag the low two
+ *                      bits of a pair code are the position's own letter, so the block also gives the single step
+ *                      LF(p) -- which the walk needs, because it must stop at a sampled position in between two steps;
+ *                      w0..w2 = four 24-bit counts of the pairs 4k..4k+3 (c1 = k, c2 = 0..3) before the block
+ *                      (bits 24 i .. 24 i + 23); all counts relative to the block's superblock of 2^23 positions;
+ *                      bit 95, the top bit of the last count (counts stay below 2^23), is set in every slice of a
+ *                      block that holds a position whose pair is not two of a,c,g,t (ambiguity letter or sentinel at
+ *                      the position or at its LF image): such blocks are stepped through the one-letter image, a
+ *                      letter at a time.
+ * pairSuper[20 sb + i] = absolute count at the start of superblock sb of pair i (i < 16) or letter i - 16 (64-bit; a
+ * 32-bit copy for LDS).
  *
  * Only hits-only searches use pair steps (a pattern without hits may end in a different empty range than the
  * letter-by-letter stepping of the reference ends in), and the LF walk, whose result is exact either way.
@@ -44,23 +47,26 @@ __device__ __forceinline__ unsigned pairOccSlice(const Piece &planes, unsigned p
   return ~((planes.x ^ pm0) | (planes.y ^ pm1) | (planes.z ^ pm2) | (planes.w ^ pm3));
 }
 
-/* superblock base of pair `pi` at position q: from LDS (images below 2^32 positions) or from memory */
-template <bool NARROW>
+/* superblock base of entry `pi` (pair 0..15, or 16 + letter) at position q: from LDS (images below 2^32 positions) or
+ * from memory.  LDS_STRIDE: entries per superblock of the LDS copy -- the search keeps the 16 pairs only (every KB of
+ * LDS costs it resident workgroups), the walk all kPairSuperStride. */
+template <bool NARROW, unsigned LDS_STRIDE = kPairSuperStride>
 __device__ __forceinline__ typename PositionType<NARROW>::type pairSuperBase(const DevIndex &ix, const unsigned *sPairSuper,
                                                                             unsigned long long q, unsigned pi) {
   typedef typename PositionType<NARROW>::type pos_t;
-  const unsigned at = (unsigned)(q >> kPairSuperShift) * 16u + pi;
-  if (NARROW) return (pos_t)(ix.pairSuperInLds ? sPairSuper[at] : ix.pairSuper32[at]);
-  return (pos_t)ix.pairSuper[at];
+  const unsigned sb = (unsigned)(q >> kPairSuperShift);
+  if (NARROW) return (pos_t)(ix.pairSuperInLds ? sPairSuper[sb * LDS_STRIDE + pi] : ix.pairSuper32[sb * kPairSuperStride + pi]);
+  return (pos_t)ix.pairSuper[sb * kPairSuperStride + pi];
 }
 
-/* copies the pair tables into LDS: sPairC[16], and (NARROW) the 32-bit superblock bases */
-template <bool NARROW>
+/* copies the pair tables into LDS: sPairC[16], and (NARROW) the first LDS_STRIDE 32-bit bases of every superblock */
+template <bool NARROW, unsigned LDS_STRIDE = kPairSuperStride>
 __device__ __forceinline__ void pairStageTables(const DevIndex &ix, unsigned long long *sPairC, unsigned *sPairSuper) {
   if (!ix.pairBlocks) return;
   if (threadIdx.x < 16) sPairC[threadIdx.x] = ix.pairC[threadIdx.x];
   if (NARROW && ix.pairSuperInLds)
-    for (unsigned e = threadIdx.x; e < ix.numPairSuper * 16u; e += blockDim.x) sPairSuper[e] = ix.pairSuper32[e];
+    for (unsigned e = threadIdx.x; e < ix.numPairSuper * LDS_STRIDE; e += blockDim.x)
+      sPairSuper[e] = ix.pairSuper32[(e / LDS_STRIDE) * kPairSuperStride + e % LDS_STRIDE];
 }
 
 /*
@@ -93,7 +99,7 @@ __device__ __forceinline__ bool pairSearchStep(const DevIndex &ix, const unsigne
   const unsigned mask0 = sMask[((unsigned)q0 & kBlockMask) * kSlices + slice];
   const unsigned mask1 = sMask[((unsigned)q1 & kBlockMask) * kSlices + slice];
   const pos_t cPair = (pos_t)sPairC[pi];
-  const pos_t super0 = pairSuperBase<NARROW>(ix, sPairSuper, q0, pi), super1 = pairSuperBase<NARROW>(ix, sPairSuper, q1, pi);
+  const pos_t super0 = pairSuperBase<NARROW, 16u>(ix, sPairSuper, q0, pi), super1 = pairSuperBase<NARROW, 16u>(ix, sPairSuper, q1, pi);
   const unsigned sameMask = same ? ~0u : 0u;
   const unsigned occ0 = pairOccSlice(p0, pm0, pm1, pm2, pm3), occ1 = pairOccSlice(p1, pm0, pm1, pm2, pm3);
   const unsigned n0 = __popc(occ0 & mask0);

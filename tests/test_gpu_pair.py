@@ -108,7 +108,7 @@ def test_pair_image_env_knob_and_device_bytes(oracle, awfm, require_gpu, monkeyp
     without = awfm.GpuIndex(ix)
     assert with_pair.has_pair_image and not without.has_pair_image
     blocks = (ix.bwt_length + 127) // 128
-    assert with_pair.device_bytes - without.device_bytes == blocks * 128 + 192 + 128  # one superblock of 2^23 positions
+    assert with_pair.device_bytes - without.device_bytes == blocks * 128 + 20 * 12 + 128  # one superblock of 2^23 positions: 20 bases
     amino = awfm.create_index(synth.text(96, 50_000, synth.AMINO_ALPHABET), awfm.AwFmAlphabetAmino, 8, 3)
     monkeypatch.delenv("AWFM_GPU_PAIR")
     ga = awfm.GpuIndex(amino)
