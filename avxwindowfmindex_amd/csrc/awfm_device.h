@@ -63,6 +63,11 @@ constexpr unsigned kAminoSuperShift = 16; /* positions per amino superblock: 2^1
 constexpr unsigned kAminoSuperStride = 24;
 constexpr unsigned kPairSuperShift = 23;  /* positions per superblock of the pair image: 2^23 (23-bit relative counts) */
 constexpr unsigned kPairCountMask = 0xFFFFFFu;
+/* where the two 16-B pieces of slice k of pair block blk are (in uint4 units): the four plane pieces fill the first
+ * 64-B sector of the line and the four count pieces the second, so each of the two load instructions of a step touches
+ * one sector (with plane and count piece of a slice side by side every instruction touched both; measured the same) */
+__host__ __device__ inline unsigned long long pairPlanesAt(unsigned long long blk, unsigned k) { return blk * 8ull + k; }
+__host__ __device__ inline unsigned long long pairCountsAt(unsigned long long blk, unsigned k) { return blk * 8ull + 4u + k; }
 constexpr unsigned kPairSuperStride = 20; /* words per superblock of the pair image: 16 pairs, then the letters a,c,g,t */
 
 /* kernel-argument view of the device image */

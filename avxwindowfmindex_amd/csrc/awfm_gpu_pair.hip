@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256)
     /* the two slices of this half: planes piece by lanes 0 / 1 (the counts piece follows later) */
     if (lane < 2u) {
       const unsigned sh = 32u * lane;
-      const u64 piece = (half >> 1) * 8ull + 2ull * ((half & 1ull) * 2ull + lane);
+      const u64 piece = pairPlanesAt(half >> 1, (unsigned)(half & 1ull) * 2u + lane);
       pairBlocks[piece] = make_uint4((unsigned)(b0 >> sh), (unsigned)(b1 >> sh), (unsigned)(b2 >> sh), (unsigned)(b3 >> sh));
     }
   }
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(256)
     const unsigned flag = (addHalf(2ull * b) | addHalf(2ull * b + 1ull)) ? 0x80000000u : 0u;
     for (unsigned k = 0; k < 4u; k++) { /* slice k: count of letter k, counts of pairs 4k..4k+3, 24 bits each */
       const unsigned c0 = before[4 * k], c1 = before[4 * k + 1], c2 = before[4 * k + 2], c3 = before[4 * k + 3];
-      pairBlocks[b * 8ull + 2ull * k + 1ull] =
+      pairBlocks[pairCountsAt(b, k)] =
           make_uint4(before[16u + k], c0 | (c1 << 24), (c1 >> 8) | (c2 << 16), (c2 >> 16) | (c3 << 8) | flag);
     }
   }

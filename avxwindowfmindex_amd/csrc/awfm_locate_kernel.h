@@ -180,9 +180,8 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
       const unsigned plocal = (unsigned)p & kBlockMask;
       Piece pl = (Piece)(0u), ph = (Piece)(0u);
       if (walk) {
-        const Piece *at = (const Piece *)(ix.pairBlocks + (pblk * 8ull + 2u * gl));
-        pl = at[0];
-        ph = at[1];
+        pl = *(const Piece *)(ix.pairBlocks + pairPlanesAt(pblk, gl));
+        ph = *(const Piece *)(ix.pairBlocks + pairCountsAt(pblk, gl));
       }
       __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */
       if (walk && (ph.w >> 31) == 0u) {

@@ -11,7 +11,8 @@
  * where C2[c1c2] = C[c1] + Occ(c1, C[c2]) is the first row of the suffixes that start with c1c2.  The results are
  * those of the two single steps, bit for bit; only the bytes read differ.
  *
- * Pair block = 128 B = one line per 128 BWT positions; slice k (positions 32k..32k+31) is two 16-B pieces:
+ * Pair block = 128 B = one line per 128 BWT positions; slice k (positions 32k..32k+31) has two 16-B pieces, the plane
+ * piece in the first 64-B sector of the line and the count piece in the second (pairPlanesAt / pairCountsAt):
  *   {b0, b1, b2, b3}   bit j of b_i = bit i of pair(128 blk + 32 k + j)
  *   {l, w0, w1, w2}    l = 24-bit count of letter k (a,c,g,t) before the block: in a block without a flag the low two
  *                      bits of a pair code are the position's own letter, so the block also gives the single step
@@ -86,14 +87,13 @@ __device__ __forceinline__ bool pairSearchStep(const DevIndex &ix, const unsigne
   /* every lane fetches both pieces of its slice (fetching only what the rank reads -- plane pieces up to the
    * position, the count piece in the owning lane: 56 of 128 bytes -- was measured slower, 4.68 against 4.40 ms per
    * 10^8 random 21-mers: four predicated loads instead of two) */
-  const Piece *a0 = (const Piece *)(ix.pairBlocks + (blk0 * 8ull + 2u * slice));
-  const Piece p0 = a0[0], h0 = a0[1];
+  const Piece p0 = *(const Piece *)(ix.pairBlocks + pairPlanesAt(blk0, slice));
+  const Piece h0 = *(const Piece *)(ix.pairBlocks + pairCountsAt(blk0, slice));
   Piece p1, h1;
   asm volatile("" : "=v"(p1), "=v"(h1));
   if (!same) {
-    const Piece *a1 = (const Piece *)(ix.pairBlocks + (blk1 * 8ull + 2u * slice));
-    p1 = a1[0];
-    h1 = a1[1];
+    p1 = *(const Piece *)(ix.pairBlocks + pairPlanesAt(blk1, slice));
+    h1 = *(const Piece *)(ix.pairBlocks + pairCountsAt(blk1, slice));
   }
   const unsigned pm0 = 0u - (pi & 1u), pm1 = 0u - ((pi >> 1) & 1u), pm2 = 0u - ((pi >> 2) & 1u), pm3 = 0u - (pi >> 3);
   const unsigned mask0 = sMask[((unsigned)q0 & kBlockMask) * kSlices + slice];

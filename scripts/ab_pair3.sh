@@ -1,7 +1,9 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
 source scripts/ab_lib.sh
-python -m pytest tests/test_gpu_pair.py -x -q 2>&1 | tail -2
-run lf2_planted -- --workload planted --no-e2e
-run lf2_default -- --no-e2e --no-secondary
-run lf2_count -- --no-e2e --mode count
+for i in 1 2; do
+run inter${i}_planted AWFM_LIB_PATH=$PWD/avxwindowfmindex_amd/libawfm_inter.so -- --workload planted --no-e2e
+run split${i}_planted -- --workload planted --no-e2e
+run inter${i}_count AWFM_LIB_PATH=$PWD/avxwindowfmindex_amd/libawfm_inter.so -- --mode count --no-e2e
+run split${i}_count -- --mode count --no-e2e
+done

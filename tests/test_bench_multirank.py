@@ -55,7 +55,8 @@ def test_two_ranks_on_one_gpu_search_their_own_shards(oracle, awfm, require_gpu,
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
-    assert line["value"] == pytest.approx(2 * Q / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    # ms_per_step is printed with three decimals: at a fraction of a millisecond per step that rounding alone is 0.2 %
+    assert line["value"] == pytest.approx(2 * Q / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3 + 0.0006 / line["ms_per_step"])
     txt = synth.text(2, n)
     oi = oracle.Index.from_text(txt.tobytes(), oracle.DNA, 8, seed_k)
     for rank in range(2):
