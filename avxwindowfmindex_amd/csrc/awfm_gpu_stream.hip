@@ -431,7 +431,7 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
       s.first = t * chunkKmers;
       s.n = numKmers - s.first < chunkKmers ? numKmers - s.first : chunkKmers;
       s.total = 0;
-      STEP_RC(ensureSlot(s, chunkKmers, inBytesPerKmer, kmerLength, locate != 0, stage));
+      STEP_RC(ensureSlot(s, chunkKmers, inBytesPerKmer, packed ? kmerLength : 0u /* ASCII needs no unpack scratch */, locate != 0, stage));
       const uint8_t *src = (const uint8_t *)input + s.first * inBytesPerKmer;
       const size_t bytes = s.n * inBytesPerKmer;
       if (stage) {

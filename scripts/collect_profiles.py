@@ -56,6 +56,8 @@ def fetch_factor(kernel):
         return 2 if (len(args) >= 5 and args[4] == "true") or args[0] == "true" else 1  # pair image / amino: 128-B blocks
     if name == "searchKernel":
         return 2 if args and args[0] == "true" else 1
+    if name == "finishKernel":
+        return 1  # one random 8-byte read of the packed sampled SA per hit: 64-B requests
     return 2
 
 

@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 KERNELS="earchKernel|walkKernel|finishKernel|fillNoHitKernel|encodeQueriesKernel|radix_sort|onesweep|expandHitsKernel|scanTileKernel|scanReduceKernel|sortKeysKernel|bucketKernel"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e "$@" > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-secondary "$@" > "$OUT/bench_trace.log" 2>&1
 declare -A PASS
 PASS[fetch]="FETCH_SIZE"
 PASS[write]="WRITE_SIZE"
@@ -20,7 +20,7 @@ PASS[tcp]="TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_RE
 PASS[ta]="TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum"
 PASS[busy]="TCC_BUSY_avr GRBM_TA_BUSY GRBM_TC_BUSY GRBM_EA_BUSY"
 for N in ${PROFILE_PASSES:-fetch write l2 sq sq2 ea tcp ta busy}; do
-  rocprofv3 --pmc ${PASS[$N]} --kernel-include-regex "$KERNELS" --output-format csv -d "$OUT/pmc_$N" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --steps 2 --warmup 1 "$@" > "$OUT/bench_pmc_$N.log" 2>&1
+  rocprofv3 --pmc ${PASS[$N]} --kernel-include-regex "$KERNELS" --output-format csv -d "$OUT/pmc_$N" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-secondary --steps 2 --warmup 1 "$@" > "$OUT/bench_pmc_$N.log" 2>&1
   echo "pass $N: $(find "$OUT/pmc_$N" -name '*counter_collection.csv' | wc -l) csv, rc $?"
 done
 for f in $(find "$OUT/trace" -name "*kernel_stats.csv"); do echo "== $f"; head -14 "$f" | cut -c1-200; done
