@@ -1,24 +1,10 @@
 #!/bin/bash
-# pair image on/off: bench lines of the main workloads, compact
+# pair image on/off, and the knobs around it: compact bench lines of the main workloads on one box
 cd "$(dirname "$0")/.."
-mkdir -p gpurun_out
-run() { # name, env..., -- bench args
-  name=$1; shift
-  envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
-  env "${envs[@]}" python bench.py --steps 10 --warmup 3 --no-cpu "$@" > gpurun_out/ab_$name.json 2> gpurun_out/ab_$name.err
-  python - <<PY
-import json
-try:
-    d=json.loads([l for l in open("gpurun_out/ab_$name.json") if l.startswith("{")][-1])
-    r=d["roofline"]; e=d.get("end_to_end") or {}
-    print("%-22s %9.1f Mk/s  step %7.3f ms  search %7.3f ms  dom %s  locate %7.3f ms  frac %.3f  build %.1fs  e2e %s" % ("$name", d["value"], d["ms_per_step"], r["kernel_ms"], (r.get("dominant_kernel") or {}).get("ms"), d["config"]["locate_kernels_ms"], r["frac"], d["config"]["index_build_s"], {k:(v["value"], v["ms"]) for k,v in e.items() if isinstance(v, dict)}))
-except Exception as e:
-    print("$name FAILED", e); print(open("gpurun_out/ab_$name.err").read()[-1500:])
-PY
-}
-run pair_default --
-run nopair_default AWFM_GPU_PAIR=0 -- --no-e2e
-run pair_planted -- --workload planted
+source scripts/ab_lib.sh
+run pair_default -- --no-e2e --no-secondary
+run nopair_default AWFM_GPU_PAIR=0 -- --no-e2e --no-secondary
+run pair_planted -- --workload planted --no-e2e
 run nopair_planted AWFM_GPU_PAIR=0 -- --workload planted --no-e2e
-run pair_mixed -- --workload mixed
-run pair_count -- --mode count
+run pair_super_global AWFM_GPU_PAIR_SUPER=global -- --no-e2e --no-secondary
+for b in 3 4 5 6; do run pair_occ${b}_count AWFM_GPU_BLOCKS_PER_CU=$b -- --mode count --no-e2e; done

@@ -1,9 +1,3 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-source scripts/ab_lib.sh
-for i in 1 2; do
-run inter${i}_planted AWFM_LIB_PATH=$PWD/avxwindowfmindex_amd/libawfm_inter.so -- --workload planted --no-e2e
-run split${i}_planted -- --workload planted --no-e2e
-run inter${i}_count AWFM_LIB_PATH=$PWD/avxwindowfmindex_amd/libawfm_inter.so -- --mode count --no-e2e
-run split${i}_count -- --mode count --no-e2e
-done
+for c in 8388608 16777216 33554432 50000000; do for w in planted random; do echo "== chunk $c $w"; python scripts/stream_probe.py 3.1e9 1e8 $w $c 2>&1 | grep "^run [123]"; done; done

@@ -14,6 +14,7 @@ from avxwindowfmindex_amd import _lib, api  # noqa: E402
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 3_100_000_000
 Q = int(float(sys.argv[2])) if len(sys.argv) > 2 else 100_000_000
 workload = sys.argv[3] if len(sys.argv) > 3 else "planted"
+chunk = int(float(sys.argv[4])) if len(sys.argv) > 4 else 0
 K = 21
 L = _lib.lib()
 d_text = torch.empty(n, dtype=torch.uint8, device="cuda")
@@ -43,6 +44,6 @@ def sink(user, first, m, counts, positions, total):
 for i in range(4):
     seen["hits"] = 0
     t0 = time.perf_counter()
-    g.stream((address, Q), K, locate=True, chunk=0, sink=sink)
+    g.stream((address, Q), K, locate=True, chunk=chunk, sink=sink)
     dt = time.perf_counter() - t0
     print(f"run {i}: {dt * 1e3:.1f} ms = {Q / dt / 1e6:.0f} Mkmers/s, {seen['hits']} hits", flush=True)
