@@ -262,7 +262,10 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
    * many more buckets than its L2 holds the blocks of (8.7 ms with the stride, 5.8 ms with tickets).  Wave w of
    * a workgroup draws from counter w of its XCD and takes chunk 4*ticket + w, so a counter sees a quarter of the
    * traffic and no barrier ties the waves of a workgroup together.  A ticket is drawn two chunks ahead and read
-   * at the end of an iteration, so its latency and the record read hide behind the current chunk. */
+   * at the end of an iteration, so its latency and the record read hide behind the current chunk.  (Requesting the
+   * table entry a chunk ahead as well -- no dependent round left for the seed lookup -- changed nothing: 4.37-4.49 ms
+   * either way per 10^8 random 21-mers, and the extra registers cost the one-letter variant a wave per SIMD.  The
+   * kernel's time follows the number of block reads that miss the L2, not the length of a wave's chain.) */
   constexpr unsigned kWaves = orderedThreads(PAIR) / 64, kChunk = 64 / G;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   unsigned *ticket = tickets + (xcd * kWaves + wave) * 64u; /* 256 bytes apart */
