@@ -41,23 +41,22 @@ def total(kernel, counter):
     return c["mean"] * c["dispatches"] if c else 0.0
 
 
+def kernel_avg_ns(prefix):
+    if not stats:
+        return None
+    for r in csv.DictReader(open(stats[0])):
+        nm = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        if nm.startswith(prefix):
+            return float(r["AverageNs"])
+    return None
+
+
 def fetch_factor(kernel):
-    """FETCH_SIZE = TCC_EA0_RDREQ x 64 B.  The L2 asks memory for 64 B when a 64-B granule of a line is touched (the
-    one-letter blocks of the search and walk kernels: their TCC_MISS count equals the number of distinct 64-B blocks,
-    not half of it) and for 128 B when a whole line streams in -- the case MI355X_MICROARCH.md describes ("exactly half
-    of the bytes of a wide coalesced streaming read"), calibrated here on encodeQueriesKernel (2.1 GB of characters
-    read, 1.05 GB of FETCH_SIZE).  So: x1 for kernels whose reads are 64-B blocks, x2 for everything else (streams,
-    and the 128-B blocks of the pair image)."""
-    name = kernel.split("<")[0]
-    args = kernel[kernel.find("<") + 1:kernel.rfind(">")].replace(" ", "").split(",") if "<" in kernel else []
-    if name == "orderedSearchKernel":
-        return 2 if len(args) >= 5 and args[4] == "true" else 1
-    if name == "walkKernel":
-        return 2 if (len(args) >= 5 and args[4] == "true") or args[0] == "true" else 1  # pair image / amino: 128-B blocks
-    if name == "searchKernel":
-        return 2 if args and args[0] == "true" else 1
-    if name == "finishKernel":
-        return 1  # one random 8-byte read of the packed sampled SA per hit: 64-B requests
+    """FETCH_SIZE = TCC_EA0_RDREQ x 64 B, but every read request the L2 sends to memory is a whole 128-B line on
+    gfx950: TCC_EA0_RDREQ_128B_sum equals TCC_EA0_RDREQ_sum for every kernel of these runs (pass `rdreq` of
+    scripts/profile_bench.sh) -- the streaming encoder (2.1 GB of characters = 1.64e7 requests), the kernels that read
+    64-B blocks, and finishKernel, whose 10^8 random 8-byte reads are 1.06e8 requests.  So reads = 2 x FETCH_SIZE
+    throughout (MI355X_MICROARCH.md: "exactly half of the bytes")."""
     return 2
 
 
@@ -75,11 +74,10 @@ if ordered:
         "kernel": "awfmGpuSearchHits (ordered path): " + ", ".join(sorted(k.split("<")[0] for k in parts)),
         "workload": workload, "per_kernel": per_kernel, "hbm_bytes_per_launch": int(hbm),
         "method": "rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc TCC_HIT_sum TCC_MISS_sum in separate passes "
-                  "(scripts/profile_bench.sh), summed over every kernel of one awfmGpuSearchHits call.  Reads = fetch_factor x "
-                  "FETCH_SIZE: on gfx950 FETCH_SIZE tallies each read request at 64 B (MI355X_MICROARCH.md, HBM), which is "
-                  "half of a streamed 128-B line (calibrated on encodeQueriesKernel: 2.1 GB of k-mer characters read as "
-                  "1.05 GB of FETCH_SIZE) but all of a 64-B block granule (kernels on the one-letter blocks: factor 1).  "
-                  "Writes = WRITE_SIZE.  TCC_MISS_sum x 128 B is kept as a cross-check; it also counts the write-allocate "
+                  "(scripts/profile_bench.sh), summed over every kernel of one awfmGpuSearchHits call.  Reads = 2 x FETCH_SIZE: "
+                  "on gfx950 FETCH_SIZE tallies each read request at 64 B (MI355X_MICROARCH.md, HBM) and every request is a "
+                  "128-B line (TCC_EA0_RDREQ_128B_sum = TCC_EA0_RDREQ_sum for every kernel; calibrated on "
+                  "encodeQueriesKernel: 2.1 GB of k-mer characters read as 1.05 GB of FETCH_SIZE).  Writes = WRITE_SIZE.  TCC_MISS_sum x 128 B is kept as a cross-check; it also counts the write-allocate "
                   "misses of the stores.",
     }, open(os.path.join(dst, f"traffic_{name}.json"), "w"), indent=1)
     print("ordered search call: HBM GB", hbm / 1e9, {k.split("<")[0]: round((v["read_bytes"] + v["write_bytes"]) / 1e9, 2) for k, v in per_kernel.items()})
@@ -90,25 +88,16 @@ if search and not ordered:
     miss = summary[k].get("TCC_MISS_sum", {"mean": None})["mean"]
     json.dump({
         "kernel": k, "workload": workload, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "TCC_MISS_sum": miss,
+        "avg_ns_kernel_trace": kernel_avg_ns(k.split("<")[0]),
         "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (scripts/profile_bench.sh); on "
-                  "gfx950 FETCH_SIZE counts each 128-B read request as 64 B for 16-B-per-lane loads "
-                  "(MI355X_MICROARCH.md, HBM), so reads = 2 x FETCH_SIZE; cross-check: TCC_MISS_sum x 128 B; "
-                  "WRITE_SIZE is exact",
+                  "gfx950 FETCH_SIZE counts each 128-B read request as 64 B (MI355X_MICROARCH.md, HBM; every request is "
+                  "128 B: TCC_EA0_RDREQ_128B_sum = TCC_EA0_RDREQ_sum), so reads = 2 x FETCH_SIZE; cross-check: "
+                  "TCC_MISS_sum x 128 B; WRITE_SIZE is exact",
     }, open(os.path.join(dst, f"traffic_{name}.json"), "w"), indent=1)
     print(k, "traffic GB/launch", (2 * fetch_kb + write_kb) * 1024 / 1e9, "TCC_MISS x128 GB", (miss or 0) * 128 / 1e9)
 # counters of the dominant kernel, condensed for bench.py's roofline record (guide: wave64 VALU issue = 2 cycles on a
 # SIMD-32; GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_WAVE_CYCLES / SQ_WAIT_ANY count in units of 4 cycles)
-def kernel_avg_ns(prefix):
-    if not stats:
-        return None
-    for r in csv.DictReader(open(stats[0])):
-        nm = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-        if nm.startswith(prefix):
-            return float(r["AverageNs"])
-    return None
-
-
 dominant = (ordered or search or [None])[0]
 if dominant:
     c = {k: v["mean"] for k, v in summary[dominant].items()}
