@@ -239,7 +239,8 @@ void awfmGpuHostFree(void *p);
  * reference's uint32 count, ref src/AwFmIndex.h:112-118), and -- locate -- numPositions text positions, the
  * hits of k-mer firstKmer+i starting where those of firstKmer+i-1 end, each list in BWT order (what
  * awFmParallelSearchLocate puts into positionList).  The arrays are page-locked staging of the pipeline, valid until
- * the sink returns; chunks arrive in order; a non-zero return stops the batch. */
+ * the sink returns; chunks arrive in order; a non-zero return stops the batch.  The sink runs on the calling thread
+ * while the image's pipeline is locked: it must not start another batch on the same image. */
 typedef int (*AwFmGpuChunkSink)(void *user, uint64_t firstKmer, uint64_t numKmers, const uint32_t *counts,
                                 const uint64_t *positions, uint64_t numPositions);
 /* Counts (locate == 0) or locates numKmers packed host-resident k-mers in chunks of chunkKmers (0: 2^24) through

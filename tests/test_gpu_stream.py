@@ -216,3 +216,32 @@ def test_locate_into_page_locked_host_memory(oracle, awfm, require_gpu, monkeypa
     assert np.array_equal(counts, cnt) and np.array_equal(positions, pos)
     g.destroy()
     ix.dealloc()
+
+
+def test_stream_edge_cases(oracle, awfm, require_gpu):
+    """an empty batch calls no sink; chunks of one k-mer; a batch smaller than a chunk; amino k-mers beyond what a word
+    holds and nucleotide k-mers beyond 32 characters are refused"""
+    from avxwindowfmindex_amd import _lib
+    n, K = 60_000, 12
+    txt = synth.text(121, n)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 4, 5)
+    g = awfm.GpuIndex(ix)
+    calls = []
+    g.stream(np.zeros(0, np.uint64), K, locate=True, sink=lambda *a: calls.append(a) or 0)
+    assert calls == []
+    kmers = synth.planted_queries(122, 7, K, txt)
+    cnt, pos = _oracle_answers(oracle, oracle.DNA, ix, 4, 5, kmers)
+    packed = awfm.pack_kmers(kmers)
+    for chunk in (1, 3, 7, 1000):
+        counts, positions = g.stream(packed, K, locate=True, chunk=chunk)
+        assert np.array_equal(counts, cnt) and np.array_equal(positions, pos), chunk
+    with pytest.raises(awfm.AwFmError):
+        g.stream(packed, 33, locate=False)
+    amino = awfm.create_index(synth.text(123, 20_000, synth.AMINO_ALPHABET), awfm.AwFmAlphabetAmino, 4, 2)
+    ga = awfm.GpuIndex(amino)
+    with pytest.raises(awfm.AwFmError):
+        ga.stream(packed, 13, locate=False)
+    for h in (g, ga):
+        h.destroy()
+    ix.dealloc()
+    amino.dealloc()
