@@ -270,6 +270,16 @@ void launchSearchKernelN(const AwFmGpuIndex *g, const DevIndex &dev, hipStream_t
                      fixedLength, nq, rng, dCounts, dTally);
 }
 
+/* hits-only general search with two characters per block read (searchKernel<..., PAIR>) */
+template <bool CSR, bool NARROW>
+void launchPairSearchKernel(const AwFmGpuIndex *g, const DevIndex &dev, hipStream_t s, const uint8_t *dChars,
+                            const unsigned long long *off, uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng,
+                            uint32_t *dCounts) {
+  const unsigned grid = gridFor(nq, g, searchKernel<false, 4, CSR, false, NARROW, false, true>, kThreads / 4);
+  hipLaunchKernelGGL((searchKernel<false, 4, CSR, false, NARROW, false, true>), dim3(grid), dim3(kThreads), 0, s, dev, dChars,
+                     off, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr);
+}
+
 template <bool AMINO, int G, bool CSR, bool TALLY>
 void launchSearchKernel(const AwFmGpuIndex *g, const DevIndex &dev, hipStream_t s, const uint8_t *dChars,
                         const unsigned long long *off, uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng,
@@ -782,9 +792,21 @@ void awfmGpuIndexSetWide(AwFmGpuIndex *g, int wide) {
     for (AwFmGpuIndex *lane : lanesOf(g)) lane->forceWide = g->forceWide;
 }
 
+static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                         uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
+                                         uint32_t *dCounts, void *stream, bool hitsOnly);
+
 enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                   uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
                                   uint32_t *dCounts, void *stream) {
+  return searchGeneral(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream, false);
+}
+
+/* the general kernel; hitsOnly: the caller accepts any empty range for a k-mer without hits, so nucleotide searches
+ * may take two characters per block read where the image has its pair blocks */
+static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                         uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
+                                         uint32_t *dCounts, void *stream, bool hitsOnly) {
   if (!g) {
     setError("awfmGpuSearch: null image");
     return AwFmNullPtrError;
@@ -797,8 +819,18 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
   const int lanes = lanesPerQuery(g);
-  launchSearch<false>(g, g->dev, lanes, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries,
-                      (ulonglong2 *)dRanges, dCounts, nullptr);
+  if (hitsOnly && !g->amino && lanes == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_GENERAL_NO_PAIR")) {
+    const unsigned long long *off = (const unsigned long long *)dOffsets;
+    const bool narrow = awfmImageNarrow(g);
+#define AWFM_PAIR_GO(CSRV, NR) \
+  launchPairSearchKernel<CSRV, NR>(g, g->dev, s, dChars, off, fixedLength, numQueries, (ulonglong2 *)dRanges, dCounts)
+    if (off) narrow ? AWFM_PAIR_GO(true, true) : AWFM_PAIR_GO(true, false);
+    else narrow ? AWFM_PAIR_GO(false, true) : AWFM_PAIR_GO(false, false);
+#undef AWFM_PAIR_GO
+  } else {
+    launchSearch<false>(g, g->dev, lanes, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries,
+                        (ulonglong2 *)dRanges, dCounts, nullptr);
+  }
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
 }
@@ -824,7 +856,7 @@ enum AwFmReturnCode awfmGpuSearchHits(AwFmGpuIndex *g, const uint8_t *dChars, co
     if (ordered < 0) return (enum AwFmReturnCode)(-ordered);
     if (ordered > 0) return AwFmSuccess;
   }
-  return awfmGpuSearch(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream);
+  return searchGeneral(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream, true);
 }
 
 void awfmGpuIndexSetOrdered(AwFmGpuIndex *g, int mode) {

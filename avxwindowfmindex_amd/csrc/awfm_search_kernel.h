@@ -21,6 +21,7 @@
 #define AWFM_SEARCH_KERNEL_H
 
 #include "awfm_device.h"
+#include "awfm_pair.h"
 
 namespace {
 
@@ -37,8 +38,15 @@ __device__ __forceinline__ unsigned pairLength(const ulonglong2 &o) {
  * subsetTotal - *subsetCount + i of `subset` (records of subsetStride bytes), its first 32-bit word at byte
  * subsetIndexAt the query number.
  */
-template <bool AMINO, int G, bool CSR, bool TALLY, bool NARROW, bool INDIRECT = false>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 4 && !TALLY && !CSR && !AMINO && !INDIRECT ? (NARROW ? 8 : 6) : 2, 8)))
+/*
+ * PAIR (nucleotide, G = 4, hits-only callers): two characters per block read through the pair image (awfm_pair.h)
+ * wherever the next two characters are a,c,g,t inside the register window.  A k-mer without hits may then end in a
+ * different empty range than the letter-by-letter stepping ends in, which the hits-only contract allows
+ * (awfmGpuSearchHits); k-mers with hits get exactly the range of the single steps.  The memory system moves whole 128-B
+ * lines whatever a block's size, so a pair block -- one line, two steps -- halves the lines of a search.
+ */
+template <bool AMINO, int G, bool CSR, bool TALLY, bool NARROW, bool INDIRECT = false, bool PAIR = false>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 4 && !TALLY && !CSR && !AMINO && !INDIRECT && !PAIR ? (NARROW ? 8 : 6) : 2, 8)))
     searchKernel(const DevIndex ix, const unsigned char *__restrict__ chars,
                  const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
                  const unsigned long long numQueries, ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts,
@@ -54,6 +62,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
   __shared__ AminoShared sAmino;
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices]; /* sMask[local * 4 + slice] = bits of the slice at positions <= local */
   __shared__ unsigned long long sSuper[!AMINO && !NARROW ? kMaxNucSuper * 4 : 1];
+  __shared__ unsigned long long sPairC[PAIR ? 16 : 1];
+  static_assert(!PAIR || (!AMINO && G == 4 && !TALLY), "pair steps: nucleotide, 4 lanes per query, not the tally");
+  if (PAIR && threadIdx.x < 16) sPairC[threadIdx.x] = ix.pairC[threadIdx.x];
   const unsigned card = AMINO ? 20u : 4u;
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   stageMaskTable(sMask);
@@ -264,6 +275,19 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
       if (TALLY) { /* the accounting is in the reference's 256-position blocks, whatever the device layout */
         tSteps++;
         tBlocks += ((unsigned long long)(sp - 1) >> 8) == ((unsigned long long)ep >> 8) ? 1ull : 2ull;
+      }
+      if (PAIR && pos > (int)wb && (badTop >> 30) == 0u) {
+        /* ---- two characters, both a,c,g,t/u inside the register window: one pair block (the superblock bases are
+         * read from memory: pairSuperInLds is 0 for this kernel) ---- */
+        const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
+        if (pairSearchStep<NARROW>(ix, sPairC, nullptr, sMask, gl, c1 * 4u + c2, sp, ep)) {
+          nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
+          if (sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
+        }
+        pos -= 2;
+        rem >>= 4;
+        badTop <<= 2;
+        continue;
       }
       if (!AMINO && __builtin_expect(pos >= (int)wb && (int)badTop >= 0, 1)) {
         /* ---- fast step: a,c,g,t/u inside the register window (letter from the 2-bit codes of the seed decode) ---- */

@@ -41,10 +41,13 @@ def _one(meta, pattern):
 
 
 def test_default_search_kernel_keeps_full_occupancy(kernel_metadata):
-    # searchKernel<AMINO=false, G=4, CSR=false, TALLY=false, NARROW=true, INDIRECT=false>
-    k = _one(kernel_metadata, r"[0-9]searchKernelILb0ELi4ELb0ELb0ELb1ELb0EE")
+    # searchKernel<AMINO=false, G=4, CSR=false, TALLY=false, NARROW=true, INDIRECT=false, PAIR=false>
+    k = _one(kernel_metadata, r"[0-9]searchKernelILb0ELi4ELb0ELb0ELb1ELb0ELb0EE")
     assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0
     assert k["lds"] <= 16 * 1024  # 8 workgroups of 256 threads per CU must fit the 160 KB of LDS
+    # the hits-only variant with pair steps holds two blocks of 32 B per lane: 6 waves per SIMD
+    k = _one(kernel_metadata, r"[0-9]searchKernelILb0ELi4ELb0ELb0ELb1ELb0ELb1EE")
+    assert k["vgpr"] <= 80 and k["spill"] == 0 and k["scratch"] == 0
 
 
 def test_default_walk_kernel_keeps_full_occupancy(kernel_metadata):
