@@ -16,6 +16,7 @@ run planted -- --workload planted
 run mixed -- --workload mixed
 run amino -- --alphabet amino
 run general AWFM_GPU_ORDERED=0 -- --mode count --no-cpu --no-e2e
+run general_letters AWFM_GPU_ORDERED=0 AWFM_GPU_GENERAL_NO_PAIR=1 -- --mode count --no-cpu --no-e2e
 run nopair_default AWFM_GPU_PAIR=0 -- --no-cpu --no-e2e
 run nopair_planted AWFM_GPU_PAIR=0 -- --workload planted --no-cpu --no-e2e
 run deep14 -- --device-seed-k 14 --no-cpu --no-e2e
