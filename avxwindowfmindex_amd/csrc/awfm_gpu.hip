@@ -275,8 +275,14 @@ template <bool CSR, bool NARROW>
 void launchPairSearchKernel(const AwFmGpuIndex *g, const DevIndex &dev, hipStream_t s, const uint8_t *dChars,
                             const unsigned long long *off, uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng,
                             uint32_t *dCounts) {
-  const unsigned grid = gridFor(nq, g, searchKernel<false, 4, CSR, false, NARROW, false, true>, kThreads / 4);
-  hipLaunchKernelGGL((searchKernel<false, 4, CSR, false, NARROW, false, true>), dim3(grid), dim3(kThreads), 0, s, dev, dChars,
+  /* the 16 pair bases of every superblock in dynamic LDS, as in the ordered kernel (same box, 10^8 random 21-mers:
+   * 11.4-11.7 ms against 12.8-12.9 ms with the bases read from memory; $AWFM_GPU_PAIR_SUPER=lds|global) */
+  const bool inLds = NARROW && awfmPairSuperInLds(g);
+  const size_t lds = inLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
+  DevIndex view = dev;
+  view.pairSuperInLds = inLds ? 1u : 0u;
+  const unsigned grid = gridFor(nq, g, searchKernel<false, 4, CSR, false, NARROW, false, true>, kThreads / 4, lds);
+  hipLaunchKernelGGL((searchKernel<false, 4, CSR, false, NARROW, false, true>), dim3(grid), dim3(kThreads), lds, s, view, dChars,
                      off, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr);
 }
 

@@ -64,7 +64,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
   __shared__ unsigned long long sSuper[!AMINO && !NARROW ? kMaxNucSuper * 4 : 1];
   __shared__ unsigned long long sPairC[PAIR ? 16 : 1];
   static_assert(!PAIR || (!AMINO && G == 4 && !TALLY), "pair steps: nucleotide, 4 lanes per query, not the tally");
-  if (PAIR && threadIdx.x < 16) sPairC[threadIdx.x] = ix.pairC[threadIdx.x];
+  extern __shared__ unsigned sPairSuper[]; /* PAIR with ix.pairSuperInLds: the 16 pair bases of every superblock */
+  if (PAIR) pairStageTables<NARROW, 16u>(ix, sPairC, sPairSuper);
   const unsigned card = AMINO ? 20u : 4u;
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   stageMaskTable(sMask);
@@ -277,10 +278,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
         tBlocks += ((unsigned long long)(sp - 1) >> 8) == ((unsigned long long)ep >> 8) ? 1ull : 2ull;
       }
       if (PAIR && pos > (int)wb && (badTop >> 30) == 0u) {
-        /* ---- two characters, both a,c,g,t/u inside the register window: one pair block (the superblock bases are
-         * read from memory: pairSuperInLds is 0 for this kernel) ---- */
+        /* ---- two characters, both a,c,g,t/u inside the register window: one pair block ---- */
         const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
-        if (pairSearchStep<NARROW>(ix, sPairC, nullptr, sMask, gl, c1 * 4u + c2, sp, ep)) {
+        if (pairSearchStep<NARROW>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep)) {
           nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
           if (sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
         }
