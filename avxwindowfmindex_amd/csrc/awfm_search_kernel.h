@@ -162,8 +162,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
       const unsigned rel = i - wb;         /* 0..31 */
       const unsigned word = rel >> 2;      /* 0..7: lane word/W, register word%W */
       unsigned mine = win[0];
+      if (W == 2) { /* named copies: hipcc turns the select over a two-element array back into an indexed (scratch) load */
+        unsigned lo = win[0], hi = win[W - 1];
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        mine = (word & 1u) ? hi : lo;
+      } else {
 #pragma unroll
-      for (int w = 1; w < W; w++) mine = (word % W) == (unsigned)w ? win[w] : mine;
+        for (int w = 1; w < W; w++) mine = (word % W) == (unsigned)w ? win[w] : mine;
+      }
       const unsigned v = groupShfl<G>(mine, word / W);
       return (v >> (8u * (rel & 3u))) & 0xFFu;
     };
@@ -277,18 +283,18 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
         tSteps++;
         tBlocks += ((unsigned long long)(sp - 1) >> 8) == ((unsigned long long)ep >> 8) ? 1ull : 2ull;
       }
-      if (PAIR && pos > (int)wb && (badTop >> 30) == 0u) {
+      const bool pairStep = PAIR && pos > (int)wb && (badTop >> 30) == 0u;
+      if (pairStep) {
         /* ---- two characters, both a,c,g,t/u inside the register window: one pair block ---- */
         const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
         if (pairSearchStep<NARROW>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep)) {
           nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
           if (sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
         }
-        pos -= 2;
-        rem >>= 4;
-        badTop <<= 2;
-        continue;
-      }
+        pos--; /* the second character: the common tail below steps past the first */
+        rem >>= 2;
+        badTop <<= 1;
+      } else
       if (!AMINO && __builtin_expect(pos >= (int)wb && (int)badTop >= 0, 1)) {
         /* ---- fast step: a,c,g,t/u inside the register window (letter from the 2-bit codes of the seed decode) ---- */
         nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
