@@ -134,8 +134,10 @@ static bool orderedApplies(const AwFmGpuIndex *g, bool hasOffsets, uint32_t fixe
     if (const char *env = getenv("AWFM_GPU_ORDERED")) mode = atoi(env) != 0;
   }
   if (mode < 0) {
-    /* worth its sort and its extra launches only when the batch is large and the image far exceeds the L2s
-     * (measured: 20 M 21-mers against 400 Mbp +25 %, 4 M against 3.1 Gbp +3 %, 4 M against 150 Mbp -11 %) */
+    /* worth its sort and its extra launches only when the batch is large and the image far exceeds the L2s.  Against
+     * the general kernel with pair steps, 3.1 Gbp index, random / planted 21-mers (scripts/threshold_probe.sh): 4 M
+     * k-mers 0.52 against 0.42 ms / 0.81 against 0.63 ms, 8 M 0.85 against 0.88 / 1.39 against 1.31, 16 M 1.45 against
+     * 1.68 / 2.35 against 2.51, 64 M 4.44 against 6.34 / 7.93 against 9.85 */
     mode = nq >= (1ull << 23) && g->dev.bwtLength >= (1ull << 28);
   }
   return mode != 0;
