@@ -43,6 +43,11 @@ class Index:
         return int(self.c.bwtLength)
 
     @property
+    def sa_width(self):
+        """bits per sampled suffix-array value (ref src/AwFmSuffixArray.c:12-18)"""
+        return int(self.c.suffixArray.valueBitWidth)
+
+    @property
     def is_amino(self):
         return self.c.config.alphabetType == AwFmAlphabetAmino
 

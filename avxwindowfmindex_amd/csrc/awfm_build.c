@@ -118,8 +118,9 @@ enum AwFmReturnCode awfmCreateIndexWithFasta(struct AwFmIndex **index, const str
   /* Texts of a megabase and more are built on the GPU when there is one (suffix sort, BWT planes, seed table and
    * SA packing in seconds for a 3.1 Gbp genome; the arrays and the file are byte-identical to this builder's,
    * tests/test_gpu_build.py).  $AWFM_HOST_BUILD=1 keeps the build on the host; so does any failure of the GPU
-   * build (no device, not enough device memory, more than 2^32-2 positions). */
-  if (sequenceLength >= AWFM_GPU_BUILD_MIN_LENGTH && saLength <= 0xFFFFFFFEull && config->suffixArrayCompressionRatio != 0) {
+   * build (no device, not enough device memory: about 25 bytes per position, 37 from 2^32-1 positions on, where
+   * suffix positions and ranks are 64-bit). */
+  if (sequenceLength >= AWFM_GPU_BUILD_MIN_LENGTH && config->suffixArrayCompressionRatio != 0) {
     const char *hostOnly = getenv("AWFM_HOST_BUILD");
     if (!(hostOnly && *hostOnly && *hostOnly != '0') && awfmGpuDeviceCount() > 0) {
       const enum AwFmReturnCode rc =

@@ -17,7 +17,9 @@
  *      same blind backward step the host DFS uses, sampled SA bit-packing;
  *   5. download of the reference-layout arrays into a host AwFmIndex; the
  *      device image is kept and registered for awFmParallelSearch*.
- * Limits: bwtLength <= 2^32 - 2 (32-bit suffix positions on the device).
+ * Suffix positions and ranks are 32-bit on the device while bwtLength <= 2^32 - 2 and 64-bit beyond (every kernel
+ * of the suffix sort is a template over the position type; the doubling keys are then 128-bit, sorted over the bits
+ * in use); $AWFM_GPU_BUILD_WIDE=1 selects the 64-bit instantiation on any text (tests).
  */
 #include <cstdio>
 #include <cstdlib>
@@ -73,26 +75,35 @@ struct DeviceBuffer {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-inline unsigned gridOf(u64 n, unsigned block = 256) { return (unsigned)((n + block - 1) / block); }
+/* grid of a kernel with one thread per element.  A launch holds fewer than 2^32 threads (the dispatch packet counts
+ * work-items in 32 bits), so the grid is capped and every such kernel strides over its elements (EACH). */
+constexpr u64 kMaxGrid = 1ull << 22;
+inline unsigned gridOf(u64 n, unsigned block = 256) {
+  const u64 blocks = (n + block - 1) / block;
+  return (unsigned)(blocks < kMaxGrid ? (blocks ? blocks : 1) : kMaxGrid);
+}
+#define EACH(i, n)                                                                                      \
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x, stride__ = (u64)gridDim.x * blockDim.x; i < (n); \
+       i += stride__)
 
 /* ---- text ---- */
 
 /* ref src/AwFmCreate.c:452-466 + src/AwFmLetter.c:24-42, :69-79; writes the '$' terminator too */
 __global__ void sanitizeKernel(const unsigned char *__restrict__ raw, u64 n, int amino, unsigned char *__restrict__ out) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i > n) return;
-  if (i == n) {
-    out[i] = '$';
-    return;
+  EACH(i, n + 1) {
+    if (i == n) {
+      out[i] = '$';
+      continue;
+    }
+    const unsigned c = raw[i];
+    const unsigned l = c | 0x20u;
+    unsigned r;
+    if (amino)
+      r = (l == 'b' || l == 'x' || c == 0) ? 'z' : c;
+    else
+      r = (l == 'a' || l == 'c' || l == 'g' || l == 't' || l == 'u' || l == '$') ? l : 'x';
+    out[i] = (unsigned char)r;
   }
-  const unsigned c = raw[i];
-  const unsigned l = c | 0x20u;
-  unsigned r;
-  if (amino)
-    r = (l == 'b' || l == 'x' || c == 0) ? 'z' : c;
-  else
-    r = (l == 'a' || l == 'c' || l == 'g' || l == 't' || l == 'u' || l == '$') ? l : 'x';
-  out[i] = (unsigned char)r;
 }
 
 __global__ void byteHistogramKernel(const unsigned char *__restrict__ text, u64 n, u64 *__restrict__ hist) {
@@ -107,157 +118,180 @@ __global__ void byteHistogramKernel(const unsigned char *__restrict__ text, u64 
 
 /* key(i) = dense codes of text[i..i+perKey) packed MSB first, 0 past the end */
 constexpr int kKeyTile = 1024;
+template <class P>
 __global__ void __launch_bounds__(256)
     suffixKeyKernel(const unsigned char *__restrict__ text, u64 n, const unsigned char *__restrict__ codeTable,
-                    unsigned bits, unsigned perKey, u64 *__restrict__ keys, u32 *__restrict__ positions) {
+                    unsigned bits, unsigned perKey, u64 *__restrict__ keys, P *__restrict__ positions) {
   __shared__ unsigned char sCode[256];
   __shared__ unsigned char sText[kKeyTile + 64];
   sCode[threadIdx.x] = codeTable[threadIdx.x];
   __syncthreads();
-  const u64 base = (u64)blockIdx.x * kKeyTile;
-  for (unsigned t = threadIdx.x; t < kKeyTile + 64; t += 256) {
-    const u64 i = base + t;
-    sText[t] = i < n ? sCode[text[i]] : 0;
-  }
-  __syncthreads();
-  for (unsigned t = threadIdx.x; t < kKeyTile; t += 256) {
-    const u64 i = base + t;
-    if (i >= n) break;
-    u64 key = 0;
-    for (unsigned c = 0; c < perKey; c++) key = (key << bits) | sText[t + c];
-    keys[i] = key;
-    positions[i] = (u32)i;
+  for (u64 base = (u64)blockIdx.x * kKeyTile; base < n; base += (u64)gridDim.x * kKeyTile) {
+    for (unsigned t = threadIdx.x; t < kKeyTile + 64; t += 256) {
+      const u64 i = base + t;
+      sText[t] = i < n ? sCode[text[i]] : 0;
+    }
+    __syncthreads();
+    for (unsigned t = threadIdx.x; t < kKeyTile; t += 256) {
+      const u64 i = base + t;
+      if (i >= n) break;
+      u64 key = 0;
+      for (unsigned c = 0; c < perKey; c++) key = (key << bits) | sText[t + c];
+      keys[i] = key;
+      positions[i] = (P)i;
+    }
+    __syncthreads();
   }
 }
 
 /* ---- suffix array refinement ---- */
 
 __global__ void tiedFlagKernel(const u64 *__restrict__ keys, u64 n, unsigned char *__restrict__ tied) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const u64 k = keys[i];
-  tied[i] = (i > 0 && keys[i - 1] == k) || (i + 1 < n && keys[i + 1] == k);
+  EACH(i, n) {
+    const u64 k = keys[i];
+    tied[i] = (i > 0 && keys[i - 1] == k) || (i + 1 < n && keys[i + 1] == k);
+  }
 }
 
-__global__ void inverseSaKernel(const u32 *__restrict__ sa, u64 n, u32 *__restrict__ rank) {
-  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) rank[sa[i]] = (u32)i;
+template <class P>
+__global__ void inverseSaKernel(const P *__restrict__ sa, u64 n, P *__restrict__ rank) {
+  EACH(i, n) rank[sa[i]] = (P)i;
 }
 
 /* compact state of the tied suffixes: slot (SA index), val (text position), headSlot candidates */
-__global__ void tiedInitKernel(const u64 *__restrict__ keys, const u32 *__restrict__ sa, const u32 *__restrict__ slot,
-                               u64 t, u32 *__restrict__ val, u32 *__restrict__ headSlot) {
-  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= t) return;
-  const u32 s = slot[j];
-  val[j] = sa[s];
-  const bool head = s == 0 || keys[s] != keys[s - 1];
-  headSlot[j] = head ? s : 0u;
+template <class P>
+__global__ void tiedInitKernel(const u64 *__restrict__ keys, const P *__restrict__ sa, const P *__restrict__ slot,
+                               u64 t, P *__restrict__ val, P *__restrict__ headSlot) {
+  EACH(j, t) {
+    const P s = slot[j];
+    val[j] = sa[s];
+    const bool head = s == 0 || keys[s] != keys[s - 1];
+    headSlot[j] = head ? s : (P)0;
+  }
 }
 
-__global__ void setRankKernel(const u32 *__restrict__ val, const u32 *__restrict__ grp, u64 t, u32 *__restrict__ rank) {
-  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < t) rank[val[j]] = grp[j];
+template <class P>
+__global__ void setRankKernel(const P *__restrict__ val, const P *__restrict__ grp, u64 t, P *__restrict__ rank) {
+  EACH(j, t) rank[val[j]] = grp[j];
 }
 
-__global__ void doublingKeyKernel(const u32 *__restrict__ val, const u32 *__restrict__ grp, const u32 *__restrict__ rank,
-                                  u64 t, u64 n, u64 h, u64 *__restrict__ key2) {
-  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= t) return;
-  const u64 next = (u64)val[j] + h;
-  const u64 second = next < n ? (u64)rank[next] + 1ull : 0ull;
-  key2[j] = ((u64)grp[j] << 32) | second;
+/* key of a tied suffix for the round with offset h: (its group, 1 + the rank of the suffix h characters on, 0 past
+ * the end), the group in the high half -- 2 x 32 bits for 32-bit positions, 2 x 64 for 64-bit ones */
+template <class P>
+struct DoublingKey {
+  typedef u64 type;
+};
+template <>
+struct DoublingKey<u64> {
+  typedef __uint128_t type;
+};
+
+template <class P>
+__global__ void doublingKeyKernel(const P *__restrict__ val, const P *__restrict__ grp, const P *__restrict__ rank,
+                                  u64 t, u64 n, u64 h, typename DoublingKey<P>::type *__restrict__ key2) {
+  typedef typename DoublingKey<P>::type K2;
+  EACH(j, t) {
+    const u64 next = (u64)val[j] + h;
+    const u64 second = next < n ? (u64)rank[next] + 1ull : 0ull;
+    key2[j] = ((K2)grp[j] << (8u * sizeof(P))) | (K2)second;
+  }
 }
 
 /* after sorting (key2,val): write the new order into the SA, derive the new group heads */
-__global__ void doublingApplyKernel(const u64 *__restrict__ key2, const u32 *__restrict__ val,
-                                    const u32 *__restrict__ slot, u64 t, u32 *__restrict__ sa,
-                                    u32 *__restrict__ headSlot) {
-  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= t) return;
-  sa[slot[j]] = val[j];
-  const bool head = j == 0 || key2[j] != key2[j - 1];
-  headSlot[j] = head ? slot[j] : 0u;
+template <class P>
+__global__ void doublingApplyKernel(const typename DoublingKey<P>::type *__restrict__ key2, const P *__restrict__ val,
+                                    const P *__restrict__ slot, u64 t, P *__restrict__ sa, P *__restrict__ headSlot) {
+  EACH(j, t) {
+    sa[slot[j]] = val[j];
+    const bool head = j == 0 || key2[j] != key2[j - 1];
+    headSlot[j] = head ? slot[j] : (P)0;
+  }
 }
 
 /* keep[j] = still tied after this round */
-__global__ void stillTiedKernel(const u64 *__restrict__ key2, u64 t, unsigned char *__restrict__ keep) {
-  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= t) return;
-  const u64 k = key2[j];
-  keep[j] = (j > 0 && key2[j - 1] == k) || (j + 1 < t && key2[j + 1] == k);
+template <class K2>
+__global__ void stillTiedKernel(const K2 *__restrict__ key2, u64 t, unsigned char *__restrict__ keep) {
+  EACH(j, t) {
+    const K2 k = key2[j];
+    keep[j] = (j > 0 && key2[j - 1] == k) || (j + 1 < t && key2[j + 1] == k);
+  }
 }
 
-__global__ void compactTriplesKernel(const unsigned char *__restrict__ keep, const u32 *__restrict__ dest, u64 t,
-                                     const u32 *__restrict__ slotIn, const u32 *__restrict__ valIn,
-                                     const u32 *__restrict__ grpIn, u32 *__restrict__ slotOut,
-                                     u32 *__restrict__ valOut, u32 *__restrict__ grpOut) {
-  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= t || !keep[j]) return;
-  const u32 d = dest[j];
-  slotOut[d] = slotIn[j];
-  valOut[d] = valIn[j];
-  grpOut[d] = grpIn[j];
+template <class P>
+__global__ void compactTriplesKernel(const unsigned char *__restrict__ keep, const P *__restrict__ dest, u64 t,
+                                     const P *__restrict__ slotIn, const P *__restrict__ valIn,
+                                     const P *__restrict__ grpIn, P *__restrict__ slotOut, P *__restrict__ valOut,
+                                     P *__restrict__ grpOut) {
+  EACH(j, t) {
+    if (!keep[j]) continue;
+    const P d = dest[j];
+    slotOut[d] = slotIn[j];
+    valOut[d] = valIn[j];
+    grpOut[d] = grpIn[j];
+  }
 }
 
-__global__ void flagsToU32Kernel(const unsigned char *__restrict__ flags, u64 t, u32 *__restrict__ out) {
-  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < t) out[j] = flags[j];
+template <class P>
+__global__ void flagsToCountsKernel(const unsigned char *__restrict__ flags, u64 t, P *__restrict__ out) {
+  EACH(j, t) out[j] = flags[j];
 }
 
+template <class P>
 struct MaxOp {
-  __host__ __device__ u32 operator()(u32 a, u32 b) const { return a > b ? a : b; }
+  __host__ __device__ P operator()(P a, P b) const { return a > b ? a : b; }
 };
 
 /* ---- BWT blocks ---- */
 
 /* one 256-thread workgroup per BWT block: bit planes by wave ballots
  * (ref src/AwFmCreate.c:291-336, :350-395) and the block's letter histogram */
-template <bool AMINO>
+template <bool AMINO, class P>
 __global__ void __launch_bounds__(256)
-    bwtBlockKernel(const unsigned char *__restrict__ text, const u32 *__restrict__ sa, u64 n, u64 numBlocks,
+    bwtBlockKernel(const unsigned char *__restrict__ text, const P *__restrict__ sa, u64 n, u64 numBlocks,
                    u64 *__restrict__ refBlocks, u64 *__restrict__ blockCounts, u64 *__restrict__ sentinelPos) {
   constexpr unsigned kPlanes = AMINO ? 5 : 3;
   constexpr unsigned kLetters = AMINO ? 22 : 6;
   constexpr unsigned kWords = AMINO ? 44 : 20; /* u64 words per reference block */
   __shared__ unsigned sCount[4][24];
-  const u64 blk = blockIdx.x;
-  const u64 i = blk * 256ull + threadIdx.x;
-  const bool valid = i < n;
-  unsigned letter = 0xFFu, code = 0;
-  if (valid) {
-    const u32 p = sa[i];
-    if (p == 0) {
-      letter = AMINO ? 21u : 5u;
-      *sentinelPos = i;
-    } else {
-      const unsigned c = text[p - 1];
-      letter = AMINO ? (c == '$' ? 21u : (unsigned)kAminoTables.letterOfAscii[c & 31u]) : nucLetterIndex(c);
+  for (u64 blk = blockIdx.x; blk < numBlocks; blk += gridDim.x) {
+    const u64 i = blk * 256ull + threadIdx.x;
+    const bool valid = i < n;
+    unsigned letter = 0xFFu, code = 0;
+    if (valid) {
+      const P p = sa[i];
+      if (p == 0) {
+        letter = AMINO ? 21u : 5u;
+        *sentinelPos = i;
+      } else {
+        const unsigned c = text[p - 1];
+        letter = AMINO ? (c == '$' ? 21u : (unsigned)kAminoTables.letterOfAscii[c & 31u]) : nucLetterIndex(c);
+      }
+      if (AMINO) {
+        /* index -> code, ref src/AwFmLetter.c:81-87 */
+        const unsigned char codes[22] = {0x0C, 0x17, 0x03, 0x06, 0x1E, 0x1A, 0x1B, 0x19, 0x15, 0x1C, 0x1D,
+                                         0x08, 0x09, 0x04, 0x13, 0x0A, 0x05, 0x16, 0x01, 0x02, 0x1F, 0x00};
+        code = codes[letter];
+      } else {
+        code = (0x421356u >> (4u * letter)) & 7u; /* {6,5,3,1,2,4}, ref src/AwFmLetter.c:44-47 */
+      }
     }
-    if (AMINO) {
-      /* index -> code, ref src/AwFmLetter.c:81-87 */
-      const unsigned char codes[22] = {0x0C, 0x17, 0x03, 0x06, 0x1E, 0x1A, 0x1B, 0x19, 0x15, 0x1C, 0x1D,
-                                       0x08, 0x09, 0x04, 0x13, 0x0A, 0x05, 0x16, 0x01, 0x02, 0x1F, 0x00};
-      code = codes[letter];
-    } else {
-      code = (0x421356u >> (4u * letter)) & 7u; /* {6,5,3,1,2,4}, ref src/AwFmLetter.c:44-47 */
-    }
-  }
-  const unsigned wave = threadIdx.x >> 6;
-  u64 *dst = refBlocks + blk * kWords;
+    const unsigned wave = threadIdx.x >> 6;
+    u64 *dst = refBlocks + blk * kWords;
 #pragma unroll
-  for (unsigned j = 0; j < kPlanes; j++) {
-    const u64 word = __ballot((code >> j) & 1u);
-    if ((threadIdx.x & 63u) == 0) dst[4 * j + wave] = word;
+    for (unsigned j = 0; j < kPlanes; j++) {
+      const u64 word = __ballot((code >> j) & 1u);
+      if ((threadIdx.x & 63u) == 0) dst[4 * j + wave] = word;
+    }
+    for (unsigned l = 0; l < kLetters; l++) {
+      const u64 m = __ballot(letter == l);
+      if ((threadIdx.x & 63u) == 0) sCount[wave][l] = (unsigned)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < kLetters)
+      blockCounts[(u64)threadIdx.x * numBlocks + blk] =
+          (u64)sCount[0][threadIdx.x] + sCount[1][threadIdx.x] + sCount[2][threadIdx.x] + sCount[3][threadIdx.x];
+    __syncthreads();
   }
-  for (unsigned l = 0; l < kLetters; l++) {
-    const u64 m = __ballot(letter == l);
-    if ((threadIdx.x & 63u) == 0) sCount[wave][l] = (unsigned)__popcll(m);
-  }
-  __syncthreads();
-  if (threadIdx.x < kLetters)
-    blockCounts[(u64)threadIdx.x * numBlocks + blk] =
-        (u64)sCount[0][threadIdx.x] + sCount[1][threadIdx.x] + sCount[2][threadIdx.x] + sCount[3][threadIdx.x];
 }
 
 /* base occurrences = exclusive scan of the per-block counts, copied into the block headers
@@ -268,11 +302,11 @@ __global__ void baseOccurrenceKernel(const u64 *__restrict__ scanned, u64 numBlo
   constexpr unsigned kCounters = AMINO ? 24 : 8;
   constexpr unsigned kWords = AMINO ? 44 : 20;
   constexpr unsigned kFirst = AMINO ? 20 : 12;
-  const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  const u64 blk = t / kCounters;
-  const unsigned c = (unsigned)(t % kCounters);
-  if (blk >= numBlocks) return;
-  refBlocks[blk * kWords + kFirst + c] = c < kLetters ? scanned[(u64)c * numBlocks + blk] : 0ull;
+  EACH(t, numBlocks * kCounters) {
+    const u64 blk = t / kCounters;
+    const unsigned c = (unsigned)(t % kCounters);
+    refBlocks[blk * kWords + kFirst + c] = c < kLetters ? scanned[(u64)c * numBlocks + blk] : 0ull;
+  }
 }
 
 /* ---- seed table ---- */
@@ -315,23 +349,25 @@ __global__ void __launch_bounds__(kThreads)
 
 /* 64-bit word j of the little-endian bit stream of samples SA[s*ratio], `width` bits each
  * (ref src/AwFmSuffixArray.c:58-112) */
-__global__ void packSampledSaKernel(const u32 *__restrict__ sa, u64 samples, unsigned ratio, unsigned width,
+template <class P>
+__global__ void packSampledSaKernel(const P *__restrict__ sa, u64 samples, unsigned ratio, unsigned width,
                                     u64 words, u64 *__restrict__ out) {
-  const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= words) return;
-  const u64 firstBit = j * 64ull;
-  u64 word = 0;
-  for (u64 s = firstBit / width; s < samples && s * width < firstBit + 64ull; s++) {
-    const u64 v = sa[s * ratio];
-    const long long shift = (long long)(s * width) - (long long)firstBit;
-    word |= shift >= 0 ? v << shift : v >> (-shift);
+  EACH(j, words) {
+    const u64 firstBit = j * 64ull;
+    u64 word = 0;
+    for (u64 s = firstBit / width; s < samples && s * width < firstBit + 64ull; s++) {
+      const u64 v = sa[s * ratio];
+      const long long shift = (long long)(s * width) - (long long)firstBit;
+      word |= shift >= 0 ? v << shift : v >> (-shift);
+    }
+    out[j] = word;
   }
-  out[j] = word;
 }
 
 /* ---- rocPRIM wrappers ---- */
 
-bool sortPairs(u64 *keysIn, u64 *keysOut, u32 *valsIn, u32 *valsOut, u64 n, unsigned endBit, DeviceBuffer &temp,
+template <class K, class V>
+bool sortPairs(K *keysIn, K *keysOut, V *valsIn, V *valsOut, u64 n, unsigned endBit, DeviceBuffer &temp,
                size_t &tempBytes) {
   size_t need = 0;
   BUILD_TRY(rocprim::radix_sort_pairs(nullptr, need, keysIn, keysOut, valsIn, valsOut, (size_t)n, 0u, endBit,
@@ -345,44 +381,36 @@ bool sortPairs(u64 *keysIn, u64 *keysOut, u32 *valsIn, u32 *valsOut, u64 n, unsi
   return true;
 }
 
-bool maxScanU32(const u32 *in, u32 *out, u64 n, DeviceBuffer &temp, size_t &tempBytes) {
+template <class P>
+bool maxScan(const P *in, P *out, u64 n, DeviceBuffer &temp, size_t &tempBytes) {
   size_t need = 0;
-  BUILD_TRY(rocprim::inclusive_scan(nullptr, need, in, out, (size_t)n, MaxOp(), (hipStream_t)0));
+  BUILD_TRY(rocprim::inclusive_scan(nullptr, need, in, out, (size_t)n, MaxOp<P>(), (hipStream_t)0));
   if (need > tempBytes) {
     if (!temp.alloc(need)) return false;
     tempBytes = need;
   }
-  BUILD_TRY(rocprim::inclusive_scan(temp.p, need, in, out, (size_t)n, MaxOp(), (hipStream_t)0));
+  BUILD_TRY(rocprim::inclusive_scan(temp.p, need, in, out, (size_t)n, MaxOp<P>(), (hipStream_t)0));
   return true;
 }
 
-bool exclusiveSumU32(const u32 *in, u32 *out, u64 n, DeviceBuffer &temp, size_t &tempBytes) {
+template <class T>
+bool exclusiveSum(const T *in, T *out, u64 n, DeviceBuffer &temp, size_t &tempBytes) {
   size_t need = 0;
-  BUILD_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0u, (size_t)n, rocprim::plus<u32>(), (hipStream_t)0));
+  BUILD_TRY(rocprim::exclusive_scan(nullptr, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), (hipStream_t)0));
   if (need > tempBytes) {
     if (!temp.alloc(need)) return false;
     tempBytes = need;
   }
-  BUILD_TRY(rocprim::exclusive_scan(temp.p, need, in, out, 0u, (size_t)n, rocprim::plus<u32>(), (hipStream_t)0));
-  return true;
-}
-
-bool exclusiveSumU64(const u64 *in, u64 *out, u64 n, DeviceBuffer &temp, size_t &tempBytes) {
-  size_t need = 0;
-  BUILD_TRY(rocprim::exclusive_scan(nullptr, need, in, out, 0ull, (size_t)n, rocprim::plus<u64>(), (hipStream_t)0));
-  if (need > tempBytes) {
-    if (!temp.alloc(need)) return false;
-    tempBytes = need;
-  }
-  BUILD_TRY(rocprim::exclusive_scan(temp.p, need, in, out, 0ull, (size_t)n, rocprim::plus<u64>(), (hipStream_t)0));
+  BUILD_TRY(rocprim::exclusive_scan(temp.p, need, in, out, (T)0, (size_t)n, rocprim::plus<T>(), (hipStream_t)0));
   return true;
 }
 
 /* indices i in [0,n) with flags[i] != 0 -> out, count -> *countHost */
-bool selectFlagged(const unsigned char *flags, u64 n, u32 *out, u64 *countHost, DeviceBuffer &temp, size_t &tempBytes) {
+template <class P>
+bool selectFlagged(const unsigned char *flags, u64 n, P *out, u64 *countHost, DeviceBuffer &temp, size_t &tempBytes) {
   DeviceBuffer dCount;
   if (!dCount.alloc(sizeof(u64))) return false;
-  rocprim::counting_iterator<u32> ids(0u);
+  rocprim::counting_iterator<P> ids((P)0);
   size_t need = 0;
   BUILD_TRY(rocprim::select(nullptr, need, ids, flags, out, dCount.as<u64>(), (size_t)n, (hipStream_t)0));
   if (need > tempBytes) {
@@ -394,8 +422,11 @@ bool selectFlagged(const unsigned char *flags, u64 n, u32 *out, u64 *countHost, 
   return true;
 }
 
-/* suffix array of dText[0..n) into dSa (u32); dText ends with the unique '$' */
-bool buildSuffixArray(const unsigned char *dText, u64 n, u32 *dSa, bool verbose) {
+/* suffix array of dText[0..n) into dSa (positions of type P); dText ends with the unique '$' */
+template <class P>
+bool buildSuffixArray(const unsigned char *dText, u64 n, P *dSa, bool verbose) {
+  typedef typename DoublingKey<P>::type K2;
+  constexpr size_t W = sizeof(P);
   /* dense codes from the byte histogram */
   DeviceBuffer dHist, dCode;
   if (!dHist.alloc(256 * sizeof(u64)) || !dCode.alloc(256)) return false;
@@ -410,6 +441,10 @@ bool buildSuffixArray(const unsigned char *dText, u64 n, u32 *dSa, bool verbose)
   while ((1u << bits) <= distinct) bits++;
   const unsigned perKey = 64 / bits;
   BUILD_TRY(hipMemcpy(dCode.p, code, 256, hipMemcpyHostToDevice));
+  /* bits of a rank + 1 (<= n): what the low half of a doubling key holds */
+  unsigned rankBits = 1;
+  while (rankBits < 64 && (n >> rankBits) != 0) rankBits++;
+  const unsigned doublingEndBit = (unsigned)(8 * W) + (W == 4 ? 32u : rankBits);
 
   DeviceBuffer temp;
   size_t tempBytes = 0;
@@ -418,12 +453,11 @@ bool buildSuffixArray(const unsigned char *dText, u64 n, u32 *dSa, bool verbose)
   DeviceBuffer dRank;
   {
     DeviceBuffer keysA, keysB, valsB;
-    if (!keysA.alloc(n * 8) || !keysB.alloc(n * 8) || !valsB.alloc(n * 4)) return false;
-    hipLaunchKernelGGL(suffixKeyKernel, dim3(gridOf(n, kKeyTile)), dim3(256), 0, 0, dText, n, dCode.as<unsigned char>(),
-                       bits, perKey, keysA.as<u64>(), valsB.as<u32>());
+    if (!keysA.alloc(n * 8) || !keysB.alloc(n * 8) || !valsB.alloc(n * W)) return false;
+    hipLaunchKernelGGL(suffixKeyKernel<P>, dim3(gridOf(n, kKeyTile)), dim3(256), 0, 0, dText, n,
+                       dCode.as<unsigned char>(), bits, perKey, keysA.as<u64>(), valsB.as<P>());
     BUILD_TRY(hipGetLastError());
-    if (!sortPairs(keysA.as<u64>(), keysB.as<u64>(), valsB.as<u32>(), dSa, n, bits * perKey, temp, tempBytes))
-      return false;
+    if (!sortPairs(keysA.as<u64>(), keysB.as<u64>(), valsB.as<P>(), dSa, n, bits * perKey, temp, tempBytes)) return false;
     keysA.reset();
     valsB.reset();
     /* which suffixes still tie on their first perKey characters */
@@ -431,30 +465,26 @@ bool buildSuffixArray(const unsigned char *dText, u64 n, u32 *dSa, bool verbose)
     if (!dTied.alloc(n)) return false;
     hipLaunchKernelGGL(tiedFlagKernel, dim3(gridOf(n)), dim3(256), 0, 0, keysB.as<u64>(), n, dTied.as<unsigned char>());
     BUILD_TRY(hipGetLastError());
-    /* select needs an output as large as the worst case only if everything ties; size it by a count first */
-    DeviceBuffer dFlag32;
-    {
-      /* count = sum of flags via select's own counter: run select into a full-size buffer lazily */
-      if (!dSlot.alloc(n * 4)) return false;
-      if (!selectFlagged(dTied.as<unsigned char>(), n, dSlot.as<u32>(), &tied, temp, tempBytes)) return false;
-    }
-    if (verbose) fprintf(stderr, "[awfm build] %llu suffixes, %u bits/char, %u chars/key, %llu tied after the key sort\n",
-                         n, bits, perKey, tied);
+    if (!dSlot.alloc(n * W)) return false; /* worst case: everything ties */
+    if (!selectFlagged(dTied.as<unsigned char>(), n, dSlot.as<P>(), &tied, temp, tempBytes)) return false;
+    if (verbose)
+      fprintf(stderr, "[awfm build] %llu suffixes (%zu-bit positions), %u bits/char, %u chars/key, %llu tied after the key sort\n",
+              n, 8 * W, bits, perKey, tied);
     if (tied == 0) return true;
-    if (!dRank.alloc(n * 4)) return false;
-    hipLaunchKernelGGL(inverseSaKernel, dim3(gridOf(n)), dim3(256), 0, 0, dSa, n, dRank.as<u32>());
+    if (!dRank.alloc(n * W)) return false;
+    hipLaunchKernelGGL(inverseSaKernel<P>, dim3(gridOf(n)), dim3(256), 0, 0, dSa, n, dRank.as<P>());
     BUILD_TRY(hipGetLastError());
     /* compact tied state, group heads from the sorted keys */
     DeviceBuffer dVal, dHead, dGrp;
-    if (!dVal.alloc(tied * 4) || !dHead.alloc(tied * 4) || !dGrp.alloc(tied * 4)) return false;
-    hipLaunchKernelGGL(tiedInitKernel, dim3(gridOf(tied)), dim3(256), 0, 0, keysB.as<u64>(), dSa, dSlot.as<u32>(), tied,
-                       dVal.as<u32>(), dHead.as<u32>());
+    if (!dVal.alloc(tied * W) || !dHead.alloc(tied * W) || !dGrp.alloc(tied * W)) return false;
+    hipLaunchKernelGGL(tiedInitKernel<P>, dim3(gridOf(tied)), dim3(256), 0, 0, keysB.as<u64>(), dSa, dSlot.as<P>(), tied,
+                       dVal.as<P>(), dHead.as<P>());
     BUILD_TRY(hipGetLastError());
     keysB.reset();
     dTied.reset();
-    if (!maxScanU32(dHead.as<u32>(), dGrp.as<u32>(), tied, temp, tempBytes)) return false;
-    hipLaunchKernelGGL(setRankKernel, dim3(gridOf(tied)), dim3(256), 0, 0, dVal.as<u32>(), dGrp.as<u32>(), tied,
-                       dRank.as<u32>());
+    if (!maxScan(dHead.as<P>(), dGrp.as<P>(), tied, temp, tempBytes)) return false;
+    hipLaunchKernelGGL(setRankKernel<P>, dim3(gridOf(tied)), dim3(256), 0, 0, dVal.as<P>(), dGrp.as<P>(), tied,
+                       dRank.as<P>());
     BUILD_TRY(hipGetLastError());
 
     /* prefix doubling on the tied subset */
@@ -465,37 +495,43 @@ bool buildSuffixArray(const unsigned char *dText, u64 n, u32 *dSa, bool verbose)
     curVal.p = dVal.release();
     curGrp.p = dGrp.release();
     for (u64 h = perKey; t > 0; h *= 2) {
-      if (!key2A.alloc(t * 8) || !key2B.alloc(t * 8) || !valOut.alloc(t * 4) || !keep.alloc(t) || !dest.alloc(t * 4))
+      if (h >= 2 * n + perKey) { /* every suffix is unique by its first n characters: cannot happen on sound state */
+        awfmGpuSetError("awfmGpuCreateIndex: the suffix sort did not converge");
         return false;
-      hipLaunchKernelGGL(doublingKeyKernel, dim3(gridOf(t)), dim3(256), 0, 0, curVal.as<u32>(), curGrp.as<u32>(),
-                         dRank.as<u32>(), t, n, h, key2A.as<u64>());
-      BUILD_TRY(hipGetLastError());
-      if (!sortPairs(key2A.as<u64>(), key2B.as<u64>(), curVal.as<u32>(), valOut.as<u32>(), t, 64, temp, tempBytes))
+      }
+      if (!key2A.alloc(t * sizeof(K2)) || !key2B.alloc(t * sizeof(K2)) || !valOut.alloc(t * W) || !keep.alloc(t) ||
+          !dest.alloc(t * W))
         return false;
-      hipLaunchKernelGGL(doublingApplyKernel, dim3(gridOf(t)), dim3(256), 0, 0, key2B.as<u64>(), valOut.as<u32>(),
-                         curSlot.as<u32>(), t, dSa, dHead.as<u32>());
+      hipLaunchKernelGGL(doublingKeyKernel<P>, dim3(gridOf(t)), dim3(256), 0, 0, curVal.as<P>(), curGrp.as<P>(),
+                         dRank.as<P>(), t, n, h, key2A.as<K2>());
       BUILD_TRY(hipGetLastError());
-      if (!maxScanU32(dHead.as<u32>(), curGrp.as<u32>(), t, temp, tempBytes)) return false;
-      hipLaunchKernelGGL(setRankKernel, dim3(gridOf(t)), dim3(256), 0, 0, valOut.as<u32>(), curGrp.as<u32>(), t,
-                         dRank.as<u32>());
-      hipLaunchKernelGGL(stillTiedKernel, dim3(gridOf(t)), dim3(256), 0, 0, key2B.as<u64>(), t, keep.as<unsigned char>());
+      if (!sortPairs(key2A.as<K2>(), key2B.as<K2>(), curVal.as<P>(), valOut.as<P>(), t, doublingEndBit, temp, tempBytes))
+        return false;
+      hipLaunchKernelGGL(doublingApplyKernel<P>, dim3(gridOf(t)), dim3(256), 0, 0, key2B.as<K2>(), valOut.as<P>(),
+                         curSlot.as<P>(), t, dSa, dHead.as<P>());
+      BUILD_TRY(hipGetLastError());
+      if (!maxScan(dHead.as<P>(), curGrp.as<P>(), t, temp, tempBytes)) return false;
+      hipLaunchKernelGGL(setRankKernel<P>, dim3(gridOf(t)), dim3(256), 0, 0, valOut.as<P>(), curGrp.as<P>(), t,
+                         dRank.as<P>());
+      hipLaunchKernelGGL(stillTiedKernel<K2>, dim3(gridOf(t)), dim3(256), 0, 0, key2B.as<K2>(), t,
+                         keep.as<unsigned char>());
       BUILD_TRY(hipGetLastError());
       /* compaction: exclusive sum of keep flags */
-      DeviceBuffer keep32;
-      if (!keep32.alloc(t * 4)) return false;
-      hipLaunchKernelGGL(flagsToU32Kernel, dim3(gridOf(t)), dim3(256), 0, 0, keep.as<unsigned char>(), t, keep32.as<u32>());
-      if (!exclusiveSumU32(keep32.as<u32>(), dest.as<u32>(), t, temp, tempBytes)) return false;
-      u32 lastDest = 0;
+      DeviceBuffer keepCounts;
+      if (!keepCounts.alloc(t * W)) return false;
+      hipLaunchKernelGGL(flagsToCountsKernel<P>, dim3(gridOf(t)), dim3(256), 0, 0, keep.as<unsigned char>(), t,
+                         keepCounts.as<P>());
+      if (!exclusiveSum<P>(keepCounts.as<P>(), dest.as<P>(), t, temp, tempBytes)) return false;
+      P lastDest = 0;
       unsigned char lastKeep = 0;
-      BUILD_TRY(hipMemcpy(&lastDest, dest.as<u32>() + (t - 1), 4, hipMemcpyDeviceToHost));
+      BUILD_TRY(hipMemcpy(&lastDest, dest.as<P>() + (t - 1), W, hipMemcpyDeviceToHost));
       BUILD_TRY(hipMemcpy(&lastKeep, keep.as<unsigned char>() + (t - 1), 1, hipMemcpyDeviceToHost));
       const u64 newT = (u64)lastDest + lastKeep;
       if (verbose) fprintf(stderr, "[awfm build]   doubling h=%llu: %llu tied -> %llu\n", h, t, newT);
       if (newT == 0) break;
-      if (!slot2.alloc(newT * 4) || !val2.alloc(newT * 4) || !grp2.alloc(newT * 4)) return false;
-      hipLaunchKernelGGL(compactTriplesKernel, dim3(gridOf(t)), dim3(256), 0, 0, keep.as<unsigned char>(), dest.as<u32>(),
-                         t, curSlot.as<u32>(), valOut.as<u32>(), curGrp.as<u32>(), slot2.as<u32>(), val2.as<u32>(),
-                         grp2.as<u32>());
+      if (!slot2.alloc(newT * W) || !val2.alloc(newT * W) || !grp2.alloc(newT * W)) return false;
+      hipLaunchKernelGGL(compactTriplesKernel<P>, dim3(gridOf(t)), dim3(256), 0, 0, keep.as<unsigned char>(), dest.as<P>(),
+                         t, curSlot.as<P>(), valOut.as<P>(), curGrp.as<P>(), slot2.as<P>(), val2.as<P>(), grp2.as<P>());
       BUILD_TRY(hipGetLastError());
       BUILD_TRY(hipDeviceSynchronize());
       curSlot.reset();
@@ -504,11 +540,33 @@ bool buildSuffixArray(const unsigned char *dText, u64 n, u32 *dSa, bool verbose)
       curSlot.p = slot2.release();
       curVal.p = val2.release();
       curGrp.p = grp2.release();
-      if (!dHead.alloc(newT * 4)) return false;
+      if (!dHead.alloc(newT * W)) return false;
       t = newT;
     }
   }
   BUILD_TRY(hipDeviceSynchronize());
+  return true;
+}
+
+/* what the rest of the build reads the suffix array for: the BWT blocks and the sampled, bit-packed SA */
+template <class P>
+bool launchBwtBlocks(bool amino, const unsigned char *dText, const void *dSa, u64 n, u64 numBlocks, u64 *refBlocks,
+                     u64 *blockCounts, u64 *sentinelPos) {
+  if (amino)
+    hipLaunchKernelGGL((bwtBlockKernel<true, P>), dim3(gridOf(numBlocks, 1)), dim3(256), 0, 0, dText, (const P *)dSa, n,
+                       numBlocks, refBlocks, blockCounts, sentinelPos);
+  else
+    hipLaunchKernelGGL((bwtBlockKernel<false, P>), dim3(gridOf(numBlocks, 1)), dim3(256), 0, 0, dText, (const P *)dSa, n,
+                       numBlocks, refBlocks, blockCounts, sentinelPos);
+  BUILD_TRY(hipGetLastError());
+  return true;
+}
+
+template <class P>
+bool launchPackSampledSa(const void *dSa, u64 samples, unsigned ratio, unsigned width, u64 words, u64 *out) {
+  hipLaunchKernelGGL(packSampledSaKernel<P>, dim3(gridOf(words)), dim3(256), 0, 0, (const P *)dSa, samples, ratio, width,
+                     words, out);
+  BUILD_TRY(hipGetLastError());
   return true;
 }
 
@@ -571,10 +629,6 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
     return AwFmGeneralFailure;
   }
   const u64 n = sequenceLength + 1; /* bwtLength */
-  if (n > 0xFFFFFFFEull) {
-    awfmGpuSetError("awfmGpuCreateIndex: the GPU builder handles bwtLength <= 2^32-2");
-    return AwFmUnsupportedVersionError;
-  }
   if (config->suffixArrayCompressionRatio == 0) {
     awfmGpuSetError("awfmGpuCreateIndex: suffixArrayCompressionRatio must be >= 1");
     return AwFmGeneralFailure;
@@ -593,6 +647,9 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
   }
   const bool verbose = getenv("AWFM_VERBOSE") != nullptr;
   const bool amino = config->alphabetType == AwFmAlphabetAmino;
+  /* 32-bit suffix positions and ranks while they fit ($AWFM_GPU_BUILD_WIDE=1: 64-bit ones on any text, for tests) */
+  const char *wideEnv = getenv("AWFM_GPU_BUILD_WIDE");
+  const bool wide = n > 0xFFFFFFFEull || (wideEnv && *wideEnv && *wideEnv != '0');
   const u64 numBlocks = awfmNumBlocks(n);
   const unsigned refWords = amino ? 44 : 20;
   const unsigned letters = amino ? 22 : 6;
@@ -640,8 +697,9 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
 
   /* 2. suffix array */
   DeviceBuffer dSa;
-  STEP(dSa.alloc(n * 4));
-  STEP(buildSuffixArray(dText.as<unsigned char>(), n, dSa.as<u32>(), verbose));
+  STEP(dSa.alloc(n * (wide ? 8 : 4)));
+  STEP(wide ? buildSuffixArray<u64>(dText.as<unsigned char>(), n, dSa.as<u64>(), verbose)
+            : buildSuffixArray<u32>(dText.as<unsigned char>(), n, dSa.as<u32>(), verbose));
 
   /* 3. reference-layout blocks */
   DeviceBuffer dRef, dCounts, dScanned, dSentinel, temp;
@@ -651,16 +709,13 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
   STEP(dScanned.alloc((u64)letters * numBlocks * 8));
   STEP(dSentinel.alloc(8));
   STEP_HIP(hipMemset(dSentinel.p, 0, 8));
-  if (amino)
-    hipLaunchKernelGGL(bwtBlockKernel<true>, dim3((unsigned)numBlocks), dim3(256), 0, 0, dText.as<unsigned char>(),
-                       dSa.as<u32>(), n, numBlocks, dRef.as<u64>(), dCounts.as<u64>(), dSentinel.as<u64>());
-  else
-    hipLaunchKernelGGL(bwtBlockKernel<false>, dim3((unsigned)numBlocks), dim3(256), 0, 0, dText.as<unsigned char>(),
-                       dSa.as<u32>(), n, numBlocks, dRef.as<u64>(), dCounts.as<u64>(), dSentinel.as<u64>());
-  STEP_HIP(hipGetLastError());
+  STEP(wide ? launchBwtBlocks<u64>(amino, dText.as<unsigned char>(), dSa.p, n, numBlocks, dRef.as<u64>(), dCounts.as<u64>(),
+                                   dSentinel.as<u64>())
+            : launchBwtBlocks<u32>(amino, dText.as<unsigned char>(), dSa.p, n, numBlocks, dRef.as<u64>(), dCounts.as<u64>(),
+                                   dSentinel.as<u64>()));
   u64 totals[24] = {0};
   for (unsigned l = 0; l < letters; l++) {
-    STEP(exclusiveSumU64(dCounts.as<u64>() + (u64)l * numBlocks, dScanned.as<u64>() + (u64)l * numBlocks, numBlocks, temp,
+    STEP(exclusiveSum<u64>(dCounts.as<u64>() + (u64)l * numBlocks, dScanned.as<u64>() + (u64)l * numBlocks, numBlocks, temp,
                          tempBytes));
     u64 lastScan = 0, lastCount = 0;
     STEP_HIP(hipMemcpy(&lastScan, dScanned.as<u64>() + (u64)l * numBlocks + (numBlocks - 1), 8, hipMemcpyDeviceToHost));
@@ -754,11 +809,12 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
   ix->suffixArray.compressedByteLength = awfmSaPackedBytes(n, config->suffixArrayCompressionRatio);
   const u64 saWords = (ix->suffixArray.compressedByteLength + 15) / 16 * 2 + 32; /* +256 B: 128-byte window reads */
   STEP(dPacked.alloc(saWords * 8));
-  hipLaunchKernelGGL(packSampledSaKernel, dim3(gridOf(saWords)), dim3(256), 0, 0, dSa.as<u32>(),
-                     awfmSaSampleCount(n, config->suffixArrayCompressionRatio),
-                     (unsigned)config->suffixArrayCompressionRatio, (unsigned)ix->suffixArray.valueBitWidth, saWords,
-                     dPacked.as<u64>());
-  STEP_HIP(hipGetLastError());
+  {
+    const u64 samples = awfmSaSampleCount(n, config->suffixArrayCompressionRatio);
+    const unsigned ratio = (unsigned)config->suffixArrayCompressionRatio, width = (unsigned)ix->suffixArray.valueBitWidth;
+    STEP(wide ? launchPackSampledSa<u64>(dSa.p, samples, ratio, width, saWords, dPacked.as<u64>())
+              : launchPackSampledSa<u32>(dSa.p, samples, ratio, width, saWords, dPacked.as<u64>()));
+  }
   STEP_HIP(hipDeviceSynchronize());
   dSa.reset();
 

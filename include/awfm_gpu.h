@@ -113,7 +113,10 @@ int awfmGpuIndexIsWide(const AwFmGpuIndex *g); /* 1 when searches on this image 
  * the device: suffix sort (radix + prefix doubling), BWT bit planes, base counts, seed table, sampled
  * SA.  `sequence` is a host pointer, or a device pointer when sequenceOnDevice != 0.  fileSrc may be
  * NULL (no .awfmi file is written; an extension over the reference).  The device image stays
- * resident and is the one awFmParallelSearch* will use.  Needs bwtLength <= 2^32-2. */
+ * resident and is the one awFmParallelSearch* will use.  Suffix positions and ranks are 32-bit on the device while
+ * bwtLength <= 2^32-2 (about 25 bytes of HBM per position at the peak) and 64-bit beyond (about 37 bytes per
+ * position: a 4.4 Gbp text builds in 12 s, a two-strand human genome of 6.2 Gbp fits one MI355X);
+ * $AWFM_GPU_BUILD_WIDE=1 selects the 64-bit suffix sort on any text (tests). */
 enum AwFmReturnCode awfmGpuCreateIndex(struct AwFmIndex **index, const struct AwFmIndexConfiguration *config,
                                        const uint8_t *sequence, uint64_t sequenceLength, int sequenceOnDevice,
                                        const char *fileSrc, int device);

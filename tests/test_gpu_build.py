@@ -13,6 +13,17 @@ from avxwindowfmindex_amd import synth
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[False, True], ids=["pos32", "pos64"])
+def build_wide(request, monkeypatch):
+    """the suffix sort of the GPU builder with 32-bit and with 64-bit positions and ranks (the latter is what texts of
+    2^32 - 1 characters and more get; $AWFM_GPU_BUILD_WIDE=1 selects it on any text)"""
+    if request.param:
+        monkeypatch.setenv("AWFM_GPU_BUILD_WIDE", "1")
+    else:
+        monkeypatch.delenv("AWFM_GPU_BUILD_WIDE", raising=False)
+    return request.param
+
+
 def _host_build(awfm, *args, **kwargs):
     """awFmCreateIndex kept on the host builder (texts of 2^20 characters and more go to the GPU builder otherwise)"""
     import os
@@ -32,7 +43,7 @@ def _same_arrays(a, b):
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 29, 255, 256, 257, 4096, 100003, 1 << 20])
-def test_dna_build_matches_host(awfm, require_gpu, n):
+def test_dna_build_matches_host(awfm, require_gpu, build_wide, n):
     txt = synth.text(40 + n, n).copy()
     if n > 100:
         txt[7:12] = ord("N")
@@ -46,7 +57,7 @@ def test_dna_build_matches_host(awfm, require_gpu, n):
 
 
 @pytest.mark.parametrize("n", [0, 1, 31, 256, 5000, 300001])
-def test_amino_build_matches_host(awfm, require_gpu, n):
+def test_amino_build_matches_host(awfm, require_gpu, build_wide, n):
     txt = synth.text(50 + n, n, synth.AMINO_ALPHABET).copy()
     if n > 100:
         txt[3:6] = ord("x")
@@ -59,7 +70,7 @@ def test_amino_build_matches_host(awfm, require_gpu, n):
         dev.dealloc()
 
 
-def test_repetitive_texts_need_doubling_rounds(awfm, require_gpu):
+def test_repetitive_texts_need_doubling_rounds(awfm, require_gpu, build_wide):
     cases = [b"a" * 5000, b"acgt" * 4000 + b"a", (b"acgtacgtaa" * 3000) + b"t" * 300,
              bytes(synth.text(3, 2000)) * 40]
     for raw in cases:

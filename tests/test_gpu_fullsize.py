@@ -181,3 +181,81 @@ def test_hits_only_search_takes_the_ordered_path_by_itself_and_agrees_with_the_g
         assert np.array_equal(counts[lo:lo + m].cpu().numpy().view(np.uint32), cnt)
     g.destroy()
     ix.dealloc()
+
+
+def test_an_index_beyond_2_pow_32_positions_built_searched_and_located_on_the_gpu(oracle, awfm, require_gpu):
+    """bwtLength > 2^32 for real (ref src/AwFmIndex.h:55-65, :88-91 and src/AwFmSuffixArray.c:12-18 are 64-bit
+    throughout): the builder's 64-bit suffix sort, 33-bit sampled SA values, two nucleotide superblocks, the 64-bit
+    search / walk kernels and the pair image's global superblock table, with nothing forced by a knob.  Planted
+    24-mers -- a share of them taken beyond position 2^32 -- must come back at their planting offsets, every hit must
+    spell its k-mer, and an oracle-checked sample of the batch (planted and random k-mers) must agree bit for bit."""
+    import time
+    import torch
+    from avxwindowfmindex_amd import _lib, synth
+    L = _lib.lib()
+    n = int(os.environ.get("AWFM_TEST_WIDE_TEXT_LEN", (1 << 32) + 100_000_000))
+    Q = int(os.environ.get("AWFM_TEST_WIDE_QUERIES", 10_000_000))
+    K = 24
+    dev = torch.device("cuda")
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * n:
+        pytest.skip(f"needs about {40 * n >> 30} GiB of HBM for the 64-bit suffix sort, {free >> 30} GiB free")
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, 7, 0, None) == 1
+    t0 = time.time()
+    ix = awfm.gpu_create_index(d_text.data_ptr(), awfm.AwFmAlphabetDna, 8, 12, on_device_length=n)
+    print(f"\n[wide build] {n} nt in {time.time() - t0:.1f} s, SA width {ix.sa_width} bits")
+    assert ix.bwt_length == n + 1 and (n < (1 << 32) or ix.sa_width == 33)
+    g = awfm.GpuIndex(ix, acquire=True)
+    assert g.has_pair_image
+    half = Q // 2
+    d_chars = torch.empty(Q * K, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthPlantedQueries(d_chars.data_ptr(), 0, half, K, 203, d_text.data_ptr(), n, None) == 1
+    assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr() + half * K, 0, Q - half, K, 204, 0, None) == 1
+    d_ranges = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+    d_hits = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+    d_counts = torch.empty(Q, dtype=torch.int32, device=dev)
+    d_counts2 = torch.empty(Q, dtype=torch.int32, device=dev)
+    d_off = torch.empty(Q + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.empty(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+    g.search(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr())  # exact ranges, general kernel
+    g.set_ordered(1)
+    g.search_hits(d_chars.data_ptr(), 0, K, Q, d_hits.data_ptr(), d_counts2.data_ptr())  # seed order + pair steps
+    torch.cuda.synchronize()
+    assert torch.equal(d_counts, d_counts2)
+    hit = d_counts > 0
+    assert torch.equal(d_ranges.view(Q, 2)[hit], d_hits.view(Q, 2)[hit])
+    assert bool(hit[:half].all()), "a planted k-mer was not found"
+    assert int(d_ranges.view(Q, 2)[hit].max()) > (1 << 32) or n < (1 << 32)
+    total = g.hit_offsets(d_hits.data_ptr(), Q, d_off.data_ptr(), d_scratch.data_ptr())
+    d_pos = torch.empty(total, dtype=torch.int64, device=dev)
+    g.locate(d_hits.data_ptr(), d_off.data_ptr(), Q, total, d_pos.data_ptr())
+    torch.cuda.synchronize()
+    lens = d_counts.to(torch.int64)
+    assert int(lens.sum()) == total and int(d_pos.min()) >= 0 and int(d_pos.max()) <= n - K
+    owner = torch.repeat_interleave(torch.arange(Q, device=dev), lens)
+    q2d = d_chars.view(Q, K)
+    for c in range(K):
+        assert torch.equal(d_text[d_pos + c], q2d[owner, c]), f"hit does not match the k-mer at character {c}"
+    planted = torch.from_numpy(synth.planted_offsets(203, half, K, n).astype(np.int64)).to(dev)
+    beyond = planted >= (1 << 32)
+    assert n < (1 << 32) or int(beyond.sum()) > half // 100
+    single = lens[:half] == 1
+    assert float(single.float().mean()) > 0.99
+    assert torch.equal(d_pos[d_off[:half][single]], planted[single])
+    assert n < (1 << 32) or bool((beyond & single).any())
+    # oracle over the downloaded (reference-layout) arrays on a sample from both halves of the batch
+    oi = oracle.Index.wrap(oracle.DNA, 8, 12, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    m = 100_000
+    for first in (0, half):
+        chars = d_chars[first * K:(first + m) * K].cpu().numpy()
+        offsets = np.arange(m + 1, dtype=np.uint64) * np.uint64(K)
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=os.cpu_count() or 1)
+        ho, pos, _ = oi.batch_locate(sp, ep, threads=os.cpu_count() or 1)
+        gr = d_ranges[2 * first: 2 * (first + m)].cpu().numpy().view(np.uint64).reshape(m, 2)
+        assert np.array_equal(gr[:, 0], sp) and np.array_equal(gr[:, 1], ep), "exact ranges differ from the oracle's"
+        base = int(d_off[first])
+        assert np.array_equal(d_off[first: first + m + 1].cpu().numpy().view(np.uint64) - np.uint64(base), ho)
+        assert np.array_equal(d_pos[base: base + int(ho[-1])].cpu().numpy().view(np.uint64), pos)
+    g.destroy()
+    ix.dealloc()
