@@ -125,30 +125,39 @@ __global__ void denseSaGatherKernel(const unsigned *__restrict__ dense, unsigned
     out[t] = dense[positions[t]];
 }
 
+/* blocks of 256 threads for n elements, at most 2^22 of them */
+inline unsigned cappedGrid(unsigned long long n) {
+  const unsigned long long blocks = (n + 255ull) / 256ull;
+  return (unsigned)(blocks < (1ull << 22) ? (blocks ? blocks : 1ull) : (1ull << 22));
+}
+
 /* dPositions[hitOffsets[i] + h] = sp_i + h (the BWT positions to trace back) */
 __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const unsigned long long *__restrict__ hitOffsets,
                                  unsigned long long n, unsigned long long *__restrict__ positions) {
-  /* one wave per 64 queries: short lists by their own lane, long lists by the whole wave */
-  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long start = 0, count = 0, sp = 0;
-  if (i < n) {
-    start = hitOffsets[i];
-    count = hitOffsets[i + 1] - start;
-    if (count) sp = ranges[i].x; /* batches with few hits: the ranges are not read at all */
-  }
-  const bool isLong = count > 32ull;
-  if (!isLong)
-    for (unsigned long long h = 0; h < count; h++) positions[start + h] = sp + h;
-  unsigned long long longMask = __ballot(isLong);
+  /* one wave per 64 queries: short lists by their own lane, long lists by the whole wave; the grid is capped (a
+   * launch holds fewer than 2^32 threads), workgroups stride over the batch */
   const unsigned lane = threadIdx.x & 63u;
-  while (longMask) {
-    const int src = __ffsll((long long)longMask) - 1;
-    longMask &= longMask - 1ull;
-    const unsigned long long s = __shfl(start, src, 64), c = __shfl(count, src, 64), p = __shfl(sp, src, 64);
-    for (unsigned long long h = lane; h < c; h += 64ull) positions[s + h] = p + h;
+  for (unsigned long long base = (unsigned long long)blockIdx.x * blockDim.x; base < n;
+       base += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned long long i = base + threadIdx.x;
+    unsigned long long start = 0, count = 0, sp = 0;
+    if (i < n) {
+      start = hitOffsets[i];
+      count = hitOffsets[i + 1] - start;
+      if (count) sp = ranges[i].x; /* batches with few hits: the ranges are not read at all */
+    }
+    const bool isLong = count > 32ull;
+    if (!isLong)
+      for (unsigned long long h = 0; h < count; h++) positions[start + h] = sp + h;
+    unsigned long long longMask = __ballot(isLong);
+    while (longMask) {
+      const int src = __ffsll((long long)longMask) - 1;
+      longMask &= longMask - 1ull;
+      const unsigned long long s = __shfl(start, src, 64), c = __shfl(count, src, 64), p = __shfl(sp, src, 64);
+      for (unsigned long long h = lane; h < c; h += 64ull) positions[s + h] = p + h;
+    }
   }
 }
-
 }  // namespace
 
 /* ------------------------------------------------------------------ host side */
@@ -270,7 +279,7 @@ void launchSearchKernelN(const AwFmGpuIndex *g, const DevIndex &dev, hipStream_t
                      fixedLength, nq, rng, dCounts, dTally);
 }
 
-/* hits-only general search with two characters per block read (searchKernel<..., PAIR>) */
+/* general search with two characters per block read (searchKernel<..., PAIR>; exact ranges) */
 template <bool CSR, bool NARROW>
 void launchPairSearchKernel(const AwFmGpuIndex *g, const DevIndex &dev, hipStream_t s, const uint8_t *dChars,
                             const unsigned long long *off, uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng,
@@ -808,8 +817,9 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
   return searchGeneral(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream, false);
 }
 
-/* the general kernel; hitsOnly: the caller accepts any empty range for a k-mer without hits, so nucleotide searches
- * may take two characters per block read where the image has its pair blocks */
+/* the general kernel: exact ranges (the reference's final range for k-mers without hits too).  Nucleotide images with
+ * pair blocks take two characters per block read (exact as well, awfm_pair.h; $AWFM_GPU_GENERAL_NO_PAIR: one-letter
+ * steps only).  hitsOnly is what the caller needs, not what it gets. */
 static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                          uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
                                          uint32_t *dCounts, void *stream, bool hitsOnly) {
@@ -825,7 +835,8 @@ static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars,
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
   const int lanes = lanesPerQuery(g);
-  if (hitsOnly && !g->amino && lanes == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_GENERAL_NO_PAIR")) {
+  (void)hitsOnly;
+  if (!g->amino && lanes == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_GENERAL_NO_PAIR")) {
     const unsigned long long *off = (const unsigned long long *)dOffsets;
     const bool narrow = awfmImageNarrow(g);
 #define AWFM_PAIR_GO(CSRV, NR) \
@@ -1029,7 +1040,7 @@ enum AwFmReturnCode awfmGpuLocateTo(AwFmGpuIndex *g, const struct AwFmSearchRang
   }
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(expandHitsKernel, dim3((unsigned)((numQueries + 255) / 256)), dim3(256), 0, s,
+  hipLaunchKernelGGL(expandHitsKernel, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
                      (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets,
                      (unsigned long long)numQueries, (unsigned long long *)dPositions);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);

@@ -67,23 +67,23 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     packKmersKernel(const unsigned char *__restrict__ chars, unsigned len, u64 n, int amino, u64 *__restrict__ packed,
                     u64 *__restrict__ bad) {
-  const u64 j = (u64)blockIdx.x * 256ull + threadIdx.x;
-  if (j >= n) return;
-  u64 w = 0;
-  bool ok = true;
-  for (unsigned c = 0; c < len; c++) {
-    const unsigned ch = chars[j * len + c];
-    if (amino) {
-      const unsigned a = ch == '$' ? 21u : (unsigned)kAminoTables.letterOfAscii[ch & 31u]; /* as the ASCII API maps it */
-      ok &= a < 20u;
-      w = (w << 5) | (a & 31u);
-    } else {
-      ok &= (nucIsAcgtu(ch) & 1u) != 0u;
-      w = (w << 2) | (nucLetterIndex(ch) & 3u);
+  for (u64 j = (u64)blockIdx.x * 256ull + threadIdx.x; j < n; j += (u64)gridDim.x * 256ull) {
+    u64 w = 0;
+    bool ok = true;
+    for (unsigned c = 0; c < len; c++) {
+      const unsigned ch = chars[j * len + c];
+      if (amino) {
+        const unsigned a = ch == '$' ? 21u : (unsigned)kAminoTables.letterOfAscii[ch & 31u]; /* as the ASCII API maps it */
+        ok &= a < 20u;
+        w = (w << 5) | (a & 31u);
+      } else {
+        ok &= (nucIsAcgtu(ch) & 1u) != 0u;
+        w = (w << 2) | (nucLetterIndex(ch) & 3u);
+      }
     }
+    packed[j] = ok ? w : ~0ull;
+    if (!ok) atomicAdd(bad, 1ull);
   }
-  packed[j] = ok ? w : ~0ull;
-  if (!ok) atomicAdd(bad, 1ull);
 }
 
 struct StreamSlot {
@@ -303,7 +303,7 @@ enum AwFmReturnCode awfmGpuPackKmers(AwFmGpuIndex *g, const uint8_t *dChars, uin
   AWFM_HIP_TRY(hipMalloc((void **)&dBad, 8), AwFmAllocationFailure);
   hipError_t e = hipMemsetAsync(dBad, 0, 8, s);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(packKmersKernel, dim3((unsigned)((numKmers + 255) / 256)), dim3(256), 0, s, dChars, kmerLength,
+    hipLaunchKernelGGL(packKmersKernel, dim3((unsigned)((numKmers + 255) / 256 < (1ull << 22) ? (numKmers + 255) / 256 : (1ull << 22))), dim3(256), 0, s, dChars, kmerLength,
                        (u64)numKmers, g->amino ? 1 : 0, (u64 *)dPacked, dBad);
     e = hipGetLastError();
   }

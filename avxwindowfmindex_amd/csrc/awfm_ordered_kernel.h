@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       }
       while (pos >= 1 && sp <= ep) {
         const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
-        if (pairSearchStep<NARROW>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep)) {
+        if (pairSearchStep<NARROW>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep) == kPairFlagged) {
           /* a block with an ambiguity letter or the sentinel: letter by letter through the one-letter image */
           nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
           if (sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);

@@ -26,8 +26,13 @@
  * pairSuper[20 sb + i] = absolute count at the start of superblock sb of pair i (i < 16) or letter i - 16 (64-bit; a
  * 32-bit copy for LDS).
  *
- * Only hits-only searches use pair steps (a pattern without hits may end in a different empty range than the
- * letter-by-letter stepping of the reference ends in), and the LF walk, whose result is exact either way.
+ * A pattern that dies inside a pair step ends, in the reference's letter-by-letter stepping, in the empty range of the
+ * first step that failed.  The general kernel reproduces it (pairSearchStep<..., EXACT>): an unflagged pair block also
+ * gives the single step of c2 -- its letter counts, and the low two planes, which are the positions' own letters --
+ * so when the pair's range comes out empty the range after c2 alone is computed from the same registers; if that one
+ * is empty it is the reference's final range, otherwise the pattern died on c1 and the caller takes that one step
+ * through the one-letter image.  The ordered (hits-only) search skips this and reports the pair's empty range; the
+ * LF walk is exact either way.
  */
 #ifndef AWFM_PAIR_H
 #define AWFM_PAIR_H
@@ -70,16 +75,23 @@ __device__ __forceinline__ void pairStageTables(const DevIndex &ix, unsigned lon
       sPairSuper[e] = ix.pairSuper32[(e / LDS_STRIDE) * kPairSuperStride + e % LDS_STRIDE];
 }
 
+/* what pairSearchStep did */
+enum PairStep : unsigned {
+  kPairStepped = 0u,      /* sp/ep are the range after both characters (EXACT: or the reference's final empty range) */
+  kPairFlagged = 1u,      /* a block is flagged: sp/ep untouched, the caller takes both steps through the one-letter image */
+  kPairDiedOnSecond = 2u, /* EXACT only: sp/ep are the non-empty range after c2; the step of c1, which empties it, is the caller's */
+};
+
 /*
  * Two backward steps (c2 first, then c1; pi = 4 c1 + c2) of a query by the 4 lanes of its group: lane k holds slice k
- * of a pair block.  Returns true when either block is flagged -- sp/ep are then untouched and the caller takes the two
- * steps through the one-letter image.  Loads and rank are arranged as in nucFastStep.
+ * of a pair block.  Loads and rank are arranged as in nucFastStep.  EXACT: see the head of this file; sC = prefix sums.
  */
-template <bool NARROW>
-__device__ __forceinline__ bool pairSearchStep(const DevIndex &ix, const unsigned long long *sPairC, const unsigned *sPairSuper,
-                                               const unsigned *sMask, unsigned slice, unsigned pi,
-                                               typename PositionType<NARROW>::type &sp,
-                                               typename PositionType<NARROW>::type &ep) {
+template <bool NARROW, bool EXACT = false>
+__device__ __forceinline__ PairStep pairSearchStep(const DevIndex &ix, const unsigned long long *sPairC,
+                                                   const unsigned *sPairSuper, const unsigned *sMask, unsigned slice,
+                                                   unsigned pi, typename PositionType<NARROW>::type &sp,
+                                                   typename PositionType<NARROW>::type &ep,
+                                                   const unsigned long long *sC = nullptr) {
   typedef typename PositionType<NARROW>::type pos_t;
   const pos_t q0 = sp - 1, q1 = ep;
   const unsigned long long blk0 = q0 >> kBlockShift, blk1 = q1 >> kBlockShift;
@@ -111,10 +123,32 @@ __device__ __forceinline__ bool pairSearchStep(const DevIndex &ix, const unsigne
   base1 = same ? base0 : base1;
   const unsigned flagged = (h0.w | (same ? 0u : h1.w)) >> 31; /* the flag is in every slice of a flagged block */
   const unsigned packed = groupSum<4>(n0 | (n1 << 16));
-  if (flagged) return true;
-  sp = cPair + super0 + (pos_t)base0 + (pos_t)(packed & 0xFFFFu);
-  ep = cPair + super1 + (pos_t)base1 + (pos_t)(packed >> 16) - (pos_t)1;
-  return false;
+  if (flagged) return kPairFlagged;
+  const pos_t sp2 = cPair + super0 + (pos_t)base0 + (pos_t)(packed & 0xFFFFu);
+  const pos_t ep2 = cPair + super1 + (pos_t)base1 + (pos_t)(packed >> 16) - (pos_t)1;
+  if (EXACT && sp2 > ep2) { /* group-uniform; once per query at most */
+    /* the step of c2 alone (ref src/AwFmSearch.c:42-103) out of the same pieces: letter count of slice c2's count
+     * piece + positions whose own letter (planes 0 and 1) is c2 */
+    const unsigned c2 = pi & 3u;
+    const unsigned lm0 = 0u - (c2 & 1u), lm1 = 0u - (c2 >> 1);
+    const unsigned own0 = ~((p0.x ^ lm0) | (p0.y ^ lm1));
+    const unsigned own1 = same ? own0 : ~((p1.x ^ lm0) | (p1.y ^ lm1));
+    const unsigned ranks = groupSum<4>(__popc(own0 & mask0) | (__popc(own1 & mask1) << 16));
+    const unsigned letters0 = groupShfl<4>(h0.x, c2);
+    unsigned letters1 = groupShfl<4>(h1.x, c2);
+    letters1 = same ? letters0 : letters1;
+    const unsigned long long e0 = (unsigned long long)(q0 >> kPairSuperShift) * kPairSuperStride + 16u + c2;
+    const unsigned long long e1 = (unsigned long long)(q1 >> kPairSuperShift) * kPairSuperStride + 16u + c2;
+    const pos_t ls0 = NARROW ? (pos_t)ix.pairSuper32[e0] : (pos_t)ix.pairSuper[e0];
+    const pos_t ls1 = NARROW ? (pos_t)ix.pairSuper32[e1] : (pos_t)ix.pairSuper[e1];
+    const pos_t cLetter = (pos_t)sC[c2];
+    sp = cLetter + ls0 + (pos_t)letters0 + (pos_t)(ranks & 0xFFFFu);
+    ep = cLetter + ls1 + (pos_t)letters1 + (pos_t)(ranks >> 16) - (pos_t)1;
+    return sp > ep ? kPairStepped : kPairDiedOnSecond;
+  }
+  sp = sp2;
+  ep = ep2;
+  return kPairStepped;
 }
 
 }  // namespace

@@ -287,10 +287,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
       if (pairStep) {
         /* ---- two characters, both a,c,g,t/u inside the register window: one pair block ---- */
         const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
-        if (pairSearchStep<NARROW>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep)) {
-          nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
-          if (sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
-        }
+        /* exact: a k-mer that dies inside the pair ends in the range the letter-by-letter stepping ends in */
+        const PairStep did = pairSearchStep<NARROW, true>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep, sC);
+        if (did == kPairFlagged) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
+        if (did != kPairStepped && sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
         pos--; /* the second character: the common tail below steps past the first */
         rem >>= 2;
         badTop <<= 1;

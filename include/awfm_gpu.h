@@ -92,9 +92,10 @@ enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK);
 enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable);
 /* Nucleotide images carry, beside the one-letter blocks, a pair image: for every BWT position the pair of its two
  * preceding text characters, in 128-byte blocks of 128 positions with 16 base counts, so that two backward steps (two
- * LF steps) are one rank over a 16-letter sequence and one block read (csrc/awfm_pair.h).  Hits-only searches
- * (awfmGpuSearchHits in seed order) and the LF walk of awfmGpuLocate use it; results are those of the letter-by-letter
- * steps (ref src/AwFmSearch.c:42-103, :369-427), bit for bit.  Built with every nucleotide image unless
+ * LF steps) are one rank over a 16-letter sequence and one block read (csrc/awfm_pair.h).  The searches and the LF
+ * walk of awfmGpuLocate use it; results are those of the letter-by-letter steps (ref src/AwFmSearch.c:42-103,
+ * :369-427), bit for bit -- awfmGpuSearch's final range of a k-mer without hits included (a k-mer that dies inside a
+ * pair step gets the range of the single step that emptied it).  Built with every nucleotide image unless
  * $AWFM_GPU_PAIR=0; enable = 0 drops it (the image then takes one step per read), enable != 0 rebuilds it.  It adds
  * 1 byte per BWT position of device memory; the host index and the .awfmi file are untouched. */
 enum AwFmReturnCode awfmGpuIndexSetPairImage(AwFmGpuIndex *g, int enable);
