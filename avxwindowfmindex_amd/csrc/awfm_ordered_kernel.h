@@ -265,7 +265,11 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
    * at the end of an iteration, so its latency and the record read hide behind the current chunk.  (Requesting the
    * table entry a chunk ahead as well -- no dependent round left for the seed lookup -- changed nothing: 4.37-4.49 ms
    * either way per 10^8 random 21-mers, and the extra registers cost the one-letter variant a wave per SIMD.  The
-   * kernel's time follows the number of block reads that miss the L2, not the length of a wave's chain.) */
+   * kernel's time follows the number of block reads that miss the L2, not the length of a wave's chain.  Nor does it
+   * follow the number of rounds a wave waits through: a variant that refilled every group of 4 lanes with the next
+   * record as soon as its k-mer was done -- record and table entry staged two k-mers ahead, one memory round per
+   * iteration for all 16 groups, 2.55 rounds per 16 k-mers instead of 1 + 3.5 -- gave the same ranges in 5.20-5.24 ms
+   * against 4.41-4.45 ms on the same box, 9.2 against 9.1-9.4 ms planted.) */
   constexpr unsigned kWaves = orderedThreads(PAIR) / 64, kChunk = 64 / G;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   unsigned *ticket = tickets + (xcd * kWaves + wave) * 64u; /* 256 bytes apart */
