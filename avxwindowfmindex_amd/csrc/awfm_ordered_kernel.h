@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256)
 constexpr int orderedThreads(bool pair) { return pair ? 256 : kThreads; }
 
 template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false>
-__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? 8 : 2, 8)))
+__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? (PAIR && !NARROW ? 6 : 8) : 2, 8)))
     orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
                         const unsigned long long numRecs,
                         const unsigned *__restrict__ generalCount, const unsigned len, const unsigned depth,

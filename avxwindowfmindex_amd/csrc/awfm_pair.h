@@ -41,11 +41,14 @@
 
 namespace {
 
-/* 24-bit count `c2` (0..3) out of the 96-bit string {w0, w1, w2} of a slice's second piece */
+/* 24-bit count `c2` (0..3) out of the 96-bit string {w0, w1, w2} of a slice's second piece: bits 24 c2 .. 24 c2 + 23,
+ * i.e. the funnel shift of the two dwords the count lies in (selects and one v_alignbit: written with 64-bit shifts
+ * under `c2 < 2 ? .. : ..` hipcc made divergent branches of it, in every step of every kernel) */
 __device__ __forceinline__ unsigned pairCount24(const Piece &h, unsigned c2) {
-  const unsigned long long lo = ((unsigned long long)h.z << 32) | h.y, hi = ((unsigned long long)h.w << 32) | h.z;
-  const unsigned v = c2 < 2u ? (unsigned)(lo >> (24u * c2)) : (unsigned)(hi >> (24u * c2 - 32u));
-  return v & (c2 == 3u ? (kPairCountMask >> 1) : kPairCountMask);
+  const unsigned low = c2 < 2u ? h.y : (c2 == 2u ? h.z : h.w);
+  const unsigned high = c2 < 2u ? h.z : (c2 == 2u ? h.w : 0u);
+  const unsigned shift = (24u * c2) & 31u; /* 0, 24, 16, 8 */
+  return __builtin_amdgcn_alignbit(high, low, shift) & (c2 == 3u ? (kPairCountMask >> 1) : kPairCountMask);
 }
 
 /* positions of a slice whose pair code is `pi`; pm[i] = bit i of pi as an all-ones mask */
@@ -61,7 +64,20 @@ __device__ __forceinline__ typename PositionType<NARROW>::type pairSuperBase(con
                                                                             unsigned long long q, unsigned pi) {
   typedef typename PositionType<NARROW>::type pos_t;
   const unsigned sb = (unsigned)(q >> kPairSuperShift);
-  if (NARROW) return (pos_t)(ix.pairSuperInLds ? sPairSuper[sb * LDS_STRIDE + pi] : ix.pairSuper32[sb * kPairSuperStride + pi]);
+  if (NARROW) {
+    /* two different loads, not one load through a selected pointer: hipcc otherwise merges them into a FLAT load,
+     * which goes through the texture path even when the address is in LDS and makes the wait for it a wait for
+     * every block read in flight.  The empty asm keeps the LDS read a ds_read of its own (it is waited for on the
+     * spot, behind the block reads that are in flight anyway). */
+    unsigned v;
+    if (ix.pairSuperInLds) {
+      v = sPairSuper[sb * LDS_STRIDE + pi];
+      asm volatile("" : "+v"(v));
+    } else {
+      v = ix.pairSuper32[sb * kPairSuperStride + pi];
+    }
+    return (pos_t)v;
+  }
   return (pos_t)ix.pairSuper[sb * kPairSuperStride + pi];
 }
 
@@ -98,7 +114,9 @@ __device__ __forceinline__ PairStep pairSearchStep(const DevIndex &ix, const uns
   const bool same = blk0 == blk1;
   /* every lane fetches both pieces of its slice (fetching only what the rank reads -- plane pieces up to the
    * position, the count piece in the owning lane: 56 of 128 bytes -- was measured slower, 4.68 against 4.40 ms per
-   * 10^8 random 21-mers: four predicated loads instead of two) */
+   * 10^8 random 21-mers: four predicated loads instead of two; so was reading only the count piece of c1, one dword
+   * per lane, and assembling count and flag by a sum over the group: 5.1 against 4.45 ms random, 12.4 against 10.4
+   * mixed lengths, 8.9 against 9.4 planted) */
   const Piece p0 = *(const Piece *)(ix.pairBlocks + pairPlanesAt(blk0, slice));
   const Piece h0 = *(const Piece *)(ix.pairBlocks + pairCountsAt(blk0, slice));
   Piece p1, h1;
