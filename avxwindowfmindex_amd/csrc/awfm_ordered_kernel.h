@@ -147,7 +147,9 @@ __global__ void __launch_bounds__(256)
   } else if (inRange) {
     /* aligned dwords that hold the query's bytes; a dword is only read when it contains one of them */
     const unsigned long long at = (unsigned long long)chars + start;
-    const unsigned *first = (const unsigned *)(at & ~3ull);
+    /* (an integer turned pointer is a generic one, read by FLAT loads: say that it is global memory) */
+    typedef const unsigned __attribute__((address_space(1))) *GlobalWords;
+    const GlobalWords first = (GlobalWords)(at & ~3ull);
     const unsigned shift = (unsigned)at & 3u;
     const unsigned numDwords = (shift + len + 3u) >> 2;
     unsigned dw[9];
