@@ -183,35 +183,40 @@ def test_hits_only_search_takes_the_ordered_path_by_itself_and_agrees_with_the_g
     ix.dealloc()
 
 
-def test_an_index_beyond_2_pow_32_positions_built_searched_and_located_on_the_gpu(oracle, awfm, require_gpu):
+@pytest.mark.parametrize("alphabet", ["dna", "amino"])
+def test_an_index_beyond_2_pow_32_positions_built_searched_and_located_on_the_gpu(oracle, awfm, require_gpu, alphabet):
     """bwtLength > 2^32 for real (ref src/AwFmIndex.h:55-65, :88-91 and src/AwFmSuffixArray.c:12-18 are 64-bit
     throughout): the builder's 64-bit suffix sort, 33-bit sampled SA values, two nucleotide superblocks, the 64-bit
     search / walk kernels and the pair image's global superblock table, with nothing forced by a knob.  Planted
     24-mers -- a share of them taken beyond position 2^32 -- must come back at their planting offsets, every hit must
-    spell its k-mer, and an oracle-checked sample of the batch (planted and random k-mers) must agree bit for bit."""
+    spell its k-mer, and an oracle-checked sample of the batch (planted and random k-mers) must agree bit for bit.
+    The amino case runs the same through the 128-byte amino blocks with their 2^16-position superblocks and 64-bit
+    bases (14-mers over a seed table of depth 4)."""
     import time
     import torch
     from avxwindowfmindex_amd import _lib, synth
     L = _lib.lib()
     n = int(os.environ.get("AWFM_TEST_WIDE_TEXT_LEN", (1 << 32) + 100_000_000))
     Q = int(os.environ.get("AWFM_TEST_WIDE_QUERIES", 10_000_000))
-    K = 24
+    amino = alphabet == "amino"
+    K, seed_k = (14, 4) if amino else (24, 12)
+    kind = awfm.AwFmAlphabetAmino if amino else awfm.AwFmAlphabetDna
     dev = torch.device("cuda")
     free, _ = torch.cuda.mem_get_info()
     if free < 40 * n:
         pytest.skip(f"needs about {40 * n >> 30} GiB of HBM for the 64-bit suffix sort, {free >> 30} GiB free")
     d_text = torch.empty(n, dtype=torch.uint8, device=dev)
-    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, 7, 0, None) == 1
+    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, 7, 1 if amino else 0, None) == 1
     t0 = time.time()
-    ix = awfm.gpu_create_index(d_text.data_ptr(), awfm.AwFmAlphabetDna, 8, 12, on_device_length=n)
-    print(f"\n[wide build] {n} nt in {time.time() - t0:.1f} s, SA width {ix.sa_width} bits")
+    ix = awfm.gpu_create_index(d_text.data_ptr(), kind, 8, seed_k, on_device_length=n)
+    print(f"\n[wide build] {n} {alphabet} characters in {time.time() - t0:.1f} s, SA width {ix.sa_width} bits")
     assert ix.bwt_length == n + 1 and (n < (1 << 32) or ix.sa_width == 33)
     g = awfm.GpuIndex(ix, acquire=True)
-    assert g.has_pair_image
+    assert g.has_pair_image == (not amino)
     half = Q // 2
     d_chars = torch.empty(Q * K, dtype=torch.uint8, device=dev)
     assert L.awfmGpuSynthPlantedQueries(d_chars.data_ptr(), 0, half, K, 203, d_text.data_ptr(), n, None) == 1
-    assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr() + half * K, 0, Q - half, K, 204, 0, None) == 1
+    assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr() + half * K, 0, Q - half, K, 204, 1 if amino else 0, None) == 1
     d_ranges = torch.empty(Q * 2, dtype=torch.int64, device=dev)
     d_hits = torch.empty(Q * 2, dtype=torch.int64, device=dev)
     d_counts = torch.empty(Q, dtype=torch.int32, device=dev)
@@ -245,7 +250,8 @@ def test_an_index_beyond_2_pow_32_positions_built_searched_and_located_on_the_gp
     assert torch.equal(d_pos[d_off[:half][single]], planted[single])
     assert n < (1 << 32) or bool((beyond & single).any())
     # oracle over the downloaded (reference-layout) arrays on a sample from both halves of the batch
-    oi = oracle.Index.wrap(oracle.DNA, 8, 12, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    oi = oracle.Index.wrap(oracle.AMINO if amino else oracle.DNA, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(),
+                           ix.seed_table(), ix.packed_sa())
     m = 100_000
     for first in (0, half):
         chars = d_chars[first * K:(first + m) * K].cpu().numpy()
