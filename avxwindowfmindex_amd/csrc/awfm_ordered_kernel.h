@@ -297,18 +297,21 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     const unsigned long long codes = COMPACT ? orderCodes(format, key, (unsigned)(raw.a >> 32)) : raw.a;
     const unsigned index = COMPACT ? (unsigned)raw.a : (unsigned)raw.b;
     const unsigned myLen = VARLEN ? (unsigned)(raw.b >> 32) : len; /* before `raw` is overwritten by the prefetch */
-    /* draw the ticket after next (consumed at the bottom), fetch the next chunk's record */
-    if (lane == 0) drawn = atomicAdd(ticket, 1u);
-    if (baseNext + lane / G < end) readRecord(baseNext + lane / G, raw);
     /* ---- seed (ref src/AwFmKmerTable.c:4-51): the index table, or the deeper device-only one ---- */
     pos_t sp = 1, ep = 0;
     int pos = -1;
     unsigned long long rem;
+    ulonglong2 entry = make_ulonglong2(1ull, 0ull);
+    /* fixed length: the table entry is requested FIRST, so that the wait for it (loads return in order) is not also a
+     * wait for the ticket atomic and the record prefetch issued below */
+    if (!VARLEN && live) entry = table[codes & tableMask];
+    /* draw the ticket after next (consumed at the bottom), fetch the next chunk's record */
+    if (lane == 0) drawn = atomicAdd(ticket, 1u);
+    if (baseNext + lane / G < end) readRecord(baseNext + lane / G, raw);
     if (!VARLEN) {
       if (live) {
-        const ulonglong2 r = table[codes & tableMask];
-        sp = (pos_t)r.x;
-        ep = (pos_t)r.y;
+        sp = (pos_t)entry.x;
+        ep = (pos_t)entry.y;
         pos = (int)(len - depth) - 1;
       }
       rem = codes >> (2u * depth); /* code of character `pos` in bits 1..0 */
