@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Differential fuzz of the ordered hits-only search (pair steps) against the general kernel (letter by letter), and of
-the pair-step LF walk against the one-letter walk, all on the GPU: random index sizes, seed depths, deeper tables,
+"""Differential fuzz of the ordered hits-only search (pair steps) and of the exact general search with pair steps
+against the general kernel stepping letter by letter, and of the pair-step LF walk against the one-letter walk, all on
+the GPU: random index sizes, seed depths, deeper tables,
 fixed and mixed k-mer lengths, ambiguity characters and runs (flagged pair blocks), buffer alignments.
 With FUZZ_WIDE=1 the side under test (hits-only search, second locate) runs the 64-bit-position instantiations
 while the general kernel it is compared with keeps 32-bit positions.
@@ -75,9 +76,18 @@ while time.time() < t_end:
         exact = torch.zeros(Q * 2, dtype=torch.int64, device=dev)
         hits = torch.full((Q * 2,), 9, dtype=torch.int64, device=dev)
         counts = torch.full((Q,), 9, dtype=torch.int32, device=dev)
+        os.environ["AWFM_GPU_GENERAL_NO_PAIR"] = "1"  # the reference side: one letter per step
         g.search(chars_ptr, off_ptr, K, Q, exact.data_ptr(), 0)
         torch.cuda.synchronize()
+        del os.environ["AWFM_GPU_GENERAL_NO_PAIR"]
         g.set_wide(fuzz_wide)
+        # the exact search with pair steps: every range, the empty ones of k-mers without hits included
+        exact_pair = torch.full((Q * 2,), 5, dtype=torch.int64, device=dev)
+        g.search(chars_ptr, off_ptr, K, Q, exact_pair.data_ptr(), 0)
+        torch.cuda.synchronize()
+        if not torch.equal(exact, exact_pair):
+            print(f"MISMATCH exact pair search n={n} k={seed_k} deep={deep_k} ratio={ratio} Q={Q} {desc}", flush=True)
+            sys.exit(1)
         assert g.is_wide == fuzz_wide
         g.search_hits(chars_ptr, off_ptr, K, Q, hits.data_ptr(), counts.data_ptr())
         torch.cuda.synchronize()
