@@ -809,20 +809,20 @@ void awfmGpuIndexSetWide(AwFmGpuIndex *g, int wide) {
 
 static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                          uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
-                                         uint32_t *dCounts, void *stream, bool hitsOnly);
+                                         uint32_t *dCounts, void *stream);
 
 enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                   uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
                                   uint32_t *dCounts, void *stream) {
-  return searchGeneral(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream, false);
+  return searchGeneral(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream);
 }
 
 /* the general kernel: exact ranges (the reference's final range for k-mers without hits too).  Nucleotide images with
  * pair blocks take two characters per block read (exact as well, awfm_pair.h; $AWFM_GPU_GENERAL_NO_PAIR: one-letter
- * steps only).  hitsOnly is what the caller needs, not what it gets. */
+ * steps only). */
 static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                          uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
-                                         uint32_t *dCounts, void *stream, bool hitsOnly) {
+                                         uint32_t *dCounts, void *stream) {
   if (!g) {
     setError("awfmGpuSearch: null image");
     return AwFmNullPtrError;
@@ -835,7 +835,6 @@ static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars,
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
   const int lanes = lanesPerQuery(g);
-  (void)hitsOnly;
   if (!g->amino && lanes == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_GENERAL_NO_PAIR")) {
     const unsigned long long *off = (const unsigned long long *)dOffsets;
     const bool narrow = awfmImageNarrow(g);
@@ -873,7 +872,7 @@ enum AwFmReturnCode awfmGpuSearchHits(AwFmGpuIndex *g, const uint8_t *dChars, co
     if (ordered < 0) return (enum AwFmReturnCode)(-ordered);
     if (ordered > 0) return AwFmSuccess;
   }
-  return searchGeneral(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream, true);
+  return searchGeneral(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream);
 }
 
 void awfmGpuIndexSetOrdered(AwFmGpuIndex *g, int mode) {
