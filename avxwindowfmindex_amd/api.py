@@ -383,6 +383,12 @@ class GpuIndex:
         _check("awfmGpuSearchHits", _lib.lib().awfmGpuSearchHits(self.handle, d_chars, d_offsets or None, fixed_length,
                                                                  n, d_ranges or None, d_counts or None, stream or None))
 
+    def search_hits_sparse(self, d_chars, d_offsets, fixed_length, n, d_ranges, d_counts, stream=0):
+        """awfmGpuSearchHitsSparse: counts for every query, ranges only for the queries with hits (the others' may stay
+        as passed); hit offsets then come from the counts"""
+        _check("awfmGpuSearchHitsSparse", _lib.lib().awfmGpuSearchHitsSparse(self.handle, d_chars, d_offsets or None, fixed_length,
+                                                                            n, d_ranges or None, d_counts, stream or None))
+
     def search_hits_packed(self, d_packed, kmer_length, n, d_ranges, d_counts, d_chars_scratch=0, stream=0):
         """awfmGpuSearchHitsPacked: hits-only search of bit-packed k-mers resident on the device"""
         _check("awfmGpuSearchHitsPacked", _lib.lib().awfmGpuSearchHitsPacked(

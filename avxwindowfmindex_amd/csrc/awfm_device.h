@@ -731,7 +731,8 @@ bool awfmGpuRelayout(const void *dRefBlocks, uint64_t bwtLength, bool amino, uns
 /* ordered hits-only search; 1 = searched, 0 = does not apply, <0 = -AwFmReturnCode (awfm_gpu_ordered.hip) */
 /* packed: dChars is one 64-bit word per fixed-length k-mer (2-bit codes) instead of ASCII */
 int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
-                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed = false);
+                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed = false,
+                         bool rangesOfHitsOnly = false);
 
 /* adopts device buffers that already hold a complete image (used by the GPU builder) */
 AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSuper, unsigned superShift,

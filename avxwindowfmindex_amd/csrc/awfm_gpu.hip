@@ -853,9 +853,30 @@ static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars,
 
 /* Hits-only search (include/awfm_gpu.h): ordered path when it applies, else the general kernel, whose exact
  * empty ranges satisfy the contract as well */
+static enum AwFmReturnCode searchHits(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets, uint32_t fixedLength,
+                                      uint64_t numQueries, struct AwFmSearchRange *dRanges, uint32_t *dCounts, void *stream,
+                                      bool rangesOfHitsOnly);
+
 enum AwFmReturnCode awfmGpuSearchHits(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                       uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
                                       uint32_t *dCounts, void *stream) {
+  return searchHits(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream, false);
+}
+
+/* include/awfm_gpu.h: counts for every k-mer, ranges for the k-mers with hits only */
+enum AwFmReturnCode awfmGpuSearchHitsSparse(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                            uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
+                                            uint32_t *dCounts, void *stream) {
+  if (!dCounts && numQueries) {
+    setError("awfmGpuSearchHitsSparse: the counts are what says which ranges were written: dCounts must not be NULL");
+    return AwFmNullPtrError;
+  }
+  return searchHits(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream, true);
+}
+
+static enum AwFmReturnCode searchHits(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets, uint32_t fixedLength,
+                                      uint64_t numQueries, struct AwFmSearchRange *dRanges, uint32_t *dCounts, void *stream,
+                                      bool rangesOfHitsOnly) {
   if (!g) {
     setError("awfmGpuSearchHits: null image");
     return AwFmNullPtrError;
@@ -868,7 +889,7 @@ enum AwFmReturnCode awfmGpuSearchHits(AwFmGpuIndex *g, const uint8_t *dChars, co
   if (g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4) {
     DeviceGuard guard(g->device);
     const int ordered = awfmGpuOrderedSearch(g, (hipStream_t)stream, dChars, (const unsigned long long *)dOffsets, fixedLength,
-                                             numQueries, (ulonglong2 *)dRanges, dCounts);
+                                             numQueries, (ulonglong2 *)dRanges, dCounts, false, rangesOfHitsOnly);
     if (ordered < 0) return (enum AwFmReturnCode)(-ordered);
     if (ordered > 0) return AwFmSuccess;
   }

@@ -164,7 +164,8 @@ extern "C" int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets,
 
 /* 1: the batch was searched; 0: the ordered path does not apply (caller runs the general kernel); <0: -AwFmReturnCode */
 int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
-                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed) {
+                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
+                         bool rangesOfHitsOnly) {
   unsigned depth = 0;
   const ulonglong2 *table = nullptr;
   if (packed && off) return 0;
@@ -222,7 +223,10 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
     }                                       \
   } while (0)
   ORDER_TRY(hipMemsetAsync(generalCount, 0, kOrderCounterBytes, s)); /* the count and the ticket counters */
-  hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s, rng, dCounts, nq);
+  /* rangesOfHitsOnly (awfmGpuSearchHitsSparse): the counts say which k-mers have hits, so only the counts are
+   * pre-filled and the ranges of the others stay as the caller left them -- 16 of the 20 bytes per k-mer not written */
+  hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
+                     rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
   ORDER_TRY(hipGetLastError());
   const unsigned encodeGrid = (unsigned)((nq + 255) / 256);
   const unsigned seedK = g->dev.seedK, deepK = g->dev.deepK;

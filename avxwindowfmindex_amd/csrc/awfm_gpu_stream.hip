@@ -322,9 +322,20 @@ enum AwFmReturnCode awfmGpuPackKmers(AwFmGpuIndex *g, const uint8_t *dChars, uin
 /* Hits-only search of bit-packed k-mers resident on the device: nucleotide batches the seed-order path takes are
  * searched straight from the packed words (they are its record format); anything else is unpacked into dCharsScratch
  * (kmerLength bytes per k-mer) and searched as ASCII. */
+static enum AwFmReturnCode searchHitsPacked(AwFmGpuIndex *g, const uint64_t *dPacked, uint32_t kmerLength, uint64_t numKmers,
+                                            struct AwFmSearchRange *dRanges, uint32_t *dCounts, uint8_t *dCharsScratch,
+                                            void *stream, bool rangesOfHitsOnly);
+
 enum AwFmReturnCode awfmGpuSearchHitsPacked(AwFmGpuIndex *g, const uint64_t *dPacked, uint32_t kmerLength, uint64_t numKmers,
                                             struct AwFmSearchRange *dRanges, uint32_t *dCounts, uint8_t *dCharsScratch,
                                             void *stream) {
+  return searchHitsPacked(g, dPacked, kmerLength, numKmers, dRanges, dCounts, dCharsScratch, stream, false);
+}
+
+/* rangesOfHitsOnly: the contract of awfmGpuSearchHitsSparse (the pipeline reads the ranges through the counts) */
+static enum AwFmReturnCode searchHitsPacked(AwFmGpuIndex *g, const uint64_t *dPacked, uint32_t kmerLength, uint64_t numKmers,
+                                            struct AwFmSearchRange *dRanges, uint32_t *dCounts, uint8_t *dCharsScratch,
+                                            void *stream, bool rangesOfHitsOnly) {
   if (!g || (!dPacked && numKmers)) {
     setError("awfmGpuSearchHitsPacked: null argument");
     return AwFmNullPtrError;
@@ -337,7 +348,7 @@ enum AwFmReturnCode awfmGpuSearchHitsPacked(AwFmGpuIndex *g, const uint64_t *dPa
   if (!g->amino && (g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) {
     DeviceGuard guard(g->device);
     const int ordered = awfmGpuOrderedSearch(g, (hipStream_t)stream, (const uint8_t *)dPacked, nullptr, kmerLength, numKmers,
-                                             (ulonglong2 *)dRanges, dCounts, true);
+                                             (ulonglong2 *)dRanges, dCounts, true, rangesOfHitsOnly && dCounts);
     if (ordered < 0) return (enum AwFmReturnCode)(-ordered);
     if (ordered > 0) return AwFmSuccess;
   }
@@ -347,7 +358,8 @@ enum AwFmReturnCode awfmGpuSearchHitsPacked(AwFmGpuIndex *g, const uint64_t *dPa
   }
   const enum AwFmReturnCode rc = awfmGpuUnpackKmers(g, dPacked, kmerLength, numKmers, dCharsScratch, stream);
   if (rc != AwFmSuccess) return rc;
-  return awfmGpuSearchHits(g, dCharsScratch, nullptr, kmerLength, numKmers, dRanges, dCounts, stream);
+  return (rangesOfHitsOnly && dCounts ? awfmGpuSearchHitsSparse : awfmGpuSearchHits)(g, dCharsScratch, nullptr, kmerLength, numKmers,
+                                                                                    dRanges, dCounts, stream);
 }
 
 /* the pipeline; packed != 0: `input` is one 64-bit word per k-mer, else kmerLength ASCII characters per k-mer */
@@ -443,13 +455,16 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
       STEP_TRY(hipMemcpyAsync(s.dIn, src, bytes, hipMemcpyHostToDevice, in));
       STEP_TRY(hipEventRecord(s.uploaded, in));
       STEP_TRY(hipStreamWaitEvent(comp, s.uploaded, 0));
+      /* the hit offsets of an image below 2^32 positions are scanned from the counts, and the locate reads a range only
+       * when its k-mer has hits: the ranges of the others need not be written */
       if (packed)
-        STEP_RC(awfmGpuSearchHitsPacked(g, (const uint64_t *)s.dIn, kmerLength, s.n,
-                                        locate ? (struct AwFmSearchRange *)s.dRanges : nullptr, (uint32_t *)s.dCounts,
-                                        (uint8_t *)s.dChars, comp));
+        STEP_RC(searchHitsPacked(g, (const uint64_t *)s.dIn, kmerLength, s.n,
+                                 locate ? (struct AwFmSearchRange *)s.dRanges : nullptr, (uint32_t *)s.dCounts,
+                                 (uint8_t *)s.dChars, comp, narrowCounts));
       else
-        STEP_RC(awfmGpuSearchHits(g, (const uint8_t *)s.dIn, nullptr, kmerLength, s.n,
-                                  locate ? (struct AwFmSearchRange *)s.dRanges : nullptr, (uint32_t *)s.dCounts, comp));
+        STEP_RC((narrowCounts ? awfmGpuSearchHitsSparse : awfmGpuSearchHits)(
+            g, (const uint8_t *)s.dIn, nullptr, kmerLength, s.n, locate ? (struct AwFmSearchRange *)s.dRanges : nullptr,
+            (uint32_t *)s.dCounts, comp));
       if (locate)
         STEP_RC(awfmGpuHitOffsetsAsync(g, narrowCounts ? (const uint32_t *)s.dCounts : nullptr,
                                        (const struct AwFmSearchRange *)s.dRanges, s.n, (uint64_t *)s.dHitOffsets, s.dScratch,

@@ -288,8 +288,13 @@ def main():
         # counting and locating need the hits only (what awFmParallelSearchCount/Locate report): large
         # fixed-length batches are searched in seed order, the others by the general kernel
         use_counts = narrow_counts and state["sparse"]
-        g.search_hits(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr() if args.mode == "locate" else 0,
-                      d_counts.data_ptr() if (args.mode == "count" or use_counts) else 0, stream)
+        if args.mode == "locate" and use_counts:
+            # the hit offsets are scanned from the counts and the locate reads the range of a k-mer only when it has
+            # hits: the ranges of the others need not be written
+            g.search_hits_sparse(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr(), d_counts.data_ptr(), stream)
+        else:
+            g.search_hits(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr() if args.mode == "locate" else 0,
+                          d_counts.data_ptr() if args.mode == "count" else 0, stream)
         if record:
             e1.record()
             search_events.append((e0, e1))
@@ -338,6 +343,9 @@ def main():
         else:
             dump["ranges"] = d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2)
             dump["hit_offsets"] = d_hit_off.cpu().numpy().view(np.uint64)
+            if narrow_counts and state["sparse"]:  # ranges were written for the k-mers with hits only: "no hit" for the rest
+                dump["ranges"] = dump["ranges"].copy()
+                dump["ranges"][np.diff(dump["hit_offsets"]) == 0] = (1, 0)
             dump["positions"] = state["positions"][: state["hits"]].cpu().numpy().view(np.uint64)
         np.savez(os.path.join(args.dump_dir, f"rank{rank}.npz"), **dump)
 
@@ -441,9 +449,12 @@ def main():
                 assert np.array_equal(d_counts[:m].cpu().numpy().view(np.uint32), cnt), "GPU counts differ from the oracle"
             else:
                 gr = d_ranges[: 2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)
-                hit = cnt > 0  # hits-only contract: exact ranges for queries with hits, an empty range otherwise
+                hit = cnt > 0  # hits-only contract: exact ranges for queries with hits ...
                 assert np.array_equal(gr[hit, 0], sp[hit]) and np.array_equal(gr[hit, 1], ep[hit]), "GPU ranges differ from the oracle"
-                assert np.all(gr[~hit, 0] > gr[~hit, 1]), "GPU reports hits the oracle does not have"
+                if narrow_counts and state["sparse"]:  # ... and count 0 for the others (awfmGpuSearchHitsSparse)
+                    assert np.array_equal(d_counts[:m].cpu().numpy().view(np.uint32), cnt), "GPU counts differ from the oracle"
+                else:  # ... and some empty range for the others (awfmGpuSearchHits)
+                    assert np.all(gr[~hit, 0] > gr[~hit, 1]), "GPU reports hits the oracle does not have"
             if args.mode == "locate":
                 gho = d_hit_off[: m + 1].cpu().numpy().view(np.uint64)
                 assert np.array_equal(gho, ho), "GPU hit offsets differ from the oracle"
@@ -536,7 +547,8 @@ def main():
                    "device_image_bytes": g.device_bytes, "device_seed_k": args.device_seed_k or args.seed_k,
                    "device_seed_build_s": round(deep_s, 2), "device_dense_sa": bool(args.device_dense_sa),
                    "device_dense_sa_build_s": round(dense_s, 2),
-                   "search_path": "awfmGpuSearchHits, seed order" if ordered else "awfmGpuSearchHits, general kernel"},
+                   "search_path": ("awfmGpuSearchHitsSparse" if (args.mode == "locate" and narrow_counts and state["sparse"]) else "awfmGpuSearchHits")
+                                  + (", seed order" if ordered else ", general kernel")},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "end_to_end": e2e,

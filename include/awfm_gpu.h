@@ -145,6 +145,14 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
 enum AwFmReturnCode awfmGpuSearchHits(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                       uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
                                       uint32_t *dCounts, void *stream);
+/* The same when the caller reads the ranges through the counts, as awfmGpuHitOffsetsFromCounts + awfmGpuLocate do:
+ * dCounts[i] (required) is written for every k-mer, dRanges[i] for the k-mers with hits -- the range of a k-mer with
+ * dCounts[i] == 0 may be left as the caller passed it (the seed-order path then streams 4 instead of 20 bytes of
+ * "no hit" per k-mer over the outputs).  Hit offsets must then come from the counts (awfmGpuHitOffsets reads every
+ * range), i.e. from images below 2^32 positions. */
+enum AwFmReturnCode awfmGpuSearchHitsSparse(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                            uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
+                                            uint32_t *dCounts, void *stream);
 /* -1 = automatic (default), 0 = never, 1 = whenever the ordered path applies */
 void awfmGpuIndexSetOrdered(AwFmGpuIndex *g, int mode);
 /* 1 when awfmGpuSearchHits would search such a batch in seed order on this image (reporting, bench.py) */

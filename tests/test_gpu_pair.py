@@ -169,3 +169,51 @@ def test_pair_image_over_several_superblocks(oracle, awfm, require_gpu):
     ho, opos, _ = oi.batch_locate(sp, ep)
     assert np.array_equal(counts[:m], cnt) and np.array_equal(pos[: int(ho[-1])], opos)
     ix.dealloc()
+
+
+@pytest.mark.parametrize("ordered", [1, 0])
+def test_search_hits_sparse_writes_counts_for_all_and_ranges_for_hits(oracle, awfm, require_gpu, wide, ordered):
+    """awfmGpuSearchHitsSparse (include/awfm_gpu.h): a count for every k-mer, the exact range for every k-mer with hits,
+    and the range of a k-mer without hits possibly untouched (the seed-order path leaves it as passed; the general
+    kernel writes its exact empty range); hit offsets from the counts and positions on top are those of the oracle"""
+    import torch
+    n, K, Q = 600_000, 19, 30011
+    txt = synth.text(131, n)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 9)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 9, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(ordered)
+    q = np.concatenate([synth.random_queries(132, Q // 2, K), synth.planted_queries(133, Q - Q // 2, K, txt)]).copy()
+    rng = np.random.default_rng(5)
+    rng.shuffle(q, axis=0)
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(np.concatenate([chars, np.zeros(8, np.uint8)])).to(dev)
+    d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
+    d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+    g.search_hits_sparse(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+    d_hit_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+    total = g.hit_offsets_from_counts(d_counts.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr())
+    d_pos = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+    g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, d_pos.data_ptr())
+    torch.cuda.synchronize()
+    ranges = d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2)
+    hit = cnt > 0
+    assert 0.3 < hit.mean() < 0.7
+    assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt)
+    assert np.array_equal(ranges[hit, 0], sp[hit]) and np.array_equal(ranges[hit, 1], ep[hit])
+    untouched = (ranges[~hit] == 7).all(axis=1)
+    empty = ranges[~hit, 0] > ranges[~hit, 1]
+    assert np.all(untouched | empty)
+    if ordered:
+        assert untouched.all(), "the seed-order path does not write the ranges of k-mers without hits"
+    assert np.array_equal(d_hit_off.cpu().numpy().view(np.uint64), hit_off)
+    assert np.array_equal(d_pos[:total].cpu().numpy().view(np.uint64), pos)
+    # counts are what says which ranges were written: they are required
+    with pytest.raises(awfm.AwFmError):
+        g.search_hits_sparse(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), 0)
+    g.destroy()
+    ix.dealloc()
