@@ -10,6 +10,7 @@ _LIB = None
 AwFmAlphabetAmino, AwFmAlphabetDna, AwFmAlphabetRna = 1, 2, 3
 AwFmSuccess, AwFmFileReadOkay, AwFmFileWriteOkay = 1, 2, 3
 AwFmGeneralFailure = -1
+AwFmIllegalPositionError = -6
 AwFmFileReadFail = -11
 
 # every symbol the two public headers declare
@@ -26,17 +27,21 @@ API_SYMBOLS = [
 ]
 GPU_SYMBOLS = [
     "awfmGpuDeviceCount", "awfmGpuLastError", "awfmGpuIndexCreate", "awfmGpuIndexDestroy", "awfmGpuIndexAcquire", "awfmGpuIndexAcquireAll",
-    "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuIndexSetWide", "awfmGpuIndexIsWide", "awfmGpuLastBatchStatus", "awfmGpuIndexSetDeepSeed", "awfmGpuIndexSetDenseSa", "awfmGpuPinnedBuffer", "awfmGpuLocateHostPinned", "awfmGpuAosLock",
+    "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuIndexSetWide", "awfmGpuIndexIsWide", "awfmGpuLastBatchStatus", "awfmGpuIndexSetDeepSeed", "awfmGpuIndexSetDenseSa", "awfmGpuPinnedBuffer", "awfmGpuLocateHostWindows", "awfmGpuLocateWindow", "awfmGpuAosLock",
     "awfmGpuAosUnlock", "awfmGpuSearch", "awfmGpuSearchHits", "awfmGpuSearchHitsSparse", "awfmGpuIndexSetOrdered", "awfmGpuSearchHitsIsOrdered", "awfmGpuLastOrderedKernelMs",
     "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuHitOffsetsFromCounts", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
     "awfmGpuCreateIndex", "awfmGpuSearchTally", "awfmGpuSynthText", "awfmGpuSynthRandomQueries", "awfmGpuSynthPlantedQueries",
-    "awfmGpuSynthMixedLengths", "awfmGpuSynthMixedQueries",
+    "awfmGpuSynthMixedLengths", "awfmGpuSynthMixedQueries", "awfmGpuSynthGenomeText", "awfmGpuSynthPlantedQueriesClean",
     "awfmPackKmers", "awfmGpuPackKmers", "awfmGpuUnpackKmers", "awfmGpuHostAlloc", "awfmGpuHostFree", "awfmGpuStreamPacked",
     "awfmGpuStreamChars", "awfmGpuCountPackedHost", "awfmGpuLocatePackedHost", "awfmGpuIndexSetPairImage", "awfmGpuIndexHasPairImage",
-    "awfmGpuSearchHitsPacked", "awfmGpuLocateTo",
+    "awfmGpuSearchHitsPacked", "awfmGpuLocateTo", "awfmGpuSearchHitsLineTally", "awfmGpuIndexDeepSeedK",
 ]
 # int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
 CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
+
+
+# int sink(void *user, uint64 queryBegin, uint64 queryEnd, uint64 hitBegin, uint64 hitEnd, const uint64 *positions)
+HIT_WINDOW_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64))
 
 
 class AwFmIndexConfiguration(C.Structure):
@@ -142,6 +147,7 @@ def lib():
         "awfmGpuIndexSetDenseSa": (C.c_int, [vp, C.c_int]),
         "awfmGpuIndexSetPairImage": (C.c_int, [vp, C.c_int]),
         "awfmGpuIndexHasPairImage": (C.c_int, [vp]),
+        "awfmGpuIndexDeepSeedK": (C.c_uint, [vp]),
         "awfmGpuSearch": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuSearchHits": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuSearchHitsSparse": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
@@ -150,14 +156,19 @@ def lib():
         "awfmGpuHitOffsetsFromCounts": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),
         "awfmGpuLocate": (C.c_int, [vp, vp, vp, u64, u64, vp, vp]),
         "awfmGpuLocateTo": (C.c_int, [vp, vp, vp, u64, u64, vp, vp, vp]),
+        "awfmGpuLocateWindow": (C.c_int, [vp, vp, vp, u64, u64, u64, u64, vp, vp, vp]),
+        "awfmGpuLocateHostWindows": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, HIT_WINDOW_SINK, vp]),
         "awfmGpuCountHost": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp]),
         "awfmGpuLocateHost": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, C.POINTER(C.POINTER(u64))]),
         "awfmGpuCreateIndex": (C.c_int, [C.POINTER(IP), C.POINTER(AwFmIndexConfiguration), vp, u64, C.c_int,
                                          C.c_char_p, C.c_int]),
         "awfmGpuSearchTally": (C.c_int, [vp, vp, vp, C.c_uint32, u64, C.POINTER(u64 * 4)]),
+        "awfmGpuSearchHitsLineTally": (C.c_int, [vp, vp, vp, C.c_uint32, u64, C.POINTER(u64 * 8)]),
         "awfmGpuSynthText": (C.c_int, [vp, u64, u64, u64, C.c_int, vp]),
         "awfmGpuSynthRandomQueries": (C.c_int, [vp, u64, u64, C.c_uint32, u64, C.c_int, vp]),
         "awfmGpuSynthPlantedQueries": (C.c_int, [vp, u64, u64, C.c_uint32, u64, vp, u64, vp]),
+        "awfmGpuSynthPlantedQueriesClean": (C.c_int, [vp, u64, u64, C.c_uint32, u64, vp, u64, vp]),
+        "awfmGpuSynthGenomeText": (C.c_int, [vp, u64, u64, vp]),
         "awfmGpuSynthMixedLengths": (C.c_int, [vp, u64, u64, C.c_uint32, C.c_uint32, u64, vp]),
         "awfmGpuSynthMixedQueries": (C.c_int, [vp, vp, u64, u64, u64, vp, u64, C.c_int, vp]),
         "awfmPackKmers": (C.c_int, [C.c_int, vp, C.c_uint32, u64, vp, C.POINTER(u64)]),

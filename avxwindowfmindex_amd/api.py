@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (AwFmAlphabetAmino, AwFmAlphabetDna, AwFmAlphabetRna, AwFmFileReadOkay, AwFmFileWriteOkay,  # noqa: F401
-                   AwFmSuccess)
+                   AwFmIllegalPositionError, AwFmSuccess)
 
 
 class AwFmError(RuntimeError):
@@ -263,6 +263,11 @@ class GpuIndex:
         """device-only deeper seed table (nucleotide); 0 drops it"""
         _check("awfmGpuIndexSetDeepSeed", _lib.lib().awfmGpuIndexSetDeepSeed(self.handle, deep_k))
 
+    @property
+    def deep_seed_k(self):
+        """depth of the device-only deeper seed table of this image (0: none)"""
+        return int(_lib.lib().awfmGpuIndexDeepSeedK(self.handle))
+
     def set_dense_sa(self, enable=True):
         """device-only full suffix array (32-bit entries) so that a locate is a single gather"""
         _check("awfmGpuIndexSetDenseSa", _lib.lib().awfmGpuIndexSetDenseSa(self.handle, int(bool(enable))))
@@ -316,6 +321,19 @@ class GpuIndex:
         L.free(C.cast(pos_ptr, C.c_void_p))
         return ranges, hit_off, pos
 
+    def locate_host_windows(self, chars, offsets, sink):
+        """awfmGpuLocateHostWindows: sink(user, query_begin, query_end, hit_begin, hit_end, positions) per window of the
+        flat hit list; returns the hit offsets (uint64[n+1])"""
+        chars = np.ascontiguousarray(chars, dtype=np.uint8)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = len(off) - 1
+        hit_off = np.zeros(n + 1, np.uint64)
+        holder = chars if chars.size else np.zeros(1, np.uint8)
+        cb = _lib.HIT_WINDOW_SINK(sink)
+        _check("awfmGpuLocateHostWindows", _lib.lib().awfmGpuLocateHostWindows(
+            self.handle, holder.ctypes.data, off.ctypes.data, 0, n, None, hit_off.ctypes.data, cb, None))
+        return hit_off
+
     # chunked pipeline on host buffers (awfm_gpu_stream.hip) ---------------------------
     def stream(self, kmers, kmer_length, locate=True, chunk=0, packed=True, threads=4, sink=None):
         """awfmGpuStreamPacked / awfmGpuStreamChars over a host array (numpy uint64[n] packed words, or uint8[n*L]
@@ -364,10 +382,13 @@ class GpuIndex:
         return counts, pos
 
     def pack_device(self, d_chars, kmer_length, n, d_packed, stream=0):
-        """awfmGpuPackKmers on device buffers; returns how many k-mers could not be expressed"""
+        """awfmGpuPackKmers on device buffers; returns how many k-mers could not be expressed (the library call itself
+        reports AwFmIllegalPositionError then: the packed words of such a batch must not be searched)"""
         bad = C.c_uint64(0)
-        _check("awfmGpuPackKmers", _lib.lib().awfmGpuPackKmers(self.handle, d_chars, kmer_length, n, d_packed, C.byref(bad),
-                                                               stream or None))
+        rc = _lib.lib().awfmGpuPackKmers(self.handle, d_chars, kmer_length, n, d_packed, C.byref(bad), stream or None)
+        if rc == AwFmIllegalPositionError and bad.value:
+            return int(bad.value)
+        _check("awfmGpuPackKmers", rc)
         return int(bad.value)
 
     def unpack_device(self, d_packed, kmer_length, n, d_chars, stream=0):
@@ -410,6 +431,16 @@ class GpuIndex:
         _check("awfmGpuSearchTally", _lib.lib().awfmGpuSearchTally(self.handle, d_chars, d_offsets or None, fixed_length,
                                                                    n, C.byref(out)))
         return {"seeded": int(out[0]), "steps": int(out[1]), "blocks": int(out[2]), "chars": int(out[3])}
+
+    def search_hits_line_tally(self, d_chars, d_offsets, fixed_length, n):
+        """compulsory traffic of the seed-order search of this batch (awfmGpuSearchHitsLineTally): distinct 128-B lines
+        per search level, records read, results stored"""
+        out = (C.c_uint64 * 8)()
+        _check("awfmGpuSearchHitsLineTally", _lib.lib().awfmGpuSearchHitsLineTally(self.handle, d_chars, d_offsets or None,
+                                                                                   fixed_length, n, C.byref(out)))
+        keys = ("seed_table_lines", "deep_table_lines", "pair_level_lines", "nuc_level_lines", "ordered_kmers",
+                "record_bytes_per_kmer", "kmers_with_hits", "general_kmers")
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def hit_offsets(self, d_ranges, n, d_hit_offsets, d_scratch, stream=0):
         total = C.c_uint64(0)

@@ -150,32 +150,65 @@ static void scatterCounts(void *p, uint64_t begin, uint64_t end, unsigned tid) {
 struct locateCtx {
   struct AwFmKmerSearchData *data;
   const uint64_t *hitOffsets;
-  const uint64_t *positions;
+  uint64_t n;
+  unsigned threads;
+  bool sized;
   int failed;
+  /* the window being scattered */
+  uint64_t queryBegin, hitBegin, hitEnd;
+  const uint64_t *positions;
 };
 
-/* ref src/AwFmParallelSearch.c:327-328, :361, :367-387: count is set, the list
- * grows by realloc to exactly `count` only when capacity is too small */
-static void scatterPositions(void *p, uint64_t begin, uint64_t end, unsigned tid) {
+/* ref src/AwFmParallelSearch.c:327-328, :367-387 (setPositionListCount): count is set, the list grows by realloc to
+ * exactly `count` only when capacity is too small */
+static void sizeLists(void *p, uint64_t begin, uint64_t end, unsigned tid) {
   (void)tid;
   struct locateCtx *c = p;
   for (uint64_t i = begin; i < end; i++) {
     struct AwFmKmerSearchData *d = &c->data[i];
-    const uint64_t hits = c->hitOffsets[i + 1] - c->hitOffsets[i];
-    const uint32_t newCount = (uint32_t)hits;
+    const uint32_t newCount = (uint32_t)(c->hitOffsets[i + 1] - c->hitOffsets[i]);
     if (d->capacity < newCount) {
       void *grown = realloc(d->positionList, (size_t)newCount * sizeof(uint64_t));
       if (!grown) {
         fprintf(stderr, "Critical memory failure: could not allocate memory for position list.\n");
         __atomic_store_n(&c->failed, 1, __ATOMIC_RELAXED);
+        d->count = 0;
         continue;
       }
       d->positionList = grown;
       d->capacity = newCount;
     }
     d->count = newCount;
-    memcpy(d->positionList, c->positions + c->hitOffsets[i], (size_t)newCount * sizeof(uint64_t));
   }
+}
+
+/* ref src/AwFmParallelSearch.c:361: the part of every list that lies in the window [hitBegin, hitEnd) of the flat hit list
+ * (a list whose hits exceed the device's hit budget arrives in several windows) */
+static void scatterWindow(void *p, uint64_t begin, uint64_t end, unsigned tid) {
+  (void)tid;
+  struct locateCtx *c = p;
+  for (uint64_t j = begin; j < end; j++) {
+    const uint64_t i = c->queryBegin + j;
+    struct AwFmKmerSearchData *d = &c->data[i];
+    const uint64_t from = c->hitOffsets[i], to = from + d->count; /* count is 0 for a list that could not be allocated */
+    const uint64_t lo = from > c->hitBegin ? from : c->hitBegin, hi = to < c->hitEnd ? to : c->hitEnd;
+    if (lo < hi) memcpy(d->positionList + (lo - from), c->positions + (lo - c->hitBegin), (size_t)(hi - lo) * sizeof(uint64_t));
+  }
+}
+
+static int locateWindowSink(void *user, uint64_t queryBegin, uint64_t queryEnd, uint64_t hitBegin, uint64_t hitEnd,
+                            const uint64_t *positions) {
+  struct locateCtx *c = user;
+  if (!c->sized) { /* the hit offsets are complete: every list gets its final size before the first position lands */
+    awfmParallelFor(c->threads, c->n, sizeLists, c);
+    c->sized = true;
+  }
+  c->queryBegin = queryBegin;
+  c->hitBegin = hitBegin;
+  c->hitEnd = hitEnd;
+  c->positions = positions;
+  awfmParallelFor(c->threads, queryEnd - queryBegin, scatterWindow, c);
+  return 0;
 }
 
 /* A shard that failed reports no hits: there is no CPU search path to fall back to, awFmParallelSearchCount
@@ -215,13 +248,17 @@ static void *runShard(void *p) {
       awfmParallelFor(job->threads, job->n, scatterCounts, &ctx);
     }
   } else {
-    const uint64_t *positions = NULL; /* page-locked staging of the image, valid while the AoS lock is held */
-    job->rc = awfmGpuLocateHostPinned(g, chars, offsets, fixedLength, job->n, out, &positions);
-    if (job->rc == AwFmSuccess) {
-      struct locateCtx ctx = {job->data, out, positions, 0};
-      awfmParallelFor(job->threads, job->n, scatterPositions, &ctx);
-      if (ctx.failed) job->rc = AwFmAllocationFailure;
-    }
+    /* the hit list arrives in windows bounded by the device's hit budget (one window for all but hit-heavy batches),
+     * in page-locked staging of the image that is valid while the sink runs */
+    struct locateCtx ctx;
+    memset(&ctx, 0, sizeof ctx);
+    ctx.data = job->data;
+    ctx.hitOffsets = out;
+    ctx.n = job->n;
+    ctx.threads = job->threads;
+    job->rc = awfmGpuLocateHostWindows(g, chars, offsets, fixedLength, job->n, NULL, out, locateWindowSink, &ctx);
+    if (job->rc == AwFmSuccess && !ctx.sized) awfmParallelFor(job->threads, job->n, sizeLists, &ctx); /* no hit at all: counts = 0 */
+    if (job->rc == AwFmSuccess && ctx.failed) job->rc = AwFmAllocationFailure;
   }
   if (job->rc != AwFmSuccess) {
     snprintf(job->error, sizeof job->error, "%s", awfmGpuLastError());

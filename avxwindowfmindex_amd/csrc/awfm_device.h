@@ -336,7 +336,38 @@ __device__ __forceinline__ typename PositionType<NARROW>::type nucBaseAny(const 
   return (pos_t)(before - acgt - (ix.sentinelPos < before ? 1ull : 0ull));
 }
 
-/* one backward step with any letter index (0..3, 4 = X; ref src/AwFmSearch.c:42-103): loads + rank */
+/* the rank half of a backward step with any letter index (0..3, 4 = X; ref src/AwFmSearch.c:42-103) from the pieces of
+ * the blocks of sp - 1 and ep this lane holds (p1 is ignored when both positions lie in one block) */
+template <int G, bool NARROW>
+__device__ __forceinline__ void nucStepAnyRank(const DevIndex &ix, const unsigned long long *sC, const unsigned long long *sSuper,
+                                               unsigned firstSlice, unsigned letter, const Piece *p0, const Piece *p1,
+                                               typename PositionType<NARROW>::type &sp,
+                                               typename PositionType<NARROW>::type &ep) {
+  constexpr int S = (int)kSlices / G;
+  typedef typename PositionType<NARROW>::type pos_t;
+  const pos_t q0 = sp - 1, q1 = ep;
+  const unsigned long long blk0 = q0 >> kBlockShift, blk1 = q1 >> kBlockShift;
+  const bool same = blk0 == blk1;
+  const PlaneSel3 sel = nucPlaneSel(letter);
+  const unsigned local0 = (unsigned)q0 & kBlockMask, local1 = (unsigned)q1 & kBlockMask;
+  const unsigned sameMask = same ? ~0u : 0u;
+  unsigned n0 = 0, n1 = 0;
+#pragma unroll
+  for (int s = 0; s < S; s++) {
+    const unsigned occ0 = nucOccSlice(p0[s], sel), occ1 = nucOccSlice(p1[s], sel);
+    n0 += __popc(occ0 & sliceMask(local0, firstSlice + s));
+    n1 += __popc(__builtin_amdgcn_bitop3_b32(occ0, occ1, sameMask, 0xE4) & sliceMask(local1, firstSlice + s));
+  }
+  const pos_t base0 = nucBaseAny<G, NARROW>(ix, sSuper, p0, letter, blk0);
+  pos_t base1 = nucBaseAny<G, NARROW>(ix, sSuper, p1, letter, blk1);
+  base1 = same ? base0 : base1;
+  const unsigned packed = groupSum<G>(n0 | (n1 << 16));
+  const pos_t cLetter = (pos_t)sC[letter];
+  sp = cLetter + base0 + (pos_t)(packed & 0xFFFFu);
+  ep = cLetter + base1 + (pos_t)(packed >> 16) - (pos_t)1;
+}
+
+/* one backward step with any letter index: loads + rank */
 template <int G, bool NARROW>
 __device__ __forceinline__ void nucStepAny(const DevIndex &ix, const unsigned long long *sC, const unsigned long long *sSuper,
                                            unsigned firstSlice, unsigned letter,
@@ -360,25 +391,9 @@ __device__ __forceinline__ void nucStepAny(const DevIndex &ix, const unsigned lo
 #pragma unroll
     for (int s = 0; s < S; s++) p1[s] = a1[s];
   }
-  const PlaneSel3 sel = nucPlaneSel(letter);
-  const unsigned local0 = (unsigned)q0 & kBlockMask, local1 = (unsigned)q1 & kBlockMask;
-  const unsigned sameMask = same ? ~0u : 0u;
-  unsigned n0 = 0, n1 = 0;
-#pragma unroll
-  for (int s = 0; s < S; s++) {
-    const unsigned occ0 = nucOccSlice(p0[s], sel), occ1 = nucOccSlice(p1[s], sel);
-    n0 += __popc(occ0 & sliceMask(local0, firstSlice + s));
-    n1 += __popc(__builtin_amdgcn_bitop3_b32(occ0, occ1, sameMask, 0xE4) & sliceMask(local1, firstSlice + s));
-  }
 #pragma unroll
   for (int s = 0; s < S; s++) asm volatile("" ::"v"(p0[s]), "v"(p1[s]));
-  const pos_t base0 = nucBaseAny<G, NARROW>(ix, sSuper, p0, letter, blk0);
-  pos_t base1 = nucBaseAny<G, NARROW>(ix, sSuper, p1, letter, blk1);
-  base1 = same ? base0 : base1;
-  const unsigned packed = groupSum<G>(n0 | (n1 << 16));
-  const pos_t cLetter = (pos_t)sC[letter];
-  sp = cLetter + base0 + (pos_t)(packed & 0xFFFFu);
-  ep = cLetter + base1 + (pos_t)(packed >> 16) - (pos_t)1;
+  nucStepAnyRank<G, NARROW>(ix, sC, sSuper, firstSlice, letter, p0, p1, sp, ep);
 }
 
 /* ------------------------------------------------------------------ amino */
@@ -649,6 +664,7 @@ struct AwFmGpuIndex {
   size_t workBytes = 0;
   void *dHits = nullptr; /* positions of the host-buffer locate calls, grow-only like dWork */
   size_t hitsBytes = 0;
+  hipEvent_t windowEvent[2] = {nullptr, nullptr}; /* the two hit windows in flight of awfmGpuLocateHostWindows */
   /* ordered search path (awfm_gpu_ordered.hip): grow-only scratch shared by all searches on this image;
    * the event orders its re-use across streams */
   int orderMode = -1; /* -1 auto, 0 off, 1 on */
@@ -748,6 +764,9 @@ void awfmGpuStreamStateFree(AwFmGpuIndex *g);
 enum AwFmReturnCode awfmGpuHitOffsetsAsync(AwFmGpuIndex *g, const uint32_t *dCounts, const struct AwFmSearchRange *dRanges,
                                            uint64_t numQueries, uint64_t *dHitOffsets, void *dScratch,
                                            unsigned long long *pinnedTotal, hipStream_t s);
+/* hits whose positions may be resident on the device at once (awfm_gpu.hip: $AWFM_GPU_HIT_BUDGET_BYTES / 8, else a quarter
+ * of the free device memory); `C` linkage like the rest of the shim */
+extern "C" uint64_t awfmGpuHitBudget(const AwFmGpuIndex *g);
 /* awfm_gpu_build.hip: level-wise construction of the deeper seed table into a new device buffer */
 bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut);
 void awfmGpuSetError(const char *what);

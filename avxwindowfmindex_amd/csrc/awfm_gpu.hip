@@ -131,9 +131,13 @@ inline unsigned cappedGrid(unsigned long long n) {
   return (unsigned)(blocks < (1ull << 22) ? (blocks ? blocks : 1ull) : (1ull << 22));
 }
 
-/* dPositions[hitOffsets[i] + h] = sp_i + h (the BWT positions to trace back) */
+/* positions[hitOffsets[i] + h - hitBegin] = sp_i + h (the BWT positions to trace back) for the hits whose number
+ * hitOffsets[i] + h lies in the window [hitBegin, hitEnd), over the queries firstQuery .. firstQuery + n - 1.  The whole
+ * batch is the window [0, total) over all queries; a budgeted locate takes the hit list window by window (a window may
+ * start and end inside the list of one k-mer). */
 __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const unsigned long long *__restrict__ hitOffsets,
-                                 unsigned long long n, unsigned long long *__restrict__ positions) {
+                                 unsigned long long firstQuery, unsigned long long n, unsigned long long hitBegin,
+                                 unsigned long long hitEnd, unsigned long long *__restrict__ positions) {
   /* one wave per 64 queries: short lists by their own lane, long lists by the whole wave; the grid is capped (a
    * launch holds fewer than 2^32 threads), workgroups stride over the batch */
   const unsigned lane = threadIdx.x & 63u;
@@ -142,9 +146,13 @@ __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const un
     const unsigned long long i = base + threadIdx.x;
     unsigned long long start = 0, count = 0, sp = 0;
     if (i < n) {
-      start = hitOffsets[i];
-      count = hitOffsets[i + 1] - start;
-      if (count) sp = ranges[i].x; /* batches with few hits: the ranges are not read at all */
+      const unsigned long long from = hitOffsets[firstQuery + i], to = hitOffsets[firstQuery + i + 1];
+      const unsigned long long lo = from > hitBegin ? from : hitBegin, hi = to < hitEnd ? to : hitEnd;
+      if (lo < hi) { /* batches with few hits: the ranges are not read at all */
+        start = lo - hitBegin;
+        count = hi - lo;
+        sp = ranges[firstQuery + i].x + (lo - from);
+      }
     }
     const bool isLong = count > 32ull;
     if (!isLong)
@@ -326,6 +334,7 @@ void launchSearch(const AwFmGpuIndex *g, const DevIndex &dev, int lanes, hipStre
 }
 }  // namespace
 
+constexpr unsigned kAutoDeepSeedK = 14; /* depth of the device-only seed table large nucleotide images get by default */
 extern "C" {
 static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g);
 static enum AwFmReturnCode applyPairFromEnv(AwFmGpuIndex *g);
@@ -535,6 +544,8 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
     if (g->orderEvent) (void)hipEventDestroy(g->orderEvent);
     for (int i = 0; i < 2; i++)
       if (g->orderTiming[i]) (void)hipEventDestroy(g->orderTiming[i]);
+    for (int i = 0; i < 2; i++)
+      if (g->windowEvent[i]) (void)hipEventDestroy(g->windowEvent[i]);
     for (int i = 0; i < 4; i++)
       if (g->pinned[i]) (void)hipHostFree(g->pinned[i]);
   }
@@ -750,9 +761,22 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
  * so no lock is taken -- awfmGpuIndexAcquireAll creates images while it holds the table lock, and the public
  * setter would ask for that lock again through lanesOf() */
 static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
-  const char *env = getenv("AWFM_GPU_DEEP_SEED_K");
-  if (!env || g->amino) return AwFmSuccess;
-  const int deepK = atoi(env);
+  if (g->amino) return AwFmSuccess;
+  int deepK = 0;
+  if (const char *env = getenv("AWFM_GPU_DEEP_SEED_K")) {
+    deepK = atoi(env); /* 0: none */
+  } else if (g->dev.bwtLength >= (1ull << 28) && g->dev.seedK >= 8 && g->dev.seedK < kAutoDeepSeedK) {
+    /* Automatic: an image far beyond the L2s gets the table of depth 14 when the device has room to spare (the table is
+     * 4^14 x 16 B = 4.3 GB, its construction holds the level below beside it; asked for: four times the table).  10^8
+     * random 21-mers against a 3.1 Gbp image, search call: 6.19 ms with it against 6.68 ms from the index's own k = 12
+     * table (13: 6.29, 15: 6.26); results are bit-identical (the table holds what the stepping would compute). */
+    size_t freeBytes = 0, totalBytes = 0;
+    DeviceGuard guard(g->device);
+    if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && freeBytes >= 4ull * (16ull << (2u * kAutoDeepSeedK)))
+      deepK = (int)kAutoDeepSeedK;
+    else
+      (void)hipGetLastError();
+  }
   if (deepK <= 0 || (unsigned)deepK <= g->dev.seedK) return AwFmSuccess; /* nothing deeper than the index's own table */
   DeviceGuard guard(g->device);
   return applyDeepSeed(g, (unsigned)deepK, {});
@@ -794,6 +818,7 @@ enum AwFmReturnCode awfmGpuIndexSetPairImage(AwFmGpuIndex *g, int enable) {
   return rc;
 }
 int awfmGpuIndexHasPairImage(const AwFmGpuIndex *g) { return g && g->dev.pairBlocks ? 1 : 0; }
+unsigned awfmGpuIndexDeepSeedK(const AwFmGpuIndex *g) { return g ? g->dev.deepK : 0u; }
 
 int awfmGpuIndexDevice(const AwFmGpuIndex *g) { return g ? g->device : -1; }
 void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel) {
@@ -1049,20 +1074,28 @@ enum AwFmReturnCode awfmGpuLocate(AwFmGpuIndex *g, const struct AwFmSearchRange 
 enum AwFmReturnCode awfmGpuLocateTo(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges,
                                     const uint64_t *dHitOffsets, uint64_t numQueries, uint64_t totalHits,
                                     uint64_t *dPositions, uint64_t *outPositions, void *stream) {
+  return awfmGpuLocateWindow(g, dRanges, dHitOffsets, 0, numQueries, 0, totalHits, dPositions, outPositions, stream);
+}
+
+enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges, const uint64_t *dHitOffsets,
+                                        uint64_t queryBegin, uint64_t queryEnd, uint64_t hitBegin, uint64_t hitEnd,
+                                        uint64_t *dPositions, uint64_t *outPositions, void *stream) {
   if (!g) {
     setError("awfmGpuLocate: null image");
     return AwFmNullPtrError;
   }
-  if (numQueries == 0 || totalHits == 0) return AwFmSuccess;
+  if (queryEnd <= queryBegin || hitEnd <= hitBegin) return AwFmSuccess;
   if (!dRanges || !dHitOffsets || !dPositions || !outPositions) {
     setError("awfmGpuLocate: null argument");
     return AwFmNullPtrError;
   }
+  const uint64_t numQueries = queryEnd - queryBegin, totalHits = hitEnd - hitBegin;
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(expandHitsKernel, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
-                     (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets,
-                     (unsigned long long)numQueries, (unsigned long long *)dPositions);
+                     (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
+                     (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
+                     (unsigned long long *)dPositions);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   if (g->dDenseSa) {
     hipLaunchKernelGGL(denseSaGatherKernel, dim3((unsigned)(g->numCUs * 8)), dim3(256), 0, s, (const unsigned *)g->dDenseSa,
@@ -1262,16 +1295,45 @@ enum AwFmReturnCode awfmGpuCountHost(AwFmGpuIndex *g, const uint8_t *chars, cons
   return AwFmSuccess;
 }
 
-/* pinnedOut: the positions land in page-locked slot 3 of the image (no malloc, full-rate copy) instead of a
- * malloc'ed array */
-static enum AwFmReturnCode locateHost(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
-                                      uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
-                                      uint64_t *hitOffsets, uint64_t **positions, bool pinnedOut) {
-  if (!g || !chars || !hitOffsets || !positions) {
+/* How many hits' positions may be resident on the device at once: $AWFM_GPU_HIT_BUDGET_BYTES / 8, else a quarter of
+ * the free device memory (what this image's own position buffer holds counted as free), between 2^25 and 2^31 hits. */
+uint64_t awfmGpuHitBudget(const AwFmGpuIndex *g) {
+  if (const char *env = getenv("AWFM_GPU_HIT_BUDGET_BYTES")) {
+    const unsigned long long bytes = strtoull(env, nullptr, 10);
+    if (bytes) return bytes / 8 > 1024 ? bytes / 8 : 1024;
+  }
+  size_t freeBytes = 0, totalBytes = 0;
+  if (hipMemGetInfo(&freeBytes, &totalBytes) != hipSuccess) {
+    (void)hipGetLastError();
+    freeBytes = (size_t)1 << 32;
+  }
+  uint64_t hits = ((uint64_t)freeBytes + g->hitsBytes) / 4 / 8;
+  if (hits < (1ull << 25)) hits = 1ull << 25;
+  if (hits > (1ull << 31)) hits = 1ull << 31;
+  return hits;
+}
+
+/* first query whose list ends after hit number h (offsets[q + 1] > h), i.e. the query hit h belongs to */
+static uint64_t queryOfHit(const uint64_t *offsets, uint64_t n, uint64_t h) {
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint64_t mid = lo + (hi - lo) / 2;
+    if (offsets[mid + 1] > h) hi = mid;
+    else lo = mid + 1;
+  }
+  return lo;
+}
+
+/* Upload, search, scan; then the hit list in windows of at most hitBudget() hits, two in flight: while the sink
+ * consumes window w on the calling thread, the walk and the download of window w+1 run.  hitOffsets[0..n] is complete
+ * before the first sink call. */
+enum AwFmReturnCode awfmGpuLocateHostWindows(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
+                                             uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
+                                             uint64_t *hitOffsets, AwFmGpuHitWindowSink sink, void *user) {
+  if (!g || !chars || !hitOffsets || !sink) {
     setError("awfmGpuLocateHost: null argument");
     return AwFmNullPtrError;
   }
-  *positions = nullptr;
   hitOffsets[0] = 0;
   if (numQueries == 0) return AwFmSuccess;
   DeviceGuard guard(g->device);
@@ -1293,58 +1355,122 @@ static enum AwFmReturnCode locateHost(AwFmGpuIndex *g, const uint8_t *chars, con
   uint64_t totalHits = 0;
   rc = awfmGpuHitOffsets(g, dRanges, numQueries, dHitOffsets, w + l.scratch, &totalHits, s);
   if (rc != AwFmSuccess) return rc;
-  uint64_t *dPositions = nullptr;
-  if (totalHits) {
-    if (totalHits * 8 > g->hitsBytes) { /* grow-only, so that a steady stream of batches never allocates */
-      if (g->dHits) (void)hipFree(g->dHits);
-      g->dHits = nullptr;
-      g->hitsBytes = 0;
-      const size_t want = totalHits * 8 + totalHits * 2 + 4096;
-      AWFM_HIP_TRY(hipMalloc(&g->dHits, want), AwFmAllocationFailure);
-      g->hitsBytes = want;
-    }
-    dPositions = (uint64_t *)g->dHits;
-    rc = awfmGpuLocate(g, dRanges, dHitOffsets, numQueries, totalHits, dPositions, s);
-    if (rc == AwFmSuccess && hipStreamSynchronize(s) != hipSuccess) {
-      setError("awfmGpuLocateHost: locate kernels failed", hipGetLastError());
-      rc = AwFmGeneralFailure;
-    }
-    if (rc != AwFmSuccess) return rc;
-  }
-  uint64_t *hostPositions = pinnedOut ? (uint64_t *)awfmGpuPinnedBuffer(g, 3, (totalHits ? totalHits : 1) * 8)
-                                      : (uint64_t *)malloc((totalHits ? totalHits : 1) * 8);
-  if (!hostPositions) {
-    setError("awfmGpuLocateHost: host allocation failed");
-    return AwFmAllocationFailure;
-  }
-  hipError_t e = hipSuccess;
-  if (totalHits) e = hipMemcpyAsync(hostPositions, dPositions, totalHits * 8, hipMemcpyDeviceToHost, s);
-  if (e == hipSuccess) e = hipMemcpyAsync(hitOffsets, dHitOffsets, (numQueries + 1) * 8, hipMemcpyDeviceToHost, s);
+  hipError_t e = hipMemcpyAsync(hitOffsets, dHitOffsets, (numQueries + 1) * 8, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess && ranges) e = hipMemcpyAsync(ranges, dRanges, numQueries * 16, hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   if (e != hipSuccess) {
-    if (!pinnedOut) free(hostPositions);
-    setError("awfmGpuLocateHost: download failed", e);
+    setError("awfmGpuLocateHost: download of the hit offsets failed", e);
     return AwFmGeneralFailure;
   }
-  *positions = hostPositions;
-  return AwFmSuccess;
+  if (totalHits == 0) return AwFmSuccess;
+  /* one window when the list fits the budget (the usual case); otherwise windows of half the budget, two resident */
+  const uint64_t budget = awfmGpuHitBudget(g);
+  const uint64_t window = totalHits <= budget ? totalHits : (budget / 2 > 0 ? budget / 2 : 1);
+  const unsigned buffers = totalHits <= budget ? 1u : 2u;
+  if (window * buffers * 8 > g->hitsBytes) { /* grow-only, so that a steady stream of batches never allocates */
+    if (g->dHits) (void)hipFree(g->dHits);
+    g->dHits = nullptr;
+    g->hitsBytes = 0;
+    const size_t want = window * buffers * 8 + (buffers == 1 ? window * 2 : 0) + 4096;
+    if (hipMalloc(&g->dHits, want) != hipSuccess) {
+      (void)hipGetLastError();
+      setError("awfmGpuLocateHost: no device memory for the positions of one window of hits ($AWFM_GPU_HIT_BUDGET_BYTES)");
+      return AwFmAllocationFailure;
+    }
+    g->hitsBytes = want;
+  }
+  uint64_t *staging = (uint64_t *)awfmGpuPinnedBuffer(g, 3, window * buffers * 8);
+  if (!staging) {
+    setError("awfmGpuLocateHost: host allocation failed");
+    return AwFmAllocationFailure;
+  }
+  if (!g->windowEvent[0]) {
+    for (int i = 0; i < 2; i++)
+      if (hipEventCreateWithFlags(&g->windowEvent[i], hipEventDisableTiming) != hipSuccess) {
+        setError("awfmGpuLocateHost: hipEventCreate failed");
+        return AwFmGeneralFailure;
+      }
+  }
+  const uint64_t numWindows = (totalHits + window - 1) / window;
+  struct Pending {
+    uint64_t qb, qe, hb, he;
+  } pending[2];
+  auto issue = [&](uint64_t wi) -> enum AwFmReturnCode {
+    Pending &p = pending[wi % buffers];
+    p.hb = wi * window;
+    p.he = p.hb + window < totalHits ? p.hb + window : totalHits;
+    p.qb = queryOfHit(hitOffsets, numQueries, p.hb);
+    p.qe = queryOfHit(hitOffsets, numQueries, p.he - 1) + 1;
+    uint64_t *dPos = (uint64_t *)g->dHits + (wi % buffers) * window;
+    const enum AwFmReturnCode r = awfmGpuLocateWindow(g, dRanges, dHitOffsets, p.qb, p.qe, p.hb, p.he, dPos, dPos, s);
+    if (r != AwFmSuccess) return r;
+    AWFM_HIP_TRY(hipMemcpyAsync(staging + (wi % buffers) * window, dPos, (p.he - p.hb) * 8, hipMemcpyDeviceToHost, s), AwFmGeneralFailure);
+    AWFM_HIP_TRY(hipEventRecord(g->windowEvent[wi % buffers], s), AwFmGeneralFailure);
+    return AwFmSuccess;
+  };
+  rc = issue(0);
+  for (uint64_t wi = 0; wi < numWindows && rc == AwFmSuccess; wi++) {
+    if (wi + 1 < numWindows) rc = issue(wi + 1); /* buffer (wi + 1) % 2 was handed to the sink an iteration ago */
+    if (rc != AwFmSuccess) break;
+    if (hipEventSynchronize(g->windowEvent[wi % buffers]) != hipSuccess) {
+      setError("awfmGpuLocateHost: locate kernels failed", hipGetLastError());
+      rc = AwFmGeneralFailure;
+      break;
+    }
+    const Pending &p = pending[wi % buffers];
+    if (sink(user, p.qb, p.qe, p.hb, p.he, staging + (wi % buffers) * window) != 0) {
+      setError("awfmGpuLocateHost: the sink asked to stop");
+      rc = AwFmGeneralFailure;
+    }
+  }
+  (void)hipStreamSynchronize(s); /* nothing of this batch is in flight when the work buffers are released */
+  return rc;
 }
 
+namespace {
+struct FlatSinkCtx {
+  uint64_t *positions;
+};
+int flatSink(void *user, uint64_t, uint64_t, uint64_t hitBegin, uint64_t hitEnd, const uint64_t *positions) {
+  memcpy(((FlatSinkCtx *)user)->positions + hitBegin, positions, (hitEnd - hitBegin) * 8);
+  return 0;
+}
+}  // namespace
 
 enum AwFmReturnCode awfmGpuLocateHost(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
                                       uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
                                       uint64_t *hitOffsets, uint64_t **positions) {
-  return locateHost(g, chars, offsets, fixedLength, numQueries, ranges, hitOffsets, positions, false);
-}
-
-enum AwFmReturnCode awfmGpuLocateHostPinned(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
-                                            uint32_t fixedLength, uint64_t numQueries, uint64_t *hitOffsets,
-                                            const uint64_t **positions) {
-  uint64_t *out = nullptr;
-  const enum AwFmReturnCode rc = locateHost(g, chars, offsets, fixedLength, numQueries, nullptr, hitOffsets, &out, true);
-  if (positions) *positions = out;
-  return rc;
+  if (!positions) {
+    setError("awfmGpuLocateHost: null argument");
+    return AwFmNullPtrError;
+  }
+  *positions = nullptr;
+  /* the flat result array needs the total first: a sink that allocates on its first window */
+  struct Lazy {
+    uint64_t *hitOffsets, n, *out;
+    bool failed;
+  } lazy = {hitOffsets, numQueries, nullptr, false};
+  auto sink = [](void *user, uint64_t qb, uint64_t qe, uint64_t hb, uint64_t he, const uint64_t *pos) -> int {
+    Lazy *z = (Lazy *)user;
+    if (!z->out) {
+      z->out = (uint64_t *)malloc((z->hitOffsets[z->n] ? z->hitOffsets[z->n] : 1) * 8);
+      if (!z->out) {
+        z->failed = true;
+        return 1;
+      }
+    }
+    FlatSinkCtx ctx = {z->out};
+    return flatSink(&ctx, qb, qe, hb, he, pos);
+  };
+  const enum AwFmReturnCode rc = awfmGpuLocateHostWindows(g, chars, offsets, fixedLength, numQueries, ranges, hitOffsets, sink, &lazy);
+  if (rc != AwFmSuccess || lazy.failed) {
+    free(lazy.out);
+    if (lazy.failed) setError("awfmGpuLocateHost: host allocation failed");
+    return lazy.failed ? AwFmAllocationFailure : rc;
+  }
+  if (!lazy.out && hitOffsets) lazy.out = (uint64_t *)malloc(8); /* no hits: an empty array the caller can free */
+  *positions = lazy.out;
+  return AwFmSuccess;
 }
 
 }  // extern "C"

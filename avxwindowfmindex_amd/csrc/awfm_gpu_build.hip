@@ -345,6 +345,53 @@ __global__ void __launch_bounds__(kThreads)
   }
 }
 
+/* The same level step for the deeper device-only table of a nucleotide image, where a level has 10^8 entries and more:
+ * a group of 4 lanes takes U consecutive entries per round and requests the blocks of all of them before it ranks any,
+ * so that a round costs one memory latency for U entries (the one-entry-per-round kernel above is bound by that latency:
+ * 3.6 s for the two levels from k = 12 to 14 of a 3.1 Gbp index).  Consecutive entries have consecutive parents, whose
+ * ranges are neighbours in the BWT: the U steps of a round mostly read the same few lines. */
+template <int U>
+__global__ void __launch_bounds__(kThreads)
+    deepSeedLevelKernel(const DevIndex ix, const ulonglong2 *__restrict__ parentLevel, u64 parentLen, u64 outLen,
+                        ulonglong2 *__restrict__ out) {
+  constexpr int G = 4;
+  __shared__ u64 sC[24];
+  __shared__ u64 sSuper[kMaxNucSuper * 4];
+  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  nucStageSuper<false>(ix, sSuper);
+  __syncthreads();
+  const unsigned g = threadIdx.x % G;
+  const u64 numGroups = (u64)gridDim.x * kSeedGroupsPerBlock;
+  for (u64 base = (((u64)blockIdx.x * kThreads + threadIdx.x) / G) * U; base < outLen; base += numGroups * U) {
+    u64 sp[U], ep[U];
+    unsigned letter[U];
+    bool step[U];
+    Piece p0[U], p1[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const u64 e = base + u < outLen ? base + u : outLen - 1; /* the tail repeats the last entry */
+      letter[u] = (unsigned)(e / parentLen);
+      const ulonglong2 r = parentLevel[e % parentLen];
+      sp[u] = r.x;
+      ep[u] = r.y;
+      /* a query stops at its first invalid range and keeps it (ref src/AwFmParallelSearch.c:293-294) */
+      step[u] = sp[u] <= ep[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const u64 blk0 = step[u] ? (sp[u] - 1ull) >> kBlockShift : 0ull, blk1 = step[u] ? ep[u] >> kBlockShift : 0ull;
+      p0[u] = *(const Piece *)(ix.blocks + (blk0 * kSlices + g));
+      p1[u] = *(const Piece *)(ix.blocks + (blk1 * kSlices + g));
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      u64 a = sp[u], b = ep[u];
+      if (step[u]) nucStepAnyRank<G, false>(ix, sC, sSuper, g, letter[u], &p0[u], &p1[u], a, b);
+      if (g == 0 && base + u < outLen) out[base + u] = make_ulonglong2(a, b);
+    }
+  }
+}
+
 /* ---- sampled SA ---- */
 
 /* 64-bit word j of the little-endian bit stream of samples SA[s*ratio], `width` bits each
@@ -590,12 +637,15 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
   for (unsigned L = K; L < deepK; L++) {
     const u64 outLen = len * 4;
     if (!nxt.alloc(outLen * 16)) return false;
-    const u64 blocks = (outLen + kSeedGroupsPerBlock - 1) / kSeedGroupsPerBlock;
-    const unsigned grid = (unsigned)(blocks < 2048 * 4 ? blocks : 2048 * 4);
-    hipLaunchKernelGGL((seedLevelKernel<false, true>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen,
+    constexpr int kUnroll = 4;
+    const u64 blocks = (outLen + kSeedGroupsPerBlock * kUnroll - 1) / (kSeedGroupsPerBlock * kUnroll);
+    const u64 resident = (u64)g->numCUs * 8u; /* a persistent grid: what does not fit the chip would only queue */
+    const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
+    hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen,
                        nxt.as<ulonglong2>());
     BUILD_TRY(hipGetLastError());
     BUILD_TRY(hipDeviceSynchronize());
+    if (getenv("AWFM_VERBOSE")) fprintf(stderr, "[awfm deep seed] level %u -> %u: %llu entries\n", L, L + 1, (unsigned long long)outLen);
     cur.reset();
     cur.p = nxt.release();
     parent = cur.as<ulonglong2>();

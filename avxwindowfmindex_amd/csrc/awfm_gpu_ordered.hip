@@ -55,17 +55,19 @@ unsigned residentGrid(const AwFmGpuIndex *g, Kernel kernel, size_t dynamicLds = 
   return (unsigned)g->numCUs * (unsigned)perCU;
 }
 
-template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false>
+template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false>
 enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t len, unsigned depth, const ulonglong2 *table,
                                         unsigned long long nq, const void *recs, const unsigned short *keys,
-                                        const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts) {
+                                        const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts,
+                                        const OrderTouch *touch = nullptr, const unsigned *bucketStart = nullptr,
+                                        const BucketFormat bucketFmt = BucketFormat()) {
   /* dynamic LDS: the 32-bit superblock bases of the pair image (images below 2^32 positions) */
   const bool superInLds = PAIR && NARROW && awfmPairSuperInLds(g);
   const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u; /* the 16 pair bases of every superblock */
   DevIndex dev = g->dev;
   dev.pairSuperInLds = superInLds ? 1u : 0u;
   constexpr int threads = orderedThreads(PAIR);
-  unsigned grid = residentGrid(g, orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR>, lds, threads);
+  unsigned grid = residentGrid(g, orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET>, lds, threads);
   const unsigned long long blocks = (nq + threads / G - 1) / (threads / G);
   if (blocks < grid) grid = (unsigned)blocks;
   if (grid >= 8u) grid &= ~7u; /* a multiple of the 8 XCDs, so that every XCD gets the same number of workgroups */
@@ -76,9 +78,10 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
     AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[1]), AwFmGeneralFailure);
   }
   if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[0], s), AwFmGeneralFailure);
-  hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR>), dim3(grid ? grid : 1u), dim3(threads), lds, s, dev, recs,
+  hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET>), dim3(grid ? grid : 1u), dim3(threads), lds, s, dev, recs,
                      keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
-                     getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0);
+                     getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0, touch ? *touch : OrderTouch(), bucketStart,
+                     bucketFmt);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[1], s), AwFmGeneralFailure);
   g->orderTimed = timed;
@@ -89,7 +92,17 @@ template <bool NARROW, bool COMPACT, bool VARLEN>
 enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                                   uint32_t len, unsigned depth, const ulonglong2 *table, unsigned long long nq,
                                   const void *recs, const unsigned short *keys, const unsigned *generalCount,
-                                  ulonglong2 *rng, uint32_t *dCounts, bool packed = false) {
+                                  ulonglong2 *rng, uint32_t *dCounts, bool packed = false, const OrderTouch *touch = nullptr) {
+  if (touch) { /* instrumented launch: the variant the image would run (4 lanes per k-mer, pair steps when it has the pair image) */
+    if constexpr (COMPACT) { /* the sorted 8-byte records ($AWFM_GPU_ORDERED_SORT=rocprim) are a measurement path: no tally */
+      setError("awfmGpuSearchHitsLineTally: not available with $AWFM_GPU_ORDERED_SORT=rocprim");
+      return AwFmUnsupportedVersionError;
+    } else {
+      if (g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR"))
+        return launchOrderedKernel<4, NARROW, COMPACT, VARLEN, true, true>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, touch);
+      return launchOrderedKernel<4, NARROW, COMPACT, VARLEN, false, true>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, touch);
+    }
+  }
   {
     const char *lanes = getenv("AWFM_GPU_ORDERED_LANES"); /* measurement knob: 1 | 2 | 4 lanes per query (default 4) */
     const int G = lanes ? atoi(lanes) : 4;
@@ -109,6 +122,30 @@ enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t 
                      off, len, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)recs,
                      COMPACT ? 8u : (unsigned)sizeof(QueryRec), COMPACT ? 0u : (unsigned)offsetof(QueryRec, index), nq,
                      generalCount);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  return AwFmSuccess;
+}
+
+/* the search over bucketed 8-byte records (partitionKernel), then the general kernel over the last bucket */
+template <bool NARROW>
+enum AwFmReturnCode launchBucketed(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t len, unsigned depth,
+                                   const ulonglong2 *table, unsigned long long nq, const void *recs, const unsigned *bucketStart,
+                                   const BucketFormat &fmt, const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts,
+                                   bool packed, const OrderTouch *touch) {
+  const bool pair = g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR");
+  enum AwFmReturnCode rc;
+  if (touch)
+    rc = pair ? launchOrderedKernel<4, NARROW, true, false, true, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, touch, bucketStart, fmt)
+              : launchOrderedKernel<4, NARROW, true, false, false, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, touch, bucketStart, fmt);
+  else
+    rc = pair ? launchOrderedKernel<4, NARROW, true, false, true, false, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt)
+              : launchOrderedKernel<4, NARROW, true, false, false, false, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt);
+  if (rc != AwFmSuccess || packed) return rc; /* bit-packed k-mers: every one of them is covered */
+  /* the last bucket: k-mers with ambiguity characters; a record of it is the query number alone */
+  const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, NARROW, true>);
+  hipLaunchKernelGGL((searchKernel<false, 4, false, false, NARROW, true>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
+                     (const unsigned long long *)nullptr, len, nq, rng, dCounts, (unsigned long long *)nullptr,
+                     (const unsigned char *)recs, 8u, 0u, nq, generalCount);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
 }
@@ -163,9 +200,100 @@ extern "C" int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets,
 }
 
 /* 1: the batch was searched; 0: the ordered path does not apply (caller runs the general kernel); <0: -AwFmReturnCode */
+static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
+                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
+                         bool rangesOfHitsOnly, const OrderTouch *touch, uint64_t *recordBytesOut);
+
+/* scratch of the image, grown when needed; the caller holds orderMutex.  false: no memory (the general kernel needs none) */
+static bool ensureOrderScratch(AwFmGpuIndex *g, size_t bytes) {
+  if (bytes <= g->orderBytes) return true;
+  /* hipFree waits for every stream of the device, so nothing still reads the old scratch */
+  if (g->dOrder) (void)hipFree(g->dOrder);
+  g->dOrder = nullptr;
+  g->orderBytes = 0;
+  const size_t want = bytes + bytes / 8;
+  if (hipMalloc(&g->dOrder, want) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  g->orderBytes = want;
+  return true;
+}
+
+/* fillNoHitKernel -> encodeCodesKernel -> bucketScanKernel -> partitionKernel -> orderedSearchKernel<BUCKET> ->
+ * searchKernel<INDIRECT> on the caller's stream; the caller holds orderMutex.  Return values as awfmGpuOrderedSearch. */
+static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength, unsigned depth,
+                          const ulonglong2 *table, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
+                          bool rangesOfHitsOnly, const OrderTouch *touch, const BucketFormat &fmt) {
+  const unsigned bins = (1u << fmt.bucketBits) + 1u, binsPad = (bins + 3u) & ~3u;
+  /* [counters 32 KB][hist: bins][cursors: bins][bucketStart: bins + 1][codes: nq x 8 unless packed][records: nq x 8] */
+  const size_t histAt = kOrderCounterBytes, cursorsAt = histAt + alignUp256(bins * 4u), startAt = cursorsAt + alignUp256(bins * 4u);
+  const size_t codesAt = startAt + alignUp256((bins + 1u) * 4u), recsAt = codesAt + (packed ? 0u : alignUp256(nq * 8u));
+  const size_t total = recsAt + alignUp256(nq * 8u);
+  if (!ensureOrderScratch(g, total)) return 0;
+#define BUCKET_TRY(call)                    \
+  do {                                      \
+    hipError_t e__ = (call);                \
+    if (e__ != hipSuccess) {                \
+      setError(#call, e__);                 \
+      return -(int)AwFmGeneralFailure;      \
+    }                                       \
+  } while (0)
+  if (!g->orderEvent) BUCKET_TRY(hipEventCreateWithFlags(&g->orderEvent, hipEventDisableTiming));
+  /* the scratch is shared by all searches on this image: order them across streams */
+  if (g->orderEventRecorded) BUCKET_TRY(hipStreamWaitEvent(s, g->orderEvent, 0));
+  uint8_t *w = (uint8_t *)g->dOrder;
+  unsigned *generalCount = (unsigned *)w;
+  unsigned *hist = (unsigned *)(w + histAt), *cursors = (unsigned *)(w + cursorsAt), *bucketStart = (unsigned *)(w + startAt);
+  const unsigned long long *codes = packed ? (const unsigned long long *)dChars : (const unsigned long long *)(w + codesAt);
+  unsigned long long *recs = (unsigned long long *)(w + recsAt);
+  BUCKET_TRY(hipMemsetAsync(w, 0, startAt, s)); /* the count, the ticket counters, the histogram, the cursors */
+  hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
+                     rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
+  BUCKET_TRY(hipGetLastError());
+  const unsigned long long encodeTiles = (nq + 255ull) / 256ull;
+  const unsigned encodeGrid = (unsigned)(encodeTiles < (unsigned long long)g->numCUs * 8u ? encodeTiles : (unsigned long long)g->numCUs * 8u);
+  if (packed)
+    hipLaunchKernelGGL((encodeCodesKernel<true>), dim3(encodeGrid), dim3(256), bins * 4u, s, dChars, fixedLength, fmt, nq,
+                       (unsigned long long *)nullptr, hist);
+  else
+    hipLaunchKernelGGL((encodeCodesKernel<false>), dim3(encodeGrid), dim3(256), bins * 4u, s, dChars, fixedLength, fmt, nq,
+                       (unsigned long long *)(w + codesAt), hist);
+  BUCKET_TRY(hipGetLastError());
+  hipLaunchKernelGGL(bucketScanKernel, dim3(1), dim3(1024), 0, s, (const unsigned *)hist, bins, bucketStart, generalCount);
+  BUCKET_TRY(hipGetLastError());
+  const size_t partitionLds = (size_t)kPartitionTile * 8u + 3u * binsPad * 4u;
+  static std::once_flag ldsOnce;
+  static hipError_t ldsError = hipSuccess;
+  std::call_once(ldsOnce, [] {
+    ldsError = hipFuncSetAttribute((const void *)partitionKernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(kPartitionTile * 8u + 3u * (((1u << kBucketBitsMax) + 4u) & ~3u) * 4u));
+  });
+  BUCKET_TRY(ldsError);
+  const unsigned long long tiles = (nq + kPartitionTile - 1ull) / kPartitionTile;
+  const unsigned partitionGrid = (unsigned)(tiles < (unsigned long long)g->numCUs ? tiles : (unsigned long long)g->numCUs);
+  hipLaunchKernelGGL(partitionKernel, dim3(partitionGrid), dim3(kPartitionThreads), partitionLds, s, codes, fixedLength, fmt, nq,
+                     (const unsigned *)bucketStart, cursors, recs, packed ? 0u : 1u);
+  BUCKET_TRY(hipGetLastError());
+  const enum AwFmReturnCode rc =
+      awfmImageNarrow(g) ? launchBucketed<true>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch)
+                         : launchBucketed<false>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch);
+  if (rc != AwFmSuccess) return -(int)rc;
+  BUCKET_TRY(hipEventRecord(g->orderEvent, s));
+  g->orderEventRecorded = true;
+#undef BUCKET_TRY
+  return 1;
+}
+
 int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                          uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
                          bool rangesOfHitsOnly) {
+  return orderedSearch(g, s, dChars, off, fixedLength, nq, rng, dCounts, packed, rangesOfHitsOnly, nullptr, nullptr);
+}
+
+static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
+                         uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
+                         bool rangesOfHitsOnly, const OrderTouch *touch, uint64_t *recordBytesOut) {
   unsigned depth = 0;
   const ulonglong2 *table = nullptr;
   if (packed && off) return 0;
@@ -173,7 +301,18 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
 
   std::lock_guard<std::mutex> lock(g->orderMutex);
   /* 8-byte records: fixed-length batches of short enough k-mers */
+  /* fixed-length batches whose records fit 8 bytes: counted and partitioned by the kernels of awfm_ordered_kernel.h
+   * ($AWFM_GPU_ORDERED_SORT=rocprim: the earlier encode + radix sort of (16-bit key, record) pairs, for comparison) */
+  const BucketFormat bucketFmt = bucketFormat(depth, nq);
+  const char *sortEnv = getenv("AWFM_GPU_ORDERED_SORT");
+  const bool bucketed = !off && bucketFits(fixedLength, bucketFmt) && !(sortEnv && !strcmp(sortEnv, "rocprim")) &&
+                        !getenv("AWFM_GPU_ORDERED_WIDE");
+  if (bucketed) {
+    if (recordBytesOut) *recordBytesOut = 8u;
+    return bucketedSearch(g, s, dChars, fixedLength, depth, table, nq, rng, dCounts, packed, rangesOfHitsOnly, touch, bucketFmt);
+  }
   const bool compact = !off && orderCompact(fixedLength, depth) && !getenv("AWFM_GPU_ORDERED_WIDE");
+  if (recordBytesOut) *recordBytesOut = compact ? 8u + 2u : sizeof(QueryRec); /* what the search reads per k-mer: record (+ key) */
   unsigned short *nullKeys = nullptr;
   size_t sortTemp = 0;
   hipError_t sized;
@@ -230,6 +369,11 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   ORDER_TRY(hipGetLastError());
   const unsigned encodeGrid = (unsigned)((nq + 255) / 256);
   const unsigned seedK = g->dev.seedK, deepK = g->dev.deepK;
+  unsigned keyMask = 0xFFFFu;
+  if (const char *env = getenv("AWFM_GPU_ORDER_KEY_BITS")) { /* measurement knob: order by the leading n of the 15 key bits */
+    const int n = atoi(env);
+    if (n >= 1 && n < 15) keyMask = (0x7FFFu << (15 - n)) & 0x7FFFu;
+  }
   size_t tempBytes = sortTemp;
   if (compact) {
     if (packed)
@@ -244,13 +388,13 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   } else {
     if (off)
       hipLaunchKernelGGL((encodeQueriesKernel<false, true>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
-                         seedK, deepK, nq, keysIn, recsIn, generalCount);
+                         seedK, deepK, nq, keysIn, recsIn, generalCount, keyMask);
     else if (packed)
       hipLaunchKernelGGL((encodeQueriesKernel<false, false, true>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength,
-                         depth, seedK, deepK, nq, keysIn, recsIn, generalCount);
+                         depth, seedK, deepK, nq, keysIn, recsIn, generalCount, keyMask);
     else
       hipLaunchKernelGGL((encodeQueriesKernel<false, false>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
-                         seedK, deepK, nq, keysIn, recsIn, generalCount);
+                         seedK, deepK, nq, keysIn, recsIn, generalCount, keyMask);
     ORDER_TRY(hipGetLastError());
     ORDER_TRY(rocprim::radix_sort_pairs(w + l.sortTemp, tempBytes, keysIn, keysOut, (QueryRec *)recsIn, (QueryRec *)recsOut,
                                         (size_t)nq, 0u, kOrderKeyBits, s));
@@ -258,7 +402,7 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   const bool narrow = awfmImageNarrow(g);
   enum AwFmReturnCode rc;
 #define ORDER_GO(NR, CP, VL) \
-  launchOrdered<NR, CP, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts, packed)
+  launchOrdered<NR, CP, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts, packed, touch)
   if (off) rc = narrow ? ORDER_GO(true, false, true) : ORDER_GO(false, false, true);
   else if (compact) rc = narrow ? ORDER_GO(true, true, false) : ORDER_GO(false, true, false);
   else rc = narrow ? ORDER_GO(true, false, false) : ORDER_GO(false, false, false);
@@ -268,4 +412,88 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   g->orderEventRecorded = true;
 #undef ORDER_TRY
   return 1;
+}
+
+/* ------------------------------------------------------------------ compulsory-traffic tally of the seed-order search */
+
+namespace {
+__global__ void __launch_bounds__(256) popcountWordsKernel(const unsigned long long *__restrict__ words, unsigned long long n,
+                                                           unsigned long long *__restrict__ total) {
+  unsigned long long sum = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull)
+    sum += (unsigned long long)__popcll(words[i]);
+  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+  if ((threadIdx.x & 63u) == 0u && sum) atomicAdd(total, sum);
+}
+}  // namespace
+
+/* see include/awfm_gpu.h */
+extern "C" enum AwFmReturnCode awfmGpuSearchHitsLineTally(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                                          uint32_t fixedLength, uint64_t numQueries, uint64_t tallyOut[8]) {
+  if (!g || !dChars || !tallyOut) {
+    setError("awfmGpuSearchHitsLineTally: null argument");
+    return AwFmNullPtrError;
+  }
+  for (int i = 0; i < 8; i++) tallyOut[i] = 0;
+  if (!awfmGpuSearchHitsIsOrdered(g, dOffsets != nullptr, fixedLength, numQueries)) {
+    setError("awfmGpuSearchHitsLineTally: this batch does not take the seed-order path on this image");
+    return AwFmUnsupportedVersionError;
+  }
+  DeviceGuard guard(g->device);
+  const uint64_t seedWords = (g->dev.seedLen * 16u / 128u + 64u) / 64u;
+  const uint64_t deepWords = g->dev.deepK ? ((1ull << (2u * g->dev.deepK)) * 16u / 128u + 64u) / 64u : 1u;
+  const uint64_t pairWords = (g->numBlocks + 64u) / 64u, nucWords = (g->numBlocks / 2u + 64u) / 64u;
+  const uint64_t words = seedWords + deepWords + (uint64_t)kTouchLevels * (pairWords + nucWords) + 8u;
+  unsigned long long *bits = nullptr;
+  if (hipMalloc((void **)&bits, words * 8u) != hipSuccess) {
+    (void)hipGetLastError();
+    setError("awfmGpuSearchHitsLineTally: no device memory for the line bitmaps");
+    return AwFmAllocationFailure;
+  }
+  hipStream_t s = nullptr;
+  enum AwFmReturnCode rc = AwFmSuccess;
+  OrderTouch touch;
+  touch.seedLines = bits;
+  touch.deepLines = touch.seedLines + seedWords;
+  touch.pairLines = touch.deepLines + deepWords;
+  touch.nucLines = touch.pairLines + (uint64_t)kTouchLevels * pairWords;
+  touch.pairWords = pairWords;
+  touch.nucWords = nucWords;
+  unsigned long long *sums = touch.nucLines + (uint64_t)kTouchLevels * nucWords; /* 8 words: hits, then the four line totals */
+  touch.hits = sums;
+  uint64_t recordBytes = 0;
+  hipError_t e = hipMemsetAsync(bits, 0, words * 8u, s);
+  if (e == hipSuccess) {
+    const int did = orderedSearch(g, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries, nullptr, nullptr, false,
+                                  false, &touch, &recordBytes);
+    if (did <= 0) rc = did < 0 ? (enum AwFmReturnCode)(-did) : AwFmGeneralFailure;
+  }
+  unsigned generalCount = 0;
+  unsigned long long host[8] = {0};
+  if (e == hipSuccess && rc == AwFmSuccess) {
+    const struct { const unsigned long long *from; uint64_t n; } parts[4] = {
+        {touch.seedLines, seedWords}, {touch.deepLines, deepWords}, {touch.pairLines, (uint64_t)kTouchLevels * pairWords},
+        {touch.nucLines, (uint64_t)kTouchLevels * nucWords}};
+    for (int i = 0; i < 4; i++)
+      hipLaunchKernelGGL(popcountWordsKernel, dim3(1024), dim3(256), 0, s, parts[i].from, (unsigned long long)parts[i].n, sums + 1 + i);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host, sums, sizeof(host), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&generalCount, g->dOrder, sizeof(generalCount), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+  }
+  (void)hipFree(bits);
+  if (e != hipSuccess) {
+    setError("awfmGpuSearchHitsLineTally", e);
+    return AwFmGeneralFailure;
+  }
+  if (rc != AwFmSuccess) return rc;
+  tallyOut[0] = host[1];                      /* 128-B lines of the index's seed table */
+  tallyOut[1] = host[2];                      /* ... of the deeper device-only table */
+  tallyOut[2] = host[3];                      /* (level, line) pairs of the pair image */
+  tallyOut[3] = host[4];                      /* (level, line) pairs of the one-letter image */
+  tallyOut[4] = numQueries - generalCount;    /* k-mers the seed-order kernel searched */
+  tallyOut[5] = recordBytes;                  /* bytes of sorted record (+ key) it reads per k-mer */
+  tallyOut[6] = host[0];                      /* k-mers with hits (each stores its result) */
+  tallyOut[7] = generalCount;                 /* k-mers left to the general kernel (ambiguity characters, > 32 characters) */
+  return AwFmSuccess;
 }

@@ -92,7 +92,8 @@ struct StreamSlot {
   void *dIn = nullptr;       /* packed words or ASCII as uploaded */
   void *dChars = nullptr;    /* ASCII the search reads (packed input only) */
   void *dRanges = nullptr, *dCounts = nullptr, *dHitOffsets = nullptr, *dScratch = nullptr;
-  size_t capKmers = 0, capChars = 0;
+  size_t capKmers = 0, capChars = 0, capInBytes = 0; /* capInBytes: what dIn holds -- its width per k-mer differs between batches */
+  bool ready = false;                                /* events and hTotal all exist */
   void *dPositions = nullptr;
   size_t capPositions = 0;
   /* page-locked host */
@@ -102,8 +103,11 @@ struct StreamSlot {
   u64 *hTotal = nullptr;
   u64 *hPositions = nullptr;
   size_t hCapPositions = 0;
+  u64 *hOffsets = nullptr; /* hit offsets of a chunk whose hits exceed the device's hit budget (taken in windows) */
+  size_t hCapOffsets = 0;
   /* the chunk in the slot */
   u64 first = 0, n = 0, total = 0;
+  bool windowed = false; /* its hit list is located window by window when the chunk is handed over */
 };
 
 }  // namespace
@@ -116,6 +120,7 @@ struct AwFmGpuStreamState {
    * back, 69 ms through one download stream against 36 ms) */
   hipStream_t copyIn = nullptr, compute = nullptr, copyOut[kStreamSlots] = {}, copyOutB = nullptr;
   hipStream_t slotStream[kStreamSlots] = {}; /* $AWFM_GPU_STREAM_MODE=slots: everything of a chunk on its slot's stream */
+  bool streamsReady = false;
   StreamSlot slot[kStreamSlots];
 };
 
@@ -125,7 +130,7 @@ void freeSlot(StreamSlot &s) {
   void *dev[] = {s.dIn, s.dChars, s.dRanges, s.dCounts, s.dHitOffsets, s.dScratch, s.dPositions};
   for (void *p : dev)
     if (p) (void)hipFree(p);
-  void *host[] = {s.hIn, s.hCounts, s.hTotal, s.hPositions};
+  void *host[] = {s.hIn, s.hCounts, s.hTotal, s.hPositions, s.hOffsets};
   for (void *p : host)
     if (p) (void)hipHostFree(p);
   hipEvent_t events[] = {s.uploaded, s.searched, s.located, s.done, s.doneB};
@@ -146,16 +151,23 @@ void freeSlot(StreamSlot &s) {
 /* (re)allocations happen while nothing of this slot is in flight: its previous chunk was handed to the sink */
 enum AwFmReturnCode ensureSlot(StreamSlot &s, size_t kmers, size_t inBytesPerKmer, size_t charsPerKmer, bool locate,
                                bool stageInput) {
-  if (!s.done) {
-    STREAM_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
-    STREAM_TRY(hipEventCreateWithFlags(&s.searched, hipEventDisableTiming));
-    STREAM_TRY(hipEventCreateWithFlags(&s.located, hipEventDisableTiming));
-    STREAM_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    STREAM_TRY(hipEventCreateWithFlags(&s.doneB, hipEventDisableTiming));
-    STREAM_TRY(hipHostMalloc((void **)&s.hTotal, 64, hipHostMallocDefault));
+  if (!s.ready) {
+    /* published only when every create succeeded: a slot half set up is torn down, not run on null events */
+    hipEvent_t *events[] = {&s.uploaded, &s.searched, &s.located, &s.done, &s.doneB};
+    hipError_t e = hipSuccess;
+    for (hipEvent_t *ev : events)
+      if (e == hipSuccess && !*ev) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+    if (e == hipSuccess && !s.hTotal) e = hipHostMalloc((void **)&s.hTotal, 64, hipHostMallocDefault);
+    if (e != hipSuccess) {
+      setError("awfmGpuStream: creating the events / staging of a pipeline slot failed", e);
+      freeSlot(s);
+      return AwFmGeneralFailure;
+    }
+    s.ready = true;
   }
   const size_t chars = kmers * charsPerKmer;
-  if (kmers > s.capKmers || chars > s.capChars) {
+  const size_t inBytes = kmers * (inBytesPerKmer > 8 ? inBytesPerKmer : 8);
+  if (kmers > s.capKmers || chars > s.capChars || inBytes > s.capInBytes) {
     void **dev[] = {&s.dIn, &s.dChars, &s.dRanges, &s.dCounts, &s.dHitOffsets, &s.dScratch};
     for (void **p : dev) {
       if (*p) (void)hipFree(*p);
@@ -163,8 +175,7 @@ enum AwFmReturnCode ensureSlot(StreamSlot &s, size_t kmers, size_t inBytesPerKme
     }
     if (s.hCounts) (void)hipHostFree(s.hCounts);
     s.hCounts = nullptr;
-    s.capKmers = s.capChars = 0;
-    const size_t inBytes = kmers * (inBytesPerKmer > 8 ? inBytesPerKmer : 8);
+    s.capKmers = s.capChars = s.capInBytes = 0;
     STREAM_TRY(hipMalloc(&s.dIn, inBytes + 256));
     STREAM_TRY(hipMalloc(&s.dChars, chars + 256));
     STREAM_TRY(hipMalloc(&s.dRanges, kmers * 16 + 256));
@@ -174,6 +185,7 @@ enum AwFmReturnCode ensureSlot(StreamSlot &s, size_t kmers, size_t inBytesPerKme
     STREAM_TRY(hipHostMalloc((void **)&s.hCounts, kmers * 4 + 256, hipHostMallocDefault));
     s.capKmers = kmers;
     s.capChars = chars;
+    s.capInBytes = inBytes;
   }
   (void)locate;
   if (stageInput && kmers * inBytesPerKmer > s.hInBytes) {
@@ -316,6 +328,11 @@ enum AwFmReturnCode awfmGpuPackKmers(AwFmGpuIndex *g, const uint8_t *dChars, uin
     return AwFmGeneralFailure;
   }
   if (numUnpackable) *numUnpackable = bad;
+  if (bad) {
+    /* the all-ones word is itself a k-mer ('t' x 32): the output must not be searched */
+    setError("awfmGpuPackKmers: the batch holds k-mers with characters a packed word cannot express; search it as ASCII");
+    return AwFmIllegalPositionError;
+  }
   return AwFmSuccess;
 }
 
@@ -385,12 +402,22 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
   if (!g->streamState) g->streamState = new AwFmGpuStreamState();
   AwFmGpuStreamState &st = *g->streamState;
   StreamSlot *slots = st.slot;
-  if (!st.compute) {
-    STREAM_TRY(hipStreamCreateWithFlags(&st.copyIn, hipStreamNonBlocking));
-    STREAM_TRY(hipStreamCreateWithFlags(&st.compute, hipStreamNonBlocking));
-    for (int i = 0; i < kStreamSlots; i++) STREAM_TRY(hipStreamCreateWithFlags(&st.copyOut[i], hipStreamNonBlocking));
-    STREAM_TRY(hipStreamCreateWithFlags(&st.copyOutB, hipStreamNonBlocking));
-    for (int i = 0; i < kStreamSlots; i++) STREAM_TRY(hipStreamCreateWithFlags(&st.slotStream[i], hipStreamNonBlocking));
+  if (!st.streamsReady) {
+    /* all nine streams or none: a later failure must not leave a guard satisfied with null streams behind it */
+    hipStream_t *streams[] = {&st.copyIn, &st.compute, &st.copyOut[0], &st.copyOut[1], &st.copyOut[2], &st.copyOutB,
+                              &st.slotStream[0], &st.slotStream[1], &st.slotStream[2]};
+    hipError_t e = hipSuccess;
+    for (hipStream_t *p : streams)
+      if (e == hipSuccess && !*p) e = hipStreamCreateWithFlags(p, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      setError("awfmGpuStream: hipStreamCreate failed", e);
+      for (hipStream_t *p : streams) {
+        if (*p) (void)hipStreamDestroy(*p);
+        *p = nullptr;
+      }
+      return AwFmGeneralFailure;
+    }
+    st.streamsReady = true;
   }
   /* $AWFM_GPU_STREAM_MODE=split: one upload stream, one kernel stream, download streams; default: everything of a
    * chunk on its slot's own stream (measured, 10^8 planted 21-mers located: 43-58 ms against 60 ms; random ones 23-25
@@ -400,6 +427,7 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
   const size_t inBytesPerKmer = packed ? 8 : kmerLength;
   const bool stage = !isPinned(input);
   const bool narrowCounts = g->dev.bwtLength < (1ull << 32);
+  const u64 hitBudget = awfmGpuHitBudget(g);
   const u64 numChunks = (numKmers + chunkKmers - 1) / chunkKmers;
   enum AwFmReturnCode rc = AwFmSuccess;
   auto drain = [&]() {
@@ -480,7 +508,10 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
         STEP_TRY(hipEventSynchronize(s.searched));
         if (trace) fprintf(stderr, "[stream] t=%llu searched(%llu) seen %.2f ms\n", (unsigned long long)t, (unsigned long long)(t - 1), now());
         s.total = *s.hTotal;
-        if (s.total) {
+        /* a chunk whose hit list exceeds what may be resident on the device is located window by window when it is its
+         * turn to be handed over (stage C), so that chunks still arrive in order */
+        s.windowed = s.total > hitBudget;
+        if (s.total && !s.windowed) {
           STEP_RC(ensurePositions(s, s.total));
           /* $AWFM_GPU_STREAM_DIRECT: the finish kernel stores into the page-locked staging itself (awfmGpuLocateTo) instead
            * of a copy afterwards; measured the same (10^8 planted 21-mers: 46-54 ms either way) */
@@ -491,8 +522,8 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
         STEP_TRY(hipEventRecord(s.located, comp));
         if (getenv("AWFM_GPU_STREAM_HOSTWAIT")) STEP_TRY(hipEventSynchronize(s.located));
         else STEP_TRY(hipStreamWaitEvent(out, s.located, 0));
-        split = !perSlot && s.total >= (1ull << 20);
-        const u64 lower = direct ? 0 : (split ? s.total / 2 : s.total);
+        split = !perSlot && s.total >= (1ull << 20) && !s.windowed;
+        const u64 lower = direct || s.windowed ? 0 : (split ? s.total / 2 : s.total);
         if (direct) split = false;
         if (lower) STEP_TRY(hipMemcpyAsync(s.hPositions, s.dPositions, lower * 8, hipMemcpyDeviceToHost, out));
         if (split) {
@@ -512,7 +543,59 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
       StreamSlot &s = slots[(t - lag) % kStreamSlots];
       STEP_TRY(hipEventSynchronize(s.done));
       if (trace) fprintf(stderr, "[stream] t=%llu done(%llu) seen %.2f ms\n", (unsigned long long)t, (unsigned long long)(t - lag), now());
-      if (sink(user, s.first, s.n, s.hCounts, locate ? (const uint64_t *)s.hPositions : nullptr, s.total) != 0) {
+      int stop = 0;
+      if (locate && s.windowed) {
+        /* Hit-budgeted hand-over: the chunk's k-mers go to the sink in consecutive groups whose hit lists fit one window
+         * (half the budget); a k-mer whose own list is longer goes alone, slice by slice (same firstKmer, numKmers = 1,
+         * counts[0] its full count every time). */
+        hipStream_t ws = perSlot ? st.slotStream[(t - lag) % kStreamSlots] : st.compute;
+        if ((s.n + 1) * 8 > s.hCapOffsets) {
+          if (s.hOffsets) (void)hipHostFree(s.hOffsets);
+          s.hOffsets = nullptr;
+          s.hCapOffsets = 0;
+          STEP_TRY(hipHostMalloc((void **)&s.hOffsets, (s.capKmers + 1) * 8, hipHostMallocDefault));
+          s.hCapOffsets = (s.capKmers + 1) * 8;
+        }
+        STEP_TRY(hipMemcpyAsync(s.hOffsets, s.dHitOffsets, (s.n + 1) * 8, hipMemcpyDeviceToHost, ws));
+        STEP_TRY(hipStreamSynchronize(ws));
+        const u64 window = hitBudget / 2 > 0 ? hitBudget / 2 : 1;
+        STEP_RC(ensurePositions(s, window));
+        const u64 *off = s.hOffsets;
+        auto deliver = [&](u64 qb, u64 qe, u64 hb, u64 he) -> enum AwFmReturnCode {
+          if (he > hb) {
+            const enum AwFmReturnCode r = awfmGpuLocateWindow(g, (const struct AwFmSearchRange *)s.dRanges, (const uint64_t *)s.dHitOffsets,
+                                                              qb, qe, hb, he, (uint64_t *)s.dPositions, (uint64_t *)s.dPositions, ws);
+            if (r != AwFmSuccess) return r;
+            if (hipMemcpyAsync(s.hPositions, s.dPositions, (he - hb) * 8, hipMemcpyDeviceToHost, ws) != hipSuccess ||
+                hipStreamSynchronize(ws) != hipSuccess) {
+              setError("awfmGpuStream: locating a window of hits failed", hipGetLastError());
+              return AwFmGeneralFailure;
+            }
+          }
+          stop = sink(user, s.first + qb, qe - qb, s.hCounts + qb, (const uint64_t *)s.hPositions, he - hb);
+          return AwFmSuccess;
+        };
+        for (u64 q = 0; q < s.n && !stop;) {
+          const u64 hb = off[q];
+          u64 lo = q, hi = s.n; /* the last qe in (q, n] with off[qe] - hb <= window, if any */
+          while (lo < hi) {
+            const u64 mid = lo + (hi - lo + 1) / 2;
+            if (off[mid] - hb <= window) lo = mid;
+            else hi = mid - 1;
+          }
+          if (lo > q) {
+            STEP_RC(deliver(q, lo, hb, off[lo]));
+            q = lo;
+          } else { /* one k-mer above a window */
+            for (u64 h = hb; h < off[q + 1] && !stop; h += window)
+              STEP_RC(deliver(q, q + 1, h, h + window < off[q + 1] ? h + window : off[q + 1]));
+            q++;
+          }
+        }
+      } else {
+        stop = sink(user, s.first, s.n, s.hCounts, locate ? (const uint64_t *)s.hPositions : nullptr, s.total);
+      }
+      if (stop != 0) {
         setError("awfmGpuStream: the sink asked to stop");
         drain();
         return AwFmGeneralFailure;

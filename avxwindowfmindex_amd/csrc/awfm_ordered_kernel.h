@@ -91,6 +91,32 @@ __device__ __forceinline__ unsigned long long orderCodes(const OrderFormat &f, u
   return ((unsigned long long)(rest >> f.lowBits) << (2u * f.depth)) | index;
 }
 
+/* 2-bit codes (last character in bits 1..0) and ambiguity mask (bit i = character i is not a,c,g,t,u) of the `len`
+ * (1..32) ASCII characters at chars + start: the aligned dwords that hold them, a dword only read when it contains one */
+__device__ __forceinline__ void decodeKmer(const unsigned char *__restrict__ chars, unsigned long long start, unsigned len,
+                                           unsigned long long &codes, unsigned &bad) {
+  const unsigned long long at = (unsigned long long)chars + start;
+  /* (an integer turned pointer is a generic one, read by FLAT loads: say that it is global memory) */
+  typedef const unsigned __attribute__((address_space(1))) *GlobalWords;
+  const GlobalWords first = (GlobalWords)(at & ~3ull);
+  const unsigned shift = (unsigned)at & 3u;
+  const unsigned numDwords = (shift + len + 3u) >> 2;
+  unsigned dw[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++) dw[j] = (unsigned)j < numDwords ? first[j] : 0u;
+  codes = 0;
+  bad = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    unsigned packed = 0, badBits = 0;
+    if (4u * j < len) decodeWord(__builtin_amdgcn_alignbyte(dw[j + 1], dw[j], shift), packed, badBits);
+    codes = (codes << 8) | packed;
+    bad |= badBits << (4 * j);
+  }
+  codes >>= 2u * (32u - len); /* character 0 was in bits 63..62: now the last character is in bits 1..0 */
+  bad &= len >= 32u ? ~0u : ((1u << len) - 1u);
+}
+
 /* "no hit" everywhere: the ordered search only stores the queries that have hits */
 __global__ void __launch_bounds__(256)
     fillNoHitKernel(ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts, const unsigned long long n) {
@@ -124,7 +150,7 @@ __global__ void __launch_bounds__(256)
     encodeQueriesKernel(const unsigned char *__restrict__ chars, const unsigned long long *__restrict__ offsets,
                         const unsigned fixedLen, const unsigned fixedDepth, const unsigned seedK, const unsigned deepK,
                         const unsigned long long numQueries, unsigned short *__restrict__ keys,
-                        void *__restrict__ recs, unsigned *__restrict__ generalCount) {
+                        void *__restrict__ recs, unsigned *__restrict__ generalCount, const unsigned keyMask = 0xFFFFu) {
   const unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
   const bool live = t < numQueries;
   unsigned long long codes = 0, start = 0;
@@ -145,25 +171,7 @@ __global__ void __launch_bounds__(256)
       codes = len >= 32u ? word : (word & ((1ull << (2u * len)) - 1ull));
     }
   } else if (inRange) {
-    /* aligned dwords that hold the query's bytes; a dword is only read when it contains one of them */
-    const unsigned long long at = (unsigned long long)chars + start;
-    /* (an integer turned pointer is a generic one, read by FLAT loads: say that it is global memory) */
-    typedef const unsigned __attribute__((address_space(1))) *GlobalWords;
-    const GlobalWords first = (GlobalWords)(at & ~3ull);
-    const unsigned shift = (unsigned)at & 3u;
-    const unsigned numDwords = (shift + len + 3u) >> 2;
-    unsigned dw[9];
-#pragma unroll
-    for (int j = 0; j < 9; j++) dw[j] = (unsigned)j < numDwords ? first[j] : 0u;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      unsigned packed = 0, badBits = 0;
-      if (4u * j < len) decodeWord(__builtin_amdgcn_alignbyte(dw[j + 1], dw[j], shift), packed, badBits);
-      codes = (codes << 8) | packed;
-      bad |= badBits << (4 * j);
-    }
-    codes >>= 2u * (32u - len); /* character 0 was in bits 63..62: now the last character is in bits 1..0 */
-    bad &= len >= 32u ? ~0u : ((1u << len) - 1u);
+    decodeKmer(chars, start, len, codes, bad);
   }
   const bool fast = inRange && bad == 0u;
   if (live) {
@@ -180,6 +188,9 @@ __global__ void __launch_bounds__(256)
         key = orderKey(orderFormat(fixedDepth), codes);
       }
     }
+    /* measurement knob ($AWFM_GPU_ORDER_KEY_BITS, 16-byte records only: an 8-byte record relies on its key for the bits
+     * the record leaves out): a coarser order */
+    if (!COMPACT && fast) key &= keyMask;
     keys[t] = (unsigned short)key;
     if (COMPACT) {
       ((unsigned long long *)recs)[t] =
@@ -201,18 +212,232 @@ __global__ void __launch_bounds__(256)
  * comes from a 16-byte record (read one iteration ahead) and only a non-empty final range is stored, under the
  * original query number.
  */
-/* workgroup size: the pair variant keeps the 32-bit superblock bases of the pair image in LDS (64 B per 2^23 positions:
- * 24 KB for a GRCh38-sized index), so it runs as 4 workgroups of 512 threads per CU instead of 8 of 256 -- the same 8
- * waves per SIMD with half the copies of the table */
+/*
+ * ---- the hand-written ordering of fixed-length batches: one counting pass + one partition pass ----
+ *
+ * The order the search needs is coarse: what is in flight on an XCD must stay within what its L2 holds, and with the k-mers
+ * partitioned by the leading 11 bits of their table index (2048 buckets, any order inside a bucket) orderedSearchKernel
+ * takes 4.59 instead of 4.41 ms per 10^8 random 21-mers (12 bits 4.54, 10 bits 4.83: $AWFM_GPU_ORDER_KEY_BITS on the
+ * sorted path).  A 2048-way partition is ONE pass whose stores still leave a workgroup as runs of 64 bytes, where the
+ * 15-bit order took two radix-sort passes over (key, record) pairs after an encoding pass:
+ *   encodeCodesKernel   k-mer characters -> 2-bit codes (8 B per k-mer, original order) + bucket histogram (skipped for
+ *                       bit-packed input, which is its own code array: then the kernel only counts);
+ *   bucketScanKernel    exclusive scan of the 2049 bin counts (the last bin: k-mers left to the general kernel);
+ *   partitionKernel     every workgroup takes tiles of 16384 codes, ranks them inside the tile by LDS atomics, reserves
+ *                       one run per non-empty bucket with a global atomic, and writes the 8-byte records run by run.
+ * A record is {rest of the code string : 64 - indexBits, query number : indexBits}; the bucket's own bits are not stored:
+ * the search kernel knows the bucket of a record from its position (bucketStart, tracked per wave).
+ * 10^8 21-mers: 2.9 + 1.6 GB of memory traffic instead of 3.1 + 0.2 + 2 x 2.0 GB.
+ */
+constexpr unsigned kBucketBitsMax = 11; /* 2048 buckets (+ 1 for the k-mers left to the general kernel) */
+constexpr unsigned kPartitionThreads = 1024, kPartitionItems = 16, kPartitionTile = kPartitionThreads * kPartitionItems;
+constexpr unsigned long long kCodeGeneral = 1ull << 63; /* a code word of a k-mer the ordered kernel does not cover */
+
+struct BucketFormat {
+  unsigned depth;      /* characters the table lookup consumes */
+  unsigned bucketBits; /* min(kBucketBitsMax, 2 * depth): leading bits of the table index */
+  unsigned lowBits;    /* 2 * depth - bucketBits: table-index bits below the bucket's */
+  unsigned indexBits;  /* bits of a query number */
+};
+__host__ __device__ inline BucketFormat bucketFormat(unsigned depth, unsigned long long numQueries) {
+  BucketFormat f;
+  f.depth = depth;
+  f.bucketBits = 2u * depth < kBucketBitsMax ? 2u * depth : kBucketBitsMax;
+  f.lowBits = 2u * depth - f.bucketBits;
+  f.indexBits = 1;
+  while (f.indexBits < 32u && (numQueries - 1ull) >> f.indexBits) f.indexBits++;
+  return f;
+}
+/* does a record of a k-mer of `len` characters fit 8 bytes? */
+__host__ __device__ inline bool bucketFits(unsigned len, const BucketFormat &f) {
+  return len >= f.depth && 2u * len - f.bucketBits + f.indexBits <= 64u;
+}
+__device__ __forceinline__ unsigned bucketOf(const BucketFormat &f, unsigned long long codes) {
+  return (unsigned)((codes & ((1ull << (2u * f.depth)) - 1ull)) >> f.lowBits);
+}
+__device__ __forceinline__ unsigned long long bucketRest(const BucketFormat &f, unsigned long long codes) {
+  return ((codes >> (2u * f.depth)) << f.lowBits) | (codes & ((1ull << f.lowBits) - 1ull));
+}
+__device__ __forceinline__ unsigned long long bucketCodes(const BucketFormat &f, unsigned bucket, unsigned long long rest) {
+  const unsigned long long low = rest & ((1ull << f.lowBits) - 1ull);
+  return ((rest >> f.lowBits) << (2u * f.depth)) | ((unsigned long long)bucket << f.lowBits) | low;
+}
+
+/* pass 1: codes (unless PACKED: `chars` is the code array already) + histogram of the buckets; persistent grid, one
+ * LDS histogram per workgroup, flushed once */
+template <bool PACKED>
+__global__ void __launch_bounds__(256)
+    encodeCodesKernel(const unsigned char *__restrict__ chars, const unsigned fixedLen, const BucketFormat f,
+                      const unsigned long long numQueries, unsigned long long *__restrict__ codesOut,
+                      unsigned *__restrict__ hist) {
+  extern __shared__ unsigned sHist[]; /* 2^bucketBits + 1 */
+  const unsigned bins = (1u << f.bucketBits) + 1u;
+  for (unsigned e = threadIdx.x; e < bins; e += 256u) sHist[e] = 0u;
+  __syncthreads();
+  const unsigned long long tiles = (numQueries + 255ull) / 256ull;
+  for (unsigned long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const unsigned long long t = tile * 256ull + threadIdx.x;
+    if (t >= numQueries) continue;
+    unsigned long long codes = 0;
+    unsigned bad = 0;
+    if (PACKED) {
+      const unsigned long long word = ((const unsigned long long *)chars)[t];
+      codes = fixedLen >= 32u ? word : (word & ((1ull << (2u * fixedLen)) - 1ull));
+    } else {
+      decodeKmer(chars, t * fixedLen, fixedLen, codes, bad);
+      codesOut[t] = bad ? kCodeGeneral : codes;
+    }
+    atomicAdd(&sHist[bad ? bins - 1u : bucketOf(f, codes)], 1u);
+  }
+  __syncthreads();
+  for (unsigned e = threadIdx.x; e < bins; e += 256u)
+    if (sHist[e]) atomicAdd(&hist[e], sHist[e]);
+}
+
+/* bucketStart[b] = k-mers in the buckets before b (2^bucketBits + 2 entries: [2^bucketBits] = k-mers the ordered
+ * kernel covers, [2^bucketBits + 1] = all); generalCount = size of the last bin; one workgroup */
+__global__ void __launch_bounds__(1024)
+    bucketScanKernel(const unsigned *__restrict__ hist, const unsigned bins, unsigned *__restrict__ bucketStart,
+                     unsigned *__restrict__ generalCount) {
+  __shared__ unsigned sWave[16];
+  constexpr unsigned kPer = 3; /* 3 x 1024 >= 2049 */
+  unsigned v[kPer], sum = 0;
+  for (unsigned j = 0; j < kPer; j++) {
+    const unsigned e = threadIdx.x * kPer + j;
+    v[j] = e < bins ? hist[e] : 0u;
+    sum += v[j];
+  }
+  unsigned incl = sum;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned up = __shfl_up(incl, off);
+    if ((int)(threadIdx.x & 63u) >= off) incl += up;
+  }
+  if ((threadIdx.x & 63u) == 63u) sWave[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  unsigned before = 0;
+  for (unsigned w = 0; w < (threadIdx.x >> 6); w++) before += sWave[w];
+  unsigned running = before + incl - sum;
+  for (unsigned j = 0; j < kPer; j++) {
+    const unsigned e = threadIdx.x * kPer + j;
+    if (e <= bins) bucketStart[e] = running; /* entry `bins` = the total */
+    running += v[j];
+  }
+  if (threadIdx.x == 0) *generalCount = hist[bins - 1u];
+}
+
+/* pass 2: codes -> records, partitioned by bucket.  cursors[b] = records of bucket b placed so far. */
+__global__ void __launch_bounds__(kPartitionThreads)
+    partitionKernel(const unsigned long long *__restrict__ codes, const unsigned fixedLen, const BucketFormat f,
+                    const unsigned long long numQueries, const unsigned *__restrict__ bucketStart,
+                    unsigned *__restrict__ cursors, unsigned long long *__restrict__ recs, const unsigned honourGeneral) {
+  extern __shared__ unsigned long long sDyn[];
+  unsigned long long *sRec = sDyn;                       /* kPartitionTile records, bucket by bucket */
+  unsigned *sCnt = (unsigned *)(sRec + kPartitionTile);  /* records of the tile per bucket */
+  const unsigned bins = (1u << f.bucketBits) + 1u;
+  const unsigned binsPad = (bins + 3u) & ~3u;
+  unsigned *sLoc = sCnt + binsPad;                       /* where a bucket's run starts in sRec */
+  unsigned *sDst = sLoc + binsPad;                       /* where it goes in recs */
+  __shared__ unsigned sWave[kPartitionThreads / 64];
+  const unsigned long long lenMask = fixedLen >= 32u ? ~0ull : ((1ull << (2u * fixedLen)) - 1ull);
+  const unsigned long long tiles = (numQueries + kPartitionTile - 1ull) / kPartitionTile;
+  constexpr unsigned kPer = 3; /* bins handled per thread in the scan: 3 x 1024 >= 2049 */
+  for (unsigned long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (unsigned e = threadIdx.x; e < bins; e += kPartitionThreads) sCnt[e] = 0u;
+    __syncthreads();
+    const unsigned long long tileBase = tile * kPartitionTile;
+    unsigned long long rec[kPartitionItems];
+    unsigned where[kPartitionItems]; /* bucket << 16 | rank inside the tile's run (a tile has 16384 records) */
+#pragma unroll
+    for (unsigned j = 0; j < kPartitionItems; j++) {
+      const unsigned long long idx = tileBase + (unsigned long long)j * kPartitionThreads + threadIdx.x;
+      rec[j] = idx < numQueries ? codes[idx] : 0ull;
+    }
+#pragma unroll
+    for (unsigned j = 0; j < kPartitionItems; j++) {
+      const unsigned long long idx = tileBase + (unsigned long long)j * kPartitionThreads + threadIdx.x;
+      where[j] = 0xFFFFFFFFu;
+      if (idx < numQueries) {
+        const bool general = honourGeneral != 0u && (rec[j] & kCodeGeneral) != 0ull; /* never for bit-packed input: every word is a k-mer */
+        const unsigned long long c = rec[j] & lenMask;
+        const unsigned b = general ? bins - 1u : bucketOf(f, c);
+        const unsigned rank = atomicAdd(&sCnt[b], 1u);
+        where[j] = (b << 16) | rank;
+        rec[j] = (general ? 0ull : bucketRest(f, c) << f.indexBits) | idx;
+      }
+    }
+    __syncthreads();
+    { /* exclusive scan of the counts; one global reservation per non-empty bucket */
+      unsigned v[kPer], sum = 0;
+      for (unsigned j = 0; j < kPer; j++) {
+        const unsigned e = threadIdx.x * kPer + j;
+        v[j] = e < bins ? sCnt[e] : 0u;
+        sum += v[j];
+      }
+      unsigned incl = sum;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned up = __shfl_up(incl, off);
+        if ((int)(threadIdx.x & 63u) >= off) incl += up;
+      }
+      if ((threadIdx.x & 63u) == 63u) sWave[threadIdx.x >> 6] = incl;
+      __syncthreads();
+      unsigned running = incl - sum;
+      for (unsigned w = 0; w < (threadIdx.x >> 6); w++) running += sWave[w];
+      for (unsigned j = 0; j < kPer; j++) {
+        const unsigned e = threadIdx.x * kPer + j;
+        if (e < bins) {
+          sLoc[e] = running;
+          if (v[j]) sDst[e] = bucketStart[e] + atomicAdd(&cursors[e], v[j]);
+        }
+        running += v[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned j = 0; j < kPartitionItems; j++)
+      if (where[j] != 0xFFFFFFFFu) sRec[sLoc[where[j] >> 16] + (where[j] & 0xFFFFu)] = rec[j];
+    __syncthreads();
+    /* runs out: 8 lanes per bucket, 8 buckets per wave instruction */
+    for (unsigned b = (threadIdx.x >> 3); b < bins; b += kPartitionThreads / 8u) {
+      const unsigned count = sCnt[b], loc = sLoc[b];
+      if (count) {
+        const unsigned long long dst = sDst[b];
+        for (unsigned j = threadIdx.x & 7u; j < count; j += 8u) recs[dst + j] = sRec[loc + j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+/* workgroup size: 256 threads for every variant (the pair variant keeps the 32-bit superblock bases of the pair image in
+ * dynamic LDS, 64 B per 2^23 positions = 24 KB for a GRCh38-sized index, which limits it to 6 workgroups per CU;
+ * 512-thread workgroups with half the copies of that table measured slower) */
 constexpr int orderedThreads(bool pair) { return pair ? 256 : kThreads; }
 
-template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false>
+/*
+ * Instrumented launch (TOUCH; awfmGpuSearchHitsLineTally, not for timing): one bit per (search level, 128-B line) the
+ * kernel reads -- the batch's COMPULSORY memory traffic: a line a level needs has to come from HBM at least once, however
+ * well the order keeps the re-reads in the L2.  Level = characters of the k-mer already consumed when the step is taken.
+ */
+constexpr unsigned kTouchLevels = 32;
+struct OrderTouch {
+  unsigned long long *seedLines; /* bit per 128-B line of the index's seed table */
+  unsigned long long *deepLines; /* ... of the deeper device-only table */
+  unsigned long long *pairLines; /* [level][pairWords]: bit per pair block (one line each) */
+  unsigned long long *nucLines;  /* [level][nucWords]: bit per line of the one-letter image (two 64-B blocks) */
+  unsigned long long pairWords, nucWords;
+  unsigned long long *hits; /* k-mers that stored a result */
+};
+
+template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false>
 __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? (PAIR && !NARROW ? 6 : 8) : 2, 8)))
     orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
                         const unsigned long long numRecs,
                         const unsigned *__restrict__ generalCount, const unsigned len, const unsigned depth,
                         const ulonglong2 *__restrict__ table, ulonglong2 *__restrict__ ranges,
-                        unsigned *__restrict__ counts, unsigned *__restrict__ tickets, const int xcdMap = 0) {
+                        unsigned *__restrict__ counts, unsigned *__restrict__ tickets, const int xcdMap = 0,
+                        const OrderTouch touch = OrderTouch(), const unsigned *__restrict__ bucketStart = nullptr,
+                        const BucketFormat bucketFmt = BucketFormat()) {
+  static_assert(!BUCKET || (COMPACT && !VARLEN), "bucketed records are the 8-byte records of fixed-length batches");
   constexpr int S = (int)kSlices / G;
   typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
@@ -240,7 +465,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   auto readRecord = [&](unsigned long long at, Raw &r) {
     if (COMPACT) {
       r.a = ((const unsigned long long *)recs)[at];
-      r.keyWord = ((const unsigned *)keys)[at >> 1];
+      if (!BUCKET) r.keyWord = ((const unsigned *)keys)[at >> 1];
     } else {
       const ulonglong2 w = *(const ulonglong2 *)((const QueryRec *)recs + at);
       r.a = w.x;
@@ -249,6 +474,24 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   };
   const unsigned gl = threadIdx.x % G;
   const unsigned firstSlice = gl * S;
+  auto markLine = [&](unsigned long long *bits, unsigned long long line) {
+    if (TOUCH && gl == 0) atomicOr(bits + (line >> 6), 1ull << (line & 63ull));
+  };
+  /* the lines a one-letter step / a pair step from the range {sp, ep} reads */
+  auto touchNuc = [&](unsigned level, unsigned long long sp, unsigned long long ep) {
+    if (TOUCH) {
+      unsigned long long *bits = touch.nucLines + (level < kTouchLevels ? level : kTouchLevels - 1u) * touch.nucWords;
+      markLine(bits, ((sp - 1ull) >> kBlockShift) >> 1);
+      markLine(bits, (ep >> kBlockShift) >> 1);
+    }
+  };
+  auto touchPair = [&](unsigned level, unsigned long long sp, unsigned long long ep) {
+    if (TOUCH) {
+      unsigned long long *bits = touch.pairLines + (level < kTouchLevels ? level : kTouchLevels - 1u) * touch.pairWords;
+      markLine(bits, (sp - 1ull) >> kBlockShift);
+      markLine(bits, ep >> kBlockShift);
+    }
+  };
   /* the records the fast path covers come first in the order; each XCD takes a contiguous eighth of them */
   const unsigned long long covered = numRecs - (unsigned long long)*generalCount;
   const unsigned xcds = (gridDim.x & 7u) == 0u && xcdMap != 2 ? 8u : 1u;
@@ -287,15 +530,47 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   const unsigned long long tableMask = (1ull << (2u * depth)) - 1ull;
   Raw raw = {0ull, 0ull, 0u}; /* the prefetched record */
   if (base + lane / G < end) readRecord(base + lane / G, raw);
+  /* BUCKET: a record does not hold the bits its bucket stands for; the bucket of a position is where bucketStart says.
+   * The wave keeps the bucket of its current chunk (its chunks come in increasing order): wave-uniform, scalar loads. */
+  const unsigned numBuckets = BUCKET ? 1u << bucketFmt.bucketBits : 0u;
+  unsigned waveBucket = 0, waveNext = 0;
+  if (BUCKET && base < end) {
+    unsigned lo = 0, hi = numBuckets - 1u; /* the last bucket that starts at or before `base` */
+    while (lo < hi) {
+      const unsigned mid = (lo + hi + 1u) >> 1;
+      if ((unsigned long long)bucketStart[mid] <= base) lo = mid;
+      else hi = mid - 1u;
+    }
+    waveBucket = lo;
+    waveNext = bucketStart[lo + 1u];
+  }
   while (base < end) { /* wave-uniform */
     const unsigned long long q = base + lane / G;
     const bool live = q < end;
+    unsigned myBucket = 0;
+    if (BUCKET) {
+      while ((unsigned long long)waveNext <= base && waveBucket + 1u < numBuckets) {
+        waveBucket++;
+        waveNext = bucketStart[waveBucket + 1u];
+      }
+      myBucket = waveBucket;
+      unsigned nb = waveBucket, ns = waveNext; /* the chunk may reach into the following bucket(s) */
+      while ((unsigned long long)ns <= base + (kChunk - 1u) && nb + 1u < numBuckets) {
+        nb++;
+        myBucket = q >= (unsigned long long)ns ? nb : myBucket;
+        ns = bucketStart[nb + 1u];
+      }
+    }
     /* the record fetched an iteration ago is taken apart BEFORE anything new is issued: a wait placed after the
      * atomic below would also wait for that atomic */
     asm volatile("" : "+v"(raw.a), "+v"(raw.b), "+v"(raw.keyWord)::"memory");
     const unsigned key = (raw.keyWord >> (16u * (unsigned)(q & 1ull))) & 0xFFFFu;
-    const unsigned long long codes = COMPACT ? orderCodes(format, key, (unsigned)(raw.a >> 32)) : raw.a;
-    const unsigned index = COMPACT ? (unsigned)raw.a : (unsigned)raw.b;
+    const unsigned long long codes = BUCKET    ? bucketCodes(bucketFmt, myBucket, raw.a >> bucketFmt.indexBits)
+                                     : COMPACT ? orderCodes(format, key, (unsigned)(raw.a >> 32))
+                                               : raw.a;
+    const unsigned index = BUCKET    ? (unsigned)(raw.a & ((1ull << bucketFmt.indexBits) - 1ull))
+                           : COMPACT ? (unsigned)raw.a
+                                     : (unsigned)raw.b;
     const unsigned myLen = VARLEN ? (unsigned)(raw.b >> 32) : len; /* before `raw` is overwritten by the prefetch */
     /* ---- seed (ref src/AwFmKmerTable.c:4-51): the index table, or the deeper device-only one ---- */
     pos_t sp = 1, ep = 0;
@@ -305,6 +580,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     /* fixed length: the table entry is requested FIRST, so that the wait for it (loads return in order) is not also a
      * wait for the ticket atomic and the record prefetch issued below */
     if (!VARLEN && live) entry = table[codes & tableMask];
+    if (TOUCH && !VARLEN && live) markLine(table == ix.seed ? touch.seedLines : touch.deepLines, (codes & tableMask) >> 3);
     /* draw the ticket after next (consumed at the bottom), fetch the next chunk's record */
     if (lane == 0) drawn = atomicAdd(ticket, 1u);
     if (baseNext + lane / G < end) readRecord(baseNext + lane / G, raw);
@@ -323,6 +599,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
         if (myDepth != 0u) {
           const ulonglong2 *from = myDepth == ix.seedK ? ix.seed : ix.deepSeed;
           const ulonglong2 r = from[codes & ((1ull << (2u * myDepth)) - 1ull)];
+          if (TOUCH) markLine(myDepth == ix.seedK ? touch.seedLines : touch.deepLines, (codes & ((1ull << (2u * myDepth)) - 1ull)) >> 3);
           sp = (pos_t)r.x;
           ep = (pos_t)r.y;
           pos = (int)(myLen - myDepth) - 1;
@@ -337,36 +614,46 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     }
 
     /* ---- extension (ref src/AwFmParallelSearch.c:273-313) ---- */
+    const int lastPos = (int)myLen - 1; /* TOUCH: level of a step = lastPos - pos = characters consumed before it */
     if (PAIR) {
       /* two characters per block read.  Only hits are reported, so it does not matter at which of the two steps a
        * range without hits became empty.  An odd step is taken alone: first in a mixed-length batch (one divergent
        * round), last in a fixed-length one (where it is wave-uniform and few k-mers are still alive). */
       if (VARLEN && pos >= 0 && sp <= ep && (pos & 1) == 0) {
+        touchNuc((unsigned)(lastPos - pos), sp, ep);
         nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
         pos--;
         rem >>= 2;
       }
       while (pos >= 1 && sp <= ep) {
         const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
+        touchPair((unsigned)(lastPos - pos), sp, ep);
         if (pairSearchStep<NARROW>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep) == kPairFlagged) {
           /* a block with an ambiguity letter or the sentinel: letter by letter through the one-letter image */
+          touchNuc((unsigned)(lastPos - pos), sp, ep);
           nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
-          if (sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
+          if (sp <= ep) {
+            touchNuc((unsigned)(lastPos - pos) + 1u, sp, ep);
+            nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
+          }
         }
         pos -= 2;
         rem >>= 4;
       }
       if (!VARLEN && pos == 0 && sp <= ep) {
+        touchNuc((unsigned)(lastPos - pos), sp, ep);
         nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
         pos--;
       }
     } else {
       while (pos >= 0 && sp <= ep) {
+        touchNuc((unsigned)(lastPos - pos), sp, ep);
         nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
         pos--;
         rem >>= 2;
       }
     }
+    if (TOUCH && live && gl == 0 && sp <= ep) atomicAdd(touch.hits, 1ull);
     if (live && gl == 0 && sp <= ep) {
       if (ranges) ranges[index] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
       if (counts) counts[index] = (unsigned)(ep - sp + (pos_t)1);

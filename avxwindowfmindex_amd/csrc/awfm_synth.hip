@@ -73,9 +73,98 @@ __global__ void synthMixedQueriesKernel(unsigned char *out, const u64 *offsets, 
     }
   }
 }
+
+/*
+ * Genome-shaped text (avxwindowfmindex_amd/synth.py: genome_text): what a uniform text lacks and an assembly like GRCh38
+ * has -- interspersed repeat families, tandem repeats, long runs of N.  Character i is a pure function of (seed, i, n):
+ * the text is cut into blocks of 1024 characters, and a block is, by its hash,
+ *   10 %  a window into the endless repetition of a 300-character consensus (a short interspersed family: about
+ *         n / 3000 copies), every character replaced by a random one with probability 10 %,
+ *   15 %  a window of a 6000-character consensus at a random offset (a long family, cut copies), 5 % divergence,
+ *    3 %  a tandem repeat of a unit of 2..64 characters of its own, 2 % divergence,
+ *   72 %  unique sequence (the characters of the uniform text of the same seed);
+ * on top, 24 runs of 'n' with seeded starts and lengths between n/6400 and n/64 (at most 10^5 .. 10^7 characters).
+ */
+constexpr unsigned kGenomeBlock = 1024, kGenomeRuns = 24;
+constexpr u64 kSaltBlock = 0xB10C5A17ull, kSaltFamA = 0xFA111A5ull, kSaltFamB = 0xFA111B5ull, kSaltDiv = 0xD17E26E5ull,
+              kSaltRunStart = 0x52554E53ull, kSaltRunLen = 0x52554E4Cull;
+
+__device__ __forceinline__ unsigned char genomeChar(u64 i, u64 n, u64 seed, const u64 *runStart, const u64 *runLen) {
+  for (unsigned r = 0; r < kGenomeRuns; r++)
+    if (i - runStart[r] < runLen[r]) return 'n';
+  const u64 b = i / kGenomeBlock, j = i % kGenomeBlock;
+  const u64 hb = mix64(seed + kSaltBlock + (b + 1ull) * kGolden);
+  const unsigned kind = (unsigned)(hb % 100ull);
+  const u64 pick = hb >> 8;
+  unsigned char base;
+  unsigned permille;
+  if (kind < 10u) {
+    base = kDna[mix64(seed + kSaltFamA + ((pick + j) % 300ull + 1ull) * kGolden) % 4ull];
+    permille = 100u;
+  } else if (kind < 25u) {
+    base = kDna[mix64(seed + kSaltFamB + ((pick + j) % 6000ull + 1ull) * kGolden) % 4ull];
+    permille = 50u;
+  } else if (kind < 28u) {
+    const u64 unit = 2ull + pick % 63ull;
+    base = kDna[mix64(hb + (j % unit + 1ull) * kGolden) % 4ull];
+    permille = 20u;
+  } else {
+    return kDna[mix64(seed + (i + 1ull) * kGolden) % 4ull];
+  }
+  const u64 r = mix64(seed + kSaltDiv + (i + 1ull) * kGolden);
+  return (unsigned)(r % 1000ull) < permille ? kDna[(r >> 16) % 4ull] : base;
+}
+
+__global__ void synthGenomeTextKernel(unsigned char *out, u64 n, u64 seed) {
+  __shared__ u64 runStart[kGenomeRuns], runLen[kGenomeRuns];
+  if (threadIdx.x < kGenomeRuns) {
+    u64 longest = n / 64ull < 10000000ull ? n / 64ull : 10000000ull;
+    if (longest < 1ull) longest = 1ull;
+    u64 shortest = longest / 100ull < 100000ull ? longest / 100ull : 100000ull;
+    if (shortest < 1ull) shortest = 1ull;
+    runStart[threadIdx.x] = mix64(seed + kSaltRunStart + threadIdx.x) % n;
+    runLen[threadIdx.x] = shortest + mix64(seed + kSaltRunLen + threadIdx.x) % (longest - shortest + 1ull);
+  }
+  __syncthreads();
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = genomeChar(i, n, seed, runStart, runLen);
+}
+
+/* k-mers copied from the text like synthPlantedQueriesKernel, but a character that is not a,c,g,t (the 'n' of a
+ * genome-shaped text) is replaced by a seeded random letter: a read has no 21 N in a row, and a k-mer of N would match
+ * every window of every N run */
+__global__ void synthPlantedCleanKernel(unsigned char *out, u64 first, u64 count, unsigned length, u64 seedQ,
+                                        const unsigned char *text, u64 n) {
+  const u64 total = count * length, stride = (u64)gridDim.x * blockDim.x;
+  for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const u64 j = t / length, c = t % length;
+    const u64 q = mix64(seedQ + first + j);
+    const u64 offset = mix64(q + kGolden) % (n - length + 1ull);
+    const unsigned char ch = text[offset + c];
+    const bool plain = ch == 'a' || ch == 'c' || ch == 'g' || ch == 't';
+    out[t] = plain ? ch : kDna[mix64(q + (c + 2ull) * kGolden) % 4ull];
+  }
+}
 }  // namespace
 
 extern "C" {
+
+enum AwFmReturnCode awfmGpuSynthGenomeText(uint8_t *dOut, uint64_t length, uint64_t seed, void *stream) {
+  if (!dOut) return AwFmNullPtrError;
+  if (length == 0) return AwFmSuccess;
+  hipLaunchKernelGGL(synthGenomeTextKernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, dOut, (u64)length, (u64)seed);
+  return hipGetLastError() == hipSuccess ? AwFmSuccess : AwFmGeneralFailure;
+}
+
+enum AwFmReturnCode awfmGpuSynthPlantedQueriesClean(uint8_t *dOut, uint64_t first, uint64_t count, uint32_t length,
+                                                    uint64_t seedQ, const uint8_t *dText, uint64_t textLength, void *stream) {
+  if (!dOut || !dText) return AwFmNullPtrError;
+  if (count == 0 || length == 0) return AwFmSuccess;
+  if (textLength < length) return AwFmIllegalPositionError;
+  hipLaunchKernelGGL(synthPlantedCleanKernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, dOut, (u64)first, (u64)count,
+                     length, (u64)seedQ, dText, (u64)textLength);
+  return hipGetLastError() == hipSuccess ? AwFmSuccess : AwFmGeneralFailure;
+}
 
 enum AwFmReturnCode awfmGpuSynthMixedLengths(uint64_t *dLengths, uint64_t first, uint64_t count, uint32_t lo,
                                              uint32_t hi, uint64_t seedQ, void *stream) {

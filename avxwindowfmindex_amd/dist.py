@@ -21,19 +21,53 @@ def shard_bounds(total, world, rank):
     return begin, min(total, begin + per)
 
 
+_TIMING_GROUP = None   # the group the barrier and the MAX reduction run on (None: the default group)
+_TIMING_BACKEND = None  # "nccl" | "gloo" once initialised with world > 1
+
+
+def timing_backend():
+    return _TIMING_BACKEND
+
+
 def init(backend):
-    """initialise torch.distributed when launched with WORLD_SIZE > 1; returns (rank, world)"""
+    """initialise torch.distributed when launched with WORLD_SIZE > 1; returns (rank, world).
+
+    The default group is always gloo (TCP on 127.0.0.1: it cannot fail for GPU reasons).  With backend "nccl" an RCCL
+    group over the same ranks is tried next -- created, exercised with one all-reduce under a timeout, and adopted for
+    the barrier / MAX reduction only if EVERY rank says it worked (agreement over gloo); otherwise all ranks stay on
+    gloo, in this same process (nothing is re-executed).  The data path has no collective either way."""
+    global _TIMING_GROUP, _TIMING_BACKEND
     import torch.distributed as dist
     rank, world, local_rank = env_world()
     if world > 1 and not dist.is_initialized():
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        kwargs = {}
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=1800))
+        _TIMING_BACKEND = "gloo"
         if backend == "nccl":
             import torch
-            torch.cuda.set_device(local_rank)
-            kwargs["device_id"] = torch.device("cuda", local_rank)
-        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+            ok, why = 1, ""
+            try:
+                # errors and time-outs of the trial all-reduce must surface as exceptions here, not abort the process
+                os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")
+                torch.cuda.set_device(local_rank)
+                group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+                probe = torch.ones(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe, group=group)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    ok, why = 0, f"trial all-reduce returned {probe.item()}"
+            except Exception as e:  # noqa: BLE001 -- anything RCCL / HIP raises: fall back
+                ok, why = 0, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # over gloo
+            if int(flag.item()) == 1:
+                _TIMING_GROUP, _TIMING_BACKEND = group, "nccl"
+            elif rank == 0 or not ok:
+                import sys
+                sys.stderr.write(f"[dist] rank {rank}: RCCL group not usable ({why or 'another rank failed'}); "
+                                 "barrier and MAX reduction stay on gloo\n")
     return rank, world
 
 
@@ -42,7 +76,7 @@ def barrier(world, sync=None):
     if sync is not None:
         sync()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=_TIMING_GROUP)
     if sync is not None:
         sync()
 
@@ -53,9 +87,42 @@ def max_over_ranks(value, world, device="cpu"):
         return value
     import torch
     import torch.distributed as dist
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = torch.tensor([value], dtype=torch.float64, device=device if _TIMING_BACKEND == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_TIMING_GROUP)
     return float(t.item())
+
+
+def gather_objects(obj, world):
+    """every rank's python object, in rank order (over the gloo default group; verification, not on the timed path)"""
+    if world == 1:
+        return [obj]
+    import torch.distributed as dist
+    parts = [None] * world
+    dist.all_gather_object(parts, obj)
+    return parts
+
+
+def balanced_bounds(prefix_weights, world, rank):
+    """contiguous shard [begin, end) of items whose weights have the inclusive-exclusive prefix sums `prefix_weights`
+    (len n+1, prefix_weights[0] == 0): cut where the running weight passes rank/world of the total, so that shards of a
+    batch of unequal items (mixed-length k-mers: work grows with length) finish together"""
+    n = len(prefix_weights) - 1
+    total = int(prefix_weights[-1])
+    if type(prefix_weights).__module__.startswith("torch"):  # a torch tensor (bench.py keeps the 10^8 lengths on the GPU)
+        import torch
+
+        def find(v):
+            return int(torch.searchsorted(prefix_weights, torch.tensor([v], dtype=prefix_weights.dtype,
+                                                                       device=prefix_weights.device)).item())
+    else:
+        import numpy as np
+
+        def find(v):
+            return int(np.searchsorted(prefix_weights, v, side="left"))
+
+    def cut(r):
+        return 0 if r <= 0 else (n if r >= world else min(find((total * r) // world), n))
+    return cut(rank), cut(rank + 1)
 
 
 def gather_counts(local, world):

@@ -40,6 +40,63 @@ def text(seed, n, alphabet=DNA_ALPHABET, start=0):
     return lut[(stream(seed, start, n) % np.uint64(len(alphabet))).astype(np.int64)]
 
 
+GENOME_BLOCK, GENOME_RUNS = 1024, 24
+_SALT_BLOCK, _SALT_FAM_A, _SALT_FAM_B, _SALT_DIV = 0xB10C5A17, 0xFA111A5, 0xFA111B5, 0xD17E26E5
+_SALT_RUN_START, _SALT_RUN_LEN = 0x52554E53, 0x52554E4C
+
+
+def genome_runs(seed, n):
+    """(starts, lengths) of the 24 runs of 'n' of genome_text(seed, n)"""
+    longest = max(1, min(n // 64, 10_000_000))
+    shortest = max(1, min(longest // 100, 100_000))
+    r = np.arange(GENOME_RUNS, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        starts = mix64(np.uint64(seed) + np.uint64(_SALT_RUN_START) + r) % np.uint64(n)
+        lengths = np.uint64(shortest) + mix64(np.uint64(seed) + np.uint64(_SALT_RUN_LEN) + r) % np.uint64(longest - shortest + 1)
+    return starts, lengths
+
+
+def genome_text(seed, n):
+    """genome-shaped nucleotide text (csrc/awfm_synth.hip synthGenomeTextKernel computes the same characters): blocks of
+    1024 characters that are, by their hash, a window into a 300-character family consensus repeated end to end (10 % of
+    the blocks, 10 % divergence), a window of a 6000-character consensus (15 %, 5 %), a tandem repeat of a unit of 2..64
+    characters (3 %, 2 %) or unique sequence (72 %: the characters of text(seed, n)); 24 runs of 'n' on top"""
+    lut = np.frombuffer(DNA_ALPHABET, dtype=np.uint8)
+    i = np.arange(n, dtype=np.uint64)
+    b, j = i // np.uint64(GENOME_BLOCK), i % np.uint64(GENOME_BLOCK)
+    with np.errstate(over="ignore"):
+        s = np.uint64(seed)
+        hb = mix64(s + np.uint64(_SALT_BLOCK) + (b + np.uint64(1)) * GOLDEN)
+        kind = hb % np.uint64(100)
+        pick = hb >> np.uint64(8)
+        fam_a = mix64(s + np.uint64(_SALT_FAM_A) + ((pick + j) % np.uint64(300) + np.uint64(1)) * GOLDEN) % np.uint64(4)
+        fam_b = mix64(s + np.uint64(_SALT_FAM_B) + ((pick + j) % np.uint64(6000) + np.uint64(1)) * GOLDEN) % np.uint64(4)
+        unit = np.uint64(2) + pick % np.uint64(63)
+        tandem = mix64(hb + (j % unit + np.uint64(1)) * GOLDEN) % np.uint64(4)
+        unique = mix64(s + (i + np.uint64(1)) * GOLDEN) % np.uint64(4)
+        r = mix64(s + np.uint64(_SALT_DIV) + (i + np.uint64(1)) * GOLDEN)
+    base = np.where(kind < 10, fam_a, np.where(kind < 25, fam_b, tandem))
+    permille = np.where(kind < 10, 100, np.where(kind < 25, 50, 20)).astype(np.uint64)
+    base = np.where(r % np.uint64(1000) < permille, (r >> np.uint64(16)) % np.uint64(4), base)
+    out = lut[np.where(kind < 28, base, unique).astype(np.int64)]
+    starts, lengths = genome_runs(seed, n)
+    for st, ln in zip(starts.tolist(), lengths.tolist()):
+        out[st:min(n, st + ln)] = ord("n")
+    return out
+
+
+def planted_queries_clean(seed_q, count, length, txt, first=0):
+    """planted_queries with every character that is not a,c,g,t replaced by a seeded random letter"""
+    q = planted_queries(seed_q, count, length, txt, first).copy()
+    lut = np.frombuffer(DNA_ALPHABET, dtype=np.uint8)
+    state = _qstate(seed_q, first, count)[:, None]
+    with np.errstate(over="ignore"):
+        z = mix64(state + (np.arange(2, length + 2, dtype=np.uint64) * GOLDEN)[None, :])
+    plain = np.isin(q, lut)
+    q[~plain] = lut[(z % np.uint64(4)).astype(np.int64)][~plain]
+    return q
+
+
 def _qstate(seed_q, first, count):
     with np.errstate(over="ignore"):
         return mix64(np.uint64(seed_q) + np.arange(first, first + count, dtype=np.uint64))

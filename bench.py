@@ -8,17 +8,26 @@ awFmParallelSearchLocate (ref src/AwFmParallelSearch.c:95-157).
 
 Workload (BASELINE.json configs[2]): 100 M uniform random 21-mers, locate, index of a 3.1 Gbp
 uniform synthetic text, SA compression 8, seed table k=12, one index replica per GPU, the query
-batch sharded over the ranks with no collective (weak scaling: every rank has its own 100 M batch).
-`--workload planted` runs the secondary case (k-mers drawn from the text, >=1 hit each).
+batch sharded over the ranks with no collective.  --scaling weak (default): every rank has its own
+100 M k-mers of a 100 M x N batch; --scaling strong: ONE batch of --queries k-mers cut into N contiguous
+shards (configs[2] as written: "query batch sharded 1->8").  `--workload planted` runs the secondary
+case (k-mers drawn from the text, >=1 hit each), `--workload mixed` configs[4] (8..30-mers; shards
+balanced by the sum of the lengths).
 
 The JSON line also carries
-  roofline     -- the search call (all of its kernels; the dominant one is timed separately):
-                  algorithmic bytes (bytes_count = L + 16 t + 104 D + 16 per query,
-                  D/t/L tallied on the device by an instrumented run of the general kernel) / mean
-                  time from HIP events on the launch stream, against the 8 TB/s HBM peak;
-  cpu_baseline -- the CPU oracle (a port of the reference's OpenMP 8-query lock-step driver) timed
-                  on this box's host cores on a bounded sample of the same queries, after checking
-                  that its results equal the GPU's on that sample.
+  roofline         -- the dominant kernel.  Seed-order path: COMPULSORY bytes of orderedSearchKernel (distinct
+                      128-B lines per search level, tallied on the device by an instrumented launch, plus records
+                      read and results stored) / that kernel's HIP-event time, against the 8 TB/s HBM peak; the
+                      L2-side figures and the whole call (encode + sort + search) priced by the reference
+                      algorithm's bytes are beside it, the latter NOT as a roofline fraction.
+                      General kernel: algorithmic bytes (L + 16 t + 104 D + 16 per query) / HIP-event time.
+  roofline_general -- the exact-range general kernel (awfmGpuSearch) on the same batch: the HBM-bound kernel
+                      north_star describes, priced by the algorithmic bytes;
+  cpu_baseline     -- the CPU oracle (a port of the reference's OpenMP 8-query lock-step driver) timed
+                      on this box's host cores on a bounded sample of the same queries, after checking
+                      that its results equal the GPU's on that sample;
+  digests          -- additive digests of every rank's counts / positions, checked against the committed
+                      digests of the 1-rank run (tests/golden/bench_digests.json).
 """
 import argparse
 import json
@@ -30,7 +39,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L2_GATHER_PEAK_GBS = 17800.0  # MI355X_MICROARCH.md "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCDs' L2s
 RANK_BYTES_DNA, RANK_BYTES_AMINO = 104, 168  # planes + one count of the reference block
+PROFILE_ROUND = "r3"
 
 
 def parse():
@@ -40,27 +51,38 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", choices=["random", "planted", "mixed"], default="random")
     p.add_argument("--mode", choices=["locate", "count"], default="locate")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                   help="weak: --queries k-mers per GPU; strong: --queries k-mers in total, cut into --gpus shards")
     count = lambda v: int(float(v))  # noqa: E731  ("3e6" is accepted)
     p.add_argument("--text-len", type=count, default=None, help="default 3.1e9 (dna) / 2e8 (amino)")
-    p.add_argument("--queries", type=count, default=None, help="k-mers per GPU per step; default 1e8 (dna) / 5e7 (amino)")
+    p.add_argument("--queries", type=count, default=None, help="k-mers per GPU per step (strong: in total); default 1e8 (dna) / 5e7 (amino)")
+    p.add_argument("--query-offset", type=count, default=0,
+                   help="global number of the batch's first k-mer (a 1-GPU run can stand in for a later shard: digests)")
     p.add_argument("--kmer", type=int, default=None, help="default 21 (dna) / 10 (amino)")
     p.add_argument("--seed-k", type=int, default=None, help="default 12 (dna) / 5 (amino)")
     p.add_argument("--sa-ratio", type=int, default=8)
     p.add_argument("--alphabet", choices=["dna", "amino"], default="dna")
+    p.add_argument("--text", choices=["uniform", "repetitive"], default="uniform",
+                   help="repetitive: a genome-shaped text (repeat families, tandem repeats, runs of N; synth.py)")
     p.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-e2e", action="store_true", help="skip the host-inclusive end_to_end leg")
     p.add_argument("--no-secondary", action="store_true", help="skip the planted (every k-mer has a hit) line of the default run")
+    p.add_argument("--general-steps", type=int, default=3,
+                   help="timed steps of the exact-range general kernel for roofline_general (0: skip)")
     p.add_argument("--e2e-aos-queries", type=count, default=10_000_000,
                    help="k-mers of the batch that also go through the drop-in AoS entry point (0: skip)")
-    p.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (gloo: several ranks on one GPU, testing)")
+    p.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; falls back to gloo in-process when it cannot be set up) | gloo")
     p.add_argument("--force-device", type=int, default=-1, help="testing: every rank uses this GPU")
     p.add_argument("--device-dense-sa", action="store_true",
                    help="optional device-only full suffix array (same positions, a locate becomes one gather)")
-    p.add_argument("--device-seed-k", type=int, default=0,
-                   help="optional device-only deeper seed table (same results, fewer block reads); 0 = the index's own table")
+    p.add_argument("--device-seed-k", type=int, default=-1,
+                   help="device-only deeper seed table (same results, fewer block reads): -1 = the library's default for "
+                        "the image, 0 = none, k = that depth")
     p.add_argument("--dump-dir", default=None,
                    help="testing: every rank writes its shard's counts / hit offsets / positions to <dir>/rank<r>.npz")
+    p.add_argument("--record-digests", default=None,
+                   help="append this run's per-shard digests to the JSON file (how tests/golden/bench_digests.json is made)")
     return p.parse_args()
 
 
@@ -70,26 +92,54 @@ def launch_ranks(args):
     The parent never touches the GPU (no HIP call, no torch.cuda call before or after the spawn): it only
     starts one child per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON
     line and fails if any rank failed.  Ranks are independent (index replica per GPU, contiguous query
-    shards, ref src/AwFmParallelSearch.c:103-129: 8-query blocks are independent), so nothing else is shared."""
+    shards, ref src/AwFmParallelSearch.c:103-129: 8-query blocks are independent), so nothing else is shared.
+    All children are polled: the first one that fails takes the others down (they would otherwise sit in the
+    rendezvous until its time-out), and none outlives the parent."""
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+    out_file = tempfile.TemporaryFile()
+    try:
+        for r in range(args.gpus):
+            # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; RCCL's intra-node
+            # transport (hipIpcGetMemHandle) fails with "invalid argument" without it.  The image exports it already;
+            # it is repeated here so that a caller's scrubbed environment does not break the N > 1 runs.
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out_file if r == 0 else subprocess.DEVNULL))
+        codes = [None] * len(procs)
+        failed_at = None
+        while any(c is None for c in codes):
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    codes[i] = p.poll()
+            if failed_at is None and any(c not in (None, 0) for c in codes):
+                failed_at = time.time()
+                for i, p in enumerate(procs):
+                    if codes[i] is None:
+                        p.terminate()
+            if failed_at is not None and time.time() - failed_at > 10.0:
+                for i, p in enumerate(procs):
+                    if codes[i] is None:
+                        p.kill()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    out_file.seek(0)
+    out = out_file.read().decode()
+    sys.stdout.write(out)
     sys.stdout.flush()
     if any(codes):
         sys.stderr.write(f"bench.py: rank exit codes {codes}\n")
         sys.exit(1)
-    lines = [ln for ln in out.decode().splitlines() if ln.startswith("{")]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     if not lines or json.loads(lines[-1]).get("n_gpus") != args.gpus:
         sys.stderr.write("bench.py: rank 0 did not report n_gpus == --gpus\n")
         sys.exit(1)
@@ -174,6 +224,11 @@ def end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, a
     return out
 
 
+def profile_file(kind, name):
+    path = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"{kind}_{name}.json")
+    return (json.load(open(path)), f"profiles/{PROFILE_ROUND}/{kind}_{name}.json") if os.path.exists(path) else (None, None)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -181,7 +236,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from avxwindowfmindex_amd import _lib, api
+    from avxwindowfmindex_amd import _lib, api, digest
     from avxwindowfmindex_amd import dist as shard
 
     if args.force_device >= 0:
@@ -189,8 +244,8 @@ def main():
     rank, world = shard.init(args.dist_backend)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: the line would misreport n_gpus")
-    if world == 1 or args.dist_backend != "nccl":
-        torch.cuda.set_device(max(args.force_device, 0) if world > 1 else 0)
+    _, _, local_rank = shard.env_world()
+    torch.cuda.set_device(local_rank if world > 1 else max(args.force_device, 0))
     dev = torch.device("cuda", torch.cuda.current_device())
     L = _lib.lib()
     amino = args.alphabet == "amino"
@@ -200,23 +255,29 @@ def main():
                                              ("kmer", 21, 10), ("seed_k", 12, 5)):
         if getattr(args, name) is None:
             setattr(args, name, amino_default if amino else dna_default)
-    n, Q, K = args.text_len, args.queries, args.kmer
+    n, K = args.text_len, args.kmer
+    if args.text == "repetitive" and args.workload == "planted":
+        args.mode = "count"  # a 21-mer out of a 300-character family with 10^6 copies has ~10^5 hits: 10^8 of them have 10^12
     if args.workload == "mixed":
-        args.mode = "count"  # 8..11-mers have ~10^4..10^5 hits each: the hit list of 10^8 of them does not fit any memory
+        args.mode = "count"  # 8..11-mers have ~10^4..10^5 hits each: the hit list of 10^8 of them is a budgeted locate (tests), not a bench step
     text_seed = 4 if amino else 2
     query_seed = 104 if amino else {"random": 102, "planted": 103, "mixed": 105}[args.workload]
 
     # ---- index replica on this GPU (text generated and indexed on the device) ----
     t0 = time.time()
     d_text = torch.empty(n, dtype=torch.uint8, device=dev)
-    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, text_seed, int(amino), None) == 1
+    if args.text == "repetitive":
+        assert not amino, "--text repetitive is a nucleotide text"
+        assert L.awfmGpuSynthGenomeText(d_text.data_ptr(), n, text_seed, None) == 1
+    else:
+        assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, text_seed, int(amino), None) == 1
     torch.cuda.synchronize()
     ix = api.gpu_create_index(d_text.data_ptr(), alpha, args.sa_ratio, args.seed_k, on_device_length=n,
                               device=dev.index)
     g = api.GpuIndex(ix, acquire=True)
     build_s = time.time() - t0
     deep_s = 0.0
-    if args.device_seed_k:
+    if args.device_seed_k >= 0:
         t1 = time.time()
         g.set_deep_seed(args.device_seed_k)
         torch.cuda.synchronize()
@@ -229,7 +290,25 @@ def main():
         dense_s = time.time() - t1
 
     # ---- this rank's query shard, resident in HBM ----
-    first, _ = shard.shard_bounds(Q * world, world, rank)  # weak scaling: the global batch is Q*world k-mers
+    # weak: the global batch is --queries x world k-mers and rank r has k-mers [r Q, (r+1) Q); strong: the global batch
+    # is --queries k-mers cut into `world` contiguous shards (mixed lengths: cut where the running sum of the lengths
+    # passes r/world of the total, so the shards carry equal work)
+    if args.scaling == "weak":
+        Q, batch_total = args.queries, args.queries * world
+        first = args.query_offset + rank * Q
+    else:
+        batch_total = args.queries
+        if args.workload == "mixed" and world > 1:
+            d_all = torch.empty(batch_total, dtype=torch.int64, device=dev)
+            assert L.awfmGpuSynthMixedLengths(d_all.data_ptr(), args.query_offset, batch_total, 8, 30, query_seed, None) == 1
+            prefix = torch.zeros(batch_total + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(d_all, 0, out=prefix[1:])
+            begin, end = shard.balanced_bounds(prefix, world, rank)
+            del d_all, prefix
+        else:
+            begin, end = shard.shard_bounds(batch_total, world, rank)
+        Q, first = end - begin, args.query_offset + begin
+    assert Q > 0, "an empty shard"
     d_offsets = None  # CSR offsets (mixed lengths only); fixed-length batches pass the length instead
     if args.workload == "mixed":
         d_len = torch.empty(Q, dtype=torch.int64, device=dev)
@@ -249,13 +328,16 @@ def main():
     elif args.workload == "random":
         assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr(), first, Q, K, query_seed, int(amino), None) == 1
     else:
-        assert L.awfmGpuSynthPlantedQueries(d_chars.data_ptr(), first, Q, K, query_seed, d_text.data_ptr(), n, None) == 1
+        # k-mers drawn from a text with runs of N get their N replaced: a k-mer of N matches every window of every run
+        plant = L.awfmGpuSynthPlantedQueriesClean if args.text == "repetitive" else L.awfmGpuSynthPlantedQueries
+        assert plant(d_chars.data_ptr(), first, Q, K, query_seed, d_text.data_ptr(), n, None) == 1
     torch.cuda.synchronize()
     off_ptr = d_offsets.data_ptr() if d_offsets is not None else 0
     # the default run also reports the dense-hit case (every k-mer located, ~7 LF steps per hit) beside the headline:
     # its k-mers are drawn from the text now, searched after everything else
     d_planted = None
-    if args.workload == "random" and not amino and world == 1 and not args.no_secondary and args.mode == "locate":
+    if (args.workload == "random" and not amino and world == 1 and not args.no_secondary and args.mode == "locate"
+            and args.text == "uniform"):
         d_planted = torch.empty(Q * K, dtype=torch.uint8, device=dev)
         assert L.awfmGpuSynthPlantedQueries(d_planted.data_ptr(), first, Q, K, 103, d_text.data_ptr(), n, None) == 1
         torch.cuda.synchronize()
@@ -329,9 +411,9 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t_start
-    elapsed = shard.max_over_ranks(elapsed, world, dev if args.dist_backend == "nccl" else "cpu")
+    elapsed = shard.max_over_ranks(elapsed, world, dev)
     ms_per_step = elapsed * 1e3 / args.steps
-    value = world * Q / (elapsed / args.steps) / 1e6  # Mkmers/s over all ranks
+    value = batch_total / (elapsed / args.steps) / 1e6  # Mkmers/s over all ranks
     search_ms = float(np.mean([a.elapsed_time(b) for a, b in search_events]))
     locate_ms = float(np.mean([a.elapsed_time(b) for a, b in locate_events])) if locate_events else 0.0
 
@@ -349,68 +431,174 @@ def main():
             dump["positions"] = state["positions"][: state["hits"]].cpu().numpy().view(np.uint64)
         np.savez(os.path.join(args.dump_dir, f"rank{rank}.npz"), **dump)
 
+    # ---- digests of this rank's results; rank 0 checks all ranks' against the committed digests of the 1-rank run ----
+    kmer_name = "8-30" if args.workload == "mixed" else str(K)
+
+    def describe(f, c):
+        return digest.key(args.alphabet + ("" if args.text == "uniform" else "-" + args.text), args.workload, args.mode, n,
+                          kmer_name, args.seed_k, args.sa_ratio, f, c)
+
+    if args.mode == "count":
+        mine = (first, Q, digest.counts_digest(first, d_counts), None)
+    else:
+        shard_counts = (d_hit_off[1:] - d_hit_off[:-1])
+        mine = (first, Q, digest.counts_digest(first, shard_counts),
+                digest.positions_digest(first, d_hit_off, state["positions"][: max(state["hits"], 1)]))
+        del shard_counts
+    all_digests = shard.gather_objects(mine, world)
+
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
 
+    digest_check = digest.check_against_golden(all_digests, digest.load_golden(), describe)  # raises on a mismatch
+    digest_check["per_rank"] = [{"first": f, "count": c, "counts": f"{dc:016x}", "positions": f"{dp:016x}" if dp is not None else None}
+                                for f, c, dc, dp in all_digests]
+    if args.record_digests:
+        known = json.load(open(args.record_digests)) if os.path.exists(args.record_digests) else {}
+        for f, c, dc, dp in all_digests:
+            known[describe(f, c)] = {"counts": f"{dc:016x}", "positions": f"{dp:016x}" if dp is not None else None}
+        os.makedirs(os.path.dirname(os.path.abspath(args.record_digests)), exist_ok=True)
+        json.dump(known, open(args.record_digests, "w"), indent=1, sort_keys=True)
+
     kdesc = "8..30-mers" if args.workload == "mixed" else f"{K}-mers"
-    # ---- roofline of the dominant kernel: algorithmic bytes / measured kernel time ----
+    # ---- roofline of the dominant kernel ----
     tally = g.search_tally(d_chars.data_ptr(), off_ptr, K, Q)
     rank_bytes = RANK_BYTES_AMINO if amino else RANK_BYTES_DNA
     alg_bytes = tally["chars"] + 16 * tally["seeded"] + rank_bytes * tally["blocks"] + 16 * Q
-    achieved = alg_bytes / (search_ms * 1e-3) / 1e9
+    per_query = {"steps": round(tally["steps"] / Q, 4), "distinct_blocks": round(tally["blocks"] / Q, 4),
+                 "seeded": round(tally["seeded"] / Q, 4), "bytes": round(alg_bytes / Q, 1)}
+    upper_bytes = tally["chars"] + 16 * tally["seeded"] + rank_bytes * 2 * tally["steps"] + 16 * Q
     # Counter-derived figures come from rocprofv3 PMC passes of THIS command line (scripts/profile_bench.sh ->
-    # scripts/collect_profiles.py -> profiles/r2/); a bench run cannot collect them itself, so they are attached only
+    # scripts/collect_profiles.py -> profiles/<round>/); a bench run cannot collect them itself, so they are attached only
     # when the arguments are the profiled ones, and labelled with their source.
     prof_name = None
-    if (not args.device_seed_k and not args.device_dense_sa and not amino and n == 3_100_000_000 and Q == 100_000_000
-            and K == 21 and args.seed_k == 12 and args.sa_ratio == 8 and args.mode == "locate"):
+    if (args.device_seed_k < 0 and not args.device_dense_sa and not amino and n == 3_100_000_000 and Q == 100_000_000
+            and K == 21 and args.seed_k == 12 and args.sa_ratio == 8 and args.mode == "locate" and args.text == "uniform"):
         prof_name = {"random": "default", "planted": "planted"}.get(args.workload)
     if any(k.startswith("AWFM_GPU_") and k not in ("AWFM_GPU_TIME_ORDERED", "AWFM_GPU_DEVICE") for k in os.environ):
         prof_name = None  # a measurement knob is set: the profiled run was of the default code path
-    traffic = counters = None
-    traffic_source = None
-    if prof_name:
-        tpath = os.path.join(ROOT, "profiles", "r2", f"traffic_{prof_name}.json")
-        cpath = os.path.join(ROOT, "profiles", "r2", f"counters_{prof_name}.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
-            traffic_source = (f"profiles/r2/traffic_{prof_name}.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                              "command line on another run of the same code (scripts/profile_bench.sh), not measured by this run")
-        if os.path.exists(cpath):
-            counters = json.load(open(cpath))
-    # The search of a large fixed-length batch is several launches (awfmGpuSearchHits: k-mer
-    # encoding, two radix-sort passes, orderedSearchKernel); `achieved` prices ALL of them (kernel_ms = HIP events
-    # around the call on its stream), the dominant kernel's own time is reported beside it.
-    kernel_name = ("awfmGpuSearchHits: fillNoHitKernel + encodeQueriesKernel + rocprim radix sort (16-bit key) + "
-                   "orderedSearchKernel") if ordered else "searchKernel"
-    # `bound`: the general kernel reads one random block per step from HBM and runs at the rate HBM serves such reads.
-    # The seed-order path turns most of those reads into L2 hits (measured hit rate below): its HBM traffic is a
-    # fraction of the algorithmic bytes, so `frac` -- algorithmic bytes of the reference algorithm per second over the
-    # HBM peak, the figure the contract defines -- can exceed 1 and is NOT an HBM utilisation; `hbm_frac_measured` is.
-    roofline = {
-        "bound": "l2" if ordered else "hbm", "kernel": kernel_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-        "hbm_frac_measured": round(traffic / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
-        "kernel_ms": round(search_ms, 3), "algorithmic_bytes_per_launch": alg_bytes,
-        "per_query": {"steps": round(tally["steps"] / Q, 4), "distinct_blocks": round(tally["blocks"] / Q, 4),
-                      "seeded": round(tally["seeded"] / Q, 4), "bytes": round(alg_bytes / Q, 1)},
-        "upper_bound_variant_GBs": round((tally["chars"] + 16 * tally["seeded"] + rank_bytes * 2 * tally["steps"]
-                                          + 16 * Q) / (search_ms * 1e-3) / 1e9, 1),
-    }
+    not_this_run = "rocprofv3 PMC passes of this command line on another run of the same code (scripts/profile_bench.sh), not measured by this run"
     if ordered:
-        roofline["bound_note"] = ("dominant kernel: L2-served block reads (hit rate in dominant_kernel.l2_hit_rate), waves "
-                                  "waiting on the compulsory HBM misses among them; neither HBM bandwidth nor VALU issue "
-                                  "is near its limit (hbm_frac_measured, dominant_kernel.valu_issue_frac)")
-        roofline["dominant_kernel"] = {"name": "orderedSearchKernel", "ms": round(float(np.mean(ordered_ms)), 3)}
+        # The search of a large batch is several launches (k-mer encoding, key sort, orderedSearchKernel).  The
+        # dominant kernel serves most block reads out of the L2, so the reference algorithm's bytes are not what it
+        # has to move: its roofline is its COMPULSORY traffic -- every 128-B line once per search level that needs
+        # it, the sorted records, the results -- over its own HIP-event time.
+        lines = g.search_hits_line_tally(d_chars.data_ptr(), off_ptr, K, Q)
+        stored = lines["kmers_with_hits"] * ((16 if args.mode == "locate" else 0) + (4 if (args.mode == "count" or (narrow_counts and state["sparse"])) else 0))
+        compulsory = (128 * (lines["seed_table_lines"] + lines["deep_table_lines"] + lines["pair_level_lines"] + lines["nuc_level_lines"])
+                      + lines["record_bytes_per_kmer"] * lines["ordered_kmers"] + stored)
+        dom_ms = float(np.mean(ordered_ms))
+        achieved = compulsory / (dom_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "orderedSearchKernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(dom_ms, 3),
+            "compulsory_bytes": int(compulsory),
+            "compulsory": {"what": "distinct (search level, 128-B line) pairs the kernel reads, tallied on the device by an "
+                                   "instrumented launch of the same kernel on the same sorted batch (awfmGpuSearchHitsLineTally), "
+                                   "x 128 B, + sorted records and keys read + results stored",
+                           **lines, "result_bytes_stored": int(stored)},
+            "limiter": "L2 request path and miss latency, not HBM bandwidth: see `l2` (requests the kernel sends to the "
+                       "L2s against the guide's L2-served gather rate) and dominant_kernel.wave_wait_frac",
+        }
+        counters, csrc = profile_file("counters", prof_name) if prof_name else (None, None)
+        traffic, tsrc = profile_file("traffic", prof_name) if prof_name else (None, None)
+        if counters and "hbm_read_bytes" in counters:
+            roofline["traffic"] = int(counters["hbm_read_bytes"] + counters.get("hbm_write_bytes", 0.0))
+            roofline["traffic_source"] = f"{csrc}: {not_this_run}; reads = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM), writes = WRITE_SIZE"
+            roofline["traffic_over_compulsory"] = round(roofline["traffic"] / compulsory, 3)
+            roofline["hbm_frac_measured"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if counters and "TCC_REQ_sum" in counters.get("raw", {}):
+            req = counters["raw"]["TCC_REQ_sum"]
+            l2_gbs = req * 128 / (dom_ms * 1e-3) / 1e9
+            roofline["l2"] = {"requests": int(req), "requests_per_kmer": round(req / Q, 3), "bytes": int(req * 128),
+                              "achieved": round(l2_gbs, 1), "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(l2_gbs / L2_GATHER_PEAK_GBS, 4),
+                              "source": f"{csrc}: TCC_REQ_sum x 128 B over this run's kernel time; peak = the guide's chip-wide rate "
+                                        "for rows gathered out of the XCDs' L2s (16.8-18.8 TB/s)"}
+        dominant = {"name": "orderedSearchKernel", "ms": round(dom_ms, 3)}
         if counters:
             for key in ("l2_hit_rate", "valu_issue_frac", "wave_wait_frac", "clock_ghz_under_profiler"):
                 if key in counters:
-                    roofline["dominant_kernel"][key] = round(counters[key], 4)
-            roofline["dominant_kernel"]["counters_source"] = (
-                f"profiles/r2/counters_{prof_name}.json (rocprofv3 PMC passes of this command line, another run); "
-                "valu_issue_frac = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), the guide's wave64 issue cost")
+                    dominant[key] = round(counters[key], 4)
+            dominant["counters_source"] = (f"{csrc} ({not_this_run}); valu_issue_frac = SQ_INSTS_VALU x 2 cycles / "
+                                           "(1024 SIMDs x GRBM_GUI_ACTIVE / 8), the guide's wave64 issue cost")
+        roofline["dominant_kernel"] = dominant
+        # the whole call, priced by what the REFERENCE algorithm would move for this batch: a throughput figure in bytes,
+        # not a roofline fraction (five sixths of those bytes never leave the L2)
+        roofline["call"] = {
+            "kernels": "awfmGpuSearchHits: fillNoHitKernel + encodeQueriesKernel + rocprim radix sort (16-bit key) + orderedSearchKernel",
+            "ms": round(search_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes), "per_query": per_query,
+            "unordered_equivalent_GBs": round(alg_bytes / (search_ms * 1e-3) / 1e9, 1),
+            "unordered_equivalent_upper_bound_variant_GBs": round(upper_bytes / (search_ms * 1e-3) / 1e9, 1),
+            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None, "traffic_source": f"{tsrc}: {not_this_run}" if traffic else None,
+        }
+        if traffic:
+            roofline["call"]["hbm_frac_measured"] = round(traffic["hbm_bytes_per_launch"] / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    else:
+        achieved = alg_bytes / (search_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": "searchKernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(search_ms, 3),
+            "algorithmic_bytes_per_launch": int(alg_bytes), "per_query": per_query,
+            "upper_bound_variant_GBs": round(upper_bytes / (search_ms * 1e-3) / 1e9, 1),
+        }
+        gname = "amino" if (amino and n == 200_000_000 and Q == 50_000_000 and K == 10 and args.seed_k == 5) else None
+        if gname and not any(k.startswith("AWFM_GPU_") and k != "AWFM_GPU_DEVICE" for k in os.environ):
+            traffic, tsrc = profile_file("traffic", gname)
+            if traffic:
+                roofline["traffic"] = traffic["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = f"{tsrc}: {not_this_run}"
+                roofline["hbm_frac_measured"] = round(roofline["traffic"] / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+
+    # ---- roofline_general: the exact-range general kernel on the same batch (awfmGpuSearch: every k-mer's final range,
+    # the reference's own stopping rule) -- one random 128-B line per block read, HBM-bound, priced by the algorithmic
+    # bytes.  Its ranges of the k-mers with hits must be the ones the timed steps produced. ----
+    roofline_general = None
+    if ordered and args.general_steps > 0:
+        # priced by the reference algorithm's bytes, so it must execute the reference algorithm's steps: the device-only
+        # deeper table (which answers the first deepK - seedK steps from one entry) is dropped for this measurement
+        had_deep = g.deep_seed_k
+        if had_deep:
+            g.set_deep_seed(0)
+        d_exact = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+        g.search(d_chars.data_ptr(), off_ptr, K, Q, d_exact.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        events = []
+        for _ in range(args.general_steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.search(d_chars.data_ptr(), off_ptr, K, Q, d_exact.data_ptr(), 0, stream)
+            e1.record()
+            events.append((e0, e1))
+        torch.cuda.synchronize()
+        gen_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        if args.mode == "locate":
+            ex = d_exact.view(Q, 2)
+            has = ex[:, 0] <= ex[:, 1]
+            assert int(has.sum().item()) == int((d_hit_off[1:] > d_hit_off[:-1]).sum().item()), "the exact kernel finds other k-mers"
+            assert torch.equal(ex[has], d_ranges.view(Q, 2)[has]), "exact ranges differ from the seed-order path's"
+            del ex, has
+        gen_gbs = alg_bytes / (gen_ms * 1e-3) / 1e9
+        roofline_general = {
+            "bound": "hbm", "kernel": "searchKernel (awfmGpuSearch: exact final range of every k-mer, pair steps)",
+            "achieved": round(gen_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gen_gbs / HBM_PEAK_GBS, 4),
+            "traffic": None, "kernel_ms": round(gen_ms, 3), "steps": args.general_steps,
+            "algorithmic_bytes_per_launch": int(alg_bytes), "per_query": per_query,
+            "Mkmers_per_s": round(Q / gen_ms / 1e3, 1), "seed_table_k": args.seed_k,
+            "checked": "ranges of every k-mer with hits equal the timed steps'" if args.mode == "locate" else None,
+        }
+        if prof_name == "default":
+            traffic, tsrc = profile_file("traffic", "general_pair")
+            if traffic:
+                roofline_general["traffic"] = traffic["hbm_bytes_per_launch"]
+                roofline_general["traffic_source"] = f"{tsrc}: {not_this_run} (AWFM_GPU_ORDERED=0 --mode count)"
+                roofline_general["hbm_frac_measured"] = round(traffic["hbm_bytes_per_launch"] / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        del d_exact
+        if had_deep:
+            g.set_deep_seed(had_deep)
+            torch.cuda.synchronize()
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample, parity-gated ----
     cpu = None
@@ -471,6 +659,19 @@ def main():
             if best is None or dt < best[0]:
                 best = (dt, c)
         cores = best[1]
+        # the port is built twice from the same source: -O2 -mpopcnt, and -O3 -mavx2 (the reference's own flags,
+        # ref CMakeLists.txt:112-148); the faster build on the probe sample is the one reported
+        builds = {"": "-O2 -mpopcnt", "avx2": "-O3 -mavx2 -mbmi2 -mpopcnt"}
+        probe = {}
+        for variant in builds:
+            try:
+                O.set_variant(variant)
+                run_sample(m)  # warm
+                probe[variant] = min(run_sample(m)[0] for _ in range(2))
+            except OSError:
+                pass
+        variant = min(probe, key=probe.get)
+        O.set_variant(variant)
         dt, tl = run_sample(m)
         for _ in range(4):
             if dt >= args.cpu_seconds / 2 or m >= Q or m >= 50_000_000:
@@ -484,6 +685,8 @@ def main():
             dtt, _ = run_sample(mt, t)
             fixed[f"threads_{t}"] = {"value": round(mt / dtt / 1e6, 3), "sample": mt}
         cpu = {"value": round(m / dt / 1e6, 3), "unit": "Mkmers/s", "cores": cores, "kind": "port", **fixed,
+               "build": builds[variant],
+               "builds_probed_Mkmers_per_s": {builds[v]: round(min(Q, 2_000_000) / t / 1e6, 3) for v, t in probe.items()},
                "sample": f"first {m} of the {Q} {args.workload} {kdesc} of rank 0, {args.mode}, same index, "
                          f"{dt:.1f} s wall on {cores} threads ({granted} CPUs granted of {os.cpu_count()}), "
                          f"results equal to the GPU's",
@@ -527,30 +730,45 @@ def main():
         assert np.array_equal(pos[ho[:-1][one]], planted_at[one]), "a planted k-mer was located somewhere else"
         for i in np.flatnonzero(~one)[:1000]:
             assert planted_at[i] in pos[ho[i]:ho[i + 1]], "a planted k-mer's own offset is missing from its hit list"
+        pkey = digest.key(args.alphabet, "planted", "locate", n, str(K), args.seed_k, args.sa_ratio, first, Q)
+        pdig = {"counts": f"{digest.counts_digest(first, d_hit_off[1:] - d_hit_off[:-1]):016x}",
+                "positions": f"{digest.positions_digest(first, d_hit_off, state['positions'][:hits]):016x}"}
+        committed = digest.load_golden().get(pkey)
+        assert committed is None or committed == pdig, f"planted digests {pdig} differ from the committed {committed}"
         secondary = {"workload": f"{Q / 1e6:g} M planted {K}-mers (every k-mer has >= 1 hit), locate, same index",
                      "value": round(Q / dt / 1e6, 2), "unit": "Mkmers/s", "ms_per_step": round(dt * 1e3, 3), "steps": 3,
-                     "hits_per_step": int(hits), "checked": f"first {m} k-mers located at their planting offsets"}
+                     "hits_per_step": int(hits), "checked": f"first {m} k-mers located at their planting offsets",
+                     "digests": dict(pdig, status="match" if committed else "unknown")}
+        if args.record_digests:
+            known = json.load(open(args.record_digests)) if os.path.exists(args.record_digests) else {}
+            known[pkey] = pdig
+            json.dump(known, open(args.record_digests, "w"), indent=1, sort_keys=True)
         del d_planted
 
+    per = "per GPU" if args.scaling == "weak" else f"in total, sharded over {world} rank(s)"
     out = {
         "metric": "Mkmers/sec located, GRCh38 nucleotide index" if not amino else "Mkmers/sec located, amino index",
         "value": round(value, 2), "unit": "Mkmers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"{Q / 1e6:g} M {args.workload} {kdesc} per GPU, {args.mode}, "
-                               f"{n / 1e9:g} G{'res' if amino else 'bp'} uniform synthetic {args.alphabet} text"
+        "config": {"workload": f"{args.queries / 1e6:g} M {args.workload} {kdesc} {per}, {args.mode}, "
+                               f"{n / 1e9:g} G{'res' if amino else 'bp'} {args.text} synthetic {args.alphabet} text"
                                f"{' (GRCh38-sized)' if n >= 3_000_000_000 and not amino else ''}, "
                                f"SA ratio {args.sa_ratio}, seed table k={args.seed_k}",
                    "parallelism": f"index replica per GPU, query batch sharded over {world} rank(s), no collective",
+                   "batch_kmers": batch_total, "rank0_kmers": Q,
+                   "timing_collective": shard.timing_backend() or "none (one rank)",
                    "hits_per_step_rank0": int(state["hits"]), "locate_kernels_ms": round(locate_ms, 3),
                    "index_build_s": round(build_s, 2),
-                   "device_image_bytes": g.device_bytes, "device_seed_k": args.device_seed_k or args.seed_k,
+                   "device_image_bytes": g.device_bytes, "device_seed_k": g.deep_seed_k or args.seed_k,
                    "device_seed_build_s": round(deep_s, 2), "device_dense_sa": bool(args.device_dense_sa),
                    "device_dense_sa_build_s": round(dense_s, 2),
                    "search_path": ("awfmGpuSearchHitsSparse" if (args.mode == "locate" and narrow_counts and state["sparse"]) else "awfmGpuSearchHits")
                                   + (", seed order" if ordered else ", general kernel")},
         "roofline": roofline,
+        "roofline_general": roofline_general,
         "cpu_baseline": cpu,
+        "digests": digest_check,
         "end_to_end": e2e,
         "secondary": secondary,
     }

@@ -82,9 +82,11 @@ int awfmGpuIndexDevice(const AwFmGpuIndex *g);
  * 4^deepK x 16 bytes of HBM: 4.3 GB at 14, 69 GB at 16) whose entries equal what the reference algorithm
  * reaches after the seed lookup plus deepK-seedK extension steps (stopping at the first invalid range), so
  * results stay bit-identical while those steps' block reads disappear.  deepK = 0 drops it.  The host
- * index, its seed table and the .awfmi file are untouched.  Also read from $AWFM_GPU_DEEP_SEED_K when an
- * image is created. */
+ * index, its seed table and the .awfmi file are untouched.  When an image is created: $AWFM_GPU_DEEP_SEED_K (0: none)
+ * if set; otherwise images of 2^28 positions and more whose own table is shallower get depth 14 when four times the
+ * table's 4.3 GB are free on the device. */
 enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK);
+unsigned awfmGpuIndexDeepSeedK(const AwFmGpuIndex *g); /* depth of the deeper table the image has, 0: none */
 /* Optional: keeps the full suffix array on the device (32-bit entries, 4 x bwtLength bytes: 12.4 GB for a
  * GRCh38-sized index), reconstructed once from the sampled SA with the LF-walk kernel, so that locating a
  * hit is one read instead of a chain of about ratio-1 dependent block reads.  Positions are bit-identical.
@@ -167,6 +169,16 @@ double awfmGpuLastOrderedKernelMs(AwFmGpuIndex *g);
 enum AwFmReturnCode awfmGpuSearchTally(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                        uint32_t fixedLength, uint64_t numQueries, uint64_t tallyOut[4]);
 
+/* Instrumented run of the seed-order path of awfmGpuSearchHits on the same batch (encode + sort + search with every
+ * line the search kernel reads marked in per-level bitmaps): the COMPULSORY memory traffic of that kernel, i.e. what an
+ * ideal cache would still have to fetch.  tallyOut = {128-B lines of the seed table touched, lines of the deeper
+ * device-only table touched, distinct (search level, 128-B line) pairs of the pair image, the same of the one-letter
+ * image, k-mers the seed-order kernel searched, bytes of sorted record + key it reads per k-mer, k-mers with hits,
+ * k-mers left to the general kernel}.  AwFmUnsupportedVersionError when the batch would not take the seed-order path
+ * (awfmGpuSearchHitsIsOrdered).  Synchronous, not for timing. */
+enum AwFmReturnCode awfmGpuSearchHitsLineTally(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                               uint32_t fixedLength, uint64_t numQueries, uint64_t tallyOut[8]);
+
 /* dHitOffsets[numQueries+1] = exclusive scan of the range lengths; the total is
  * also copied to *totalHits (host) -- this call synchronises `stream`.
  * dScratch must hold awfmGpuScanScratchBytes(numQueries) bytes. */
@@ -191,6 +203,16 @@ enum AwFmReturnCode awfmGpuLocateTo(AwFmGpuIndex *g, const struct AwFmSearchRang
                                     const uint64_t *dHitOffsets, uint64_t numQueries, uint64_t totalHits,
                                     uint64_t *dPositions, uint64_t *outPositions, void *stream);
 
+/* A window of the batch's hit list: the hits numbered hitBegin .. hitEnd-1 (in the numbering of dHitOffsets, i.e. hit h of
+ * query i has number dHitOffsets[i] + h), which belong to the queries queryBegin .. queryEnd-1 (any superset of the
+ * queries whose lists meet the window will do); dPositions / outPositions hold hitEnd - hitBegin entries, entry 0 is hit
+ * hitBegin.  A window may begin and end inside the list of one k-mer: this is how a locate whose hit list exceeds a
+ * device-memory budget is taken in pieces (the reference grows every positionList on its own, ref
+ * src/AwFmParallelSearch.c:315-387; here the list is flat and the budget bounds what is resident). */
+enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges, const uint64_t *dHitOffsets,
+                                        uint64_t queryBegin, uint64_t queryEnd, uint64_t hitBegin, uint64_t hitEnd,
+                                        uint64_t *dPositions, uint64_t *outPositions, void *stream);
+
 /* ---- pinned staging for the drop-in AoS entry points ---- */
 /* A grow-only page-locked host buffer cached in the image (slot 0..3); valid until the next call for the
  * same slot.  awfmGpuAosLock/Unlock serialise the AoS entry points that share these buffers. */
@@ -211,12 +233,19 @@ enum AwFmReturnCode awfmGpuLocateHost(AwFmGpuIndex *g, const uint8_t *chars, con
                                       uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
                                       uint64_t *hitOffsets, uint64_t **positions);
 
-/* Same, for the drop-in AoS entry points: *positions points into page-locked slot 3 of the image (valid until
- * the next call for that slot; hold awfmGpuAosLock), so the download runs at the full PCIe rate and nothing
- * is malloc'ed. */
-enum AwFmReturnCode awfmGpuLocateHostPinned(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
-                                            uint32_t fixedLength, uint64_t numQueries, uint64_t *hitOffsets,
-                                            const uint64_t **positions);
+/* The same with the hit list delivered in windows, for batches whose hits exceed what may be resident on the device
+ * ($AWFM_GPU_HIT_BUDGET_BYTES; default a quarter of the free device memory, at most 2^31 hits): hitOffsets[0..numQueries]
+ * is complete before the first call of the sink; the sink then receives consecutive windows [hitBegin, hitEnd) of the
+ * flat hit list (hit h of query i has number hitOffsets[i] + h), `positions` holding hitEnd - hitBegin entries in
+ * page-locked staging that stays valid until the sink returns, and the queries queryBegin .. queryEnd-1 whose lists meet
+ * the window (the first and the last may be cut).  While the sink runs, the next window is walked and downloaded.  A
+ * non-zero return stops the batch.  A batch that fits the budget is one window.  This is what the drop-in AoS entry
+ * points run on (hold awfmGpuAosLock: the staging is slot 3 of the image's pinned buffers). */
+typedef int (*AwFmGpuHitWindowSink)(void *user, uint64_t queryBegin, uint64_t queryEnd, uint64_t hitBegin, uint64_t hitEnd,
+                                    const uint64_t *positions);
+enum AwFmReturnCode awfmGpuLocateHostWindows(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
+                                             uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,
+                                             uint64_t *hitOffsets, AwFmGpuHitWindowSink sink, void *user);
 
 /* ---- packed k-mers and the chunked host-buffer pipeline (awfm_gpu_stream.hip) ----
  * The reference's batch is an array of structs: a kmerString pointer in and a malloc'ed positionList out per
@@ -232,7 +261,9 @@ enum AwFmReturnCode awfmGpuLocateHostPinned(AwFmGpuIndex *g, const uint8_t *char
  * k-mer that cannot be expressed in *firstUnpackable (may be NULL) */
 enum AwFmReturnCode awfmPackKmers(enum AwFmAlphabetType alphabet, const uint8_t *chars, uint32_t kmerLength,
                                   uint64_t numKmers, uint64_t *packedOut, uint64_t *firstUnpackable);
-/* the same on device buffers (k-mers that cannot be expressed become the all-ones word and are counted), and back */
+/* the same on device buffers, and back.  K-mers that cannot be expressed are counted in *numUnpackable and become the
+ * all-ones word -- itself a k-mer ('t' x 32), so the call then returns AwFmIllegalPositionError like awfmPackKmers: the
+ * output of such a batch must not be searched (search it as ASCII instead) */
 enum AwFmReturnCode awfmGpuPackKmers(AwFmGpuIndex *g, const uint8_t *dChars, uint32_t kmerLength, uint64_t numKmers,
                                      uint64_t *dPacked, uint64_t *numUnpackable, void *stream);
 enum AwFmReturnCode awfmGpuUnpackKmers(AwFmGpuIndex *g, const uint64_t *dPacked, uint32_t kmerLength, uint64_t numKmers,
@@ -252,7 +283,11 @@ void awfmGpuHostFree(void *p);
  * hits of k-mer firstKmer+i starting where those of firstKmer+i-1 end, each list in BWT order (what
  * awFmParallelSearchLocate puts into positionList).  The arrays are page-locked staging of the pipeline, valid until
  * the sink returns; chunks arrive in order; a non-zero return stops the batch.  The sink runs on the calling thread
- * while the image's pipeline is locked: it must not start another batch on the same image. */
+ * while the image's pipeline is locked: it must not start another batch on the same image.
+ * A chunk whose hits exceed the device's hit budget ($AWFM_GPU_HIT_BUDGET_BYTES; default a quarter of the free device
+ * memory) arrives in several calls: consecutive groups of whole k-mers, and a k-mer whose own list exceeds a window
+ * alone, in consecutive calls with the same firstKmer and numKmers == 1, each with the next slice of its list
+ * (counts[0] is its full count every time).  Concatenating the positions of all calls gives the batch's flat list. */
 typedef int (*AwFmGpuChunkSink)(void *user, uint64_t firstKmer, uint64_t numKmers, const uint32_t *counts,
                                 const uint64_t *positions, uint64_t numPositions);
 /* Counts (locate == 0) or locates numKmers packed host-resident k-mers in chunks of chunkKmers (0: 2^24) through
@@ -282,6 +317,14 @@ enum AwFmReturnCode awfmGpuSynthRandomQueries(uint8_t *dOut, uint64_t first, uin
 /* `count` k-mers copied from the (unsanitised) device text at seeded uniform offsets */
 enum AwFmReturnCode awfmGpuSynthPlantedQueries(uint8_t *dOut, uint64_t first, uint64_t count, uint32_t length,
                                                uint64_t seedQ, const uint8_t *dText, uint64_t textLength, void *stream);
+
+/* A genome-shaped nucleotide text of `length` characters (csrc/awfm_synth.hip, synth.py genome_text): interspersed repeat
+ * families (a 300-character unit in about length/3000 copies at 10 % divergence, a 6000-character one in cut copies at
+ * 5 %), tandem repeats, 24 runs of 'n' of up to 10^7 characters, unique sequence in between. */
+enum AwFmReturnCode awfmGpuSynthGenomeText(uint8_t *dOut, uint64_t length, uint64_t seed, void *stream);
+/* awfmGpuSynthPlantedQueries with every character that is not a,c,g,t replaced by a seeded random letter */
+enum AwFmReturnCode awfmGpuSynthPlantedQueriesClean(uint8_t *dOut, uint64_t first, uint64_t count, uint32_t length,
+                                                    uint64_t seedQ, const uint8_t *dText, uint64_t textLength, void *stream);
 
 /* mixed-length set: lengths lo..hi, even ids random, odd ids copied from the text.
  * Lengths first; the caller turns them into count+1 exclusive-scan offsets; then the characters. */

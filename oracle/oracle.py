@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_VARIANT = ""  # "" = liboracle.so (-O2 -mpopcnt), "avx2" = liboracle_avx2.so (-O3 -mavx2): same source, same results
 
 AMINO, DNA, RNA = 1, 2, 3
 
@@ -42,19 +43,34 @@ class OrcTally(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+def _so_name():
+    return "liboracle_avx2.so" if _VARIANT == "avx2" else "liboracle.so"
+
+
 def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+    so = os.path.join(_HERE, _so_name())
     src = [os.path.join(_HERE, f) for f in ("awfm_oracle.c", "awfm_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", _so_name()])
     return so
+
+
+def set_variant(name):
+    """switch the build the module calls into ("" or "avx2"); indices made before the switch stay usable (plain C
+    structs), the next call goes to the other library"""
+    global _LIB, _VARIANT
+    if name not in ("", "avx2"):
+        raise ValueError(name)
+    if name != _VARIANT:
+        _VARIANT = name
+        _LIB = None
 
 
 def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    so = os.path.join(_HERE, "liboracle.so")
+    so = os.path.join(_HERE, _so_name())
     if not os.path.exists(so):
         build()
     L = C.CDLL(so)

@@ -24,6 +24,7 @@ PASS[busy]="TCC_BUSY_avr GRBM_TA_BUSY GRBM_TC_BUSY GRBM_EA_BUSY"
 # sat in its finalisation until the call's limit: name it (or `busy`) in $PROFILE_PASSES only under a short `timeout`
 for N in ${PROFILE_PASSES:-fetch write l2 sq sq2 ea tcp}; do
   rocprofv3 --pmc ${PASS[$N]} --kernel-include-regex "$KERNELS" --output-format csv -d "$OUT/pmc_$N" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-secondary --steps 2 --warmup 1 "$@" > "$OUT/bench_pmc_$N.log" 2>&1
-  echo "pass $N: $(find "$OUT/pmc_$N" -name '*counter_collection.csv' | wc -l) csv, rc $?"
+  rc=$?
+  echo "pass $N: $(find "$OUT/pmc_$N" -name '*counter_collection.csv' | wc -l) csv, rc $rc"
 done
 for f in $(find "$OUT/trace" -name "*kernel_stats.csv"); do echo "== $f"; head -14 "$f" | cut -c1-200; done

@@ -49,3 +49,15 @@ def wide(request, monkeypatch):
     if request.param == "wide-superblocks":
         monkeypatch.setenv("AWFM_GPU_NUC_SUPER_SHIFT", "auto")
     return request.param != "narrow"
+
+
+@pytest.fixture(params=["partition", "rocprim"])
+def order_sort(request, monkeypatch):
+    """how the seed-order path of awfmGpuSearchHits orders a fixed-length batch: the hand-written count + partition
+    kernels (2048 buckets, 8-byte records without their bucket's bits; the default), or the earlier encode + rocPRIM radix
+    sort of (16-bit key, record) pairs ($AWFM_GPU_ORDERED_SORT=rocprim, kept for comparison)"""
+    if request.param == "rocprim":
+        monkeypatch.setenv("AWFM_GPU_ORDERED_SORT", "rocprim")
+    else:
+        monkeypatch.delenv("AWFM_GPU_ORDERED_SORT", raising=False)
+    return request.param

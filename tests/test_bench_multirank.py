@@ -80,3 +80,88 @@ def test_two_ranks_on_one_gpu_search_their_own_shards(oracle, awfm, require_gpu,
     a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     key = "counts" if mode == "count" else "positions"
     assert a[key].shape != b[key].shape or not np.array_equal(a[key], b[key])
+
+
+def _line(r):
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,mode,scaling", [("planted", "locate", "strong"), ("mixed", "count", "strong"),
+                                                   ("random", "count", "weak")])
+def test_n_rank_digests_equal_the_one_rank_run(require_gpu, tmp_path, workload, mode, scaling):
+    """what the first real multi-GPU run is checked by: every rank's additive digest of its shard's counts / positions,
+    summed on rank 0, must equal the digest the 1-rank run of the same batch recorded (strong: one batch cut in two,
+    mixed lengths cut by the sum of the lengths; weak: the 2-rank batch is the 1-rank batch plus a second one)"""
+    golden = str(tmp_path / "digests.json")
+    common = ["--text-len", "3e6", "--queries", "1e6", "--kmer", "15", "--seed-k", "8", "--workload", workload, "--mode", mode,
+              "--no-cpu", "--no-e2e", "--no-secondary", "--general-steps", "0", "--steps", "1", "--warmup", "1"]
+    one = _line(_run_bench(common + ["--gpus", "1", "--scaling", scaling, "--record-digests", golden]))
+    assert one["digests"]["status"] == "unknown"  # nothing committed for this toy configuration
+    if scaling == "weak":  # the second rank's batch, recorded by a 1-rank run that starts at its first k-mer
+        _line(_run_bench(common + ["--gpus", "1", "--query-offset", "1e6", "--record-digests", golden]))
+    env_golden = dict(AWFM_BENCH_DIGESTS=golden)
+    os.environ.update(env_golden)
+    try:
+        two = _line(_run_bench(common + ["--gpus", "2", "--force-device", "0", "--dist-backend", "gloo", "--scaling", scaling]))
+        again = _line(_run_bench(common + ["--gpus", "1", "--scaling", scaling]))
+    finally:
+        os.environ.pop("AWFM_BENCH_DIGESTS")
+    assert two["n_gpus"] == 2 and two["scaling"] == scaling
+    assert two["digests"]["status"] == "match" and two["digests"]["shards"] == 2, two["digests"]
+    assert again["digests"]["status"] == "match"
+    if scaling == "strong":
+        assert two["config"]["batch_kmers"] == 1_000_000 and two["digests"]["counts"] == one["digests"]["counts"]
+        firsts = [p["first"] for p in two["digests"]["per_rank"]]
+        assert firsts[0] == 0 and 0 < firsts[1] < 1_000_000
+        if workload == "mixed":
+            assert firsts[1] != 500_000  # cut by the sum of the lengths, not by the number of k-mers
+    else:
+        assert two["config"]["batch_kmers"] == 2_000_000
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_two_distinct_gpus_over_rccl(require_gpu, tmp_path):
+    """--gpus 2 the way the driver runs it at N > 1: one rank per device, barrier and MAX reduction over RCCL"""
+    from avxwindowfmindex_amd import _lib
+    if _lib.lib().awfmGpuDeviceCount() < 2:
+        pytest.skip("needs two GPUs")
+    golden = str(tmp_path / "digests.json")
+    common = ["--text-len", "3e6", "--queries", "1e6", "--kmer", "15", "--seed-k", "8", "--workload", "planted", "--no-cpu",
+              "--no-e2e", "--no-secondary", "--general-steps", "0", "--steps", "2", "--warmup", "1", "--scaling", "strong"]
+    _line(_run_bench(common + ["--gpus", "1", "--record-digests", golden]))
+    os.environ["AWFM_BENCH_DIGESTS"] = golden
+    try:
+        two = _line(_run_bench(common + ["--gpus", "2"]))
+    finally:
+        os.environ.pop("AWFM_BENCH_DIGESTS")
+    assert two["n_gpus"] == 2 and two["digests"]["status"] == "match"
+    assert two["config"]["timing_collective"] in ("nccl", "gloo")
+
+
+@pytest.mark.gpu
+def test_aos_locate_shards_over_two_devices(oracle, awfm, require_gpu):
+    """AWFM_GPU_DEVICES=0,1: awFmParallelSearchLocate cuts the list over two devices, one index replica each"""
+    from avxwindowfmindex_amd import _lib, synth
+    if _lib.lib().awfmGpuDeviceCount() < 2:
+        pytest.skip("needs two GPUs")
+    os.environ["AWFM_GPU_DEVICES"] = "0,1"
+    try:
+        txt = synth.text(91, 400_000)
+        ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+        kmers = np.concatenate([synth.random_queries(92, 20_000, 19), synth.planted_queries(93, 20_001, 19, txt)])
+        lst = awfm.KmerSearchList(len(kmers))
+        lst.fill(kmers)
+        awfm.parallel_search_locate(ix, lst, 8)
+        oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+        chars, offsets = synth.fixed_csr(kmers)
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+        ho, pos, _ = oi.batch_locate(sp, ep)
+        assert np.array_equal(lst.counts(), cnt)
+        for i in list(range(0, len(kmers), 997)) + [len(kmers) - 1]:
+            assert np.array_equal(lst.positions(i), pos[ho[i]:ho[i + 1]])
+        lst.dealloc()
+        ix.dealloc()
+    finally:
+        os.environ.pop("AWFM_GPU_DEVICES")

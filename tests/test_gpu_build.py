@@ -187,3 +187,31 @@ def test_drop_in_create_index_goes_to_the_gpu_builder_and_writes_the_same_file(a
         blobs[where] = open(f, "rb").read()
         ix.dealloc()
     assert blobs["gpu"] == blobs["host"], "FASTA index files differ"
+
+
+def test_genome_shaped_text_generator_and_build(awfm, require_gpu):
+    """the genome-shaped synthetic text (repeat families, tandem repeats, runs of N: what GRCh38 is and a uniform text is
+    not): the device generator writes the characters synth.genome_text defines, and the GPU builder's arrays are byte
+    identical to the host builder's on 16 Mbp of it -- N runs of up to 2.6*10^5 characters (suffixes that tie over their
+    whole length), 10^3 copies of a 300-character family, 6000-character units, tandem repeats"""
+    import torch
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    for n in (5000, 300_001):
+        d = torch.empty(n, dtype=torch.uint8, device="cuda")
+        assert L.awfmGpuSynthGenomeText(d.data_ptr(), n, 7, None) == 1
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy(), synth.genome_text(7, n))
+    n = 1 << 24
+    txt = synth.genome_text(2, n)
+    counts = {chr(c): int(k) for c, k in zip(*np.unique(txt, return_counts=True))}
+    assert set(counts) == set("acgtn") and 0.02 < counts["n"] / n < 0.4
+    d = torch.from_numpy(txt).cuda()
+    q = torch.empty(3000 * 21, dtype=torch.uint8, device="cuda")
+    assert L.awfmGpuSynthPlantedQueriesClean(q.data_ptr(), 5, 3000, 21, 13, d.data_ptr(), n, None) == 1
+    assert np.array_equal(q.cpu().numpy().reshape(3000, 21), synth.planted_queries_clean(13, 3000, 21, txt, first=5))
+    host = _host_build(awfm, txt, awfm.AwFmAlphabetDna, 8, 8)
+    dev = awfm.gpu_create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    _same_arrays(host, dev)
+    host.dealloc()
+    dev.dealloc()

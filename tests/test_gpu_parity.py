@@ -391,7 +391,7 @@ def _check_hits_contract(ranges, counts, sp, ep, cnt):
 @pytest.mark.parametrize("n,ratio,seed_k,deep_k,K", [(300000, 8, 8, 0, 21), (300000, 5, 8, 0, 8), (200000, 8, 6, 9, 32),
                                                      (200000, 8, 6, 9, 7), (4096, 3, 4, 0, 13), (100000, 8, 1, 0, 5),
                                                      (150000, 8, 10, 11, 11)])
-def test_ordered_hits_only_search_is_exact_on_hits(oracle, awfm, require_gpu, wide, n, ratio, seed_k, deep_k, K):
+def test_ordered_hits_only_search_is_exact_on_hits(oracle, awfm, require_gpu, wide, order_sort, n, ratio, seed_k, deep_k, K):
     """awfmGpuSearchHits with the ordered path forced on (fixed-length DNA batches): ambiguity characters and upper
     case included, query buffer at every byte alignment, ranges only / counts only / both, then the locate
     pipeline on top of the hits-only ranges"""
@@ -444,6 +444,48 @@ def test_ordered_hits_only_search_is_exact_on_hits(oracle, awfm, require_gpu, wi
     g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, d_pos.data_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(d_pos[:total].cpu().numpy().view(np.uint64), pos)
+    g.destroy()
+    ix.dealloc()
+
+
+@pytest.mark.parametrize("shape", ["one-kmer", "two-buckets", "tiny", "every-bucket-small", "sorted"])
+def test_bucketed_order_with_skewed_and_tiny_batches(oracle, awfm, require_gpu, wide, shape):
+    """the partitioned order leaves the bucket of a record to its position: batches in which one bucket holds everything,
+    in which most buckets are empty, and in which a chunk of 16 records crosses many buckets"""
+    import torch
+    n, K, seed_k = 400_000, 19, 8
+    txt = synth.text(771, n)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, seed_k)
+    oi = oracle.Index.wrap(oracle.DNA, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    planted = synth.planted_queries(772, 40_000, K, txt)
+    if shape == "one-kmer":
+        q = np.repeat(planted[:1], 20_000, axis=0)
+    elif shape == "two-buckets":
+        q = np.concatenate([np.repeat(planted[:1], 9_000, axis=0), np.repeat(planted[1:2], 11_111, axis=0), planted[:3]])
+    elif shape == "tiny":
+        q = np.concatenate([planted[:37], synth.random_queries(773, 40, K)])
+    elif shape == "every-bucket-small":
+        q = np.concatenate([planted[:3000], synth.random_queries(774, 3000, K)])  # 6000 k-mers over 2048 buckets
+    else:
+        q = planted[np.lexsort(planted[:, ::-1].T)]  # the batch arrives sorted: long runs of one bucket after another
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    Q = len(q)
+    d_chars = torch.from_numpy(chars.copy()).cuda()
+    d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device="cuda")
+    d_counts = torch.full((Q,), 7, dtype=torch.int32, device="cuda")
+    g.search_hits(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+    torch.cuda.synchronize()
+    _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2), d_counts.cpu().numpy().view(np.uint32), sp, ep, cnt)
+    # the same k-mers bit-packed (the packed words are the partition's code array: no encoding pass)
+    d_packed = torch.from_numpy(awfm.pack_kmers(q).view(np.int64)).cuda()
+    d_ranges.fill_(7)
+    d_counts.fill_(7)
+    g.search_hits_packed(d_packed.data_ptr(), K, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+    torch.cuda.synchronize()
+    _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2), d_counts.cpu().numpy().view(np.uint32), sp, ep, cnt)
     g.destroy()
     ix.dealloc()
 

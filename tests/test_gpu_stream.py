@@ -245,3 +245,33 @@ def test_stream_edge_cases(oracle, awfm, require_gpu):
         h.destroy()
     ix.dealloc()
     amino.dealloc()
+
+
+def test_one_image_packed_then_ascii_and_growing_kmer_length(oracle, awfm, require_gpu):
+    """the pipeline's slots are re-used across batches on one image: a slot sized for 8-byte packed words (or 10-byte
+    ASCII k-mers) must grow before a batch of wider k-mers with the same chunk size is uploaded into it"""
+    n, chunk = 200_000, 2048
+    txt = synth.text(81, n)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 6)
+    g = awfm.GpuIndex(ix)
+    k21 = np.concatenate([synth.random_queries(82, 3000, 21), synth.planted_queries(83, 3000, 21, txt)])
+    k10 = synth.planted_queries(84, 6000, 10, txt)
+    k30 = np.concatenate([synth.random_queries(85, 3000, 30), synth.planted_queries(86, 3000, 30, txt)])
+    want = {K: _oracle_answers(oracle, oracle.DNA, ix, 8, 6, q) for K, q in ((21, k21), (10, k10), (30, k30))}
+    # (1) packed words first (8 B per k-mer in the slot), then ASCII 21-mers (21 B per k-mer), same chunk size
+    counts, positions = g.stream(awfm.pack_kmers(k21), 21, locate=True, chunk=chunk)
+    assert np.array_equal(counts, want[21][0]) and np.array_equal(positions, want[21][1])
+    counts, positions = g.stream(k21.reshape(-1), 21, locate=True, chunk=chunk, packed=False)
+    assert np.array_equal(counts, want[21][0]) and np.array_equal(positions, want[21][1])
+    g.destroy()
+    # (2) ASCII 10-mers, then ASCII 30-mers on a fresh image, same chunk size
+    g = awfm.GpuIndex(ix)
+    counts, positions = g.stream(k10.reshape(-1), 10, locate=True, chunk=chunk, packed=False)
+    assert np.array_equal(counts, want[10][0]) and np.array_equal(positions, want[10][1])
+    counts, positions = g.stream(k30.reshape(-1), 30, locate=True, chunk=chunk, packed=False)
+    assert np.array_equal(counts, want[30][0]) and np.array_equal(positions, want[30][1])
+    # and back down: the larger slot serves the narrower batch
+    counts, positions = g.stream(awfm.pack_kmers(k21), 21, locate=True, chunk=chunk)
+    assert np.array_equal(counts, want[21][0]) and np.array_equal(positions, want[21][1])
+    g.destroy()
+    ix.dealloc()

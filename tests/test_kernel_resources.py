@@ -59,11 +59,12 @@ def test_default_walk_kernel_keeps_full_occupancy(kernel_metadata):
 
 
 def test_ordered_search_kernels_keep_full_occupancy(kernel_metadata):
-    # orderedSearchKernel<G=4, NARROW=true, COMPACT, VARLEN, PAIR>: the 8-byte-record, the 16-byte-record and the CSR
-    # variant, with one step per block read and with two (pair image, the default)
-    for variant in ("Lb1ELb1ELb0E", "Lb1ELb0ELb0E", "Lb1ELb0ELb1E"):
+    # orderedSearchKernel<G=4, NARROW=true, COMPACT, VARLEN, PAIR, TOUCH=false, BUCKET>: bucketed 8-byte records (the
+    # default of fixed-length batches), the 16-byte-record and the CSR variant, with one step per block read and with two
+    # (pair image, the default)
+    for variant, bucket in (("Lb1ELb1ELb0E", "Lb1E"), ("Lb1ELb0ELb0E", "Lb0E"), ("Lb1ELb0ELb1E", "Lb0E")):
         for pair in ("Lb0E", "Lb1E"):
-            k = _one(kernel_metadata, r"orderedSearchKernelILi4E" + variant + pair)
+            k = _one(kernel_metadata, r"orderedSearchKernelILi4E" + variant + pair + "Lb0E" + bucket + "E")
             assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0, variant + pair
             assert k["lds"] <= 16 * 1024  # static; the pair variant adds 64 B per 2^23 positions of dynamic LDS
 

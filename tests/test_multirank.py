@@ -63,3 +63,85 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     for w in (1, 2, 3, 8):
         b = [shard.shard_bounds(total, w, r) for r in range(w)]
         assert b[0][0] == 0 and b[-1][1] == total and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+def _fallback_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from avxwindowfmindex_amd import dist as shard
+    r, w = shard.init("nccl")  # no GPU here: the RCCL trial fails on every rank and all of them agree on gloo
+    assert (r, w) == (rank, world) and shard.timing_backend() == "gloo"
+    shard.barrier(w)
+    assert shard.max_over_ranks(10.0 + rank, w, device="cpu") == 10.0 + world - 1
+    parts = shard.gather_objects((rank, "x" * rank), w)
+    assert parts == [(i, "x" * i) for i in range(world)]
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("1")
+    dist.destroy_process_group()
+
+
+def test_rccl_failure_falls_back_to_gloo_in_the_same_process(tmp_path):
+    """bench.py asks for the RCCL backend; when that cannot be set up (here: no GPU at all) the ranks keep the gloo group
+    they rendezvoused on -- no re-exec, no hang -- and the barrier / MAX reduction still work"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the RCCL trial may succeed")
+    import torch.multiprocessing as mp
+    mp.spawn(_fallback_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_digests_add_up_over_any_sharding_and_catch_errors():
+    """the digests bench.py compares across --gpus N: per-k-mer / per-hit hashes keyed by GLOBAL k-mer number, summed"""
+    import torch
+    from avxwindowfmindex_amd import digest
+    rng = np.random.default_rng(3)
+    Q = 5000
+    counts = rng.integers(0, 4, Q).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    pos = rng.integers(0, 1 << 33, int(off[-1])).astype(np.int64)
+    t = torch.from_numpy
+    whole = (digest.counts_digest(0, t(counts)), digest.positions_digest(0, t(off), t(pos)))
+    for cuts in ([0, Q], [0, 1234, Q], [0, 1, 2, 4000, 4001, Q]):
+        dc = dp = 0
+        for b, e in zip(cuts, cuts[1:]):
+            dc += digest.counts_digest(b, t(counts[b:e]))
+            dp += digest.positions_digest(b, t(off[b:e + 1] - off[b]), t(pos[off[b]:off[e]]))
+        assert (dc & digest.MASK, dp & digest.MASK) == whole, cuts
+    # a count under the wrong k-mer number, two hits of one list swapped, a changed position: all seen
+    assert digest.counts_digest(1, t(counts)) != whole[0]
+    i = int(np.flatnonzero(counts >= 2)[0])
+    swapped = pos.copy()
+    swapped[off[i]], swapped[off[i] + 1] = pos[off[i] + 1], pos[off[i]]
+    assert pos[off[i]] != pos[off[i] + 1] and digest.positions_digest(0, t(off), t(swapped)) != whole[1]
+    # the check against committed values: per shard, as a sum over a chain of committed pieces, unknown, mismatch
+    describe = lambda f, c: digest.key("dna", "random", "locate", 1000, "21", 8, 8, f, c)  # noqa: E731
+    hexes = lambda dc, dp: {"counts": f"{dc:016x}", "positions": f"{dp:016x}"}  # noqa: E731
+    halves = [(0, 2500), (2500, 2500)]
+    shard_d = [(b, c, digest.counts_digest(b, t(counts[b:b + c])),
+                digest.positions_digest(b, t(off[b:b + c + 1] - off[b]), t(pos[off[b]:off[b + c]]))) for b, c in halves]
+    golden_whole = {describe(0, Q): hexes(*whole)}
+    assert digest.check_against_golden(shard_d, golden_whole, describe)["status"] == "match"
+    golden_halves = {describe(b, c): hexes(dc, dp) for b, c, dc, dp in shard_d}
+    assert digest.check_against_golden([(0, Q, *whole)], golden_halves, describe)["status"] == "match"
+    assert digest.check_against_golden(shard_d, golden_halves, describe)["status"] == "match"
+    assert digest.check_against_golden(shard_d, {}, describe)["status"] == "unknown"
+    bad = [shard_d[0], (shard_d[1][0], shard_d[1][1], shard_d[1][2] ^ 1, shard_d[1][3])]
+    with pytest.raises(AssertionError):
+        digest.check_against_golden(bad, golden_whole, describe)
+    with pytest.raises(AssertionError):  # shards that leave a gap
+        digest.check_against_golden([shard_d[0], (2600, 2400, 0, 0)], golden_whole, describe)
+
+
+def test_balanced_shard_bounds_follow_the_weights():
+    from avxwindowfmindex_amd import dist as shard
+    rng = np.random.default_rng(5)
+    lengths = rng.integers(8, 31, 100_000).astype(np.int64)
+    prefix = np.concatenate([[0], np.cumsum(lengths)])
+    for world in (1, 2, 4, 8):
+        b = [shard.balanced_bounds(prefix, world, r) for r in range(world)]
+        assert b[0][0] == 0 and b[-1][1] == lengths.size and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        work = [int(prefix[e] - prefix[s]) for s, e in b]
+        assert max(work) - min(work) <= 31, work  # within one k-mer of each other
