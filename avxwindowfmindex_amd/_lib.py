@@ -34,12 +34,17 @@ GPU_SYMBOLS = [
     "awfmGpuSynthMixedLengths", "awfmGpuSynthMixedQueries", "awfmGpuSynthGenomeText", "awfmGpuSynthPlantedQueriesClean",
     "awfmPackKmers", "awfmGpuPackKmers", "awfmGpuUnpackKmers", "awfmGpuHostAlloc", "awfmGpuHostFree", "awfmGpuStreamPacked",
     "awfmGpuStreamChars", "awfmGpuCountPackedHost", "awfmGpuLocatePackedHost", "awfmGpuIndexSetPairImage", "awfmGpuIndexHasPairImage",
-    "awfmGpuSearchHitsPacked", "awfmGpuLocateTo", "awfmGpuSearchHitsLineTally", "awfmGpuIndexDeepSeedK",
+    "awfmGpuSearchHitsPacked", "awfmGpuLocateTo", "awfmGpuSearchHitsLineTally", "awfmGpuIndexDeepSeedK", "awfmGpuSearchHitsCompact", "awfmGpuCompactHits", "awfmGpuSortHits",
+    "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse",
 ]
 # int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
 CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
 
 
+# int sink(void *user, uint64 firstKmer, uint64 numKmers, uint64 numHitKmers, const uint32 *hitKmers, const uint64 *hitOffsets,
+#          const uint64 *positions, uint64 numPositions)
+SPARSE_CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                C.POINTER(C.c_uint64), C.c_uint64)
 # int sink(void *user, uint64 queryBegin, uint64 queryEnd, uint64 hitBegin, uint64 hitEnd, const uint64 *positions)
 HIT_WINDOW_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64))
 
@@ -151,6 +156,9 @@ def lib():
         "awfmGpuSearch": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuSearchHits": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuSearchHitsSparse": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
+        "awfmGpuSearchHitsCompact": (C.c_int, [vp, vp, vp, C.c_uint32, u64, C.c_int, vp, vp, C.c_uint32, vp, vp]),
+        "awfmGpuCompactHits": (C.c_int, [vp, vp, vp, u64, vp, vp, vp, vp, C.c_uint32, vp, vp]),
+        "awfmGpuSortHits": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
         "awfmGpuScanScratchBytes": (u64, [u64]),
         "awfmGpuHitOffsets": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),
         "awfmGpuHitOffsetsFromCounts": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),
@@ -179,6 +187,8 @@ def lib():
         "awfmGpuHostFree": (None, [vp]),
         "awfmGpuStreamPacked": (C.c_int, [vp, vp, C.c_uint32, u64, u64, C.c_int, C.c_uint, CHUNK_SINK, vp]),
         "awfmGpuStreamChars": (C.c_int, [vp, vp, C.c_uint32, u64, u64, C.c_int, C.c_uint, CHUNK_SINK, vp]),
+        "awfmGpuStreamPackedSparse": (C.c_int, [vp, vp, C.c_uint32, u64, u64, C.c_int, C.c_uint, SPARSE_CHUNK_SINK, vp]),
+        "awfmGpuStreamCharsSparse": (C.c_int, [vp, vp, C.c_uint32, u64, u64, C.c_int, C.c_uint, SPARSE_CHUNK_SINK, vp]),
         "awfmGpuCountPackedHost": (C.c_int, [vp, vp, C.c_uint32, u64, vp]),
         "awfmGpuLocatePackedHost": (C.c_int, [vp, vp, C.c_uint32, u64, vp, C.POINTER(C.POINTER(u64)), C.POINTER(u64)]),
     }

@@ -196,7 +196,9 @@ class KmerSearchList:
 
     def positions(self, i):
         d = self.ptr.contents.kmerSearchData[i]
-        return np.array([d.positionList[j] for j in range(d.count)], dtype=np.uint64)
+        if not d.count:
+            return np.zeros(0, np.uint64)
+        return np.ctypeslib.as_array(d.positionList, shape=(d.count,)).astype(np.uint64)
 
     def dealloc(self):
         if self.ptr:
@@ -362,6 +364,35 @@ class GpuIndex:
             return None
         return counts, (np.concatenate(parts) if parts else np.zeros(0, np.uint64)) if locate else None
 
+    def stream_sparse(self, kmers, kmer_length, locate=True, chunk=0, packed=True, threads=4, sink=None):
+        """awfmGpuStreamPackedSparse / awfmGpuStreamCharsSparse.  Without a sink the chunks are gathered: returns
+        (hit_kmers uint64[m] batch-wide numbers, hit_offsets uint64[m+1], positions uint64[total] or None)."""
+        L = _lib.lib()
+        if isinstance(kmers, tuple):
+            address, n = kmers
+        else:
+            kmers = np.ascontiguousarray(kmers, dtype=np.uint64 if packed else np.uint8)
+            n = kmers.size if packed else kmers.size // kmer_length
+            address = kmers.ctypes.data if kmers.size else None
+        ids, lens, parts = [], [], []
+
+        def gather(user, first, m, num, hit_kmers, hit_offsets, p, total):
+            if num:
+                ids.append(np.ctypeslib.as_array(hit_kmers, shape=(num,)).astype(np.uint64) + np.uint64(first))
+                lens.append(np.diff(np.ctypeslib.as_array(hit_offsets, shape=(num + 1,))))
+            if locate and total:
+                parts.append(np.ctypeslib.as_array(p, shape=(total,)).copy())
+            return 0
+
+        cb = _lib.SPARSE_CHUNK_SINK(sink or gather)
+        fn = L.awfmGpuStreamPackedSparse if packed else L.awfmGpuStreamCharsSparse
+        _check(fn.__name__, fn(self.handle, address, kmer_length, n, chunk, int(bool(locate)), threads, cb, None))
+        if sink is not None:
+            return None
+        hit_kmers = np.concatenate(ids) if ids else np.zeros(0, np.uint64)
+        offsets = np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.uint64) if lens else np.zeros(1, np.uint64)
+        return hit_kmers, offsets, (np.concatenate(parts) if parts else np.zeros(0, np.uint64)) if locate else None
+
     def count_packed_host(self, packed, kmer_length):
         packed = np.ascontiguousarray(packed, dtype=np.uint64)
         counts = np.zeros(packed.size, np.uint32)
@@ -415,6 +446,21 @@ class GpuIndex:
         _check("awfmGpuSearchHitsPacked", _lib.lib().awfmGpuSearchHitsPacked(
             self.handle, d_packed, kmer_length, n, d_ranges or None, d_counts or None, d_chars_scratch or None, stream or None))
 
+    def search_hits_compact(self, d_chars, d_offsets, fixed_length, n, d_hit_kmers, d_hit_ranges, capacity, d_num_hits,
+                            packed=False, stream=0):
+        """awfmGpuSearchHitsCompact: the k-mers with hits appended to a list (seed-order path only)"""
+        _check("awfmGpuSearchHitsCompact", _lib.lib().awfmGpuSearchHitsCompact(
+            self.handle, d_chars, d_offsets or None, fixed_length, n, int(bool(packed)), d_hit_kmers, d_hit_ranges, capacity,
+            d_num_hits, stream or None))
+
+    def compact_hits(self, d_counts, d_ranges, n, d_flag_offsets, d_scratch, d_hit_kmers, d_hit_ranges, capacity, d_num_hits,
+                     stream=0):
+        _check("awfmGpuCompactHits", _lib.lib().awfmGpuCompactHits(self.handle, d_counts, d_ranges, n, d_flag_offsets, d_scratch,
+                                                                   d_hit_kmers, d_hit_ranges, capacity, d_num_hits, stream or None))
+
+    def sort_hits(self, d_hit_kmers, d_hit_ranges, num_entries, stream=0):
+        _check("awfmGpuSortHits", _lib.lib().awfmGpuSortHits(self.handle, d_hit_kmers, d_hit_ranges, num_entries, stream or None))
+
     def search_hits_is_ordered(self, has_offsets, fixed_length, n):
         return bool(_lib.lib().awfmGpuSearchHitsIsOrdered(self.handle, int(bool(has_offsets)), fixed_length, n))
 
@@ -457,6 +503,11 @@ class GpuIndex:
     def locate(self, d_ranges, d_hit_offsets, n, total_hits, d_positions, stream=0):
         _check("awfmGpuLocate", _lib.lib().awfmGpuLocate(self.handle, d_ranges, d_hit_offsets, n, total_hits,
                                                          d_positions, stream or None))
+
+    def locate_window(self, d_ranges, d_hit_offsets, query_begin, query_end, hit_begin, hit_end, d_positions, stream=0):
+        """awfmGpuLocateWindow: the hits numbered hit_begin .. hit_end-1 of the batch's flat hit list"""
+        _check("awfmGpuLocateWindow", _lib.lib().awfmGpuLocateWindow(self.handle, d_ranges, d_hit_offsets, query_begin, query_end,
+                                                                     hit_begin, hit_end, d_positions, d_positions, stream or None))
 
     @staticmethod
     def scan_scratch_bytes(n):

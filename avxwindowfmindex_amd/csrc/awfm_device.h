@@ -91,6 +91,10 @@ struct DevIndex {
    * invalid range; NULL when not built */
   const ulonglong2 *deepSeed;
   unsigned int deepK;
+  /* entries of the deeper table: 16 bytes {sp, ep}, or (1) 8 bytes {sp, length} on images below 2^32 positions -- exact:
+   * the stepping stops at the FIRST empty range, and that one is always {sp, sp - 1} (sp = C + Occ(sp' - 1),
+   * ep = C + Occ(ep') - 1 from a valid {sp', ep'}), so a length of 0 says all there is to say; sp >= 1 always */
+  unsigned int deepNarrow;
   /* optional device-only pair image (nucleotide; awfm_pair.h): two backward / LF steps per block read; NULL when
    * not built.  pairSuper32 is the 32-bit copy of the superblock bases the kernels of images below 2^32 positions
    * keep in LDS (kPairSuperStride words per superblock). */
@@ -102,6 +106,14 @@ struct DevIndex {
   unsigned int pairSuperInLds; /* set per launch: the kernel was given numPairSuper * 64 bytes of dynamic LDS for pairSuper32 */
 };
 
+__device__ __forceinline__ ulonglong2 deepSeedEntry(const DevIndex &ix, unsigned long long i) {
+  if (ix.deepNarrow) { /* image-wide: uniform */
+    const uint2 e = ((const uint2 *)ix.deepSeed)[i];
+    return make_ulonglong2((unsigned long long)e.x, (unsigned long long)e.x + e.y - 1ull);
+  }
+  return ix.deepSeed[i];
+}
+
 /* a nucleotide query prepared for the ordered search path (awfm_ordered_kernel.h) */
 struct QueryRec {
   unsigned long long codes; /* 2-bit letter codes of the k-mer, last character in bits 1..0 */
@@ -110,6 +122,34 @@ struct QueryRec {
 };
 
 constexpr int kThreads = 256;
+
+/* Sparse results (awfmGpuSearchHitsCompact): instead of a range / count under every query number, the k-mers with hits
+ * are appended to a list {query number, range}, one returning atomic per wave instruction that has any (the order of the
+ * list is whatever the waves make it: awfmGpuSortHits puts it in query order).  Entries beyond `cap` are counted, not
+ * stored.  count == NULL: dense results. */
+struct SparseOut {
+  unsigned *count;
+  unsigned cap;
+  unsigned *kmers;
+  ulonglong2 *ranges;
+};
+__device__ __forceinline__ void sparseAppend(const SparseOut &out, bool hit, unsigned index, unsigned long long sp,
+                                             unsigned long long ep) {
+  const unsigned long long mask = __ballot(hit);
+  if (mask == 0ull) return; /* wave-uniform */
+  const unsigned lane = threadIdx.x & 63u;
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned base = 0;
+  if ((int)lane == leader) base = atomicAdd(out.count, (unsigned)__popcll(mask));
+  base = (unsigned)__shfl((int)base, leader, 64);
+  if (hit) {
+    const unsigned slot = base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    if (slot < out.cap) {
+      out.kmers[slot] = index;
+      out.ranges[slot] = make_ulonglong2(sp, ep);
+    }
+  }
+}
 
 /* BWT positions are 32-bit when bwtLength < 2^32 (NARROW): half the integer work of the range arithmetic */
 template <bool NARROW>
@@ -664,6 +704,8 @@ struct AwFmGpuIndex {
   size_t workBytes = 0;
   void *dHits = nullptr; /* positions of the host-buffer locate calls, grow-only like dWork */
   size_t hitsBytes = 0;
+  void *dSparse = nullptr; /* temporaries of awfmGpuSortHits, grow-only (under orderMutex) */
+  size_t sparseBytes = 0;
   hipEvent_t windowEvent[2] = {nullptr, nullptr}; /* the two hit windows in flight of awfmGpuLocateHostWindows */
   /* ordered search path (awfm_gpu_ordered.hip): grow-only scratch shared by all searches on this image;
    * the event orders its re-use across streams */
@@ -767,6 +809,9 @@ enum AwFmReturnCode awfmGpuHitOffsetsAsync(AwFmGpuIndex *g, const uint32_t *dCou
 /* hits whose positions may be resident on the device at once (awfm_gpu.hip: $AWFM_GPU_HIT_BUDGET_BYTES / 8, else a quarter
  * of the free device memory); `C` linkage like the rest of the shim */
 extern "C" uint64_t awfmGpuHitBudget(const AwFmGpuIndex *g);
+/* exclusive scan of the flags (counts[i] != 0) into dFlagOffsets[0..n] (awfm_gpu.hip); scratch as for the hit offsets */
+enum AwFmReturnCode awfmGpuScanFlags(AwFmGpuIndex *g, const uint32_t *dCounts, uint64_t numQueries, uint64_t *dFlagOffsets,
+                                     void *dScratch, hipStream_t s);
 /* awfm_gpu_build.hip: level-wise construction of the deeper seed table into a new device buffer */
 bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut);
 void awfmGpuSetError(const char *what);

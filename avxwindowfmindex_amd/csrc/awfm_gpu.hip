@@ -41,7 +41,7 @@ constexpr int kScanTile = kScanThreads * kScanItems;
 /* per-tile sums */
 /* element i of a scan input: a plain u64 array (SOURCE 0), the length of range i (1; ref
  * src/AwFmIndexStruct.c:126-130), or a u32 count (2) */
-constexpr int kScanU64 = 0, kScanRanges = 1, kScanU32 = 2;
+constexpr int kScanU64 = 0, kScanRanges = 1, kScanU32 = 2, kScanFlags = 3; /* 3: 1 where a u32 count is not 0 */
 template <int SOURCE>
 __device__ __forceinline__ unsigned long long scanInput(const void *in, unsigned long long i) {
   if (SOURCE == kScanRanges) {
@@ -49,6 +49,7 @@ __device__ __forceinline__ unsigned long long scanInput(const void *in, unsigned
     return r.x <= r.y ? r.y - r.x + 1ull : 0ull;
   }
   if (SOURCE == kScanU32) return ((const unsigned *)in)[i];
+  if (SOURCE == kScanFlags) return ((const unsigned *)in)[i] != 0u ? 1ull : 0ull;
   return ((const unsigned long long *)in)[i];
 }
 
@@ -238,6 +239,7 @@ void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned super
   d.seedK = index->config.kmerLengthInSeedTable;
   d.deepSeed = nullptr;
   d.deepK = 0;
+  d.deepNarrow = 0;
   d.pairBlocks = nullptr;
   d.pairSuper = nullptr;
   d.pairSuper32 = nullptr;
@@ -541,6 +543,7 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
     if (g->dWork) (void)hipFree(g->dWork);
     if (g->dHits) (void)hipFree(g->dHits);
     if (g->dOrder) (void)hipFree(g->dOrder);
+    if (g->dSparse) (void)hipFree(g->dSparse);
     if (g->orderEvent) (void)hipEventDestroy(g->orderEvent);
     for (int i = 0; i < 2; i++)
       if (g->orderTiming[i]) (void)hipEventDestroy(g->orderTiming[i]);
@@ -736,6 +739,7 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
   g->deepSeedBytes = 0;
   g->dev.deepSeed = nullptr;
   g->dev.deepK = 0;
+  g->dev.deepNarrow = 0;
   enum AwFmReturnCode rc = AwFmSuccess;
   if (deepK != 0) {
     void *table = nullptr;
@@ -745,6 +749,7 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
       g->deepSeedBytes = bytes;
       g->dev.deepSeed = (const ulonglong2 *)table;
       g->dev.deepK = deepK;
+      g->dev.deepNarrow = g->dev.bwtLength < (1ull << 32) ? 1u : 0u;
     } else {
       rc = AwFmGeneralFailure;
     }
@@ -752,6 +757,7 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
   for (AwFmGpuIndex *lane : laneList) {
     lane->dDeepSeed = g->dDeepSeed;
     lane->dev.deepSeed = g->dev.deepSeed;
+    lane->dev.deepNarrow = g->dev.deepNarrow;
     lane->dev.deepK = g->dev.deepK;
   }
   return rc;
@@ -1061,6 +1067,15 @@ enum AwFmReturnCode awfmGpuHitOffsetsAsync(AwFmGpuIndex *g, const uint32_t *dCou
   if (rc != AwFmSuccess) return rc;
   AWFM_HIP_TRY(hipMemcpyAsync(pinnedTotal, dHitOffsets + numQueries, 8, hipMemcpyDeviceToHost, s), AwFmGeneralFailure);
   return AwFmSuccess;
+}
+
+enum AwFmReturnCode awfmGpuScanFlags(AwFmGpuIndex *g, const uint32_t *dCounts, uint64_t numQueries, uint64_t *dFlagOffsets,
+                                     void *dScratch, hipStream_t s) {
+  if (!g || !dCounts || !dFlagOffsets || !dScratch || numQueries == 0) {
+    setError("awfmGpuScanFlags: null argument");
+    return AwFmNullPtrError;
+  }
+  return scanRecursive<kScanFlags>(dCounts, numQueries, (unsigned long long *)dFlagOffsets, (unsigned long long *)dScratch, s);
 }
 
 extern "C" {

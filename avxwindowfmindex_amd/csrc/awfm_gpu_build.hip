@@ -350,7 +350,8 @@ __global__ void __launch_bounds__(kThreads)
  * so that a round costs one memory latency for U entries (the one-entry-per-round kernel above is bound by that latency:
  * 3.6 s for the two levels from k = 12 to 14 of a 3.1 Gbp index).  Consecutive entries have consecutive parents, whose
  * ranges are neighbours in the BWT: the U steps of a round mostly read the same few lines. */
-template <int U>
+/* OUT8: the level is the table itself on an image below 2^32 positions: 8-byte entries {sp, length} (awfm_device.h) */
+template <int U, bool OUT8>
 __global__ void __launch_bounds__(kThreads)
     deepSeedLevelKernel(const DevIndex ix, const ulonglong2 *__restrict__ parentLevel, u64 parentLen, u64 outLen,
                         ulonglong2 *__restrict__ out) {
@@ -387,7 +388,10 @@ __global__ void __launch_bounds__(kThreads)
     for (int u = 0; u < U; u++) {
       u64 a = sp[u], b = ep[u];
       if (step[u]) nucStepAnyRank<G, false>(ix, sC, sSuper, g, letter[u], &p0[u], &p1[u], a, b);
-      if (g == 0 && base + u < outLen) out[base + u] = make_ulonglong2(a, b);
+      if (g == 0 && base + u < outLen) {
+        if (OUT8) ((uint2 *)out)[base + u] = make_uint2((unsigned)a, (unsigned)(b + 1ull - a));
+        else out[base + u] = make_ulonglong2(a, b);
+      }
     }
   }
 }
@@ -636,13 +640,18 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
   const ulonglong2 *parent = g->dev.seed;
   for (unsigned L = K; L < deepK; L++) {
     const u64 outLen = len * 4;
-    if (!nxt.alloc(outLen * 16)) return false;
+    const bool out8 = L + 1 == deepK && g->dev.bwtLength < (1ull << 32); /* the table itself, 8-byte entries */
+    if (!nxt.alloc(outLen * (out8 ? 8 : 16))) return false;
     constexpr int kUnroll = 4;
     const u64 blocks = (outLen + kSeedGroupsPerBlock * kUnroll - 1) / (kSeedGroupsPerBlock * kUnroll);
     const u64 resident = (u64)g->numCUs * 8u; /* a persistent grid: what does not fit the chip would only queue */
     const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
-    hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen,
-                       nxt.as<ulonglong2>());
+    if (out8)
+      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, true>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen,
+                         nxt.as<ulonglong2>());
+    else
+      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, false>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen,
+                         nxt.as<ulonglong2>());
     BUILD_TRY(hipGetLastError());
     BUILD_TRY(hipDeviceSynchronize());
     if (getenv("AWFM_VERBOSE")) fprintf(stderr, "[awfm deep seed] level %u -> %u: %llu entries\n", L, L + 1, (unsigned long long)outLen);
@@ -651,7 +660,7 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
     parent = cur.as<ulonglong2>();
     len = outLen;
   }
-  *bytesOut = len * 16;
+  *bytesOut = len * (g->dev.bwtLength < (1ull << 32) ? 8 : 16);
   *tableOut = cur.release();
   return true;
 }

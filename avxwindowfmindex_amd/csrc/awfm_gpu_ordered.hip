@@ -60,7 +60,7 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
                                         unsigned long long nq, const void *recs, const unsigned short *keys,
                                         const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts,
                                         const OrderTouch *touch = nullptr, const unsigned *bucketStart = nullptr,
-                                        const BucketFormat bucketFmt = BucketFormat()) {
+                                        const BucketFormat bucketFmt = BucketFormat(), const SparseOut *sparse = nullptr) {
   /* dynamic LDS: the 32-bit superblock bases of the pair image (images below 2^32 positions) */
   const bool superInLds = PAIR && NARROW && awfmPairSuperInLds(g);
   const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u; /* the 16 pair bases of every superblock */
@@ -81,7 +81,7 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
   hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET>), dim3(grid ? grid : 1u), dim3(threads), lds, s, dev, recs,
                      keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
                      getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0, touch ? *touch : OrderTouch(), bucketStart,
-                     bucketFmt);
+                     bucketFmt, sparse ? *sparse : SparseOut());
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[1], s), AwFmGeneralFailure);
   g->orderTimed = timed;
@@ -92,7 +92,8 @@ template <bool NARROW, bool COMPACT, bool VARLEN>
 enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                                   uint32_t len, unsigned depth, const ulonglong2 *table, unsigned long long nq,
                                   const void *recs, const unsigned short *keys, const unsigned *generalCount,
-                                  ulonglong2 *rng, uint32_t *dCounts, bool packed = false, const OrderTouch *touch = nullptr) {
+                                  ulonglong2 *rng, uint32_t *dCounts, bool packed = false, const OrderTouch *touch = nullptr,
+                                  const SparseOut *sparse = nullptr) {
   if (touch) { /* instrumented launch: the variant the image would run (4 lanes per k-mer, pair steps when it has the pair image) */
     if constexpr (COMPACT) { /* the sorted 8-byte records ($AWFM_GPU_ORDERED_SORT=rocprim) are a measurement path: no tally */
       setError("awfmGpuSearchHitsLineTally: not available with $AWFM_GPU_ORDERED_SORT=rocprim");
@@ -107,11 +108,12 @@ enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t 
     const char *lanes = getenv("AWFM_GPU_ORDERED_LANES"); /* measurement knob: 1 | 2 | 4 lanes per query (default 4) */
     const int G = lanes ? atoi(lanes) : 4;
     enum AwFmReturnCode rc;
+    const BucketFormat none = BucketFormat();
     if (G == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR"))
-      rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN, true>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
-    else if (G == 2) rc = launchOrderedKernel<2, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
-    else if (G == 1) rc = launchOrderedKernel<1, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
-    else rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts);
+      rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN, true>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse);
+    else if (G == 2) rc = launchOrderedKernel<2, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse);
+    else if (G == 1) rc = launchOrderedKernel<1, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse);
+    else rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse);
     if (rc != AwFmSuccess) return rc;
   }
   if (packed) return AwFmSuccess; /* bit-packed k-mers: every one of them is covered */
@@ -121,7 +123,7 @@ enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t 
   hipLaunchKernelGGL((searchKernel<false, 4, VARLEN, false, NARROW, true>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
                      off, len, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)recs,
                      COMPACT ? 8u : (unsigned)sizeof(QueryRec), COMPACT ? 0u : (unsigned)offsetof(QueryRec, index), nq,
-                     generalCount);
+                     generalCount, sparse ? *sparse : SparseOut());
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
 }
@@ -131,21 +133,21 @@ template <bool NARROW>
 enum AwFmReturnCode launchBucketed(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t len, unsigned depth,
                                    const ulonglong2 *table, unsigned long long nq, const void *recs, const unsigned *bucketStart,
                                    const BucketFormat &fmt, const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts,
-                                   bool packed, const OrderTouch *touch) {
+                                   bool packed, const OrderTouch *touch, const SparseOut *sparse) {
   const bool pair = g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR");
   enum AwFmReturnCode rc;
   if (touch)
     rc = pair ? launchOrderedKernel<4, NARROW, true, false, true, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, touch, bucketStart, fmt)
               : launchOrderedKernel<4, NARROW, true, false, false, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, touch, bucketStart, fmt);
   else
-    rc = pair ? launchOrderedKernel<4, NARROW, true, false, true, false, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt)
-              : launchOrderedKernel<4, NARROW, true, false, false, false, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt);
+    rc = pair ? launchOrderedKernel<4, NARROW, true, false, true, false, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse)
+              : launchOrderedKernel<4, NARROW, true, false, false, false, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse);
   if (rc != AwFmSuccess || packed) return rc; /* bit-packed k-mers: every one of them is covered */
   /* the last bucket: k-mers with ambiguity characters; a record of it is the query number alone */
   const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, NARROW, true>);
   hipLaunchKernelGGL((searchKernel<false, 4, false, false, NARROW, true>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
                      (const unsigned long long *)nullptr, len, nq, rng, dCounts, (unsigned long long *)nullptr,
-                     (const unsigned char *)recs, 8u, 0u, nq, generalCount);
+                     (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut());
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
 }
@@ -202,7 +204,8 @@ extern "C" int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets,
 /* 1: the batch was searched; 0: the ordered path does not apply (caller runs the general kernel); <0: -AwFmReturnCode */
 static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                          uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
-                         bool rangesOfHitsOnly, const OrderTouch *touch, uint64_t *recordBytesOut);
+                         bool rangesOfHitsOnly, const OrderTouch *touch, uint64_t *recordBytesOut,
+                         const SparseOut *sparse);
 
 /* scratch of the image, grown when needed; the caller holds orderMutex.  false: no memory (the general kernel needs none) */
 static bool ensureOrderScratch(AwFmGpuIndex *g, size_t bytes) {
@@ -220,11 +223,25 @@ static bool ensureOrderScratch(AwFmGpuIndex *g, size_t bytes) {
   return true;
 }
 
+/* encodeCodes4Kernel<K> for the batch's k-mer length */
+template <unsigned K>
+static void launchEncode4At(unsigned len, unsigned grid, size_t lds, hipStream_t s, const uint8_t *dChars, const BucketFormat &fmt,
+                            unsigned long long nq, unsigned long long *codes, unsigned *hist) {
+  if (len == K)
+    hipLaunchKernelGGL((encodeCodes4Kernel<K>), dim3(grid), dim3(256), lds, s, dChars, fmt, nq, codes, hist);
+  else if constexpr (K > 1u)
+    launchEncode4At<K - 1u>(len, grid, lds, s, dChars, fmt, nq, codes, hist);
+}
+static void launchEncode4(unsigned len, unsigned grid, size_t lds, hipStream_t s, const uint8_t *dChars, const BucketFormat &fmt,
+                          unsigned long long nq, unsigned long long *codes, unsigned *hist) {
+  launchEncode4At<32u>(len, grid, lds, s, dChars, fmt, nq, codes, hist);
+}
+
 /* fillNoHitKernel -> encodeCodesKernel -> bucketScanKernel -> partitionKernel -> orderedSearchKernel<BUCKET> ->
  * searchKernel<INDIRECT> on the caller's stream; the caller holds orderMutex.  Return values as awfmGpuOrderedSearch. */
 static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength, unsigned depth,
                           const ulonglong2 *table, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
-                          bool rangesOfHitsOnly, const OrderTouch *touch, const BucketFormat &fmt) {
+                          bool rangesOfHitsOnly, const OrderTouch *touch, const BucketFormat &fmt, const SparseOut *sparse) {
   const unsigned bins = (1u << fmt.bucketBits) + 1u, binsPad = (bins + 3u) & ~3u;
   /* [counters 32 KB][hist: bins][cursors: bins][bucketStart: bins + 1][codes: nq x 8 unless packed][records: nq x 8] */
   const size_t histAt = kOrderCounterBytes, cursorsAt = histAt + alignUp256(bins * 4u), startAt = cursorsAt + alignUp256(bins * 4u);
@@ -248,17 +265,21 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   const unsigned long long *codes = packed ? (const unsigned long long *)dChars : (const unsigned long long *)(w + codesAt);
   unsigned long long *recs = (unsigned long long *)(w + recsAt);
   BUCKET_TRY(hipMemsetAsync(w, 0, startAt, s)); /* the count, the ticket counters, the histogram, the cursors */
-  hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
-                     rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
-  BUCKET_TRY(hipGetLastError());
+  if (!sparse) { /* a sparse search lists its hits: there is nothing to pre-fill */
+    hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
+                       rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
+    BUCKET_TRY(hipGetLastError());
+  }
   const unsigned long long encodeTiles = (nq + 255ull) / 256ull;
   const unsigned encodeGrid = (unsigned)(encodeTiles < (unsigned long long)g->numCUs * 8u ? encodeTiles : (unsigned long long)g->numCUs * 8u);
   if (packed)
     hipLaunchKernelGGL((encodeCodesKernel<true>), dim3(encodeGrid), dim3(256), bins * 4u, s, dChars, fixedLength, fmt, nq,
                        (unsigned long long *)nullptr, hist);
-  else
+  else if (getenv("AWFM_GPU_ENCODE_ONE")) /* measurement knob: one k-mer per thread */
     hipLaunchKernelGGL((encodeCodesKernel<false>), dim3(encodeGrid), dim3(256), bins * 4u, s, dChars, fixedLength, fmt, nq,
                        (unsigned long long *)(w + codesAt), hist);
+  else
+    launchEncode4(fixedLength, encodeGrid, bins * 4u, s, dChars, fmt, nq, (unsigned long long *)(w + codesAt), hist);
   BUCKET_TRY(hipGetLastError());
   hipLaunchKernelGGL(bucketScanKernel, dim3(1), dim3(1024), 0, s, (const unsigned *)hist, bins, bucketStart, generalCount);
   BUCKET_TRY(hipGetLastError());
@@ -273,11 +294,12 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   const unsigned long long tiles = (nq + kPartitionTile - 1ull) / kPartitionTile;
   const unsigned partitionGrid = (unsigned)(tiles < (unsigned long long)g->numCUs ? tiles : (unsigned long long)g->numCUs);
   hipLaunchKernelGGL(partitionKernel, dim3(partitionGrid), dim3(kPartitionThreads), partitionLds, s, codes, fixedLength, fmt, nq,
-                     (const unsigned *)bucketStart, cursors, recs, packed ? 0u : 1u);
+                     (const unsigned *)bucketStart, cursors, recs, packed ? 0u : 1u,
+                     getenv("AWFM_GPU_PARTITION_PROBE") ? (unsigned)atoi(getenv("AWFM_GPU_PARTITION_PROBE")) : 0u);
   BUCKET_TRY(hipGetLastError());
   const enum AwFmReturnCode rc =
-      awfmImageNarrow(g) ? launchBucketed<true>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch)
-                         : launchBucketed<false>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch);
+      awfmImageNarrow(g) ? launchBucketed<true>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse)
+                         : launchBucketed<false>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse);
   if (rc != AwFmSuccess) return -(int)rc;
   BUCKET_TRY(hipEventRecord(g->orderEvent, s));
   g->orderEventRecorded = true;
@@ -288,12 +310,12 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
 int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                          uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
                          bool rangesOfHitsOnly) {
-  return orderedSearch(g, s, dChars, off, fixedLength, nq, rng, dCounts, packed, rangesOfHitsOnly, nullptr, nullptr);
+  return orderedSearch(g, s, dChars, off, fixedLength, nq, rng, dCounts, packed, rangesOfHitsOnly, nullptr, nullptr, nullptr);
 }
 
 static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                          uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
-                         bool rangesOfHitsOnly, const OrderTouch *touch, uint64_t *recordBytesOut) {
+                         bool rangesOfHitsOnly, const OrderTouch *touch, uint64_t *recordBytesOut, const SparseOut *sparse) {
   unsigned depth = 0;
   const ulonglong2 *table = nullptr;
   if (packed && off) return 0;
@@ -309,7 +331,7 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
                         !getenv("AWFM_GPU_ORDERED_WIDE");
   if (bucketed) {
     if (recordBytesOut) *recordBytesOut = 8u;
-    return bucketedSearch(g, s, dChars, fixedLength, depth, table, nq, rng, dCounts, packed, rangesOfHitsOnly, touch, bucketFmt);
+    return bucketedSearch(g, s, dChars, fixedLength, depth, table, nq, rng, dCounts, packed, rangesOfHitsOnly, touch, bucketFmt, sparse);
   }
   const bool compact = !off && orderCompact(fixedLength, depth) && !getenv("AWFM_GPU_ORDERED_WIDE");
   if (recordBytesOut) *recordBytesOut = compact ? 8u + 2u : sizeof(QueryRec); /* what the search reads per k-mer: record (+ key) */
@@ -364,9 +386,11 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   ORDER_TRY(hipMemsetAsync(generalCount, 0, kOrderCounterBytes, s)); /* the count and the ticket counters */
   /* rangesOfHitsOnly (awfmGpuSearchHitsSparse): the counts say which k-mers have hits, so only the counts are
    * pre-filled and the ranges of the others stay as the caller left them -- 16 of the 20 bytes per k-mer not written */
-  hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
-                     rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
-  ORDER_TRY(hipGetLastError());
+  if (!sparse) {
+    hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
+                       rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
+    ORDER_TRY(hipGetLastError());
+  }
   const unsigned encodeGrid = (unsigned)((nq + 255) / 256);
   const unsigned seedK = g->dev.seedK, deepK = g->dev.deepK;
   unsigned keyMask = 0xFFFFu;
@@ -402,7 +426,7 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   const bool narrow = awfmImageNarrow(g);
   enum AwFmReturnCode rc;
 #define ORDER_GO(NR, CP, VL) \
-  launchOrdered<NR, CP, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts, packed, touch)
+  launchOrdered<NR, CP, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts, packed, touch, sparse)
   if (off) rc = narrow ? ORDER_GO(true, false, true) : ORDER_GO(false, false, true);
   else if (compact) rc = narrow ? ORDER_GO(true, true, false) : ORDER_GO(false, true, false);
   else rc = narrow ? ORDER_GO(true, false, false) : ORDER_GO(false, false, false);
@@ -441,7 +465,7 @@ extern "C" enum AwFmReturnCode awfmGpuSearchHitsLineTally(AwFmGpuIndex *g, const
   }
   DeviceGuard guard(g->device);
   const uint64_t seedWords = (g->dev.seedLen * 16u / 128u + 64u) / 64u;
-  const uint64_t deepWords = g->dev.deepK ? ((1ull << (2u * g->dev.deepK)) * 16u / 128u + 64u) / 64u : 1u;
+  const uint64_t deepWords = g->dev.deepK ? ((1ull << (2u * g->dev.deepK)) * (g->dev.deepNarrow ? 8u : 16u) / 128u + 64u) / 64u : 1u;
   const uint64_t pairWords = (g->numBlocks + 64u) / 64u, nucWords = (g->numBlocks / 2u + 64u) / 64u;
   const uint64_t words = seedWords + deepWords + (uint64_t)kTouchLevels * (pairWords + nucWords) + 8u;
   unsigned long long *bits = nullptr;
@@ -465,7 +489,7 @@ extern "C" enum AwFmReturnCode awfmGpuSearchHitsLineTally(AwFmGpuIndex *g, const
   hipError_t e = hipMemsetAsync(bits, 0, words * 8u, s);
   if (e == hipSuccess) {
     const int did = orderedSearch(g, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries, nullptr, nullptr, false,
-                                  false, &touch, &recordBytes);
+                                  false, &touch, &recordBytes, nullptr);
     if (did <= 0) rc = did < 0 ? (enum AwFmReturnCode)(-did) : AwFmGeneralFailure;
   }
   unsigned generalCount = 0;
@@ -495,5 +519,144 @@ extern "C" enum AwFmReturnCode awfmGpuSearchHitsLineTally(AwFmGpuIndex *g, const
   tallyOut[5] = recordBytes;                  /* bytes of sorted record (+ key) it reads per k-mer */
   tallyOut[6] = host[0];                      /* k-mers with hits (each stores its result) */
   tallyOut[7] = generalCount;                 /* k-mers left to the general kernel (ambiguity characters, > 32 characters) */
+  return AwFmSuccess;
+}
+
+/* ------------------------------------------------------------------ sparse results */
+
+namespace {
+__global__ void __launch_bounds__(256) fillSparseKernel(unsigned *__restrict__ kmers, ulonglong2 *__restrict__ ranges, unsigned cap,
+                                                        unsigned *__restrict__ count) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i < cap) {
+    kmers[i] = 0xFFFFFFFFu; /* sorts behind every k-mer */
+    ranges[i] = make_ulonglong2(1ull, 0ull);
+  }
+  if (i == 0) *count = 0u;
+}
+/* the list of the k-mers with hits out of dense results, in batch order: entry flagOffsets[i] when counts[i] != 0 */
+__global__ void __launch_bounds__(256) compactDenseKernel(const unsigned *__restrict__ counts, const ulonglong2 *__restrict__ ranges,
+                                                          const unsigned long long *__restrict__ flagOffsets, unsigned long long n,
+                                                          unsigned cap, unsigned *__restrict__ kmers, ulonglong2 *__restrict__ outRanges,
+                                                          unsigned *__restrict__ count) {
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull) {
+    if (counts[i] != 0u) {
+      const unsigned long long at = flagOffsets[i];
+      if (at < cap) {
+        kmers[at] = (unsigned)i;
+        outRanges[at] = ranges[i];
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *count = (unsigned)(flagOffsets[n] < 0xFFFFFFFFull ? flagOffsets[n] : 0xFFFFFFFFull);
+}
+}  // namespace
+
+/* see include/awfm_gpu.h */
+extern "C" enum AwFmReturnCode awfmGpuSearchHitsCompact(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                                        uint32_t fixedLength, uint64_t numQueries, int packed, uint32_t *dHitKmers,
+                                                        struct AwFmSearchRange *dHitRanges, uint32_t capacity, uint32_t *dNumHits,
+                                                        void *stream) {
+  if (!g || !dChars || !dHitKmers || !dHitRanges || !dNumHits) {
+    setError("awfmGpuSearchHitsCompact: null argument");
+    return AwFmNullPtrError;
+  }
+  if (capacity == 0) {
+    setError("awfmGpuSearchHitsCompact: the list needs a capacity");
+    return AwFmIllegalPositionError;
+  }
+  if (g->amino || !(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4) || (packed && dOffsets)) {
+    setError("awfmGpuSearchHitsCompact: this batch does not take the seed-order path on this image");
+    return AwFmUnsupportedVersionError;
+  }
+  DeviceGuard guard(g->device);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(fillSparseKernel, dim3((capacity + 255u) / 256u), dim3(256), 0, s, (unsigned *)dHitKmers, (ulonglong2 *)dHitRanges,
+                     (unsigned)capacity, (unsigned *)dNumHits);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  SparseOut sparse;
+  sparse.count = (unsigned *)dNumHits;
+  sparse.cap = capacity;
+  sparse.kmers = (unsigned *)dHitKmers;
+  sparse.ranges = (ulonglong2 *)dHitRanges;
+  const int did = orderedSearch(g, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries, nullptr, nullptr,
+                                packed != 0, false, nullptr, nullptr, &sparse);
+  if (did < 0) return (enum AwFmReturnCode)(-did);
+  if (did == 0) {
+    setError("awfmGpuSearchHitsCompact: this batch does not take the seed-order path on this image");
+    return AwFmUnsupportedVersionError;
+  }
+  return AwFmSuccess;
+}
+
+extern "C" enum AwFmReturnCode awfmGpuCompactHits(AwFmGpuIndex *g, const uint32_t *dCounts, const struct AwFmSearchRange *dRanges,
+                                                  uint64_t numQueries, uint64_t *dFlagOffsets, void *dScratch, uint32_t *dHitKmers,
+                                                  struct AwFmSearchRange *dHitRanges, uint32_t capacity, uint32_t *dNumHits,
+                                                  void *stream) {
+  if (!g || !dCounts || !dRanges || !dFlagOffsets || !dScratch || !dHitKmers || !dHitRanges || !dNumHits) {
+    setError("awfmGpuCompactHits: null argument");
+    return AwFmNullPtrError;
+  }
+  if (numQueries == 0 || numQueries >= 0xFFFFFFFFull) {
+    setError("awfmGpuCompactHits: 1 .. 2^32 - 2 k-mers");
+    return AwFmIllegalPositionError;
+  }
+  DeviceGuard guard(g->device);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(fillSparseKernel, dim3((capacity + 255u) / 256u), dim3(256), 0, s, (unsigned *)dHitKmers, (ulonglong2 *)dHitRanges,
+                     (unsigned)capacity, (unsigned *)dNumHits);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  const enum AwFmReturnCode rc = awfmGpuScanFlags(g, dCounts, numQueries, dFlagOffsets, dScratch, s);
+  if (rc != AwFmSuccess) return rc;
+  hipLaunchKernelGGL(compactDenseKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s, (const unsigned *)dCounts,
+                     (const ulonglong2 *)dRanges, (const unsigned long long *)dFlagOffsets, (unsigned long long)numQueries,
+                     (unsigned)capacity, (unsigned *)dHitKmers, (ulonglong2 *)dHitRanges, (unsigned *)dNumHits);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  return AwFmSuccess;
+}
+
+extern "C" enum AwFmReturnCode awfmGpuSortHits(AwFmGpuIndex *g, uint32_t *dHitKmers, struct AwFmSearchRange *dHitRanges,
+                                               uint32_t numEntries, void *stream) {
+  if (!g || !dHitKmers || !dHitRanges) {
+    setError("awfmGpuSortHits: null argument");
+    return AwFmNullPtrError;
+  }
+  if (numEntries < 2) return AwFmSuccess;
+  DeviceGuard guard(g->device);
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  size_t tempBytes = 0;
+  unsigned *nullKeys = nullptr;
+  ulonglong2 *nullValues = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, tempBytes, nullKeys, nullKeys, nullValues, nullValues, (size_t)numEntries, 0u, 32u, s) != hipSuccess) {
+    setError("awfmGpuSortHits: radix sort sizing failed");
+    return AwFmGeneralFailure;
+  }
+  const size_t keysAt = alignUp256(tempBytes), valuesAt = keysAt + alignUp256((size_t)numEntries * 4u);
+  const size_t total = valuesAt + alignUp256((size_t)numEntries * 16u);
+  if (total > g->sparseBytes) {
+    if (g->dSparse) (void)hipFree(g->dSparse);
+    g->dSparse = nullptr;
+    g->sparseBytes = 0;
+    if (hipMalloc(&g->dSparse, total + total / 4) != hipSuccess) {
+      (void)hipGetLastError();
+      setError("awfmGpuSortHits: no device memory for the sort");
+      return AwFmAllocationFailure;
+    }
+    g->sparseBytes = total + total / 4;
+  }
+  /* the temporaries are shared by every sort on this image: order their use across streams (as the searches' scratch is) */
+  if (!g->orderEvent) AWFM_HIP_TRY(hipEventCreateWithFlags(&g->orderEvent, hipEventDisableTiming), AwFmGeneralFailure);
+  if (g->orderEventRecorded) AWFM_HIP_TRY(hipStreamWaitEvent(s, g->orderEvent, 0), AwFmGeneralFailure);
+  uint8_t *w = (uint8_t *)g->dSparse;
+  unsigned *keysOut = (unsigned *)(w + keysAt);
+  ulonglong2 *valuesOut = (ulonglong2 *)(w + valuesAt);
+  AWFM_HIP_TRY(rocprim::radix_sort_pairs(w, tempBytes, (unsigned *)dHitKmers, keysOut, (ulonglong2 *)dHitRanges, valuesOut,
+                                         (size_t)numEntries, 0u, 32u, s),
+               AwFmGeneralFailure);
+  AWFM_HIP_TRY(hipMemcpyAsync(dHitKmers, keysOut, (size_t)numEntries * 4u, hipMemcpyDeviceToDevice, s), AwFmGeneralFailure);
+  AWFM_HIP_TRY(hipMemcpyAsync(dHitRanges, valuesOut, (size_t)numEntries * 16u, hipMemcpyDeviceToDevice, s), AwFmGeneralFailure);
+  AWFM_HIP_TRY(hipEventRecord(g->orderEvent, s), AwFmGeneralFailure);
+  g->orderEventRecorded = true;
   return AwFmSuccess;
 }

@@ -103,6 +103,14 @@ struct StreamSlot {
   u64 *hTotal = nullptr;
   u64 *hPositions = nullptr;
   size_t hCapPositions = 0;
+  /* sparse results (awfmGpuStream*Sparse): the k-mers with hits as a list */
+  void *dHitKmers = nullptr, *dHitRanges = nullptr, *dListOffsets = nullptr, *dNumHits = nullptr, *dFlagOffsets = nullptr;
+  size_t capList = 0, capFlags = 0;
+  uint32_t *hHitKmers = nullptr;
+  u64 *hListOffsets = nullptr;
+  size_t hCapList = 0;
+  u64 numHitKmers = 0;
+  uint32_t capUsed = 0; /* entries of the list buffers the chunk in the slot was searched with */
   u64 *hOffsets = nullptr; /* hit offsets of a chunk whose hits exceed the device's hit budget (taken in windows) */
   size_t hCapOffsets = 0;
   /* the chunk in the slot */
@@ -127,10 +135,11 @@ struct AwFmGpuStreamState {
 namespace {
 
 void freeSlot(StreamSlot &s) {
-  void *dev[] = {s.dIn, s.dChars, s.dRanges, s.dCounts, s.dHitOffsets, s.dScratch, s.dPositions};
+  void *dev[] = {s.dIn, s.dChars, s.dRanges, s.dCounts, s.dHitOffsets, s.dScratch, s.dPositions,
+                 s.dHitKmers, s.dHitRanges, s.dListOffsets, s.dNumHits, s.dFlagOffsets};
   for (void *p : dev)
     if (p) (void)hipFree(p);
-  void *host[] = {s.hIn, s.hCounts, s.hTotal, s.hPositions, s.hOffsets};
+  void *host[] = {s.hIn, s.hCounts, s.hTotal, s.hPositions, s.hOffsets, s.hHitKmers, s.hListOffsets};
   for (void *p : host)
     if (p) (void)hipHostFree(p);
   hipEvent_t events[] = {s.uploaded, s.searched, s.located, s.done, s.doneB};
@@ -222,6 +231,42 @@ enum AwFmReturnCode ensurePositions(StreamSlot &s, u64 total) {
       return AwFmAllocationFailure;
     }
     s.hCapPositions = want;
+  }
+  return AwFmSuccess;
+}
+
+/* the list buffers of a slot for `entries` k-mers with hits (device + page-locked host); flags: the scan work space of
+ * the dense -> list conversion (awfmGpuCompactHits) for a chunk of `kmers` */
+enum AwFmReturnCode ensureList(StreamSlot &s, size_t entries, size_t flagsForKmers) {
+  if (entries > s.capList) {
+    void **dev[] = {&s.dHitKmers, &s.dHitRanges, &s.dListOffsets};
+    for (void **p : dev) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    s.capList = 0;
+    STREAM_TRY(hipMalloc(&s.dHitKmers, entries * 4 + 256));
+    STREAM_TRY(hipMalloc(&s.dHitRanges, entries * 16 + 256));
+    STREAM_TRY(hipMalloc(&s.dListOffsets, (entries + 1) * 8 + 256));
+    if (!s.dNumHits) STREAM_TRY(hipMalloc(&s.dNumHits, 256));
+    s.capList = entries;
+  }
+  if (entries > s.hCapList) {
+    if (s.hHitKmers) (void)hipHostFree(s.hHitKmers);
+    if (s.hListOffsets) (void)hipHostFree(s.hListOffsets);
+    s.hHitKmers = nullptr;
+    s.hListOffsets = nullptr;
+    s.hCapList = 0;
+    STREAM_TRY(hipHostMalloc((void **)&s.hHitKmers, entries * 4 + 256, hipHostMallocDefault));
+    STREAM_TRY(hipHostMalloc((void **)&s.hListOffsets, (entries + 1) * 8 + 256, hipHostMallocDefault));
+    s.hCapList = entries;
+  }
+  if (flagsForKmers > s.capFlags) {
+    if (s.dFlagOffsets) (void)hipFree(s.dFlagOffsets);
+    s.dFlagOffsets = nullptr;
+    s.capFlags = 0;
+    STREAM_TRY(hipMalloc(&s.dFlagOffsets, (flagsForKmers + 1) * 8 + 256));
+    s.capFlags = flagsForKmers;
   }
   return AwFmSuccess;
 }
@@ -379,11 +424,27 @@ static enum AwFmReturnCode searchHitsPacked(AwFmGpuIndex *g, const uint64_t *dPa
                                                                                     dRanges, dCounts, stream);
 }
 
+/* dense search of the chunk in the slot, then the list of its k-mers with hits (in k-mer order) made from the counts */
+static enum AwFmReturnCode denseToList(AwFmGpuIndex *g, StreamSlot &s, int packed, uint32_t kmerLength, hipStream_t comp) {
+  enum AwFmReturnCode rc;
+  if (packed)
+    rc = searchHitsPacked(g, (const uint64_t *)s.dIn, kmerLength, s.n, (struct AwFmSearchRange *)s.dRanges, (uint32_t *)s.dCounts,
+                          (uint8_t *)s.dChars, comp, false);
+  else
+    rc = awfmGpuSearchHits(g, (const uint8_t *)s.dIn, nullptr, kmerLength, s.n, (struct AwFmSearchRange *)s.dRanges,
+                           (uint32_t *)s.dCounts, comp);
+  if (rc != AwFmSuccess) return rc;
+  return awfmGpuCompactHits(g, (const uint32_t *)s.dCounts, (const struct AwFmSearchRange *)s.dRanges, s.n, (uint64_t *)s.dFlagOffsets,
+                            s.dScratch, (uint32_t *)s.dHitKmers, (struct AwFmSearchRange *)s.dHitRanges, (uint32_t)s.capList,
+                            (uint32_t *)s.dNumHits, comp);
+}
+
 /* the pipeline; packed != 0: `input` is one 64-bit word per k-mer, else kmerLength ASCII characters per k-mer */
 static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int packed, uint32_t kmerLength,
                                        uint64_t numKmers, uint64_t chunkKmers, int locate, unsigned hostThreads,
-                                       AwFmGpuChunkSink sink, void *user) {
-  if (!g || (!input && numKmers) || !sink) {
+                                       AwFmGpuChunkSink sink, void *user, AwFmGpuSparseChunkSink sparseSink = nullptr) {
+  const bool sparse = sparseSink != nullptr;
+  if (!g || (!input && numKmers) || (!sink && !sparseSink)) {
     setError("awfmGpuStream: null argument");
     return AwFmNullPtrError;
   }
@@ -428,6 +489,7 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
   const bool stage = !isPinned(input);
   const bool narrowCounts = g->dev.bwtLength < (1ull << 32);
   const u64 hitBudget = awfmGpuHitBudget(g);
+  bool denseList = false; /* sparse results: a chunk's list overflowed, so the batch is not sparse: lists out of dense results from now on */
   const u64 numChunks = (numKmers + chunkKmers - 1) / chunkKmers;
   enum AwFmReturnCode rc = AwFmSuccess;
   auto drain = [&]() {
@@ -485,6 +547,24 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
       STEP_TRY(hipStreamWaitEvent(comp, s.uploaded, 0));
       /* the hit offsets of an image below 2^32 positions are scanned from the counts, and the locate reads a range only
        * when its k-mer has hits: the ranges of the others need not be written */
+      if (sparse) {
+        /* the k-mers with hits as a list: appended by the seed-order search itself when the chunk takes that path (and
+         * few of its k-mers occur: capacity n / 64), otherwise made from the dense results */
+        const bool fused = awfmGpuSearchHitsIsOrdered(g, 0, kmerLength, s.n) != 0 && !denseList;
+        const uint32_t cap = (uint32_t)(fused ? (s.n / 64 > 1024 ? s.n / 64 : 1024) : s.n);
+        STEP_RC(ensureList(s, cap, fused ? 0 : chunkKmers));
+        if (fused) {
+          STEP_RC(awfmGpuSearchHitsCompact(g, (const uint8_t *)s.dIn, nullptr, kmerLength, s.n, packed, (uint32_t *)s.dHitKmers,
+                                           (struct AwFmSearchRange *)s.dHitRanges, cap, (uint32_t *)s.dNumHits, comp));
+          STEP_RC(awfmGpuSortHits(g, (uint32_t *)s.dHitKmers, (struct AwFmSearchRange *)s.dHitRanges, cap, comp));
+        } else {
+          STEP_RC(denseToList(g, s, packed, kmerLength, comp));
+        }
+        s.capUsed = cap;
+        STEP_RC(awfmGpuHitOffsetsAsync(g, nullptr, (const struct AwFmSearchRange *)s.dHitRanges, cap, (uint64_t *)s.dListOffsets,
+                                       s.dScratch, s.hTotal, comp));
+        STEP_TRY(hipMemcpyAsync(s.hTotal + 1, s.dNumHits, 4, hipMemcpyDeviceToHost, comp));
+      } else {
       if (packed)
         STEP_RC(searchHitsPacked(g, (const uint64_t *)s.dIn, kmerLength, s.n,
                                  locate ? (struct AwFmSearchRange *)s.dRanges : nullptr, (uint32_t *)s.dCounts,
@@ -497,6 +577,7 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
         STEP_RC(awfmGpuHitOffsetsAsync(g, narrowCounts ? (const uint32_t *)s.dCounts : nullptr,
                                        (const struct AwFmSearchRange *)s.dRanges, s.n, (uint64_t *)s.dHitOffsets, s.dScratch,
                                        s.hTotal, comp));
+      }
       STEP_TRY(hipEventRecord(s.searched, comp));
     }
     if (t >= 1 && t - 1 < numChunks) { /* ---- B(t-1): locate; download ---- */
@@ -504,6 +585,44 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
       hipStream_t out = perSlot ? st.slotStream[(t - 1) % kStreamSlots] : st.copyOut[(t - 1) % kStreamSlots];
       hipStream_t comp = perSlot ? st.slotStream[(t - 1) % kStreamSlots] : st.compute;
       bool split = false, direct = false;
+      if (sparse) {
+        STEP_TRY(hipEventSynchronize(s.searched));
+        u64 listed = *(const uint32_t *)(s.hTotal + 1);
+        if (listed > s.capUsed) { /* more k-mers with hits than the list holds: this chunk again, densely */
+          denseList = true;
+          STEP_RC(ensureList(s, s.n, chunkKmers));
+          STEP_RC(denseToList(g, s, packed, kmerLength, comp));
+          s.capUsed = (uint32_t)s.n;
+          STEP_RC(awfmGpuHitOffsetsAsync(g, nullptr, (const struct AwFmSearchRange *)s.dHitRanges, s.capUsed, (uint64_t *)s.dListOffsets,
+                                         s.dScratch, s.hTotal, comp));
+          STEP_TRY(hipMemcpyAsync(s.hTotal + 1, s.dNumHits, 4, hipMemcpyDeviceToHost, comp));
+          STEP_TRY(hipStreamSynchronize(comp));
+          listed = *(const uint32_t *)(s.hTotal + 1);
+        }
+        s.total = *s.hTotal;
+        s.numHitKmers = listed;
+        s.windowed = false;
+        if (trace)
+          fprintf(stderr, "[stream] t=%llu sparse chunk %llu: %llu k-mers with hits (list of %u), %llu hits, budget %llu\n", (unsigned long long)t,
+                  (unsigned long long)(t - 1), (unsigned long long)listed, s.capUsed, (unsigned long long)s.total, (unsigned long long)hitBudget);
+        if (locate && s.total > hitBudget) {
+          setError("awfmGpuStream (sparse results): the hits of a chunk exceed the device's hit budget; use smaller chunks, or the "
+                   "dense pipeline, which takes such a chunk in windows");
+          drain();
+          return AwFmAllocationFailure;
+        }
+        if (locate && s.total) {
+          STEP_RC(ensurePositions(s, s.total));
+          STEP_RC(awfmGpuLocateTo(g, (const struct AwFmSearchRange *)s.dHitRanges, (const uint64_t *)s.dListOffsets, s.capUsed, s.total,
+                                  (uint64_t *)s.dPositions, (uint64_t *)s.dPositions, comp));
+        }
+        STEP_TRY(hipEventRecord(s.located, comp));
+        STEP_TRY(hipStreamWaitEvent(out, s.located, 0));
+        if (locate && s.total) STEP_TRY(hipMemcpyAsync(s.hPositions, s.dPositions, s.total * 8, hipMemcpyDeviceToHost, out));
+        if (listed) STEP_TRY(hipMemcpyAsync(s.hHitKmers, s.dHitKmers, listed * 4, hipMemcpyDeviceToHost, out));
+        STEP_TRY(hipMemcpyAsync(s.hListOffsets, s.dListOffsets, (listed + 1) * 8, hipMemcpyDeviceToHost, out));
+        STEP_TRY(hipEventRecord(s.done, out));
+      } else {
       if (locate) {
         STEP_TRY(hipEventSynchronize(s.searched));
         if (trace) fprintf(stderr, "[stream] t=%llu searched(%llu) seen %.2f ms\n", (unsigned long long)t, (unsigned long long)(t - 1), now());
@@ -538,13 +657,17 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
       }
       STEP_TRY(hipMemcpyAsync(s.hCounts, s.dCounts, s.n * 4, hipMemcpyDeviceToHost, out));
       STEP_TRY(hipEventRecord(s.done, out));
+      }
     }
     if (t >= lag) { /* ---- C(t-lag): hand the chunk to the caller ---- */
       StreamSlot &s = slots[(t - lag) % kStreamSlots];
       STEP_TRY(hipEventSynchronize(s.done));
       if (trace) fprintf(stderr, "[stream] t=%llu done(%llu) seen %.2f ms\n", (unsigned long long)t, (unsigned long long)(t - lag), now());
       int stop = 0;
-      if (locate && s.windowed) {
+      if (sparse) {
+        stop = sparseSink(user, s.first, s.n, s.numHitKmers, s.hHitKmers, (const uint64_t *)s.hListOffsets, locate ? (const uint64_t *)s.hPositions : nullptr,
+                          locate ? s.total : 0);
+      } else if (locate && s.windowed) {
         /* Hit-budgeted hand-over: the chunk's k-mers go to the sink in consecutive groups whose hit lists fit one window
          * (half the budget); a k-mer whose own list is longer goes alone, slice by slice (same firstKmer, numKmers = 1,
          * counts[0] its full count every time). */
@@ -617,6 +740,26 @@ enum AwFmReturnCode awfmGpuStreamChars(AwFmGpuIndex *g, const uint8_t *chars, ui
                                        uint64_t chunkKmers, int locate, unsigned hostThreads, AwFmGpuChunkSink sink,
                                        void *user) {
   return streamBatch(g, chars, 0, kmerLength, numKmers, chunkKmers, locate, hostThreads, sink, user);
+}
+
+enum AwFmReturnCode awfmGpuStreamPackedSparse(AwFmGpuIndex *g, const uint64_t *packedKmers, uint32_t kmerLength,
+                                              uint64_t numKmers, uint64_t chunkKmers, int locate, unsigned hostThreads,
+                                              AwFmGpuSparseChunkSink sink, void *user) {
+  if (!sink) {
+    setError("awfmGpuStreamPackedSparse: null sink");
+    return AwFmNullPtrError;
+  }
+  return streamBatch(g, packedKmers, 1, kmerLength, numKmers, chunkKmers, locate, hostThreads, nullptr, user, sink);
+}
+
+enum AwFmReturnCode awfmGpuStreamCharsSparse(AwFmGpuIndex *g, const uint8_t *chars, uint32_t kmerLength, uint64_t numKmers,
+                                             uint64_t chunkKmers, int locate, unsigned hostThreads, AwFmGpuSparseChunkSink sink,
+                                             void *user) {
+  if (!sink) {
+    setError("awfmGpuStreamCharsSparse: null sink");
+    return AwFmNullPtrError;
+  }
+  return streamBatch(g, chars, 0, kmerLength, numKmers, chunkKmers, locate, hostThreads, nullptr, user, sink);
 }
 
 /* ---- whole-batch convenience on top of the pipeline: results gathered into caller arrays ---- */

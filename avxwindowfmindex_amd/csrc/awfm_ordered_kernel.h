@@ -294,6 +294,85 @@ __global__ void __launch_bounds__(256)
     if (sHist[e]) atomicAdd(&hist[e], sHist[e]);
 }
 
+/* pass 1 for ASCII k-mers of a length known at compile time: a thread takes FOUR consecutive k-mers -- 4 K bytes, i.e.
+ * K whole dwords wherever the batch starts -- with 16-byte loads, brings them to dword alignment once (the misalignment of
+ * the batch is the same for every thread), and takes the four k-mers apart at compile-time offsets: K / 4 + 1 load
+ * instructions per four k-mers instead of K / 4 + 2 per k-mer (encodeCodesKernel: one k-mer per thread at a 21-byte
+ * stride), which is what bounds that kernel, not the bytes.  The last k-mers of a batch (fewer than five) go one by one. */
+typedef unsigned Dwords4 __attribute__((ext_vector_type(4), aligned(4))); /* a 16-byte load at dword alignment */
+template <unsigned K>
+__global__ void __launch_bounds__(256)
+    encodeCodes4Kernel(const unsigned char *__restrict__ chars, const BucketFormat f, const unsigned long long numQueries,
+                       unsigned long long *__restrict__ codesOut, unsigned *__restrict__ hist) {
+  extern __shared__ unsigned sHist[]; /* 2^bucketBits + 1 */
+  const unsigned bins = (1u << f.bucketBits) + 1u;
+  for (unsigned e = threadIdx.x; e < bins; e += 256u) sHist[e] = 0u;
+  __syncthreads();
+  constexpr unsigned kLoads = (K + 1u + 3u) / 4u; /* 16-byte loads that cover K + 1 dwords */
+  const unsigned shift = (unsigned)((unsigned long long)chars & 3ull);
+  typedef const Dwords4 __attribute__((address_space(1))) *GlobalDwords4;
+  const unsigned long long groups = (numQueries + 3ull) / 4ull;
+  for (unsigned long long grp = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; grp < groups; grp += (unsigned long long)gridDim.x * 256ull) {
+    const unsigned long long t = grp * 4ull;
+    unsigned long long codes[4];
+    unsigned bad[4];
+    if (t + 4ull < numQueries) { /* four whole k-mers and at least one behind them: no load leaves the batch */
+      const GlobalDwords4 first = (GlobalDwords4)(((unsigned long long)chars + t * K) & ~3ull);
+      unsigned dw[kLoads * 4u + 1u];
+#pragma unroll
+      for (unsigned j = 0; j < kLoads; j++) {
+        const Dwords4 q = first[j];
+        dw[4u * j] = q.x;
+        dw[4u * j + 1u] = q.y;
+        dw[4u * j + 2u] = q.z;
+        dw[4u * j + 3u] = q.w;
+      }
+      dw[kLoads * 4u] = 0u;
+      unsigned al[K + 1u]; /* the 4 K bytes at dword alignment */
+#pragma unroll
+      for (unsigned j = 0; j < K; j++) al[j] = __builtin_amdgcn_alignbyte(dw[j + 1u], dw[j], shift);
+      al[K] = 0u;
+#pragma unroll
+      for (unsigned i = 0; i < 4u; i++) {
+        constexpr unsigned kWords = (K + 3u) / 4u; /* groups of four characters */
+        const unsigned at = i * K; /* byte offset of k-mer i: compile time after unrolling */
+        unsigned long long c = 0;
+        unsigned b = 0;
+#pragma unroll
+        for (unsigned w = 0; w < 8u; w++) {
+          unsigned packed = 0, badBits = 0;
+          if (w < kWords) {
+            const unsigned lo = al[(at >> 2) + w], hi = (at >> 2) + w + 1u <= K ? al[(at >> 2) + w + 1u] : 0u;
+            decodeWord(__builtin_amdgcn_alignbyte(hi, lo, at & 3u), packed, badBits);
+          }
+          c = (c << 8) | packed;
+          b |= badBits << (4u * w);
+        }
+        codes[i] = c >> (2u * (32u - K));
+        constexpr unsigned kLenMask = K >= 32u ? ~0u : ((1u << (K & 31u)) - 1u);
+        bad[i] = b & kLenMask;
+      }
+    } else {
+#pragma unroll
+      for (unsigned i = 0; i < 4u; i++) {
+        codes[i] = 0;
+        bad[i] = 0;
+        if (t + i < numQueries) decodeKmer(chars, (t + i) * K, K, codes[i], bad[i]);
+      }
+    }
+#pragma unroll
+    for (unsigned i = 0; i < 4u; i++) {
+      if (t + i < numQueries) {
+        codesOut[t + i] = bad[i] ? kCodeGeneral : codes[i];
+        atomicAdd(&sHist[bad[i] ? bins - 1u : bucketOf(f, codes[i])], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (unsigned e = threadIdx.x; e < bins; e += 256u)
+    if (sHist[e]) atomicAdd(&hist[e], sHist[e]);
+}
+
 /* bucketStart[b] = k-mers in the buckets before b (2^bucketBits + 2 entries: [2^bucketBits] = k-mers the ordered
  * kernel covers, [2^bucketBits + 1] = all); generalCount = size of the last bin; one workgroup */
 __global__ void __launch_bounds__(1024)
@@ -329,7 +408,8 @@ __global__ void __launch_bounds__(1024)
 __global__ void __launch_bounds__(kPartitionThreads)
     partitionKernel(const unsigned long long *__restrict__ codes, const unsigned fixedLen, const BucketFormat f,
                     const unsigned long long numQueries, const unsigned *__restrict__ bucketStart,
-                    unsigned *__restrict__ cursors, unsigned long long *__restrict__ recs, const unsigned honourGeneral) {
+                    unsigned *__restrict__ cursors, unsigned long long *__restrict__ recs, const unsigned honourGeneral,
+                    const unsigned probe = 0u /* measurement only: 1 = no global reservations, 2 = no stores (results are wrong) */) {
   extern __shared__ unsigned long long sDyn[];
   unsigned long long *sRec = sDyn;                       /* kPartitionTile records, bucket by bucket */
   unsigned *sCnt = (unsigned *)(sRec + kPartitionTile);  /* records of the tile per bucket */
@@ -341,17 +421,23 @@ __global__ void __launch_bounds__(kPartitionThreads)
   const unsigned long long lenMask = fixedLen >= 32u ? ~0ull : ((1ull << (2u * fixedLen)) - 1ull);
   const unsigned long long tiles = (numQueries + kPartitionTile - 1ull) / kPartitionTile;
   constexpr unsigned kPer = 3; /* bins handled per thread in the scan: 3 x 1024 >= 2049 */
-  for (unsigned long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    for (unsigned e = threadIdx.x; e < bins; e += kPartitionThreads) sCnt[e] = 0u;
-    __syncthreads();
+  /* two register sets: the codes of the tile after the current one are requested before the current one is touched, so
+   * that their way from memory overlaps ALL of its phases (with one workgroup per CU nothing else hides it: the kernel
+   * ran at half the streaming rate while the loads were issued only a phase ahead) */
+  unsigned long long recA[kPartitionItems], recB[kPartitionItems];
+  auto loadTile = [&](unsigned long long tile, unsigned long long *rec) {
     const unsigned long long tileBase = tile * kPartitionTile;
-    unsigned long long rec[kPartitionItems];
-    unsigned where[kPartitionItems]; /* bucket << 16 | rank inside the tile's run (a tile has 16384 records) */
 #pragma unroll
     for (unsigned j = 0; j < kPartitionItems; j++) {
       const unsigned long long idx = tileBase + (unsigned long long)j * kPartitionThreads + threadIdx.x;
       rec[j] = idx < numQueries ? codes[idx] : 0ull;
     }
+  };
+  auto processTile = [&](unsigned long long tile, unsigned long long *rec) {
+    for (unsigned e = threadIdx.x; e < bins; e += kPartitionThreads) sCnt[e] = 0u;
+    __syncthreads();
+    const unsigned long long tileBase = tile * kPartitionTile;
+    unsigned where[kPartitionItems]; /* bucket << 16 | rank inside the tile's run (a tile has 16384 records) */
 #pragma unroll
     for (unsigned j = 0; j < kPartitionItems; j++) {
       const unsigned long long idx = tileBase + (unsigned long long)j * kPartitionThreads + threadIdx.x;
@@ -366,12 +452,19 @@ __global__ void __launch_bounds__(kPartitionThreads)
       }
     }
     __syncthreads();
-    { /* exclusive scan of the counts; one global reservation per non-empty bucket */
-      unsigned v[kPer], sum = 0;
+    { /* exclusive scan of the counts; one global reservation per non-empty bucket, all of a thread's in flight together */
+      unsigned v[kPer], got[kPer], start[kPer], sum = 0;
+#pragma unroll
       for (unsigned j = 0; j < kPer; j++) {
         const unsigned e = threadIdx.x * kPer + j;
         v[j] = e < bins ? sCnt[e] : 0u;
         sum += v[j];
+      }
+#pragma unroll
+      for (unsigned j = 0; j < kPer; j++) {
+        const unsigned e = threadIdx.x * kPer + j;
+        got[j] = v[j] && probe != 1u ? atomicAdd(&cursors[e], v[j]) : 0u;
+        start[j] = v[j] ? bucketStart[e] : 0u;
       }
       unsigned incl = sum;
       for (int off = 1; off < 64; off <<= 1) {
@@ -382,11 +475,12 @@ __global__ void __launch_bounds__(kPartitionThreads)
       __syncthreads();
       unsigned running = incl - sum;
       for (unsigned w = 0; w < (threadIdx.x >> 6); w++) running += sWave[w];
+#pragma unroll
       for (unsigned j = 0; j < kPer; j++) {
         const unsigned e = threadIdx.x * kPer + j;
         if (e < bins) {
           sLoc[e] = running;
-          if (v[j]) sDst[e] = bucketStart[e] + atomicAdd(&cursors[e], v[j]);
+          sDst[e] = start[j] + got[j];
         }
         running += v[j];
       }
@@ -401,10 +495,22 @@ __global__ void __launch_bounds__(kPartitionThreads)
       const unsigned count = sCnt[b], loc = sLoc[b];
       if (count) {
         const unsigned long long dst = sDst[b];
-        for (unsigned j = threadIdx.x & 7u; j < count; j += 8u) recs[dst + j] = sRec[loc + j];
+        if (probe != 2u)
+          for (unsigned j = threadIdx.x & 7u; j < count; j += 8u) recs[dst + j] = sRec[loc + j];
       }
     }
     __syncthreads();
+  };
+  unsigned long long tile = blockIdx.x;
+  if (tile < tiles) loadTile(tile, recA);
+  while (tile < tiles) {
+    if (tile + gridDim.x < tiles) loadTile(tile + gridDim.x, recB);
+    processTile(tile, recA);
+    tile += gridDim.x;
+    if (tile >= tiles) break;
+    if (tile + gridDim.x < tiles) loadTile(tile + gridDim.x, recA);
+    processTile(tile, recB);
+    tile += gridDim.x;
   }
 }
 
@@ -436,7 +542,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
                         const ulonglong2 *__restrict__ table, ulonglong2 *__restrict__ ranges,
                         unsigned *__restrict__ counts, unsigned *__restrict__ tickets, const int xcdMap = 0,
                         const OrderTouch touch = OrderTouch(), const unsigned *__restrict__ bucketStart = nullptr,
-                        const BucketFormat bucketFmt = BucketFormat()) {
+                        const BucketFormat bucketFmt = BucketFormat(), const SparseOut sparse = SparseOut()) {
   static_assert(!BUCKET || (COMPACT && !VARLEN), "bucketed records are the 8-byte records of fixed-length batches");
   constexpr int S = (int)kSlices / G;
   typedef typename PositionType<NARROW>::type pos_t;
@@ -579,8 +685,9 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     ulonglong2 entry = make_ulonglong2(1ull, 0ull);
     /* fixed length: the table entry is requested FIRST, so that the wait for it (loads return in order) is not also a
      * wait for the ticket atomic and the record prefetch issued below */
-    if (!VARLEN && live) entry = table[codes & tableMask];
-    if (TOUCH && !VARLEN && live) markLine(table == ix.seed ? touch.seedLines : touch.deepLines, (codes & tableMask) >> 3);
+    if (!VARLEN && live) entry = table == ix.deepSeed ? deepSeedEntry(ix, codes & tableMask) : table[codes & tableMask];
+    if (TOUCH && !VARLEN && live)
+      markLine(table == ix.seed ? touch.seedLines : touch.deepLines, (codes & tableMask) >> (table == ix.deepSeed && ix.deepNarrow ? 4 : 3));
     /* draw the ticket after next (consumed at the bottom), fetch the next chunk's record */
     if (lane == 0) drawn = atomicAdd(ticket, 1u);
     if (baseNext + lane / G < end) readRecord(baseNext + lane / G, raw);
@@ -597,9 +704,9 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       const unsigned myDepth = orderStartDepth(myLen, ix.seedK, ix.deepK);
       if (live) {
         if (myDepth != 0u) {
-          const ulonglong2 *from = myDepth == ix.seedK ? ix.seed : ix.deepSeed;
-          const ulonglong2 r = from[codes & ((1ull << (2u * myDepth)) - 1ull)];
-          if (TOUCH) markLine(myDepth == ix.seedK ? touch.seedLines : touch.deepLines, (codes & ((1ull << (2u * myDepth)) - 1ull)) >> 3);
+          const unsigned long long at = codes & ((1ull << (2u * myDepth)) - 1ull);
+          const ulonglong2 r = myDepth == ix.seedK ? ix.seed[at] : deepSeedEntry(ix, at);
+          if (TOUCH) markLine(myDepth == ix.seedK ? touch.seedLines : touch.deepLines, at >> (myDepth != ix.seedK && ix.deepNarrow ? 4 : 3));
           sp = (pos_t)r.x;
           ep = (pos_t)r.y;
           pos = (int)(myLen - myDepth) - 1;
@@ -654,7 +761,9 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       }
     }
     if (TOUCH && live && gl == 0 && sp <= ep) atomicAdd(touch.hits, 1ull);
-    if (live && gl == 0 && sp <= ep) {
+    if (sparse.count) { /* kernel argument: uniform */
+      sparseAppend(sparse, live && gl == 0 && sp <= ep, index, (unsigned long long)sp, (unsigned long long)ep);
+    } else if (live && gl == 0 && sp <= ep) {
       if (ranges) ranges[index] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
       if (counts) counts[index] = (unsigned)(ep - sp + (pos_t)1);
     }

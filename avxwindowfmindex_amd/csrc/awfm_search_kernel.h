@@ -52,7 +52,8 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
                  const unsigned long long numQueries, ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts,
                  unsigned long long *__restrict__ tally, const unsigned char *__restrict__ subset = nullptr,
                  const unsigned subsetStride = 0, const unsigned subsetIndexAt = 0,
-                 const unsigned long long subsetTotal = 0, const unsigned *__restrict__ subsetCount = nullptr) {
+                 const unsigned long long subsetTotal = 0, const unsigned *__restrict__ subsetCount = nullptr,
+                 const SparseOut sparse = SparseOut()) {
   constexpr int W = 8 / G; /* window dwords per lane: the group holds the last 32 characters of its k-mer */
   constexpr int S = (int)kSlices / G; /* block slices per lane */
   constexpr int kGroups = kThreads / G;
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
         if (DK != 0u && len >= DK) {
           const unsigned long long deepChars = ((1ull << DK) - 1ull) << (e - DK);
           if (((unsigned long long)allBad & deepChars) == 0ull) {
-            const ulonglong2 r = ix.deepSeed[tail & ((1ull << (2u * DK)) - 1ull)];
+            const ulonglong2 r = deepSeedEntry(ix, tail & ((1ull << (2u * DK)) - 1ull));
             sp = (pos_t)r.x;
             ep = (pos_t)r.y;
             pos = (int)(len - DK) - 1;
@@ -315,7 +316,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
       badTop <<= 1;
     }
 
-    if (gl == 0) {
+    if (sparse.count) { /* kernel argument: uniform (the tail of a sparse ordered search: awfmGpuSearchHitsCompact) */
+      sparseAppend(sparse, gl == 0 && sp <= ep, (unsigned)queryNumber(q), (unsigned long long)sp, (unsigned long long)ep);
+    } else if (gl == 0) {
       const unsigned long long out = queryNumber(q);
       if (ranges) ranges[out] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
       if (counts) counts[out] = sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u;

@@ -42,6 +42,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_GATHER_PEAK_GBS = 17800.0  # MI355X_MICROARCH.md "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCDs' L2s
 RANK_BYTES_DNA, RANK_BYTES_AMINO = 104, 168  # planes + one count of the reference block
 PROFILE_ROUND = "r3"
+WINDOW_HITS = 1 << 28  # hits located per window when a batch's hit list is not kept resident (--workload mixed --mode locate)
 
 
 def parse():
@@ -50,7 +51,8 @@ def parse():
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", choices=["random", "planted", "mixed"], default="random")
-    p.add_argument("--mode", choices=["locate", "count"], default="locate")
+    p.add_argument("--mode", choices=["locate", "count"], default=None,
+                   help="default: locate (mixed lengths: count; --workload mixed --mode locate is 2 M k-mers located in windows)")
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                    help="weak: --queries k-mers per GPU; strong: --queries k-mers in total, cut into --gpus shards")
     count = lambda v: int(float(v))  # noqa: E731  ("3e6" is accepted)
@@ -195,6 +197,40 @@ def end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, a
         "output": "4 B/k-mer counts" + (" + 8 B/hit positions" if locate else "") + " in page-locked staging, per chunk",
         "pcie_bytes": {"h2d": Q * 8, "d2h": Q * 4 + (seen["hits"] * 8 if locate else 0)},
         "checked": "counts and positions equal the device-buffer API's for the whole batch"}
+    # the same batch through the pipeline with SPARSE results (awfmGpuStreamPackedSparse): per chunk the k-mers with hits as
+    # a list + positions -- the download is 12 bytes per k-mer with hits instead of 4 per k-mer
+    if locate and state["listed"]:  # a batch in which few k-mers occur (the list form is what the timed steps used)
+        sp_seen = {"kmers": 0, "listed": 0, "hits": 0}
+
+        def sparse_sink(user, first, m, num, hit_kmers, hit_offsets, positions, total):
+            sp_seen["kmers"] += m
+            sp_seen["listed"] += num
+            sp_seen["hits"] += total
+            return 0
+
+        def run_sparse():
+            sp_seen.update(kmers=0, listed=0, hits=0)
+            t0 = time.perf_counter()
+            g.stream_sparse((address, Q), K, locate=True, chunk=0, sink=sparse_sink)
+            return time.perf_counter() - t0
+
+        run_sparse()
+        sparse_times = [run_sparse() for _ in range(3)]
+        assert sp_seen["kmers"] == Q and sp_seen["hits"] == state["hits"], "sparse pipeline lost k-mers or hits"
+        ids, off, positions = g.stream_sparse((address, Q), K, locate=True, chunk=0)
+        ho = d_hit_off.cpu().numpy().view(np.uint64)
+        cnt = np.diff(ho)
+        assert np.array_equal(ids, np.flatnonzero(cnt).astype(np.uint64)), "sparse pipeline lists other k-mers than the device API found"
+        assert np.array_equal(np.diff(off), cnt[cnt > 0]) and np.array_equal(
+            positions, state["positions"][: state["hits"]].cpu().numpy().view(np.uint64)), "sparse pipeline positions differ"
+        del ids, off, positions, cnt, ho
+        best_sparse = min(sparse_times)
+        out["flat_packed_pipeline_sparse"] = {
+            "value": round(Q / best_sparse / 1e6, 1), "ms": round(best_sparse * 1e3, 2), "kmers": Q,
+            "entry_point": "awfmGpuStreamPackedSparse", "kmers_with_hits": sp_seen["listed"],
+            "output": "per chunk: list of the k-mers with hits (4 B) + hit offsets (8 B) + positions (8 B/hit)",
+            "pcie_bytes": {"h2d": Q * 8, "d2h": sp_seen["listed"] * 12 + sp_seen["hits"] * 8},
+            "checked": "listed k-mers, hit offsets and positions equal the device-buffer API's for the whole batch"}
     L.awfmGpuHostFree(address)
     # the drop-in AoS entry point on a prefix of the batch (one kmerString pointer in, one positionList out per k-mer)
     m = min(Q, args.e2e_aos_queries)
@@ -256,10 +292,14 @@ def main():
         if getattr(args, name) is None:
             setattr(args, name, amino_default if amino else dna_default)
     n, K = args.text_len, args.kmer
+    if args.mode is None:
+        args.mode = "count" if args.workload == "mixed" else "locate"
     if args.text == "repetitive" and args.workload == "planted":
         args.mode = "count"  # a 21-mer out of a 300-character family with 10^6 copies has ~10^5 hits: 10^8 of them have 10^12
-    if args.workload == "mixed":
-        args.mode = "count"  # 8..11-mers have ~10^4..10^5 hits each: the hit list of 10^8 of them is a budgeted locate (tests), not a bench step
+    if args.workload == "mixed" and args.mode == "locate" and args.queries == 100_000_000 and not amino:
+        # 8..11-mers have 10^3..10^5 hits each (2.7 * 10^3 per k-mer on average): the hit list of 10^8 mixed k-mers is
+        # 2 * 10^11 positions.  The locate form of this workload is 2 M k-mers (5 * 10^9 hits), located in windows.
+        args.queries = 2_000_000
     text_seed = 4 if amino else 2
     query_seed = 104 if amino else {"random": 102, "planted": 103, "mixed": 105}[args.workload]
 
@@ -349,7 +389,7 @@ def main():
     d_hit_off = torch.empty(Q + 1, dtype=torch.int64, device=dev)
     d_scratch = torch.empty(api.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    state = {"positions": None, "hits": 0, "sparse": True}
+    state = {"positions": None, "hits": 0, "sparse": True, "windowed": False}
 
     def ensure_positions(total):
         if state["positions"] is None or state["positions"].numel() < max(total, 1):
@@ -363,6 +403,20 @@ def main():
     if ordered:
         os.environ["AWFM_GPU_TIME_ORDERED"] = "1"  # HIP events around orderedSearchKernel inside the library
 
+    # Sparse results (awfmGpuSearchHitsCompact): when few k-mers of a batch occur -- 7 * 10^4 of 10^8 random 21-mers -- the
+    # k-mers with hits are a LIST {k-mer number, range}, sorted by k-mer number, with hit offsets over that list: nothing
+    # of size 10^8 is filled, scanned or expanded after the search.  Same information as the dense form (a k-mer that is
+    # not listed has count 0).  Dense-hit batches (planted) keep the dense form: decided from the previous step's hits.
+    sparse_cap = max(Q // 64, 1024)
+    can_list = ordered and args.mode == "locate" and not os.environ.get("AWFM_BENCH_DENSE_RESULTS")
+    if can_list:
+        d_hit_kmers = torch.empty(sparse_cap, dtype=torch.int32, device=dev)
+        d_hit_ranges = torch.empty(sparse_cap * 2, dtype=torch.int64, device=dev)
+        d_hit_off_c = torch.empty(sparse_cap + 1, dtype=torch.int64, device=dev)
+        d_num_hits = torch.zeros(1, dtype=torch.int32, device=dev)
+        h_num_hits = torch.zeros(1, dtype=torch.int32).pin_memory()
+    state["listed"] = False  # the last step's results are in the list form
+
     def step(record):
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -370,7 +424,11 @@ def main():
         # counting and locating need the hits only (what awFmParallelSearchCount/Locate report): large
         # fixed-length batches are searched in seed order, the others by the general kernel
         use_counts = narrow_counts and state["sparse"]
-        if args.mode == "locate" and use_counts:
+        use_list = can_list and state["sparse"]
+        if use_list:
+            g.search_hits_compact(d_chars.data_ptr(), off_ptr, K, Q, d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), sparse_cap,
+                                  d_num_hits.data_ptr(), stream=stream)
+        elif args.mode == "locate" and use_counts:
             # the hit offsets are scanned from the counts and the locate reads the range of a k-mer only when it has
             # hits: the ranges of the others need not be written
             g.search_hits_sparse(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr(), d_counts.data_ptr(), stream)
@@ -383,19 +441,56 @@ def main():
             if ordered:
                 ordered_ms.append(g.last_ordered_kernel_ms())  # waits for that kernel only
         if args.mode == "locate":
+            if use_list:
+                h_num_hits.copy_(d_num_hits, non_blocking=True)  # lands before the wait inside hit_offsets() below returns
+                g.sort_hits(d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), sparse_cap, stream)
+                total = g.hit_offsets(d_hit_ranges.data_ptr(), sparse_cap, d_hit_off_c.data_ptr(), d_scratch.data_ptr(), stream)
+                listed = int(h_num_hits[0])
+                if listed > sparse_cap:  # not a sparse batch after all: this step again, densely
+                    state["sparse"] = False
+                    if record:
+                        search_events.pop()
+                        ordered_ms.pop()
+                    return step(record)
+                ensure_positions(total)
+                if record:
+                    e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e2.record()
+                g.locate(d_hit_ranges.data_ptr(), d_hit_off_c.data_ptr(), sparse_cap, total, state["positions"].data_ptr(), stream)
+                if record:
+                    e3.record()
+                    locate_events.append((e2, e3))
+                state.update(hits=total, listed=True, num_listed=listed)
+                return
             if use_counts:  # the scan reads 4-byte counts instead of 16-byte ranges
                 total = g.hit_offsets_from_counts(d_counts.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
             else:
                 total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
-            ensure_positions(total)
+            window = total > WINDOW_HITS  # a hit list beyond what is kept resident: window by window (awfmGpuLocateWindow)
+            ensure_positions(WINDOW_HITS if window else total)
             if record:
                 e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e2.record()
-            g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, state["positions"].data_ptr(), stream)
+            if window:
+                # window boundaries in k-mers: the queries whose lists meet [hb, he) -- found on the device, one sync each
+                bounds = torch.arange(0, total + WINDOW_HITS, WINDOW_HITS, dtype=torch.int64, device=dev).clamp_(max=total)
+                cut = torch.searchsorted(d_hit_off[: Q + 1], bounds, right=True).cpu().tolist()  # first k-mer whose list ends after the bound
+                bounds = bounds.cpu().tolist()
+                state["first_window"] = max(cut[1] - 1, 0)  # k-mers whose whole list lies in the first window
+                for w in range(len(bounds) - 1):
+                    qb, qe = max(cut[w] - 1, 0), min(cut[w + 1], Q)
+                    g.locate_window(d_ranges.data_ptr(), d_hit_off.data_ptr(), qb, qe, bounds[w], bounds[w + 1],
+                                    state["positions"].data_ptr(), stream)
+                    if w == 0 and state.get("keep_first_window"):
+                        state["window0"] = state["positions"][: bounds[1]].clone()
+            else:
+                g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, state["positions"].data_ptr(), stream)
             if record:
                 e3.record()
                 locate_events.append((e2, e3))
             state["hits"] = total
+            state["listed"] = False
+            state["windowed"] = window
             # when most k-mers have hits, a second per-query result (the count) costs a scattered store each in
             # the ordered search, more than scanning the ranges does: decided from the previous step's hit total
             state["sparse"] = total < Q // 4
@@ -416,6 +511,28 @@ def main():
     value = batch_total / (elapsed / args.steps) / 1e6  # Mkmers/s over all ranks
     search_ms = float(np.mean([a.elapsed_time(b) for a, b in search_events]))
     locate_ms = float(np.mean([a.elapsed_time(b) for a, b in locate_events])) if locate_events else 0.0
+    if state["windowed"]:  # the positions of the first window, kept for the oracle check of the k-mers that lie in it
+        state["keep_first_window"] = True
+        step(False)
+        torch.cuda.synchronize()
+        state["keep_first_window"] = False
+    if state["listed"]:
+        # every check below (oracle sample, digests, pipeline and AoS comparison, dumps) reads the dense form: the list is
+        # expanded into it here, outside the timed region -- counts, hit offsets and ranges under every k-mer number
+        m = state["num_listed"]
+        kmers = d_hit_kmers[:m].to(torch.int64)
+        assert m == 0 or bool((kmers[1:] > kmers[:-1]).all()), "the hit list is not in k-mer order"
+        lens = d_hit_off_c[1:m + 1] - d_hit_off_c[:m]
+        d_counts.zero_()
+        d_counts[kmers] = lens.to(torch.int32)
+        d_hit_off[0] = 0
+        torch.cumsum(d_counts.to(torch.int64), 0, out=d_hit_off[1:])
+        dense = d_ranges.view(Q, 2)
+        dense[:, 0] = 1
+        dense[:, 1] = 0
+        dense[kmers] = d_hit_ranges.view(sparse_cap, 2)[:m]
+        assert int(d_hit_off[-1].item()) == state["hits"]
+        del kmers, lens, dense
 
     if args.dump_dir:  # testing: this rank's shard results, for a check against the oracle outside the bench
         os.makedirs(args.dump_dir, exist_ok=True)
@@ -428,7 +545,8 @@ def main():
             if narrow_counts and state["sparse"]:  # ranges were written for the k-mers with hits only: "no hit" for the rest
                 dump["ranges"] = dump["ranges"].copy()
                 dump["ranges"][np.diff(dump["hit_offsets"]) == 0] = (1, 0)
-            dump["positions"] = state["positions"][: state["hits"]].cpu().numpy().view(np.uint64)
+            if not state["windowed"]:
+                dump["positions"] = state["positions"][: state["hits"]].cpu().numpy().view(np.uint64)
         np.savez(os.path.join(args.dump_dir, f"rank{rank}.npz"), **dump)
 
     # ---- digests of this rank's results; rank 0 checks all ranks' against the committed digests of the 1-rank run ----
@@ -443,7 +561,7 @@ def main():
     else:
         shard_counts = (d_hit_off[1:] - d_hit_off[:-1])
         mine = (first, Q, digest.counts_digest(first, shard_counts),
-                digest.positions_digest(first, d_hit_off, state["positions"][: max(state["hits"], 1)]))
+                None if state["windowed"] else digest.positions_digest(first, d_hit_off, state["positions"][: max(state["hits"], 1)]))
         del shard_counts
     all_digests = shard.gather_objects(mine, world)
 
@@ -646,47 +764,50 @@ def main():
             if args.mode == "locate":
                 gho = d_hit_off[: m + 1].cpu().numpy().view(np.uint64)
                 assert np.array_equal(gho, ho), "GPU hit offsets differ from the oracle"
-                gp = state["positions"][: int(ho[-1])].cpu().numpy().view(np.uint64)
+                gp = (state["window0"] if state["windowed"] else state["positions"])[: int(ho[-1])].cpu().numpy().view(np.uint64)
                 assert np.array_equal(gp, pos), "GPU positions differ from the oracle"
             return dt, tl
 
         # grow the sample until it costs about --cpu-seconds of wall time (thread start-up and first-touch
         # page faults dominate tiny samples)
-        m = min(Q, 2_000_000)
+        sample_cap = min(Q, 50_000_000)
+        if state["windowed"]:  # positions are checked for the k-mers whose lists lie in the first window
+            sample_cap = max(1, min(sample_cap, state["first_window"]))
+        m = min(sample_cap, 2_000_000)
         best = None
         for c in candidates:  # thread-count probe
             dt, tl = run_sample(m, c)
             if best is None or dt < best[0]:
                 best = (dt, c)
         cores = best[1]
-        # the port is built twice from the same source: -O2 -mpopcnt, and -O3 -mavx2 (the reference's own flags,
-        # ref CMakeLists.txt:112-148); the faster build on the probe sample is the one reported
-        builds = {"": "-O2 -mpopcnt", "avx2": "-O3 -mavx2 -mbmi2 -mpopcnt"}
-        probe = {}
-        for variant in builds:
-            try:
-                O.set_variant(variant)
-                run_sample(m)  # warm
-                probe[variant] = min(run_sample(m)[0] for _ in range(2))
-            except OSError:
-                pass
-        variant = min(probe, key=probe.get)
-        O.set_variant(variant)
         dt, tl = run_sample(m)
         for _ in range(4):
-            if dt >= args.cpu_seconds / 2 or m >= Q or m >= 50_000_000:
+            if dt >= args.cpu_seconds / 2 or m >= sample_cap:
                 break
-            m = int(min(Q, 50_000_000, max(2 * m, m * args.cpu_seconds / max(dt, 1e-3))))
+            m = int(min(sample_cap, max(2 * m, m * args.cpu_seconds / max(dt, 1e-3))))
             dt, tl = run_sample(m)
+        # the port is built twice from the same source: -O2 -mpopcnt, and -O3 -mavx2 (the reference's own flags,
+        # ref CMakeLists.txt:112-148); both are timed on the final sample and the faster one is the one reported
+        builds = {"": "-O2 -mpopcnt", "avx2": "-O3 -mavx2 -mbmi2 -mpopcnt"}
+        timed = {"": dt}
+        try:
+            O.set_variant("avx2")
+            run_sample(min(m, 2_000_000))  # load + warm
+            timed["avx2"], tl = run_sample(m)
+        except OSError:
+            pass
+        variant = min(timed, key=timed.get)
+        O.set_variant(variant)
+        dt = timed[variant]
         # SURVEY.md 8d also asks for the 1-thread and 8-thread figures of the same port
         fixed = {}
         for t, mt in ((1, 2_000_000), (8, 8_000_000)):
-            mt = min(Q, mt)
+            mt = min(sample_cap, mt)
             dtt, _ = run_sample(mt, t)
             fixed[f"threads_{t}"] = {"value": round(mt / dtt / 1e6, 3), "sample": mt}
         cpu = {"value": round(m / dt / 1e6, 3), "unit": "Mkmers/s", "cores": cores, "kind": "port", **fixed,
                "build": builds[variant],
-               "builds_probed_Mkmers_per_s": {builds[v]: round(min(Q, 2_000_000) / t / 1e6, 3) for v, t in probe.items()},
+               "builds_timed_Mkmers_per_s": {builds[v]: round(m / t / 1e6, 3) for v, t in timed.items()},
                "sample": f"first {m} of the {Q} {args.workload} {kdesc} of rank 0, {args.mode}, same index, "
                          f"{dt:.1f} s wall on {cores} threads ({granted} CPUs granted of {os.cpu_count()}), "
                          f"results equal to the GPU's",
@@ -763,8 +884,11 @@ def main():
                    "device_image_bytes": g.device_bytes, "device_seed_k": g.deep_seed_k or args.seed_k,
                    "device_seed_build_s": round(deep_s, 2), "device_dense_sa": bool(args.device_dense_sa),
                    "device_dense_sa_build_s": round(dense_s, 2),
-                   "search_path": ("awfmGpuSearchHitsSparse" if (args.mode == "locate" and narrow_counts and state["sparse"]) else "awfmGpuSearchHits")
-                                  + (", seed order" if ordered else ", general kernel")},
+                   "search_path": ("awfmGpuSearchHitsCompact" if state["listed"] else
+                                   "awfmGpuSearchHitsSparse" if (args.mode == "locate" and narrow_counts and state["sparse"]) else "awfmGpuSearchHits")
+                                  + (", seed order" if ordered else ", general kernel"),
+                   "result_format": ("list of the k-mers with hits {k-mer number, range} in k-mer order + hit offsets over the list + positions"
+                                     if state["listed"] else "range / count under every k-mer number + hit offsets over the batch + positions")},
         "roofline": roofline,
         "roofline_general": roofline_general,
         "cpu_baseline": cpu,

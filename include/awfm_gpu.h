@@ -79,7 +79,8 @@ void awfmGpuIndexRelease(const struct AwFmIndex *index);
 uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g);
 int awfmGpuIndexDevice(const AwFmGpuIndex *g);
 /* Optional, nucleotide images: builds a device-only seed table of depth deepK (seedK < deepK <= 16,
- * 4^deepK x 16 bytes of HBM: 4.3 GB at 14, 69 GB at 16) whose entries equal what the reference algorithm
+ * 4^deepK x 8 bytes of HBM on images below 2^32 positions -- {sp, length}: 2.1 GB at 14, 34 GB at 16 -- and 16 bytes
+ * {sp, ep} beyond) whose entries equal what the reference algorithm
  * reaches after the seed lookup plus deepK-seedK extension steps (stopping at the first invalid range), so
  * results stay bit-identical while those steps' block reads disappear.  deepK = 0 drops it.  The host
  * index, its seed table and the .awfmi file are untouched.  When an image is created: $AWFM_GPU_DEEP_SEED_K (0: none)
@@ -155,6 +156,29 @@ enum AwFmReturnCode awfmGpuSearchHits(AwFmGpuIndex *g, const uint8_t *dChars, co
 enum AwFmReturnCode awfmGpuSearchHitsSparse(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                             uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
                                             uint32_t *dCounts, void *stream);
+/* Sparse results: the k-mers with hits as a list instead of a range / count under every query number -- for batches in
+ * which few k-mers occur (10^8 random 21-mers against a human-sized text: 7 * 10^4), where writing, scanning and moving
+ * 10^8 "no hit" records is most of what happens after the search.  Only batches that take the seed-order path
+ * (awfmGpuSearchHitsIsOrdered; AwFmUnsupportedVersionError otherwise -- run awfmGpuSearchHits + awfmGpuCompactHits then).
+ * dHitKmers[capacity] / dHitRanges[capacity] are first filled with {0xFFFFFFFF, empty range}; every k-mer with hits then
+ * appends {its number in the batch, its range} (order: as the waves come); *dNumHits (device) = how many there are, which
+ * may exceed capacity -- the list is then incomplete and the caller repeats densely (a dense batch should not be searched
+ * this way in the first place: its appends contend for one counter; capacity = numQueries / 64 keeps a mistaken attempt
+ * cheap).  `packed`: dChars is one 64-bit word per k-mer (awfmGpuSearchHitsPacked).  awfmGpuSortHits orders the list by
+ * k-mer number (entries beyond the hits sort last); awfmGpuHitOffsets / awfmGpuLocate then take the list as if it were
+ * the batch (numQueries = capacity or the number of hits). */
+enum AwFmReturnCode awfmGpuSearchHitsCompact(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                             uint32_t fixedLength, uint64_t numQueries, int packed, uint32_t *dHitKmers,
+                                             struct AwFmSearchRange *dHitRanges, uint32_t capacity, uint32_t *dNumHits,
+                                             void *stream);
+/* the same list from dense results (dCounts / dRanges of awfmGpuSearchHits or awfmGpuSearch), already in k-mer order:
+ * dFlagOffsets[numQueries + 1] and dScratch (awfmGpuScanScratchBytes) are work space */
+enum AwFmReturnCode awfmGpuCompactHits(AwFmGpuIndex *g, const uint32_t *dCounts, const struct AwFmSearchRange *dRanges,
+                                       uint64_t numQueries, uint64_t *dFlagOffsets, void *dScratch, uint32_t *dHitKmers,
+                                       struct AwFmSearchRange *dHitRanges, uint32_t capacity, uint32_t *dNumHits, void *stream);
+enum AwFmReturnCode awfmGpuSortHits(AwFmGpuIndex *g, uint32_t *dHitKmers, struct AwFmSearchRange *dHitRanges,
+                                    uint32_t numEntries, void *stream);
+
 /* -1 = automatic (default), 0 = never, 1 = whenever the ordered path applies */
 void awfmGpuIndexSetOrdered(AwFmGpuIndex *g, int mode);
 /* 1 when awfmGpuSearchHits would search such a batch in seed order on this image (reporting, bench.py) */
@@ -300,6 +324,24 @@ enum AwFmReturnCode awfmGpuStreamPacked(AwFmGpuIndex *g, const uint64_t *packedK
 enum AwFmReturnCode awfmGpuStreamChars(AwFmGpuIndex *g, const uint8_t *chars, uint32_t kmerLength, uint64_t numKmers,
                                        uint64_t chunkKmers, int locate, unsigned hostThreads, AwFmGpuChunkSink sink,
                                        void *user);
+/* The same pipelines with SPARSE results: per chunk the k-mers with hits as a list -- hitKmers[j] = number of the j-th such
+ * k-mer relative to firstKmer (ascending), its hits positions[hitOffsets[j] .. hitOffsets[j + 1]) in BWT order
+ * (hitOffsets has numHitKmers + 1 entries; locate == 0: positions is NULL and the offsets only say how many hits each
+ * has) -- instead of a count for every k-mer of the chunk: for a batch in which few k-mers occur the download shrinks
+ * from 4 bytes per k-mer to 12 bytes per k-mer WITH hits, and nothing of the chunk's size is written after the search.
+ * A chunk with more than numKmers / 64 k-mers with hits is searched again densely and its list made from the counts (and
+ * so are the chunks after it): correct for any batch, fast for sparse ones.  A chunk whose hits exceed the device's hit
+ * budget fails with AwFmAllocationFailure (the dense pipeline takes such chunks in windows). */
+typedef int (*AwFmGpuSparseChunkSink)(void *user, uint64_t firstKmer, uint64_t numKmers, uint64_t numHitKmers,
+                                      const uint32_t *hitKmers, const uint64_t *hitOffsets, const uint64_t *positions,
+                                      uint64_t numPositions);
+enum AwFmReturnCode awfmGpuStreamPackedSparse(AwFmGpuIndex *g, const uint64_t *packedKmers, uint32_t kmerLength,
+                                              uint64_t numKmers, uint64_t chunkKmers, int locate, unsigned hostThreads,
+                                              AwFmGpuSparseChunkSink sink, void *user);
+enum AwFmReturnCode awfmGpuStreamCharsSparse(AwFmGpuIndex *g, const uint8_t *chars, uint32_t kmerLength, uint64_t numKmers,
+                                             uint64_t chunkKmers, int locate, unsigned hostThreads, AwFmGpuSparseChunkSink sink,
+                                             void *user);
+
 /* whole batch into caller arrays: counts[numKmers]; *positions is malloc'ed (caller frees), *numPositions entries */
 enum AwFmReturnCode awfmGpuCountPackedHost(AwFmGpuIndex *g, const uint64_t *packedKmers, uint32_t kmerLength,
                                            uint64_t numKmers, uint32_t *counts);

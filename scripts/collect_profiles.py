@@ -74,14 +74,19 @@ def fetch_factor(kernel):
 
 
 ordered = [k for k in summary if k.startswith("orderedSearchKernel") and "FETCH_SIZE" in summary[k]]
+# the instantiation the timed steps run (the instrumented one of the line tally is launched once)
+ordered.sort(key=lambda k: -summary[k]["FETCH_SIZE"]["dispatches"])
 if ordered:
     calls = summary[ordered[0]]["FETCH_SIZE"]["dispatches"]
-    parts = [k for k in summary if k.startswith(("orderedSearchKernel", "fillNoHitKernel", "encodeQueriesKernel"))
-             or ("radix_sort" in k and "unsigned short" in k) or (k.startswith("searchKernel") and k.rstrip(">").endswith("true, true"))]
+    parts = [k for k in summary if "FETCH_SIZE" in summary[k] and (
+             k == ordered[0] or k.startswith(("fillNoHitKernel", "fillSparseKernel", "encodeQueriesKernel", "encodeCodes", "partitionKernel",
+                                              "bucketScanKernel"))
+             or ("radix_sort" in k and "unsigned short" in k) or (k.startswith("searchKernel") and k.rstrip(">").endswith("true, false")))]
     per_kernel = {k: {"read_bytes": fetch_factor(k) * 1024 * total(k, "FETCH_SIZE") / calls, "fetch_factor": fetch_factor(k),
                       "write_bytes": 1024 * total(k, "WRITE_SIZE") / calls,
                       "TCC_MISS_lines_x128": 128 * total(k, "TCC_MISS_sum") / calls,
-                      "launches_per_call": summary[k]["FETCH_SIZE"]["dispatches"] / calls} for k in parts}
+                      "launches_per_call": round(summary[k]["FETCH_SIZE"]["dispatches"] / calls, 3),
+                      "avg_ns_kernel_trace": kernel_avg_ns(k)} for k in parts}
     hbm = sum(v["read_bytes"] + v["write_bytes"] for v in per_kernel.values())
     json.dump({
         "kernel": "awfmGpuSearchHits (ordered path): " + ", ".join(sorted(k.split("<")[0] for k in parts)),

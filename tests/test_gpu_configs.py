@@ -191,6 +191,65 @@ def test_cfg3b_planted_21mers_located(grch38):
     big.check_sample_against_oracle(d_chars, None, K, Q, ranges, None, hit_off, d_pos, exact_ranges=True)
 
 
+def test_cfg3a_sparse_hit_list_at_full_size(grch38):
+    """the list form of the results (awfmGpuSearchHitsCompact + awfmGpuSortHits) of the 100 M random 21-mers: the same
+    k-mers, ranges and positions as the dense form, nothing of the batch's size written after the search"""
+    big, t, Q, K = grch38, grch38.torch, BATCH, 21
+    d_chars = _random_batch(big, Q, K, 102)
+    ranges, counts, hit_off, scratch = big.buffers(Q)
+    big.g.search_hits(d_chars.data_ptr(), 0, K, Q, ranges.data_ptr(), counts.data_ptr())
+    cap = Q // 64
+    kmers = t.empty(cap, dtype=t.int32, device=big.dev)
+    lranges = t.empty(cap * 2, dtype=t.int64, device=big.dev)
+    num = t.zeros(1, dtype=t.int32, device=big.dev)
+    big.g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, kmers.data_ptr(), lranges.data_ptr(), cap, num.data_ptr())
+    big.g.sort_hits(kmers.data_ptr(), lranges.data_ptr(), cap)
+    t.cuda.synchronize()
+    m = int(num.item())
+    want = t.nonzero(counts).flatten()
+    assert m == want.numel() and t.equal(kmers[:m].to(t.int64), want)
+    assert t.equal(lranges.view(cap, 2)[:m], ranges.view(Q, 2)[want])
+    loff = t.empty(cap + 1, dtype=t.int64, device=big.dev)
+    total = big.g.hit_offsets(lranges.data_ptr(), cap, loff.data_ptr(), scratch.data_ptr())
+    total_dense = big.g.hit_offsets_from_counts(counts.data_ptr(), Q, hit_off.data_ptr(), scratch.data_ptr())
+    assert total == total_dense
+    pos_list = t.empty(max(total, 1), dtype=t.int64, device=big.dev)
+    pos_dense = t.empty(max(total, 1), dtype=t.int64, device=big.dev)
+    big.g.locate(lranges.data_ptr(), loff.data_ptr(), cap, total, pos_list.data_ptr())
+    big.g.locate(ranges.data_ptr(), hit_off.data_ptr(), Q, total, pos_dense.data_ptr())
+    t.cuda.synchronize()
+    assert t.equal(pos_list, pos_dense)
+
+
+def test_hit_heavy_8mers_through_the_drop_in_api_with_a_bounded_hit_budget(grch38, awfm, monkeypatch):
+    """awFmParallelSearchLocate on k-mers with about 47 000 hits each -- what the reference serves by growing every
+    positionList on its own (ref src/AwFmParallelSearch.c:315-387): here the flat hit list (4.7 * 10^8 positions) goes
+    through a device budget of 512 MB in windows that cut through the lists, and every list must come out complete and
+    in BWT order"""
+    big, t = grch38, grch38.torch
+    monkeypatch.setenv("AWFM_GPU_HIT_BUDGET_BYTES", str(512 << 20))
+    N, K = 10_000, 8
+    kmers = synth.random_queries(801, N, K)
+    chars, offsets = synth.fixed_csr(kmers)
+    sp, ep, cnt, _ = big.oracle.batch_search(chars, offsets, threads=os.cpu_count() or 1)
+    assert cnt.min() > 30_000 and int(cnt.astype(np.int64).sum()) > 4 * 10**8
+    lst = awfm.KmerSearchList(N)
+    lst.fill([bytes(k) for k in kmers])
+    assert awfm.parallel_search_locate(big.ix, lst, 16) == awfm.AwFmSuccess
+    assert np.array_equal(lst.counts(), cnt)
+    ho, pos, _ = big.oracle.batch_locate(sp[:40], ep[:40], threads=os.cpu_count() or 1)
+    for i in range(40):  # whole lists against the oracle
+        assert np.array_equal(lst.positions(i), pos[ho[i]:ho[i + 1]]), i
+    text_len = big.n
+    for i in range(40, N, 97):  # the others: every position in range, none twice, and spelling the k-mer
+        p = lst.positions(i)
+        assert p.size == cnt[i] and p.max() <= text_len - K and np.unique(p).size == p.size
+        at = t.from_numpy(p[:: max(1, p.size // 2000)].astype(np.int64)).to(big.dev)
+        for c in range(K):
+            assert bool((big.text[at + c] == int(kmers[i, c])).all()), (i, c)
+    lst.dealloc()
+
+
 def test_cfg5_mixed_length_8_to_30mers_counted(grch38):
     """divergent depth: 8..11-mers walk wide ranges from a letter range (no seed), 12..30-mers take 0..18 steps;
     even ids random, odd ids planted"""

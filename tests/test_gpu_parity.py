@@ -182,7 +182,7 @@ def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, requir
     g = awfm.GpuIndex(ix)
     before = g.device_bytes
     g.set_deep_seed(deep_k)
-    assert g.device_bytes == before + 16 * 4 ** deep_k
+    assert g.device_bytes == before + 8 * 4 ** deep_k  # {sp, length}: 8 bytes per entry below 2^32 positions
     ranges, ho, p = g.locate_host(chars, offsets)
     assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep)
     assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
@@ -490,6 +490,76 @@ def test_bucketed_order_with_skewed_and_tiny_batches(oracle, awfm, require_gpu, 
     ix.dealloc()
 
 
+@pytest.mark.parametrize("K,packed", [(19, False), (19, True), (32, False)])
+def test_sparse_hit_list_matches_the_dense_results(oracle, awfm, require_gpu, wide, K, packed):
+    """awfmGpuSearchHitsCompact + awfmGpuSortHits: the k-mers with hits as a list in k-mer order (ambiguous k-mers, which
+    the general kernel answers at the end of the call, included), the same list out of dense results
+    (awfmGpuCompactHits), locate on top of the list, and a list that overflows its capacity says so"""
+    import torch
+    n, seed_k, Q = 300_000, 8, 20_000
+    txt = synth.text(881, n).copy()
+    txt[5000:5040] = ord("n")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, seed_k)
+    oi = oracle.Index.wrap(oracle.DNA, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    q = np.concatenate([synth.random_queries(882, Q - 300, K), synth.planted_queries(883, 300, K, synth.text(881, n))]).copy()
+    q = q[np.random.default_rng(5).permutation(Q)]
+    if not packed:
+        q[17, 3] = ord("n")      # no hit
+        q[18] = ord("n")         # all n: matches inside the run of the text -- through the general kernel
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    ho, pos, _ = oi.batch_locate(sp, ep)
+    hits = np.flatnonzero(cnt)
+    assert 290 <= hits.size < 400 and (packed or cnt[18] > 0)  # (a planted k-mer may overlap the run of n)
+    dev = torch.device("cuda")
+    d_in = (torch.from_numpy(awfm.pack_kmers(q).view(np.int64)) if packed else torch.from_numpy(chars.copy())).to(dev)
+    cap = 1024
+    d_kmers = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_ranges = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+    d_num = torch.zeros(1, dtype=torch.int32, device=dev)
+    g.search_hits_compact(d_in.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr(), packed=packed)
+    g.sort_hits(d_kmers.data_ptr(), d_ranges.data_ptr(), cap)
+    torch.cuda.synchronize()
+    assert int(d_num.item()) == hits.size
+    kmers = d_kmers.cpu().numpy().view(np.uint32)
+    ranges = d_ranges.cpu().numpy().view(np.uint64).reshape(cap, 2)
+    assert np.array_equal(kmers[:hits.size], hits) and np.all(kmers[hits.size:] == 0xFFFFFFFF)
+    assert np.array_equal(ranges[:hits.size, 0], sp[hits]) and np.array_equal(ranges[:hits.size, 1], ep[hits])
+    assert np.all(ranges[hits.size:, 0] > ranges[hits.size:, 1])
+    # locate over the list as if it were the batch
+    d_off = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(cap), dtype=torch.uint8, device=dev)
+    total = g.hit_offsets(d_ranges.data_ptr(), cap, d_off.data_ptr(), d_scratch.data_ptr())
+    assert total == len(pos)
+    d_pos = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+    g.locate(d_ranges.data_ptr(), d_off.data_ptr(), cap, total, d_pos.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_pos[:total].cpu().numpy().view(np.uint64), pos)  # lists in k-mer order = the flat list of the batch
+    # a capacity below the number of hits: the count still says how many there are
+    g.search_hits_compact(d_in.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), 100, d_num.data_ptr(), packed=packed)
+    torch.cuda.synchronize()
+    assert int(d_num.item()) == hits.size
+    # the same list out of dense results
+    if not packed:
+        d_dr = torch.zeros(Q * 2, dtype=torch.int64, device=dev)
+        d_dc = torch.zeros(Q, dtype=torch.int32, device=dev)
+        g.search_hits(d_in.data_ptr(), 0, K, Q, d_dr.data_ptr(), d_dc.data_ptr())
+        d_flags = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+        d_scratch2 = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+        d_k2 = torch.zeros(cap, dtype=torch.int32, device=dev)
+        d_r2 = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+        g.compact_hits(d_dc.data_ptr(), d_dr.data_ptr(), Q, d_flags.data_ptr(), d_scratch2.data_ptr(), d_k2.data_ptr(),
+                       d_r2.data_ptr(), cap, d_num.data_ptr())
+        torch.cuda.synchronize()
+        assert int(d_num.item()) == hits.size
+        assert np.array_equal(d_k2.cpu().numpy().view(np.uint32), kmers)
+        assert np.array_equal(d_r2.cpu().numpy().view(np.uint64).reshape(cap, 2)[:hits.size], ranges[:hits.size])
+    g.destroy()
+    ix.dealloc()
+
+
 def test_hits_only_search_falls_back_to_the_general_kernel(oracle, awfm, require_gpu):
     """batches the ordered path does not cover (CSR offsets, k-mers shorter than the seed or longer than 32
     characters, amino indices) still honour the hits-only contract"""
@@ -739,7 +809,7 @@ def test_deep_seed_env_knob_through_the_drop_in_api(oracle, awfm, require_gpu, m
         lst.dealloc()
         img = L.awfmGpuIndexAcquire(ix.ptr)
         plain = awfm.GpuIndex(ix)  # a second image of the same index, created without going through the table
-        deep_bytes = 4 ** 9 * 16
+        deep_bytes = 4 ** 9 * 8  # {sp, length} entries below 2^32 positions
         assert L.awfmGpuIndexDeviceBytes(C.c_void_p(img)) >= deep_bytes  # the table was really built
         plain.destroy()
 

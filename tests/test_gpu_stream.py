@@ -275,3 +275,47 @@ def test_one_image_packed_then_ascii_and_growing_kmer_length(oracle, awfm, requi
     assert np.array_equal(counts, want[21][0]) and np.array_equal(positions, want[21][1])
     g.destroy()
     ix.dealloc()
+
+
+@pytest.mark.parametrize("ordered,chunk", [(1, 0), (1, 2500), (0, 3000)])
+def test_sparse_result_pipeline_matches_oracle(oracle, awfm, require_gpu, ordered, chunk):
+    """awfmGpuStreamPackedSparse / CharsSparse: per chunk the k-mers with hits as a list {k-mer, hit offsets} + positions.
+    Sparse chunks take the fused path (the seed-order search appends the list itself); a chunk in which more than 1/64 of
+    the k-mers occur overflows that list and is redone from dense results, as are the chunks after it; chunks that do not
+    take the seed-order path are always made from dense results.  Same lists either way."""
+    n, K = 300_000, 20
+    txt = synth.text(301, n)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(ordered)
+    # first 20000 k-mers: 100 occur (sparse: 1/200); then 6000 of which half occur (dense: the list overflows)
+    head = np.concatenate([synth.random_queries(302, 19_900, K), synth.planted_queries(303, 100, K, txt)])
+    head = head[np.random.default_rng(9).permutation(len(head))]
+    tail = np.concatenate([synth.random_queries(304, 3000, K), synth.planted_queries(305, 3000, K, txt)])
+    tail = tail[np.random.default_rng(10).permutation(len(tail))]
+    for kmers in (head, np.concatenate([head, tail])):
+        cnt, pos = _oracle_answers(oracle, oracle.DNA, ix, 8, 8, kmers)
+        want_ids = np.flatnonzero(cnt).astype(np.uint64)
+        want_off = np.concatenate([[0], np.cumsum(cnt[cnt > 0])]).astype(np.uint64)
+        for packed in (True, False):
+            data = awfm.pack_kmers(kmers) if packed else kmers.reshape(-1)
+            ids, off, positions = g.stream_sparse(data, K, locate=True, chunk=chunk, packed=packed)
+            assert np.array_equal(ids, want_ids), "k-mers with hits"
+            assert np.array_equal(off, want_off) and np.array_equal(positions, pos), "hit offsets / positions"
+            ids, off, none = g.stream_sparse(data, K, locate=False, chunk=chunk, packed=packed)
+            assert none is None and np.array_equal(ids, want_ids) and np.array_equal(off, want_off)
+    # chunk order, and what a chunk's call carries
+    calls = []
+
+    def sink(user, first, m, num, hit_kmers, hit_offsets, p, total):
+        calls.append((first, m, num, total, list(np.ctypeslib.as_array(hit_kmers, shape=(num,))) if num else []))
+        return 0
+
+    g.stream_sparse(awfm.pack_kmers(head), K, locate=True, chunk=4096, sink=sink)
+    assert [c[0] for c in calls] == list(range(0, len(head), 4096)) and sum(c[1] for c in calls) == len(head)
+    cnt, _ = _oracle_answers(oracle, oracle.DNA, ix, 8, 8, head)
+    for first, m, num, total, rel in calls:
+        assert num == int((cnt[first:first + m] > 0).sum()) and total == int(cnt[first:first + m].sum())
+        assert rel == sorted(rel) and all(0 <= r < m for r in rel)
+    g.destroy()
+    ix.dealloc()
