@@ -422,8 +422,11 @@ __global__ void __launch_bounds__(kPartitionThreads)
   const unsigned long long tiles = (numQueries + kPartitionTile - 1ull) / kPartitionTile;
   constexpr unsigned kPer = 3; /* bins handled per thread in the scan: 3 x 1024 >= 2049 */
   /* two register sets: the codes of the tile after the current one are requested before the current one is touched, so
-   * that their way from memory overlaps ALL of its phases (with one workgroup per CU nothing else hides it: the kernel
-   * ran at half the streaming rate while the loads were issued only a phase ahead) */
+   * that their way from memory overlaps all of its phases (one workgroup per CU: nothing else hides it).  What bounds
+   * the kernel are its stores -- 2048 runs of 64 bytes on average per tile, 1.2 GB written for 0.8 GB of records: with
+   * every tile storing to the same place (wrong results, measurement only) it takes 0.34 instead of 0.63 ms; with
+   * per-tile offsets from a scan instead of the atomic reservations (a stable partition, three small launches more)
+   * 0.59 + 0.12 ms. */
   unsigned long long recA[kPartitionItems], recB[kPartitionItems];
   auto loadTile = [&](unsigned long long tile, unsigned long long *rec) {
     const unsigned long long tileBase = tile * kPartitionTile;
@@ -535,7 +538,10 @@ struct OrderTouch {
 };
 
 template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false>
-__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? (PAIR && !NARROW ? 6 : 8) : 2, 8)))
+/* registers: 8 waves per SIMD (64 VGPRs) where nothing else limits the occupancy; the bucketed variant carries a chunk more
+ * (codes, query number and table entry of the next chunk) and is given 80: the pair tables in LDS hold a GRCh38-sized
+ * image at 6 workgroups per CU anyway; so are the instrumented variant and the wide two-lane measurement variant */
+__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || BUCKET || TOUCH || (G == 2 && !NARROW) ? 6 : 8) : 2, 8)))
     orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
                         const unsigned long long numRecs,
                         const unsigned *__restrict__ generalCount, const unsigned len, const unsigned depth,
@@ -637,7 +643,8 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   Raw raw = {0ull, 0ull, 0u}; /* the prefetched record */
   if (base + lane / G < end) readRecord(base + lane / G, raw);
   /* BUCKET: a record does not hold the bits its bucket stands for; the bucket of a position is where bucketStart says.
-   * The wave keeps the bucket of its current chunk (its chunks come in increasing order): wave-uniform, scalar loads. */
+   * The wave keeps the bucket of the chunk it looked at last (its chunks come in increasing order): wave-uniform, scalar
+   * loads. */
   const unsigned numBuckets = BUCKET ? 1u << bucketFmt.bucketBits : 0u;
   unsigned waveBucket = 0, waveNext = 0;
   if (BUCKET && base < end) {
@@ -650,47 +657,97 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     waveBucket = lo;
     waveNext = bucketStart[lo + 1u];
   }
+  /* bucket of this lane's record in the chunk that starts at chunkAt (not before the chunk asked for last) */
+  auto laneBucket = [&](unsigned long long chunkAt) -> unsigned {
+    while ((unsigned long long)waveNext <= chunkAt && waveBucket + 1u < numBuckets) {
+      waveBucket++;
+      waveNext = bucketStart[waveBucket + 1u];
+    }
+    unsigned mine = waveBucket, nb = waveBucket, ns = waveNext; /* the chunk may reach into the following bucket(s) */
+    while ((unsigned long long)ns <= chunkAt + (kChunk - 1u) && nb + 1u < numBuckets) {
+      nb++;
+      mine = chunkAt + lane / G >= (unsigned long long)ns ? nb : mine;
+      ns = bucketStart[nb + 1u];
+    }
+    return mine;
+  };
+  auto tableEntry = [&](unsigned long long at) -> ulonglong2 { return table == ix.deepSeed ? deepSeedEntry(ix, at) : table[at]; };
+  auto touchTable = [&](unsigned long long at) {
+    if (TOUCH) markLine(table == ix.seed ? touch.seedLines : touch.deepLines, at >> (table == ix.deepSeed && ix.deepNarrow ? 4 : 3));
+  };
+  /* BUCKET runs one chunk further ahead than the other formats: at the top of an iteration the record of the NEXT chunk
+   * is taken apart and its table entry requested, so that an entry has a whole iteration to arrive and its wait merges
+   * with the first block reads of the chunk before it.  (With the deeper table most entries are compulsory misses: one
+   * of the 3.5 memory rounds of a chunk of random 21-mers.  10^8 random 21-mers: 3.77-3.80 against 3.87-3.93 ms.)
+   * `raw` then holds the record of the chunk after `base`. */
+  unsigned long long codesCur = 0, baseNext2 = 0;
+  unsigned indexCur = 0;
+  ulonglong2 entryCur = make_ulonglong2(1ull, 0ull);
+  if (BUCKET) {
+    if (lane == 0) drawn = atomicAdd(ticket, 1u);
+    baseNext2 = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
+    if (base < end) {
+      const unsigned mine = laneBucket(base);
+      codesCur = bucketCodes(bucketFmt, mine, raw.a >> bucketFmt.indexBits);
+      indexCur = (unsigned)(raw.a & ((1ull << bucketFmt.indexBits) - 1ull));
+      if (base + lane / G < end) {
+        entryCur = tableEntry(codesCur & tableMask);
+        touchTable(codesCur & tableMask);
+      }
+    }
+    if (baseNext + lane / G < end) readRecord(baseNext + lane / G, raw);
+  }
   while (base < end) { /* wave-uniform */
     const unsigned long long q = base + lane / G;
     const bool live = q < end;
-    unsigned myBucket = 0;
+    pos_t sp = 1, ep = 0;
+    int pos = -1;
+    unsigned long long rem;
+    unsigned long long codes;
+    unsigned index;
+    ulonglong2 entry = make_ulonglong2(1ull, 0ull);
     if (BUCKET) {
-      while ((unsigned long long)waveNext <= base && waveBucket + 1u < numBuckets) {
-        waveBucket++;
-        waveNext = bucketStart[waveBucket + 1u];
+      /* this chunk: taken apart an iteration ago, its entry requested then */
+      codes = codesCur;
+      index = indexCur;
+      entry = entryCur;
+      asm volatile("" : "+v"(entry.x), "+v"(entry.y));
+      /* the next chunk: its record (requested an iteration ago) is taken apart, its table entry and the record of the
+       * chunk after it are requested */
+      entryCur = make_ulonglong2(1ull, 0ull);
+      if (baseNext < end) { /* wave-uniform */
+        const unsigned mine = laneBucket(baseNext);
+        asm volatile("" : "+v"(raw.a)::"memory");
+        codesCur = bucketCodes(bucketFmt, mine, raw.a >> bucketFmt.indexBits);
+        indexCur = (unsigned)(raw.a & ((1ull << bucketFmt.indexBits) - 1ull));
+        if (baseNext + lane / G < end) {
+          entryCur = tableEntry(codesCur & tableMask);
+          touchTable(codesCur & tableMask);
+        }
       }
-      myBucket = waveBucket;
-      unsigned nb = waveBucket, ns = waveNext; /* the chunk may reach into the following bucket(s) */
-      while ((unsigned long long)ns <= base + (kChunk - 1u) && nb + 1u < numBuckets) {
-        nb++;
-        myBucket = q >= (unsigned long long)ns ? nb : myBucket;
-        ns = bucketStart[nb + 1u];
-      }
-    }
+      if (lane == 0) drawn = atomicAdd(ticket, 1u);
+      if (baseNext2 + lane / G < end) readRecord(baseNext2 + lane / G, raw);
+    } else {
     /* the record fetched an iteration ago is taken apart BEFORE anything new is issued: a wait placed after the
      * atomic below would also wait for that atomic */
     asm volatile("" : "+v"(raw.a), "+v"(raw.b), "+v"(raw.keyWord)::"memory");
     const unsigned key = (raw.keyWord >> (16u * (unsigned)(q & 1ull))) & 0xFFFFu;
-    const unsigned long long codes = BUCKET    ? bucketCodes(bucketFmt, myBucket, raw.a >> bucketFmt.indexBits)
-                                     : COMPACT ? orderCodes(format, key, (unsigned)(raw.a >> 32))
-                                               : raw.a;
-    const unsigned index = BUCKET    ? (unsigned)(raw.a & ((1ull << bucketFmt.indexBits) - 1ull))
-                           : COMPACT ? (unsigned)raw.a
-                                     : (unsigned)raw.b;
+    codes = COMPACT ? orderCodes(format, key, (unsigned)(raw.a >> 32)) : raw.a;
+    index = COMPACT ? (unsigned)raw.a : (unsigned)raw.b;
+    }
     const unsigned myLen = VARLEN ? (unsigned)(raw.b >> 32) : len; /* before `raw` is overwritten by the prefetch */
     /* ---- seed (ref src/AwFmKmerTable.c:4-51): the index table, or the deeper device-only one ---- */
-    pos_t sp = 1, ep = 0;
-    int pos = -1;
-    unsigned long long rem;
-    ulonglong2 entry = make_ulonglong2(1ull, 0ull);
+    if (!BUCKET) {
     /* fixed length: the table entry is requested FIRST, so that the wait for it (loads return in order) is not also a
      * wait for the ticket atomic and the record prefetch issued below */
-    if (!VARLEN && live) entry = table == ix.deepSeed ? deepSeedEntry(ix, codes & tableMask) : table[codes & tableMask];
-    if (TOUCH && !VARLEN && live)
-      markLine(table == ix.seed ? touch.seedLines : touch.deepLines, (codes & tableMask) >> (table == ix.deepSeed && ix.deepNarrow ? 4 : 3));
+    if (!VARLEN && live) {
+      entry = tableEntry(codes & tableMask);
+      touchTable(codes & tableMask);
+    }
     /* draw the ticket after next (consumed at the bottom), fetch the next chunk's record */
     if (lane == 0) drawn = atomicAdd(ticket, 1u);
     if (baseNext + lane / G < end) readRecord(baseNext + lane / G, raw);
+    }
     if (!VARLEN) {
       if (live) {
         sp = (pos_t)entry.x;
@@ -768,7 +825,12 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       if (counts) counts[index] = (unsigned)(ep - sp + (pos_t)1);
     }
     base = baseNext;
-    baseNext = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
+    if (BUCKET) {
+      baseNext = baseNext2;
+      baseNext2 = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
+    } else {
+      baseNext = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
+    }
   }
 }
 

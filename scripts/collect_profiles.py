@@ -80,7 +80,7 @@ if ordered:
     calls = summary[ordered[0]]["FETCH_SIZE"]["dispatches"]
     parts = [k for k in summary if "FETCH_SIZE" in summary[k] and (
              k == ordered[0] or k.startswith(("fillNoHitKernel", "fillSparseKernel", "encodeQueriesKernel", "encodeCodes", "partitionKernel",
-                                              "bucketScanKernel"))
+                                              "bucketScanKernel", "segmentSumsKernel", "tileOffsetsKernel"))
              or ("radix_sort" in k and "unsigned short" in k) or (k.startswith("searchKernel") and k.rstrip(">").endswith("true, false")))]
     per_kernel = {k: {"read_bytes": fetch_factor(k) * 1024 * total(k, "FETCH_SIZE") / calls, "fetch_factor": fetch_factor(k),
                       "write_bytes": 1024 * total(k, "WRITE_SIZE") / calls,

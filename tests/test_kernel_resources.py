@@ -65,7 +65,9 @@ def test_ordered_search_kernels_keep_full_occupancy(kernel_metadata):
     for variant, bucket in (("Lb1ELb1ELb0E", "Lb1E"), ("Lb1ELb0ELb0E", "Lb0E"), ("Lb1ELb0ELb1E", "Lb0E")):
         for pair in ("Lb0E", "Lb1E"):
             k = _one(kernel_metadata, r"orderedSearchKernelILi4E" + variant + pair + "Lb0E" + bucket + "E")
-            assert k["vgpr"] <= 64 and k["spill"] == 0 and k["scratch"] == 0, variant + pair
+            # the bucketed variant holds the next chunk's codes and table entry as well: 80 registers (6 waves per SIMD,
+            # which is what the pair tables in LDS leave a GRCh38-sized image anyway)
+            assert k["vgpr"] <= (80 if bucket == "Lb1E" else 64) and k["spill"] == 0 and k["scratch"] == 0, variant + pair
             assert k["lds"] <= 16 * 1024  # static; the pair variant adds 64 B per 2^23 positions of dynamic LDS
 
 
