@@ -61,7 +61,7 @@ constexpr unsigned kNucSuperShift = 32;   /* positions per nucleotide superblock
 constexpr unsigned kMaxNucSuper = 64;     /* nucleotide images of up to 2^38 positions */
 constexpr unsigned kAminoSuperShift = 16; /* positions per amino superblock: 2^16 */
 constexpr unsigned kAminoSuperStride = 24;
-constexpr unsigned kPairSuperShift = 23;  /* positions per superblock of the pair image: 2^23 (23-bit relative counts) */
+constexpr unsigned kPairSuperShift = 24;  /* positions per superblock of the pair image: 2^24 (a count BEFORE a block is at most 2^24 - 128: 24 bits) */
 constexpr unsigned kPairCountMask = 0xFFFFFFu;
 /* where the two 16-B pieces of slice k of pair block blk are (in uint4 units): the four plane pieces fill the first
  * 64-B sector of the line and the four count pieces the second, so each of the two load instructions of a step touches

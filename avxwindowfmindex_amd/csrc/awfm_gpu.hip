@@ -1153,9 +1153,14 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     DevIndex pairDev = g->dev;
     pairDev.pairSuperInLds = superInLds ? 1u : 0u;
 #define AWFM_LOCP(P2, NR)                                                                                                    \
-  hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true>),                                                                   \
-                     dim3(gridFor(th, g, walkKernel<false, 4, P2, NR, true>, walkThreads(true) / 4, pairLds, walkThreads(true))), \
-                     dim3(walkThreads(true)), pairLds, s, pairDev, th, pos)
+  do {                                                                                                                       \
+    const unsigned grid__ = gridFor(th, g, walkKernel<false, 4, P2, NR, true>, walkThreads(true) / 4, pairLds, walkThreads(true)); \
+    /* a short hit list: batches of 4 instead of 16 hits per lane group, when the grid has a group for every one */         \
+    if (th <= (unsigned long long)grid__ * (walkThreads(true) / 4) * 4ull)                                                   \
+      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true, 1u>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos); \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos); \
+  } while (0)
 #define AWFM_LOC3(AM, GG, P2, NR)                                                                                  \
   hipLaunchKernelGGL((walkKernel<AM, GG, P2, NR>), dim3(gridFor(th, g, walkKernel<AM, GG, P2, NR>, kThreads / GG)), \
                      dim3(kThreads), 0, s, g->dev, th, pos)

@@ -4,7 +4,7 @@
  *   pairCodesKernel   one lane per BWT position p: letter at p, q = LF(p) (rank in p's own block), letter at q (one
  *                     random 16-B read), the pair code; a wave turns 64 positions into two slices of bit planes with
  *                     ballots and leaves a 32-byte histogram of its half block (16 pairs, 4 letters) for the counting pass
- *   pairCountsKernel  one workgroup per superblock of 2^23 positions: exclusive scan of the half-block histograms,
+ *   pairCountsKernel  one workgroup per superblock of 2^24 positions: exclusive scan of the half-block histograms,
  *                     24-bit relative counts (pairs and letters) into the blocks, totals per superblock
  *   pairStartKernel   C2[c1c2] = C[c1] + Occ(c1, C[c2]) by one rank on the one-letter image each
  * and a 64-bit prefix sum over the few hundred superblock totals on the host.
@@ -108,13 +108,14 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-/* one workgroup per superblock (2^16 blocks): thread t owns blocks 256 t .. 256 t + 255 of it */
+/* one workgroup per superblock: thread t owns kPerThread consecutive blocks of it */
 __global__ void __launch_bounds__(256)
     pairCountsKernel(const uint4 *__restrict__ halfHist, u64 numBlocks, uint4 *__restrict__ pairBlocks,
                      u64 *__restrict__ superTotals) {
   __shared__ unsigned sPart[256][kPairSuperStride + 1]; /* +1: no bank conflicts on the column walk */
+  constexpr u64 kPerThread = (1ull << (kPairSuperShift - kBlockShift)) / 256ull;
   const u64 firstBlock = (u64)blockIdx.x << (kPairSuperShift - kBlockShift);
-  const u64 myFirst = firstBlock + 256ull * threadIdx.x;
+  const u64 myFirst = firstBlock + kPerThread * threadIdx.x;
   unsigned acc[kPairSuperStride]; /* 16 pairs, 4 letters */
   for (unsigned i = 0; i < kPairSuperStride; i++) acc[i] = 0;
   auto addHalf = [&](u64 half) -> unsigned { /* returns the flag bit of the half */
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(256)
     for (unsigned i = 0; i < kPairSuperStride; i++) acc[i] += (w[i >> 2] >> (8u * (i & 3u))) & 0xFFu;
     return h.x & 0x80u;
   };
-  for (u64 b = myFirst; b < myFirst + 256ull && b < numBlocks; b++) {
+  for (u64 b = myFirst; b < myFirst + kPerThread && b < numBlocks; b++) {
     (void)addHalf(2ull * b);
     (void)addHalf(2ull * b + 1ull);
   }
@@ -140,14 +141,14 @@ __global__ void __launch_bounds__(256)
   }
   __syncthreads();
   for (unsigned i = 0; i < kPairSuperStride; i++) acc[i] = sPart[threadIdx.x][i];
-  for (u64 b = myFirst; b < myFirst + 256ull && b < numBlocks; b++) {
+  for (u64 b = myFirst; b < myFirst + kPerThread && b < numBlocks; b++) {
     unsigned before[kPairSuperStride];
     for (unsigned i = 0; i < kPairSuperStride; i++) before[i] = acc[i];
     const unsigned flag = (addHalf(2ull * b) | addHalf(2ull * b + 1ull)) ? 0x80000000u : 0u;
-    for (unsigned k = 0; k < 4u; k++) { /* slice k: count of letter k, counts of pairs 4k..4k+3, 24 bits each */
+    for (unsigned k = 0; k < 4u; k++) { /* slice k: count of letter k (+ the flag), counts of pairs 4k..4k+3, 24 bits each */
       const unsigned c0 = before[4 * k], c1 = before[4 * k + 1], c2 = before[4 * k + 2], c3 = before[4 * k + 3];
       pairBlocks[pairCountsAt(b, k)] =
-          make_uint4(before[16u + k], c0 | (c1 << 24), (c1 >> 8) | (c2 << 16), (c2 >> 16) | (c3 << 8) | flag);
+          make_uint4(before[16u + k] | flag, c0 | (c1 << 24), (c1 >> 8) | (c2 << 16), (c2 >> 16) | (c3 << 8));
     }
   }
 }

@@ -56,7 +56,11 @@ __device__ __forceinline__ unsigned long long finishPosition(const DevIndex &ix,
  * GRCh38-sized index) would otherwise limit a CU to 6 workgroups of 256 */
 constexpr int walkThreads(bool pair) { return pair ? 512 : kThreads; }
 
-template <bool AMINO, int G, bool POW2, bool NARROW, bool PAIR = false>
+/* PERLANE: hits a lane holds of its group's batch (a batch = PERLANE * G hits, walked one after the other).  4: a batch is
+ * read and written as whole lines, which is what a long hit list wants; 1: a quarter of the chain per group, which is what
+ * a short one wants (7 * 10^4 hits of 10^8 random 21-mers: every group of the grid gets at most one batch either way, and
+ * the kernel's time is the length of that chain: 0.16 ms with batches of 16) */
+template <bool AMINO, int G, bool POW2, bool NARROW, bool PAIR = false, unsigned PERLANE = 4u>
 __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80)))
     walkKernel(const DevIndex ix, unsigned long long totalHits, unsigned long long *__restrict__ positions) {
   static_assert(!PAIR || (!AMINO && G == 4), "pair steps: nucleotide images, 4 lanes per hit");
@@ -87,7 +91,8 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
    * one coalesced read brings a batch in, the hand-over values replace the BWT positions in the registers,
    * one coalesced write takes the batch out.  (One hit per refill, 8 bytes at a time, cost an extra
    * partial-line read and a read-modify-write per hit: the L2 lines do not survive between the refills.) */
-  constexpr unsigned kPerLane = 4u, kBatch = kPerLane * G;
+  constexpr unsigned kPerLane = PERLANE, kBatch = kPerLane * G;
+  static_assert(PERLANE == 4u || PERLANE == 1u, "a lane holds four hits of a batch, or one");
   const unsigned long long batchStride = numGroups * kBatch;
   const bool aligned = ((unsigned long long)positions & 15ull) == 0ull;
   /* (the four entries of a lane are named scalars: hipcc moves a small array that is indexed in any
@@ -98,7 +103,10 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
   auto loadBatch = [&](unsigned long long base) -> Four {
     const unsigned long long first = base + kPerLane * gl;
     Four r;
-    if (aligned && first + kPerLane <= totalHits) {
+    if (kPerLane == 1u) {
+      r.a = first < totalHits ? positions[first] : 0ull;
+      r.b = r.c = r.d = 0ull;
+    } else if (aligned && first + kPerLane <= totalHits) {
       const ulonglong2 lo = *(const ulonglong2 *)(positions + first), hi = *(const ulonglong2 *)(positions + first + 2);
       r.a = lo.x;
       r.b = lo.y;
@@ -114,7 +122,9 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
   };
   auto storeBatch = [&](unsigned long long base, const Four &v) {
     const unsigned long long first = base + kPerLane * gl;
-    if (aligned && first + kPerLane <= totalHits) {
+    if (kPerLane == 1u) {
+      if (first < totalHits) positions[first] = v.a;
+    } else if (aligned && first + kPerLane <= totalHits) {
       *(ulonglong2 *)(positions + first) = make_ulonglong2(v.a, v.b);
       *(ulonglong2 *)(positions + first + 2) = make_ulonglong2(v.c, v.d);
     } else {
@@ -184,7 +194,7 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
         ph = *(const Piece *)(ix.pairBlocks + pairCountsAt(pblk, gl));
       }
       __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0) */
-      if (walk && (ph.w >> 31) == 0u) {
+      if (walk && (ph.x >> 31) == 0u) {
         const unsigned bit = plocal & 31u, ownerSlice = plocal >> 5;
         const unsigned mine = ((pl.x >> bit) & 1u) | (((pl.y >> bit) & 1u) << 1) | (((pl.z >> bit) & 1u) << 2) | (((pl.w >> bit) & 1u) << 3);
         const unsigned pi = groupShfl<G>(mine, ownerSlice) & 15u; /* pair code at p */

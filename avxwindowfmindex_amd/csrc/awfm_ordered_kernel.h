@@ -539,9 +539,10 @@ struct OrderTouch {
 
 template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false>
 /* registers: 8 waves per SIMD (64 VGPRs) where nothing else limits the occupancy; the bucketed variant carries a chunk more
- * (codes, query number and table entry of the next chunk) and is given 80: the pair tables in LDS hold a GRCh38-sized
- * image at 6 workgroups per CU anyway; so are the instrumented variant and the wide two-lane measurement variant */
-__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || BUCKET || TOUCH || (G == 2 && !NARROW) ? 6 : 8) : 2, 8)))
+ * (codes, query number and table entry of the next chunk) and is given 72, like the mixed-length variant (7 waves per
+ * SIMD; the pair tables of a GRCh38-sized image, 12 KB of LDS, allow that many workgroups); the 64-bit pair variants, the instrumented variant and
+ * the wide two-lane measurement variant get 80 */
+__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || TOUCH || (G == 2 && !NARROW) ? 6 : (BUCKET || VARLEN ? 7 : 8)) : 2, 8)))
     orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
                         const unsigned long long numRecs,
                         const unsigned *__restrict__ generalCount, const unsigned len, const unsigned depth,

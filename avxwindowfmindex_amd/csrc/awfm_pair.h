@@ -18,11 +18,12 @@
  *                      bits of a pair code are the position's own letter, so the block also gives the single step
  *                      LF(p) -- which the walk needs, because it must stop at a sampled position in between two steps;
  *                      w0..w2 = four 24-bit counts of the pairs 4k..4k+3 (c1 = k, c2 = 0..3) before the block
- *                      (bits 24 i .. 24 i + 23); all counts relative to the block's superblock of 2^23 positions;
- *                      bit 95, the top bit of the last count (counts stay below 2^23), is set in every slice of a
- *                      block that holds a position whose pair is not two of a,c,g,t (ambiguity letter or sentinel at
- *                      the position or at its LF image): such blocks are stepped through the one-letter image, a
- *                      letter at a time.
+ *                      (bits 24 i .. 24 i + 23); all counts relative to the block's superblock of 2^24 positions (a
+ *                      count before a block is at most 2^24 - 128: the superblock table of a GRCh38-sized image is
+ *                      12 KB of LDS per workgroup instead of the 24 KB of 2^23-position superblocks);
+ *                      bit 31 of l is set in every slice of a block that holds a position whose pair is not two of
+ *                      a,c,g,t (ambiguity letter or sentinel at the position or at its LF image): such blocks are
+ *                      stepped through the one-letter image, a letter at a time.
  * pairSuper[20 sb + i] = absolute count at the start of superblock sb of pair i (i < 16) or letter i - 16 (64-bit; a
  * 32-bit copy for LDS).
  *
@@ -48,7 +49,7 @@ __device__ __forceinline__ unsigned pairCount24(const Piece &h, unsigned c2) {
   const unsigned low = c2 < 2u ? h.y : (c2 == 2u ? h.z : h.w);
   const unsigned high = c2 < 2u ? h.z : (c2 == 2u ? h.w : 0u);
   const unsigned shift = (24u * c2) & 31u; /* 0, 24, 16, 8 */
-  return __builtin_amdgcn_alignbit(high, low, shift) & (c2 == 3u ? (kPairCountMask >> 1) : kPairCountMask);
+  return __builtin_amdgcn_alignbit(high, low, shift) & kPairCountMask;
 }
 
 /* positions of a slice whose pair code is `pi`; pm[i] = bit i of pi as an all-ones mask */
@@ -139,7 +140,7 @@ __device__ __forceinline__ PairStep pairSearchStep(const DevIndex &ix, const uns
   const unsigned base0 = groupShfl<4>(c0, pi >> 2);
   unsigned base1 = groupShfl<4>(c1, pi >> 2);
   base1 = same ? base0 : base1;
-  const unsigned flagged = (h0.w | (same ? 0u : h1.w)) >> 31; /* the flag is in every slice of a flagged block */
+  const unsigned flagged = (h0.x | (same ? 0u : h1.x)) >> 31; /* the flag is in every slice of a flagged block */
   const unsigned packed = groupSum<4>(n0 | (n1 << 16));
   if (flagged) return kPairFlagged;
   const pos_t sp2 = cPair + super0 + (pos_t)base0 + (pos_t)(packed & 0xFFFFu);

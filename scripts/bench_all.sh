@@ -1,6 +1,6 @@
 #!/bin/bash
 # every bench.py configuration quoted in DESIGN.md, one JSON line each -> gpurun_out/bench_<tag>/bench_<name>.json
-TAG=${1:-r2}
+TAG=${1:-r3}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/bench_$TAG
 mkdir -p "$OUT"
@@ -10,17 +10,22 @@ run() { # name [ENV=..]... -- bench args
   envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   env "${envs[@]}" python3 bench.py "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/bench_$name.json"
 }
-run default --
+run default -- --steps 20 --warmup 5
 run count -- --mode count
 run planted -- --workload planted
 run mixed -- --workload mixed
+run mixed_locate -- --workload mixed --mode locate --no-e2e --steps 2 --warmup 1
 run amino -- --alphabet amino
-run general AWFM_GPU_ORDERED=0 -- --mode count --no-cpu --no-e2e
-run general_letters AWFM_GPU_ORDERED=0 AWFM_GPU_GENERAL_NO_PAIR=1 -- --mode count --no-cpu --no-e2e
-run nopair_default AWFM_GPU_PAIR=0 -- --no-cpu --no-e2e
-run nopair_planted AWFM_GPU_PAIR=0 -- --workload planted --no-cpu --no-e2e
-run deep14 -- --device-seed-k 14 --no-cpu --no-e2e
-run planted_dense -- --workload planted --device-dense-sa --no-cpu --no-e2e
+run strong -- --scaling strong --no-cpu --no-e2e --no-secondary --general-steps 0
+run general AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 -- --mode count --no-cpu --no-e2e
+run general_letters AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 AWFM_GPU_GENERAL_NO_PAIR=1 -- --mode count --no-cpu --no-e2e
+run dense_results AWFM_BENCH_DENSE_RESULTS=1 -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run no_deep_table -- --device-seed-k 0 --no-cpu --no-e2e --no-secondary --general-steps 0
+run rocprim_sort AWFM_GPU_ORDERED_SORT=rocprim -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run nopair_default AWFM_GPU_PAIR=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run planted_dense_sa -- --workload planted --device-dense-sa --no-cpu --no-e2e
+run repetitive_random -- --text repetitive --no-cpu --no-e2e --general-steps 0
+run repetitive_planted -- --text repetitive --workload planted --no-cpu --no-e2e --general-steps 0
 python3 - "$OUT" <<'PY'
 import glob, json, os, sys
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):

@@ -82,10 +82,17 @@ if ordered:
              k == ordered[0] or k.startswith(("fillNoHitKernel", "fillSparseKernel", "encodeQueriesKernel", "encodeCodes", "partitionKernel",
                                               "bucketScanKernel", "segmentSumsKernel", "tileOffsetsKernel"))
              or ("radix_sort" in k and "unsigned short" in k) or (k.startswith("searchKernel") and k.rstrip(">").endswith("true, false")))]
-    per_kernel = {k: {"read_bytes": fetch_factor(k) * 1024 * total(k, "FETCH_SIZE") / calls, "fetch_factor": fetch_factor(k),
-                      "write_bytes": 1024 * total(k, "WRITE_SIZE") / calls,
-                      "TCC_MISS_lines_x128": 128 * total(k, "TCC_MISS_sum") / calls,
-                      "launches_per_call": round(summary[k]["FETCH_SIZE"]["dispatches"] / calls, 3),
+    def per_call(k, counter):
+        """mean per dispatch x launches of the kernel in one search call (the instrumented tally launch of bench.py runs the
+        ordering kernels once more than the timed steps do: whole launches per call, not a ratio of dispatch counts)"""
+        c = summary[k].get(counter)
+        launches = max(1, summary[k]["FETCH_SIZE"]["dispatches"] // calls)
+        return (c["mean"] * launches if c else 0.0), launches
+
+    per_kernel = {k: {"read_bytes": fetch_factor(k) * 1024 * per_call(k, "FETCH_SIZE")[0], "fetch_factor": fetch_factor(k),
+                      "write_bytes": 1024 * per_call(k, "WRITE_SIZE")[0],
+                      "TCC_MISS_lines_x128": 128 * per_call(k, "TCC_MISS_sum")[0],
+                      "launches_per_call": per_call(k, "FETCH_SIZE")[1],
                       "avg_ns_kernel_trace": kernel_avg_ns(k)} for k in parts}
     hbm = sum(v["read_bytes"] + v["write_bytes"] for v in per_kernel.values())
     json.dump({
