@@ -35,7 +35,7 @@ GPU_SYMBOLS = [
     "awfmPackKmers", "awfmGpuPackKmers", "awfmGpuUnpackKmers", "awfmGpuHostAlloc", "awfmGpuHostFree", "awfmGpuStreamPacked",
     "awfmGpuStreamChars", "awfmGpuCountPackedHost", "awfmGpuLocatePackedHost", "awfmGpuIndexSetPairImage", "awfmGpuIndexHasPairImage",
     "awfmGpuSearchHitsPacked", "awfmGpuLocateTo", "awfmGpuSearchHitsLineTally", "awfmGpuIndexDeepSeedK", "awfmGpuSearchHitsCompact", "awfmGpuCompactHits", "awfmGpuSortHits",
-    "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse",
+    "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse", "awfmGpuSearchHitsInOrder",
 ]
 # int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
 CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
@@ -158,6 +158,7 @@ def lib():
         "awfmGpuSearchHitsSparse": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuSearchHitsCompact": (C.c_int, [vp, vp, vp, C.c_uint32, u64, C.c_int, vp, vp, C.c_uint32, vp, vp]),
         "awfmGpuCompactHits": (C.c_int, [vp, vp, vp, u64, vp, vp, vp, vp, C.c_uint32, vp, vp]),
+        "awfmGpuSearchHitsInOrder": (C.c_int, [vp, vp, vp, C.c_uint32, u64, C.c_int, vp, vp, vp]),
         "awfmGpuSortHits": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
         "awfmGpuScanScratchBytes": (u64, [u64]),
         "awfmGpuHitOffsets": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),

@@ -126,7 +126,9 @@ constexpr int kThreads = 256;
 /* Sparse results (awfmGpuSearchHitsCompact): instead of a range / count under every query number, the k-mers with hits
  * are appended to a list {query number, range}, one returning atomic per wave instruction that has any (the order of the
  * list is whatever the waves make it: awfmGpuSortHits puts it in query order).  Entries beyond `cap` are counted, not
- * stored.  count == NULL: dense results. */
+ * stored.  count == NULL and kmers != NULL: results IN SEARCH ORDER (awfmGpuSearchHitsInOrder) -- entry q of the order
+ * gets {query number, range}, every k-mer one entry, written as whole lines: for batches in which most k-mers have hits,
+ * where the stores under the original query numbers are 10^8 partial-line writes.  Both NULL: dense results. */
 struct SparseOut {
   unsigned *count;
   unsigned cap;

@@ -313,6 +313,81 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   return orderedSearch(g, s, dChars, off, fixedLength, nq, rng, dCounts, packed, rangesOfHitsOnly, nullptr, nullptr, nullptr);
 }
 
+/* encodeRecordsKernel -> bucketScanKernel -> partitionRecordsKernel -> orderedSearchKernel (16-byte records) ->
+ * searchKernel<INDIRECT>; the caller holds orderMutex.  Return values as awfmGpuOrderedSearch. */
+static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off, uint32_t fixedLength,
+                              unsigned depth, const ulonglong2 *table, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts,
+                              bool rangesOfHitsOnly, const OrderTouch *touch, const SparseOut *sparse) {
+  constexpr unsigned bins = (1u << kBucketBitsMax) + 1u, binsPad = (bins + 3u) & ~3u;
+  const size_t histAt = kOrderCounterBytes, cursorsAt = histAt + alignUp256(bins * 4u), startAt = cursorsAt + alignUp256(bins * 4u);
+  const size_t inAt = startAt + alignUp256((bins + 1u) * 4u), outAt = inAt + alignUp256(nq * sizeof(QueryRec));
+  const size_t total = outAt + alignUp256(nq * sizeof(QueryRec));
+  if (!ensureOrderScratch(g, total)) return 0;
+#define WIDE_TRY(call)                      \
+  do {                                      \
+    hipError_t e__ = (call);                \
+    if (e__ != hipSuccess) {                \
+      setError(#call, e__);                 \
+      return -(int)AwFmGeneralFailure;      \
+    }                                       \
+  } while (0)
+  if (!g->orderEvent) WIDE_TRY(hipEventCreateWithFlags(&g->orderEvent, hipEventDisableTiming));
+  if (g->orderEventRecorded) WIDE_TRY(hipStreamWaitEvent(s, g->orderEvent, 0));
+  uint8_t *w = (uint8_t *)g->dOrder;
+  unsigned *generalCount = (unsigned *)w;
+  unsigned *hist = (unsigned *)(w + histAt), *cursors = (unsigned *)(w + cursorsAt), *bucketStart = (unsigned *)(w + startAt);
+  QueryRec *recsIn = (QueryRec *)(w + inAt), *recsOut = (QueryRec *)(w + outAt);
+  WIDE_TRY(hipMemsetAsync(w, 0, startAt, s));
+  if (!sparse) {
+    hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
+                       rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
+    WIDE_TRY(hipGetLastError());
+  }
+  const unsigned long long encodeTiles = (nq + 255ull) / 256ull;
+  const unsigned encodeGrid = (unsigned)(encodeTiles < (unsigned long long)g->numCUs * 8u ? encodeTiles : (unsigned long long)g->numCUs * 8u);
+  const unsigned seedK = g->dev.seedK, deepK = g->dev.deepK;
+  if (off)
+    hipLaunchKernelGGL((encodeRecordsKernel<true>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth, seedK, deepK, nq,
+                       recsIn, hist);
+  else
+    hipLaunchKernelGGL((encodeRecordsKernel<false>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth, seedK, deepK, nq,
+                       recsIn, hist);
+  WIDE_TRY(hipGetLastError());
+  hipLaunchKernelGGL(bucketScanKernel, dim3(1), dim3(1024), 0, s, (const unsigned *)hist, bins, bucketStart, generalCount);
+  WIDE_TRY(hipGetLastError());
+  const size_t lds = (size_t)kWideTile * 16u + 3u * binsPad * 4u;
+  static std::once_flag ldsOnce;
+  static hipError_t ldsError = hipSuccess;
+  std::call_once(ldsOnce, [] {
+    ldsError = hipFuncSetAttribute((const void *)partitionRecordsKernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ldsError == hipSuccess)
+      ldsError = hipFuncSetAttribute((const void *)partitionRecordsKernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  });
+  WIDE_TRY(ldsError);
+  const unsigned long long tiles = (nq + kWideTile - 1ull) / kWideTile;
+  const unsigned grid = (unsigned)(tiles < (unsigned long long)g->numCUs ? tiles : (unsigned long long)g->numCUs);
+  if (off)
+    hipLaunchKernelGGL((partitionRecordsKernel<true>), dim3(grid), dim3(kPartitionThreads), lds, s, (const QueryRec *)recsIn, depth, seedK,
+                       deepK, nq, (const unsigned *)bucketStart, cursors, recsOut);
+  else
+    hipLaunchKernelGGL((partitionRecordsKernel<false>), dim3(grid), dim3(kPartitionThreads), lds, s, (const QueryRec *)recsIn, depth, seedK,
+                       deepK, nq, (const unsigned *)bucketStart, cursors, recsOut);
+  WIDE_TRY(hipGetLastError());
+  const bool narrow = awfmImageNarrow(g);
+  enum AwFmReturnCode rc;
+  const unsigned short *noKeys = nullptr;
+#define WIDE_GO(NR, VL) \
+  launchOrdered<NR, false, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, noKeys, generalCount, rng, dCounts, false, touch, sparse)
+  if (off) rc = narrow ? WIDE_GO(true, true) : WIDE_GO(false, true);
+  else rc = narrow ? WIDE_GO(true, false) : WIDE_GO(false, false);
+#undef WIDE_GO
+  if (rc != AwFmSuccess) return -(int)rc;
+  WIDE_TRY(hipEventRecord(g->orderEvent, s));
+  g->orderEventRecorded = true;
+#undef WIDE_TRY
+  return 1;
+}
+
 static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                          uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
                          bool rangesOfHitsOnly, const OrderTouch *touch, uint64_t *recordBytesOut, const SparseOut *sparse) {
@@ -332,6 +407,12 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   if (bucketed) {
     if (recordBytesOut) *recordBytesOut = 8u;
     return bucketedSearch(g, s, dChars, fixedLength, depth, table, nq, rng, dCounts, packed, rangesOfHitsOnly, touch, bucketFmt, sparse);
+  }
+  /* everything else the path covers -- mixed-length batches, fixed-length k-mers whose record does not fit 8 bytes --
+   * through the same two passes over 16-byte records */
+  if (!(sortEnv && !strcmp(sortEnv, "rocprim")) && !getenv("AWFM_GPU_ORDER_KEY_BITS") && !packed) {
+    if (recordBytesOut) *recordBytesOut = sizeof(QueryRec);
+    return wideBucketedSearch(g, s, dChars, off, fixedLength, depth, table, nq, rng, dCounts, rangesOfHitsOnly, touch, sparse);
   }
   const bool compact = !off && orderCompact(fixedLength, depth) && !getenv("AWFM_GPU_ORDERED_WIDE");
   if (recordBytesOut) *recordBytesOut = compact ? 8u + 2u : sizeof(QueryRec); /* what the search reads per k-mer: record (+ key) */
@@ -584,6 +665,34 @@ extern "C" enum AwFmReturnCode awfmGpuSearchHitsCompact(AwFmGpuIndex *g, const u
   if (did < 0) return (enum AwFmReturnCode)(-did);
   if (did == 0) {
     setError("awfmGpuSearchHitsCompact: this batch does not take the seed-order path on this image");
+    return AwFmUnsupportedVersionError;
+  }
+  return AwFmSuccess;
+}
+
+/* see include/awfm_gpu.h */
+extern "C" enum AwFmReturnCode awfmGpuSearchHitsInOrder(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                                        uint32_t fixedLength, uint64_t numQueries, int packed, uint32_t *dOrderKmers,
+                                                        struct AwFmSearchRange *dOrderRanges, void *stream) {
+  if (!g || !dChars || !dOrderKmers || !dOrderRanges) {
+    setError("awfmGpuSearchHitsInOrder: null argument");
+    return AwFmNullPtrError;
+  }
+  if (g->amino || !(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4) || (packed && dOffsets)) {
+    setError("awfmGpuSearchHitsInOrder: this batch does not take the seed-order path on this image");
+    return AwFmUnsupportedVersionError;
+  }
+  DeviceGuard guard(g->device);
+  SparseOut out;
+  out.count = nullptr;
+  out.cap = 0;
+  out.kmers = (unsigned *)dOrderKmers;
+  out.ranges = (ulonglong2 *)dOrderRanges;
+  const int did = orderedSearch(g, (hipStream_t)stream, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries, nullptr,
+                                nullptr, packed != 0, false, nullptr, nullptr, &out);
+  if (did < 0) return (enum AwFmReturnCode)(-did);
+  if (did == 0) {
+    setError("awfmGpuSearchHitsInOrder: this batch does not take the seed-order path on this image");
     return AwFmUnsupportedVersionError;
   }
   return AwFmSuccess;

@@ -117,6 +117,14 @@ __device__ __forceinline__ void decodeKmer(const unsigned char *__restrict__ cha
   bad &= len >= 32u ? ~0u : ((1u << len) - 1u);
 }
 
+/* leading 15 bits of the string the search of a k-mer starts from: its last `depth` characters (the table index), or the
+ * whole k-mer when it starts from a letter range -- where its search lands in the BWT */
+__device__ __forceinline__ unsigned startKey15(unsigned long long codes, unsigned len, unsigned depth) {
+  const unsigned span = depth ? depth : len; /* characters of that string, 1..32 */
+  const unsigned long long str = span >= 32u ? codes : (codes & ((1ull << (2u * span)) - 1ull));
+  return 2u * span >= 15u ? (unsigned)(str >> (2u * span - 15u)) : (unsigned)(str << (15u - 2u * span));
+}
+
 /* "no hit" everywhere: the ordered search only stores the queries that have hits */
 __global__ void __launch_bounds__(256)
     fillNoHitKernel(ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts, const unsigned long long n) {
@@ -180,10 +188,7 @@ __global__ void __launch_bounds__(256)
       if (VARLEN) {
         /* leading 15 bits of the string the search starts from: the last `depth` characters, or the whole
          * k-mer when it starts from a letter range */
-        const unsigned depth = orderStartDepth(len, seedK, deepK);
-        const unsigned span = depth ? depth : len; /* characters of that string, 1..32 */
-        const unsigned long long str = span >= 32u ? codes : (codes & ((1ull << (2u * span)) - 1ull));
-        key = 2u * span >= 15u ? (unsigned)(str >> (2u * span - 15u)) : (unsigned)(str << (15u - 2u * span));
+        key = startKey15(codes, len, orderStartDepth(len, seedK, deepK));
       } else {
         key = orderKey(orderFormat(fixedDepth), codes);
       }
@@ -517,6 +522,145 @@ __global__ void __launch_bounds__(kPartitionThreads)
   }
 }
 
+/*
+ * The same two passes for batches whose records are 16 bytes (QueryRec: mixed-length batches, fixed-length k-mers of more
+ * than 24 characters): encodeRecordsKernel writes the records in batch order and counts buckets, partitionRecordsKernel
+ * puts them in bucket order (tiles of 8192 records).  A record carries its whole code string and its length, so the search
+ * kernel needs nothing but the order.  Replaces encode + two radix-sort passes over (key, 16-byte record) pairs:
+ * 75 instead of 117 bytes of memory traffic per mixed-length k-mer.
+ */
+constexpr unsigned kWideItems = 8, kWideTile = kPartitionThreads * kWideItems;
+constexpr unsigned kWideBucketShift = 15u - kBucketBitsMax; /* bucket = 15-bit start key >> 4 */
+
+__device__ __forceinline__ unsigned wideBucket(const QueryRec &r, unsigned seedK, unsigned deepK, unsigned fixedDepth, bool varlen) {
+  if (r.length == 0xFFFFFFFFu) return 1u << kBucketBitsMax; /* left to the general kernel: the last bin */
+  const unsigned depth = varlen ? orderStartDepth(r.length, seedK, deepK) : fixedDepth;
+  return startKey15(r.codes, r.length, depth) >> kWideBucketShift;
+}
+
+template <bool VARLEN>
+__global__ void __launch_bounds__(256)
+    encodeRecordsKernel(const unsigned char *__restrict__ chars, const unsigned long long *__restrict__ offsets, const unsigned fixedLen,
+                        const unsigned fixedDepth, const unsigned seedK, const unsigned deepK, const unsigned long long numQueries,
+                        QueryRec *__restrict__ recs, unsigned *__restrict__ hist) {
+  __shared__ unsigned sHist[(1u << kBucketBitsMax) + 1u];
+  constexpr unsigned bins = (1u << kBucketBitsMax) + 1u;
+  for (unsigned e = threadIdx.x; e < bins; e += 256u) sHist[e] = 0u;
+  __syncthreads();
+  const unsigned long long tiles = (numQueries + 255ull) / 256ull;
+  for (unsigned long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const unsigned long long t = tile * 256ull + threadIdx.x;
+    if (t >= numQueries) continue;
+    unsigned long long start, codes = 0;
+    unsigned len = fixedLen, bad = 0;
+    if (VARLEN) {
+      start = offsets[t];
+      const unsigned long long l = offsets[t + 1] - start;
+      len = l > 33ull ? 33u : (unsigned)l;
+    } else {
+      start = t * fixedLen;
+    }
+    const bool inRange = len >= 1u && len <= 32u;
+    if (inRange) decodeKmer(chars, start, len, codes, bad);
+    QueryRec r;
+    r.codes = codes;
+    r.index = (unsigned)t;
+    r.length = inRange && bad == 0u ? len : 0xFFFFFFFFu;
+    recs[t] = r;
+    atomicAdd(&sHist[wideBucket(r, seedK, deepK, fixedDepth, VARLEN)], 1u);
+  }
+  __syncthreads();
+  for (unsigned e = threadIdx.x; e < bins; e += 256u)
+    if (sHist[e]) atomicAdd(&hist[e], sHist[e]);
+}
+
+template <bool VARLEN>
+__global__ void __launch_bounds__(kPartitionThreads)
+    partitionRecordsKernel(const QueryRec *__restrict__ in, const unsigned fixedDepth, const unsigned seedK, const unsigned deepK,
+                           const unsigned long long numQueries, const unsigned *__restrict__ bucketStart,
+                           unsigned *__restrict__ cursors, QueryRec *__restrict__ out) {
+  extern __shared__ unsigned long long sDyn[];
+  ulonglong2 *sRec = (ulonglong2 *)sDyn;            /* kWideTile records, bucket by bucket */
+  unsigned *sCnt = (unsigned *)(sRec + kWideTile);
+  constexpr unsigned bins = (1u << kBucketBitsMax) + 1u, binsPad = (bins + 3u) & ~3u;
+  unsigned *sLoc = sCnt + binsPad, *sDst = sLoc + binsPad;
+  __shared__ unsigned sWave[kPartitionThreads / 64];
+  const unsigned long long tiles = (numQueries + kWideTile - 1ull) / kWideTile;
+  constexpr unsigned kPer = 3;
+  for (unsigned long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    for (unsigned e = threadIdx.x; e < bins; e += kPartitionThreads) sCnt[e] = 0u;
+    __syncthreads();
+    const unsigned long long tileBase = tile * kWideTile;
+    ulonglong2 rec[kWideItems];
+    unsigned where[kWideItems];
+#pragma unroll
+    for (unsigned j = 0; j < kWideItems; j++) {
+      const unsigned long long idx = tileBase + (unsigned long long)j * kPartitionThreads + threadIdx.x;
+      rec[j] = idx < numQueries ? *(const ulonglong2 *)(in + idx) : make_ulonglong2(0ull, 0ull);
+    }
+#pragma unroll
+    for (unsigned j = 0; j < kWideItems; j++) {
+      const unsigned long long idx = tileBase + (unsigned long long)j * kPartitionThreads + threadIdx.x;
+      where[j] = 0xFFFFFFFFu;
+      if (idx < numQueries) {
+        QueryRec r;
+        r.codes = rec[j].x;
+        r.index = (unsigned)rec[j].y;
+        r.length = (unsigned)(rec[j].y >> 32);
+        const unsigned b = wideBucket(r, seedK, deepK, fixedDepth, VARLEN);
+        where[j] = (b << 16) | atomicAdd(&sCnt[b], 1u);
+      }
+    }
+    __syncthreads();
+    {
+      unsigned v[kPer], got[kPer], start[kPer], sum = 0;
+#pragma unroll
+      for (unsigned j = 0; j < kPer; j++) {
+        const unsigned e = threadIdx.x * kPer + j;
+        v[j] = e < bins ? sCnt[e] : 0u;
+        sum += v[j];
+      }
+#pragma unroll
+      for (unsigned j = 0; j < kPer; j++) {
+        const unsigned e = threadIdx.x * kPer + j;
+        got[j] = v[j] ? atomicAdd(&cursors[e], v[j]) : 0u;
+        start[j] = v[j] ? bucketStart[e] : 0u;
+      }
+      unsigned incl = sum;
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned up = __shfl_up(incl, off);
+        if ((int)(threadIdx.x & 63u) >= off) incl += up;
+      }
+      if ((threadIdx.x & 63u) == 63u) sWave[threadIdx.x >> 6] = incl;
+      __syncthreads();
+      unsigned running = incl - sum;
+      for (unsigned w = 0; w < (threadIdx.x >> 6); w++) running += sWave[w];
+#pragma unroll
+      for (unsigned j = 0; j < kPer; j++) {
+        const unsigned e = threadIdx.x * kPer + j;
+        if (e < bins) {
+          sLoc[e] = running;
+          sDst[e] = start[j] + got[j];
+        }
+        running += v[j];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned j = 0; j < kWideItems; j++)
+      if (where[j] != 0xFFFFFFFFu) sRec[sLoc[where[j] >> 16] + (where[j] & 0xFFFFu)] = rec[j];
+    __syncthreads();
+    for (unsigned b = (threadIdx.x >> 3); b < bins; b += kPartitionThreads / 8u) { /* 8 lanes per bucket: runs of 16-byte records */
+      const unsigned count = sCnt[b], loc = sLoc[b];
+      if (count) {
+        ulonglong2 *dst = (ulonglong2 *)(out + sDst[b]);
+        for (unsigned j = threadIdx.x & 7u; j < count; j += 8u) dst[j] = sRec[loc + j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 /* workgroup size: 256 threads for every variant (the pair variant keeps the 32-bit superblock bases of the pair image in
  * dynamic LDS, 64 B per 2^23 positions = 24 KB for a GRCh38-sized index, which limits it to 6 workgroups per CU;
  * 512-thread workgroups with half the copies of that table measured slower) */
@@ -538,11 +682,11 @@ struct OrderTouch {
 };
 
 template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false>
-/* registers: 8 waves per SIMD (64 VGPRs) where nothing else limits the occupancy; the bucketed variant carries a chunk more
- * (codes, query number and table entry of the next chunk) and is given 72, like the mixed-length variant (7 waves per
- * SIMD; the pair tables of a GRCh38-sized image, 12 KB of LDS, allow that many workgroups); the 64-bit pair variants, the instrumented variant and
- * the wide two-lane measurement variant get 80 */
-__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || TOUCH || (G == 2 && !NARROW) ? 6 : (BUCKET || VARLEN ? 7 : 8)) : 2, 8)))
+/* registers: 8 waves per SIMD (64 VGPRs) for the plain variants; the mixed-length variant gets 72 (7 waves); the bucketed
+ * variant, which carries the next chunk's codes, query number and table entry as well, the 64-bit pair variants, the
+ * instrumented variant and the wide two-lane measurement variant get 80 (6 waves).  Occupancy beyond 6 buys nothing here:
+ * the bucketed kernel built for 7 waves (72 registers, 4 spilled) and for 6 measured the same (3.75-3.94 ms either way) */
+__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || TOUCH || BUCKET || (G == 2 && !NARROW) ? 6 : (VARLEN ? 7 : 8)) : 2, 8)))
     orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
                         const unsigned long long numRecs,
                         const unsigned *__restrict__ generalCount, const unsigned len, const unsigned depth,
@@ -818,12 +962,21 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
         rem >>= 2;
       }
     }
-    if (TOUCH && live && gl == 0 && sp <= ep) atomicAdd(touch.hits, 1ull);
-    if (sparse.count) { /* kernel argument: uniform */
-      sparseAppend(sparse, live && gl == 0 && sp <= ep, index, (unsigned long long)sp, (unsigned long long)ep);
-    } else if (live && gl == 0 && sp <= ep) {
-      if (ranges) ranges[index] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
-      if (counts) counts[index] = (unsigned)(ep - sp + (pos_t)1);
+    if (TOUCH && base + lane / G < end && gl == 0 && sp <= ep) atomicAdd(touch.hits, 1ull);
+    { /* (position in the order and liveness are recomputed here rather than kept in registers across the steps) */
+      const unsigned long long at = base + lane / G;
+      const bool mine = at < end && gl == 0;
+      if (sparse.count) { /* kernel argument: uniform */
+        sparseAppend(sparse, mine && sp <= ep, index, (unsigned long long)sp, (unsigned long long)ep);
+      } else if (sparse.kmers) { /* results in search order: entry `at`, whatever the outcome */
+        if (mine) {
+          sparse.kmers[at] = index;
+          sparse.ranges[at] = sp <= ep ? make_ulonglong2((unsigned long long)sp, (unsigned long long)ep) : make_ulonglong2(1ull, 0ull);
+        }
+      } else if (mine && sp <= ep) {
+        if (ranges) ranges[index] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
+        if (counts) counts[index] = (unsigned)(ep - sp + (pos_t)1);
+      }
     }
     base = baseNext;
     if (BUCKET) {

@@ -318,6 +318,12 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
 
     if (sparse.count) { /* kernel argument: uniform (the tail of a sparse ordered search: awfmGpuSearchHitsCompact) */
       sparseAppend(sparse, gl == 0 && sp <= ep, (unsigned)queryNumber(q), (unsigned long long)sp, (unsigned long long)ep);
+    } else if (sparse.kmers) { /* the tail of a search with results in search order: the listed k-mers are the order's last */
+      if (gl == 0) {
+        const unsigned long long slot = subsetTotal - listed + q;
+        sparse.kmers[slot] = (unsigned)queryNumber(q);
+        sparse.ranges[slot] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
+      }
     } else if (gl == 0) {
       const unsigned long long out = queryNumber(q);
       if (ranges) ranges[out] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);

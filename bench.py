@@ -416,6 +416,35 @@ def main():
         d_num_hits = torch.zeros(1, dtype=torch.int32, device=dev)
         h_num_hits = torch.zeros(1, dtype=torch.int32).pin_memory()
     state["listed"] = False  # the last step's results are in the list form
+    # Results in search order (awfmGpuSearchHitsInOrder): when most k-mers of a batch have hits, every k-mer gets an entry
+    # {k-mer number, range} in the order the seed-order search took it -- whole-line stores instead of 10^8 partial-line
+    # ones under the original numbers -- and hit offsets and positions follow that order (the walk's first steps then share
+    # blocks).  Same information; a consumer that scatters into per-k-mer lists (the AoS API) reads it as it is.
+    can_order = ordered and args.mode == "locate" and not os.environ.get("AWFM_BENCH_DENSE_RESULTS")
+    d_order_kmers = torch.empty(Q, dtype=torch.int32, device=dev) if can_order else None
+    state["in_order"] = False
+
+    def order_to_dense(order_kmers, order_ranges, order_off, order_pos, total):
+        """the dense form (ranges / hit offsets under every k-mer number, positions in k-mer order) of results in search
+        order; outside the timed region, for the checks"""
+        kmers = order_kmers.to(torch.int64)
+        assert int(torch.bincount(kmers, minlength=Q).max().item()) == 1, "a k-mer is missing from the order or listed twice"
+        lens = order_off[1:] - order_off[:-1]
+        counts = torch.zeros(Q, dtype=torch.int64, device=dev)
+        counts[kmers] = lens
+        dense_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=dense_off[1:])
+        dense_ranges = torch.empty(Q, 2, dtype=torch.int64, device=dev)
+        dense_ranges[kmers] = order_ranges.view(Q, 2)
+        dense_pos = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+        step_q = 1 << 24
+        for b in range(0, Q, step_q):  # destination of every hit: its k-mer's dense offset + its rank in the list
+            e = min(Q, b + step_q)
+            lo, hi = int(order_off[b].item()), int(order_off[e].item())
+            if hi > lo:
+                shift = torch.repeat_interleave(dense_off[:-1][kmers[b:e]] - order_off[b:e], lens[b:e])
+                dense_pos[shift + torch.arange(lo, hi, dtype=torch.int64, device=dev)] = order_pos[lo:hi]
+        return dense_ranges.view(-1), counts.to(torch.int32), dense_off, dense_pos
 
     def step(record):
         if record:
@@ -425,7 +454,10 @@ def main():
         # fixed-length batches are searched in seed order, the others by the general kernel
         use_counts = narrow_counts and state["sparse"]
         use_list = can_list and state["sparse"]
-        if use_list:
+        use_order = can_order and not state["sparse"]
+        if use_order:
+            g.search_hits_in_order(d_chars.data_ptr(), off_ptr, K, Q, d_order_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
+        elif use_list:
             g.search_hits_compact(d_chars.data_ptr(), off_ptr, K, Q, d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), sparse_cap,
                                   d_num_hits.data_ptr(), stream=stream)
         elif args.mode == "locate" and use_counts:
@@ -441,6 +473,19 @@ def main():
             if ordered:
                 ordered_ms.append(g.last_ordered_kernel_ms())  # waits for that kernel only
         if args.mode == "locate":
+            if use_order:
+                total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
+                ensure_positions(total)
+                if record:
+                    e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e2.record()
+                g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, state["positions"].data_ptr(), stream)
+                if record:
+                    e3.record()
+                    locate_events.append((e2, e3))
+                state.update(hits=total, listed=False, in_order=True, windowed=False)
+                state["sparse"] = total < Q // 4
+                return
             if use_list:
                 # how many k-mers are listed (one small wait): the sort and the scan then run over the list, not over its
                 # capacity (sorting 1.5 M mostly empty entries took 0.19 ms of a 5.8 ms step)
@@ -465,7 +510,7 @@ def main():
                 if record:
                     e3.record()
                     locate_events.append((e2, e3))
-                state.update(hits=total, listed=True, num_listed=listed)
+                state.update(hits=total, listed=True, num_listed=listed, in_order=False)
                 return
             if use_counts:  # the scan reads 4-byte counts instead of 16-byte ranges
                 total = g.hit_offsets_from_counts(d_counts.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
@@ -495,6 +540,7 @@ def main():
                 locate_events.append((e2, e3))
             state["hits"] = total
             state["listed"] = False
+            state["in_order"] = False
             state["windowed"] = window
             # when most k-mers have hits, a second per-query result (the count) costs a scattered store each in
             # the ordered search, more than scanning the ranges does: decided from the previous step's hit total
@@ -521,6 +567,14 @@ def main():
         step(False)
         torch.cuda.synchronize()
         state["keep_first_window"] = False
+    if state["in_order"]:
+        # every check below reads the dense form: regroup by k-mer number, outside the timed region
+        r, c, o, p2 = order_to_dense(d_order_kmers, d_ranges, d_hit_off, state["positions"], state["hits"])
+        d_ranges.copy_(r)
+        d_counts.copy_(c)
+        d_hit_off.copy_(o)
+        state["positions"] = p2
+        del r, c, o, p2
     if state["listed"]:
         # every check below (oracle sample, digests, pipeline and AoS comparison, dumps) reads the dense form: the list is
         # expanded into it here, outside the timed region -- counts, hit offsets and ranges under every k-mer number
@@ -831,11 +885,22 @@ def main():
         from avxwindowfmindex_amd import synth
 
         def planted_step():
-            g.search_hits(d_planted.data_ptr(), 0, K, Q, d_ranges.data_ptr(), 0, stream)
+            if can_order:  # results in search order (most k-mers have hits)
+                g.search_hits_in_order(d_planted.data_ptr(), 0, K, Q, d_order_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
+            else:
+                g.search_hits(d_planted.data_ptr(), 0, K, Q, d_ranges.data_ptr(), 0, stream)
             total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
             ensure_positions(total)
             g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, state["positions"].data_ptr(), stream)
             return total
+
+        def planted_dense():
+            """the last planted step's results under the k-mer numbers (outside the timing)"""
+            if can_order:
+                r, c, o, p2 = order_to_dense(d_order_kmers, d_ranges, d_hit_off, state["positions"], hits)
+                d_ranges.copy_(r)
+                d_hit_off.copy_(o)
+                state["positions"] = p2
 
         planted_step()
         torch.cuda.synchronize()
@@ -844,6 +909,7 @@ def main():
             hits = planted_step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
+        planted_dense()
         # every planted k-mer must come back at its planting offset (checked on the first 10^6: a k-mer with one hit has
         # exactly that position, one with several has it among them)
         m = min(Q, 1_000_000)
@@ -876,6 +942,7 @@ def main():
                 planted_step()
             torch.cuda.synchronize()
             dense_dt = (time.perf_counter() - t1) / 3
+            planted_dense()
             dense_pos = f"{digest.positions_digest(first, d_hit_off, state['positions'][:hits]):016x}"
             assert dense_pos == pdig["positions"], "positions through the dense suffix array differ from the walk's"
             dense = {"value": round(Q / dense_dt / 1e6, 2), "ms_per_step": round(dense_dt * 1e3, 3), "build_s": round(dense_build, 2),
@@ -912,10 +979,12 @@ def main():
                    "device_image_bytes": g.device_bytes, "device_seed_k": g.deep_seed_k or args.seed_k,
                    "device_seed_build_s": round(deep_s, 2), "device_dense_sa": bool(args.device_dense_sa),
                    "device_dense_sa_build_s": round(dense_s, 2),
-                   "search_path": ("awfmGpuSearchHitsCompact" if state["listed"] else
+                   "search_path": ("awfmGpuSearchHitsInOrder" if state["in_order"] else "awfmGpuSearchHitsCompact" if state["listed"] else
                                    "awfmGpuSearchHitsSparse" if (args.mode == "locate" and narrow_counts and state["sparse"]) else "awfmGpuSearchHits")
                                   + (", seed order" if ordered else ", general kernel"),
-                   "result_format": ("list of the k-mers with hits {k-mer number, range} in k-mer order + hit offsets over the list + positions"
+                   "result_format": ("every k-mer {k-mer number, range} in search order + hit offsets and positions in that order"
+                                     if state["in_order"] else
+                                     "list of the k-mers with hits {k-mer number, range} in k-mer order + hit offsets over the list + positions"
                                      if state["listed"] else "range / count under every k-mer number + hit offsets over the batch + positions")},
         "roofline": roofline,
         "roofline_general": roofline_general,

@@ -171,6 +171,16 @@ enum AwFmReturnCode awfmGpuSearchHitsCompact(AwFmGpuIndex *g, const uint8_t *dCh
                                              uint32_t fixedLength, uint64_t numQueries, int packed, uint32_t *dHitKmers,
                                              struct AwFmSearchRange *dHitRanges, uint32_t capacity, uint32_t *dNumHits,
                                              void *stream);
+/* Results IN SEARCH ORDER, for batches in which most k-mers have hits: entry q = {number of the k-mer the seed-order search
+ * took q-th, its range (exact when it has hits, empty otherwise)}, every k-mer of the batch exactly once, written as whole
+ * lines -- instead of 10^8 partial-line stores under the original k-mer numbers.  awfmGpuHitOffsets / awfmGpuLocate take
+ * dOrderRanges as if it were the batch: hit offsets and positions then follow the search order too (neighbouring entries
+ * are neighbours in the BWT, which the walk's first steps share), and dOrderKmers says whose they are -- what a consumer
+ * that scatters into per-k-mer lists anyway (awFmParallelSearchLocate does: ref src/AwFmParallelSearch.c:327-361) needs.
+ * Only batches that take the seed-order path (AwFmUnsupportedVersionError otherwise). */
+enum AwFmReturnCode awfmGpuSearchHitsInOrder(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                             uint32_t fixedLength, uint64_t numQueries, int packed, uint32_t *dOrderKmers,
+                                             struct AwFmSearchRange *dOrderRanges, void *stream);
 /* the same list from dense results (dCounts / dRanges of awfmGpuSearchHits or awfmGpuSearch), already in k-mer order:
  * dFlagOffsets[numQueries + 1] and dScratch (awfmGpuScanScratchBytes) are work space */
 enum AwFmReturnCode awfmGpuCompactHits(AwFmGpuIndex *g, const uint32_t *dCounts, const struct AwFmSearchRange *dRanges,

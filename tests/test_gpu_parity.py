@@ -560,6 +560,58 @@ def test_sparse_hit_list_matches_the_dense_results(oracle, awfm, require_gpu, wi
     ix.dealloc()
 
 
+@pytest.mark.parametrize("K,csr", [(19, False), (32, False), (0, True)])
+def test_results_in_search_order_are_a_permutation_with_exact_ranges(oracle, awfm, require_gpu, wide, K, csr):
+    """awfmGpuSearchHitsInOrder: every k-mer exactly once, {number, range} in the order the seed-order search took them
+    (k-mers with ambiguity characters, answered by the general kernel, at the end); locate over that order gives every
+    k-mer's list, in BWT order, under its number"""
+    import torch
+    n, seed_k, Q = 300_000, 8, 20_001
+    txt = synth.text(891, n).copy()
+    txt[7000:7050] = ord("n")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, seed_k)
+    oi = oracle.Index.wrap(oracle.DNA, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    if csr:
+        chars, offsets = _mixed_queries(892, Q, synth.text(891, n), synth.DNA_ALPHABET, 1, 40, ambiguity=ord("x"), upper=True)
+    else:
+        q = np.concatenate([synth.random_queries(893, Q // 3, K), synth.planted_queries(894, Q - Q // 3, K, synth.text(891, n))]).copy()
+        q = q[np.random.default_rng(6).permutation(Q)]
+        q[5, 1] = ord("n")
+        q[6] = ord("n")
+        chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    ho, pos, _ = oi.batch_locate(sp, ep)
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(chars.copy()).to(dev)
+    d_off = torch.from_numpy(offsets.view(np.int64).copy()).to(dev) if csr else None
+    d_kmers = torch.full((Q,), -1, dtype=torch.int32, device=dev)
+    d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
+    g.search_hits_in_order(d_chars.data_ptr(), d_off.data_ptr() if csr else 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr())
+    d_hoff = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+    total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hoff.data_ptr(), d_scratch.data_ptr())
+    d_pos = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+    g.locate(d_ranges.data_ptr(), d_hoff.data_ptr(), Q, total, d_pos.data_ptr())
+    torch.cuda.synchronize()
+    kmers = d_kmers.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(kmers), np.arange(Q)), "not a permutation of the batch"
+    r = d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2)
+    hit = cnt[kmers] > 0
+    assert np.array_equal(r[hit, 0], sp[kmers][hit]) and np.array_equal(r[hit, 1], ep[kmers][hit])
+    assert np.all(r[~hit, 0] > r[~hit, 1])
+    assert total == len(pos)
+    off_o = d_hoff.cpu().numpy().view(np.uint64)
+    pos_o = d_pos[:total].cpu().numpy().view(np.uint64)
+    assert np.array_equal(np.diff(off_o), cnt[kmers].astype(np.uint64))
+    for e in list(range(0, Q, 37)) + [Q - 1]:
+        i = kmers[e]
+        assert np.array_equal(pos_o[int(off_o[e]):int(off_o[e + 1])], pos[int(ho[i]):int(ho[i + 1])]), (e, i)
+    g.destroy()
+    ix.dealloc()
+
+
 def test_hits_only_search_falls_back_to_the_general_kernel(oracle, awfm, require_gpu):
     """batches the ordered path does not cover (CSR offsets, k-mers shorter than the seed or longer than 32
     characters, amino indices) still honour the hits-only contract"""
