@@ -682,11 +682,11 @@ struct OrderTouch {
 };
 
 template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false>
-/* registers: 8 waves per SIMD (64 VGPRs) for the plain variants; the mixed-length variant gets 72 (7 waves); the bucketed
+/* registers: 8 waves per SIMD (64 VGPRs) for the one-step variants; the mixed-length and the pair variants get 72 (7 waves); the bucketed
  * variant, which carries the next chunk's codes, query number and table entry as well, the 64-bit pair variants, the
  * instrumented variant and the wide two-lane measurement variant get 80 (6 waves).  Occupancy beyond 6 buys nothing here:
  * the bucketed kernel built for 7 waves (72 registers, 4 spilled) and for 6 measured the same (3.75-3.94 ms either way) */
-__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || TOUCH || BUCKET || (G == 2 && !NARROW) ? 6 : (VARLEN ? 7 : 8)) : 2, 8)))
+__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || TOUCH || BUCKET || (G == 2 && !NARROW) ? 6 : (VARLEN || PAIR ? 7 : 8)) : 2, 8)))
     orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
                         const unsigned long long numRecs,
                         const unsigned *__restrict__ generalCount, const unsigned len, const unsigned depth,

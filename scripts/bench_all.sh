@@ -13,6 +13,7 @@ run() { # name [ENV=..]... -- bench args
 run default -- --steps 20 --warmup 5
 run count -- --mode count
 run planted -- --workload planted
+run planted_dense_results AWFM_BENCH_DENSE_RESULTS=1 -- --workload planted --no-cpu --no-e2e
 run mixed -- --workload mixed
 run mixed_locate -- --workload mixed --mode locate --no-e2e --steps 2 --warmup 1
 run amino -- --alphabet amino
@@ -22,6 +23,7 @@ run general_letters AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 AWFM_GPU_GENERAL_N
 run dense_results AWFM_BENCH_DENSE_RESULTS=1 -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run no_deep_table -- --device-seed-k 0 --no-cpu --no-e2e --no-secondary --general-steps 0
 run rocprim_sort AWFM_GPU_ORDERED_SORT=rocprim -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run mixed_rocprim_sort AWFM_GPU_ORDERED_SORT=rocprim -- --workload mixed --no-cpu --no-e2e --general-steps 0
 run nopair_default AWFM_GPU_PAIR=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run planted_dense_sa -- --workload planted --device-dense-sa --no-cpu --no-e2e
 run repetitive_random -- --text repetitive --no-cpu --no-e2e --general-steps 0

@@ -189,6 +189,27 @@ def test_cfg3b_planted_21mers_located(grch38):
     t.cuda.synchronize()
     assert t.equal(exact, ranges)
     big.check_sample_against_oracle(d_chars, None, K, Q, ranges, None, hit_off, d_pos, exact_ranges=True)
+    # the same batch with its results in search order (awfmGpuSearchHitsInOrder): a permutation of the batch whose entries
+    # carry the dense form's ranges, and whose positions, regrouped by k-mer number, are the dense form's positions
+    del exact
+    kmers = t.empty(Q, dtype=t.int32, device=big.dev)
+    oranges = t.empty(Q * 2, dtype=t.int64, device=big.dev)
+    big.g.search_hits_in_order(d_chars.data_ptr(), 0, K, Q, kmers.data_ptr(), oranges.data_ptr())
+    ooff = t.empty(Q + 1, dtype=t.int64, device=big.dev)
+    assert big.g.hit_offsets(oranges.data_ptr(), Q, ooff.data_ptr(), scratch.data_ptr()) == total
+    opos = t.empty(total, dtype=t.int64, device=big.dev)
+    big.g.locate(oranges.data_ptr(), ooff.data_ptr(), Q, total, opos.data_ptr())
+    t.cuda.synchronize()
+    k64 = kmers.to(t.int64)
+    assert int(t.bincount(k64, minlength=Q).max()) == 1 and int(k64.min()) == 0 and int(k64.max()) == Q - 1
+    assert t.equal(oranges.view(Q, 2), ranges.view(Q, 2)[k64])
+    olens = ooff[1:] - ooff[:-1]
+    assert t.equal(olens, lens[k64])
+    for b in range(0, Q, 1 << 24):  # entry e's list = k-mer kmers[e]'s list of the dense form
+        e = min(Q, b + (1 << 24))
+        lo, hi = int(ooff[b]), int(ooff[e])
+        src = t.repeat_interleave(hit_off[:-1][k64[b:e]] - ooff[b:e], olens[b:e]) + t.arange(lo, hi, device=big.dev)
+        assert t.equal(opos[lo:hi], d_pos[src])
 
 
 def test_cfg3a_sparse_hit_list_at_full_size(grch38):
