@@ -226,25 +226,27 @@ static bool ensureOrderScratch(AwFmGpuIndex *g, size_t bytes) {
 /* encodeCodes4Kernel<K> for the batch's k-mer length */
 template <unsigned K>
 static void launchEncode4At(unsigned len, unsigned grid, size_t lds, hipStream_t s, const uint8_t *dChars, const BucketFormat &fmt,
-                            unsigned long long nq, unsigned long long *codes, unsigned *hist) {
+                            unsigned long long nq, unsigned long long *codes, unsigned *hist, unsigned binsPad) {
   if (len == K)
-    hipLaunchKernelGGL((encodeCodes4Kernel<K>), dim3(grid), dim3(256), lds, s, dChars, fmt, nq, codes, hist);
+    hipLaunchKernelGGL((encodeCodes4Kernel<K>), dim3(grid), dim3(256), lds, s, dChars, fmt, nq, codes, hist, binsPad);
   else if constexpr (K > 1u)
-    launchEncode4At<K - 1u>(len, grid, lds, s, dChars, fmt, nq, codes, hist);
+    launchEncode4At<K - 1u>(len, grid, lds, s, dChars, fmt, nq, codes, hist, binsPad);
 }
 static void launchEncode4(unsigned len, unsigned grid, size_t lds, hipStream_t s, const uint8_t *dChars, const BucketFormat &fmt,
-                          unsigned long long nq, unsigned long long *codes, unsigned *hist) {
-  launchEncode4At<32u>(len, grid, lds, s, dChars, fmt, nq, codes, hist);
+                          unsigned long long nq, unsigned long long *codes, unsigned *hist, unsigned binsPad) {
+  launchEncode4At<32u>(len, grid, lds, s, dChars, fmt, nq, codes, hist, binsPad);
 }
 
-/* fillNoHitKernel -> encodeCodesKernel -> bucketScanKernel -> partitionKernel -> orderedSearchKernel<BUCKET> ->
+/* fillNoHitKernel -> encodeCodes4Kernel -> bucketScanSharesKernel -> partitionKernel -> orderedSearchKernel<BUCKET> ->
  * searchKernel<INDIRECT> on the caller's stream; the caller holds orderMutex.  Return values as awfmGpuOrderedSearch. */
 static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength, unsigned depth,
                           const ulonglong2 *table, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
                           bool rangesOfHitsOnly, const OrderTouch *touch, const BucketFormat &fmt, const SparseOut *sparse) {
   const unsigned bins = (1u << fmt.bucketBits) + 1u, binsPad = (bins + 3u) & ~3u;
-  /* [counters 32 KB][hist: bins][cursors: bins][bucketStart: bins + 1][codes: nq x 8 unless packed][records: nq x 8] */
-  const size_t histAt = kOrderCounterBytes, cursorsAt = histAt + alignUp256(bins * 4u), startAt = cursorsAt + alignUp256(bins * 4u);
+  /* [counters 32 KB][hist -> sub-run starts: 8 shares x binsPad][cursors: 8 x binsPad][bucketStart: bins + 1]
+   * [codes: nq x 8 unless packed][records: nq x 8] */
+  const size_t histAt = kOrderCounterBytes, cursorsAt = histAt + alignUp256((size_t)kShares * binsPad * 4u);
+  const size_t startAt = cursorsAt + alignUp256((size_t)kShares * binsPad * 4u);
   const size_t codesAt = startAt + alignUp256((bins + 1u) * 4u), recsAt = codesAt + (packed ? 0u : alignUp256(nq * 8u));
   const size_t total = recsAt + alignUp256(nq * 8u);
   if (!ensureOrderScratch(g, total)) return 0;
@@ -264,24 +266,26 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   unsigned *hist = (unsigned *)(w + histAt), *cursors = (unsigned *)(w + cursorsAt), *bucketStart = (unsigned *)(w + startAt);
   const unsigned long long *codes = packed ? (const unsigned long long *)dChars : (const unsigned long long *)(w + codesAt);
   unsigned long long *recs = (unsigned long long *)(w + recsAt);
-  BUCKET_TRY(hipMemsetAsync(w, 0, startAt, s)); /* the count, the ticket counters, the histogram, the cursors */
+  BUCKET_TRY(hipMemsetAsync(w, 0, startAt, s)); /* the count, the ticket counters, the histograms, the cursors */
   if (!sparse) { /* a sparse search lists its hits: there is nothing to pre-fill */
     hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
                        rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
     BUCKET_TRY(hipGetLastError());
   }
-  const unsigned long long encodeTiles = (nq + 255ull) / 256ull;
-  const unsigned encodeGrid = (unsigned)(encodeTiles < (unsigned long long)g->numCUs * 8u ? encodeTiles : (unsigned long long)g->numCUs * 8u);
+  /* grids: multiples of the 8 shares (workgroup b works on share b % 8) */
+  const unsigned long long perShare256 = (shareSize(nq) + 255ull) / 256ull;
+  unsigned encodeGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * 8u ? perShare256 * kShares : (unsigned long long)g->numCUs * 8u);
+  encodeGrid = (encodeGrid + kShares - 1u) / kShares * kShares;
   if (packed)
     hipLaunchKernelGGL((encodeCodesKernel<true>), dim3(encodeGrid), dim3(256), bins * 4u, s, dChars, fixedLength, fmt, nq,
-                       (unsigned long long *)nullptr, hist);
+                       (unsigned long long *)nullptr, hist, binsPad);
   else if (getenv("AWFM_GPU_ENCODE_ONE")) /* measurement knob: one k-mer per thread */
     hipLaunchKernelGGL((encodeCodesKernel<false>), dim3(encodeGrid), dim3(256), bins * 4u, s, dChars, fixedLength, fmt, nq,
-                       (unsigned long long *)(w + codesAt), hist);
+                       (unsigned long long *)(w + codesAt), hist, binsPad);
   else
-    launchEncode4(fixedLength, encodeGrid, bins * 4u, s, dChars, fmt, nq, (unsigned long long *)(w + codesAt), hist);
+    launchEncode4(fixedLength, encodeGrid, bins * 4u, s, dChars, fmt, nq, (unsigned long long *)(w + codesAt), hist, binsPad);
   BUCKET_TRY(hipGetLastError());
-  hipLaunchKernelGGL(bucketScanKernel, dim3(1), dim3(1024), 0, s, (const unsigned *)hist, bins, bucketStart, generalCount);
+  hipLaunchKernelGGL(bucketScanSharesKernel, dim3(1), dim3(1024), 0, s, hist, bins, binsPad, bucketStart, generalCount);
   BUCKET_TRY(hipGetLastError());
   const size_t partitionLds = (size_t)kPartitionTile * 8u + 3u * binsPad * 4u;
   static std::once_flag ldsOnce;
@@ -291,11 +295,11 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
                                    (int)(kPartitionTile * 8u + 3u * (((1u << kBucketBitsMax) + 4u) & ~3u) * 4u));
   });
   BUCKET_TRY(ldsError);
-  const unsigned long long tiles = (nq + kPartitionTile - 1ull) / kPartitionTile;
-  const unsigned partitionGrid = (unsigned)(tiles < (unsigned long long)g->numCUs ? tiles : (unsigned long long)g->numCUs);
+  const unsigned long long tilesPerShare = shareSize(nq) / kPartitionTile;
+  unsigned partitionGrid = (unsigned)(tilesPerShare * kShares < (unsigned long long)g->numCUs ? tilesPerShare * kShares : (unsigned long long)g->numCUs);
+  partitionGrid = (partitionGrid + kShares - 1u) / kShares * kShares;
   hipLaunchKernelGGL(partitionKernel, dim3(partitionGrid), dim3(kPartitionThreads), partitionLds, s, codes, fixedLength, fmt, nq,
-                     (const unsigned *)bucketStart, cursors, recs, packed ? 0u : 1u,
-                     getenv("AWFM_GPU_PARTITION_PROBE") ? (unsigned)atoi(getenv("AWFM_GPU_PARTITION_PROBE")) : 0u);
+                     (const unsigned *)hist, cursors, recs, packed ? 0u : 1u);
   BUCKET_TRY(hipGetLastError());
   const enum AwFmReturnCode rc =
       awfmImageNarrow(g) ? launchBucketed<true>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse)

@@ -202,11 +202,11 @@ def test_cfg3b_planted_21mers_located(grch38):
     t.cuda.synchronize()
     k64 = kmers.to(t.int64)
     assert int(t.bincount(k64, minlength=Q).max()) == 1 and int(k64.min()) == 0 and int(k64.max()) == Q - 1
-    assert t.equal(oranges.view(Q, 2), ranges.view(Q, 2)[k64])
     olens = ooff[1:] - ooff[:-1]
-    assert t.equal(olens, lens[k64])
-    for b in range(0, Q, 1 << 24):  # entry e's list = k-mer kmers[e]'s list of the dense form
+    for b in range(0, Q, 1 << 24):  # entry e: the range, the list length and the list of k-mer kmers[e] in the dense form
         e = min(Q, b + (1 << 24))
+        assert t.equal(oranges.view(Q, 2)[b:e], ranges.view(Q, 2)[k64[b:e]]), b
+        assert t.equal(olens[b:e], lens[k64[b:e]]), b
         lo, hi = int(ooff[b]), int(ooff[e])
         src = t.repeat_interleave(hit_off[:-1][k64[b:e]] - ooff[b:e], olens[b:e]) + t.arange(lo, hi, device=big.dev)
         assert t.equal(opos[lo:hi], d_pos[src])
