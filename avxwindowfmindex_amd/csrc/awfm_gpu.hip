@@ -336,7 +336,7 @@ void launchSearch(const AwFmGpuIndex *g, const DevIndex &dev, int lanes, hipStre
 }
 }  // namespace
 
-constexpr unsigned kAutoDeepSeedK = 14; /* depth of the device-only seed table large nucleotide images get by default */
+constexpr unsigned kAutoDeepSeedMin = 14, kAutoDeepSeedMax = 16; /* depths of the device-only seed table large nucleotide images get by default */
 extern "C" {
 static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g);
 static enum AwFmReturnCode applyPairFromEnv(AwFmGpuIndex *g);
@@ -771,17 +771,24 @@ static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
   int deepK = 0;
   if (const char *env = getenv("AWFM_GPU_DEEP_SEED_K")) {
     deepK = atoi(env); /* 0: none */
-  } else if (g->dev.bwtLength >= (1ull << 28) && g->dev.seedK >= 8 && g->dev.seedK < kAutoDeepSeedK) {
-    /* Automatic: an image far beyond the L2s gets the table of depth 14 when the device has room to spare (the table is
-     * 4^14 x 16 B = 4.3 GB, its construction holds the level below beside it; asked for: four times the table).  10^8
-     * random 21-mers against a 3.1 Gbp image, search call: 6.19 ms with it against 6.68 ms from the index's own k = 12
-     * table (13: 6.29, 15: 6.26); results are bit-identical (the table holds what the stepping would compute). */
+  } else if (g->dev.bwtLength >= (1ull << 28) && g->dev.seedK >= 8 && g->dev.seedK < kAutoDeepSeedMin) {
+    /* Automatic: an image far beyond the L2s gets the deepest table of 14..16 characters that has no more than two
+     * entries per text position, when the device has room to spare (8 B -- 16 B from 2^32 positions -- x 4^K: 2.1 GB
+     * at 14, 34 GB at 16; its construction holds the level below beside it; asked for: three times the table).  Every
+     * level of the table replaces a dependent block read of EVERY k-mer by a wider spread of the one table read: 10^8
+     * random 21-mers against a 3.1 Gbp image, seed-order search kernel 3.44 ms at 14, 3.21 at 15, 2.87 at 16 (the
+     * index's own k = 12 table: 4.6); planted 21-mers 6.08 -> 5.13 ms.  Results are bit-identical (the table holds
+     * what the stepping would compute, stop-at-first-invalid rule included). */
     size_t freeBytes = 0, totalBytes = 0;
     DeviceGuard guard(g->device);
-    if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess && freeBytes >= 4ull * (16ull << (2u * kAutoDeepSeedK)))
-      deepK = (int)kAutoDeepSeedK;
-    else
+    if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) {
+      const uint64_t entryBytes = g->dev.bwtLength < (1ull << 32) ? 8u : 16u;
+      for (unsigned k = kAutoDeepSeedMax; k >= kAutoDeepSeedMin && deepK == 0; k--)
+        if ((1ull << (2u * k)) <= 2ull * g->dev.bwtLength && freeBytes / 3u >= (entryBytes << (2u * k))) deepK = (int)k;
+      if (deepK == 0 && freeBytes / 4u >= (16ull << (2u * kAutoDeepSeedMin))) deepK = (int)kAutoDeepSeedMin;
+    } else {
       (void)hipGetLastError();
+    }
   }
   if (deepK <= 0 || (unsigned)deepK <= g->dev.seedK) return AwFmSuccess; /* nothing deeper than the index's own table */
   DeviceGuard guard(g->device);

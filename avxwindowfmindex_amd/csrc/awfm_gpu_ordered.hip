@@ -81,7 +81,10 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
   hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET>), dim3(grid ? grid : 1u), dim3(threads), lds, s, dev, recs,
                      keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
                      getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0, touch ? *touch : OrderTouch(), bucketStart,
-                     bucketFmt, sparse ? *sparse : SparseOut());
+                     bucketFmt, sparse ? *sparse : SparseOut(),
+                     /* chunks a ticket is worth: 10^8 random 21-mers 3.92 (1), 3.49 (2), 3.47 (4), 3.50 (8), 3.65 ms (16); mixed-length and
+                      * planted batches show no gain */
+                     getenv("AWFM_GPU_CHUNKS_PER_TICKET") && atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) >= 1 ? (unsigned)atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) : (BUCKET ? 4u : 1u));
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[1], s), AwFmGeneralFailure);
   g->orderTimed = timed;

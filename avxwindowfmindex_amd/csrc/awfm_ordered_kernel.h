@@ -751,8 +751,10 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
                         const ulonglong2 *__restrict__ table, ulonglong2 *__restrict__ ranges,
                         unsigned *__restrict__ counts, unsigned *__restrict__ tickets, const int xcdMap = 0,
                         const OrderTouch touch = OrderTouch(), const unsigned *__restrict__ bucketStart = nullptr,
-                        const BucketFormat bucketFmt = BucketFormat(), const SparseOut sparse = SparseOut()) {
+                        const BucketFormat bucketFmt = BucketFormat(), const SparseOut sparse = SparseOut(),
+                        const unsigned chunksPerTicket = 1u) {
   static_assert(!BUCKET || (COMPACT && !VARLEN), "bucketed records are the 8-byte records of fixed-length batches");
+  constexpr bool AHEAD = BUCKET; /* the next chunk's table entry is requested a chunk ahead */
   constexpr int S = (int)kSlices / G;
   typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
@@ -833,14 +835,30 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   constexpr unsigned kWaves = orderedThreads(PAIR) / 64, kChunk = 64 / G;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   unsigned *ticket = tickets + (xcd * kWaves + wave) * 64u; /* 256 bytes apart */
-  auto chunkBase = [&](unsigned t) -> unsigned long long {
-    return begin + ((unsigned long long)t * kWaves + wave) * kChunk;
+  /* A ticket is worth chunksPerTicket consecutive chunks of the wave (one returning atomic on a counter that 48-64 waves
+   * share, per ticket): the next ticket is drawn when the wave starts on the current one and read when that one is used
+   * up, so the atomic has chunksPerTicket iterations to come back.  (One chunk per ticket: 52 atomics per microsecond and
+   * counter, the order of what one word takes (MI355X_MICROARCH.md: 88); an iteration could not end before its own
+   * atomic had come back, and that round trip, not the k-mers' memory rounds, set the kernel's time: a build that cut
+   * the search short after one or two pair steps was no faster.) */
+  auto ticketBase = [&](unsigned t) -> unsigned long long {
+    return begin + ((unsigned long long)t * kWaves + wave) * chunksPerTicket * kChunk;
   };
   unsigned drawn = 0;
   if (lane == 0) drawn = atomicAdd(ticket, 1u);
-  unsigned long long base = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
-  if (lane == 0) drawn = atomicAdd(ticket, 1u);
-  unsigned long long baseNext = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
+  unsigned long long ticketAt = ticketBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
+  unsigned sub = 0;
+  if (lane == 0) drawn = atomicAdd(ticket, 1u); /* the ticket after */
+  auto nextChunk = [&]() -> unsigned long long { /* wave-uniform */
+    if (sub == chunksPerTicket) {
+      ticketAt = ticketBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
+      sub = 0;
+      if (lane == 0) drawn = atomicAdd(ticket, 1u);
+    }
+    return ticketAt + (unsigned long long)(sub++) * kChunk;
+  };
+  unsigned long long base = nextChunk();
+  unsigned long long baseNext = nextChunk();
 
   const unsigned long long tableMask = (1ull << (2u * depth)) - 1ull;
   Raw raw = {0ull, 0ull, 0u}; /* the prefetched record */
@@ -886,9 +904,8 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   unsigned long long codesCur = 0, baseNext2 = 0;
   unsigned indexCur = 0;
   ulonglong2 entryCur = make_ulonglong2(1ull, 0ull);
-  if (BUCKET) {
-    if (lane == 0) drawn = atomicAdd(ticket, 1u);
-    baseNext2 = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
+  if (AHEAD) {
+    baseNext2 = nextChunk();
     if (base < end) {
       const unsigned mine = laneBucket(base);
       codesCur = bucketCodes(bucketFmt, mine, raw.a >> bucketFmt.indexBits);
@@ -909,7 +926,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     unsigned long long codes;
     unsigned index;
     ulonglong2 entry = make_ulonglong2(1ull, 0ull);
-    if (BUCKET) {
+    if (AHEAD) {
       /* this chunk: taken apart an iteration ago, its entry requested then */
       codes = codesCur;
       index = indexCur;
@@ -928,27 +945,27 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
           touchTable(codesCur & tableMask);
         }
       }
-      if (lane == 0) drawn = atomicAdd(ticket, 1u);
       if (baseNext2 + lane / G < end) readRecord(baseNext2 + lane / G, raw);
     } else {
     /* the record fetched an iteration ago is taken apart BEFORE anything new is issued: a wait placed after the
      * atomic below would also wait for that atomic */
     asm volatile("" : "+v"(raw.a), "+v"(raw.b), "+v"(raw.keyWord)::"memory");
     const unsigned key = (raw.keyWord >> (16u * (unsigned)(q & 1ull))) & 0xFFFFu;
-    codes = COMPACT ? orderCodes(format, key, (unsigned)(raw.a >> 32)) : raw.a;
-    index = COMPACT ? (unsigned)raw.a : (unsigned)raw.b;
+    codes = BUCKET    ? bucketCodes(bucketFmt, laneBucket(base), raw.a >> bucketFmt.indexBits)
+            : COMPACT ? orderCodes(format, key, (unsigned)(raw.a >> 32))
+                      : raw.a;
+    index = BUCKET ? (unsigned)(raw.a & ((1ull << bucketFmt.indexBits) - 1ull)) : COMPACT ? (unsigned)raw.a : (unsigned)raw.b;
     }
     const unsigned myLen = VARLEN ? (unsigned)(raw.b >> 32) : len; /* before `raw` is overwritten by the prefetch */
     /* ---- seed (ref src/AwFmKmerTable.c:4-51): the index table, or the deeper device-only one ---- */
-    if (!BUCKET) {
+    if (!AHEAD) {
     /* fixed length: the table entry is requested FIRST, so that the wait for it (loads return in order) is not also a
      * wait for the ticket atomic and the record prefetch issued below */
     if (!VARLEN && live) {
       entry = tableEntry(codes & tableMask);
       touchTable(codes & tableMask);
     }
-    /* draw the ticket after next (consumed at the bottom), fetch the next chunk's record */
-    if (lane == 0) drawn = atomicAdd(ticket, 1u);
+    /* fetch the next chunk's record */
     if (baseNext + lane / G < end) readRecord(baseNext + lane / G, raw);
     }
     if (!VARLEN) {
@@ -1037,11 +1054,11 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       }
     }
     base = baseNext;
-    if (BUCKET) {
+    if (AHEAD) {
       baseNext = baseNext2;
-      baseNext2 = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
+      baseNext2 = nextChunk();
     } else {
-      baseNext = chunkBase((unsigned)__builtin_amdgcn_readfirstlane((int)drawn));
+      baseNext = nextChunk();
     }
   }
 }

@@ -166,7 +166,7 @@ def test_sa_staged_from_file(oracle, awfm, require_gpu, tmp_path):
     ix2.dealloc()
 
 
-@pytest.mark.parametrize("seed_k,deep_k", [(3, 5), (6, 9), (8, 12)])
+@pytest.mark.parametrize("seed_k,deep_k", [(3, 5), (6, 9), (8, 12), (12, 16)])  # 16: the depth GRCh38-sized images get (34 GB)
 def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, require_gpu, wide, seed_k, deep_k):
     """the optional device-only deeper seed table must not change a single range or position, including
     queries shorter than it, ambiguity letters inside/outside the deep suffix and absent k-mers"""
@@ -390,7 +390,7 @@ def _check_hits_contract(ranges, counts, sp, ep, cnt):
 
 @pytest.mark.parametrize("n,ratio,seed_k,deep_k,K", [(300000, 8, 8, 0, 21), (300000, 5, 8, 0, 8), (200000, 8, 6, 9, 32),
                                                      (200000, 8, 6, 9, 7), (4096, 3, 4, 0, 13), (100000, 8, 1, 0, 5),
-                                                     (150000, 8, 10, 11, 11)])
+                                                     (150000, 8, 10, 11, 11), (300000, 8, 12, 16, 21)])
 def test_ordered_hits_only_search_is_exact_on_hits(oracle, awfm, require_gpu, wide, order_sort, n, ratio, seed_k, deep_k, K):
     """awfmGpuSearchHits with the ordered path forced on (fixed-length DNA batches): ambiguity characters and upper
     case included, query buffer at every byte alignment, ranges only / counts only / both, then the locate
@@ -691,7 +691,7 @@ def test_drop_in_aos_api_uses_the_ordered_search_when_forced(oracle, awfm, requi
 
 
 @pytest.mark.parametrize("n,ratio,seed_k,deep_k", [(300000, 8, 8, 0), (200000, 8, 6, 9), (4096, 3, 4, 0), (100000, 8, 1, 0),
-                                                   (150000, 8, 10, 11), (250000, 7, 12, 0)])
+                                                   (150000, 8, 10, 11), (250000, 7, 12, 0), (250000, 8, 12, 16)])
 def test_ordered_hits_only_search_of_mixed_length_batches(oracle, awfm, require_gpu, wide, n, ratio, seed_k, deep_k):
     """CSR batches through the ordered path (forced on): lengths 0..40, so k-mers start from the deeper table, the
     seed table or a letter range (shorter than the seed), and empty / over-long / ambiguous ones go to the general
