@@ -54,6 +54,7 @@ void awFmDeallocKmerSearchList(struct AwFmKmerSearchList *_RESTRICT_ const searc
 }
 
 #include <pthread.h>
+#include <time.h>
 
 #define AWFM_MAX_IMAGES 16
 #define AWFM_MIN_SHARDED_LIST 65536u
@@ -104,19 +105,66 @@ static void packChars(void *p, uint64_t begin, uint64_t end, unsigned tid) {
   }
 }
 
-/* Packs n k-mers starting at data[0] into page-locked staging buffers of the image, with `threads` host threads
- * (lengths are summed per chunk first, so that every chunk knows where its characters go).  When every k-mer
- * has the same length the offsets array is dropped (*offsetsOut = NULL, *fixedOut = that length). */
+/* 8..32 characters (every seed-and-extend k-mer length): two overlapping fixed-size copies instead of a call with a
+ * run-time length; both stay inside the string */
+static inline void copyKmer(uint8_t *dst, const char *src, uint64_t len) {
+  if (len >= 16 && len <= 32) {
+    memcpy(dst, src, 16);
+    memcpy(dst + len - 16, src + len - 16, 16);
+  } else if (len >= 8 && len < 16) {
+    memcpy(dst, src, 8);
+    memcpy(dst + len - 8, src + len - 8, 8);
+  } else {
+    memcpy(dst, src, len);
+  }
+}
+
+/* the usual list -- every k-mer of one length -- is packed in ONE pass over the AoS: each range copies as if the list
+ * were uniform and says so if it met another length (the two passes below then redo the chunk) */
+struct packUniformCtx {
+  const struct AwFmKmerSearchData *data;
+  uint64_t length;
+  uint8_t *chars;
+  int mixed;
+};
+static void packUniform(void *p, uint64_t begin, uint64_t end, unsigned tid) {
+  (void)tid;
+  struct packUniformCtx *c = p;
+  const uint64_t len = c->length;
+  for (uint64_t i = begin; i < end; i++) {
+    if (c->data[i].kmerLength != len) {
+      __atomic_store_n(&c->mixed, 1, __ATOMIC_RELAXED);
+      return;
+    }
+    copyKmer(c->chars + i * len, c->data[i].kmerString, len);
+  }
+}
+
+/* Packs n k-mers starting at data[0] into page-locked staging buffers of the image, with `threads` host threads.
+ * When every k-mer has the same length the offsets array is dropped (*offsetsOut = NULL, *fixedOut = that length);
+ * otherwise lengths are summed per range first, so that every range knows where its characters go. */
 static bool packQueries(AwFmGpuIndex *g, const struct AwFmKmerSearchData *data, uint64_t n, unsigned threads,
                         uint8_t **charsOut, uint64_t **offsetsOut, uint32_t *fixedOut) {
+  const uint64_t firstLength = data[0].kmerLength;
+  if (firstLength != 0 && firstLength <= 4096) {
+    struct packUniformCtx u = {data, firstLength, awfmGpuPinnedBuffer(g, 0, n * firstLength), 0};
+    if (!u.chars) return false;
+    awfmParallelFor(threads, n, packUniform, &u);
+    if (!u.mixed) {
+      *charsOut = u.chars;
+      *offsetsOut = NULL;
+      *fixedOut = (uint32_t)firstLength;
+      return true;
+    }
+  }
   struct packCtx ctx;
   memset(&ctx, 0, sizeof ctx);
   ctx.data = data;
-  ctx.firstLength = data[0].kmerLength;
+  ctx.firstLength = firstLength;
   awfmParallelFor(threads, n, packMeasure, &ctx);
   uint64_t total = 0;
   bool uniform = ctx.firstLength != 0 && ctx.firstLength <= 0xFFFFFFFFull;
-  for (unsigned t = 0; t < AWFM_MAX_PACK_THREADS; t++) { /* chunks are in query order; a run may use fewer */
+  for (unsigned t = 0; t < AWFM_MAX_PACK_THREADS; t++) { /* ranges are in query order; a run may use fewer */
     ctx.chunkStart[t] = total;
     if (!ctx.chunkUsed[t]) continue;
     total += ctx.chunkChars[t];
@@ -157,29 +205,30 @@ struct locateCtx {
   /* the window being scattered */
   uint64_t queryBegin, hitBegin, hitEnd;
   const uint64_t *positions;
+  double waitMs, scatterMs; /* $AWFM_GPU_AOS_TRACE */
 };
 
 /* ref src/AwFmParallelSearch.c:327-328, :367-387 (setPositionListCount): count is set, the list grows by realloc to
  * exactly `count` only when capacity is too small */
+static inline void sizeList(struct locateCtx *c, uint64_t i) {
+  struct AwFmKmerSearchData *d = &c->data[i];
+  const uint32_t newCount = (uint32_t)(c->hitOffsets[i + 1] - c->hitOffsets[i]);
+  if (d->capacity < newCount) {
+    void *grown = realloc(d->positionList, (size_t)newCount * sizeof(uint64_t));
+    if (!grown) {
+      fprintf(stderr, "Critical memory failure: could not allocate memory for position list.\n");
+      __atomic_store_n(&c->failed, 1, __ATOMIC_RELAXED);
+      d->count = 0;
+      return;
+    }
+    d->positionList = grown;
+    d->capacity = newCount;
+  }
+  d->count = newCount;
+}
 static void sizeLists(void *p, uint64_t begin, uint64_t end, unsigned tid) {
   (void)tid;
-  struct locateCtx *c = p;
-  for (uint64_t i = begin; i < end; i++) {
-    struct AwFmKmerSearchData *d = &c->data[i];
-    const uint32_t newCount = (uint32_t)(c->hitOffsets[i + 1] - c->hitOffsets[i]);
-    if (d->capacity < newCount) {
-      void *grown = realloc(d->positionList, (size_t)newCount * sizeof(uint64_t));
-      if (!grown) {
-        fprintf(stderr, "Critical memory failure: could not allocate memory for position list.\n");
-        __atomic_store_n(&c->failed, 1, __ATOMIC_RELAXED);
-        d->count = 0;
-        continue;
-      }
-      d->positionList = grown;
-      d->capacity = newCount;
-    }
-    d->count = newCount;
-  }
+  for (uint64_t i = begin; i < end; i++) sizeList(p, i);
 }
 
 /* ref src/AwFmParallelSearch.c:361: the part of every list that lies in the window [hitBegin, hitEnd) of the flat hit list
@@ -196,9 +245,26 @@ static void scatterWindow(void *p, uint64_t begin, uint64_t end, unsigned tid) {
   }
 }
 
+/* the whole hit list in one window (all but hit-heavy chunks): sizeLists and scatterWindow in one pass over the AoS */
+static void sizeAndScatter(void *p, uint64_t begin, uint64_t end, unsigned tid) {
+  (void)tid;
+  struct locateCtx *c = p;
+  for (uint64_t i = begin; i < end; i++) {
+    sizeList(c, i);
+    struct AwFmKmerSearchData *d = &c->data[i];
+    if (d->count) memcpy(d->positionList, c->positions + c->hitOffsets[i], (size_t)d->count * sizeof(uint64_t));
+  }
+}
+
 static int locateWindowSink(void *user, uint64_t queryBegin, uint64_t queryEnd, uint64_t hitBegin, uint64_t hitEnd,
                             const uint64_t *positions) {
   struct locateCtx *c = user;
+  if (!c->sized && hitBegin == 0 && hitEnd == c->hitOffsets[c->n]) {
+    c->positions = positions;
+    awfmParallelFor(c->threads, c->n, sizeAndScatter, c);
+    c->sized = true;
+    return 0;
+  }
   if (!c->sized) { /* the hit offsets are complete: every list gets its final size before the first position lands */
     awfmParallelFor(c->threads, c->n, sizeLists, c);
     c->sized = true;
@@ -218,66 +284,127 @@ static void invalidateCounts(struct AwFmKmerSearchData *data, uint64_t n) {
   for (uint64_t i = 0; i < n; i++) data[i].count = 0;
 }
 
-/* ---- one contiguous shard of the list on one device image ---- */
-struct shardJob {
+/* ---- the list in chunks, over the lanes of the device images ---- */
+/* The host stages of a chunk (packing its k-mers, scattering its results) and its device stage (upload, kernels,
+ * download) alternate, so a list is cut into chunks that the lanes -- one host thread per device image, three images
+ * on the default device -- take in turn: while one lane waits for the device, another packs or scatters with ALL the
+ * caller's threads.  The host stages take turns (hostStage); a lane never waits for the device while it holds the
+ * turn.  $AWFM_GPU_AOS_CHUNK: k-mers per chunk; $AWFM_GPU_AOS_TRACE: one line per chunk on stderr. */
+#define AWFM_AOS_CHUNK_DEFAULT (1u << 20) /* 10^7 random 21-mers, locate, 32 threads: 8.5 ms at 2^20 or 2^21, 13.7 ms at 4*10^6 */
+static pthread_mutex_t hostStage = PTHREAD_MUTEX_INITIALIZER;
+
+static double nowMs(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return (double)t.tv_sec * 1e3 + (double)t.tv_nsec * 1e-6;
+}
+
+struct laneJob {
   AwFmGpuIndex *image;
-  struct AwFmKmerSearchData *data; /* first query of the shard */
-  uint64_t n;
-  unsigned threads;
-  bool locate;
+  struct AwFmKmerSearchData *data; /* the whole list */
+  uint64_t n, chunk;
+  unsigned lane, numLanes, threads;
+  bool locate, trace;
   enum AwFmReturnCode rc;
-  char error[256]; /* awfmGpuLastError() of the thread that ran the shard (the message is thread-local) */
+  char error[256]; /* awfmGpuLastError() of the thread that ran the lane (the message is thread-local) */
 };
 
-static void *runShard(void *p) {
-  struct shardJob *job = p;
+static int locateWindowSinkTurn(void *user, uint64_t queryBegin, uint64_t queryEnd, uint64_t hitBegin, uint64_t hitEnd,
+                                const uint64_t *positions) {
+  struct locateCtx *c = user;
+  const double t0 = nowMs();
+  pthread_mutex_lock(&hostStage);
+  const double t1 = nowMs();
+  const int r = locateWindowSink(user, queryBegin, queryEnd, hitBegin, hitEnd, positions);
+  pthread_mutex_unlock(&hostStage);
+  c->waitMs += t1 - t0;
+  c->scatterMs += nowMs() - t1;
+  return r;
+}
+
+static enum AwFmReturnCode runChunk(struct laneJob *job, struct AwFmKmerSearchData *data, uint64_t n, uint64_t chunkNumber) {
   AwFmGpuIndex *g = job->image;
-  job->rc = AwFmSuccess;
-  if (job->n == 0) return NULL;
-  awfmGpuAosLock(g);
+  enum AwFmReturnCode rc = AwFmSuccess;
   uint8_t *chars = NULL;
   uint64_t *offsets = NULL;
   uint32_t fixedLength = 0;
-  void *out = awfmGpuPinnedBuffer(g, 2, (job->n + 1) * sizeof(uint64_t)); /* counts (u32) or hit offsets (u64) */
-  if (!out || !packQueries(g, job->data, job->n, job->threads, &chars, &offsets, &fixedLength)) {
-    job->rc = AwFmAllocationFailure;
+  double waitMs = 0, scatterMs = 0;
+  const double t0 = nowMs();
+  pthread_mutex_lock(&hostStage);
+  const double t1 = nowMs();
+  void *out = awfmGpuPinnedBuffer(g, 2, (n + 1) * sizeof(uint64_t)); /* counts (u32) or hit offsets (u64) */
+  const bool packed = out && packQueries(g, data, n, job->threads, &chars, &offsets, &fixedLength);
+  pthread_mutex_unlock(&hostStage);
+  const double t2 = nowMs();
+  if (!packed) {
+    rc = AwFmAllocationFailure;
   } else if (!job->locate) {
-    job->rc = awfmGpuCountHost(g, chars, offsets, fixedLength, job->n, NULL, out);
-    if (job->rc == AwFmSuccess) {
-      struct countCtx ctx = {job->data, out};
-      awfmParallelFor(job->threads, job->n, scatterCounts, &ctx);
+    rc = awfmGpuCountHost(g, chars, offsets, fixedLength, n, NULL, out);
+    if (rc == AwFmSuccess) {
+      struct countCtx ctx = {data, out};
+      const double t3 = nowMs();
+      pthread_mutex_lock(&hostStage);
+      const double t4 = nowMs();
+      awfmParallelFor(job->threads, n, scatterCounts, &ctx);
+      pthread_mutex_unlock(&hostStage);
+      waitMs = t4 - t3;
+      scatterMs = nowMs() - t4;
     }
   } else {
-    /* the hit list arrives in windows bounded by the device's hit budget (one window for all but hit-heavy batches),
+    /* the hit list arrives in windows bounded by the device's hit budget (one window for all but hit-heavy chunks),
      * in page-locked staging of the image that is valid while the sink runs */
     struct locateCtx ctx;
     memset(&ctx, 0, sizeof ctx);
-    ctx.data = job->data;
+    ctx.data = data;
     ctx.hitOffsets = out;
-    ctx.n = job->n;
+    ctx.n = n;
     ctx.threads = job->threads;
-    job->rc = awfmGpuLocateHostWindows(g, chars, offsets, fixedLength, job->n, NULL, out, locateWindowSink, &ctx);
-    if (job->rc == AwFmSuccess && !ctx.sized) awfmParallelFor(job->threads, job->n, sizeLists, &ctx); /* no hit at all: counts = 0 */
-    if (job->rc == AwFmSuccess && ctx.failed) job->rc = AwFmAllocationFailure;
+    rc = awfmGpuLocateHostWindows(g, chars, offsets, fixedLength, n, NULL, out, locateWindowSinkTurn, &ctx);
+    if (rc == AwFmSuccess && !ctx.sized) { /* no hit at all: counts = 0 */
+      pthread_mutex_lock(&hostStage);
+      awfmParallelFor(job->threads, n, sizeLists, &ctx);
+      pthread_mutex_unlock(&hostStage);
+    }
+    if (rc == AwFmSuccess && ctx.failed) rc = AwFmAllocationFailure;
+    waitMs = ctx.waitMs;
+    scatterMs = ctx.scatterMs;
   }
-  if (job->rc != AwFmSuccess) {
-    snprintf(job->error, sizeof job->error, "%s", awfmGpuLastError());
-    invalidateCounts(job->data, job->n);
+  if (job->trace)
+    fprintf(stderr, "[awfm aos] lane %u chunk %llu: %llu k-mers, turn %.2f ms, pack %.2f ms, device call %.2f ms (of which turn %.2f, scatter %.2f)\n",
+            job->lane, (unsigned long long)chunkNumber, (unsigned long long)n, t1 - t0, t2 - t1, nowMs() - t2, waitMs, scatterMs);
+  return rc;
+}
+
+static void *runLane(void *p) {
+  struct laneJob *job = p;
+  AwFmGpuIndex *g = job->image;
+  job->rc = AwFmSuccess;
+  awfmGpuAosLock(g);
+  for (uint64_t c = job->lane; c * job->chunk < job->n; c += job->numLanes) {
+    const uint64_t begin = c * job->chunk, m = job->n - begin < job->chunk ? job->n - begin : job->chunk;
+    job->rc = runChunk(job, job->data + begin, m, c);
+    if (job->rc != AwFmSuccess) {
+      snprintf(job->error, sizeof job->error, "%s", awfmGpuLastError());
+      for (uint64_t d = c; d * job->chunk < job->n; d += job->numLanes) { /* this chunk and what the lane still had to do */
+        const uint64_t b = d * job->chunk;
+        invalidateCounts(job->data + b, job->n - b < job->chunk ? job->n - b : job->chunk);
+      }
+      break;
+    }
   }
   awfmGpuAosUnlock(g);
   return NULL;
 }
 
-/* Shards the list contiguously over the images of $AWFM_GPU_DEVICES (one host thread per device; the
- * shards are independent, there is no exchange: ref src/AwFmParallelSearch.c:103-129 treats 8-query
- * blocks the same way).  Returns the first failure. */
+/* Chunks of the list go round-robin over the images of $AWFM_GPU_DEVICES (one host thread per image; the chunks are
+ * independent, there is no exchange: ref src/AwFmParallelSearch.c:103-129 treats 8-query blocks the same way).
+ * Returns the first failure. */
 static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKmerSearchList *list, uint32_t numThreads,
                                     bool locate, const char *who) {
   const uint64_t n = (uint32_t)list->count; /* the reference reads the count as uint32_t (:100, :164) */
   if (n == 0) return AwFmSuccess;
   AwFmGpuIndex *images[AWFM_MAX_IMAGES];
-  /* without an explicit device list a small batch is one shard: splitting it over the two default lanes
-   * would only add launches */
+  /* without an explicit device list a small batch is one chunk on one lane: splitting it would only add launches */
   const char *deviceList = getenv("AWFM_GPU_DEVICES");
   const bool oneShard = !(deviceList && *deviceList) && n < AWFM_MIN_SHARDED_LIST;
   const int numImages = awfmGpuIndexAcquireAll(index, images, oneShard ? 1 : AWFM_MAX_IMAGES);
@@ -286,24 +413,24 @@ static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKm
     invalidateCounts(list->kmerSearchData, n);
     return AwFmGeneralFailure;
   }
-  struct shardJob jobs[AWFM_MAX_IMAGES];
+  uint64_t chunk = AWFM_AOS_CHUNK_DEFAULT;
+  if (getenv("AWFM_GPU_AOS_CHUNK") && strtoull(getenv("AWFM_GPU_AOS_CHUNK"), NULL, 10) > 0) chunk = strtoull(getenv("AWFM_GPU_AOS_CHUNK"), NULL, 10);
+  const uint64_t even = (n + (uint64_t)numImages - 1) / (uint64_t)numImages; /* a list of less than a chunk per image: even shares */
+  if (chunk > even) chunk = even;
+  struct laneJob jobs[AWFM_MAX_IMAGES];
   pthread_t threads[AWFM_MAX_IMAGES];
   bool spawned[AWFM_MAX_IMAGES] = {false};
-  const uint64_t per = (n + (uint64_t)numImages - 1) / (uint64_t)numImages;
-  const unsigned threadsPerShard = numThreads / (unsigned)numImages > 0 ? numThreads / (unsigned)numImages : 1;
-  for (int i = 0; i < numImages; i++) {
-    const uint64_t begin = per * (uint64_t)i < n ? per * (uint64_t)i : n;
-    const uint64_t end = begin + per < n ? begin + per : n;
-    jobs[i] = (struct shardJob){images[i], list->kmerSearchData + begin, end - begin, threadsPerShard, locate, AwFmSuccess, {0}};
-  }
-  for (int i = 1; i < numImages; i++) spawned[i] = pthread_create(&threads[i], NULL, runShard, &jobs[i]) == 0;
-  runShard(&jobs[0]);
+  for (int i = 0; i < numImages; i++)
+    jobs[i] = (struct laneJob){images[i], list->kmerSearchData, n, chunk, (unsigned)i, (unsigned)numImages, numThreads > 0 ? numThreads : 1,
+                               locate, getenv("AWFM_GPU_AOS_TRACE") != NULL, AwFmSuccess, {0}};
+  for (int i = 1; i < numImages; i++) spawned[i] = pthread_create(&threads[i], NULL, runLane, &jobs[i]) == 0;
+  runLane(&jobs[0]);
   int firstFailed = jobs[0].rc != AwFmSuccess ? 0 : -1;
   for (int i = 1; i < numImages; i++) {
     if (spawned[i])
       pthread_join(threads[i], NULL);
     else
-      runShard(&jobs[i]);
+      runLane(&jobs[i]);
     if (firstFailed < 0 && jobs[i].rc != AwFmSuccess) firstFailed = i;
   }
   if (firstFailed < 0) return AwFmSuccess;

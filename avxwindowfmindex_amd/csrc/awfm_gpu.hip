@@ -556,8 +556,8 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
 }
 
 /* device ordinals the AoS entry points shard over: $AWFM_GPU_DEVICES = "all" or a comma list (a device named
- * again gets a lane on its image); unset = the default device (-1) with two lanes, so that one half of a
- * batch is packed / scattered on the host while the other half is on the PCIe bus or in the kernels */
+ * again gets a lane on its image); unset = the default device (-1) with three lanes, so that one chunk of a
+ * list is packed / scattered on the host while others are on the PCIe bus or in the kernels (awfm_batch.c) */
 static int aosDevices(int *devs, int maxOut) {
   int n = 0;
   const char *env = getenv("AWFM_GPU_DEVICES");
@@ -571,9 +571,9 @@ static int aosDevices(int *devs, int maxOut) {
       if (*c == ',') c++;
     }
   }
-  if (n == 0) {
+  if (n == 0) { /* three lanes on the default device: one packs or scatters while two are in their device stage */
     devs[n++] = -1;
-    if (maxOut > 1) devs[n++] = -1;
+    for (int lane = 1; lane < 3 && n < maxOut; lane++) devs[n++] = -1;
   }
   return n;
 }
@@ -1302,7 +1302,7 @@ enum AwFmReturnCode awfmGpuCountHost(AwFmGpuIndex *g, const uint8_t *chars, cons
   enum AwFmReturnCode rc = ensureWork(g, l.total);
   if (rc != AwFmSuccess) return rc;
   uint8_t *w = (uint8_t *)g->dWork;
-  /* the calling thread's own stream: two host lanes (or two user threads with two images) overlap one's
+  /* the calling thread's own stream: the host lanes (or two user threads with two images) overlap one's
    * transfers with the other's kernels */
   hipStream_t s = hipStreamPerThread;
   AWFM_HIP_TRY(hipMemcpyAsync(w + l.chars, chars, totalChars, hipMemcpyHostToDevice, s), AwFmGeneralFailure);

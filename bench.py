@@ -245,9 +245,12 @@ def end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, a
         threads = min(32, 2 * (os.cpu_count() or 1))
         fn = (lambda: api.parallel_search_locate(ix, lst, threads)) if locate else (lambda: api.parallel_search_count(ix, lst, threads))
         fn()
-        t0 = time.perf_counter()
-        fn()
-        dt = time.perf_counter() - t0
+        aos_times = []
+        for _ in range(5):  # host threads on a shared box: the best of five calls, every call in `ms_all`
+            t0 = time.perf_counter()
+            fn()
+            aos_times.append(time.perf_counter() - t0)
+        dt = min(aos_times)
         got = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint32)), shape=(m, 8))[:, 6]
         if locate:
             ho = d_hit_off[: m + 1].cpu().numpy().view(np.uint64)
@@ -255,6 +258,7 @@ def end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, a
         else:
             assert np.array_equal(got, d_counts[:m].cpu().numpy().view(np.uint32)), "AoS counts differ from the device API's"
         out["aos_drop_in"] = {"value": round(m / dt / 1e6, 1), "ms": round(dt * 1e3, 2), "kmers": m, "host_threads": threads,
+                              "ms_all": [round(t * 1e3, 2) for t in aos_times],
                               "entry_point": "awFmParallelSearchLocate" if locate else "awFmParallelSearchCount"}
         lst.dealloc()
     return out

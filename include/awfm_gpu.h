@@ -69,10 +69,10 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g);
 /* Side table used by awFmParallelSearch*: image for a host index, created on first use. */
 AwFmGpuIndex *awfmGpuIndexAcquire(const struct AwFmIndex *index);
 /* Handles on the device images of a host index for every entry of $AWFM_GPU_DEVICES ("all" or a comma list of
- * ordinals), created on first use; awFmParallelSearch* shard a batch over them, one host thread each.  A device
+ * ordinals), created on first use; awFmParallelSearch* deal the chunks of a list to them, one host thread each.  A device
  * named again gets a lane: a handle with its own staging buffers and locks on the image that device already
- * has (no second copy of the index), so that its shard overlaps the other's transfers and kernels.  Unset:
- * the default device with two lanes.  Returns how many handles were written to out[0..maxOut). */
+ * has (no second copy of the index), so that its chunks overlap the others' transfers and kernels.  Unset:
+ * the default device with three lanes.  Returns how many handles were written to out[0..maxOut). */
 int awfmGpuIndexAcquireAll(const struct AwFmIndex *index, AwFmGpuIndex **out, int maxOut);
 /* Drops the side-table entries of the index (called by awFmDeallocIndex). */
 void awfmGpuIndexRelease(const struct AwFmIndex *index);
@@ -256,7 +256,7 @@ void awfmGpuAosUnlock(AwFmGpuIndex *g);
 
 /* ---- flat batch API on host buffers (upload, kernels, download) ---- */
 /* Synchronous for the caller; the work is issued on the calling thread's own stream (hipStreamPerThread), so
- * several host threads (or the two lanes of the AoS entry points) overlap on the device.
+ * several host threads (or the lanes of the AoS entry points) overlap on the device.
  * ranges / counts may be NULL. */
 enum AwFmReturnCode awfmGpuCountHost(AwFmGpuIndex *g, const uint8_t *chars, const uint64_t *offsets,
                                      uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *ranges,

@@ -217,6 +217,48 @@ def test_device_dense_sa_keeps_positions_bit_identical(oracle, awfm, require_gpu
     ix.dealloc()
 
 
+@pytest.mark.parametrize("lanes,chunk,budget", [("0,0,0", 4096, None), ("0,0", 5000, 1 << 15), (None, 70001, None), ("0", 1500, None)])
+def test_drop_in_api_takes_a_list_in_chunks(oracle, awfm, require_gpu, monkeypatch, lanes, chunk, budget):
+    """awFmParallelSearchCount / Locate cut a list into chunks ($AWFM_GPU_AOS_CHUNK) that the lanes take in turn, packing
+    and scattering with all the caller's threads while the other lanes are in their device stage.  The list holds
+    stretches of one length (packed in one pass) and stretches of mixed lengths (CSR), so neighbouring chunks differ in
+    kind; with a small hit budget the positions of a chunk arrive in several windows.  Position lists keep the capacity
+    rule of the reference (ref src/AwFmParallelSearch.c:367-387): grown to exactly `count` only when too small."""
+    txt = synth.text(188, 150000)
+    n_fixed, n_mixed = 9000, 7013
+    fixed = synth.planted_queries(189, n_fixed, 9, txt)
+    chars_m, offsets_m = synth.mixed_queries(190, n_mixed, txt, synth.DNA_ALPHABET, 1, 30)
+    kmers = [fixed[i].tobytes() for i in range(n_fixed // 2)]
+    kmers += [chars_m[int(offsets_m[i]):int(offsets_m[i + 1])].tobytes() for i in range(n_mixed)]
+    kmers += [fixed[i].tobytes() for i in range(n_fixed // 2, n_fixed)]
+    n = len(kmers)
+    chars = np.frombuffer(b"".join(kmers), dtype=np.uint8)
+    offsets = np.concatenate([[0], np.cumsum([len(k) for k in kmers])]).astype(np.uint64)
+    oi = oracle.Index.from_text(txt.tobytes(), oracle.DNA, 8, 7)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    if lanes is None:
+        monkeypatch.delenv("AWFM_GPU_DEVICES", raising=False)
+    else:
+        monkeypatch.setenv("AWFM_GPU_DEVICES", lanes)
+    monkeypatch.setenv("AWFM_GPU_AOS_CHUNK", str(chunk))
+    if budget:
+        monkeypatch.setenv("AWFM_GPU_HIT_BUDGET_BYTES", str(budget))
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 7)
+    lst = awfm.KmerSearchList(n)
+    lst.fill(kmers)
+    for threads in (7, 1):
+        awfm.parallel_search_count(ix, lst, threads)
+        assert np.array_equal(lst.counts(), cnt)
+        assert awfm.parallel_search_locate(ix, lst, threads) == awfm.AwFmSuccess
+        assert np.array_equal(lst.counts(), cnt)
+        assert np.array_equal(lst.capacities(), np.maximum(cnt, 4))
+        for i in list(range(0, n, 7)) + [n - 1]:
+            assert np.array_equal(lst.positions(i), pos[int(hit_off[i]):int(hit_off[i + 1])]), i
+    lst.dealloc()
+    ix.dealloc()
+
+
 def test_drop_in_api_shards_over_device_images(oracle, awfm, require_gpu, monkeypatch):
     """AWFM_GPU_DEVICES lists the devices awFmParallelSearch* shard a batch over (one host thread per entry,
     contiguous shards, no exchange; one index replica per distinct device, a device named again gets a lane
@@ -350,8 +392,8 @@ def test_flat_locate_with_any_position_buffer_alignment_and_hit_count(oracle, aw
     ix.dealloc()
 
 
-def test_drop_in_aos_api_two_default_lanes(oracle, awfm, require_gpu, monkeypatch):
-    """lists of 65536 k-mers and more are split over two host lanes on the one default image (no device list in
+def test_drop_in_aos_api_default_lanes(oracle, awfm, require_gpu, monkeypatch):
+    """lists of 65536 k-mers and more are dealt to three host lanes on the one default image (no device list in
     the environment): counts and position lists against the oracle, twice in a row (staging buffers re-used)"""
     monkeypatch.delenv("AWFM_GPU_DEVICES", raising=False)
     txt = synth.text(95, 300000)
@@ -375,7 +417,7 @@ def test_drop_in_aos_api_two_default_lanes(oracle, awfm, require_gpu, monkeypatc
     from avxwindowfmindex_amd import _lib
     import ctypes as C
     imgs = (C.c_void_p * 4)()
-    assert _lib.lib().awfmGpuIndexAcquireAll(ix.ptr, imgs, 4) == 2 and imgs[0] != imgs[1]
+    assert _lib.lib().awfmGpuIndexAcquireAll(ix.ptr, imgs, 4) == 3 and len({imgs[0], imgs[1], imgs[2]}) == 3
     lst.dealloc()
     ix.dealloc()
 
