@@ -95,6 +95,15 @@ struct DevIndex {
    * the stepping stops at the FIRST empty range, and that one is always {sp, sp - 1} (sp = C + Occ(sp' - 1),
    * ep = C + Occ(ep') - 1 from a valid {sp', ep'}), so a length of 0 says all there is to say; sp >= 1 always */
   unsigned int deepNarrow;
+  /* (1) the 8-byte entries are {sp, length16 | next16 << 16} (awfmGpuDeepSeedAddNext, built when the image has pair
+   * blocks): bit c of next16 says whether the range is still non-empty after the pair step with code c (the two
+   * characters that precede the deepK-mer in a longer k-mer; awfm_pair.h), so a hits-only search drops a k-mer whose
+   * bit is clear without reading a block.  A length of 0xFFFF stands for "0xFFFF or more": the exact one is in the side
+   * list (deepBigKeys ascending: entry numbers, deepBigLengths beside it; few entries: repeats only). */
+  unsigned int deepNext;
+  unsigned int numDeepBig;
+  const unsigned int *deepBigKeys;
+  const unsigned int *deepBigLengths;
   /* optional device-only pair image (nucleotide; awfm_pair.h): two backward / LF steps per block read; NULL when
    * not built.  pairSuper32 is the 32-bit copy of the superblock bases the kernels of images below 2^32 positions
    * keep in LDS (kPairSuperStride words per superblock). */
@@ -106,11 +115,32 @@ struct DevIndex {
   unsigned int pairSuperInLds; /* set per launch: the kernel was given numPairSuper * 64 bytes of dynamic LDS for pairSuper32 */
 };
 
-__device__ __forceinline__ ulonglong2 deepSeedEntry(const DevIndex &ix, unsigned long long i) {
-  if (ix.deepNarrow) { /* image-wide: uniform */
-    const uint2 e = ((const uint2 *)ix.deepSeed)[i];
-    return make_ulonglong2((unsigned long long)e.x, (unsigned long long)e.x + e.y - 1ull);
+/* exact length of an entry whose 16-bit length field is saturated */
+__device__ inline unsigned deepBigLength(const DevIndex &ix, unsigned long long i) {
+  unsigned lo = 0, hi = ix.numDeepBig;
+  while (lo < hi) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (ix.deepBigKeys[mid] < (unsigned)i) lo = mid + 1;
+    else hi = mid;
   }
+  return lo < ix.numDeepBig && ix.deepBigKeys[lo] == (unsigned)i ? ix.deepBigLengths[lo] : 0xFFFFu;
+}
+/* {sp, ep} from the two words of a narrow entry; *next16 (may be NULL): the pair steps that keep the range non-empty
+ * (all of them when the table has no such bits) */
+__device__ __forceinline__ ulonglong2 deepSeedOpen(const DevIndex &ix, unsigned long long i, uint2 e, unsigned *next16) {
+  unsigned length = e.y;
+  if (ix.deepNext) {
+    length = e.y & 0xFFFFu;
+    if (length == 0xFFFFu) length = deepBigLength(ix, i);
+    if (next16) *next16 = e.y >> 16;
+  } else if (next16) {
+    *next16 = 0xFFFFu;
+  }
+  return make_ulonglong2((unsigned long long)e.x, (unsigned long long)e.x + length - 1ull);
+}
+__device__ __forceinline__ ulonglong2 deepSeedEntry(const DevIndex &ix, unsigned long long i) {
+  if (ix.deepNarrow) /* image-wide: uniform */
+    return deepSeedOpen(ix, i, ((const uint2 *)ix.deepSeed)[i], nullptr);
   return ix.deepSeed[i];
 }
 
@@ -690,6 +720,7 @@ struct AwFmGpuIndex {
   void *dPrefix = nullptr;
   void *dDeepSeed = nullptr;
   uint64_t deepSeedBytes = 0;
+  void *dDeepBig = nullptr; /* side list of the deeper table: keys, then lengths (DevIndex::deepBigKeys) */
   void *dDenseSa = nullptr; /* optional full suffix array, 32-bit entries */
   uint64_t denseSaBytes = 0;
   void *dPairBlocks = nullptr, *dPairSuper = nullptr, *dPairSuper32 = nullptr, *dPairC = nullptr; /* pair image */
@@ -816,6 +847,11 @@ enum AwFmReturnCode awfmGpuScanFlags(AwFmGpuIndex *g, const uint32_t *dCounts, u
                                      void *dScratch, hipStream_t s);
 /* awfm_gpu_build.hip: level-wise construction of the deeper seed table into a new device buffer */
 bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut);
+/* awfm_gpu_ordered.hip: rewrites the 8-byte entries {sp, length} of a finished table as {sp, length16 | next16 << 16}
+ * (DevIndex::deepNext) and returns the side list of the saturated lengths in *bigOut (one allocation: *numBigOut keys,
+ * then as many lengths; NULL when there is none).  Needs the pair image.  1: done; 0: not applicable, nothing was
+ * changed; -1: failed, the table is no longer usable. */
+int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **bigOut, unsigned *numBigOut);
 void awfmGpuSetError(const char *what);
 void awfmGpuSetHipError(const char *what, hipError_t e);
 

@@ -359,8 +359,8 @@ AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void 
   g->deviceBytes = deviceBytes;
   fillDevIndex(g, index, superShift, sentinelPos);
   if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
+  (void)applyPairFromEnv(g);     /* first: the deeper table's next-step bits are computed through the pair image */
   (void)applyDeepSeedFromEnv(g); /* optional accelerator: on failure the image simply has no deeper table */
-  (void)applyPairFromEnv(g);
   return g;
 }
 
@@ -517,8 +517,8 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
 
   fillDevIndex(g, index, superShift, sentinelPos);
   if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
-  if (applyDeepSeedFromEnv(g) != AwFmSuccess) return fail(AwFmGeneralFailure);
   (void)applyPairFromEnv(g); /* without it (no memory left) searches simply take one step per read */
+  if (applyDeepSeedFromEnv(g) != AwFmSuccess) return fail(AwFmGeneralFailure);
   *out = g;
   return AwFmSuccess;
 }
@@ -535,6 +535,7 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
       if (g->dSa) (void)hipFree(g->dSa);
       if (g->dPrefix) (void)hipFree(g->dPrefix);
       if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
+      if (g->dDeepBig) (void)hipFree(g->dDeepBig);
       if (g->dDenseSa) (void)hipFree(g->dDenseSa);
       void *pairOwned[] = {g->dPairBlocks, g->dPairSuper, g->dPairSuper32, g->dPairC};
       for (void *p : pairOwned)
@@ -735,21 +736,39 @@ enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK) {
 static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const std::vector<AwFmGpuIndex *> &laneList) {
   (void)hipDeviceSynchronize();
   if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
+  if (g->dDeepBig) (void)hipFree(g->dDeepBig);
   g->dDeepSeed = nullptr;
+  g->dDeepBig = nullptr;
   g->deepSeedBytes = 0;
   g->dev.deepSeed = nullptr;
   g->dev.deepK = 0;
   g->dev.deepNarrow = 0;
+  g->dev.deepNext = 0;
+  g->dev.numDeepBig = 0;
+  g->dev.deepBigKeys = g->dev.deepBigLengths = nullptr;
   enum AwFmReturnCode rc = AwFmSuccess;
   if (deepK != 0) {
     void *table = nullptr;
     uint64_t bytes = 0;
     if (awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes)) {
-      g->dDeepSeed = table;
-      g->deepSeedBytes = bytes;
-      g->dev.deepSeed = (const ulonglong2 *)table;
-      g->dev.deepK = deepK;
-      g->dev.deepNarrow = g->dev.bwtLength < (1ull << 32) ? 1u : 0u;
+      void *big = nullptr;
+      unsigned numBig = 0;
+      const int next = awfmGpuDeepSeedAddNext(g, table, deepK, &big, &numBig); /* images with pair blocks, below 2^32 positions */
+      if (next < 0) {
+        (void)hipFree(table);
+        rc = AwFmGeneralFailure;
+      } else {
+        g->dDeepSeed = table;
+        g->dDeepBig = big;
+        g->deepSeedBytes = bytes + (uint64_t)numBig * 8u;
+        g->dev.deepSeed = (const ulonglong2 *)table;
+        g->dev.deepK = deepK;
+        g->dev.deepNarrow = g->dev.bwtLength < (1ull << 32) ? 1u : 0u;
+        g->dev.deepNext = next > 0 ? 1u : 0u;
+        g->dev.numDeepBig = numBig;
+        g->dev.deepBigKeys = (const unsigned *)big;
+        g->dev.deepBigLengths = (const unsigned *)big + numBig;
+      }
     } else {
       rc = AwFmGeneralFailure;
     }
@@ -759,6 +778,10 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
     lane->dev.deepSeed = g->dev.deepSeed;
     lane->dev.deepNarrow = g->dev.deepNarrow;
     lane->dev.deepK = g->dev.deepK;
+    lane->dev.deepNext = g->dev.deepNext;
+    lane->dev.numDeepBig = g->dev.numDeepBig;
+    lane->dev.deepBigKeys = g->dev.deepBigKeys;
+    lane->dev.deepBigLengths = g->dev.deepBigLengths;
   }
   return rc;
 }

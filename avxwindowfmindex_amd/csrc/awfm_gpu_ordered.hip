@@ -18,7 +18,8 @@
 namespace {
 
 inline size_t alignUp256(size_t v) { return (v + 255) / 256 * 256; }
-constexpr size_t kOrderCounterBytes = 32768; /* 256 B for the count + 8 XCDs x 8 waves x 256 B of ticket counters */
+constexpr size_t kOrderCounterBytes = 131072; /* 256 B for the count + 8 XCDs x kTicketGroups x 8 waves x 256 B of ticket counters */
+static_assert(256 + 8 * kTicketGroups * 8 * 256 <= kOrderCounterBytes, "ticket counters");
 
 struct OrderScratch {
   size_t keysIn, keysOut, recsIn, recsOut, generalCount, sortTemp, total;
@@ -187,6 +188,70 @@ static bool orderedApplies(const AwFmGpuIndex *g, bool hasOffsets, uint32_t fixe
 
 /* milliseconds orderedSearchKernel took in the last awfmGpuSearchHits on this image that ran with
  * $AWFM_GPU_TIME_ORDERED set (waits for it); negative when there is none */
+/* awfm_device.h.  Two passes over the finished table: the saturated lengths are counted (so that the side list is
+ * allocated exactly and the in-place rewrite cannot fail half-way), then deepNextKernel rewrites the entries. */
+int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **bigOut, unsigned *numBigOut) {
+  *bigOut = nullptr;
+  *numBigOut = 0;
+  if (!g || g->amino || !table || !g->dev.pairBlocks || g->dev.bwtLength >= (1ull << 32) || deepK == 0 || deepK > 16) return 0;
+  if (getenv("AWFM_GPU_DEEP_NEXT") && atoi(getenv("AWFM_GPU_DEEP_NEXT")) == 0) return 0; /* comparison runs */
+  DeviceGuard guard(g->device);
+  const unsigned long long numEntries = 1ull << (2u * deepK);
+  unsigned long long *dCursor = nullptr; /* cursor (8 bytes), number of saturated lengths (4 bytes) */
+  if (hipMalloc((void **)&dCursor, 16) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  unsigned *dNumBig = (unsigned *)(dCursor + 1);
+  bool ok = hipMemset(dCursor, 0, 16) == hipSuccess;
+  unsigned numBig = 0;
+  if (ok) {
+    hipLaunchKernelGGL(deepBigCountKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const uint2 *)table, numEntries, dNumBig);
+    ok = hipMemcpy(&numBig, dNumBig, 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemset(dNumBig, 0, 4) == hipSuccess;
+  }
+  unsigned *dBig = nullptr;
+  if (ok && numBig != 0) ok = hipMalloc((void **)&dBig, (size_t)numBig * 8u) == hipSuccess;
+  if (ok) {
+    const bool superInLds = awfmPairSuperInLds(g);
+    const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
+    DevIndex dev = g->dev;
+    dev.pairSuperInLds = superInLds ? 1u : 0u;
+    constexpr int threads = orderedThreads(true);
+    unsigned grid = residentGrid(g, deepNextKernel, lds, threads);
+    hipLaunchKernelGGL(deepNextKernel, dim3(grid ? grid : 1u), dim3(threads), lds, 0, dev, (uint2 *)table, numEntries, dCursor, dBig,
+                       dBig + numBig, dNumBig, numBig);
+    ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  }
+  if (ok && numBig != 0) { /* ascending entry numbers: the kernels look a length up by bisection */
+    unsigned *sorted = nullptr;
+    size_t tempBytes = 0;
+    void *temp = nullptr;
+    ok = hipMalloc((void **)&sorted, (size_t)numBig * 8u) == hipSuccess &&
+         rocprim::radix_sort_pairs(nullptr, tempBytes, dBig, sorted, dBig + numBig, sorted + numBig, numBig) == hipSuccess &&
+         hipMalloc(&temp, tempBytes ? tempBytes : 16) == hipSuccess &&
+         rocprim::radix_sort_pairs(temp, tempBytes, dBig, sorted, dBig + numBig, sorted + numBig, numBig) == hipSuccess &&
+         hipDeviceSynchronize() == hipSuccess;
+    if (temp) (void)hipFree(temp);
+    if (ok) {
+      (void)hipFree(dBig);
+      dBig = sorted;
+    } else if (sorted) {
+      (void)hipFree(sorted);
+    }
+  }
+  (void)hipFree(dCursor);
+  if (!ok) {
+    /* the table may have been rewritten in part: the caller must not use it */
+    (void)hipGetLastError();
+    if (dBig) (void)hipFree(dBig);
+    awfmGpuSetError("deep seed table: the pass that adds the next-step bits failed");
+    return -1;
+  }
+  *bigOut = dBig;
+  *numBigOut = numBig;
+  return 1;
+}
+
 extern "C" double awfmGpuLastOrderedKernelMs(AwFmGpuIndex *g) {
   if (!g) return -1.0;
   std::lock_guard<std::mutex> lock(g->orderMutex);
@@ -246,7 +311,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
                           const ulonglong2 *table, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed,
                           bool rangesOfHitsOnly, const OrderTouch *touch, const BucketFormat &fmt, const SparseOut *sparse) {
   const unsigned bins = (1u << fmt.bucketBits) + 1u, binsPad = (bins + 3u) & ~3u;
-  /* [counters 32 KB][hist -> sub-run starts: 8 shares x binsPad][cursors: 8 x binsPad][bucketStart: bins + 1]
+  /* [counters 128 KB][hist -> sub-run starts: 8 shares x binsPad][cursors: 8 x binsPad][bucketStart: bins + 1]
    * [codes: nq x 8 unless packed][records: nq x 8] */
   const size_t histAt = kOrderCounterBytes, cursorsAt = histAt + alignUp256((size_t)kShares * binsPad * 4u);
   const size_t startAt = cursorsAt + alignUp256((size_t)kShares * binsPad * 4u);

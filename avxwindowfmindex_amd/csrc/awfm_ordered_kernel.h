@@ -739,12 +739,14 @@ struct OrderTouch {
   unsigned long long *hits; /* k-mers that stored a result */
 };
 
+constexpr unsigned kTicketGroups = 4; /* ticket counters per XCD and wave slot */
 template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false>
-/* registers: 8 waves per SIMD (64 VGPRs) for the one-step variants; the mixed-length and the pair variants get 72 (7 waves); the bucketed
- * variant, which carries the next chunk's codes, query number and table entry as well, the 64-bit pair variants, the
- * instrumented variant and the wide two-lane measurement variant get 80 (6 waves).  Occupancy beyond 6 buys nothing here:
- * the bucketed kernel built for 7 waves (72 registers, 4 spilled) and for 6 measured the same (3.75-3.94 ms either way) */
-__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || TOUCH || BUCKET || (G == 2 && !NARROW) ? 6 : (VARLEN || PAIR ? 7 : 8)) : 2, 8)))
+/* registers: 8 waves per SIMD (64 VGPRs) for the one-step variants; the mixed-length, the pair and the bucketed variants get
+ * 72 (7 waves) -- the bucketed pair variant, which carries the next chunk's codes, query number and table entry as well,
+ * spills two registers there and is still the faster build since most k-mers of a batch without hits end at the deeper
+ * table (10^8 random 21-mers 2.31-2.38 against 2.57-2.59 ms with 80 registers and 6 waves; planted 5.17 against 5.25) --;
+ * the 64-bit pair variants, the instrumented variant and the wide two-lane measurement variant get 80 (6 waves). */
+__global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || TOUCH || (G == 2 && !NARROW) ? 6 : (VARLEN || PAIR || BUCKET ? 7 : 8)) : 2, 8)))
     orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
                         const unsigned long long numRecs,
                         const unsigned *__restrict__ generalCount, const unsigned len, const unsigned depth,
@@ -818,7 +820,6 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   const unsigned long long share = (covered + xcds - 1ull) / xcds;
   const unsigned long long begin = share * xcd;
   const unsigned long long end = begin + share < covered ? begin + share : covered;
-  (void)blockInXcd;
   /* The waves of an XCD take chunks of 64/G consecutive records from ticket counters instead of a fixed stride:
    * free-running waves drift apart, and with a fixed stride the records in flight on an XCD would then span
    * many more buckets than its L2 holds the blocks of (8.7 ms with the stride, 5.8 ms with tickets).  Wave w of
@@ -834,7 +835,10 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
    * against 4.41-4.45 ms on the same box, 9.2 against 9.1-9.4 ms planted.) */
   constexpr unsigned kWaves = orderedThreads(PAIR) / 64, kChunk = 64 / G;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  unsigned *ticket = tickets + (xcd * kWaves + wave) * 64u; /* 256 bytes apart */
+  /* kTicketGroups x kWaves counters per XCD: wave w of workgroup b draws from counter (b % kTicketGroups, w) */
+  constexpr unsigned kCounters = kTicketGroups * kWaves;
+  const unsigned counter = (blockInXcd % kTicketGroups) * kWaves + wave;
+  unsigned *ticket = tickets + (xcd * kCounters + counter) * 64u; /* 256 bytes apart */
   /* A ticket is worth chunksPerTicket consecutive chunks of the wave (one returning atomic on a counter that 48-64 waves
    * share, per ticket): the next ticket is drawn when the wave starts on the current one and read when that one is used
    * up, so the atomic has chunksPerTicket iterations to come back.  (One chunk per ticket: 52 atomics per microsecond and
@@ -842,7 +846,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
    * atomic had come back, and that round trip, not the k-mers' memory rounds, set the kernel's time: a build that cut
    * the search short after one or two pair steps was no faster.) */
   auto ticketBase = [&](unsigned t) -> unsigned long long {
-    return begin + ((unsigned long long)t * kWaves + wave) * chunksPerTicket * kChunk;
+    return begin + ((unsigned long long)t * kCounters + counter) * chunksPerTicket * kChunk;
   };
   unsigned drawn = 0;
   if (lane == 0) drawn = atomicAdd(ticket, 1u);
@@ -892,7 +896,22 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     }
     return mine;
   };
-  auto tableEntry = [&](unsigned long long at) -> ulonglong2 { return table == ix.deepSeed ? deepSeedEntry(ix, at) : table[at]; };
+  /* With the next-step bits of the deeper table (DevIndex::deepNext) a k-mer whose first pair step would empty the range
+   * ends at the table, without the block read (fixed-length batches with a pair step to come; only hits are reported):
+   * 10^8 random 21-mers, depth 16: 8.1 instead of 25 million distinct pair-block lines, 2.55-2.70 against 2.9-3.0 ms.
+   * (Taking the entry apart where it is used instead of where it is loaded: 2.86 ms.) */
+  const bool rawEntries = NARROW && table == ix.deepSeed && ix.deepNarrow != 0u; /* uniform (narrow entries: narrow images) */
+  const bool dropByNext = PAIR && !VARLEN && rawEntries && ix.deepNext != 0u && len >= depth + 2u;
+  auto tableEntry = [&](unsigned long long codes) -> ulonglong2 {
+    const unsigned long long at = codes & tableMask;
+    if (rawEntries) {
+      unsigned next16;
+      ulonglong2 r = deepSeedOpen(ix, at, ((const uint2 *)ix.deepSeed)[at], &next16);
+      if (dropByNext && ((next16 >> ((unsigned)(codes >> (2u * depth)) & 15u)) & 1u) == 0u) r = make_ulonglong2(1ull, 0ull);
+      return r;
+    }
+    return table == ix.deepSeed ? deepSeedEntry(ix, at) : table[at];
+  };
   auto touchTable = [&](unsigned long long at) {
     if (TOUCH) markLine(table == ix.seed ? touch.seedLines : touch.deepLines, at >> (table == ix.deepSeed && ix.deepNarrow ? 4 : 3));
   };
@@ -903,7 +922,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
    * `raw` then holds the record of the chunk after `base`. */
   unsigned long long codesCur = 0, baseNext2 = 0;
   unsigned indexCur = 0;
-  ulonglong2 entryCur = make_ulonglong2(1ull, 0ull);
+  pos_t entrySpCur = 1, entryEpCur = 0; /* the next chunk's table entry, in position width */
   if (AHEAD) {
     baseNext2 = nextChunk();
     if (base < end) {
@@ -911,7 +930,9 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       codesCur = bucketCodes(bucketFmt, mine, raw.a >> bucketFmt.indexBits);
       indexCur = (unsigned)(raw.a & ((1ull << bucketFmt.indexBits) - 1ull));
       if (base + lane / G < end) {
-        entryCur = tableEntry(codesCur & tableMask);
+        const ulonglong2 r = tableEntry(codesCur);
+        entrySpCur = (pos_t)r.x;
+        entryEpCur = (pos_t)r.y;
         touchTable(codesCur & tableMask);
       }
     }
@@ -925,23 +946,27 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     unsigned long long rem;
     unsigned long long codes;
     unsigned index;
-    ulonglong2 entry = make_ulonglong2(1ull, 0ull);
+    pos_t entrySp = 1, entryEp = 0;
     if (AHEAD) {
       /* this chunk: taken apart an iteration ago, its entry requested then */
       codes = codesCur;
       index = indexCur;
-      entry = entryCur;
-      asm volatile("" : "+v"(entry.x), "+v"(entry.y));
+      entrySp = entrySpCur;
+      entryEp = entryEpCur;
+      asm volatile("" : "+v"(entrySp), "+v"(entryEp));
       /* the next chunk: its record (requested an iteration ago) is taken apart, its table entry and the record of the
        * chunk after it are requested */
-      entryCur = make_ulonglong2(1ull, 0ull);
+      entrySpCur = 1;
+      entryEpCur = 0;
       if (baseNext < end) { /* wave-uniform */
         const unsigned mine = laneBucket(baseNext);
         asm volatile("" : "+v"(raw.a)::"memory");
         codesCur = bucketCodes(bucketFmt, mine, raw.a >> bucketFmt.indexBits);
         indexCur = (unsigned)(raw.a & ((1ull << bucketFmt.indexBits) - 1ull));
         if (baseNext + lane / G < end) {
-          entryCur = tableEntry(codesCur & tableMask);
+          const ulonglong2 r = tableEntry(codesCur);
+          entrySpCur = (pos_t)r.x;
+          entryEpCur = (pos_t)r.y;
           touchTable(codesCur & tableMask);
         }
       }
@@ -962,7 +987,9 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     /* fixed length: the table entry is requested FIRST, so that the wait for it (loads return in order) is not also a
      * wait for the ticket atomic and the record prefetch issued below */
     if (!VARLEN && live) {
-      entry = tableEntry(codes & tableMask);
+      const ulonglong2 r = tableEntry(codes);
+      entrySp = (pos_t)r.x;
+      entryEp = (pos_t)r.y;
       touchTable(codes & tableMask);
     }
     /* fetch the next chunk's record */
@@ -970,8 +997,8 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     }
     if (!VARLEN) {
       if (live) {
-        sp = (pos_t)entry.x;
-        ep = (pos_t)entry.y;
+        sp = entrySp;
+        ep = entryEp;
         pos = (int)(len - depth) - 1;
       }
       rem = codes >> (2u * depth); /* code of character `pos` in bits 1..0 */
@@ -1061,6 +1088,74 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       baseNext = nextChunk();
     }
   }
+}
+
+
+/* ---- the "next pair step" bits of the deeper table (DevIndex::deepNext) ----
+ * One group of 4 lanes per entry {sp, length} with length > 0: the 16 pair steps the search kernel could take from that
+ * range -- the same device functions, flagged blocks through the one-letter image as there -- and bit c of next16 set
+ * when the range after step c still holds a position.  Entries whose length does not fit 16 bits go to the side list
+ * (appended; sorted by the caller).  Persistent grid, entries dealt by a counter in chunks of 16 per wave. */
+__global__ void __launch_bounds__(orderedThreads(true)) __attribute__((amdgpu_num_sgpr(80)))
+    deepNextKernel(const DevIndex ix, uint2 *__restrict__ table, const unsigned long long numEntries,
+                   unsigned long long *__restrict__ cursor, unsigned *__restrict__ bigKeys, unsigned *__restrict__ bigLengths,
+                   unsigned *__restrict__ numBig, const unsigned bigCapacity) {
+  constexpr int G = 4;
+  constexpr int S = (int)kSlices / G;
+  __shared__ unsigned long long sC[24];
+  __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
+  __shared__ unsigned long long sSuper[1];
+  __shared__ unsigned long long sPairC[16];
+  extern __shared__ unsigned sPairSuper[];
+  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  stageMaskTable(sMask);
+  nucStageSuper<true>(ix, sSuper);
+  pairStageTables<true, 16u>(ix, sPairC, sPairSuper);
+  __syncthreads();
+  const unsigned gl = threadIdx.x % G, lane = threadIdx.x & 63u;
+  const unsigned firstSlice = gl * S;
+  constexpr unsigned long long kChunk = 64 / G;
+  for (;;) {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(cursor, kChunk);
+    base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+    if (base >= numEntries) break;
+    const unsigned long long at = base + lane / G;
+    const uint2 e = at < numEntries ? table[at] : make_uint2(1u, 0u);
+    if (e.y != 0u) { /* (0: no such deepK-mer, and {sp, 0} is {sp, 0 | 0 << 16} already) whole groups of 4 lanes */
+      unsigned next16 = 0;
+      for (unsigned code = 0; code < 16u; code++) {
+        PositionType<true>::type sp = e.x, ep = e.x + e.y - 1u;
+        if (pairSearchStep<true>(ix, sPairC, sPairSuper, sMask, gl, code, sp, ep) == kPairFlagged) {
+          nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, code & 3u, sp, ep);
+          if (sp <= ep) nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, code >> 2, sp, ep);
+        }
+        if (sp <= ep) next16 |= 1u << code;
+      }
+      if (gl == 0) {
+        if (e.y >= 0xFFFFu) {
+          const unsigned slot = atomicAdd(numBig, 1u);
+          if (slot < bigCapacity) {
+            bigKeys[slot] = (unsigned)at;
+            bigLengths[slot] = e.y;
+          }
+        }
+        table[at] = make_uint2(e.x, (e.y < 0xFFFFu ? e.y : 0xFFFFu) | next16 << 16);
+      }
+    }
+  }
+}
+
+/* how many entries of a narrow table have a length that does not fit 16 bits */
+__global__ void __launch_bounds__(256) deepBigCountKernel(const uint2 *__restrict__ table, const unsigned long long numEntries,
+                                                          unsigned *__restrict__ numBig) {
+  unsigned mine = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < numEntries;
+       i += (unsigned long long)gridDim.x * blockDim.x)
+    mine += table[i].y >= 0xFFFFu;
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(numBig, mine);
 }
 
 }  // namespace

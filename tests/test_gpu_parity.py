@@ -193,6 +193,50 @@ def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, requir
     ix.dealloc()
 
 
+@pytest.mark.parametrize("pair", ["1", "0"])
+def test_deep_seed_table_next_step_bits_and_long_ranges(oracle, awfm, require_gpu, monkeypatch, pair):
+    """On images with pair blocks the 8-byte entries of the deeper table are {sp, length16 | next16 << 16}: the lengths
+    that do not fit (a tandem repeat: six 5-mers with 120 000 occurrences each) come from the side list, and the seed-order
+    search drops k-mers by the next-step bits.  General kernels (exact ranges), the seed-order search (hits) and the
+    positions against the oracle; without pair blocks ($AWFM_GPU_PAIR=0) the entries stay {sp, length}."""
+    import torch
+    monkeypatch.setenv("AWFM_GPU_PAIR", pair)
+    unit = np.frombuffer(b"acgtta", dtype=np.uint8)
+    txt = np.concatenate([np.tile(unit, 120000), synth.text(501, 200000)]).copy()
+    txt[720100:720104] = ord("n")
+    seed_k, deep_k = 3, 5
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, seed_k)
+    oi = oracle.Index.wrap(oracle.DNA, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    before = g.device_bytes
+    g.set_deep_seed(deep_k)
+    long_ranges = 6 if pair == "1" else 0   # the six 5-mers of the repeat
+    assert g.device_bytes == before + 8 * 4 ** deep_k + 8 * long_ranges
+    # mixed lengths through the general kernels: exact ranges, k-mers shorter than the table included
+    chars, offsets = _mixed_queries(502, 4000, txt, synth.DNA_ALPHABET, 1, 30, ambiguity=ord("x"), upper=True)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    ranges, counts = g.count_host(chars, offsets)
+    assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep) and np.array_equal(counts, cnt)
+    # fixed lengths through the seed-order search: 7 = table + one pair step, 8 = + a single step, 12, 5 = the table alone
+    g.set_ordered(1)
+    dev = torch.device("cuda")
+    for K in (7, 8, 12, 5, 6):
+        Q = 20011
+        q = np.concatenate([synth.random_queries(503 + K, Q // 2, K), synth.planted_queries(504 + K, Q - Q // 2, K, txt)]).copy()
+        chars, offsets = synth.fixed_csr(q)
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+        assert (cnt > 65535).any() or K > 8
+        d_chars = torch.from_numpy(chars).to(dev)
+        d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
+        d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+        g.search_hits(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+        torch.cuda.synchronize()
+        _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2), d_counts.cpu().numpy().view(np.uint32), sp, ep, cnt)
+    g.destroy()
+    ix.dealloc()
+
+
 @pytest.mark.parametrize("alphabet_name,ratio", [("dna", 8), ("dna", 255), ("amino", 5)])
 def test_device_dense_sa_keeps_positions_bit_identical(oracle, awfm, require_gpu, wide, alphabet_name, ratio):
     amino = alphabet_name == "amino"

@@ -66,15 +66,18 @@ def test_ordered_search_kernels_keep_full_occupancy(kernel_metadata):
     for variant, bucket in (("Lb1ELb1ELb0E", "Lb1E"), ("Lb1ELb0ELb0E", "Lb0E"), ("Lb1ELb0ELb1E", "Lb0E")):
         for pair in ("Lb0E", "Lb1E"):
             k = _one(kernel_metadata, r"orderedSearchKernelILi4E" + variant + pair + "Lb0E" + bucket + "E")
-            # the bucketed variant holds the next chunk's codes and table entry as well: 80 registers (6 waves per SIMD,
-            # which is what the pair tables in LDS leave a GRCh38-sized image anyway)
-            # bucketed: 6 waves per SIMD; mixed-length and pair variants: 7; the others 8
-            limit = 80 if bucket == "Lb1E" else (72 if (variant.endswith("Lb1E") or pair == "Lb1E") else 64)
-            assert k["vgpr"] <= limit and k["spill"] == 0 and k["scratch"] == 0, variant + pair
+            # mixed-length, pair and bucketed variants: 7 waves per SIMD (72 registers); the others 8.  The bucketed pair
+            # variant holds the next chunk's codes and table entry as well and may spill two registers (measured faster
+            # than the spill-free build at 80 registers and 6 waves: awfm_ordered_kernel.h)
+            limit = 72 if (bucket == "Lb1E" or variant.endswith("Lb1E") or pair == "Lb1E") else 64
+            spills = 2 if (bucket == "Lb1E" and pair == "Lb1E") else 0
+            assert k["vgpr"] <= limit and k["spill"] <= spills and k["scratch"] <= 8 * spills, variant + pair
             assert k["lds"] <= 16 * 1024  # static; the pair variant adds 64 B per 2^23 positions of dynamic LDS
 
 
 def test_no_search_or_walk_variant_uses_scratch(kernel_metadata):
+    bucketed_pair = r"orderedSearchKernelILi4ELb1ELb1ELb0ELb1ELb0ELb1EE"  # two spilled registers by choice (see above)
     bad = {n: v for n, v in kernel_metadata.items()
-           if ("searchKernel" in n or "walkKernel" in n or "orderedSearchKernel" in n) and v["scratch"]}
+           if ("searchKernel" in n or "walkKernel" in n or "orderedSearchKernel" in n) and v["scratch"]
+           and not re.search(bucketed_pair, n)}
     assert not bad, bad
