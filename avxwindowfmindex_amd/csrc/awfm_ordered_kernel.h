@@ -56,6 +56,20 @@ __device__ __forceinline__ void decodeWord(unsigned word, unsigned &packed, unsi
   packed = ((t & 3u) << 6) | ((t >> 4) & 0x30u) | ((t >> 14) & 0x0Cu) | (t >> 24);
 }
 
+/* The same for a kernel that only asks whether ANY character of a k-mer is not a,c,g,t,u: the expected letters come from
+ * one byte permute ('a','c','g','t' selected by the codes), and the differences of the characters that count
+ * (`countMask`: 0xFF per character of the k-mer in this word) are OR-ed into `diffs` as they are.  decodeWord: 35 VALU
+ * instructions per word, this: 19 -- encodeCodes4Kernel was bound by its VALU instructions (94 % of its cycles), not by its
+ * 2.9 GB. */
+__device__ __forceinline__ void decodeWordAny(unsigned word, unsigned countMask, unsigned &packed, unsigned &diffs) {
+  unsigned t = (word >> 1) & 0x03030303u;
+  t ^= (t >> 1) & 0x01010101u;
+  const unsigned b01 = t & (t >> 1) & 0x01010101u;                   /* code 3: 't' or 'u' (they differ in bit 0) */
+  const unsigned expect = __builtin_amdgcn_perm(0u, 0x74676361u, t); /* byte i = "acgt"[code i] */
+  diffs |= ((word | 0x20202020u) ^ expect) & ~b01 & countMask;
+  packed = ((t & 3u) << 6) | ((t >> 4) & 0x30u) | ((t >> 14) & 0x0Cu) | (t >> 24);
+}
+
 /*
  * Sort key and record.  The key is the leading keyBits = min(15, 2*depth) bits of the table index (the low
  * 2*depth bits of the code string), left-aligned in 15 bits.  A 16-byte QueryRec carries the whole code string.
@@ -357,17 +371,16 @@ __global__ void __launch_bounds__(256)
         unsigned b = 0;
 #pragma unroll
         for (unsigned w = 0; w < 8u; w++) {
-          unsigned packed = 0, badBits = 0;
+          unsigned packed = 0;
           if (w < kWords) {
             const unsigned lo = al[(at >> 2) + w], hi = (at >> 2) + w + 1u <= K ? al[(at >> 2) + w + 1u] : 0u;
-            decodeWord(__builtin_amdgcn_alignbyte(hi, lo, at & 3u), packed, badBits);
+            const unsigned inKmer = K - 4u * w >= 4u ? 4u : K - 4u * w; /* characters of the k-mer in this word */
+            decodeWordAny(__builtin_amdgcn_alignbyte(hi, lo, at & 3u), inKmer >= 4u ? ~0u : (1u << (8u * inKmer)) - 1u, packed, b);
           }
           c = (c << 8) | packed;
-          b |= badBits << (4u * w);
         }
         codes[i] = c >> (2u * (32u - K));
-        constexpr unsigned kLenMask = K >= 32u ? ~0u : ((1u << (K & 31u)) - 1u);
-        bad[i] = b & kLenMask;
+        bad[i] = b;
       }
     } else {
 #pragma unroll
@@ -899,7 +912,10 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   /* With the next-step bits of the deeper table (DevIndex::deepNext) a k-mer whose first pair step would empty the range
    * ends at the table, without the block read (fixed-length batches with a pair step to come; only hits are reported):
    * 10^8 random 21-mers, depth 16: 8.1 instead of 25 million distinct pair-block lines, 2.55-2.70 against 2.9-3.0 ms.
-   * (Taking the entry apart where it is used instead of where it is loaded: 2.86 ms.) */
+   * (Taking the entry apart where it is used instead of where it is loaded: 2.86 ms.  With the bits the kernel reads
+   * 13.5 GB in 2.34 ms = 5.8 TB/s of random 128-byte lines, 10.7 GB of them table lines: a variant that gave every LANE a
+   * record and a table entry -- 64 lookups per wave instruction -- and handed the k-mers still alive to the groups of 4
+   * lanes, 16 per round (ds_permute / ds_bpermute), measured 2.44 ms, and 5.99 against 5.22 ms on planted k-mers.) */
   const bool rawEntries = NARROW && table == ix.deepSeed && ix.deepNarrow != 0u; /* uniform (narrow entries: narrow images) */
   const bool dropByNext = PAIR && !VARLEN && rawEntries && ix.deepNext != 0u && len >= depth + 2u;
   auto tableEntry = [&](unsigned long long codes) -> ulonglong2 {
@@ -1009,7 +1025,18 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       if (live) {
         if (myDepth != 0u) {
           const unsigned long long at = codes & ((1ull << (2u * myDepth)) - 1ull);
-          const ulonglong2 r = myDepth == ix.seedK ? ix.seed[at] : deepSeedEntry(ix, at);
+          ulonglong2 r;
+          if (myDepth == ix.seedK) {
+            r = ix.seed[at];
+          } else if (NARROW && ix.deepNarrow != 0u) {
+            unsigned next16;
+            r = deepSeedOpen(ix, at, ((const uint2 *)ix.deepSeed)[at], &next16);
+            /* the first step from the deeper table is a pair step (below): a clear bit ends the k-mer here */
+            if (PAIR && ix.deepNext != 0u && myLen >= myDepth + 2u && ((next16 >> ((unsigned)(codes >> (2u * myDepth)) & 15u)) & 1u) == 0u)
+              r = make_ulonglong2(1ull, 0ull);
+          } else {
+            r = deepSeedEntry(ix, at);
+          }
           if (TOUCH) markLine(myDepth == ix.seedK ? touch.seedLines : touch.deepLines, at >> (myDepth != ix.seedK && ix.deepNarrow ? 4 : 3));
           sp = (pos_t)r.x;
           ep = (pos_t)r.y;
@@ -1028,14 +1055,8 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     const int lastPos = (int)myLen - 1; /* TOUCH: level of a step = lastPos - pos = characters consumed before it */
     if (PAIR) {
       /* two characters per block read.  Only hits are reported, so it does not matter at which of the two steps a
-       * range without hits became empty.  An odd step is taken alone: first in a mixed-length batch (one divergent
-       * round), last in a fixed-length one (where it is wave-uniform and few k-mers are still alive). */
-      if (VARLEN && pos >= 0 && sp <= ep && (pos & 1) == 0) {
-        touchNuc((unsigned)(lastPos - pos), sp, ep);
-        nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
-        pos--;
-        rem >>= 2;
-      }
+       * range without hits became empty.  An odd step is taken alone and last: few k-mers are still alive then, and the
+       * first step from the deeper table is the pair step its next-step bits speak about. */
       while (pos >= 1 && sp <= ep) {
         const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
         touchPair((unsigned)(lastPos - pos), sp, ep);
@@ -1051,7 +1072,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
         pos -= 2;
         rem >>= 4;
       }
-      if (!VARLEN && pos == 0 && sp <= ep) {
+      if (pos == 0 && sp <= ep) {
         touchNuc((unsigned)(lastPos - pos), sp, ep);
         nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
         pos--;

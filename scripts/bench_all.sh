@@ -22,6 +22,8 @@ run general AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 -- --mode count --no-cpu -
 run general_letters AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 AWFM_GPU_GENERAL_NO_PAIR=1 -- --mode count --no-cpu --no-e2e
 run dense_results AWFM_BENCH_DENSE_RESULTS=1 -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run no_deep_table -- --device-seed-k 0 --no-cpu --no-e2e --no-secondary --general-steps 0
+run deep_table_14 -- --device-seed-k 14 --no-cpu --no-e2e --no-secondary --general-steps 0
+run no_next_bits AWFM_GPU_DEEP_NEXT=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run rocprim_sort AWFM_GPU_ORDERED_SORT=rocprim -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run mixed_rocprim_sort AWFM_GPU_ORDERED_SORT=rocprim -- --workload mixed --no-cpu --no-e2e --general-steps 0
 run nopair_default AWFM_GPU_PAIR=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
