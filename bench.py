@@ -662,9 +662,9 @@ def main():
         prof_name = None  # a measurement knob is set: the profiled run was of the default code path
     not_this_run = "rocprofv3 PMC passes of this command line on another run of the same code (scripts/profile_bench.sh), not measured by this run"
     if ordered:
-        # The search of a large batch is several launches (k-mer encoding, key sort, orderedSearchKernel).  The
-        # dominant kernel serves most block reads out of the L2, so the reference algorithm's bytes are not what it
-        # has to move: its roofline is its COMPULSORY traffic -- every 128-B line once per search level that needs
+        # The search of a large batch is several launches (k-mer encoding + bucket count, partition, orderedSearchKernel).
+        # The dominant kernel starts from a deeper table and serves repeated block reads out of the L2, so the reference
+        # algorithm's bytes are not what it has to move: its roofline is its COMPULSORY traffic -- every 128-B line once per search level that needs
         # it, the sorted records, the results -- over its own HIP-event time.
         lines = g.search_hits_line_tally(d_chars.data_ptr(), off_ptr, K, Q)
         stored = lines["kmers_with_hits"] * ((16 if args.mode == "locate" else 0) + (4 if (args.mode == "count" or (narrow_counts and state["sparse"])) else 0))
@@ -680,8 +680,9 @@ def main():
                                    "instrumented launch of the same kernel on the same sorted batch (awfmGpuSearchHitsLineTally), "
                                    "x 128 B, + sorted records and keys read + results stored",
                            **lines, "result_bytes_stored": int(stored)},
-            "limiter": "L2 request path and miss latency, not HBM bandwidth: see `l2` (requests the kernel sends to the "
-                       "L2s against the guide's L2-served gather rate) and dominant_kernel.wave_wait_frac",
+            "limiter": "HBM, as a gather of random 128-B lines (the guide measures 5.5-5.8 TB/s for such reads, 0.69-0.73 of the "
+                       "peak): most lines are entries of the deeper seed table, one per k-mer; see hbm_frac_measured for this "
+                       "kernel's measured traffic and `l2` for the requests it sends to the L2s",
         }
         counters, csrc = profile_file("counters", prof_name) if prof_name else (None, None)
         traffic, tsrc = profile_file("traffic", prof_name) if prof_name else (None, None)
@@ -709,7 +710,9 @@ def main():
         # the whole call, priced by what the REFERENCE algorithm would move for this batch: a throughput figure in bytes,
         # not a roofline fraction (five sixths of those bytes never leave the L2)
         roofline["call"] = {
-            "kernels": "awfmGpuSearchHits: fillNoHitKernel + encodeQueriesKernel + rocprim radix sort (16-bit key) + orderedSearchKernel",
+            "kernels": "awfmGpuSearchHits*: fill / memset + encodeCodes4Kernel (count) + bucketScanSharesKernel + partitionKernel + "
+                       "orderedSearchKernel (fixed lengths with 8-byte records; 16-byte records: encodeRecordsKernel + "
+                       "partitionRecordsKernel)",
             "ms": round(search_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes), "per_query": per_query,
             "unordered_equivalent_GBs": round(alg_bytes / (search_ms * 1e-3) / 1e9, 1),
             "unordered_equivalent_upper_bound_variant_GBs": round(upper_bytes / (search_ms * 1e-3) / 1e9, 1),
