@@ -51,6 +51,8 @@ def parse():
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", choices=["random", "planted", "mixed"], default="random")
+    p.add_argument("--mixed-lengths", type=int, nargs=2, default=[8, 30], metavar=("LO", "HI"),
+                   help="--workload mixed: the k-mer lengths (configs[4]: 8 30)")
     p.add_argument("--mode", choices=["locate", "count"], default=None,
                    help="default: locate (mixed lengths: count; --workload mixed --mode locate is 2 M k-mers located in windows)")
     p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
@@ -344,7 +346,7 @@ def main():
         batch_total = args.queries
         if args.workload == "mixed" and world > 1:
             d_all = torch.empty(batch_total, dtype=torch.int64, device=dev)
-            assert L.awfmGpuSynthMixedLengths(d_all.data_ptr(), args.query_offset, batch_total, 8, 30, query_seed, None) == 1
+            assert L.awfmGpuSynthMixedLengths(d_all.data_ptr(), args.query_offset, batch_total, args.mixed_lengths[0], args.mixed_lengths[1], query_seed, None) == 1
             prefix = torch.zeros(batch_total + 1, dtype=torch.int64, device=dev)
             torch.cumsum(d_all, 0, out=prefix[1:])
             begin, end = shard.balanced_bounds(prefix, world, rank)
@@ -356,7 +358,7 @@ def main():
     d_offsets = None  # CSR offsets (mixed lengths only); fixed-length batches pass the length instead
     if args.workload == "mixed":
         d_len = torch.empty(Q, dtype=torch.int64, device=dev)
-        assert L.awfmGpuSynthMixedLengths(d_len.data_ptr(), first, Q, 8, 30, query_seed, None) == 1
+        assert L.awfmGpuSynthMixedLengths(d_len.data_ptr(), first, Q, args.mixed_lengths[0], args.mixed_lengths[1], query_seed, None) == 1
         d_offsets = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
         torch.cumsum(d_len, 0, out=d_offsets[1:])
         total_chars = int(d_offsets[-1].item())
@@ -613,7 +615,7 @@ def main():
         np.savez(os.path.join(args.dump_dir, f"rank{rank}.npz"), **dump)
 
     # ---- digests of this rank's results; rank 0 checks all ranks' against the committed digests of the 1-rank run ----
-    kmer_name = "8-30" if args.workload == "mixed" else str(K)
+    kmer_name = f"{args.mixed_lengths[0]}-{args.mixed_lengths[1]}" if args.workload == "mixed" else str(K)
 
     def describe(f, c):
         return digest.key(args.alphabet + ("" if args.text == "uniform" else "-" + args.text), args.workload, args.mode, n,
@@ -643,7 +645,7 @@ def main():
         os.makedirs(os.path.dirname(os.path.abspath(args.record_digests)), exist_ok=True)
         json.dump(known, open(args.record_digests, "w"), indent=1, sort_keys=True)
 
-    kdesc = "8..30-mers" if args.workload == "mixed" else f"{K}-mers"
+    kdesc = f"{args.mixed_lengths[0]}..{args.mixed_lengths[1]}-mers" if args.workload == "mixed" else f"{K}-mers"
     # ---- roofline of the dominant kernel ----
     tally = g.search_tally(d_chars.data_ptr(), off_ptr, K, Q)
     rank_bytes = RANK_BYTES_AMINO if amino else RANK_BYTES_DNA

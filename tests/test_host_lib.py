@@ -262,3 +262,55 @@ def test_pack_kmers_layout_and_rejections(awfm):
         awfm.pack_kmers(np.full((1, 33), ord("a"), np.uint8))
     with pytest.raises(ValueError):
         awfm.pack_kmers(np.full((1, 13), ord("a"), np.uint8), awfm.AwFmAlphabetAmino)
+
+
+def test_parallel_for_ranges_pool_and_concurrent_callers(awfm):
+    """awfmParallelFor (awfm_threads.c): the ranges of a loop depend on (numThreads, n) alone -- the AoS packing pairs two
+    loops by range number --, they tile [0, n), every range runs once, and the kept workers serve loops of different widths
+    one after another; a second caller that finds the pool taken runs its loop on threads of its own."""
+    import threading
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    RANGE = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint)
+    L.awfmParallelFor.argtypes = [C.c_uint, C.c_uint64, RANGE, C.c_void_p]
+    L.awfmParallelFor.restype = None
+
+    def run(threads, n):
+        seen, lock = [], threading.Lock()
+
+        def body(_ctx, begin, end, tid):
+            with lock:
+                seen.append((tid, begin, end))
+        cb = RANGE(body)
+        L.awfmParallelFor(threads, n, cb, None)
+        return sorted(seen)
+
+    for threads, n in ((8, 100000), (3, 4096), (8, 100001), (32, 70001), (5, 100000), (8, 100000), (64, 5000), (1, 9999)):
+        got = run(threads, n)
+        if threads == 1:
+            assert got == [(0, 0, n)]
+            continue
+        chunk = (n + min(threads, 64) - 1) // min(threads, 64)
+        want = [(t, t * chunk, min(n, (t + 1) * chunk)) for t in range(min(threads, 64)) if t * chunk < n]
+        assert got == want, (threads, n)
+    assert run(8, 100) == [(0, 0, 100)]  # short loops run on the caller
+    # two callers at once: both loops complete with their own ranges
+    results = {}
+
+    def caller(name, threads, n):
+        results[name] = run(threads, n)
+    ts = [threading.Thread(target=caller, args=(i, 4 + i, 50000 + i)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in range(4):
+        threads, n = 4 + i, 50000 + i
+        chunk = (n + threads - 1) // threads
+        assert results[i] == [(t, t * chunk, min(n, (t + 1) * chunk)) for t in range(threads) if t * chunk < n]
+    # a forked child starts over with an empty pool
+    pid = os.fork()
+    if pid == 0:
+        ok = run(6, 60000) == [(t, t * 10000, (t + 1) * 10000) for t in range(6)]
+        os._exit(0 if ok else 1)
+    assert os.waitpid(pid, 0)[1] == 0
