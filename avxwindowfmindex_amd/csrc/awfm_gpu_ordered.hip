@@ -197,13 +197,12 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **
   if (getenv("AWFM_GPU_DEEP_NEXT") && atoi(getenv("AWFM_GPU_DEEP_NEXT")) == 0) return 0; /* comparison runs */
   DeviceGuard guard(g->device);
   const unsigned long long numEntries = 1ull << (2u * deepK);
-  unsigned long long *dCursor = nullptr; /* cursor (8 bytes), number of saturated lengths (4 bytes) */
-  if (hipMalloc((void **)&dCursor, 16) != hipSuccess) {
+  unsigned *dNumBig = nullptr; /* number of saturated lengths */
+  if (hipMalloc((void **)&dNumBig, 16) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
-  unsigned *dNumBig = (unsigned *)(dCursor + 1);
-  bool ok = hipMemset(dCursor, 0, 16) == hipSuccess;
+  bool ok = hipMemset(dNumBig, 0, 16) == hipSuccess;
   unsigned numBig = 0;
   if (ok) {
     hipLaunchKernelGGL(deepBigCountKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const uint2 *)table, numEntries, dNumBig);
@@ -218,7 +217,7 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **
     dev.pairSuperInLds = superInLds ? 1u : 0u;
     constexpr int threads = orderedThreads(true);
     unsigned grid = residentGrid(g, deepNextKernel, lds, threads);
-    hipLaunchKernelGGL(deepNextKernel, dim3(grid ? grid : 1u), dim3(threads), lds, 0, dev, (uint2 *)table, numEntries, dCursor, dBig,
+    hipLaunchKernelGGL(deepNextKernel, dim3(grid ? grid : 1u), dim3(threads), lds, 0, dev, (uint2 *)table, numEntries, dBig,
                        dBig + numBig, dNumBig, numBig);
     ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
   }
@@ -239,7 +238,7 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **
       (void)hipFree(sorted);
     }
   }
-  (void)hipFree(dCursor);
+  (void)hipFree(dNumBig);
   if (!ok) {
     /* the table may have been rewritten in part: the caller must not use it */
     (void)hipGetLastError();

@@ -390,10 +390,15 @@ __global__ void __launch_bounds__(256)
         if (t + i < numQueries) decodeKmer(chars, (t + i) * K, K, codes[i], bad[i]);
       }
     }
+    if (t + 3ull < last) { /* the four code words are 32 consecutive bytes at a 32-byte boundary: two 16-byte stores */
+      ulonglong2 *out = (ulonglong2 *)(codesOut + t);
+      out[0] = make_ulonglong2(bad[0] ? kCodeGeneral : codes[0], bad[1] ? kCodeGeneral : codes[1]);
+      out[1] = make_ulonglong2(bad[2] ? kCodeGeneral : codes[2], bad[3] ? kCodeGeneral : codes[3]);
+    }
 #pragma unroll
     for (unsigned i = 0; i < 4u; i++) {
       if (t + i < last) {
-        codesOut[t + i] = bad[i] ? kCodeGeneral : codes[i];
+        if (t + 3ull >= last) codesOut[t + i] = bad[i] ? kCodeGeneral : codes[i];
         atomicAdd(&sHist[bad[i] ? bins - 1u : bucketOf(f, codes[i])], 1u);
       }
     }
@@ -1116,10 +1121,10 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
  * One group of 4 lanes per entry {sp, length} with length > 0: the 16 pair steps the search kernel could take from that
  * range -- the same device functions, flagged blocks through the one-letter image as there -- and bit c of next16 set
  * when the range after step c still holds a position.  Entries whose length does not fit 16 bits go to the side list
- * (appended; sorted by the caller).  Persistent grid, entries dealt by a counter in chunks of 16 per wave. */
+ * (appended; sorted by the caller).  Persistent grid, chunks of 16 entries per wave at a fixed stride. */
 __global__ void __launch_bounds__(orderedThreads(true)) __attribute__((amdgpu_num_sgpr(80)))
     deepNextKernel(const DevIndex ix, uint2 *__restrict__ table, const unsigned long long numEntries,
-                   unsigned long long *__restrict__ cursor, unsigned *__restrict__ bigKeys, unsigned *__restrict__ bigLengths,
+                   unsigned *__restrict__ bigKeys, unsigned *__restrict__ bigLengths,
                    unsigned *__restrict__ numBig, const unsigned bigCapacity) {
   constexpr int G = 4;
   constexpr int S = (int)kSlices / G;
@@ -1136,12 +1141,11 @@ __global__ void __launch_bounds__(orderedThreads(true)) __attribute__((amdgpu_nu
   const unsigned gl = threadIdx.x % G, lane = threadIdx.x & 63u;
   const unsigned firstSlice = gl * S;
   constexpr unsigned long long kChunk = 64 / G;
-  for (;;) {
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(cursor, kChunk);
-    base = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-           (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-    if (base >= numEntries) break;
+  /* waves take chunks of 16 entries at a fixed stride (a shared cursor -- 2.7 * 10^8 atomics on one word for a depth-16
+   * table -- took 3.2 s at the 88 atomics per microsecond a word serves) */
+  const unsigned long long waveStride = (unsigned long long)gridDim.x * (blockDim.x / 64u) * kChunk;
+  for (unsigned long long base = ((unsigned long long)blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u) * kChunk; base < numEntries;
+       base += waveStride) {
     const unsigned long long at = base + lane / G;
     const uint2 e = at < numEntries ? table[at] : make_uint2(1u, 0u);
     if (e.y != 0u) { /* (0: no such deepK-mer, and {sp, 0} is {sp, 0 | 0 << 16} already) whole groups of 4 lanes */
