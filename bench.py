@@ -692,7 +692,12 @@ def main():
             roofline["traffic"] = int(counters["hbm_read_bytes"] + counters.get("hbm_write_bytes", 0.0))
             roofline["traffic_source"] = f"{csrc}: {not_this_run}; reads = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM), writes = WRITE_SIZE"
             roofline["traffic_over_compulsory"] = round(roofline["traffic"] / compulsory, 3)
-            roofline["hbm_frac_measured"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            profiled_ms = counters.get("avg_ns_kernel_trace", 0.0) / 1e6
+            if profiled_ms and abs(profiled_ms - dom_ms) <= 0.15 * dom_ms:
+                roofline["hbm_frac_measured"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            else:  # bytes of launches that ran at another speed say nothing about this run's rate
+                roofline["traffic_note"] = (f"the profiled launches of this kernel averaged {profiled_ms:.2f} ms under rocprofv3 against "
+                                            f"{dom_ms:.2f} ms here: no measured-traffic fraction is derived")
         if counters and "TCC_REQ_sum" in counters.get("raw", {}):
             req = counters["raw"]["TCC_REQ_sum"]
             l2_gbs = req * 128 / (dom_ms * 1e-3) / 1e9

@@ -1,0 +1,8 @@
+#!/bin/bash
+OUT=gpurun_out/r3_run45
+mkdir -p $OUT
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1
+echo "pytest rc $?" >> $OUT/pytest_gpu.log
+tail -4 $OUT/pytest_gpu.log
+bash scripts/refresh_profiles.sh r3
