@@ -1,5 +1,6 @@
 #!/bin/bash
-OUT=gpurun_out/r3_run45
+# smoke, the whole GPU suite, every bench line and the rocprofv3 passes behind profiles/<round>: gpurun -- bash scripts/full_gpu_check.sh
+OUT=gpurun_out/full_gpu_check
 mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
 timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1
