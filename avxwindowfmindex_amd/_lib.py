@@ -28,7 +28,7 @@ API_SYMBOLS = [
 GPU_SYMBOLS = [
     "awfmGpuDeviceCount", "awfmGpuLastError", "awfmGpuIndexCreate", "awfmGpuIndexDestroy", "awfmGpuIndexAcquire", "awfmGpuIndexAcquireAll",
     "awfmGpuIndexRelease", "awfmGpuIndexDeviceBytes", "awfmGpuIndexDevice", "awfmGpuIndexSetKernel", "awfmGpuIndexSetWide", "awfmGpuIndexIsWide", "awfmGpuLastBatchStatus", "awfmGpuIndexSetDeepSeed", "awfmGpuIndexSetDenseSa", "awfmGpuPinnedBuffer", "awfmGpuLocateHostWindows", "awfmGpuLocateWindow", "awfmGpuAosLock",
-    "awfmGpuAosUnlock", "awfmGpuSearch", "awfmGpuSearchHits", "awfmGpuSearchHitsSparse", "awfmGpuIndexSetOrdered", "awfmGpuSearchHitsIsOrdered", "awfmGpuLastOrderedKernelMs",
+    "awfmGpuAosUnlock", "awfmGpuSearch", "awfmGpuSearchHits", "awfmGpuSearchHitsSparse", "awfmGpuIndexSetOrdered", "awfmGpuSearchHitsIsOrdered", "awfmGpuLastOrderedKernelMs", "awfmGpuLastOrderedKernelIsLookup", "awfmGpuLastOrderedKept",
     "awfmGpuScanScratchBytes", "awfmGpuHitOffsets", "awfmGpuHitOffsetsFromCounts", "awfmGpuLocate", "awfmGpuCountHost", "awfmGpuLocateHost",
     "awfmGpuCreateIndex", "awfmGpuSearchTally", "awfmGpuSynthText", "awfmGpuSynthRandomQueries", "awfmGpuSynthPlantedQueries",
     "awfmGpuSynthMixedLengths", "awfmGpuSynthMixedQueries", "awfmGpuSynthGenomeText", "awfmGpuSynthPlantedQueriesClean",
@@ -148,6 +148,8 @@ def lib():
         "awfmGpuIndexSetOrdered": (None, [vp, C.c_int]),
         "awfmGpuSearchHitsIsOrdered": (C.c_int, [vp, C.c_int, C.c_uint32, u64]),
         "awfmGpuLastOrderedKernelMs": (C.c_double, [vp]),
+        "awfmGpuLastOrderedKernelIsLookup": (C.c_int, [vp]),
+        "awfmGpuLastOrderedKept": (C.c_uint64, [vp]),
         "awfmGpuIndexSetDeepSeed": (C.c_int, [vp, C.c_uint]),
         "awfmGpuIndexSetDenseSa": (C.c_int, [vp, C.c_int]),
         "awfmGpuIndexSetPairImage": (C.c_int, [vp, C.c_int]),

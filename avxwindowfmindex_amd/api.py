@@ -472,6 +472,14 @@ class GpuIndex:
     def last_ordered_kernel_ms(self):
         return float(_lib.lib().awfmGpuLastOrderedKernelMs(self.handle))
 
+    def last_ordered_kept(self):
+        """k-mers the last seed-order search with 8-byte records ordered and searched (awfmGpuLastOrderedKept)"""
+        return int(_lib.lib().awfmGpuLastOrderedKept(self.handle))
+
+    def last_ordered_kernel_is_lookup(self):
+        """the kernel last_ordered_kernel_ms() timed was encodeLookupKernel ("lookup first", include/awfm_gpu.h)"""
+        return bool(_lib.lib().awfmGpuLastOrderedKernelIsLookup(self.handle))
+
     def set_ordered(self, mode):
         """-1 automatic, 0 never, 1 always: search_hits() of fixed-length nucleotide batches in seed order"""
         _lib.lib().awfmGpuIndexSetOrdered(self.handle, mode)

@@ -750,6 +750,8 @@ struct AwFmGpuIndex {
   bool orderEventRecorded = false;
   hipEvent_t orderTiming[2] = {nullptr, nullptr}; /* around orderedSearchKernel when $AWFM_GPU_TIME_ORDERED is set */
   bool orderTimed = false;
+  bool orderLookupFirst = false; /* the last bucketed search kept its k-mers by encodeLookupKernel (and timed that kernel) */
+  const unsigned *orderKeptAt = nullptr; /* device word: k-mers that search ordered (after encodeLookupKernel: the ones it kept) */
   std::mutex aosMutex;       /* serialises the AoS entry points (they share the pinned buffers) */
   void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pinnedBytes[4] = {0, 0, 0, 0};

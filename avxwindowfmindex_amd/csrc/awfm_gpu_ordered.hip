@@ -73,7 +73,8 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
   if (blocks < grid) grid = (unsigned)blocks;
   if (grid >= 8u) grid &= ~7u; /* a multiple of the 8 XCDs, so that every XCD gets the same number of workgroups */
   /* measurement hook (bench.py): HIP events around the dominant kernel on its launch stream */
-  const bool timed = getenv("AWFM_GPU_TIME_ORDERED") != nullptr;
+  const bool keepTiming = BUCKET && g->orderLookupFirst; /* the call's dominant kernel was encodeLookupKernel: its times stay */
+  const bool timed = getenv("AWFM_GPU_TIME_ORDERED") != nullptr && !keepTiming;
   if (timed && !g->orderTiming[0]) {
     AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[0]), AwFmGeneralFailure);
     AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[1]), AwFmGeneralFailure);
@@ -88,7 +89,7 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
                      getenv("AWFM_GPU_CHUNKS_PER_TICKET") && atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) >= 1 ? (unsigned)atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) : (BUCKET ? 4u : 1u));
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[1], s), AwFmGeneralFailure);
-  g->orderTimed = timed;
+  if (!keepTiming) g->orderTimed = timed;
   return AwFmSuccess;
 }
 
@@ -251,6 +252,23 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **
   return 1;
 }
 
+/* 1 when the last seed-order search on the image kept its k-mers by encodeLookupKernel: that kernel is then the one
+ * awfmGpuLastOrderedKernelMs timed */
+extern "C" int awfmGpuLastOrderedKernelIsLookup(const AwFmGpuIndex *g) { return g && g->orderLookupFirst ? 1 : 0; }
+
+/* k-mers the last bucketed seed-order search on the image ordered and searched: the batch, or what encodeLookupKernel kept
+ * of it (reporting; waits for the device) */
+extern "C" uint64_t awfmGpuLastOrderedKept(AwFmGpuIndex *g) {
+  if (!g || !g->orderKeptAt) return 0;
+  DeviceGuard guard(g->device);
+  unsigned kept = 0;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&kept, g->orderKeptAt, sizeof kept, hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return kept;
+}
+
 extern "C" double awfmGpuLastOrderedKernelMs(AwFmGpuIndex *g) {
   if (!g) return -1.0;
   std::lock_guard<std::mutex> lock(g->orderMutex);
@@ -280,6 +298,7 @@ static bool ensureOrderScratch(AwFmGpuIndex *g, size_t bytes) {
   /* hipFree waits for every stream of the device, so nothing still reads the old scratch */
   if (g->dOrder) (void)hipFree(g->dOrder);
   g->dOrder = nullptr;
+  g->orderKeptAt = nullptr;
   g->orderBytes = 0;
   const size_t want = bytes + bytes / 8;
   if (hipMalloc(&g->dOrder, want) != hipSuccess) {
@@ -304,6 +323,18 @@ static void launchEncode4(unsigned len, unsigned grid, size_t lds, hipStream_t s
   launchEncode4At<32u>(len, grid, lds, s, dChars, fmt, nq, codes, hist, binsPad);
 }
 
+/* encodeLookupKernel<K> for the batch's k-mer length */
+template <unsigned K>
+static void launchEncodeLookupAt(unsigned len, unsigned grid, size_t lds, hipStream_t s, const DevIndex &dev, const uint8_t *dChars,
+                                 const BucketFormat &fmt, unsigned useNext, unsigned long long nq, unsigned long long *codes,
+                                 unsigned *numbers, unsigned *shareCount, unsigned *hist, unsigned binsPad) {
+  if (len == K)
+    hipLaunchKernelGGL((encodeLookupKernel<K>), dim3(grid), dim3(256), lds, s, dev, dChars, fmt, useNext, nq, codes, numbers, shareCount,
+                       hist, binsPad);
+  else if constexpr (K > 1u)
+    launchEncodeLookupAt<K - 1u>(len, grid, lds, s, dev, dChars, fmt, useNext, nq, codes, numbers, shareCount, hist, binsPad);
+}
+
 /* fillNoHitKernel -> encodeCodes4Kernel -> bucketScanSharesKernel -> partitionKernel -> orderedSearchKernel<BUCKET> ->
  * searchKernel<INDIRECT> on the caller's stream; the caller holds orderMutex.  Return values as awfmGpuOrderedSearch. */
 static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength, unsigned depth,
@@ -315,8 +346,18 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   const size_t histAt = kOrderCounterBytes, cursorsAt = histAt + alignUp256((size_t)kShares * binsPad * 4u);
   const size_t startAt = cursorsAt + alignUp256((size_t)kShares * binsPad * 4u);
   const size_t codesAt = startAt + alignUp256((bins + 1u) * 4u), recsAt = codesAt + (packed ? 0u : alignUp256(nq * 8u));
-  const size_t total = recsAt + alignUp256(nq * 8u);
+  /* "lookup first" (encodeLookupKernel): ASCII k-mers that start from the narrow deeper table, results dense or as the list of
+   * hits (results in search order owe an entry to every k-mer).  Its k-mer numbers: 4 bytes per k-mer behind the records;
+   * share counts and the sample's count: in the counter block, beyond the ticket counters. */
+  const bool lookupCapable = !packed && !touch && awfmImageNarrow(g) && table == g->dev.deepSeed && g->dev.deepNarrow != 0u &&
+                             !(sparse && sparse->kmers && !sparse->count);
+  const char *lookupEnv = getenv("AWFM_GPU_LOOKUP_FIRST"); /* 0: never, 1: whenever it applies; unset: by a sample of the batch */
+  const bool lookupWanted = lookupCapable && (lookupEnv ? atoi(lookupEnv) != 0 : nq >= (1ull << 20));
+  const size_t numbersAt = recsAt + alignUp256(nq * 8u);
+  const size_t total = numbersAt + (lookupWanted ? alignUp256(nq * 4u) : 0u);
   if (!ensureOrderScratch(g, total)) return 0;
+  constexpr size_t kShareCountAt = 98304, kSampleAt = kShareCountAt + kShares * kShareCountStride * 4u; /* bytes into the counter block (tickets end at 65792) */
+  static_assert(256 + 8 * kTicketGroups * 8 * 256 <= kShareCountAt && kSampleAt + 4 <= kOrderCounterBytes, "counter block");
 #define BUCKET_TRY(call)                    \
   do {                                      \
     hipError_t e__ = (call);                \
@@ -343,7 +384,35 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   const unsigned long long perShare256 = (shareSize(nq) + 255ull) / 256ull;
   unsigned encodeGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * 8u ? perShare256 * kShares : (unsigned long long)g->numCUs * 8u);
   encodeGrid = (encodeGrid + kShares - 1u) / kShares * kShares;
-  if (packed)
+  unsigned *shareCount = (unsigned *)(w + kShareCountAt), *numbers = (unsigned *)(w + numbersAt);
+  const unsigned useNext = g->dev.deepNext != 0u && g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR") && fixedLength >= depth + 2u ? 1u : 0u;
+  bool lookupFirst = lookupWanted && lookupEnv && atoi(lookupEnv) == 1;
+  if (lookupWanted && !lookupFirst) {
+    /* 65536 k-mers at a fixed stride: the pass pays when few of them are alive after the table (the only point where a
+     * search on a stream waits for the device: 4 bytes come back) */
+    constexpr unsigned kSamples = 65536;
+    unsigned sampleAlive = 0;
+    hipLaunchKernelGGL(sampleAliveKernel, dim3(kSamples / 256u), dim3(256), 0, s, g->dev, dChars, fixedLength, depth, useNext, nq, kSamples,
+                       (unsigned *)(w + kSampleAt));
+    BUCKET_TRY(hipGetLastError());
+    BUCKET_TRY(hipMemcpyAsync(&sampleAlive, w + kSampleAt, sizeof sampleAlive, hipMemcpyDeviceToHost, s));
+    BUCKET_TRY(hipStreamSynchronize(s));
+    lookupFirst = sampleAlive * 4u < kSamples;
+  }
+  g->orderLookupFirst = lookupFirst;
+  g->orderKeptAt = bucketStart + bins; /* the scan's total */
+  if (lookupFirst) {
+    const bool timed = getenv("AWFM_GPU_TIME_ORDERED") != nullptr;
+    if (timed && !g->orderTiming[0]) {
+      BUCKET_TRY(hipEventCreate(&g->orderTiming[0]));
+      BUCKET_TRY(hipEventCreate(&g->orderTiming[1]));
+    }
+    if (timed) BUCKET_TRY(hipEventRecord(g->orderTiming[0], s));
+    launchEncodeLookupAt<32u>(fixedLength, encodeGrid, bins * 4u, s, g->dev, dChars, fmt, useNext, nq, (unsigned long long *)(w + codesAt), numbers,
+                              shareCount, hist, binsPad);
+    if (timed) BUCKET_TRY(hipEventRecord(g->orderTiming[1], s));
+    g->orderTimed = timed;
+  } else if (packed)
     hipLaunchKernelGGL((encodeCodesKernel<true>), dim3(encodeGrid), dim3(256), bins * 4u, s, dChars, fixedLength, fmt, nq,
                        (unsigned long long *)nullptr, hist, binsPad);
   else if (getenv("AWFM_GPU_ENCODE_ONE")) /* measurement knob: one k-mer per thread */
@@ -352,7 +421,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   else
     launchEncode4(fixedLength, encodeGrid, bins * 4u, s, dChars, fmt, nq, (unsigned long long *)(w + codesAt), hist, binsPad);
   BUCKET_TRY(hipGetLastError());
-  hipLaunchKernelGGL(bucketScanSharesKernel, dim3(1), dim3(1024), 0, s, hist, bins, binsPad, bucketStart, generalCount);
+  hipLaunchKernelGGL(bucketScanSharesKernel, dim3(1), dim3(1024), 0, s, hist, bins, binsPad, bucketStart, generalCount, (unsigned)nq);
   BUCKET_TRY(hipGetLastError());
   const size_t partitionLds = (size_t)kPartitionTile * 8u + 3u * binsPad * 4u;
   static std::once_flag ldsOnce;
@@ -366,7 +435,8 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   unsigned partitionGrid = (unsigned)(tilesPerShare * kShares < (unsigned long long)g->numCUs ? tilesPerShare * kShares : (unsigned long long)g->numCUs);
   partitionGrid = (partitionGrid + kShares - 1u) / kShares * kShares;
   hipLaunchKernelGGL(partitionKernel, dim3(partitionGrid), dim3(kPartitionThreads), partitionLds, s, codes, fixedLength, fmt, nq,
-                     (const unsigned *)hist, cursors, recs, packed ? 0u : 1u);
+                     (const unsigned *)hist, cursors, recs, packed ? 0u : 1u, lookupFirst ? (const unsigned *)shareCount : (const unsigned *)nullptr,
+                     lookupFirst ? (const unsigned *)numbers : (const unsigned *)nullptr);
   BUCKET_TRY(hipGetLastError());
   const enum AwFmReturnCode rc =
       awfmImageNarrow(g) ? launchBucketed<true>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse)
@@ -468,6 +538,7 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   if (!orderedApplies(g, off != nullptr, fixedLength, nq, &depth, &table)) return 0;
 
   std::lock_guard<std::mutex> lock(g->orderMutex);
+  g->orderLookupFirst = false;
   /* 8-byte records: fixed-length batches of short enough k-mers */
   /* fixed-length batches whose records fit 8 bytes: counted and partitioned by the kernels of awfm_ordered_kernel.h
    * ($AWFM_GPU_ORDERED_SORT=rocprim: the earlier encode + radix sort of (16-bit key, record) pairs, for comparison) */

@@ -251,6 +251,9 @@ __global__ void __launch_bounds__(256)
 constexpr unsigned kBucketBitsMax = 11; /* 2048 buckets (+ 1 for the k-mers left to the general kernel) */
 constexpr unsigned kPartitionThreads = 1024, kPartitionItems = 16, kPartitionTile = kPartitionThreads * kPartitionItems;
 constexpr unsigned long long kCodeGeneral = 1ull << 63; /* a code word of a k-mer the ordered kernel does not cover */
+constexpr unsigned long long kCodeNone = 1ull << 62;    /* no k-mer: an unused slot of a block encodeLookupKernel reserved */
+constexpr unsigned kLookupBlock = 64;                   /* slots a wave of encodeLookupKernel reserves at a time */
+constexpr unsigned kShareCountStride = 64;              /* words between the shares' slot counters (a line each) */
 /* The batch is cut into 8 SHARES of whole tiles, one per XCD (workgroup b works on share b % 8, the XCD it runs on under
  * round-robin dispatch: for speed only), and every bucket's place in the order into 8 sub-runs, share by share.  The
  * workgroups that append to a sub-run are then on ONE XCD: its L2 sees all the 64-byte runs that make up a line and writes
@@ -408,11 +411,156 @@ __global__ void __launch_bounds__(256)
     if (sHist[e]) atomicAdd(&hist[share * binsPad + e], sHist[e]);
 }
 
+/* ---- looking the table entry up in the encode pass ("lookup first") ----
+ * In a batch most of whose k-mers do not occur, nearly every k-mer ends at its entry of the deeper table (no such
+ * deepK-mer, or a clear next-step bit: 95.6 % of 10^8 random 21-mers against 3.1 Gbp), and ordering the batch first means
+ * writing, reading and partitioning 10^8 code words so that a kernel can then read one table line per k-mer in a nicer
+ * order.  This pass decodes as encodeCodes4Kernel does, looks the entry up right away (four lookups per thread in flight),
+ * and keeps only the k-mers that are still alive: their code words and numbers are appended to the share's region of the
+ * code array (one atomic per wave and round), and only they are counted, partitioned and searched -- by the same kernels,
+ * which look a survivor's entry up again.  Results are the same: a k-mer dropped here has no hit.
+ * alive = ambiguity characters (the general kernel's) | length != 0 and, with next-step bits and a pair step to come, its bit. */
+template <unsigned K>
+__global__ void __launch_bounds__(256)
+    encodeLookupKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const BucketFormat f, const unsigned useNext,
+                       const unsigned long long numQueries, unsigned long long *__restrict__ codesOut,
+                       unsigned *__restrict__ numbersOut, unsigned *__restrict__ shareCount, unsigned *__restrict__ hist,
+                       const unsigned binsPad) {
+  extern __shared__ unsigned sHist[]; /* 2^bucketBits + 1 */
+  const unsigned bins = (1u << f.bucketBits) + 1u;
+  for (unsigned e = threadIdx.x; e < bins; e += 256u) sHist[e] = 0u;
+  __syncthreads();
+  constexpr unsigned kLoads = (K + 1u + 3u) / 4u;
+  const unsigned shift = (unsigned)((unsigned long long)chars & 3ull);
+  typedef const Dwords4 __attribute__((address_space(1))) *GlobalDwords4;
+  const unsigned share = blockIdx.x % kShares, localBlock = blockIdx.x / kShares, localGrid = gridDim.x / kShares;
+  const unsigned long long size = shareSize(numQueries), first = size * share;
+  const unsigned long long last = first + size < numQueries ? first + size : numQueries;
+  const unsigned long long tableMask = (1ull << (2u * f.depth)) - 1ull;
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned blockBase = 0, blockUsed = 0, blockSlots = 0; /* the wave's block of slots in its share's region (wave-uniform) */
+  /* wave-uniform trip count: the append below is a wave-wide exchange */
+  const unsigned long long waveFirst = first + 4ull * ((unsigned long long)localBlock * 256ull + (threadIdx.x & ~63u));
+  for (unsigned long long tw = waveFirst; tw < last; tw += 4ull * localGrid * 256ull) {
+    const unsigned long long t = tw + 4ull * lane;
+    unsigned long long codes[4];
+    unsigned bad[4];
+    if (t + 4ull < numQueries) { /* four whole k-mers and at least one behind them: no load leaves the batch */
+      const GlobalDwords4 from = (GlobalDwords4)(((unsigned long long)chars + t * K) & ~3ull);
+      unsigned dw[kLoads * 4u + 1u];
+#pragma unroll
+      for (unsigned j = 0; j < kLoads; j++) {
+        const Dwords4 q = from[j];
+        dw[4u * j] = q.x;
+        dw[4u * j + 1u] = q.y;
+        dw[4u * j + 2u] = q.z;
+        dw[4u * j + 3u] = q.w;
+      }
+      dw[kLoads * 4u] = 0u;
+      unsigned al[K + 1u];
+#pragma unroll
+      for (unsigned j = 0; j < K; j++) al[j] = __builtin_amdgcn_alignbyte(dw[j + 1u], dw[j], shift);
+      al[K] = 0u;
+#pragma unroll
+      for (unsigned i = 0; i < 4u; i++) {
+        constexpr unsigned kWords = (K + 3u) / 4u;
+        const unsigned at = i * K;
+        unsigned long long c = 0;
+        unsigned b = 0;
+#pragma unroll
+        for (unsigned w = 0; w < 8u; w++) {
+          unsigned packed = 0;
+          if (w < kWords) {
+            const unsigned lo = al[(at >> 2) + w], hi = (at >> 2) + w + 1u <= K ? al[(at >> 2) + w + 1u] : 0u;
+            const unsigned inKmer = K - 4u * w >= 4u ? 4u : K - 4u * w;
+            decodeWordAny(__builtin_amdgcn_alignbyte(hi, lo, at & 3u), inKmer >= 4u ? ~0u : (1u << (8u * inKmer)) - 1u, packed, b);
+          }
+          c = (c << 8) | packed;
+        }
+        codes[i] = c >> (2u * (32u - K));
+        bad[i] = b;
+      }
+    } else {
+#pragma unroll
+      for (unsigned i = 0; i < 4u; i++) {
+        codes[i] = 0;
+        bad[i] = 0;
+        if (t + i < numQueries) decodeKmer(chars, (t + i) * K, K, codes[i], bad[i]);
+      }
+    }
+    uint2 entry[4];
+#pragma unroll
+    for (unsigned i = 0; i < 4u; i++) entry[i] = ((const uint2 *)ix.deepSeed)[t + i < last && !bad[i] ? (codes[i] & tableMask) : 0ull];
+    bool alive[4];
+    unsigned long long mask[4];
+    unsigned before[4], total = 0;
+#pragma unroll
+    for (unsigned i = 0; i < 4u; i++) {
+      const unsigned length = ix.deepNext ? (entry[i].y & 0xFFFFu) : entry[i].y;
+      const bool bit = !useNext || ((entry[i].y >> (16u + ((unsigned)(codes[i] >> (2u * f.depth)) & 15u))) & 1u) != 0u;
+      alive[i] = t + i < last && (bad[i] != 0u || (length != 0u && bit));
+      mask[i] = __ballot(alive[i]);
+      before[i] = total;
+      total += (unsigned)__popcll(mask[i]);
+    }
+    if (total != 0u) { /* wave-uniform */
+      if (blockUsed + total > blockSlots) {
+        /* a new block of slots (the counters of the shares are a line apart: returning atomics on one line serialise, and
+         * one per wave and round -- 4 * 10^5 of them -- took longer than the whole pass); what is left of the old one holds no k-mer */
+        if (blockUsed + lane < blockSlots) codesOut[first + blockBase + blockUsed + lane] = kCodeNone;
+        blockSlots = total > kLookupBlock ? total : kLookupBlock;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&shareCount[share * kShareCountStride], blockSlots);
+        blockBase = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        blockUsed = 0;
+      }
+#pragma unroll
+      for (unsigned i = 0; i < 4u; i++) {
+        if (alive[i]) {
+          const unsigned long long slot = first + blockBase + blockUsed + before[i] + (unsigned)__popcll(mask[i] & ((1ull << lane) - 1ull));
+          codesOut[slot] = bad[i] ? kCodeGeneral : codes[i];
+          numbersOut[slot] = (unsigned)(t + i);
+          atomicAdd(&sHist[bad[i] ? bins - 1u : bucketOf(f, codes[i])], 1u);
+        }
+      }
+      blockUsed += total;
+    }
+  }
+  for (unsigned at = blockUsed + lane; at < blockSlots; at += 64u) codesOut[first + blockBase + at] = kCodeNone;
+  __syncthreads();
+  for (unsigned e = threadIdx.x; e < bins; e += 256u)
+    if (sHist[e]) atomicAdd(&hist[share * binsPad + e], sHist[e]);
+}
+
+/* how many of `samples` k-mers taken at a fixed stride over the batch are alive in the sense above: says beforehand
+ * whether the batch is one for encodeLookupKernel */
+__global__ void __launch_bounds__(256)
+    sampleAliveKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const unsigned fixedLen, const unsigned depth,
+                      const unsigned useNext, const unsigned long long numQueries, const unsigned samples, unsigned *__restrict__ aliveOut) {
+  const unsigned j = blockIdx.x * 256u + threadIdx.x;
+  bool alive = false;
+  if (j < samples) {
+    const unsigned long long t = (unsigned long long)j * (numQueries / samples);
+    unsigned long long codes = 0;
+    unsigned bad = 0;
+    decodeKmer(chars, t * fixedLen, fixedLen, codes, bad);
+    if (bad) {
+      alive = true;
+    } else {
+      const uint2 e = ((const uint2 *)ix.deepSeed)[codes & ((1ull << (2u * depth)) - 1ull)];
+      const unsigned length = ix.deepNext ? (e.y & 0xFFFFu) : e.y;
+      alive = length != 0u && (!useNext || ((e.y >> (16u + ((unsigned)(codes >> (2u * depth)) & 15u))) & 1u) != 0u);
+    }
+  }
+  const unsigned n = (unsigned)__popcll(__ballot(alive));
+  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(aliveOut, n);
+}
+
 /* The same scan for the shared histogram hist[kShares][binsPad]: bucketStart as below (a bucket's sub-runs are contiguous,
  * share by share), and hist[share][b] is overwritten with where the share's sub-run of bucket b begins */
 __global__ void __launch_bounds__(1024)
     bucketScanSharesKernel(unsigned *__restrict__ hist, const unsigned bins, const unsigned binsPad, unsigned *__restrict__ bucketStart,
-                           unsigned *__restrict__ generalCount) {
+                           unsigned *__restrict__ generalCount, const unsigned generalEnd /* records in the array: the batch's k-mers */) {
   __shared__ unsigned sWave[16];
   constexpr unsigned kPer = 3; /* 3 x 1024 >= 2049 */
   unsigned v[kPer], sum = 0;
@@ -437,7 +585,9 @@ __global__ void __launch_bounds__(1024)
     const unsigned e = threadIdx.x * kPer + j;
     if (e <= bins) bucketStart[e] = running; /* entry `bins` = the total */
     if (e < bins) {
-      unsigned at = running;
+      /* the last bin (k-mers left to the general kernel) sits at the END of the record array, where that kernel looks for
+       * it -- the same place as `running` when every k-mer of the batch is in some bin, behind a gap after encodeLookupKernel */
+      unsigned at = e == bins - 1u ? generalEnd - v[j] : running;
       for (unsigned sh = 0; sh < kShares; sh++) {
         const unsigned n = hist[sh * binsPad + e];
         hist[sh * binsPad + e] = at;
@@ -485,7 +635,9 @@ __global__ void __launch_bounds__(1024)
 __global__ void __launch_bounds__(kPartitionThreads)
     partitionKernel(const unsigned long long *__restrict__ codes, const unsigned fixedLen, const BucketFormat f,
                     const unsigned long long numQueries, const unsigned *__restrict__ subStart,
-                    unsigned *__restrict__ cursors, unsigned long long *__restrict__ recs, const unsigned honourGeneral) {
+                    unsigned *__restrict__ cursors, unsigned long long *__restrict__ recs, const unsigned honourGeneral,
+                    const unsigned *__restrict__ shareCount = nullptr /* after encodeLookupKernel: code words in the share's region */,
+                    const unsigned *__restrict__ numbers = nullptr /* ... and the k-mer numbers beside them */) {
   extern __shared__ unsigned long long sDyn[];
   unsigned long long *sRec = sDyn;                       /* kPartitionTile records, bucket by bucket */
   unsigned *sCnt = (unsigned *)(sRec + kPartitionTile);  /* records of the tile per bucket */
@@ -497,9 +649,11 @@ __global__ void __launch_bounds__(kPartitionThreads)
   const unsigned long long lenMask = fixedLen >= 32u ? ~0ull : ((1ull << (2u * fixedLen)) - 1ull);
   /* the tiles of this workgroup's share */
   const unsigned share = blockIdx.x % kShares, localBlock = blockIdx.x / kShares, localGrid = gridDim.x / kShares;
-  const unsigned long long allTiles = (numQueries + kPartitionTile - 1ull) / kPartitionTile;
   const unsigned long long tilesPerShare = shareSize(numQueries) / kPartitionTile;
-  const unsigned long long tiles = tilesPerShare * (share + 1ull) < allTiles ? tilesPerShare * (share + 1ull) : allTiles;
+  const unsigned long long shareFirst = shareSize(numQueries) * share;
+  const unsigned long long shareEnd = shareCount ? shareFirst + shareCount[share * kShareCountStride]
+                                                 : (shareFirst + shareSize(numQueries) < numQueries ? shareFirst + shareSize(numQueries) : numQueries);
+  const unsigned long long tiles = tilesPerShare * share + (shareEnd > shareFirst ? (shareEnd - shareFirst + kPartitionTile - 1ull) / kPartitionTile : 0ull);
   const unsigned *myStart = subStart + share * binsPad;
   unsigned *myCursors = cursors + share * binsPad;
   constexpr unsigned kPer = 3; /* bins handled per thread in the scan: 3 x 1024 >= 2049 */
@@ -515,7 +669,7 @@ __global__ void __launch_bounds__(kPartitionThreads)
 #pragma unroll
     for (unsigned j = 0; j < kPartitionItems; j++) {
       const unsigned long long idx = tileBase + (unsigned long long)j * kPartitionThreads + threadIdx.x;
-      rec[j] = idx < numQueries ? codes[idx] : 0ull;
+      rec[j] = idx < shareEnd ? codes[idx] : 0ull;
     }
   };
   auto processTile = [&](unsigned long long tile, unsigned long long *rec) {
@@ -527,13 +681,13 @@ __global__ void __launch_bounds__(kPartitionThreads)
     for (unsigned j = 0; j < kPartitionItems; j++) {
       const unsigned long long idx = tileBase + (unsigned long long)j * kPartitionThreads + threadIdx.x;
       where[j] = 0xFFFFFFFFu;
-      if (idx < numQueries) {
+      if (idx < shareEnd && !(shareCount && rec[j] == kCodeNone)) { /* (an unused slot of encodeLookupKernel's) */
         const bool general = honourGeneral != 0u && (rec[j] & kCodeGeneral) != 0ull; /* never for bit-packed input: every word is a k-mer */
         const unsigned long long c = rec[j] & lenMask;
         const unsigned b = general ? bins - 1u : bucketOf(f, c);
         const unsigned rank = atomicAdd(&sCnt[b], 1u);
         where[j] = (b << 16) | rank;
-        rec[j] = (general ? 0ull : bucketRest(f, c) << f.indexBits) | idx;
+        rec[j] = (general ? 0ull : bucketRest(f, c) << f.indexBits) | (numbers ? (unsigned long long)numbers[idx] : idx);
       }
     }
     __syncthreads();
@@ -761,7 +915,7 @@ constexpr unsigned kTicketGroups = 4; /* ticket counters per XCD and wave slot *
 template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false>
 /* registers: 8 waves per SIMD (64 VGPRs) for the one-step variants; the mixed-length, the pair and the bucketed variants get
  * 72 (7 waves) -- the bucketed pair variant, which carries the next chunk's codes, query number and table entry as well,
- * spills two registers there and is still the faster build since most k-mers of a batch without hits end at the deeper
+ * spills a few registers there (six since a wave collects its hits for the list) and is still the faster build since most k-mers of a batch without hits end at the deeper
  * table (10^8 random 21-mers 2.31-2.38 against 2.57-2.59 ms with 80 registers and 6 waves; planted 5.17 against 5.25) --;
  * the 64-bit pair variants, the instrumented variant and the wide two-lane measurement variant get 80 (6 waves). */
 __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || TOUCH || (G == 2 && !NARROW) ? 6 : (VARLEN || PAIR || BUCKET ? 7 : 8)) : 2, 8)))
@@ -784,6 +938,14 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   __shared__ unsigned long long sPairC[PAIR ? 16 : 1];
   extern __shared__ unsigned sPairSuper[];
   static_assert(!PAIR || G == 4, "pair steps are written for 4 lanes per query");
+  /* the list of hits (SparseOut::count): a wave collects its hits here and appends them kHitBuffer at a time, or when it is
+   * done.  One returning atomic per wave round with a hit is 7 * 10^4 atomics on one word for 10^8 random 21-mers, and a
+   * word takes 88 per microsecond: 0.8 ms -- unnoticed inside a 2.3 ms kernel, twice the kernel once encodeLookupKernel had
+   * left it 4 * 10^6 k-mers (0.78 against 0.35 ms with dense results) */
+  constexpr unsigned kHitBuffer = BUCKET ? 32 : 1; /* (the bucketed variant: the one that runs after encodeLookupKernel) */
+  __shared__ unsigned sHitKmers[BUCKET ? orderedThreads(PAIR) / 64 : 1][kHitBuffer];
+  __shared__ unsigned long long sHitRanges[BUCKET ? orderedThreads(PAIR) / 64 : 1][kHitBuffer][2];
+  unsigned hitFill = 0; /* wave-uniform */
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   stageMaskTable(sMask);
   nucStageSuper<NARROW>(ix, sSuper);
@@ -830,7 +992,9 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     }
   };
   /* the records the fast path covers come first in the order; each XCD takes a contiguous eighth of them */
-  const unsigned long long covered = numRecs - (unsigned long long)*generalCount;
+  /* (bucketed records: what lies before the last bin -- the batch without the k-mers of the general kernel, or the k-mers
+   * encodeLookupKernel kept) */
+  const unsigned long long covered = BUCKET ? (unsigned long long)bucketStart[1u << bucketFmt.bucketBits] : numRecs - (unsigned long long)*generalCount;
   const unsigned xcds = (gridDim.x & 7u) == 0u && xcdMap != 2 ? 8u : 1u;
   const unsigned perXcd = gridDim.x / xcds;
   const unsigned xcd = xcds == 8u ? (xcdMap == 1 ? blockIdx.x / perXcd : (blockIdx.x & 7u)) : 0u;
@@ -853,6 +1017,22 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
    * against 4.41-4.45 ms on the same box, 9.2 against 9.1-9.4 ms planted.) */
   constexpr unsigned kWaves = orderedThreads(PAIR) / 64, kChunk = 64 / G;
   const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  auto flushHits = [&]() { /* wave-uniform: the wave's collected hits go to the list, one reservation for all of them */
+    if (hitFill != 0u) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      unsigned listBase = 0;
+      if (lane == 0) listBase = atomicAdd(sparse.count, hitFill);
+      listBase = (unsigned)__builtin_amdgcn_readfirstlane((int)listBase);
+      if (lane < hitFill && listBase + lane < sparse.cap) {
+        const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        sparse.kmers[listBase + lane] = sHitKmers[w][lane];
+        sparse.ranges[listBase + lane] = make_ulonglong2(sHitRanges[w][lane][0], sHitRanges[w][lane][1]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      hitFill = 0;
+    }
+  };
   /* kTicketGroups x kWaves counters per XCD: wave w of workgroup b draws from counter (b % kTicketGroups, w) */
   constexpr unsigned kCounters = kTicketGroups * kWaves;
   const unsigned counter = (blockInXcd % kTicketGroups) * kWaves + wave;
@@ -1095,7 +1275,20 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       const unsigned long long at = base + lane / G;
       const bool mine = at < end && gl == 0;
       if (sparse.count) { /* kernel argument: uniform */
-        sparseAppend(sparse, mine && sp <= ep, index, (unsigned long long)sp, (unsigned long long)ep);
+        const bool hit = mine && sp <= ep;
+        if (!BUCKET) sparseAppend(sparse, hit, index, (unsigned long long)sp, (unsigned long long)ep);
+        const unsigned long long hitMask = BUCKET ? __ballot(hit) : 0ull;
+        if (hitMask != 0ull) { /* wave-uniform; at most 64 / G hits a round */
+          const unsigned hits = (unsigned)__builtin_amdgcn_readfirstlane((int)__popcll(hitMask));
+          if (hit) { /* there is room: the buffer is emptied below whenever a round's worth might not fit */
+            const unsigned at = hitFill + (unsigned)__popcll(hitMask & ((1ull << (threadIdx.x & 63u)) - 1ull));
+            const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            sHitKmers[w][at] = index;
+            sHitRanges[w][at][0] = (unsigned long long)sp;
+            sHitRanges[w][at][1] = (unsigned long long)ep;
+          }
+          hitFill = (unsigned)__builtin_amdgcn_readfirstlane((int)(hitFill + hits));
+        }
       } else if (sparse.kmers) { /* results in search order: entry `at`, whatever the outcome */
         if (mine) {
           sparse.kmers[at] = index;
@@ -1106,6 +1299,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
         if (counts) counts[index] = (unsigned)(ep - sp + (pos_t)1);
       }
     }
+    if (BUCKET && hitFill + 64u / G > kHitBuffer) flushHits();
     base = baseNext;
     if (AHEAD) {
       baseNext = baseNext2;
@@ -1114,6 +1308,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       baseNext = nextChunk();
     }
   }
+  if (BUCKET) flushHits();
 }
 
 

@@ -404,6 +404,7 @@ def main():
     search_events = []
     locate_events = []
     ordered_ms = []
+    lookup_steps = []  # per timed step: the search looked the table entries up while encoding (encodeLookupKernel was timed)
     narrow_counts = ix.bwt_length < (1 << 32)  # 32-bit counts are exact: hit offsets can be scanned from them
     ordered = g.search_hits_is_ordered(d_offsets is not None, K, Q)
     if ordered:
@@ -478,6 +479,7 @@ def main():
             search_events.append((e0, e1))
             if ordered:
                 ordered_ms.append(g.last_ordered_kernel_ms())  # waits for that kernel only
+                lookup_steps.append(g.last_ordered_kernel_is_lookup())
         if args.mode == "locate":
             if use_order:
                 total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
@@ -507,6 +509,7 @@ def main():
                     if record:
                         search_events.pop()
                         ordered_ms.pop()
+                        lookup_steps.pop()
                     return step(record)
                 ensure_positions(total)
                 if record:
@@ -568,6 +571,8 @@ def main():
     value = batch_total / (elapsed / args.steps) / 1e6  # Mkmers/s over all ranks
     search_ms = float(np.mean([a.elapsed_time(b) for a, b in search_events]))
     locate_ms = float(np.mean([a.elapsed_time(b) for a, b in locate_events])) if locate_events else 0.0
+    lookup_first = bool(lookup_steps) and all(lookup_steps)  # the timed kernel of every step was encodeLookupKernel
+    lookup_kept = g.last_ordered_kept() if lookup_first else 0  # before any other search re-uses the scratch
     if state["windowed"]:  # the positions of the first window, kept for the oracle check of the k-mers that lie in it
         state["keep_first_window"] = True
         step(False)
@@ -673,21 +678,36 @@ def main():
         compulsory = (128 * (lines["seed_table_lines"] + lines["deep_table_lines"] + lines["pair_level_lines"] + lines["nuc_level_lines"])
                       + lines["record_bytes_per_kmer"] * lines["ordered_kmers"] + stored)
         dom_ms = float(np.mean(ordered_ms))
+        dom_name = "orderedSearchKernel"
+        what = ("distinct (search level, 128-B line) pairs the kernel reads, tallied on the device by an "
+                "instrumented launch of the same kernel on the same sorted batch (awfmGpuSearchHitsLineTally), "
+                "x 128 B, + sorted records and keys read + results stored")
+        if lookup_first:
+            # The batch was one for "lookup first" (DESIGN.md 4a): the dominant kernel is encodeLookupKernel, which reads the
+            # k-mers' characters and one table entry per k-mer and keeps the few that are still alive; the kernels after it
+            # (partition, orderedSearchKernel over what was kept) are priced in `call`.  Its compulsory bytes: the characters
+            # + every distinct table line once (the tally's deep_table_lines: the same entries, whatever the order) + what it
+            # appends per k-mer kept (code word 8 B + number 4 B).
+            dom_name = "encodeLookupKernel"
+            compulsory = Q * K + 128 * lines["deep_table_lines"] + 12 * lookup_kept
+            lines = dict(lines, kmers_kept=int(lookup_kept), characters_read=int(Q * K))
+            what = ("the k-mers' characters + 128 B x the distinct lines of the deeper table the batch's k-mers need (tallied on the "
+                    "device by awfmGpuSearchHitsLineTally: deep_table_lines) + 12 B per k-mer kept; pair_level_lines / "
+                    "nuc_level_lines are the lines the kernels AFTER it read for the k-mers kept")
         achieved = compulsory / (dom_ms * 1e-3) / 1e9
         roofline = {
-            "bound": "hbm", "kernel": "orderedSearchKernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(dom_ms, 3),
             "compulsory_bytes": int(compulsory),
-            "compulsory": {"what": "distinct (search level, 128-B line) pairs the kernel reads, tallied on the device by an "
-                                   "instrumented launch of the same kernel on the same sorted batch (awfmGpuSearchHitsLineTally), "
-                                   "x 128 B, + sorted records and keys read + results stored",
-                           **lines, "result_bytes_stored": int(stored)},
+            "compulsory": {"what": what, **lines, "result_bytes_stored": int(stored)},
             "limiter": "HBM, as a gather of random 128-B lines (the guide measures 5.5-5.8 TB/s for such reads, 0.69-0.73 of the "
                        "peak): most lines are entries of the deeper seed table, one per k-mer; see hbm_frac_measured for this "
                        "kernel's measured traffic and `l2` for the requests it sends to the L2s",
         }
         counters, csrc = profile_file("counters", prof_name) if prof_name else (None, None)
         traffic, tsrc = profile_file("traffic", prof_name) if prof_name else (None, None)
+        if counters and not str(counters.get("kernel", "")).startswith(dom_name):
+            counters = None  # the committed counters are another kernel's (a profile from before this path existed)
         if counters and "hbm_read_bytes" in counters:
             roofline["traffic"] = int(counters["hbm_read_bytes"] + counters.get("hbm_write_bytes", 0.0))
             roofline["traffic_source"] = f"{csrc}: {not_this_run}; reads = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM), writes = WRITE_SIZE"
@@ -706,7 +726,7 @@ def main():
                               "frac": round(l2_gbs / L2_GATHER_PEAK_GBS, 4),
                               "source": f"{csrc}: TCC_REQ_sum x 128 B over this run's kernel time; peak = the guide's chip-wide rate "
                                         "for rows gathered out of the XCDs' L2s (16.8-18.8 TB/s)"}
-        dominant = {"name": "orderedSearchKernel", "ms": round(dom_ms, 3)}
+        dominant = {"name": dom_name, "ms": round(dom_ms, 3)}
         if counters:
             for key in ("l2_hit_rate", "valu_issue_frac", "wave_wait_frac", "clock_ghz_under_profiler"):
                 if key in counters:
@@ -717,9 +737,11 @@ def main():
         # the whole call, priced by what the REFERENCE algorithm would move for this batch: a throughput figure in bytes,
         # not a roofline fraction (five sixths of those bytes never leave the L2)
         roofline["call"] = {
-            "kernels": "awfmGpuSearchHits*: fill / memset + encodeCodes4Kernel (count) + bucketScanSharesKernel + partitionKernel + "
-                       "orderedSearchKernel (fixed lengths with 8-byte records; 16-byte records: encodeRecordsKernel + "
-                       "partitionRecordsKernel)",
+            "kernels": ("awfmGpuSearchHits*: fill / memset + sampleAliveKernel + encodeLookupKernel + bucketScanSharesKernel + "
+                        "partitionKernel + orderedSearchKernel over the k-mers kept" if lookup_first else
+                        "awfmGpuSearchHits*: fill / memset + encodeCodes4Kernel (count) + bucketScanSharesKernel + partitionKernel + "
+                        "orderedSearchKernel (fixed lengths with 8-byte records; 16-byte records: encodeRecordsKernel + "
+                        "partitionRecordsKernel)"),
             "ms": round(search_ms, 3), "algorithmic_bytes_per_launch": int(alg_bytes), "per_query": per_query,
             "unordered_equivalent_GBs": round(alg_bytes / (search_ms * 1e-3) / 1e9, 1),
             "unordered_equivalent_upper_bound_variant_GBs": round(upper_bytes / (search_ms * 1e-3) / 1e9, 1),

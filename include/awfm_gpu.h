@@ -196,6 +196,14 @@ int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets, uint32_t f
 /* measurement hook: with $AWFM_GPU_TIME_ORDERED set, awfmGpuSearchHits brackets its dominant kernel
  * (orderedSearchKernel) with HIP events on the launch stream; this returns the last bracket in ms (<0: none) */
 double awfmGpuLastOrderedKernelMs(AwFmGpuIndex *g);
+/* 1 when the last seed-order search on the image looked the table entries up while encoding ("lookup first": batches of
+ * ASCII k-mers of which, by a sample, fewer than a quarter are still alive after the deeper table; only those are then
+ * ordered and searched; $AWFM_GPU_LOOKUP_FIRST=0 / 1: never / whenever it applies) -- the timed kernel is then
+ * encodeLookupKernel */
+int awfmGpuLastOrderedKernelIsLookup(const AwFmGpuIndex *g);
+/* k-mers the last seed-order search with 8-byte records ordered and searched: the batch, or what the lookup-first pass kept
+ * of it (reporting; waits for the device) */
+uint64_t awfmGpuLastOrderedKept(AwFmGpuIndex *g);
 
 /* Instrumented run of the same kernel for the roofline accounting: tallyOut =
  * {queries that used the seed table, backward steps executed, distinct blocks over those steps,

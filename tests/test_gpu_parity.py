@@ -466,6 +466,100 @@ def test_drop_in_aos_api_default_lanes(oracle, awfm, require_gpu, monkeypatch):
     ix.dealloc()
 
 
+@pytest.mark.parametrize("n,seed_k,deep_k,K,pair", [(300000, 8, 12, 21, "1"), (300000, 8, 12, 13, "1"), (200000, 6, 9, 9, "1"),
+                                                    (300000, 8, 12, 21, "0"), (250000, 12, 16, 24, "1"), (150000, 6, 9, 26, "1")])
+def test_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, monkeypatch, n, seed_k, deep_k, K, pair):
+    """"Lookup first" (encodeLookupKernel): the table entry of every k-mer is read while the batch is encoded, and only the
+    k-mers that are still alive after it -- and the ones with ambiguity characters, which go to the general kernel -- are
+    ordered and searched.  Forced on and off over the same batches (random + planted k-mers, ambiguity characters, upper
+    case, every byte alignment): dense results, counts only, and the list of hits must all be the oracle's."""
+    import torch
+    monkeypatch.setenv("AWFM_GPU_PAIR", pair)
+    txt = synth.text(n + 31, n, synth.DNA_ALPHABET).copy()
+    txt[10:14] = ord("n")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, seed_k)
+    oi = oracle.Index.wrap(oracle.DNA, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(deep_k)
+    Q = 70013
+    q = np.concatenate([synth.random_queries(7, Q - Q // 8, K), synth.planted_queries(8, Q // 8, K, txt)]).copy()
+    rng = np.random.default_rng(n + K)
+    q = q[rng.permutation(Q)]
+    flat = q.reshape(-1)
+    flat[rng.random(flat.size) < 0.0005] = ord("x")
+    up = rng.random(flat.size) < 0.3
+    flat[up] = flat[up] & 0xDF
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    assert cnt.sum() > 0 and (cnt == 0).sum() > Q // 4
+    dev = torch.device("cuda")
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AWFM_GPU_LOOKUP_FIRST", mode)
+        for mis in (0, 1, 2, 3):
+            buf = torch.zeros(chars.size + 64, dtype=torch.uint8, device=dev)
+            buf[mis:mis + chars.size] = torch.from_numpy(chars).to(dev)
+            d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
+            d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+            g.search_hits(buf.data_ptr() + mis, 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+            torch.cuda.synchronize()
+            assert g.last_ordered_kernel_is_lookup() == (mode == "1")
+            _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2), d_counts.cpu().numpy().view(np.uint32), sp, ep, cnt)
+        d_counts2 = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+        g.search_hits(buf.data_ptr() + 3, 0, K, Q, 0, d_counts2.data_ptr())  # counts only
+        torch.cuda.synchronize()
+        assert np.array_equal(d_counts2.cpu().numpy().view(np.uint32), cnt)
+        # the list of the k-mers with hits
+        cap = Q
+        d_kmers = torch.zeros(cap, dtype=torch.int32, device=dev)
+        d_hit_ranges = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+        d_num = torch.zeros(1, dtype=torch.int32, device=dev)
+        g.search_hits_compact(buf.data_ptr() + 3, 0, K, Q, d_kmers.data_ptr(), d_hit_ranges.data_ptr(), cap, d_num.data_ptr())
+        torch.cuda.synchronize()
+        listed = int(d_num.item())
+        assert listed == int((cnt > 0).sum())
+        g.sort_hits(d_kmers.data_ptr(), d_hit_ranges.data_ptr(), listed)
+        torch.cuda.synchronize()
+        ids = d_kmers[:listed].cpu().numpy().view(np.uint32)
+        r = d_hit_ranges[:listed * 2].cpu().numpy().view(np.uint64).reshape(listed, 2)
+        assert np.array_equal(ids, np.flatnonzero(cnt > 0)) and np.array_equal(r[:, 0], sp[cnt > 0]) and np.array_equal(r[:, 1], ep[cnt > 0])
+    g.destroy()
+    ix.dealloc()
+
+
+def test_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, monkeypatch):
+    """Without $AWFM_GPU_LOOKUP_FIRST a batch of 2^20 k-mers or more is sampled (65536 k-mers at a fixed stride): random
+    21-mers against a small text nearly all end at the deeper table -> encodeLookupKernel; k-mers drawn from the text all
+    survive it -> the count + partition passes as before.  Counts against the oracle either way."""
+    import torch
+    monkeypatch.delenv("AWFM_GPU_LOOKUP_FIRST", raising=False)
+    n, K, Q = 300000, 21, (1 << 20) + 5
+    txt = synth.text(n + 41, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(12)
+    dev = torch.device("cuda")
+    for name, q in (("random", synth.random_queries(9, Q, K).copy()), ("planted", synth.planted_queries(10, Q, K, txt).copy())):
+        q[::1000, 3] = ord("n")  # some for the general kernel
+        if name == "random":
+            q[5::64] = synth.planted_queries(11, len(q[5::64]), K, txt)  # and some hits
+        chars, offsets = synth.fixed_csr(q)
+        _, _, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+        d_chars = torch.from_numpy(chars).to(dev)
+        d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+        g.search_hits(d_chars.data_ptr(), 0, K, Q, 0, d_counts.data_ptr())
+        torch.cuda.synchronize()
+        assert g.last_ordered_kernel_is_lookup() == (name == "random"), name
+        kept = g.last_ordered_kept()
+        assert (kept < Q // 8) if name == "random" else (kept == Q), (name, kept)
+        assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt), name
+    g.destroy()
+    ix.dealloc()
+
+
 def _check_hits_contract(ranges, counts, sp, ep, cnt):
     """awfmGpuSearchHits: exact range and count for queries with hits, count 0 and an empty range otherwise"""
     hit = cnt > 0
