@@ -24,6 +24,8 @@ run dense_results AWFM_BENCH_DENSE_RESULTS=1 -- --no-cpu --no-e2e --no-secondary
 run no_deep_table -- --device-seed-k 0 --no-cpu --no-e2e --no-secondary --general-steps 0
 run deep_table_14 -- --device-seed-k 14 --no-cpu --no-e2e --no-secondary --general-steps 0
 run no_next_bits AWFM_GPU_DEEP_NEXT=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run no_lookup_first AWFM_GPU_LOOKUP_FIRST=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run no_lookup_first_count AWFM_GPU_LOOKUP_FIRST=0 -- --mode count --no-cpu --no-e2e --no-secondary --general-steps 0
 run rocprim_sort AWFM_GPU_ORDERED_SORT=rocprim -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run mixed_rocprim_sort AWFM_GPU_ORDERED_SORT=rocprim -- --workload mixed --no-cpu --no-e2e --general-steps 0
 run nopair_default AWFM_GPU_PAIR=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
