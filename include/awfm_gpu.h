@@ -140,11 +140,13 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
  * exactly the range and count awfmGpuSearch gives them; a query WITHOUT hits gets count 0 and some empty range
  * (sp > ep), not necessarily the one the stepping ended in.  That freedom lets large nucleotide batches (>= 2^23
  * k-mers against >= 2^28 positions, fixed length or CSR; $AWFM_GPU_ORDERED=0|1 or awfmGpuIndexSetOrdered override)
- * be searched in seed order: the k-mers are packed into 8- or 16-byte records, sorted by the leading bits of the
- * string their search starts from (rocPRIM, 16-bit key), searched in that order so that neighbouring queries read
- * neighbouring blocks out of the L2, and only the non-empty results are stored under their query numbers over a
- * "no hit" fill.  Other batches run awfmGpuSearch.  Scratch: 22-36 bytes per query, owned by the
- * image and re-used; searches on one image are ordered across streams. */
+ * be searched in seed order: the k-mers are packed into 8- or 16-byte records, partitioned by the leading bits of the
+ * string their search starts from, searched in that order so that neighbouring queries read neighbouring blocks out of
+ * the L2, and only the non-empty results are stored under their query numbers over a "no hit" fill.
+ * Other batches run awfmGpuSearch.  Scratch: 16-36 bytes per query, owned by the image and re-used; searches on one
+ * image are ordered across streams.  The launches are asynchronous on `stream` with one exception: a fixed-length
+ * ASCII batch of >= 2^20 k-mers that starts from the deeper table is sampled first (awfmGpuLastOrderedKernelIsLookup
+ * below), and the call waits for the 4 bytes of that sample ($AWFM_GPU_LOOKUP_FIRST=0|1: no sample, no wait). */
 enum AwFmReturnCode awfmGpuSearchHits(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                       uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
                                       uint32_t *dCounts, void *stream);
