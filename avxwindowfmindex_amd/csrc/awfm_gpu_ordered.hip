@@ -259,7 +259,9 @@ extern "C" int awfmGpuLastOrderedKernelIsLookup(const AwFmGpuIndex *g) { return 
 /* k-mers the last bucketed seed-order search on the image ordered and searched: the batch, or what encodeLookupKernel kept
  * of it (reporting; waits for the device) */
 extern "C" uint64_t awfmGpuLastOrderedKept(AwFmGpuIndex *g) {
-  if (!g || !g->orderKeptAt) return 0;
+  if (!g) return 0;
+  std::lock_guard<std::mutex> lock(g->orderMutex); /* the word lives in the scratch a search may be re-allocating */
+  if (!g->orderKeptAt) return 0;
   DeviceGuard guard(g->device);
   unsigned kept = 0;
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&kept, g->orderKeptAt, sizeof kept, hipMemcpyDeviceToHost) != hipSuccess) {
