@@ -765,7 +765,17 @@ constexpr unsigned kWideBucketShift = 15u - kBucketBitsMax; /* bucket = 15-bit s
 __device__ __forceinline__ unsigned wideBucket(const QueryRec &r, unsigned seedK, unsigned deepK, unsigned fixedDepth, bool varlen) {
   if (r.length == 0xFFFFFFFFu) return 1u << kBucketBitsMax; /* left to the general kernel: the last bin */
   const unsigned depth = varlen ? orderStartDepth(r.length, seedK, deepK) : fixedDepth;
-  return startKey15(r.codes, r.length, depth) >> kWideBucketShift;
+  unsigned key = startKey15(r.codes, r.length, depth) >> kWideBucketShift;
+  if (varlen) {
+    /* the k-mers of a wave round finish together when they have about as many memory rounds to go (pair steps from a
+     * table, single steps from a letter range): the two low bits of the bucket say how many, 9 bits are left for the place
+     * in the BWT.  10^8 mixed 8..30-mers: search kernel 8.7-8.8 -> 7.4-7.8 ms (three class bits: 7.7; the class as the
+     * MAJOR key: 10.2) */
+    const unsigned rounds = depth != 0u ? (r.length - depth + 1u) / 2u : r.length - 1u;
+    const unsigned cls = rounds <= 1u ? 0u : (rounds <= 3u ? 1u : (rounds <= 5u ? 2u : 3u));
+    key = (key & ~3u) | cls;
+  }
+  return key;
 }
 
 template <bool VARLEN>
