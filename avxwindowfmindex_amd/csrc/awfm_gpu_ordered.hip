@@ -56,7 +56,7 @@ unsigned residentGrid(const AwFmGpuIndex *g, Kernel kernel, size_t dynamicLds = 
   return (unsigned)g->numCUs * (unsigned)perCU;
 }
 
-template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false>
+template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false, bool LIST = false>
 enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t len, unsigned depth, const ulonglong2 *table,
                                         unsigned long long nq, const void *recs, const unsigned short *keys,
                                         const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts,
@@ -68,7 +68,7 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
   DevIndex dev = g->dev;
   dev.pairSuperInLds = superInLds ? 1u : 0u;
   constexpr int threads = orderedThreads(PAIR);
-  unsigned grid = residentGrid(g, orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET>, lds, threads);
+  unsigned grid = residentGrid(g, orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET, LIST>, lds, threads);
   const unsigned long long blocks = (nq + threads / G - 1) / (threads / G);
   if (blocks < grid) grid = (unsigned)blocks;
   if (grid >= 8u) grid &= ~7u; /* a multiple of the 8 XCDs, so that every XCD gets the same number of workgroups */
@@ -80,7 +80,7 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
     AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[1]), AwFmGeneralFailure);
   }
   if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[0], s), AwFmGeneralFailure);
-  hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET>), dim3(grid ? grid : 1u), dim3(threads), lds, s, dev, recs,
+  hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET, LIST>), dim3(grid ? grid : 1u), dim3(threads), lds, s, dev, recs,
                      keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
                      getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0, touch ? *touch : OrderTouch(), bucketStart,
                      bucketFmt, sparse ? *sparse : SparseOut(),
@@ -144,6 +144,9 @@ enum AwFmReturnCode launchBucketed(AwFmGpuIndex *g, hipStream_t s, const uint8_t
   if (touch)
     rc = pair ? launchOrderedKernel<4, NARROW, true, false, true, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, touch, bucketStart, fmt)
               : launchOrderedKernel<4, NARROW, true, false, false, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, touch, bucketStart, fmt);
+  else if (sparse && sparse->count) /* the list of hits: collected per wave */
+    rc = pair ? launchOrderedKernel<4, NARROW, true, false, true, false, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse)
+              : launchOrderedKernel<4, NARROW, true, false, false, false, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse);
   else
     rc = pair ? launchOrderedKernel<4, NARROW, true, false, true, false, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse)
               : launchOrderedKernel<4, NARROW, true, false, false, false, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse);

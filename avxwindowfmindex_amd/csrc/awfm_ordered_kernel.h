@@ -922,10 +922,11 @@ struct OrderTouch {
 };
 
 constexpr unsigned kTicketGroups = 4; /* ticket counters per XCD and wave slot */
-template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false>
+template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false,
+          bool LIST = false /* bucketed records + the list of hits: a wave collects its hits (below) */>
 /* registers: 8 waves per SIMD (64 VGPRs) for the one-step variants; the mixed-length, the pair and the bucketed variants get
  * 72 (7 waves) -- the bucketed pair variant, which carries the next chunk's codes, query number and table entry as well,
- * spills a few registers there (six since a wave collects its hits for the list) and is still the faster build since most k-mers of a batch without hits end at the deeper
+ * spills two registers there (six in its LIST twin, which collects a wave's hits for the list) and is still the faster build since most k-mers of a batch without hits end at the deeper
  * table (10^8 random 21-mers 2.31-2.38 against 2.57-2.59 ms with 80 registers and 6 waves; planted 5.17 against 5.25) --;
  * the 64-bit pair variants, the instrumented variant and the wide two-lane measurement variant get 80 (6 waves). */
 __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || TOUCH || (G == 2 && !NARROW) ? 6 : (VARLEN || PAIR || BUCKET ? 7 : 8)) : 2, 8)))
@@ -952,9 +953,10 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
    * done.  One returning atomic per wave round with a hit is 7 * 10^4 atomics on one word for 10^8 random 21-mers, and a
    * word takes 88 per microsecond: 0.8 ms -- unnoticed inside a 2.3 ms kernel, twice the kernel once encodeLookupKernel had
    * left it 4 * 10^6 k-mers (0.78 against 0.35 ms with dense results) */
-  constexpr unsigned kHitBuffer = BUCKET ? 32 : 1; /* (the bucketed variant: the one that runs after encodeLookupKernel) */
-  __shared__ unsigned sHitKmers[BUCKET ? orderedThreads(PAIR) / 64 : 1][kHitBuffer];
-  __shared__ unsigned long long sHitRanges[BUCKET ? orderedThreads(PAIR) / 64 : 1][kHitBuffer][2];
+  static_assert(!LIST || BUCKET, "the collected list belongs to the bucketed variant (the one that runs after encodeLookupKernel)");
+  constexpr unsigned kHitBuffer = LIST ? 32 : 1;
+  __shared__ unsigned sHitKmers[LIST ? orderedThreads(PAIR) / 64 : 1][kHitBuffer];
+  __shared__ unsigned long long sHitRanges[LIST ? orderedThreads(PAIR) / 64 : 1][kHitBuffer][2];
   unsigned hitFill = 0; /* wave-uniform */
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   stageMaskTable(sMask);
@@ -1286,8 +1288,8 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       const bool mine = at < end && gl == 0;
       if (sparse.count) { /* kernel argument: uniform */
         const bool hit = mine && sp <= ep;
-        if (!BUCKET) sparseAppend(sparse, hit, index, (unsigned long long)sp, (unsigned long long)ep);
-        const unsigned long long hitMask = BUCKET ? __ballot(hit) : 0ull;
+        if (!LIST) sparseAppend(sparse, hit, index, (unsigned long long)sp, (unsigned long long)ep);
+        const unsigned long long hitMask = LIST ? __ballot(hit) : 0ull;
         if (hitMask != 0ull) { /* wave-uniform; at most 64 / G hits a round */
           const unsigned hits = (unsigned)__builtin_amdgcn_readfirstlane((int)__popcll(hitMask));
           if (hit) { /* there is room: the buffer is emptied below whenever a round's worth might not fit */
@@ -1309,7 +1311,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
         if (counts) counts[index] = (unsigned)(ep - sp + (pos_t)1);
       }
     }
-    if (BUCKET && hitFill + 64u / G > kHitBuffer) flushHits();
+    if (LIST && hitFill + 64u / G > kHitBuffer) flushHits();
     base = baseNext;
     if (AHEAD) {
       baseNext = baseNext2;
@@ -1318,7 +1320,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       baseNext = nextChunk();
     }
   }
-  if (BUCKET) flushHits();
+  if (LIST) flushHits();
 }
 
 
