@@ -40,6 +40,7 @@ def measure(name, chars):
     print(f"{name:44s} call {min(ts[1:]):6.2f} ms   orderedSearchKernel {min(ks[1:]):6.2f} ms   hits {int((d_counts > 0).sum())}", flush=True)
 
 
+DEPTH = g.deep_seed_k or SEEDK  # the table the search starts from
 for workload in ("random", "planted"):
     d_q = torch.empty(Q * K, dtype=torch.uint8, device=dev)
     if workload == "random":
@@ -48,17 +49,19 @@ for workload in ("random", "planted"):
         L.awfmGpuSynthPlantedQueries(d_q.data_ptr(), 0, Q, K, 103, d_text.data_ptr(), n, None)
     q2 = d_q.view(Q, K)
     measure(f"{workload}: as generated", d_q)
-    # key over the characters the search consumes first: the seed (last 12), then the ones before it
-    for extra in (0, 2, 4):
+    # key over the characters the search consumes first: the table index (last DEPTH characters, first one most
+    # significant), then the ones before it; the partition pass scrambles inside a tile of 16384 k-mers only, so a sorted
+    # batch reaches the search kernel in an order that fine
+    for extra in (0, 2):
         key = torch.zeros(Q, dtype=torch.int64, device=dev)
-        for j in range(K - SEEDK, K):                    # seed, first character most significant (the table index)
+        for j in range(K - DEPTH, K):
             key = key * 4 + lut[q2[:, j].long()]
-        for j in range(K - SEEDK - 1, K - SEEDK - 1 - extra, -1):   # then the characters prepended next
+        for j in range(K - DEPTH - 1, K - DEPTH - 1 - extra, -1):
             key = key * 4 + lut[q2[:, j].long()]
         order = torch.argsort(key)
         del key
         sorted_q = q2[order].contiguous().view(-1)
         del order
-        measure(f"{workload}: pre-sorted by the seed + {extra} characters", sorted_q)
+        measure(f"{workload}: pre-sorted by the table index + {extra} characters", sorted_q)
         del sorted_q
     del d_q, q2
