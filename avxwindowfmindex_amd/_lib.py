@@ -36,6 +36,7 @@ GPU_SYMBOLS = [
     "awfmGpuStreamChars", "awfmGpuCountPackedHost", "awfmGpuLocatePackedHost", "awfmGpuIndexSetPairImage", "awfmGpuIndexHasPairImage",
     "awfmGpuSearchHitsPacked", "awfmGpuLocateTo", "awfmGpuSearchHitsLineTally", "awfmGpuIndexDeepSeedK", "awfmGpuSearchHitsCompact", "awfmGpuCompactHits", "awfmGpuSortHits",
     "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse", "awfmGpuSearchHitsInOrder",
+    "awfmGpuSortHitsOnDevice", "awfmGpuHitOffsetsOnDevice", "awfmGpuLocateOnDevice", "awfmGpuLastOrderedSearchKernelMs", "awfmGpuOrderedKernelLog", "awfmGpuIndexDeepSeedBuildSeconds", "awfmGpuIndexDeepSeedTransientBytes",
 ]
 # int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
 CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
@@ -155,6 +156,8 @@ def lib():
         "awfmGpuIndexSetPairImage": (C.c_int, [vp, C.c_int]),
         "awfmGpuIndexHasPairImage": (C.c_int, [vp]),
         "awfmGpuIndexDeepSeedK": (C.c_uint, [vp]),
+        "awfmGpuIndexDeepSeedBuildSeconds": (C.c_double, [vp]),
+        "awfmGpuIndexDeepSeedTransientBytes": (u64, [vp]),
         "awfmGpuSearch": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuSearchHits": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuSearchHitsSparse": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
@@ -162,6 +165,11 @@ def lib():
         "awfmGpuCompactHits": (C.c_int, [vp, vp, vp, u64, vp, vp, vp, vp, C.c_uint32, vp, vp]),
         "awfmGpuSearchHitsInOrder": (C.c_int, [vp, vp, vp, C.c_uint32, u64, C.c_int, vp, vp, vp]),
         "awfmGpuSortHits": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
+        "awfmGpuSortHitsOnDevice": (C.c_int, [vp, vp, vp, C.c_uint32, vp, u64, vp]),
+        "awfmGpuHitOffsetsOnDevice": (C.c_int, [vp, vp, vp, u64, vp, vp, vp]),
+        "awfmGpuLocateOnDevice": (C.c_int, [vp, vp, vp, u64, u64, vp, vp]),
+        "awfmGpuLastOrderedSearchKernelMs": (C.c_double, [vp]),
+        "awfmGpuOrderedKernelLog": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
         "awfmGpuScanScratchBytes": (u64, [u64]),
         "awfmGpuHitOffsets": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),
         "awfmGpuHitOffsetsFromCounts": (C.c_int, [vp, vp, u64, vp, vp, C.POINTER(u64), vp]),

@@ -270,6 +270,12 @@ class GpuIndex:
         """depth of the device-only deeper seed table of this image (0: none)"""
         return int(_lib.lib().awfmGpuIndexDeepSeedK(self.handle))
 
+    @property
+    def deep_seed_build(self):
+        """(wall seconds, transient device bytes) of the construction of that table, whoever started it"""
+        L = _lib.lib()
+        return float(L.awfmGpuIndexDeepSeedBuildSeconds(self.handle)), int(L.awfmGpuIndexDeepSeedTransientBytes(self.handle))
+
     def set_dense_sa(self, enable=True):
         """device-only full suffix array (32-bit entries) so that a locate is a single gather"""
         _check("awfmGpuIndexSetDenseSa", _lib.lib().awfmGpuIndexSetDenseSa(self.handle, int(bool(enable))))
@@ -465,6 +471,32 @@ class GpuIndex:
 
     def sort_hits(self, d_hit_kmers, d_hit_ranges, num_entries, stream=0):
         _check("awfmGpuSortHits", _lib.lib().awfmGpuSortHits(self.handle, d_hit_kmers, d_hit_ranges, num_entries, stream or None))
+
+    def sort_hits_on_device(self, d_hit_kmers, d_hit_ranges, capacity, d_num_hits, n, stream=0):
+        """awfmGpuSortHitsOnDevice: the list in k-mer order, its length read on the device (no host wait)"""
+        _check("awfmGpuSortHitsOnDevice", _lib.lib().awfmGpuSortHitsOnDevice(self.handle, d_hit_kmers, d_hit_ranges, capacity,
+                                                                             d_num_hits, n, stream or None))
+
+    def hit_offsets_on_device(self, d_counts, d_ranges, n, d_hit_offsets, d_scratch, stream=0):
+        """awfmGpuHitOffsetsOnDevice: the scan; the total stays in d_hit_offsets[n]"""
+        _check("awfmGpuHitOffsetsOnDevice", _lib.lib().awfmGpuHitOffsetsOnDevice(self.handle, d_counts or None, d_ranges or None, n,
+                                                                                 d_hit_offsets, d_scratch, stream or None))
+
+    def locate_on_device(self, d_ranges, d_hit_offsets, n, capacity_hits, d_positions, stream=0):
+        """awfmGpuLocateOnDevice: the locate with the number of hits read on the device, at most capacity_hits of them"""
+        _check("awfmGpuLocateOnDevice", _lib.lib().awfmGpuLocateOnDevice(self.handle, d_ranges, d_hit_offsets, n, capacity_hits,
+                                                                         d_positions, stream or None))
+
+    def ordered_kernel_log(self, max_entries=1024):
+        """awfmGpuOrderedKernelLog: [(encodeLookupKernel ms or -1, orderedSearchKernel ms or -1)] of the searches timed since
+        the last call ($AWFM_GPU_TIME_ORDERED), oldest first"""
+        front = (C.c_double * max_entries)()
+        kern = (C.c_double * max_entries)()
+        n = _lib.lib().awfmGpuOrderedKernelLog(self.handle, front, kern, max_entries)
+        return [(front[i], kern[i]) for i in range(n)]
+
+    def last_ordered_search_kernel_ms(self):
+        return float(_lib.lib().awfmGpuLastOrderedSearchKernelMs(self.handle))
 
     def search_hits_is_ordered(self, has_offsets, fixed_length, n):
         return bool(_lib.lib().awfmGpuSearchHitsIsOrdered(self.handle, int(bool(has_offsets)), fixed_length, n))

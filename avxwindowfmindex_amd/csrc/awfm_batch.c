@@ -146,11 +146,13 @@ static void packUniform(void *p, uint64_t begin, uint64_t end, unsigned tid) {
 static bool packQueries(AwFmGpuIndex *g, const struct AwFmKmerSearchData *data, uint64_t n, unsigned threads,
                         uint8_t **charsOut, uint64_t **offsetsOut, uint32_t *fixedOut) {
   const uint64_t firstLength = data[0].kmerLength;
-  if (firstLength != 0 && firstLength <= 4096) {
+  /* (the one-pass try sizes its buffer by the FIRST k-mer: bounded to the lengths seed-and-extend k-mers have, so that a
+   * mixed list whose first string is long does not pin n x 4096 bytes it then throws away; if the buffer cannot be had
+   * the two passes below, which need the summed lengths only, still run) */
+  if (firstLength != 0 && firstLength <= 64) {
     struct packUniformCtx u = {data, firstLength, awfmGpuPinnedBuffer(g, 0, n * firstLength), 0};
-    if (!u.chars) return false;
-    awfmParallelFor(threads, n, packUniform, &u);
-    if (!u.mixed) {
+    if (u.chars) awfmParallelFor(threads, n, packUniform, &u);
+    if (u.chars && !u.mixed) {
       *charsOut = u.chars;
       *offsetsOut = NULL;
       *fixedOut = (uint32_t)firstLength;

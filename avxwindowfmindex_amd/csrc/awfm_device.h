@@ -33,6 +33,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <vector>
 #include <string>
 
 #include "awfm_internal.h"
@@ -720,6 +722,8 @@ struct AwFmGpuIndex {
   void *dPrefix = nullptr;
   void *dDeepSeed = nullptr;
   uint64_t deepSeedBytes = 0;
+  double deepSeedBuildSeconds = 0.0;    /* wall time of the last construction of the deeper table (reporting) */
+  uint64_t deepSeedTransientBytes = 0;  /* device memory that construction held beyond the table itself, at its peak */
   void *dDeepBig = nullptr; /* side list of the deeper table: keys, then lengths (DevIndex::deepBigKeys) */
   void *dDenseSa = nullptr; /* optional full suffix array, 32-bit entries */
   uint64_t denseSaBytes = 0;
@@ -737,6 +741,7 @@ struct AwFmGpuIndex {
   size_t workBytes = 0;
   void *dHits = nullptr; /* positions of the host-buffer locate calls, grow-only like dWork */
   size_t hitsBytes = 0;
+  mutable uint64_t hitBudgetAuto = 0; /* awfmGpuHitBudget's automatic value, asked of the device once (0: not yet) */
   void *dSparse = nullptr; /* temporaries of awfmGpuSortHits, grow-only (under orderMutex) */
   size_t sparseBytes = 0;
   hipEvent_t windowEvent[2] = {nullptr, nullptr}; /* the two hit windows in flight of awfmGpuLocateHostWindows */
@@ -744,13 +749,51 @@ struct AwFmGpuIndex {
    * the event orders its re-use across streams */
   int orderMode = -1; /* -1 auto, 0 off, 1 on */
   std::mutex orderMutex;
-  void *dOrder = nullptr;
-  size_t orderBytes = 0;
-  hipEvent_t orderEvent = nullptr;
-  bool orderEventRecorded = false;
-  hipEvent_t orderTiming[2] = {nullptr, nullptr}; /* around orderedSearchKernel when $AWFM_GPU_TIME_ORDERED is set */
-  bool orderTimed = false;
-  bool orderLookupFirst = false; /* the last bucketed search kept its k-mers by encodeLookupKernel (and timed that kernel) */
+  /* who used a piece of scratch last, so that the next user on ANOTHER stream waits for it (and one on the same stream,
+   * which is ordered behind it anyway, does not pay for an event) */
+  struct StreamGate {
+    hipEvent_t done = nullptr;
+    bool recorded = false; /* `done` says when the last use is over */
+    bool pending = false;  /* the last use left no event: it is recorded on lastStream when another stream needs it */
+    hipStream_t lastStream = nullptr;
+    std::thread::id lastThread; /* hipStreamPerThread is one handle for a different stream in every thread */
+  };
+  /* the scratch of a seed-order search: kOrderSlots of them, so that two callers on two streams overlap instead of queueing
+   * (a caller keeps the slot it used last; a newcomer takes the one that has rested longest) */
+  struct OrderSlot {
+    void *mem = nullptr;
+    size_t bytes = 0;
+    StreamGate gate;
+    unsigned long long lastUse = 0;
+  };
+  static constexpr int kOrderSlots = 2;
+  OrderSlot orderSlot[kOrderSlots];
+  unsigned long long orderUses = 0;
+  int orderCur = 0;           /* the slot of the search being enqueued (under orderMutex) */
+  void *dOrder = nullptr;     /* = orderSlot[orderCur].mem */
+  size_t orderBytes = 0;      /* = orderSlot[orderCur].bytes */
+  hipEvent_t orderDoneEvent = nullptr; /* set while a search is enqueued: its last kernel carries it (stop event) ... */
+  bool orderDoneArmed = false;         /* ... and says so here */
+  StreamGate sparseGate; /* dSparse */
+  /* $AWFM_GPU_TIME_ORDERED: [0],[1] around the front end that looks the table up (encodeLookupKernel), [2],[3] around
+   * orderedSearchKernel; which pair is the call's dominant kernel follows from orderLookup */
+  hipEvent_t orderTiming[4] = {nullptr, nullptr, nullptr, nullptr}; /* the current entry of orderLog */
+  bool orderTimedFront = false, orderTimedKernel = false;
+  /* one entry per timed search, so that a caller can time every step of a loop without waiting inside it
+   * (awfmGpuOrderedKernelLog): a ring of kOrderLogMax entries, events created on first use */
+  struct OrderLogEntry {
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool front = false, kernel = false;
+  };
+  static constexpr unsigned kOrderLogMax = 1024;
+  std::vector<OrderLogEntry> orderLog;
+  unsigned long long orderLogCount = 0; /* searches timed since the log was last read */
+  /* did the last bucketed search keep its k-mers by encodeLookupKernel?  0 no, 1 yes, 2 decided ON THE DEVICE from the
+   * sample (no host wait inside the search): the sample's count is the device word orderSampleAt, the pass was taken when
+   * 4 x that count < orderSamples */
+  int orderLookup = 0;
+  const unsigned *orderSampleAt = nullptr;
+  unsigned orderSamples = 0;
   const unsigned *orderKeptAt = nullptr; /* device word: k-mers that search ordered (after encodeLookupKernel: the ones it kept) */
   std::mutex aosMutex;       /* serialises the AoS entry points (they share the pinned buffers) */
   void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -848,7 +891,8 @@ extern "C" uint64_t awfmGpuHitBudget(const AwFmGpuIndex *g);
 enum AwFmReturnCode awfmGpuScanFlags(AwFmGpuIndex *g, const uint32_t *dCounts, uint64_t numQueries, uint64_t *dFlagOffsets,
                                      void *dScratch, hipStream_t s);
 /* awfm_gpu_build.hip: level-wise construction of the deeper seed table into a new device buffer */
-bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut);
+/* peakBytesOut (may be NULL): the most device memory the construction held at once (the table and the level below it) */
+bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut, uint64_t *peakBytesOut = nullptr);
 /* awfm_gpu_ordered.hip: rewrites the 8-byte entries {sp, length} of a finished table as {sp, length16 | next16 << 16}
  * (DevIndex::deepNext) and returns the side list of the saturated lengths in *bigOut (one allocation: *numBigOut keys,
  * then as many lengths; NULL when there is none).  Needs the pair image.  1: done; 0: not applicable, nothing was

@@ -120,7 +120,12 @@ __global__ void narrowKernel(const unsigned long long *in, unsigned long long co
 /* positions[t] = denseSa[positions[t]]: the whole backtrace as one gather (hits of a query are consecutive
  * BWT positions, so the reads are contiguous per query) */
 __global__ void denseSaGatherKernel(const unsigned *__restrict__ dense, unsigned long long totalHits,
-                                    const unsigned long long *positions, unsigned long long *out) {
+                                    const unsigned long long *positions, unsigned long long *out,
+                                    const unsigned long long *__restrict__ totalOnDevice = nullptr) {
+  if (totalOnDevice) { /* the number of hits is still on the device: totalHits is the capacity */
+    const unsigned long long t = *totalOnDevice;
+    totalHits = t < totalHits ? t : totalHits;
+  }
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < totalHits; t += stride)
     out[t] = dense[positions[t]];
@@ -251,7 +256,7 @@ void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned super
 
 namespace {
 enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions,
-                                 hipStream_t s, unsigned long long *out = nullptr);
+                                 hipStream_t s, unsigned long long *out = nullptr, const unsigned long long *totalOnDevice = nullptr);
 /* lanes that cooperate on one query: image setting, else $AWFM_GPU_KERNEL (g4|g2|g1), else the default.  A device
  * block has 4 slices, so 4 lanes is the widest group (GROUP8 of the enum maps to it); amino slices are 32 B, 2 lanes
  * per query already hold 64 registers of block data */
@@ -543,11 +548,15 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
     }
     if (g->dWork) (void)hipFree(g->dWork);
     if (g->dHits) (void)hipFree(g->dHits);
-    if (g->dOrder) (void)hipFree(g->dOrder);
+    for (auto &slot : g->orderSlot) {
+      if (slot.mem) (void)hipFree(slot.mem);
+      if (slot.gate.done) (void)hipEventDestroy(slot.gate.done);
+    }
     if (g->dSparse) (void)hipFree(g->dSparse);
-    if (g->orderEvent) (void)hipEventDestroy(g->orderEvent);
-    for (int i = 0; i < 2; i++)
-      if (g->orderTiming[i]) (void)hipEventDestroy(g->orderTiming[i]);
+    if (g->sparseGate.done) (void)hipEventDestroy(g->sparseGate.done);
+    for (auto &entry : g->orderLog)
+      for (int i = 0; i < 4; i++)
+        if (entry.ev[i]) (void)hipEventDestroy(entry.ev[i]);
     for (int i = 0; i < 2; i++)
       if (g->windowEvent[i]) (void)hipEventDestroy(g->windowEvent[i]);
     for (int i = 0; i < 4; i++)
@@ -747,13 +756,21 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
   g->dev.numDeepBig = 0;
   g->dev.deepBigKeys = g->dev.deepBigLengths = nullptr;
   enum AwFmReturnCode rc = AwFmSuccess;
+  g->deepSeedBuildSeconds = 0.0;
+  g->deepSeedTransientBytes = 0;
   if (deepK != 0) {
     void *table = nullptr;
-    uint64_t bytes = 0;
-    if (awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes)) {
+    uint64_t bytes = 0, peak = 0;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes, &peak)) {
       void *big = nullptr;
       unsigned numBig = 0;
       const int next = awfmGpuDeepSeedAddNext(g, table, deepK, &big, &numBig); /* images with pair blocks, below 2^32 positions */
+      (void)hipDeviceSynchronize();
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      g->deepSeedBuildSeconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+      g->deepSeedTransientBytes = peak > bytes ? peak - bytes : 0;
       if (next < 0) {
         (void)hipFree(table);
         rc = AwFmGeneralFailure;
@@ -855,6 +872,8 @@ enum AwFmReturnCode awfmGpuIndexSetPairImage(AwFmGpuIndex *g, int enable) {
 }
 int awfmGpuIndexHasPairImage(const AwFmGpuIndex *g) { return g && g->dev.pairBlocks ? 1 : 0; }
 unsigned awfmGpuIndexDeepSeedK(const AwFmGpuIndex *g) { return g ? g->dev.deepK : 0u; }
+double awfmGpuIndexDeepSeedBuildSeconds(const AwFmGpuIndex *g) { return g ? (g->shares ? g->shares : g)->deepSeedBuildSeconds : 0.0; }
+uint64_t awfmGpuIndexDeepSeedTransientBytes(const AwFmGpuIndex *g) { return g ? (g->shares ? g->shares : g)->deepSeedTransientBytes : 0; }
 
 int awfmGpuIndexDevice(const AwFmGpuIndex *g) { return g ? g->device : -1; }
 void awfmGpuIndexSetKernel(AwFmGpuIndex *g, enum AwFmGpuKernel kernel) {
@@ -951,7 +970,8 @@ static enum AwFmReturnCode searchHits(AwFmGpuIndex *g, const uint8_t *dChars, co
     DeviceGuard guard(g->device);
     const int ordered = awfmGpuOrderedSearch(g, (hipStream_t)stream, dChars, (const unsigned long long *)dOffsets, fixedLength,
                                              numQueries, (ulonglong2 *)dRanges, dCounts, false, rangesOfHitsOnly);
-    if (ordered < 0) return (enum AwFmReturnCode)(-ordered);
+    /* (no memory for the seed-order scratch: the general kernel needs none and gives the same hits) */
+    if (ordered < 0 && ordered != -(int)AwFmAllocationFailure) return (enum AwFmReturnCode)(-ordered);
     if (ordered > 0) return AwFmSuccess;
   }
   return searchGeneral(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream);
@@ -1151,10 +1171,52 @@ enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearch
   return launchLocate(g, totalHits, (unsigned long long *)dPositions, s, (unsigned long long *)outPositions);
 }
 
+/* see include/awfm_gpu.h */
+enum AwFmReturnCode awfmGpuHitOffsetsOnDevice(AwFmGpuIndex *g, const uint32_t *dCounts, const struct AwFmSearchRange *dRanges,
+                                              uint64_t numQueries, uint64_t *dHitOffsets, void *dScratch, void *stream) {
+  if (!g || (!dCounts && !dRanges) || !dHitOffsets || !dScratch || numQueries == 0) {
+    setError("awfmGpuHitOffsetsOnDevice: null argument");
+    return AwFmNullPtrError;
+  }
+  if (dCounts && g->dev.bwtLength >= (1ull << 32)) {
+    setError("awfmGpuHitOffsetsOnDevice: 32-bit counts are exact only for images below 2^32 positions; pass the ranges");
+    return AwFmUnsupportedVersionError;
+  }
+  DeviceGuard guard(g->device);
+  hipStream_t s = (hipStream_t)stream;
+  return dCounts ? scanRecursive<kScanU32>(dCounts, numQueries, (unsigned long long *)dHitOffsets, (unsigned long long *)dScratch, s)
+                 : scanRecursive<kScanRanges>(dRanges, numQueries, (unsigned long long *)dHitOffsets, (unsigned long long *)dScratch, s);
+}
+
+enum AwFmReturnCode awfmGpuLocateOnDevice(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges, const uint64_t *dHitOffsets,
+                                          uint64_t numQueries, uint64_t capacityHits, uint64_t *dPositions, void *stream) {
+  if (!g || !dRanges || !dHitOffsets || !dPositions) {
+    setError("awfmGpuLocateOnDevice: null argument");
+    return AwFmNullPtrError;
+  }
+  if (numQueries == 0 || capacityHits == 0) return AwFmSuccess;
+  DeviceGuard guard(g->device);
+  hipStream_t s = (hipStream_t)stream;
+  /* the window [0, capacity) of the hit list: the hits beyond what `dPositions` holds are left out (the caller sees from
+   * the total, when it gets to read it, that the buffer was too small) */
+  hipLaunchKernelGGL(expandHitsKernel, dim3(cappedGrid(numQueries)), dim3(256), 0, s, (const ulonglong2 *)dRanges,
+                     (const unsigned long long *)dHitOffsets, 0ull, (unsigned long long)numQueries, 0ull,
+                     (unsigned long long)capacityHits, (unsigned long long *)dPositions);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  const unsigned long long *total = (const unsigned long long *)dHitOffsets + numQueries;
+  if (g->dDenseSa) {
+    hipLaunchKernelGGL(denseSaGatherKernel, dim3((unsigned)(g->numCUs * 8)), dim3(256), 0, s, (const unsigned *)g->dDenseSa,
+                       (unsigned long long)capacityHits, (const unsigned long long *)dPositions, (unsigned long long *)dPositions, total);
+    AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+    return AwFmSuccess;
+  }
+  return launchLocate(g, capacityHits, (unsigned long long *)dPositions, s, (unsigned long long *)dPositions, total);
+}
+
 namespace {
 /* LF-walk + sampled-SA kernel over `totalHits` BWT positions stored in dPositions (in place) */
 enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions,
-                                 hipStream_t s, unsigned long long *out) {
+                                 hipStream_t s, unsigned long long *out, const unsigned long long *totalOnDevice) {
   {
     /* the walk runs at the rate the chip delivers random granules whatever the group width (17.2 / 17.5 / 18.3 ms
      * for g4 / g2 / g1 on 1.0007*10^8 hits); four lanes keep the fewest instructions per step */
@@ -1187,13 +1249,13 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     const unsigned grid__ = gridFor(th, g, walkKernel<false, 4, P2, NR, true>, walkThreads(true) / 4, pairLds, walkThreads(true)); \
     /* a short hit list: batches of 4 instead of 16 hits per lane group, when the grid has a group for every one */         \
     if (th <= (unsigned long long)grid__ * (walkThreads(true) / 4) * 4ull)                                                   \
-      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true, 1u>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos); \
+      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true, 1u>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos, totalOnDevice); \
     else                                                                                                                     \
-      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos); \
+      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos, totalOnDevice); \
   } while (0)
 #define AWFM_LOC3(AM, GG, P2, NR)                                                                                  \
   hipLaunchKernelGGL((walkKernel<AM, GG, P2, NR>), dim3(gridFor(th, g, walkKernel<AM, GG, P2, NR>, kThreads / GG)), \
-                     dim3(kThreads), 0, s, g->dev, th, pos)
+                     dim3(kThreads), 0, s, g->dev, th, pos, totalOnDevice)
 #define AWFM_LOC(AM, GG)                                      \
   do {                                                        \
     if (pow2 && narrow) AWFM_LOC3(AM, GG, true, true);        \
@@ -1221,7 +1283,7 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     /* out-of-place: the final positions go to `out` (page-locked host memory in the pipeline): a smaller grid, so that
      * a kernel paced by the PCIe writes leaves the chip to whatever runs beside it */
     const unsigned finishGrid = out && out != pos ? (unsigned)g->numCUs * (getenv("AWFM_GPU_FINISH_BLOCKS") ? (unsigned)atoi(getenv("AWFM_GPU_FINISH_BLOCKS")) : 2u) : (unsigned)g->numCUs * 8u;
-    hipLaunchKernelGGL(finishKernel, dim3(finishGrid), dim3(256), 0, s, g->dev, th, (const unsigned long long *)pos, out ? out : pos);
+    hipLaunchKernelGGL(finishKernel, dim3(finishGrid), dim3(256), 0, s, g->dev, th, (const unsigned long long *)pos, out ? out : pos, totalOnDevice);
   }
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
@@ -1352,14 +1414,20 @@ uint64_t awfmGpuHitBudget(const AwFmGpuIndex *g) {
     const unsigned long long bytes = strtoull(env, nullptr, 10);
     if (bytes) return bytes / 8 > 1024 ? bytes / 8 : 1024;
   }
+  /* the automatic budget: asked of the device once per image.  Up to three callers hold a budget's worth of positions at
+   * a time (the AoS entry points' lanes, the pipeline's slots), each with page-locked staging of the same size: a quarter
+   * of the free memory is shared among them, and 2^28 hits (2 GB) is as large as a window gets by itself */
+  const uint64_t cached = __atomic_load_n(&g->hitBudgetAuto, __ATOMIC_RELAXED);
+  if (cached) return cached;
   size_t freeBytes = 0, totalBytes = 0;
   if (hipMemGetInfo(&freeBytes, &totalBytes) != hipSuccess) {
     (void)hipGetLastError();
     freeBytes = (size_t)1 << 32;
   }
-  uint64_t hits = ((uint64_t)freeBytes + g->hitsBytes) / 4 / 8;
+  uint64_t hits = ((uint64_t)freeBytes + g->hitsBytes) / 4 / 3 / 8;
   if (hits < (1ull << 25)) hits = 1ull << 25;
-  if (hits > (1ull << 31)) hits = 1ull << 31;
+  if (hits > (1ull << 28)) hits = 1ull << 28;
+  __atomic_store_n(&g->hitBudgetAuto, hits, __ATOMIC_RELAXED);
   return hits;
 }
 

@@ -625,9 +625,11 @@ bool launchPackSampledSa(const void *dSa, u64 samples, unsigned ratio, unsigned 
 
 /* Deeper seed table for the device image: level seedK is the index's own table; level L+1 extends
  * every level-L entry by one more (prepended) letter with the search path's stop-at-first-invalid rule. */
-bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut) {
+bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut, uint64_t *peakBytesOut) {
   *tableOut = nullptr;
   *bytesOut = 0;
+  if (peakBytesOut) *peakBytesOut = 0;
+  u64 curBytes = 0; /* the level the next one is made from (0: the index's own table) */
   const unsigned K = g->dev.seedK;
   if (g->amino || deepK <= K || deepK > 16 || K == 0) {
     awfmGpuSetError("deep seed table: nucleotide images only, seedK < deepK <= 16");
@@ -642,6 +644,7 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
     const u64 outLen = len * 4;
     const bool out8 = L + 1 == deepK && g->dev.bwtLength < (1ull << 32); /* the table itself, 8-byte entries */
     if (!nxt.alloc(outLen * (out8 ? 8 : 16))) return false;
+    if (peakBytesOut && curBytes + outLen * (out8 ? 8 : 16) > *peakBytesOut) *peakBytesOut = curBytes + outLen * (out8 ? 8 : 16);
     constexpr int kUnroll = 4;
     const u64 blocks = (outLen + kSeedGroupsPerBlock * kUnroll - 1) / (kSeedGroupsPerBlock * kUnroll);
     const u64 resident = (u64)g->numCUs * 8u; /* a persistent grid: what does not fit the chip would only queue */
@@ -657,6 +660,7 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
     if (getenv("AWFM_VERBOSE")) fprintf(stderr, "[awfm deep seed] level %u -> %u: %llu entries\n", L, L + 1, (unsigned long long)outLen);
     cur.reset();
     cur.p = nxt.release();
+    curBytes = outLen * (out8 ? 8 : 16);
     parent = cur.as<ulonglong2>();
     len = outLen;
   }

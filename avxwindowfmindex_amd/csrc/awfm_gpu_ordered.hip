@@ -11,6 +11,7 @@
 #include <cstddef>
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rocprim/rocprim.hpp>
 
 #include "awfm_ordered_kernel.h"
@@ -72,24 +73,22 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
   const unsigned long long blocks = (nq + threads / G - 1) / (threads / G);
   if (blocks < grid) grid = (unsigned)blocks;
   if (grid >= 8u) grid &= ~7u; /* a multiple of the 8 XCDs, so that every XCD gets the same number of workgroups */
-  /* measurement hook (bench.py): HIP events around the dominant kernel on its launch stream */
-  const bool keepTiming = BUCKET && g->orderLookupFirst; /* the call's dominant kernel was encodeLookupKernel: its times stay */
-  const bool timed = getenv("AWFM_GPU_TIME_ORDERED") != nullptr && !keepTiming;
-  if (timed && !g->orderTiming[0]) {
-    AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[0]), AwFmGeneralFailure);
-    AWFM_HIP_TRY(hipEventCreate(&g->orderTiming[1]), AwFmGeneralFailure);
-  }
-  if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[0], s), AwFmGeneralFailure);
-  hipLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET, LIST>), dim3(grid ? grid : 1u), dim3(threads), lds, s, dev, recs,
-                     keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
-                     getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0, touch ? *touch : OrderTouch(), bucketStart,
-                     bucketFmt, sparse ? *sparse : SparseOut(),
-                     /* chunks a ticket is worth: 10^8 random 21-mers 3.92 (1), 3.49 (2), 3.47 (4), 3.50 (8), 3.65 ms (16); mixed-length and
-                      * planted batches show no gain */
-                     getenv("AWFM_GPU_CHUNKS_PER_TICKET") && atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) >= 1 ? (unsigned)atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) : (BUCKET ? 4u : 1u));
+  /* measurement hook (bench.py): HIP events around the kernel on its launch stream (events [2],[3]; when the call's
+   * dominant kernel was encodeLookupKernel its own events [0],[1] are the ones reported) */
+  /* (the events ride on the kernel's own dispatch -- hipExtLaunchKernelGGL -- instead of being recorded around it: a
+   * recorded event is a packet of its own and left the queue idle for about 5 us each, 24 us per search) */
+  const bool timed = g->orderTiming[2] != nullptr; /* this search has an entry in the timing log */
+  hipExtLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET, LIST>), dim3(grid ? grid : 1u), dim3(threads), (unsigned)lds, s,
+                        timed ? g->orderTiming[2] : nullptr, timed ? g->orderTiming[3] : nullptr, 0u, dev, recs,
+                        keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
+                        getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0, touch ? *touch : OrderTouch(), bucketStart,
+                        bucketFmt, sparse ? *sparse : SparseOut(),
+                        /* chunks a ticket is worth: 10^8 random 21-mers 3.92 (1), 3.49 (2), 3.47 (4), 3.50 (8), 3.65 ms (16); mixed-length and
+                         * planted batches show no gain */
+                        getenv("AWFM_GPU_CHUNKS_PER_TICKET") && atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) >= 1 ? (unsigned)atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) : (BUCKET ? 4u : 1u));
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-  if (timed) AWFM_HIP_TRY(hipEventRecord(g->orderTiming[1], s), AwFmGeneralFailure);
-  if (!keepTiming) g->orderTimed = timed;
+  g->orderTimedKernel = timed;
+  if (timed) g->orderLog[(g->orderLogCount - 1u) % AwFmGpuIndex::kOrderLogMax].kernel = true;
   return AwFmSuccess;
 }
 
@@ -125,11 +124,13 @@ enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t 
   /* the queries the fast path left out (ambiguity characters, empty or longer than 32; normally none): general
    * kernel over the tail of the order */
   const unsigned grid = residentGrid(g, searchKernel<false, 4, VARLEN, false, NARROW, true>);
-  hipLaunchKernelGGL((searchKernel<false, 4, VARLEN, false, NARROW, true>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
-                     off, len, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)recs,
-                     COMPACT ? 8u : (unsigned)sizeof(QueryRec), COMPACT ? 0u : (unsigned)offsetof(QueryRec, index), nq,
-                     generalCount, sparse ? *sparse : SparseOut());
+  /* the last kernel of the search: it carries the event that says the scratch slot is free again */
+  hipExtLaunchKernelGGL((searchKernel<false, 4, VARLEN, false, NARROW, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, 0u,
+                        g->dev, dChars, off, len, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)recs,
+                        COMPACT ? 8u : (unsigned)sizeof(QueryRec), COMPACT ? 0u : (unsigned)offsetof(QueryRec, index), nq,
+                        generalCount, sparse ? *sparse : SparseOut());
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  g->orderDoneArmed = g->orderDoneEvent != nullptr;
   return AwFmSuccess;
 }
 
@@ -153,10 +154,12 @@ enum AwFmReturnCode launchBucketed(AwFmGpuIndex *g, hipStream_t s, const uint8_t
   if (rc != AwFmSuccess || packed) return rc; /* bit-packed k-mers: every one of them is covered */
   /* the last bucket: k-mers with ambiguity characters; a record of it is the query number alone */
   const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, NARROW, true>);
-  hipLaunchKernelGGL((searchKernel<false, 4, false, false, NARROW, true>), dim3(grid), dim3(kThreads), 0, s, g->dev, dChars,
-                     (const unsigned long long *)nullptr, len, nq, rng, dCounts, (unsigned long long *)nullptr,
-                     (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut());
+  /* the last kernel of the search: it carries the event that says the scratch slot is free again */
+  hipExtLaunchKernelGGL((searchKernel<false, 4, false, false, NARROW, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, 0u,
+                        g->dev, dChars, (const unsigned long long *)nullptr, len, nq, rng, dCounts, (unsigned long long *)nullptr,
+                        (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut());
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  g->orderDoneArmed = g->orderDoneEvent != nullptr;
   return AwFmSuccess;
 }
 
@@ -255,9 +258,28 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **
   return 1;
 }
 
+/* did the last bucketed search on the image keep its k-mers by encodeLookupKernel?  When the search left the decision to
+ * the device (orderLookup == 2) the sample's count is read back here -- a reporting call, it waits for the device.  The
+ * caller holds orderMutex. */
+static bool lastSearchLookedUpFirst(AwFmGpuIndex *g) {
+  if (g->orderLookup != 2) return g->orderLookup == 1;
+  if (!g->orderSampleAt) return false;
+  DeviceGuard guard(g->device);
+  unsigned alive = 0;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&alive, g->orderSampleAt, sizeof alive, hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return alive * 4u < g->orderSamples;
+}
+
 /* 1 when the last seed-order search on the image kept its k-mers by encodeLookupKernel: that kernel is then the one
- * awfmGpuLastOrderedKernelMs timed */
-extern "C" int awfmGpuLastOrderedKernelIsLookup(const AwFmGpuIndex *g) { return g && g->orderLookupFirst ? 1 : 0; }
+ * awfmGpuLastOrderedKernelMs timed (reporting; may wait for the device) */
+extern "C" int awfmGpuLastOrderedKernelIsLookup(AwFmGpuIndex *g) {
+  if (!g) return 0;
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  return lastSearchLookedUpFirst(g) ? 1 : 0;
+}
 
 /* k-mers the last bucketed seed-order search on the image ordered and searched: the batch, or what encodeLookupKernel kept
  * of it (reporting; waits for the device) */
@@ -274,13 +296,50 @@ extern "C" uint64_t awfmGpuLastOrderedKept(AwFmGpuIndex *g) {
   return kept;
 }
 
+/* milliseconds the dominant kernel of the last awfmGpuSearchHits* on this image took -- encodeLookupKernel when the batch
+ * was one for "lookup first", orderedSearchKernel otherwise -- when the call ran with $AWFM_GPU_TIME_ORDERED set (waits
+ * for it); negative when there is none */
 extern "C" double awfmGpuLastOrderedKernelMs(AwFmGpuIndex *g) {
   if (!g) return -1.0;
   std::lock_guard<std::mutex> lock(g->orderMutex);
-  if (!g->orderTimed || !g->orderTiming[0]) return -1.0;
+  const bool front = lastSearchLookedUpFirst(g);
+  if (front ? !g->orderTimedFront : !g->orderTimedKernel) return -1.0;
+  hipEvent_t from = g->orderTiming[front ? 0 : 2], to = g->orderTiming[front ? 1 : 3];
+  if (!from || !to) return -1.0;
   float ms = 0.0f;
-  if (hipEventSynchronize(g->orderTiming[1]) != hipSuccess ||
-      hipEventElapsedTime(&ms, g->orderTiming[0], g->orderTiming[1]) != hipSuccess)
+  if (hipEventSynchronize(to) != hipSuccess || hipEventElapsedTime(&ms, from, to) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+/* The brackets of every search since the log was last read (at most the last kOrderLogMax), oldest first: frontMs[i] =
+ * encodeLookupKernel's (< 0: that search had none), kernelMs[i] = orderedSearchKernel's.  Waits for the last of them; the
+ * log is empty afterwards.  Lets a caller time every step of a loop without a host wait inside the loop. */
+extern "C" int awfmGpuOrderedKernelLog(AwFmGpuIndex *g, double *frontMs, double *kernelMs, int max) {
+  if (!g || !frontMs || !kernelMs || max <= 0) return 0;
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  DeviceGuard guard(g->device);
+  unsigned long long n = g->orderLogCount;
+  if (n > AwFmGpuIndex::kOrderLogMax) n = AwFmGpuIndex::kOrderLogMax;
+  if (n > (unsigned long long)max) n = (unsigned long long)max;
+  for (unsigned long long i = 0; i < n; i++) {
+    const AwFmGpuIndex::OrderLogEntry &e = g->orderLog[(g->orderLogCount - n + i) % AwFmGpuIndex::kOrderLogMax];
+    float ms = 0.0f;
+    frontMs[i] = e.front && hipEventSynchronize(e.ev[1]) == hipSuccess && hipEventElapsedTime(&ms, e.ev[0], e.ev[1]) == hipSuccess ? (double)ms : -1.0;
+    kernelMs[i] = e.kernel && hipEventSynchronize(e.ev[3]) == hipSuccess && hipEventElapsedTime(&ms, e.ev[2], e.ev[3]) == hipSuccess ? (double)ms : -1.0;
+  }
+  (void)hipGetLastError();
+  g->orderLogCount = 0;
+  return (int)n;
+}
+
+/* the other of the two: orderedSearchKernel over the k-mers encodeLookupKernel kept (negative when the last search did
+ * not look up first, or was not timed) */
+extern "C" double awfmGpuLastOrderedSearchKernelMs(AwFmGpuIndex *g) {
+  if (!g) return -1.0;
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  if (!g->orderTimedKernel || !g->orderTiming[2] || !g->orderTiming[3]) return -1.0;
+  float ms = 0.0f;
+  if (hipEventSynchronize(g->orderTiming[3]) != hipSuccess || hipEventElapsedTime(&ms, g->orderTiming[2], g->orderTiming[3]) != hipSuccess)
     return -1.0;
   return (double)ms;
 }
@@ -297,19 +356,112 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
                          bool rangesOfHitsOnly, const OrderTouch *touch, uint64_t *recordBytesOut,
                          const SparseOut *sparse);
 
-/* scratch of the image, grown when needed; the caller holds orderMutex.  false: no memory (the general kernel needs none) */
+/* what the seed-order search returns when its scratch cannot be allocated: distinguishable from "does not apply" (0), so
+ * that a caller with another way to the same results (the general kernel needs no scratch) takes it and the others say
+ * what really happened */
+constexpr int kOrderNoScratch = -(int)AwFmAllocationFailure;
+
+/* ---- gates: who used a piece of scratch last ---- */
+/* `s` is about to use what the gate guards: it waits for the last user unless that was the same stream (in the same thread:
+ * hipStreamPerThread names a different stream in every thread), which is ordered behind it already */
+/* A recorded event -- whether by hipEventRecord or as the stop event of a kernel launch -- leaves the queue idle for about
+ * 5 us (measured: the launches behind one start 4.5-7 us late), and a search that is followed by another on the SAME
+ * stream, the usual case, needs none.  So for a stream the caller created (a handle that names the same stream from every
+ * thread) nothing is recorded when the use ends: the event is recorded on that stream when a user on ANOTHER stream shows
+ * up, behind whatever the first stream has been given since -- more than needed, never less.  (Such a stream must therefore
+ * outlive its searches on the image: destroy it only after synchronising it.)  The null stream and hipStreamPerThread,
+ * whose handles do not name one stream, record eagerly. */
+static bool gateLazy(hipStream_t s) { return s != nullptr && s != hipStreamPerThread && s != hipStreamLegacy; }
+static hipError_t gateEnter(AwFmGpuIndex::StreamGate &gate, hipStream_t s) {
+  if (!gate.done) {
+    const hipError_t e = hipEventCreate(&gate.done);
+    if (e != hipSuccess) return e;
+  }
+  if (!gate.recorded && !gate.pending) return hipSuccess;
+  if (gate.lastStream == s && (gateLazy(s) || gate.lastThread == std::this_thread::get_id())) return hipSuccess;
+  if (gate.pending) { /* the last user left no event behind: now one is needed */
+    if (hipEventRecord(gate.done, gate.lastStream) != hipSuccess) {
+      (void)hipGetLastError();
+      const hipError_t e = hipDeviceSynchronize(); /* that stream is gone: whatever it was given has to be over */
+      gate.pending = gate.recorded = false;
+      return e;
+    }
+    gate.pending = false;
+    gate.recorded = true;
+  }
+  return hipStreamWaitEvent(s, gate.done, 0);
+}
+/* `s` has enqueued its last use; armed: the last kernel was launched with gate.done as its stop event (hipExtLaunchKernelGGL),
+ * which costs nothing, where a hipEventRecord is a packet of its own and about 5 us of idle queue */
+static hipError_t gateLeave(AwFmGpuIndex::StreamGate &gate, hipStream_t s, bool armed) {
+  if (gateLazy(s) && !getenv("AWFM_GPU_EAGER_EVENTS")) {
+    gate.pending = true;
+    gate.recorded = false;
+  } else {
+    if (!armed) {
+      const hipError_t e = hipEventRecord(gate.done, s);
+      if (e != hipSuccess) return e;
+    }
+    gate.recorded = true;
+    gate.pending = false;
+  }
+  gate.lastStream = s;
+  gate.lastThread = std::this_thread::get_id();
+  return hipSuccess;
+}
+
+/* the scratch slot of a search on stream `s` (the caller holds orderMutex): the one this stream used last, else the one
+ * that has rested longest; `s` waits for that slot's last user */
+static hipError_t orderBeginSlot(AwFmGpuIndex *g, hipStream_t s) {
+  int pick = -1;
+  for (int i = 0; i < AwFmGpuIndex::kOrderSlots; i++) {
+    const AwFmGpuIndex::StreamGate &gate = g->orderSlot[i].gate;
+    if ((gate.recorded || gate.pending) && gate.lastStream == s && (gateLazy(s) || gate.lastThread == std::this_thread::get_id())) pick = i;
+  }
+  if (pick < 0) {
+    pick = 0;
+    for (int i = 1; i < AwFmGpuIndex::kOrderSlots; i++)
+      if (g->orderSlot[i].lastUse < g->orderSlot[pick].lastUse) pick = i;
+  }
+  if (const char *env = getenv("AWFM_GPU_ORDER_SLOTS")) /* measurement knob: 1 = one slot, every search queues on it */
+    if (atoi(env) == 1) pick = 0;
+  AwFmGpuIndex::OrderSlot &slot = g->orderSlot[pick];
+  slot.lastUse = ++g->orderUses;
+  g->orderCur = pick;
+  g->dOrder = slot.mem;
+  g->orderBytes = slot.bytes;
+  g->orderDoneArmed = false;
+  const hipError_t e = gateEnter(slot.gate, s);
+  g->orderDoneEvent = e == hipSuccess && !(gateLazy(s) && !getenv("AWFM_GPU_EAGER_EVENTS")) ? slot.gate.done : nullptr;
+  return e;
+}
+static hipError_t orderEndSlot(AwFmGpuIndex *g, hipStream_t s) {
+  const hipError_t e = gateLeave(g->orderSlot[g->orderCur].gate, s, g->orderDoneArmed);
+  g->orderDoneEvent = nullptr;
+  g->orderDoneArmed = false;
+  return e;
+}
+
+/* scratch of the current slot, grown when needed; the caller holds orderMutex.  false: no memory (the general kernel needs none) */
 static bool ensureOrderScratch(AwFmGpuIndex *g, size_t bytes) {
-  if (bytes <= g->orderBytes) return true;
+  AwFmGpuIndex::OrderSlot &slot = g->orderSlot[g->orderCur];
+  if (bytes <= slot.bytes) return true;
   /* hipFree waits for every stream of the device, so nothing still reads the old scratch */
-  if (g->dOrder) (void)hipFree(g->dOrder);
+  if (slot.mem) (void)hipFree(slot.mem);
+  slot.mem = nullptr;
+  slot.bytes = 0;
   g->dOrder = nullptr;
-  g->orderKeptAt = nullptr;
   g->orderBytes = 0;
+  g->orderKeptAt = nullptr;
+  g->orderSampleAt = nullptr;
   const size_t want = bytes + bytes / 8;
-  if (hipMalloc(&g->dOrder, want) != hipSuccess) {
+  if (hipMalloc(&slot.mem, want) != hipSuccess) {
     (void)hipGetLastError();
+    setError("seed-order search: no device memory for its scratch");
     return false;
   }
+  slot.bytes = want;
+  g->dOrder = slot.mem;
   g->orderBytes = want;
   return true;
 }
@@ -317,27 +469,31 @@ static bool ensureOrderScratch(AwFmGpuIndex *g, size_t bytes) {
 /* encodeCodes4Kernel<K> for the batch's k-mer length */
 template <unsigned K>
 static void launchEncode4At(unsigned len, unsigned grid, size_t lds, hipStream_t s, const uint8_t *dChars, const BucketFormat &fmt,
-                            unsigned long long nq, unsigned long long *codes, unsigned *hist, unsigned binsPad) {
+                            unsigned long long nq, unsigned long long *codes, unsigned *hist, unsigned binsPad,
+                            const unsigned *sampleAlive, unsigned samples) {
   if (len == K)
-    hipLaunchKernelGGL((encodeCodes4Kernel<K>), dim3(grid), dim3(256), lds, s, dChars, fmt, nq, codes, hist, binsPad);
+    hipLaunchKernelGGL((encodeCodes4Kernel<K>), dim3(grid), dim3(256), lds, s, dChars, fmt, nq, codes, hist, binsPad, sampleAlive, samples);
   else if constexpr (K > 1u)
-    launchEncode4At<K - 1u>(len, grid, lds, s, dChars, fmt, nq, codes, hist, binsPad);
+    launchEncode4At<K - 1u>(len, grid, lds, s, dChars, fmt, nq, codes, hist, binsPad, sampleAlive, samples);
 }
 static void launchEncode4(unsigned len, unsigned grid, size_t lds, hipStream_t s, const uint8_t *dChars, const BucketFormat &fmt,
-                          unsigned long long nq, unsigned long long *codes, unsigned *hist, unsigned binsPad) {
-  launchEncode4At<32u>(len, grid, lds, s, dChars, fmt, nq, codes, hist, binsPad);
+                          unsigned long long nq, unsigned long long *codes, unsigned *hist, unsigned binsPad,
+                          const unsigned *sampleAlive = nullptr, unsigned samples = 0u) {
+  launchEncode4At<32u>(len, grid, lds, s, dChars, fmt, nq, codes, hist, binsPad, sampleAlive, samples);
 }
 
 /* encodeLookupKernel<K> for the batch's k-mer length */
 template <unsigned K>
 static void launchEncodeLookupAt(unsigned len, unsigned grid, size_t lds, hipStream_t s, const DevIndex &dev, const uint8_t *dChars,
                                  const BucketFormat &fmt, unsigned useNext, unsigned long long nq, unsigned long long *codes,
-                                 unsigned *numbers, unsigned *shareCount, unsigned *hist, unsigned binsPad) {
+                                 unsigned *numbers, unsigned *shareCount, unsigned *hist, unsigned binsPad,
+                                 const unsigned *sampleAlive, unsigned samples, hipEvent_t start, hipEvent_t stop) {
   if (len == K)
-    hipLaunchKernelGGL((encodeLookupKernel<K>), dim3(grid), dim3(256), lds, s, dev, dChars, fmt, useNext, nq, codes, numbers, shareCount,
-                       hist, binsPad);
+    hipExtLaunchKernelGGL((encodeLookupKernel<K>), dim3(grid), dim3(256), (unsigned)lds, s, start, stop, 0u, dev, dChars, fmt, useNext, nq, codes,
+                          numbers, shareCount, hist, binsPad, sampleAlive, samples);
   else if constexpr (K > 1u)
-    launchEncodeLookupAt<K - 1u>(len, grid, lds, s, dev, dChars, fmt, useNext, nq, codes, numbers, shareCount, hist, binsPad);
+    launchEncodeLookupAt<K - 1u>(len, grid, lds, s, dev, dChars, fmt, useNext, nq, codes, numbers, shareCount, hist, binsPad, sampleAlive, samples,
+                                 start, stop);
 }
 
 /* fillNoHitKernel -> encodeCodes4Kernel -> bucketScanSharesKernel -> partitionKernel -> orderedSearchKernel<BUCKET> ->
@@ -360,7 +516,11 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   const bool lookupWanted = lookupCapable && (lookupEnv ? atoi(lookupEnv) != 0 : nq >= (1ull << 20));
   const size_t numbersAt = recsAt + alignUp256(nq * 8u);
   const size_t total = numbersAt + (lookupWanted ? alignUp256(nq * 4u) : 0u);
-  if (!ensureOrderScratch(g, total)) return 0;
+  if (orderBeginSlot(g, s) != hipSuccess) {
+    setError("seed-order search: could not order the use of its scratch across streams");
+    return -(int)AwFmGeneralFailure;
+  }
+  if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
   constexpr size_t kShareCountAt = 98304, kSampleAt = kShareCountAt + kShares * kShareCountStride * 4u; /* bytes into the counter block (tickets end at 65792) */
   static_assert(256 + 8 * kTicketGroups * 8 * 256 <= kShareCountAt && kSampleAt + 4 <= kOrderCounterBytes, "counter block");
 #define BUCKET_TRY(call)                    \
@@ -371,9 +531,6 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
       return -(int)AwFmGeneralFailure;      \
     }                                       \
   } while (0)
-  if (!g->orderEvent) BUCKET_TRY(hipEventCreateWithFlags(&g->orderEvent, hipEventDisableTiming));
-  /* the scratch is shared by all searches on this image: order them across streams */
-  if (g->orderEventRecorded) BUCKET_TRY(hipStreamWaitEvent(s, g->orderEvent, 0));
   uint8_t *w = (uint8_t *)g->dOrder;
   unsigned *generalCount = (unsigned *)w;
   unsigned *hist = (unsigned *)(w + histAt), *cursors = (unsigned *)(w + cursorsAt), *bucketStart = (unsigned *)(w + startAt);
@@ -391,40 +548,52 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   encodeGrid = (encodeGrid + kShares - 1u) / kShares * kShares;
   unsigned *shareCount = (unsigned *)(w + kShareCountAt), *numbers = (unsigned *)(w + numbersAt);
   const unsigned useNext = g->dev.deepNext != 0u && g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR") && fixedLength >= depth + 2u ? 1u : 0u;
-  bool lookupFirst = lookupWanted && lookupEnv && atoi(lookupEnv) == 1;
-  if (lookupWanted && !lookupFirst) {
-    /* 65536 k-mers at a fixed stride: the pass pays when few of them are alive after the table (the only point where a
-     * search on a stream waits for the device: 4 bytes come back) */
-    constexpr unsigned kSamples = 65536;
-    unsigned sampleAlive = 0;
+  /* lookup first: forced ($AWFM_GPU_LOOKUP_FIRST=1), or left to a sample of the batch -- 16384 k-mers at a fixed stride; the
+   * pass pays when fewer than a quarter of them are alive after the table.  The sample's count stays on the device: both
+   * front ends are launched and the one it does not choose returns at once (lookupChosen), so the search never waits
+   * for the host.  ($AWFM_GPU_LOOKUP_HOST_DECIDES=1: round 3's read-back of the count, 4 bytes and a stream
+   * synchronisation inside the search, for comparison.) */
+  constexpr unsigned kSamples = 16384;
+  const bool forced = lookupWanted && lookupEnv && atoi(lookupEnv) == 1;
+  bool bySample = lookupWanted && !forced;
+  const unsigned *sampleAlive = bySample ? (const unsigned *)(w + kSampleAt) : nullptr;
+  bool lookupFirst = forced;
+  if (bySample) {
     hipLaunchKernelGGL(sampleAliveKernel, dim3(kSamples / 256u), dim3(256), 0, s, g->dev, dChars, fixedLength, depth, useNext, nq, kSamples,
                        (unsigned *)(w + kSampleAt));
     BUCKET_TRY(hipGetLastError());
-    BUCKET_TRY(hipMemcpyAsync(&sampleAlive, w + kSampleAt, sizeof sampleAlive, hipMemcpyDeviceToHost, s));
-    BUCKET_TRY(hipStreamSynchronize(s));
-    lookupFirst = sampleAlive * 4u < kSamples;
-  }
-  g->orderLookupFirst = lookupFirst;
-  g->orderKeptAt = bucketStart + bins; /* the scan's total */
-  if (lookupFirst) {
-    const bool timed = getenv("AWFM_GPU_TIME_ORDERED") != nullptr;
-    if (timed && !g->orderTiming[0]) {
-      BUCKET_TRY(hipEventCreate(&g->orderTiming[0]));
-      BUCKET_TRY(hipEventCreate(&g->orderTiming[1]));
+    if (getenv("AWFM_GPU_LOOKUP_HOST_DECIDES")) {
+      unsigned alive = 0;
+      BUCKET_TRY(hipMemcpyAsync(&alive, w + kSampleAt, sizeof alive, hipMemcpyDeviceToHost, s));
+      BUCKET_TRY(hipStreamSynchronize(s));
+      lookupFirst = alive * 4u < kSamples;
+      bySample = false;
+      sampleAlive = nullptr;
     }
-    if (timed) BUCKET_TRY(hipEventRecord(g->orderTiming[0], s));
+  }
+  g->orderLookup = bySample ? 2 : (lookupFirst ? 1 : 0);
+  g->orderSampleAt = (const unsigned *)(w + kSampleAt);
+  g->orderSamples = kSamples;
+  g->orderKeptAt = bucketStart + bins; /* the scan's total */
+  g->orderTimedFront = false;
+  if (lookupFirst || bySample) {
+    const bool timed = g->orderTiming[0] != nullptr; /* this search has an entry in the timing log: the events ride on the dispatch */
     launchEncodeLookupAt<32u>(fixedLength, encodeGrid, bins * 4u, s, g->dev, dChars, fmt, useNext, nq, (unsigned long long *)(w + codesAt), numbers,
-                              shareCount, hist, binsPad);
-    if (timed) BUCKET_TRY(hipEventRecord(g->orderTiming[1], s));
-    g->orderTimed = timed;
+                              shareCount, hist, binsPad, sampleAlive, kSamples, timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr);
+    g->orderTimedFront = timed;
+    if (timed) g->orderLog[(g->orderLogCount - 1u) % AwFmGpuIndex::kOrderLogMax].front = true;
+    BUCKET_TRY(hipGetLastError());
+  }
+  if (lookupFirst) {
+    /* (forced or decided by the host: the other front end is not launched) */
   } else if (packed)
     hipLaunchKernelGGL((encodeCodesKernel<true>), dim3(encodeGrid), dim3(256), bins * 4u, s, dChars, fixedLength, fmt, nq,
                        (unsigned long long *)nullptr, hist, binsPad);
-  else if (getenv("AWFM_GPU_ENCODE_ONE")) /* measurement knob: one k-mer per thread */
+  else if (getenv("AWFM_GPU_ENCODE_ONE")) /* measurement knob: one k-mer per thread (never beside a sample) */
     hipLaunchKernelGGL((encodeCodesKernel<false>), dim3(encodeGrid), dim3(256), bins * 4u, s, dChars, fixedLength, fmt, nq,
                        (unsigned long long *)(w + codesAt), hist, binsPad);
   else
-    launchEncode4(fixedLength, encodeGrid, bins * 4u, s, dChars, fmt, nq, (unsigned long long *)(w + codesAt), hist, binsPad);
+    launchEncode4(fixedLength, encodeGrid, bins * 4u, s, dChars, fmt, nq, (unsigned long long *)(w + codesAt), hist, binsPad, sampleAlive, kSamples);
   BUCKET_TRY(hipGetLastError());
   hipLaunchKernelGGL(bucketScanSharesKernel, dim3(1), dim3(1024), 0, s, hist, bins, binsPad, bucketStart, generalCount, (unsigned)nq);
   BUCKET_TRY(hipGetLastError());
@@ -440,15 +609,15 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   unsigned partitionGrid = (unsigned)(tilesPerShare * kShares < (unsigned long long)g->numCUs ? tilesPerShare * kShares : (unsigned long long)g->numCUs);
   partitionGrid = (partitionGrid + kShares - 1u) / kShares * kShares;
   hipLaunchKernelGGL(partitionKernel, dim3(partitionGrid), dim3(kPartitionThreads), partitionLds, s, codes, fixedLength, fmt, nq,
-                     (const unsigned *)hist, cursors, recs, packed ? 0u : 1u, lookupFirst ? (const unsigned *)shareCount : (const unsigned *)nullptr,
-                     lookupFirst ? (const unsigned *)numbers : (const unsigned *)nullptr);
+                     (const unsigned *)hist, cursors, recs, packed ? 0u : 1u,
+                     lookupFirst || bySample ? (const unsigned *)shareCount : (const unsigned *)nullptr,
+                     lookupFirst || bySample ? (const unsigned *)numbers : (const unsigned *)nullptr, sampleAlive, kSamples);
   BUCKET_TRY(hipGetLastError());
   const enum AwFmReturnCode rc =
       awfmImageNarrow(g) ? launchBucketed<true>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse)
                          : launchBucketed<false>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse);
   if (rc != AwFmSuccess) return -(int)rc;
-  BUCKET_TRY(hipEventRecord(g->orderEvent, s));
-  g->orderEventRecorded = true;
+  BUCKET_TRY(orderEndSlot(g, s));
 #undef BUCKET_TRY
   return 1;
 }
@@ -468,7 +637,11 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   const size_t histAt = kOrderCounterBytes, cursorsAt = histAt + alignUp256(bins * 4u), startAt = cursorsAt + alignUp256(bins * 4u);
   const size_t inAt = startAt + alignUp256((bins + 1u) * 4u), outAt = inAt + alignUp256(nq * sizeof(QueryRec));
   const size_t total = outAt + alignUp256(nq * sizeof(QueryRec));
-  if (!ensureOrderScratch(g, total)) return 0;
+  if (orderBeginSlot(g, s) != hipSuccess) {
+    setError("seed-order search: could not order the use of its scratch across streams");
+    return -(int)AwFmGeneralFailure;
+  }
+  if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
 #define WIDE_TRY(call)                      \
   do {                                      \
     hipError_t e__ = (call);                \
@@ -477,8 +650,6 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
       return -(int)AwFmGeneralFailure;      \
     }                                       \
   } while (0)
-  if (!g->orderEvent) WIDE_TRY(hipEventCreateWithFlags(&g->orderEvent, hipEventDisableTiming));
-  if (g->orderEventRecorded) WIDE_TRY(hipStreamWaitEvent(s, g->orderEvent, 0));
   uint8_t *w = (uint8_t *)g->dOrder;
   unsigned *generalCount = (unsigned *)w;
   unsigned *hist = (unsigned *)(w + histAt), *cursors = (unsigned *)(w + cursorsAt), *bucketStart = (unsigned *)(w + startAt);
@@ -528,8 +699,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   else rc = narrow ? WIDE_GO(true, false) : WIDE_GO(false, false);
 #undef WIDE_GO
   if (rc != AwFmSuccess) return -(int)rc;
-  WIDE_TRY(hipEventRecord(g->orderEvent, s));
-  g->orderEventRecorded = true;
+  WIDE_TRY(orderEndSlot(g, s));
 #undef WIDE_TRY
   return 1;
 }
@@ -543,7 +713,26 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   if (!orderedApplies(g, off != nullptr, fixedLength, nq, &depth, &table)) return 0;
 
   std::lock_guard<std::mutex> lock(g->orderMutex);
-  g->orderLookupFirst = false;
+  g->orderLookup = 0;
+  g->orderTimedFront = false;
+  g->orderTimedKernel = false;
+  for (int i = 0; i < 4; i++) g->orderTiming[i] = nullptr;
+  if (getenv("AWFM_GPU_TIME_ORDERED")) { /* measurement hook: this search's entry of the timing log */
+    DeviceGuard guard(g->device);
+    const unsigned at = (unsigned)(g->orderLogCount % AwFmGpuIndex::kOrderLogMax);
+    if (at >= g->orderLog.size()) g->orderLog.resize(at + 1u);
+    AwFmGpuIndex::OrderLogEntry &entry = g->orderLog[at];
+    bool ok = true;
+    for (int i = 0; i < 4 && ok; i++)
+      if (!entry.ev[i]) ok = hipEventCreate(&entry.ev[i]) == hipSuccess;
+    if (ok) {
+      entry.front = entry.kernel = false;
+      for (int i = 0; i < 4; i++) g->orderTiming[i] = entry.ev[i];
+      g->orderLogCount++;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   /* 8-byte records: fixed-length batches of short enough k-mers */
   /* fixed-length batches whose records fit 8 bytes: counted and partitioned by the kernels of awfm_ordered_kernel.h
    * ($AWFM_GPU_ORDERED_SORT=rocprim: the earlier encode + radix sort of (16-bit key, record) pairs, for comparison) */
@@ -578,27 +767,11 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
     return -(int)AwFmGeneralFailure;
   }
   const OrderScratch l = scratchLayout(nq, compact ? 8 : sizeof(QueryRec), sortTemp);
-  if (l.total > g->orderBytes) {
-    /* hipFree waits for every stream of the device, so nothing still reads the old scratch */
-    if (g->dOrder) (void)hipFree(g->dOrder);
-    g->dOrder = nullptr;
-    g->orderBytes = 0;
-    const size_t want = l.total + l.total / 8;
-    if (hipMalloc(&g->dOrder, want) != hipSuccess) {
-      (void)hipGetLastError();
-      return 0; /* no room for the scratch: the general kernel needs none */
-    }
-    g->orderBytes = want;
-  }
-  if (!g->orderEvent && hipEventCreateWithFlags(&g->orderEvent, hipEventDisableTiming) != hipSuccess) {
-    setError("awfmGpuSearchHits: hipEventCreate failed");
+  if (orderBeginSlot(g, s) != hipSuccess) {
+    setError("seed-order search: could not order the use of its scratch across streams");
     return -(int)AwFmGeneralFailure;
   }
-  /* the scratch is shared by all searches on this image: order them across streams */
-  if (g->orderEventRecorded && hipStreamWaitEvent(s, g->orderEvent, 0) != hipSuccess) {
-    setError("awfmGpuSearchHits: hipStreamWaitEvent failed");
-    return -(int)AwFmGeneralFailure;
-  }
+  if (!ensureOrderScratch(g, l.total)) return kOrderNoScratch; /* no room for the scratch: the general kernel needs none */
   uint8_t *w = (uint8_t *)g->dOrder;
   unsigned *generalCount = (unsigned *)(w + l.generalCount);
   unsigned short *keysIn = (unsigned short *)(w + l.keysIn), *keysOut = (unsigned short *)(w + l.keysOut);
@@ -660,8 +833,7 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   else rc = narrow ? ORDER_GO(true, false, false) : ORDER_GO(false, false, false);
 #undef ORDER_GO
   if (rc != AwFmSuccess) return -(int)rc;
-  ORDER_TRY(hipEventRecord(g->orderEvent, s));
-  g->orderEventRecorded = true;
+  ORDER_TRY(orderEndSlot(g, s));
 #undef ORDER_TRY
   return 1;
 }
@@ -902,8 +1074,7 @@ extern "C" enum AwFmReturnCode awfmGpuSortHits(AwFmGpuIndex *g, uint32_t *dHitKm
     g->sparseBytes = total + total / 4;
   }
   /* the temporaries are shared by every sort on this image: order their use across streams (as the searches' scratch is) */
-  if (!g->orderEvent) AWFM_HIP_TRY(hipEventCreateWithFlags(&g->orderEvent, hipEventDisableTiming), AwFmGeneralFailure);
-  if (g->orderEventRecorded) AWFM_HIP_TRY(hipStreamWaitEvent(s, g->orderEvent, 0), AwFmGeneralFailure);
+  AWFM_HIP_TRY(gateEnter(g->sparseGate, s), AwFmGeneralFailure);
   uint8_t *w = (uint8_t *)g->dSparse;
   unsigned *keysOut = (unsigned *)(w + keysAt);
   ulonglong2 *valuesOut = (ulonglong2 *)(w + valuesAt);
@@ -912,7 +1083,133 @@ extern "C" enum AwFmReturnCode awfmGpuSortHits(AwFmGpuIndex *g, uint32_t *dHitKm
                AwFmGeneralFailure);
   AWFM_HIP_TRY(hipMemcpyAsync(dHitKmers, keysOut, (size_t)numEntries * 4u, hipMemcpyDeviceToDevice, s), AwFmGeneralFailure);
   AWFM_HIP_TRY(hipMemcpyAsync(dHitRanges, valuesOut, (size_t)numEntries * 16u, hipMemcpyDeviceToDevice, s), AwFmGeneralFailure);
-  AWFM_HIP_TRY(hipEventRecord(g->orderEvent, s), AwFmGeneralFailure);
-  g->orderEventRecorded = true;
+  AWFM_HIP_TRY(gateLeave(g->sparseGate, s, false), AwFmGeneralFailure);
+  return AwFmSuccess;
+}
+
+/* ---- the list of hits put in k-mer order without the host knowing how long it is ----
+ * The k-mer numbers of a list are distinct and below numQueries, so the place of an entry in k-mer order is the number of
+ * listed k-mers before it: a bitmap of the batch (one bit per k-mer, 12.5 MB for 10^8), a count per 4096 bits, one scan of
+ * those counts, and every entry finds its rank by popcounts.  Every kernel has a fixed grid and reads the list's length
+ * from the device word the search left it in, so nothing waits for the host (awfmGpuSortHits, a radix sort, needs the
+ * length on the host -- a stream synchronisation per batch -- or sorts the list's whole capacity). */
+namespace {
+constexpr unsigned kRankBlockWords = 64; /* 64-bit words per counted block: 4096 k-mers */
+__global__ void __launch_bounds__(256) rankMarkKernel(const unsigned *__restrict__ kmers, const ulonglong2 *__restrict__ ranges,
+                                                      const unsigned *__restrict__ count, const unsigned cap, const unsigned long long numQueries,
+                                                      unsigned long long *__restrict__ bitmap, unsigned *__restrict__ tmpKmers,
+                                                      ulonglong2 *__restrict__ tmpRanges) {
+  const unsigned n = *count < cap ? *count : cap;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const unsigned key = kmers[i];
+    tmpKmers[i] = key;
+    tmpRanges[i] = ranges[i];
+    if ((unsigned long long)key < numQueries) atomicOr(bitmap + (key >> 6), 1ull << (key & 63u));
+  }
+}
+/* one wave per block of the bitmap */
+__global__ void __launch_bounds__(256) rankBlockCountKernel(const unsigned long long *__restrict__ bitmap, const unsigned numBlocks,
+                                                            unsigned *__restrict__ blockCount) {
+  const unsigned lane = threadIdx.x & 63u, wavesPerGrid = gridDim.x * 4u;
+  for (unsigned b = blockIdx.x * 4u + (threadIdx.x >> 6); b < numBlocks; b += wavesPerGrid) {
+    unsigned c = (unsigned)__popcll(bitmap[(unsigned long long)b * kRankBlockWords + lane]);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if (lane == 0) blockCount[b] = c;
+  }
+}
+/* exclusive scan of blockCount[0..numBlocks) in place, one workgroup */
+__global__ void __launch_bounds__(1024) rankBlockScanKernel(unsigned *__restrict__ blockCount, const unsigned numBlocks) {
+  __shared__ unsigned sWave[16];
+  __shared__ unsigned sCarry;
+  if (threadIdx.x == 0) sCarry = 0u;
+  __syncthreads();
+  for (unsigned base = 0; base < numBlocks; base += 1024u) {
+    const unsigned e = base + threadIdx.x;
+    const unsigned v = e < numBlocks ? blockCount[e] : 0u;
+    unsigned incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned up = __shfl_up(incl, off);
+      if ((int)(threadIdx.x & 63u) >= off) incl += up;
+    }
+    if ((threadIdx.x & 63u) == 63u) sWave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned before = sCarry;
+    for (unsigned w = 0; w < (threadIdx.x >> 6); w++) before += sWave[w];
+    if (e < numBlocks) blockCount[e] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023u) sCarry = before + incl;
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) rankPlaceKernel(const unsigned *__restrict__ tmpKmers, const ulonglong2 *__restrict__ tmpRanges,
+                                                       const unsigned *__restrict__ count, const unsigned cap, const unsigned long long numQueries,
+                                                       const unsigned long long *__restrict__ bitmap, const unsigned *__restrict__ blockStart,
+                                                       unsigned *__restrict__ kmers, ulonglong2 *__restrict__ ranges) {
+  const unsigned n = *count < cap ? *count : cap;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const unsigned key = tmpKmers[i];
+    if ((unsigned long long)key >= numQueries) continue; /* not a k-mer of the batch: the entry stays where the search put it */
+    const unsigned word = key >> 6, block = word / kRankBlockWords;
+    unsigned rank = blockStart[block];
+    for (unsigned w = block * kRankBlockWords; w < word; w++) rank += (unsigned)__popcll(bitmap[w]);
+    rank += (unsigned)__popcll(bitmap[word] & ((1ull << (key & 63u)) - 1ull));
+    kmers[rank] = key;
+    ranges[rank] = tmpRanges[i];
+  }
+}
+}  // namespace
+
+/* see include/awfm_gpu.h */
+extern "C" enum AwFmReturnCode awfmGpuSortHitsOnDevice(AwFmGpuIndex *g, uint32_t *dHitKmers, struct AwFmSearchRange *dHitRanges,
+                                                       uint32_t capacity, const uint32_t *dNumHits, uint64_t numQueries, void *stream) {
+  if (!g || !dHitKmers || !dHitRanges || !dNumHits) {
+    setError("awfmGpuSortHitsOnDevice: null argument");
+    return AwFmNullPtrError;
+  }
+  if (capacity == 0 || numQueries == 0 || numQueries >= 0xFFFFFFFFull) {
+    setError("awfmGpuSortHitsOnDevice: a list needs a capacity and a batch of 1 .. 2^32 - 2 k-mers");
+    return AwFmIllegalPositionError;
+  }
+  DeviceGuard guard(g->device);
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  const unsigned numBlocks = (unsigned)((numQueries + 64ull * kRankBlockWords - 1ull) / (64ull * kRankBlockWords));
+  const size_t bitmapBytes = (size_t)numBlocks * kRankBlockWords * 8u;
+  const size_t countsAt = alignUp256(bitmapBytes), keysAt = countsAt + alignUp256((size_t)numBlocks * 4u);
+  const size_t valuesAt = keysAt + alignUp256((size_t)capacity * 4u), total = valuesAt + alignUp256((size_t)capacity * 16u);
+  if (total > g->sparseBytes) {
+    if (g->dSparse) (void)hipFree(g->dSparse);
+    g->dSparse = nullptr;
+    g->sparseBytes = 0;
+    if (hipMalloc(&g->dSparse, total + total / 4) != hipSuccess) {
+      (void)hipGetLastError();
+      setError("awfmGpuSortHitsOnDevice: no device memory for the bitmap of the batch");
+      return AwFmAllocationFailure;
+    }
+    g->sparseBytes = total + total / 4;
+  }
+  /* the temporaries are shared by every sort on this image: order their use across streams (as the searches' scratch is) */
+  AWFM_HIP_TRY(gateEnter(g->sparseGate, s), AwFmGeneralFailure);
+  uint8_t *w = (uint8_t *)g->dSparse;
+  unsigned long long *bitmap = (unsigned long long *)w;
+  unsigned *blockCount = (unsigned *)(w + countsAt), *tmpKmers = (unsigned *)(w + keysAt);
+  ulonglong2 *tmpRanges = (ulonglong2 *)(w + valuesAt);
+  AWFM_HIP_TRY(hipMemsetAsync(bitmap, 0, bitmapBytes, s), AwFmGeneralFailure);
+  const unsigned listGrid = (capacity + 255u) / 256u < (unsigned)g->numCUs * 4u ? (capacity + 255u) / 256u : (unsigned)g->numCUs * 4u;
+  hipLaunchKernelGGL(rankMarkKernel, dim3(listGrid), dim3(256), 0, s, (const unsigned *)dHitKmers, (const ulonglong2 *)dHitRanges,
+                     (const unsigned *)dNumHits, (unsigned)capacity, (unsigned long long)numQueries, bitmap, tmpKmers, tmpRanges);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  const unsigned countGrid = (numBlocks + 3u) / 4u < (unsigned)g->numCUs * 8u ? (numBlocks + 3u) / 4u : (unsigned)g->numCUs * 8u;
+  hipLaunchKernelGGL(rankBlockCountKernel, dim3(countGrid), dim3(256), 0, s, (const unsigned long long *)bitmap, numBlocks, blockCount);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  hipLaunchKernelGGL(rankBlockScanKernel, dim3(1), dim3(1024), 0, s, blockCount, numBlocks);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  /* the last kernel carries the gate's event as its stop event */
+  const bool eager = !(gateLazy(s) && !getenv("AWFM_GPU_EAGER_EVENTS"));
+  hipExtLaunchKernelGGL(rankPlaceKernel, dim3(listGrid), dim3(256), 0, s, nullptr, eager ? g->sparseGate.done : nullptr, 0, (const unsigned *)tmpKmers,
+                        (const ulonglong2 *)tmpRanges, (const unsigned *)dNumHits, (unsigned)capacity, (unsigned long long)numQueries,
+                        (const unsigned long long *)bitmap, (const unsigned *)blockCount, (unsigned *)dHitKmers, (ulonglong2 *)dHitRanges);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  AWFM_HIP_TRY(gateLeave(g->sparseGate, s, eager), AwFmGeneralFailure);
   return AwFmSuccess;
 }

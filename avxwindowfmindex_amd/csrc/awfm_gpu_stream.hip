@@ -411,7 +411,7 @@ static enum AwFmReturnCode searchHitsPacked(AwFmGpuIndex *g, const uint64_t *dPa
     DeviceGuard guard(g->device);
     const int ordered = awfmGpuOrderedSearch(g, (hipStream_t)stream, (const uint8_t *)dPacked, nullptr, kmerLength, numKmers,
                                              (ulonglong2 *)dRanges, dCounts, true, rangesOfHitsOnly && dCounts);
-    if (ordered < 0) return (enum AwFmReturnCode)(-ordered);
+    if (ordered < 0 && ordered != -(int)AwFmAllocationFailure) return (enum AwFmReturnCode)(-ordered);
     if (ordered > 0) return AwFmSuccess;
   }
   if (!dCharsScratch) {
@@ -553,15 +553,25 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
         const bool fused = awfmGpuSearchHitsIsOrdered(g, 0, kmerLength, s.n) != 0 && !denseList;
         const uint32_t cap = (uint32_t)(fused ? (s.n / 64 > 1024 ? s.n / 64 : 1024) : s.n);
         STEP_RC(ensureList(s, cap, fused ? 0 : chunkKmers));
+        uint32_t capUsed = cap;
         if (fused) {
-          STEP_RC(awfmGpuSearchHitsCompact(g, (const uint8_t *)s.dIn, nullptr, kmerLength, s.n, packed, (uint32_t *)s.dHitKmers,
-                                           (struct AwFmSearchRange *)s.dHitRanges, cap, (uint32_t *)s.dNumHits, comp));
-          STEP_RC(awfmGpuSortHits(g, (uint32_t *)s.dHitKmers, (struct AwFmSearchRange *)s.dHitRanges, cap, comp));
+          rc = awfmGpuSearchHitsCompact(g, (const uint8_t *)s.dIn, nullptr, kmerLength, s.n, packed, (uint32_t *)s.dHitKmers,
+                                        (struct AwFmSearchRange *)s.dHitRanges, cap, (uint32_t *)s.dNumHits, comp);
+          if (rc == AwFmAllocationFailure) {
+            /* no memory for the seed-order scratch: the list out of dense results (general kernel), for this chunk and the rest */
+            denseList = true;
+            capUsed = (uint32_t)s.n;
+            STEP_RC(ensureList(s, capUsed, chunkKmers));
+            STEP_RC(denseToList(g, s, packed, kmerLength, comp));
+          } else {
+            STEP_RC(rc);
+            STEP_RC(awfmGpuSortHits(g, (uint32_t *)s.dHitKmers, (struct AwFmSearchRange *)s.dHitRanges, cap, comp));
+          }
         } else {
           STEP_RC(denseToList(g, s, packed, kmerLength, comp));
         }
-        s.capUsed = cap;
-        STEP_RC(awfmGpuHitOffsetsAsync(g, nullptr, (const struct AwFmSearchRange *)s.dHitRanges, cap, (uint64_t *)s.dListOffsets,
+        s.capUsed = capUsed;
+        STEP_RC(awfmGpuHitOffsetsAsync(g, nullptr, (const struct AwFmSearchRange *)s.dHitRanges, capUsed, (uint64_t *)s.dListOffsets,
                                        s.dScratch, s.hTotal, comp));
         STEP_TRY(hipMemcpyAsync(s.hTotal + 1, s.dNumHits, 4, hipMemcpyDeviceToHost, comp));
       } else {

@@ -62,8 +62,15 @@ constexpr int walkThreads(bool pair) { return pair ? 512 : kThreads; }
  * the kernel's time is the length of that chain: 0.16 ms with batches of 16) */
 template <bool AMINO, int G, bool POW2, bool NARROW, bool PAIR = false, unsigned PERLANE = 4u>
 __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80)))
-    walkKernel(const DevIndex ix, unsigned long long totalHits, unsigned long long *__restrict__ positions) {
+    walkKernel(const DevIndex ix, unsigned long long totalHits, unsigned long long *__restrict__ positions,
+               const unsigned long long *__restrict__ totalOnDevice = nullptr) {
   static_assert(!PAIR || (!AMINO && G == 4), "pair steps: nucleotide images, 4 lanes per hit");
+  /* the number of hits may still be on the device when the kernel is launched (awfmGpuLocateOnDevice: the total of the
+   * scan, never read by the host); totalHits is then the capacity of `positions` */
+  if (totalOnDevice) {
+    const unsigned long long t = *totalOnDevice;
+    totalHits = t < totalHits ? t : totalHits;
+  }
   constexpr int S = (int)kSlices / G;
   constexpr int V = AMINO ? 2 : 1;
   constexpr int kGroups = walkThreads(PAIR) / G;
@@ -284,7 +291,11 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
 /* out == positions: in place.  Otherwise every entry is written to `out`, which may be page-locked host memory (the
  * pipeline of awfm_gpu_stream.hip lets the kernel that produces the positions deliver them: sequential 8-byte stores) */
 __global__ void finishKernel(const DevIndex ix, unsigned long long totalHits, const unsigned long long *positions,
-                             unsigned long long *out) {
+                             unsigned long long *out, const unsigned long long *__restrict__ totalOnDevice = nullptr) {
+  if (totalOnDevice) {
+    const unsigned long long t = *totalOnDevice;
+    totalHits = t < totalHits ? t : totalHits;
+  }
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   const bool inPlace = out == positions;
   for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < totalHits; t += stride) {

@@ -269,6 +269,13 @@ __device__ __forceinline__ unsigned ldsCountRank(unsigned *counters, unsigned bi
   return valid ? atomicAdd(&counters[bin], 1u) : 0u;
 }
 
+/* "Lookup first" chosen on the device: sampleAliveKernel leaves the number of its samples that are alive in a device
+ * word, and the kernels of BOTH front ends are launched -- the one the sample does not choose returns at once -- so that
+ * a search never waits for the host to read that word.  sampleAlive == nullptr: no sample was taken, `otherwise` says. */
+__device__ __forceinline__ bool lookupChosen(const unsigned *__restrict__ sampleAlive, const unsigned samples, const bool otherwise) {
+  return sampleAlive ? *sampleAlive * 4u < samples : otherwise;
+}
+
 constexpr unsigned long long kCodeNone = 1ull << 62;    /* no k-mer: an unused slot of a block encodeLookupKernel reserved */
 constexpr unsigned kLookupBlock = 64;                   /* slots a wave of encodeLookupKernel reserves at a time */
 constexpr unsigned kShareCountStride = 64;              /* words between the shares' slot counters (a line each) */
@@ -348,14 +355,15 @@ __global__ void __launch_bounds__(256)
  * K whole dwords wherever the batch starts -- with 16-byte loads, brings them to dword alignment once (the misalignment of
  * the batch is the same for every thread), and takes the four k-mers apart at compile-time offsets: K / 4 + 1 load
  * instructions per four k-mers instead of K / 4 + 2 per k-mer (encodeCodesKernel: one k-mer per thread at a 21-byte
- * stride), which is what bounds that kernel, not the bytes.  The last k-mers of a batch (fewer than five) go one by one. */
+ * stride), which is what bounds that kernel, not the bytes.  The last k-mers of a batch (those whose loads would run past its end) go one by one. */
 typedef unsigned Dwords4 __attribute__((ext_vector_type(4), aligned(4))); /* a 16-byte load at dword alignment */
 template <unsigned K>
 __global__ void __launch_bounds__(256)
     encodeCodes4Kernel(const unsigned char *__restrict__ chars, const BucketFormat f, const unsigned long long numQueries,
                        unsigned long long *__restrict__ codesOut, unsigned *__restrict__ hist /* [kShares][binsPad] */,
-                       const unsigned binsPad) {
+                       const unsigned binsPad, const unsigned *__restrict__ sampleAlive = nullptr, const unsigned samples = 0u) {
   extern __shared__ unsigned sHist[]; /* 2^bucketBits + 1 */
+  if (lookupChosen(sampleAlive, samples, false)) return; /* this batch is encodeLookupKernel's (uniform) */
   const unsigned bins = (1u << f.bucketBits) + 1u;
   for (unsigned e = threadIdx.x; e < bins; e += 256u) sHist[e] = 0u;
   __syncthreads();
@@ -368,7 +376,7 @@ __global__ void __launch_bounds__(256)
   for (unsigned long long t = first + 4ull * ((unsigned long long)localBlock * 256ull + threadIdx.x); t < last; t += 4ull * localGrid * 256ull) {
     unsigned long long codes[4];
     unsigned bad[4];
-    if (t + 4ull < numQueries) { /* four whole k-mers and at least one behind them: no load leaves the batch */
+    if (t * K + 16ull * kLoads <= numQueries * K) { /* the 16-byte loads from the aligned-down start stay inside the batch */
       const GlobalDwords4 first = (GlobalDwords4)(((unsigned long long)chars + t * K) & ~3ull);
       unsigned dw[kLoads * 4u + 1u];
 #pragma unroll
@@ -441,8 +449,9 @@ __global__ void __launch_bounds__(256)
     encodeLookupKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const BucketFormat f, const unsigned useNext,
                        const unsigned long long numQueries, unsigned long long *__restrict__ codesOut,
                        unsigned *__restrict__ numbersOut, unsigned *__restrict__ shareCount, unsigned *__restrict__ hist,
-                       const unsigned binsPad) {
+                       const unsigned binsPad, const unsigned *__restrict__ sampleAlive = nullptr, const unsigned samples = 0u) {
   extern __shared__ unsigned sHist[]; /* 2^bucketBits + 1 */
+  if (!lookupChosen(sampleAlive, samples, true)) return; /* this batch is encodeCodes4Kernel's (uniform) */
   const unsigned bins = (1u << f.bucketBits) + 1u;
   for (unsigned e = threadIdx.x; e < bins; e += 256u) sHist[e] = 0u;
   __syncthreads();
@@ -461,7 +470,7 @@ __global__ void __launch_bounds__(256)
     const unsigned long long t = tw + 4ull * lane;
     unsigned long long codes[4];
     unsigned bad[4];
-    if (t + 4ull < numQueries) { /* four whole k-mers and at least one behind them: no load leaves the batch */
+    if (t * K + 16ull * kLoads <= numQueries * K) { /* the 16-byte loads from the aligned-down start stay inside the batch */
       const GlobalDwords4 from = (GlobalDwords4)(((unsigned long long)chars + t * K) & ~3ull);
       unsigned dw[kLoads * 4u + 1u];
 #pragma unroll
@@ -524,7 +533,10 @@ __global__ void __launch_bounds__(256)
         /* a new block of slots (the counters of the shares are a line apart: returning atomics on one line serialise, and
          * one per wave and round -- 4 * 10^5 of them -- took longer than the whole pass); what is left of the old one holds no k-mer */
         if (blockUsed + lane < blockSlots) codesOut[first + blockBase + blockUsed + lane] = kCodeNone;
-        blockSlots = total > kLookupBlock ? total : kLookupBlock;
+        /* (never rounded up in the round that reaches the end of the share: the share's region holds as many slots as the
+         * share has k-mers, and a round of fewer than 64 k-mers that took 64 would run past it -- into the next region,
+         * or, in the last share, past the code array) */
+        blockSlots = total > kLookupBlock || tw + 256ull > last ? total : kLookupBlock;
         unsigned base = 0;
         if (lane == 0) base = atomicAdd(&shareCount[share * kShareCountStride], blockSlots);
         blockBase = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
@@ -568,8 +580,14 @@ __global__ void __launch_bounds__(256)
       alive = length != 0u && (!useNext || ((e.y >> (16u + ((unsigned)(codes >> (2u * depth)) & 15u))) & 1u) != 0u);
     }
   }
+  /* one atomic per workgroup: a thousand waves each adding to the one word were 12 of this kernel's 17 us */
+  __shared__ unsigned sAlive;
+  if (threadIdx.x == 0) sAlive = 0u;
+  __syncthreads();
   const unsigned n = (unsigned)__popcll(__ballot(alive));
-  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(aliveOut, n);
+  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&sAlive, n);
+  __syncthreads();
+  if (threadIdx.x == 0 && sAlive) atomicAdd(aliveOut, sAlive);
 }
 
 /* The same scan for the shared histogram hist[kShares][binsPad]: bucketStart as below (a bucket's sub-runs are contiguous,
@@ -652,8 +670,12 @@ __global__ void __launch_bounds__(kPartitionThreads)
     partitionKernel(const unsigned long long *__restrict__ codes, const unsigned fixedLen, const BucketFormat f,
                     const unsigned long long numQueries, const unsigned *__restrict__ subStart,
                     unsigned *__restrict__ cursors, unsigned long long *__restrict__ recs, const unsigned honourGeneral,
-                    const unsigned *__restrict__ shareCount = nullptr /* after encodeLookupKernel: code words in the share's region */,
-                    const unsigned *__restrict__ numbers = nullptr /* ... and the k-mer numbers beside them */) {
+                    const unsigned *__restrict__ shareCountIn = nullptr /* after encodeLookupKernel: code words in the share's region */,
+                    const unsigned *__restrict__ numbersIn = nullptr /* ... and the k-mer numbers beside them */,
+                    const unsigned *__restrict__ sampleAlive = nullptr, const unsigned samples = 0u /* lookupChosen: was it that kernel? */) {
+  const bool afterLookup = shareCountIn != nullptr && lookupChosen(sampleAlive, samples, true);
+  const unsigned *__restrict__ shareCount = afterLookup ? shareCountIn : nullptr;
+  const unsigned *__restrict__ numbers = afterLookup ? numbersIn : nullptr;
   extern __shared__ unsigned long long sDyn[];
   unsigned long long *sRec = sDyn;                       /* kPartitionTile records, bucket by bucket */
   unsigned *sCnt = (unsigned *)(sRec + kPartitionTile);  /* records of the tile per bucket */
@@ -1001,6 +1023,11 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   __shared__ unsigned sHitKmers[LIST ? orderedThreads(PAIR) / 64 : 1][kHitBuffer];
   __shared__ unsigned long long sHitRanges[LIST ? orderedThreads(PAIR) / 64 : 1][kHitBuffer][2];
   unsigned hitFill = 0; /* wave-uniform */
+  /* ... and what the waves of a workgroup still hold when they are done goes out in ONE reservation, made by the wave that
+   * finishes last: the waves of the grid end together, and 7168 of them each taking a returning atomic on the list's counter
+   * were a tail of 60-80 us on a kernel that searched 5 * 10^5 k-mers (a word takes 88 atomics per microsecond) */
+  __shared__ unsigned sHitLeft[LIST ? orderedThreads(PAIR) / 64 : 1], sWavesDone;
+  if (LIST && threadIdx.x == 0) sWavesDone = 0u;
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   stageMaskTable(sMask);
   nucStageSuper<NARROW>(ix, sSuper);
@@ -1363,7 +1390,33 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
       baseNext = nextChunk();
     }
   }
-  if (LIST) flushHits();
+  if (LIST) {
+    const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (lane == 0) sHitLeft[w] = hitFill;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    unsigned arrived = 0;
+    if (lane == 0) arrived = atomicAdd(&sWavesDone, 1u);
+    arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+    if (arrived == kWaves - 1u) { /* wave-uniform: every wave's leftovers are in LDS */
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      unsigned total = 0;
+      for (unsigned v = 0; v < kWaves; v++) total += sHitLeft[v];
+      if (total != 0u) {
+        unsigned listBase = 0;
+        if (lane == 0) listBase = atomicAdd(sparse.count, total);
+        listBase = (unsigned)__builtin_amdgcn_readfirstlane((int)listBase);
+        unsigned before = 0;
+        for (unsigned v = 0; v < kWaves; v++) {
+          const unsigned n = sHitLeft[v]; /* at most kHitBuffer <= 64 */
+          if (lane < n && listBase + before + lane < sparse.cap) {
+            sparse.kmers[listBase + before + lane] = sHitKmers[v][lane];
+            sparse.ranges[listBase + before + lane] = make_ulonglong2(sHitRanges[v][lane][0], sHitRanges[v][lane][1]);
+          }
+          before += n;
+        }
+      }
+    }
+  }
 }
 
 

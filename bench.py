@@ -8,9 +8,10 @@ awFmParallelSearchLocate (ref src/AwFmParallelSearch.c:95-157).
 
 Workload (BASELINE.json configs[2]): 100 M uniform random 21-mers, locate, index of a 3.1 Gbp
 uniform synthetic text, SA compression 8, seed table k=12, one index replica per GPU, the query
-batch sharded over the ranks with no collective.  --scaling weak (default): every rank has its own
-100 M k-mers of a 100 M x N batch; --scaling strong: ONE batch of --queries k-mers cut into N contiguous
-shards (configs[2] as written: "query batch sharded 1->8").  `--workload planted` runs the secondary
+batch sharded over the ranks with no collective.  --scaling strong (default; configs[2] as written: "query
+batch sharded 1->8"): ONE batch of --queries k-mers cut into N contiguous shards; --scaling weak: every rank
+has its own 100 M k-mers of a 100 M x N batch.  A 1-GPU run also times the shards 2, 4 and 8 ranks would hold
+(`scaling_proxy`).  `--workload planted` runs the secondary
 case (k-mers drawn from the text, >=1 hit each), `--workload mixed` configs[4] (8..30-mers; shards
 balanced by the sum of the lengths).
 
@@ -55,8 +56,9 @@ def parse():
                    help="--workload mixed: the k-mer lengths (configs[4]: 8 30)")
     p.add_argument("--mode", choices=["locate", "count"], default=None,
                    help="default: locate (mixed lengths: count; --workload mixed --mode locate is 2 M k-mers located in windows)")
-    p.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                   help="weak: --queries k-mers per GPU; strong: --queries k-mers in total, cut into --gpus shards")
+    p.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                   help="strong (default; configs[2]: ONE batch of --queries k-mers, sharded over the --gpus ranks) | "
+                        "weak: --queries k-mers per GPU")
     count = lambda v: int(float(v))  # noqa: E731  ("3e6" is accepted)
     p.add_argument("--text-len", type=count, default=None, help="default 3.1e9 (dna) / 2e8 (amino)")
     p.add_argument("--queries", type=count, default=None, help="k-mers per GPU per step (strong: in total); default 1e8 (dna) / 5e7 (amino)")
@@ -72,6 +74,11 @@ def parse():
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-e2e", action="store_true", help="skip the host-inclusive end_to_end leg")
     p.add_argument("--no-secondary", action="store_true", help="skip the planted (every k-mer has a hit) line of the default run")
+    p.add_argument("--no-shard-proxy", dest="shard_proxy", action="store_false",
+                   help="skip the single-GPU strong-scaling proxy (the shards 2, 4 and 8 ranks would hold, each timed alone)")
+    p.add_argument("--proxy-steps", type=int, default=5, help="timed steps per shard of the proxy")
+    p.add_argument("--no-dense-form", dest="dense_form", action="store_false",
+                   help="skip timing the dense form of the results beside the form the steps used")
     p.add_argument("--general-steps", type=int, default=3,
                    help="timed steps of the exact-range general kernel for roofline_general (0: skip)")
     p.add_argument("--e2e-aos-queries", type=count, default=10_000_000,
@@ -322,6 +329,7 @@ def main():
                               device=dev.index)
     g = api.GpuIndex(ix, acquire=True)
     build_s = time.time() - t0
+    deep_first_build = g.deep_seed_build  # (seconds, transient bytes) of the table the library built by itself, if it did
     deep_s = 0.0
     if args.device_seed_k >= 0:
         t1 = time.time()
@@ -395,214 +403,248 @@ def main():
     d_hit_off = torch.empty(Q + 1, dtype=torch.int64, device=dev)
     d_scratch = torch.empty(api.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-    state = {"positions": None, "hits": 0, "sparse": True, "windowed": False}
-
-    def ensure_positions(total):
-        if state["positions"] is None or state["positions"].numel() < max(total, 1):
-            state["positions"] = torch.empty(max(total, 1) + total // 8, dtype=torch.int64, device=dev)
-
-    search_events = []
-    locate_events = []
-    ordered_ms = []
-    lookup_steps = []  # per timed step: the search looked the table entries up while encoding (encodeLookupKernel was timed)
     narrow_counts = ix.bwt_length < (1 << 32)  # 32-bit counts are exact: hit offsets can be scanned from them
     ordered = g.search_hits_is_ordered(d_offsets is not None, K, Q)
     if ordered:
-        os.environ["AWFM_GPU_TIME_ORDERED"] = "1"  # HIP events around orderedSearchKernel inside the library
+        os.environ["AWFM_GPU_TIME_ORDERED"] = "1"  # HIP events around the dominant kernel inside the library, logged per search
+    locate = args.mode == "locate"
+    dense_only = bool(os.environ.get("AWFM_BENCH_DENSE_RESULTS"))
 
-    # Sparse results (awfmGpuSearchHitsCompact): when few k-mers of a batch occur -- 7 * 10^4 of 10^8 random 21-mers -- the
-    # k-mers with hits are a LIST {k-mer number, range}, sorted by k-mer number, with hit offsets over that list: nothing
-    # of size 10^8 is filled, scanned or expanded after the search.  Same information as the dense form (a k-mer that is
-    # not listed has count 0).  Dense-hit batches (planted) keep the dense form: decided from the previous step's hits.
-    sparse_cap = max(Q // 64, 1024)
-    can_list = ordered and args.mode == "locate" and not os.environ.get("AWFM_BENCH_DENSE_RESULTS")
-    if can_list:
-        d_hit_kmers = torch.empty(sparse_cap, dtype=torch.int32, device=dev)
-        d_hit_ranges = torch.empty(sparse_cap * 2, dtype=torch.int64, device=dev)
-        d_hit_off_c = torch.empty(sparse_cap + 1, dtype=torch.int64, device=dev)
+    # ---- the forms a step's results can take (config.result_format says which one the timed steps used) ----
+    # "list"  (awfmGpuSearchHitsCompact): when few k-mers of a batch occur -- 7 * 10^4 of 10^8 random 21-mers -- the k-mers with
+    #         hits are a LIST {k-mer number, range}, in k-mer order, with hit offsets over that list: nothing of size 10^8 is
+    #         filled, scanned or expanded after the search.  Same information as the dense form (a k-mer not listed has count 0).
+    # "order" (awfmGpuSearchHitsInOrder): when most k-mers have hits, every k-mer gets an entry {k-mer number, range} in the
+    #         order the seed-order search took it -- whole-line stores instead of 10^8 partial-line ones under the original
+    #         numbers -- and hit offsets and positions follow that order.  A consumer that scatters into per-k-mer lists (the
+    #         AoS API) reads it as it is.
+    # "dense" range / count under every k-mer number + hit offsets over the batch + positions in k-mer order: what the
+    #         reference's own result is, flattened.  `config.dense_form` times it beside whichever form the steps used.
+    # Which one: decided by an untimed PROBE step per batch (it reads the number of listed k-mers and the number of hits back
+    # and sizes the buffers).  The timed steps then run WITHOUT ONE HOST WAIT: the list's length and the hit total are read
+    # on the device (awfmGpuSortHitsOnDevice / awfmGpuHitOffsetsOnDevice / awfmGpuLocateOnDevice), and what they were is
+    # checked against the probe's after the timed region.
+    list_cap = max(Q // 64, 1024)
+    have_list = ordered and locate and not dense_only
+    have_order = ordered and locate and not dense_only
+    if have_list:
+        d_hit_kmers = torch.empty(list_cap, dtype=torch.int32, device=dev)
+        d_hit_ranges = torch.empty(list_cap * 2, dtype=torch.int64, device=dev)
+        d_hit_off_c = torch.empty(list_cap + 1, dtype=torch.int64, device=dev)
         d_num_hits = torch.zeros(1, dtype=torch.int32, device=dev)
-        h_num_hits = torch.zeros(1, dtype=torch.int32).pin_memory()
-    state["listed"] = False  # the last step's results are in the list form
-    # Results in search order (awfmGpuSearchHitsInOrder): when most k-mers of a batch have hits, every k-mer gets an entry
-    # {k-mer number, range} in the order the seed-order search took it -- whole-line stores instead of 10^8 partial-line
-    # ones under the original numbers -- and hit offsets and positions follow that order (the walk's first steps then share
-    # blocks).  Same information; a consumer that scatters into per-k-mer lists (the AoS API) reads it as it is.
-    can_order = ordered and args.mode == "locate" and not os.environ.get("AWFM_BENCH_DENSE_RESULTS")
-    d_order_kmers = torch.empty(Q, dtype=torch.int32, device=dev) if can_order else None
-    state["in_order"] = False
+    d_order_kmers = torch.empty(Q, dtype=torch.int32, device=dev) if have_order else None
+    pos_buf = {"t": None}
 
-    def order_to_dense(order_kmers, order_ranges, order_off, order_pos, total):
-        """the dense form (ranges / hit offsets under every k-mer number, positions in k-mer order) of results in search
-        order; outside the timed region, for the checks"""
-        kmers = order_kmers.to(torch.int64)
-        assert int(torch.bincount(kmers, minlength=Q).max().item()) == 1, "a k-mer is missing from the order or listed twice"
-        lens = order_off[1:] - order_off[:-1]
-        counts = torch.zeros(Q, dtype=torch.int64, device=dev)
-        counts[kmers] = lens
-        dense_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(counts, 0, out=dense_off[1:])
-        dense_ranges = torch.empty(Q, 2, dtype=torch.int64, device=dev)
-        dense_ranges[kmers] = order_ranges.view(Q, 2)
-        dense_pos = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
-        step_q = 1 << 24
-        for b in range(0, Q, step_q):  # destination of every hit: its k-mer's dense offset + its rank in the list
-            e = min(Q, b + step_q)
-            lo, hi = int(order_off[b].item()), int(order_off[e].item())
-            if hi > lo:
-                shift = torch.repeat_interleave(dense_off[:-1][kmers[b:e]] - order_off[b:e], lens[b:e])
-                dense_pos[shift + torch.arange(lo, hi, dtype=torch.int64, device=dev)] = order_pos[lo:hi]
-        return dense_ranges.view(-1), counts.to(torch.int32), dense_off, dense_pos
+    def ensure_positions(total):
+        if pos_buf["t"] is None or pos_buf["t"].numel() < max(total, 1):
+            pos_buf["t"] = None
+            pos_buf["t"] = torch.empty(max(total, 1) + total // 8 + 64, dtype=torch.int64, device=dev)
+        return pos_buf["t"]
 
-    def step(record):
-        if record:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        # counting and locating need the hits only (what awFmParallelSearchCount/Locate report): large
-        # fixed-length batches are searched in seed order, the others by the general kernel
-        use_counts = narrow_counts and state["sparse"]
-        use_list = can_list and state["sparse"]
-        use_order = can_order and not state["sparse"]
-        if use_order:
-            g.search_hits_in_order(d_chars.data_ptr(), off_ptr, K, Q, d_order_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
-        elif use_list:
-            g.search_hits_compact(d_chars.data_ptr(), off_ptr, K, Q, d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), sparse_cap,
+    class Piece:
+        """a contiguous piece [begin, begin + q) of this rank's k-mers: what one step searches (the whole shard, or -- for
+        --shard-proxy -- the part of it one of N ranks would hold)"""
+
+        def __init__(self, begin, q, chars=None):
+            self.begin, self.q = begin, q
+            base = d_chars if chars is None else chars
+            self.chars_ptr = base.data_ptr() + (begin * K if d_offsets is None else 0)
+            self.off_ptr = d_offsets.data_ptr() + 8 * begin if d_offsets is not None else 0
+            self.cap = max(q // 64, 1024)  # the list's capacity
+            # (a small piece may fall below the size from which batches are searched in seed order: dense results then)
+            self.ordered = bool(ordered and g.search_hits_is_ordered(d_offsets is not None, K, q))
+            self.form = None
+            self.hits = self.listed = 0
+            self.windowed = False
+            self.events = []  # per recorded step: (search begin, search end, locate end)
+
+    def search_part(p, form):
+        if not locate:
+            g.search_hits(p.chars_ptr, p.off_ptr, K, p.q, 0, d_counts.data_ptr(), stream)
+        elif form == "list":
+            g.search_hits_compact(p.chars_ptr, p.off_ptr, K, p.q, d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), p.cap,
                                   d_num_hits.data_ptr(), stream=stream)
-        elif args.mode == "locate" and use_counts:
-            # the hit offsets are scanned from the counts and the locate reads the range of a k-mer only when it has
-            # hits: the ranges of the others need not be written
-            g.search_hits_sparse(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr(), d_counts.data_ptr(), stream)
+        elif form == "order":
+            g.search_hits_in_order(p.chars_ptr, p.off_ptr, K, p.q, d_order_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
+        elif narrow_counts:
+            # the hit offsets are scanned from the counts and the locate reads the range of a k-mer only when it has hits: the
+            # ranges of the others need not be written
+            g.search_hits_sparse(p.chars_ptr, p.off_ptr, K, p.q, d_ranges.data_ptr(), d_counts.data_ptr(), stream)
         else:
-            g.search_hits(d_chars.data_ptr(), off_ptr, K, Q, d_ranges.data_ptr() if args.mode == "locate" else 0,
-                          d_counts.data_ptr() if args.mode == "count" else 0, stream)
+            g.search_hits(p.chars_ptr, p.off_ptr, K, p.q, d_ranges.data_ptr(), 0, stream)
+
+    def offsets_part(p, form):
+        """hit offsets on the device; returns (ranges, offsets, entries) the locate reads"""
+        if form == "list":
+            g.sort_hits_on_device(d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), p.cap, d_num_hits.data_ptr(), p.q, stream)
+            g.hit_offsets_on_device(0, d_hit_ranges.data_ptr(), p.cap, d_hit_off_c.data_ptr(), d_scratch.data_ptr(), stream)
+            return d_hit_ranges, d_hit_off_c, p.cap
+        if form == "dense" and narrow_counts:
+            g.hit_offsets_on_device(d_counts.data_ptr(), 0, p.q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
+        else:
+            g.hit_offsets_on_device(0, d_ranges.data_ptr(), p.q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
+        return d_ranges, d_hit_off, p.q
+
+    def probe(p, force=None):
+        """one untimed, synchronous step: which form this piece's results take, how many hits there are, buffers to size"""
+        p.form, p.windowed = "dense", False
+        if not locate:
+            search_part(p, "dense")
+            torch.cuda.synchronize()
+            return
+        form = force or ("list" if have_list and p.ordered else "dense")
+        if form == "list":
+            search_part(p, "list")
+            p.listed = int(d_num_hits.item())
+            if p.listed > p.cap:  # not a sparse batch after all
+                form = "order" if have_order and p.ordered else "dense"
+        if form != "list":
+            search_part(p, form)
+        ranges, offsets, entries = offsets_part(p, form)
+        p.hits = int(offsets[entries].item())
+        if form != "list":
+            p.listed = 0
+            if force is None and form == "dense" and have_order and p.ordered and p.hits >= p.q // 4:
+                return probe(p, "order")  # most k-mers have hits: results in search order
+        p.form = form
+        p.windowed = p.hits > WINDOW_HITS  # a hit list beyond what is kept resident: window by window (awfmGpuLocateWindow)
+        ensure_positions(WINDOW_HITS if p.windowed else p.hits)
+        torch.cuda.synchronize()
+
+    def step(p, record=False):
         if record:
-            e1.record()
-            search_events.append((e0, e1))
-            if ordered:
-                ordered_ms.append(g.last_ordered_kernel_ms())  # waits for that kernel only
-                lookup_steps.append(g.last_ordered_kernel_is_lookup())
-        if args.mode == "locate":
-            if use_order:
-                total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
-                ensure_positions(total)
-                if record:
-                    e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e2.record()
-                g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, state["positions"].data_ptr(), stream)
-                if record:
-                    e3.record()
-                    locate_events.append((e2, e3))
-                state.update(hits=total, listed=False, in_order=True, windowed=False)
-                state["sparse"] = total < Q // 4
-                return
-            if use_list:
-                # how many k-mers are listed (one small wait): the sort and the scan then run over the list, not over its
-                # capacity (sorting 1.5 M mostly empty entries took 0.19 ms of a 5.8 ms step)
-                h_num_hits.copy_(d_num_hits, non_blocking=True)
-                torch.cuda.current_stream().synchronize()
-                listed = int(h_num_hits[0])
-                total = 0
-                if 0 < listed <= sparse_cap:
-                    g.sort_hits(d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), listed, stream)
-                    total = g.hit_offsets(d_hit_ranges.data_ptr(), listed, d_hit_off_c.data_ptr(), d_scratch.data_ptr(), stream)
-                if listed > sparse_cap:  # not a sparse batch after all: this step again, densely
-                    state["sparse"] = False
-                    if record:
-                        search_events.pop()
-                        ordered_ms.pop()
-                        lookup_steps.pop()
-                    return step(record)
-                ensure_positions(total)
-                if record:
-                    e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e2.record()
-                g.locate(d_hit_ranges.data_ptr(), d_hit_off_c.data_ptr(), listed, total, state["positions"].data_ptr(), stream)
-                if record:
-                    e3.record()
-                    locate_events.append((e2, e3))
-                state.update(hits=total, listed=True, num_listed=listed, in_order=False)
-                return
-            if use_counts:  # the scan reads 4-byte counts instead of 16-byte ranges
-                total = g.hit_offsets_from_counts(d_counts.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
-            else:
-                total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
-            window = total > WINDOW_HITS  # a hit list beyond what is kept resident: window by window (awfmGpuLocateWindow)
-            ensure_positions(WINDOW_HITS if window else total)
-            if record:
-                e2, e3 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e2.record()
-            if window:
-                # window boundaries in k-mers: the queries whose lists meet [hb, he) -- found on the device, one sync each
-                bounds = torch.arange(0, total + WINDOW_HITS, WINDOW_HITS, dtype=torch.int64, device=dev).clamp_(max=total)
-                cut = torch.searchsorted(d_hit_off[: Q + 1], bounds, right=True).cpu().tolist()  # first k-mer whose list ends after the bound
-                bounds = bounds.cpu().tolist()
-                state["first_window"] = max(cut[1] - 1, 0)  # k-mers whose whole list lies in the first window
-                for w in range(len(bounds) - 1):
-                    qb, qe = max(cut[w] - 1, 0), min(cut[w + 1], Q)
-                    g.locate_window(d_ranges.data_ptr(), d_hit_off.data_ptr(), qb, qe, bounds[w], bounds[w + 1],
-                                    state["positions"].data_ptr(), stream)
-                    if w == 0 and state.get("keep_first_window"):
-                        state["window0"] = state["positions"][: bounds[1]].clone()
-            else:
-                g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, state["positions"].data_ptr(), stream)
-            if record:
-                e3.record()
-                locate_events.append((e2, e3))
-            state["hits"] = total
-            state["listed"] = False
-            state["in_order"] = False
-            state["windowed"] = window
-            # when most k-mers have hits, a second per-query result (the count) costs a scattered store each in
-            # the ordered search, more than scanning the ranges does: decided from the previous step's hit total
-            state["sparse"] = total < Q // 4
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+        search_part(p, p.form)
+        if record:
+            ev[1].record()
+        if locate and not p.windowed:
+            ranges, offsets, entries = offsets_part(p, p.form)
+            g.locate_on_device(ranges.data_ptr(), offsets.data_ptr(), entries, pos_buf["t"].numel(), pos_buf["t"].data_ptr(), stream)
+        elif locate:
+            # (the one form with host waits: a hit list of 5 * 10^9 positions is located in windows, whose boundaries in
+            # k-mers are found from the offsets)
+            total = g.hit_offsets_from_counts(d_counts.data_ptr(), p.q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream) if narrow_counts \
+                else g.hit_offsets(d_ranges.data_ptr(), p.q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
+            bounds = torch.arange(0, total + WINDOW_HITS, WINDOW_HITS, dtype=torch.int64, device=dev).clamp_(max=total)
+            cut = torch.searchsorted(d_hit_off[: p.q + 1], bounds, right=True).cpu().tolist()  # first k-mer whose list ends after the bound
+            bounds = bounds.cpu().tolist()
+            p.first_window = max(cut[1] - 1, 0)  # k-mers whose whole list lies in the first window
+            for w in range(len(bounds) - 1):
+                qb, qe = max(cut[w] - 1, 0), min(cut[w + 1], p.q)
+                g.locate_window(d_ranges.data_ptr(), d_hit_off.data_ptr(), qb, qe, bounds[w], bounds[w + 1], pos_buf["t"].data_ptr(), stream)
+                if w == 0 and getattr(p, "keep_first_window", False):
+                    p.window0 = pos_buf["t"][: bounds[1]].clone()
+        if record:
+            ev[2].record()
+            p.events.append(ev)
+
+    def check_against_probe(p):
+        """after a loop of steps: what the device read as the list's length and the number of hits is what the probe saw"""
+        if not locate or p.windowed:
+            return
+        if p.form == "list":
+            assert int(d_num_hits.item()) == p.listed, "the list's length changed between the probe and the timed steps"
+            total = int(d_hit_off_c[p.cap].item())
+        else:
+            total = int(d_hit_off[p.q].item())
+        assert total == p.hits and total <= pos_buf["t"].numel(), "the number of hits changed between the probe and the timed steps"
+
+    def to_dense(p):
+        """the dense form of the piece's last step -- ranges ({1, 0} where there is no hit), counts, hit offsets under every
+        k-mer number of the piece (entries [0, q) of d_ranges / d_counts / d_hit_off), positions in k-mer order -- whatever
+        form the step used; outside any timed region: every check reads this"""
+        q = p.q
+        if not locate:
+            return None
+        pos = pos_buf["t"]
+        if p.form == "order":
+            kmers = d_order_kmers[:q].to(torch.int64)
+            assert int(torch.bincount(kmers, minlength=q).max().item()) == 1, "a k-mer is missing from the order or listed twice"
+            order_off = d_hit_off[: q + 1].clone()
+            lens = order_off[1:] - order_off[:-1]
+            counts = torch.zeros(q, dtype=torch.int64, device=dev)
+            counts[kmers] = lens
+            dense_off = torch.zeros(q + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(counts, 0, out=dense_off[1:])
+            dense_ranges = torch.empty(q, 2, dtype=torch.int64, device=dev)
+            dense_ranges[kmers] = d_ranges[: 2 * q].view(q, 2)
+            dense_pos = torch.empty(max(p.hits, 1), dtype=torch.int64, device=dev)
+            step_q = 1 << 24
+            for b in range(0, q, step_q):  # destination of every hit: its k-mer's dense offset + its rank in the list
+                e = min(q, b + step_q)
+                lo, hi = int(order_off[b].item()), int(order_off[e].item())
+                if hi > lo:
+                    shift = torch.repeat_interleave(dense_off[:-1][kmers[b:e]] - order_off[b:e], lens[b:e])
+                    dense_pos[shift + torch.arange(lo, hi, dtype=torch.int64, device=dev)] = pos[lo:hi]
+            d_ranges[: 2 * q].copy_(dense_ranges.view(-1))
+            d_counts[:q].copy_(counts.to(torch.int32))
+            d_hit_off[: q + 1].copy_(dense_off)
+            return dense_pos
+        if p.form == "list":
+            m = p.listed
+            kmers = d_hit_kmers[:m].to(torch.int64)
+            assert m == 0 or bool((kmers[1:] > kmers[:-1]).all()), "the hit list is not in k-mer order"
+            assert m == p.cap or int(d_hit_kmers[m].item()) == -1, "an entry behind the list's length"
+            lens = d_hit_off_c[1:m + 1] - d_hit_off_c[:m]
+            d_counts[:q].zero_()
+            d_counts[:q][kmers] = lens.to(torch.int32)
+            d_hit_off[0] = 0
+            torch.cumsum(d_counts[:q].to(torch.int64), 0, out=d_hit_off[1:q + 1])
+            dense = d_ranges[: 2 * q].view(q, 2)
+            dense[:, 0] = 1
+            dense[:, 1] = 0
+            dense[kmers] = d_hit_ranges.view(-1, 2)[:m]
+            assert int(d_hit_off[q].item()) == p.hits
+            return pos
+        # dense: ranges were written for the k-mers with hits only (awfmGpuSearchHitsSparse): "no hit" for the rest
+        lens = d_hit_off[1:q + 1] - d_hit_off[:q]
+        if narrow_counts:
+            d_ranges[: 2 * q].view(q, 2)[lens == 0] = torch.tensor([1, 0], dtype=torch.int64, device=dev)
+        else:
+            d_counts[:q].copy_(lens.clamp(max=0xFFFFFFFF).to(torch.int32))
+        return pos
 
     def barrier():
         shard.barrier(world, torch.cuda.synchronize)
 
-    for _ in range(args.warmup):
-        step(False)
+    whole = Piece(0, Q)
+    probe(whole)
+    # the warm-up steps carry the events that split a step into its search call and its locate kernels (reporting); the timed
+    # steps carry none: a recorded event is a packet of its own in the queue, about 5 us of idle device each
+    for _ in range(max(args.warmup, 1)):
+        step(whole, True)
+    torch.cuda.synchronize()
+    g.ordered_kernel_log()  # the log of the library's own kernel brackets starts with the timed steps
     barrier()
     t_start = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        step(whole)
     barrier()
     elapsed = time.perf_counter() - t_start
     elapsed = shard.max_over_ranks(elapsed, world, dev)
     ms_per_step = elapsed * 1e3 / args.steps
     value = batch_total / (elapsed / args.steps) / 1e6  # Mkmers/s over all ranks
-    search_ms = float(np.mean([a.elapsed_time(b) for a, b in search_events]))
-    locate_ms = float(np.mean([a.elapsed_time(b) for a, b in locate_events])) if locate_events else 0.0
-    lookup_first = bool(lookup_steps) and all(lookup_steps)  # the timed kernel of every step was encodeLookupKernel
+    check_against_probe(whole)
+    search_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in whole.events]))
+    locate_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in whole.events])) if locate else 0.0
+    kernel_log = g.ordered_kernel_log() if ordered else []
+    assert not ordered or len(kernel_log) == min(args.steps, 1024), "the library logged another number of searches than were timed"
+    lookup_first = bool(ordered and g.last_ordered_kernel_is_lookup())  # the dominant kernel of every step was encodeLookupKernel
     lookup_kept = g.last_ordered_kept() if lookup_first else 0  # before any other search re-uses the scratch
-    if state["windowed"]:  # the positions of the first window, kept for the oracle check of the k-mers that lie in it
-        state["keep_first_window"] = True
-        step(False)
+    ordered_ms = [(f if lookup_first else k) for f, k in kernel_log]
+    after_lookup_ms = float(np.mean([k for _, k in kernel_log])) if lookup_first else None
+    state = {"hits": whole.hits, "listed": whole.form == "list", "in_order": whole.form == "order", "windowed": whole.windowed,
+             "form": whole.form}
+    if whole.windowed:  # the positions of the first window, kept for the oracle check of the k-mers that lie in it
+        whole.keep_first_window = True
+        step(whole)
         torch.cuda.synchronize()
-        state["keep_first_window"] = False
-    if state["in_order"]:
-        # every check below reads the dense form: regroup by k-mer number, outside the timed region
-        r, c, o, p2 = order_to_dense(d_order_kmers, d_ranges, d_hit_off, state["positions"], state["hits"])
-        d_ranges.copy_(r)
-        d_counts.copy_(c)
-        d_hit_off.copy_(o)
-        state["positions"] = p2
-        del r, c, o, p2
-    if state["listed"]:
-        # every check below (oracle sample, digests, pipeline and AoS comparison, dumps) reads the dense form: the list is
-        # expanded into it here, outside the timed region -- counts, hit offsets and ranges under every k-mer number
-        m = state["num_listed"]
-        kmers = d_hit_kmers[:m].to(torch.int64)
-        assert m == 0 or bool((kmers[1:] > kmers[:-1]).all()), "the hit list is not in k-mer order"
-        lens = d_hit_off_c[1:m + 1] - d_hit_off_c[:m]
-        d_counts.zero_()
-        d_counts[kmers] = lens.to(torch.int32)
-        d_hit_off[0] = 0
-        torch.cumsum(d_counts.to(torch.int64), 0, out=d_hit_off[1:])
-        dense = d_ranges.view(Q, 2)
-        dense[:, 0] = 1
-        dense[:, 1] = 0
-        dense[kmers] = d_hit_ranges.view(sparse_cap, 2)[:m]
-        assert int(d_hit_off[-1].item()) == state["hits"]
-        del kmers, lens, dense
+        whole.keep_first_window = False
+        state["window0"], state["first_window"] = whole.window0, whole.first_window
+    # every check below (oracle sample, digests, pipelines, dumps) reads the dense form, made here outside the timed region
+    state["positions"] = to_dense(whole)
+    state["sparse"] = False  # (the dense arrays are complete: ranges of the k-mers without hits are {1, 0}, counts are written)
 
     if args.dump_dir:  # testing: this rank's shard results, for a check against the oracle outside the bench
         os.makedirs(args.dump_dir, exist_ok=True)
@@ -612,9 +654,6 @@ def main():
         else:
             dump["ranges"] = d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2)
             dump["hit_offsets"] = d_hit_off.cpu().numpy().view(np.uint64)
-            if narrow_counts and state["sparse"]:  # ranges were written for the k-mers with hits only: "no hit" for the rest
-                dump["ranges"] = dump["ranges"].copy()
-                dump["ranges"][np.diff(dump["hit_offsets"]) == 0] = (1, 0)
             if not state["windowed"]:
                 dump["positions"] = state["positions"][: state["hits"]].cpu().numpy().view(np.uint64)
         np.savez(os.path.join(args.dump_dir, f"rank{rank}.npz"), **dump)
@@ -674,7 +713,9 @@ def main():
         # algorithm's bytes are not what it has to move: its roofline is its COMPULSORY traffic -- every 128-B line once per search level that needs
         # it, the sorted records, the results -- over its own HIP-event time.
         lines = g.search_hits_line_tally(d_chars.data_ptr(), off_ptr, K, Q)
-        stored = lines["kmers_with_hits"] * ((16 if args.mode == "locate" else 0) + (4 if (args.mode == "count" or (narrow_counts and state["sparse"])) else 0))
+        # what the search stores per result, by the form the timed steps used
+        stored = {"list": 20 * lines["kmers_with_hits"], "order": 20 * lines["ordered_kmers"],
+                  "dense": (16 + (4 if narrow_counts else 0)) * lines["kmers_with_hits"]}[whole.form] if locate else 4 * lines["kmers_with_hits"]
         compulsory = (128 * (lines["seed_table_lines"] + lines["deep_table_lines"] + lines["pair_level_lines"] + lines["nuc_level_lines"])
                       + lines["record_bytes_per_kmer"] * lines["ordered_kmers"] + stored)
         dom_ms = float(np.mean(ordered_ms))
@@ -695,10 +736,25 @@ def main():
                     "device by awfmGpuSearchHitsLineTally: deep_table_lines) + 12 B per k-mer kept; pair_level_lines / "
                     "nuc_level_lines are the lines the kernels AFTER it read for the k-mers kept")
         achieved = compulsory / (dom_ms * 1e-3) / 1e9
+        # NEEDED bytes: what the kernel consumes -- a table lookup is an 8-byte entry (16 from 2^32 positions), not the 128-B
+        # line it arrives in; the block reads of the search levels stay at their distinct lines.  traffic / needed says how
+        # much of what the kernel moves is the rest of a line nobody asked for.
+        entry_bytes = 8 if narrow_counts else 16
+        if lookup_first:
+            needed = Q * K + entry_bytes * Q + 12 * lookup_kept
+        else:
+            needed = (entry_bytes * lines["ordered_kmers"] + 128 * (lines["pair_level_lines"] + lines["nuc_level_lines"])
+                      + lines["record_bytes_per_kmer"] * lines["ordered_kmers"] + stored)
         roofline = {
             "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel_ms": round(dom_ms, 3),
-            "compulsory_bytes": int(compulsory),
+            "basis": "compulsory_lines",
+            "basis_note": "achieved = compulsory_bytes / kernel_ms: every distinct 128-B line the kernel needs, once (the builder's "
+                          "accounting, not SURVEY 8(d)'s); the reference algorithm's bytes over THIS kernel's time would be "
+                          "algorithmic_frac_of_this_kernel (> 1: the deeper table answers most k-mers in one gather, those bytes are "
+                          "never read); the kernel that does execute the reference algorithm's steps is priced in reference_algorithm",
+            "compulsory_bytes": int(compulsory), "needed_bytes": int(needed), "frac_needed": round(needed / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "algorithmic_frac_of_this_kernel": round(alg_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
             "compulsory": {"what": what, **lines, "result_bytes_stored": int(stored)},
             "limiter": "HBM, as a gather of random 128-B lines (the guide measures 5.5-5.8 TB/s for such reads, 0.69-0.73 of the "
                        "peak): most lines are entries of the deeper seed table, one per k-mer; see hbm_frac_measured for this "
@@ -712,6 +768,7 @@ def main():
             roofline["traffic"] = int(counters["hbm_read_bytes"] + counters.get("hbm_write_bytes", 0.0))
             roofline["traffic_source"] = f"{csrc}: {not_this_run}; reads = 2 x FETCH_SIZE (MI355X_MICROARCH.md, HBM), writes = WRITE_SIZE"
             roofline["traffic_over_compulsory"] = round(roofline["traffic"] / compulsory, 3)
+            roofline["traffic_over_needed"] = round(roofline["traffic"] / needed, 3)
             profiled_ms = counters.get("avg_ns_kernel_trace", 0.0) / 1e6
             if profiled_ms and abs(profiled_ms - dom_ms) <= 0.15 * dom_ms:
                 roofline["hbm_frac_measured"] = round(roofline["traffic"] / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -727,6 +784,8 @@ def main():
                               "source": f"{csrc}: TCC_REQ_sum x 128 B over this run's kernel time; peak = the guide's chip-wide rate "
                                         "for rows gathered out of the XCDs' L2s (16.8-18.8 TB/s)"}
         dominant = {"name": dom_name, "ms": round(dom_ms, 3)}
+        if after_lookup_ms is not None:
+            dominant["orderedSearchKernel_over_the_kmers_kept_ms"] = round(after_lookup_ms, 3)
         if counters:
             for key in ("l2_hit_rate", "valu_issue_frac", "wave_wait_frac", "clock_ghz_under_profiler"):
                 if key in counters:
@@ -812,6 +871,14 @@ def main():
         if had_deep:
             g.set_deep_seed(had_deep)
             torch.cuda.synchronize()
+        # the same figures inside `roofline`, flat, for readers that keep its scalars only: SURVEY 8(d)'s bytes over the time of
+        # the kernel that reads them
+        roofline["reference_algorithm"] = {"kernel": "searchKernel", "bytes": int(alg_bytes), "kernel_ms": round(gen_ms, 3),
+                                           "frac": round(gen_gbs / HBM_PEAK_GBS, 4), "steps": args.general_steps}
+        roofline["reference_algorithm_kernel"] = "searchKernel (awfmGpuSearch, exact ranges, no deeper table)"
+        roofline["reference_algorithm_bytes"] = int(alg_bytes)
+        roofline["reference_algorithm_kernel_ms"] = round(gen_ms, 3)
+        roofline["reference_algorithm_frac"] = round(gen_gbs / HBM_PEAK_GBS, 4)
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample, parity-gated ----
     cpu = None
@@ -852,10 +919,9 @@ def main():
                 gr = d_ranges[: 2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)
                 hit = cnt > 0  # hits-only contract: exact ranges for queries with hits ...
                 assert np.array_equal(gr[hit, 0], sp[hit]) and np.array_equal(gr[hit, 1], ep[hit]), "GPU ranges differ from the oracle"
-                if narrow_counts and state["sparse"]:  # ... and count 0 for the others (awfmGpuSearchHitsSparse)
-                    assert np.array_equal(d_counts[:m].cpu().numpy().view(np.uint32), cnt), "GPU counts differ from the oracle"
-                else:  # ... and some empty range for the others (awfmGpuSearchHits)
-                    assert np.all(gr[~hit, 0] > gr[~hit, 1]), "GPU reports hits the oracle does not have"
+                # ... and count 0 and some empty range for the others
+                assert np.array_equal(d_counts[:m].cpu().numpy().view(np.uint32), cnt), "GPU counts differ from the oracle"
+                assert np.all(gr[~hit, 0] > gr[~hit, 1]), "GPU reports hits the oracle does not have"
             if args.mode == "locate":
                 gho = d_hit_off[: m + 1].cpu().numpy().view(np.uint64)
                 assert np.array_equal(gho, ho), "GPU hit offsets differ from the oracle"
@@ -915,43 +981,50 @@ def main():
     if not args.no_e2e and world == 1 and d_offsets is None and K <= (12 if amino else 32):
         e2e = end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, amino, dev)
 
+    def time_piece(p, steps, force=None):
+        """probe + one warm-up + `steps` timed steps (wall clock between two device synchronisations) of a piece; ms per step"""
+        # (without the library's per-kernel events, which only the main timed loop needs: four events per search are ~20 us)
+        timing = os.environ.pop("AWFM_GPU_TIME_ORDERED", None)
+        try:
+            probe(p, force)
+            step(p)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step(p)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            check_against_probe(p)
+        finally:
+            if timing is not None:
+                os.environ["AWFM_GPU_TIME_ORDERED"] = timing
+        return dt * 1e3
+
+    # ---- the DENSE form of the results, timed beside whichever form the steps used (3 steps): range / count under every
+    # k-mer number, hit offsets over the whole batch, positions in k-mer order -- the reference's result, flattened ----
+    dense_form = None
+    if args.dense_form and locate and ordered and whole.form != "dense" and not whole.windowed:
+        p = Piece(0, Q)
+        ms = time_piece(p, 3, force="dense")
+        dense_form = {"ms_per_step": round(ms, 3), "value": round(Q / ms / 1e3, 1), "steps": 3, "hits": p.hits,
+                      "timed_form": whole.form, "timed_form_ms_per_step": round(ms_per_step, 3)}
+        assert p.hits == whole.hits, "the dense form finds another number of hits"
+
     # ---- secondary: the same index, 10^8 k-mers drawn from the text (BASELINE config 3b), same step, 3 timed steps ----
     secondary = None
     if d_planted is not None:
         from avxwindowfmindex_amd import synth
 
-        def planted_step():
-            if can_order:  # results in search order (most k-mers have hits)
-                g.search_hits_in_order(d_planted.data_ptr(), 0, K, Q, d_order_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
-            else:
-                g.search_hits(d_planted.data_ptr(), 0, K, Q, d_ranges.data_ptr(), 0, stream)
-            total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
-            ensure_positions(total)
-            g.locate(d_ranges.data_ptr(), d_hit_off.data_ptr(), Q, total, state["positions"].data_ptr(), stream)
-            return total
-
-        def planted_dense():
-            """the last planted step's results under the k-mer numbers (outside the timing)"""
-            if can_order:
-                r, c, o, p2 = order_to_dense(d_order_kmers, d_ranges, d_hit_off, state["positions"], hits)
-                d_ranges.copy_(r)
-                d_hit_off.copy_(o)
-                state["positions"] = p2
-
-        planted_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            hits = planted_step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
-        planted_dense()
+        planted = Piece(0, Q, chars=d_planted)
+        dt = time_piece(planted, 3) * 1e-3
+        hits = planted.hits
+        planted_pos = to_dense(planted)
         # every planted k-mer must come back at its planting offset (checked on the first 10^6: a k-mer with one hit has
         # exactly that position, one with several has it among them)
         m = min(Q, 1_000_000)
         planted_at = synth.planted_offsets(103, m, K, n, first=first)
         ho = d_hit_off[: m + 1].cpu().numpy().view(np.uint64)
-        pos = state["positions"][: int(ho[m])].cpu().numpy().view(np.uint64)
+        pos = planted_pos[: int(ho[m])].cpu().numpy().view(np.uint64)
         cnt = np.diff(ho)
         assert cnt.min() >= 1, "a planted k-mer was not found"
         one = cnt == 1
@@ -960,9 +1033,14 @@ def main():
             assert planted_at[i] in pos[ho[i]:ho[i + 1]], "a planted k-mer's own offset is missing from its hit list"
         pkey = digest.key(args.alphabet, "planted", "locate", n, str(K), args.seed_k, args.sa_ratio, first, Q)
         pdig = {"counts": f"{digest.counts_digest(first, d_hit_off[1:] - d_hit_off[:-1]):016x}",
-                "positions": f"{digest.positions_digest(first, d_hit_off, state['positions'][:hits]):016x}"}
+                "positions": f"{digest.positions_digest(first, d_hit_off, planted_pos[:hits]):016x}"}
         committed = digest.load_golden().get(pkey)
         assert committed is None or committed == pdig, f"planted digests {pdig} differ from the committed {committed}"
+        del planted_pos, pos
+        # the dense form of the same batch (see dense_form above)
+        pd = Piece(0, Q, chars=d_planted)
+        planted_dense_ms = time_piece(pd, 3, force="dense")
+        assert pd.hits == hits
         # the same steps with the optional device-only full suffix array (awfmGpuIndexSetDenseSa: 4 bytes per BWT position
         # of HBM, a locate is one gather instead of the LF walk): identical positions, reported beside the walk's number
         dense = None
@@ -971,15 +1049,10 @@ def main():
             g.set_dense_sa(True)
             torch.cuda.synchronize()
             dense_build = time.perf_counter() - t1
-            planted_step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                planted_step()
-            torch.cuda.synchronize()
-            dense_dt = (time.perf_counter() - t1) / 3
-            planted_dense()
-            dense_pos = f"{digest.positions_digest(first, d_hit_off, state['positions'][:hits]):016x}"
+            dense_dt = time_piece(planted, 3) * 1e-3
+            dense_positions = to_dense(planted)
+            dense_pos = f"{digest.positions_digest(first, d_hit_off, dense_positions[:hits]):016x}"
+            del dense_positions
             assert dense_pos == pdig["positions"], "positions through the dense suffix array differ from the walk's"
             dense = {"value": round(Q / dense_dt / 1e6, 2), "ms_per_step": round(dense_dt * 1e3, 3), "build_s": round(dense_build, 2),
                      "extra_device_bytes": 4 * ix.bwt_length, "checked": "positions digest equals the LF walk's"}
@@ -989,45 +1062,113 @@ def main():
         secondary = {"workload": f"{Q / 1e6:g} M planted {K}-mers (every k-mer has >= 1 hit), locate, same index",
                      "with_device_dense_sa": dense,
                      "value": round(Q / dt / 1e6, 2), "unit": "Mkmers/s", "ms_per_step": round(dt * 1e3, 3), "steps": 3,
+                     "result_form": planted.form,
+                     "dense_form": {"ms_per_step": round(planted_dense_ms, 3), "value": round(Q / planted_dense_ms / 1e3, 1), "steps": 3},
                      "hits_per_step": int(hits), "checked": f"first {m} k-mers located at their planting offsets",
                      "digests": dict(pdig, status="match" if committed else "unknown")}
         if args.record_digests:
             known = json.load(open(args.record_digests)) if os.path.exists(args.record_digests) else {}
             known[pkey] = pdig
             json.dump(known, open(args.record_digests, "w"), indent=1, sort_keys=True)
-        del d_planted
+
+    # ---- strong-scaling proxy on ONE GPU: the contiguous shards N ranks would hold of this batch (configs[2]: "query
+    # batch sharded 1 -> 8"), each timed by itself with the same step; a rank of an N-GPU run does exactly this work on
+    # its own replica, with nothing exchanged (ref src/AwFmParallelSearch.c:103-129: 8-query blocks are independent), so
+    # N x the slowest shard's time is what N GPUs would take.  The shards' digests must add up to the batch's. ----
+    proxy = None
+    if args.shard_proxy and world == 1 and not whole.windowed:
+        whole_again_ms = time_piece(Piece(0, Q), args.proxy_steps)  # the whole batch, timed the way the shards are
+        proxy = {"what": "the N contiguous shards of this batch, each timed alone on this GPU (probe + warm-up + steps, wall "
+                         "clock between device synchronisations, no per-kernel events); efficiency = whole-batch ms timed the "
+                         "same way / (N x slowest shard's ms).  A step's cost is a + b x k-mers: b is the table gather "
+                         "(encodeLookupKernel, 26 us per 10^6 k-mers), a the chains that do not shrink with the batch -- the "
+                         "search of the k-mers kept (3 dependent block reads x 5 rounds of what fits the chip), the longest LF "
+                         "walk of the batch (~60 steps), and ~20 launches",
+                 "whole_batch_ms": round(whole_again_ms, 4), "whole_batch_ms_timed_loop": round(ms_per_step, 4),
+                 "steps": args.proxy_steps, "shards": {}}
+        sources = [("batch", d_chars, mine)]
+        if d_planted is not None:
+            sources.append(("planted", d_planted, (first, Q, int(pdig["counts"], 16), int(pdig["positions"], 16))))
+            planted_whole_ms = time_piece(Piece(0, Q, chars=d_planted), args.proxy_steps)
+            proxy["planted_whole_batch_ms"] = round(planted_whole_ms, 4)
+        for name, chars, full in sources:
+            per_n = {}
+            for parts in (2, 4, 8):
+                times, sum_c, sum_p = [], 0, 0
+                for r in range(parts):
+                    if d_offsets is not None:
+                        lo, hi = shard.balanced_bounds(d_offsets, parts, r)
+                    else:
+                        lo, hi = shard.shard_bounds(Q, parts, r)
+                    p = Piece(lo, hi - lo, chars=chars)
+                    times.append(time_piece(p, args.proxy_steps))
+                    if locate:
+                        ppos = to_dense(p)
+                        sum_c += digest.counts_digest(first + lo, d_hit_off[1:p.q + 1] - d_hit_off[:p.q])
+                        sum_p += digest.positions_digest(first + lo, d_hit_off[: p.q + 1], ppos[: max(p.hits, 1)])
+                        del ppos
+                    else:
+                        sum_c += digest.counts_digest(first + lo, d_counts[: p.q])
+                assert (sum_c & digest.MASK) == full[2], f"{name}: the counts digests of {parts} shards do not add up to the batch's"
+                assert full[3] is None or (sum_p & digest.MASK) == full[3], f"{name}: the positions digests of {parts} shards do not add up"
+                base_ms = whole_again_ms if name == "batch" else planted_whole_ms
+                per_n[str(parts)] = {"kmers_per_shard": Q // parts, "ms_max": round(max(times), 4), "ms_mean": round(float(np.mean(times)), 4),
+                                     "Mkmers_per_s_at_N_gpus": round(Q / max(times) / 1e3, 1),
+                                     "efficiency": round(base_ms / (parts * max(times)), 4)}
+            proxy["shards"][name] = per_n
+        proxy["digests"] = "the shards' counts and positions digests add up to the whole batch's for every N"
+    del d_planted
 
     per = "per GPU" if args.scaling == "weak" else f"in total, sharded over {world} rank(s)"
+    deep_build_s, deep_transient = deep_first_build if args.device_seed_k < 0 else g.deep_seed_build
+    deep_rebuild_s = g.deep_seed_build[0]
+    form_names = {"order": "every k-mer {k-mer number, range} in search order + hit offsets and positions in that order",
+                  "list": "list of the k-mers with hits {k-mer number, range} in k-mer order + hit offsets over the list + positions",
+                  "dense": "range / count under every k-mer number + hit offsets over the batch + positions"}
+    config = {"workload": f"{args.queries / 1e6:g} M {args.workload} {kdesc} {per}, {args.mode}, "
+                          f"{n / 1e9:g} G{'res' if amino else 'bp'} {args.text} synthetic {args.alphabet} text"
+                          f"{' (GRCh38-sized)' if n >= 3_000_000_000 and not amino else ''}, "
+                          f"SA ratio {args.sa_ratio}, seed table k={args.seed_k}",
+              "parallelism": f"index replica per GPU, query batch sharded over {world} rank(s), no collective",
+              "batch_kmers": batch_total, "rank0_kmers": Q,
+              "timing_collective": shard.timing_backend() or "none (one rank)",
+              "hits_per_step_rank0": int(state["hits"]), "locate_kernels_ms": round(locate_ms, 3),
+              "search_call_ms": round(search_ms, 3), "host_waits_per_step": 0 if not whole.windowed else "one per window",
+              "index_build_s": round(build_s, 2),
+              "device_image_bytes": g.device_bytes, "device_seed_k": g.deep_seed_k or args.seed_k,
+              # the deeper table's construction, whoever started it (the library by itself at awfmGpuIndexAcquire, inside
+              # index_build_s; or --device-seed-k): wall seconds and the device memory held beyond the table at the peak
+              "device_seed_build_s": round(deep_build_s, 2), "device_seed_transient_bytes": int(deep_transient),
+              "device_seed_rebuild_s": round(deep_rebuild_s, 2),  # the same construction once more (after roofline_general dropped the table): the allocator has the memory at hand
+              "device_dense_sa": bool(args.device_dense_sa), "device_dense_sa_build_s": round(dense_s, 2),
+              "search_path": ({"order": "awfmGpuSearchHitsInOrder", "list": "awfmGpuSearchHitsCompact",
+                               "dense": "awfmGpuSearchHitsSparse" if narrow_counts else "awfmGpuSearchHits"}[whole.form] if locate
+                              else "awfmGpuSearchHits") + (", seed order" if ordered else ", general kernel"),
+              "result_format": form_names[whole.form] if locate else "count under every k-mer number"}
+    if dense_form:  # flat copies for readers that keep scalars only
+        config["dense_form"] = dense_form
+        config["dense_form_ms_per_step"] = dense_form["ms_per_step"]
+        config["dense_form_value"] = dense_form["value"]
+    if secondary:
+        config["planted_ms_per_step"] = secondary["ms_per_step"]
+        config["planted_dense_form_ms_per_step"] = secondary["dense_form"]["ms_per_step"]
+    if proxy:
+        e8 = proxy["shards"]["batch"]["8"]
+        config["scaling_proxy_8_efficiency"] = e8["efficiency"]
+        config["scaling_proxy_8_ms"] = e8["ms_max"]
     out = {
         "metric": "Mkmers/sec located, GRCh38 nucleotide index" if not amino else "Mkmers/sec located, amino index",
         "value": round(value, 2), "unit": "Mkmers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
-        "config": {"workload": f"{args.queries / 1e6:g} M {args.workload} {kdesc} {per}, {args.mode}, "
-                               f"{n / 1e9:g} G{'res' if amino else 'bp'} {args.text} synthetic {args.alphabet} text"
-                               f"{' (GRCh38-sized)' if n >= 3_000_000_000 and not amino else ''}, "
-                               f"SA ratio {args.sa_ratio}, seed table k={args.seed_k}",
-                   "parallelism": f"index replica per GPU, query batch sharded over {world} rank(s), no collective",
-                   "batch_kmers": batch_total, "rank0_kmers": Q,
-                   "timing_collective": shard.timing_backend() or "none (one rank)",
-                   "hits_per_step_rank0": int(state["hits"]), "locate_kernels_ms": round(locate_ms, 3),
-                   "index_build_s": round(build_s, 2),
-                   "device_image_bytes": g.device_bytes, "device_seed_k": g.deep_seed_k or args.seed_k,
-                   "device_seed_build_s": round(deep_s, 2), "device_dense_sa": bool(args.device_dense_sa),
-                   "device_dense_sa_build_s": round(dense_s, 2),
-                   "search_path": ("awfmGpuSearchHitsInOrder" if state["in_order"] else "awfmGpuSearchHitsCompact" if state["listed"] else
-                                   "awfmGpuSearchHitsSparse" if (args.mode == "locate" and narrow_counts and state["sparse"]) else "awfmGpuSearchHits")
-                                  + (", seed order" if ordered else ", general kernel"),
-                   "result_format": ("every k-mer {k-mer number, range} in search order + hit offsets and positions in that order"
-                                     if state["in_order"] else
-                                     "list of the k-mers with hits {k-mer number, range} in k-mer order + hit offsets over the list + positions"
-                                     if state["listed"] else "range / count under every k-mer number + hit offsets over the batch + positions")},
+        "config": config,
         "roofline": roofline,
         "roofline_general": roofline_general,
         "cpu_baseline": cpu,
         "digests": digest_check,
         "end_to_end": e2e,
         "secondary": secondary,
+        "scaling_proxy": proxy,
     }
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -88,6 +88,11 @@ int awfmGpuIndexDevice(const AwFmGpuIndex *g);
  * table's 4.3 GB are free on the device. */
 enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK);
 unsigned awfmGpuIndexDeepSeedK(const AwFmGpuIndex *g); /* depth of the deeper table the image has, 0: none */
+/* reporting: wall seconds the construction of that table took (levels + next-step bits; whoever built it: the automatic
+ * choice at awfmGpuIndexCreate / Acquire, or awfmGpuIndexSetDeepSeed), and the device memory the construction held
+ * beyond the table itself at its peak (the level below the deepest, 16 B x 4^(k-1)) */
+double awfmGpuIndexDeepSeedBuildSeconds(const AwFmGpuIndex *g);
+uint64_t awfmGpuIndexDeepSeedTransientBytes(const AwFmGpuIndex *g);
 /* Optional: keeps the full suffix array on the device (32-bit entries, 4 x bwtLength bytes: 12.4 GB for a
  * GRCh38-sized index), reconstructed once from the sampled SA with the LF-walk kernel, so that locating a
  * hit is one read instead of a chain of about ratio-1 dependent block reads.  Positions are bit-identical.
@@ -144,9 +149,10 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
  * string their search starts from, searched in that order so that neighbouring queries read neighbouring blocks out of
  * the L2, and only the non-empty results are stored under their query numbers over a "no hit" fill.
  * Other batches run awfmGpuSearch.  Scratch: 16-36 bytes per query, owned by the image and re-used; searches on one
- * image are ordered across streams.  The launches are asynchronous on `stream` with one exception: a fixed-length
- * ASCII batch of >= 2^20 k-mers that starts from the deeper table is sampled first (awfmGpuLastOrderedKernelIsLookup
- * below), and the call waits for the 4 bytes of that sample ($AWFM_GPU_LOOKUP_FIRST=0|1: no sample, no wait). */
+ * image are ordered across streams.  Every launch is asynchronous on `stream`: a fixed-length ASCII batch of >= 2^20
+ * k-mers that starts from the deeper table is sampled first (awfmGpuLastOrderedKernelIsLookup below), and the sample's
+ * verdict stays on the device -- the kernels of both front ends are launched and the one it does not choose returns at
+ * once ($AWFM_GPU_LOOKUP_FIRST=0|1: no sample). */
 enum AwFmReturnCode awfmGpuSearchHits(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                       uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
                                       uint32_t *dCounts, void *stream);
@@ -190,19 +196,34 @@ enum AwFmReturnCode awfmGpuCompactHits(AwFmGpuIndex *g, const uint32_t *dCounts,
                                        struct AwFmSearchRange *dHitRanges, uint32_t capacity, uint32_t *dNumHits, void *stream);
 enum AwFmReturnCode awfmGpuSortHits(AwFmGpuIndex *g, uint32_t *dHitKmers, struct AwFmSearchRange *dHitRanges,
                                     uint32_t numEntries, void *stream);
+/* The same order without the host knowing the list's length: the first min(*dNumHits, capacity) entries of the list
+ * awfmGpuSearchHitsCompact appended (k-mer numbers distinct and below numQueries, the batch's size) are put in k-mer order
+ * by ranking them in a bitmap of the batch; *dNumHits is read on the device, every launch is asynchronous on `stream`, and
+ * the entries beyond the hits stay {0xFFFFFFFF, empty range}.  With awfmGpuHitOffsetsOnDevice / awfmGpuLocateOnDevice a
+ * batch is searched, listed and located without one host wait. */
+enum AwFmReturnCode awfmGpuSortHitsOnDevice(AwFmGpuIndex *g, uint32_t *dHitKmers, struct AwFmSearchRange *dHitRanges,
+                                            uint32_t capacity, const uint32_t *dNumHits, uint64_t numQueries, void *stream);
 
 /* -1 = automatic (default), 0 = never, 1 = whenever the ordered path applies */
 void awfmGpuIndexSetOrdered(AwFmGpuIndex *g, int mode);
 /* 1 when awfmGpuSearchHits would search such a batch in seed order on this image (reporting, bench.py) */
 int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets, uint32_t fixedLength, uint64_t numQueries);
-/* measurement hook: with $AWFM_GPU_TIME_ORDERED set, awfmGpuSearchHits brackets its dominant kernel
- * (orderedSearchKernel) with HIP events on the launch stream; this returns the last bracket in ms (<0: none) */
+/* measurement hook: with $AWFM_GPU_TIME_ORDERED set, awfmGpuSearchHits brackets its dominant kernel (orderedSearchKernel,
+ * or encodeLookupKernel when the batch was one for "lookup first") with HIP events on the launch stream; this returns the
+ * last bracket in ms (<0: none).  Reporting calls: this one and the two below may wait for the device. */
 double awfmGpuLastOrderedKernelMs(AwFmGpuIndex *g);
 /* 1 when the last seed-order search on the image looked the table entries up while encoding ("lookup first": batches of
  * ASCII k-mers of which, by a sample, fewer than a quarter are still alive after the deeper table; only those are then
  * ordered and searched; $AWFM_GPU_LOOKUP_FIRST=0 / 1: never / whenever it applies) -- the timed kernel is then
  * encodeLookupKernel */
-int awfmGpuLastOrderedKernelIsLookup(const AwFmGpuIndex *g);
+int awfmGpuLastOrderedKernelIsLookup(AwFmGpuIndex *g);
+/* with $AWFM_GPU_TIME_ORDERED: orderedSearchKernel's own bracket of the last search, whichever kernel was the dominant one
+ * (after encodeLookupKernel it searched only the k-mers that kernel kept); < 0: none */
+double awfmGpuLastOrderedSearchKernelMs(AwFmGpuIndex *g);
+/* the brackets of EVERY timed search since the last call (at most the last 1024), oldest first: frontMs[i] =
+ * encodeLookupKernel's (< 0: that search had none), kernelMs[i] = orderedSearchKernel's; returns how many and empties the
+ * log.  A loop of searches is timed kernel by kernel without a host wait inside the loop (bench.py). */
+int awfmGpuOrderedKernelLog(AwFmGpuIndex *g, double *frontMs, double *kernelMs, int max);
 /* k-mers the last seed-order search with 8-byte records ordered and searched: the batch, or what the lookup-first pass kept
  * of it (reporting; waits for the device) */
 uint64_t awfmGpuLastOrderedKept(AwFmGpuIndex *g);
@@ -233,6 +254,16 @@ enum AwFmReturnCode awfmGpuHitOffsets(AwFmGpuIndex *g, const struct AwFmSearchRa
  * ranges); exact, hence allowed, only for images below 2^32 positions. */
 enum AwFmReturnCode awfmGpuHitOffsetsFromCounts(AwFmGpuIndex *g, const uint32_t *dCounts, uint64_t numQueries,
                                                 uint64_t *dHitOffsets, void *dScratch, uint64_t *totalHits, void *stream);
+
+/* The scan without the read-back: dHitOffsets[numQueries] (device) holds the total, nothing waits for the host.  From
+ * the 32-bit counts (images below 2^32 positions) when dCounts is given, from the ranges otherwise. */
+enum AwFmReturnCode awfmGpuHitOffsetsOnDevice(AwFmGpuIndex *g, const uint32_t *dCounts, const struct AwFmSearchRange *dRanges,
+                                              uint64_t numQueries, uint64_t *dHitOffsets, void *dScratch, void *stream);
+/* awfmGpuLocate with the number of hits read ON THE DEVICE (dHitOffsets[numQueries]): dPositions holds capacityHits
+ * entries, the first min(total, capacityHits) hits are located; the caller learns the total whenever it next reads
+ * dHitOffsets[numQueries] and repeats with a larger buffer if it was too small.  Asynchronous on `stream`. */
+enum AwFmReturnCode awfmGpuLocateOnDevice(AwFmGpuIndex *g, const struct AwFmSearchRange *dRanges, const uint64_t *dHitOffsets,
+                                          uint64_t numQueries, uint64_t capacityHits, uint64_t *dPositions, void *stream);
 
 /* dPositions[dHitOffsets[i] + h] = text position of hit h (BWT order) of query i.
  * Asynchronous on `stream`. */

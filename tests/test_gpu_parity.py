@@ -528,8 +528,99 @@ def test_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, monkey
     ix.dealloc()
 
 
+@pytest.mark.parametrize("tail", [1, 31, 32, 63, 64, 255])
+@pytest.mark.parametrize("K", [21, 12])
+def test_lookup_first_all_hits_batch_whose_last_round_is_short(oracle, awfm, require_gpu, monkeypatch, tail, K):
+    """encodeLookupKernel reserves slots in blocks of 64 per wave; in the last partial round of the last share (nq % 256 in
+    1..63) a block of 64 would reach past the share's region -- past the code array -- when every earlier k-mer was kept.
+    Forced lookup first on batches in which EVERY k-mer has hits (nothing is dropped, no slack anywhere), with
+    nq = 8 shares' worth of whole rounds + a short tail; K = 12 also runs the vector loads at the end of the batch (the
+    caller's buffer ends with the batch: a guard page is not available, so the k-mers sit at the very end of an allocation)."""
+    import torch
+    monkeypatch.setenv("AWFM_GPU_LOOKUP_FIRST", "1")
+    n = 200000
+    txt = synth.text(n + 7, n, synth.DNA_ALPHABET).copy()
+    seed_k, deep_k = (8, 12) if K == 21 else (6, 9)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, seed_k)
+    oi = oracle.Index.wrap(oracle.DNA, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(deep_k)
+    dev = torch.device("cuda")
+    for rounds in (8 * 64, 3):  # several tiles per share / a batch smaller than one share
+        Q = rounds * 256 + tail
+        q = synth.planted_queries(100 + tail, Q, K, txt)
+        chars, offsets = synth.fixed_csr(q)
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+        assert cnt.min() >= 1
+        buf = torch.zeros(4096 + chars.size, dtype=torch.uint8, device=dev)
+        buf[4096:] = torch.from_numpy(chars).to(dev)  # the batch ends where the buffer ends
+        d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
+        d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+        g.search_hits(buf.data_ptr() + 4096, 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+        torch.cuda.synchronize()
+        assert g.last_ordered_kernel_is_lookup()
+        assert g.last_ordered_kept() == Q
+        _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2), d_counts.cpu().numpy().view(np.uint32), sp, ep, cnt)
+    g.destroy()
+    ix.dealloc()
+
+
+@pytest.mark.parametrize("planted_share", [0.02, 0.6])
+def test_list_sorted_scanned_and_located_without_a_host_wait(oracle, awfm, require_gpu, planted_share):
+    """awfmGpuSearchHitsCompact -> awfmGpuSortHitsOnDevice -> awfmGpuHitOffsetsOnDevice -> awfmGpuLocateOnDevice: the list's
+    length and the number of hits are read on the device only.  The sorted list, its offsets and the positions must be what
+    the host-counted calls (awfmGpuSortHits / awfmGpuHitOffsets / awfmGpuLocate) and the oracle give; a position buffer that
+    is too small gets the first `capacity` hits and nothing behind them."""
+    import torch
+    n, K, Q = 300000, 15, 90011
+    txt = synth.text(n + 3, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(11)
+    m = int(Q * planted_share)
+    q = np.concatenate([synth.random_queries(21, Q - m, K), synth.planted_queries(22, m, K, txt)])
+    q = q[np.random.default_rng(5).permutation(Q)]
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+    has = np.flatnonzero(cnt > 0)
+    oho, opos, _ = oi.batch_locate(sp[has], ep[has], threads=4)
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(chars).to(dev)
+    cap = Q
+    d_kmers = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_ranges = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+    d_num = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_off = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(cap), dtype=torch.uint8, device=dev)
+    for capacity_hits in (len(opos) + 100, max(len(opos) // 2, 1)):
+        d_pos = torch.full((len(opos) + 200,), -1, dtype=torch.int64, device=dev)
+        g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr())
+        g.sort_hits_on_device(d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr(), Q)
+        g.hit_offsets_on_device(0, d_ranges.data_ptr(), cap, d_off.data_ptr(), d_scratch.data_ptr())
+        g.locate_on_device(d_ranges.data_ptr(), d_off.data_ptr(), cap, capacity_hits, d_pos.data_ptr())
+        torch.cuda.synchronize()
+        listed = int(d_num.item())
+        assert listed == len(has)
+        ids = d_kmers.cpu().numpy().view(np.uint32)
+        r = d_ranges.cpu().numpy().view(np.uint64).reshape(cap, 2)
+        assert np.array_equal(ids[:listed], has)
+        assert np.array_equal(r[:listed, 0], sp[has]) and np.array_equal(r[:listed, 1], ep[has])
+        assert np.all(ids[listed:] == 0xFFFFFFFF) and np.all(r[listed:, 0] > r[listed:, 1])
+        off = d_off.cpu().numpy().view(np.uint64)
+        assert np.array_equal(off[:listed + 1], oho) and np.all(off[listed:] == oho[-1])
+        pos = d_pos.cpu().numpy()
+        got = min(capacity_hits, len(opos))
+        assert np.array_equal(pos[:got].view(np.uint64), opos[:got])
+        assert np.all(pos[capacity_hits:] == -1), "written behind the capacity"
+    g.destroy()
+    ix.dealloc()
+
+
 def test_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, monkeypatch):
-    """Without $AWFM_GPU_LOOKUP_FIRST a batch of 2^20 k-mers or more is sampled (65536 k-mers at a fixed stride): random
+    """Without $AWFM_GPU_LOOKUP_FIRST a batch of 2^20 k-mers or more is sampled (16384 k-mers at a fixed stride): random
     21-mers against a small text nearly all end at the deeper table -> encodeLookupKernel; k-mers drawn from the text all
     survive it -> the count + partition passes as before.  Counts against the oracle either way."""
     import torch

@@ -1,0 +1,144 @@
+"""The reference's threading contract: the index is read-only during a search, every query's slot is written
+by exactly one thread, and callers may run concurrent searches on ONE index with DIFFERENT lists
+(ref src/AwFmParallelSearch.c:103-129: every 8-query block writes its own slots; :167 the same for counting).
+
+Here the searches of concurrent callers meet on one device image: its lanes, its scratch slots, its sort temporaries.  These
+tests start several host threads on one index and require every caller's results to be the oracle's."""
+import threading
+
+import numpy as np
+import pytest
+
+from avxwindowfmindex_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_four_host_threads_search_one_index_with_their_own_lists(oracle, awfm, require_gpu):
+    """awFmParallelSearchLocate / awFmParallelSearchCount from four threads at once, one index, four lists (two located, two
+    counted; uniform and mixed lengths), several rounds: counts and every position list against the oracle"""
+    txt = synth.text(401, 400000)
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    n = 70003  # above the size from which a list is dealt to the image's lanes in chunks
+    jobs = []
+    for t in range(4):
+        if t % 2 == 0:
+            q = np.concatenate([synth.random_queries(410 + t, n // 2, 14), synth.planted_queries(420 + t, n - n // 2, 14, txt)])
+            kmers = [bytes(r) for r in q]
+        else:
+            chars, offsets = synth.mixed_queries(430 + t, n, txt, synth.DNA_ALPHABET, 6, 30)
+            kmers = [chars[int(offsets[i]):int(offsets[i + 1])].tobytes() for i in range(n)]
+        sp, ep, cnt, _ = oi.search_list(kmers)
+        hit_off, pos, _ = oi.batch_locate(sp, ep)
+        lst = awfm.KmerSearchList(n)
+        lst.fill(kmers)
+        jobs.append({"kmers": kmers, "cnt": cnt, "hit_off": hit_off, "pos": pos, "list": lst, "locate": t < 2, "errors": []})
+
+    def work(job):
+        try:
+            for _ in range(3):
+                if job["locate"]:
+                    rc = awfm.parallel_search_locate(ix, job["list"], 4)
+                    if rc != awfm.AwFmSuccess:
+                        raise AssertionError(f"awFmParallelSearchLocate returned {rc}")
+                else:
+                    awfm.parallel_search_count(ix, job["list"], 4)
+                if not np.array_equal(job["list"].counts(), job["cnt"]):
+                    raise AssertionError("counts differ from the oracle")
+                if job["locate"]:
+                    for i in range(0, n, 41):
+                        if not np.array_equal(job["list"].positions(i), job["pos"][int(job["hit_off"][i]):int(job["hit_off"][i + 1])]):
+                            raise AssertionError(f"positions of k-mer {i} differ from the oracle")
+        except Exception as e:  # noqa: BLE001  (reported by the main thread)
+            job["errors"].append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(job,)) for job in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not any(t.is_alive() for t in threads), "a caller did not come back"
+    for i, job in enumerate(jobs):
+        assert not job["errors"], f"caller {i}: {job['errors']}"
+        job["list"].dealloc()
+    ix.dealloc()
+
+
+@pytest.mark.parametrize("callers", [2, 3])
+def test_callers_on_their_own_streams_share_one_image(oracle, awfm, require_gpu, callers):
+    """the device-buffer API from several threads, each on its own stream with its own buffers, the seed-order path forced
+    on: dense results (awfmGpuSearchHits) and the listed pipeline (SearchHitsCompact -> SortHitsOnDevice ->
+    HitOffsetsOnDevice -> LocateOnDevice) run concurrently on one image -- two scratch slots, one set of sort temporaries,
+    gates between the streams -- and every round of every caller must give the oracle's results"""
+    import torch
+    n, K = 300000, 15
+    txt = synth.text(n + 5, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(11)
+    dev = torch.device("cuda")
+    jobs = []
+    for c in range(callers):
+        Q = 60000 + 1777 * c
+        m = Q // (3 + c)
+        q = np.concatenate([synth.random_queries(500 + c, Q - m, K), synth.planted_queries(510 + c, m, K, txt)])
+        q = q[np.random.default_rng(c).permutation(Q)]
+        chars, offsets = synth.fixed_csr(q)
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+        has = np.flatnonzero(cnt > 0)
+        oho, opos, _ = oi.batch_locate(sp[has], ep[has], threads=4)
+        jobs.append({"Q": Q, "chars": chars, "sp": sp, "ep": ep, "cnt": cnt, "has": has, "oho": oho, "opos": opos, "errors": []})
+
+    def work(job):
+        try:
+            Q = job["Q"]
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                d_chars = torch.from_numpy(job["chars"]).to(dev)
+                d_ranges = torch.zeros(Q * 2, dtype=torch.int64, device=dev)
+                d_counts = torch.zeros(Q, dtype=torch.int32, device=dev)
+                d_kmers = torch.zeros(Q, dtype=torch.int32, device=dev)
+                d_list = torch.zeros(Q * 2, dtype=torch.int64, device=dev)
+                d_num = torch.zeros(1, dtype=torch.int32, device=dev)
+                d_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+                d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+                d_pos = torch.zeros(len(job["opos"]) + 64, dtype=torch.int64, device=dev)
+            stream.synchronize()
+            s = stream.cuda_stream
+            for _ in range(12):
+                g.search_hits(d_chars.data_ptr(), 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr(), s)
+                g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_list.data_ptr(), Q, d_num.data_ptr(), stream=s)
+                g.sort_hits_on_device(d_kmers.data_ptr(), d_list.data_ptr(), Q, d_num.data_ptr(), Q, s)
+                g.hit_offsets_on_device(0, d_list.data_ptr(), Q, d_off.data_ptr(), d_scratch.data_ptr(), s)
+                g.locate_on_device(d_list.data_ptr(), d_off.data_ptr(), Q, d_pos.numel(), d_pos.data_ptr(), s)
+                stream.synchronize()
+                counts = d_counts.cpu().numpy().view(np.uint32)
+                ranges = d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2)
+                hit = job["cnt"] > 0
+                if not np.array_equal(counts, job["cnt"]):
+                    raise AssertionError("dense counts differ from the oracle")
+                if not (np.array_equal(ranges[hit, 0], job["sp"][hit]) and np.array_equal(ranges[hit, 1], job["ep"][hit])):
+                    raise AssertionError("dense ranges differ from the oracle")
+                listed = int(d_num.item())
+                if listed != len(job["has"]) or not np.array_equal(d_kmers[:listed].cpu().numpy().view(np.uint32), job["has"]):
+                    raise AssertionError("the list of k-mers with hits differs from the oracle")
+                if not np.array_equal(d_off[:listed + 1].cpu().numpy().view(np.uint64), job["oho"]):
+                    raise AssertionError("hit offsets over the list differ from the oracle")
+                if not np.array_equal(d_pos[:len(job["opos"])].cpu().numpy().view(np.uint64), job["opos"]):
+                    raise AssertionError("positions differ from the oracle")
+        except Exception as e:  # noqa: BLE001
+            job["errors"].append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(job,)) for job in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not any(t.is_alive() for t in threads), "a caller did not come back"
+    for i, job in enumerate(jobs):
+        assert not job["errors"], f"caller {i}: {job['errors']}"
+    g.destroy()
+    ix.dealloc()
