@@ -794,6 +794,8 @@ struct AwFmGpuIndex {
   int orderLookup = 0;
   const unsigned *orderSampleAt = nullptr;
   unsigned orderSamples = 0;
+  bool orderLookupFused = false;               /* ... by lookupSearchKernel, which searched the k-mers it kept itself */
+  const unsigned *orderFusedKeptAt = nullptr;  /* its survivor counters (kFusedCounters words, 64 B apart) */
   const unsigned *orderKeptAt = nullptr; /* device word: k-mers that search ordered (after encodeLookupKernel: the ones it kept) */
   std::mutex aosMutex;       /* serialises the AoS entry points (they share the pinned buffers) */
   void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};

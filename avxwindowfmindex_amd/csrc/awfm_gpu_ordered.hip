@@ -293,6 +293,18 @@ extern "C" uint64_t awfmGpuLastOrderedKept(AwFmGpuIndex *g) {
     (void)hipGetLastError();
     return 0;
   }
+  if (g->orderLookupFused && g->orderFusedKeptAt && lastSearchLookedUpFirst(g)) {
+    /* the survivors were searched by the kernel that looked them up: its waves counted them (what `kept` holds are the
+     * k-mers left to the general kernel) */
+    unsigned words[kFusedCounters * 16u];
+    if (hipMemcpy(words, g->orderFusedKeptAt, sizeof words, hipMemcpyDeviceToHost) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    uint64_t total = kept;
+    for (unsigned i = 0; i < kFusedCounters; i++) total += words[i * 16u];
+    return total;
+  }
   return kept;
 }
 
@@ -496,6 +508,21 @@ static void launchEncodeLookupAt(unsigned len, unsigned grid, size_t lds, hipStr
                                  start, stop);
 }
 
+/* lookupSearchKernel<K> for the batch's k-mer length */
+template <unsigned K>
+static void launchLookupSearchAt(unsigned len, unsigned grid, size_t lds, hipStream_t s, const DevIndex &dev, const uint8_t *dChars,
+                                 const BucketFormat &fmt, unsigned useNext, unsigned long long nq, unsigned long long *codes,
+                                 unsigned *numbers, unsigned *shareCount, unsigned *hist, unsigned binsPad,
+                                 const unsigned *sampleAlive, unsigned samples, ulonglong2 *rng, unsigned *dCounts,
+                                 const SparseOut &sparse, unsigned *keptCounters, hipEvent_t start, hipEvent_t stop) {
+  if (len == K)
+    hipExtLaunchKernelGGL((lookupSearchKernel<K>), dim3(grid), dim3(256), (unsigned)lds, s, start, stop, 0u, dev, dChars, fmt, useNext, nq, codes,
+                          numbers, shareCount, hist, binsPad, sampleAlive, samples, rng, dCounts, sparse, keptCounters);
+  else if constexpr (K > 1u)
+    launchLookupSearchAt<K - 1u>(len, grid, lds, s, dev, dChars, fmt, useNext, nq, codes, numbers, shareCount, hist, binsPad, sampleAlive, samples,
+                                 rng, dCounts, sparse, keptCounters, start, stop);
+}
+
 /* fillNoHitKernel -> encodeCodes4Kernel -> bucketScanSharesKernel -> partitionKernel -> orderedSearchKernel<BUCKET> ->
  * searchKernel<INDIRECT> on the caller's stream; the caller holds orderMutex.  Return values as awfmGpuOrderedSearch. */
 static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength, unsigned depth,
@@ -522,7 +549,8 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   }
   if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
   constexpr size_t kShareCountAt = 98304, kSampleAt = kShareCountAt + kShares * kShareCountStride * 4u; /* bytes into the counter block (tickets end at 65792) */
-  static_assert(256 + 8 * kTicketGroups * 8 * 256 <= kShareCountAt && kSampleAt + 4 <= kOrderCounterBytes, "counter block");
+  constexpr size_t kKeptAt = 102400; /* lookupSearchKernel's survivor counters: kFusedCounters words a line apart */
+  static_assert(256 + 8 * kTicketGroups * 8 * 256 <= kShareCountAt && kSampleAt + 4 <= kKeptAt && kKeptAt + kFusedCounters * 64u <= kOrderCounterBytes, "counter block");
 #define BUCKET_TRY(call)                    \
   do {                                      \
     hipError_t e__ = (call);                \
@@ -578,8 +606,28 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   g->orderTimedFront = false;
   if (lookupFirst || bySample) {
     const bool timed = g->orderTiming[0] != nullptr; /* this search has an entry in the timing log: the events ride on the dispatch */
-    launchEncodeLookupAt<32u>(fixedLength, encodeGrid, bins * 4u, s, g->dev, dChars, fmt, useNext, nq, (unsigned long long *)(w + codesAt), numbers,
-                              shareCount, hist, binsPad, sampleAlive, kSamples, timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr);
+    /* fused (default): the k-mers still alive after the table are searched by the kernel that looked them up;
+     * $AWFM_GPU_LOOKUP_FUSED=0: they are kept, partitioned and searched by orderedSearchKernel (round 3) */
+    const char *fusedEnv = getenv("AWFM_GPU_LOOKUP_FUSED");
+    const bool fused = !(fusedEnv && atoi(fusedEnv) == 0);
+    g->orderLookupFused = fused;
+    g->orderFusedKeptAt = (const unsigned *)(w + kKeptAt);
+    if (fused) {
+      const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
+      const bool superInLds = !pairOff && awfmPairSuperInLds(g);
+      DevIndex dev = g->dev;
+      dev.pairSuperInLds = superInLds ? 1u : 0u;
+      const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
+      /* persistent grid: what is resident (7 workgroups per CU), a multiple of the 8 shares */
+      unsigned fusedGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * 7u ? perShare256 * kShares : (unsigned long long)g->numCUs * 7u);
+      fusedGrid = (fusedGrid + kShares - 1u) / kShares * kShares;
+      launchLookupSearchAt<32u>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt, useNext | (pairOff ? 2u : 0u), nq, (unsigned long long *)(w + codesAt),
+                                numbers, shareCount, hist, binsPad, sampleAlive, kSamples, rng, dCounts, sparse ? *sparse : SparseOut(),
+                                (unsigned *)(w + kKeptAt), timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr);
+    } else {
+      launchEncodeLookupAt<32u>(fixedLength, encodeGrid, bins * 4u, s, g->dev, dChars, fmt, useNext, nq, (unsigned long long *)(w + codesAt), numbers,
+                                shareCount, hist, binsPad, sampleAlive, kSamples, timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr);
+    }
     g->orderTimedFront = timed;
     if (timed) g->orderLog[(g->orderLogCount - 1u) % AwFmGpuIndex::kOrderLogMax].front = true;
     BUCKET_TRY(hipGetLastError());

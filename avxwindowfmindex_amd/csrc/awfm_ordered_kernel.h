@@ -560,6 +560,271 @@ __global__ void __launch_bounds__(256)
     if (sHist[e]) atomicAdd(&hist[share * binsPad + e], sHist[e]);
 }
 
+/* ---- lookup first, fused: the k-mers still alive after the table are searched where they are found ----
+ * encodeLookupKernel hands its survivors (4.4 % of 10^8 random 21-mers) to a scan, a partition and orderedSearchKernel, which
+ * looks every survivor's table entry up again; those kernels take 0.45 ms per 10^8 k-mers and -- being chains of dependent
+ * reads over a few k-mers -- hardly less per 10^7, which is what a rank of an 8-GPU run holds.  Here a wave that has looked
+ * its 256 entries up puts the survivors' {codes, number, range} into LDS and takes them through their steps 16 at a time
+ * (4 lanes per k-mer, the device functions of orderedSearchKernel: pair steps, flagged blocks and the odd step through the
+ * one-letter image), then stores the hits: dense, or into the list.  The survivors' block reads are in input order, so
+ * nothing is shared in the L2 -- but there are 1.1 * 10^7 of them against 10^8 table lines, and the 4.4 * 10^6 table
+ * lines the ordered kernel read a second time are not read at all.  K-mers with ambiguity characters still go to the
+ * general kernel by way of the share's region, the scan and the partition (all but empty now).
+ * Results: every k-mer with hits gets the range the reference's stepping gives it (same entry, same steps); a k-mer dropped at
+ * the table or emptied on the way has no hit. */
+constexpr unsigned kFusedSlots = 64;    /* survivors a wave takes through the steps at a time */
+constexpr unsigned kFusedCounters = 64; /* words (a line apart) the waves count their survivors into: reporting */
+template <unsigned K>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(7, 8)))
+    lookupSearchKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const BucketFormat f, const unsigned useNext,
+                       const unsigned long long numQueries, unsigned long long *__restrict__ codesOut,
+                       unsigned *__restrict__ numbersOut, unsigned *__restrict__ shareCount, unsigned *__restrict__ hist,
+                       const unsigned binsPad, const unsigned *__restrict__ sampleAlive, const unsigned samples,
+                       ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts, const SparseOut sparse,
+                       unsigned *__restrict__ keptCounters) {
+  constexpr int G = 4;
+  typedef unsigned pos_t; /* narrow images only (awfmImageNarrow: what the narrow table entries imply) */
+  /* kernel arguments, uniform (one instantiation per k-mer length, not four): pair steps when the image has its pair
+   * blocks; the hits into the list when there is one */
+  const bool PAIR = ix.pairBlocks != nullptr && useNext != 2u;
+  const bool LIST = sparse.count != nullptr;
+  __shared__ unsigned long long sC[24];
+  __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
+  __shared__ unsigned long long sSuper[1];
+  __shared__ unsigned long long sPairC[16];
+  extern __shared__ unsigned sPairSuper[];
+  __shared__ unsigned long long sCodes[4][kFusedSlots];
+  __shared__ unsigned sNum[4][kFusedSlots], sSp[4][kFusedSlots], sEp[4][kFusedSlots];
+  constexpr unsigned kHitBuffer = 32;
+  __shared__ unsigned sHitKmers[4][kHitBuffer];
+  __shared__ unsigned long long sHitRanges[4][kHitBuffer][2];
+  __shared__ unsigned sHitLeft[4], sWavesDone;
+  if (!lookupChosen(sampleAlive, samples, true)) return; /* this batch is encodeCodes4Kernel's (uniform) */
+  if (threadIdx.x == 0) sWavesDone = 0u;
+  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  stageMaskTable(sMask);
+  nucStageSuper<true>(ix, sSuper);
+  if (PAIR) pairStageTables<true, 16u>(ix, sPairC, sPairSuper);
+  __syncthreads();
+  const unsigned bins = (1u << f.bucketBits) + 1u;
+  constexpr unsigned kLoads = (K + 1u + 3u) / 4u;
+  const unsigned shift = (unsigned)((unsigned long long)chars & 3ull);
+  typedef const Dwords4 __attribute__((address_space(1))) *GlobalDwords4;
+  const unsigned share = blockIdx.x % kShares, localBlock = blockIdx.x / kShares, localGrid = gridDim.x / kShares;
+  const unsigned long long size = shareSize(numQueries), first = size * share;
+  const unsigned long long last = first + size < numQueries ? first + size : numQueries;
+  const unsigned long long tableMask = (1ull << (2u * f.depth)) - 1ull;
+  const unsigned lane = threadIdx.x & 63u, gl = threadIdx.x % G, firstSlice = gl;
+  const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  unsigned blockBase = 0, blockUsed = 0, blockSlots = 0; /* the wave's block of slots in its share's region: general k-mers */
+  unsigned hitFill = 0, keptHere = 0; /* wave-uniform */
+  auto flushHits = [&]() {
+    if (hitFill != 0u) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      unsigned listBase = 0;
+      if (lane == 0) listBase = atomicAdd(sparse.count, hitFill);
+      listBase = (unsigned)__builtin_amdgcn_readfirstlane((int)listBase);
+      if (lane < hitFill && listBase + lane < sparse.cap) {
+        sparse.kmers[listBase + lane] = sHitKmers[w][lane];
+        sparse.ranges[listBase + lane] = make_ulonglong2(sHitRanges[w][lane][0], sHitRanges[w][lane][1]);
+      }
+      __builtin_amdgcn_wave_barrier();
+      hitFill = 0;
+    }
+  };
+  const unsigned long long waveFirst = first + 4ull * ((unsigned long long)localBlock * 256ull + (threadIdx.x & ~63u));
+  for (unsigned long long tw = waveFirst; tw < last; tw += 4ull * localGrid * 256ull) {
+    const unsigned long long t = tw + 4ull * lane;
+    unsigned long long codes[4];
+    unsigned bad[4];
+    if (t * K + 16ull * kLoads <= numQueries * K) { /* the 16-byte loads from the aligned-down start stay inside the batch */
+      const GlobalDwords4 from = (GlobalDwords4)(((unsigned long long)chars + t * K) & ~3ull);
+      unsigned dw[kLoads * 4u + 1u];
+#pragma unroll
+      for (unsigned j = 0; j < kLoads; j++) {
+        const Dwords4 q = from[j];
+        dw[4u * j] = q.x;
+        dw[4u * j + 1u] = q.y;
+        dw[4u * j + 2u] = q.z;
+        dw[4u * j + 3u] = q.w;
+      }
+      dw[kLoads * 4u] = 0u;
+      unsigned al[K + 1u];
+#pragma unroll
+      for (unsigned j = 0; j < K; j++) al[j] = __builtin_amdgcn_alignbyte(dw[j + 1u], dw[j], shift);
+      al[K] = 0u;
+#pragma unroll
+      for (unsigned i = 0; i < 4u; i++) {
+        constexpr unsigned kWords = (K + 3u) / 4u;
+        const unsigned at = i * K;
+        unsigned long long c = 0;
+        unsigned b = 0;
+#pragma unroll
+        for (unsigned x = 0; x < 8u; x++) {
+          unsigned packed = 0;
+          if (x < kWords) {
+            const unsigned lo = al[(at >> 2) + x], hi = (at >> 2) + x + 1u <= K ? al[(at >> 2) + x + 1u] : 0u;
+            const unsigned inKmer = K - 4u * x >= 4u ? 4u : K - 4u * x;
+            decodeWordAny(__builtin_amdgcn_alignbyte(hi, lo, at & 3u), inKmer >= 4u ? ~0u : (1u << (8u * inKmer)) - 1u, packed, b);
+          }
+          c = (c << 8) | packed;
+        }
+        codes[i] = c >> (2u * (32u - K));
+        bad[i] = b;
+      }
+    } else {
+#pragma unroll
+      for (unsigned i = 0; i < 4u; i++) {
+        codes[i] = 0;
+        bad[i] = 0;
+        if (t + i < numQueries) decodeKmer(chars, (t + i) * K, K, codes[i], bad[i]);
+      }
+    }
+    uint2 entry[4];
+#pragma unroll
+    for (unsigned i = 0; i < 4u; i++) entry[i] = ((const uint2 *)ix.deepSeed)[t + i < last && !bad[i] ? (codes[i] & tableMask) : 0ull];
+    /* a survivor is searched here when it is among the first kFusedSlots of its round (a round of 256 random 21-mers has
+     * 11); the others -- and the k-mers with ambiguity characters, which are the general kernel's -- go to the share's
+     * region as encodeLookupKernel's survivors do, and the kernels behind this one take them from there.  Nothing of a
+     * k-mer is kept in registers past this point: the steps below work out of LDS. */
+    unsigned long long amask[4];
+    unsigned abefore[4], atotal = 0, stotal = 0;
+    bool append[4];
+#pragma unroll
+    for (unsigned i = 0; i < 4u; i++) {
+      const unsigned length = ix.deepNext ? (entry[i].y & 0xFFFFu) : entry[i].y;
+      const bool bit = (useNext & 1u) == 0u || ((entry[i].y >> (16u + ((unsigned)(codes[i] >> (2u * f.depth)) & 15u))) & 1u) != 0u;
+      const bool general = t + i < last && bad[i] != 0u;
+      const bool survives = t + i < last && bad[i] == 0u && length != 0u && bit;
+      const unsigned long long smask = __ballot(survives);
+      const unsigned rank = stotal + (unsigned)__popcll(smask & ((1ull << lane) - 1ull));
+      stotal += (unsigned)__popcll(smask);
+      if (survives && rank < kFusedSlots) {
+        const ulonglong2 r = deepSeedOpen(ix, codes[i] & tableMask, entry[i], nullptr);
+        sCodes[w][rank] = codes[i];
+        sNum[w][rank] = (unsigned)(t + i);
+        sSp[w][rank] = (unsigned)r.x;
+        sEp[w][rank] = (unsigned)r.y;
+      }
+      append[i] = general || (survives && rank >= kFusedSlots);
+      amask[i] = __ballot(append[i]);
+      abefore[i] = atotal;
+      atotal += (unsigned)__popcll(amask[i]);
+    }
+    if (atotal != 0u) { /* wave-uniform; rare */
+      if (blockUsed + atotal > blockSlots) {
+        if (blockUsed + lane < blockSlots) codesOut[first + blockBase + blockUsed + lane] = kCodeNone;
+        blockSlots = atotal > kLookupBlock || tw + 256ull > last ? atotal : kLookupBlock;
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&shareCount[share * kShareCountStride], blockSlots);
+        blockBase = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        blockUsed = 0;
+      }
+#pragma unroll
+      for (unsigned i = 0; i < 4u; i++)
+        if (append[i]) {
+          const unsigned long long slot = first + blockBase + blockUsed + abefore[i] + (unsigned)__popcll(amask[i] & ((1ull << lane) - 1ull));
+          codesOut[slot] = bad[i] ? kCodeGeneral : codes[i];
+          numbersOut[slot] = (unsigned)(t + i);
+          atomicAdd(&hist[share * binsPad + (bad[i] ? bins - 1u : bucketOf(f, codes[i]))], 1u);
+        }
+      blockUsed += atotal;
+    }
+    const unsigned inBatch = stotal < kFusedSlots ? stotal : kFusedSlots;
+    keptHere += inBatch;
+    if (inBatch != 0u) { /* wave-uniform */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (unsigned pass = 0; pass < inBatch; pass += 64u / G) { /* wave-uniform */
+        const unsigned slot = pass + lane / G;
+        const bool live = slot < inBatch;
+        pos_t sp = 1, ep = 0;
+        unsigned long long rem = 0;
+        unsigned index = 0;
+        int pos = -1;
+        if (live) {
+          const unsigned long long c = sCodes[w][slot];
+          index = sNum[w][slot];
+          sp = sSp[w][slot];
+          ep = sEp[w][slot];
+          rem = c >> (2u * f.depth);
+          pos = (int)(K - f.depth) - 1;
+        }
+        if (PAIR) {
+          while (pos >= 1 && sp <= ep) {
+            const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
+            if (pairSearchStep<true>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep) == kPairFlagged) {
+              nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
+              if (sp <= ep) nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
+            }
+            pos -= 2;
+            rem >>= 4;
+          }
+          if (pos == 0 && sp <= ep) {
+            nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+            pos--;
+          }
+        } else {
+          while (pos >= 0 && sp <= ep) {
+            nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+            pos--;
+            rem >>= 2;
+          }
+        }
+        const bool hit = live && gl == 0 && sp <= ep;
+        if (LIST) {
+          const unsigned long long hitMask = __ballot(hit);
+          if (hitMask != 0ull) { /* wave-uniform; at most 16 hits a pass */
+            const unsigned hits = (unsigned)__builtin_amdgcn_readfirstlane((int)__popcll(hitMask));
+            if (hit) {
+              const unsigned at = hitFill + (unsigned)__popcll(hitMask & ((1ull << lane) - 1ull));
+              sHitKmers[w][at] = index;
+              sHitRanges[w][at][0] = (unsigned long long)sp;
+              sHitRanges[w][at][1] = (unsigned long long)ep;
+            }
+            hitFill = (unsigned)__builtin_amdgcn_readfirstlane((int)(hitFill + hits));
+          }
+          if (hitFill + 64u / G > kHitBuffer) flushHits();
+        } else if (hit) {
+          if (ranges) ranges[index] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
+          if (counts) counts[index] = (unsigned)(ep - sp + (pos_t)1);
+        }
+      }
+      __builtin_amdgcn_wave_barrier(); /* the slots are written again by the next round */
+    }
+  }
+  for (unsigned at = blockUsed + lane; at < blockSlots; at += 64u) codesOut[first + blockBase + at] = kCodeNone;
+  if (lane == 0 && keptHere) atomicAdd(&keptCounters[((blockIdx.x * 4u + w) % kFusedCounters) * 16u], keptHere);
+  if (LIST) { /* the waves' leftovers in one reservation, as in orderedSearchKernel */
+    if (lane == 0) sHitLeft[w] = hitFill;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    unsigned arrived = 0;
+    if (lane == 0) arrived = atomicAdd(&sWavesDone, 1u);
+    arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+    if (arrived == 3u) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      unsigned total = 0;
+      for (unsigned v = 0; v < 4u; v++) total += sHitLeft[v];
+      if (total != 0u) {
+        unsigned listBase = 0;
+        if (lane == 0) listBase = atomicAdd(sparse.count, total);
+        listBase = (unsigned)__builtin_amdgcn_readfirstlane((int)listBase);
+        unsigned before = 0;
+        for (unsigned v = 0; v < 4u; v++) {
+          const unsigned n = sHitLeft[v];
+          if (lane < n && listBase + before + lane < sparse.cap) {
+            sparse.kmers[listBase + before + lane] = sHitKmers[v][lane];
+            sparse.ranges[listBase + before + lane] = make_ulonglong2(sHitRanges[v][lane][0], sHitRanges[v][lane][1]);
+          }
+          before += n;
+        }
+      }
+    }
+  }
+}
+
 /* how many of `samples` k-mers taken at a fixed stride over the batch are alive in the sense above: says beforehand
  * whether the batch is one for encodeLookupKernel */
 __global__ void __launch_bounds__(256)

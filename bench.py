@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_GATHER_PEAK_GBS = 17800.0  # MI355X_MICROARCH.md "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCDs' L2s
 RANK_BYTES_DNA, RANK_BYTES_AMINO = 104, 168  # planes + one count of the reference block
-PROFILE_ROUND = "r3"
+PROFILE_ROUND = "r4"
 WINDOW_HITS = 1 << 28  # hits located per window when a batch's hit list is not kept resident (--workload mixed --mode locate)
 
 
@@ -704,6 +704,9 @@ def main():
     if (args.device_seed_k < 0 and not args.device_dense_sa and not amino and n == 3_100_000_000 and Q == 100_000_000
             and K == 21 and args.seed_k == 12 and args.sa_ratio == 8 and args.mode == "locate" and args.text == "uniform"):
         prof_name = {"random": "default", "planted": "planted"}.get(args.workload)
+    if (args.device_seed_k < 0 and not args.device_dense_sa and not amino and n == 3_100_000_000 and Q == 100_000_000
+            and args.workload == "mixed" and args.seed_k == 12 and args.sa_ratio == 8 and args.mode == "count" and args.text == "uniform"):
+        prof_name = "mixed"
     if any(k.startswith("AWFM_GPU_") and k not in ("AWFM_GPU_TIME_ORDERED", "AWFM_GPU_DEVICE") for k in os.environ):
         prof_name = None  # a measurement knob is set: the profiled run was of the default code path
     not_this_run = "rocprofv3 PMC passes of this command line on another run of the same code (scripts/profile_bench.sh), not measured by this run"
@@ -723,12 +726,24 @@ def main():
         what = ("distinct (search level, 128-B line) pairs the kernel reads, tallied on the device by an "
                 "instrumented launch of the same kernel on the same sorted batch (awfmGpuSearchHitsLineTally), "
                 "x 128 B, + sorted records and keys read + results stored")
-        if lookup_first:
-            # The batch was one for "lookup first" (DESIGN.md 4a): the dominant kernel is encodeLookupKernel, which reads the
-            # k-mers' characters and one table entry per k-mer and keeps the few that are still alive; the kernels after it
-            # (partition, orderedSearchKernel over what was kept) are priced in `call`.  Its compulsory bytes: the characters
-            # + every distinct table line once (the tally's deep_table_lines: the same entries, whatever the order) + what it
-            # appends per k-mer kept (code word 8 B + number 4 B).
+        fused = lookup_first and os.environ.get("AWFM_GPU_LOOKUP_FUSED", "1") != "0"
+        if lookup_first and fused:
+            # The batch was one for "lookup first"  and the kernel that looks the table entries up also searches
+            # the few k-mers that are still alive after them (lookupSearchKernel).  Its compulsory bytes: the characters +
+            # every distinct table line once (the tally's deep_table_lines: the same entries, whatever the order) + every
+            # distinct (level, line) of the block reads of the k-mers kept (the tally's pair / one-letter level lines: the
+            # same steps, whatever the order) + the results.
+            dom_name = "lookupSearchKernel"
+            compulsory = Q * K + 128 * (lines["deep_table_lines"] + lines["pair_level_lines"] + lines["nuc_level_lines"]) + stored
+            lines = dict(lines, kmers_kept=int(lookup_kept), characters_read=int(Q * K))
+            what = ("the k-mers' characters + 128 B x (the distinct lines of the deeper table the batch's k-mers need + the distinct "
+                    "(search level, line) pairs of the block reads of the k-mers still alive after the table), tallied on the "
+                    "device by awfmGpuSearchHitsLineTally, + the results stored")
+        elif lookup_first:
+            # $AWFM_GPU_LOOKUP_FUSED=0: the dominant kernel is encodeLookupKernel, which reads the k-mers' characters and one
+            # table entry per k-mer and keeps the few that are still alive; the kernels after it (partition,
+            # orderedSearchKernel over what was kept) are priced in `call`.  Its compulsory bytes: the characters + every
+            # distinct table line once + what it appends per k-mer kept (code word 8 B + number 4 B).
             dom_name = "encodeLookupKernel"
             compulsory = Q * K + 128 * lines["deep_table_lines"] + 12 * lookup_kept
             lines = dict(lines, kmers_kept=int(lookup_kept), characters_read=int(Q * K))
@@ -740,7 +755,9 @@ def main():
         # line it arrives in; the block reads of the search levels stay at their distinct lines.  traffic / needed says how
         # much of what the kernel moves is the rest of a line nobody asked for.
         entry_bytes = 8 if narrow_counts else 16
-        if lookup_first:
+        if lookup_first and fused:
+            needed = Q * K + entry_bytes * Q + 128 * (lines["pair_level_lines"] + lines["nuc_level_lines"]) + stored
+        elif lookup_first:
             needed = Q * K + entry_bytes * Q + 12 * lookup_kept
         else:
             needed = (entry_bytes * lines["ordered_kmers"] + 128 * (lines["pair_level_lines"] + lines["nuc_level_lines"])
@@ -784,7 +801,7 @@ def main():
                               "source": f"{csrc}: TCC_REQ_sum x 128 B over this run's kernel time; peak = the guide's chip-wide rate "
                                         "for rows gathered out of the XCDs' L2s (16.8-18.8 TB/s)"}
         dominant = {"name": dom_name, "ms": round(dom_ms, 3)}
-        if after_lookup_ms is not None:
+        if after_lookup_ms is not None and not fused:
             dominant["orderedSearchKernel_over_the_kmers_kept_ms"] = round(after_lookup_ms, 3)
         if counters:
             for key in ("l2_hit_rate", "valu_issue_frac", "wave_wait_frac", "clock_ghz_under_profiler"):
@@ -796,7 +813,9 @@ def main():
         # the whole call, priced by what the REFERENCE algorithm would move for this batch: a throughput figure in bytes,
         # not a roofline fraction (five sixths of those bytes never leave the L2)
         roofline["call"] = {
-            "kernels": ("awfmGpuSearchHits*: fill / memset + sampleAliveKernel + encodeLookupKernel + bucketScanSharesKernel + "
+            "kernels": ("awfmGpuSearchHits*: fill / memset + sampleAliveKernel + lookupSearchKernel (+ the kernels of the other front "
+                        "end, which return at once)" if lookup_first and fused else
+                        "awfmGpuSearchHits*: fill / memset + sampleAliveKernel + encodeLookupKernel + bucketScanSharesKernel + "
                         "partitionKernel + orderedSearchKernel over the k-mers kept" if lookup_first else
                         "awfmGpuSearchHits*: fill / memset + encodeCodes4Kernel (count) + bucketScanSharesKernel + partitionKernel + "
                         "orderedSearchKernel (fixed lengths with 8-byte records; 16-byte records: encodeRecordsKernel + "
@@ -816,7 +835,9 @@ def main():
             "algorithmic_bytes_per_launch": int(alg_bytes), "per_query": per_query,
             "upper_bound_variant_GBs": round(upper_bytes / (search_ms * 1e-3) / 1e9, 1),
         }
-        gname = "amino" if (amino and n == 200_000_000 and Q == 50_000_000 and K == 10 and args.seed_k == 5) else None
+        gname = None
+        if amino and Q == 50_000_000 and K == 10 and args.seed_k == 5 and n in (200_000_000, 2_000_000_000):
+            gname = "amino" if n == 200_000_000 else "amino_2e9"
         if gname and not any(k.startswith("AWFM_GPU_") and k != "AWFM_GPU_DEVICE" for k in os.environ):
             traffic, tsrc = profile_file("traffic", gname)
             if traffic:
