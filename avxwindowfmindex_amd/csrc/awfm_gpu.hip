@@ -807,10 +807,25 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
  * so no lock is taken -- awfmGpuIndexAcquireAll creates images while it holds the table lock, and the public
  * setter would ask for that lock again through lanesOf() */
 static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
-  if (g->amino) return AwFmSuccess;
   int deepK = 0;
-  if (const char *env = getenv("AWFM_GPU_DEEP_SEED_K")) {
+  if (const char *env = getenv(g->amino ? "AWFM_GPU_AMINO_DEEP_SEED_K" : "AWFM_GPU_DEEP_SEED_K")) {
     deepK = atoi(env); /* 0: none */
+  } else if (g->amino) {
+    /* Automatic, amino: an image of >= 2^26 positions whose own table is shallower gets the deepest table of up to 7
+     * characters with at most 8 entries per text position, when three times its size is free on the device: 20^7 x 8 B =
+     * 10.2 GB for a Swiss-Prot-sized text (2 * 10^8 residues), where 85 % of random 10-mers end at their entry (no such
+     * 7-mer) and the rest start two steps further on.  Exact: an entry is what the stepping holds after those steps. */
+    size_t freeBytes = 0, totalBytes = 0;
+    DeviceGuard guard(g->device);
+    if (g->dev.bwtLength >= (1ull << 26) && g->dev.bwtLength < (1ull << 32) && g->dev.seedK >= 2 && hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) {
+      unsigned long long entries = 1;
+      for (unsigned k = 1; k <= 7u; k++) {
+        entries *= 20ull;
+        if (k > g->dev.seedK && entries <= 8ull * g->dev.bwtLength && freeBytes / 3u >= entries * 8ull) deepK = (int)k;
+      }
+    } else {
+      (void)hipGetLastError();
+    }
   } else if (g->dev.bwtLength >= (1ull << 28) && g->dev.seedK >= 8 && g->dev.seedK < kAutoDeepSeedMin) {
     /* Automatic: an image far beyond the L2s gets the deepest table of 14..16 characters that has no more than two
      * entries per text position, when the device has room to spare (8 B -- 16 B from 2^32 positions -- x 4^K: 2.1 GB
@@ -998,8 +1013,10 @@ enum AwFmReturnCode awfmGpuSearchTally(AwFmGpuIndex *g, const uint8_t *dChars, c
      * the image view without the device-only deeper table; the image itself is not touched (other threads may
      * be searching through it) */
     DevIndex plain = g->dev;
-    plain.deepSeed = nullptr;
-    plain.deepK = 0;
+    if (!getenv("AWFM_GPU_TALLY_WITH_DEEP")) { /* (measurement knob: what the kernel executes behind the deeper table) */
+      plain.deepSeed = nullptr;
+      plain.deepK = 0;
+    }
     launchSearch<true>(g, plain, lanesPerQuery(g), (hipStream_t)0, dChars, (const unsigned long long *)dOffsets,
                        fixedLength, numQueries, nullptr, nullptr, dTally);
     e = hipGetLastError();

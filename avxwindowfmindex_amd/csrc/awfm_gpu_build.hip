@@ -396,6 +396,37 @@ __global__ void __launch_bounds__(kThreads)
   }
 }
 
+/* The same level step for the amino alphabet: entry letter * parentLen + p of the level is the level-below entry p after
+ * one backward step with `letter` (0..19: the index puts the leftmost character first, ref src/AwFmKmerTable.c:37-51), or
+ * that entry unchanged when its range is already empty.  One group of 4 lanes per entry (aminoStepAny: the step of the
+ * search kernel); consecutive entries have consecutive parents, whose ranges are neighbours in the BWT. */
+template <bool OUT8>
+__global__ void __launch_bounds__(kThreads)
+    aminoDeepSeedLevelKernel(const DevIndex ix, const ulonglong2 *__restrict__ parentLevel, u64 parentLen, u64 outLen,
+                             ulonglong2 *__restrict__ out) {
+  constexpr int G = 4;
+  __shared__ u64 sC[24];
+  __shared__ AminoShared sAmino;
+  __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
+  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  aminoStageTables(sAmino);
+  stageMaskTable(sMask);
+  __syncthreads();
+  const unsigned g = threadIdx.x % G;
+  const u64 numGroups = (u64)gridDim.x * (kThreads / G);
+  for (u64 e = ((u64)blockIdx.x * kThreads + threadIdx.x) / G; e < outLen; e += numGroups) {
+    const unsigned letter = (unsigned)(e / parentLen);
+    const ulonglong2 r = parentLevel[e % parentLen];
+    u64 sp = r.x, ep = r.y;
+    /* a query stops at its first invalid range and keeps it (ref src/AwFmParallelSearch.c:293-294) */
+    if (sp <= ep) aminoStepAny<G, false>(ix, sC, sAmino, sMask, g, letter, sp, ep);
+    if (g == 0) {
+      if (OUT8) ((uint2 *)out)[e] = make_uint2((unsigned)sp, (unsigned)(ep + 1ull - sp));
+      else out[e] = make_ulonglong2(sp, ep);
+    }
+  }
+}
+
 /* ---- sampled SA ---- */
 
 /* 64-bit word j of the little-endian bit stream of samples SA[s*ratio], `width` bits each
@@ -631,17 +662,19 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
   if (peakBytesOut) *peakBytesOut = 0;
   u64 curBytes = 0; /* the level the next one is made from (0: the index's own table) */
   const unsigned K = g->dev.seedK;
-  if (g->amino || deepK <= K || deepK > 16 || K == 0) {
-    awfmGpuSetError("deep seed table: nucleotide images only, seedK < deepK <= 16");
+  /* nucleotide: up to 16 characters (2^32 entries); amino: up to 7 (20^7 = 1.28 * 10^9 entries, the index a 32-bit sum) */
+  if (deepK <= K || deepK > (g->amino ? 7u : 16u) || K == 0) {
+    awfmGpuSetError("deep seed table: seedK < deepK <= 16 (nucleotide) / 7 (amino)");
     return false;
   }
+  const unsigned card = g->amino ? 20u : 4u;
   DeviceGuard guard(g->device);
   u64 len = 1;
-  for (unsigned i = 0; i < K; i++) len *= 4;
+  for (unsigned i = 0; i < K; i++) len *= card;
   DeviceBuffer cur, nxt;
   const ulonglong2 *parent = g->dev.seed;
   for (unsigned L = K; L < deepK; L++) {
-    const u64 outLen = len * 4;
+    const u64 outLen = len * card;
     const bool out8 = L + 1 == deepK && g->dev.bwtLength < (1ull << 32); /* the table itself, 8-byte entries */
     if (!nxt.alloc(outLen * (out8 ? 8 : 16))) return false;
     if (peakBytesOut && curBytes + outLen * (out8 ? 8 : 16) > *peakBytesOut) *peakBytesOut = curBytes + outLen * (out8 ? 8 : 16);
@@ -649,7 +682,14 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
     const u64 blocks = (outLen + kSeedGroupsPerBlock * kUnroll - 1) / (kSeedGroupsPerBlock * kUnroll);
     const u64 resident = (u64)g->numCUs * 8u; /* a persistent grid: what does not fit the chip would only queue */
     const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
-    if (out8)
+    if (g->amino) {
+      const u64 aminoBlocks = (outLen + kThreads / 4 - 1) / (kThreads / 4);
+      const unsigned aminoGrid = (unsigned)(aminoBlocks < resident ? aminoBlocks : resident);
+      if (out8)
+        hipLaunchKernelGGL((aminoDeepSeedLevelKernel<true>), dim3(aminoGrid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>());
+      else
+        hipLaunchKernelGGL((aminoDeepSeedLevelKernel<false>), dim3(aminoGrid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>());
+    } else if (out8)
       hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, true>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen,
                          nxt.as<ulonglong2>());
     else

@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
   typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sPow[32];
+  __shared__ unsigned sPowDeep[AMINO ? 32 : 1]; /* amino: the same weights for the device-only deeper table */
   __shared__ AminoShared sAmino;
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices]; /* sMask[local * 4 + slice] = bits of the slice at positions <= local */
   __shared__ unsigned long long sSuper[!AMINO && !NARROW ? kMaxNucSuper * 4 : 1];
@@ -76,6 +77,11 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
     unsigned w = 1;
     for (unsigned e = threadIdx.x + 1; e < ix.seedK; e++) w *= card;
     sPow[threadIdx.x] = w;
+    if (AMINO) {
+      unsigned d = 1;
+      for (unsigned e = threadIdx.x + 1; e < ix.deepK; e++) d *= card;
+      sPowDeep[threadIdx.x] = d;
+    }
   }
   if (AMINO) aminoStageTables(sAmino);
   __syncthreads();
@@ -186,8 +192,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
       unsigned long long index = 0;
       bool ambiguousGroup = false; /* group-uniform */
       if (AMINO) {
-        unsigned partial = 0;
-        bool ambiguous = false;
+        unsigned partial = 0, partialDeep = 0;
+        bool ambiguous = false, ambiguousDeep = false;
+        const unsigned DK = ix.deepK; /* device-only deeper table (0: none): the index over the last DK characters */
+        const bool tryDeep = DK != 0u && len >= DK;
         if (tryTable) {
 #pragma unroll
           for (int w = 0; w < W; w++) {
@@ -197,14 +205,30 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
               const int j = (int)i - (int)(len - K);             /* index in the seed */
               const unsigned c = (win[w] >> (8u * b)) & 0xFFu;
               const bool inSeed = i < len && j >= 0;
+              const unsigned letter = aminoLetterIndex(sAmino, c);
               ambiguous |= inSeed && aminoIsAmbiguous(c);
-              partial += inSeed ? aminoLetterIndex(sAmino, c) * sPow[j & 31] : 0u;
+              partial += inSeed ? letter * sPow[j & 31] : 0u;
+              const int jd = (int)i - (int)(len - DK);           /* index in the last DK characters */
+              const bool inDeep = tryDeep && i < len && jd >= 0;
+              ambiguousDeep |= inDeep && aminoIsAmbiguous(c);
+              partialDeep += inDeep ? letter * sPowDeep[jd & 31] : 0u;
             }
           }
         }
         index = groupSum<G>(partial);
         const unsigned long long ballot = __ballot(ambiguous);
         ambiguousGroup = ((unsigned)(ballot >> (lane & ~(unsigned)(G - 1))) & ((1u << G) - 1u)) != 0u;
+        if (tryDeep) { /* (uniform across the group) same answer as the seed entry followed by DK - K extension steps */
+          const unsigned indexDeep = groupSum<G>(partialDeep);
+          const unsigned long long ballotDeep = __ballot(ambiguousDeep);
+          if (((unsigned)(ballotDeep >> (lane & ~(unsigned)(G - 1))) & ((1u << G) - 1u)) == 0u) {
+            const ulonglong2 r = deepSeedEntry(ix, indexDeep);
+            sp = (pos_t)r.x;
+            ep = (pos_t)r.y;
+            pos = (int)(len - DK) - 1;
+            deep = true;
+          }
+        }
       } else {
         /* Nucleotide: with 4 letters the table index is simply the 2-bit letter codes of the last K
          * characters concatenated, first character most significant.  Decode the window 4 characters at a

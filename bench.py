@@ -156,7 +156,7 @@ def launch_ranks(args):
         sys.exit(1)
 
 
-def end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, amino, dev):
+def end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, amino, dev, d_planted=None, first=0, n=0):
     """wall-clock rates with the batch in HOST memory at the start and the results in host memory at the end"""
     import ctypes as C
     import numpy as np
@@ -269,6 +269,27 @@ def end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, a
         out["aos_drop_in"] = {"value": round(m / dt / 1e6, 1), "ms": round(dt * 1e3, 2), "kmers": m, "host_threads": threads,
                               "ms_all": [round(t * 1e3, 2) for t in aos_times],
                               "entry_point": "awFmParallelSearchLocate" if locate else "awFmParallelSearchCount"}
+        if locate and d_planted is not None:
+            # the same call on k-mers drawn from the text: every one has a position list to size, fill and hand back
+            from avxwindowfmindex_amd import synth
+            pchars = np.ascontiguousarray(d_planted[: m * K].cpu().numpy())
+            arr[:, 0] = pchars.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(K)
+            fn()
+            planted_times = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                fn()
+                planted_times.append(time.perf_counter() - t0)
+            got = np.ctypeslib.as_array(C.cast(data, C.POINTER(C.c_uint32)), shape=(m, 8))[:, 6]
+            assert got.min() >= 1, "a planted k-mer has no hit through the AoS entry point"
+            planted_at = synth.planted_offsets(103, 1000, K, n, first=first)
+            for i in range(1000):
+                assert int(planted_at[i]) in lst.positions(i), "a planted k-mer's own offset is missing from its positionList"
+            pdt = min(planted_times)
+            out["aos_drop_in_planted"] = {"value": round(m / pdt / 1e6, 1), "ms": round(pdt * 1e3, 2), "kmers": m, "hits": int(got.sum()),
+                                          "host_threads": threads, "ms_all": [round(t * 1e3, 2) for t in planted_times],
+                                          "entry_point": "awFmParallelSearchLocate",
+                                          "checked": "every k-mer has hits; the first 1000 position lists hold their planting offsets"}
         lst.dealloc()
     return out
 
@@ -827,6 +848,57 @@ def main():
         }
         if traffic:
             roofline["call"]["hbm_frac_measured"] = round(traffic["hbm_bytes_per_launch"] / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    elif g.deep_seed_k:
+        # The general kernel with the device-only deeper table (amino: DESIGN.md 4b): most k-mers end at their table entry,
+        # so the reference algorithm's bytes are not what the kernel reads.  `frac` prices what it EXECUTES -- an instrumented
+        # launch of the same kernel with the table on: a 128-B line per table lookup, 168 B per distinct block of the steps
+        # behind it -- and `reference_algorithm` is the same kernel without the table (the reference's steps),
+        # timed on the same batch, whose ranges must equal the timed steps'.
+        os.environ["AWFM_GPU_TALLY_WITH_DEEP"] = "1"
+        executed = g.search_tally(d_chars.data_ptr(), off_ptr, K, Q)
+        del os.environ["AWFM_GPU_TALLY_WITH_DEEP"]
+        deep_lookups = Q - executed["seeded"] if K >= g.deep_seed_k else 0  # fixed-length k-mers without ambiguity letters start at the deeper table
+        exec_bytes = executed["chars"] + 128 * deep_lookups + 16 * executed["seeded"] + rank_bytes * executed["blocks"] + 16 * Q
+        achieved = exec_bytes / (search_ms * 1e-3) / 1e9
+        had_deep = g.deep_seed_k
+        d_exact = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+        g.search(d_chars.data_ptr(), off_ptr, K, Q, d_exact.data_ptr(), 0, stream)
+        g.set_deep_seed(0)
+        d_plain = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+        g.search(d_chars.data_ptr(), off_ptr, K, Q, d_plain.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(d_exact, d_plain), "the deeper table changes a range"
+        events = []
+        for _ in range(max(args.general_steps, 1)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.search_hits(d_chars.data_ptr(), off_ptr, K, Q, d_plain.data_ptr(), d_counts.data_ptr(), stream)
+            e1.record()
+            events.append((e0, e1))
+        torch.cuda.synchronize()
+        plain_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        del d_exact, d_plain
+        g.set_deep_seed(had_deep)
+        torch.cuda.synchronize()
+        plain_gbs = alg_bytes / (plain_ms * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "kernel": f"searchKernel (device-only table of depth {had_deep})", "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel_ms": round(search_ms, 3), "basis": "executed_reads",
+            "basis_note": "achieved = (characters + 128 B per lookup in the deeper table + 16 B per seed-table entry + 168 B per "
+                          "distinct block of the steps executed behind the table + 16 B out) / kernel_ms, tallied by an instrumented "
+                          "launch of the same kernel; the reference algorithm's bytes over this kernel's time would be "
+                          "algorithmic_frac_of_this_kernel; the kernel that executes the reference's steps is in reference_algorithm",
+            "executed_bytes": int(exec_bytes), "executed_per_query": {"steps": round(executed["steps"] / Q, 4), "distinct_blocks": round(executed["blocks"] / Q, 4),
+                                                                      "deep_table_lookups": round(deep_lookups / Q, 4)},
+            "algorithmic_bytes_per_launch": int(alg_bytes), "per_query": per_query,
+            "algorithmic_frac_of_this_kernel": round(alg_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
+            "reference_algorithm": {"kernel": "searchKernel (no deeper table)", "bytes": int(alg_bytes), "kernel_ms": round(plain_ms, 3),
+                                    "frac": round(plain_gbs / HBM_PEAK_GBS, 4), "steps": max(args.general_steps, 1),
+                                    "checked": "every range equals the timed kernel's"},
+            "reference_algorithm_bytes": int(alg_bytes), "reference_algorithm_kernel_ms": round(plain_ms, 3),
+            "reference_algorithm_frac": round(plain_gbs / HBM_PEAK_GBS, 4),
+        }
     else:
         achieved = alg_bytes / (search_ms * 1e-3) / 1e9
         roofline = {
@@ -835,6 +907,7 @@ def main():
             "algorithmic_bytes_per_launch": int(alg_bytes), "per_query": per_query,
             "upper_bound_variant_GBs": round(upper_bytes / (search_ms * 1e-3) / 1e9, 1),
         }
+    if not ordered:
         gname = None
         if amino and Q == 50_000_000 and K == 10 and args.seed_k == 5 and n in (200_000_000, 2_000_000_000):
             gname = "amino" if n == 200_000_000 else "amino_2e9"
@@ -1000,7 +1073,7 @@ def main():
     # AoS entry point (awFmParallelSearchCount/Locate, ref src/AwFmParallelSearch.c:95-220), wall clock, rank 0 ----
     e2e = None
     if not args.no_e2e and world == 1 and d_offsets is None and K <= (12 if amino else 32):
-        e2e = end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, amino, dev)
+        e2e = end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, amino, dev, d_planted, first, n)
 
     def time_piece(p, steps, force=None):
         """probe + one warm-up + `steps` timed steps (wall clock between two device synchronisations) of a piece; ms per step"""
@@ -1140,9 +1213,44 @@ def main():
         proxy["digests"] = "the shards' counts and positions digests add up to the whole batch's for every N"
     del d_planted
 
+    deep_last_build = g.deep_seed_build
+    # ---- the drop-in user's FIRST call: the index in host memory (as awFmReadIndexFromFile leaves it), no device image yet.
+    # awFmParallelSearchLocate then uploads the image (3.8 GB), builds the pair image and the deeper table, and searches.
+    # The image of this run is dropped for it, so this is the last thing the run does with the GPU. ----
+    image_bytes, image_deep_k = g.device_bytes, g.deep_seed_k or args.seed_k
+    first_call = None
+    if e2e is not None and locate and args.e2e_aos_queries:
+        import ctypes as C
+        m = min(Q, 1_000_000)
+        chars = np.ascontiguousarray(d_chars[: m * K].cpu().numpy())
+        lst = api.KmerSearchList(m)
+        arr = np.ctypeslib.as_array(C.cast(lst.ptr.contents.kmerSearchData, C.POINTER(C.c_uint64)), shape=(m, 4))
+        arr[:, 0] = chars.ctypes.data + np.arange(m, dtype=np.uint64) * np.uint64(K)
+        arr[:, 1] = K
+        lst.ptr.contents.count = m
+        threads = min(32, 2 * (os.cpu_count() or 1))
+        torch.cuda.synchronize()
+        g.handle = None  # the handle belongs to the index's registry entry, which goes now
+        L.awfmGpuIndexRelease(ix.ptr)
+        t0 = time.perf_counter()
+        rc = api.parallel_search_locate(ix, lst, threads)
+        t1 = time.perf_counter()
+        api.parallel_search_locate(ix, lst, threads)
+        t2 = time.perf_counter()
+        assert rc == api.AwFmSuccess
+        got = np.ctypeslib.as_array(C.cast(lst.ptr.contents.kmerSearchData, C.POINTER(C.c_uint32)), shape=(m, 8))[:, 6]
+        assert int(got.sum()) > 0
+        first_call = {"first_call_s": round(t1 - t0, 3), "second_call_s": round(t2 - t1, 4), "kmers": m,
+                      "what": "awFmParallelSearchLocate on an index that has no device image yet: image upload + pair image + "
+                              "deeper table + the search; the second call is the same list again"}
+        if e2e is not None:
+            e2e["first_call"] = first_call
+        lst.dealloc()
+        g = None
+
     per = "per GPU" if args.scaling == "weak" else f"in total, sharded over {world} rank(s)"
-    deep_build_s, deep_transient = deep_first_build if args.device_seed_k < 0 else g.deep_seed_build
-    deep_rebuild_s = g.deep_seed_build[0]
+    deep_build_s, deep_transient = deep_first_build if args.device_seed_k < 0 else deep_last_build
+    deep_rebuild_s = deep_last_build[0]
     form_names = {"order": "every k-mer {k-mer number, range} in search order + hit offsets and positions in that order",
                   "list": "list of the k-mers with hits {k-mer number, range} in k-mer order + hit offsets over the list + positions",
                   "dense": "range / count under every k-mer number + hit offsets over the batch + positions"}
@@ -1156,7 +1264,7 @@ def main():
               "hits_per_step_rank0": int(state["hits"]), "locate_kernels_ms": round(locate_ms, 3),
               "search_call_ms": round(search_ms, 3), "host_waits_per_step": 0 if not whole.windowed else "one per window",
               "index_build_s": round(build_s, 2),
-              "device_image_bytes": g.device_bytes, "device_seed_k": g.deep_seed_k or args.seed_k,
+              "device_image_bytes": image_bytes, "device_seed_k": image_deep_k,
               # the deeper table's construction, whoever started it (the library by itself at awfmGpuIndexAcquire, inside
               # index_build_s; or --device-seed-k): wall seconds and the device memory held beyond the table at the peak
               "device_seed_build_s": round(deep_build_s, 2), "device_seed_transient_bytes": int(deep_transient),
@@ -1173,6 +1281,8 @@ def main():
     if secondary:
         config["planted_ms_per_step"] = secondary["ms_per_step"]
         config["planted_dense_form_ms_per_step"] = secondary["dense_form"]["ms_per_step"]
+    if first_call:
+        config["aos_first_call_s"] = first_call["first_call_s"]
     if proxy:
         e8 = proxy["shards"]["batch"]["8"]
         config["scaling_proxy_8_efficiency"] = e8["efficiency"]

@@ -126,6 +126,79 @@ def _planted_batch(big, Q, K, seed, first=0):
     return d
 
 
+def test_full_size_index_arrays_against_the_text(grch38):
+    """The 3.1 Gbp index is too large for the oracle to rebuild, so the searches above are checked by the oracle's arithmetic
+    over the PRODUCT's index arrays.  This test closes that gap one notch with checks that use no FM-index code at all --
+    only the text, the reference's array formats (ref src/AwFmCreate.c:291-344, src/AwFmSuffixArray.c:22-39) and the
+    definition of a suffix array (the properties the reference's own tests assert: test/bwtTest/bwtTest.c:95-126,
+    test/createTests/AwFmCreationTest.c:151-183):
+      prefixSums           = 1 + the byte histogram of the text, letter by letter;
+      10^6 random samples i: the suffixes at SA_sampled[i] and SA_sampled[i + 1] are in lexicographic order by direct
+                             comparison of the text, and the BWT letter stored at position i * ratio is text[SA - 1]."""
+    big, t = grch38, grch38.torch
+    n, ratio = big.n, big.ratio
+    ix = big.ix
+    # ---- prefix sums against the histogram of the text ----
+    hist = t.zeros(256, dtype=t.int64, device=big.dev)
+    step = 1 << 28
+    for b in range(0, n, step):
+        hist += t.bincount(big.text[b:b + step].to(t.int64), minlength=256)
+    hist = hist.cpu().numpy()
+    letters = [ord(c) for c in "acgt"]
+    assert hist[letters].sum() == n, "the synthetic text holds other characters than a, c, g, t"
+    expect = np.concatenate([[1], 1 + np.cumsum(hist[letters]), [1 + n]]).astype(np.uint64)  # a, c, g, t, x (none), end
+    assert np.array_equal(ix.prefix_sums(), expect), "prefixSums differ from the text's histogram"
+    # ---- the sampled suffix array, unpacked by its format alone ----
+    bwt_length = n + 1
+    width = int(bwt_length - 1).bit_length()
+    packed = ix.packed_sa()
+    num_samples = (bwt_length + ratio - 1) // ratio
+    rng = np.random.default_rng(12345)
+    i = np.unique(np.concatenate([rng.integers(0, num_samples - 1, 1_000_000), [0, 1, num_samples - 2]])).astype(np.uint64)
+
+    def sample(idx):
+        bit = idx * np.uint64(width)
+        byte = (bit >> np.uint64(3)).astype(np.int64)
+        word = np.zeros(len(idx), dtype=np.uint64)
+        for k in range(8):  # the 8 bytes that hold the value (width <= 57), little endian
+            word |= packed[byte + k].astype(np.uint64) << np.uint64(8 * k)
+        return (word >> (bit & np.uint64(7))) & np.uint64((1 << width) - 1)
+
+    sa0, sa1 = sample(i), sample(i + np.uint64(1))
+    assert sa0.max() <= n and sa1.max() <= n
+    assert sample(np.array([0], dtype=np.uint64))[0] == n, "the first suffix is the sentinel's"
+    # lexicographic order by the text itself: first difference within 64 characters (uniform text: ties end after ~16);
+    # running off the end of the text is the sentinel, which sorts first
+    a, b = t.from_numpy(sa0.astype(np.int64)).to(big.dev), t.from_numpy(sa1.astype(np.int64)).to(big.dev)
+    undecided = t.ones(len(i), dtype=t.bool, device=big.dev)
+    ordered = t.zeros(len(i), dtype=t.bool, device=big.dev)
+    for c in range(64):
+        pa, pb = a + c, b + c
+        ca = t.where(pa < n, big.text[pa.clamp(max=n - 1)].to(t.int64), t.full_like(pa, -1))
+        cb = t.where(pb < n, big.text[pb.clamp(max=n - 1)].to(t.int64), t.full_like(pb, -1))
+        ordered |= undecided & (ca < cb)
+        wrong = undecided & (ca > cb)
+        assert not bool(wrong.any()), f"sampled suffixes out of order (character {c})"
+        undecided &= ca == cb
+        if not bool(undecided.any()):
+            break
+    assert not bool(undecided.any()) and bool(ordered.all()), "sampled suffixes tie for 64 characters"
+    # ---- the BWT letter at the sampled positions, read from the reference-layout blocks by their format alone ----
+    blocks = ix.blocks()
+    p = (i * np.uint64(ratio)).astype(np.int64)
+    blk, within = p // 256, p % 256
+    code = np.zeros(len(p), dtype=np.uint8)
+    for plane in range(3):  # planes at byte offsets 0 / 32 / 64 of a 160-byte block, position j -> byte j / 8, bit j % 8
+        code |= ((blocks[blk * 160 + 32 * plane + within // 8] >> (within % 8).astype(np.uint8)) & 1) << plane
+    letter_of_code = np.zeros(8, dtype=np.uint8)  # ref src/AwFmLetter.c:44-47: a 110b, c 101b, g 011b, t 001b, x 010b, $ 100b
+    letter_of_code[[6, 5, 3, 1, 2, 4]] = [ord(c) for c in "acgtx$"]
+    got = letter_of_code[code]
+    before = t.from_numpy(np.maximum(sa0.astype(np.int64) - 1, 0)).to(big.dev)
+    want = big.text[before].cpu().numpy().copy()
+    want[sa0 == 0] = ord("$")  # the suffix that starts the text is preceded by the sentinel
+    assert np.array_equal(got, want), "a BWT letter is not the character before its suffix"
+
+
 def test_cfg2_and_cfg3a_random_21mers_counted_and_located(grch38):
     """cfg 2 (count) and cfg 3a (locate) share the batch: 100 M uniform random 21-mers, seed 102"""
     big, t, Q, K = grch38, grch38.torch, BATCH, 21

@@ -193,6 +193,45 @@ def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, requir
     ix.dealloc()
 
 
+@pytest.mark.parametrize("seed_k,deep_k,lanes", [(2, 4, None), (3, 5, None), (1, 3, "g4"), (2, 5, "g4")])
+def test_amino_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, require_gpu, wide, monkeypatch, seed_k, deep_k, lanes):
+    """the same for the amino alphabet (20^deep_k entries, the index of ref src/AwFmKmerTable.c:37-51 over the last deep_k
+    characters): exact ranges -- the first empty range of an absent k-mer included --, counts and positions, for k-mers
+    shorter than the table, ambiguity letters (z, x, b) inside and outside its characters, upper case; two and four
+    lanes per k-mer"""
+    if lanes:
+        monkeypatch.setenv("AWFM_GPU_KERNEL", lanes)
+    n = 120000
+    txt = synth.text(700 + deep_k, n, synth.AMINO_ALPHABET).copy()
+    txt[500:503] = ord("x")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetAmino, 8, seed_k)
+    oi = oracle.Index.wrap(oracle.AMINO, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
+                           ix.packed_sa())
+    chars, offsets = _mixed_queries(800 + deep_k, 6000, txt, synth.AMINO_ALPHABET, 1, 14, ambiguity=ord("z"), upper=True)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    assert (cnt == 0).sum() > 500 and (cnt > 0).sum() > 500
+    g = awfm.GpuIndex(ix)
+    before = g.device_bytes
+    g.set_deep_seed(deep_k)
+    assert g.deep_seed_k == deep_k and g.device_bytes == before + 8 * 20 ** deep_k
+    ranges, ho, p = g.locate_host(chars, offsets)
+    assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep)
+    assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
+    # fixed-length batches through the hits-only entry point (what the bench and the pipelines call)
+    K = deep_k + 2
+    q = np.concatenate([synth.random_queries(810 + deep_k, 3000, K, synth.AMINO_ALPHABET), synth.planted_queries(811, 3000, K, txt)])
+    fchars, foffsets = synth.fixed_csr(q)
+    fsp, fep, fcnt, _ = oi.batch_search(fchars, foffsets)
+    franges, fcounts = g.count_host(fchars, foffsets)
+    assert np.array_equal(franges[:, 0], fsp) and np.array_equal(franges[:, 1], fep) and np.array_equal(fcounts, fcnt)
+    g.set_deep_seed(0)
+    ranges2, counts2 = g.count_host(chars, offsets)
+    assert np.array_equal(ranges2, ranges) and np.array_equal(counts2, cnt) and g.device_bytes == before
+    g.destroy()
+    ix.dealloc()
+
+
 @pytest.mark.parametrize("pair", ["1", "0"])
 def test_deep_seed_table_next_step_bits_and_long_ranges(oracle, awfm, require_gpu, monkeypatch, pair):
     """On images with pair blocks the 8-byte entries of the deeper table are {sp, length16 | next16 << 16}: the lengths
