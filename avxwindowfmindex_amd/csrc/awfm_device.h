@@ -185,6 +185,13 @@ __device__ __forceinline__ void sparseAppend(const SparseOut &out, bool hit, uns
   }
 }
 
+/* "Lookup first" chosen on the device: sampleAliveKernel leaves the number of its samples that are alive in a device
+ * word, and the kernels of BOTH front ends are launched -- the one the sample does not choose returns at once -- so that
+ * a search never waits for the host to read that word.  sampleAlive == nullptr: no sample was taken, `otherwise` says. */
+__device__ __forceinline__ bool lookupChosen(const unsigned *__restrict__ sampleAlive, const unsigned samples, const bool otherwise) {
+  return sampleAlive ? *sampleAlive * 4u < samples : otherwise;
+}
+
 /* BWT positions are 32-bit when bwtLength < 2^32 (NARROW): half the integer work of the range arithmetic */
 template <bool NARROW>
 struct PositionType {
@@ -871,6 +878,11 @@ bool awfmGpuRelayout(const void *dRefBlocks, uint64_t bwtLength, bool amino, uns
 int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                          uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, bool packed = false,
                          bool rangesOfHitsOnly = false);
+
+/* hits-only search of a large fixed-length amino batch through the deeper table (awfm_amino_lookup_kernel.h):
+ * 1 = searched, 0 = does not apply, < 0 = -AwFmReturnCode */
+int awfmGpuAminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength, unsigned long long nq,
+                             ulonglong2 *rng, uint32_t *dCounts, bool rangesOfHitsOnly);
 
 /* adopts device buffers that already hold a complete image (used by the GPU builder) */
 AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSuper, unsigned superShift,

@@ -989,6 +989,13 @@ static enum AwFmReturnCode searchHits(AwFmGpuIndex *g, const uint8_t *dChars, co
     if (ordered < 0 && ordered != -(int)AwFmAllocationFailure) return (enum AwFmReturnCode)(-ordered);
     if (ordered > 0) return AwFmSuccess;
   }
+  if (g->amino && !dOffsets) { /* large fixed-length amino batches: the deeper table looked up first (awfm_amino_lookup_kernel.h) */
+    DeviceGuard guard(g->device);
+    const int did = awfmGpuAminoLookupSearch(g, (hipStream_t)stream, dChars, fixedLength, numQueries, (ulonglong2 *)dRanges, dCounts,
+                                             rangesOfHitsOnly);
+    if (did < 0 && did != -(int)AwFmAllocationFailure) return (enum AwFmReturnCode)(-did);
+    if (did > 0) return AwFmSuccess;
+  }
   return searchGeneral(g, dChars, dOffsets, fixedLength, numQueries, dRanges, dCounts, stream);
 }
 

@@ -15,6 +15,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "awfm_ordered_kernel.h"
+#include "awfm_amino_lookup_kernel.h"
 
 namespace {
 
@@ -128,7 +129,7 @@ enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t 
   hipExtLaunchKernelGGL((searchKernel<false, 4, VARLEN, false, NARROW, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, 0u,
                         g->dev, dChars, off, len, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)recs,
                         COMPACT ? 8u : (unsigned)sizeof(QueryRec), COMPACT ? 0u : (unsigned)offsetof(QueryRec, index), nq,
-                        generalCount, sparse ? *sparse : SparseOut());
+                        generalCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   g->orderDoneArmed = g->orderDoneEvent != nullptr;
   return AwFmSuccess;
@@ -157,7 +158,7 @@ enum AwFmReturnCode launchBucketed(AwFmGpuIndex *g, hipStream_t s, const uint8_t
   /* the last kernel of the search: it carries the event that says the scratch slot is free again */
   hipExtLaunchKernelGGL((searchKernel<false, 4, false, false, NARROW, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, 0u,
                         g->dev, dChars, (const unsigned long long *)nullptr, len, nq, rng, dCounts, (unsigned long long *)nullptr,
-                        (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut());
+                        (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   g->orderDoneArmed = g->orderDoneEvent != nullptr;
   return AwFmSuccess;
@@ -358,6 +359,7 @@ extern "C" double awfmGpuLastOrderedSearchKernelMs(AwFmGpuIndex *g) {
 
 extern "C" int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets, uint32_t fixedLength, uint64_t numQueries) {
   if (!g) return 0;
+  if (g->amino) return 0;
   if (!(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) return 0;
   return orderedApplies(g, hasOffsets != 0, fixedLength, numQueries, nullptr, nullptr) ? 1 : 0;
 }
@@ -886,6 +888,97 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   return 1;
 }
 
+
+/* ------------------------------------------------------------------ amino: lookup first (awfm_amino_lookup_kernel.h) */
+
+template <unsigned K>
+static void launchAminoLookupAt(unsigned len, unsigned grid, hipStream_t s, const DevIndex &dev, const uint8_t *dChars, unsigned long long nq,
+                                const unsigned *sampleAlive, unsigned samples, ulonglong2 *rng, unsigned *dCounts, const SparseOut &sparse,
+                                unsigned long long *leftover, unsigned *leftoverCount, unsigned *kept) {
+  if (len == K)
+    hipLaunchKernelGGL((aminoLookupSearchKernel<K>), dim3(grid), dim3(256), 0, s, dev, dChars, nq, sampleAlive, samples, rng, dCounts, sparse,
+                       leftover, leftoverCount, kept);
+  else if constexpr (K > 2u)
+    launchAminoLookupAt<K - 1u>(len, grid, s, dev, dChars, nq, sampleAlive, samples, rng, dCounts, sparse, leftover, leftoverCount, kept);
+}
+
+/* Hits-only search of a large fixed-length amino batch through the device-only deeper table: 1 = searched, 0 = does not
+ * apply (the caller runs the general kernel), < 0 = -AwFmReturnCode.  $AWFM_GPU_AMINO_LOOKUP=0|1: never / whenever it can
+ * (no sample); unset: batches of >= 2^20 k-mers, by a sample of the batch. */
+static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength, unsigned long long nq,
+                             ulonglong2 *rng, uint32_t *dCounts, bool rangesOfHitsOnly, const SparseOut *sparse) {
+  constexpr unsigned kMaxLength = 19; /* the table's 7 characters + 12 in front of them (5 bits each in one word) */
+  if (!g->amino || !awfmImageNarrow(g) || g->dev.deepK == 0u || g->dev.deepNarrow == 0u || g->dev.deepSeed == nullptr) return 0;
+  if (fixedLength < g->dev.deepK || fixedLength > kMaxLength || fixedLength - g->dev.deepK > 12u || nq >= 0xFFFFFFFFull) return 0;
+  if (!(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP2)) return 0;
+  const char *env = getenv("AWFM_GPU_AMINO_LOOKUP");
+  if (env ? atoi(env) == 0 : nq < (1ull << 20)) return 0;
+  const bool forced = env && atoi(env) == 1;
+  constexpr unsigned kSamples = 16384;
+  if (!forced && nq < kSamples) return 0;
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  /* [counters 4 KB: sample @0, leftover count @64 B, survivor counters @256 B][leftover list: nq x 8 B] */
+  constexpr size_t kCounterBytes = 256u + kFusedCounters * 64u;
+  const size_t listAt = alignUp256(kCounterBytes), total = listAt + alignUp256(nq * 8u);
+#define AMINO_TRY(call)                     \
+  do {                                      \
+    hipError_t e__ = (call);                \
+    if (e__ != hipSuccess) {                \
+      setError(#call, e__);                 \
+      return -(int)AwFmGeneralFailure;      \
+    }                                       \
+  } while (0)
+  AMINO_TRY(orderBeginSlot(g, s));
+  if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
+  uint8_t *w = (uint8_t *)g->dOrder;
+  unsigned *sampleWord = (unsigned *)w, *leftoverCount = (unsigned *)(w + 64), *kept = (unsigned *)(w + 256);
+  unsigned long long *leftover = (unsigned long long *)(w + listAt);
+  AMINO_TRY(hipMemsetAsync(w, 0, kCounterBytes, s));
+  if (!sparse) {
+    hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
+                       rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
+    AMINO_TRY(hipGetLastError());
+  }
+  const unsigned *sampleAlive = nullptr;
+  if (!forced) {
+    hipLaunchKernelGGL(aminoSampleAliveKernel, dim3(kSamples / 256u), dim3(256), 0, s, g->dev, dChars, fixedLength, nq, kSamples, sampleWord);
+    AMINO_TRY(hipGetLastError());
+    sampleAlive = sampleWord;
+  }
+  g->orderLookup = forced ? 1 : 2;
+  g->orderSampleAt = sampleWord;
+  g->orderSamples = kSamples;
+  g->orderLookupFused = true;
+  g->orderFusedKeptAt = kept;
+  g->orderKeptAt = leftoverCount;
+  const SparseOut out = sparse ? *sparse : SparseOut();
+  const unsigned long long rounds = (nq + 1023ull) / 1024ull; /* a workgroup takes 1024 k-mers a round */
+  unsigned grid = residentGrid(g, aminoLookupSearchKernel<10u>);
+  if (rounds < grid) grid = (unsigned)rounds;
+  launchAminoLookupAt<kMaxLength>(fixedLength, grid ? grid : 1u, s, g->dev, dChars, nq, sampleAlive, kSamples, rng, dCounts, out, leftover, leftoverCount, kept);
+  AMINO_TRY(hipGetLastError());
+  if (!forced) { /* the whole batch through the general kernel when the sample says so (it returns at once otherwise) */
+    const unsigned full = residentGrid(g, searchKernel<true, 2, false, false, true>);
+    hipLaunchKernelGGL((searchKernel<true, 2, false, false, true>), dim3(full), dim3(kThreads), 0, s, g->dev, dChars,
+                       (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
+                       (const unsigned char *)nullptr, 0u, 0u, 0ull, (const unsigned *)nullptr, out, sampleAlive, kSamples);
+    AMINO_TRY(hipGetLastError());
+  }
+  /* what the lookup kernel left: the last *leftoverCount records of the list */
+  const unsigned tail = residentGrid(g, searchKernel<true, 2, false, false, true, true>);
+  hipLaunchKernelGGL((searchKernel<true, 2, false, false, true, true>), dim3(tail), dim3(kThreads), 0, s, g->dev, dChars,
+                     (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
+                     (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out, (const unsigned *)nullptr, 0u);
+  AMINO_TRY(hipGetLastError());
+  AMINO_TRY(orderEndSlot(g, s));
+#undef AMINO_TRY
+  return 1;
+}
+int awfmGpuAminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength, unsigned long long nq,
+                             ulonglong2 *rng, uint32_t *dCounts, bool rangesOfHitsOnly) {
+  return aminoLookupSearch(g, s, dChars, fixedLength, nq, rng, dCounts, rangesOfHitsOnly, nullptr);
+}
+
 /* ------------------------------------------------------------------ compulsory-traffic tally of the seed-order search */
 
 namespace {
@@ -1013,7 +1106,7 @@ extern "C" enum AwFmReturnCode awfmGpuSearchHitsCompact(AwFmGpuIndex *g, const u
     setError("awfmGpuSearchHitsCompact: the list needs a capacity");
     return AwFmIllegalPositionError;
   }
-  if (g->amino || !(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4) || (packed && dOffsets)) {
+  if ((g->amino && (packed || dOffsets)) || (!g->amino && !(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) || (packed && dOffsets)) {
     setError("awfmGpuSearchHitsCompact: this batch does not take the seed-order path on this image");
     return AwFmUnsupportedVersionError;
   }
@@ -1027,8 +1120,9 @@ extern "C" enum AwFmReturnCode awfmGpuSearchHitsCompact(AwFmGpuIndex *g, const u
   sparse.cap = capacity;
   sparse.kmers = (unsigned *)dHitKmers;
   sparse.ranges = (ulonglong2 *)dHitRanges;
-  const int did = orderedSearch(g, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries, nullptr, nullptr,
-                                packed != 0, false, nullptr, nullptr, &sparse);
+  const int did = g->amino ? aminoLookupSearch(g, s, dChars, fixedLength, numQueries, nullptr, nullptr, false, &sparse)
+                           : orderedSearch(g, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries, nullptr, nullptr,
+                                           packed != 0, false, nullptr, nullptr, &sparse);
   if (did < 0) return (enum AwFmReturnCode)(-did);
   if (did == 0) {
     setError("awfmGpuSearchHitsCompact: this batch does not take the seed-order path on this image");

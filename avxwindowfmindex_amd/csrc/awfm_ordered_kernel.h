@@ -269,13 +269,6 @@ __device__ __forceinline__ unsigned ldsCountRank(unsigned *counters, unsigned bi
   return valid ? atomicAdd(&counters[bin], 1u) : 0u;
 }
 
-/* "Lookup first" chosen on the device: sampleAliveKernel leaves the number of its samples that are alive in a device
- * word, and the kernels of BOTH front ends are launched -- the one the sample does not choose returns at once -- so that
- * a search never waits for the host to read that word.  sampleAlive == nullptr: no sample was taken, `otherwise` says. */
-__device__ __forceinline__ bool lookupChosen(const unsigned *__restrict__ sampleAlive, const unsigned samples, const bool otherwise) {
-  return sampleAlive ? *sampleAlive * 4u < samples : otherwise;
-}
-
 constexpr unsigned long long kCodeNone = 1ull << 62;    /* no k-mer: an unused slot of a block encodeLookupKernel reserved */
 constexpr unsigned kLookupBlock = 64;                   /* slots a wave of encodeLookupKernel reserves at a time */
 constexpr unsigned kShareCountStride = 64;              /* words between the shares' slot counters (a line each) */

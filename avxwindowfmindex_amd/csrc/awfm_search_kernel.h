@@ -53,7 +53,10 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
                  unsigned long long *__restrict__ tally, const unsigned char *__restrict__ subset = nullptr,
                  const unsigned subsetStride = 0, const unsigned subsetIndexAt = 0,
                  const unsigned long long subsetTotal = 0, const unsigned *__restrict__ subsetCount = nullptr,
-                 const SparseOut sparse = SparseOut()) {
+                 const SparseOut sparse = SparseOut(),
+                 /* launched beside a lookup-first kernel whose sample decides on the device which of the two works */
+                 const unsigned *__restrict__ skipWhenLookup = nullptr, const unsigned skipSamples = 0) {
+  if (skipWhenLookup && lookupChosen(skipWhenLookup, skipSamples, false)) return; /* uniform */
   constexpr int W = 8 / G; /* window dwords per lane: the group holds the last 32 characters of its k-mer */
   constexpr int S = (int)kSlices / G; /* block slices per lane */
   constexpr int kGroups = kThreads / G;
@@ -210,7 +213,9 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
               partial += inSeed ? letter * sPow[j & 31] : 0u;
               const int jd = (int)i - (int)(len - DK);           /* index in the last DK characters */
               const bool inDeep = tryDeep && i < len && jd >= 0;
-              ambiguousDeep |= inDeep && aminoIsAmbiguous(c);
+              /* (any character that is not one of the 20 letters: its index 20 would carry into the next digit of the
+               * sum and name another k-mer's entry; such k-mers start from the index's own table, as in the reference) */
+              ambiguousDeep |= inDeep && (aminoIsAmbiguous(c) || letter >= 20u);
               partialDeep += inDeep ? letter * sPowDeep[jd & 31] : 0u;
             }
           }

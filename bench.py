@@ -446,7 +446,11 @@ def main():
     # on the device (awfmGpuSortHitsOnDevice / awfmGpuHitOffsetsOnDevice / awfmGpuLocateOnDevice), and what they were is
     # checked against the probe's after the timed region.
     list_cap = max(Q // 64, 1024)
-    have_list = ordered and locate and not dense_only
+    # (amino: large fixed-length batches whose k-mers reach the device-only deeper table are looked up first, and that kernel
+    # can list its hits as the seed-order search does: awfm_amino_lookup_kernel.h)
+    amino_lookup = bool(amino and d_offsets is None and g.deep_seed_k and g.deep_seed_k <= K <= 19 and K - g.deep_seed_k <= 12
+                        and os.environ.get("AWFM_GPU_AMINO_LOOKUP") != "0")
+    have_list = (ordered or amino_lookup) and locate and not dense_only
     have_order = ordered and locate and not dense_only
     if have_list:
         d_hit_kmers = torch.empty(list_cap, dtype=torch.int32, device=dev)
@@ -473,7 +477,7 @@ def main():
             self.off_ptr = d_offsets.data_ptr() + 8 * begin if d_offsets is not None else 0
             self.cap = max(q // 64, 1024)  # the list's capacity
             # (a small piece may fall below the size from which batches are searched in seed order: dense results then)
-            self.ordered = bool(ordered and g.search_hits_is_ordered(d_offsets is not None, K, q))
+            self.ordered = bool(ordered and g.search_hits_is_ordered(d_offsets is not None, K, q)) or (amino_lookup and q >= (1 << 20))
             self.form = None
             self.hits = self.listed = 0
             self.windowed = False
@@ -849,7 +853,8 @@ def main():
         if traffic:
             roofline["call"]["hbm_frac_measured"] = round(traffic["hbm_bytes_per_launch"] / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     elif g.deep_seed_k:
-        # The general kernel with the device-only deeper table (amino: DESIGN.md 4b): most k-mers end at their table entry,
+        # The kernel that starts from the device-only deeper table -- aminoLookupSearchKernel for large fixed-length amino
+        # batches, the general kernel otherwise (amino: DESIGN.md 4b): most k-mers end at their table entry,
         # so the reference algorithm's bytes are not what the kernel reads.  `frac` prices what it EXECUTES -- an instrumented
         # launch of the same kernel with the table on: a 128-B line per table lookup, 168 B per distinct block of the steps
         # behind it -- and `reference_algorithm` is the same kernel without the table (the reference's steps),
@@ -882,7 +887,8 @@ def main():
         torch.cuda.synchronize()
         plain_gbs = alg_bytes / (plain_ms * 1e-3) / 1e9
         roofline = {
-            "bound": "hbm", "kernel": f"searchKernel (device-only table of depth {had_deep})", "achieved": round(achieved, 1),
+            "bound": "hbm", "kernel": ("aminoLookupSearchKernel" if amino_lookup and Q >= (1 << 20) else "searchKernel") + f" (device-only table of depth {had_deep})",
+            "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "kernel_ms": round(search_ms, 3), "basis": "executed_reads",
             "basis_note": "achieved = (characters + 128 B per lookup in the deeper table + 16 B per seed-table entry + 168 B per "

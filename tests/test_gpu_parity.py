@@ -208,6 +208,11 @@ def test_amino_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, 
     oi = oracle.Index.wrap(oracle.AMINO, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
                            ix.packed_sa())
     chars, offsets = _mixed_queries(800 + deep_k, 6000, txt, synth.AMINO_ALPHABET, 1, 14, ambiguity=ord("z"), upper=True)
+    odd = np.random.default_rng(deep_k).random(chars.size) < 0.01
+    chars[odd] = np.frombuffer(b"xbXB", dtype=np.uint8)[np.random.default_rng(deep_k + 1).integers(0, 4, int(odd.sum()))]  # the other ambiguity letters
+    # (characters that are no amino letters at all -- j, o, u, $ -- are outside what the reference defines: its table index
+    # runs past the table, ref src/AwFmKmerTable.c:37-51, and so does the oracle's; the kernels keep such k-mers away from
+    # both tables, but there is nothing to compare them with)
     sp, ep, cnt, _ = oi.batch_search(chars, offsets)
     hit_off, pos, _ = oi.batch_locate(sp, ep)
     assert (cnt == 0).sum() > 500 and (cnt > 0).sum() > 500
@@ -228,6 +233,102 @@ def test_amino_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, 
     g.set_deep_seed(0)
     ranges2, counts2 = g.count_host(chars, offsets)
     assert np.array_equal(ranges2, ranges) and np.array_equal(counts2, cnt) and g.device_bytes == before
+    g.destroy()
+    ix.dealloc()
+
+
+@pytest.mark.parametrize("seed_k,deep_k,K,planted_share", [(2, 4, 6, 0.1), (3, 5, 10, 0.5), (2, 5, 5, 0.05), (1, 3, 15, 1.0), (2, 4, 16, 0.3)])
+def test_amino_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, monkeypatch, seed_k, deep_k, K, planted_share):
+    """aminoLookupSearchKernel forced on ($AWFM_GPU_AMINO_LOOKUP=1) for fixed-length amino batches: the deeper table is looked
+    up while the k-mers are decoded, survivors are stepped out of LDS, what the kernel does not cover (characters that are not
+    one of the 20 letters among the table's, more than 64 survivors in a round of 256: the all-planted case) goes to the
+    general kernel through the leftover list.  Dense results, counts only and the list of hits against the oracle; every
+    byte alignment of the batch; upper case, ambiguity letters and non-letters anywhere in the k-mers."""
+    import torch
+    monkeypatch.setenv("AWFM_GPU_AMINO_LOOKUP", "1")
+    n = 150000
+    txt = synth.text(900 + K, n, synth.AMINO_ALPHABET).copy()
+    txt[700:703] = ord("x")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetAmino, 8, seed_k)
+    oi = oracle.Index.wrap(oracle.AMINO, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_deep_seed(deep_k)
+    Q = 40009
+    m = int(Q * planted_share)
+    q = np.concatenate([synth.random_queries(910 + K, Q - m, K, synth.AMINO_ALPHABET), synth.planted_queries(911 + K, m, K, txt)]).copy()
+    rng = np.random.default_rng(K)
+    q = q[rng.permutation(Q)]
+    flat = q.reshape(-1)
+    odd = rng.random(flat.size) < 0.002
+    flat[odd] = np.frombuffer(b"zxbZXB", dtype=np.uint8)[rng.integers(0, 6, int(odd.sum()))]
+    up = rng.random(flat.size) < 0.3
+    flat[up] = flat[up] & 0xDF
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+    assert (cnt > 0).sum() >= m // 2
+    dev = torch.device("cuda")
+    for mis in (0, 1, 2, 3):
+        buf = torch.zeros(chars.size + 64, dtype=torch.uint8, device=dev)
+        buf[mis:mis + chars.size] = torch.from_numpy(chars).to(dev)
+        d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
+        d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+        g.search_hits(buf.data_ptr() + mis, 0, K, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+        torch.cuda.synchronize()
+        assert g.last_ordered_kernel_is_lookup()
+        _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2), d_counts.cpu().numpy().view(np.uint32), sp, ep, cnt)
+    d_counts2 = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+    g.search_hits(buf.data_ptr() + 3, 0, K, Q, 0, d_counts2.data_ptr())  # counts only
+    torch.cuda.synchronize()
+    assert np.array_equal(d_counts2.cpu().numpy().view(np.uint32), cnt)
+    # the batch at the very end of its buffer (the 16-byte loads of the last k-mers must not leave it)
+    tail = torch.zeros(4096 + chars.size, dtype=torch.uint8, device=dev)
+    tail[4096:] = torch.from_numpy(chars).to(dev)
+    g.search_hits(tail.data_ptr() + 4096, 0, K, Q, 0, d_counts2.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_counts2.cpu().numpy().view(np.uint32), cnt)
+    # the list of the k-mers with hits, sorted and located without a host wait
+    cap = Q
+    d_kmers = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_list = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+    d_num = torch.zeros(1, dtype=torch.int32, device=dev)
+    g.search_hits_compact(buf.data_ptr() + 3, 0, K, Q, d_kmers.data_ptr(), d_list.data_ptr(), cap, d_num.data_ptr())
+    g.sort_hits_on_device(d_kmers.data_ptr(), d_list.data_ptr(), cap, d_num.data_ptr(), Q)
+    torch.cuda.synchronize()
+    has = np.flatnonzero(cnt > 0)
+    listed = int(d_num.item())
+    assert listed == len(has)
+    r = d_list[:listed * 2].cpu().numpy().view(np.uint64).reshape(listed, 2)
+    assert np.array_equal(d_kmers[:listed].cpu().numpy().view(np.uint32), has)
+    assert np.array_equal(r[:, 0], sp[has]) and np.array_equal(r[:, 1], ep[has])
+    g.destroy()
+    ix.dealloc()
+
+
+def test_amino_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, monkeypatch):
+    """without $AWFM_GPU_AMINO_LOOKUP a batch of 2^20 amino k-mers or more is sampled: random 8-mers nearly all end at the
+    deeper table -> aminoLookupSearchKernel; k-mers drawn from the text all survive it -> the general kernel; counts against
+    the oracle either way"""
+    import torch
+    monkeypatch.delenv("AWFM_GPU_AMINO_LOOKUP", raising=False)
+    n, K, Q = 200000, 8, (1 << 20) + 7
+    txt = synth.text(950, n, synth.AMINO_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetAmino, 8, 3)
+    oi = oracle.Index.wrap(oracle.AMINO, 8, 3, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_deep_seed(5)
+    dev = torch.device("cuda")
+    for name, q in (("random", synth.random_queries(951, Q, K, synth.AMINO_ALPHABET).copy()), ("planted", synth.planted_queries(952, Q, K, txt).copy())):
+        q[::1000, 5] = ord("x")
+        if name == "random":
+            q[5::64] = synth.planted_queries(953, len(q[5::64]), K, txt)
+        chars, offsets = synth.fixed_csr(q)
+        _, _, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+        d_chars = torch.from_numpy(chars).to(dev)
+        d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+        g.search_hits(d_chars.data_ptr(), 0, K, Q, 0, d_counts.data_ptr())
+        torch.cuda.synchronize()
+        assert g.last_ordered_kernel_is_lookup() == (name == "random"), name
+        assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt), name
     g.destroy()
     ix.dealloc()
 
