@@ -280,6 +280,14 @@ class GpuIndex:
         """device-only full suffix array (32-bit entries) so that a locate is a single gather"""
         _check("awfmGpuIndexSetDenseSa", _lib.lib().awfmGpuIndexSetDenseSa(self.handle, int(bool(enable))))
 
+    @property
+    def has_dense_sa(self):
+        return bool(_lib.lib().awfmGpuIndexHasDenseSa(self.handle))
+
+    @property
+    def dense_sa_build_s(self):
+        return float(_lib.lib().awfmGpuIndexDenseSaBuildSeconds(self.handle))
+
     def set_pair_image(self, enable=True):
         """device-only pair image (two steps per block read); built by default with nucleotide images"""
         _check("awfmGpuIndexSetPairImage", _lib.lib().awfmGpuIndexSetPairImage(self.handle, int(bool(enable))))

@@ -734,6 +734,7 @@ struct AwFmGpuIndex {
   void *dDeepBig = nullptr; /* side list of the deeper table: keys, then lengths (DevIndex::deepBigKeys) */
   void *dDenseSa = nullptr; /* optional full suffix array, 32-bit entries */
   uint64_t denseSaBytes = 0;
+  double denseSaBuildSeconds = 0.0; /* wall time of the automatic construction (reporting) */
   void *dPairBlocks = nullptr, *dPairSuper = nullptr, *dPairSuper32 = nullptr, *dPairC = nullptr; /* pair image */
   uint64_t pairBytes = 0;
   uint64_t deviceBytes = 0;

@@ -345,6 +345,8 @@ constexpr unsigned kAutoDeepSeedMin = 14, kAutoDeepSeedMax = 16; /* depths of th
 extern "C" {
 static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g);
 static enum AwFmReturnCode applyPairFromEnv(AwFmGpuIndex *g);
+static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable);
+static enum AwFmReturnCode applyDenseSaFromEnv(AwFmGpuIndex *g);
 }
 
 AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void *dBlocks, void *dSuper, unsigned superShift,
@@ -366,6 +368,7 @@ AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void 
   if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
   (void)applyPairFromEnv(g);     /* first: the deeper table's next-step bits are computed through the pair image */
   (void)applyDeepSeedFromEnv(g); /* optional accelerator: on failure the image simply has no deeper table */
+  (void)applyDenseSaFromEnv(g);  /* the same: without it a locate walks */
   return g;
 }
 
@@ -524,6 +527,7 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
   if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
   (void)applyPairFromEnv(g); /* without it (no memory left) searches simply take one step per read */
   if (applyDeepSeedFromEnv(g) != AwFmSuccess) return fail(AwFmGeneralFailure);
+  (void)applyDenseSaFromEnv(g); /* optional accelerator: without it (no memory left) a locate walks */
   *out = g;
   return AwFmSuccess;
 }
@@ -1328,11 +1332,17 @@ enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable) {
   DeviceGuard guard(g->device);
   LaneLocks lanes(g);
   std::lock_guard<std::mutex> lock(g->workMutex);
+  const enum AwFmReturnCode rc = applyDenseSa(g, enable != 0);
+  for (AwFmGpuIndex *lane : lanes.lanes) lane->dDenseSa = g->dDenseSa;
+  return rc;
+}
+
+/* the caller holds whatever locks the image needs (none for an image nobody else has a pointer to yet) */
+static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable) {
   (void)hipDeviceSynchronize();
   if (g->dDenseSa) (void)hipFree(g->dDenseSa);
   g->dDenseSa = nullptr;
   g->denseSaBytes = 0;
-  for (AwFmGpuIndex *lane : lanes.lanes) lane->dDenseSa = nullptr;
   if (!enable) return AwFmSuccess;
   const unsigned long long n = g->dev.bwtLength;
   if (n >= (1ull << 32)) {
@@ -1365,9 +1375,37 @@ enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable) {
   }
   g->dDenseSa = dense;
   g->denseSaBytes = n * 4;
-  for (AwFmGpuIndex *lane : lanes.lanes) lane->dDenseSa = dense;
   return AwFmSuccess;
 }
+
+/* $AWFM_GPU_DENSE_SA=0|1 on an image that was just created or adopted (no lanes, nobody else holds it); unset: automatic.
+ * Automatic: an image far beyond the caches (>= 2^28 positions, below 2^32: 32-bit entries) whose suffix array is sampled
+ * gets the full one when four times its size is free on the device -- 12.4 GB of 288 for a GRCh38-sized image, computed
+ * by the LF-walk kernel itself from the sampled array (0.3 s).  A locate is then one gather per hit instead of a chain
+ * of ~ratio dependent block reads plus the sample: 10^8 planted 21-mers 18.1 -> 9.7 ms per step, and the longest chain of
+ * a small batch (60 us) is gone.  Positions are those of the walk (it wrote them); the host index, its sampled array
+ * and the .awfmi file are untouched. */
+static enum AwFmReturnCode applyDenseSaFromEnv(AwFmGpuIndex *g) {
+  bool want = false;
+  if (const char *env = getenv("AWFM_GPU_DENSE_SA")) {
+    want = atoi(env) != 0;
+  } else if (g->dev.bwtLength >= (1ull << 28) && g->dev.bwtLength < (1ull << 32) && g->dev.saRatio > 1u) {
+    size_t freeBytes = 0, totalBytes = 0;
+    DeviceGuard guard(g->device);
+    if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) want = freeBytes / 4u >= g->dev.bwtLength * 4ull + (1ull << 31);
+    else (void)hipGetLastError();
+  }
+  if (!want || g->dev.bwtLength >= (1ull << 32)) return AwFmSuccess;
+  DeviceGuard guard(g->device);
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  const enum AwFmReturnCode rc = applyDenseSa(g, true);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  g->denseSaBuildSeconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  return rc;
+}
+int awfmGpuIndexHasDenseSa(const AwFmGpuIndex *g) { return g && g->dDenseSa ? 1 : 0; }
+double awfmGpuIndexDenseSaBuildSeconds(const AwFmGpuIndex *g) { return g ? (g->shares ? g->shares : g)->denseSaBuildSeconds : 0.0; }
 
 /* ---- host-buffer entry points ---- */
 

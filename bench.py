@@ -85,8 +85,11 @@ def parse():
                    help="k-mers of the batch that also go through the drop-in AoS entry point (0: skip)")
     p.add_argument("--dist-backend", default="nccl", help="nccl (RCCL; falls back to gloo in-process when it cannot be set up) | gloo")
     p.add_argument("--force-device", type=int, default=-1, help="testing: every rank uses this GPU")
-    p.add_argument("--device-dense-sa", action="store_true",
-                   help="optional device-only full suffix array (same positions, a locate becomes one gather)")
+    p.add_argument("--device-dense-sa", action="store_true", default=None,
+                   help="device-only full suffix array (same positions, a locate becomes one gather): on whatever the library's "
+                        "default for the image (large images have it when memory allows)")
+    p.add_argument("--no-device-dense-sa", dest="device_dense_sa", action="store_false",
+                   help="locate through the LF walk and the sampled suffix array even where the image would carry the full one")
     p.add_argument("--device-seed-k", type=int, default=-1,
                    help="device-only deeper seed table (same results, fewer block reads): -1 = the library's default for "
                         "the image, 0 = none, k = that depth")
@@ -357,12 +360,13 @@ def main():
         g.set_deep_seed(args.device_seed_k)
         torch.cuda.synchronize()
         deep_s = time.time() - t1
-    dense_s = 0.0
-    if args.device_dense_sa:
+    dense_s = g.dense_sa_build_s if g.has_dense_sa else 0.0  # the library's own choice for the image
+    if args.device_dense_sa is not None and bool(args.device_dense_sa) != g.has_dense_sa:
         t1 = time.time()
-        g.set_dense_sa(True)
+        g.set_dense_sa(bool(args.device_dense_sa))
         torch.cuda.synchronize()
-        dense_s = time.time() - t1
+        dense_s = time.time() - t1 if args.device_dense_sa else 0.0
+    dense_sa_default = g.has_dense_sa  # what the timed steps locate with
 
     # ---- this rank's query shard, resident in HBM ----
     # weak: the global batch is --queries x world k-mers and rank r has k-mers [r Q, (r+1) Q); strong: the global batch
@@ -726,10 +730,10 @@ def main():
     # scripts/collect_profiles.py -> profiles/<round>/); a bench run cannot collect them itself, so they are attached only
     # when the arguments are the profiled ones, and labelled with their source.
     prof_name = None
-    if (args.device_seed_k < 0 and not args.device_dense_sa and not amino and n == 3_100_000_000 and Q == 100_000_000
+    if (args.device_seed_k < 0 and args.device_dense_sa is None and not amino and n == 3_100_000_000 and Q == 100_000_000
             and K == 21 and args.seed_k == 12 and args.sa_ratio == 8 and args.mode == "locate" and args.text == "uniform"):
         prof_name = {"random": "default", "planted": "planted"}.get(args.workload)
-    if (args.device_seed_k < 0 and not args.device_dense_sa and not amino and n == 3_100_000_000 and Q == 100_000_000
+    if (args.device_seed_k < 0 and args.device_dense_sa is None and not amino and n == 3_100_000_000 and Q == 100_000_000
             and args.workload == "mixed" and args.seed_k == 12 and args.sa_ratio == 8 and args.mode == "count" and args.text == "uniform"):
         prof_name = "mixed"
     if any(k.startswith("AWFM_GPU_") and k not in ("AWFM_GPU_TIME_ORDERED", "AWFM_GPU_DEVICE") for k in os.environ):
@@ -1067,6 +1071,7 @@ def main():
             dtt, _ = run_sample(mt, t)
             fixed[f"threads_{t}"] = {"value": round(mt / dtt / 1e6, 3), "sample": mt}
         cpu = {"value": round(m / dt / 1e6, 3), "unit": "Mkmers/s", "cores": cores, "kind": "port", **fixed,
+               "threads_1_value": fixed["threads_1"]["value"], "threads_8_value": fixed["threads_8"]["value"],  # flat copies (the 1- and 8-thread points)
                "build": builds[variant],
                "builds_timed_Mkmers_per_s": {builds[v]: round(m / t / 1e6, 3) for v, t in timed.items()},
                "sample": f"first {m} of the {Q} {args.workload} {kdesc} of rank 0, {args.mode}, same index, "
@@ -1141,26 +1146,31 @@ def main():
         pd = Piece(0, Q, chars=d_planted)
         planted_dense_ms = time_piece(pd, 3, force="dense")
         assert pd.hits == hits
-        # the same steps with the optional device-only full suffix array (awfmGpuIndexSetDenseSa: 4 bytes per BWT position
-        # of HBM, a locate is one gather instead of the LF walk): identical positions, reported beside the walk's number
-        dense = None
+        # the same steps the OTHER way of locating: through the device-only full suffix array (awfmGpuIndexSetDenseSa: 4 bytes
+        # per BWT position of HBM, a locate is one gather) when the steps above walked, through the LF walk and the sampled
+        # array (the reference's backtrace) when the image carries the full array: identical positions either way
+        other = None
         try:
             t1 = time.perf_counter()
-            g.set_dense_sa(True)
+            g.set_dense_sa(not dense_sa_default)
             torch.cuda.synchronize()
-            dense_build = time.perf_counter() - t1
-            dense_dt = time_piece(planted, 3) * 1e-3
-            dense_positions = to_dense(planted)
-            dense_pos = f"{digest.positions_digest(first, d_hit_off, dense_positions[:hits]):016x}"
-            del dense_positions
-            assert dense_pos == pdig["positions"], "positions through the dense suffix array differ from the walk's"
-            dense = {"value": round(Q / dense_dt / 1e6, 2), "ms_per_step": round(dense_dt * 1e3, 3), "build_s": round(dense_build, 2),
-                     "extra_device_bytes": 4 * ix.bwt_length, "checked": "positions digest equals the LF walk's"}
+            other_build = time.perf_counter() - t1
+            other_dt = time_piece(planted, 3) * 1e-3
+            other_positions = to_dense(planted)
+            other_pos = f"{digest.positions_digest(first, d_hit_off, other_positions[:hits]):016x}"
+            del other_positions
+            assert other_pos == pdig["positions"], "positions through the full suffix array differ from the walk's"
+            other = {"value": round(Q / other_dt / 1e6, 2), "ms_per_step": round(other_dt * 1e3, 3),
+                     "checked": "positions digest equals the other way's"}
+            if not dense_sa_default:
+                other.update(build_s=round(other_build, 2), extra_device_bytes=4 * ix.bwt_length)
         except api.AwFmError as e:  # not enough device memory: the line simply has no such entry
-            dense = {"skipped": str(e)}
-        g.set_dense_sa(False)
+            other = {"skipped": str(e)}
+        g.set_dense_sa(dense_sa_default)
+        torch.cuda.synchronize()
         secondary = {"workload": f"{Q / 1e6:g} M planted {K}-mers (every k-mer has >= 1 hit), locate, same index",
-                     "with_device_dense_sa": dense,
+                     "device_dense_sa": dense_sa_default,
+                     ("with_lf_walk" if dense_sa_default else "with_device_dense_sa"): other,
                      "value": round(Q / dt / 1e6, 2), "unit": "Mkmers/s", "ms_per_step": round(dt * 1e3, 3), "steps": 3,
                      "result_form": planted.form,
                      "dense_form": {"ms_per_step": round(planted_dense_ms, 3), "value": round(Q / planted_dense_ms / 1e3, 1), "steps": 3},
@@ -1254,6 +1264,15 @@ def main():
         lst.dealloc()
         g = None
 
+    # the clocks this box ran at (boxes of the pool differ by several per cent on the same code: the line says which one it was)
+    clocks = None
+    try:
+        import subprocess
+        smi = json.loads(subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout)
+        card = smi[sorted(smi)[max(args.force_device, 0) if world == 1 else rank]]
+        clocks = {k.split(" ")[0]: v for k, v in card.items() if "clock level" in k}
+    except Exception:  # noqa: BLE001  (reporting only)
+        pass
     per = "per GPU" if args.scaling == "weak" else f"in total, sharded over {world} rank(s)"
     deep_build_s, deep_transient = deep_first_build if args.device_seed_k < 0 else deep_last_build
     deep_rebuild_s = deep_last_build[0]
@@ -1275,7 +1294,7 @@ def main():
               # index_build_s; or --device-seed-k): wall seconds and the device memory held beyond the table at the peak
               "device_seed_build_s": round(deep_build_s, 2), "device_seed_transient_bytes": int(deep_transient),
               "device_seed_rebuild_s": round(deep_rebuild_s, 2),  # the same construction once more (after roofline_general dropped the table): the allocator has the memory at hand
-              "device_dense_sa": bool(args.device_dense_sa), "device_dense_sa_build_s": round(dense_s, 2),
+              "device_dense_sa": dense_sa_default, "device_dense_sa_build_s": round(dense_s, 2),
               "search_path": ({"order": "awfmGpuSearchHitsInOrder", "list": "awfmGpuSearchHitsCompact",
                                "dense": "awfmGpuSearchHitsSparse" if narrow_counts else "awfmGpuSearchHits"}[whole.form] if locate
                               else "awfmGpuSearchHits") + (", seed order" if ordered else ", general kernel"),
@@ -1286,7 +1305,17 @@ def main():
         config["dense_form_value"] = dense_form["value"]
     if secondary:
         config["planted_ms_per_step"] = secondary["ms_per_step"]
+        if secondary.get("with_lf_walk") and "ms_per_step" in secondary["with_lf_walk"]:
+            config["planted_lf_walk_ms_per_step"] = secondary["with_lf_walk"]["ms_per_step"]
         config["planted_dense_form_ms_per_step"] = secondary["dense_form"]["ms_per_step"]
+    if clocks:
+        config["gpu_clocks"] = clocks
+        for name in ("sclk", "mclk", "fclk"):
+            if name in clocks:
+                config[f"gpu_{name}"] = str(clocks[name])
+    if kernel_log:
+        doms = [(f if lookup_first else k) for f, k in kernel_log]
+        config["dominant_kernel_ms_first_min_max"] = [round(doms[0], 3), round(min(doms), 3), round(max(doms), 3)]
     if first_call:
         config["aos_first_call_s"] = first_call["first_call_s"]
     if proxy:

@@ -93,11 +93,14 @@ unsigned awfmGpuIndexDeepSeedK(const AwFmGpuIndex *g); /* depth of the deeper ta
  * beyond the table itself at its peak (the level below the deepest, 16 B x 4^(k-1)) */
 double awfmGpuIndexDeepSeedBuildSeconds(const AwFmGpuIndex *g);
 uint64_t awfmGpuIndexDeepSeedTransientBytes(const AwFmGpuIndex *g);
-/* Optional: keeps the full suffix array on the device (32-bit entries, 4 x bwtLength bytes: 12.4 GB for a
- * GRCh38-sized index), reconstructed once from the sampled SA with the LF-walk kernel, so that locating a
- * hit is one read instead of a chain of about ratio-1 dependent block reads.  Positions are bit-identical.
- * enable = 0 drops it.  Needs bwtLength < 2^32. */
+/* The full suffix array on the device (32-bit entries, 4 x bwtLength bytes: 12.4 GB for a GRCh38-sized index),
+ * reconstructed once from the sampled SA with the LF-walk kernel, so that locating a hit is one read instead of a
+ * chain of about ratio-1 dependent block reads.  Positions are bit-identical (the walk wrote them).  Built by default for
+ * images of 2^28 .. 2^32 positions with a sampled array when four times its size is free on the device
+ * ($AWFM_GPU_DENSE_SA=0|1: never / always); enable = 0 drops it, 1 builds it.  Needs bwtLength < 2^32. */
 enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable);
+int awfmGpuIndexHasDenseSa(const AwFmGpuIndex *g);
+double awfmGpuIndexDenseSaBuildSeconds(const AwFmGpuIndex *g); /* reporting: wall seconds of the automatic construction */
 /* Nucleotide images carry, beside the one-letter blocks, a pair image: for every BWT position the pair of its two
  * preceding text characters, in 128-byte blocks of 128 positions with 16 base counts, so that two backward steps (two
  * LF steps) are one rank over a 16-letter sequence and one block read (csrc/awfm_pair.h).  The searches and the LF

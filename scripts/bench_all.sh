@@ -1,6 +1,6 @@
 #!/bin/bash
 # every bench.py configuration quoted in DESIGN.md, one JSON line each -> gpurun_out/bench_<tag>/bench_<name>.json
-TAG=${1:-r3}
+TAG=${1:-r4}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/bench_$TAG
 mkdir -p "$OUT"
@@ -17,7 +17,13 @@ run planted_dense_results AWFM_BENCH_DENSE_RESULTS=1 -- --workload planted --no-
 run mixed -- --workload mixed
 run mixed_locate -- --workload mixed --mode locate --no-e2e --steps 2 --warmup 1
 run amino -- --alphabet amino
-run strong -- --scaling strong --no-cpu --no-e2e --no-secondary --general-steps 0
+run amino_2e9 -- --alphabet amino --text-len 2e9 --no-e2e
+run amino_no_lookup AWFM_GPU_AMINO_LOOKUP=0 -- --alphabet amino --no-cpu --no-e2e
+run amino_no_deep_table AWFM_GPU_AMINO_DEEP_SEED_K=0 -- --alphabet amino --no-cpu --no-e2e
+run weak -- --scaling weak --no-cpu --no-e2e --no-secondary --general-steps 0 --no-shard-proxy
+run no_fused_lookup AWFM_GPU_LOOKUP_FUSED=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run lookup_host_decides AWFM_GPU_LOOKUP_HOST_DECIDES=1 -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run eager_events AWFM_GPU_EAGER_EVENTS=1 -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run general AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 -- --mode count --no-cpu --no-e2e
 run general_letters AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 AWFM_GPU_GENERAL_NO_PAIR=1 -- --mode count --no-cpu --no-e2e
 run dense_results AWFM_BENCH_DENSE_RESULTS=1 -- --no-cpu --no-e2e --no-secondary --general-steps 0
@@ -29,7 +35,8 @@ run no_lookup_first_count AWFM_GPU_LOOKUP_FIRST=0 -- --mode count --no-cpu --no-
 run rocprim_sort AWFM_GPU_ORDERED_SORT=rocprim -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run mixed_rocprim_sort AWFM_GPU_ORDERED_SORT=rocprim -- --workload mixed --no-cpu --no-e2e --general-steps 0
 run nopair_default AWFM_GPU_PAIR=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
-run planted_dense_sa -- --workload planted --device-dense-sa --no-cpu --no-e2e
+run planted_lf_walk -- --workload planted --no-device-dense-sa --no-cpu --no-e2e
+run lf_walk -- --no-device-dense-sa --no-cpu --no-e2e --no-secondary --general-steps 0
 run repetitive_random -- --text repetitive --no-cpu --no-e2e --general-steps 0
 run repetitive_planted -- --text repetitive --workload planted --no-cpu --no-e2e --general-steps 0
 python3 - "$OUT" <<'PY'

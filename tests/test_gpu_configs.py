@@ -262,6 +262,17 @@ def test_cfg3b_planted_21mers_located(grch38):
     t.cuda.synchronize()
     assert t.equal(exact, ranges)
     big.check_sample_against_oracle(d_chars, None, K, Q, ranges, None, hit_off, d_pos, exact_ranges=True)
+    # a GRCh38-sized image carries the full suffix array by default (a locate is one gather): the same locate through the
+    # LF walk and the sampled array -- the reference's backtrace, ref src/AwFmParallelSearch.c:338-361 -- must give every
+    # one of the 10^8 positions again
+    if big.g.has_dense_sa:
+        big.g.set_dense_sa(False)
+        walked = t.empty(total, dtype=t.int64, device=big.dev)
+        big.g.locate(ranges.data_ptr(), hit_off.data_ptr(), Q, total, walked.data_ptr())
+        t.cuda.synchronize()
+        assert t.equal(walked, d_pos), "the LF walk and the full suffix array disagree"
+        del walked
+        big.g.set_dense_sa(True)
     # the same batch with its results in search order (awfmGpuSearchHitsInOrder): a permutation of the batch whose entries
     # carry the dense form's ranges, and whose positions, regrouped by k-mer number, are the dense form's positions
     del exact
