@@ -1270,7 +1270,7 @@ def main():
         import subprocess
         smi = json.loads(subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout)
         card = smi[sorted(smi)[max(args.force_device, 0) if world == 1 else rank]]
-        clocks = {k.split(" ")[0]: v for k, v in card.items() if "clock level" in k}
+        clocks = {k.split(" ")[0]: str(v).strip("()") for k, v in card.items() if "clock speed" in k}
     except Exception:  # noqa: BLE001  (reporting only)
         pass
     per = "per GPU" if args.scaling == "weak" else f"in total, sharded over {world} rank(s)"
