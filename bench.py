@@ -661,6 +661,7 @@ def main():
     assert not ordered or len(kernel_log) == min(args.steps, 1024), "the library logged another number of searches than were timed"
     lookup_first = bool(ordered and g.last_ordered_kernel_is_lookup())  # the dominant kernel of every step was encodeLookupKernel
     lookup_kept = g.last_ordered_kept() if lookup_first else 0  # before any other search re-uses the scratch
+    amino_looked_up = bool(amino_lookup and whole.ordered and g.last_ordered_kernel_is_lookup())  # aminoLookupSearchKernel did the timed steps (its sample said so)
     ordered_ms = [(f if lookup_first else k) for f, k in kernel_log]
     after_lookup_ms = float(np.mean([k for _, k in kernel_log])) if lookup_first else None
     state = {"hits": whole.hits, "listed": whole.form == "list", "in_order": whole.form == "order", "windowed": whole.windowed,
@@ -870,28 +871,30 @@ def main():
         exec_bytes = executed["chars"] + 128 * deep_lookups + 16 * executed["seeded"] + rank_bytes * executed["blocks"] + 16 * Q
         achieved = exec_bytes / (search_ms * 1e-3) / 1e9
         had_deep = g.deep_seed_k
-        d_exact = torch.empty(Q * 2, dtype=torch.int64, device=dev)
-        g.search(d_chars.data_ptr(), off_ptr, K, Q, d_exact.data_ptr(), 0, stream)
-        g.set_deep_seed(0)
-        d_plain = torch.empty(Q * 2, dtype=torch.int64, device=dev)
-        g.search(d_chars.data_ptr(), off_ptr, K, Q, d_plain.data_ptr(), 0, stream)
-        torch.cuda.synchronize()
-        assert torch.equal(d_exact, d_plain), "the deeper table changes a range"
-        events = []
-        for _ in range(max(args.general_steps, 1)):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            g.search_hits(d_chars.data_ptr(), off_ptr, K, Q, d_plain.data_ptr(), d_counts.data_ptr(), stream)
-            e1.record()
-            events.append((e0, e1))
-        torch.cuda.synchronize()
-        plain_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
-        del d_exact, d_plain
-        g.set_deep_seed(had_deep)
-        torch.cuda.synchronize()
-        plain_gbs = alg_bytes / (plain_ms * 1e-3) / 1e9
+        plain_ms = None
+        if args.general_steps > 0:
+            d_exact = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+            g.search(d_chars.data_ptr(), off_ptr, K, Q, d_exact.data_ptr(), 0, stream)
+            g.set_deep_seed(0)
+            d_plain = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+            g.search(d_chars.data_ptr(), off_ptr, K, Q, d_plain.data_ptr(), 0, stream)
+            torch.cuda.synchronize()
+            assert torch.equal(d_exact, d_plain), "the deeper table changes a range"
+            events = []
+            for _ in range(args.general_steps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.search_hits(d_chars.data_ptr(), off_ptr, K, Q, d_plain.data_ptr(), d_counts.data_ptr(), stream)
+                e1.record()
+                events.append((e0, e1))
+            torch.cuda.synchronize()
+            plain_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+            del d_exact, d_plain
+            g.set_deep_seed(had_deep)
+            torch.cuda.synchronize()
+        plain_gbs = alg_bytes / (plain_ms * 1e-3) / 1e9 if plain_ms else None
         roofline = {
-            "bound": "hbm", "kernel": ("aminoLookupSearchKernel" if amino_lookup and Q >= (1 << 20) else "searchKernel") + f" (device-only table of depth {had_deep})",
+            "bound": "hbm", "kernel": ("aminoLookupSearchKernel" if amino_looked_up else "searchKernel") + f" (device-only table of depth {had_deep})",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "kernel_ms": round(search_ms, 3), "basis": "executed_reads",
@@ -903,12 +906,13 @@ def main():
                                                                       "deep_table_lookups": round(deep_lookups / Q, 4)},
             "algorithmic_bytes_per_launch": int(alg_bytes), "per_query": per_query,
             "algorithmic_frac_of_this_kernel": round(alg_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
-            "reference_algorithm": {"kernel": "searchKernel (no deeper table)", "bytes": int(alg_bytes), "kernel_ms": round(plain_ms, 3),
-                                    "frac": round(plain_gbs / HBM_PEAK_GBS, 4), "steps": max(args.general_steps, 1),
-                                    "checked": "every range equals the timed kernel's"},
-            "reference_algorithm_bytes": int(alg_bytes), "reference_algorithm_kernel_ms": round(plain_ms, 3),
-            "reference_algorithm_frac": round(plain_gbs / HBM_PEAK_GBS, 4),
         }
+        if plain_ms:
+            roofline["reference_algorithm"] = {"kernel": "searchKernel (no deeper table)", "bytes": int(alg_bytes), "kernel_ms": round(plain_ms, 3),
+                                               "frac": round(plain_gbs / HBM_PEAK_GBS, 4), "steps": args.general_steps,
+                                               "checked": "every range equals the timed kernel's"}
+            roofline.update(reference_algorithm_bytes=int(alg_bytes), reference_algorithm_kernel_ms=round(plain_ms, 3),
+                            reference_algorithm_frac=round(plain_gbs / HBM_PEAK_GBS, 4))
     else:
         achieved = alg_bytes / (search_ms * 1e-3) / 1e9
         roofline = {
@@ -1196,6 +1200,7 @@ def main():
                          "walk of the batch (~60 steps), and ~20 launches",
                  "whole_batch_ms": round(whole_again_ms, 4), "whole_batch_ms_timed_loop": round(ms_per_step, 4),
                  "steps": args.proxy_steps, "shards": {}}
+        shard_digests = {}
         sources = [("batch", d_chars, mine)]
         if d_planted is not None:
             sources.append(("planted", d_planted, (first, Q, int(pdig["counts"], 16), int(pdig["positions"], 16))))
@@ -1214,11 +1219,20 @@ def main():
                     times.append(time_piece(p, args.proxy_steps))
                     if locate:
                         ppos = to_dense(p)
-                        sum_c += digest.counts_digest(first + lo, d_hit_off[1:p.q + 1] - d_hit_off[:p.q])
-                        sum_p += digest.positions_digest(first + lo, d_hit_off[: p.q + 1], ppos[: max(p.hits, 1)])
+                        dc = digest.counts_digest(first + lo, d_hit_off[1:p.q + 1] - d_hit_off[:p.q])
+                        dp = digest.positions_digest(first + lo, d_hit_off[: p.q + 1], ppos[: max(p.hits, 1)])
                         del ppos
                     else:
-                        sum_c += digest.counts_digest(first + lo, d_counts[: p.q])
+                        dc, dp = digest.counts_digest(first + lo, d_counts[: p.q]), None
+                    sum_c += dc
+                    sum_p += dp or 0
+                    # the shard's own committed digest (what rank r of an N-rank strong run must produce), when there is one
+                    skey = digest.key(args.alphabet + ("" if args.text == "uniform" else "-" + args.text), "planted" if name == "planted" else args.workload,
+                                      args.mode, n, kmer_name, args.seed_k, args.sa_ratio, first + lo, hi - lo)
+                    sdig = {"counts": f"{dc:016x}", "positions": f"{dp:016x}" if dp is not None else None}
+                    committed_shard = digest.load_golden().get(skey)
+                    assert committed_shard is None or committed_shard == sdig, f"shard digest {sdig} differs from the committed {committed_shard} ({skey})"
+                    shard_digests[skey] = sdig
                 assert (sum_c & digest.MASK) == full[2], f"{name}: the counts digests of {parts} shards do not add up to the batch's"
                 assert full[3] is None or (sum_p & digest.MASK) == full[3], f"{name}: the positions digests of {parts} shards do not add up"
                 base_ms = whole_again_ms if name == "batch" else planted_whole_ms
@@ -1226,7 +1240,12 @@ def main():
                                      "Mkmers_per_s_at_N_gpus": round(Q / max(times) / 1e3, 1),
                                      "efficiency": round(base_ms / (parts * max(times)), 4)}
             proxy["shards"][name] = per_n
-        proxy["digests"] = "the shards' counts and positions digests add up to the whole batch's for every N"
+        proxy["digests"] = ("the shards' counts and positions digests add up to the whole batch's for every N; every shard that has "
+                            "a committed digest of its own (tests/golden/bench_digests.json) equals it")
+        if args.record_digests:
+            known = json.load(open(args.record_digests)) if os.path.exists(args.record_digests) else {}
+            known.update(shard_digests)
+            json.dump(known, open(args.record_digests, "w"), indent=1, sort_keys=True)
     del d_planted
 
     deep_last_build = g.deep_seed_build
@@ -1264,15 +1283,24 @@ def main():
         lst.dealloc()
         g = None
 
-    # the clocks this box ran at (boxes of the pool differ by several per cent on the same code: the line says which one it was)
+    # the clocks this box runs at (boxes of the pool differ by several per cent on the same code: the line says which one it
+    # was).  Read from sysfs -- no child process: a process that has initialised the GPU must not start one.
     clocks = None
     try:
-        import subprocess
-        smi = json.loads(subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20).stdout)
-        card = smi[sorted(smi)[max(args.force_device, 0) if world == 1 else rank]]
-        clocks = {k.split(" ")[0]: str(v).strip("()") for k, v in card.items() if "clock speed" in k}
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        if cards:
+            base = os.path.dirname(cards[min(max(args.force_device, 0) if world == 1 else local_rank, len(cards) - 1)])
+            clocks = {}
+            for name in ("sclk", "mclk", "fclk"):
+                path = os.path.join(base, f"pp_dpm_{name}")
+                if os.path.exists(path):
+                    levels = open(path).read().split("\n")
+                    current = [ln for ln in levels if ln.strip().endswith("*")]
+                    clocks[name] = (current[0].split(":")[1].replace("*", "").strip() if current else None)
+                    clocks[name + "_max"] = levels[-2].split(":")[1].replace("*", "").strip() if len(levels) > 1 and ":" in levels[-2] else None
     except Exception:  # noqa: BLE001  (reporting only)
-        pass
+        clocks = None
     per = "per GPU" if args.scaling == "weak" else f"in total, sharded over {world} rank(s)"
     deep_build_s, deep_transient = deep_first_build if args.device_seed_k < 0 else deep_last_build
     deep_rebuild_s = deep_last_build[0]
