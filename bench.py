@@ -77,6 +77,12 @@ def parse():
     p.add_argument("--no-shard-proxy", dest="shard_proxy", action="store_false",
                    help="skip the single-GPU strong-scaling proxy (the shards 2, 4 and 8 ranks would hold, each timed alone)")
     p.add_argument("--proxy-steps", type=int, default=5, help="timed steps per shard of the proxy")
+    p.add_argument("--streams", type=int, default=1,
+                   help="streams the steps alternate between (each with its own result buffers; the image has two scratch slots): with 2 "
+                        "the launch-bound tail of step i -- ranking the list, its offsets, the locate of a few hits -- runs beside "
+                        "the table gather of step i + 1 (10^8 random 21-mers 2.85 -> 2.80 ms, a 12.5 M shard 0.45 -> 0.42 ms; the "
+                        "dominant kernels of two steps then overlap as well, so their own times say less).  1 (default): every "
+                        "step behind the one before it")
     p.add_argument("--no-dense-form", dest="dense_form", action="store_false",
                    help="skip timing the dense form of the results beside the form the steps used")
     p.add_argument("--general-steps", type=int, default=3,
@@ -464,10 +470,43 @@ def main():
     d_order_kmers = torch.empty(Q, dtype=torch.int32, device=dev) if have_order else None
     pos_buf = {"t": None}
 
+    class Lane:
+        """the result buffers and the stream of one step in flight.  Lane 0 is the buffers above on the current stream (every
+        check reads them); the others exist so that consecutive steps overlap: a step's tail is a dozen launches of kernels
+        that leave the chip idle, and the next step's table gather does not depend on it."""
+
+        def __init__(self, primary):
+            self.primary = primary
+            if primary:
+                self.ranges, self.counts, self.hit_off, self.scratch, self.order_kmers = d_ranges, d_counts, d_hit_off, d_scratch, d_order_kmers
+                if have_list:
+                    self.hit_kmers, self.hit_ranges, self.hit_off_c, self.num_hits = d_hit_kmers, d_hit_ranges, d_hit_off_c, d_num_hits
+            else:
+                self.ranges, self.counts, self.hit_off = torch.empty_like(d_ranges), torch.empty_like(d_counts), torch.empty_like(d_hit_off)
+                self.scratch = torch.empty_like(d_scratch)
+                self.order_kmers = torch.empty_like(d_order_kmers) if have_order else None
+                if have_list:
+                    self.hit_kmers, self.hit_ranges = torch.empty_like(d_hit_kmers), torch.empty_like(d_hit_ranges)
+                    self.hit_off_c, self.num_hits = torch.empty_like(d_hit_off_c), torch.zeros_like(d_num_hits)
+            # a stream of its own for every lane, lane 0 included: torch's current stream is the null stream, which waits for
+            # every other one and which the library cannot tell apart from another thread's (it records an event per call on it)
+            self.torch_stream = torch.cuda.Stream()
+            self.stream = self.torch_stream.cuda_stream
+            self.pos = None
+
+    lanes = [Lane(True)]
+
     def ensure_positions(total):
         if pos_buf["t"] is None or pos_buf["t"].numel() < max(total, 1):
             pos_buf["t"] = None
+            for ln in lanes:
+                ln.pos = None
             pos_buf["t"] = torch.empty(max(total, 1) + total // 8 + 64, dtype=torch.int64, device=dev)
+        for ln in lanes:
+            if ln.primary:
+                ln.pos = pos_buf["t"]
+            elif ln.pos is None or ln.pos.numel() != pos_buf["t"].numel():
+                ln.pos = torch.empty_like(pos_buf["t"])
         return pos_buf["t"]
 
     class Piece:
@@ -487,49 +526,55 @@ def main():
             self.windowed = False
             self.events = []  # per recorded step: (search begin, search end, locate end)
 
-    def search_part(p, form):
+    def search_part(p, form, ln=None):
+        ln = ln or lanes[0]
         if not locate:
-            g.search_hits(p.chars_ptr, p.off_ptr, K, p.q, 0, d_counts.data_ptr(), stream)
+            g.search_hits(p.chars_ptr, p.off_ptr, K, p.q, 0, ln.counts.data_ptr(), ln.stream)
         elif form == "list":
-            g.search_hits_compact(p.chars_ptr, p.off_ptr, K, p.q, d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), p.cap,
-                                  d_num_hits.data_ptr(), stream=stream)
+            g.search_hits_compact(p.chars_ptr, p.off_ptr, K, p.q, ln.hit_kmers.data_ptr(), ln.hit_ranges.data_ptr(), p.cap,
+                                  ln.num_hits.data_ptr(), stream=ln.stream)
         elif form == "order":
-            g.search_hits_in_order(p.chars_ptr, p.off_ptr, K, p.q, d_order_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
+            g.search_hits_in_order(p.chars_ptr, p.off_ptr, K, p.q, ln.order_kmers.data_ptr(), ln.ranges.data_ptr(), stream=ln.stream)
         elif narrow_counts:
             # the hit offsets are scanned from the counts and the locate reads the range of a k-mer only when it has hits: the
             # ranges of the others need not be written
-            g.search_hits_sparse(p.chars_ptr, p.off_ptr, K, p.q, d_ranges.data_ptr(), d_counts.data_ptr(), stream)
+            g.search_hits_sparse(p.chars_ptr, p.off_ptr, K, p.q, ln.ranges.data_ptr(), ln.counts.data_ptr(), ln.stream)
         else:
-            g.search_hits(p.chars_ptr, p.off_ptr, K, p.q, d_ranges.data_ptr(), 0, stream)
+            g.search_hits(p.chars_ptr, p.off_ptr, K, p.q, ln.ranges.data_ptr(), 0, ln.stream)
 
-    def offsets_part(p, form):
+    def offsets_part(p, form, ln=None):
         """hit offsets on the device; returns (ranges, offsets, entries) the locate reads"""
+        ln = ln or lanes[0]
         if form == "list":
-            g.sort_hits_on_device(d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), p.cap, d_num_hits.data_ptr(), p.q, stream)
-            g.hit_offsets_on_device(0, d_hit_ranges.data_ptr(), p.cap, d_hit_off_c.data_ptr(), d_scratch.data_ptr(), stream)
-            return d_hit_ranges, d_hit_off_c, p.cap
+            g.sort_hits_on_device(ln.hit_kmers.data_ptr(), ln.hit_ranges.data_ptr(), p.cap, ln.num_hits.data_ptr(), p.q, ln.stream)
+            g.hit_offsets_on_device(0, ln.hit_ranges.data_ptr(), p.cap, ln.hit_off_c.data_ptr(), ln.scratch.data_ptr(), ln.stream)
+            return ln.hit_ranges, ln.hit_off_c, p.cap
         if form == "dense" and narrow_counts:
-            g.hit_offsets_on_device(d_counts.data_ptr(), 0, p.q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
+            g.hit_offsets_on_device(ln.counts.data_ptr(), 0, p.q, ln.hit_off.data_ptr(), ln.scratch.data_ptr(), ln.stream)
         else:
-            g.hit_offsets_on_device(0, d_ranges.data_ptr(), p.q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
-        return d_ranges, d_hit_off, p.q
+            g.hit_offsets_on_device(0, ln.ranges.data_ptr(), p.q, ln.hit_off.data_ptr(), ln.scratch.data_ptr(), ln.stream)
+        return ln.ranges, ln.hit_off, p.q
 
     def probe(p, force=None):
         """one untimed, synchronous step: which form this piece's results take, how many hits there are, buffers to size"""
         p.form, p.windowed = "dense", False
         if not locate:
+            torch.cuda.synchronize()
             search_part(p, "dense")
             torch.cuda.synchronize()
             return
         form = force or ("list" if have_list and p.ordered else "dense")
+        torch.cuda.synchronize()  # (what the default stream did to the buffers is over before the lane's stream touches them)
         if form == "list":
             search_part(p, "list")
+            torch.cuda.synchronize()
             p.listed = int(d_num_hits.item())
             if p.listed > p.cap:  # not a sparse batch after all
                 form = "order" if have_order and p.ordered else "dense"
         if form != "list":
             search_part(p, form)
         ranges, offsets, entries = offsets_part(p, form)
+        torch.cuda.synchronize()
         p.hits = int(offsets[entries].item())
         if form != "list":
             p.listed = 0
@@ -540,22 +585,25 @@ def main():
         ensure_positions(WINDOW_HITS if p.windowed else p.hits)
         torch.cuda.synchronize()
 
-    def step(p, record=False):
+    def step(p, record=False, ln=None):
+        ln = ln or lanes[0]
         if record:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            ev[0].record()
-        search_part(p, p.form)
+            ev[0].record(ln.torch_stream)
+        search_part(p, p.form, ln)
         if record:
-            ev[1].record()
+            ev[1].record(ln.torch_stream)
         if locate and not p.windowed:
-            ranges, offsets, entries = offsets_part(p, p.form)
-            g.locate_on_device(ranges.data_ptr(), offsets.data_ptr(), entries, pos_buf["t"].numel(), pos_buf["t"].data_ptr(), stream)
+            ranges, offsets, entries = offsets_part(p, p.form, ln)
+            g.locate_on_device(ranges.data_ptr(), offsets.data_ptr(), entries, ln.pos.numel(), ln.pos.data_ptr(), ln.stream)
         elif locate:
             # (the one form with host waits: a hit list of 5 * 10^9 positions is located in windows, whose boundaries in
-            # k-mers are found from the offsets)
+            # k-mers are found from the offsets; lane 0 only)
+            stream = lanes[0].stream
             total = g.hit_offsets_from_counts(d_counts.data_ptr(), p.q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream) if narrow_counts \
                 else g.hit_offsets(d_ranges.data_ptr(), p.q, d_hit_off.data_ptr(), d_scratch.data_ptr(), stream)
             bounds = torch.arange(0, total + WINDOW_HITS, WINDOW_HITS, dtype=torch.int64, device=dev).clamp_(max=total)
+            lanes[0].torch_stream.synchronize()
             cut = torch.searchsorted(d_hit_off[: p.q + 1], bounds, right=True).cpu().tolist()  # first k-mer whose list ends after the bound
             bounds = bounds.cpu().tolist()
             p.first_window = max(cut[1] - 1, 0)  # k-mers whose whole list lies in the first window
@@ -563,21 +611,36 @@ def main():
                 qb, qe = max(cut[w] - 1, 0), min(cut[w + 1], p.q)
                 g.locate_window(d_ranges.data_ptr(), d_hit_off.data_ptr(), qb, qe, bounds[w], bounds[w + 1], pos_buf["t"].data_ptr(), stream)
                 if w == 0 and getattr(p, "keep_first_window", False):
+                    lanes[0].torch_stream.synchronize()
                     p.window0 = pos_buf["t"][: bounds[1]].clone()
+                    torch.cuda.synchronize()
         if record:
-            ev[2].record()
+            ev[2].record(ln.torch_stream)
             p.events.append(ev)
 
-    def check_against_probe(p):
-        """after a loop of steps: what the device read as the list's length and the number of hits is what the probe saw"""
+    def run_steps(p, count):
+        """`count` steps of a piece, alternating between the lanes so that the LAST one lands in lane 0 (whose buffers every
+        check reads); the caller synchronises the device before and after"""
+        use = lanes if not p.windowed else lanes[:1]
+        for i in range(count):
+            step(p, False, use[(count - 1 - i) % len(use)])
+
+    def check_against_probe(p, steps_run=None):
+        """after a loop of steps: what the device read as the list's length and the number of hits is what the probe saw -- in
+        every lane the loop used, and the lanes hold the same results"""
         if not locate or p.windowed:
             return
-        if p.form == "list":
-            assert int(d_num_hits.item()) == p.listed, "the list's length changed between the probe and the timed steps"
-            total = int(d_hit_off_c[p.cap].item())
-        else:
-            total = int(d_hit_off[p.q].item())
-        assert total == p.hits and total <= pos_buf["t"].numel(), "the number of hits changed between the probe and the timed steps"
+        used = lanes[: min(len(lanes), steps_run)] if steps_run else lanes[:1]
+        for ln in used:
+            if p.form == "list":
+                assert int(ln.num_hits.item()) == p.listed, "the list's length changed between the probe and the timed steps"
+                total = int(ln.hit_off_c[p.cap].item())
+                assert ln.primary or (torch.equal(ln.hit_kmers[: p.listed], d_hit_kmers[: p.listed]) and torch.equal(ln.pos[: p.hits], pos_buf["t"][: p.hits])), \
+                    "two lanes hold different results of the same batch"
+            else:
+                total = int(ln.hit_off[p.q].item())
+                assert ln.primary or p.form == "order" or torch.equal(ln.pos[: p.hits], pos_buf["t"][: p.hits]), "two lanes hold different positions"
+            assert total == p.hits and total <= ln.pos.numel(), "the number of hits changed between the probe and the timed steps"
 
     def to_dense(p):
         """the dense form of the piece's last step -- ranges ({1, 0} where there is no hit), counts, hit offsets under every
@@ -639,6 +702,9 @@ def main():
 
     whole = Piece(0, Q)
     probe(whole)
+    if args.streams > 1 and not whole.windowed:
+        lanes.extend(Lane(False) for _ in range(args.streams - 1))
+        ensure_positions(whole.hits)
     # the warm-up steps carry the events that split a step into its search call and its locate kernels (reporting); the timed
     # steps carry none: a recorded event is a packet of its own in the queue, about 5 us of idle device each
     for _ in range(max(args.warmup, 1)):
@@ -647,14 +713,13 @@ def main():
     g.ordered_kernel_log()  # the log of the library's own kernel brackets starts with the timed steps
     barrier()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step(whole)
+    run_steps(whole, args.steps)
     barrier()
     elapsed = time.perf_counter() - t_start
     elapsed = shard.max_over_ranks(elapsed, world, dev)
     ms_per_step = elapsed * 1e3 / args.steps
     value = batch_total / (elapsed / args.steps) / 1e6  # Mkmers/s over all ranks
-    check_against_probe(whole)
+    check_against_probe(whole, args.steps)
     search_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in whole.events]))
     locate_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in whole.events])) if locate else 0.0
     kernel_log = g.ordered_kernel_log() if ordered else []
@@ -1096,14 +1161,13 @@ def main():
         timing = os.environ.pop("AWFM_GPU_TIME_ORDERED", None)
         try:
             probe(p, force)
-            step(p)
+            run_steps(p, len(lanes))
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(steps):
-                step(p)
+            run_steps(p, steps)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
-            check_against_probe(p)
+            check_against_probe(p, steps)
         finally:
             if timing is not None:
                 os.environ["AWFM_GPU_TIME_ORDERED"] = timing
@@ -1324,6 +1388,8 @@ def main():
               "timing_collective": shard.timing_backend() or "none (one rank)",
               "hits_per_step_rank0": int(state["hits"]), "locate_kernels_ms": round(locate_ms, 3),
               "search_call_ms": round(search_ms, 3), "host_waits_per_step": 0 if not whole.windowed else "one per window",
+              # consecutive steps alternate between this many streams, each with its own result buffers and scratch slot
+              "streams": 1 if whole.windowed else len(lanes),
               "index_build_s": round(build_s, 2),
               "device_image_bytes": image_bytes, "device_seed_k": image_deep_k,
               # the deeper table's construction, whoever started it (the library by itself at awfmGpuIndexAcquire, inside
