@@ -141,9 +141,14 @@ inline unsigned cappedGrid(unsigned long long n) {
  * hitOffsets[i] + h lies in the window [hitBegin, hitEnd), over the queries firstQuery .. firstQuery + n - 1.  The whole
  * batch is the window [0, total) over all queries; a budgeted locate takes the hit list window by window (a window may
  * start and end inside the list of one k-mer). */
+/* DENSE: the image carries the full suffix array, so a hit's text position is one read away: positions[...] = dense[sp_i + h]
+ * at once, instead of the BWT position for a gather kernel behind this one (10^8 planted 21-mers: a launch and 1.6 GB of
+ * intermediate positions written and read back less, 9.7 -> 9.4 ms per step) */
+template <bool DENSE>
 __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const unsigned long long *__restrict__ hitOffsets,
                                  unsigned long long firstQuery, unsigned long long n, unsigned long long hitBegin,
-                                 unsigned long long hitEnd, unsigned long long *__restrict__ positions) {
+                                 unsigned long long hitEnd, unsigned long long *__restrict__ positions,
+                                 const unsigned *__restrict__ dense = nullptr) {
   /* one wave per 64 queries: short lists by their own lane, long lists by the whole wave; the grid is capped (a
    * launch holds fewer than 2^32 threads), workgroups stride over the batch */
   const unsigned lane = threadIdx.x & 63u;
@@ -162,13 +167,13 @@ __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const un
     }
     const bool isLong = count > 32ull;
     if (!isLong)
-      for (unsigned long long h = 0; h < count; h++) positions[start + h] = sp + h;
+      for (unsigned long long h = 0; h < count; h++) positions[start + h] = DENSE ? (unsigned long long)dense[sp + h] : sp + h;
     unsigned long long longMask = __ballot(isLong);
     while (longMask) {
       const int src = __ffsll((long long)longMask) - 1;
       longMask &= longMask - 1ull;
       const unsigned long long s = __shfl(start, src, 64), c = __shfl(count, src, 64), p = __shfl(sp, src, 64);
-      for (unsigned long long h = lane; h < c; h += 64ull) positions[s + h] = p + h;
+      for (unsigned long long h = lane; h < c; h += 64ull) positions[s + h] = DENSE ? (unsigned long long)dense[p + h] : p + h;
     }
   }
 }
@@ -1185,17 +1190,19 @@ enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearch
   const uint64_t numQueries = queryEnd - queryBegin, totalHits = hitEnd - hitBegin;
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(expandHitsKernel, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
-                     (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
-                     (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
-                     (unsigned long long *)dPositions);
-  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-  if (g->dDenseSa) {
-    hipLaunchKernelGGL(denseSaGatherKernel, dim3((unsigned)(g->numCUs * 8)), dim3(256), 0, s, (const unsigned *)g->dDenseSa,
-                       (unsigned long long)totalHits, (const unsigned long long *)dPositions, (unsigned long long *)outPositions);
+  if (g->dDenseSa) { /* the full suffix array: expand and gather in one kernel, straight to where the positions go */
+    hipLaunchKernelGGL(expandHitsKernel<true>, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
+                       (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
+                       (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
+                       (unsigned long long *)outPositions, (const unsigned *)g->dDenseSa);
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
   }
+  hipLaunchKernelGGL(expandHitsKernel<false>, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
+                     (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
+                     (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
+                     (unsigned long long *)dPositions, (const unsigned *)nullptr);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return launchLocate(g, totalHits, (unsigned long long *)dPositions, s, (unsigned long long *)outPositions);
 }
 
@@ -1227,17 +1234,18 @@ enum AwFmReturnCode awfmGpuLocateOnDevice(AwFmGpuIndex *g, const struct AwFmSear
   hipStream_t s = (hipStream_t)stream;
   /* the window [0, capacity) of the hit list: the hits beyond what `dPositions` holds are left out (the caller sees from
    * the total, when it gets to read it, that the buffer was too small) */
-  hipLaunchKernelGGL(expandHitsKernel, dim3(cappedGrid(numQueries)), dim3(256), 0, s, (const ulonglong2 *)dRanges,
-                     (const unsigned long long *)dHitOffsets, 0ull, (unsigned long long)numQueries, 0ull,
-                     (unsigned long long)capacityHits, (unsigned long long *)dPositions);
-  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-  const unsigned long long *total = (const unsigned long long *)dHitOffsets + numQueries;
-  if (g->dDenseSa) {
-    hipLaunchKernelGGL(denseSaGatherKernel, dim3((unsigned)(g->numCUs * 8)), dim3(256), 0, s, (const unsigned *)g->dDenseSa,
-                       (unsigned long long)capacityHits, (const unsigned long long *)dPositions, (unsigned long long *)dPositions, total);
+  if (g->dDenseSa) { /* the full suffix array: expand and gather in one kernel */
+    hipLaunchKernelGGL(expandHitsKernel<true>, dim3(cappedGrid(numQueries)), dim3(256), 0, s, (const ulonglong2 *)dRanges,
+                       (const unsigned long long *)dHitOffsets, 0ull, (unsigned long long)numQueries, 0ull,
+                       (unsigned long long)capacityHits, (unsigned long long *)dPositions, (const unsigned *)g->dDenseSa);
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
   }
+  hipLaunchKernelGGL(expandHitsKernel<false>, dim3(cappedGrid(numQueries)), dim3(256), 0, s, (const ulonglong2 *)dRanges,
+                     (const unsigned long long *)dHitOffsets, 0ull, (unsigned long long)numQueries, 0ull,
+                     (unsigned long long)capacityHits, (unsigned long long *)dPositions, (const unsigned *)nullptr);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  const unsigned long long *total = (const unsigned long long *)dHitOffsets + numQueries;
   return launchLocate(g, capacityHits, (unsigned long long *)dPositions, s, (unsigned long long *)dPositions, total);
 }
 

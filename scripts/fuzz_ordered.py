@@ -89,15 +89,39 @@ while time.time() < t_end:
             print(f"MISMATCH exact pair search n={n} k={seed_k} deep={deep_k} ratio={ratio} Q={Q} {desc}", flush=True)
             sys.exit(1)
         assert g.is_wide == fuzz_wide
+        # lookup first (the kernel that looks the deeper table up also searches what is still alive): forced, never, or by
+        # its sample -- whichever applies to this batch and image
+        lookup = str(rng.choice(["1", "0", ""]))
+        if lookup:
+            os.environ["AWFM_GPU_LOOKUP_FIRST"] = lookup
+        else:
+            os.environ.pop("AWFM_GPU_LOOKUP_FIRST", None)
         g.search_hits(chars_ptr, off_ptr, K, Q, hits.data_ptr(), counts.data_ptr())
         torch.cuda.synchronize()
+        listed_ok = True
+        if g.search_hits_is_ordered(off_ptr != 0, K, Q) and not fuzz_wide:
+            # the list form of the same search, put in k-mer order, sized and located with nothing read back by the host
+            cap = Q
+            lk = torch.zeros(cap, dtype=torch.int32, device=dev)
+            lr = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+            ln = torch.zeros(1, dtype=torch.int32, device=dev)
+            g.search_hits_compact(chars_ptr, off_ptr, K, Q, lk.data_ptr(), lr.data_ptr(), cap, ln.data_ptr())
+            g.sort_hits_on_device(lk.data_ptr(), lr.data_ptr(), cap, ln.data_ptr(), Q)
+            torch.cuda.synchronize()
+            m = int(ln.item())
+            want = torch.nonzero(counts).flatten()
+            listed_ok = (m == want.numel() and torch.equal(lk[:m].to(torch.int64), want)
+                         and torch.equal(lr.view(cap, 2)[:m], hits.view(Q, 2)[want]))
         g.set_wide(False)
         a, b = exact.view(Q, 2), hits.view(Q, 2)
         has = a[:, 0] <= a[:, 1]
         expect = torch.where(has, a[:, 1] - a[:, 0] + 1, torch.zeros_like(a[:, 0])).clamp(max=0xFFFFFFFF)
         ok = (torch.equal(a[has], b[has]) and bool((b[~has, 0] > b[~has, 1]).all())
               and torch.equal(counts.to(torch.int64) & 0xFFFFFFFF, expect))
-        tag = f"n={n} k={seed_k} deep={deep_k} ratio={ratio} Q={Q} {desc} mis={mis} ordered={g.search_hits_is_ordered(off_ptr != 0, K, Q)}"
+        tag = f"n={n} k={seed_k} deep={deep_k} ratio={ratio} Q={Q} {desc} mis={mis} ordered={g.search_hits_is_ordered(off_ptr != 0, K, Q)} lookup_first={lookup!r}"
+        if not listed_ok:
+            print("LIST MISMATCH", tag, flush=True)
+            sys.exit(1)
         if not ok:
             print("MISMATCH", tag, flush=True)
             sys.exit(1)
@@ -118,8 +142,13 @@ while time.time() < t_end:
             torch.cuda.synchronize()
             del os.environ["AWFM_GPU_LOCATE_NO_PAIR"]
             g.set_wide(fuzz_wide)
+            dense_sa = ix.bwt_length < (1 << 32) and rng.random() < 0.3  # side B through the full suffix array now and then
+            if dense_sa:
+                g.set_dense_sa(True)
             g.locate(hits.data_ptr(), off_b.data_ptr(), Q, total_b, pos_b.data_ptr())
             torch.cuda.synchronize()
+            if dense_sa:
+                g.set_dense_sa(False)
             g.set_wide(False)
             if not (total_a == total_b and torch.equal(off_a, off_b) and torch.equal(pos_a, pos_b)):
                 print("LOCATE MISMATCH", tag, flush=True)
