@@ -29,6 +29,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "awfm_device.h"
+#include "awfm_pair.h"
 
 namespace {
 
@@ -396,6 +397,46 @@ __global__ void __launch_bounds__(kThreads)
   }
 }
 
+/* TWO levels in one: entry code * parentLen + p of level L + 2 is the level-L entry p after the pair step `code` = 4 c0 + c1
+ * (c1 prepended first, then c0: the index puts the leftmost character first) through the pair image (awfm_pair.h), EXACT --
+ * a range that dies inside the pair ends in the empty range the letter-by-letter stepping ends in, as in the general search
+ * kernel, whose three lines these are.  The level in between is never written: a depth-16 table is built 12 -> 14 -> 16 and
+ * the 17 GB of level 15 -- a quarter of the construction's allocations, which are most of its time -- are not needed.
+ * Images below 2^32 positions that have their pair image. */
+template <bool OUT8>
+__global__ void __launch_bounds__(kThreads)
+    deepSeedPairLevelKernel(const DevIndex ix, const ulonglong2 *__restrict__ parentLevel, u64 parentLen, u64 outLen,
+                            ulonglong2 *__restrict__ out) {
+  constexpr int G = 4;
+  __shared__ u64 sC[24];
+  __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
+  __shared__ u64 sSuper[1];
+  __shared__ u64 sPairC[16];
+  extern __shared__ unsigned sPairSuper[];
+  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  stageMaskTable(sMask);
+  nucStageSuper<true>(ix, sSuper);
+  pairStageTables<true, 16u>(ix, sPairC, sPairSuper);
+  __syncthreads();
+  const unsigned gl = threadIdx.x % G;
+  const u64 numGroups = (u64)gridDim.x * kSeedGroupsPerBlock;
+  for (u64 e = ((u64)blockIdx.x * kThreads + threadIdx.x) / G; e < outLen; e += numGroups) {
+    const unsigned code = (unsigned)(e / parentLen);
+    const ulonglong2 r = parentLevel[e % parentLen];
+    unsigned sp = (unsigned)r.x, ep = (unsigned)r.y;
+    if (r.x <= r.y) { /* a query stops at its first invalid range and keeps it (ref src/AwFmParallelSearch.c:293-294) */
+      const unsigned c2 = code & 3u, c1 = code >> 2;
+      const PairStep did = pairSearchStep<true, true>(ix, sPairC, sPairSuper, sMask, gl, code, sp, ep, sC);
+      if (did == kPairFlagged) nucFastStep<G, true>(ix, sC, sSuper, sMask, gl, c2, sp, ep);
+      if (did != kPairStepped && sp <= ep) nucFastStep<G, true>(ix, sC, sSuper, sMask, gl, c1, sp, ep);
+    }
+    if (gl == 0) {
+      if (OUT8) ((uint2 *)out)[e] = make_uint2(sp, ep + 1u - sp);
+      else out[e] = r.x <= r.y ? make_ulonglong2((u64)sp, (u64)ep) : r; /* (an empty range is {sp, sp - 1}, sp >= 1) */
+    }
+  }
+}
+
 /* The same level step for the amino alphabet: entry letter * parentLen + p of the level is the level-below entry p after
  * one backward step with `letter` (0..19: the index puts the leftmost character first, ref src/AwFmKmerTable.c:37-51), or
  * that entry unchanged when its range is already empty.  One group of 4 lanes per entry (aminoStepAny: the step of the
@@ -673,16 +714,34 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
   for (unsigned i = 0; i < K; i++) len *= card;
   DeviceBuffer cur, nxt;
   const ulonglong2 *parent = g->dev.seed;
-  for (unsigned L = K; L < deepK; L++) {
-    const u64 outLen = len * card;
-    const bool out8 = L + 1 == deepK && g->dev.bwtLength < (1ull << 32); /* the table itself, 8-byte entries */
+  /* two levels per pass through the pair image where the image has one and runs 32-bit positions (deepSeedPairLevelKernel) */
+  const bool pairLevels = !g->amino && g->dev.pairBlocks && awfmImageNarrow(g) && !getenv("AWFM_GPU_DEEP_SINGLE_LEVELS");
+  const bool pairSuperInLds = pairLevels && awfmPairSuperInLds(g);
+  for (unsigned L = K; L < deepK;) {
+    const unsigned levels = pairLevels && deepK - L >= 2u ? 2u : 1u;
+    u64 outLen = len;
+    for (unsigned i = 0; i < levels; i++) outLen *= card;
+    const bool out8 = L + levels == deepK && g->dev.bwtLength < (1ull << 32); /* the table itself, 8-byte entries */
+    struct timespec ta, tb, tc;
+    clock_gettime(CLOCK_MONOTONIC, &ta);
     if (!nxt.alloc(outLen * (out8 ? 8 : 16))) return false;
+    clock_gettime(CLOCK_MONOTONIC, &tb);
     if (peakBytesOut && curBytes + outLen * (out8 ? 8 : 16) > *peakBytesOut) *peakBytesOut = curBytes + outLen * (out8 ? 8 : 16);
     constexpr int kUnroll = 4;
     const u64 blocks = (outLen + kSeedGroupsPerBlock * kUnroll - 1) / (kSeedGroupsPerBlock * kUnroll);
     const u64 resident = (u64)g->numCUs * 8u; /* a persistent grid: what does not fit the chip would only queue */
     const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
-    if (g->amino) {
+    if (levels == 2u) {
+      DevIndex dev = g->dev;
+      dev.pairSuperInLds = pairSuperInLds ? 1u : 0u;
+      const size_t lds = pairSuperInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
+      const u64 pairBlocks = (outLen + kSeedGroupsPerBlock - 1) / kSeedGroupsPerBlock;
+      const unsigned pairGrid = (unsigned)(pairBlocks < resident ? pairBlocks : resident);
+      if (out8)
+        hipLaunchKernelGGL((deepSeedPairLevelKernel<true>), dim3(pairGrid), dim3(kThreads), lds, 0, dev, parent, len, outLen, nxt.as<ulonglong2>());
+      else
+        hipLaunchKernelGGL((deepSeedPairLevelKernel<false>), dim3(pairGrid), dim3(kThreads), lds, 0, dev, parent, len, outLen, nxt.as<ulonglong2>());
+    } else if (g->amino) {
       const u64 aminoBlocks = (outLen + kThreads / 4 - 1) / (kThreads / 4);
       const unsigned aminoGrid = (unsigned)(aminoBlocks < resident ? aminoBlocks : resident);
       if (out8)
@@ -697,12 +756,16 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
                          nxt.as<ulonglong2>());
     BUILD_TRY(hipGetLastError());
     BUILD_TRY(hipDeviceSynchronize());
-    if (getenv("AWFM_VERBOSE")) fprintf(stderr, "[awfm deep seed] level %u -> %u: %llu entries\n", L, L + 1, (unsigned long long)outLen);
+    clock_gettime(CLOCK_MONOTONIC, &tc);
+    if (getenv("AWFM_VERBOSE"))
+      fprintf(stderr, "[awfm deep seed] level %u -> %u: %llu entries, allocation %.3f s, kernel %.3f s\n", L, L + levels, (unsigned long long)outLen,
+              (double)(tb.tv_sec - ta.tv_sec) + 1e-9 * (double)(tb.tv_nsec - ta.tv_nsec), (double)(tc.tv_sec - tb.tv_sec) + 1e-9 * (double)(tc.tv_nsec - tb.tv_nsec));
     cur.reset();
     cur.p = nxt.release();
     curBytes = outLen * (out8 ? 8 : 16);
     parent = cur.as<ulonglong2>();
     len = outLen;
+    L += levels;
   }
   *bytesOut = len * (g->dev.bwtLength < (1ull << 32) ? 8 : 16);
   *tableOut = cur.release();

@@ -51,7 +51,7 @@ def test_two_ranks_on_one_gpu_search_their_own_shards(oracle, awfm, require_gpu,
     n, Q, K, seed_k = 3_000_000, 1_000_000, 21 if workload == "planted" else 13, 8
     r = _run_bench(["--gpus", "2", "--force-device", "0", "--dist-backend", "gloo", "--text-len", "3e6", "--queries",
                     "1e6", "--kmer", str(K), "--seed-k", str(seed_k), "--workload", workload, "--mode", mode, "--no-cpu",
-                    "--steps", "2", "--warmup", "1", "--scaling", "weak", "--dump-dir", str(tmp_path)])
+                    "--steps", "3", "--warmup", "1", "--scaling", "weak", "--streams", "2", "--dump-dir", str(tmp_path)])
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak"
