@@ -111,7 +111,8 @@ if ordered:
 search = [k for k in summary if k.startswith(("searchKernel", "aminoLookupSearchKernel")) and "FETCH_SIZE" in summary[k]]
 # large fixed-length amino batches: the timed steps run aminoLookupSearchKernel (the general kernel beside it is the
 # reference-algorithm measurement of bench.py, or returns at once)
-search.sort(key=lambda x: (not (x.startswith("aminoLookupSearchKernel") and (kernel_avg_ns(x) or 0) > 1e5), -summary[x]["FETCH_SIZE"]["dispatches"]))
+search.sort(key=lambda x: ((0 if (kernel_avg_ns(x) or 0) > 1e5 else 2) if x.startswith("aminoLookupSearchKernel") else 1,
+                           -summary[x]["FETCH_SIZE"]["dispatches"]))
 if search and not ordered:
     k = search[0]
     fetch_kb, write_kb = summary[k]["FETCH_SIZE"]["mean"], summary[k].get("WRITE_SIZE", {"mean": 0.0})["mean"]

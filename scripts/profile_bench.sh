@@ -23,6 +23,7 @@ PASS[busy]="TCC_BUSY_avr GRBM_TA_BUSY GRBM_TC_BUSY GRBM_EA_BUSY"
 # the default passes are the ones that have always come back; `ta` aborted inside rocprofv3 (signal 6) on this pool and then
 # sat in its finalisation until the call's limit: name it (or `busy`) in $PROFILE_PASSES only under a short `timeout`
 for N in ${PROFILE_PASSES:-fetch write l2 sq sq2 ea tcp}; do
+  [ "$N" = "-" ] && continue  # PROFILE_PASSES=-: the kernel trace only
   rocprofv3 --pmc ${PASS[$N]} --kernel-include-regex "$KERNELS" --output-format csv -d "$OUT/pmc_$N" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-secondary --no-shard-proxy --no-dense-form --general-steps 0 --steps 2 --warmup 1 "$@" > "$OUT/bench_pmc_$N.log" 2>&1
   rc=$?
   echo "pass $N: $(find "$OUT/pmc_$N" -name '*counter_collection.csv' | wc -l) csv, rc $rc"

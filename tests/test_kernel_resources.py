@@ -89,3 +89,14 @@ def test_no_search_or_walk_variant_uses_scratch(kernel_metadata):
            if ("searchKernel" in n or "walkKernel" in n or "orderedSearchKernel" in n) and v["scratch"]
            and not re.search(bucketed_pair, n)}
     assert not bad, bad
+
+
+def test_lookup_search_kernels_resources(kernel_metadata):
+    """the kernels that look the deeper table up and search what is still alive (round 4): lookupSearchKernel<21> -- the
+    dominant kernel of the headline batch -- must keep 7 waves per SIMD (72 registers; it spills 14 in its decode phase by
+    choice: 80 registers and 6 waves left 25 spilled and fewer lookups in flight), aminoLookupSearchKernel<10> spills nothing;
+    both keep their LDS small enough for 7 workgroups per CU beside the pair image's superblock bases"""
+    k = _one(kernel_metadata, r"lookupSearchKernelILj21EEE")
+    assert k["vgpr"] <= 72 and k["spill"] <= 16 and k["scratch"] <= 64 and k["lds"] <= 12 * 1024
+    k = _one(kernel_metadata, r"[0-9]aminoLookupSearchKernelILj10EEE")
+    assert k["vgpr"] <= 72 and k["spill"] == 0 and k["scratch"] == 0 and k["lds"] <= 12 * 1024
