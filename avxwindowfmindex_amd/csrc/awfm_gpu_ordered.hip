@@ -84,9 +84,10 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
                         keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
                         getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0, touch ? *touch : OrderTouch(), bucketStart,
                         bucketFmt, sparse ? *sparse : SparseOut(),
-                        /* chunks a ticket is worth: 10^8 random 21-mers 3.92 (1), 3.49 (2), 3.47 (4), 3.50 (8), 3.65 ms (16); mixed-length and
-                         * planted batches show no gain */
-                        getenv("AWFM_GPU_CHUNKS_PER_TICKET") && atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) >= 1 ? (unsigned)atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) : (BUCKET ? 4u : 1u));
+                        /* chunks a ticket is worth: 10^8 random 21-mers 3.92 (1), 3.49 (2), 3.47 (4), 3.50 (8), 3.65 ms (16); planted
+                         * 21-mers (round 4, the batches this kernel still sees whole: the others end in lookupSearchKernel) 5.06 (1),
+                         * 5.01 (2), 5.19 (3), 5.18 (4): the records in flight on an XCD span fewer buckets.  Mixed lengths: no gain */
+                        getenv("AWFM_GPU_CHUNKS_PER_TICKET") && atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) >= 1 ? (unsigned)atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) : (BUCKET ? 2u : 1u));
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   g->orderTimedKernel = timed;
   if (timed) g->orderLog[(g->orderLogCount - 1u) % AwFmGpuIndex::kOrderLogMax].kernel = true;
