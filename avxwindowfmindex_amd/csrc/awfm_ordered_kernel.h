@@ -1281,6 +1281,8 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   __shared__ unsigned sHitKmers[LIST ? orderedThreads(PAIR) / 64 : 1][kHitBuffer];
   __shared__ unsigned long long sHitRanges[LIST ? orderedThreads(PAIR) / 64 : 1][kHitBuffer][2];
   unsigned hitFill = 0; /* wave-uniform */
+  /* nothing to search (the batch ended in lookupSearchKernel): not even the tables are staged */
+  if (BUCKET && bucketStart[1u << bucketFmt.bucketBits] == 0u) return;
   /* ... and what the waves of a workgroup still hold when they are done goes out in ONE reservation, made by the wave that
    * finishes last: the waves of the grid end together, and 7168 of them each taking a returning atomic on the list's counter
    * were a tail of 60-80 us on a kernel that searched 5 * 10^5 k-mers (a word takes 88 atomics per microsecond) */

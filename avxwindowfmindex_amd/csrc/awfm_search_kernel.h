@@ -57,6 +57,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
                  /* launched beside a lookup-first kernel whose sample decides on the device which of the two works */
                  const unsigned *__restrict__ skipWhenLookup = nullptr, const unsigned skipSamples = 0) {
   if (skipWhenLookup && lookupChosen(skipWhenLookup, skipSamples, false)) return; /* uniform */
+  if (INDIRECT && *subsetCount == 0u) return; /* nothing was left to this kernel (the usual case): no table is staged */
   constexpr int W = 8 / G; /* window dwords per lane: the group holds the last 32 characters of its k-mer */
   constexpr int S = (int)kSlices / G; /* block slices per lane */
   constexpr int kGroups = kThreads / G;
