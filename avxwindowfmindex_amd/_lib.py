@@ -36,7 +36,7 @@ GPU_SYMBOLS = [
     "awfmGpuStreamChars", "awfmGpuCountPackedHost", "awfmGpuLocatePackedHost", "awfmGpuIndexSetPairImage", "awfmGpuIndexHasPairImage",
     "awfmGpuSearchHitsPacked", "awfmGpuLocateTo", "awfmGpuSearchHitsLineTally", "awfmGpuIndexDeepSeedK", "awfmGpuSearchHitsCompact", "awfmGpuCompactHits", "awfmGpuSortHits",
     "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse", "awfmGpuSearchHitsInOrder",
-    "awfmGpuSortHitsOnDevice", "awfmGpuHitOffsetsOnDevice", "awfmGpuLocateOnDevice", "awfmGpuLastOrderedSearchKernelMs", "awfmGpuOrderedKernelLog", "awfmGpuIndexDeepSeedBuildSeconds", "awfmGpuIndexDeepSeedTransientBytes", "awfmGpuIndexHasDenseSa", "awfmGpuIndexDenseSaBuildSeconds",
+    "awfmGpuSortHitsOnDevice", "awfmGpuHitOffsetsOnDevice", "awfmGpuLocateOnDevice", "awfmGpuLastOrderedSearchKernelMs", "awfmGpuOrderedKernelLog", "awfmGpuIndexDeepSeedBuildSeconds", "awfmGpuIndexDeepSeedTransientBytes", "awfmGpuIndexHasDenseSa", "awfmGpuIndexDenseSaBuildSeconds", "awfmGpuIndexLengthTableBytes", "awfmGpuIndexLengthTableBuildSeconds", "awfmGpuMixedLookupLineTally",
 ]
 # int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
 CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
@@ -160,6 +160,9 @@ def lib():
         "awfmGpuIndexDeepSeedTransientBytes": (u64, [vp]),
         "awfmGpuIndexHasDenseSa": (C.c_int, [vp]),
         "awfmGpuIndexDenseSaBuildSeconds": (C.c_double, [vp]),
+        "awfmGpuIndexLengthTableBytes": (u64, [vp]),
+        "awfmGpuIndexLengthTableBuildSeconds": (C.c_double, [vp]),
+        "awfmGpuMixedLookupLineTally": (C.c_int, [vp, vp, vp, u64, C.POINTER(u64 * 8)]),
         "awfmGpuSearch": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuSearchHits": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),
         "awfmGpuSearchHitsSparse": (C.c_int, [vp, vp, vp, C.c_uint32, u64, vp, vp, vp]),

@@ -288,6 +288,19 @@ class GpuIndex:
     def dense_sa_build_s(self):
         return float(_lib.lib().awfmGpuIndexDenseSaBuildSeconds(self.handle))
 
+    @property
+    def length_tables(self):
+        """(bytes, build seconds) of the device-only tables per k-mer length a mixed-length batch builds on first use; (0, 0.0): none"""
+        return (int(_lib.lib().awfmGpuIndexLengthTableBytes(self.handle)), float(_lib.lib().awfmGpuIndexLengthTableBuildSeconds(self.handle)))
+
+    def mixed_lookup_line_tally(self, d_chars, d_offsets, n):
+        """what the lookup-first kernel of mixed-length batches has to read for this batch (awfmGpuMixedLookupLineTally)"""
+        out = (C.c_uint64 * 8)()
+        _check("awfmGpuMixedLookupLineTally", _lib.lib().awfmGpuMixedLookupLineTally(self.handle, d_chars, d_offsets, n, C.byref(out)))
+        keys = ("length_table_lines", "deep_table_lines", "pair_level_lines", "nuc_level_lines", "kmers_alive_after_the_table",
+                "kmers_with_hits", "general_kmers", "block_reads_executed")
+        return {k: int(v) for k, v in zip(keys, out)}
+
     def set_pair_image(self, enable=True):
         """device-only pair image (two steps per block read); built by default with nucleotide images"""
         _check("awfmGpuIndexSetPairImage", _lib.lib().awfmGpuIndexSetPairImage(self.handle, int(bool(enable))))

@@ -117,6 +117,9 @@ struct DevIndex {
   unsigned int pairSuperInLds; /* set per launch: the kernel was given numPairSuper * 64 bytes of dynamic LDS for pairSuper32 */
 };
 
+/* first entry of level d (the d-letter strings, d >= 1) in the length tables: 4 + 16 + ... + 4^(d-1) */
+__host__ __device__ inline unsigned long long awfmLengthTableAt(unsigned d) { return ((1ull << (2u * d)) - 4ull) / 3ull; }
+
 /* exact length of an entry whose 16-bit length field is saturated */
 __device__ inline unsigned deepBigLength(const DevIndex &ix, unsigned long long i) {
   unsigned lo = 0, hi = ix.numDeepBig;
@@ -732,6 +735,14 @@ struct AwFmGpuIndex {
   double deepSeedBuildSeconds = 0.0;    /* wall time of the last construction of the deeper table (reporting) */
   uint64_t deepSeedTransientBytes = 0;  /* device memory that construction held beyond the table itself, at its peak */
   void *dDeepBig = nullptr; /* side list of the deeper table: keys, then lengths (DevIndex::deepBigKeys) */
+  /* optional tables of the k-mer lengths below the deeper table's (awfmGpuBuildLengthTables), built by the first
+   * mixed-length batch that can use them; owned by the primary, found there by its lanes (under lengthMutex) */
+  std::mutex lengthMutex;
+  void *dLengthTable = nullptr;
+  unsigned lengthDepths = 0; /* levels 1 .. lengthDepths */
+  bool lengthTried = false;  /* a construction was attempted (it is not repeated when it fails for lack of memory) */
+  uint64_t lengthTableBytes = 0;
+  double lengthTableBuildSeconds = 0.0;
   void *dDenseSa = nullptr; /* optional full suffix array, 32-bit entries */
   uint64_t denseSaBytes = 0;
   double denseSaBuildSeconds = 0.0; /* wall time of the automatic construction (reporting) */
@@ -908,6 +919,23 @@ enum AwFmReturnCode awfmGpuScanFlags(AwFmGpuIndex *g, const uint32_t *dCounts, u
 /* awfm_gpu_build.hip: level-wise construction of the deeper seed table into a new device buffer */
 /* peakBytesOut (may be NULL): the most device memory the construction held at once (the table and the level below it) */
 bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut, uint64_t *peakBytesOut = nullptr);
+/* one table per k-mer length 1 .. maxDepth (<= 15), 8-byte entries {sp, length}, level d at entry awfmLengthTableAt(d) of one
+ * allocation: nucleotide images below 2^32 positions (awfm_gpu_build.hip) */
+bool awfmGpuBuildLengthTables(const AwFmGpuIndex *g, unsigned maxDepth, void **tableOut, uint64_t *bytesOut);
+/* awfm_gpu_mixed.hip: the launches of awfm_mixed_lookup_kernel.h (a translation unit of their own) */
+hipError_t awfmGpuLaunchMixedSample(const AwFmGpuIndex *g, hipStream_t s, const void *lengthTable, const uint8_t *dChars,
+                                    const unsigned long long *off, unsigned long long nq, unsigned useNext, unsigned samples,
+                                    unsigned *aliveOut);
+hipError_t awfmGpuLaunchMixedLookup(const AwFmGpuIndex *g, hipStream_t s, hipEvent_t start, hipEvent_t stop, const void *lengthTable,
+                                    const uint8_t *dChars, const unsigned long long *off, unsigned long long nq, unsigned useNext,
+                                    bool superInLds, const unsigned *sampleAlive, unsigned chooseOf, ulonglong2 *rng, unsigned *dCounts,
+                                    unsigned *sparseCount, unsigned sparseCap, unsigned *sparseKmers, ulonglong2 *sparseRanges,
+                                    unsigned long long *leftover, unsigned *leftoverCount, unsigned *kept);
+hipError_t awfmGpuLaunchMixedTally(const AwFmGpuIndex *g, hipStream_t s, const void *lengthTable, const uint8_t *dChars,
+                                   const unsigned long long *off, unsigned long long nq, unsigned useNext, unsigned long long *bits,
+                                   unsigned long long lengthWords, unsigned long long deepWords, unsigned long long pairWords,
+                                   unsigned long long nucWords);
+unsigned awfmGpuMixedTouchLevels(void);
 /* awfm_gpu_ordered.hip: rewrites the 8-byte entries {sp, length} of a finished table as {sp, length16 | next16 << 16}
  * (DevIndex::deepNext) and returns the side list of the saturated lengths in *bigOut (one allocation: *numBigOut keys,
  * then as many lengths; NULL when there is none).  Needs the pair image.  1: done; 0: not applicable, nothing was

@@ -551,6 +551,7 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
       if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
       if (g->dDeepBig) (void)hipFree(g->dDeepBig);
       if (g->dDenseSa) (void)hipFree(g->dDenseSa);
+      if (g->dLengthTable) (void)hipFree(g->dLengthTable);
       void *pairOwned[] = {g->dPairBlocks, g->dPairSuper, g->dPairSuper32, g->dPairC};
       for (void *p : pairOwned)
         if (p) (void)hipFree(p);
@@ -710,7 +711,7 @@ void awfmGpuAosUnlock(AwFmGpuIndex *g) {
 }
 
 uint64_t awfmGpuIndexDeviceBytes(const AwFmGpuIndex *g) {
-  return g ? g->deviceBytes + g->deepSeedBytes + g->denseSaBytes + g->pairBytes : 0;
+  return g ? g->deviceBytes + g->deepSeedBytes + g->denseSaBytes + g->pairBytes + g->lengthTableBytes : 0;
 }
 
 namespace {
@@ -764,6 +765,14 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
   g->dev.deepNext = 0;
   g->dev.numDeepBig = 0;
   g->dev.deepBigKeys = g->dev.deepBigLengths = nullptr;
+  { /* the tables of the shorter lengths go with the deeper table they complete; the next mixed-length batch builds them again */
+    std::lock_guard<std::mutex> lock(g->lengthMutex);
+    if (g->dLengthTable) (void)hipFree(g->dLengthTable);
+    g->dLengthTable = nullptr;
+    g->lengthDepths = 0;
+    g->lengthTableBytes = 0;
+    g->lengthTried = false;
+  }
   enum AwFmReturnCode rc = AwFmSuccess;
   g->deepSeedBuildSeconds = 0.0;
   g->deepSeedTransientBytes = 0;
@@ -1414,6 +1423,9 @@ static enum AwFmReturnCode applyDenseSaFromEnv(AwFmGpuIndex *g) {
 }
 int awfmGpuIndexHasDenseSa(const AwFmGpuIndex *g) { return g && g->dDenseSa ? 1 : 0; }
 double awfmGpuIndexDenseSaBuildSeconds(const AwFmGpuIndex *g) { return g ? (g->shares ? g->shares : g)->denseSaBuildSeconds : 0.0; }
+/* the tables per k-mer length a mixed-length batch builds on first use (awfm_gpu_ordered.hip: ensureLengthTables) */
+uint64_t awfmGpuIndexLengthTableBytes(const AwFmGpuIndex *g) { return g ? (g->shares ? g->shares : g)->lengthTableBytes : 0; }
+double awfmGpuIndexLengthTableBuildSeconds(const AwFmGpuIndex *g) { return g ? (g->shares ? g->shares : g)->lengthTableBuildSeconds : 0.0; }
 
 /* ---- host-buffer entry points ---- */
 

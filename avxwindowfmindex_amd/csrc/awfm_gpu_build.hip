@@ -437,6 +437,50 @@ __global__ void __launch_bounds__(kThreads)
   }
 }
 
+/* ---- one table per k-mer length below the deeper table's (awfmGpuBuildLengthTables) ----
+ * Level d holds, for every string X of d letters (index: leftmost letter first, as in the seed table), the 8-byte entry
+ * {sp, length} of its range -- what the reference reaches for a k-mer of exactly d characters: from the letter range of the
+ * last character and d - 1 steps when d is below the seed table's length (ref src/AwFmSearch.c:485-520), the seed table's
+ * entry at d = seedK (ref src/AwFmKmerTable.c:4-51), that entry and d - seedK steps that stop at the first empty range above
+ * it (ref src/AwFmParallelSearch.c:273-313).  A length of 0 says "no hit" (all a hits-only search reports of it).  Level
+ * d + 1 from level d: entry letter * 4^d + p is entry p after one backward step with `letter`; one group of 4 lanes per entry
+ * (nucFastStep: the step of the search kernels), consecutive entries have consecutive parents, whose ranges are neighbours
+ * in the BWT.  Images below 2^32 positions. */
+__global__ void __launch_bounds__(kThreads)
+    lengthLevelKernel(const DevIndex ix, const uint2 *__restrict__ parentLevel, u64 parentLen, u64 outLen, uint2 *__restrict__ out) {
+  constexpr int G = 4;
+  __shared__ u64 sC[24];
+  __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
+  __shared__ u64 sSuper[1];
+  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  stageMaskTable(sMask);
+  nucStageSuper<true>(ix, sSuper);
+  __syncthreads();
+  const unsigned gl = threadIdx.x % G;
+  const u64 numGroups = (u64)gridDim.x * kSeedGroupsPerBlock;
+  for (u64 e = ((u64)blockIdx.x * kThreads + threadIdx.x) / G; e < outLen; e += numGroups) {
+    const unsigned letter = (unsigned)(e / parentLen);
+    const uint2 r = parentLevel[e % parentLen];
+    unsigned sp = r.x, ep = r.x + r.y - 1u;
+    if (r.y != 0u) nucFastStep<G, true>(ix, sC, sSuper, sMask, gl, letter, sp, ep);
+    if (gl == 0) out[e] = make_uint2(sp, r.y != 0u && sp <= ep ? ep + 1u - sp : 0u);
+  }
+}
+
+/* level 1: the letter ranges; level seedK: the index's own table in 8-byte form */
+__global__ void lengthLettersKernel(const DevIndex ix, uint2 *__restrict__ out) {
+  if (threadIdx.x < 4u) {
+    const u64 first = ix.prefixSums[threadIdx.x], next = ix.prefixSums[threadIdx.x + 1u];
+    out[threadIdx.x] = make_uint2((unsigned)first, (unsigned)(next - first));
+  }
+}
+__global__ void __launch_bounds__(256) lengthFromSeedKernel(const ulonglong2 *__restrict__ seed, u64 len, uint2 *__restrict__ out) {
+  for (u64 e = (u64)blockIdx.x * 256u + threadIdx.x; e < len; e += (u64)gridDim.x * 256u) {
+    const ulonglong2 r = seed[e];
+    out[e] = make_uint2((unsigned)r.x, r.x <= r.y ? (unsigned)(r.y + 1ull - r.x) : 0u);
+  }
+}
+
 /* The same level step for the amino alphabet: entry letter * parentLen + p of the level is the level-below entry p after
  * one backward step with `letter` (0..19: the index puts the leftmost character first, ref src/AwFmKmerTable.c:37-51), or
  * that entry unchanged when its range is already empty.  One group of 4 lanes per entry (aminoStepAny: the step of the
@@ -769,6 +813,42 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
   }
   *bytesOut = len * (g->dev.bwtLength < (1ull << 32) ? 8 : 16);
   *tableOut = cur.release();
+  return true;
+}
+
+/* awfm_device.h: the tables of the k-mer lengths 1 .. maxDepth in one allocation, level d at entry awfmLengthTableAt(d) */
+bool awfmGpuBuildLengthTables(const AwFmGpuIndex *g, unsigned maxDepth, void **tableOut, uint64_t *bytesOut) {
+  *tableOut = nullptr;
+  *bytesOut = 0;
+  if (g->amino || maxDepth < 1u || maxDepth > 15u || g->dev.bwtLength >= (1ull << 32)) {
+    awfmGpuSetError("length tables: nucleotide images below 2^32 positions, k-mer lengths 1..15");
+    return false;
+  }
+  DeviceGuard guard(g->device);
+  const u64 entries = awfmLengthTableAt(maxDepth + 1u);
+  DeviceBuffer table;
+  if (!table.alloc(entries * sizeof(uint2))) return false;
+  uint2 *base = table.as<uint2>();
+  hipLaunchKernelGGL(lengthLettersKernel, dim3(1), dim3(64), 0, 0, g->dev, base);
+  BUILD_TRY(hipGetLastError());
+  const u64 resident = (u64)g->numCUs * 8u;
+  u64 len = 4;
+  for (unsigned d = 1; d < maxDepth; d++, len *= 4u) { /* level d + 1 */
+    const u64 outLen = len * 4u;
+    uint2 *out = base + awfmLengthTableAt(d + 1u);
+    if (d + 1u == g->dev.seedK && g->dev.seed) {
+      const u64 blocks = (outLen + 255u) / 256u;
+      hipLaunchKernelGGL(lengthFromSeedKernel, dim3((unsigned)(blocks < resident ? blocks : resident)), dim3(256), 0, 0, g->dev.seed, outLen, out);
+    } else {
+      const u64 blocks = (outLen + kSeedGroupsPerBlock - 1) / kSeedGroupsPerBlock;
+      hipLaunchKernelGGL(lengthLevelKernel, dim3((unsigned)(blocks < resident ? blocks : resident)), dim3(kThreads), 0, 0, g->dev,
+                         (const uint2 *)(base + awfmLengthTableAt(d)), len, outLen, out);
+    }
+    BUILD_TRY(hipGetLastError());
+  }
+  BUILD_TRY(hipDeviceSynchronize());
+  *bytesOut = entries * sizeof(uint2);
+  *tableOut = table.release();
   return true;
 }
 

@@ -63,7 +63,8 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
                                         unsigned long long nq, const void *recs, const unsigned short *keys,
                                         const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts,
                                         const OrderTouch *touch = nullptr, const unsigned *bucketStart = nullptr,
-                                        const BucketFormat bucketFmt = BucketFormat(), const SparseOut *sparse = nullptr) {
+                                        const BucketFormat bucketFmt = BucketFormat(), const SparseOut *sparse = nullptr,
+                                        const unsigned *skipSampleAlive = nullptr, unsigned skipSamples = 0u) {
   /* dynamic LDS: the 32-bit superblock bases of the pair image (images below 2^32 positions) */
   const bool superInLds = PAIR && NARROW && awfmPairSuperInLds(g);
   const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u; /* the 16 pair bases of every superblock */
@@ -79,6 +80,11 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
   /* (the events ride on the kernel's own dispatch -- hipExtLaunchKernelGGL -- instead of being recorded around it: a
    * recorded event is a packet of its own and left the queue idle for about 5 us each, 24 us per search) */
   const bool timed = g->orderTiming[2] != nullptr; /* this search has an entry in the timing log */
+  OrderSkip<VARLEN> skip;
+  if constexpr (VARLEN) {
+    skip.sampleAlive = skipSampleAlive;
+    skip.samples = skipSamples;
+  }
   hipExtLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET, LIST>), dim3(grid ? grid : 1u), dim3(threads), (unsigned)lds, s,
                         timed ? g->orderTiming[2] : nullptr, timed ? g->orderTiming[3] : nullptr, 0u, dev, recs,
                         keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
@@ -87,7 +93,8 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
                         /* chunks a ticket is worth: 10^8 random 21-mers 3.92 (1), 3.49 (2), 3.47 (4), 3.50 (8), 3.65 ms (16); planted
                          * 21-mers (round 4, the batches this kernel still sees whole: the others end in lookupSearchKernel) 5.06 (1),
                          * 5.01 (2), 5.19 (3), 5.18 (4): the records in flight on an XCD span fewer buckets.  Mixed lengths: no gain */
-                        getenv("AWFM_GPU_CHUNKS_PER_TICKET") && atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) >= 1 ? (unsigned)atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) : (BUCKET ? 2u : 1u));
+                        getenv("AWFM_GPU_CHUNKS_PER_TICKET") && atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) >= 1 ? (unsigned)atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) : (BUCKET ? 2u : 1u),
+                        skip);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   g->orderTimedKernel = timed;
   if (timed) g->orderLog[(g->orderLogCount - 1u) % AwFmGpuIndex::kOrderLogMax].kernel = true;
@@ -99,7 +106,7 @@ enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t 
                                   uint32_t len, unsigned depth, const ulonglong2 *table, unsigned long long nq,
                                   const void *recs, const unsigned short *keys, const unsigned *generalCount,
                                   ulonglong2 *rng, uint32_t *dCounts, bool packed = false, const OrderTouch *touch = nullptr,
-                                  const SparseOut *sparse = nullptr) {
+                                  const SparseOut *sparse = nullptr, const unsigned *skipSampleAlive = nullptr, unsigned skipSamples = 0u) {
   if (touch) { /* instrumented launch: the variant the image would run (4 lanes per k-mer, pair steps when it has the pair image) */
     if constexpr (COMPACT) { /* the sorted 8-byte records ($AWFM_GPU_ORDERED_SORT=rocprim) are a measurement path: no tally */
       setError("awfmGpuSearchHitsLineTally: not available with $AWFM_GPU_ORDERED_SORT=rocprim");
@@ -116,10 +123,10 @@ enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t 
     enum AwFmReturnCode rc;
     const BucketFormat none = BucketFormat();
     if (G == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR"))
-      rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN, true>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse);
-    else if (G == 2) rc = launchOrderedKernel<2, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse);
-    else if (G == 1) rc = launchOrderedKernel<1, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse);
-    else rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse);
+      rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN, true>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse, skipSampleAlive, skipSamples);
+    else if (G == 2) rc = launchOrderedKernel<2, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse, skipSampleAlive, skipSamples);
+    else if (G == 1) rc = launchOrderedKernel<1, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse, skipSampleAlive, skipSamples);
+    else rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse, skipSampleAlive, skipSamples);
     if (rc != AwFmSuccess) return rc;
   }
   if (packed) return AwFmSuccess; /* bit-packed k-mers: every one of them is covered */
@@ -617,12 +624,15 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
     g->orderFusedKeptAt = (const unsigned *)(w + kKeptAt);
     if (fused) {
       const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
-      const bool superInLds = !pairOff && awfmPairSuperInLds(g);
+      const char *superEnv = getenv("AWFM_GPU_LOOKUP_PAIR_SUPER"); /* measurement knob: lds | global */
+      const bool superInLds = !pairOff && (superEnv ? !strcmp(superEnv, "lds") : awfmPairSuperInLds(g));
       DevIndex dev = g->dev;
       dev.pairSuperInLds = superInLds ? 1u : 0u;
       const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
       /* persistent grid: what is resident (7 workgroups per CU), a multiple of the 8 shares */
-      unsigned fusedGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * 7u ? perShare256 * kShares : (unsigned long long)g->numCUs * 7u);
+      unsigned perCU = 7u;
+      if (const char *env = getenv("AWFM_GPU_LOOKUP_BLOCKS_PER_CU")) perCU = (unsigned)atoi(env) >= 1u ? (unsigned)atoi(env) : 7u;
+      unsigned fusedGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * perCU ? perShare256 * kShares : (unsigned long long)g->numCUs * perCU);
       fusedGrid = (fusedGrid + kShares - 1u) / kShares * kShares;
       launchLookupSearchAt<32u>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt, useNext | (pairOff ? 2u : 0u), nq, (unsigned long long *)(w + codesAt),
                                 numbers, shareCount, hist, binsPad, sampleAlive, kSamples, rng, dCounts, sparse ? *sparse : SparseOut(),
@@ -679,15 +689,64 @@ int awfmGpuOrderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   return orderedSearch(g, s, dChars, off, fixedLength, nq, rng, dCounts, packed, rangesOfHitsOnly, nullptr, nullptr, nullptr);
 }
 
+/* the tables of the k-mer lengths below the deeper table's, built by the first search that can use them (on the primary
+ * image, for its lanes too); nullptr: there are none (no memory, or the image is not one for them) */
+static const uint2 *ensureLengthTables(AwFmGpuIndex *g) {
+  AwFmGpuIndex *p = g->shares ? g->shares : g;
+  const unsigned need = g->dev.deepK - 1u;
+  std::lock_guard<std::mutex> lock(p->lengthMutex);
+  if (p->dLengthTable && p->lengthDepths >= need) return (const uint2 *)p->dLengthTable;
+  if (p->lengthTried) return nullptr;
+  p->lengthTried = true;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  void *table = nullptr;
+  uint64_t bytes = 0;
+  if (!awfmGpuBuildLengthTables(p, need, &table, &bytes)) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  p->dLengthTable = table;
+  p->lengthDepths = need;
+  p->lengthTableBytes = bytes;
+  p->lengthTableBuildSeconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  if (getenv("AWFM_VERBOSE"))
+    fprintf(stderr, "[awfm length tables] lengths 1..%u: %.2f GB in %.3f s\n", need, (double)bytes * 1e-9, p->lengthTableBuildSeconds);
+  return (const uint2 *)table;
+}
+
 /* encodeRecordsKernel -> bucketScanKernel -> partitionRecordsKernel -> orderedSearchKernel (16-byte records) ->
- * searchKernel<INDIRECT>; the caller holds orderMutex.  Return values as awfmGpuOrderedSearch. */
+ * searchKernel<INDIRECT>; the caller holds orderMutex.  Return values as awfmGpuOrderedSearch.
+ * Mixed-length batches on an image with the narrow deeper table: "lookup first" through one table per k-mer length
+ * (awfm_mixed_lookup_kernel.h) -- forced ($AWFM_GPU_MIXED_LOOKUP=1), never (=0), or (unset, batches of >= 2^20 k-mers) left to
+ * a sample of the batch that stays on the device: both front ends are launched, the one it does not choose returns at once. */
 static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off, uint32_t fixedLength,
                               unsigned depth, const ulonglong2 *table, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts,
                               bool rangesOfHitsOnly, const OrderTouch *touch, const SparseOut *sparse) {
   constexpr unsigned bins = (1u << kBucketBitsMax) + 1u, binsPad = (bins + 3u) & ~3u;
   const size_t histAt = kOrderCounterBytes, cursorsAt = histAt + alignUp256(bins * 4u), startAt = cursorsAt + alignUp256(bins * 4u);
   const size_t inAt = startAt + alignUp256((bins + 1u) * 4u), outAt = inAt + alignUp256(nq * sizeof(QueryRec));
-  const size_t total = outAt + alignUp256(nq * sizeof(QueryRec));
+  const size_t leftAt = outAt + alignUp256(nq * sizeof(QueryRec));
+  /* the sample: 16384 k-mers at a fixed stride; the lookup kernel is chosen when fewer than THREE quarters of them are still
+   * alive after their table entry (lookupChosen compares 4 x alive with the number it is given: 3 x the sample's size) --
+   * the records of the other path cost a mixed-length batch 2.5 ms per 10^8 before anything is searched, and its search
+   * kernel is the slower one even when half the k-mers survive (8..30-mers, half drawn from the text: 6.4 against 9.8 ms;
+   * 18..30-mers: 9.1 against 10.7 ms) */
+  constexpr unsigned kSamples = 16384, kChooseOf = 3u * kSamples;
+  const char *mixedEnv = getenv("AWFM_GPU_MIXED_LOOKUP");
+  const bool mixedCapable = off && !touch && !g->amino && awfmImageNarrow(g) && g->dev.deepSeed && g->dev.deepNarrow != 0u &&
+                            g->dev.deepK >= 2u && g->dev.deepK <= 16u && g->dev.seedK < g->dev.deepK &&
+                            !(sparse && sparse->kmers && !sparse->count) /* results in search order owe an entry to every k-mer */;
+  const bool mixedForced = mixedCapable && mixedEnv && atoi(mixedEnv) == 1;
+  const bool mixedWanted = mixedCapable && (mixedEnv ? atoi(mixedEnv) != 0 : nq >= (1ull << 20)) && (mixedForced || nq >= kSamples);
+  const uint2 *lengthTable = mixedWanted ? ensureLengthTables(g) : nullptr;
+  const bool lookupOnly = lengthTable && mixedForced, bySample = lengthTable && !mixedForced;
+  const size_t total = leftAt + (lengthTable ? alignUp256(nq * 8u) : 0u);
+  /* in the counter block, beyond the ticket counters (which end at 65792): the leftover count, the sample's count, the
+   * survivor counters (kFusedCounters words a line apart) */
+  constexpr size_t kLeftCountAt = 98304, kSampleAt = 98304 + 256, kKeptAt = 102400;
+  static_assert(kKeptAt + kFusedCounters * 64u <= kOrderCounterBytes, "counter block");
   if (orderBeginSlot(g, s) != hipSuccess) {
     setError("seed-order search: could not order the use of its scratch across streams");
     return -(int)AwFmGeneralFailure;
@@ -711,12 +770,51 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
                        rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
     WIDE_TRY(hipGetLastError());
   }
+  const unsigned *sampleAlive = nullptr;
+  if (lengthTable) {
+    const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
+    const unsigned useNext = (g->dev.deepNext != 0u && !pairOff ? 1u : 0u) | (pairOff ? 2u : 0u);
+    /* the superblock bases of the pair image are read from memory: 24 KB of them in LDS (a 3.1 Gbp image) would leave room
+     * for 3 workgroups per CU where the survivors' slots alone allow 6 (10^8 8..30-mers: 6.36 against 6.74 ms);
+     * $AWFM_GPU_LOOKUP_PAIR_SUPER=lds|global: measurement knob */
+    const char *superEnv = getenv("AWFM_GPU_LOOKUP_PAIR_SUPER");
+    const bool superInLds = !pairOff && superEnv && !strcmp(superEnv, "lds");
+    unsigned *leftoverCount = (unsigned *)(w + kLeftCountAt), *sampleWord = (unsigned *)(w + kSampleAt), *kept = (unsigned *)(w + kKeptAt);
+    unsigned long long *leftover = (unsigned long long *)(w + leftAt);
+    if (bySample) {
+      WIDE_TRY(awfmGpuLaunchMixedSample(g, s, lengthTable, dChars, off, nq, useNext, kSamples, sampleWord));
+      sampleAlive = sampleWord;
+    }
+    g->orderLookup = bySample ? 2 : 1;
+    g->orderSampleAt = sampleWord;
+    g->orderSamples = kChooseOf;
+    g->orderLookupFused = true;
+    g->orderFusedKeptAt = kept;
+    g->orderKeptAt = leftoverCount;
+    const SparseOut out = sparse ? *sparse : SparseOut();
+    const bool timed = g->orderTiming[0] != nullptr; /* this search has an entry in the timing log: the events ride on the dispatch */
+    WIDE_TRY(awfmGpuLaunchMixedLookup(g, s, timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr, lengthTable, dChars, off, nq,
+                                      useNext, superInLds, sampleAlive, kChooseOf, rng, dCounts, out.count, out.cap, out.kmers, out.ranges, leftover,
+                                      leftoverCount, kept));
+    g->orderTimedFront = timed;
+    if (timed) g->orderLog[(g->orderLogCount - 1u) % AwFmGpuIndex::kOrderLogMax].front = true;
+    /* what the lookup kernel left: the last *leftoverCount records of the list */
+    const unsigned tail = residentGrid(g, searchKernel<false, 4, true, false, true, true>);
+    hipLaunchKernelGGL((searchKernel<false, 4, true, false, true, true>), dim3(tail), dim3(kThreads), 0, s, g->dev, dChars, off, fixedLength, nq, rng,
+                       dCounts, (unsigned long long *)nullptr, (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out,
+                       (const unsigned *)nullptr, 0u);
+    WIDE_TRY(hipGetLastError());
+    if (lookupOnly) { /* forced: the other front end is not launched */
+      WIDE_TRY(orderEndSlot(g, s));
+      return 1;
+    }
+  }
   const unsigned long long encodeTiles = (nq + 255ull) / 256ull;
   const unsigned encodeGrid = (unsigned)(encodeTiles < (unsigned long long)g->numCUs * 8u ? encodeTiles : (unsigned long long)g->numCUs * 8u);
   const unsigned seedK = g->dev.seedK, deepK = g->dev.deepK;
   if (off)
     hipLaunchKernelGGL((encodeRecordsKernel<true>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth, seedK, deepK, nq,
-                       recsIn, hist);
+                       recsIn, hist, sampleAlive, kChooseOf);
   else
     hipLaunchKernelGGL((encodeRecordsKernel<false>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth, seedK, deepK, nq,
                        recsIn, hist);
@@ -736,7 +834,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   const unsigned grid = (unsigned)(tiles < (unsigned long long)g->numCUs ? tiles : (unsigned long long)g->numCUs);
   if (off)
     hipLaunchKernelGGL((partitionRecordsKernel<true>), dim3(grid), dim3(kPartitionThreads), lds, s, (const QueryRec *)recsIn, depth, seedK,
-                       deepK, nq, (const unsigned *)bucketStart, cursors, recsOut);
+                       deepK, nq, (const unsigned *)bucketStart, cursors, recsOut, sampleAlive, kChooseOf);
   else
     hipLaunchKernelGGL((partitionRecordsKernel<false>), dim3(grid), dim3(kPartitionThreads), lds, s, (const QueryRec *)recsIn, depth, seedK,
                        deepK, nq, (const unsigned *)bucketStart, cursors, recsOut);
@@ -745,7 +843,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   enum AwFmReturnCode rc;
   const unsigned short *noKeys = nullptr;
 #define WIDE_GO(NR, VL) \
-  launchOrdered<NR, false, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, noKeys, generalCount, rng, dCounts, false, touch, sparse)
+  launchOrdered<NR, false, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, noKeys, generalCount, rng, dCounts, false, touch, sparse, sampleAlive, kChooseOf)
   if (off) rc = narrow ? WIDE_GO(true, true) : WIDE_GO(false, true);
   else rc = narrow ? WIDE_GO(true, false) : WIDE_GO(false, false);
 #undef WIDE_GO
@@ -992,6 +1090,69 @@ __global__ void __launch_bounds__(256) popcountWordsKernel(const unsigned long l
   if ((threadIdx.x & 63u) == 0u && sum) atomicAdd(total, sum);
 }
 }  // namespace
+
+/* see include/awfm_gpu.h */
+extern "C" enum AwFmReturnCode awfmGpuMixedLookupLineTally(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                                           uint64_t numQueries, uint64_t tallyOut[8]) {
+  if (!g || !dChars || !dOffsets || !tallyOut) {
+    setError("awfmGpuMixedLookupLineTally: null argument");
+    return AwFmNullPtrError;
+  }
+  for (int i = 0; i < 8; i++) tallyOut[i] = 0;
+  const bool capable = !g->amino && awfmImageNarrow(g) && g->dev.deepSeed && g->dev.deepNarrow != 0u && g->dev.deepK >= 2u &&
+                       g->dev.deepK <= 16u && g->dev.seedK < g->dev.deepK;
+  DeviceGuard guard(g->device);
+  const uint2 *lengthTable = capable ? ensureLengthTables(g) : nullptr;
+  if (!lengthTable) {
+    setError("awfmGpuMixedLookupLineTally: this image has no tables per k-mer length (a nucleotide image below 2^32 positions with its narrow deeper table)");
+    return AwFmUnsupportedVersionError;
+  }
+  const uint64_t lengthWords = (awfmLengthTableAt(g->dev.deepK) * 8u / 128u + 64u) / 64u;
+  const uint64_t deepWords = ((1ull << (2u * g->dev.deepK)) * 8u / 128u + 64u) / 64u;
+  const uint64_t pairWords = (g->numBlocks + 64u) / 64u, nucWords = (g->numBlocks / 2u + 64u) / 64u;
+  const unsigned levels = awfmGpuMixedTouchLevels();
+  const uint64_t words = lengthWords + deepWords + (uint64_t)levels * (pairWords + nucWords) + 8u;
+  unsigned long long *bits = nullptr;
+  if (hipMalloc((void **)&bits, words * 8u) != hipSuccess) {
+    (void)hipGetLastError();
+    setError("awfmGpuMixedLookupLineTally: no device memory for the line bitmaps");
+    return AwFmAllocationFailure;
+  }
+  hipStream_t s = nullptr;
+  unsigned long long *pairLines = bits + lengthWords + deepWords, *nucLines = pairLines + (uint64_t)levels * pairWords;
+  unsigned long long *sums = nucLines + (uint64_t)levels * nucWords; /* [0..2] the kernel's counts, [3..6] the four line totals */
+  const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
+  const unsigned useNext = (g->dev.deepNext != 0u && !pairOff ? 1u : 0u) | (pairOff ? 2u : 0u);
+  hipError_t e = hipMemsetAsync(bits, 0, words * 8u, s);
+  unsigned long long host[8] = {0};
+  if (e == hipSuccess)
+    e = awfmGpuLaunchMixedTally(g, s, lengthTable, dChars, (const unsigned long long *)dOffsets, (unsigned long long)numQueries, useNext, bits,
+                                lengthWords, deepWords, pairWords, nucWords);
+  if (e == hipSuccess) {
+    const struct { const unsigned long long *from; uint64_t n; } parts[4] = {
+        {bits, lengthWords}, {bits + lengthWords, deepWords}, {pairLines, (uint64_t)levels * pairWords}, {nucLines, (uint64_t)levels * nucWords}};
+    for (int i = 0; i < 4 && e == hipSuccess; i++) {
+      hipLaunchKernelGGL(popcountWordsKernel, dim3(2048), dim3(256), 0, s, parts[i].from, (unsigned long long)parts[i].n, sums + 3 + i);
+      e = hipGetLastError();
+    }
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(host, sums, sizeof host, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(bits);
+  if (e != hipSuccess) {
+    setError("awfmGpuMixedLookupLineTally", e);
+    return AwFmGeneralFailure;
+  }
+  tallyOut[0] = host[3];
+  tallyOut[1] = host[4];
+  tallyOut[2] = host[5];
+  tallyOut[3] = host[6];
+  tallyOut[4] = host[0];
+  tallyOut[5] = host[1];
+  tallyOut[6] = host[2];
+  tallyOut[7] = host[7];
+  return AwFmSuccess;
+}
 
 /* see include/awfm_gpu.h */
 extern "C" enum AwFmReturnCode awfmGpuSearchHitsLineTally(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,

@@ -1093,9 +1093,11 @@ template <bool VARLEN>
 __global__ void __launch_bounds__(256)
     encodeRecordsKernel(const unsigned char *__restrict__ chars, const unsigned long long *__restrict__ offsets, const unsigned fixedLen,
                         const unsigned fixedDepth, const unsigned seedK, const unsigned deepK, const unsigned long long numQueries,
-                        QueryRec *__restrict__ recs, unsigned *__restrict__ hist) {
+                        QueryRec *__restrict__ recs, unsigned *__restrict__ hist, const unsigned *__restrict__ sampleAlive = nullptr,
+                        const unsigned samples = 0u) {
   __shared__ unsigned sHist[(1u << kBucketBitsMax) + 1u];
   constexpr unsigned bins = (1u << kBucketBitsMax) + 1u;
+  if (lookupChosen(sampleAlive, samples, false)) return; /* this batch is mixedLookupSearchKernel's (uniform) */
   for (unsigned e = threadIdx.x; e < bins; e += 256u) sHist[e] = 0u;
   __syncthreads();
   const unsigned long long tiles = (numQueries + 255ull) / 256ull;
@@ -1129,8 +1131,10 @@ template <bool VARLEN>
 __global__ void __launch_bounds__(kPartitionThreads)
     partitionRecordsKernel(const QueryRec *__restrict__ in, const unsigned fixedDepth, const unsigned seedK, const unsigned deepK,
                            const unsigned long long numQueries, const unsigned *__restrict__ bucketStart,
-                           unsigned *__restrict__ cursors, QueryRec *__restrict__ out) {
+                           unsigned *__restrict__ cursors, QueryRec *__restrict__ out, const unsigned *__restrict__ sampleAlive = nullptr,
+                           const unsigned samples = 0u) {
   extern __shared__ unsigned long long sDyn[];
+  if (lookupChosen(sampleAlive, samples, false)) return; /* this batch is mixedLookupSearchKernel's (uniform) */
   ulonglong2 *sRec = (ulonglong2 *)sDyn;            /* kWideTile records, bucket by bucket */
   unsigned *sCnt = (unsigned *)(sRec + kWideTile);
   constexpr unsigned bins = (1u << kBucketBitsMax) + 1u, binsPad = (bins + 3u) & ~3u;
@@ -1244,6 +1248,19 @@ struct OrderTouch {
   unsigned long long *hits; /* k-mers that stored a result */
 };
 
+/* mixed-length batches: the sample's word that says whether the batch went to mixedLookupSearchKernel instead (the other
+ * variants carry no such argument: the fixed-length kernels keep their registers) */
+template <bool VARLEN>
+struct OrderSkip {
+  __device__ __forceinline__ bool chosen() const { return false; }
+};
+template <>
+struct OrderSkip<true> {
+  const unsigned *sampleAlive = nullptr;
+  unsigned samples = 0;
+  __device__ __forceinline__ bool chosen() const { return lookupChosen(sampleAlive, samples, false); }
+};
+
 constexpr unsigned kTicketGroups = 4; /* ticket counters per XCD and wave slot */
 template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false,
           bool LIST = false /* bucketed records + the list of hits: a wave collects its hits (below) */>
@@ -1260,8 +1277,10 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
                         unsigned *__restrict__ counts, unsigned *__restrict__ tickets, const int xcdMap = 0,
                         const OrderTouch touch = OrderTouch(), const unsigned *__restrict__ bucketStart = nullptr,
                         const BucketFormat bucketFmt = BucketFormat(), const SparseOut sparse = SparseOut(),
-                        const unsigned chunksPerTicket = 1u) {
+                        const unsigned chunksPerTicket = 1u, const OrderSkip<VARLEN> skip = OrderSkip<VARLEN>()) {
   static_assert(!BUCKET || (COMPACT && !VARLEN), "bucketed records are the 8-byte records of fixed-length batches");
+  /* a mixed-length batch that the sample gave to mixedLookupSearchKernel: no records were written (uniform) */
+  if (skip.chosen()) return;
   constexpr bool AHEAD = BUCKET; /* the next chunk's table entry is requested a chunk ahead */
   constexpr int S = (int)kSlices / G;
   typedef typename PositionType<NARROW>::type pos_t;

@@ -810,7 +810,11 @@ def main():
         # The dominant kernel starts from a deeper table and serves repeated block reads out of the L2, so the reference
         # algorithm's bytes are not what it has to move: its roofline is its COMPULSORY traffic -- every 128-B line once per search level that needs
         # it, the sorted records, the results -- over its own HIP-event time.
-        lines = g.search_hits_line_tally(d_chars.data_ptr(), off_ptr, K, Q)
+        mixed_lookup = lookup_first and d_offsets is not None  # mixedLookupSearchKernel: its own tally (below)
+        lines = g.search_hits_line_tally(d_chars.data_ptr(), off_ptr, K, Q) if not mixed_lookup else \
+            g.mixed_lookup_line_tally(d_chars.data_ptr(), off_ptr, Q)
+        if mixed_lookup:
+            lines.update(seed_table_lines=0, ordered_kmers=Q - lines["general_kmers"], record_bytes_per_kmer=0)
         # what the search stores per result, by the form the timed steps used
         stored = {"list": 20 * lines["kmers_with_hits"], "order": 20 * lines["ordered_kmers"],
                   "dense": (16 + (4 if narrow_counts else 0)) * lines["kmers_with_hits"]}[whole.form] if locate else 4 * lines["kmers_with_hits"]
@@ -821,8 +825,23 @@ def main():
         what = ("distinct (search level, 128-B line) pairs the kernel reads, tallied on the device by an "
                 "instrumented launch of the same kernel on the same sorted batch (awfmGpuSearchHitsLineTally), "
                 "x 128 B, + sorted records and keys read + results stored")
-        fused = lookup_first and os.environ.get("AWFM_GPU_LOOKUP_FUSED", "1") != "0"
-        if lookup_first and fused:
+        fused = lookup_first and (mixed_lookup or os.environ.get("AWFM_GPU_LOOKUP_FUSED", "1") != "0")
+        if mixed_lookup:
+            # A mixed-length batch that took "lookup first" (DESIGN.md 4c): ONE table entry per k-mer -- from the table of its
+            # own length (k-mers shorter than the deeper table's) or from the deeper table --, then the steps of the k-mers
+            # still alive.  Its compulsory bytes: characters + offsets + every distinct line of those tables once + every
+            # distinct (level, line) of the survivors' block reads + the results; tallied by an instrumented pass over the
+            # same k-mers (awfmGpuMixedLookupLineTally).
+            dom_name = "mixedLookupSearchKernel"
+            lines["characters"] = total_chars
+            streamed = total_chars + 8 * (Q + 1)
+            compulsory = streamed + 128 * (lines["length_table_lines"] + lines["deep_table_lines"] + lines["pair_level_lines"]
+                                           + lines["nuc_level_lines"]) + stored
+            lines = dict(lines, kmers_kept=int(lookup_kept), characters_read=int(lines["characters"]), offsets_read_bytes=8 * (Q + 1))
+            what = ("the k-mers' characters and offsets + 128 B x (the distinct lines of the length tables and of the deeper table the "
+                    "batch's k-mers need + the distinct (search level, line) pairs of the block reads of the k-mers still alive after "
+                    "their entry), tallied on the device by awfmGpuMixedLookupLineTally, + the results stored")
+        elif lookup_first and fused:
             # The batch was one for "lookup first"  and the kernel that looks the table entries up also searches
             # the few k-mers that are still alive after them (lookupSearchKernel).  Its compulsory bytes: the characters +
             # every distinct table line once (the tally's deep_table_lines: the same entries, whatever the order) + every
@@ -850,7 +869,9 @@ def main():
         # line it arrives in; the block reads of the search levels stay at their distinct lines.  traffic / needed says how
         # much of what the kernel moves is the rest of a line nobody asked for.
         entry_bytes = 8 if narrow_counts else 16
-        if lookup_first and fused:
+        if mixed_lookup:
+            needed = streamed + 8 * lines["ordered_kmers"] + 128 * (lines["pair_level_lines"] + lines["nuc_level_lines"]) + stored
+        elif lookup_first and fused:
             needed = Q * K + entry_bytes * Q + 128 * (lines["pair_level_lines"] + lines["nuc_level_lines"]) + stored
         elif lookup_first:
             needed = Q * K + entry_bytes * Q + 12 * lookup_kept
@@ -872,6 +893,13 @@ def main():
                        "peak): most lines are entries of the deeper seed table, one per k-mer; see hbm_frac_measured for this "
                        "kernel's measured traffic and `l2` for the requests it sends to the L2s",
         }
+        if mixed_lookup:
+            # what the kernel reads AS EXECUTED: it takes the k-mers in batch order, so no two k-mers share a line the way an
+            # ideal cache (the compulsory figure) would have them -- one 128-B line per table entry, one per block read of a
+            # survivor's step -- a gather of random lines, whose ceiling on this chip is 0.69-0.73 of the HBM peak
+            executed = streamed + 128 * (lines["ordered_kmers"] + lines["block_reads_executed"]) + stored
+            roofline["executed_read_bytes"] = int(executed)
+            roofline["frac_executed_reads"] = round(executed / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         counters, csrc = profile_file("counters", prof_name) if prof_name else (None, None)
         traffic, tsrc = profile_file("traffic", prof_name) if prof_name else (None, None)
         if counters and not str(counters.get("kernel", "")).startswith(dom_name):
@@ -908,7 +936,9 @@ def main():
         # the whole call, priced by what the REFERENCE algorithm would move for this batch: a throughput figure in bytes,
         # not a roofline fraction (five sixths of those bytes never leave the L2)
         roofline["call"] = {
-            "kernels": ("awfmGpuSearchHits*: fill / memset + sampleAliveKernel + lookupSearchKernel (+ the kernels of the other front "
+            "kernels": ("awfmGpuSearchHits*: fill / memset + mixedSampleAliveKernel + mixedLookupSearchKernel + the general kernel over "
+                        "what it left (+ the kernels of the 16-byte-record path, which return at once)" if mixed_lookup else
+                        "awfmGpuSearchHits*: fill / memset + sampleAliveKernel + lookupSearchKernel (+ the kernels of the other front "
                         "end, which return at once)" if lookup_first and fused else
                         "awfmGpuSearchHits*: fill / memset + sampleAliveKernel + encodeLookupKernel + bucketScanSharesKernel + "
                         "partitionKernel + orderedSearchKernel over the k-mers kept" if lookup_first else
@@ -1402,6 +1432,10 @@ def main():
                                "dense": "awfmGpuSearchHitsSparse" if narrow_counts else "awfmGpuSearchHits"}[whole.form] if locate
                               else "awfmGpuSearchHits") + (", seed order" if ordered else ", general kernel"),
               "result_format": form_names[whole.form] if locate else "count under every k-mer number"}
+    lt_bytes, lt_s = g.length_tables
+    if lt_bytes:  # built by the probe step of a mixed-length batch (awfm_mixed_lookup_kernel.h): device-only, kept with the image
+        config["length_tables_bytes"] = lt_bytes
+        config["length_tables_build_s"] = round(lt_s, 3)
     if dense_form:  # flat copies for readers that keep scalars only
         config["dense_form"] = dense_form
         config["dense_form_ms_per_step"] = dense_form["ms_per_step"]

@@ -101,6 +101,14 @@ uint64_t awfmGpuIndexDeepSeedTransientBytes(const AwFmGpuIndex *g);
 enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable);
 int awfmGpuIndexHasDenseSa(const AwFmGpuIndex *g);
 double awfmGpuIndexDenseSaBuildSeconds(const AwFmGpuIndex *g); /* reporting: wall seconds of the automatic construction */
+/* Device-only tables per k-mer length (nucleotide images below 2^32 positions with the narrow deeper table of depth D): for
+ * every length d = 1 .. D-1 the 8-byte entry {first position, length} of the range of EVERY d-letter string -- what the
+ * reference reaches for a k-mer of exactly d characters (ref src/AwFmSearch.c:485-520 below the seed table's length,
+ * src/AwFmKmerTable.c:4-51 at it, src/AwFmParallelSearch.c:273-313 above it) -- (4^D - 4) / 3 entries, 11.5 GB for D = 16.
+ * Built on the device by the first mixed-length batch (CSR offsets) that takes the lookup-first kernel
+ * ($AWFM_GPU_MIXED_LOOKUP=0: never), kept with the image; bytes / wall seconds of that construction (0: none yet). */
+uint64_t awfmGpuIndexLengthTableBytes(const AwFmGpuIndex *g);
+double awfmGpuIndexLengthTableBuildSeconds(const AwFmGpuIndex *g);
 /* Nucleotide images carry, beside the one-letter blocks, a pair image: for every BWT position the pair of its two
  * preceding text characters, in 128-byte blocks of 128 positions with 16 base counts, so that two backward steps (two
  * LF steps) are one rank over a 16-letter sequence and one block read (csrc/awfm_pair.h).  The searches and the LF
@@ -236,6 +244,17 @@ uint64_t awfmGpuLastOrderedKept(AwFmGpuIndex *g);
  * query characters}.  Synchronous, not for timing. */
 enum AwFmReturnCode awfmGpuSearchTally(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                        uint32_t fixedLength, uint64_t numQueries, uint64_t tallyOut[4]);
+
+/* What the lookup-first kernel of mixed-length batches (awfm_mixed_lookup_kernel.h: one table entry per k-mer, from the table
+ * of its own length or from the deeper table, then the steps of the k-mers still alive) has to read for this batch: an
+ * instrumented pass over the same k-mers with every 128-B line marked in a bitmap.  tallyOut = {lines of the length tables
+ * touched, lines of the deeper table touched, distinct (search level, 128-B line) pairs of the pair image, the same of the
+ * one-letter image, k-mers still alive after their table entry, k-mers with hits, k-mers left to the general kernel,
+ * block lines the steps of the k-mers still alive read as executed (no line shared between two k-mers)}.  Builds the length tables when the image can have them and has none yet;
+ * AwFmUnsupportedVersionError when it cannot (amino, 2^32 positions or more, no narrow deeper table).  Synchronous, not for
+ * timing. */
+enum AwFmReturnCode awfmGpuMixedLookupLineTally(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                                uint64_t numQueries, uint64_t tallyOut[8]);
 
 /* Instrumented run of the seed-order path of awfmGpuSearchHits on the same batch (encode + sort + search with every
  * line the search kernel reads marked in per-level bitmaps): the COMPULSORY memory traffic of that kernel, i.e. what an

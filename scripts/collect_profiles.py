@@ -79,7 +79,7 @@ ordered.sort(key=lambda k: -summary[k]["FETCH_SIZE"]["dispatches"])
 if ordered:
     calls = summary[ordered[0]]["FETCH_SIZE"]["dispatches"]
     parts = [k for k in summary if "FETCH_SIZE" in summary[k] and (
-             k == ordered[0] or k.startswith(("fillNoHitKernel", "fillSparseKernel", "encodeQueriesKernel", "encodeCodes", "encodeLookup", "lookupSearch", "encodeRecords", "partitionRecords",
+             k == ordered[0] or k.startswith(("fillNoHitKernel", "fillSparseKernel", "encodeQueriesKernel", "encodeCodes", "encodeLookup", "lookupSearch", "mixedLookupSearch", "mixedSampleAlive", "encodeRecords", "partitionRecords",
                                               "sampleAlive", "partitionKernel", "bucketScan", "segmentSumsKernel", "tileOffsetsKernel"))
              or ("radix_sort" in k and "unsigned short" in k) or (k.startswith("searchKernel") and k.rstrip(">").endswith("true, false")))]
     # kernels that ran fewer times than the dominant one belong to the one instrumented tally call, not to a timed call
@@ -131,7 +131,7 @@ if search and not ordered:
 # SIMD-32; GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_WAVE_CYCLES / SQ_WAIT_ANY count in units of 4 cycles)
 dominant = (ordered or search or [None])[0]
 # "lookup first" batches: the call's dominant kernel is encodeLookupKernel, the ordered kernel only sees what it kept
-lookup = [k for k in summary if k.startswith(("encodeLookupKernel", "lookupSearchKernel")) and "FETCH_SIZE" in summary[k]]
+lookup = [k for k in summary if k.startswith(("encodeLookupKernel", "lookupSearchKernel", "mixedLookupSearchKernel")) and "FETCH_SIZE" in summary[k]]
 lookup.sort(key=lambda k: -(kernel_avg_ns(k) or 0))
 if lookup and ordered and (kernel_avg_ns(lookup[0]) or 0) > (kernel_avg_ns(ordered[0]) or 0):
     dominant = lookup[0]

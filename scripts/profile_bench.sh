@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-KERNELS="earchKernel|lookupSearch|encodeLookup|encodeRecords|partitionRecords|rankMark|rankBlock|rankPlace|sampleAlive|bucketScanShares|walkKernel|finishKernel|fillNoHitKernel|fillSparseKernel|encodeQueriesKernel|encodeCodes|partitionKernel|bucketScanKernel|segmentSumsKernel|tileOffsetsKernel|radix_sort|onesweep|expandHitsKernel|scanTileKernel|scanReduceKernel|sortKeysKernel|bucketKernel"
+KERNELS="earchKernel|lookupSearch|SampleAlive|mixedLookupTally|encodeLookup|encodeRecords|partitionRecords|rankMark|rankBlock|rankPlace|sampleAlive|bucketScanShares|walkKernel|finishKernel|fillNoHitKernel|fillSparseKernel|encodeQueriesKernel|encodeCodes|partitionKernel|bucketScanKernel|segmentSumsKernel|tileOffsetsKernel|radix_sort|onesweep|expandHitsKernel|scanTileKernel|scanReduceKernel|sortKeysKernel|bucketKernel"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-secondary --no-shard-proxy --no-dense-form "$@" > "$OUT/bench_trace.log" 2>&1
 declare -A PASS
 PASS[fetch]="FETCH_SIZE"

@@ -1143,6 +1143,113 @@ def test_ordered_hits_only_search_of_mixed_length_batches(oracle, awfm, require_
     ix.dealloc()
 
 
+@pytest.mark.parametrize("n,seed_k,deep_k,pair,lo,hi", [(300000, 8, 12, "1", 0, 40), (300000, 8, 12, "0", 1, 32), (200000, 6, 9, "1", 0, 36),
+                                                        (4096, 3, 5, "1", 0, 20), (250000, 12, 16, "1", 8, 30), (150000, 1, 2, "1", 0, 12)])
+def test_mixed_length_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, monkeypatch, n, seed_k, deep_k, pair, lo, hi):
+    """"Lookup first" for mixed-length batches (mixedLookupSearchKernel): one table entry per k-mer -- the table of its own
+    length when it is shorter than the deeper table's k-mers, the deeper table otherwise --, the survivors stepped by the
+    kernel that looked them up, what it does not cover (ambiguity characters, no characters, more than 32) left to the
+    general kernel.  Forced on and off over the same batch (random + planted k-mers of every length, ambiguity characters,
+    upper case, every byte alignment): dense results, counts only and the list of hits must all be the oracle's."""
+    import torch
+    monkeypatch.setenv("AWFM_GPU_PAIR", pair)
+    txt = synth.text(n + 57, n, synth.DNA_ALPHABET).copy()
+    txt[10:14] = ord("n")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, seed_k)
+    oi = oracle.Index.wrap(oracle.DNA, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(deep_k)
+    Q = 70013
+    chars, offsets = _mixed_queries(5000 + n, Q, txt, synth.DNA_ALPHABET, lo, min(hi, n), ambiguity=ord("x"), upper=True)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    assert cnt.sum() > 0 and (cnt == 0).sum() > Q // 16
+    dev = torch.device("cuda")
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("AWFM_GPU_MIXED_LOOKUP", mode)
+        for mis in (0, 1, 2, 3):
+            buf = torch.zeros(chars.size + 4, dtype=torch.uint8, device=dev)  # (the batch all but ends where the buffer ends)
+            buf[mis:mis + chars.size] = torch.from_numpy(chars).to(dev)
+            d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
+            d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+            g.search_hits(buf.data_ptr() + mis, d_off.data_ptr(), 0, Q, d_ranges.data_ptr(), d_counts.data_ptr())
+            torch.cuda.synchronize()
+            assert g.last_ordered_kernel_is_lookup() == (mode == "1")
+            _check_hits_contract(d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2), d_counts.cpu().numpy().view(np.uint32), sp, ep, cnt)
+        d_counts2 = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+        g.search_hits(buf.data_ptr() + 3, d_off.data_ptr(), 0, Q, 0, d_counts2.data_ptr())  # counts only
+        torch.cuda.synchronize()
+        assert np.array_equal(d_counts2.cpu().numpy().view(np.uint32), cnt)
+        # the list of the k-mers with hits
+        cap = Q
+        d_kmers = torch.zeros(cap, dtype=torch.int32, device=dev)
+        d_hit_ranges = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+        d_num = torch.zeros(1, dtype=torch.int32, device=dev)
+        g.search_hits_compact(buf.data_ptr() + 3, d_off.data_ptr(), 0, Q, d_kmers.data_ptr(), d_hit_ranges.data_ptr(), cap, d_num.data_ptr())
+        torch.cuda.synchronize()
+        listed = int(d_num.item())
+        assert listed == int((cnt > 0).sum())
+        g.sort_hits(d_kmers.data_ptr(), d_hit_ranges.data_ptr(), listed)
+        torch.cuda.synchronize()
+        ids = d_kmers[:listed].cpu().numpy().view(np.uint32)
+        r = d_hit_ranges[:listed * 2].cpu().numpy().view(np.uint64).reshape(listed, 2)
+        assert np.array_equal(ids, np.flatnonzero(cnt > 0)) and np.array_equal(r[:, 0], sp[cnt > 0]) and np.array_equal(r[:, 1], ep[cnt > 0])
+    # the instrumented pass over the same k-mers (what bench.py prices the kernel by) reads them the same way
+    tally = g.mixed_lookup_line_tally(buf.data_ptr() + 3, d_off.data_ptr(), Q)
+    lens = np.diff(offsets.astype(np.int64))
+    is_letter = np.isin(chars, np.frombuffer(b"acgtuACGTU", np.uint8))
+    bad = np.add.reduceat(~is_letter, offsets[:-1].astype(np.int64).clip(max=max(chars.size - 1, 0))) * (lens > 0) > 0 if chars.size else np.zeros(Q, bool)
+    general = (lens == 0) | (lens > 32) | bad
+    assert tally["general_kmers"] == int(general.sum())
+    assert tally["pair_level_lines"] + tally["nuc_level_lines"] <= tally["block_reads_executed"] <= 2 * 17 * tally["kmers_alive_after_the_table"]
+    assert tally["kmers_with_hits"] == int(((cnt > 0) & ~general).sum())
+    assert tally["kmers_alive_after_the_table"] <= int(((lens > deep_k) & ~general).sum())
+    assert 0 < tally["length_table_lines"] + tally["deep_table_lines"] <= int((~general).sum())
+    assert g.length_tables[0] == 8 * (4 ** deep_k - 4) // 3
+    g.destroy()
+    ix.dealloc()
+
+
+def test_mixed_length_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, monkeypatch):
+    """Without $AWFM_GPU_MIXED_LOOKUP a mixed-length batch of 2^20 k-mers or more is sampled: random 8..30-mers against a
+    small text mostly end at their table entry -> mixedLookupSearchKernel; k-mers drawn from the text, most of them longer
+    than the deeper table's, survive it -> the 16-byte-record path as before.  Counts against the oracle either way."""
+    import torch
+    monkeypatch.delenv("AWFM_GPU_MIXED_LOOKUP", raising=False)
+    n, Q = 300000, (1 << 20) + 77
+    txt = synth.text(n + 43, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(12)
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(5)
+    lengths = rng.integers(8, 31, Q)
+    offsets = np.zeros(Q + 1, np.uint64)
+    np.cumsum(lengths, out=offsets[1:])
+    total = int(offsets[-1])
+    starts = rng.integers(0, n - 40, Q)
+    for name in ("random", "planted"):
+        if name == "random":
+            chars = np.frombuffer(synth.DNA_ALPHABET, np.uint8)[rng.integers(0, 4, total)].copy()
+        else:
+            idx = np.repeat(starts, lengths) + (np.arange(total) - np.repeat(offsets[:-1].astype(np.int64), lengths))
+            chars = txt[idx].copy()
+        chars[::5000] = ord("n")  # some for the general kernel
+        _, _, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+        d_chars = torch.from_numpy(np.concatenate([chars, np.zeros(8, np.uint8)])).to(dev)
+        d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+        d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+        g.search_hits(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, 0, d_counts.data_ptr())
+        torch.cuda.synchronize()
+        assert g.last_ordered_kernel_is_lookup() == (name == "random"), name
+        assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt), name
+    g.destroy()
+    ix.dealloc()
+
+
 def test_ordered_search_when_every_wave_takes_many_chunks(oracle, awfm, require_gpu, wide):
     """batches large enough that every wave of the ordered kernel draws several tickets (its record prefetch runs
     ahead of the k-mer being searched): 600 000 mixed-length and 600 000 fixed-length k-mers, device generators,

@@ -18,7 +18,7 @@ def kernel_metadata(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
     text = ""
-    for source in ("awfm_gpu.hip", "awfm_gpu_ordered.hip"):
+    for source in ("awfm_gpu.hip", "awfm_gpu_ordered.hip", "awfm_gpu_mixed.hip"):
         out = tmp_path_factory.mktemp("isa") / (source + ".s")
         subprocess.check_call([HIPCC, "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
                                "-I" + CSRC, "-Wno-unused-function", "-S", "--cuda-device-only", "-o", str(out),
@@ -100,3 +100,7 @@ def test_lookup_search_kernels_resources(kernel_metadata):
     assert k["vgpr"] <= 72 and k["spill"] <= 16 and k["scratch"] <= 64 and k["lds"] <= 12 * 1024
     k = _one(kernel_metadata, r"[0-9]aminoLookupSearchKernelILj10EEE")
     assert k["vgpr"] <= 72 and k["spill"] == 0 and k["scratch"] == 0 and k["lds"] <= 12 * 1024
+    # mixedLookupSearchKernel (mixed-length batches): four decoded k-mers and their entries per lane, 192 survivor slots per
+    # wave: 5 waves per SIMD (<= 96 registers; builds held to 80 measured slower), no spills, 6 workgroups' LDS per CU
+    k = _one(kernel_metadata, r"[0-9]mixedLookupSearchKernelE")
+    assert k["vgpr"] <= 96 and k["spill"] == 0 and k["scratch"] == 0 and k["lds"] <= 26 * 1024
