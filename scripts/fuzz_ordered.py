@@ -96,6 +96,12 @@ while time.time() < t_end:
             os.environ["AWFM_GPU_LOOKUP_FIRST"] = lookup
         else:
             os.environ.pop("AWFM_GPU_LOOKUP_FIRST", None)
+        # mixed-length batches: the lookup-first kernel over the tables per k-mer length, forced / never / by its sample
+        mixed = str(rng.choice(["1", "0", ""]))
+        if mixed:
+            os.environ["AWFM_GPU_MIXED_LOOKUP"] = mixed
+        else:
+            os.environ.pop("AWFM_GPU_MIXED_LOOKUP", None)
         g.search_hits(chars_ptr, off_ptr, K, Q, hits.data_ptr(), counts.data_ptr())
         torch.cuda.synchronize()
         listed_ok = True
@@ -118,7 +124,7 @@ while time.time() < t_end:
         expect = torch.where(has, a[:, 1] - a[:, 0] + 1, torch.zeros_like(a[:, 0])).clamp(max=0xFFFFFFFF)
         ok = (torch.equal(a[has], b[has]) and bool((b[~has, 0] > b[~has, 1]).all())
               and torch.equal(counts.to(torch.int64) & 0xFFFFFFFF, expect))
-        tag = f"n={n} k={seed_k} deep={deep_k} ratio={ratio} Q={Q} {desc} mis={mis} ordered={g.search_hits_is_ordered(off_ptr != 0, K, Q)} lookup_first={lookup!r}"
+        tag = f"n={n} k={seed_k} deep={deep_k} ratio={ratio} Q={Q} {desc} mis={mis} ordered={g.search_hits_is_ordered(off_ptr != 0, K, Q)} lookup_first={lookup!r} mixed_lookup={mixed!r}"
         if not listed_ok:
             print("LIST MISMATCH", tag, flush=True)
             sys.exit(1)
