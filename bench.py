@@ -581,6 +581,10 @@ def main():
             if force is None and form == "dense" and have_order and p.ordered and p.hits >= p.q // 4:
                 return probe(p, "order")  # most k-mers have hits: results in search order
         p.form = form
+        if form == "list" and not os.environ.get("AWFM_BENCH_WIDE_LIST"):
+            # the list's capacity for the timed steps: what the probe listed + a quarter (a caller sizes its list by what its
+            # batches yield; every pass over the list -- fill, sort, scan -- is a pass over the capacity)
+            p.cap = min(p.cap, max(1024, -(-(p.listed * 5 // 4) // 1024) * 1024))
         p.windowed = p.hits > WINDOW_HITS  # a hit list beyond what is kept resident: window by window (awfmGpuLocateWindow)
         ensure_positions(WINDOW_HITS if p.windowed else p.hits)
         torch.cuda.synchronize()
