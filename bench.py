@@ -426,6 +426,18 @@ def main():
         d_planted = torch.empty(Q * K, dtype=torch.uint8, device=dev)
         assert L.awfmGpuSynthPlantedQueries(d_planted.data_ptr(), first, Q, K, 103, d_text.data_ptr(), n, None) == 1
         torch.cuda.synchronize()
+    # ... and cfg 5's batch (configs[4]: k-mers of 8..30 characters, every second one drawn from the text; counted)
+    d_mixed = None
+    if d_planted is not None and n >= (1 << 28):
+        m_len = torch.empty(Q, dtype=torch.int64, device=dev)
+        assert L.awfmGpuSynthMixedLengths(m_len.data_ptr(), first, Q, 8, 30, 105, None) == 1
+        m_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(m_len, 0, out=m_off[1:])
+        del m_len
+        m_chars = torch.empty(int(m_off[-1].item()), dtype=torch.uint8, device=dev)
+        assert L.awfmGpuSynthMixedQueries(m_chars.data_ptr(), m_off.data_ptr(), first, Q, 105, d_text.data_ptr(), n, 0, None) == 1
+        torch.cuda.synchronize()
+        d_mixed = (m_chars, m_off)
     del d_text  # planted k-mers are already copied out; free 3.1 GB
     torch.cuda.empty_cache()
 
@@ -1283,6 +1295,43 @@ def main():
             known[pkey] = pdig
             json.dump(known, open(args.record_digests, "w"), indent=1, sort_keys=True)
 
+    # ---- and cfg 5's mixed-length batch on the same index, counted (awfmGpuSearchHits with CSR offsets): 3 timed steps,
+    # the counts' digest against the committed one of `--workload mixed` ----
+    if d_mixed is not None and secondary is not None:
+        m_chars, m_off = d_mixed
+        m_counts = torch.empty(Q, dtype=torch.int32, device=dev)
+        lane0 = lanes[0]
+
+        def mixed_step():
+            g.search_hits(m_chars.data_ptr(), m_off.data_ptr(), 0, Q, 0, m_counts.data_ptr(), lane0.stream)
+        torch.cuda.synchronize()
+        mixed_step()  # (the first mixed-length batch builds the tables per k-mer length)
+        mixed_step()
+        torch.cuda.synchronize()
+        g.ordered_kernel_log()  # (drop the log entries of everything before)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            mixed_step()
+        torch.cuda.synchronize()
+        mixed_dt = (time.perf_counter() - t0) / 3
+        mixed_lookup_chosen = bool(g.last_ordered_kernel_is_lookup())
+        mlog = g.ordered_kernel_log()
+        mkey = digest.key(args.alphabet, "mixed", "count", n, "8-30", args.seed_k, args.sa_ratio, first, Q)
+        mdig = f"{digest.counts_digest(first, m_counts):016x}"
+        committed = digest.load_golden().get(mkey)
+        assert committed is None or committed["counts"] == mdig, f"mixed-length counts digest {mdig} differs from the committed {committed}"
+        lt_bytes, lt_s = g.length_tables
+        secondary["mixed_lengths"] = {
+            "workload": f"{Q / 1e6:g} M k-mers of 8..30 characters (every second one drawn from the text), counted, same index",
+            "value": round(Q / mixed_dt / 1e6, 2), "unit": "Mkmers/s", "ms_per_step": round(mixed_dt * 1e3, 3), "steps": 3,
+            "kernel": "mixedLookupSearchKernel (one table entry per k-mer: the table of its own length, or the deeper table)"
+                      if mixed_lookup_chosen else "orderedSearchKernel (16-byte records)",
+            "kernel_ms": round(float(np.mean([(f if mixed_lookup_chosen else k) for f, k in mlog])), 3) if mlog else None,
+            "length_tables_bytes": lt_bytes, "length_tables_build_s": round(lt_s, 3),
+            "kmers_with_hits": int((m_counts != 0).sum().item()),
+            "digests": {"counts": mdig, "status": "match" if committed else "unknown"}}
+        del m_counts, m_chars, m_off, d_mixed
+
     # ---- strong-scaling proxy on ONE GPU: the contiguous shards N ranks would hold of this batch (configs[2]: "query
     # batch sharded 1 -> 8"), each timed by itself with the same step; a rank of an N-GPU run does exactly this work on
     # its own replica, with nothing exchanged (ref src/AwFmParallelSearch.c:103-129: 8-query blocks are independent), so
@@ -1449,6 +1498,9 @@ def main():
         if secondary.get("with_lf_walk") and "ms_per_step" in secondary["with_lf_walk"]:
             config["planted_lf_walk_ms_per_step"] = secondary["with_lf_walk"]["ms_per_step"]
         config["planted_dense_form_ms_per_step"] = secondary["dense_form"]["ms_per_step"]
+        if "mixed_lengths" in secondary:
+            config["mixed_lengths_ms_per_step"] = secondary["mixed_lengths"]["ms_per_step"]
+            config["mixed_lengths_value"] = secondary["mixed_lengths"]["value"]
     if clocks:
         config["gpu_clocks"] = clocks
         for name in ("sclk", "mclk", "fclk"):
