@@ -1199,11 +1199,28 @@ enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearch
   const uint64_t numQueries = queryEnd - queryBegin, totalHits = hitEnd - hitBegin;
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
-  if (g->dDenseSa) { /* the full suffix array: expand and gather in one kernel, straight to where the positions go */
+  if (g->dDenseSa && totalHits < 64ull * numQueries) {
+    /* the full suffix array: expand and gather in one kernel, straight to where the positions go */
     hipLaunchKernelGGL(expandHitsKernel<true>, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
                        (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
                        (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
                        (unsigned long long *)outPositions, (const unsigned *)g->dDenseSa);
+    AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+    return AwFmSuccess;
+  }
+  if (g->dDenseSa) {
+    /* long hit lists (a window of 2^28 hits of 8..11-mers is a few thousand k-mers): the expansion is parallel over the
+     * k-mers, and with the gather inside it a wave walks its lists one memory latency at a time -- 2 * 10^6 mixed
+     * 8..30-mers with 5.5 * 10^9 hits: 72 ms fused, 32 ms as two kernels, the second one parallel over the hits */
+    hipLaunchKernelGGL(expandHitsKernel<false>, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
+                       (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
+                       (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
+                       (unsigned long long *)dPositions, (const unsigned *)nullptr);
+    AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+    const unsigned long long blocks = (totalHits + 255ull) / 256ull, resident = (unsigned long long)g->numCUs * 16ull;
+    hipLaunchKernelGGL(denseSaGatherKernel, dim3((unsigned)(blocks < resident ? blocks : resident)), dim3(256), 0, s,
+                       (const unsigned *)g->dDenseSa, (unsigned long long)totalHits, (const unsigned long long *)dPositions,
+                       (unsigned long long *)outPositions, (const unsigned long long *)nullptr);
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
   }

@@ -1400,6 +1400,7 @@ def main():
     # awFmParallelSearchLocate then uploads the image (3.8 GB), builds the pair image and the deeper table, and searches.
     # The image of this run is dropped for it, so this is the last thing the run does with the GPU. ----
     image_bytes, image_deep_k = g.device_bytes, g.deep_seed_k or args.seed_k
+    length_tables_built = g.length_tables  # (bytes, seconds): before the image is released for the first-call leg
     first_call = None
     if e2e is not None and locate and args.e2e_aos_queries:
         import ctypes as C
@@ -1485,7 +1486,7 @@ def main():
                                "dense": "awfmGpuSearchHitsSparse" if narrow_counts else "awfmGpuSearchHits"}[whole.form] if locate
                               else "awfmGpuSearchHits") + (", seed order" if ordered else ", general kernel"),
               "result_format": form_names[whole.form] if locate else "count under every k-mer number"}
-    lt_bytes, lt_s = g.length_tables
+    lt_bytes, lt_s = length_tables_built
     if lt_bytes:  # built by the probe step of a mixed-length batch (awfm_mixed_lookup_kernel.h): device-only, kept with the image
         config["length_tables_bytes"] = lt_bytes
         config["length_tables_build_s"] = round(lt_s, 3)
