@@ -108,6 +108,43 @@ __global__ void __launch_bounds__(kScanThreads)
   if (writeTotal && base <= n - 1 && n - 1 < base + kScanItems) out[n] = running;
 }
 
+/* the same scan of up to kScanSmall elements by ONE workgroup in one launch (16 consecutive elements per thread): the
+ * list of hits of a small batch -- 10^4 entries -- is not worth the three launches of the tiled scan (reduce, scan of the
+ * sums, tiles: 14 us of a 0.44-ms step) */
+constexpr int kScanSmallThreads = 1024, kScanSmallItems = 16, kScanSmall = kScanSmallThreads * kScanSmallItems;
+template <int SOURCE>
+__global__ void __launch_bounds__(kScanSmallThreads)
+    scanSmallKernel(const void *__restrict__ in, unsigned long long n, unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long sWave[kScanSmallThreads / 64];
+  const unsigned long long base = (unsigned long long)threadIdx.x * kScanSmallItems;
+  unsigned long long vals[kScanSmallItems];
+  unsigned long long sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanSmallItems; k++) {
+    vals[k] = base + k < n ? scanInput<SOURCE>(in, base + k) : 0ull;
+    sum += vals[k];
+  }
+  unsigned long long incl = sum;
+  const unsigned lane = threadIdx.x & 63u;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long up = __shfl_up(incl, d, 64);
+    if (lane >= (unsigned)d) incl += up;
+  }
+  if (lane == 63u) sWave[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  unsigned long long running = incl - sum, total = 0;
+  for (unsigned w = 0; w < kScanSmallThreads / 64; w++) {
+    running += w < (threadIdx.x >> 6) ? sWave[w] : 0ull;
+    total += sWave[w];
+  }
+#pragma unroll
+  for (int k = 0; k < kScanSmallItems; k++) {
+    if (base + k < n) out[base + k] = running;
+    running += vals[k];
+  }
+  if (threadIdx.x == 0) out[n] = total;
+}
+
 /* dense device SA construction helpers */
 __global__ void iotaKernel(unsigned long long *out, unsigned long long first, unsigned long long count) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1073,6 +1110,11 @@ template <int SOURCE>
 enum AwFmReturnCode scanRecursive(const void *in, uint64_t n, unsigned long long *out, unsigned long long *scratch,
                                   hipStream_t s) {
   const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
+  if (tiles > 1 && n <= (uint64_t)kScanSmall && !getenv("AWFM_GPU_SCAN_TILED")) {
+    hipLaunchKernelGGL(scanSmallKernel<SOURCE>, dim3(1), dim3(kScanSmallThreads), 0, s, in, (unsigned long long)n, out);
+    AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+    return AwFmSuccess;
+  }
   if (tiles <= 1) {
     hipLaunchKernelGGL(scanTileKernel<SOURCE>, dim3(1), dim3(kScanThreads), 0, s, in, (unsigned long long)n,
                        (const unsigned long long *)nullptr, out, 1);
