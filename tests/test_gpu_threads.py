@@ -142,3 +142,67 @@ def test_callers_on_their_own_streams_share_one_image(oracle, awfm, require_gpu,
         assert not job["errors"], f"caller {i}: {job['errors']}"
     g.destroy()
     ix.dealloc()
+
+
+def test_mixed_length_callers_race_for_the_length_tables(oracle, awfm, require_gpu, monkeypatch):
+    """three threads on their own streams send mixed-length batches to one fresh image at once: the first of them builds the
+    tables per k-mer length (under the image's lock, while the others wait for it), then all three run the lookup-first
+    kernel side by side -- two scratch slots, the third queues -- for several rounds; counts and hit ranges of every
+    caller against the oracle"""
+    import torch
+    monkeypatch.setenv("AWFM_GPU_MIXED_LOOKUP", "1")
+    n = 300000
+    txt = synth.text(n + 9, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(12)
+    assert g.length_tables[0] == 0
+    dev = torch.device("cuda")
+    jobs = []
+    for c in range(3):
+        Q = 50000 + 3331 * c
+        chars, offsets = synth.mixed_queries(600 + c, Q, txt, synth.DNA_ALPHABET, 1 + c, 34)
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+        jobs.append({"Q": Q, "chars": chars, "offsets": offsets, "sp": sp, "ep": ep, "cnt": cnt, "errors": []})
+    start = threading.Barrier(3)
+
+    def work(job):
+        try:
+            Q = job["Q"]
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                d_chars = torch.from_numpy(np.concatenate([job["chars"], np.zeros(8, np.uint8)])).to(dev)
+                d_off = torch.from_numpy(job["offsets"].view(np.int64)).to(dev)
+                d_ranges = torch.zeros(Q * 2, dtype=torch.int64, device=dev)
+                d_counts = torch.zeros(Q, dtype=torch.int32, device=dev)
+            stream.synchronize()
+            start.wait(60)
+            for _ in range(8):
+                g.search_hits(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, d_ranges.data_ptr(), d_counts.data_ptr(), stream.cuda_stream)
+                stream.synchronize()
+                counts = d_counts.cpu().numpy().view(np.uint32)
+                ranges = d_ranges.cpu().numpy().view(np.uint64).reshape(Q, 2)
+                hit = job["cnt"] > 0
+                if not np.array_equal(counts, job["cnt"]):
+                    raise AssertionError("counts differ from the oracle")
+                if not (np.array_equal(ranges[hit, 0], job["sp"][hit]) and np.array_equal(ranges[hit, 1], job["ep"][hit])):
+                    raise AssertionError("ranges of the hits differ from the oracle")
+                d_counts.fill_(9)
+                d_ranges.fill_(9)
+                stream.synchronize()
+        except Exception as e:  # noqa: BLE001
+            job["errors"].append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(job,)) for job in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not any(t.is_alive() for t in threads), "a caller did not come back"
+    for c, job in enumerate(jobs):
+        assert not job["errors"], (c, job["errors"])
+    assert g.length_tables[0] == 8 * (4 ** 12 - 4) // 3 and g.last_ordered_kernel_is_lookup()
+    g.destroy()
+    ix.dealloc()
