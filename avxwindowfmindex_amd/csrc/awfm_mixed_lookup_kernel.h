@@ -14,8 +14,8 @@
  * (k-mer tw + 64 i + lane of the wave's 256: neighbouring lanes read neighbouring offsets and characters), has their four
  * entries in flight at once, stores the results the entries settle, and the wave takes the survivors through their steps
  * out of LDS, 16 at a time (4 lanes per k-mer: pair steps, flagged blocks and the odd step through the one-letter image).
- * What it does not cover -- k-mers with a character that is not a,c,g,t,u, no characters or more than 32, survivors beyond
- * the 64 slots of a round -- goes to a list the general kernel searches afterwards (INDIRECT).  A sample decides, on the
+ * What it does not cover -- k-mers with a character that is not a,c,g,t,u, no characters or more than 32 -- goes to a list
+ * the general kernel searches afterwards (INDIRECT; a wave has a slot for every k-mer of its round, so no survivor does).  A sample decides, on the
  * device, between this kernel and the 16-byte-record path for the whole batch (lookupChosen).
  *
  * Results: every k-mer with hits gets the range the reference reaches for it (the tables hold the ranges of the reference's
@@ -30,7 +30,7 @@
 
 namespace {
 
-constexpr unsigned kMixedSlots = 192; /* survivors a wave takes through the steps per round */
+constexpr unsigned kMixedSlots = 256; /* survivors a wave takes through the steps per round: as many as the round has k-mers */
 
 /* decodeKmer (awfm_ordered_kernel.h) for a k-mer that is followed by at least 48 bytes of the character array: two 16-byte
  * loads and a dword from the aligned-down start instead of up to nine conditional dword loads, and the any-character test of
