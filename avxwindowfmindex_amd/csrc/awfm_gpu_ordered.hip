@@ -723,11 +723,13 @@ static const uint2 *ensureLengthTables(AwFmGpuIndex *g) {
  * a sample of the batch that stays on the device: both front ends are launched, the one it does not choose returns at once. */
 static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off, uint32_t fixedLength,
                               unsigned depth, const ulonglong2 *table, unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts,
-                              bool rangesOfHitsOnly, const OrderTouch *touch, const SparseOut *sparse) {
+                              bool rangesOfHitsOnly, const OrderTouch *touch, const SparseOut *sparse, bool lookupAlways = false) {
   constexpr unsigned bins = (1u << kBucketBitsMax) + 1u, binsPad = (bins + 3u) & ~3u;
   const size_t histAt = kOrderCounterBytes, cursorsAt = histAt + alignUp256(bins * 4u), startAt = cursorsAt + alignUp256(bins * 4u);
-  const size_t inAt = startAt + alignUp256((bins + 1u) * 4u), outAt = inAt + alignUp256(nq * sizeof(QueryRec));
-  const size_t leftAt = outAt + alignUp256(nq * sizeof(QueryRec));
+  /* (lookupAlways: a batch below the size from which ordering pays -- the lookup kernel or nothing: no records) */
+  const size_t recordBytes = lookupAlways ? 0u : alignUp256(nq * sizeof(QueryRec));
+  const size_t inAt = startAt + alignUp256((bins + 1u) * 4u), outAt = inAt + recordBytes;
+  const size_t leftAt = outAt + recordBytes;
   /* the sample: 16384 k-mers at a fixed stride; the lookup kernel is chosen when fewer than THREE quarters of them are still
    * alive after their table entry (lookupChosen compares 4 x alive with the number it is given: 3 x the sample's size) --
    * the records of the other path cost a mixed-length batch 2.5 ms per 10^8 before anything is searched, and its search
@@ -738,10 +740,11 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   const bool mixedCapable = off && !touch && !g->amino && awfmImageNarrow(g) && g->dev.deepSeed && g->dev.deepNarrow != 0u &&
                             g->dev.deepK >= 2u && g->dev.deepK <= 16u && g->dev.seedK < g->dev.deepK &&
                             !(sparse && sparse->kmers && !sparse->count) /* results in search order owe an entry to every k-mer */;
-  const bool mixedForced = mixedCapable && mixedEnv && atoi(mixedEnv) == 1;
+  const bool mixedForced = mixedCapable && (lookupAlways || (mixedEnv && atoi(mixedEnv) == 1));
   const bool mixedWanted = mixedCapable && (mixedEnv ? atoi(mixedEnv) != 0 : nq >= (1ull << 20)) && (mixedForced || nq >= kSamples);
   const uint2 *lengthTable = mixedWanted ? ensureLengthTables(g) : nullptr;
   const bool lookupOnly = lengthTable && mixedForced, bySample = lengthTable && !mixedForced;
+  if (lookupAlways && !lengthTable) return 0; /* (no tables after all: the general kernel) */
   const size_t total = leftAt + (lengthTable ? alignUp256(nq * 8u) : 0u);
   /* in the counter block, beyond the ticket counters (which end at 65792): the leftover count, the sample's count, the
    * survivor counters (kFusedCounters words a line apart) */
@@ -859,7 +862,22 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   unsigned depth = 0;
   const ulonglong2 *table = nullptr;
   if (packed && off) return 0;
-  if (!orderedApplies(g, off != nullptr, fixedLength, nq, &depth, &table)) return 0;
+  bool lookupAlways = false;
+  if (!orderedApplies(g, off != nullptr, fixedLength, nq, &depth, &table)) {
+    /* Mixed-length batches below the size from which ordering pays (2^23 k-mers) on an image that has, or can have, its
+     * tables per k-mer length: mixedLookupSearchKernel reads what the general kernel reads of the deeper table and of the
+     * blocks -- 256 entries per wave at once instead of 16 chains -- and one entry where that kernel walks a short k-mer
+     * up from a letter range.  From 2^20 k-mers (below that the general kernel's single launch wins);
+     * $AWFM_GPU_MIXED_LOOKUP=0 and a seed-order path that is switched off keep the general kernel. */
+    int mode = g->orderMode;
+    if (mode < 0)
+      if (const char *env = getenv("AWFM_GPU_ORDERED")) mode = atoi(env) != 0;
+    const char *mixedEnv = getenv("AWFM_GPU_MIXED_LOOKUP");
+    lookupAlways = off && !touch && mode != 0 && !g->amino && nq < 0xFFFFFFFFull && awfmImageNarrow(g) && g->dev.deepSeed &&
+                   g->dev.deepNarrow != 0u && g->dev.deepK >= 2u && g->dev.deepK <= 16u && g->dev.seedK < g->dev.deepK &&
+                   !(sparse && sparse->kmers && !sparse->count) && (mixedEnv ? atoi(mixedEnv) != 0 : nq >= (1ull << 20));
+    if (!lookupAlways) return 0;
+  }
 
   std::lock_guard<std::mutex> lock(g->orderMutex);
   g->orderLookup = 0;
@@ -881,6 +899,10 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
     } else {
       (void)hipGetLastError();
     }
+  }
+  if (lookupAlways) {
+    if (recordBytesOut) *recordBytesOut = 0u;
+    return wideBucketedSearch(g, s, dChars, off, fixedLength, 0u, nullptr, nq, rng, dCounts, rangesOfHitsOnly, nullptr, sparse, true);
   }
   /* 8-byte records: fixed-length batches of short enough k-mers */
   /* fixed-length batches whose records fit 8 bytes: counted and partitioned by the kernels of awfm_ordered_kernel.h

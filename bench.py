@@ -741,6 +741,8 @@ def main():
     kernel_log = g.ordered_kernel_log() if ordered else []
     assert not ordered or len(kernel_log) == min(args.steps, 1024), "the library logged another number of searches than were timed"
     lookup_first = bool(ordered and g.last_ordered_kernel_is_lookup())  # the dominant kernel of every step was encodeLookupKernel
+    # (a mixed-length batch below the seed-order size on an image with its tables per k-mer length: the lookup kernel alone)
+    small_mixed_lookup = bool(d_offsets is not None and not ordered and not amino and g.length_tables[0] and g.last_ordered_kernel_is_lookup())
     lookup_kept = g.last_ordered_kept() if lookup_first else 0  # before any other search re-uses the scratch
     amino_looked_up = bool(amino_lookup and whole.ordered and g.last_ordered_kernel_is_lookup())  # aminoLookupSearchKernel did the timed steps (its sample said so)
     ordered_ms = [(f if lookup_first else k) for f, k in kernel_log]
@@ -1484,7 +1486,7 @@ def main():
               "device_dense_sa": dense_sa_default, "device_dense_sa_build_s": round(dense_s, 2),
               "search_path": ({"order": "awfmGpuSearchHitsInOrder", "list": "awfmGpuSearchHitsCompact",
                                "dense": "awfmGpuSearchHitsSparse" if narrow_counts else "awfmGpuSearchHits"}[whole.form] if locate
-                              else "awfmGpuSearchHits") + (", seed order" if ordered else ", general kernel"),
+                              else "awfmGpuSearchHits") + (", seed order" if ordered else ", mixedLookupSearchKernel" if small_mixed_lookup else ", general kernel"),
               "result_format": form_names[whole.form] if locate else "count under every k-mer number"}
     lt_bytes, lt_s = length_tables_built
     if lt_bytes:  # built by the probe step of a mixed-length batch (awfm_mixed_lookup_kernel.h): device-only, kept with the image

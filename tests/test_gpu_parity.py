@@ -1211,10 +1211,13 @@ def test_mixed_length_lookup_first_keeps_hits_bit_identical(oracle, awfm, requir
     ix.dealloc()
 
 
-def test_mixed_length_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, monkeypatch):
+@pytest.mark.parametrize("seed_order", [True, False])
+def test_mixed_length_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, monkeypatch, seed_order):
     """Without $AWFM_GPU_MIXED_LOOKUP a mixed-length batch of 2^20 k-mers or more is sampled: random 8..30-mers against a
     small text mostly end at their table entry -> mixedLookupSearchKernel; k-mers drawn from the text, most of them longer
-    than the deeper table's, survive it -> the 16-byte-record path as before.  Counts against the oracle either way."""
+    than the deeper table's, survive it -> the 16-byte-record path as before.  Counts against the oracle either way.
+    seed_order False: the batch is below the size from which the seed-order path applies (not forced on here) -- there is
+    no other front end to choose, the lookup kernel takes both batches."""
     import torch
     monkeypatch.delenv("AWFM_GPU_MIXED_LOOKUP", raising=False)
     n, Q = 300000, (1 << 20) + 77
@@ -1222,8 +1225,10 @@ def test_mixed_length_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, aw
     ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
     oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
     g = awfm.GpuIndex(ix)
-    g.set_ordered(1)
+    if seed_order:
+        g.set_ordered(1)
     g.set_deep_seed(12)
+    assert g.search_hits_is_ordered(True, 0, Q) == seed_order
     dev = torch.device("cuda")
     rng = np.random.default_rng(5)
     lengths = rng.integers(8, 31, Q)
@@ -1244,8 +1249,15 @@ def test_mixed_length_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, aw
         d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
         g.search_hits(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, 0, d_counts.data_ptr())
         torch.cuda.synchronize()
-        assert g.last_ordered_kernel_is_lookup() == (name == "random"), name
+        assert g.last_ordered_kernel_is_lookup() == (name == "random" or not seed_order), name
         assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt), name
+        if not seed_order and name == "planted":  # ... unless told otherwise: the general kernel, same counts
+            monkeypatch.setenv("AWFM_GPU_MIXED_LOOKUP", "0")
+            d_counts.fill_(7)
+            g.search_hits(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, 0, d_counts.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt), "general kernel"
+            monkeypatch.delenv("AWFM_GPU_MIXED_LOOKUP")
     g.destroy()
     ix.dealloc()
 
