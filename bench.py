@@ -1007,7 +1007,9 @@ def main():
             torch.cuda.synchronize()
         plain_gbs = alg_bytes / (plain_ms * 1e-3) / 1e9 if plain_ms else None
         roofline = {
-            "bound": "hbm", "kernel": ("aminoLookupSearchKernel" if amino_looked_up else "searchKernel") + f" (device-only table of depth {had_deep})",
+            "bound": "hbm", "kernel": ("aminoLookupSearchKernel" if amino_looked_up else
+                                       "mixedLookupSearchKernel (priced by the general kernel's reads of the same batch: an upper bound)"
+                                       if small_mixed_lookup else "searchKernel") + f" (device-only table of depth {had_deep})",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "kernel_ms": round(search_ms, 3), "basis": "executed_reads",
