@@ -214,6 +214,64 @@ __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const un
     }
   }
 }
+/* The same for windows of LONG hit lists (a window of 2^28 hits of 8..11-mers is a few thousand k-mers, 5 * 10^4 hits each):
+ * parallel over the HITS.  A workgroup takes chunks of kLongChunk hits of the window, finds the k-mer the chunk begins in
+ * (one binary search over the hit offsets per chunk), and walks the k-mers from there, their offsets and first positions
+ * staged 64 at a time: every k-mer's part of the chunk is copied by all 256 threads, positions[h - hitBegin] =
+ * dense[sp + h - from].  expandHitsKernel<true> gives a k-mer to a wave, which walks a long list one memory latency at a
+ * time (2 * 10^6 mixed 8..30-mers, 5.5 * 10^9 hits: 72 ms); expandHitsKernel<false> + denseSaGatherKernel are parallel where
+ * it matters but move every position three times (154 GB: 32 ms); this kernel reads 4 and writes 8 bytes per hit. */
+constexpr unsigned kLongChunk = 16384, kLongStage = 64;
+__global__ void __launch_bounds__(256)
+    expandLongKernel(const ulonglong2 *__restrict__ ranges, const unsigned long long *__restrict__ hitOffsets,
+                     const unsigned long long firstQuery, const unsigned long long n, const unsigned long long hitBegin,
+                     const unsigned long long hitEnd, unsigned long long *__restrict__ positions, const unsigned *__restrict__ dense) {
+  __shared__ unsigned long long sOff[kLongStage + 1], sSp[kLongStage], sFirst;
+  const unsigned tid = threadIdx.x;
+  const unsigned long long chunks = (hitEnd - hitBegin + kLongChunk - 1ull) / kLongChunk;
+  for (unsigned long long chunk = blockIdx.x; chunk < chunks; chunk += gridDim.x) {
+    const unsigned long long c0 = hitBegin + chunk * kLongChunk, c1 = c0 + kLongChunk < hitEnd ? c0 + kLongChunk : hitEnd;
+    if (tid == 0) { /* the last k-mer of the window whose list begins at or before the chunk (the first one when none does) */
+      unsigned long long lo = 0, hi = n;
+      while (hi - lo > 1ull) {
+        const unsigned long long mid = (lo + hi) >> 1;
+        if (hitOffsets[firstQuery + mid] <= c0) lo = mid;
+        else hi = mid;
+      }
+      sFirst = lo;
+    }
+    __syncthreads();
+    bool done = false; /* uniform */
+    for (unsigned long long qb = sFirst; qb < n && !done; qb += kLongStage) {
+      if (tid <= kLongStage) sOff[tid] = hitOffsets[firstQuery + (qb + tid < n ? qb + tid : n)];
+      if (tid < kLongStage) sSp[tid] = qb + tid < n ? ranges[firstQuery + qb + tid].x : 0ull;
+      __syncthreads();
+      for (unsigned i = 0; i < kLongStage && qb + i < n; i++) {
+        const unsigned long long from = sOff[i], to = sOff[i + 1];
+        if (from >= c1) {
+          done = true;
+          break;
+        }
+        const unsigned long long lo = from > c0 ? from : c0, hi = to < c1 ? to : c1;
+        if (lo < hi) {
+          const unsigned long long src = sSp[i] + (lo - from) - lo; /* dense[src + h] for hit h */
+          unsigned long long h = lo + tid;
+          for (; h + 768ull < hi; h += 1024ull) { /* four gathers of the thread in flight */
+            const unsigned a = dense[src + h], b = dense[src + h + 256ull], c = dense[src + h + 512ull], d = dense[src + h + 768ull];
+            positions[h - hitBegin] = a;
+            positions[h + 256ull - hitBegin] = b;
+            positions[h + 512ull - hitBegin] = c;
+            positions[h + 768ull - hitBegin] = d;
+          }
+          for (; h < hi; h += 256ull) positions[h - hitBegin] = dense[src + h];
+        }
+      }
+      if (sOff[kLongStage] >= c1) done = true;
+      __syncthreads(); /* the stage is written again */
+    }
+    __syncthreads(); /* sFirst is written again */
+  }
+}
 }  // namespace
 
 /* ------------------------------------------------------------------ host side */
@@ -1250,10 +1308,20 @@ enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearch
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
   }
+  if (g->dDenseSa && !getenv("AWFM_GPU_LONG_LISTS_TWO_KERNELS")) {
+    /* long hit lists (64 hits per k-mer and more on average): parallel over the hits (expandLongKernel) */
+    const unsigned long long chunks = (totalHits + kLongChunk - 1ull) / kLongChunk, resident = (unsigned long long)g->numCUs * 8ull;
+    hipLaunchKernelGGL(expandLongKernel, dim3((unsigned)(chunks < resident ? chunks : resident)), dim3(256), 0, s,
+                       (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
+                       (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
+                       (unsigned long long *)outPositions, (const unsigned *)g->dDenseSa);
+    AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+    return AwFmSuccess;
+  }
   if (g->dDenseSa) {
-    /* long hit lists (a window of 2^28 hits of 8..11-mers is a few thousand k-mers): the expansion is parallel over the
-     * k-mers, and with the gather inside it a wave walks its lists one memory latency at a time -- 2 * 10^6 mixed
-     * 8..30-mers with 5.5 * 10^9 hits: 72 ms fused, 32 ms as two kernels, the second one parallel over the hits */
+    /* ($AWFM_GPU_LONG_LISTS_TWO_KERNELS: the expansion parallel over the k-mers, then the gather parallel over the hits --
+     * every position moved three times; 2 * 10^6 mixed 8..30-mers with 5.5 * 10^9 hits: 32 ms; with the gather inside the
+     * k-mer-parallel expansion a wave walks its lists one memory latency at a time: 72 ms) */
     hipLaunchKernelGGL(expandHitsKernel<false>, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
                        (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
                        (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,

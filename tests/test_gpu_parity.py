@@ -113,6 +113,58 @@ def test_repetitive_text_many_hits(oracle, awfm, require_gpu, wide):
         ix.dealloc()
 
 
+@pytest.mark.parametrize("two_kernels", [False, True])
+def test_long_hit_lists_located_in_windows_through_the_full_suffix_array(oracle, awfm, require_gpu, monkeypatch, two_kernels):
+    """windows of LONG hit lists (64 hits per k-mer and more) on an image with the full suffix array: expandLongKernel, parallel
+    over the hits -- chunks of 16384 hits that begin and end inside a list, lists of a few hits and k-mers without hits
+    between lists of 10^4, windows that begin and end inside a list or hold a single hit, the whole list as one window --
+    against the oracle's positions (and the two-kernel way, $AWFM_GPU_LONG_LISTS_TWO_KERNELS, against the same)"""
+    import torch
+    if two_kernels:
+        monkeypatch.setenv("AWFM_GPU_LONG_LISTS_TWO_KERNELS", "1")
+    rng = np.random.default_rng(11)
+    unit = rng.integers(0, 4, 700)
+    body = np.frombuffer(b"acgt", np.uint8)[np.concatenate([unit] * 120 + [rng.integers(0, 4, 30000)])]
+    txt = np.concatenate([body, np.frombuffer(b"t" * 40, np.uint8)]).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 4)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 4, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_dense_sa(True)
+    kmers = []
+    for i in range(600):  # 1..5-mers (10^3..10^4 hits), windows of the repeat unit (120 hits), random 12-mers (none), a few long ones
+        r = i % 6
+        if r < 3:
+            kmers.append(bytes(np.frombuffer(b"acgt", np.uint8)[rng.integers(0, 4, 1 + (i % 5))]))
+        elif r == 3:
+            at = int(rng.integers(0, 600))
+            kmers.append(txt[at:at + 20].tobytes())
+        elif r == 4:
+            kmers.append(bytes(np.frombuffer(b"acgt", np.uint8)[rng.integers(0, 4, 12)]))
+        else:
+            at = int(rng.integers(84000, 110000))
+            kmers.append(txt[at:at + 25].tobytes())
+    chars, offsets = oracle.pack_queries(kmers)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    total, Q = int(hit_off[-1]), len(kmers)
+    assert total > 64 * Q and (cnt == 0).sum() > 50 and ((cnt > 0) & (cnt < 4)).sum() > 50
+    dev = torch.device("cuda")
+    d_ranges = torch.from_numpy(np.stack([sp, ep], 1).astype(np.uint64).view(np.int64).reshape(-1)).to(dev)
+    d_off = torch.from_numpy(hit_off.view(np.int64)).to(dev)
+    cuts = sorted({0, total, 1, 16384, 16385, 40000, total - 1, total // 2, int(hit_off[7]), int(hit_off[7]) + 3, int(hit_off[300]) - 1})
+    for b, e in list(zip(cuts[:-1], cuts[1:])) + [(0, total), (5, 6)]:
+        qb = int(np.searchsorted(hit_off, b, side="right")) - 1
+        qe = int(np.searchsorted(hit_off, e, side="left"))
+        d_pos = torch.full((e - b + 8,), -1, dtype=torch.int64, device=dev)
+        g.locate_window(d_ranges.data_ptr(), d_off.data_ptr(), max(qb, 0), min(max(qe, qb + 1), Q), b, e, d_pos.data_ptr())
+        torch.cuda.synchronize()
+        got = d_pos.cpu().numpy()
+        assert np.array_equal(got[:e - b].view(np.uint64), pos[b:e]), (b, e)
+        assert np.all(got[e - b:] == -1), "written behind the window"
+    g.destroy()
+    ix.dealloc()
+
+
 def test_drop_in_aos_api(oracle, awfm, require_gpu):
     """awFmCreateKmerSearchList / awFmParallelSearchCount / awFmParallelSearchLocate exactly as a
     reference user calls them (ref test/parallelSearch/parallelSearchTest.c:105-214)"""
