@@ -203,6 +203,19 @@ def test_batch_search_fails_loudly_without_a_gpu(awfm):
     ix.dealloc()
 
 
+def test_gpu_entry_points_reject_null_arguments_without_touching_a_device(awfm):
+    """the flat GPU entry points added for mixed-length batches answer a null image or null buffers with an error code and
+    a message -- no device call, so this runs without a GPU; the reporting accessors of a null image say "nothing"."""
+    import ctypes as C
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    out = (C.c_uint64 * 8)()
+    assert L.awfmGpuMixedLookupLineTally(None, None, None, 0, C.byref(out)) == -4  # AwFmNullPtrError (include/AwFmIndex.h)
+    assert b"awfmGpuMixedLookupLineTally" in L.awfmGpuLastError()
+    assert L.awfmGpuIndexLengthTableBytes(None) == 0 and L.awfmGpuIndexLengthTableBuildSeconds(None) == 0.0
+    assert L.awfmGpuSearchHits(None, None, None, 0, 5, None, None, None) == -4  # AwFmNullPtrError (include/AwFmIndex.h)
+
+
 def test_reference_shared_library_program_relinks_unchanged(awfm, tmp_path):
     """oracle/_ref/sharedLibTest is the reference's own test/sharedLibTest/awfmiTest.c (it includes nothing but
     "AwFmIndex.h"), compiled where it lies against include/AwFmIndex.h and libawfmindex_amd.so by
