@@ -1480,9 +1480,9 @@ def main():
               "device_image_bytes": image_bytes, "device_seed_k": image_deep_k,
               # the deeper table's construction, whoever started it (the library by itself at awfmGpuIndexAcquire, inside
               # index_build_s; or --device-seed-k): wall seconds and the device memory held beyond the table at the peak.  In
-              # this process it follows the GPU index builder, whose ~77 GB of freed temporaries the runtime hands back inside
-              # the first allocation it cannot serve from them -- here the table's (3.7 of the 4.3 s); in a process that reads
-              # its index from a file the same construction takes 0.6 s (scripts/first_call_probe.py; device_seed_rebuild_s here)
+              # this process it follows the GPU index builder; 0.55 s in most runs, 4-6 s in some -- one hipMalloc, the first the
+              # runtime cannot serve from blocks it holds (memory to hand back or to scrub after the process before); in a process
+              # that reads its index from a file the construction takes 0.6 s (scripts/first_call_probe.py; device_seed_rebuild_s here)
               "device_seed_build_s": round(deep_build_s, 2), "device_seed_transient_bytes": int(deep_transient),
               "device_seed_rebuild_s": round(deep_rebuild_s, 2),  # the same construction once more (after roofline_general dropped the table): the allocator has the memory at hand
               "device_dense_sa": dense_sa_default, "device_dense_sa_build_s": round(dense_s, 2),
