@@ -936,6 +936,10 @@ hipError_t awfmGpuLaunchMixedTally(const AwFmGpuIndex *g, hipStream_t s, const v
                                    unsigned long long lengthWords, unsigned long long deepWords, unsigned long long pairWords,
                                    unsigned long long nucWords);
 unsigned awfmGpuMixedTouchLevels(void);
+/* awfm_gpu.hip: the suffix array (32-bit positions, `length` of them) the builder of this thread hands to the image it adopts
+ * next (applyDenseSa takes it; whoever set it frees it when it is still there afterwards) */
+extern thread_local void *awfmGpuDenseSaStash;
+extern thread_local unsigned long long awfmGpuDenseSaStashLength;
 /* awfm_gpu_ordered.hip: rewrites the 8-byte entries {sp, length} of a finished table as {sp, length16 | next16 << 16}
  * (DevIndex::deepNext) and returns the side list of the saturated lengths in *bigOut (one allocation: *numBigOut keys,
  * then as many lengths; NULL when there is none).  Needs the pair image.  1: done; 0: not applicable, nothing was

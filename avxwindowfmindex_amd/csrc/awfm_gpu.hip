@@ -356,7 +356,8 @@ void fillDevIndex(AwFmGpuIndex *g, const struct AwFmIndex *index, unsigned super
 
 namespace {
 enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions,
-                                 hipStream_t s, unsigned long long *out = nullptr, const unsigned long long *totalOnDevice = nullptr);
+                                 hipStream_t s, unsigned long long *out = nullptr, const unsigned long long *totalOnDevice = nullptr,
+                                 unsigned stepCap = 0u);
 /* lanes that cooperate on one query: image setting, else $AWFM_GPU_KERNEL (g4|g2|g1), else the default.  A device
  * block has 4 slices, so 4 lanes is the widest group (GROUP8 of the enum maps to it); amino slices are 32 B, 2 lanes
  * per query already hold 64 registers of block data */
@@ -445,7 +446,7 @@ constexpr unsigned kAutoDeepSeedMin = 14, kAutoDeepSeedMax = 16; /* depths of th
 extern "C" {
 static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g);
 static enum AwFmReturnCode applyPairFromEnv(AwFmGpuIndex *g);
-static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable);
+static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool capped = false);
 static enum AwFmReturnCode applyDenseSaFromEnv(AwFmGpuIndex *g);
 }
 
@@ -1388,7 +1389,7 @@ enum AwFmReturnCode awfmGpuLocateOnDevice(AwFmGpuIndex *g, const struct AwFmSear
 namespace {
 /* LF-walk + sampled-SA kernel over `totalHits` BWT positions stored in dPositions (in place) */
 enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions,
-                                 hipStream_t s, unsigned long long *out, const unsigned long long *totalOnDevice) {
+                                 hipStream_t s, unsigned long long *out, const unsigned long long *totalOnDevice, unsigned stepCap) {
   {
     /* the walk runs at the rate the chip delivers random granules whatever the group width (17.2 / 17.5 / 18.3 ms
      * for g4 / g2 / g1 on 1.0007*10^8 hits); four lanes keep the fewest instructions per step */
@@ -1421,13 +1422,13 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     const unsigned grid__ = gridFor(th, g, walkKernel<false, 4, P2, NR, true>, walkThreads(true) / 4, pairLds, walkThreads(true)); \
     /* a short hit list: batches of 4 instead of 16 hits per lane group, when the grid has a group for every one */         \
     if (th <= (unsigned long long)grid__ * (walkThreads(true) / 4) * 4ull)                                                   \
-      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true, 1u>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos, totalOnDevice); \
+      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true, 1u>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos, totalOnDevice, stepCap); \
     else                                                                                                                     \
-      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos, totalOnDevice); \
+      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos, totalOnDevice, stepCap); \
   } while (0)
 #define AWFM_LOC3(AM, GG, P2, NR)                                                                                  \
   hipLaunchKernelGGL((walkKernel<AM, GG, P2, NR>), dim3(gridFor(th, g, walkKernel<AM, GG, P2, NR>, kThreads / GG)), \
-                     dim3(kThreads), 0, s, g->dev, th, pos, totalOnDevice)
+                     dim3(kThreads), 0, s, g->dev, th, pos, totalOnDevice, stepCap)
 #define AWFM_LOC(AM, GG)                                      \
   do {                                                        \
     if (pow2 && narrow) AWFM_LOC3(AM, GG, true, true);        \
@@ -1482,7 +1483,31 @@ enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable) {
 }
 
 /* the caller holds whatever locks the image needs (none for an image nobody else has a pointer to yet) */
-static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable) {
+namespace {
+/* how many entries of the construction were given up (walkKernel's stepCap) */
+__global__ void __launch_bounds__(256) countGaveUpKernel(const unsigned *__restrict__ dense, unsigned long long n, unsigned long long *__restrict__ out) {
+  unsigned long long mine = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull)
+    mine += dense[i] == (unsigned)kWalkGaveUp ? 1ull : 0ull;
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(out, mine);
+}
+}  // namespace
+
+/* the full suffix array an index builder of this thread still holds (awfm_gpu_build.hip: 32-bit positions of the text it has
+ * just sorted): the image it adopts next takes it as it is instead of walking every position to its sample */
+extern "C++" {
+thread_local void *awfmGpuDenseSaStash = nullptr;
+thread_local unsigned long long awfmGpuDenseSaStashLength = 0;
+}
+
+/* capped (the AUTOMATIC construction): a position that has not reached a sample after 32 x ratio LF steps (a random walk is
+ * that long once in e^32 positions) is given up, and an array with such entries is dropped -- the image then locates by
+ * walking, as the reference does.  A text with R long runs of one letter, R a multiple of the ratio (a genome's runs of N),
+ * otherwise costs the construction 10^5..10^7 steps for every position inside a run: 566 s instead of 0.3 for the
+ * genome-shaped 3.1 Gbp text of bench.py --text repetitive.  A construction that was asked for (awfmGpuIndexSetDenseSa,
+ * $AWFM_GPU_DENSE_SA=1) walks every position to the end. */
+static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool capped) {
   (void)hipDeviceSynchronize();
   if (g->dDenseSa) (void)hipFree(g->dDenseSa);
   g->dDenseSa = nullptr;
@@ -1492,6 +1517,13 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable) {
   if (n >= (1ull << 32)) {
     setError("awfmGpuIndexSetDenseSa: 32-bit entries need bwtLength < 2^32");
     return AwFmUnsupportedVersionError;
+  }
+  if (awfmGpuDenseSaStash && awfmGpuDenseSaStashLength == n) { /* this thread's builder hands its array over */
+    g->dDenseSa = awfmGpuDenseSaStash;
+    g->denseSaBytes = n * 4;
+    awfmGpuDenseSaStash = nullptr;
+    awfmGpuDenseSaStashLength = 0;
+    return AwFmSuccess;
   }
   unsigned *dense = nullptr;
   unsigned long long *chunkBuf = nullptr;
@@ -1506,11 +1538,27 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable) {
   for (unsigned long long first = 0; first < n && rc == AwFmSuccess; first += chunk) {
     const unsigned long long count = n - first < chunk ? n - first : chunk;
     hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, first, count);
-    rc = launchLocate(g, count, chunkBuf, (hipStream_t)0);
+    rc = launchLocate(g, count, chunkBuf, (hipStream_t)0, nullptr, nullptr, capped ? 32u * g->dev.saRatio : 0u);
     hipLaunchKernelGGL(narrowKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, count, dense + first);
     if (hipGetLastError() != hipSuccess) rc = AwFmGeneralFailure;
   }
   if (hipDeviceSynchronize() != hipSuccess) rc = AwFmGeneralFailure;
+  if (rc == AwFmSuccess && capped) {
+    unsigned long long gaveUp = 0;
+    if (hipMemset(chunkBuf, 0, 8) != hipSuccess) rc = AwFmGeneralFailure;
+    if (rc == AwFmSuccess) {
+      hipLaunchKernelGGL(countGaveUpKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const unsigned *)dense, n, chunkBuf);
+      if (hipGetLastError() != hipSuccess || hipMemcpy(&gaveUp, chunkBuf, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
+    }
+    if (rc == AwFmSuccess && gaveUp != 0) {
+      if (getenv("AWFM_VERBOSE"))
+        fprintf(stderr, "[awfm full suffix array] %llu of %llu positions not at a sample after %u LF steps: no full array, locates walk\n",
+                gaveUp, n, 32u * g->dev.saRatio);
+      (void)hipFree(chunkBuf);
+      (void)hipFree(dense);
+      return AwFmSuccess;
+    }
+  }
   (void)hipFree(chunkBuf);
   if (rc != AwFmSuccess) {
     (void)hipFree(dense);
@@ -1530,20 +1578,24 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable) {
  * a small batch (60 us) is gone.  Positions are those of the walk (it wrote them); the host index, its sampled array
  * and the .awfmi file are untouched. */
 static enum AwFmReturnCode applyDenseSaFromEnv(AwFmGpuIndex *g) {
-  bool want = false;
-  if (const char *env = getenv("AWFM_GPU_DENSE_SA")) {
+  bool want = false, automatic = false;
+  const char *env = getenv("AWFM_GPU_DENSE_SA");
+  if (env && !strcmp(env, "auto")) { /* the automatic construction whatever the image's size (tests) */
+    want = automatic = g->dev.saRatio > 1u;
+  } else if (env) {
     want = atoi(env) != 0;
   } else if (g->dev.bwtLength >= (1ull << 28) && g->dev.bwtLength < (1ull << 32) && g->dev.saRatio > 1u) {
     size_t freeBytes = 0, totalBytes = 0;
     DeviceGuard guard(g->device);
     if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) want = freeBytes / 4u >= g->dev.bwtLength * 4ull + (1ull << 31);
     else (void)hipGetLastError();
+    automatic = true;
   }
   if (!want || g->dev.bwtLength >= (1ull << 32)) return AwFmSuccess;
   DeviceGuard guard(g->device);
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
-  const enum AwFmReturnCode rc = applyDenseSa(g, true);
+  const enum AwFmReturnCode rc = applyDenseSa(g, true, automatic);
   clock_gettime(CLOCK_MONOTONIC, &t1);
   g->denseSaBuildSeconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
   return rc;

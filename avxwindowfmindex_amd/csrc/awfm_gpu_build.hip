@@ -1062,7 +1062,8 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
               : launchPackSampledSa<u32>(dSa.p, samples, ratio, width, saWords, dPacked.as<u64>()));
   }
   STEP_HIP(hipDeviceSynchronize());
-  dSa.reset();
+  /* (32-bit positions: the array is kept for the image this index gets below, which takes it as its full suffix array) */
+  if (wide) dSa.reset();
 
   /* 5. download the reference-layout arrays */
   STEP_HIP(hipMemcpy(ix->bwtBlockList.asNucleotide, dRef.p, numBlocks * refWords * 8, hipMemcpyDeviceToHost));
@@ -1079,8 +1080,19 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
 
   /* keep the device image for awFmParallelSearch* */
   const uint64_t deviceBytes = awfmDeviceBlocks(n) * awfmDeviceBlockBytes(amino) + awfmSuperBytes(n, amino, superShift) + seedLen * 16 + saWords * 8;
+  if (dSa.p && config->suffixArrayCompressionRatio > 1) { /* hand-over: see awfm_device.h */
+    awfmGpuDenseSaStash = dSa.release();
+    awfmGpuDenseSaStashLength = n;
+  } else {
+    dSa.reset();
+  }
   AwFmGpuIndex *g = awfmGpuIndexAdopt(ix, device, dBlocks.release(), dSuper.release(), superShift, dSeedA.release(), dPacked.release(),
                                       dPrefix.release(), sentinelPos, deviceBytes);
+  if (awfmGpuDenseSaStash) { /* the image did not want a full suffix array */
+    (void)hipFree(awfmGpuDenseSaStash);
+    awfmGpuDenseSaStash = nullptr;
+    awfmGpuDenseSaStashLength = 0;
+  }
   awfmGpuIndexRegister(ix, g);
 
   enum AwFmReturnCode rc = AwFmFileWriteOkay;

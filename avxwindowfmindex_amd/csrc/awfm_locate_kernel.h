@@ -27,6 +27,7 @@
 namespace {
 
 /* in-place hand-over between the two kernels: bit 63 set, steps in bits 62..40, sample index in 39..0 */
+constexpr unsigned long long kWalkGaveUp = 0xFFFFFFFFull; /* (untagged: finishKernel passes it on; no position of a 32-bit image) */
 constexpr unsigned long long kWalkTag = 1ull << 63;
 constexpr unsigned kWalkStepBits = 23;
 constexpr unsigned long long kWalkSampleMask = (1ull << 40) - 1ull;
@@ -63,7 +64,7 @@ constexpr int walkThreads(bool pair) { return pair ? 512 : kThreads; }
 template <bool AMINO, int G, bool POW2, bool NARROW, bool PAIR = false, unsigned PERLANE = 4u>
 __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80)))
     walkKernel(const DevIndex ix, unsigned long long totalHits, unsigned long long *__restrict__ positions,
-               const unsigned long long *__restrict__ totalOnDevice = nullptr) {
+               const unsigned long long *__restrict__ totalOnDevice = nullptr, const unsigned stepCap = 0u) {
   static_assert(!PAIR || (!AMINO && G == 4), "pair steps: nucleotide images, 4 lanes per hit");
   /* the number of hits may still be on the device when the kernel is launched (awfmGpuLocateOnDevice: the total of the
    * scan, never read by the host); totalHits is then the capacity of `positions` */
@@ -92,7 +93,11 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
   const unsigned firstSlice = gl * S;
   const unsigned long long numGroups = (unsigned long long)gridDim.x * kGroups;
   const pos_t ratio = (pos_t)ix.saRatio;
-  const unsigned long long maxSteps = (1ull << kWalkStepBits) - 1ull;
+  /* stepCap (the construction of the full suffix array, awfm_gpu.hip): a position that has not reached a sample after so
+   * many steps is given up -- kWalkGaveUp instead of a position -- rather than followed for up to 2^23 steps: in a text
+   * with R long runs of one letter the suffixes inside the runs map, LF step by LF step, R places further in the suffix
+   * array, and with R a multiple of the sampling ratio they never meet a sample until a run ends */
+  const unsigned long long maxSteps = stepCap ? (unsigned long long)stepCap : (1ull << kWalkStepBits) - 1ull;
 
   /* A group works through batches of 4*G consecutive hits (lane j holds hits 4j..4j+3 of the batch, 32 B):
    * one coalesced read brings a batch in, the hand-over values replace the BWT positions in the registers,
@@ -167,7 +172,7 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
       /* hand the hit over (or, after 2^23-1 steps, which only a corrupt index reaches, finish it here) */
       const unsigned long long sample = POW2 ? (unsigned long long)(p >> ix.saShift) : (unsigned long long)(p / ratio);
       const unsigned long long result = sampled ? (kWalkTag | ((unsigned long long)steps << 40) | (sample & kWalkSampleMask))
-                                                : finishPosition(ix, sample, steps);
+                                                : (stepCap ? kWalkGaveUp : finishPosition(ix, sample, steps));
       const bool owner = gl == j / kPerLane;
       const unsigned k = j % kPerLane;
       slot.a = owner && k == 0u ? result : slot.a;

@@ -165,6 +165,49 @@ def test_long_hit_lists_located_in_windows_through_the_full_suffix_array(oracle,
     ix.dealloc()
 
 
+def test_full_suffix_array_of_a_text_with_long_runs(oracle, awfm, require_gpu, monkeypatch):
+    """A text with R long runs of one letter, R a multiple of the sampling ratio (a genome's runs of N): the suffixes inside
+    the runs move R places per LF step and never meet a sample until a run ends.  The AUTOMATIC construction of the full
+    suffix array gives such positions up after 32 x ratio steps and drops the array (the locate then walks, as the reference
+    does); a construction that was asked for walks to the end; an index built on the GPU hands its own suffix array to its
+    image and walks nothing.  Positions against the oracle in all three cases."""
+    import torch
+    n, runs, run_len, ratio = 160000, 8, 3000, 8
+    txt = synth.text(n + 71, n, synth.DNA_ALPHABET).copy()
+    starts = [5000 + i * 19000 for i in range(runs)]
+    for at in starts:
+        txt[at:at + run_len] = ord("n")
+    kmers = [txt[at + run_len: at + run_len + 14].tobytes() for at in starts]  # right behind a run: the walk enters it
+    kmers += [txt[at - 14: at].tobytes() for at in starts] + [bytes(r) for r in synth.planted_queries(72, 400, 16, txt)]
+    kmers = [k for k in kmers if b"n" not in k]
+    chars, offsets = oracle.pack_queries(kmers)
+
+    def check(ix, expect_dense):
+        oi = oracle.Index.wrap(oracle.DNA, ratio, 6, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets)
+        hit_off, pos, _ = oi.batch_locate(sp, ep)
+        g = awfm.GpuIndex(ix, acquire=True)
+        assert g.has_dense_sa == expect_dense
+        ranges, ho, p = g.locate_host(chars, offsets)
+        assert np.array_equal(ho, hit_off) and np.array_equal(p, pos) and len(pos) >= len(kmers)
+        return g
+
+    monkeypatch.setenv("AWFM_GPU_DENSE_SA", "auto")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, 6)
+    check(ix, False)  # given up: 7/8 of the positions inside the runs
+    ix.dealloc()
+    monkeypatch.setenv("AWFM_GPU_DENSE_SA", "1")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, 6)
+    check(ix, True)  # asked for: walked to the end
+    ix.dealloc()
+    monkeypatch.setenv("AWFM_GPU_DENSE_SA", "auto")
+    d_text = torch.from_numpy(txt).to(torch.device("cuda"))
+    ix = awfm.gpu_create_index(d_text.data_ptr(), awfm.AwFmAlphabetDna, ratio, 6, on_device_length=n)
+    g = check(ix, True)  # the builder's own array
+    assert g.dense_sa_build_s < 0.05
+    ix.dealloc()
+
+
 def test_drop_in_aos_api(oracle, awfm, require_gpu):
     """awFmCreateKmerSearchList / awFmParallelSearchCount / awFmParallelSearchLocate exactly as a
     reference user calls them (ref test/parallelSearch/parallelSearchTest.c:105-214)"""
