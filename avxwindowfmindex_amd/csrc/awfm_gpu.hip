@@ -1484,13 +1484,49 @@ enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable) {
 
 /* the caller holds whatever locks the image needs (none for an image nobody else has a pointer to yet) */
 namespace {
-/* how many entries of the construction were given up (walkKernel's stepCap) */
-__global__ void __launch_bounds__(256) countGaveUpKernel(const unsigned *__restrict__ dense, unsigned long long n, unsigned long long *__restrict__ out) {
+constexpr unsigned kDenseUnknown = 0xFFFFFFFFu; /* an entry the capped walk did not reach a sample for (no position: n < 2^32 - 1) */
+/* a chunk of the construction: final positions to 32 bits; a parked walk (kWalkParked) leaves kDenseUnknown and, in `park`,
+ * {steps walked << 32 | the position it stands at}: SA[this] = SA[that position] + steps */
+__global__ void __launch_bounds__(256) narrowParkKernel(const unsigned long long *__restrict__ in, unsigned long long count,
+                                                        unsigned *__restrict__ dense, unsigned long long *__restrict__ park,
+                                                        unsigned long long *__restrict__ parked) {
   unsigned long long mine = 0;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull)
-    mine += dense[i] == (unsigned)kWalkGaveUp ? 1ull : 0ull;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < count; i += (unsigned long long)gridDim.x * 256ull) {
+    const unsigned long long v = in[i];
+    if (v & kWalkParked) {
+      dense[i] = kDenseUnknown;
+      park[i] = (((v >> 32) & 0x3FFFFFFFull) << 32) | (v & 0xFFFFFFFFull);
+      mine++;
+    } else {
+      dense[i] = (unsigned)v;
+    }
+  }
   for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-  if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(out, mine);
+  if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(parked, mine);
+}
+/* One round of completing the parked entries from each other: entry j = {d, t} says SA[j] = SA[t] + d (mod n).  When t is
+ * known by now, so is j; otherwise j takes t's own {d', t'} on board -- SA[j] = SA[t'] + d + d' -- which at least doubles the
+ * distance it looks ahead every round (pointer jumping along the LF permutation; an entry read while another thread rewrites
+ * it is valid before and after: 8-byte loads and stores).  `left`: entries still unknown after the round. */
+__global__ void __launch_bounds__(256) denseSaJumpKernel(unsigned *__restrict__ dense, unsigned long long *__restrict__ park,
+                                                         unsigned long long n, unsigned long long *__restrict__ left) {
+  unsigned long long mine = 0;
+  for (unsigned long long j = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * 256ull) {
+    if (dense[j] != kDenseUnknown) continue;
+    const unsigned long long e = ((volatile unsigned long long *)park)[j];
+    const unsigned t = (unsigned)e;
+    const unsigned long long d = e >> 32;
+    const unsigned at = ((volatile unsigned *)dense)[t];
+    if (at != kDenseUnknown) {
+      dense[j] = (unsigned)(((unsigned long long)at + d) % n);
+    } else {
+      const unsigned long long e2 = ((volatile unsigned long long *)park)[t];
+      park[j] = ((d + (e2 >> 32)) << 32) | (e2 & 0xFFFFFFFFull);
+      mine++;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(left, mine);
 }
 }  // namespace
 
@@ -1502,10 +1538,12 @@ thread_local unsigned long long awfmGpuDenseSaStashLength = 0;
 }
 
 /* capped (the AUTOMATIC construction): a position that has not reached a sample after 32 x ratio LF steps (a random walk is
- * that long once in e^32 positions) is given up, and an array with such entries is dropped -- the image then locates by
- * walking, as the reference does.  A text with R long runs of one letter, R a multiple of the ratio (a genome's runs of N),
- * otherwise costs the construction 10^5..10^7 steps for every position inside a run: 566 s instead of 0.3 for the
- * genome-shaped 3.1 Gbp text of bench.py --text repetitive.  A construction that was asked for (awfmGpuIndexSetDenseSa,
+ * that long once in e^32 positions) is parked where it stands, and the parked entries are completed from each other by
+ * pointer jumping (denseSaJumpKernel: log2 of the longest chain rounds).  A text with R long runs of one letter, R a
+ * multiple of the ratio (a genome's runs of N), otherwise costs the construction 10^5..10^7 steps for every position
+ * inside a run: 566 s instead of 0.3 for the genome-shaped 3.1 Gbp text of bench.py --text repetitive.  Without memory for
+ * the parked entries (8 bytes per position while it runs) or when 64 rounds do not finish, no array is kept and the image
+ * locates by walking, as the reference does.  A construction that was asked for (awfmGpuIndexSetDenseSa,
  * $AWFM_GPU_DENSE_SA=1) walks every position to the end. */
 static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool capped) {
   (void)hipDeviceSynchronize();
@@ -1526,39 +1564,57 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
     return AwFmSuccess;
   }
   unsigned *dense = nullptr;
-  unsigned long long *chunkBuf = nullptr;
+  unsigned long long *chunkBuf = nullptr, *park = nullptr, *counter = nullptr;
   const unsigned long long chunk = n < (1ull << 28) ? n : (1ull << 28);
   AWFM_HIP_TRY(hipMalloc((void **)&dense, n * 4), AwFmAllocationFailure);
-  if (hipMalloc((void **)&chunkBuf, chunk * 8) != hipSuccess) {
+  if (hipMalloc((void **)&chunkBuf, chunk * 8 + 16) != hipSuccess) {
     (void)hipFree(dense);
     setError("awfmGpuIndexSetDenseSa: hipMalloc of the work buffer failed");
     return AwFmAllocationFailure;
   }
+  counter = chunkBuf + chunk; /* two words behind the chunk: parked entries, entries left */
+  if (capped && hipMalloc((void **)&park, n * 8) != hipSuccess) { /* no room to park walks: no automatic array */
+    (void)hipGetLastError();
+    (void)hipFree(chunkBuf);
+    (void)hipFree(dense);
+    return AwFmSuccess;
+  }
   enum AwFmReturnCode rc = AwFmSuccess;
+  if (hipMemset(counter, 0, 16) != hipSuccess) rc = AwFmGeneralFailure;
+  const unsigned stepCap = capped ? 32u * g->dev.saRatio : 0u;
   for (unsigned long long first = 0; first < n && rc == AwFmSuccess; first += chunk) {
     const unsigned long long count = n - first < chunk ? n - first : chunk;
     hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, first, count);
-    rc = launchLocate(g, count, chunkBuf, (hipStream_t)0, nullptr, nullptr, capped ? 32u * g->dev.saRatio : 0u);
-    hipLaunchKernelGGL(narrowKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, count, dense + first);
+    rc = launchLocate(g, count, chunkBuf, (hipStream_t)0, nullptr, nullptr, stepCap);
+    if (capped)
+      hipLaunchKernelGGL(narrowParkKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const unsigned long long *)chunkBuf, count,
+                         dense + first, park + first, counter);
+    else
+      hipLaunchKernelGGL(narrowKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, count, dense + first);
     if (hipGetLastError() != hipSuccess) rc = AwFmGeneralFailure;
   }
   if (hipDeviceSynchronize() != hipSuccess) rc = AwFmGeneralFailure;
   if (rc == AwFmSuccess && capped) {
-    unsigned long long gaveUp = 0;
-    if (hipMemset(chunkBuf, 0, 8) != hipSuccess) rc = AwFmGeneralFailure;
-    if (rc == AwFmSuccess) {
-      hipLaunchKernelGGL(countGaveUpKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const unsigned *)dense, n, chunkBuf);
-      if (hipGetLastError() != hipSuccess || hipMemcpy(&gaveUp, chunkBuf, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
+    unsigned long long parked = 0, left = 0;
+    if (hipMemcpy(&parked, counter, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
+    left = parked;
+    unsigned rounds = 0;
+    for (; rc == AwFmSuccess && left != 0 && rounds < 64u; rounds++) {
+      if (hipMemset(counter + 1, 0, 8) != hipSuccess) rc = AwFmGeneralFailure;
+      hipLaunchKernelGGL(denseSaJumpKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, dense, park, n, counter + 1);
+      if (hipGetLastError() != hipSuccess || hipMemcpy(&left, counter + 1, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
     }
-    if (rc == AwFmSuccess && gaveUp != 0) {
-      if (getenv("AWFM_VERBOSE"))
-        fprintf(stderr, "[awfm full suffix array] %llu of %llu positions not at a sample after %u LF steps: no full array, locates walk\n",
-                gaveUp, n, 32u * g->dev.saRatio);
+    if (getenv("AWFM_VERBOSE") && parked)
+      fprintf(stderr, "[awfm full suffix array] %llu of %llu walks parked after %u LF steps; %u rounds of pointer jumping, %llu left\n",
+              parked, n, stepCap, rounds, left);
+    if (rc == AwFmSuccess && left != 0) { /* (64 rounds look 2^64 steps ahead: not reached by an index that is one) */
+      (void)hipFree(park);
       (void)hipFree(chunkBuf);
       (void)hipFree(dense);
       return AwFmSuccess;
     }
   }
+  if (park) (void)hipFree(park);
   (void)hipFree(chunkBuf);
   if (rc != AwFmSuccess) {
     (void)hipFree(dense);

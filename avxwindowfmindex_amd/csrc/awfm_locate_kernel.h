@@ -27,7 +27,10 @@
 namespace {
 
 /* in-place hand-over between the two kernels: bit 63 set, steps in bits 62..40, sample index in 39..0 */
-constexpr unsigned long long kWalkGaveUp = 0xFFFFFFFFull; /* (untagged: finishKernel passes it on; no position of a 32-bit image) */
+/* a walk given up after stepCap steps (the construction of the full suffix array): bit 62 set, the steps walked in bits
+ * 61..32, the BWT position it stands at in bits 31..0 (images below 2^32 positions) -- untagged for finishKernel, which
+ * passes it on; awfm_gpu.hip completes such entries from each other */
+constexpr unsigned long long kWalkParked = 1ull << 62;
 constexpr unsigned long long kWalkTag = 1ull << 63;
 constexpr unsigned kWalkStepBits = 23;
 constexpr unsigned long long kWalkSampleMask = (1ull << 40) - 1ull;
@@ -94,7 +97,7 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
   const unsigned long long numGroups = (unsigned long long)gridDim.x * kGroups;
   const pos_t ratio = (pos_t)ix.saRatio;
   /* stepCap (the construction of the full suffix array, awfm_gpu.hip): a position that has not reached a sample after so
-   * many steps is given up -- kWalkGaveUp instead of a position -- rather than followed for up to 2^23 steps: in a text
+   * many steps is given up -- parked: kWalkParked, where it stands and how far it came -- rather than followed for up to 2^23 steps: in a text
    * with R long runs of one letter the suffixes inside the runs map, LF step by LF step, R places further in the suffix
    * array, and with R a multiple of the sampling ratio they never meet a sample until a run ends */
   const unsigned long long maxSteps = stepCap ? (unsigned long long)stepCap : (1ull << kWalkStepBits) - 1ull;
@@ -172,7 +175,8 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
       /* hand the hit over (or, after 2^23-1 steps, which only a corrupt index reaches, finish it here) */
       const unsigned long long sample = POW2 ? (unsigned long long)(p >> ix.saShift) : (unsigned long long)(p / ratio);
       const unsigned long long result = sampled ? (kWalkTag | ((unsigned long long)steps << 40) | (sample & kWalkSampleMask))
-                                                : (stepCap ? kWalkGaveUp : finishPosition(ix, sample, steps));
+                                                : (stepCap ? (kWalkParked | ((unsigned long long)steps << 32) | (unsigned long long)(unsigned)p)
+                                                           : finishPosition(ix, sample, steps));
       const bool owner = gl == j / kPerLane;
       const unsigned k = j % kPerLane;
       slot.a = owner && k == 0u ? result : slot.a;

@@ -168,9 +168,10 @@ def test_long_hit_lists_located_in_windows_through_the_full_suffix_array(oracle,
 def test_full_suffix_array_of_a_text_with_long_runs(oracle, awfm, require_gpu, monkeypatch):
     """A text with R long runs of one letter, R a multiple of the sampling ratio (a genome's runs of N): the suffixes inside
     the runs move R places per LF step and never meet a sample until a run ends.  The AUTOMATIC construction of the full
-    suffix array gives such positions up after 32 x ratio steps and drops the array (the locate then walks, as the reference
-    does); a construction that was asked for walks to the end; an index built on the GPU hands its own suffix array to its
-    image and walks nothing.  Positions against the oracle in all three cases."""
+    suffix array parks such walks after 32 x ratio steps and completes the parked entries from each other (pointer
+    jumping); a construction that was asked for walks to the end; an index built on the GPU hands its own suffix array to
+    its image and walks nothing; without the array the locate walks, as the reference does.  Positions against the oracle
+    in all four cases -- k-mers right behind a run (their walks enter it) and k-mers of N (hits INSIDE the runs) included."""
     import torch
     n, runs, run_len, ratio = 160000, 8, 3000, 8
     txt = synth.text(n + 71, n, synth.DNA_ALPHABET).copy()
@@ -179,7 +180,7 @@ def test_full_suffix_array_of_a_text_with_long_runs(oracle, awfm, require_gpu, m
         txt[at:at + run_len] = ord("n")
     kmers = [txt[at + run_len: at + run_len + 14].tobytes() for at in starts]  # right behind a run: the walk enters it
     kmers += [txt[at - 14: at].tobytes() for at in starts] + [bytes(r) for r in synth.planted_queries(72, 400, 16, txt)]
-    kmers = [k for k in kmers if b"n" not in k]
+    kmers = [k for k in kmers if b"n" not in k] + [b"n" * 12, b"n" * 31]
     chars, offsets = oracle.pack_queries(kmers)
 
     def check(ix, expect_dense):
@@ -194,7 +195,11 @@ def test_full_suffix_array_of_a_text_with_long_runs(oracle, awfm, require_gpu, m
 
     monkeypatch.setenv("AWFM_GPU_DENSE_SA", "auto")
     ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, 6)
-    check(ix, False)  # given up: 7/8 of the positions inside the runs
+    check(ix, True)  # 7/8 of the positions inside the runs parked, then completed
+    ix.dealloc()
+    monkeypatch.setenv("AWFM_GPU_DENSE_SA", "0")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, 6)
+    check(ix, False)  # the walk at query time
     ix.dealloc()
     monkeypatch.setenv("AWFM_GPU_DENSE_SA", "1")
     ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, 6)
