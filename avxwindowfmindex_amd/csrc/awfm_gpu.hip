@@ -1495,7 +1495,7 @@ __global__ void __launch_bounds__(256) narrowParkKernel(const unsigned long long
     const unsigned long long v = in[i];
     if (v & kWalkParked) {
       dense[i] = kDenseUnknown;
-      park[i] = (((v >> 32) & 0x3FFFFFFFull) << 32) | (v & 0xFFFFFFFFull);
+      if (park) park[i] = (((v >> 32) & 0x3FFFFFFFull) << 32) | (v & 0xFFFFFFFFull); /* (NULL: the pass that only counts) */
       mine++;
     } else {
       dense[i] = (unsigned)v;
@@ -1573,30 +1573,38 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
     return AwFmAllocationFailure;
   }
   counter = chunkBuf + chunk; /* two words behind the chunk: parked entries, entries left */
-  if (capped && hipMalloc((void **)&park, n * 8) != hipSuccess) { /* no room to park walks: no automatic array */
-    (void)hipGetLastError();
-    (void)hipFree(chunkBuf);
-    (void)hipFree(dense);
-    return AwFmSuccess;
-  }
   enum AwFmReturnCode rc = AwFmSuccess;
-  if (hipMemset(counter, 0, 16) != hipSuccess) rc = AwFmGeneralFailure;
   const unsigned stepCap = capped ? 32u * g->dev.saRatio : 0u;
-  for (unsigned long long first = 0; first < n && rc == AwFmSuccess; first += chunk) {
-    const unsigned long long count = n - first < chunk ? n - first : chunk;
-    hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, first, count);
-    rc = launchLocate(g, count, chunkBuf, (hipStream_t)0, nullptr, nullptr, stepCap);
-    if (capped)
-      hipLaunchKernelGGL(narrowParkKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const unsigned long long *)chunkBuf, count,
-                         dense + first, park + first, counter);
-    else
-      hipLaunchKernelGGL(narrowKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, count, dense + first);
-    if (hipGetLastError() != hipSuccess) rc = AwFmGeneralFailure;
-  }
-  if (hipDeviceSynchronize() != hipSuccess) rc = AwFmGeneralFailure;
+  auto walkAll = [&]() { /* every position walked (capped: parked walks counted, and kept where there is a `park`) */
+    if (hipMemset(counter, 0, 16) != hipSuccess) rc = AwFmGeneralFailure;
+    for (unsigned long long first = 0; first < n && rc == AwFmSuccess; first += chunk) {
+      const unsigned long long count = n - first < chunk ? n - first : chunk;
+      hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, first, count);
+      rc = launchLocate(g, count, chunkBuf, (hipStream_t)0, nullptr, nullptr, stepCap);
+      if (capped)
+        hipLaunchKernelGGL(narrowParkKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const unsigned long long *)chunkBuf, count,
+                           dense + first, park ? park + first : (unsigned long long *)nullptr, counter);
+      else
+        hipLaunchKernelGGL(narrowKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, count, dense + first);
+      if (hipGetLastError() != hipSuccess) rc = AwFmGeneralFailure;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) rc = AwFmGeneralFailure;
+  };
+  walkAll();
   if (rc == AwFmSuccess && capped) {
     unsigned long long parked = 0, left = 0;
     if (hipMemcpy(&parked, counter, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
+    if (rc == AwFmSuccess && parked != 0) {
+      /* (the usual text parks nothing and never pays for this: 8 bytes per position, and the walks once more to fill them) */
+      if (hipMalloc((void **)&park, n * 8) != hipSuccess) { /* no room to park walks: no automatic array */
+        (void)hipGetLastError();
+        (void)hipFree(chunkBuf);
+        (void)hipFree(dense);
+        return AwFmSuccess;
+      }
+      walkAll();
+      if (rc == AwFmSuccess && hipMemcpy(&parked, counter, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
+    }
     left = parked;
     unsigned rounds = 0;
     for (; rc == AwFmSuccess && left != 0 && rounds < 64u; rounds++) {
