@@ -37,6 +37,7 @@ GPU_SYMBOLS = [
     "awfmGpuSearchHitsPacked", "awfmGpuLocateTo", "awfmGpuSearchHitsLineTally", "awfmGpuIndexDeepSeedK", "awfmGpuSearchHitsCompact", "awfmGpuCompactHits", "awfmGpuSortHits",
     "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse", "awfmGpuSearchHitsInOrder",
     "awfmGpuSortHitsOnDevice", "awfmGpuHitOffsetsOnDevice", "awfmGpuLocateOnDevice", "awfmGpuLastOrderedSearchKernelMs", "awfmGpuOrderedKernelLog", "awfmGpuIndexDeepSeedBuildSeconds", "awfmGpuIndexDeepSeedTransientBytes", "awfmGpuIndexHasDenseSa", "awfmGpuIndexDenseSaBuildSeconds", "awfmGpuIndexLengthTableBytes", "awfmGpuIndexLengthTableBuildSeconds", "awfmGpuMixedLookupLineTally",
+    "awfmGpuListLocateOnDevice", "awfmGpuLastLookupFront",
 ]
 # int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
 CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
@@ -171,6 +172,8 @@ def lib():
         "awfmGpuSearchHitsInOrder": (C.c_int, [vp, vp, vp, C.c_uint32, u64, C.c_int, vp, vp, vp]),
         "awfmGpuSortHits": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),
         "awfmGpuSortHitsOnDevice": (C.c_int, [vp, vp, vp, C.c_uint32, vp, u64, vp]),
+        "awfmGpuListLocateOnDevice": (C.c_int, [vp, vp, vp, C.c_uint32, vp, u64, vp, vp, vp, u64, vp, vp]),
+        "awfmGpuLastLookupFront": (C.c_int, [vp]),
         "awfmGpuHitOffsetsOnDevice": (C.c_int, [vp, vp, vp, u64, vp, vp, vp]),
         "awfmGpuLocateOnDevice": (C.c_int, [vp, vp, vp, u64, u64, vp, vp]),
         "awfmGpuLastOrderedSearchKernelMs": (C.c_double, [vp]),

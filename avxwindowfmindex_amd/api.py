@@ -498,6 +498,17 @@ class GpuIndex:
         _check("awfmGpuSortHitsOnDevice", _lib.lib().awfmGpuSortHitsOnDevice(self.handle, d_hit_kmers, d_hit_ranges, capacity,
                                                                              d_num_hits, n, stream or None))
 
+    def last_lookup_front(self):
+        """awfmGpuLastLookupFront: 0 both front ends, 1 the lookup kernel only, 2 the ordered kernels only, -1 none yet"""
+        return int(_lib.lib().awfmGpuLastLookupFront(self.handle))
+
+    def list_locate_on_device(self, d_hit_kmers, d_hit_ranges, capacity, d_num_hits, n, d_sorted_kmers, d_sorted_ranges, d_hit_offsets,
+                              capacity_hits, d_positions, stream=0):
+        """awfmGpuListLocateOnDevice: the appended list -> the list in k-mer order, its hit offsets and positions, in one launch"""
+        _check("awfmGpuListLocateOnDevice", _lib.lib().awfmGpuListLocateOnDevice(
+            self.handle, d_hit_kmers, d_hit_ranges, capacity, d_num_hits, n, d_sorted_kmers, d_sorted_ranges, d_hit_offsets,
+            capacity_hits, d_positions or None, stream or None))
+
     def hit_offsets_on_device(self, d_counts, d_ranges, n, d_hit_offsets, d_scratch, stream=0):
         """awfmGpuHitOffsetsOnDevice: the scan; the total stays in d_hit_offsets[n]"""
         _check("awfmGpuHitOffsetsOnDevice", _lib.lib().awfmGpuHitOffsetsOnDevice(self.handle, d_counts or None, d_ranges or None, n,

@@ -784,11 +784,15 @@ struct AwFmGpuIndex {
     size_t bytes = 0;
     StreamGate gate;
     unsigned long long lastUse = 0;
+    /* lookupPrepKernel's two sample words (awfm_ordered_kernel.h): which of them the last search left zero for the next
+     * one, or -1 when another kind of search has used the counter block since (the words are then zeroed by a memset) */
+    int prepParity = -1;
   };
   static constexpr int kOrderSlots = 2;
   OrderSlot orderSlot[kOrderSlots];
   unsigned long long orderUses = 0;
   int orderCur = 0;           /* the slot of the search being enqueued (under orderMutex) */
+  int orderPrevParity = -1;   /* that slot's prepParity as the search before left it (orderBeginSlot resets the slot's own) */
   void *dOrder = nullptr;     /* = orderSlot[orderCur].mem */
   size_t orderBytes = 0;      /* = orderSlot[orderCur].bytes */
   hipEvent_t orderDoneEvent = nullptr; /* set while a search is enqueued: its last kernel carries it (stop event) ... */
@@ -816,6 +820,25 @@ struct AwFmGpuIndex {
   bool orderLookupFused = false;               /* ... by lookupSearchKernel, which searched the k-mers it kept itself */
   const unsigned *orderFusedKeptAt = nullptr;  /* its survivor counters (kFusedCounters words, 64 B apart) */
   const unsigned *orderKeptAt = nullptr; /* device word: k-mers that search ordered (after encodeLookupKernel: the ones it kept) */
+  /* Lookup prediction (round 5, awfm_gpu_ordered.hip): a sampled search publishes {its number, the sample's count} in
+   * page-locked host memory when its sample is in; a later search of the same k-mer length reads the newest verdict -- no
+   * wait: whatever has arrived -- and launches only the front end it names (the lookup kernel with what it cannot finish
+   * left to the general kernel, or the ordering passes and the ordered kernel), both when there is none.  Either front end
+   * alone is correct for any batch; a verdict that contradicts the mode its own search ran in switches prediction off for
+   * the next kPredictHoldoff searches.  Under orderMutex. */
+  struct LookupPredict {
+    unsigned long long *verdictHost = nullptr; /* (search number << 32) | k-mers of its sample still alive */
+    unsigned searches = 0;                     /* sampled searches so far: the number of the last one */
+    struct Entry {
+      unsigned number = 0;
+      unsigned char front = 0; /* 0 both, 1 lookup only, 2 ordered only */
+      unsigned length = 0, samples = 0;
+    } ring[16];
+    unsigned lastJudged = 0; /* the newest verdict that was compared with its own search's mode */
+    unsigned holdoff = 0;      /* searches that still launch both front ends after a miss */
+    unsigned holdoffNext = 8;  /* what the next miss sets it to (doubles per miss up to 1024, back to 8 after 64 good predictions) */
+    unsigned agreed = 0;
+  } predict;
   std::mutex aosMutex;       /* serialises the AoS entry points (they share the pinned buffers) */
   void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pinnedBytes[4] = {0, 0, 0, 0};

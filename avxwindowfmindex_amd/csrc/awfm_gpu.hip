@@ -272,6 +272,159 @@ __global__ void __launch_bounds__(256)
     __syncthreads(); /* sFirst is written again */
   }
 }
+
+/* ---- the tail of a step whose results are the LIST of the k-mers with hits, in ONE launch (round 5) ----
+ * awfmGpuSearchHitsCompact leaves {k-mer number, range} entries in the order the waves appended them; what follows -- the
+ * list in k-mer order, the hit offsets over it, the positions -- was a memset, four ranking kernels over a bitmap of the
+ * batch, a scan and the expand / gather kernel: seven dependent launches of 5-14 us each, 48 of the 470 us a
+ * 1.25 * 10^7-k-mer shard of an 8-GPU run takes (ref src/AwFmParallelSearch.c:315-365 does this per k-mer on the host).
+ * Here workgroup c owns the k-mer numbers [c R, (c + 1) R): it reads the whole list once (the keys: 4 bytes an entry, out
+ * of the L2), counts the entries below its range and their hits -- its own prefix, no scan across workgroups, no atomics,
+ * no scratch --, gathers its own entries in LDS, ranks them by counting, scans their lengths and writes them out: sorted
+ * entry, hit offset, and the hits' positions (through the full suffix array when the image has it).  The list's k-mer
+ * numbers are distinct, so a range of kListTailSlots numbers holds at most that many entries: a workgroup whose range
+ * holds more (clustered hits) goes through it in sub-ranges of that width, re-reading the keys for each.  The last workgroup
+ * knows the total and fills what lies behind the list. */
+constexpr unsigned kListTailThreads = 1024, kListTailSlots = 4096;
+constexpr unsigned kListTailMaxEntries = 1u << 18; /* longer lists: the three calls this kernel replaces (the tail is then no longer launch-bound) */
+template <bool DENSE>
+__global__ void __launch_bounds__(kListTailThreads)
+    listTailKernel(const unsigned *__restrict__ inKmers, const ulonglong2 *__restrict__ inRanges, const unsigned *__restrict__ count,
+                   const unsigned cap, const unsigned long long numQueries, unsigned *__restrict__ outKmers,
+                   ulonglong2 *__restrict__ outRanges, unsigned long long *__restrict__ hitOffsets, const unsigned long long capacityHits,
+                   unsigned long long *__restrict__ positions, const unsigned *__restrict__ dense) {
+  __shared__ unsigned sKey[kListTailSlots], sIdx[kListTailSlots], sOrder[kListTailSlots];
+  __shared__ unsigned long long sWave[kListTailThreads / 64], sRed[2][kListTailThreads / 64];
+  __shared__ unsigned sMine;
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const unsigned n = *count < cap ? *count : cap;
+  const unsigned long long width = (numQueries + gridDim.x - 1ull) / gridDim.x;
+  const unsigned long long lo = width * blockIdx.x;
+  const bool lastGroup = blockIdx.x == gridDim.x - 1u;
+  const unsigned long long hi = lastGroup ? (1ull << 32) : lo + width; /* (a number that is no k-mer of the batch sorts last) */
+  if (tid == 0) sMine = 0u;
+  __syncthreads();
+  /* one pass over the list: entries below the range (count, hits), own entries into the slots */
+  unsigned long long below = 0, belowHits = 0;
+  for (unsigned i = tid; i < n; i += kListTailThreads) {
+    const unsigned long long key = inKmers[i];
+    if (key < lo) {
+      const ulonglong2 r = inRanges[i];
+      below++;
+      belowHits += r.x <= r.y ? r.y - r.x + 1ull : 0ull;
+    } else if (key < hi) {
+      const unsigned at = atomicAdd(&sMine, 1u);
+      if (at < kListTailSlots) {
+        sKey[at] = (unsigned)key;
+        sIdx[at] = i;
+      }
+    }
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    below += __shfl_xor(below, d, 64);
+    belowHits += __shfl_xor(belowHits, d, 64);
+  }
+  if (lane == 0) {
+    sRed[0][wave] = below;
+    sRed[1][wave] = belowHits;
+  }
+  __syncthreads();
+  unsigned long long rankBase = 0, hitBase = 0; /* uniform: where the next entry of this workgroup goes */
+  for (unsigned v = 0; v < kListTailThreads / 64; v++) {
+    rankBase += sRed[0][v];
+    hitBase += sRed[1][v];
+  }
+  const unsigned mine = sMine;
+  /* the entries in the slots [0, m): ranked, scanned, written out */
+  auto emit = [&](const unsigned m) {
+    for (unsigned j = tid; j < m; j += kListTailThreads) {
+      const unsigned key = sKey[j];
+      unsigned r = 0; /* (ties -- a k-mer listed twice, which a search never does -- by slot: the ranks stay a permutation) */
+      for (unsigned i = 0; i < m; i++) r += sKey[i] < key || (sKey[i] == key && i < j) ? 1u : 0u;
+      sOrder[r] = j;
+    }
+    __syncthreads();
+    for (unsigned base = 0; base < m; base += kListTailThreads) { /* uniform trip count */
+      const unsigned r = base + tid;
+      unsigned key = 0;
+      ulonglong2 range = make_ulonglong2(1ull, 0ull);
+      unsigned long long len = 0;
+      if (r < m) {
+        const unsigned j = sOrder[r];
+        key = sKey[j];
+        range = inRanges[sIdx[j]];
+        len = range.x <= range.y ? range.y - range.x + 1ull : 0ull;
+      }
+      unsigned long long incl = len;
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long up = __shfl_up(incl, d, 64);
+        if (lane >= (unsigned)d) incl += up;
+      }
+      if (lane == 63u) sWave[wave] = incl;
+      __syncthreads();
+      unsigned long long before = hitBase, chunk = 0;
+      for (unsigned v = 0; v < kListTailThreads / 64; v++) {
+        before += v < wave ? sWave[v] : 0ull;
+        chunk += sWave[v];
+      }
+      const unsigned long long off = before + incl - len;
+      if (r < m) {
+        outKmers[rankBase + r] = key;
+        outRanges[rankBase + r] = range;
+        hitOffsets[rankBase + r] = off;
+      }
+      /* the hits of the entry: short lists by their own lane, long ones by the wave (as expandHitsKernel) */
+      unsigned long long countHere = 0;
+      if (positions && off < capacityHits) countHere = off + len <= capacityHits ? len : capacityHits - off;
+      const bool isLong = countHere > 32ull;
+      if (!isLong)
+        for (unsigned long long h = 0; h < countHere; h++) positions[off + h] = DENSE ? (unsigned long long)dense[range.x + h] : range.x + h;
+      unsigned long long longMask = __ballot(isLong);
+      while (longMask) {
+        const int src = __ffsll((long long)longMask) - 1;
+        longMask &= longMask - 1ull;
+        const unsigned long long o = __shfl(off, src, 64), c = __shfl(countHere, src, 64), p = __shfl(range.x, src, 64);
+        for (unsigned long long h = lane; h < c; h += 64ull) positions[o + h] = DENSE ? (unsigned long long)dense[p + h] : p + h;
+      }
+      hitBase += chunk;
+      __syncthreads(); /* sWave is written again */
+    }
+    rankBase += m;
+  };
+  if (mine <= kListTailSlots) {
+    emit(mine);
+  } else {
+    /* more entries than slots in this range: sub-ranges of kListTailSlots k-mer numbers, the keys read again for each */
+    for (unsigned long long sub = lo; sub < hi && rankBase < n; sub += kListTailSlots) {
+      const unsigned long long subEnd = sub + kListTailSlots < hi ? sub + kListTailSlots : hi;
+      __syncthreads();
+      if (tid == 0) sMine = 0u;
+      __syncthreads();
+      for (unsigned i = tid; i < n; i += kListTailThreads) {
+        const unsigned long long key = inKmers[i];
+        if (key >= sub && key < subEnd) {
+          const unsigned at = atomicAdd(&sMine, 1u);
+          if (at < kListTailSlots) { /* (more only when the list names a k-mer twice, which a search never does) */
+            sKey[at] = (unsigned)key;
+            sIdx[at] = i;
+          }
+        }
+      }
+      __syncthreads();
+      const unsigned m = sMine < kListTailSlots ? sMine : kListTailSlots;
+      if (m) emit(m);
+    }
+  }
+  if (lastGroup) { /* behind the list: empty entries, every offset the total */
+    for (unsigned long long i = rankBase + tid; i <= cap; i += kListTailThreads) {
+      if (i < cap) {
+        outKmers[i] = 0xFFFFFFFFu;
+        outRanges[i] = make_ulonglong2(1ull, 0ull);
+      }
+      hitOffsets[i] = hitBase;
+    }
+  }
+}
 }  // namespace
 
 /* ------------------------------------------------------------------ host side */
@@ -667,6 +820,7 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
       if (g->windowEvent[i]) (void)hipEventDestroy(g->windowEvent[i]);
     for (int i = 0; i < 4; i++)
       if (g->pinned[i]) (void)hipHostFree(g->pinned[i]);
+    if (g->predict.verdictHost) (void)hipHostFree(g->predict.verdictHost);
   }
   delete g;
 }
@@ -1384,6 +1538,66 @@ enum AwFmReturnCode awfmGpuLocateOnDevice(AwFmGpuIndex *g, const struct AwFmSear
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   const unsigned long long *total = (const unsigned long long *)dHitOffsets + numQueries;
   return launchLocate(g, capacityHits, (unsigned long long *)dPositions, s, (unsigned long long *)dPositions, total);
+}
+
+
+/* see include/awfm_gpu.h */
+enum AwFmReturnCode awfmGpuListLocateOnDevice(AwFmGpuIndex *g, const uint32_t *dHitKmers, const struct AwFmSearchRange *dHitRanges,
+                                              uint32_t capacity, const uint32_t *dNumHits, uint64_t numQueries, uint32_t *dSortedKmers,
+                                              struct AwFmSearchRange *dSortedRanges, uint64_t *dHitOffsets, uint64_t capacityHits,
+                                              uint64_t *dPositions, void *stream) {
+  if (!g || !dHitKmers || !dHitRanges || !dNumHits || !dSortedKmers || !dSortedRanges || !dHitOffsets) {
+    setError("awfmGpuListLocateOnDevice: null argument");
+    return AwFmNullPtrError;
+  }
+  if (capacity == 0 || numQueries == 0 || numQueries >= 0xFFFFFFFFull) {
+    setError("awfmGpuListLocateOnDevice: a list needs a capacity and a batch of 1 .. 2^32 - 2 k-mers");
+    return AwFmIllegalPositionError;
+  }
+  if ((const void *)dHitKmers == (const void *)dSortedKmers || (const void *)dHitRanges == (const void *)dSortedRanges) {
+    setError("awfmGpuListLocateOnDevice: the list is not put in order in place (awfmGpuSortHitsOnDevice does that)");
+    return AwFmIllegalPositionError;
+  }
+  DeviceGuard guard(g->device);
+  hipStream_t s = (hipStream_t)stream;
+  if (!dPositions) capacityHits = 0;
+  const char *env = getenv("AWFM_GPU_LIST_TAIL"); /* 0: the three calls this one replaces (measurement knob) */
+  if (capacity > kListTailMaxEntries || (env && atoi(env) == 0)) {
+    /* a long list: copy, rank in a bitmap of the batch, scan, expand (what a caller did before this entry point existed) */
+    AWFM_HIP_TRY(hipMemcpyAsync(dSortedKmers, dHitKmers, (size_t)capacity * 4u, hipMemcpyDeviceToDevice, s), AwFmGeneralFailure);
+    AWFM_HIP_TRY(hipMemcpyAsync(dSortedRanges, dHitRanges, (size_t)capacity * 16u, hipMemcpyDeviceToDevice, s), AwFmGeneralFailure);
+    enum AwFmReturnCode rc = awfmGpuSortHitsOnDevice(g, dSortedKmers, dSortedRanges, capacity, dNumHits, numQueries, stream);
+    if (rc != AwFmSuccess) return rc;
+    void *scratch = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(g->workMutex);
+      rc = ensureWork(g, awfmGpuScanScratchBytes(capacity));
+      scratch = g->dWork;
+    }
+    if (rc != AwFmSuccess) return rc;
+    rc = awfmGpuHitOffsetsOnDevice(g, nullptr, dSortedRanges, capacity, dHitOffsets, scratch, stream);
+    if (rc != AwFmSuccess || capacityHits == 0) return rc;
+    return awfmGpuLocateOnDevice(g, dSortedRanges, dHitOffsets, capacity, capacityHits, dPositions, stream);
+  }
+  /* a workgroup per stretch of the batch; a short list does not need the whole chip */
+  unsigned grid = capacity / 16u;
+  grid = grid < 1u ? 1u : (grid > (unsigned)g->numCUs ? (unsigned)g->numCUs : grid);
+  if ((unsigned long long)grid > numQueries) grid = (unsigned)numQueries;
+  if (g->dDenseSa)
+    hipLaunchKernelGGL(listTailKernel<true>, dim3(grid), dim3(kListTailThreads), 0, s, (const unsigned *)dHitKmers, (const ulonglong2 *)dHitRanges,
+                       (const unsigned *)dNumHits, (unsigned)capacity, (unsigned long long)numQueries, (unsigned *)dSortedKmers,
+                       (ulonglong2 *)dSortedRanges, (unsigned long long *)dHitOffsets, (unsigned long long)capacityHits,
+                       (unsigned long long *)dPositions, (const unsigned *)g->dDenseSa);
+  else
+    hipLaunchKernelGGL(listTailKernel<false>, dim3(grid), dim3(kListTailThreads), 0, s, (const unsigned *)dHitKmers, (const ulonglong2 *)dHitRanges,
+                       (const unsigned *)dNumHits, (unsigned)capacity, (unsigned long long)numQueries, (unsigned *)dSortedKmers,
+                       (ulonglong2 *)dSortedRanges, (unsigned long long *)dHitOffsets, (unsigned long long)capacityHits,
+                       (unsigned long long *)dPositions, (const unsigned *)nullptr);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  if (g->dDenseSa || capacityHits == 0) return AwFmSuccess;
+  /* no full suffix array: the kernel left the BWT positions; the LF walk and the sample reads take them from there */
+  return launchLocate(g, capacityHits, (unsigned long long *)dPositions, s, (unsigned long long *)dPositions,
+                      (const unsigned long long *)dHitOffsets + capacity);
 }
 
 namespace {

@@ -20,6 +20,23 @@
 namespace {
 
 inline size_t alignUp256(size_t v) { return (v + 255) / 256 * 256; }
+
+/* the list of hits of a sparse search (awfmGpuSearchHitsCompact) before anything is appended: empty entries, count 0 */
+__global__ void __launch_bounds__(256) fillSparseKernel(unsigned *__restrict__ kmers, ulonglong2 *__restrict__ ranges, unsigned cap,
+                                                        unsigned *__restrict__ count) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i < cap) {
+    kmers[i] = 0xFFFFFFFFu; /* sorts behind every k-mer */
+    ranges[i] = make_ulonglong2(1ull, 0ull);
+  }
+  if (i == 0) *count = 0u;
+}
+/* every search path that lists its hits starts with this (the bucketed path's lookupPrepKernel does it beside its other work) */
+inline hipError_t fillSparseList(const SparseOut *sparse, hipStream_t s) {
+  if (!sparse || !sparse->count) return hipSuccess;
+  hipLaunchKernelGGL(fillSparseKernel, dim3((sparse->cap + 255u) / 256u), dim3(256), 0, s, sparse->kmers, sparse->ranges, sparse->cap, sparse->count);
+  return hipGetLastError();
+}
 constexpr size_t kOrderCounterBytes = 131072; /* 256 B for the count + 8 XCDs x kTicketGroups x 8 waves x 256 B of ticket counters */
 static_assert(256 + 8 * kTicketGroups * 8 * 256 <= kOrderCounterBytes, "ticket counters");
 
@@ -365,6 +382,15 @@ extern "C" double awfmGpuLastOrderedSearchKernelMs(AwFmGpuIndex *g) {
   return (double)ms;
 }
 
+/* see include/awfm_gpu.h */
+extern "C" int awfmGpuLastLookupFront(AwFmGpuIndex *g) {
+  if (!g) return -1;
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  const AwFmGpuIndex::LookupPredict &p = g->predict;
+  if (p.searches == 0u) return -1;
+  return (int)p.ring[p.searches % 16u].front;
+}
+
 extern "C" int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets, uint32_t fixedLength, uint64_t numQueries) {
   if (!g) return 0;
   if (g->amino) return 0;
@@ -449,6 +475,8 @@ static hipError_t orderBeginSlot(AwFmGpuIndex *g, hipStream_t s) {
     if (atoi(env) == 1) pick = 0;
   AwFmGpuIndex::OrderSlot &slot = g->orderSlot[pick];
   slot.lastUse = ++g->orderUses;
+  g->orderPrevParity = slot.prepParity; /* (a search that keeps the two sample words in step sets it again) */
+  slot.prepParity = -1;
   g->orderCur = pick;
   g->dOrder = slot.mem;
   g->orderBytes = slot.bytes;
@@ -476,6 +504,7 @@ static bool ensureOrderScratch(AwFmGpuIndex *g, size_t bytes) {
   g->orderBytes = 0;
   g->orderKeptAt = nullptr;
   g->orderSampleAt = nullptr;
+  g->orderPrevParity = -1;
   const size_t want = bytes + bytes / 8;
   if (hipMalloc(&slot.mem, want) != hipSuccess) {
     (void)hipGetLastError();
@@ -533,6 +562,41 @@ static void launchLookupSearchAt(unsigned len, unsigned grid, size_t lds, hipStr
                                  rng, dCounts, sparse, keptCounters, start, stop);
 }
 
+/* ---- lookup prediction (AwFmGpuIndex::LookupPredict) ---- */
+enum { kFrontBoth = 0, kFrontLookupOnly = 1, kFrontOrderedOnly = 2 };
+constexpr unsigned kPredictHoldoff = 8;
+/* which front end(s) a sampled search of fixed-length k-mers launches, from the newest verdict that has reached the host
+ * (nothing waits for one); the caller holds orderMutex.  $AWFM_GPU_LOOKUP_PREDICT=0: always both (round 4). */
+static int predictFront(AwFmGpuIndex *g, unsigned fixedLength) {
+  AwFmGpuIndex::LookupPredict &p = g->predict;
+  if (const char *env = getenv("AWFM_GPU_LOOKUP_PREDICT"))
+    if (atoi(env) == 0) return kFrontBoth;
+  if (!p.verdictHost) return kFrontBoth;
+  const unsigned long long v = *(volatile unsigned long long *)p.verdictHost;
+  const unsigned number = (unsigned)(v >> 32), alive = (unsigned)v;
+  if (number == 0u) return kFrontBoth;
+  const AwFmGpuIndex::LookupPredict::Entry &e = p.ring[number % 16u];
+  if (e.number != number || e.samples == 0u) return kFrontBoth; /* older than the ring remembers */
+  const bool lookup = alive * 4u < e.samples; /* lookupChosen's rule */
+  if (number != p.lastJudged) {
+    p.lastJudged = number;
+    if ((e.front == kFrontLookupOnly && !lookup) || (e.front == kFrontOrderedOnly && lookup)) {
+      /* a stream whose batches keep changing character: every miss doubles the searches that launch both front ends */
+      p.holdoff = p.holdoffNext;
+      p.holdoffNext = p.holdoffNext < 1024u ? 2u * p.holdoffNext : 1024u;
+      p.agreed = 0;
+    } else if (e.front != kFrontBoth && ++p.agreed >= 64u) {
+      p.holdoffNext = kPredictHoldoff;
+    }
+  }
+  if (p.holdoff) {
+    p.holdoff--;
+    return kFrontBoth;
+  }
+  if (e.length != fixedLength) return kFrontBoth;
+  return lookup ? kFrontLookupOnly : kFrontOrderedOnly;
+}
+
 /* fillNoHitKernel -> encodeCodes4Kernel -> bucketScanSharesKernel -> partitionKernel -> orderedSearchKernel<BUCKET> ->
  * searchKernel<INDIRECT> on the caller's stream; the caller holds orderMutex.  Return values as awfmGpuOrderedSearch. */
 static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength, unsigned depth,
@@ -574,12 +638,6 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   unsigned *hist = (unsigned *)(w + histAt), *cursors = (unsigned *)(w + cursorsAt), *bucketStart = (unsigned *)(w + startAt);
   const unsigned long long *codes = packed ? (const unsigned long long *)dChars : (const unsigned long long *)(w + codesAt);
   unsigned long long *recs = (unsigned long long *)(w + recsAt);
-  BUCKET_TRY(hipMemsetAsync(w, 0, startAt, s)); /* the count, the ticket counters, the histograms, the cursors */
-  if (!sparse) { /* a sparse search lists its hits: there is nothing to pre-fill */
-    hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
-                       rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
-    BUCKET_TRY(hipGetLastError());
-  }
   /* grids: multiples of the 8 shares (workgroup b works on share b % 8) */
   const unsigned long long perShare256 = (shareSize(nq) + 255ull) / 256ull;
   unsigned encodeGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * 8u ? perShare256 * kShares : (unsigned long long)g->numCUs * 8u);
@@ -589,37 +647,103 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   /* lookup first: forced ($AWFM_GPU_LOOKUP_FIRST=1), or left to a sample of the batch -- 16384 k-mers at a fixed stride; the
    * pass pays when fewer than a quarter of them are alive after the table.  The sample's count stays on the device: both
    * front ends are launched and the one it does not choose returns at once (lookupChosen), so the search never waits
-   * for the host.  ($AWFM_GPU_LOOKUP_HOST_DECIDES=1: round 3's read-back of the count, 4 bytes and a stream
-   * synchronisation inside the search, for comparison.) */
+   * for the host -- unless (round 5) the sample of an earlier search of this k-mer length has reached the host by now:
+   * then only the front end it chose is launched (predictFront).  ($AWFM_GPU_LOOKUP_HOST_DECIDES=1: round 3's read-back
+   * of the count, 4 bytes and a stream synchronisation inside the search, for comparison.) */
   constexpr unsigned kSamples = 16384;
   const bool forced = lookupWanted && lookupEnv && atoi(lookupEnv) == 1;
   bool bySample = lookupWanted && !forced;
-  const unsigned *sampleAlive = bySample ? (const unsigned *)(w + kSampleAt) : nullptr;
-  bool lookupFirst = forced;
-  if (bySample) {
-    hipLaunchKernelGGL(sampleAliveKernel, dim3(kSamples / 256u), dim3(256), 0, s, g->dev, dChars, fixedLength, depth, useNext, nq, kSamples,
-                       (unsigned *)(w + kSampleAt));
-    BUCKET_TRY(hipGetLastError());
-    if (getenv("AWFM_GPU_LOOKUP_HOST_DECIDES")) {
-      unsigned alive = 0;
-      BUCKET_TRY(hipMemcpyAsync(&alive, w + kSampleAt, sizeof alive, hipMemcpyDeviceToHost, s));
-      BUCKET_TRY(hipStreamSynchronize(s));
-      lookupFirst = alive * 4u < kSamples;
-      bySample = false;
-      sampleAlive = nullptr;
+  /* the memset, the list's fill and the sample in one launch (lookupPrepKernel); $AWFM_GPU_PREP_FUSED=0: round 4's three */
+  const char *prepEnv = getenv("AWFM_GPU_PREP_FUSED");
+  const bool prepFused = bySample && nq >= kSamples && !getenv("AWFM_GPU_LOOKUP_HOST_DECIDES") && !(prepEnv && atoi(prepEnv) == 0);
+  AwFmGpuIndex::LookupPredict &predict = g->predict;
+  if (prepFused && !predict.verdictHost) {
+    if (hipHostMalloc((void **)&predict.verdictHost, 64, hipHostMallocDefault) == hipSuccess) {
+      memset(predict.verdictHost, 0, 64);
+    } else {
+      (void)hipGetLastError();
+      predict.verdictHost = nullptr; /* no verdicts: every search launches both front ends */
     }
   }
+  const int front = prepFused ? predictFront(g, fixedLength) : kFrontBoth;
+  const unsigned *sampleAlive = nullptr;
+  bool lookupFirst = forced;
+  if (prepFused) {
+    /* the two sample words, a line each (kSampleAt, kSampleAt + 128): this search adds to the one the last search on the
+     * slot left zero and zeroes the other */
+    int parity = g->orderPrevParity;
+    if (parity < 0) {
+      BUCKET_TRY(hipMemsetAsync(w + kSampleAt, 0, 256, s));
+      parity = 0;
+    }
+    unsigned long long *aliveOut = (unsigned long long *)(w + kSampleAt + 128u * (unsigned)parity);
+    unsigned long long *aliveNext = (unsigned long long *)(w + kSampleAt + 128u * (unsigned)(1 - parity));
+    /* what the launch zeroes: everything the memset did but the sample words -- or, when only the lookup kernel follows, the
+     * line of the general kernel's count and the survivor counters */
+    uint4 *zeroA = (uint4 *)w, *zeroB = (uint4 *)(w + kSampleAt + 256u);
+    unsigned vecsA = (unsigned)(kSampleAt / 16u), vecsB = (unsigned)((startAt - kSampleAt - 256u) / 16u);
+    if (front == kFrontLookupOnly) {
+      vecsA = 256u / 16u;
+      zeroB = (uint4 *)(w + kKeptAt);
+      vecsB = kFusedCounters * 64u / 16u;
+    }
+    const unsigned number = ++predict.searches ? predict.searches : ++predict.searches; /* never 0: "no verdict yet" */
+    AwFmGpuIndex::LookupPredict::Entry &entry = predict.ring[number % 16u];
+    entry.number = number;
+    entry.front = (unsigned char)front;
+    entry.length = fixedLength;
+    entry.samples = kSamples;
+    const unsigned prepGrid = front == kFrontLookupOnly && !(sparse && sparse->count) ? kSamples / 256u : 2u * (kSamples / 256u);
+    hipLaunchKernelGGL(lookupPrepKernel, dim3(prepGrid), dim3(256), 0, s, g->dev, dChars, fixedLength, depth, useNext, nq, kSamples, aliveOut,
+                       aliveNext, zeroA, vecsA, zeroB, vecsB, sparse && sparse->count ? *sparse : SparseOut(), predict.verdictHost, number);
+    BUCKET_TRY(hipGetLastError());
+    g->orderSlot[g->orderCur].prepParity = 1 - parity;
+    if (!sparse) {
+      hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
+                         rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
+      BUCKET_TRY(hipGetLastError());
+    }
+    g->orderSampleAt = (const unsigned *)aliveOut; /* (the count is the word's low half) */
+    if (front == kFrontBoth) sampleAlive = (const unsigned *)aliveOut;
+    else {
+      bySample = false; /* the host has decided: one front end, which does not look at the sample */
+      lookupFirst = front == kFrontLookupOnly;
+    }
+  } else {
+    BUCKET_TRY(hipMemsetAsync(w, 0, startAt, s)); /* the count, the ticket counters, the histograms, the cursors */
+    BUCKET_TRY(fillSparseList(sparse, s)); /* (lookupPrepKernel fills the list beside its other work) */
+    if (!sparse) { /* a sparse search lists its hits: there is nothing to pre-fill */
+      hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
+                         rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
+      BUCKET_TRY(hipGetLastError());
+    }
+    sampleAlive = bySample ? (const unsigned *)(w + kSampleAt) : nullptr;
+    if (bySample) {
+      hipLaunchKernelGGL(sampleAliveKernel, dim3(kSamples / 256u), dim3(256), 0, s, g->dev, dChars, fixedLength, depth, useNext, nq, kSamples,
+                         (unsigned *)(w + kSampleAt));
+      BUCKET_TRY(hipGetLastError());
+      if (getenv("AWFM_GPU_LOOKUP_HOST_DECIDES")) {
+        unsigned alive = 0;
+        BUCKET_TRY(hipMemcpyAsync(&alive, w + kSampleAt, sizeof alive, hipMemcpyDeviceToHost, s));
+        BUCKET_TRY(hipStreamSynchronize(s));
+        lookupFirst = alive * 4u < kSamples;
+        bySample = false;
+        sampleAlive = nullptr;
+      }
+    }
+    g->orderSampleAt = (const unsigned *)(w + kSampleAt);
+  }
+  const bool lookupOnly = prepFused && front == kFrontLookupOnly; /* no ordering passes, no ordered kernel behind the lookup kernel */
   g->orderLookup = bySample ? 2 : (lookupFirst ? 1 : 0);
-  g->orderSampleAt = (const unsigned *)(w + kSampleAt);
   g->orderSamples = kSamples;
-  g->orderKeptAt = bucketStart + bins; /* the scan's total */
+  g->orderKeptAt = lookupOnly ? generalCount : bucketStart + bins; /* the k-mers left to the general kernel / the scan's total */
   g->orderTimedFront = false;
   if (lookupFirst || bySample) {
     const bool timed = g->orderTiming[0] != nullptr; /* this search has an entry in the timing log: the events ride on the dispatch */
     /* fused (default): the k-mers still alive after the table are searched by the kernel that looked them up;
      * $AWFM_GPU_LOOKUP_FUSED=0: they are kept, partitioned and searched by orderedSearchKernel (round 3) */
     const char *fusedEnv = getenv("AWFM_GPU_LOOKUP_FUSED");
-    const bool fused = !(fusedEnv && atoi(fusedEnv) == 0);
+    const bool fused = lookupOnly || !(fusedEnv && atoi(fusedEnv) == 0);
     g->orderLookupFused = fused;
     g->orderFusedKeptAt = (const unsigned *)(w + kKeptAt);
     if (fused) {
@@ -634,8 +758,11 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
       if (const char *env = getenv("AWFM_GPU_LOOKUP_BLOCKS_PER_CU")) perCU = (unsigned)atoi(env) >= 1u ? (unsigned)atoi(env) : 7u;
       unsigned fusedGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * perCU ? perShare256 * kShares : (unsigned long long)g->numCUs * perCU);
       fusedGrid = (fusedGrid + kShares - 1u) / kShares * kShares;
-      launchLookupSearchAt<32u>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt, useNext | (pairOff ? 2u : 0u), nq, (unsigned long long *)(w + codesAt),
-                                numbers, shareCount, hist, binsPad, sampleAlive, kSamples, rng, dCounts, sparse ? *sparse : SparseOut(),
+      /* (lookup only: what the kernel does not search itself goes to the END of the record array, 8 bytes a k-mer number,
+       * counted in the general kernel's word -- no code words, no numbers, no histogram) */
+      launchLookupSearchAt<32u>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt, useNext | (pairOff ? 2u : 0u) | (lookupOnly ? 4u : 0u), nq,
+                                (unsigned long long *)(w + codesAt), lookupOnly ? (unsigned *)recs : numbers, lookupOnly ? generalCount : shareCount,
+                                hist, binsPad, sampleAlive, kSamples, rng, dCounts, sparse ? *sparse : SparseOut(),
                                 (unsigned *)(w + kKeptAt), timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr);
     } else {
       launchEncodeLookupAt<32u>(fixedLength, encodeGrid, bins * 4u, s, g->dev, dChars, fmt, useNext, nq, (unsigned long long *)(w + codesAt), numbers,
@@ -644,6 +771,22 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
     g->orderTimedFront = timed;
     if (timed) g->orderLog[(g->orderLogCount - 1u) % AwFmGpuIndex::kOrderLogMax].front = true;
     BUCKET_TRY(hipGetLastError());
+  }
+  if (lookupOnly) {
+    /* what the lookup kernel left (k-mers with ambiguity characters, survivors beyond a round's slots): the general kernel
+     * over the tail of the record array -- the last kernel of the search: it carries the event that says the slot is free */
+    enum AwFmReturnCode rc = AwFmSuccess;
+    if (!packed) {
+      const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, true, true>);
+      hipExtLaunchKernelGGL((searchKernel<false, 4, false, false, true, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, 0u,
+                            g->dev, dChars, (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
+                            (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u);
+      if (hipGetLastError() != hipSuccess) rc = AwFmGeneralFailure;
+      g->orderDoneArmed = g->orderDoneEvent != nullptr;
+    }
+    if (rc != AwFmSuccess) return -(int)rc;
+    BUCKET_TRY(orderEndSlot(g, s));
+    return 1;
   }
   if (lookupFirst) {
     /* (forced or decided by the host: the other front end is not launched) */
@@ -768,6 +911,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   unsigned *hist = (unsigned *)(w + histAt), *cursors = (unsigned *)(w + cursorsAt), *bucketStart = (unsigned *)(w + startAt);
   QueryRec *recsIn = (QueryRec *)(w + inAt), *recsOut = (QueryRec *)(w + outAt);
   WIDE_TRY(hipMemsetAsync(w, 0, startAt, s));
+  WIDE_TRY(fillSparseList(sparse, s));
   if (!sparse) {
     hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
                        rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
@@ -956,6 +1100,7 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
     }                                       \
   } while (0)
   ORDER_TRY(hipMemsetAsync(generalCount, 0, kOrderCounterBytes, s)); /* the count and the ticket counters */
+  ORDER_TRY(fillSparseList(sparse, s));
   /* rangesOfHitsOnly (awfmGpuSearchHitsSparse): the counts say which k-mers have hits, so only the counts are
    * pre-filled and the ranges of the others stay as the caller left them -- 16 of the 20 bytes per k-mer not written */
   if (!sparse) {
@@ -1055,6 +1200,7 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
   unsigned *sampleWord = (unsigned *)w, *leftoverCount = (unsigned *)(w + 64), *kept = (unsigned *)(w + 256);
   unsigned long long *leftover = (unsigned long long *)(w + listAt);
   AMINO_TRY(hipMemsetAsync(w, 0, kCounterBytes, s));
+  AMINO_TRY(fillSparseList(sparse, s));
   if (!sparse) {
     hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
                        rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
@@ -1250,15 +1396,6 @@ extern "C" enum AwFmReturnCode awfmGpuSearchHitsLineTally(AwFmGpuIndex *g, const
 /* ------------------------------------------------------------------ sparse results */
 
 namespace {
-__global__ void __launch_bounds__(256) fillSparseKernel(unsigned *__restrict__ kmers, ulonglong2 *__restrict__ ranges, unsigned cap,
-                                                        unsigned *__restrict__ count) {
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  if (i < cap) {
-    kmers[i] = 0xFFFFFFFFu; /* sorts behind every k-mer */
-    ranges[i] = make_ulonglong2(1ull, 0ull);
-  }
-  if (i == 0) *count = 0u;
-}
 /* the list of the k-mers with hits out of dense results, in batch order: entry flagOffsets[i] when counts[i] != 0 */
 __global__ void __launch_bounds__(256) compactDenseKernel(const unsigned *__restrict__ counts, const ulonglong2 *__restrict__ ranges,
                                                           const unsigned long long *__restrict__ flagOffsets, unsigned long long n,
@@ -1296,10 +1433,7 @@ extern "C" enum AwFmReturnCode awfmGpuSearchHitsCompact(AwFmGpuIndex *g, const u
   }
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(fillSparseKernel, dim3((capacity + 255u) / 256u), dim3(256), 0, s, (unsigned *)dHitKmers, (ulonglong2 *)dHitRanges,
-                     (unsigned)capacity, (unsigned *)dNumHits);
-  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-  SparseOut sparse;
+  SparseOut sparse; /* (the search path the batch takes fills the list first: fillSparseList / lookupPrepKernel) */
   sparse.count = (unsigned *)dNumHits;
   sparse.cap = capacity;
   sparse.kmers = (unsigned *)dHitKmers;

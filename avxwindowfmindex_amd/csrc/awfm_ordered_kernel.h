@@ -705,7 +705,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
       abefore[i] = atotal;
       atotal += (unsigned)__popcll(amask[i]);
     }
-    if (atotal != 0u) { /* wave-uniform; rare */
+    if (atotal != 0u && (useNext & 4u) != 0u) { /* wave-uniform; rare */
+      /* LOOKUP ONLY (the search launched no ordered kernels behind this one: the sample of an earlier batch of the stream
+       * said this kernel would be the one, awfm_gpu_ordered.hip): what is not searched here is the general kernel's, which
+       * takes the LAST *shareCount 8-byte records of numbersOut[0 .. numQueries) -- a k-mer number each */
+      unsigned base = 0;
+      if (lane == 0) base = atomicAdd(shareCount, atotal);
+      base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+      for (unsigned i = 0; i < 4u; i++)
+        if (append[i]) {
+          const unsigned long long rec = numQueries - 1ull - (base + abefore[i] + (unsigned)__popcll(amask[i] & ((1ull << lane) - 1ull)));
+          ((unsigned long long *)numbersOut)[rec] = (unsigned long long)(t + i);
+        }
+    } else if (atotal != 0u) { /* wave-uniform; rare */
       if (blockUsed + atotal > blockSlots) {
         if (blockUsed + lane < blockSlots) codesOut[first + blockBase + blockUsed + lane] = kCodeNone;
         blockSlots = atotal > kLookupBlock || tw + 256ull > last ? atotal : kLookupBlock;
@@ -846,6 +859,61 @@ __global__ void __launch_bounds__(256)
   if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&sAlive, n);
   __syncthreads();
   if (threadIdx.x == 0 && sAlive) atomicAdd(aliveOut, sAlive);
+}
+
+/* Everything a bucketed search needs before its front end, in ONE launch (round 5; they were a memset, a fill kernel and
+ * sampleAliveKernel: 17 of the 470 us a 1.25 * 10^7-k-mer shard takes): the scratch counters zeroed (two regions of 16-byte
+ * pieces), the caller's list of hits pre-filled, and the sample taken.  The sample's word is not zeroed by the launch that
+ * adds to it -- the workgroups of a launch are not ordered -- : a search leaves the OTHER of two words zero for the search
+ * that uses the scratch slot next (`aliveNext`; the host keeps the parity).  The word is 64 bits: every sampling workgroup
+ * adds {1, its count} in one atomic, so the one whose add returns "all the others are in" knows the total and publishes
+ * it -- {number of this search, k-mers alive} -- in page-locked host memory, where a later search of the stream reads it
+ * without a wait and launches only the front end the sample chose (awfm_gpu_ordered.hip: lookup prediction).  The front
+ * ends read the low half of the word as sampleAliveKernel's count. */
+__global__ void __launch_bounds__(256)
+    lookupPrepKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const unsigned fixedLen, const unsigned depth,
+                     const unsigned useNext, const unsigned long long numQueries, const unsigned samples,
+                     unsigned long long *__restrict__ aliveOut, unsigned long long *__restrict__ aliveNext,
+                     uint4 *__restrict__ zeroA, const unsigned vecsA, uint4 *__restrict__ zeroB, const unsigned vecsB,
+                     const SparseOut fill, unsigned long long *__restrict__ verdictHost, const unsigned searchNumber) {
+  const unsigned gid = blockIdx.x * 256u + threadIdx.x, gsize = gridDim.x * 256u;
+  for (unsigned i = gid; i < vecsA; i += gsize) zeroA[i] = make_uint4(0u, 0u, 0u, 0u);
+  for (unsigned i = gid; i < vecsB; i += gsize) zeroB[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (fill.count) { /* the list of hits (awfmGpuSearchHitsCompact): empty entries sort behind every k-mer */
+    for (unsigned i = gid; i < fill.cap; i += gsize) {
+      fill.kmers[i] = 0xFFFFFFFFu;
+      fill.ranges[i] = make_ulonglong2(1ull, 0ull);
+    }
+    if (gid == 0u) *fill.count = 0u;
+  }
+  if (gid == 0u) *aliveNext = 0ull;
+  const unsigned sampleBlocks = (samples + 255u) / 256u; /* uniform per workgroup from here */
+  if (blockIdx.x >= sampleBlocks) return;
+  bool alive = false;
+  if (gid < samples) {
+    const unsigned long long t = (unsigned long long)gid * (numQueries / samples);
+    unsigned long long codes = 0;
+    unsigned bad = 0;
+    decodeKmer(chars, t * fixedLen, fixedLen, codes, bad);
+    if (bad) {
+      alive = true;
+    } else {
+      const uint2 e = ((const uint2 *)ix.deepSeed)[codes & ((1ull << (2u * depth)) - 1ull)];
+      const unsigned length = ix.deepNext ? (e.y & 0xFFFFu) : e.y;
+      alive = length != 0u && (!useNext || ((e.y >> (16u + ((unsigned)(codes >> (2u * depth)) & 15u))) & 1u) != 0u);
+    }
+  }
+  __shared__ unsigned sAlive;
+  if (threadIdx.x == 0) sAlive = 0u;
+  __syncthreads();
+  const unsigned n = (unsigned)__popcll(__ballot(alive));
+  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&sAlive, n);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long old = atomicAdd(aliveOut, (1ull << 32) | (unsigned long long)sAlive);
+    if ((unsigned)(old >> 32) == sampleBlocks - 1u && verdictHost)
+      *(volatile unsigned long long *)verdictHost = ((unsigned long long)searchNumber << 32) | (unsigned long long)((unsigned)old + sAlive);
+  }
 }
 
 /* The same scan for the shared histogram hist[kShares][binsPad]: bucketStart as below (a bucket's sub-runs are contiguous,

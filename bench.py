@@ -479,6 +479,10 @@ def main():
         d_hit_ranges = torch.empty(list_cap * 2, dtype=torch.int64, device=dev)
         d_hit_off_c = torch.empty(list_cap + 1, dtype=torch.int64, device=dev)
         d_num_hits = torch.zeros(1, dtype=torch.int32, device=dev)
+        # the list as the search appends it (d_hit_kmers / d_hit_ranges) and in k-mer order (what every check reads):
+        # awfmGpuListLocateOnDevice makes the second from the first, with the hit offsets and the positions, in one launch
+        d_sorted_kmers = torch.empty(list_cap, dtype=torch.int32, device=dev)
+        d_sorted_ranges = torch.empty(list_cap * 2, dtype=torch.int64, device=dev)
     d_order_kmers = torch.empty(Q, dtype=torch.int32, device=dev) if have_order else None
     pos_buf = {"t": None}
 
@@ -493,6 +497,7 @@ def main():
                 self.ranges, self.counts, self.hit_off, self.scratch, self.order_kmers = d_ranges, d_counts, d_hit_off, d_scratch, d_order_kmers
                 if have_list:
                     self.hit_kmers, self.hit_ranges, self.hit_off_c, self.num_hits = d_hit_kmers, d_hit_ranges, d_hit_off_c, d_num_hits
+                    self.sorted_kmers, self.sorted_ranges = d_sorted_kmers, d_sorted_ranges
             else:
                 self.ranges, self.counts, self.hit_off = torch.empty_like(d_ranges), torch.empty_like(d_counts), torch.empty_like(d_hit_off)
                 self.scratch = torch.empty_like(d_scratch)
@@ -500,6 +505,7 @@ def main():
                 if have_list:
                     self.hit_kmers, self.hit_ranges = torch.empty_like(d_hit_kmers), torch.empty_like(d_hit_ranges)
                     self.hit_off_c, self.num_hits = torch.empty_like(d_hit_off_c), torch.zeros_like(d_num_hits)
+                    self.sorted_kmers, self.sorted_ranges = torch.empty_like(d_sorted_kmers), torch.empty_like(d_sorted_ranges)
             # a stream of its own for every lane, lane 0 included: torch's current stream is the null stream, which waits for
             # every other one and which the library cannot tell apart from another thread's (it records an event per call on it)
             self.torch_stream = torch.cuda.Stream()
@@ -554,9 +560,23 @@ def main():
         else:
             g.search_hits(p.chars_ptr, p.off_ptr, K, p.q, ln.ranges.data_ptr(), 0, ln.stream)
 
-    def offsets_part(p, form, ln=None):
-        """hit offsets on the device; returns (ranges, offsets, entries) the locate reads"""
+    # AWFM_BENCH_LIST_TAIL=0: round 4's tail of a list step (rank the list in a bitmap of the batch, scan, expand: three calls,
+    # seven launches) instead of awfmGpuListLocateOnDevice's one
+    list_tail = os.environ.get("AWFM_BENCH_LIST_TAIL", "1") != "0"
+
+    def sorted_list(ln):
+        """(k-mer numbers, ranges) of a lane's list in k-mer order"""
+        return (ln.sorted_kmers, ln.sorted_ranges) if list_tail else (ln.hit_kmers, ln.hit_ranges)
+
+    def offsets_part(p, form, ln=None, pos=None):
+        """hit offsets on the device; returns (ranges, offsets, entries) the locate reads.  The list form: the whole tail -- the
+        list in k-mer order, its offsets and, when `pos` is given, the positions -- in one call"""
         ln = ln or lanes[0]
+        if form == "list" and list_tail:
+            g.list_locate_on_device(ln.hit_kmers.data_ptr(), ln.hit_ranges.data_ptr(), p.cap, ln.num_hits.data_ptr(), p.q,
+                                    ln.sorted_kmers.data_ptr(), ln.sorted_ranges.data_ptr(), ln.hit_off_c.data_ptr(),
+                                    pos.numel() if pos is not None else 0, pos.data_ptr() if pos is not None else 0, ln.stream)
+            return ln.sorted_ranges, ln.hit_off_c, p.cap
         if form == "list":
             g.sort_hits_on_device(ln.hit_kmers.data_ptr(), ln.hit_ranges.data_ptr(), p.cap, ln.num_hits.data_ptr(), p.q, ln.stream)
             g.hit_offsets_on_device(0, ln.hit_ranges.data_ptr(), p.cap, ln.hit_off_c.data_ptr(), ln.scratch.data_ptr(), ln.stream)
@@ -609,7 +629,9 @@ def main():
         search_part(p, p.form, ln)
         if record:
             ev[1].record(ln.torch_stream)
-        if locate and not p.windowed:
+        if locate and not p.windowed and p.form == "list" and list_tail:
+            offsets_part(p, p.form, ln, ln.pos)
+        elif locate and not p.windowed:
             ranges, offsets, entries = offsets_part(p, p.form, ln)
             g.locate_on_device(ranges.data_ptr(), offsets.data_ptr(), entries, ln.pos.numel(), ln.pos.data_ptr(), ln.stream)
         elif locate:
@@ -651,7 +673,7 @@ def main():
             if p.form == "list":
                 assert int(ln.num_hits.item()) == p.listed, "the list's length changed between the probe and the timed steps"
                 total = int(ln.hit_off_c[p.cap].item())
-                assert ln.primary or (torch.equal(ln.hit_kmers[: p.listed], d_hit_kmers[: p.listed]) and torch.equal(ln.pos[: p.hits], pos_buf["t"][: p.hits])), \
+                assert ln.primary or (torch.equal(sorted_list(ln)[0][: p.listed], sorted_list(lanes[0])[0][: p.listed]) and torch.equal(ln.pos[: p.hits], pos_buf["t"][: p.hits])), \
                     "two lanes hold different results of the same batch"
             else:
                 total = int(ln.hit_off[p.q].item())
@@ -691,9 +713,10 @@ def main():
             return dense_pos
         if p.form == "list":
             m = p.listed
-            kmers = d_hit_kmers[:m].to(torch.int64)
+            list_kmers, list_ranges = sorted_list(lanes[0])
+            kmers = list_kmers[:m].to(torch.int64)
             assert m == 0 or bool((kmers[1:] > kmers[:-1]).all()), "the hit list is not in k-mer order"
-            assert m == p.cap or int(d_hit_kmers[m].item()) == -1, "an entry behind the list's length"
+            assert m == p.cap or int(list_kmers[m].item()) == -1, "an entry behind the list's length"
             lens = d_hit_off_c[1:m + 1] - d_hit_off_c[:m]
             d_counts[:q].zero_()
             d_counts[:q][kmers] = lens.to(torch.int32)
@@ -702,7 +725,7 @@ def main():
             dense = d_ranges[: 2 * q].view(q, 2)
             dense[:, 0] = 1
             dense[:, 1] = 0
-            dense[kmers] = d_hit_ranges.view(-1, 2)[:m]
+            dense[kmers] = list_ranges.view(-1, 2)[:m]
             assert int(d_hit_off[q].item()) == p.hits
             return pos
         # dense: ranges were written for the k-mers with hits only (awfmGpuSearchHitsSparse): "no hit" for the rest

@@ -215,6 +215,19 @@ enum AwFmReturnCode awfmGpuSortHits(AwFmGpuIndex *g, uint32_t *dHitKmers, struct
 enum AwFmReturnCode awfmGpuSortHitsOnDevice(AwFmGpuIndex *g, uint32_t *dHitKmers, struct AwFmSearchRange *dHitRanges,
                                             uint32_t capacity, const uint32_t *dNumHits, uint64_t numQueries, void *stream);
 
+/* The whole tail of a step whose results are the list, in one launch (lists of up to 2^18 entries; longer ones through the
+ * three calls above): the first min(*dNumHits, capacity) entries of the list awfmGpuSearchHitsCompact appended -- left as
+ * they are -- come out in k-mer order in dSortedKmers / dSortedRanges (entries beyond the hits: {0xFFFFFFFF, empty range}),
+ * dHitOffsets[0 .. capacity] are the hit offsets over the sorted list (every entry from the list's length on holds the
+ * total), and dPositions[0 .. capacityHits) the first capacityHits positions in that order (may be NULL: offsets only) --
+ * what awfmGpuSortHitsOnDevice + awfmGpuHitOffsetsOnDevice + awfmGpuLocateOnDevice leave, from seven dependent launches less
+ * (ref src/AwFmParallelSearch.c:315-365: the reference sizes and fills one list per k-mer on the host).  Nothing waits for
+ * the host; the sorted arrays must not be the unsorted ones. */
+enum AwFmReturnCode awfmGpuListLocateOnDevice(AwFmGpuIndex *g, const uint32_t *dHitKmers, const struct AwFmSearchRange *dHitRanges,
+                                              uint32_t capacity, const uint32_t *dNumHits, uint64_t numQueries, uint32_t *dSortedKmers,
+                                              struct AwFmSearchRange *dSortedRanges, uint64_t *dHitOffsets, uint64_t capacityHits,
+                                              uint64_t *dPositions, void *stream);
+
 /* -1 = automatic (default), 0 = never, 1 = whenever the ordered path applies */
 void awfmGpuIndexSetOrdered(AwFmGpuIndex *g, int mode);
 /* 1 when awfmGpuSearchHits would search such a batch in seed order on this image (reporting, bench.py) */
@@ -228,6 +241,14 @@ double awfmGpuLastOrderedKernelMs(AwFmGpuIndex *g);
  * ordered and searched; $AWFM_GPU_LOOKUP_FIRST=0 / 1: never / whenever it applies) -- the timed kernel is then
  * encodeLookupKernel */
 int awfmGpuLastOrderedKernelIsLookup(AwFmGpuIndex *g);
+/* Which front end(s) the last SAMPLED search on the image launched (reporting): 0 both -- the sample's verdict stays on the
+ * device and the kernels of the front end it does not choose return at once --, 1 the lookup kernel only, 2 the ordering
+ * passes and the ordered kernel only; -1: no sampled search yet.  1 and 2 happen when the verdict of an earlier search of
+ * the same k-mer length has reached the host (it is published in page-locked memory by the kernel that takes the sample;
+ * nothing waits for it): a stream of like batches then pays for one front end's launches, not two ($AWFM_GPU_LOOKUP_PREDICT=0:
+ * always both).  Either front end alone searches any batch correctly; a verdict that contradicts the mode its own search
+ * ran in switches the prediction off for the next 8, 16, ... searches. */
+int awfmGpuLastLookupFront(AwFmGpuIndex *g);
 /* with $AWFM_GPU_TIME_ORDERED: orderedSearchKernel's own bracket of the last search, whichever kernel was the dominant one
  * (after encodeLookupKernel it searched only the k-mers that kernel kept); < 0: none */
 double awfmGpuLastOrderedSearchKernelMs(AwFmGpuIndex *g);

@@ -859,12 +859,201 @@ def test_list_sorted_scanned_and_located_without_a_host_wait(oracle, awfm, requi
     ix.dealloc()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dense_sa", [False, True])
+@pytest.mark.parametrize("shape", ["sparse", "half", "clustered"])
+def test_list_tail_in_one_launch(oracle, awfm, require_gpu, shape, dense_sa):
+    """awfmGpuSearchHitsCompact -> awfmGpuListLocateOnDevice: the appended list comes out in k-mer order with its hit offsets
+    and positions from ONE kernel (each workgroup finds its own prefix: no scan, no scratch), with and without the full suffix
+    array, equal to the oracle's and to what the three calls it replaces leave; `clustered`: a stretch of 12 000 consecutive
+    k-mers that all occur, i.e. more entries in one workgroup's range than its LDS slots hold (sub-ranges); a position buffer
+    that is too small gets the first `capacity` hits and nothing behind them; offsets only when there is no buffer."""
+    import torch
+    n, K = 300000, 15
+    Q = 90011 if shape != "clustered" else 3_000_017
+    txt = synth.text(n + 3, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(11)
+    g.set_dense_sa(dense_sa)
+    assert g.has_dense_sa == dense_sa
+    if shape == "clustered":
+        q = synth.random_queries(21, Q, K).copy()
+        q[1_000_000:1_012_000] = synth.planted_queries(22, 12000, K, txt)
+        q[Q - 300:] = synth.planted_queries(23, 300, K, txt)  # ... and the very last k-mers of the batch
+    else:
+        m = int(Q * (0.02 if shape == "sparse" else 0.6))
+        q = np.concatenate([synth.random_queries(21, Q - m, K), synth.planted_queries(22, m, K, txt)])
+        q = q[np.random.default_rng(5).permutation(Q)]
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+    has = np.flatnonzero(cnt > 0)
+    oho, opos, _ = oi.batch_locate(sp[has], ep[has], threads=4)
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(chars).to(dev)
+    cap = len(has) + len(has) // 3 + 17
+    d_kmers = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_ranges = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+    d_num = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_skmers = torch.full((cap,), 5, dtype=torch.int32, device=dev)
+    d_sranges = torch.full((cap * 2,), 5, dtype=torch.int64, device=dev)
+    d_off = torch.full((cap + 1,), -3, dtype=torch.int64, device=dev)
+    for capacity_hits in (len(opos) + 100, max(len(opos) // 2, 1), 0):
+        d_pos = torch.full((len(opos) + 200,), -1, dtype=torch.int64, device=dev)
+        g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr())
+        before = (d_kmers.clone(), d_ranges.clone())
+        g.list_locate_on_device(d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr(), Q, d_skmers.data_ptr(), d_sranges.data_ptr(),
+                                d_off.data_ptr(), capacity_hits, d_pos.data_ptr() if capacity_hits else 0)
+        torch.cuda.synchronize()
+        assert torch.equal(before[0], d_kmers) and torch.equal(before[1], d_ranges), "the appended list was touched"
+        listed = int(d_num.item())
+        assert listed == len(has)
+        ids = d_skmers.cpu().numpy().view(np.uint32)
+        r = d_sranges.cpu().numpy().view(np.uint64).reshape(cap, 2)
+        assert np.array_equal(ids[:listed], has)
+        assert np.array_equal(r[:listed, 0], sp[has]) and np.array_equal(r[:listed, 1], ep[has])
+        assert np.all(ids[listed:] == 0xFFFFFFFF) and np.all(r[listed:, 0] > r[listed:, 1])
+        off = d_off.cpu().numpy().view(np.uint64)
+        assert np.array_equal(off[:listed + 1], oho) and np.all(off[listed:] == oho[-1])
+        pos = d_pos.cpu().numpy()
+        got = min(capacity_hits, len(opos))
+        assert np.array_equal(pos[:got].view(np.uint64), opos[:got])
+        assert np.all(pos[capacity_hits:] == -1), "written behind the capacity"
+    # a list that overflowed its capacity: the first `capacity` entries the search stored, in k-mer order
+    small = max(len(has) // 3, 1)
+    g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), small, d_num.data_ptr())
+    g.list_locate_on_device(d_kmers.data_ptr(), d_ranges.data_ptr(), small, d_num.data_ptr(), Q, d_skmers.data_ptr(), d_sranges.data_ptr(),
+                            d_off.data_ptr(), 0, 0)
+    torch.cuda.synchronize()
+    assert int(d_num.item()) == len(has)
+    stored = np.sort(d_kmers[:small].cpu().numpy().view(np.uint32))
+    assert np.array_equal(d_skmers[:small].cpu().numpy().view(np.uint32), stored) and np.all(np.isin(stored, has))
+    assert int(d_off[small].item()) == int(cnt[stored].sum())
+    g.destroy()
+    ix.dealloc()
+
+
+@pytest.mark.gpu
+def test_list_tail_of_a_long_list_takes_the_three_calls(oracle, awfm, require_gpu, monkeypatch):
+    """a list of more than 2^18 entries (and any list with $AWFM_GPU_LIST_TAIL=0) goes through copy + awfmGpuSortHitsOnDevice +
+    awfmGpuHitOffsetsOnDevice + awfmGpuLocateOnDevice inside awfmGpuListLocateOnDevice: the same arrays come out"""
+    import torch
+    n, K, Q = 300000, 14, 700_001
+    txt = synth.text(n + 5, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    q = synth.planted_queries(31, Q, K, txt).copy()
+    q[::3] = synth.random_queries(32, len(q[::3]), K)
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+    has = np.flatnonzero(cnt > 0)
+    assert len(has) > (1 << 18)
+    oho, opos, _ = oi.batch_locate(sp[has], ep[has], threads=4)
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(chars).to(dev)
+    for cap, knob in ((len(has) + 1000, None), (len(has) + 1000, "0")):
+        if knob is not None:
+            monkeypatch.setenv("AWFM_GPU_LIST_TAIL", knob)
+        d_kmers = torch.zeros(cap, dtype=torch.int32, device=dev)
+        d_ranges = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+        d_num = torch.zeros(1, dtype=torch.int32, device=dev)
+        d_skmers = torch.zeros(cap, dtype=torch.int32, device=dev)
+        d_sranges = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+        d_off = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
+        d_pos = torch.full((len(opos) + 8,), -1, dtype=torch.int64, device=dev)
+        g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr())
+        g.list_locate_on_device(d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr(), Q, d_skmers.data_ptr(), d_sranges.data_ptr(),
+                                d_off.data_ptr(), len(opos) + 8, d_pos.data_ptr())
+        torch.cuda.synchronize()
+        listed = int(d_num.item())
+        assert listed == len(has)
+        assert np.array_equal(d_skmers[:listed].cpu().numpy().view(np.uint32), has)
+        assert np.array_equal(d_off[:listed + 1].cpu().numpy().view(np.uint64), oho)
+        assert np.array_equal(d_pos[:len(opos)].cpu().numpy().view(np.uint64), opos)
+    g.destroy()
+    ix.dealloc()
+
+
+@pytest.mark.gpu
+def test_lookup_prediction_launches_one_front_end_and_keeps_the_results(oracle, awfm, require_gpu, monkeypatch):
+    """Round 5: a sampled search publishes its sample's verdict in page-locked host memory, and a later search of the same
+    k-mer length launches only the front end that verdict names (awfmGpuLastLookupFront: 0 both, 1 the lookup kernel alone
+    with what it cannot finish left to the general kernel, 2 the ordering passes + ordered kernel alone).  Either front end
+    alone must give every batch the oracle's counts and list -- the batch the prediction is wrong for included (k-mers drawn
+    from the text right behind random ones and the other way round) -- and a wrong prediction must switch it off for a while."""
+    import torch
+    for name in ("AWFM_GPU_LOOKUP_FIRST", "AWFM_GPU_LOOKUP_PREDICT", "AWFM_GPU_PREP_FUSED"):
+        monkeypatch.delenv(name, raising=False)
+    n, K, Q = 300000, 21, (1 << 20) + 5
+    txt = synth.text(n + 41, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(12)
+    dev = torch.device("cuda")
+    batches = {}
+    for name, q in (("random", synth.random_queries(9, Q, K).copy()), ("planted", synth.planted_queries(10, Q, K, txt).copy())):
+        q[::1000, 3] = ord("n")  # some for the general kernel
+        if name == "random":
+            q[5::64] = synth.planted_queries(11, len(q[5::64]), K, txt)  # and some hits
+        chars, offsets = synth.fixed_csr(q)
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+        batches[name] = (torch.from_numpy(chars).to(dev), sp, ep, cnt)
+    d_counts = torch.empty(Q, dtype=torch.int32, device=dev)
+    cap = Q
+    d_kmers = torch.zeros(cap, dtype=torch.int32, device=dev)
+    d_ranges = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+    d_num = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(name, listed):
+        d_chars, sp, ep, cnt = batches[name]
+        if listed:
+            g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr())
+            torch.cuda.synchronize()
+            m = int(d_num.item())
+            has = np.flatnonzero(cnt > 0)
+            assert m == len(has), (name, m, len(has))
+            ids = d_kmers[:m].cpu().numpy().view(np.uint32)
+            order = np.argsort(ids)
+            r = d_ranges[: 2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)[order]
+            assert np.array_equal(ids[order], has) and np.array_equal(r[:, 0], sp[has]) and np.array_equal(r[:, 1], ep[has]), name
+        else:
+            d_counts.fill_(7)
+            g.search_hits(d_chars.data_ptr(), 0, K, Q, 0, d_counts.data_ptr())
+            torch.cuda.synchronize()
+            assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt), name
+        return g.last_lookup_front()
+
+    fronts = [run("random", False), run("random", True), run("random", False), run("random", True)]
+    assert fronts[0] == 0 and fronts[2:] == [1, 1], fronts  # the first search has no verdict to go by; the third certainly has
+    assert g.last_ordered_kernel_is_lookup()
+    wrong = run("planted", False)  # predicted from the random batches: the lookup kernel alone, three quarters through the general kernel
+    assert wrong == 1
+    held = [run("planted", i % 2 == 1) for i in range(9)]
+    assert held[:8] == [0] * 8, held  # the miss switched the prediction off for eight searches
+    later = [run("planted", i % 2 == 0) for i in range(3)]
+    assert later[-1] == 2, (held, later)  # ... and then the ordered kernels alone
+    assert not g.last_ordered_kernel_is_lookup()
+    assert run("random", True) == 2  # (wrong again, the other way round: slower, the same list)
+    assert run("random", False) == 0
+    monkeypatch.setenv("AWFM_GPU_LOOKUP_PREDICT", "0")
+    assert [run("random", False), run("random", True)] == [0, 0]
+    g.destroy()
+    ix.dealloc()
+
+
 def test_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, monkeypatch):
     """Without $AWFM_GPU_LOOKUP_FIRST a batch of 2^20 k-mers or more is sampled (16384 k-mers at a fixed stride): random
     21-mers against a small text nearly all end at the deeper table -> encodeLookupKernel; k-mers drawn from the text all
     survive it -> the count + partition passes as before.  Counts against the oracle either way."""
     import torch
     monkeypatch.delenv("AWFM_GPU_LOOKUP_FIRST", raising=False)
+    monkeypatch.setenv("AWFM_GPU_LOOKUP_PREDICT", "0")  # every search by its own sample (the prediction: test_lookup_prediction_*)
     n, K, Q = 300000, 21, (1 << 20) + 5
     txt = synth.text(n + 41, n, synth.DNA_ALPHABET).copy()
     ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
