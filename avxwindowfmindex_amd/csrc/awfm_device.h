@@ -158,6 +158,17 @@ struct QueryRec {
 
 constexpr int kThreads = 256;
 
+/* A launch that carries HIP events on the kernel's own dispatch when it is given any (hipExtLaunchKernelGGL: an event recorded
+ * around a kernel is a packet of its own), and the plain launch otherwise: the extended launch with both events null still
+ * left the queue idle for 5-7 us in front of the kernel (round 5 traces of a 1.25 * 10^7-k-mer step: the only launches with a
+ * gap before them were the extended ones). */
+#define AWFM_LAUNCH_WITH_EVENTS(kernel, grid, block, lds, stream, startEvent, stopEvent, ...)                 \
+  do {                                                                                                        \
+    hipEvent_t start__ = (startEvent), stop__ = (stopEvent);                                                  \
+    if (start__ || stop__) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, start__, stop__, 0u, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                   \
+  } while (0)
+
 /* Sparse results (awfmGpuSearchHitsCompact): instead of a range / count under every query number, the k-mers with hits
  * are appended to a list {query number, range}, one returning atomic per wave instruction that has any (the order of the
  * list is whatever the waves make it: awfmGpuSortHits puts it in query order).  Entries beyond `cap` are counted, not
@@ -827,13 +838,11 @@ struct AwFmGpuIndex {
    * alone is correct for any batch; a verdict that contradicts the mode its own search ran in switches prediction off for
    * the next kPredictHoldoff searches.  Under orderMutex. */
   struct LookupPredict {
-    unsigned long long *verdictHost = nullptr; /* (search number << 32) | k-mers of its sample still alive */
-    unsigned searches = 0;                     /* sampled searches so far: the number of the last one */
-    struct Entry {
-      unsigned number = 0;
-      unsigned char front = 0; /* 0 both, 1 lookup only, 2 ordered only */
-      unsigned length = 0, samples = 0;
-    } ring[16];
+    /* (tag << 32) | k-mers of the sample still alive; tag = the search's number (22 bits, never 0) | the front end(s) it
+     * launched << 22 (0 both, 1 lookup only, 2 ordered only) | its k-mer length << 24 */
+    unsigned long long *verdictHost = nullptr;
+    unsigned searches = 0; /* the number of the last sampled search */
+    int lastFront = -1;    /* what it launched (reporting) */
     unsigned lastJudged = 0; /* the newest verdict that was compared with its own search's mode */
     unsigned holdoff = 0;      /* searches that still launch both front ends after a miss */
     unsigned holdoffNext = 8;  /* what the next miss sets it to (doubles per miss up to 1024, back to 8 after 64 good predictions) */

@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(256)
  * numbers are distinct, so a range of kListTailSlots numbers holds at most that many entries: a workgroup whose range
  * holds more (clustered hits) goes through it in sub-ranges of that width, re-reading the keys for each.  The last workgroup
  * knows the total and fills what lies behind the list. */
-constexpr unsigned kListTailThreads = 1024, kListTailSlots = 4096;
+constexpr unsigned kListTailThreads = 1024, kListTailSlots = 2048;
 constexpr unsigned kListTailMaxEntries = 1u << 18; /* longer lists: the three calls this kernel replaces (the tail is then no longer launch-bound) */
 template <bool DENSE>
 __global__ void __launch_bounds__(kListTailThreads)
@@ -293,7 +293,8 @@ __global__ void __launch_bounds__(kListTailThreads)
                    const unsigned cap, const unsigned long long numQueries, unsigned *__restrict__ outKmers,
                    ulonglong2 *__restrict__ outRanges, unsigned long long *__restrict__ hitOffsets, const unsigned long long capacityHits,
                    unsigned long long *__restrict__ positions, const unsigned *__restrict__ dense) {
-  __shared__ unsigned sKey[kListTailSlots], sIdx[kListTailSlots], sOrder[kListTailSlots];
+  __shared__ unsigned sKey[kListTailSlots], sOrder[kListTailSlots];
+  __shared__ ulonglong2 sRange[kListTailSlots];
   __shared__ unsigned long long sWave[kListTailThreads / 64], sRed[2][kListTailThreads / 64];
   __shared__ unsigned sMine;
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -305,18 +306,40 @@ __global__ void __launch_bounds__(kListTailThreads)
   if (tid == 0) sMine = 0u;
   __syncthreads();
   /* one pass over the list: entries below the range (count, hits), own entries into the slots */
+  /* (eight entries a thread and trip, all their loads requested before any is used: the pass is a chain of L2 latencies --
+   * one entry a trip took 13 us over the 9 * 10^3 entries of a shard's list, and would take 100 over the 7 * 10^4 of the
+   * whole batch's) */
   unsigned long long below = 0, belowHits = 0;
-  for (unsigned i = tid; i < n; i += kListTailThreads) {
-    const unsigned long long key = inKmers[i];
-    if (key < lo) {
-      const ulonglong2 r = inRanges[i];
-      below++;
-      belowHits += r.x <= r.y ? r.y - r.x + 1ull : 0ull;
-    } else if (key < hi) {
-      const unsigned at = atomicAdd(&sMine, 1u);
-      if (at < kListTailSlots) {
-        sKey[at] = (unsigned)key;
-        sIdx[at] = i;
+  constexpr unsigned kPer = 8;
+  const bool vec = ((unsigned long long)inKmers & 15ull) == 0ull;
+  const bool allRanges = n <= 16384u;
+  for (unsigned base = tid * kPer; base < n; base += kListTailThreads * kPer) {
+    unsigned long long key[kPer];
+    if (vec && base + kPer <= n) {
+      const uint4 a = *(const uint4 *)(inKmers + base), b = *(const uint4 *)(inKmers + base + 4u);
+      key[0] = a.x, key[1] = a.y, key[2] = a.z, key[3] = a.w;
+      key[4] = b.x, key[5] = b.y, key[6] = b.z, key[7] = b.w;
+    } else {
+#pragma unroll
+      for (unsigned j = 0; j < kPer; j++) key[j] = base + j < n ? (unsigned long long)inKmers[base + j] : ~0ull;
+    }
+    /* (the ranges of the entries below and inside the range; of a short list -- a shard's -- every range, requested beside
+     * the keys instead of behind them: one latency less) */
+    ulonglong2 r[kPer];
+#pragma unroll
+    for (unsigned j = 0; j < kPer; j++)
+      r[j] = (allRanges ? base + j < n : key[j] < hi) ? inRanges[base + j] : make_ulonglong2(1ull, 0ull);
+#pragma unroll
+    for (unsigned j = 0; j < kPer; j++) {
+      if (key[j] < lo) {
+        below++;
+        belowHits += r[j].x <= r[j].y ? r[j].y - r[j].x + 1ull : 0ull;
+      } else if (key[j] < hi) {
+        const unsigned at = atomicAdd(&sMine, 1u);
+        if (at < kListTailSlots) {
+          sKey[at] = (unsigned)key[j];
+          sRange[at] = r[j];
+        }
       }
     }
   }
@@ -352,7 +375,7 @@ __global__ void __launch_bounds__(kListTailThreads)
       if (r < m) {
         const unsigned j = sOrder[r];
         key = sKey[j];
-        range = inRanges[sIdx[j]];
+        range = sRange[j];
         len = range.x <= range.y ? range.y - range.x + 1ull : 0ull;
       }
       unsigned long long incl = len;
@@ -406,7 +429,7 @@ __global__ void __launch_bounds__(kListTailThreads)
           const unsigned at = atomicAdd(&sMine, 1u);
           if (at < kListTailSlots) { /* (more only when the list names a k-mer twice, which a search never does) */
             sKey[at] = (unsigned)key;
-            sIdx[at] = i;
+            sRange[at] = inRanges[i];
           }
         }
       }
@@ -1631,18 +1654,25 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     const size_t pairLds = superInLds ? (size_t)g->dev.numPairSuper * (kPairSuperStride * 4u) : 0u;
     DevIndex pairDev = g->dev;
     pairDev.pairSuperInLds = superInLds ? 1u : 0u;
+    /* steps after which an uncapped walk is parked for finishKernel to walk on (the hand-over holds 23 bits of steps);
+     * $AWFM_GPU_WALK_GIVE_UP: a small number, so that the tests reach that path on ordinary texts */
+    unsigned giveUp = (1u << kWalkStepBits) - 1u;
+    if (const char *env = getenv("AWFM_GPU_WALK_GIVE_UP")) {
+      const long v = atol(env);
+      if (v >= 1 && v < (long)giveUp) giveUp = (unsigned)v;
+    }
 #define AWFM_LOCP(P2, NR)                                                                                                    \
   do {                                                                                                                       \
     const unsigned grid__ = gridFor(th, g, walkKernel<false, 4, P2, NR, true>, walkThreads(true) / 4, pairLds, walkThreads(true)); \
     /* a short hit list: batches of 4 instead of 16 hits per lane group, when the grid has a group for every one */         \
     if (th <= (unsigned long long)grid__ * (walkThreads(true) / 4) * 4ull)                                                   \
-      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true, 1u>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos, totalOnDevice, stepCap); \
+      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true, 1u>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos, totalOnDevice, stepCap, giveUp); \
     else                                                                                                                     \
-      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos, totalOnDevice, stepCap); \
+      hipLaunchKernelGGL((walkKernel<false, 4, P2, NR, true>), dim3(grid__), dim3(walkThreads(true)), pairLds, s, pairDev, th, pos, totalOnDevice, stepCap, giveUp); \
   } while (0)
 #define AWFM_LOC3(AM, GG, P2, NR)                                                                                  \
   hipLaunchKernelGGL((walkKernel<AM, GG, P2, NR>), dim3(gridFor(th, g, walkKernel<AM, GG, P2, NR>, kThreads / GG)), \
-                     dim3(kThreads), 0, s, g->dev, th, pos, totalOnDevice, stepCap)
+                     dim3(kThreads), 0, s, g->dev, th, pos, totalOnDevice, stepCap, giveUp)
 #define AWFM_LOC(AM, GG)                                      \
   do {                                                        \
     if (pow2 && narrow) AWFM_LOC3(AM, GG, true, true);        \
@@ -1670,7 +1700,8 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     /* out-of-place: the final positions go to `out` (page-locked host memory in the pipeline): a smaller grid, so that
      * a kernel paced by the PCIe writes leaves the chip to whatever runs beside it */
     const unsigned finishGrid = out && out != pos ? (unsigned)g->numCUs * (getenv("AWFM_GPU_FINISH_BLOCKS") ? (unsigned)atoi(getenv("AWFM_GPU_FINISH_BLOCKS")) : 2u) : (unsigned)g->numCUs * 8u;
-    hipLaunchKernelGGL(finishKernel, dim3(finishGrid), dim3(256), 0, s, g->dev, th, (const unsigned long long *)pos, out ? out : pos, totalOnDevice);
+    hipLaunchKernelGGL(finishKernel, dim3(finishGrid), dim3(256), 0, s, g->dev, th, (const unsigned long long *)pos, out ? out : pos, totalOnDevice,
+                       stepCap ? 0u : (g->amino ? 2u : 1u), giveUp);
   }
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return AwFmSuccess;
@@ -1788,14 +1819,19 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
   }
   counter = chunkBuf + chunk; /* two words behind the chunk: parked entries, entries left */
   enum AwFmReturnCode rc = AwFmSuccess;
-  const unsigned stepCap = capped ? 32u * g->dev.saRatio : 0u;
+  /* every construction caps its walks and completes the parked ones by pointer jumping (round 5: the explicit one as well --
+   * awfmGpuIndexSetDenseSa, $AWFM_GPU_DENSE_SA=1 -- which used to walk every position to the end: 566 s for a text with long
+   * runs); `capped` = false now only says what happens when the parked walks cannot be kept: the array that was asked for
+   * is then built by walking to the end, the automatic one is dropped */
+  const bool explicitBuild = !capped;
+  unsigned stepCap = 32u * g->dev.saRatio;
   auto walkAll = [&]() { /* every position walked (capped: parked walks counted, and kept where there is a `park`) */
     if (hipMemset(counter, 0, 16) != hipSuccess) rc = AwFmGeneralFailure;
     for (unsigned long long first = 0; first < n && rc == AwFmSuccess; first += chunk) {
       const unsigned long long count = n - first < chunk ? n - first : chunk;
       hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, first, count);
       rc = launchLocate(g, count, chunkBuf, (hipStream_t)0, nullptr, nullptr, stepCap);
-      if (capped)
+      if (stepCap)
         hipLaunchKernelGGL(narrowParkKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const unsigned long long *)chunkBuf, count,
                            dense + first, park ? park + first : (unsigned long long *)nullptr, counter);
       else
@@ -1805,21 +1841,29 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
     if (hipDeviceSynchronize() != hipSuccess) rc = AwFmGeneralFailure;
   };
   walkAll();
-  if (rc == AwFmSuccess && capped) {
+  bool jumping = rc == AwFmSuccess;
+  if (jumping) {
     unsigned long long parked = 0, left = 0;
     if (hipMemcpy(&parked, counter, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
     if (rc == AwFmSuccess && parked != 0) {
       /* (the usual text parks nothing and never pays for this: 8 bytes per position, and the walks once more to fill them) */
-      if (hipMalloc((void **)&park, n * 8) != hipSuccess) { /* no room to park walks: no automatic array */
+      if (hipMalloc((void **)&park, n * 8) != hipSuccess) { /* no room to park walks */
         (void)hipGetLastError();
-        (void)hipFree(chunkBuf);
-        (void)hipFree(dense);
-        return AwFmSuccess;
+        park = nullptr;
+        if (!explicitBuild) { /* no automatic array */
+          (void)hipFree(chunkBuf);
+          (void)hipFree(dense);
+          return AwFmSuccess;
+        }
+        stepCap = 0u; /* the array was asked for: every walk to its sample, however long (exact: finishKernel resumes) */
+        walkAll();
+        jumping = false;
+      } else {
+        walkAll();
+        if (rc == AwFmSuccess && hipMemcpy(&parked, counter, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
       }
-      walkAll();
-      if (rc == AwFmSuccess && hipMemcpy(&parked, counter, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
     }
-    left = parked;
+    left = jumping ? parked : 0;
     unsigned rounds = 0;
     for (; rc == AwFmSuccess && left != 0 && rounds < 64u; rounds++) {
       if (hipMemset(counter + 1, 0, 8) != hipSuccess) rc = AwFmGeneralFailure;
@@ -1849,7 +1893,7 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
 }
 
 /* $AWFM_GPU_DENSE_SA=0|1 on an image that was just created or adopted (no lanes, nobody else holds it); unset: automatic.
- * Automatic: an image far beyond the caches (>= 2^28 positions, below 2^32: 32-bit entries) whose suffix array is sampled
+ * Automatic: an image beyond the caches (>= 2^26 positions, below 2^32: 32-bit entries) whose suffix array is sampled
  * gets the full one when four times its size is free on the device -- 12.4 GB of 288 for a GRCh38-sized image, computed
  * by the LF-walk kernel itself from the sampled array (0.3 s).  A locate is then one gather per hit instead of a chain
  * of ~ratio dependent block reads plus the sample: 10^8 planted 21-mers 18.1 -> 9.7 ms per step, and the longest chain of
@@ -1862,7 +1906,9 @@ static enum AwFmReturnCode applyDenseSaFromEnv(AwFmGpuIndex *g) {
     want = automatic = g->dev.saRatio > 1u;
   } else if (env) {
     want = atoi(env) != 0;
-  } else if (g->dev.bwtLength >= (1ull << 28) && g->dev.bwtLength < (1ull << 32) && g->dev.saRatio > 1u) {
+  } else if (g->dev.bwtLength >= (1ull << 26) && g->dev.bwtLength < (1ull << 32) && g->dev.saRatio > 1u) {
+    /* (round 5: from 2^26 positions instead of 2^28 -- a Swiss-Prot-sized amino image, 0.8 GB of entries: the LF walk of the
+     * few hits of a shard's list was a chain of 130 us, a third of the shard's step) */
     size_t freeBytes = 0, totalBytes = 0;
     DeviceGuard guard(g->device);
     if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) want = freeBytes / 4u >= g->dev.bwtLength * 4ull + (1ull << 31);

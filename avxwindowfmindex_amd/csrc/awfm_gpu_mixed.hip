@@ -40,7 +40,7 @@ hipError_t awfmGpuLaunchMixedLookup(const AwFmGpuIndex *g, hipStream_t s, hipEve
   const unsigned long long rounds = (nq + 1023ull) / 1024ull;
   unsigned grid = (unsigned)g->numCUs * (unsigned)perCU;
   if (rounds < grid) grid = (unsigned)rounds;
-  hipExtLaunchKernelGGL(mixedLookupSearchKernel, dim3(grid ? grid : 1u), dim3(256), (unsigned)lds, s, start, stop, 0u, dev,
+  AWFM_LAUNCH_WITH_EVENTS(mixedLookupSearchKernel, dim3(grid ? grid : 1u), dim3(256), (unsigned)lds, s, start, stop, dev,
                         (const uint2 *)lengthTable, dChars, off, nq, useNext, sampleAlive, chooseOf, rng, dCounts, out, leftover, leftoverCount,
                         kept);
   return hipGetLastError();

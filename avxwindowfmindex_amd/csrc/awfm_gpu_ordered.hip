@@ -102,8 +102,8 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
     skip.sampleAlive = skipSampleAlive;
     skip.samples = skipSamples;
   }
-  hipExtLaunchKernelGGL((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET, LIST>), dim3(grid ? grid : 1u), dim3(threads), (unsigned)lds, s,
-                        timed ? g->orderTiming[2] : nullptr, timed ? g->orderTiming[3] : nullptr, 0u, dev, recs,
+  AWFM_LAUNCH_WITH_EVENTS((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET, LIST>), dim3(grid ? grid : 1u), dim3(threads), (unsigned)lds, s,
+                        timed ? g->orderTiming[2] : nullptr, timed ? g->orderTiming[3] : nullptr, dev, recs,
                         keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
                         getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0, touch ? *touch : OrderTouch(), bucketStart,
                         bucketFmt, sparse ? *sparse : SparseOut(),
@@ -151,7 +151,7 @@ enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t 
    * kernel over the tail of the order */
   const unsigned grid = residentGrid(g, searchKernel<false, 4, VARLEN, false, NARROW, true>);
   /* the last kernel of the search: it carries the event that says the scratch slot is free again */
-  hipExtLaunchKernelGGL((searchKernel<false, 4, VARLEN, false, NARROW, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, 0u,
+  AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, VARLEN, false, NARROW, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent,
                         g->dev, dChars, off, len, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)recs,
                         COMPACT ? 8u : (unsigned)sizeof(QueryRec), COMPACT ? 0u : (unsigned)offsetof(QueryRec, index), nq,
                         generalCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u);
@@ -181,7 +181,7 @@ enum AwFmReturnCode launchBucketed(AwFmGpuIndex *g, hipStream_t s, const uint8_t
   /* the last bucket: k-mers with ambiguity characters; a record of it is the query number alone */
   const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, NARROW, true>);
   /* the last kernel of the search: it carries the event that says the scratch slot is free again */
-  hipExtLaunchKernelGGL((searchKernel<false, 4, false, false, NARROW, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, 0u,
+  AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, false, false, NARROW, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent,
                         g->dev, dChars, (const unsigned long long *)nullptr, len, nq, rng, dCounts, (unsigned long long *)nullptr,
                         (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
@@ -387,8 +387,7 @@ extern "C" int awfmGpuLastLookupFront(AwFmGpuIndex *g) {
   if (!g) return -1;
   std::lock_guard<std::mutex> lock(g->orderMutex);
   const AwFmGpuIndex::LookupPredict &p = g->predict;
-  if (p.searches == 0u) return -1;
-  return (int)p.ring[p.searches % 16u].front;
+  return p.searches == 0u ? -1 : p.lastFront;
 }
 
 extern "C" int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets, uint32_t fixedLength, uint64_t numQueries) {
@@ -540,7 +539,7 @@ static void launchEncodeLookupAt(unsigned len, unsigned grid, size_t lds, hipStr
                                  unsigned *numbers, unsigned *shareCount, unsigned *hist, unsigned binsPad,
                                  const unsigned *sampleAlive, unsigned samples, hipEvent_t start, hipEvent_t stop) {
   if (len == K)
-    hipExtLaunchKernelGGL((encodeLookupKernel<K>), dim3(grid), dim3(256), (unsigned)lds, s, start, stop, 0u, dev, dChars, fmt, useNext, nq, codes,
+    AWFM_LAUNCH_WITH_EVENTS((encodeLookupKernel<K>), dim3(grid), dim3(256), (unsigned)lds, s, start, stop, dev, dChars, fmt, useNext, nq, codes,
                           numbers, shareCount, hist, binsPad, sampleAlive, samples);
   else if constexpr (K > 1u)
     launchEncodeLookupAt<K - 1u>(len, grid, lds, s, dev, dChars, fmt, useNext, nq, codes, numbers, shareCount, hist, binsPad, sampleAlive, samples,
@@ -555,7 +554,7 @@ static void launchLookupSearchAt(unsigned len, unsigned grid, size_t lds, hipStr
                                  const unsigned *sampleAlive, unsigned samples, ulonglong2 *rng, unsigned *dCounts,
                                  const SparseOut &sparse, unsigned *keptCounters, hipEvent_t start, hipEvent_t stop) {
   if (len == K)
-    hipExtLaunchKernelGGL((lookupSearchKernel<K>), dim3(grid), dim3(256), (unsigned)lds, s, start, stop, 0u, dev, dChars, fmt, useNext, nq, codes,
+    AWFM_LAUNCH_WITH_EVENTS((lookupSearchKernel<K>), dim3(grid), dim3(256), (unsigned)lds, s, start, stop, dev, dChars, fmt, useNext, nq, codes,
                           numbers, shareCount, hist, binsPad, sampleAlive, samples, rng, dCounts, sparse, keptCounters);
   else if constexpr (K > 1u)
     launchLookupSearchAt<K - 1u>(len, grid, lds, s, dev, dChars, fmt, useNext, nq, codes, numbers, shareCount, hist, binsPad, sampleAlive, samples,
@@ -564,7 +563,7 @@ static void launchLookupSearchAt(unsigned len, unsigned grid, size_t lds, hipStr
 
 /* ---- lookup prediction (AwFmGpuIndex::LookupPredict) ---- */
 enum { kFrontBoth = 0, kFrontLookupOnly = 1, kFrontOrderedOnly = 2 };
-constexpr unsigned kPredictHoldoff = 8;
+constexpr unsigned kPredictHoldoff = 8, kPredictSamples = 16384, kPredictNumberMask = (1u << 22) - 1u;
 /* which front end(s) a sampled search of fixed-length k-mers launches, from the newest verdict that has reached the host
  * (nothing waits for one); the caller holds orderMutex.  $AWFM_GPU_LOOKUP_PREDICT=0: always both (round 4). */
 static int predictFront(AwFmGpuIndex *g, unsigned fixedLength) {
@@ -572,20 +571,21 @@ static int predictFront(AwFmGpuIndex *g, unsigned fixedLength) {
   if (const char *env = getenv("AWFM_GPU_LOOKUP_PREDICT"))
     if (atoi(env) == 0) return kFrontBoth;
   if (!p.verdictHost) return kFrontBoth;
+  /* the newest verdict: {tag of its search, k-mers of its sample alive}; the tag says what the host needs to know about that
+   * search -- its number, the front end(s) it launched, its k-mer length -- however long ago it was enqueued */
   const unsigned long long v = *(volatile unsigned long long *)p.verdictHost;
-  const unsigned number = (unsigned)(v >> 32), alive = (unsigned)v;
+  const unsigned tag = (unsigned)(v >> 32), alive = (unsigned)v;
+  const unsigned number = tag & kPredictNumberMask, front = (tag >> 22) & 3u, length = (tag >> 24) & 63u;
   if (number == 0u) return kFrontBoth;
-  const AwFmGpuIndex::LookupPredict::Entry &e = p.ring[number % 16u];
-  if (e.number != number || e.samples == 0u) return kFrontBoth; /* older than the ring remembers */
-  const bool lookup = alive * 4u < e.samples; /* lookupChosen's rule */
+  const bool lookup = alive * 4u < kPredictSamples; /* lookupChosen's rule */
   if (number != p.lastJudged) {
     p.lastJudged = number;
-    if ((e.front == kFrontLookupOnly && !lookup) || (e.front == kFrontOrderedOnly && lookup)) {
+    if ((front == kFrontLookupOnly && !lookup) || (front == kFrontOrderedOnly && lookup)) {
       /* a stream whose batches keep changing character: every miss doubles the searches that launch both front ends */
       p.holdoff = p.holdoffNext;
       p.holdoffNext = p.holdoffNext < 1024u ? 2u * p.holdoffNext : 1024u;
       p.agreed = 0;
-    } else if (e.front != kFrontBoth && ++p.agreed >= 64u) {
+    } else if (front != kFrontBoth && ++p.agreed >= 64u) {
       p.holdoffNext = kPredictHoldoff;
     }
   }
@@ -593,8 +593,16 @@ static int predictFront(AwFmGpuIndex *g, unsigned fixedLength) {
     p.holdoff--;
     return kFrontBoth;
   }
-  if (e.length != fixedLength) return kFrontBoth;
+  if (length != fixedLength) return kFrontBoth;
   return lookup ? kFrontLookupOnly : kFrontOrderedOnly;
+}
+/* the tag of the next sampled search (never 0 in its number: "no verdict yet") */
+static unsigned predictTag(AwFmGpuIndex *g, int front, unsigned fixedLength) {
+  AwFmGpuIndex::LookupPredict &p = g->predict;
+  p.searches = (p.searches + 1u) & kPredictNumberMask;
+  if (p.searches == 0u) p.searches = 1u;
+  p.lastFront = front;
+  return p.searches | ((unsigned)front << 22) | ((fixedLength & 63u) << 24);
 }
 
 /* fillNoHitKernel -> encodeCodes4Kernel -> bucketScanSharesKernel -> partitionKernel -> orderedSearchKernel<BUCKET> ->
@@ -687,14 +695,10 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
       zeroB = (uint4 *)(w + kKeptAt);
       vecsB = kFusedCounters * 64u / 16u;
     }
-    const unsigned number = ++predict.searches ? predict.searches : ++predict.searches; /* never 0: "no verdict yet" */
-    AwFmGpuIndex::LookupPredict::Entry &entry = predict.ring[number % 16u];
-    entry.number = number;
-    entry.front = (unsigned char)front;
-    entry.length = fixedLength;
-    entry.samples = kSamples;
+    static_assert(kSamples == kPredictSamples, "the verdict is judged against the sample's size");
+    const unsigned number = predictTag(g, front, fixedLength);
     const unsigned prepGrid = front == kFrontLookupOnly && !(sparse && sparse->count) ? kSamples / 256u : 2u * (kSamples / 256u);
-    hipLaunchKernelGGL(lookupPrepKernel, dim3(prepGrid), dim3(256), 0, s, g->dev, dChars, fixedLength, depth, useNext, nq, kSamples, aliveOut,
+    hipLaunchKernelGGL(lookupPrepKernel<false>, dim3(prepGrid), dim3(256), 0, s, g->dev, dChars, fixedLength, depth, useNext, nq, kSamples, aliveOut,
                        aliveNext, zeroA, vecsA, zeroB, vecsB, sparse && sparse->count ? *sparse : SparseOut(), predict.verdictHost, number);
     BUCKET_TRY(hipGetLastError());
     g->orderSlot[g->orderCur].prepParity = 1 - parity;
@@ -778,7 +782,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
     enum AwFmReturnCode rc = AwFmSuccess;
     if (!packed) {
       const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, true, true>);
-      hipExtLaunchKernelGGL((searchKernel<false, 4, false, false, true, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, 0u,
+      AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, false, false, true, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent,
                             g->dev, dChars, (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
                             (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u);
       if (hipGetLastError() != hipSuccess) rc = AwFmGeneralFailure;
@@ -1197,46 +1201,85 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
   AMINO_TRY(orderBeginSlot(g, s));
   if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
   uint8_t *w = (uint8_t *)g->dOrder;
-  unsigned *sampleWord = (unsigned *)w, *leftoverCount = (unsigned *)(w + 64), *kept = (unsigned *)(w + 256);
+  unsigned *leftoverCount = (unsigned *)(w + 64), *kept = (unsigned *)(w + 256);
   unsigned long long *leftover = (unsigned long long *)(w + listAt);
-  AMINO_TRY(hipMemsetAsync(w, 0, kCounterBytes, s));
-  AMINO_TRY(fillSparseList(sparse, s));
+  /* round 5, as the nucleotide bucketed search: the counters zeroed, the list pre-filled and the sample taken by ONE launch
+   * (lookupPrepKernel<true>; the sample's two words at bytes 0 and 128 of the counter block), and only the kernel an earlier
+   * search's sample named when its verdict has reached the host (predictFront: 1 = this kernel, 2 = the general kernel) */
+  const char *prepEnv = getenv("AWFM_GPU_PREP_FUSED");
+  const bool prepFused = !forced && !(prepEnv && atoi(prepEnv) == 0);
+  AwFmGpuIndex::LookupPredict &predict = g->predict;
+  if (prepFused && !predict.verdictHost) {
+    if (hipHostMalloc((void **)&predict.verdictHost, 64, hipHostMallocDefault) == hipSuccess) {
+      memset(predict.verdictHost, 0, 64);
+    } else {
+      (void)hipGetLastError();
+      predict.verdictHost = nullptr;
+    }
+  }
+  const int front = prepFused ? predictFront(g, fixedLength) : kFrontBoth;
+  const unsigned *sampleAlive = nullptr;
+  unsigned *sampleWord = (unsigned *)w;
+  if (prepFused) {
+    int parity = g->orderPrevParity;
+    if (parity < 0) {
+      AMINO_TRY(hipMemsetAsync(w, 0, 256, s));
+      parity = 0;
+    }
+    unsigned long long *aliveOut = (unsigned long long *)(w + 128u * (unsigned)parity);
+    unsigned long long *aliveNext = (unsigned long long *)(w + 128u * (unsigned)(1 - parity));
+    static_assert(kSamples == kPredictSamples, "the verdict is judged against the sample's size");
+    const unsigned number = predictTag(g, front, fixedLength);
+    hipLaunchKernelGGL(lookupPrepKernel<true>, dim3(sparse && sparse->count ? 2u * (kSamples / 256u) : kSamples / 256u), dim3(256), 0, s, g->dev, dChars,
+                       fixedLength, g->dev.deepK, 0u, nq, kSamples, aliveOut, aliveNext, (uint4 *)(w + 64), 64u / 16u, (uint4 *)(w + 256),
+                       (unsigned)(kFusedCounters * 64u / 16u), sparse && sparse->count ? *sparse : SparseOut(), predict.verdictHost, number);
+    AMINO_TRY(hipGetLastError());
+    g->orderSlot[g->orderCur].prepParity = 1 - parity;
+    sampleWord = (unsigned *)aliveOut;
+    if (front == kFrontBoth) sampleAlive = sampleWord;
+  } else {
+    AMINO_TRY(hipMemsetAsync(w, 0, kCounterBytes, s));
+    AMINO_TRY(fillSparseList(sparse, s));
+    if (!forced) {
+      hipLaunchKernelGGL(aminoSampleAliveKernel, dim3(kSamples / 256u), dim3(256), 0, s, g->dev, dChars, fixedLength, nq, kSamples, sampleWord);
+      AMINO_TRY(hipGetLastError());
+      sampleAlive = sampleWord;
+    }
+  }
   if (!sparse) {
     hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
                        rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
     AMINO_TRY(hipGetLastError());
   }
-  const unsigned *sampleAlive = nullptr;
-  if (!forced) {
-    hipLaunchKernelGGL(aminoSampleAliveKernel, dim3(kSamples / 256u), dim3(256), 0, s, g->dev, dChars, fixedLength, nq, kSamples, sampleWord);
-    AMINO_TRY(hipGetLastError());
-    sampleAlive = sampleWord;
-  }
-  g->orderLookup = forced ? 1 : 2;
+  const bool lookupRuns = !(prepFused && front == kFrontOrderedOnly), generalRuns = !forced && !(prepFused && front == kFrontLookupOnly);
+  g->orderLookup = sampleAlive ? 2 : (lookupRuns ? 1 : 0);
   g->orderSampleAt = sampleWord;
   g->orderSamples = kSamples;
   g->orderLookupFused = true;
   g->orderFusedKeptAt = kept;
   g->orderKeptAt = leftoverCount;
   const SparseOut out = sparse ? *sparse : SparseOut();
-  const unsigned long long rounds = (nq + 1023ull) / 1024ull; /* a workgroup takes 1024 k-mers a round */
-  unsigned grid = residentGrid(g, aminoLookupSearchKernel<10u>);
-  if (rounds < grid) grid = (unsigned)rounds;
-  launchAminoLookupAt<kMaxLength>(fixedLength, grid ? grid : 1u, s, g->dev, dChars, nq, sampleAlive, kSamples, rng, dCounts, out, leftover, leftoverCount, kept);
-  AMINO_TRY(hipGetLastError());
-  if (!forced) { /* the whole batch through the general kernel when the sample says so (it returns at once otherwise) */
+  if (lookupRuns) {
+    const unsigned long long rounds = (nq + 1023ull) / 1024ull; /* a workgroup takes 1024 k-mers a round */
+    unsigned grid = residentGrid(g, aminoLookupSearchKernel<10u>);
+    if (rounds < grid) grid = (unsigned)rounds;
+    launchAminoLookupAt<kMaxLength>(fixedLength, grid ? grid : 1u, s, g->dev, dChars, nq, sampleAlive, kSamples, rng, dCounts, out, leftover, leftoverCount, kept);
+    AMINO_TRY(hipGetLastError());
+  }
+  if (generalRuns) { /* the whole batch through the general kernel when the sample says so (it returns at once otherwise) */
     const unsigned full = residentGrid(g, searchKernel<true, 2, false, false, true>);
     hipLaunchKernelGGL((searchKernel<true, 2, false, false, true>), dim3(full), dim3(kThreads), 0, s, g->dev, dChars,
                        (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
                        (const unsigned char *)nullptr, 0u, 0u, 0ull, (const unsigned *)nullptr, out, sampleAlive, kSamples);
     AMINO_TRY(hipGetLastError());
   }
-  /* what the lookup kernel left: the last *leftoverCount records of the list */
-  const unsigned tail = residentGrid(g, searchKernel<true, 2, false, false, true, true>);
-  hipLaunchKernelGGL((searchKernel<true, 2, false, false, true, true>), dim3(tail), dim3(kThreads), 0, s, g->dev, dChars,
-                     (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
-                     (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out, (const unsigned *)nullptr, 0u);
-  AMINO_TRY(hipGetLastError());
+  if (lookupRuns) { /* what the lookup kernel left: the last *leftoverCount records of the list */
+    const unsigned tail = residentGrid(g, searchKernel<true, 2, false, false, true, true>);
+    hipLaunchKernelGGL((searchKernel<true, 2, false, false, true, true>), dim3(tail), dim3(kThreads), 0, s, g->dev, dChars,
+                       (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
+                       (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out, (const unsigned *)nullptr, 0u);
+    AMINO_TRY(hipGetLastError());
+  }
   AMINO_TRY(orderEndSlot(g, s));
 #undef AMINO_TRY
   return 1;
@@ -1666,7 +1709,7 @@ extern "C" enum AwFmReturnCode awfmGpuSortHitsOnDevice(AwFmGpuIndex *g, uint32_t
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   /* the last kernel carries the gate's event as its stop event */
   const bool eager = !(gateLazy(s) && !getenv("AWFM_GPU_EAGER_EVENTS"));
-  hipExtLaunchKernelGGL(rankPlaceKernel, dim3(listGrid), dim3(256), 0, s, nullptr, eager ? g->sparseGate.done : nullptr, 0, (const unsigned *)tmpKmers,
+  AWFM_LAUNCH_WITH_EVENTS(rankPlaceKernel, dim3(listGrid), dim3(256), 0, s, nullptr, eager ? g->sparseGate.done : nullptr, (const unsigned *)tmpKmers,
                         (const ulonglong2 *)tmpRanges, (const unsigned *)dNumHits, (unsigned)capacity, (unsigned long long)numQueries,
                         (const unsigned long long *)bitmap, (const unsigned *)blockCount, (unsigned *)dHitKmers, (ulonglong2 *)dHitRanges);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);

@@ -56,6 +56,62 @@ __device__ __forceinline__ unsigned long long finishPosition(const DevIndex &ix,
   return v;
 }
 
+/* One LF step by ONE thread (ref src/AwFmSearch.c:369-427, src/AwFmOccurrence.c:170-217): the slow path that takes a walk on
+ * from where walkKernel gave it up (finishKernel).  Nothing from LDS: the superblock bases and the prefix sums are read where
+ * they live; `amino`: the image's alphabet. */
+__device__ inline unsigned long long lfStepSerial(const DevIndex &ix, const bool amino, const unsigned long long p) {
+  const unsigned long long blk = p >> kBlockShift;
+  const unsigned local = (unsigned)p & kBlockMask, slice = local >> 5, bit = local & 31u;
+  if (!amino) {
+    Piece pc[kSlices];
+    for (unsigned k = 0; k < kSlices; k++) pc[k] = *(const Piece *)(ix.blocks + (blk * kSlices + k));
+    unsigned code = 0;
+    for (unsigned k = 0; k < kSlices; k++)
+      if (k == slice) code = ((pc[k].x >> bit) & 1u) | (((pc[k].y >> bit) & 1u) << 1) | (((pc[k].z >> bit) & 1u) << 2);
+    const unsigned letter = (0x00152435u >> (4u * code)) & 7u; /* code -> index {5,3,4,2,5,1,0,0}, ref src/AwFmLetter.c:49-53 */
+    if (letter == 5u) return 0ull;                             /* sentinel: ref src/AwFmSearch.c:384-386 */
+    const unsigned safe = letter < 5u ? letter : 0u;
+    const PlaneSel3 sel = nucPlaneSel(safe);
+    unsigned n = 0;
+    unsigned long long acgt = 0, mine = 0;
+    for (unsigned k = 0; k < kSlices; k++) {
+      n += __popc(nucOccSlice(pc[k], sel) & sliceMask(local, k));
+      acgt += pc[k].w;
+      if (k == safe) mine = pc[k].w;
+    }
+    const unsigned long long sb = blk >> (ix.nucSuperShift - kBlockShift);
+    unsigned long long base;
+    if (safe < 4u) {
+      base = mine + ix.super[sb * 4ull + safe];
+    } else { /* X: everything before the block that is not a,c,g,t or the sentinel */
+      acgt += ix.super[sb * 4ull] + ix.super[sb * 4ull + 1ull] + ix.super[sb * 4ull + 2ull] + ix.super[sb * 4ull + 3ull];
+      const unsigned long long before = blk << kBlockShift;
+      base = before - acgt - (ix.sentinelPos < before ? 1ull : 0ull);
+    }
+    return ix.prefixSums[safe] + base + n - 1ull;
+  }
+  Piece lo[kSlices], hi[kSlices];
+  for (unsigned k = 0; k < kSlices; k++) {
+    lo[k] = *(const Piece *)(ix.blocks + (blk * kSlices + k) * 2ull);
+    hi[k] = *(const Piece *)(ix.blocks + (blk * kSlices + k) * 2ull + 1ull);
+  }
+  unsigned code = 0;
+  for (unsigned k = 0; k < kSlices; k++)
+    if (k == slice)
+      code = ((lo[k].x >> bit) & 1u) | (((lo[k].y >> bit) & 1u) << 1) | (((lo[k].z >> bit) & 1u) << 2) | (((lo[k].w >> bit) & 1u) << 3) |
+             (((hi[k].x >> bit) & 1u) << 4);
+  const unsigned letter = kAminoTables.letterOfCode[code];
+  if (letter == 21u) return 0ull; /* sentinel: ref src/AwFmSearch.c:414-416 */
+  const unsigned safe = letter < 21u ? letter : 0u;
+  const unsigned pm = kAminoTables.planeMask[safe];
+  unsigned n = 0, count16 = 0;
+  for (unsigned k = 0; k < kSlices; k++) {
+    n += __popc(aminoOccSlice(lo[k], hi[k], pm & 0xFFu, pm >> 8) & sliceMask(local, k));
+    if (k == safe / 6u) count16 = aminoCount16(hi[k], safe % 6u);
+  }
+  return ix.prefixSums[safe] + ix.super[(p >> kAminoSuperShift) * kAminoSuperStride + safe] + count16 + n - 1ull;
+}
+
 /* workgroup size: 512 threads for the pair variant, whose LDS copy of the pair image's superblock bases (24 KB for a
  * GRCh38-sized index) would otherwise limit a CU to 6 workgroups of 256 */
 constexpr int walkThreads(bool pair) { return pair ? 512 : kThreads; }
@@ -67,7 +123,8 @@ constexpr int walkThreads(bool pair) { return pair ? 512 : kThreads; }
 template <bool AMINO, int G, bool POW2, bool NARROW, bool PAIR = false, unsigned PERLANE = 4u>
 __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80)))
     walkKernel(const DevIndex ix, unsigned long long totalHits, unsigned long long *__restrict__ positions,
-               const unsigned long long *__restrict__ totalOnDevice = nullptr, const unsigned stepCap = 0u) {
+               const unsigned long long *__restrict__ totalOnDevice = nullptr, const unsigned stepCap = 0u,
+               const unsigned giveUpAfter = (1u << kWalkStepBits) - 1u) {
   static_assert(!PAIR || (!AMINO && G == 4), "pair steps: nucleotide images, 4 lanes per hit");
   /* the number of hits may still be on the device when the kernel is launched (awfmGpuLocateOnDevice: the total of the
    * scan, never read by the host); totalHits is then the capacity of `positions` */
@@ -100,7 +157,11 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
    * many steps is given up -- parked: kWalkParked, where it stands and how far it came -- rather than followed for up to 2^23 steps: in a text
    * with R long runs of one letter the suffixes inside the runs map, LF step by LF step, R places further in the suffix
    * array, and with R a multiple of the sampling ratio they never meet a sample until a run ends */
-  const unsigned long long maxSteps = stepCap ? (unsigned long long)stepCap : (1ull << kWalkStepBits) - 1ull;
+  /* without a cap (every ordinary locate): the hand-over holds 23 bits of steps, so a walk that has not met a sample after
+   * `giveUpAfter` (2^23 - 1) steps -- a hit right behind such a run: rare, but a valid index -- is parked too, in its own
+   * format (kWalkParked | one step more than giveUpAfter << 61 | position), and finishKernel walks it to its sample one
+   * thread at a time: slow, and exact (round 4 finished such a walk as if it stood on a sample) */
+  const unsigned long long maxSteps = stepCap ? (unsigned long long)stepCap : (unsigned long long)giveUpAfter;
 
   /* A group works through batches of 4*G consecutive hits (lane j holds hits 4j..4j+3 of the batch, 32 B):
    * one coalesced read brings a batch in, the hand-over values replace the BWT positions in the registers,
@@ -172,11 +233,11 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
   while (alive) {
     bool sampled = POW2 ? (p & (ratio - 1)) == 0 : (p % ratio) == 0; /* ref src/AwFmIndexStruct.c:88-91 */
     if (sampled || steps >= maxSteps) {
-      /* hand the hit over (or, after 2^23-1 steps, which only a corrupt index reaches, finish it here) */
+      /* hand the hit over, or park it */
       const unsigned long long sample = POW2 ? (unsigned long long)(p >> ix.saShift) : (unsigned long long)(p / ratio);
       const unsigned long long result = sampled ? (kWalkTag | ((unsigned long long)steps << 40) | (sample & kWalkSampleMask))
                                                 : (stepCap ? (kWalkParked | ((unsigned long long)steps << 32) | (unsigned long long)(unsigned)p)
-                                                           : finishPosition(ix, sample, steps));
+                                                           : (kWalkParked | ((unsigned long long)(steps - (unsigned)maxSteps) << 61) | (unsigned long long)p));
       const bool owner = gl == j / kPerLane;
       const unsigned k = j % kPerLane;
       slot.a = owner && k == 0u ? result : slot.a;
@@ -299,8 +360,13 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
 /* second half: the bit-packed sample of every handed-over hit */
 /* out == positions: in place.  Otherwise every entry is written to `out`, which may be page-locked host memory (the
  * pipeline of awfm_gpu_stream.hip lets the kernel that produces the positions deliver them: sequential 8-byte stores) */
+/* resume: 0 -- parked entries are passed on as they are (the construction of the full suffix array completes them from each
+ * other); 1 / 2 -- a nucleotide / amino image's ordinary locate: an entry walkKernel parked after giveUpAfter (+ 0 or 1)
+ * steps is walked on here, one LF step at a time by its thread, until it stands on a sample (ref
+ * src/AwFmParallelSearch.c:338-361 walks every hit that way) */
 __global__ void finishKernel(const DevIndex ix, unsigned long long totalHits, const unsigned long long *positions,
-                             unsigned long long *out, const unsigned long long *__restrict__ totalOnDevice = nullptr) {
+                             unsigned long long *out, const unsigned long long *__restrict__ totalOnDevice = nullptr,
+                             const unsigned resume = 0u, const unsigned giveUpAfter = (1u << kWalkStepBits) - 1u) {
   if (totalOnDevice) {
     const unsigned long long t = *totalOnDevice;
     totalHits = t < totalHits ? t : totalHits;
@@ -309,8 +375,18 @@ __global__ void finishKernel(const DevIndex ix, unsigned long long totalHits, co
   const bool inPlace = out == positions;
   for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < totalHits; t += stride) {
     const unsigned long long v = positions[t];
-    if (v & kWalkTag) out[t] = finishPosition(ix, v & kWalkSampleMask, (v >> 40) & ((1ull << kWalkStepBits) - 1ull));
-    else if (!inPlace) out[t] = v;
+    if (v & kWalkTag) {
+      out[t] = finishPosition(ix, v & kWalkSampleMask, (v >> 40) & ((1ull << kWalkStepBits) - 1ull));
+    } else if ((v & kWalkParked) && resume) {
+      unsigned long long p = v & ((1ull << 61) - 1ull), steps = (unsigned long long)giveUpAfter + ((v >> 61) & 1ull);
+      while (p % ix.saRatio != 0ull && steps <= ix.bwtLength) { /* (the bound: a corrupt index must not hang the device) */
+        p = lfStepSerial(ix, resume == 2u, p);
+        steps++;
+      }
+      out[t] = finishPosition(ix, p / ix.saRatio, steps);
+    } else if (!inPlace) {
+      out[t] = v;
+    }
   }
 }
 

@@ -870,6 +870,7 @@ __global__ void __launch_bounds__(256)
  * it -- {number of this search, k-mers alive} -- in page-locked host memory, where a later search of the stream reads it
  * without a wait and launches only the front end the sample chose (awfm_gpu_ordered.hip: lookup prediction).  The front
  * ends read the low half of the word as sampleAliveKernel's count. */
+template <bool AMINO>
 __global__ void __launch_bounds__(256)
     lookupPrepKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const unsigned fixedLen, const unsigned depth,
                      const unsigned useNext, const unsigned long long numQueries, const unsigned samples,
@@ -889,23 +890,37 @@ __global__ void __launch_bounds__(256)
   if (gid == 0u) *aliveNext = 0ull;
   const unsigned sampleBlocks = (samples + 255u) / 256u; /* uniform per workgroup from here */
   if (blockIdx.x >= sampleBlocks) return;
+  __shared__ AminoShared sAmino;
+  __shared__ unsigned sAlive;
+  if (AMINO) aminoStageTables(sAmino);
+  if (threadIdx.x == 0) sAlive = 0u;
+  __syncthreads();
   bool alive = false;
   if (gid < samples) {
     const unsigned long long t = (unsigned long long)gid * (numQueries / samples);
-    unsigned long long codes = 0;
-    unsigned bad = 0;
-    decodeKmer(chars, t * fixedLen, fixedLen, codes, bad);
-    if (bad) {
-      alive = true;
+    if (AMINO) { /* aminoSampleAliveKernel's test (awfm_amino_lookup_kernel.h): the entry over the last `depth` characters */
+      const unsigned char *at = chars + t * fixedLen;
+      unsigned idx = 0;
+      bool bad = false;
+      for (unsigned c = fixedLen - depth; c < fixedLen; c++) {
+        const unsigned letter = aminoLetterIndex(sAmino, at[c]);
+        idx = idx * 20u + letter;
+        bad |= letter >= 20u;
+      }
+      alive = bad || ((const uint2 *)ix.deepSeed)[bad ? 0u : idx].y != 0u;
     } else {
-      const uint2 e = ((const uint2 *)ix.deepSeed)[codes & ((1ull << (2u * depth)) - 1ull)];
-      const unsigned length = ix.deepNext ? (e.y & 0xFFFFu) : e.y;
-      alive = length != 0u && (!useNext || ((e.y >> (16u + ((unsigned)(codes >> (2u * depth)) & 15u))) & 1u) != 0u);
+      unsigned long long codes = 0;
+      unsigned bad = 0;
+      decodeKmer(chars, t * fixedLen, fixedLen, codes, bad);
+      if (bad) {
+        alive = true;
+      } else {
+        const uint2 e = ((const uint2 *)ix.deepSeed)[codes & ((1ull << (2u * depth)) - 1ull)];
+        const unsigned length = ix.deepNext ? (e.y & 0xFFFFu) : e.y;
+        alive = length != 0u && (!useNext || ((e.y >> (16u + ((unsigned)(codes >> (2u * depth)) & 15u))) & 1u) != 0u);
+      }
     }
   }
-  __shared__ unsigned sAlive;
-  if (threadIdx.x == 0) sAlive = 0u;
-  __syncthreads();
   const unsigned n = (unsigned)__popcll(__ballot(alive));
   if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&sAlive, n);
   __syncthreads();

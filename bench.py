@@ -43,6 +43,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_GATHER_PEAK_GBS = 17800.0  # MI355X_MICROARCH.md "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCDs' L2s
 RANK_BYTES_DNA, RANK_BYTES_AMINO = 104, 168  # planes + one count of the reference block
 PROFILE_ROUND = "r4"
+T_START = time.time()
 WINDOW_HITS = 1 << 28  # hits located per window when a batch's hit list is not kept resident (--workload mixed --mode locate)
 
 
@@ -74,6 +75,7 @@ def parse():
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-e2e", action="store_true", help="skip the host-inclusive end_to_end leg")
     p.add_argument("--no-secondary", action="store_true", help="skip the planted (every k-mer has a hit) line of the default run")
+    p.add_argument("--no-amino", action="store_true", help="skip the amino lines (configs[3]) of the default run's secondary")
     p.add_argument("--no-shard-proxy", dest="shard_proxy", action="store_false",
                    help="skip the single-GPU strong-scaling proxy (the shards 2, 4 and 8 ranks would hold, each timed alone)")
     p.add_argument("--proxy-steps", type=int, default=5, help="timed steps per shard of the proxy")
@@ -300,6 +302,148 @@ def end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, a
                                           "entry_point": "awFmParallelSearchLocate",
                                           "checked": "every k-mer has hits; the first 1000 position lists hold their planting offsets"}
         lst.dealloc()
+    return out
+
+
+def amino_leg(L, api, digest, torch, np, dev, n, Q=50_000_000, K=10, seed_k=5, sa_ratio=8, steps=5, record_digests=None):
+    """BASELINE.json configs[3] beside the headline, in the driver's own run (round 5): Q random K-mers located against an amino
+    index of n residues (seed 4 / 104, as `--alphabet amino`), the step a caller of the list form runs -- awfmGpuSearchHitsCompact
+    + awfmGpuListLocateOnDevice --, the results checked against the CPU oracle on a sample and against the committed digests,
+    the search call priced by what it executes (the basis of `--alphabet amino`'s own roofline) and the reference algorithm's
+    kernel (no deeper table) timed beside it.  The index and its image live only for this leg."""
+    import ctypes as C  # noqa: F401
+    t0 = time.time()
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, 4, 1, None) == 1
+    torch.cuda.synchronize()
+    ix = api.gpu_create_index(d_text.data_ptr(), api.AwFmAlphabetAmino, sa_ratio, seed_k, on_device_length=n, device=dev.index)
+    del d_text
+    g = api.GpuIndex(ix, acquire=True)
+    build_s = time.time() - t0
+    d_chars = torch.empty(Q * K, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr(), 0, Q, K, 104, 1, None) == 1
+    cap = max(Q // 64, 1024)
+    d_kmers = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_ranges = torch.empty(cap * 2, dtype=torch.int64, device=dev)
+    d_skmers = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_sranges = torch.empty(cap * 2, dtype=torch.int64, device=dev)
+    d_off = torch.empty(cap + 1, dtype=torch.int64, device=dev)
+    d_num = torch.zeros(1, dtype=torch.int32, device=dev)
+    stream_obj = torch.cuda.Stream()
+    stream = stream_obj.cuda_stream
+    torch.cuda.synchronize()
+    # probe: how long the list is, how many hits (the buffers of the timed steps are sized by it, as a caller's are)
+    g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr(), stream=stream)
+    g.list_locate_on_device(d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr(), Q, d_skmers.data_ptr(), d_sranges.data_ptr(),
+                            d_off.data_ptr(), 0, 0, stream)
+    torch.cuda.synchronize()
+    listed, hits = int(d_num.item()), int(d_off[cap].item())
+    assert listed <= cap, "the amino batch is not one for the list form"
+    cap = min(cap, max(1024, -(-(listed * 5 // 4) // 1024) * 1024))
+    d_pos = torch.empty(hits + hits // 8 + 64, dtype=torch.int64, device=dev)
+
+    def step(record=None):
+        if record is not None:
+            record[0].record(stream_obj)
+        g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr(), stream=stream)
+        if record is not None:
+            record[1].record(stream_obj)
+        g.list_locate_on_device(d_kmers.data_ptr(), d_ranges.data_ptr(), cap, d_num.data_ptr(), Q, d_skmers.data_ptr(), d_sranges.data_ptr(),
+                                d_off.data_ptr(), d_pos.numel(), d_pos.data_ptr(), stream)
+
+    events = []
+    for _ in range(2):  # warm-up steps carry the events that say what the search call alone takes
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        step(ev)
+        events.append(ev)
+    torch.cuda.synchronize()
+    search_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t1) * 1e3 / steps
+    looked_up = bool(g.last_ordered_kernel_is_lookup())
+    front = g.last_lookup_front()
+    assert int(d_num.item()) == listed and int(d_off[cap].item()) == hits, "the list changed between the probe and the timed steps"
+    # dense form of the results (outside the timed region): counts, hit offsets, positions in k-mer order
+    kmers = d_skmers[:listed].to(torch.int64)
+    assert listed == 0 or bool((kmers[1:] > kmers[:-1]).all()), "the hit list is not in k-mer order"
+    lens = d_off[1:listed + 1] - d_off[:listed]
+    counts = torch.zeros(Q, dtype=torch.int64, device=dev)
+    counts[kmers] = lens
+    hit_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=hit_off[1:])
+    assert int(hit_off[Q].item()) == hits
+    # parity gate: the CPU oracle on the first m k-mers (ranges of the k-mers with hits, counts, positions in BWT order)
+    from oracle import oracle as O
+    oi = O.Index.wrap(O.AMINO, sa_ratio, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    m = min(Q, 1_000_000)
+    chars = d_chars[: m * K].cpu().numpy()
+    sp, ep, cnt, _ = oi.batch_search(chars, np.arange(m + 1, dtype=np.uint64) * np.uint64(K), threads=min(os.cpu_count() or 1, 16))
+    ho, pos, _ = oi.batch_locate(sp, ep, threads=min(os.cpu_count() or 1, 16))
+    assert np.array_equal(counts[:m].cpu().numpy().astype(np.uint32), cnt), "amino: GPU counts differ from the oracle"
+    assert np.array_equal(hit_off[: m + 1].cpu().numpy().view(np.uint64), ho), "amino: GPU hit offsets differ from the oracle"
+    assert np.array_equal(d_pos[: int(ho[-1])].cpu().numpy().view(np.uint64), pos), "amino: GPU positions differ from the oracle"
+    in_sample = int((kmers < m).sum().item())
+    gr = d_sranges[: 2 * in_sample].cpu().numpy().view(np.uint64).reshape(in_sample, 2)
+    hit = cnt > 0
+    assert np.array_equal(gr[:, 0], sp[hit]) and np.array_equal(gr[:, 1], ep[hit]), "amino: GPU ranges differ from the oracle"
+    key = digest.key("amino", "random", "locate", n, str(K), seed_k, sa_ratio, 0, Q)
+    dig = {"counts": f"{digest.counts_digest(0, counts):016x}", "positions": f"{digest.positions_digest(0, hit_off, d_pos[: max(hits, 1)]):016x}"}
+    committed = digest.load_golden().get(key)
+    assert committed is None or committed == dig, f"amino digests {dig} differ from the committed {committed}"
+    if record_digests:
+        known = json.load(open(record_digests)) if os.path.exists(record_digests) else {}
+        known[key] = dig
+        json.dump(known, open(record_digests, "w"), indent=1, sort_keys=True)
+    del counts, hit_off, lens, kmers
+    # roofline of the search call: what it executes (a 128-B line per lookup in the deeper table + 168 B per distinct block of
+    # the steps behind it), tallied by an instrumented launch; and the reference algorithm's kernel (no deeper table) beside it
+    tally = g.search_tally(d_chars.data_ptr(), 0, K, Q)
+    alg_bytes = tally["chars"] + 16 * tally["seeded"] + RANK_BYTES_AMINO * tally["blocks"] + 16 * Q
+    roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel_ms": round(search_ms, 3)}
+    deep_k = g.deep_seed_k
+    if deep_k:
+        os.environ["AWFM_GPU_TALLY_WITH_DEEP"] = "1"
+        executed = g.search_tally(d_chars.data_ptr(), 0, K, Q)
+        del os.environ["AWFM_GPU_TALLY_WITH_DEEP"]
+        lookups = Q - executed["seeded"] if K >= deep_k else 0
+        exec_bytes = executed["chars"] + 128 * lookups + 16 * executed["seeded"] + RANK_BYTES_AMINO * executed["blocks"] + 16 * Q
+        roofline.update(kernel=("aminoLookupSearchKernel" if looked_up else "searchKernel") + f" (device-only table of depth {deep_k})",
+                        basis="executed_reads", achieved=round(exec_bytes / (search_ms * 1e-3) / 1e9, 1),
+                        frac=round(exec_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), executed_bytes=int(exec_bytes),
+                        algorithmic_frac_of_this_kernel=round(alg_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3))
+        d_counts = torch.empty(Q, dtype=torch.int32, device=dev)
+        g.set_deep_seed(0)
+        ev = []
+        for i in range(4):  # (the first one warms up)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream_obj)
+            g.search_hits(d_chars.data_ptr(), 0, K, Q, 0, d_counts.data_ptr(), stream)
+            b.record(stream_obj)
+            ev.append((a, b))
+        torch.cuda.synchronize()
+        plain_ms = float(np.mean([a.elapsed_time(b) for a, b in ev[1:]]))
+        assert int((d_counts != 0).sum().item()) == listed, "the reference algorithm's kernel finds other k-mers"
+        roofline["reference_algorithm"] = {"kernel": "searchKernel (no deeper table)", "bytes": int(alg_bytes), "kernel_ms": round(plain_ms, 3),
+                                           "frac": round(alg_bytes / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": 3}
+        roofline["reference_algorithm_frac"] = roofline["reference_algorithm"]["frac"]
+        del d_counts
+    else:
+        roofline.update(kernel="searchKernel", achieved=round(alg_bytes / (search_ms * 1e-3) / 1e9, 1),
+                        frac=round(alg_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    out = {"workload": f"{Q / 1e6:g} M random {K}-mers, locate, {n / 1e9:g} Gres uniform synthetic amino text, SA ratio {sa_ratio}, seed table k={seed_k}",
+           "value": round(Q / ms / 1e3, 2), "unit": "Mkmers/s", "ms_per_step": round(ms, 3), "steps": steps, "search_call_ms": round(search_ms, 3),
+           "hits_per_step": hits, "kmers_with_hits": listed, "result_form": "list", "lookup_front": front,
+           "index_build_s": round(build_s, 2), "device_image_bytes": g.device_bytes, "device_seed_k": deep_k, "device_dense_sa": bool(g.has_dense_sa),
+           "roofline": roofline, "checked": f"first {m} k-mers against the CPU oracle (ranges of the k-mers with hits, counts, positions)",
+           "digests": dict(dig, status="match" if committed else "unknown")}
+    g.handle = None
+    L.awfmGpuIndexRelease(ix.ptr)
+    ix.dealloc()
+    del d_chars, d_kmers, d_ranges, d_skmers, d_sranges, d_off, d_pos
+    torch.cuda.empty_cache()
     return out
 
 
@@ -764,6 +908,9 @@ def main():
     kernel_log = g.ordered_kernel_log() if ordered else []
     assert not ordered or len(kernel_log) == min(args.steps, 1024), "the library logged another number of searches than were timed"
     lookup_first = bool(ordered and g.last_ordered_kernel_is_lookup())  # the dominant kernel of every step was encodeLookupKernel
+    # which front end(s) the last timed step launched: 0 both (the sample's verdict stays on the device), 1 the lookup kernel
+    # only / 2 the ordered kernels only (the verdict of an earlier step had reached the host: awfmGpuLastLookupFront), -1: no sample
+    lookup_front = g.last_lookup_front()
     # (a mixed-length batch below the seed-order size on an image with its tables per k-mer length: the lookup kernel alone)
     small_mixed_lookup = bool(d_offsets is not None and not ordered and not amino and g.length_tables[0] and g.last_ordered_kernel_is_lookup())
     lookup_kept = g.last_ordered_kept() if lookup_first else 0  # before any other search re-uses the scratch
@@ -1359,6 +1506,14 @@ def main():
             "digests": {"counts": mdig, "status": "match" if committed else "unknown"}}
         del m_counts, m_chars, m_off, d_mixed
 
+    # ---- and BASELINE configs[3] -- 5 * 10^7 random amino 10-mers against a Swiss-Prot-sized index (2 * 10^8 residues), located --
+    # with its own index, in this same run; the HBM-bound variant (2 * 10^9 residues: the image is ten times the Infinity Cache)
+    # as well while the run is young enough ----
+    if secondary is not None and not args.no_amino:
+        secondary["amino"] = amino_leg(L, api, digest, torch, np, dev, 200_000_000, record_digests=args.record_digests)
+        if time.time() - T_START < 150:
+            secondary["amino_2e9"] = amino_leg(L, api, digest, torch, np, dev, 2_000_000_000, steps=3, record_digests=args.record_digests)
+
     # ---- strong-scaling proxy on ONE GPU: the contiguous shards N ranks would hold of this batch (configs[2]: "query
     # batch sharded 1 -> 8"), each timed by itself with the same step; a rank of an N-GPU run does exactly this work on
     # its own replica, with nothing exchanged (ref src/AwFmParallelSearch.c:103-129: 8-query blocks are independent), so
@@ -1512,7 +1667,10 @@ def main():
               "search_path": ({"order": "awfmGpuSearchHitsInOrder", "list": "awfmGpuSearchHitsCompact",
                                "dense": "awfmGpuSearchHitsSparse" if narrow_counts else "awfmGpuSearchHits"}[whole.form] if locate
                               else "awfmGpuSearchHits") + (", seed order" if ordered else ", mixedLookupSearchKernel" if small_mixed_lookup else ", general kernel"),
-              "result_format": form_names[whole.form] if locate else "count under every k-mer number"}
+              "result_format": form_names[whole.form] if locate else "count under every k-mer number",
+              "lookup_front": {0: "both front ends launched, the sample decides on the device", 1: "lookup kernel only (predicted from an earlier step's sample)",
+                               2: "ordered kernels only (predicted from an earlier step's sample)"}.get(lookup_front, "no sample"),
+              "list_tail": "awfmGpuListLocateOnDevice (one launch)" if locate and whole.form == "list" and list_tail else None}
     lt_bytes, lt_s = length_tables_built
     if lt_bytes:  # built by the probe step of a mixed-length batch (awfm_mixed_lookup_kernel.h): device-only, kept with the image
         config["length_tables_bytes"] = lt_bytes
@@ -1529,6 +1687,11 @@ def main():
         if "mixed_lengths" in secondary:
             config["mixed_lengths_ms_per_step"] = secondary["mixed_lengths"]["ms_per_step"]
             config["mixed_lengths_value"] = secondary["mixed_lengths"]["value"]
+        for name in ("amino", "amino_2e9"):
+            if name in secondary:
+                config[name + "_value"] = secondary[name]["value"]
+                config[name + "_ms_per_step"] = secondary[name]["ms_per_step"]
+                config[name + "_roofline_frac"] = secondary[name]["roofline"].get("frac")
     if clocks:
         config["gpu_clocks"] = clocks
         for name in ("sclk", "mclk", "fclk"):

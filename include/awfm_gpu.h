@@ -96,7 +96,7 @@ uint64_t awfmGpuIndexDeepSeedTransientBytes(const AwFmGpuIndex *g);
 /* The full suffix array on the device (32-bit entries, 4 x bwtLength bytes: 12.4 GB for a GRCh38-sized index),
  * reconstructed once from the sampled SA with the LF-walk kernel, so that locating a hit is one read instead of a
  * chain of about ratio-1 dependent block reads.  Positions are bit-identical (the walk wrote them).  Built by default for
- * images of 2^28 .. 2^32 positions with a sampled array when four times its size is free on the device
+ * images of 2^26 .. 2^32 positions with a sampled array when four times its size is free on the device
  * ($AWFM_GPU_DENSE_SA=0|1: never / always); enable = 0 drops it, 1 builds it.  Needs bwtLength < 2^32. */
 enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable);
 int awfmGpuIndexHasDenseSa(const AwFmGpuIndex *g);

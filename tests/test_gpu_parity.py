@@ -410,6 +410,7 @@ def test_amino_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, req
     the oracle either way"""
     import torch
     monkeypatch.delenv("AWFM_GPU_AMINO_LOOKUP", raising=False)
+    monkeypatch.setenv("AWFM_GPU_LOOKUP_PREDICT", "0")  # every search by its own sample
     n, K, Q = 200000, 8, (1 << 20) + 7
     txt = synth.text(950, n, synth.AMINO_ALPHABET).copy()
     ix = awfm.create_index(txt, awfm.AwFmAlphabetAmino, 8, 3)
@@ -497,6 +498,39 @@ def test_device_dense_sa_keeps_positions_bit_identical(oracle, awfm, require_gpu
     g.set_dense_sa(False)
     _, ho2, p2 = g.locate_host(chars, offsets)
     assert np.array_equal(ho2, hit_off) and np.array_equal(p2, pos) and g.device_bytes == before
+    g.destroy()
+    ix.dealloc()
+
+
+@pytest.mark.parametrize("alphabet_name,ratio,pair", [("dna", 16, "1"), ("dna", 13, "0"), ("amino", 16, "1")])
+def test_a_walk_the_walk_kernel_gives_up_is_walked_on_exactly(oracle, awfm, require_gpu, wide, monkeypatch, alphabet_name, ratio, pair):
+    """The hand-over between walkKernel and finishKernel holds 23 bits of LF steps.  A walk that has not met a sample by then --
+    a hit right behind a long run of one letter: a valid index -- used to be finished as if it stood on one (advisor, round
+    4); now it is parked and finishKernel walks it on, one thread, to its sample.  $AWFM_GPU_WALK_GIVE_UP=3 moves the limit
+    to three steps, so that most walks of an ordinary text (ratio 13 / 16) take that path: positions must be the oracle's,
+    through the pair image and without, amino, 32- and 64-bit positions."""
+    monkeypatch.setenv("AWFM_GPU_WALK_GIVE_UP", "3")
+    monkeypatch.setenv("AWFM_GPU_PAIR", pair)
+    amino = alphabet_name == "amino"
+    letters = synth.AMINO_ALPHABET if amino else synth.DNA_ALPHABET
+    alpha, oalpha = (awfm.AwFmAlphabetAmino, oracle.AMINO) if amino else (awfm.AwFmAlphabetDna, oracle.DNA)
+    txt = synth.text(700 + ratio, 90000, letters).copy()
+    if not amino:
+        txt[40000:40300] = ord("n")  # a run of the ambiguity letter: flagged pair blocks, the X count
+    ix = awfm.create_index(txt, alpha, ratio, 3)
+    oi = oracle.Index.from_text(txt.tobytes(), oalpha, ratio, 3)
+    chars, offsets = _mixed_queries(701, 6000, txt, letters, 2, 20)
+    sp, ep, _, _ = oi.batch_search(chars, offsets)
+    hit_off, pos, _ = oi.batch_locate(sp, ep)
+    g = awfm.GpuIndex(ix)
+    g.set_dense_sa(False)
+    _, ho, p = g.locate_host(chars, offsets)
+    assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
+    # the full suffix array, asked for: capped walks + pointer jumping (the cap is 32 x ratio: nothing parks on this text),
+    # every entry the sorted suffixes' position
+    g.set_dense_sa(True)
+    _, ho, p = g.locate_host(chars, offsets)
+    assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
     g.destroy()
     ix.dealloc()
 
