@@ -306,39 +306,51 @@ __global__ void __launch_bounds__(kListTailThreads)
   if (tid == 0) sMine = 0u;
   __syncthreads();
   /* one pass over the list: entries below the range (count, hits), own entries into the slots */
-  /* (eight entries a thread and trip, all their loads requested before any is used: the pass is a chain of L2 latencies --
-   * one entry a trip took 13 us over the 9 * 10^3 entries of a shard's list, and would take 100 over the 7 * 10^4 of the
-   * whole batch's) */
+  /* Sixteen entries a thread and trip -- two groups of eight --, all their loads requested before any is used, and requested
+   * before the list's length has arrived (the trips run over the list's CAPACITY, which is an argument; an entry beyond the
+   * length is read and ignored): the pass is a chain of memory latencies, 2 us each -- one entry a trip took 13 us over the
+   * 9 * 10^3 entries of a shard's list and would take 100 over the 7 * 10^4 of the whole batch's. */
   unsigned long long below = 0, belowHits = 0;
-  constexpr unsigned kPer = 8;
+  constexpr unsigned kPer = 8, kGroups = 2;
   const bool vec = ((unsigned long long)inKmers & 15ull) == 0ull;
-  const bool allRanges = n <= 16384u;
-  for (unsigned base = tid * kPer; base < n; base += kListTailThreads * kPer) {
-    unsigned long long key[kPer];
-    if (vec && base + kPer <= n) {
-      const uint4 a = *(const uint4 *)(inKmers + base), b = *(const uint4 *)(inKmers + base + 4u);
-      key[0] = a.x, key[1] = a.y, key[2] = a.z, key[3] = a.w;
-      key[4] = b.x, key[5] = b.y, key[6] = b.z, key[7] = b.w;
-    } else {
+  const bool allRanges = cap <= 16384u; /* a short list: every range is requested beside its key, not behind it */
+  for (unsigned trip = 0; trip < cap; trip += kListTailThreads * kPer * kGroups) {
+    unsigned key32[kGroups][kPer];
+    ulonglong2 r[kGroups][kPer];
 #pragma unroll
-      for (unsigned j = 0; j < kPer; j++) key[j] = base + j < n ? (unsigned long long)inKmers[base + j] : ~0ull;
+    for (unsigned u = 0; u < kGroups; u++) {
+      const unsigned base = trip + u * kListTailThreads * kPer + tid * kPer;
+      if (vec && base + kPer <= cap) {
+        const uint4 a = *(const uint4 *)(inKmers + base), b = *(const uint4 *)(inKmers + base + 4u);
+        key32[u][0] = a.x, key32[u][1] = a.y, key32[u][2] = a.z, key32[u][3] = a.w;
+        key32[u][4] = b.x, key32[u][5] = b.y, key32[u][6] = b.z, key32[u][7] = b.w;
+      } else {
+#pragma unroll
+        for (unsigned j = 0; j < kPer; j++) key32[u][j] = base + j < cap ? inKmers[base + j] : 0xFFFFFFFFu;
+      }
     }
-    /* (the ranges of the entries below and inside the range; of a short list -- a shard's -- every range, requested beside
-     * the keys instead of behind them: one latency less) */
-    ulonglong2 r[kPer];
 #pragma unroll
-    for (unsigned j = 0; j < kPer; j++)
-      r[j] = (allRanges ? base + j < n : key[j] < hi) ? inRanges[base + j] : make_ulonglong2(1ull, 0ull);
+    for (unsigned u = 0; u < kGroups; u++) {
+      const unsigned base = trip + u * kListTailThreads * kPer + tid * kPer;
 #pragma unroll
-    for (unsigned j = 0; j < kPer; j++) {
-      if (key[j] < lo) {
-        below++;
-        belowHits += r[j].x <= r[j].y ? r[j].y - r[j].x + 1ull : 0ull;
-      } else if (key[j] < hi) {
-        const unsigned at = atomicAdd(&sMine, 1u);
-        if (at < kListTailSlots) {
-          sKey[at] = (unsigned)key[j];
-          sRange[at] = r[j];
+      for (unsigned j = 0; j < kPer; j++)
+        r[u][j] = base + j < cap && (allRanges || (unsigned long long)key32[u][j] < hi) ? inRanges[base + j] : make_ulonglong2(1ull, 0ull);
+    }
+#pragma unroll
+    for (unsigned u = 0; u < kGroups; u++) {
+      const unsigned base = trip + u * kListTailThreads * kPer + tid * kPer;
+#pragma unroll
+      for (unsigned j = 0; j < kPer; j++) {
+        const unsigned long long key = base + j < n ? (unsigned long long)key32[u][j] : ~0ull;
+        if (key < lo) {
+          below++;
+          belowHits += r[u][j].x <= r[u][j].y ? r[u][j].y - r[u][j].x + 1ull : 0ull;
+        } else if (key < hi) {
+          const unsigned at = atomicAdd(&sMine, 1u);
+          if (at < kListTailSlots) {
+            sKey[at] = (unsigned)key;
+            sRange[at] = r[u][j];
+          }
         }
       }
     }

@@ -762,6 +762,16 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
       if (const char *env = getenv("AWFM_GPU_LOOKUP_BLOCKS_PER_CU")) perCU = (unsigned)atoi(env) >= 1u ? (unsigned)atoi(env) : 7u;
       unsigned fusedGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * perCU ? perShare256 * kShares : (unsigned long long)g->numCUs * perCU);
       fusedGrid = (fusedGrid + kShares - 1u) / kShares * kShares;
+      /* A workgroup takes its share 1024 k-mers a trip.  A small batch is a few trips per workgroup -- 6.8 for the 1.25 * 10^7
+       * k-mers of a shard of an 8-GPU run on 1792 workgroups: most take 7, and the chip idles while they finish -- so the grid
+       * is trimmed to the workgroups that share the trips evenly (1744 x 7); $AWFM_GPU_LOOKUP_EVEN_TRIPS=0: the resident grid */
+      if (!(getenv("AWFM_GPU_LOOKUP_EVEN_TRIPS") && atoi(getenv("AWFM_GPU_LOOKUP_EVEN_TRIPS")) == 0)) {
+        const unsigned long long tripsPerShare = (shareSize(nq) + 1023ull) / 1024ull, groupsPerShare = fusedGrid / kShares;
+        if (groupsPerShare > 0u && tripsPerShare > groupsPerShare) {
+          const unsigned long long tripsEach = (tripsPerShare + groupsPerShare - 1ull) / groupsPerShare;
+          if (tripsEach <= 64ull) fusedGrid = (unsigned)((tripsPerShare + tripsEach - 1ull) / tripsEach) * kShares;
+        }
+      }
       /* (lookup only: what the kernel does not search itself goes to the END of the record array, 8 bytes a k-mer number,
        * counted in the general kernel's word -- no code words, no numbers, no histogram) */
       launchLookupSearchAt<32u>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt, useNext | (pairOff ? 2u : 0u) | (lookupOnly ? 4u : 0u), nq,
