@@ -968,6 +968,14 @@ hipError_t awfmGpuLaunchMixedTally(const AwFmGpuIndex *g, hipStream_t s, const v
                                    unsigned long long lengthWords, unsigned long long deepWords, unsigned long long pairWords,
                                    unsigned long long nucWords);
 unsigned awfmGpuMixedTouchLevels(void);
+/* awfm_gpu_exact.hip: the launch of exactLookupSearchKernel (awfm_exact_lookup_kernel.h) */
+hipError_t awfmGpuLaunchExactLookup(const AwFmGpuIndex *g, hipStream_t s, hipEvent_t start, hipEvent_t stop, const void *lengthTable,
+                                    const uint8_t *dChars, const unsigned long long *off, unsigned fixedLength, unsigned long long nq,
+                                    bool pairOff, ulonglong2 *rng, unsigned *dCounts, unsigned long long *leftover, unsigned *leftoverCount);
+/* awfm_gpu_ordered.hip: awfmGpuSearch's exact ranges through the device-only tables: 1 = searched, 0 = does not apply (the
+ * caller runs the general kernel), < 0 = -AwFmReturnCode */
+int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off, uint32_t fixedLength,
+                             unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts);
 /* awfm_gpu.hip: the suffix array (32-bit positions, `length` of them) the builder of this thread hands to the image it adopts
  * next (applyDenseSa takes it; whoever set it frees it when it is still there afterwards) */
 extern thread_local void *awfmGpuDenseSaStash;

@@ -1,0 +1,212 @@
+/*
+ * awfm_exact_lookup_kernel.h -- "lookup first" for awfmGpuSearch: the EXACT final range of every k-mer through the tables.
+ *
+ * awfmGpuSearch owes every k-mer the range the reference's stepping ends in -- for a k-mer without hits the FIRST empty range
+ * (ref src/AwFmParallelSearch.c:273-313 keeps it; src/AwFmSearch.c:317-358 returns it) --, which the hits-only kernels
+ * (lookupSearchKernel, mixedLookupSearchKernel) do not produce: they drop a k-mer on a clear next-step bit and let a pair step
+ * end in the pair's empty range.  The tables themselves are exact: an entry is {sp, length} of what the reference reaches with
+ * its stop-at-the-first-empty-range rule, and an empty range of that stepping is always {sp, sp - 1} (awfm_device.h), so a
+ * length of 0 IS the reference's final range.  This kernel is mixedLookupSearchKernel without the shortcuts:
+ *   one entry per k-mer -- the deeper table's over its last deepK characters, or, for a k-mer shorter than that, the entry of
+ *   its own length's table (awfmGpuBuildLengthTables) --; an empty entry, or one that covers the whole k-mer, is the result;
+ *   the others (10^8 random 21-mers against 3.1 Gbp: 51 %) go on out of LDS, 16 at a time, each taking the next one's place as
+ *   soon as it is done: EXACT pair steps (pairSearchStep<true, true>: a k-mer that dies inside a pair gets the range of the
+ *   single step that emptied it), flagged blocks and the odd last character through the one-letter image;
+ *   every k-mer's {sp, ep} and count stored under its number (batch order: whole lines).
+ * K-mers with a character that is not a,c,g,t,u, none or more than 32 characters go to a list for the general kernel.
+ * Fixed-length batches (offsets == NULL) and CSR ones; images below 2^32 positions with the narrow deeper table.
+ */
+#ifndef AWFM_EXACT_LOOKUP_KERNEL_H
+#define AWFM_EXACT_LOOKUP_KERNEL_H
+
+#include "awfm_mixed_lookup_kernel.h"
+
+namespace {
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
+    exactLookupSearchKernel(const DevIndex ix, const uint2 *__restrict__ lengthTable, const unsigned char *__restrict__ chars,
+                            const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
+                            const unsigned long long numQueries, const unsigned pairOff, ulonglong2 *__restrict__ ranges,
+                            unsigned *__restrict__ counts, unsigned long long *__restrict__ leftover,
+                            unsigned *__restrict__ leftoverCount) {
+  constexpr int G = 4;
+  typedef unsigned pos_t; /* narrow images only (what the 8-byte table entries imply) */
+  __shared__ unsigned long long sC[24];
+  __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
+  __shared__ unsigned long long sSuper[1];
+  __shared__ unsigned long long sPairC[16];
+  extern __shared__ unsigned sPairSuper[];
+  __shared__ unsigned long long sLevelAt[17];
+  __shared__ unsigned long long sRem[4][kMixedSlots];
+  __shared__ unsigned sNum[4][kMixedSlots], sSp[4][kMixedSlots], sEp[4][kMixedSlots];
+  __shared__ unsigned char sLeft[4][kMixedSlots], sOdd[4][kMixedSlots];
+  const bool PAIR = ix.pairBlocks != nullptr && pairOff == 0u;
+  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  if (threadIdx.x < 17) sLevelAt[threadIdx.x] = threadIdx.x >= 1u ? awfmLengthTableAt(threadIdx.x) : 0ull;
+  stageMaskTable(sMask);
+  nucStageSuper<true>(ix, sSuper);
+  if (PAIR) pairStageTables<true, 16u>(ix, sPairC, sPairSuper);
+  __syncthreads();
+  const unsigned DK = ix.deepK;
+  const unsigned long long charsBytes = offsets ? offsets[numQueries] : numQueries * (unsigned long long)fixedLength; /* uniform */
+  const unsigned lane = threadIdx.x & 63u, gl = threadIdx.x % G, firstSlice = gl;
+  const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  auto store = [&](const unsigned long long q, const pos_t sp, const pos_t ep) {
+    if (ranges) ranges[q] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
+    if (counts) counts[q] = sp <= ep ? ep - sp + 1u : 0u; /* ref src/AwFmIndexStruct.c:126-130 */
+  };
+  const unsigned long long waveStride = 1024ull * gridDim.x;
+  for (unsigned long long tw = 1024ull * blockIdx.x + 256ull * w; tw < numQueries; tw += waveStride) {
+    unsigned long long codes[4];
+    unsigned len[4]; /* 0: not looked up (not in the batch, or the general kernel's) */
+    bool general[4];
+#pragma unroll
+    for (unsigned i = 0; i < 4u; i++) {
+      const unsigned long long q = tw + 64ull * i + lane;
+      const bool inBatch = q < numQueries;
+      unsigned long long start = 0, l = 0;
+      if (inBatch) {
+        if (offsets) {
+          start = offsets[q];
+          l = offsets[q + 1ull] - start;
+        } else {
+          start = q * (unsigned long long)fixedLength;
+          l = fixedLength;
+        }
+      }
+      const unsigned n = l > 33ull ? 33u : (unsigned)l;
+      /* (a k-mer shorter than the deeper table needs the table of its own length) */
+      const bool inRange = inBatch && n >= 1u && n <= 32u && (n >= DK || lengthTable != nullptr);
+      unsigned bad = 0;
+      codes[i] = 0;
+      if (inRange) {
+        if (start + 48ull <= charsBytes) decodeKmerWide(chars, start, n, codes[i], bad);
+        else decodeKmer(chars, start, n, codes[i], bad);
+      }
+      general[i] = inBatch && (!inRange || bad != 0u);
+      len[i] = inRange && bad == 0u ? n : 0u;
+    }
+    uint2 entry[4];
+#pragma unroll
+    for (unsigned i = 0; i < 4u; i++)
+      entry[i] = *(len[i] != 0u ? mixedEntryAt(ix, lengthTable, sLevelAt, len[i], codes[i]) : (const uint2 *)ix.deepSeed);
+    unsigned stotal = 0;
+#pragma unroll
+    for (unsigned i = 0; i < 4u; i++) {
+      const unsigned long long q = tw + 64ull * i + lane;
+      unsigned length = entry[i].y;
+      if (len[i] >= DK && ix.deepNext != 0u) { /* {sp, length16 | next16 << 16}: the next-step bits are no use to an exact search */
+        length &= 0xFFFFu;
+        if (length == 0xFFFFu) length = deepBigLength(ix, codes[i] & ((1ull << (2u * DK)) - 1ull));
+      }
+      const bool looked = len[i] != 0u;
+      const bool survives = looked && len[i] > DK && length != 0u;
+      if (looked && !survives) store(q, entry[i].x, entry[i].x + length - 1u); /* the entry is the k-mer's final range */
+      const unsigned long long smask = __ballot(survives);
+      const unsigned rank = stotal + (unsigned)__popcll(smask & ((1ull << lane) - 1ull));
+      stotal += (unsigned)__popcll(smask);
+      if (survives) { /* (a slot for every k-mer of the round) */
+        sRem[w][rank] = codes[i] >> (2u * DK);
+        sLeft[w][rank] = (unsigned char)(len[i] - DK);
+        sNum[w][rank] = (unsigned)q;
+        sSp[w][rank] = entry[i].x;
+        sEp[w][rank] = entry[i].x + length - 1u;
+      }
+      const unsigned long long lmask = __ballot(general[i]);
+      if (lmask != 0ull) { /* wave-uniform; rare */
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(leftoverCount, (unsigned)__popcll(lmask));
+        base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+        /* the list is filled from its END: searchKernel<INDIRECT> reads the last *count records of the array */
+        if (general[i]) leftover[numQueries - 1ull - (base + (unsigned)__popcll(lmask & ((1ull << lane) - 1ull)))] = q;
+      }
+    }
+    if (stotal != 0u) { /* wave-uniform */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      constexpr unsigned kGroups = 64u / G;
+      const unsigned leader = lane & ~(unsigned)(G - 1);
+      unsigned nextSlot = kGroups, oddCount = 0; /* wave-uniform */
+      unsigned mySlot = lane / G;
+      bool live = mySlot < stotal;
+      pos_t sp = 1, ep = 0;
+      unsigned long long rem = 0;
+      unsigned index = 0;
+      int pos = -1;
+      auto take = [&]() {
+        rem = sRem[w][mySlot];
+        index = sNum[w][mySlot];
+        sp = sSp[w][mySlot];
+        ep = sEp[w][mySlot];
+        pos = (int)sLeft[w][mySlot] - 1;
+      };
+      if (live) take();
+      const int stepChars = PAIR ? 2 : 1;
+      while (__ballot(live) != 0ull) { /* wave-uniform */
+        if (live && pos >= stepChars - 1) { /* (a k-mer in a group is alive: sp <= ep) */
+          if (PAIR) {
+            const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
+            /* exact: a k-mer that dies inside the pair ends in the range the letter-by-letter stepping ends in */
+            const PairStep did = pairSearchStep<true, true>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep, sC);
+            if (did == kPairFlagged) nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
+            if (did != kPairStepped && sp <= ep) nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
+            pos -= 2;
+            rem >>= 4;
+          } else {
+            nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+            pos--;
+            rem >>= 2;
+          }
+        }
+        /* done: the range is empty (the reference's final range), or no character is left; parked: one is left that the
+         * pair steps cannot take (taken through the one-letter image after the loop: a wave iteration issues one kind of read) */
+        const bool gone = live && (sp > ep || pos < stepChars - 1);
+        const bool park = gone && sp <= ep && pos == 0; /* PAIR only */
+        if (gone && !park && gl == 0) store(index, sp, ep);
+        const unsigned long long parkMask = __ballot(park && gl == 0);
+        if (parkMask != 0ull) { /* wave-uniform */
+          if (park && gl == 0) {
+            sSp[w][mySlot] = sp;
+            sEp[w][mySlot] = ep;
+            sRem[w][mySlot] = rem;
+            sOdd[w][oddCount + (unsigned)__popcll(parkMask & ((1ull << lane) - 1ull))] = (unsigned char)mySlot;
+          }
+          oddCount += (unsigned)__popcll(parkMask);
+        }
+        const unsigned long long goneMask = __ballot(gone && gl == 0);
+        if (gone) {
+          mySlot = nextSlot + (unsigned)__popcll(goneMask & ((1ull << leader) - 1ull));
+          live = mySlot < stotal;
+          sp = 1;
+          ep = 0;
+          pos = -1;
+          if (live) take();
+        }
+        nextSlot += (unsigned)__popcll(goneMask);
+      }
+      if (oddCount != 0u) { /* wave-uniform: the parked k-mers' last step */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (unsigned pass = 0; pass < oddCount; pass += kGroups) { /* wave-uniform */
+          const unsigned k = pass + lane / G;
+          const bool parked = k < oddCount;
+          sp = 1;
+          ep = 0;
+          if (parked) {
+            mySlot = sOdd[w][k];
+            take();
+            nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+            if (gl == 0) store(index, sp, ep);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier(); /* the slots are written again by the next round */
+    }
+  }
+}
+
+}  // namespace
+
+#endif

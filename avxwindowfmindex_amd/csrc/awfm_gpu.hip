@@ -1233,6 +1233,13 @@ static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars,
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
   const int lanes = lanesPerQuery(g);
+  if (!g->amino && lanes == 4) {
+    /* large batches on an image with its device-only tables: the exact range of every k-mer from one table entry and the
+     * few steps behind it (awfm_exact_lookup_kernel.h); no scratch memory for it: the general kernel needs none */
+    const int did = awfmGpuExactLookupSearch(g, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries, (ulonglong2 *)dRanges, dCounts);
+    if (did > 0) return AwFmSuccess;
+    if (did < 0 && did != -(int)AwFmAllocationFailure) return (enum AwFmReturnCode)(-did);
+  }
   if (!g->amino && lanes == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_GENERAL_NO_PAIR")) {
     const unsigned long long *off = (const unsigned long long *)dOffsets;
     const bool narrow = awfmImageNarrow(g);

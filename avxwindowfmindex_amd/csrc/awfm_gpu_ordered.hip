@@ -1299,6 +1299,74 @@ int awfmGpuAminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
   return aminoLookupSearch(g, s, dChars, fixedLength, nq, rng, dCounts, rangesOfHitsOnly, nullptr);
 }
 
+/* ------------------------------------------------------------------ awfmGpuSearch: exact ranges through the tables */
+
+/* awfm_device.h.  Batches of 2^18 k-mers and more on a nucleotide image below 2^32 positions with its narrow deeper table
+ * ($AWFM_GPU_EXACT_LOOKUP=0|1: never / whenever the image can): exactLookupSearchKernel (awfm_exact_lookup_kernel.h), then the
+ * letter-by-letter general kernel over what it left (ambiguity characters, no or more than 32 characters).  K-mers shorter
+ * than the deeper table need the tables per k-mer length: used when the image has them; built for a CSR batch of 2^20
+ * k-mers and more as the hits-only search of such a batch would; without them a fixed-length batch of short k-mers is the
+ * general kernel's, and the short k-mers of a CSR batch go to it through the list. */
+int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off, uint32_t fixedLength,
+                             unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts) {
+  if (g->amino || !awfmImageNarrow(g) || !g->dev.deepSeed || g->dev.deepNarrow == 0u || g->dev.deepK < 2u || g->dev.deepK > 16u ||
+      g->dev.seedK >= g->dev.deepK || nq >= 0xFFFFFFFFull)
+    return 0;
+  if (!(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) return 0;
+  if (!off && (fixedLength == 0u || fixedLength > 32u)) return 0;
+  const char *env = getenv("AWFM_GPU_EXACT_LOOKUP");
+  if (env ? atoi(env) == 0 : nq < (1ull << 18)) return 0;
+  const bool forced = env && atoi(env) == 1;
+  const uint2 *lengthTable = nullptr;
+  if (off || fixedLength < g->dev.deepK) {
+    AwFmGpuIndex *p = g->shares ? g->shares : g;
+    {
+      std::lock_guard<std::mutex> lock(p->lengthMutex);
+      if (p->dLengthTable && p->lengthDepths >= g->dev.deepK - 1u) lengthTable = (const uint2 *)p->dLengthTable;
+    }
+    const char *mixedEnv = getenv("AWFM_GPU_MIXED_LOOKUP");
+    if (!lengthTable && (forced || (off && nq >= (1ull << 20))) && !(mixedEnv && atoi(mixedEnv) == 0)) lengthTable = ensureLengthTables(g);
+    if (!lengthTable && !off) return 0;
+  }
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  /* [counters 256 B: the leftover count][leftover list: nq x 8 B] */
+  const size_t listAt = 256u, total = listAt + alignUp256(nq * 8u);
+#define EXACT_TRY(call)                     \
+  do {                                      \
+    hipError_t e__ = (call);                \
+    if (e__ != hipSuccess) {                \
+      setError(#call, e__);                 \
+      return -(int)AwFmGeneralFailure;      \
+    }                                       \
+  } while (0)
+  EXACT_TRY(orderBeginSlot(g, s));
+  if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
+  uint8_t *w = (uint8_t *)g->dOrder;
+  unsigned *leftoverCount = (unsigned *)w;
+  unsigned long long *leftover = (unsigned long long *)(w + listAt);
+  EXACT_TRY(hipMemsetAsync(w, 0, 256, s));
+  const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_GENERAL_NO_PAIR");
+  EXACT_TRY(awfmGpuLaunchExactLookup(g, s, nullptr, nullptr, lengthTable, dChars, off, fixedLength, nq, pairOff, rng, dCounts, leftover, leftoverCount));
+  /* what the lookup kernel left, letter by letter (exact by construction): the last kernel of the search carries the event
+   * that says the scratch slot is free again */
+  if (off) {
+    const unsigned tail = residentGrid(g, searchKernel<false, 4, true, false, true, true>);
+    AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, true, false, true, true>), dim3(tail), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, g->dev, dChars, off,
+                            fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)leftover, 8u, 0u, nq,
+                            (const unsigned *)leftoverCount, SparseOut(), (const unsigned *)nullptr, 0u);
+  } else {
+    const unsigned tail = residentGrid(g, searchKernel<false, 4, false, false, true, true>);
+    AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, false, false, true, true>), dim3(tail), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, g->dev, dChars,
+                            (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
+                            (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, SparseOut(), (const unsigned *)nullptr, 0u);
+  }
+  EXACT_TRY(hipGetLastError());
+  g->orderDoneArmed = g->orderDoneEvent != nullptr;
+  EXACT_TRY(orderEndSlot(g, s));
+#undef EXACT_TRY
+  return 1;
+}
+
 /* ------------------------------------------------------------------ compulsory-traffic tally of the seed-order search */
 
 namespace {

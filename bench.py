@@ -1260,10 +1260,32 @@ def main():
                 roofline_general["traffic"] = traffic["hbm_bytes_per_launch"]
                 roofline_general["traffic_source"] = f"{tsrc}: {not_this_run} (AWFM_GPU_ORDERED=0 --mode count)"
                 roofline_general["hbm_frac_measured"] = round(traffic["hbm_bytes_per_launch"] / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-        del d_exact
         if had_deep:
             g.set_deep_seed(had_deep)
             torch.cuda.synchronize()
+            # ... and the same call -- awfmGpuSearch: the exact final range of EVERY k-mer, the first empty range of the reference's
+            # stepping for the k-mers without hits -- with the device-only tables back in place: large batches take
+            # exactLookupSearchKernel (one table entry per k-mer, exact pair steps behind it); every range must equal the
+            # general kernel's
+            d_tables = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+            g.search(d_chars.data_ptr(), off_ptr, K, Q, d_tables.data_ptr(), 0, stream)
+            torch.cuda.synchronize()
+            events = []
+            for _ in range(args.general_steps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.search(d_chars.data_ptr(), off_ptr, K, Q, d_tables.data_ptr(), 0, stream)
+                e1.record()
+                events.append((e0, e1))
+            torch.cuda.synchronize()
+            tables_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+            assert torch.equal(d_tables, d_exact), "awfmGpuSearch through the tables differs from the general kernel in some k-mer's final range"
+            roofline_general["through_the_tables"] = {
+                "kernel": "exactLookupSearchKernel (awfmGpuSearch with the device-only tables: one entry per k-mer, exact pair steps behind it)",
+                "kernel_ms": round(tables_ms, 3), "Mkmers_per_s": round(Q / tables_ms / 1e3, 1), "steps": args.general_steps,
+                "checked": "the final range of every k-mer of the batch equals the general kernel's (no deeper table)"}
+            del d_tables
+        del d_exact
         # the same figures inside `roofline`, flat, for readers that keep its scalars only: SURVEY 8(d)'s bytes over the time of
         # the kernel that reads them
         roofline["reference_algorithm"] = {"kernel": "searchKernel", "bytes": int(alg_bytes), "kernel_ms": round(gen_ms, 3),
@@ -1272,6 +1294,9 @@ def main():
         roofline["reference_algorithm_bytes"] = int(alg_bytes)
         roofline["reference_algorithm_kernel_ms"] = round(gen_ms, 3)
         roofline["reference_algorithm_frac"] = round(gen_gbs / HBM_PEAK_GBS, 4)
+        if "through_the_tables" in roofline_general:
+            roofline["exact_ranges_through_the_tables_ms"] = roofline_general["through_the_tables"]["kernel_ms"]
+            roofline["exact_ranges_through_the_tables_Mkmers_per_s"] = roofline_general["through_the_tables"]["Mkmers_per_s"]
 
     # ---- CPU baseline: the oracle on this box's host cores, bounded sample, parity-gated ----
     cpu = None

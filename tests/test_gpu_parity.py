@@ -535,6 +535,56 @@ def test_a_walk_the_walk_kernel_gives_up_is_walked_on_exactly(oracle, awfm, requ
     ix.dealloc()
 
 
+@pytest.mark.parametrize("pair", ["1", "0"])
+def test_exact_ranges_through_the_tables(oracle, awfm, require_gpu, monkeypatch, pair):
+    """awfmGpuSearch through exactLookupSearchKernel (round 5; forced here, large batches take it by themselves): every k-mer's
+    final range -- for a k-mer without hits the reference's first empty range, not just some empty one -- from ONE table entry
+    (the deeper table's, or the table of the k-mer's own length) and exact pair steps behind it.  Fixed lengths at, around and far
+    beyond the deeper table's depth and below it; CSR batches of 0..40 characters with ambiguity characters; a tandem repeat
+    whose 11-mers occur more than 65535 times (saturated 16-bit lengths: the side list); the same batches through the general
+    kernel for comparison.  Against the oracle, for every k-mer."""
+    import torch
+    monkeypatch.setenv("AWFM_GPU_PAIR", pair)
+    n = 300000
+    txt = synth.text(n + 77, n, synth.DNA_ALPHABET).copy()
+    txt[100000:240000] = np.frombuffer(b"ac" * 70000, np.uint8)
+    txt[50000:50400] = ord("n")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_deep_seed(11)
+    dev = torch.device("cuda")
+    Q = 40000
+
+    def check(chars, offsets, fixed, what):
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+        m = len(offsets) - 1
+        d_chars = torch.from_numpy(np.concatenate([chars, np.zeros(8, np.uint8)])).to(dev)
+        d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+        for knob in ("1", "0"):
+            monkeypatch.setenv("AWFM_GPU_EXACT_LOOKUP", knob)
+            d_ranges = torch.full((2 * m,), 5, dtype=torch.int64, device=dev)
+            d_counts = torch.full((m,), 5, dtype=torch.int32, device=dev)
+            g.search(d_chars.data_ptr(), 0 if fixed else d_off.data_ptr(), fixed, m, d_ranges.data_ptr(), d_counts.data_ptr())
+            torch.cuda.synchronize()
+            r = d_ranges.cpu().numpy().view(np.uint64).reshape(m, 2)
+            assert np.array_equal(r[:, 0], sp) and np.array_equal(r[:, 1], ep), (what, knob, int(np.flatnonzero((r[:, 0] != sp) | (r[:, 1] != ep))[0]))
+            assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt), (what, knob)
+
+    for K in (11, 12, 13, 14, 21, 32, 9, 3):
+        q = np.concatenate([synth.random_queries(300 + K, Q // 2, K), synth.planted_queries(400 + K, Q // 2, K, txt)])
+        q = q[np.random.default_rng(K).permutation(len(q))].copy()
+        q[::97, K // 2] = ord("n")
+        q[5::1000] = np.frombuffer((b"ac" * 16)[:K], np.uint8)  # the tandem repeat's own k-mers: ranges of 7 * 10^4
+        chars, offsets = synth.fixed_csr(q)
+        check(chars, offsets, K, f"fixed {K}")
+    chars, offsets = _mixed_queries(901, Q, txt, synth.DNA_ALPHABET, 0, 40, ambiguity=ord("n"), upper=True)
+    check(chars, offsets, 0, "csr 0..40")
+    assert g.length_tables[0] == 8 * (4 ** 11 - 4) // 3  # (the forced mode built the tables of the lengths 1..10)
+    g.destroy()
+    ix.dealloc()
+
+
 @pytest.mark.parametrize("lanes,chunk,budget", [("0,0,0", 4096, None), ("0,0", 5000, 1 << 15), (None, 70001, None), ("0", 1500, None)])
 def test_drop_in_api_takes_a_list_in_chunks(oracle, awfm, require_gpu, monkeypatch, lanes, chunk, budget):
     """awFmParallelSearchCount / Locate cut a list into chunks ($AWFM_GPU_AOS_CHUNK) that the lanes take in turn, packing

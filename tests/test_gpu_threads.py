@@ -189,8 +189,9 @@ def test_mixed_length_callers_race_for_the_length_tables(oracle, awfm, require_g
                     raise AssertionError("counts differ from the oracle")
                 if not (np.array_equal(ranges[hit, 0], job["sp"][hit]) and np.array_equal(ranges[hit, 1], job["ep"][hit])):
                     raise AssertionError("ranges of the hits differ from the oracle")
-                d_counts.fill_(9)
-                d_ranges.fill_(9)
+                with torch.cuda.stream(stream):  # (on the caller's own stream: torch's current stream in a new thread is the null
+                    d_counts.fill_(9)            # stream, which a non-blocking stream does not wait for -- the fills raced with
+                    d_ranges.fill_(9)            # the next round's results)
                 stream.synchronize()
         except Exception as e:  # noqa: BLE001
             job["errors"].append(repr(e))
