@@ -100,12 +100,13 @@ struct DevIndex {
   /* (1) the 8-byte entries are {sp, length16 | next16 << 16} (awfmGpuDeepSeedAddNext, built when the image has pair
    * blocks): bit c of next16 says whether the range is still non-empty after the pair step with code c (the two
    * characters that precede the deepK-mer in a longer k-mer; awfm_pair.h), so a hits-only search drops a k-mer whose
-   * bit is clear without reading a block.  A length of 0xFFFF stands for "0xFFFF or more": the exact one is in the side
-   * list (deepBigKeys ascending: entry numbers, deepBigLengths beside it; few entries: repeats only). */
+   * bit is clear without reading a block.  A length of 0xFFFF stands for "0xFFFF or more": the exact one is
+   * deepBigBySp[sp >> 15] -- the ranges of two entries are disjoint, so two that are 65535 positions long or longer begin
+   * 65535 or more apart and never share a window of 2^15 positions: one read instead of round 4's search in a sorted side
+   * list (9 dependent reads for the 316 such entries of a genome-shaped text, which 2 % of the k-mers drawn from it hit). */
   unsigned int deepNext;
-  unsigned int numDeepBig;
-  const unsigned int *deepBigKeys;
-  const unsigned int *deepBigLengths;
+  unsigned int numDeepBig; /* how many such entries the table has (reporting) */
+  const unsigned int *deepBigBySp;
   /* optional device-only pair image (nucleotide; awfm_pair.h): two backward / LF steps per block read; NULL when
    * not built.  pairSuper32 is the 32-bit copy of the superblock bases the kernels of images below 2^32 positions
    * keep in LDS (kPairSuperStride words per superblock). */
@@ -120,23 +121,17 @@ struct DevIndex {
 /* first entry of level d (the d-letter strings, d >= 1) in the length tables: 4 + 16 + ... + 4^(d-1) */
 __host__ __device__ inline unsigned long long awfmLengthTableAt(unsigned d) { return ((1ull << (2u * d)) - 4ull) / 3ull; }
 
-/* exact length of an entry whose 16-bit length field is saturated */
-__device__ inline unsigned deepBigLength(const DevIndex &ix, unsigned long long i) {
-  unsigned lo = 0, hi = ix.numDeepBig;
-  while (lo < hi) {
-    const unsigned mid = (lo + hi) >> 1;
-    if (ix.deepBigKeys[mid] < (unsigned)i) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo < ix.numDeepBig && ix.deepBigKeys[lo] == (unsigned)i ? ix.deepBigLengths[lo] : 0xFFFFu;
-}
+constexpr unsigned kDeepBigShift = 15;
+/* exact length of an entry whose 16-bit length field is saturated, from where its range begins */
+__device__ __forceinline__ unsigned deepBigLength(const DevIndex &ix, unsigned sp) { return ix.deepBigBySp[sp >> kDeepBigShift]; }
 /* {sp, ep} from the two words of a narrow entry; *next16 (may be NULL): the pair steps that keep the range non-empty
  * (all of them when the table has no such bits) */
 __device__ __forceinline__ ulonglong2 deepSeedOpen(const DevIndex &ix, unsigned long long i, uint2 e, unsigned *next16) {
   unsigned length = e.y;
   if (ix.deepNext) {
     length = e.y & 0xFFFFu;
-    if (length == 0xFFFFu) length = deepBigLength(ix, i);
+    if (length == 0xFFFFu) length = deepBigLength(ix, e.x);
+    (void)i;
     if (next16) *next16 = e.y >> 16;
   } else if (next16) {
     *next16 = 0xFFFFu;
@@ -745,7 +740,7 @@ struct AwFmGpuIndex {
   uint64_t deepSeedBytes = 0;
   double deepSeedBuildSeconds = 0.0;    /* wall time of the last construction of the deeper table (reporting) */
   uint64_t deepSeedTransientBytes = 0;  /* device memory that construction held beyond the table itself, at its peak */
-  void *dDeepBig = nullptr; /* side list of the deeper table: keys, then lengths (DevIndex::deepBigKeys) */
+  void *dDeepBig = nullptr; /* the deeper table's lengths of 65535 and more, by where the range begins (DevIndex::deepBigBySp) */
   /* optional tables of the k-mer lengths below the deeper table's (awfmGpuBuildLengthTables), built by the first
    * mixed-length batch that can use them; owned by the primary, found there by its lanes (under lengthMutex) */
   std::mutex lengthMutex;
@@ -981,9 +976,9 @@ int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
 extern thread_local void *awfmGpuDenseSaStash;
 extern thread_local unsigned long long awfmGpuDenseSaStashLength;
 /* awfm_gpu_ordered.hip: rewrites the 8-byte entries {sp, length} of a finished table as {sp, length16 | next16 << 16}
- * (DevIndex::deepNext) and returns the side list of the saturated lengths in *bigOut (one allocation: *numBigOut keys,
- * then as many lengths; NULL when there is none).  Needs the pair image.  1: done; 0: not applicable, nothing was
- * changed; -1: failed, the table is no longer usable. */
+ * (DevIndex::deepNext) and returns the lengths that do not fit 16 bits in *bigOut ((bwtLength >> 15) + 1 words, indexed by
+ * sp >> 15: DevIndex::deepBigBySp; *numBigOut: how many there are).  Needs the pair image.  1: done; 0: not applicable,
+ * nothing was changed; -1: failed, the table is no longer usable. */
 int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **bigOut, unsigned *numBigOut);
 void awfmGpuSetError(const char *what);
 void awfmGpuSetHipError(const char *what, hipError_t e);

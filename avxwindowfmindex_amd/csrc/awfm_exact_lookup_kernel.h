@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
       unsigned length = entry[i].y;
       if (len[i] >= DK && ix.deepNext != 0u) { /* {sp, length16 | next16 << 16}: the next-step bits are no use to an exact search */
         length &= 0xFFFFu;
-        if (length == 0xFFFFu) length = deepBigLength(ix, codes[i] & ((1ull << (2u * DK)) - 1ull));
+        if (length == 0xFFFFu) length = deepBigLength(ix, entry[i].x);
       }
       const bool looked = len[i] != 0u;
       const bool survives = looked && len[i] > DK && length != 0u;

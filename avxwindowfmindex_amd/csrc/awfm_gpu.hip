@@ -1049,7 +1049,7 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
   g->dev.deepNarrow = 0;
   g->dev.deepNext = 0;
   g->dev.numDeepBig = 0;
-  g->dev.deepBigKeys = g->dev.deepBigLengths = nullptr;
+  g->dev.deepBigBySp = nullptr;
   { /* the tables of the shorter lengths go with the deeper table they complete; the next mixed-length batch builds them again */
     std::lock_guard<std::mutex> lock(g->lengthMutex);
     if (g->dLengthTable) (void)hipFree(g->dLengthTable);
@@ -1080,14 +1080,16 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
       } else {
         g->dDeepSeed = table;
         g->dDeepBig = big;
-        g->deepSeedBytes = bytes + (uint64_t)numBig * 8u;
+        g->deepSeedBytes = bytes + (big ? ((g->dev.bwtLength >> kDeepBigShift) + 5u) * 4u : 0u);
         g->dev.deepSeed = (const ulonglong2 *)table;
         g->dev.deepK = deepK;
         g->dev.deepNarrow = g->dev.bwtLength < (1ull << 32) ? 1u : 0u;
         g->dev.deepNext = next > 0 ? 1u : 0u;
         g->dev.numDeepBig = numBig;
-        g->dev.deepBigKeys = (const unsigned *)big;
-        g->dev.deepBigLengths = (const unsigned *)big + numBig;
+        g->dev.deepBigBySp = (const unsigned *)big;
+        if (getenv("AWFM_VERBOSE"))
+          fprintf(stderr, "[awfm deeper table] depth %u: %.2f GB in %.2f s; next-step bits %s; %u entries with ranges of 65535 and more\n",
+                  deepK, (double)bytes * 1e-9, g->deepSeedBuildSeconds, next > 0 ? "yes" : "no", numBig);
       }
     } else {
       rc = AwFmGeneralFailure;
@@ -1100,8 +1102,7 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
     lane->dev.deepK = g->dev.deepK;
     lane->dev.deepNext = g->dev.deepNext;
     lane->dev.numDeepBig = g->dev.numDeepBig;
-    lane->dev.deepBigKeys = g->dev.deepBigKeys;
-    lane->dev.deepBigLengths = g->dev.deepBigLengths;
+    lane->dev.deepBigBySp = g->dev.deepBigBySp;
   }
   return rc;
 }

@@ -230,19 +230,16 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **
   if (getenv("AWFM_GPU_DEEP_NEXT") && atoi(getenv("AWFM_GPU_DEEP_NEXT")) == 0) return 0; /* comparison runs */
   DeviceGuard guard(g->device);
   const unsigned long long numEntries = 1ull << (2u * deepK);
-  unsigned *dNumBig = nullptr; /* number of saturated lengths */
-  if (hipMalloc((void **)&dNumBig, 16) != hipSuccess) {
+  /* the lengths that do not fit the entries' 16 bits, by where their ranges begin (awfm_device.h: deepBigLength), allocated
+   * before the in-place rewrite so that it cannot fail half-way; + the word that counts them */
+  const size_t bigWords = (size_t)(g->dev.bwtLength >> kDeepBigShift) + 1u;
+  unsigned *dBig = nullptr;
+  if (hipMalloc((void **)&dBig, (bigWords + 4u) * 4u) != hipSuccess) {
     (void)hipGetLastError();
     return 0;
   }
-  bool ok = hipMemset(dNumBig, 0, 16) == hipSuccess;
+  bool ok = hipMemset(dBig, 0, (bigWords + 4u) * 4u) == hipSuccess;
   unsigned numBig = 0;
-  if (ok) {
-    hipLaunchKernelGGL(deepBigCountKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const uint2 *)table, numEntries, dNumBig);
-    ok = hipMemcpy(&numBig, dNumBig, 4, hipMemcpyDeviceToHost) == hipSuccess && hipMemset(dNumBig, 0, 4) == hipSuccess;
-  }
-  unsigned *dBig = nullptr;
-  if (ok && numBig != 0) ok = hipMalloc((void **)&dBig, (size_t)numBig * 8u) == hipSuccess;
   if (ok) {
     const bool superInLds = awfmPairSuperInLds(g);
     const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
@@ -250,32 +247,14 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **
     dev.pairSuperInLds = superInLds ? 1u : 0u;
     constexpr int threads = orderedThreads(true);
     unsigned grid = residentGrid(g, deepNextKernel, lds, threads);
-    hipLaunchKernelGGL(deepNextKernel, dim3(grid ? grid : 1u), dim3(threads), lds, 0, dev, (uint2 *)table, numEntries, dBig,
-                       dBig + numBig, dNumBig, numBig);
-    ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    hipLaunchKernelGGL(deepNextKernel, dim3(grid ? grid : 1u), dim3(threads), lds, 0, dev, (uint2 *)table, numEntries, dBig, dBig + bigWords);
+    ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+         hipMemcpy(&numBig, dBig + bigWords, 4, hipMemcpyDeviceToHost) == hipSuccess;
   }
-  if (ok && numBig != 0) { /* ascending entry numbers: the kernels look a length up by bisection */
-    unsigned *sorted = nullptr;
-    size_t tempBytes = 0;
-    void *temp = nullptr;
-    ok = hipMalloc((void **)&sorted, (size_t)numBig * 8u) == hipSuccess &&
-         rocprim::radix_sort_pairs(nullptr, tempBytes, dBig, sorted, dBig + numBig, sorted + numBig, numBig) == hipSuccess &&
-         hipMalloc(&temp, tempBytes ? tempBytes : 16) == hipSuccess &&
-         rocprim::radix_sort_pairs(temp, tempBytes, dBig, sorted, dBig + numBig, sorted + numBig, numBig) == hipSuccess &&
-         hipDeviceSynchronize() == hipSuccess;
-    if (temp) (void)hipFree(temp);
-    if (ok) {
-      (void)hipFree(dBig);
-      dBig = sorted;
-    } else if (sorted) {
-      (void)hipFree(sorted);
-    }
-  }
-  (void)hipFree(dNumBig);
   if (!ok) {
     /* the table may have been rewritten in part: the caller must not use it */
     (void)hipGetLastError();
-    if (dBig) (void)hipFree(dBig);
+    (void)hipFree(dBig);
     awfmGpuSetError("deep seed table: the pass that adds the next-step bits failed");
     return -1;
   }

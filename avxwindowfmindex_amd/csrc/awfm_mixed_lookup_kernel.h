@@ -72,7 +72,7 @@ __device__ __forceinline__ MixedVerdict mixedRead(const DevIndex &ix, unsigned u
   if (deep && ix.deepNext != 0u) {
     next16 = length >> 16;
     length &= 0xFFFFu;
-    if (length == 0xFFFFu) length = deepBigLength(ix, codes & ((1ull << (2u * DK)) - 1ull));
+    if (length == 0xFFFFu) length = deepBigLength(ix, entry.x);
   }
   v.length = length;
   v.hitNow = len != 0u && len <= DK && length != 0u;

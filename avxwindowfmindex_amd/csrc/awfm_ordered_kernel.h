@@ -1785,12 +1785,11 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
 /* ---- the "next pair step" bits of the deeper table (DevIndex::deepNext) ----
  * One group of 4 lanes per entry {sp, length} with length > 0: the 16 pair steps the search kernel could take from that
  * range -- the same device functions, flagged blocks through the one-letter image as there -- and bit c of next16 set
- * when the range after step c still holds a position.  Entries whose length does not fit 16 bits go to the side list
- * (appended; sorted by the caller).  Persistent grid, chunks of 16 entries per wave at a fixed stride. */
+ * when the range after step c still holds a position.  A length that does not fit 16 bits goes to bigBySp[sp >> 15]
+ * (awfm_device.h: deepBigLength).  Persistent grid, chunks of 16 entries per wave at a fixed stride. */
 __global__ void __launch_bounds__(orderedThreads(true)) __attribute__((amdgpu_num_sgpr(80)))
     deepNextKernel(const DevIndex ix, uint2 *__restrict__ table, const unsigned long long numEntries,
-                   unsigned *__restrict__ bigKeys, unsigned *__restrict__ bigLengths,
-                   unsigned *__restrict__ numBig, const unsigned bigCapacity) {
+                   unsigned *__restrict__ bigBySp, unsigned *__restrict__ numBig) {
   constexpr int G = 4;
   constexpr int S = (int)kSlices / G;
   __shared__ unsigned long long sC[24];
@@ -1824,28 +1823,14 @@ __global__ void __launch_bounds__(orderedThreads(true)) __attribute__((amdgpu_nu
         if (sp <= ep) next16 |= 1u << code;
       }
       if (gl == 0) {
-        if (e.y >= 0xFFFFu) {
-          const unsigned slot = atomicAdd(numBig, 1u);
-          if (slot < bigCapacity) {
-            bigKeys[slot] = (unsigned)at;
-            bigLengths[slot] = e.y;
-          }
+        if (e.y >= 0xFFFFu) { /* (awfm_device.h: deepBigLength) */
+          bigBySp[e.x >> kDeepBigShift] = e.y;
+          atomicAdd(numBig, 1u);
         }
         table[at] = make_uint2(e.x, (e.y < 0xFFFFu ? e.y : 0xFFFFu) | next16 << 16);
       }
     }
   }
-}
-
-/* how many entries of a narrow table have a length that does not fit 16 bits */
-__global__ void __launch_bounds__(256) deepBigCountKernel(const uint2 *__restrict__ table, const unsigned long long numEntries,
-                                                          unsigned *__restrict__ numBig) {
-  unsigned mine = 0;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < numEntries;
-       i += (unsigned long long)gridDim.x * blockDim.x)
-    mine += table[i].y >= 0xFFFFu;
-  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
-  if ((threadIdx.x & 63u) == 0 && mine) atomicAdd(numBig, mine);
 }
 
 }  // namespace
