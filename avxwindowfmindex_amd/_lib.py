@@ -37,7 +37,7 @@ GPU_SYMBOLS = [
     "awfmGpuSearchHitsPacked", "awfmGpuLocateTo", "awfmGpuSearchHitsLineTally", "awfmGpuIndexDeepSeedK", "awfmGpuSearchHitsCompact", "awfmGpuCompactHits", "awfmGpuSortHits",
     "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse", "awfmGpuSearchHitsInOrder",
     "awfmGpuSortHitsOnDevice", "awfmGpuHitOffsetsOnDevice", "awfmGpuLocateOnDevice", "awfmGpuLastOrderedSearchKernelMs", "awfmGpuOrderedKernelLog", "awfmGpuIndexDeepSeedBuildSeconds", "awfmGpuIndexDeepSeedTransientBytes", "awfmGpuIndexHasDenseSa", "awfmGpuIndexDenseSaBuildSeconds", "awfmGpuIndexLengthTableBytes", "awfmGpuIndexLengthTableBuildSeconds", "awfmGpuMixedLookupLineTally",
-    "awfmGpuListLocateOnDevice", "awfmGpuLastLookupFront",
+    "awfmGpuListLocateOnDevice", "awfmGpuLastLookupFront", "awfmGpuSynthPlantedQueriesUnique",
 ]
 # int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
 CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
@@ -195,6 +195,7 @@ def lib():
         "awfmGpuSynthRandomQueries": (C.c_int, [vp, u64, u64, C.c_uint32, u64, C.c_int, vp]),
         "awfmGpuSynthPlantedQueries": (C.c_int, [vp, u64, u64, C.c_uint32, u64, vp, u64, vp]),
         "awfmGpuSynthPlantedQueriesClean": (C.c_int, [vp, u64, u64, C.c_uint32, u64, vp, u64, vp]),
+        "awfmGpuSynthPlantedQueriesUnique": (C.c_int, [vp, u64, u64, C.c_uint32, u64, vp, u64, u64, vp, vp]),
         "awfmGpuSynthGenomeText": (C.c_int, [vp, u64, u64, vp]),
         "awfmGpuSynthMixedLengths": (C.c_int, [vp, u64, u64, C.c_uint32, C.c_uint32, u64, vp]),
         "awfmGpuSynthMixedQueries": (C.c_int, [vp, vp, u64, u64, u64, vp, u64, C.c_int, vp]),

@@ -145,9 +145,46 @@ __global__ void synthPlantedCleanKernel(unsigned char *out, u64 first, u64 count
     out[t] = plain ? ch : kDna[mix64(q + (c + 2ull) * kGolden) % 4ull];
   }
 }
+/* k-mers drawn from the UNIQUE sequence of a genome-shaped text (the 72 % of its 1024-character blocks that are no repeat
+ * family's and no tandem repeat's, outside the runs of 'n'): offset number t of k-mer j is mix64(q + (t + 1) kGolden) mod
+ * (n - length + 1), and the k-mer takes the first of up to 64 whose window lies in unique blocks and holds only a,c,g,t -- so
+ * that every k-mer has a hit at a known offset and few besides (a 21-mer out of a repeat family has 10^5): the batch a
+ * locate of k-mers "drawn from the text" can be timed on.  One thread per k-mer. */
+__global__ void synthPlantedUniqueKernel(unsigned char *out, u64 first, u64 count, unsigned length, u64 seedQ,
+                                         const unsigned char *text, u64 n, u64 textSeed, u64 *offsetsOut) {
+  const u64 stride = (u64)gridDim.x * blockDim.x;
+  for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+    const u64 q = mix64(seedQ + first + j);
+    u64 offset = 0;
+    for (u64 t = 0; t < 64ull; t++) {
+      offset = mix64(q + (t + 1ull) * kGolden) % (n - length + 1ull);
+      const u64 b0 = offset / kGenomeBlock, b1 = (offset + length - 1ull) / kGenomeBlock;
+      bool ok = mix64(textSeed + kSaltBlock + (b0 + 1ull) * kGolden) % 100ull >= 28ull &&
+                mix64(textSeed + kSaltBlock + (b1 + 1ull) * kGolden) % 100ull >= 28ull;
+      for (unsigned c = 0; ok && c < length; c++) {
+        const unsigned char ch = text[offset + c];
+        ok = ch == 'a' || ch == 'c' || ch == 'g' || ch == 't';
+      }
+      if (ok) break;
+    }
+    for (unsigned c = 0; c < length; c++) out[j * length + c] = text[offset + c];
+    if (offsetsOut) offsetsOut[j] = offset;
+  }
+}
 }  // namespace
 
 extern "C" {
+
+enum AwFmReturnCode awfmGpuSynthPlantedQueriesUnique(uint8_t *dOut, uint64_t first, uint64_t count, uint32_t length, uint64_t seedQ,
+                                                     const uint8_t *dText, uint64_t textLength, uint64_t textSeed,
+                                                     uint64_t *dOffsetsOut, void *stream) {
+  if (!dOut || !dText) return AwFmNullPtrError;
+  if (count == 0 || length == 0) return AwFmSuccess;
+  if (textLength < length) return AwFmIllegalPositionError;
+  hipLaunchKernelGGL(synthPlantedUniqueKernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, dOut, (u64)first, (u64)count, length,
+                     (u64)seedQ, dText, (u64)textLength, (u64)textSeed, (u64 *)dOffsetsOut);
+  return hipGetLastError() == hipSuccess ? AwFmSuccess : AwFmGeneralFailure;
+}
 
 enum AwFmReturnCode awfmGpuSynthGenomeText(uint8_t *dOut, uint64_t length, uint64_t seed, void *stream) {
   if (!dOut) return AwFmNullPtrError;

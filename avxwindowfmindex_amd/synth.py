@@ -97,6 +97,30 @@ def planted_queries_clean(seed_q, count, length, txt, first=0):
     return q
 
 
+def planted_unique_offsets(seed_q, count, length, txt, text_seed, first=0):
+    """the offsets awfmGpuSynthPlantedQueriesUnique takes its k-mers from: the first of up to 64 seeded offsets whose window lies
+    in unique blocks of the genome-shaped text `txt` = genome_text(text_seed, n) and holds only a,c,g,t"""
+    n = len(txt)
+    q = _qstate(seed_q, first, count)
+    lut = np.frombuffer(DNA_ALPHABET, dtype=np.uint8)
+    plain = np.isin(txt, lut)
+    bad_before = np.concatenate([[0], np.cumsum(~plain)])  # characters that are no a,c,g,t before position i
+    out = np.zeros(count, dtype=np.uint64)
+    done = np.zeros(count, dtype=bool)
+    with np.errstate(over="ignore"):
+        for t in range(64):
+            off = mix64(q + np.uint64(t + 1) * GOLDEN) % np.uint64(n - length + 1)
+            b0, b1 = off // np.uint64(GENOME_BLOCK), (off + np.uint64(length - 1)) // np.uint64(GENOME_BLOCK)
+            k0 = mix64(np.uint64(text_seed) + np.uint64(_SALT_BLOCK) + (b0 + np.uint64(1)) * GOLDEN) % np.uint64(100)
+            k1 = mix64(np.uint64(text_seed) + np.uint64(_SALT_BLOCK) + (b1 + np.uint64(1)) * GOLDEN) % np.uint64(100)
+            o = off.astype(np.int64)
+            ok = (k0 >= 28) & (k1 >= 28) & (bad_before[o + length] == bad_before[o])
+            take = ~done & (ok | (t == 63))
+            out[take] = off[take]
+            done |= take
+    return out
+
+
 def _qstate(seed_q, first, count):
     with np.errstate(over="ignore"):
         return mix64(np.uint64(seed_q) + np.arange(first, first + count, dtype=np.uint64))

@@ -52,7 +52,10 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--workload", choices=["random", "planted", "mixed"], default="random")
+    p.add_argument("--workload", choices=["random", "planted", "mixed", "unique"], default="random",
+                   help="unique (with --text repetitive): k-mers drawn from the unique sequence of the genome-shaped text -- every "
+                        "k-mer has a hit and few besides, so the batch can be LOCATED (planted k-mers of that text are counted: a "
+                        "21-mer out of a repeat family has 10^5 hits)")
     p.add_argument("--mixed-lengths", type=int, nargs=2, default=[8, 30], metavar=("LO", "HI"),
                    help="--workload mixed: the k-mer lengths (configs[4]: 8 30)")
     p.add_argument("--mode", choices=["locate", "count"], default=None,
@@ -76,6 +79,7 @@ def parse():
     p.add_argument("--no-e2e", action="store_true", help="skip the host-inclusive end_to_end leg")
     p.add_argument("--no-secondary", action="store_true", help="skip the planted (every k-mer has a hit) line of the default run")
     p.add_argument("--no-amino", action="store_true", help="skip the amino lines (configs[3]) of the default run's secondary")
+    p.add_argument("--no-repetitive", action="store_true", help="skip the genome-shaped-text line of the default run's secondary")
     p.add_argument("--no-shard-proxy", dest="shard_proxy", action="store_false",
                    help="skip the single-GPU strong-scaling proxy (the shards 2, 4 and 8 ranks would hold, each timed alone)")
     p.add_argument("--proxy-steps", type=int, default=5, help="timed steps per shard of the proxy")
@@ -447,6 +451,131 @@ def amino_leg(L, api, digest, torch, np, dev, n, Q=50_000_000, K=10, seed_k=5, s
     return out
 
 
+def repetitive_leg(L, api, digest, torch, np, dev, n=3_100_000_000, Q=100_000_000, K=21, seed_k=12, sa_ratio=8, steps=3, record_digests=None):
+    """The text shape real users have, in the driver's own run (round 5): a genome-shaped 3.1 Gbp text (repeat families, tandem
+    repeats, runs of N: synth.genome_text) indexed on the device, and Q K-mers drawn from its UNIQUE sequence LOCATED -- every
+    k-mer has a hit at a known offset and few besides -- with the step the planted secondary runs (results in search order:
+    awfmGpuSearchHitsInOrder + hit offsets + awfmGpuLocateOnDevice).  Checked: every k-mer listed once, every k-mer's own
+    offset among its positions (first 10^6 of the order), the CPU oracle on a sample, committed digests."""
+    t0 = time.time()
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthGenomeText(d_text.data_ptr(), n, 2, None) == 1
+    torch.cuda.synchronize()
+    ix = api.gpu_create_index(d_text.data_ptr(), api.AwFmAlphabetDna, sa_ratio, seed_k, on_device_length=n, device=dev.index)
+    g = api.GpuIndex(ix, acquire=True)
+    build_s = time.time() - t0
+    d_chars = torch.empty(Q * K, dtype=torch.uint8, device=dev)
+    d_planted_at = torch.empty(Q, dtype=torch.int64, device=dev)
+    assert L.awfmGpuSynthPlantedQueriesUnique(d_chars.data_ptr(), 0, Q, K, 106, d_text.data_ptr(), n, 2, d_planted_at.data_ptr(), None) == 1
+    torch.cuda.synchronize()
+    del d_text
+    torch.cuda.empty_cache()
+    assert g.search_hits_is_ordered(False, K, Q), "the batch is not one for the seed-order path"
+    d_kmers = torch.empty(Q, dtype=torch.int32, device=dev)
+    d_ranges = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+    d_off = torch.empty(Q + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.empty(api.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+    stream_obj = torch.cuda.Stream()
+    stream = stream_obj.cuda_stream
+    torch.cuda.synchronize()
+    g.search_hits_in_order(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
+    g.hit_offsets_on_device(0, d_ranges.data_ptr(), Q, d_off.data_ptr(), d_scratch.data_ptr(), stream)
+    torch.cuda.synchronize()
+    hits = int(d_off[Q].item())
+    d_pos = torch.empty(hits + hits // 8 + 64, dtype=torch.int64, device=dev)
+
+    def step():
+        g.search_hits_in_order(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
+        g.hit_offsets_on_device(0, d_ranges.data_ptr(), Q, d_off.data_ptr(), d_scratch.data_ptr(), stream)
+        g.locate_on_device(d_ranges.data_ptr(), d_off.data_ptr(), Q, d_pos.numel(), d_pos.data_ptr(), stream)
+
+    timing = os.environ.get("AWFM_GPU_TIME_ORDERED")
+    os.environ["AWFM_GPU_TIME_ORDERED"] = "1"
+    step()
+    torch.cuda.synchronize()
+    g.ordered_kernel_log()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t1) * 1e3 / steps
+    kernel_ms = float(np.mean([k for _, k in g.ordered_kernel_log()]))
+    if timing is None:
+        del os.environ["AWFM_GPU_TIME_ORDERED"]
+    assert int(d_off[Q].item()) == hits
+    # ---- checks ----
+    kmers = d_kmers.to(torch.int64)
+    assert int(torch.bincount(kmers, minlength=Q).max().item()) == 1, "a k-mer is missing from the order or listed twice"
+    lens = d_off[1:] - d_off[:-1]
+    assert int(lens.min().item()) >= 1, "a k-mer drawn from the text was not found"
+    m = min(Q, 1_000_000)
+    ho = d_off[: m + 1].cpu().numpy().view(np.uint64)
+    pos = d_pos[: int(ho[m])].cpu().numpy().view(np.uint64)
+    at = d_planted_at[kmers[:m]].cpu().numpy().view(np.uint64)
+    cnt = np.diff(ho)
+    one = cnt == 1
+    assert np.array_equal(pos[ho[:-1][one]], at[one]), "a k-mer was located somewhere else than where it was taken from"
+    for i in np.flatnonzero(~one)[:1000]:
+        assert at[i] in pos[ho[i]:ho[i + 1]], "a k-mer's own offset is missing from its hit list"
+    # the CPU oracle on the first k-mers of the batch: ranges, counts, positions in BWT order
+    from oracle import oracle as O
+    oi = O.Index.wrap(O.DNA, sa_ratio, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    ms_ = min(Q, 200_000)
+    chars = d_chars[: ms_ * K].cpu().numpy()
+    sp, ep, ocnt, _ = oi.batch_search(chars, np.arange(ms_ + 1, dtype=np.uint64) * np.uint64(K), threads=min(os.cpu_count() or 1, 16))
+    oho, opos, _ = oi.batch_locate(sp, ep, threads=min(os.cpu_count() or 1, 16))
+    slot = torch.empty(Q, dtype=torch.int64, device=dev)
+    slot[kmers] = torch.arange(Q, dtype=torch.int64, device=dev)
+    sl = slot[:ms_]
+    gr = d_ranges.view(Q, 2)[sl].cpu().numpy().view(np.uint64)
+    assert np.array_equal(gr[:, 0], sp) and np.array_equal(gr[:, 1], ep), "genome-shaped text: GPU ranges differ from the oracle"
+    starts, ends = d_off[:-1][sl].cpu().numpy(), d_off[1:][sl].cpu().numpy()
+    gpos = np.concatenate([d_pos[int(a):int(b)].cpu().numpy() for a, b in zip(starts[:2000], ends[:2000])]).view(np.uint64)
+    assert np.array_equal(gpos, opos[: int(oho[2000])]), "genome-shaped text: GPU positions differ from the oracle"
+    # digests of the whole batch (k-mer order): counts, and positions through the dense offsets
+    counts = torch.zeros(Q, dtype=torch.int64, device=dev)
+    counts[kmers] = lens
+    dense_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=dense_off[1:])
+    dense_pos = torch.empty(max(hits, 1), dtype=torch.int64, device=dev)
+    step_q = 1 << 24
+    for b in range(0, Q, step_q):
+        e = min(Q, b + step_q)
+        lo, hi = int(d_off[b].item()), int(d_off[e].item())
+        if hi > lo:
+            shift = torch.repeat_interleave(dense_off[:-1][kmers[b:e]] - d_off[b:e], lens[b:e])
+            dense_pos[shift + torch.arange(lo, hi, dtype=torch.int64, device=dev)] = d_pos[lo:hi]
+    key = digest.key("dna-repetitive", "unique", "locate", n, str(K), seed_k, sa_ratio, 0, Q)
+    dig = {"counts": f"{digest.counts_digest(0, counts):016x}", "positions": f"{digest.positions_digest(0, dense_off, dense_pos[: max(hits, 1)]):016x}"}
+    committed = digest.load_golden().get(key)
+    assert committed is None or committed == dig, f"genome-shaped text: digests {dig} differ from the committed {committed}"
+    if record_digests:
+        known = json.load(open(record_digests)) if os.path.exists(record_digests) else {}
+        known[key] = dig
+        json.dump(known, open(record_digests, "w"), indent=1, sort_keys=True)
+    del counts, dense_off, dense_pos, slot, lens, kmers
+    # roofline of the dominant kernel: compulsory lines (the main line's basis), tallied by the instrumented launch
+    lines = g.search_hits_line_tally(d_chars.data_ptr(), 0, K, Q)
+    compulsory = (128 * (lines["seed_table_lines"] + lines["deep_table_lines"] + lines["pair_level_lines"] + lines["nuc_level_lines"])
+                  + lines["record_bytes_per_kmer"] * lines["ordered_kmers"] + 20 * lines["ordered_kmers"])
+    out = {"workload": f"{Q / 1e6:g} M {K}-mers drawn from the unique sequence of a genome-shaped {n / 1e9:g} Gbp text (repeat families, tandem repeats, "
+                       f"24 runs of N), locate, SA ratio {sa_ratio}, seed table k={seed_k}; results in search order",
+           "value": round(Q / ms / 1e3, 2), "unit": "Mkmers/s", "ms_per_step": round(ms, 3), "steps": steps, "hits_per_step": hits,
+           "index_build_s": round(build_s, 2), "device_image_bytes": g.device_bytes, "device_seed_k": g.deep_seed_k, "device_dense_sa": bool(g.has_dense_sa),
+           "roofline": {"bound": "hbm", "kernel": "orderedSearchKernel", "basis": "compulsory_lines", "kernel_ms": round(kernel_ms, 3),
+                        "compulsory_bytes": int(compulsory), "achieved": round(compulsory / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(compulsory / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "compulsory": lines},
+           "checked": f"every k-mer once in the order; the first {m} entries located where they were taken from; ranges of the first {ms_} k-mers and "
+                      "positions of the first 2000 against the CPU oracle",
+           "digests": dict(dig, status="match" if committed else "unknown")}
+    g.handle = None
+    L.awfmGpuIndexRelease(ix.ptr)
+    ix.dealloc()
+    del d_chars, d_planted_at, d_kmers, d_ranges, d_off, d_scratch, d_pos
+    torch.cuda.empty_cache()
+    return out
+
+
 def profile_file(kind, name):
     path = os.path.join(ROOT, "profiles", PROFILE_ROUND, f"{kind}_{name}.json")
     return (json.load(open(path)), f"profiles/{PROFILE_ROUND}/{kind}_{name}.json") if os.path.exists(path) else (None, None)
@@ -488,7 +617,8 @@ def main():
         # 2 * 10^11 positions.  The locate form of this workload is 2 M k-mers (5 * 10^9 hits), located in windows.
         args.queries = 2_000_000
     text_seed = 4 if amino else 2
-    query_seed = 104 if amino else {"random": 102, "planted": 103, "mixed": 105}[args.workload]
+    query_seed = 104 if amino else {"random": 102, "planted": 103, "mixed": 105, "unique": 106}[args.workload]
+    assert args.workload != "unique" or args.text == "repetitive", "--workload unique draws from a genome-shaped text (--text repetitive)"
 
     # ---- index replica on this GPU (text generated and indexed on the device) ----
     t0 = time.time()
@@ -556,6 +686,8 @@ def main():
         pass
     elif args.workload == "random":
         assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr(), first, Q, K, query_seed, int(amino), None) == 1
+    elif args.workload == "unique":
+        assert L.awfmGpuSynthPlantedQueriesUnique(d_chars.data_ptr(), first, Q, K, query_seed, d_text.data_ptr(), n, text_seed, None, None) == 1
     else:
         # k-mers drawn from a text with runs of N get their N replaced: a k-mer of N matches every window of every run
         plant = L.awfmGpuSynthPlantedQueriesClean if args.text == "repetitive" else L.awfmGpuSynthPlantedQueries
@@ -1601,6 +1733,11 @@ def main():
             known.update(shard_digests)
             json.dump(known, open(args.record_digests, "w"), indent=1, sort_keys=True)
     del d_planted
+    # ---- the same step on the text shape real users have: a genome-shaped 3.1 Gbp text with an index of its own, 10^8 21-mers
+    # drawn from its unique sequence, located (repetitive_leg); while the run is young enough ----
+    if secondary is not None and not args.no_repetitive and time.time() - T_START < 240:
+        torch.cuda.empty_cache()
+        secondary["repetitive"] = repetitive_leg(L, api, digest, torch, np, dev, record_digests=args.record_digests)
 
     deep_last_build = g.deep_seed_build
     # ---- the drop-in user's FIRST call: the index in host memory (as awFmReadIndexFromFile leaves it), no device image yet.
@@ -1712,7 +1849,7 @@ def main():
         if "mixed_lengths" in secondary:
             config["mixed_lengths_ms_per_step"] = secondary["mixed_lengths"]["ms_per_step"]
             config["mixed_lengths_value"] = secondary["mixed_lengths"]["value"]
-        for name in ("amino", "amino_2e9"):
+        for name in ("amino", "amino_2e9", "repetitive"):
             if name in secondary:
                 config[name + "_value"] = secondary[name]["value"]
                 config[name + "_ms_per_step"] = secondary[name]["ms_per_step"]

@@ -462,6 +462,13 @@ enum AwFmReturnCode awfmGpuSynthGenomeText(uint8_t *dOut, uint64_t length, uint6
 enum AwFmReturnCode awfmGpuSynthPlantedQueriesClean(uint8_t *dOut, uint64_t first, uint64_t count, uint32_t length,
                                                     uint64_t seedQ, const uint8_t *dText, uint64_t textLength, void *stream);
 
+/* `count` k-mers copied from the UNIQUE sequence of the genome-shaped text of awfmGpuSynthGenomeText(textSeed): the first of up
+ * to 64 seeded offsets whose window lies in blocks that are no repeat's and holds only a,c,g,t; dOffsetsOut (may be NULL)
+ * gets the offset each k-mer was taken from */
+enum AwFmReturnCode awfmGpuSynthPlantedQueriesUnique(uint8_t *dOut, uint64_t first, uint64_t count, uint32_t length, uint64_t seedQ,
+                                                     const uint8_t *dText, uint64_t textLength, uint64_t textSeed,
+                                                     uint64_t *dOffsetsOut, void *stream);
+
 /* mixed-length set: lengths lo..hi, even ids random, odd ids copied from the text.
  * Lengths first; the caller turns them into count+1 exclusive-scan offsets; then the characters. */
 enum AwFmReturnCode awfmGpuSynthMixedLengths(uint64_t *dLengths, uint64_t first, uint64_t count, uint32_t lo,

@@ -210,6 +210,13 @@ def test_genome_shaped_text_generator_and_build(awfm, require_gpu):
     q = torch.empty(3000 * 21, dtype=torch.uint8, device="cuda")
     assert L.awfmGpuSynthPlantedQueriesClean(q.data_ptr(), 5, 3000, 21, 13, d.data_ptr(), n, None) == 1
     assert np.array_equal(q.cpu().numpy().reshape(3000, 21), synth.planted_queries_clean(13, 3000, 21, txt, first=5))
+    # k-mers drawn from the unique sequence only (no repeat family's block, no N): the offsets synth.py defines, letters only
+    offs = torch.empty(3000, dtype=torch.int64, device="cuda")
+    assert L.awfmGpuSynthPlantedQueriesUnique(q.data_ptr(), 5, 3000, 21, 13, d.data_ptr(), n, 2, offs.data_ptr(), None) == 1
+    want = synth.planted_unique_offsets(13, 3000, 21, txt, 2, first=5)
+    assert np.array_equal(offs.cpu().numpy().view(np.uint64), want)
+    got = q.cpu().numpy().reshape(3000, 21)
+    assert np.array_equal(got, txt[want.astype(np.int64)[:, None] + np.arange(21)[None, :]]) and np.all(np.isin(got, np.frombuffer(b"acgt", np.uint8)))
     host = _host_build(awfm, txt, awfm.AwFmAlphabetDna, 8, 8)
     dev = awfm.gpu_create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
     _same_arrays(host, dev)

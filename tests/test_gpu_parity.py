@@ -282,7 +282,9 @@ def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, requir
     g = awfm.GpuIndex(ix)
     before = g.device_bytes
     g.set_deep_seed(deep_k)
-    assert g.device_bytes == before + 8 * 4 ** deep_k  # {sp, length}: 8 bytes per entry below 2^32 positions
+    # {sp, length}: 8 bytes per entry below 2^32 positions; with the next-step bits (images with pair blocks) the lengths of
+    # 65535 and more have a table of their own, a word per 2^15 positions
+    assert g.device_bytes - before - 8 * 4 ** deep_k in (0, 4 * ((ix.bwt_length >> 15) + 5))
     ranges, ho, p = g.locate_host(chars, offsets)
     assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep)
     assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
@@ -437,7 +439,7 @@ def test_amino_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, req
 @pytest.mark.parametrize("pair", ["1", "0"])
 def test_deep_seed_table_next_step_bits_and_long_ranges(oracle, awfm, require_gpu, monkeypatch, pair):
     """On images with pair blocks the 8-byte entries of the deeper table are {sp, length16 | next16 << 16}: the lengths
-    that do not fit (a tandem repeat: six 5-mers with 120 000 occurrences each) come from the side list, and the seed-order
+    that do not fit (a tandem repeat: six 5-mers with 120 000 occurrences each) come from deepBigBySp[sp >> 15], and the seed-order
     search drops k-mers by the next-step bits.  General kernels (exact ranges), the seed-order search (hits) and the
     positions against the oracle; without pair blocks ($AWFM_GPU_PAIR=0) the entries stay {sp, length}."""
     import torch
@@ -452,8 +454,9 @@ def test_deep_seed_table_next_step_bits_and_long_ranges(oracle, awfm, require_gp
     g = awfm.GpuIndex(ix)
     before = g.device_bytes
     g.set_deep_seed(deep_k)
-    long_ranges = 6 if pair == "1" else 0   # the six 5-mers of the repeat
-    assert g.device_bytes == before + 8 * 4 ** deep_k + 8 * long_ranges
+    # (with the next-step bits, i.e. pair blocks: the table of the lengths of 65535 and more -- the six 5-mers of the repeat --,
+    # a word per 2^15 positions)
+    assert g.device_bytes == before + 8 * 4 ** deep_k + (4 * ((ix.bwt_length >> 15) + 5) if pair == "1" else 0)
     # mixed lengths through the general kernels: exact ranges, k-mers shorter than the table included
     chars, offsets = _mixed_queries(502, 4000, txt, synth.DNA_ALPHABET, 1, 30, ambiguity=ord("x"), upper=True)
     sp, ep, cnt, _ = oi.batch_search(chars, offsets)
