@@ -9,7 +9,7 @@ print("value", d["value"], "ms/step", d["ms_per_step"], "| front:", c.get("looku
 r = d["roofline"]
 print("roofline", r["kernel"], "frac", r["frac"], "kernel_ms", r["kernel_ms"], "hbm_measured", r.get("hbm_frac_measured"), "ref_alg", (r.get("reference_algorithm") or {}).get("frac"), (r.get("reference_algorithm") or {}).get("kernel_ms"))
 for k in ("search_call_ms", "locate_kernels_ms", "index_build_s", "device_seed_build_s", "planted_ms_per_step", "planted_lf_walk_ms_per_step", "mixed_lengths_ms_per_step",
-          "amino_value", "amino_ms_per_step", "amino_roofline_frac", "amino_2e9_value", "amino_2e9_ms_per_step", "amino_2e9_roofline_frac", "dense_form_ms_per_step", "device_image_bytes"):
+          "amino_value", "amino_ms_per_step", "amino_roofline_frac", "amino_2e9_value", "amino_2e9_ms_per_step", "amino_2e9_roofline_frac", "repetitive_value", "repetitive_ms_per_step", "repetitive_roofline_frac", "dense_form_ms_per_step", "device_image_bytes"):
     if k in c:
         print(" ", k, c[k])
 sp = d.get("scaling_proxy")
