@@ -265,3 +265,78 @@ def test_an_index_beyond_2_pow_32_positions_built_searched_and_located_on_the_gp
         assert np.array_equal(d_pos[base: base + int(ho[-1])].cpu().numpy().view(np.uint64), pos)
     g.destroy()
     ix.dealloc()
+
+
+def test_full_suffix_array_of_a_genome_shaped_index_at_full_size(awfm, require_gpu, monkeypatch):
+    """The full suffix array of a LOADED genome-shaped 3.1 Gbp index (24 runs of N of 10^5..10^7 characters: LF walks that never
+    meet a sample until a run ends) -- the automatic construction (capped walks, the parked ones completed from each other by
+    pointer jumping) and, since round 5, the one that is asked for -- against the array the GPU builder sorted: an image
+    acquired from the host arrays alone must have its array within seconds (it took 566 s before round 4's last day), and
+    10^6 k-mers drawn from the text, the 21-mers right behind every run and a 21-mer of N (10^8 hits, all inside the runs) must
+    come back at the builder's positions; the LF walk itself (no array) agrees on the 10^6."""
+    import time
+    import torch
+    from avxwindowfmindex_amd import _lib
+    L = _lib.lib()
+    n = int(os.environ.get("AWFM_TEST_GENOME_LEN", 3_100_000_000))
+    Q, K = 1_000_000, 21
+    dev = torch.device("cuda")
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthGenomeText(d_text.data_ptr(), n, 2, None) == 1
+    ix = awfm.gpu_create_index(d_text.data_ptr(), awfm.AwFmAlphabetDna, 8, 12, on_device_length=n)
+    g0 = awfm.GpuIndex(ix, acquire=True)
+    assert g0.has_dense_sa and g0.dense_sa_build_s < 0.5, "the image of an index built on the GPU takes the builder's own array"
+    d_q = torch.empty(Q * K, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthPlantedQueriesUnique(d_q.data_ptr(), 0, Q, K, 7, d_text.data_ptr(), n, 2, None, None) == 1
+    ends = []  # the first character behind every run of N (in pieces: torch.nonzero indexes with 32 bits)
+    piece = 1 << 30
+    for b in range(0, n - 1, piece):
+        e = min(n - 1, b + piece)
+        is_n = d_text[b:e + 1] == ord("n")
+        ends += (torch.nonzero(is_n[:-1] & ~is_n[1:]).flatten() + (b + 1)).tolist()
+        del is_n
+    behind = [d_text[int(e): int(e) + K].cpu().numpy().tobytes() for e in ends if int(e) + K <= n]
+    behind = [k for k in behind if b"n" not in k]
+    assert len(behind) >= 20, "the text has 24 runs of N"
+    chars = np.concatenate([d_q.cpu().numpy(), np.frombuffer(b"".join(behind), np.uint8), np.frombuffer(b"n" * K, np.uint8)])
+    total = Q + len(behind) + 1
+    d_chars = torch.from_numpy(chars).to(dev)
+    del d_text, d_q
+    torch.cuda.empty_cache()
+
+    def locate(g, count):
+        d_ranges = torch.empty(count * 2, dtype=torch.int64, device=dev)
+        g.search(d_chars.data_ptr(), 0, K, count, d_ranges.data_ptr(), 0)
+        d_off = torch.empty(count + 1, dtype=torch.int64, device=dev)
+        d_scratch = torch.empty(awfm.GpuIndex.scan_scratch_bytes(count), dtype=torch.uint8, device=dev)
+        hits = g.hit_offsets(d_ranges.data_ptr(), count, d_off.data_ptr(), d_scratch.data_ptr())
+        d_pos = torch.empty(max(hits, 1), dtype=torch.int64, device=dev)
+        g.locate(d_ranges.data_ptr(), d_off.data_ptr(), count, hits, d_pos.data_ptr())
+        torch.cuda.synchronize()
+        return d_off, d_pos
+
+    off0, pos0 = locate(g0, total)
+    assert int(off0[-1] - off0[-2]) > n // 100, "the k-mer of N has its hits inside the runs"
+    # the image goes; the next one comes from the host arrays alone, as for an index read from a file
+    g0.handle = None
+    L.awfmGpuIndexRelease(ix.ptr)
+    t0 = time.perf_counter()
+    g1 = awfm.GpuIndex(ix, acquire=True)
+    acquire_s = time.perf_counter() - t0
+    assert g1.has_dense_sa and g1.dense_sa_build_s < 5.0, (g1.has_dense_sa, g1.dense_sa_build_s, acquire_s)
+    off1, pos1 = locate(g1, total)
+    assert torch.equal(off0, off1) and torch.equal(pos0, pos1), "the automatic full suffix array gives other positions than the builder's"
+    # no array: the LF walk (the 10^6 k-mers from the unique sequence; a walk from behind a run is as long as the run)
+    g1.set_dense_sa(False)
+    off2, pos2 = locate(g1, Q)
+    assert torch.equal(off0[: Q + 1], off2) and torch.equal(pos0[: int(off0[Q])], pos2), "the LF walk gives other positions"
+    # the array that is asked for: capped walks and pointer jumping as well
+    t0 = time.perf_counter()
+    g1.set_dense_sa(True)
+    torch.cuda.synchronize()
+    asked_s = time.perf_counter() - t0
+    assert g1.has_dense_sa and asked_s < 10.0, asked_s
+    off3, pos3 = locate(g1, total)
+    assert torch.equal(off0, off3) and torch.equal(pos0, pos3), "the full suffix array that was asked for gives other positions"
+    g1.handle = None
+    ix.dealloc()
