@@ -498,6 +498,10 @@ class GpuIndex:
         _check("awfmGpuSortHitsOnDevice", _lib.lib().awfmGpuSortHitsOnDevice(self.handle, d_hit_kmers, d_hit_ranges, capacity,
                                                                              d_num_hits, n, stream or None))
 
+    def stream_retire(self, stream):
+        """awfmGpuStreamRetire: call before destroying a stream that has searched on this image"""
+        _lib.lib().awfmGpuStreamRetire(self.handle, stream or None)
+
     def last_lookup_front(self):
         """awfmGpuLastLookupFront: 0 both front ends, 1 the lookup kernel only, 2 the ordered kernels only, -1 none yet"""
         return int(_lib.lib().awfmGpuLastLookupFront(self.handle))

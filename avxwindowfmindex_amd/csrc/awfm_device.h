@@ -746,7 +746,8 @@ struct AwFmGpuIndex {
   std::mutex lengthMutex;
   void *dLengthTable = nullptr;
   unsigned lengthDepths = 0; /* levels 1 .. lengthDepths */
-  bool lengthTried = false;  /* a construction was attempted (it is not repeated when it fails for lack of memory) */
+  bool lengthTried = false;  /* a construction was attempted and failed, or is done */
+  unsigned lengthRetryIn = 0; /* calls since it failed: every 64th tries again */
   uint64_t lengthTableBytes = 0;
   double lengthTableBuildSeconds = 0.0;
   void *dDenseSa = nullptr; /* optional full suffix array, 32-bit entries */

@@ -404,7 +404,8 @@ static hipError_t gateEnter(AwFmGpuIndex::StreamGate &gate, hipStream_t s) {
     if (e != hipSuccess) return e;
   }
   if (!gate.recorded && !gate.pending) return hipSuccess;
-  if (gate.lastStream == s && (gateLazy(s) || gate.lastThread == std::this_thread::get_id())) return hipSuccess;
+  if (gate.lastStream == s && s != nullptr && (gateLazy(s) || gate.lastThread == std::this_thread::get_id())) return hipSuccess;
+  if (gate.lastStream == s && s == nullptr && gate.lastThread == std::this_thread::get_id()) return hipSuccess;
   if (gate.pending) { /* the last user left no event behind: now one is needed */
     if (hipEventRecord(gate.done, gate.lastStream) != hipSuccess) {
       (void)hipGetLastError();
@@ -434,6 +435,34 @@ static hipError_t gateLeave(AwFmGpuIndex::StreamGate &gate, hipStream_t s, bool 
   gate.lastStream = s;
   gate.lastThread = std::this_thread::get_id();
   return hipSuccess;
+}
+
+/* see include/awfm_gpu.h: the caller is about to destroy `stream`.  Whatever the image remembers of it -- a gate whose event
+ * was left to be recorded on that stream when another stream shows up -- is settled now, while the handle is still good:
+ * the event is recorded (behind everything the stream has been given), and the stream's handle is forgotten. */
+extern "C" void awfmGpuStreamRetire(AwFmGpuIndex *g, void *stream) {
+  if (!g) return;
+  hipStream_t s = (hipStream_t)stream;
+  DeviceGuard guard(g->device);
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  auto settle = [&](AwFmGpuIndex::StreamGate &gate) {
+    if (gate.lastStream != s || !(gate.pending || gate.recorded)) return;
+    if (gate.pending) {
+      if (!gate.done && hipEventCreate(&gate.done) != hipSuccess) gate.done = nullptr;
+      if (gate.done && hipEventRecord(gate.done, s) == hipSuccess) {
+        gate.recorded = true;
+      } else { /* no event to be had: whatever the stream was given has to be over before the handle goes */
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(s);
+        gate.recorded = false;
+      }
+      gate.pending = false;
+    }
+    gate.lastStream = nullptr; /* a new stream that gets the same handle is another stream: it waits for the event */
+    gate.lastThread = std::thread::id();
+  };
+  for (auto &slot : g->orderSlot) settle(slot.gate);
+  settle(g->sparseGate);
 }
 
 /* the scratch slot of a search on stream `s` (the caller holds orderMutex): the one this stream used last, else the one
@@ -469,6 +498,28 @@ static hipError_t orderEndSlot(AwFmGpuIndex *g, hipStream_t s) {
   g->orderDoneArmed = false;
   return e;
 }
+
+/* Every exit of a search behind orderBeginSlot ends the slot's use -- the failing ones too (advisor, round 4: a kernel launch
+ * that failed half-way left the kernels already enqueued on the slot's scratch unrecorded in its gate, and the next search on
+ * another stream would not have waited for them). */
+struct OrderSlotScope {
+  AwFmGpuIndex *g;
+  hipStream_t s;
+  bool ended = false;
+  OrderSlotScope(AwFmGpuIndex *image, hipStream_t stream) : g(image), s(stream) {}
+  OrderSlotScope(const OrderSlotScope &) = delete;
+  OrderSlotScope &operator=(const OrderSlotScope &) = delete;
+  hipError_t end() {
+    ended = true;
+    return orderEndSlot(g, s);
+  }
+  ~OrderSlotScope() {
+    if (!ended) {
+      (void)orderEndSlot(g, s);
+      (void)hipGetLastError();
+    }
+  }
+};
 
 /* scratch of the current slot, grown when needed; the caller holds orderMutex.  false: no memory (the general kernel needs none) */
 static bool ensureOrderScratch(AwFmGpuIndex *g, size_t bytes) {
@@ -608,6 +659,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
     setError("seed-order search: could not order the use of its scratch across streams");
     return -(int)AwFmGeneralFailure;
   }
+  OrderSlotScope slotScope(g, s);
   if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
   constexpr size_t kShareCountAt = 98304, kSampleAt = kShareCountAt + kShares * kShareCountStride * 4u; /* bytes into the counter block (tickets end at 65792) */
   constexpr size_t kKeptAt = 102400; /* lookupSearchKernel's survivor counters: kFusedCounters words a line apart */
@@ -778,7 +830,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
       g->orderDoneArmed = g->orderDoneEvent != nullptr;
     }
     if (rc != AwFmSuccess) return -(int)rc;
-    BUCKET_TRY(orderEndSlot(g, s));
+    BUCKET_TRY(slotScope.end());
     return 1;
   }
   if (lookupFirst) {
@@ -814,7 +866,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
       awfmImageNarrow(g) ? launchBucketed<true>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse)
                          : launchBucketed<false>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse);
   if (rc != AwFmSuccess) return -(int)rc;
-  BUCKET_TRY(orderEndSlot(g, s));
+  BUCKET_TRY(slotScope.end());
 #undef BUCKET_TRY
   return 1;
 }
@@ -832,8 +884,17 @@ static const uint2 *ensureLengthTables(AwFmGpuIndex *g) {
   const unsigned need = g->dev.deepK - 1u;
   std::lock_guard<std::mutex> lock(p->lengthMutex);
   if (p->dLengthTable && p->lengthDepths >= need) return (const uint2 *)p->dLengthTable;
-  if (p->lengthTried) return nullptr;
+  /* after a failed attempt the next ones wait: every 64th call tries again (memory may have been freed since) */
+  if (p->lengthTried && (++p->lengthRetryIn & 63u) != 0u) return nullptr;
   p->lengthTried = true;
+  { /* the same headroom rule as the other automatic tables: three times the table free on the device */
+    const uint64_t tableBytes = awfmLengthTableAt(need + 1u) * 8ull;
+    size_t freeBytes = 0, totalBytes = 0;
+    if (hipMemGetInfo(&freeBytes, &totalBytes) != hipSuccess || (uint64_t)freeBytes / 3u < tableBytes) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+  }
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   void *table = nullptr;
@@ -890,6 +951,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
     setError("seed-order search: could not order the use of its scratch across streams");
     return -(int)AwFmGeneralFailure;
   }
+  OrderSlotScope slotScope(g, s);
   if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
 #define WIDE_TRY(call)                      \
   do {                                      \
@@ -945,7 +1007,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
                        (const unsigned *)nullptr, 0u);
     WIDE_TRY(hipGetLastError());
     if (lookupOnly) { /* forced: the other front end is not launched */
-      WIDE_TRY(orderEndSlot(g, s));
+      WIDE_TRY(slotScope.end());
       return 1;
     }
   }
@@ -988,7 +1050,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   else rc = narrow ? WIDE_GO(true, false) : WIDE_GO(false, false);
 #undef WIDE_GO
   if (rc != AwFmSuccess) return -(int)rc;
-  WIDE_TRY(orderEndSlot(g, s));
+  WIDE_TRY(slotScope.end());
 #undef WIDE_TRY
   return 1;
 }
@@ -1079,6 +1141,7 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
     setError("seed-order search: could not order the use of its scratch across streams");
     return -(int)AwFmGeneralFailure;
   }
+  OrderSlotScope slotScope(g, s);
   if (!ensureOrderScratch(g, l.total)) return kOrderNoScratch; /* no room for the scratch: the general kernel needs none */
   uint8_t *w = (uint8_t *)g->dOrder;
   unsigned *generalCount = (unsigned *)(w + l.generalCount);
@@ -1142,7 +1205,7 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   else rc = narrow ? ORDER_GO(true, false, false) : ORDER_GO(false, false, false);
 #undef ORDER_GO
   if (rc != AwFmSuccess) return -(int)rc;
-  ORDER_TRY(orderEndSlot(g, s));
+  ORDER_TRY(slotScope.end());
 #undef ORDER_TRY
   return 1;
 }
@@ -1188,6 +1251,7 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
     }                                       \
   } while (0)
   AMINO_TRY(orderBeginSlot(g, s));
+  OrderSlotScope slotScope(g, s);
   if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
   uint8_t *w = (uint8_t *)g->dOrder;
   unsigned *leftoverCount = (unsigned *)(w + 64), *kept = (unsigned *)(w + 256);
@@ -1269,7 +1333,7 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
                        (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out, (const unsigned *)nullptr, 0u);
     AMINO_TRY(hipGetLastError());
   }
-  AMINO_TRY(orderEndSlot(g, s));
+  AMINO_TRY(slotScope.end());
 #undef AMINO_TRY
   return 1;
 }
@@ -1319,6 +1383,7 @@ int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
     }                                       \
   } while (0)
   EXACT_TRY(orderBeginSlot(g, s));
+  OrderSlotScope slotScope(g, s);
   if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
   uint8_t *w = (uint8_t *)g->dOrder;
   unsigned *leftoverCount = (unsigned *)w;
@@ -1341,7 +1406,7 @@ int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
   }
   EXACT_TRY(hipGetLastError());
   g->orderDoneArmed = g->orderDoneEvent != nullptr;
-  EXACT_TRY(orderEndSlot(g, s));
+  EXACT_TRY(slotScope.end());
 #undef EXACT_TRY
   return 1;
 }

@@ -94,8 +94,9 @@ unsigned awfmGpuIndexDeepSeedK(const AwFmGpuIndex *g); /* depth of the deeper ta
 double awfmGpuIndexDeepSeedBuildSeconds(const AwFmGpuIndex *g);
 uint64_t awfmGpuIndexDeepSeedTransientBytes(const AwFmGpuIndex *g);
 /* The full suffix array on the device (32-bit entries, 4 x bwtLength bytes: 12.4 GB for a GRCh38-sized index),
- * reconstructed once from the sampled SA with the LF-walk kernel, so that locating a hit is one read instead of a
- * chain of about ratio-1 dependent block reads.  Positions are bit-identical (the walk wrote them).  Built by default for
+ * reconstructed once from the sampled SA with the LF-walk kernel (walks capped at 32 x ratio steps; the ones that have
+ * not met a sample by then -- positions inside long runs of one letter -- are completed from each other by pointer jumping),
+ * so that locating a hit is one read instead of a chain of about ratio-1 dependent block reads.  Positions are bit-identical (the walk wrote them).  Built by default for
  * images of 2^26 .. 2^32 positions with a sampled array when four times its size is free on the device
  * ($AWFM_GPU_DENSE_SA=0|1: never / always); enable = 0 drops it, 1 builds it.  Needs bwtLength < 2^32. */
 enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable);
@@ -232,6 +233,16 @@ enum AwFmReturnCode awfmGpuListLocateOnDevice(AwFmGpuIndex *g, const uint32_t *d
 void awfmGpuIndexSetOrdered(AwFmGpuIndex *g, int mode);
 /* 1 when awfmGpuSearchHits would search such a batch in seed order on this image (reporting, bench.py) */
 int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets, uint32_t fixedLength, uint64_t numQueries);
+/* STREAMS AND THE IMAGE'S SCRATCH.  The seed-order searches and the list's ordering share scratch memory that belongs to the
+ * image, and the image orders its use across streams with events.  For a stream the caller created, the event of a use is
+ * not recorded when the use is enqueued (a recorded event leaves the queue idle for ~5 us; a search followed by another on the
+ * SAME stream needs none) but when a search on ANOTHER stream needs the scratch -- on the first stream, behind whatever it has
+ * been given since.  The image therefore keeps the handle of the last stream that used each piece of scratch.  Rule: a stream
+ * that has searched on an image must either outlive the image, or be RETIRED before it is destroyed:
+ * awfmGpuStreamRetire(g, stream) records what is still owed on it and forgets the handle (cheap; no wait unless an event
+ * cannot be recorded).  The null stream and hipStreamPerThread need nothing: their uses are recorded at once. */
+void awfmGpuStreamRetire(AwFmGpuIndex *g, void *stream);
+
 /* measurement hook: with $AWFM_GPU_TIME_ORDERED set, awfmGpuSearchHits brackets its dominant kernel (orderedSearchKernel,
  * or encodeLookupKernel when the batch was one for "lookup first") with HIP events on the launch stream; this returns the
  * last bracket in ms (<0: none).  Reporting calls: this one and the two below may wait for the device. */

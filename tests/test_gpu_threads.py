@@ -207,3 +207,48 @@ def test_mixed_length_callers_race_for_the_length_tables(oracle, awfm, require_g
     assert g.length_tables[0] == 8 * (4 ** 12 - 4) // 3 and g.last_ordered_kernel_is_lookup()
     g.destroy()
     ix.dealloc()
+
+
+def test_a_stream_is_retired_before_it_is_destroyed(oracle, awfm, require_gpu):
+    """awfmGpuStreamRetire (round 5): the image keeps the handle of the last stream that used a scratch slot, because the event
+    of that use is recorded lazily -- on that stream, when another stream shows up.  A caller that destroys a stream first
+    retires it: the owed event is recorded while the handle is good.  Streams come and go between searches here, every one
+    retired; the searches on the streams after them must wait for the retired streams' work and give the oracle's hits."""
+    import torch
+    n, K, Q = 300000, 15, 60007
+    txt = synth.text(n + 11, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(11)
+    dev = torch.device("cuda")
+    batches = []
+    for c in range(3):
+        q = np.concatenate([synth.random_queries(31 + c, Q // 2, K), synth.planted_queries(41 + c, Q - Q // 2, K, txt)])
+        chars, offsets = synth.fixed_csr(q)
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+        batches.append((torch.from_numpy(chars).to(dev), sp, ep, cnt))
+    d_ranges = [torch.zeros(Q * 2, dtype=torch.int64, device=dev) for _ in range(3)]
+    d_counts = [torch.zeros(Q, dtype=torch.int32, device=dev) for _ in range(3)]
+    torch.cuda.synchronize()
+    for round_ in range(6):
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        for c, st in enumerate(streams):  # three streams, two scratch slots: the third queues behind a lazily recorded gate
+            g.search_hits(batches[c][0].data_ptr(), 0, K, Q, d_ranges[c].data_ptr(), d_counts[c].data_ptr(), st.cuda_stream)
+        for c, st in enumerate(streams):
+            st.synchronize()
+            _, sp, ep, cnt = batches[c]
+            counts = d_counts[c].cpu().numpy().view(np.uint32)
+            ranges = d_ranges[c].cpu().numpy().view(np.uint64).reshape(Q, 2)
+            hit = cnt > 0
+            assert np.array_equal(counts, cnt), (round_, c)
+            assert np.array_equal(ranges[hit, 0], sp[hit]) and np.array_equal(ranges[hit, 1], ep[hit]), (round_, c)
+            g.stream_retire(st.cuda_stream)
+        del streams  # destroyed: the next round's streams may well get the same handles
+        for c in range(3):
+            d_counts[c].fill_(9)
+            d_ranges[c].fill_(9)
+        torch.cuda.synchronize()
+    g.destroy()
+    ix.dealloc()
