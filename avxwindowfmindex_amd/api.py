@@ -276,6 +276,11 @@ class GpuIndex:
         L = _lib.lib()
         return float(L.awfmGpuIndexDeepSeedBuildSeconds(self.handle)), int(L.awfmGpuIndexDeepSeedTransientBytes(self.handle))
 
+    @property
+    def deep_seed_alloc_s(self):
+        """seconds of that construction spent inside hipMalloc"""
+        return float(_lib.lib().awfmGpuIndexDeepSeedAllocSeconds(self.handle))
+
     def set_dense_sa(self, enable=True):
         """device-only full suffix array (32-bit entries) so that a locate is a single gather"""
         _check("awfmGpuIndexSetDenseSa", _lib.lib().awfmGpuIndexSetDenseSa(self.handle, int(bool(enable))))
@@ -497,6 +502,13 @@ class GpuIndex:
         """awfmGpuSortHitsOnDevice: the list in k-mer order, its length read on the device (no host wait)"""
         _check("awfmGpuSortHitsOnDevice", _lib.lib().awfmGpuSortHitsOnDevice(self.handle, d_hit_kmers, d_hit_ranges, capacity,
                                                                              d_num_hits, n, stream or None))
+
+    def describe(self):
+        """awfmGpuIndexDescribe: one line about what the image holds and which accelerators it did not get"""
+        import ctypes as C
+        buf = C.create_string_buffer(2048)
+        _lib.lib().awfmGpuIndexDescribe(self.handle, buf, 2048)
+        return buf.value.decode()
 
     def stream_retire(self, stream):
         """awfmGpuStreamRetire: call before destroying a stream that has searched on this image"""

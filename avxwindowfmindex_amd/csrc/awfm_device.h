@@ -739,6 +739,7 @@ struct AwFmGpuIndex {
   void *dDeepSeed = nullptr;
   uint64_t deepSeedBytes = 0;
   double deepSeedBuildSeconds = 0.0;    /* wall time of the last construction of the deeper table (reporting) */
+  double deepSeedAllocSeconds = 0.0;    /* ... of which inside hipMalloc */
   uint64_t deepSeedTransientBytes = 0;  /* device memory that construction held beyond the table itself, at its peak */
   void *dDeepBig = nullptr; /* the deeper table's lengths of 65535 and more, by where the range begins (DevIndex::deepBigBySp) */
   /* optional tables of the k-mer lengths below the deeper table's (awfmGpuBuildLengthTables), built by the first
@@ -755,6 +756,9 @@ struct AwFmGpuIndex {
   double denseSaBuildSeconds = 0.0; /* wall time of the automatic construction (reporting) */
   void *dPairBlocks = nullptr, *dPairSuper = nullptr, *dPairSuper32 = nullptr, *dPairC = nullptr; /* pair image */
   uint64_t pairBytes = 0;
+  /* what became of the optional accelerators when the image was made -- which ones it would have got by its size and did not,
+   * and why (awfmGpuIndexDescribe; the searches simply run without them) */
+  std::string accelNotes;
   uint64_t deviceBytes = 0;
   uint64_t numBlocks = 0; /* device blocks (128 positions each) */
   AwFmGpuKernel kernel = AWFM_GPU_KERNEL_AUTO;
@@ -946,7 +950,10 @@ enum AwFmReturnCode awfmGpuScanFlags(AwFmGpuIndex *g, const uint32_t *dCounts, u
                                      void *dScratch, hipStream_t s);
 /* awfm_gpu_build.hip: level-wise construction of the deeper seed table into a new device buffer */
 /* peakBytesOut (may be NULL): the most device memory the construction held at once (the table and the level below it) */
-bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut, uint64_t *peakBytesOut = nullptr);
+/* allocSecondsOut (may be NULL): wall seconds spent inside the hipMalloc calls of the levels -- on this pool a process's first
+ * allocation of tens of GB sometimes takes seconds (memory the driver hands back from, or scrubs after, the process before) */
+bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut, uint64_t *peakBytesOut = nullptr,
+                               double *allocSecondsOut = nullptr);
 /* one table per k-mer length 1 .. maxDepth (<= 15), 8-byte entries {sp, length}, level d at entry awfmLengthTableAt(d) of one
  * allocation: nucleotide images below 2^32 positions (awfm_gpu_build.hip) */
 bool awfmGpuBuildLengthTables(const AwFmGpuIndex *g, unsigned maxDepth, void **tableOut, uint64_t *bytesOut);

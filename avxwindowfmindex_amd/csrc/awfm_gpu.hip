@@ -1066,7 +1066,7 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
     uint64_t bytes = 0, peak = 0;
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    if (awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes, &peak)) {
+    if (awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes, &peak, &g->deepSeedAllocSeconds)) {
       void *big = nullptr;
       unsigned numBig = 0;
       const int next = awfmGpuDeepSeedAddNext(g, table, deepK, &big, &numBig); /* images with pair blocks, below 2^32 positions */
@@ -1126,6 +1126,7 @@ static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
       for (unsigned k = 1; k <= 7u; k++) {
         entries *= 20ull;
         if (k > g->dev.seedK && entries <= 8ull * g->dev.bwtLength && freeBytes / 3u >= entries * 8ull) deepK = (int)k;
+        else if (k > g->dev.seedK && entries <= 8ull * g->dev.bwtLength && k > (unsigned)deepK) g->accelNotes += "deeper table: depth " + std::to_string(k) + " not built (less than 3 x its size free); ";
       }
     } else {
       (void)hipGetLastError();
@@ -1145,6 +1146,12 @@ static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
       for (unsigned k = kAutoDeepSeedMax; k >= kAutoDeepSeedMin && deepK == 0; k--)
         if ((1ull << (2u * k)) <= 2ull * g->dev.bwtLength && freeBytes / 3u >= (entryBytes << (2u * k))) deepK = (int)k;
       if (deepK == 0 && freeBytes / 4u >= (16ull << (2u * kAutoDeepSeedMin))) deepK = (int)kAutoDeepSeedMin;
+      unsigned wanted = 0; /* the depth the image's size asks for */
+      for (unsigned k = kAutoDeepSeedMax; k >= kAutoDeepSeedMin && wanted == 0; k--)
+        if ((1ull << (2u * k)) <= 2ull * g->dev.bwtLength) wanted = k;
+      if ((unsigned)deepK < wanted)
+        g->accelNotes += "deeper table: depth " + std::to_string(wanted) + " not built (less than 3 x its size free)" +
+                         (deepK ? ", depth " + std::to_string(deepK) + " instead; " : "; ");
     } else {
       (void)hipGetLastError();
     }
@@ -1162,7 +1169,10 @@ static enum AwFmReturnCode applyPairFromEnv(AwFmGpuIndex *g) {
     if (atoi(env) == 0) return AwFmSuccess;
   DeviceGuard guard(g->device);
   const enum AwFmReturnCode rc = awfmGpuApplyPairImage(g, true);
-  if (rc != AwFmSuccess) (void)awfmGpuApplyPairImage(g, false);
+  if (rc != AwFmSuccess) {
+    (void)awfmGpuApplyPairImage(g, false);
+    g->accelNotes += "pair image: not built (no device memory for 1 byte per position); ";
+  }
   return rc;
 }
 
@@ -1191,6 +1201,7 @@ enum AwFmReturnCode awfmGpuIndexSetPairImage(AwFmGpuIndex *g, int enable) {
 }
 int awfmGpuIndexHasPairImage(const AwFmGpuIndex *g) { return g && g->dev.pairBlocks ? 1 : 0; }
 unsigned awfmGpuIndexDeepSeedK(const AwFmGpuIndex *g) { return g ? g->dev.deepK : 0u; }
+double awfmGpuIndexDeepSeedAllocSeconds(const AwFmGpuIndex *g) { return g ? (g->shares ? g->shares : g)->deepSeedAllocSeconds : 0.0; }
 double awfmGpuIndexDeepSeedBuildSeconds(const AwFmGpuIndex *g) { return g ? (g->shares ? g->shares : g)->deepSeedBuildSeconds : 0.0; }
 uint64_t awfmGpuIndexDeepSeedTransientBytes(const AwFmGpuIndex *g) { return g ? (g->shares ? g->shares : g)->deepSeedTransientBytes : 0; }
 
@@ -1933,6 +1944,7 @@ static enum AwFmReturnCode applyDenseSaFromEnv(AwFmGpuIndex *g) {
     DeviceGuard guard(g->device);
     if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) want = freeBytes / 4u >= g->dev.bwtLength * 4ull + (1ull << 31);
     else (void)hipGetLastError();
+    if (!want) g->accelNotes += "full suffix array: not built (less than 4 x its size free); ";
     automatic = true;
   }
   if (!want || g->dev.bwtLength >= (1ull << 32)) return AwFmSuccess;
@@ -1940,11 +1952,29 @@ static enum AwFmReturnCode applyDenseSaFromEnv(AwFmGpuIndex *g) {
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
   const enum AwFmReturnCode rc = applyDenseSa(g, true, automatic);
+  if (!g->dDenseSa) g->accelNotes += "full suffix array: not built (no device memory, or walks that could not be completed); ";
   clock_gettime(CLOCK_MONOTONIC, &t1);
   g->denseSaBuildSeconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
   return rc;
 }
 int awfmGpuIndexHasDenseSa(const AwFmGpuIndex *g) { return g && g->dDenseSa ? 1 : 0; }
+/* see include/awfm_gpu.h */
+int awfmGpuIndexDescribe(const AwFmGpuIndex *g, char *out, int outBytes) {
+  if (!g || !out || outBytes <= 0) return 0;
+  const AwFmGpuIndex *p = g->shares ? g->shares : g;
+  std::string text = std::string(p->amino ? "amino" : "nucleotide") + " image of " + std::to_string(p->dev.bwtLength) + " positions, " +
+                     std::to_string(awfmGpuIndexDeviceBytes(p)) + " bytes on device " + std::to_string(p->device) + ": ";
+  if (!p->amino) text += p->dev.pairBlocks ? "pair image yes; " : "pair image no; ";
+  text += p->dev.deepK ? "deeper table depth " + std::to_string(p->dev.deepK) + (p->dev.deepNext ? " with next-step bits; " : "; ") : "deeper table no; ";
+  text += p->dDenseSa ? "full suffix array yes; " : "full suffix array no; ";
+  if (!p->amino) text += p->dLengthTable ? "tables per k-mer length 1.." + std::to_string(p->lengthDepths) + "; " : "tables per k-mer length not built (the first large mixed-length batch builds them); ";
+  if (!p->accelNotes.empty()) text += "notes: " + p->accelNotes;
+  while (!text.empty() && (text.back() == ' ' || text.back() == ';')) text.pop_back();
+  const int n = (int)text.size() < outBytes - 1 ? (int)text.size() : outBytes - 1;
+  memcpy(out, text.data(), (size_t)n);
+  out[n] = 0;
+  return (int)text.size();
+}
 double awfmGpuIndexDenseSaBuildSeconds(const AwFmGpuIndex *g) { return g ? (g->shares ? g->shares : g)->denseSaBuildSeconds : 0.0; }
 /* the tables per k-mer length a mixed-length batch builds on first use (awfm_gpu_ordered.hip: ensureLengthTables) */
 uint64_t awfmGpuIndexLengthTableBytes(const AwFmGpuIndex *g) { return g ? (g->shares ? g->shares : g)->lengthTableBytes : 0; }

@@ -741,10 +741,12 @@ bool launchPackSampledSa(const void *dSa, u64 samples, unsigned ratio, unsigned 
 
 /* Deeper seed table for the device image: level seedK is the index's own table; level L+1 extends
  * every level-L entry by one more (prepended) letter with the search path's stop-at-first-invalid rule. */
-bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut, uint64_t *peakBytesOut) {
+bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut, uint64_t *peakBytesOut,
+                               double *allocSecondsOut) {
   *tableOut = nullptr;
   *bytesOut = 0;
   if (peakBytesOut) *peakBytesOut = 0;
+  if (allocSecondsOut) *allocSecondsOut = 0.0;
   u64 curBytes = 0; /* the level the next one is made from (0: the index's own table) */
   const unsigned K = g->dev.seedK;
   /* nucleotide: up to 16 characters (2^32 entries); amino: up to 7 (20^7 = 1.28 * 10^9 entries, the index a 32-bit sum) */
@@ -770,6 +772,7 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
     clock_gettime(CLOCK_MONOTONIC, &ta);
     if (!nxt.alloc(outLen * (out8 ? 8 : 16))) return false;
     clock_gettime(CLOCK_MONOTONIC, &tb);
+    if (allocSecondsOut) *allocSecondsOut += (double)(tb.tv_sec - ta.tv_sec) + 1e-9 * (double)(tb.tv_nsec - ta.tv_nsec);
     if (peakBytesOut && curBytes + outLen * (out8 ? 8 : 16) > *peakBytesOut) *peakBytesOut = curBytes + outLen * (out8 ? 8 : 16);
     constexpr int kUnroll = 4;
     const u64 blocks = (outLen + kSeedGroupsPerBlock * kUnroll - 1) / (kSeedGroupsPerBlock * kUnroll);

@@ -634,6 +634,7 @@ def main():
     g = api.GpuIndex(ix, acquire=True)
     build_s = time.time() - t0
     deep_first_build = g.deep_seed_build  # (seconds, transient bytes) of the table the library built by itself, if it did
+    deep_first_alloc_s = g.deep_seed_alloc_s  # ... of which inside hipMalloc
     deep_s = 0.0
     if args.device_seed_k >= 0:
         t1 = time.time()
@@ -1744,6 +1745,7 @@ def main():
     # awFmParallelSearchLocate then uploads the image (3.8 GB), builds the pair image and the deeper table, and searches.
     # The image of this run is dropped for it, so this is the last thing the run does with the GPU. ----
     image_bytes, image_deep_k = g.device_bytes, g.deep_seed_k or args.seed_k
+    image_described = g.describe()  # which accelerators the image holds, which ones it did not get and why
     length_tables_built = g.length_tables  # (bytes, seconds): before the image is released for the first-call leg
     first_call = None
     if e2e is not None and locate and args.e2e_aos_queries:
@@ -1817,13 +1819,15 @@ def main():
               # consecutive steps alternate between this many streams, each with its own result buffers and scratch slot
               "streams": 1 if whole.windowed else len(lanes),
               "index_build_s": round(build_s, 2),
-              "device_image_bytes": image_bytes, "device_seed_k": image_deep_k,
+              "device_image_bytes": image_bytes, "device_seed_k": image_deep_k, "device_image": image_described,
               # the deeper table's construction, whoever started it (the library by itself at awfmGpuIndexAcquire, inside
               # index_build_s; or --device-seed-k): wall seconds and the device memory held beyond the table at the peak.  In
               # this process it follows the GPU index builder; 0.55 s in most runs, 4-6 s in some -- one hipMalloc, the first the
               # runtime cannot serve from blocks it holds (memory to hand back or to scrub after the process before); in a process
               # that reads its index from a file the construction takes 0.6 s (scripts/first_call_probe.py; device_seed_rebuild_s here)
               "device_seed_build_s": round(deep_build_s, 2), "device_seed_transient_bytes": int(deep_transient),
+              # of which inside the hipMalloc calls (the table's 34 GB): the seconds some runs show are the allocation, not the kernels
+              "device_seed_alloc_s": round(deep_first_alloc_s, 2),
               "device_seed_rebuild_s": round(deep_rebuild_s, 2),  # the same construction once more (after roofline_general dropped the table): the allocator has the memory at hand
               "device_dense_sa": dense_sa_default, "device_dense_sa_build_s": round(dense_s, 2),
               "search_path": ({"order": "awfmGpuSearchHitsInOrder", "list": "awfmGpuSearchHitsCompact",

@@ -92,6 +92,9 @@ unsigned awfmGpuIndexDeepSeedK(const AwFmGpuIndex *g); /* depth of the deeper ta
  * choice at awfmGpuIndexCreate / Acquire, or awfmGpuIndexSetDeepSeed), and the device memory the construction held
  * beyond the table itself at its peak (the level below the deepest, 16 B x 4^(k-1)) */
 double awfmGpuIndexDeepSeedBuildSeconds(const AwFmGpuIndex *g);
+/* ... of which spent inside hipMalloc (a process's first allocation of tens of GB can take seconds on some boxes: device
+ * memory handed back from, or scrubbed after, the process before -- not the construction) */
+double awfmGpuIndexDeepSeedAllocSeconds(const AwFmGpuIndex *g);
 uint64_t awfmGpuIndexDeepSeedTransientBytes(const AwFmGpuIndex *g);
 /* The full suffix array on the device (32-bit entries, 4 x bwtLength bytes: 12.4 GB for a GRCh38-sized index),
  * reconstructed once from the sampled SA with the LF-walk kernel (walks capped at 32 x ratio steps; the ones that have
@@ -101,6 +104,11 @@ uint64_t awfmGpuIndexDeepSeedTransientBytes(const AwFmGpuIndex *g);
  * ($AWFM_GPU_DENSE_SA=0|1: never / always); enable = 0 drops it, 1 builds it.  Needs bwtLength < 2^32. */
 enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable);
 int awfmGpuIndexHasDenseSa(const AwFmGpuIndex *g);
+/* One line of text about what the image holds: its size, which of the optional accelerators it has (pair image, deeper table
+ * and its depth, full suffix array, tables per k-mer length) and which ones its size asked for and it did NOT get, with the
+ * reason (every one of them is dropped silently when device memory is short: the searches run without it, results are the
+ * same).  Returns the length of the whole text; at most outBytes - 1 characters and a 0 are written. */
+int awfmGpuIndexDescribe(const AwFmGpuIndex *g, char *out, int outBytes);
 double awfmGpuIndexDenseSaBuildSeconds(const AwFmGpuIndex *g); /* reporting: wall seconds of the automatic construction */
 /* Device-only tables per k-mer length (nucleotide images below 2^32 positions with the narrow deeper table of depth D): for
  * every length d = 1 .. D-1 the 8-byte entry {first position, length} of the range of EVERY d-letter string -- what the
