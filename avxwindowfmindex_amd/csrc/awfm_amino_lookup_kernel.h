@@ -23,7 +23,10 @@
 
 namespace {
 
-constexpr unsigned kAminoSlots = 64; /* survivors a wave takes through the steps per round */
+/* survivors a wave takes through the steps per round: as many as the round has k-mers (round 5; 64 until then, the rest went
+ * to the general kernel's list -- fine for a Swiss-Prot-sized text, where 15 % of random 10-mers survive their entry, not for
+ * 2 * 10^9 residues, where 79 % do) */
+constexpr unsigned kAminoSlots = 256;
 
 /* letter indices (ref src/AwFmLetter.c:55-67) of the K characters of k-mer i of a thread's four: idx = the table index over
  * the last DK of them (leftmost first), lead = the K - DK before them, 5 bits each, the one stepped first in bits 4..0;
@@ -166,29 +169,37 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (unsigned pass = 0; pass < inRound; pass += 64u / G) { /* wave-uniform */
-        const unsigned slot = pass + lane / G;
-        const bool live = slot < inRound;
-        pos_t sp = 1, ep = 0;
-        unsigned long long rem = 0;
-        unsigned index = 0;
-        int pos = -1;
-        if (live) {
-          rem = sLead[w][slot];
-          index = sNum[w][slot];
-          sp = sSp[w][slot];
-          ep = sEp[w][slot];
-          pos = (int)(K - DK) - 1;
-        }
-        while (pos >= 0 && sp <= ep) {
+      /* 16 groups of 4 lanes, each with one survivor; a group that is done with its k-mer -- the range is empty (most are
+       * after one step) or no character is left -- takes the next slot at once (as mixedLookupSearchKernel's groups do), so
+       * that every iteration of the loop is one memory round for 16 k-mers as long as there are 16 */
+      constexpr unsigned kGroups = 64u / G;
+      const unsigned leader = lane & ~(unsigned)(G - 1);
+      unsigned nextSlot = kGroups; /* wave-uniform */
+      unsigned mySlot = lane / G;
+      bool live = mySlot < inRound;
+      pos_t sp = 1, ep = 0;
+      unsigned long long rem = 0;
+      unsigned index = 0;
+      int pos = -1;
+      auto take = [&]() {
+        rem = sLead[w][mySlot];
+        index = sNum[w][mySlot];
+        sp = sSp[w][mySlot];
+        ep = sEp[w][mySlot];
+        pos = (int)(K - DK) - 1;
+      };
+      if (live) take();
+      while (__ballot(live) != 0ull) { /* wave-uniform */
+        if (live && pos >= 0) { /* (a k-mer in a group is alive: sp <= ep) */
           aminoStepAny<G, true>(ix, sC, sAmino, sMask, gl, (unsigned)rem & 31u, sp, ep);
           pos--;
           rem >>= 5;
         }
-        const bool hit = live && gl == 0 && sp <= ep;
+        const bool gone = live && (sp > ep || pos < 0);
+        const bool hit = gone && gl == 0 && sp <= ep;
         if (LIST) {
           const unsigned long long hitMask = __ballot(hit);
-          if (hitMask != 0ull) { /* wave-uniform; at most 16 hits a pass */
+          if (hitMask != 0ull) { /* wave-uniform; at most 16 hits an iteration */
             const unsigned hits = (unsigned)__builtin_amdgcn_readfirstlane((int)__popcll(hitMask));
             if (hit) {
               const unsigned at = hitFill + (unsigned)__popcll(hitMask & ((1ull << lane) - 1ull));
@@ -198,11 +209,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
             }
             hitFill = (unsigned)__builtin_amdgcn_readfirstlane((int)(hitFill + hits));
           }
-          if (hitFill + 64u / G > kHitBuffer) flushHits();
+          if (hitFill + kGroups > kHitBuffer) flushHits();
         } else if (hit) {
           if (ranges) ranges[index] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
           if (counts) counts[index] = (unsigned)(ep - sp + (pos_t)1);
         }
+        const unsigned long long goneMask = __ballot(gone && gl == 0);
+        if (gone) {
+          mySlot = nextSlot + (unsigned)__popcll(goneMask & ((1ull << leader) - 1ull));
+          live = mySlot < inRound;
+          sp = 1;
+          ep = 0;
+          pos = -1;
+          if (live) take();
+        }
+        nextSlot += (unsigned)__popcll(goneMask);
       }
       __builtin_amdgcn_wave_barrier(); /* the slots are written again by the next round */
     }

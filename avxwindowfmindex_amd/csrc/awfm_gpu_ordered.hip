@@ -596,7 +596,7 @@ enum { kFrontBoth = 0, kFrontLookupOnly = 1, kFrontOrderedOnly = 2 };
 constexpr unsigned kPredictHoldoff = 8, kPredictSamples = 16384, kPredictNumberMask = (1u << 22) - 1u;
 /* which front end(s) a sampled search of fixed-length k-mers launches, from the newest verdict that has reached the host
  * (nothing waits for one); the caller holds orderMutex.  $AWFM_GPU_LOOKUP_PREDICT=0: always both (round 4). */
-static int predictFront(AwFmGpuIndex *g, unsigned fixedLength) {
+static int predictFront(AwFmGpuIndex *g, unsigned fixedLength, unsigned chooseOf = kPredictSamples) {
   AwFmGpuIndex::LookupPredict &p = g->predict;
   if (const char *env = getenv("AWFM_GPU_LOOKUP_PREDICT"))
     if (atoi(env) == 0) return kFrontBoth;
@@ -607,7 +607,7 @@ static int predictFront(AwFmGpuIndex *g, unsigned fixedLength) {
   const unsigned tag = (unsigned)(v >> 32), alive = (unsigned)v;
   const unsigned number = tag & kPredictNumberMask, front = (tag >> 22) & 3u, length = (tag >> 24) & 63u;
   if (number == 0u) return kFrontBoth;
-  const bool lookup = alive * 4u < kPredictSamples; /* lookupChosen's rule */
+  const bool lookup = alive * 4u < chooseOf; /* lookupChosen's rule (chooseOf: the sample's size, or more of it where the lookup kernel pays up to a higher share) */
   if (number != p.lastJudged) {
     p.lastJudged = number;
     if ((front == kFrontLookupOnly && !lookup) || (front == kFrontOrderedOnly && lookup)) {
@@ -1270,7 +1270,15 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
       predict.verdictHost = nullptr;
     }
   }
-  const int front = prepFused ? predictFront(g, fixedLength) : kFrontBoth;
+  /* the lookup kernel has a slot for every k-mer of a round (round 5): it is chosen while fewer than `percent` of the sample
+   * are still alive after their entry (lookupChosen compares 4 x alive with the number it is given) -- the general kernel
+   * keeps twice the chains in flight per wave, which wins when nearly every k-mer goes on for several steps (k-mers drawn
+   * from the text); $AWFM_GPU_AMINO_CHOOSE_PERCENT: measurement knob */
+  unsigned percent = 90u;
+  if (const char *e = getenv("AWFM_GPU_AMINO_CHOOSE_PERCENT"))
+    if (atoi(e) >= 1 && atoi(e) <= 100) percent = (unsigned)atoi(e);
+  const unsigned chooseOf = (unsigned)((unsigned long long)kSamples * 4ull * percent / 100ull);
+  const int front = prepFused ? predictFront(g, fixedLength, chooseOf) : kFrontBoth;
   const unsigned *sampleAlive = nullptr;
   unsigned *sampleWord = (unsigned *)w;
   if (prepFused) {
@@ -1307,7 +1315,7 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
   const bool lookupRuns = !(prepFused && front == kFrontOrderedOnly), generalRuns = !forced && !(prepFused && front == kFrontLookupOnly);
   g->orderLookup = sampleAlive ? 2 : (lookupRuns ? 1 : 0);
   g->orderSampleAt = sampleWord;
-  g->orderSamples = kSamples;
+  g->orderSamples = chooseOf;
   g->orderLookupFused = true;
   g->orderFusedKeptAt = kept;
   g->orderKeptAt = leftoverCount;
@@ -1316,14 +1324,14 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
     const unsigned long long rounds = (nq + 1023ull) / 1024ull; /* a workgroup takes 1024 k-mers a round */
     unsigned grid = residentGrid(g, aminoLookupSearchKernel<10u>);
     if (rounds < grid) grid = (unsigned)rounds;
-    launchAminoLookupAt<kMaxLength>(fixedLength, grid ? grid : 1u, s, g->dev, dChars, nq, sampleAlive, kSamples, rng, dCounts, out, leftover, leftoverCount, kept);
+    launchAminoLookupAt<kMaxLength>(fixedLength, grid ? grid : 1u, s, g->dev, dChars, nq, sampleAlive, chooseOf, rng, dCounts, out, leftover, leftoverCount, kept);
     AMINO_TRY(hipGetLastError());
   }
   if (generalRuns) { /* the whole batch through the general kernel when the sample says so (it returns at once otherwise) */
     const unsigned full = residentGrid(g, searchKernel<true, 2, false, false, true>);
     hipLaunchKernelGGL((searchKernel<true, 2, false, false, true>), dim3(full), dim3(kThreads), 0, s, g->dev, dChars,
                        (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
-                       (const unsigned char *)nullptr, 0u, 0u, 0ull, (const unsigned *)nullptr, out, sampleAlive, kSamples);
+                       (const unsigned char *)nullptr, 0u, 0u, 0ull, (const unsigned *)nullptr, out, sampleAlive, chooseOf);
     AMINO_TRY(hipGetLastError());
   }
   if (lookupRuns) { /* what the lookup kernel left: the last *leftoverCount records of the list */
