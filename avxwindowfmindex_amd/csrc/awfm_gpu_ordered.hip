@@ -975,7 +975,8 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   const unsigned *sampleAlive = nullptr;
   if (lengthTable) {
     const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
-    const unsigned useNext = (g->dev.deepNext != 0u && !pairOff ? 1u : 0u) | (pairOff ? 2u : 0u);
+    unsigned useNext = (g->dev.deepNext != 0u && !pairOff ? 1u : 0u) | (pairOff ? 2u : 0u);
+    if (getenv("AWFM_GPU_MIXED_DROP_SURVIVORS")) useNext |= 8u; /* MEASUREMENT ONLY (wrong results): the lookup phase alone */
     /* the superblock bases of the pair image are read from memory: 24 KB of them in LDS (a 3.1 Gbp image) would leave room
      * for 3 workgroups per CU where the survivors' slots alone allow 6 (10^8 8..30-mers: 6.36 against 6.74 ms);
      * $AWFM_GPU_LOOKUP_PAIR_SUPER=lds|global: measurement knob */

@@ -79,7 +79,7 @@ __device__ __forceinline__ MixedVerdict mixedRead(const DevIndex &ix, unsigned u
   /* the first step from the deeper table is a pair step when two or more characters are left and the image has its pair
    * blocks: its next-step bit says whether that step leaves anything (bit 0 of useNext: the bits are there and in use) */
   const bool bit = (useNext & 1u) == 0u || len < DK + 2u || ((next16 >> ((unsigned)(codes >> (2u * DK)) & 15u)) & 1u) != 0u;
-  v.survives = len > DK && length != 0u && bit;
+  v.survives = len > DK && length != 0u && bit && (useNext & 8u) == 0u; /* (bit 3: a measurement knob that drops them) */
   return v;
 }
 /* where the entry of a k-mer of `len` (>= 1) characters is: entry `at` of the deeper table (len >= deepK) or of the length tables */
@@ -227,6 +227,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      /* (Round 5 measured what bounds these steps: with the survivors dropped -- $AWFM_GPU_MIXED_DROP_SURVIVORS, wrong results --
+       * the kernel takes 2.8 of its 6.7 ms per 10^8 8..30-mers, so the steps of 3.3 * 10^7 survivors take 3.9: 1.2 * 10^8 block
+       * lines at 3.1 * 10^7 a second.  TWO k-mers per group of 4 lanes, the loads of both requested before either is ranked --
+       * 32 chains a wave, at 4 and at 5 waves per SIMD -- took 6.74 and 6.60 ms: the same.  The chains in flight are not the
+       * bound.) */
       /* The survivors of a round have one to eight pair steps to go (and many end after the first): taken 16 at a time, a
        * pass lasts as long as its longest chain while the other groups of 4 lanes idle -- 10^8 8..30-mers, half of them
        * drawn from the text: 6.4 ms.  So a group that is done with its k-mer takes the next slot at once, and every
