@@ -37,7 +37,7 @@ GPU_SYMBOLS = [
     "awfmGpuSearchHitsPacked", "awfmGpuLocateTo", "awfmGpuSearchHitsLineTally", "awfmGpuIndexDeepSeedK", "awfmGpuSearchHitsCompact", "awfmGpuCompactHits", "awfmGpuSortHits",
     "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse", "awfmGpuSearchHitsInOrder",
     "awfmGpuSortHitsOnDevice", "awfmGpuHitOffsetsOnDevice", "awfmGpuLocateOnDevice", "awfmGpuLastOrderedSearchKernelMs", "awfmGpuOrderedKernelLog", "awfmGpuIndexDeepSeedBuildSeconds", "awfmGpuIndexDeepSeedTransientBytes", "awfmGpuIndexHasDenseSa", "awfmGpuIndexDenseSaBuildSeconds", "awfmGpuIndexLengthTableBytes", "awfmGpuIndexLengthTableBuildSeconds", "awfmGpuMixedLookupLineTally",
-    "awfmGpuListLocateOnDevice", "awfmGpuLastLookupFront", "awfmGpuSynthPlantedQueriesUnique", "awfmGpuStreamRetire", "awfmGpuIndexDescribe", "awfmGpuIndexDeepSeedAllocSeconds",
+    "awfmGpuListLocateOnDevice", "awfmGpuLastLookupFront", "awfmGpuSynthPlantedQueriesUnique", "awfmGpuStreamRetire", "awfmGpuIndexDescribe", "awfmGpuIndexDeepSeedAllocSeconds", "awfmGpuAosLastStages", "awfmHostCopyGBs",
 ]
 # int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
 CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
@@ -177,6 +177,8 @@ def lib():
         "awfmGpuStreamRetire": (None, [vp, vp]),
         "awfmGpuIndexDescribe": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "awfmGpuIndexDeepSeedAllocSeconds": (C.c_double, [vp]),
+        "awfmGpuAosLastStages": (None, [C.POINTER(C.c_double * 10)]),
+        "awfmHostCopyGBs": (C.c_double, [C.c_uint32, u64]),
         "awfmGpuHitOffsetsOnDevice": (C.c_int, [vp, vp, vp, u64, vp, vp, vp]),
         "awfmGpuLocateOnDevice": (C.c_int, [vp, vp, vp, u64, u64, vp, vp]),
         "awfmGpuLastOrderedSearchKernelMs": (C.c_double, [vp]),

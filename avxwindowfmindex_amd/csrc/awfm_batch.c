@@ -301,6 +301,14 @@ static double nowMs(void) {
   return (double)t.tv_sec * 1e3 + (double)t.tv_nsec * 1e-6;
 }
 
+/* what the last awFmParallelSearchCount / Locate of the process spent where, summed over its chunks (the lanes overlap, so the
+ * sums exceed the wall time): reporting (awfmGpuAosLastStages; bench.py's end_to_end) */
+static pthread_mutex_t stageLock = PTHREAD_MUTEX_INITIALIZER;
+static struct {
+  double wallMs, turnMs, packMs, deviceMs, scatterMs;
+  uint64_t chunks, kmers, hits, packBytes, scatterBytes;
+} lastStages;
+
 struct laneJob {
   AwFmGpuIndex *image;
   struct AwFmKmerSearchData *data; /* the whole list */
@@ -371,9 +379,29 @@ static enum AwFmReturnCode runChunk(struct laneJob *job, struct AwFmKmerSearchDa
     waitMs = ctx.waitMs;
     scatterMs = ctx.scatterMs;
   }
+  const double t5 = nowMs();
   if (job->trace)
     fprintf(stderr, "[awfm aos] lane %u chunk %llu: %llu k-mers, turn %.2f ms, pack %.2f ms, device call %.2f ms (of which turn %.2f, scatter %.2f)\n",
-            job->lane, (unsigned long long)chunkNumber, (unsigned long long)n, t1 - t0, t2 - t1, nowMs() - t2, waitMs, scatterMs);
+            job->lane, (unsigned long long)chunkNumber, (unsigned long long)n, t1 - t0, t2 - t1, t5 - t2, waitMs, scatterMs);
+  {
+    /* bytes the host stages move for the chunk: pack reads a 32-byte entry and the k-mer's characters and writes the
+     * characters (+ 8 bytes of offset in a mixed-length chunk); scatter reads 8 bytes of hit offset (4 of count) and the
+     * positions, writes the positions into their lists, and rewrites the entry's line (count, possibly the list pointer) */
+    uint64_t chars = 0, hits = 0;
+    if (packed) chars = offsets ? offsets[n] : (uint64_t)fixedLength * n;
+    if (packed && job->locate && rc == AwFmSuccess) hits = ((const uint64_t *)out)[n];
+    pthread_mutex_lock(&stageLock);
+    lastStages.turnMs += (t1 - t0) + waitMs;
+    lastStages.packMs += t2 - t1;
+    lastStages.deviceMs += (t5 - t2) - waitMs - scatterMs;
+    lastStages.scatterMs += scatterMs;
+    lastStages.chunks++;
+    lastStages.kmers += n;
+    lastStages.hits += hits;
+    lastStages.packBytes += 32u * n + 2u * chars + (offsets ? 8u * n : 0u);
+    lastStages.scatterBytes += (job->locate ? 8u : 4u) * n + 64u * n + 16u * hits;
+    pthread_mutex_unlock(&stageLock);
+  }
   return rc;
 }
 
@@ -405,6 +433,10 @@ static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKm
                                     bool locate, const char *who) {
   const uint64_t n = (uint32_t)list->count; /* the reference reads the count as uint32_t (:100, :164) */
   if (n == 0) return AwFmSuccess;
+  const double batchStart = nowMs();
+  pthread_mutex_lock(&stageLock);
+  memset(&lastStages, 0, sizeof lastStages);
+  pthread_mutex_unlock(&stageLock);
   AwFmGpuIndex *images[AWFM_MAX_IMAGES];
   /* without an explicit device list a small batch is one chunk on one lane: splitting it would only add launches */
   const char *deviceList = getenv("AWFM_GPU_DEVICES");
@@ -435,10 +467,62 @@ static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKm
       runLane(&jobs[i]);
     if (firstFailed < 0 && jobs[i].rc != AwFmSuccess) firstFailed = i;
   }
+  pthread_mutex_lock(&stageLock);
+  lastStages.wallMs = nowMs() - batchStart;
+  pthread_mutex_unlock(&stageLock);
   if (firstFailed < 0) return AwFmSuccess;
   fprintf(stderr, "%s: GPU search failed (%d) on image %d: %s\n", who, (int)jobs[firstFailed].rc, firstFailed,
           jobs[firstFailed].error);
   return jobs[firstFailed].rc;
+}
+
+/* see include/awfm_gpu.h */
+void awfmGpuAosLastStages(double out[10]) {
+  pthread_mutex_lock(&stageLock);
+  out[0] = lastStages.wallMs;
+  out[1] = lastStages.turnMs;
+  out[2] = lastStages.packMs;
+  out[3] = lastStages.deviceMs;
+  out[4] = lastStages.scatterMs;
+  out[5] = (double)lastStages.chunks;
+  out[6] = (double)lastStages.kmers;
+  out[7] = (double)lastStages.hits;
+  out[8] = (double)lastStages.packBytes;
+  out[9] = (double)lastStages.scatterBytes;
+  pthread_mutex_unlock(&stageLock);
+}
+
+/* a copy of `bytes` bytes by `threads` threads of the pool the host stages run on: what this box's memory system gives them
+ * (GB/s of bytes read + bytes written; the second of two passes -- the first touches the pages) */
+struct copyCtx {
+  uint8_t *dst;
+  const uint8_t *src;
+};
+static void copyRange(void *p, uint64_t begin, uint64_t end, unsigned tid) {
+  (void)tid;
+  struct copyCtx *c = p;
+  memcpy(c->dst + begin, c->src + begin, (size_t)(end - begin));
+}
+double awfmHostCopyGBs(unsigned threads, uint64_t bytes) {
+  if (bytes < 4096u) bytes = 4096u;
+  struct copyCtx c = {malloc(bytes), malloc(bytes)};
+  if (!c.dst || !c.src) {
+    free(c.dst);
+    free((void *)c.src);
+    return 0.0;
+  }
+  memset((void *)c.src, 1, bytes);
+  awfmParallelFor(threads ? threads : 1, bytes, copyRange, &c);
+  double best = 0.0;
+  for (int pass = 0; pass < 3; pass++) {
+    const double t0 = nowMs();
+    awfmParallelFor(threads ? threads : 1, bytes, copyRange, &c);
+    const double gbs = 2.0 * (double)bytes / ((nowMs() - t0) * 1e-3) / 1e9;
+    if (gbs > best) best = gbs;
+  }
+  free(c.dst);
+  free((void *)c.src);
+  return best;
 }
 
 static _Thread_local enum AwFmReturnCode lastBatchStatus = AwFmSuccess;

@@ -281,9 +281,27 @@ def end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, a
             assert np.array_equal(got, np.diff(ho).astype(np.uint32)), "AoS counts differ from the device API's"
         else:
             assert np.array_equal(got, d_counts[:m].cpu().numpy().view(np.uint32)), "AoS counts differ from the device API's"
+        def host_side(value):
+            """the host stages of the LAST call (awfmGpuAosLastStages) against what this box's memory system gives the same
+            threads: pack and scatter move bytes and nothing else, so bytes moved / measured copy rate bounds a call from below"""
+            st = (C.c_double * 10)()
+            L.awfmGpuAosLastStages(C.byref(st))
+            wall, turn, pack, device, scatter, chunks, kmers, hits, pack_b, scatter_b = list(st)
+            bound_ms = (pack_b + scatter_b) / (copy_gbs * 1e9) * 1e3 if copy_gbs else None
+            return {"last_call_ms": round(wall, 2), "chunks": int(chunks), "stage_ms_summed_over_chunks": {
+                        "waiting_for_the_host_turn": round(turn, 2), "pack": round(pack, 2), "device_call": round(device, 2), "scatter": round(scatter, 2)},
+                    "bytes_moved_by_pack": int(pack_b), "bytes_moved_by_scatter": int(scatter_b), "bytes_per_kmer": round((pack_b + scatter_b) / max(kmers, 1), 1),
+                    "host_copy_GBs": round(copy_gbs, 1), "host_copy_what": f"1 GiB memcpy by the same {threads} pool threads, bytes read + written per second",
+                    "host_bound_ms": round(bound_ms, 2) if bound_ms else None,
+                    "host_bound_Mkmers_per_s": round(kmers / bound_ms / 1e3, 1) if bound_ms else None,
+                    "frac_of_host_bound": round(bound_ms / wall, 3) if bound_ms else None,
+                    "host_stages_GBs": round((pack_b + scatter_b) / ((pack + scatter) * 1e-3) / 1e9, 1) if pack + scatter > 0 else None}
+
+        copy_gbs = float(L.awfmHostCopyGBs(threads, 1 << 30))
         out["aos_drop_in"] = {"value": round(m / dt / 1e6, 1), "ms": round(dt * 1e3, 2), "kmers": m, "host_threads": threads,
                               "ms_all": [round(t * 1e3, 2) for t in aos_times],
-                              "entry_point": "awFmParallelSearchLocate" if locate else "awFmParallelSearchCount"}
+                              "entry_point": "awFmParallelSearchLocate" if locate else "awFmParallelSearchCount",
+                              "host": host_side(m / dt / 1e6)}
         if locate and d_planted is not None:
             # the same call on k-mers drawn from the text: every one has a position list to size, fill and hand back
             from avxwindowfmindex_amd import synth
@@ -303,7 +321,7 @@ def end_to_end(args, L, api, g, ix, d_chars, d_counts, d_hit_off, state, Q, K, a
             pdt = min(planted_times)
             out["aos_drop_in_planted"] = {"value": round(m / pdt / 1e6, 1), "ms": round(pdt * 1e3, 2), "kmers": m, "hits": int(got.sum()),
                                           "host_threads": threads, "ms_all": [round(t * 1e3, 2) for t in planted_times],
-                                          "entry_point": "awFmParallelSearchLocate",
+                                          "entry_point": "awFmParallelSearchLocate", "host": host_side(m / pdt / 1e6),
                                           "checked": "every k-mer has hits; the first 1000 position lists hold their planting offsets"}
         lst.dealloc()
     return out

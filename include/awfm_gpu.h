@@ -350,6 +350,14 @@ enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearch
                                         uint64_t queryBegin, uint64_t queryEnd, uint64_t hitBegin, uint64_t hitEnd,
                                         uint64_t *dPositions, uint64_t *outPositions, void *stream);
 
+/* Reporting for the drop-in AoS entry points: what the process's last awFmParallelSearchCount / Locate spent where, summed over
+ * its chunks -- out = {wall ms, ms waiting for the host stages' turn, ms packing, ms in the device calls, ms scattering, chunks,
+ * k-mers, hits, bytes the pack stage read + wrote, bytes the scatter stage read + wrote} (the lanes overlap: the sums of the
+ * stages exceed the wall time) -- and the copy rate this box gives `threads` of the same thread pool (GB/s, bytes read + bytes
+ * written, over `bytes`): the pack and scatter stages move bytes and nothing else, so that rate bounds them. */
+void awfmGpuAosLastStages(double out[10]);
+double awfmHostCopyGBs(unsigned threads, uint64_t bytes);
+
 /* ---- pinned staging for the drop-in AoS entry points ---- */
 /* A grow-only page-locked host buffer cached in the image (slot 0..3); valid until the next call for the
  * same slot.  awfmGpuAosLock/Unlock serialise the AoS entry points that share these buffers. */
