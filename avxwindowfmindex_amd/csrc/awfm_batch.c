@@ -384,9 +384,12 @@ static enum AwFmReturnCode runChunk(struct laneJob *job, struct AwFmKmerSearchDa
     fprintf(stderr, "[awfm aos] lane %u chunk %llu: %llu k-mers, turn %.2f ms, pack %.2f ms, device call %.2f ms (of which turn %.2f, scatter %.2f)\n",
             job->lane, (unsigned long long)chunkNumber, (unsigned long long)n, t1 - t0, t2 - t1, t5 - t2, waitMs, scatterMs);
   {
-    /* bytes the host stages move for the chunk: pack reads a 32-byte entry and the k-mer's characters and writes the
-     * characters (+ 8 bytes of offset in a mixed-length chunk); scatter reads 8 bytes of hit offset (4 of count) and the
-     * positions, writes the positions into their lists, and rewrites the entry's line (count, possibly the list pointer) */
+    /* bytes the host stages move for the chunk, at the granularity the memory system moves them: pack reads a 32-byte entry
+     * and the k-mer's characters and writes the characters (+ 8 bytes of offset in a mixed-length chunk); scatter reads 8
+     * bytes of hit offset (4 of count) per k-mer and 8 per position, rewrites every entry's line (count, possibly the list
+     * pointer: 64 bytes read + written per 32-byte entry pair, i.e. 64 per k-mer), and for a k-mer with hits its position
+     * list -- the reference's own 4-slot malloc per k-mer (ref src/AwFmParallelSearch.c:36-84): 48 bytes of heap, read for
+     * ownership and written back; hits beyond the four slots at 16 bytes each */
     uint64_t chars = 0, hits = 0;
     if (packed) chars = offsets ? offsets[n] : (uint64_t)fixedLength * n;
     if (packed && job->locate && rc == AwFmSuccess) hits = ((const uint64_t *)out)[n];
@@ -399,7 +402,7 @@ static enum AwFmReturnCode runChunk(struct laneJob *job, struct AwFmKmerSearchDa
     lastStages.kmers += n;
     lastStages.hits += hits;
     lastStages.packBytes += 32u * n + 2u * chars + (offsets ? 8u * n : 0u);
-    lastStages.scatterBytes += (job->locate ? 8u : 4u) * n + 64u * n + 16u * hits;
+    lastStages.scatterBytes += (job->locate ? 8u : 4u) * n + 64u * n + 96u * (hits < n ? hits : n) + 8u * hits + (hits > 4u * n ? 16u * (hits - 4u * n) : 0u);
     pthread_mutex_unlock(&stageLock);
   }
   return rc;
