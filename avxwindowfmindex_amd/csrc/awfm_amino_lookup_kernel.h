@@ -142,7 +142,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
 #pragma unroll
     for (unsigned i = 0; i < 4u; i++) {
       const bool inBatch = t + i < numQueries;
-      const bool survives = inBatch && !bad[i] && entry[i].y != 0u;
+      /* alive after the entry: its range holds something and -- tables with next-step bits -- still will after the next
+       * letter (the first of the lead's: bits 4..0; a k-mer that ends at the table has no next letter) */
+      const unsigned length = aminoDeepLength(ix, entry[i]);
+      const bool survives = inBatch && !bad[i] && length != 0u && (K == DK || aminoDeepNextBit(ix, entry[i], (unsigned)lead[i] & 31u));
       const unsigned long long smask = __ballot(survives);
       const unsigned rank = stotal + (unsigned)__popcll(smask & ((1ull << lane) - 1ull));
       stotal += (unsigned)__popcll(smask);
@@ -150,7 +153,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
         sLead[w][rank] = lead[i];
         sNum[w][rank] = (unsigned)(t + i);
         sSp[w][rank] = entry[i].x;
-        sEp[w][rank] = entry[i].x + entry[i].y - 1u;
+        sEp[w][rank] = entry[i].x + length - 1u;
       }
       /* the general kernel's: a character among the table's that is not one of the 20 letters; a survivor without a slot */
       const bool left = inBatch && (bad[i] || (survives && rank >= kAminoSlots));
@@ -278,7 +281,9 @@ __global__ void __launch_bounds__(256)
       idx = idx * 20u + letter;
       bad |= letter >= 20u;
     }
-    alive = bad || ((const uint2 *)ix.deepSeed)[bad ? 0u : idx].y != 0u;
+    const uint2 e = ((const uint2 *)ix.deepSeed)[bad ? 0u : idx];
+    const unsigned nextLetter = fixedLen > ix.deepK ? aminoLetterIndex(sAmino, at[fixedLen - ix.deepK - 1u]) : 20u;
+    alive = bad || (aminoDeepLength(ix, e) != 0u && aminoDeepNextBit(ix, e, nextLetter));
   }
   const unsigned n = (unsigned)__popcll(__ballot(alive));
   if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&sAlive, n);

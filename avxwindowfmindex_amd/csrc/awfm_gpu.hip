@@ -1080,7 +1080,7 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
       } else {
         g->dDeepSeed = table;
         g->dDeepBig = big;
-        g->deepSeedBytes = bytes + (big ? ((g->dev.bwtLength >> kDeepBigShift) + 5u) * 4u : 0u);
+        g->deepSeedBytes = bytes + (big ? ((g->dev.bwtLength >> (g->amino ? kAminoDeepBigShift : kDeepBigShift)) + 5u) * 4u : 0u);
         g->dev.deepSeed = (const ulonglong2 *)table;
         g->dev.deepK = deepK;
         g->dev.deepNarrow = g->dev.bwtLength < (1ull << 32) ? 1u : 0u;

@@ -226,9 +226,37 @@ static bool orderedApplies(const AwFmGpuIndex *g, bool hasOffsets, uint32_t fixe
 int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **bigOut, unsigned *numBigOut) {
   *bigOut = nullptr;
   *numBigOut = 0;
-  if (!g || g->amino || !table || !g->dev.pairBlocks || g->dev.bwtLength >= (1ull << 32) || deepK == 0 || deepK > 16) return 0;
+  if (!g || !table || g->dev.bwtLength >= (1ull << 32) || deepK == 0) return 0;
+  if (g->amino ? deepK > 7u : (!g->dev.pairBlocks || deepK > 16u)) return 0;
   if (getenv("AWFM_GPU_DEEP_NEXT") && atoi(getenv("AWFM_GPU_DEEP_NEXT")) == 0) return 0; /* comparison runs */
   DeviceGuard guard(g->device);
+  if (g->amino) { /* {sp, length12 | next20 << 12}, the long lengths by sp >> 11 (awfm_device.h) */
+    unsigned long long numEntries = 1;
+    for (unsigned k = 0; k < deepK; k++) numEntries *= 20ull;
+    const size_t bigWords = (size_t)(g->dev.bwtLength >> kAminoDeepBigShift) + 1u;
+    unsigned *dBig = nullptr;
+    if (hipMalloc((void **)&dBig, (bigWords + 4u) * 4u) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    unsigned numBig = 0;
+    bool ok = hipMemset(dBig, 0, (bigWords + 4u) * 4u) == hipSuccess;
+    if (ok) {
+      const unsigned grid = residentGrid(g, aminoDeepNextKernel, 0, kThreads);
+      hipLaunchKernelGGL(aminoDeepNextKernel, dim3(grid ? grid : 1u), dim3(kThreads), 0, 0, g->dev, (uint2 *)table, numEntries, dBig, dBig + bigWords);
+      ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+           hipMemcpy(&numBig, dBig + bigWords, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (!ok) {
+      (void)hipGetLastError();
+      (void)hipFree(dBig);
+      awfmGpuSetError("deep seed table: the pass that adds the next-step bits failed");
+      return -1;
+    }
+    *bigOut = dBig;
+    *numBigOut = numBig;
+    return 1;
+  }
   const unsigned long long numEntries = 1ull << (2u * deepK);
   /* the lengths that do not fit the entries' 16 bits, by where their ranges begin (awfm_device.h: deepBigLength), allocated
    * before the in-place rewrite so that it cannot fail half-way; + the word that counts them */

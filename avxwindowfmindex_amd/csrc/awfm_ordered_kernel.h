@@ -907,7 +907,9 @@ __global__ void __launch_bounds__(256)
         idx = idx * 20u + letter;
         bad |= letter >= 20u;
       }
-      alive = bad || ((const uint2 *)ix.deepSeed)[bad ? 0u : idx].y != 0u;
+      const uint2 e = ((const uint2 *)ix.deepSeed)[bad ? 0u : idx];
+      const unsigned nextLetter = fixedLen > depth ? aminoLetterIndex(sAmino, at[fixedLen - depth - 1u]) : 20u;
+      alive = bad || (aminoDeepLength(ix, e) != 0u && aminoDeepNextBit(ix, e, nextLetter));
     } else {
       unsigned long long codes = 0;
       unsigned bad = 0;
@@ -1828,6 +1830,46 @@ __global__ void __launch_bounds__(orderedThreads(true)) __attribute__((amdgpu_nu
           atomicAdd(numBig, 1u);
         }
         table[at] = make_uint2(e.x, (e.y < 0xFFFFu ? e.y : 0xFFFFu) | next16 << 16);
+      }
+    }
+  }
+}
+
+/* The amino twin (awfm_device.h: kAminoDeepLengthBits): every non-empty entry {sp, length} of a finished depth-deepK table
+ * becomes {sp, length12 | next20 << 12}, bit c set when the range still holds a position after one more step with letter c.
+ * One group of 4 lanes per entry, 20 steps each (aminoStepAny: the search kernels' step); lengths of 4095 and more go to
+ * bigBySp[sp >> 11]. */
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
+    aminoDeepNextKernel(const DevIndex ix, uint2 *__restrict__ table, const unsigned long long numEntries, unsigned *__restrict__ bigBySp,
+                        unsigned *__restrict__ numBig) {
+  constexpr int G = 4;
+  __shared__ unsigned long long sC[24];
+  __shared__ AminoShared sAmino;
+  __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
+  if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
+  aminoStageTables(sAmino);
+  stageMaskTable(sMask);
+  __syncthreads();
+  const unsigned gl = threadIdx.x % G, lane = threadIdx.x & 63u;
+  constexpr unsigned long long kChunk = 64 / G;
+  const unsigned long long waveStride = (unsigned long long)gridDim.x * (blockDim.x / 64u) * kChunk;
+  for (unsigned long long base = ((unsigned long long)blockIdx.x * (blockDim.x / 64u) + threadIdx.x / 64u) * kChunk; base < numEntries;
+       base += waveStride) {
+    const unsigned long long at = base + lane / G;
+    const uint2 e = at < numEntries ? table[at] : make_uint2(1u, 0u);
+    if (e.y != 0u) { /* whole groups of 4 lanes */
+      unsigned next20 = 0;
+      for (unsigned letter = 0; letter < 20u; letter++) {
+        PositionType<true>::type sp = e.x, ep = e.x + e.y - 1u;
+        aminoStepAny<G, true>(ix, sC, sAmino, sMask, gl, letter, sp, ep);
+        if (sp <= ep) next20 |= 1u << letter;
+      }
+      if (gl == 0) {
+        if (e.y >= kAminoDeepLengthMask) {
+          bigBySp[e.x >> kAminoDeepBigShift] = e.y;
+          atomicAdd(numBig, 1u);
+        }
+        table[at] = make_uint2(e.x, (e.y < kAminoDeepLengthMask ? e.y : kAminoDeepLengthMask) | next20 << kAminoDeepLengthBits);
       }
     }
   }

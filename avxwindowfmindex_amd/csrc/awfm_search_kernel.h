@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
           const unsigned indexDeep = groupSum<G>(partialDeep);
           const unsigned long long ballotDeep = __ballot(ambiguousDeep);
           if (((unsigned)(ballotDeep >> (lane & ~(unsigned)(G - 1))) & ((1u << G) - 1u)) == 0u) {
-            const ulonglong2 r = deepSeedEntry(ix, indexDeep);
+            const ulonglong2 r = aminoDeepSeedEntry(ix, indexDeep);
             sp = (pos_t)r.x;
             ep = (pos_t)r.y;
             pos = (int)(len - DK) - 1;

@@ -306,6 +306,8 @@ def test_amino_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, 
     n = 120000
     txt = synth.text(700 + deep_k, n, synth.AMINO_ALPHABET).copy()
     txt[500:503] = ord("x")
+    txt[60000:100000] = np.frombuffer(b"acdefghikl" * 4000, np.uint8)  # a repeat: ranges of 4000 and more (12-bit lengths saturate)
+    txt[20000:32000] = np.frombuffer(b"mnp" * 4000, np.uint8)
     ix = awfm.create_index(txt, awfm.AwFmAlphabetAmino, 8, seed_k)
     oi = oracle.Index.wrap(oracle.AMINO, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(),
                            ix.packed_sa())
@@ -321,7 +323,8 @@ def test_amino_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, 
     g = awfm.GpuIndex(ix)
     before = g.device_bytes
     g.set_deep_seed(deep_k)
-    assert g.deep_seed_k == deep_k and g.device_bytes == before + 8 * 20 ** deep_k
+    # (8-byte entries {sp, length12 | next20 << 12}; the lengths of 4095 and more have a table of their own, a word per 2^11 positions)
+    assert g.deep_seed_k == deep_k and g.device_bytes == before + 8 * 20 ** deep_k + 4 * ((ix.bwt_length >> 11) + 5)
     ranges, ho, p = g.locate_host(chars, offsets)
     assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep)
     assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
