@@ -1,6 +1,6 @@
 #!/bin/bash
 # every bench.py configuration quoted in DESIGN.md, one JSON line each -> gpurun_out/bench_<tag>/bench_<name>.json
-TAG=${1:-r4}
+TAG=${1:-r5}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/bench_$TAG
 mkdir -p "$OUT"
@@ -42,6 +42,17 @@ run planted_lf_walk -- --workload planted --no-device-dense-sa --no-cpu --no-e2e
 run lf_walk -- --no-device-dense-sa --no-cpu --no-e2e --no-secondary --general-steps 0
 run repetitive_random -- --text repetitive --no-cpu --no-e2e --general-steps 0
 run repetitive_planted -- --text repetitive --workload planted --no-cpu --no-e2e --general-steps 0
+run repetitive_unique -- --text repetitive --workload unique --no-cpu --no-e2e --general-steps 0
+# round 5
+run no_prediction AWFM_GPU_LOOKUP_PREDICT=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run no_fused_prologue AWFM_GPU_PREP_FUSED=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run no_list_tail AWFM_BENCH_LIST_TAIL=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run round4_step AWFM_GPU_LOOKUP_PREDICT=0 AWFM_GPU_PREP_FUSED=0 AWFM_BENCH_LIST_TAIL=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
+run exact_tables AWFM_GPU_ORDERED=0 -- --mode count --no-cpu --no-e2e --no-secondary
+run exact_tables_off AWFM_GPU_ORDERED=0 AWFM_GPU_EXACT_LOOKUP=0 -- --mode count --no-cpu --no-e2e --no-secondary
+run amino_no_next_bits AWFM_GPU_DEEP_NEXT=0 -- --alphabet amino --no-cpu --no-e2e
+run amino_2e9_no_next_bits AWFM_GPU_DEEP_NEXT=0 -- --alphabet amino --text-len 2e9 --no-cpu --no-e2e
+run amino_planted -- --alphabet amino --workload planted --no-cpu --no-e2e
 python3 - "$OUT" <<'PY'
 import glob, json, os, sys
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):

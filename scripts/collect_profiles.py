@@ -3,7 +3,13 @@
 kernel_stats_<name>_bench.csv (rocprofv3 --kernel-trace --stats), pmc_summary_<name>_bench.json (mean counter values per
 kernel) and traffic_<name>.json (HBM bytes per launch of the search kernel, MI355X_MICROARCH.md rules).
 
-usage: scripts/collect_profiles.py gpurun_out/prof_<tag> profiles/r1 <name> "<workload text>"
+usage: scripts/collect_profiles.py gpurun_out/prof_<tag> profiles/r1 <name> "<workload text>" [bench line of the same configuration]
+
+Round 5: every file written carries the commit the profiled tree was at (prof_<tag>/commit.txt, written by
+scripts/profile_bench.sh from $AWFM_COMMIT), and a set is REFUSED -- no counters_<name>.json, exit status 3 -- when the
+dominant kernel's average duration in the kernel trace differs by more than 5 % from `roofline.kernel_ms` of the bench line
+it is meant to explain (the line the profiled run printed, and the un-profiled line given as the fifth argument): an average
+over launches that are not the timed ones, or counters of another code state, say nothing about that line.
 """
 import collections
 import csv
@@ -14,7 +20,19 @@ import shutil
 import sys
 
 src, dst, name, workload = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
+bench_line_path = sys.argv[5] if len(sys.argv) > 5 else None
 os.makedirs(dst, exist_ok=True)
+commit = open(os.path.join(src, "commit.txt")).read().strip() if os.path.exists(os.path.join(src, "commit.txt")) else None
+
+
+def bench_kernel_ms(path):
+    """roofline.kernel / kernel_ms of a bench.py JSON line (None when there is none)"""
+    try:
+        lines = [ln for ln in open(path) if ln.startswith("{")]
+        r = json.loads(lines[-1])["roofline"]
+        return r.get("kernel"), float(r["kernel_ms"])
+    except Exception:  # noqa: BLE001
+        return None, None
 def newest(paths):
     """gpurun_out accumulates the files of every profiling call for a tag: keep the latest run of each pass"""
     return sorted(paths, key=os.path.getmtime)[-1:]
@@ -99,7 +117,7 @@ if ordered:
     hbm = sum(v["read_bytes"] + v["write_bytes"] for v in per_kernel.values())
     json.dump({
         "kernel": "awfmGpuSearchHits (ordered path): " + ", ".join(sorted(k.split("<")[0] for k in parts)),
-        "workload": workload, "per_kernel": per_kernel, "hbm_bytes_per_launch": int(hbm),
+        "workload": workload, "commit": commit, "per_kernel": per_kernel, "hbm_bytes_per_launch": int(hbm),
         "method": "rocprofv3 --pmc FETCH_SIZE, --pmc WRITE_SIZE and --pmc TCC_HIT_sum TCC_MISS_sum in separate passes "
                   "(scripts/profile_bench.sh), summed over every kernel of one awfmGpuSearchHits call.  Reads = 2 x FETCH_SIZE: "
                   "on gfx950 FETCH_SIZE tallies each read request at 64 B (MI355X_MICROARCH.md, HBM) and every request is a "
@@ -118,7 +136,7 @@ if search and not ordered:
     fetch_kb, write_kb = summary[k]["FETCH_SIZE"]["mean"], summary[k].get("WRITE_SIZE", {"mean": 0.0})["mean"]
     miss = summary[k].get("TCC_MISS_sum", {"mean": None})["mean"]
     json.dump({
-        "kernel": k, "workload": workload, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "TCC_MISS_sum": miss,
+        "kernel": k, "workload": workload, "commit": commit, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb, "TCC_MISS_sum": miss,
         "avg_ns_kernel_trace": kernel_avg_ns(k),
         "hbm_bytes_per_launch": int(2 * fetch_kb * 1024 + write_kb * 1024),
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (scripts/profile_bench.sh); on "
@@ -156,6 +174,21 @@ if dominant:
             out["hbm_read_GBs"] = out["hbm_read_bytes"] / ns
     if "WRITE_SIZE" in c:
         out["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024.0
+    out["commit"] = commit
+    # the gate: this kernel's average in the kernel trace against the kernel_ms of the bench lines it explains
+    refused = []
+    for label, path in (("the profiled run's own line", os.path.join(src, "bench_trace.log")), ("the un-profiled line", bench_line_path)):
+        if not path or not os.path.exists(path) or not ns:
+            continue
+        kernel, ms = bench_kernel_ms(path)
+        if ms is None or not kernel or not str(dominant).startswith(str(kernel).split(" ")[0].split("<")[0]):
+            continue  # (the line's roofline is another kernel's: nothing to compare)
+        out.setdefault("bench_kernel_ms", {})[label] = ms
+        if abs(ns / 1e6 - ms) > 0.05 * ms:
+            refused.append(f"{label}: kernel_ms {ms:.3f} against {ns / 1e6:.3f} ms in the kernel trace")
+    if refused:
+        print(f"REFUSED counters_{name}: " + "; ".join(refused), file=sys.stderr)
+        sys.exit(3)
     json.dump(out, open(os.path.join(dst, f"counters_{name}.json"), "w"), indent=1, sort_keys=True)
     print("dominant kernel", dominant, {k: v for k, v in out.items() if k not in ("raw", "kernel", "workload")})
 # every kernel of the run: bytes and time per launch (for the locate kernels of the planted workload)
@@ -169,6 +202,7 @@ for k in summary:
             "l2_hit_rate": (summary[k]["TCC_HIT_sum"]["mean"] / max(1.0, summary[k]["TCC_HIT_sum"]["mean"] + summary[k]["TCC_MISS_sum"]["mean"]))
             if "TCC_HIT_sum" in summary[k] else None,
             "avg_ns_kernel_trace": kernel_avg_ns(k.split("(")[0])}
+table["_commit"] = commit
 json.dump(table, open(os.path.join(dst, f"kernels_{name}.json"), "w"), indent=1, sort_keys=True)
 for line in open(os.path.join(src, "bench_trace.log")):
     if line.startswith("{"):

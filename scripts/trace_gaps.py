@@ -21,7 +21,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "--around":
     idx = [i for i, r in enumerate(rows) if pat in r[2]]
     if not idx:
         sys.exit(f"no kernel named *{pat}*")
-    rows = rows[max(idx[-k:][0] - 8, 0): idx[-1] + 30]
+    rows = rows[max(idx[-k:][0] - 8, 0): idx[-1] + 12]
 else:
     rows = rows[-(int(sys.argv[2]) if len(sys.argv) > 2 else 80):]
 t0 = rows[0][0]
