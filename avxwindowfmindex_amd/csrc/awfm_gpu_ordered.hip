@@ -691,8 +691,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
   constexpr size_t kShareCountAt = 98304, kSampleAt = kShareCountAt + kShares * kShareCountStride * 4u; /* bytes into the counter block (tickets end at 65792) */
   constexpr size_t kKeptAt = 102400; /* lookupSearchKernel's survivor counters: kFusedCounters words a line apart */
-  constexpr size_t kTripTicketBytes = kShares * 128u; /* lookupSearchKernel's trip counters, a line per share, behind its survivor counters */
-  static_assert(256 + 8 * kTicketGroups * 8 * 256 <= kShareCountAt && kSampleAt + 4 <= kKeptAt && kKeptAt + kFusedCounters * 64u + kTripTicketBytes <= kOrderCounterBytes, "counter block");
+  static_assert(256 + 8 * kTicketGroups * 8 * 256 <= kShareCountAt && kSampleAt + 4 <= kKeptAt && kKeptAt + kFusedCounters * 64u <= kOrderCounterBytes, "counter block");
 #define BUCKET_TRY(call)                    \
   do {                                      \
     hipError_t e__ = (call);                \
@@ -753,7 +752,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
     if (front == kFrontLookupOnly) {
       vecsA = 256u / 16u;
       zeroB = (uint4 *)(w + kKeptAt);
-      vecsB = (unsigned)((kFusedCounters * 64u + kTripTicketBytes) / 16u);
+      vecsB = kFusedCounters * 64u / 16u;
     }
     static_assert(kSamples == kPredictSamples, "the verdict is judged against the sample's size");
     const unsigned number = predictTag(g, front, fixedLength);
@@ -825,8 +824,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
       /* A workgroup takes its share 1024 k-mers a trip.  A small batch is a few trips per workgroup -- 6.8 for the 1.25 * 10^7
        * k-mers of a shard of an 8-GPU run on 1792 workgroups: most take 7, and the chip idles while they finish -- so the grid
        * is trimmed to the workgroups that share the trips evenly (1744 x 7); $AWFM_GPU_LOOKUP_EVEN_TRIPS=0: the resident grid */
-      const bool dealtTrips = !(getenv("AWFM_GPU_LOOKUP_TICKETS") && atoi(getenv("AWFM_GPU_LOOKUP_TICKETS")) == 0); /* trips dealt from a counter per share */
-      if (!dealtTrips && !(getenv("AWFM_GPU_LOOKUP_EVEN_TRIPS") && atoi(getenv("AWFM_GPU_LOOKUP_EVEN_TRIPS")) == 0)) {
+      if (!(getenv("AWFM_GPU_LOOKUP_EVEN_TRIPS") && atoi(getenv("AWFM_GPU_LOOKUP_EVEN_TRIPS")) == 0)) {
         const unsigned long long tripsPerShare = (shareSize(nq) + 1023ull) / 1024ull, groupsPerShare = fusedGrid / kShares;
         if (groupsPerShare > 0u && tripsPerShare > groupsPerShare) {
           const unsigned long long tripsEach = (tripsPerShare + groupsPerShare - 1ull) / groupsPerShare;
@@ -835,7 +833,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
       }
       /* (lookup only: what the kernel does not search itself goes to the END of the record array, 8 bytes a k-mer number,
        * counted in the general kernel's word -- no code words, no numbers, no histogram) */
-      launchLookupSearchAt<32u>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt, useNext | (pairOff ? 2u : 0u) | (lookupOnly ? 4u : 0u) | (dealtTrips ? 16u : 0u), nq,
+      launchLookupSearchAt<32u>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt, useNext | (pairOff ? 2u : 0u) | (lookupOnly ? 4u : 0u), nq,
                                 (unsigned long long *)(w + codesAt), lookupOnly ? (unsigned *)recs : numbers, lookupOnly ? generalCount : shareCount,
                                 hist, binsPad, sampleAlive, kSamples, rng, dCounts, sparse ? *sparse : SparseOut(),
                                 (unsigned *)(w + kKeptAt), timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr);

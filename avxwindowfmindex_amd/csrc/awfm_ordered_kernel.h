@@ -626,21 +626,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
       hitFill = 0;
     }
   };
-  /* Round 5: the 256-k-mer trips of a share are DEALT to its waves from a counter (bit 4 of useNext; a line per share behind
-   * the survivor counters), the next ticket drawn one trip ahead: a trip lasts as long as its survivors' steps, and with a
-   * fixed stride the waves that drew long trips kept the chip waiting at the end of the kernel -- which a small batch, 7
-   * trips a wave, cannot hide.  One returning atomic per 256 k-mers: 18 a microsecond and counter for 10^8 k-mers. */
-  const bool dealt = (useNext & 16u) != 0u;
-  unsigned *const ticket = keptCounters + kFusedCounters * 16u + share * 32u;
   const unsigned long long waveFirst = first + 4ull * ((unsigned long long)localBlock * 256ull + (threadIdx.x & ~63u));
-  unsigned long long tw = waveFirst;
-  unsigned nextTrip = 0;
-  if (dealt) {
-    if (lane == 0) nextTrip = atomicAdd(ticket, 1u);
-    tw = first + 256ull * (unsigned)__builtin_amdgcn_readfirstlane((int)nextTrip);
-  }
-  for (; tw < last;) {
-    if (dealt && lane == 0) nextTrip = atomicAdd(ticket, 1u);
+  for (unsigned long long tw = waveFirst; tw < last; tw += 4ull * localGrid * 256ull) {
     const unsigned long long t = tw + 4ull * lane;
     unsigned long long codes[4];
     unsigned bad[4];
@@ -813,8 +800,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
       }
       __builtin_amdgcn_wave_barrier(); /* the slots are written again by the next round */
     }
-    if (dealt) tw = first + 256ull * (unsigned)__builtin_amdgcn_readfirstlane((int)nextTrip);
-    else tw += 4ull * localGrid * 256ull;
   }
   for (unsigned at = blockUsed + lane; at < blockSlots; at += 64u) codesOut[first + blockBase + at] = kCodeNone;
   if (lane == 0 && keptHere) atomicAdd(&keptCounters[((blockIdx.x * 4u + w) % kFusedCounters) * 16u], keptHere);
