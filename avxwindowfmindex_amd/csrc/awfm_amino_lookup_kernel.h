@@ -52,7 +52,7 @@ __device__ __forceinline__ void aminoDecode(const AminoShared &t, const Bytes &b
 }
 
 template <unsigned K>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(6, 8))) /* 6 workgroups' LDS fit a CU: 6 waves per SIMD, 80 registers */
     aminoLookupSearchKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const unsigned long long numQueries,
                             const unsigned *__restrict__ sampleAlive, const unsigned samples, ulonglong2 *__restrict__ ranges,
                             unsigned *__restrict__ counts, const SparseOut sparse, unsigned long long *__restrict__ leftover,
