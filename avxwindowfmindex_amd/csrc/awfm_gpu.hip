@@ -1804,6 +1804,71 @@ __global__ void __launch_bounds__(256) denseSaJumpKernel(unsigned *__restrict__ 
   for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
   if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(left, mine);
 }
+/* Round 5: the same with the parked walks in a LIST.  The first pass over a chunk appends a parked walk's {position j, {steps,
+ * where it stands}} to the list and leaves the entry's SLOT in dense[j]; nothing of 8 bytes per position is allocated and no
+ * position is walked twice (a genome-shaped 3.1 Gbp text parks 3.6 * 10^7 of its walks: 0.4 GB of list instead of 24.8 GB).
+ * Slots beyond the list's capacity are only counted: the caller then takes the array of all positions above. */
+__global__ void __launch_bounds__(256) narrowParkListKernel(const unsigned long long *__restrict__ in, unsigned long long count,
+                                                            unsigned long long first, unsigned *__restrict__ dense,
+                                                            unsigned *__restrict__ listAt, unsigned long long *__restrict__ listEntry,
+                                                            unsigned long long capacity, unsigned long long *__restrict__ parked) {
+  const unsigned lane = threadIdx.x & 63u;
+  for (unsigned long long at = (unsigned long long)blockIdx.x * 256ull; at < count; at += (unsigned long long)gridDim.x * 256ull) {
+    const unsigned long long i = at + threadIdx.x;
+    const unsigned long long v = i < count ? in[i] : 0ull;
+    const bool isParked = (v & kWalkParked) != 0ull;
+    const unsigned long long mask = __ballot(isParked);
+    if (mask == 0ull) {
+      if (i < count) dense[first + i] = (unsigned)v;
+      continue;
+    }
+    unsigned long long base = 0;
+    const unsigned leader = (unsigned)__ffsll((long long)mask) - 1u;
+    if (lane == leader) base = atomicAdd(parked, (unsigned long long)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (isParked) {
+      const unsigned long long slot = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+      if (slot < capacity) {
+        listAt[slot] = (unsigned)(first + i);
+        listEntry[slot] = (((v >> 32) & 0x3FFFFFFFull) << 32) | (v & 0xFFFFFFFFull);
+        dense[first + i] = (unsigned)slot;
+      } else {
+        dense[first + i] = kDenseUnknown;
+      }
+    } else if (i < count) {
+      dense[first + i] = (unsigned)v;
+    }
+  }
+}
+/* One round over the list.  Slot s is still open while dense[its position] == s.  Whether the position t it waits for is known
+ * is read off dense[t] alone: a value x with x < listed and listAt[x] == t is t's slot -- or, once in 2^32 or so, t's final
+ * position that happens to equal its slot number; t is then taken for open, which is harmless: its entry {d', t'} stays a true
+ * statement about SA[t] for ever, so j takes it on board and gets its answer from further along the walk (a chain ends at a
+ * position that was never parked, and those are always recognised).  The same goes for a stale dense[t] from another XCD's
+ * L2.  A finished slot whose value equals its number is computed again every round, to the same value. */
+__global__ void __launch_bounds__(256) denseSaJumpListKernel(unsigned *__restrict__ dense, const unsigned *__restrict__ listAt,
+                                                             unsigned long long *__restrict__ listEntry, unsigned long long listed,
+                                                             unsigned long long n, unsigned long long *__restrict__ left) {
+  unsigned long long mine = 0;
+  for (unsigned long long s = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; s < listed; s += (unsigned long long)gridDim.x * 256ull) {
+    const unsigned j = listAt[s];
+    if ((unsigned long long)dense[j] != s) continue;
+    const unsigned long long e = listEntry[s];
+    const unsigned t = (unsigned)e;
+    const unsigned long long d = e >> 32;
+    const unsigned at = ((volatile unsigned *)dense)[t];
+    const bool open = (unsigned long long)at < listed && listAt[at] == t;
+    if (!open) {
+      dense[j] = (unsigned)(((unsigned long long)at + d) % n);
+    } else {
+      const unsigned long long e2 = ((volatile unsigned long long *)listEntry)[at];
+      listEntry[s] = ((d + (e2 >> 32)) << 32) | (e2 & 0xFFFFFFFFull);
+      mine++;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(left, mine);
+}
 }  // namespace
 
 /* the full suffix array an index builder of this thread still holds (awfm_gpu_build.hip: 32-bit positions of the text it has
@@ -1817,10 +1882,11 @@ thread_local unsigned long long awfmGpuDenseSaStashLength = 0;
  * that long once in e^32 positions) is parked where it stands, and the parked entries are completed from each other by
  * pointer jumping (denseSaJumpKernel: log2 of the longest chain rounds).  A text with R long runs of one letter, R a
  * multiple of the ratio (a genome's runs of N), otherwise costs the construction 10^5..10^7 steps for every position
- * inside a run: 566 s instead of 0.3 for the genome-shaped 3.1 Gbp text of bench.py --text repetitive.  Without memory for
- * the parked entries (8 bytes per position while it runs) or when 64 rounds do not finish, no array is kept and the image
- * locates by walking, as the reference does.  A construction that was asked for (awfmGpuIndexSetDenseSa,
- * $AWFM_GPU_DENSE_SA=1) walks every position to the end. */
+ * inside a run: 566 s instead of 0.3 for the genome-shaped 3.1 Gbp text of bench.py --text repetitive.  The parked walks of
+ * the one pass are kept in a list (12 bytes each); only a text that parks more than a quarter of its positions (or 2^26) pays
+ * 8 bytes per position and a second pass.  Without memory for either, or when 64 rounds do not finish, no array is kept and
+ * the image locates by walking, as the reference does; a construction that was asked for (awfmGpuIndexSetDenseSa,
+ * $AWFM_GPU_DENSE_SA=1) then walks every position to its sample, however long that takes. */
 static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool capped) {
   (void)hipDeviceSynchronize();
   if (g->dDenseSa) (void)hipFree(g->dDenseSa);
@@ -1856,13 +1922,33 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
    * is then built by walking to the end, the automatic one is dropped */
   const bool explicitBuild = !capped;
   unsigned stepCap = 32u * g->dev.saRatio;
+  /* the parked walks of the first pass go into a list (narrowParkListKernel) of at most a quarter of the positions, 2^26 at
+   * most (0.8 GB; $AWFM_GPU_DENSE_SA_PARK_LIST = entries, 0 = none): a text that parks more -- one that is mostly runs -- takes
+   * the array over all positions and a second pass, as round 4 did for every text that parked anything */
+  unsigned *listAt = nullptr;
+  unsigned long long *listEntry = nullptr;
+  unsigned long long listCapacity = n / 4u + 1024u < (1ull << 26) ? n / 4u + 1024u : (1ull << 26);
+  if (const char *env = getenv("AWFM_GPU_DENSE_SA_PARK_LIST")) listCapacity = strtoull(env, nullptr, 10);
+  if (listCapacity > n) listCapacity = n;
+  if (listCapacity != 0 && (hipMalloc((void **)&listAt, listCapacity * 4) != hipSuccess ||
+                            hipMalloc((void **)&listEntry, listCapacity * 8) != hipSuccess)) {
+    (void)hipGetLastError();
+    if (listAt) (void)hipFree(listAt);
+    listAt = nullptr;
+    listEntry = nullptr;
+    listCapacity = 0;
+  }
+  bool listing = listCapacity != 0;
   auto walkAll = [&]() { /* every position walked (capped: parked walks counted, and kept where there is a `park`) */
     if (hipMemset(counter, 0, 16) != hipSuccess) rc = AwFmGeneralFailure;
     for (unsigned long long first = 0; first < n && rc == AwFmSuccess; first += chunk) {
       const unsigned long long count = n - first < chunk ? n - first : chunk;
       hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, first, count);
       rc = launchLocate(g, count, chunkBuf, (hipStream_t)0, nullptr, nullptr, stepCap);
-      if (stepCap)
+      if (stepCap && listing)
+        hipLaunchKernelGGL(narrowParkListKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const unsigned long long *)chunkBuf,
+                           count, first, dense, listAt, listEntry, listCapacity, counter);
+      else if (stepCap)
         hipLaunchKernelGGL(narrowParkKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const unsigned long long *)chunkBuf, count,
                            dense + first, park ? park + first : (unsigned long long *)nullptr, counter);
       else
@@ -1876,7 +1962,15 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
   if (jumping) {
     unsigned long long parked = 0, left = 0;
     if (hipMemcpy(&parked, counter, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
-    if (rc == AwFmSuccess && parked != 0) {
+    const bool listed = listing && parked <= listCapacity; /* every parked walk of the one pass is in the list */
+    listing = false;
+    if (!listed && listAt) { /* (make room for the array over all positions) */
+      (void)hipFree(listAt);
+      (void)hipFree(listEntry);
+      listAt = nullptr;
+      listEntry = nullptr;
+    }
+    if (rc == AwFmSuccess && parked != 0 && !listed) {
       /* (the usual text parks nothing and never pays for this: 8 bytes per position, and the walks once more to fill them) */
       if (hipMalloc((void **)&park, n * 8) != hipSuccess) { /* no room to park walks */
         (void)hipGetLastError();
@@ -1898,20 +1992,28 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
     unsigned rounds = 0;
     for (; rc == AwFmSuccess && left != 0 && rounds < 64u; rounds++) {
       if (hipMemset(counter + 1, 0, 8) != hipSuccess) rc = AwFmGeneralFailure;
-      hipLaunchKernelGGL(denseSaJumpKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, dense, park, n, counter + 1);
+      if (listed)
+        hipLaunchKernelGGL(denseSaJumpListKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, dense, (const unsigned *)listAt, listEntry,
+                           parked, n, counter + 1);
+      else
+        hipLaunchKernelGGL(denseSaJumpKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, dense, park, n, counter + 1);
       if (hipGetLastError() != hipSuccess || hipMemcpy(&left, counter + 1, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
     }
     if (getenv("AWFM_VERBOSE") && parked)
-      fprintf(stderr, "[awfm full suffix array] %llu of %llu walks parked after %u LF steps; %u rounds of pointer jumping, %llu left\n",
-              parked, n, stepCap, rounds, left);
+      fprintf(stderr, "[awfm full suffix array] %llu of %llu walks parked after %u LF steps (%s); %u rounds of pointer jumping, %llu left\n",
+              parked, n, stepCap, listed ? "in a list" : "an entry per position, walked twice", rounds, left);
     if (rc == AwFmSuccess && left != 0) { /* (64 rounds look 2^64 steps ahead: not reached by an index that is one) */
-      (void)hipFree(park);
+      if (listAt) (void)hipFree(listAt);
+      if (listEntry) (void)hipFree(listEntry);
+      if (park) (void)hipFree(park);
       (void)hipFree(chunkBuf);
       (void)hipFree(dense);
       return AwFmSuccess;
     }
   }
   if (park) (void)hipFree(park);
+  if (listAt) (void)hipFree(listAt);
+  if (listEntry) (void)hipFree(listEntry);
   (void)hipFree(chunkBuf);
   if (rc != AwFmSuccess) {
     (void)hipFree(dense);

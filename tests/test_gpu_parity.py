@@ -194,9 +194,13 @@ def test_full_suffix_array_of_a_text_with_long_runs(oracle, awfm, require_gpu, m
         return g
 
     monkeypatch.setenv("AWFM_GPU_DENSE_SA", "auto")
-    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, 6)
-    check(ix, True)  # 7/8 of the positions inside the runs parked, then completed
-    ix.dealloc()
+    for park_list in (None, "0", "1000"):  # the parked walks in a list (round 5) / an entry per position / a list that overflows
+        if park_list is not None:
+            monkeypatch.setenv("AWFM_GPU_DENSE_SA_PARK_LIST", park_list)
+        ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, 6)
+        check(ix, True)  # 7/8 of the positions inside the runs parked, then completed
+        ix.dealloc()
+    monkeypatch.delenv("AWFM_GPU_DENSE_SA_PARK_LIST")
     monkeypatch.setenv("AWFM_GPU_DENSE_SA", "0")
     ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, 6)
     check(ix, False)  # the walk at query time
