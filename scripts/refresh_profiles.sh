@@ -7,16 +7,21 @@
 TAG=${1:-r5}
 export AWFM_COMMIT=${AWFM_COMMIT:-unknown}
 if [ "${SKIP_BENCH_ALL:-0}" != "1" ]; then bash scripts/bench_all.sh "$TAG" 2>&1 | tail -45; fi
+# SETS="planted mixed" limits the rocprofv3 part to those sets (a call that ran out of time is continued, SKIP_BENCH_ALL=1).
 P="fetch write l2 sq"
-PROFILE_PASSES="fetch write l2 sq sq2 rdreq" bash scripts/profile_bench.sh default 2>&1 | grep -E "^pass|rc" | tail -8
-AWFM_GPU_LOOKUP_FIRST=0 PROFILE_PASSES="$P rdreq" bash scripts/profile_bench.sh ordered_only 2>&1 | grep -E "^pass" | tail -5
-PROFILE_PASSES="$P" bash scripts/profile_bench.sh planted --workload planted 2>&1 | grep -E "^pass" | tail -4
-AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 PROFILE_PASSES="$P" bash scripts/profile_bench.sh general_pair --mode count 2>&1 | grep -E "^pass" | tail -4
-AWFM_GPU_ORDERED=0 PROFILE_PASSES="$P" bash scripts/profile_bench.sh exact_tables --mode count 2>&1 | grep -E "^pass" | tail -4
-PROFILE_PASSES="$P" bash scripts/profile_bench.sh mixed --workload mixed 2>&1 | grep -E "^pass" | tail -4
-PROFILE_PASSES="$P" bash scripts/profile_bench.sh amino --alphabet amino 2>&1 | grep -E "^pass" | tail -4
-PROFILE_PASSES="$P" bash scripts/profile_bench.sh amino_2e9 --alphabet amino --text-len 2e9 2>&1 | grep -E "^pass" | tail -4
-PROFILE_PASSES="$P" bash scripts/profile_bench.sh repetitive_unique --text repetitive --workload unique 2>&1 | grep -E "^pass" | tail -4
-PROFILE_PASSES="$P" bash scripts/profile_bench.sh repetitive_planted --text repetitive --workload planted 2>&1 | grep -E "^pass" | tail -4
+SETS=${SETS:-default ordered_only planted general_pair exact_tables mixed amino amino_2e9 repetitive_unique repetitive_planted shards}
+want() { case " $SETS " in *" $1 "*) return 0;; esac; return 1; }
+prof() { bash scripts/profile_bench.sh "$@" 2>&1 | grep -E "^pass|rc" | tail -8; }
+want default && PROFILE_PASSES="fetch write l2 sq sq2 rdreq" prof default
+want ordered_only && AWFM_GPU_LOOKUP_FIRST=0 PROFILE_PASSES="$P rdreq" prof ordered_only
+want planted && PROFILE_PASSES="$P" prof planted --workload planted
+want general_pair && AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 PROFILE_PASSES="$P" prof general_pair --mode count
+want exact_tables && AWFM_GPU_ORDERED=0 PROFILE_PASSES="$P" prof exact_tables --mode count
+want mixed && PROFILE_PASSES="$P" prof mixed --workload mixed
+want amino && PROFILE_PASSES="$P" prof amino --alphabet amino
+want amino_2e9 && PROFILE_PASSES="$P" prof amino_2e9 --alphabet amino --text-len 2e9
+want repetitive_unique && PROFILE_PASSES="$P" prof repetitive_unique --text repetitive --workload unique
+want repetitive_planted && PROFILE_PASSES="$P" prof repetitive_planted --text repetitive --workload planted
 # the shard-sized step (what a rank of an 8-GPU strong run does): kernel-trace timelines
-bash scripts/r5_trace_shards.sh shards_"$TAG" > /dev/null 2>&1
+want shards && bash scripts/r5_trace_shards.sh shards_"$TAG" > /dev/null 2>&1
+exit 0
