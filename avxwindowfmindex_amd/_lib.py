@@ -37,7 +37,7 @@ GPU_SYMBOLS = [
     "awfmGpuSearchHitsPacked", "awfmGpuLocateTo", "awfmGpuSearchHitsLineTally", "awfmGpuIndexDeepSeedK", "awfmGpuSearchHitsCompact", "awfmGpuCompactHits", "awfmGpuSortHits",
     "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse", "awfmGpuSearchHitsInOrder",
     "awfmGpuSortHitsOnDevice", "awfmGpuHitOffsetsOnDevice", "awfmGpuLocateOnDevice", "awfmGpuLastOrderedSearchKernelMs", "awfmGpuOrderedKernelLog", "awfmGpuIndexDeepSeedBuildSeconds", "awfmGpuIndexDeepSeedTransientBytes", "awfmGpuIndexHasDenseSa", "awfmGpuIndexDenseSaBuildSeconds", "awfmGpuIndexLengthTableBytes", "awfmGpuIndexLengthTableBuildSeconds", "awfmGpuMixedLookupLineTally",
-    "awfmGpuListLocateOnDevice", "awfmGpuLastLookupFront", "awfmGpuSynthPlantedQueriesUnique", "awfmGpuStreamRetire", "awfmGpuIndexDescribe", "awfmGpuIndexDeepSeedAllocSeconds", "awfmGpuAosLastStages", "awfmHostCopyGBs",
+    "awfmGpuListLocateOnDevice", "awfmGpuLastLookupFront", "awfmGpuLastSearchWasExactLookup", "awfmGpuSynthPlantedQueriesUnique", "awfmGpuStreamRetire", "awfmGpuIndexDescribe", "awfmGpuIndexDeepSeedAllocSeconds", "awfmGpuAosLastStages", "awfmHostCopyGBs",
 ]
 # int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
 CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
@@ -174,6 +174,7 @@ def lib():
         "awfmGpuSortHitsOnDevice": (C.c_int, [vp, vp, vp, C.c_uint32, vp, u64, vp]),
         "awfmGpuListLocateOnDevice": (C.c_int, [vp, vp, vp, C.c_uint32, vp, u64, vp, vp, vp, u64, vp, vp]),
         "awfmGpuLastLookupFront": (C.c_int, [vp]),
+        "awfmGpuLastSearchWasExactLookup": (C.c_int, [vp]),
         "awfmGpuStreamRetire": (None, [vp, vp]),
         "awfmGpuIndexDescribe": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "awfmGpuIndexDeepSeedAllocSeconds": (C.c_double, [vp]),

@@ -518,6 +518,10 @@ class GpuIndex:
         """awfmGpuLastLookupFront: 0 both front ends, 1 the lookup kernel only, 2 the ordered kernels only, -1 none yet"""
         return int(_lib.lib().awfmGpuLastLookupFront(self.handle))
 
+    def last_search_was_exact_lookup(self):
+        """awfmGpuLastSearchWasExactLookup: the last awfmGpuSearch took exactLookupSearchKernel"""
+        return bool(_lib.lib().awfmGpuLastSearchWasExactLookup(self.handle))
+
     def list_locate_on_device(self, d_hit_kmers, d_hit_ranges, capacity, d_num_hits, n, d_sorted_kmers, d_sorted_ranges, d_hit_offsets,
                               capacity_hits, d_positions, stream=0):
         """awfmGpuListLocateOnDevice: the appended list -> the list in k-mer order, its hit offsets and positions, in one launch"""

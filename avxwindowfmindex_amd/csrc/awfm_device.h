@@ -871,6 +871,7 @@ struct AwFmGpuIndex {
     unsigned holdoffNext = 8;  /* what the next miss sets it to (doubles per miss up to 1024, back to 8 after 64 good predictions) */
     unsigned agreed = 0;
   } predict;
+  int lastSearchExact = 0; /* awfmGpuLastSearchWasExactLookup */
   std::mutex aosMutex;       /* serialises the AoS entry points (they share the pinned buffers) */
   void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pinnedBytes[4] = {0, 0, 0, 0};
@@ -983,7 +984,7 @@ bool awfmGpuBuildLengthTables(const AwFmGpuIndex *g, unsigned maxDepth, void **t
 /* awfm_gpu_mixed.hip: the launches of awfm_mixed_lookup_kernel.h (a translation unit of their own) */
 hipError_t awfmGpuLaunchMixedSample(const AwFmGpuIndex *g, hipStream_t s, const void *lengthTable, const uint8_t *dChars,
                                     const unsigned long long *off, unsigned long long nq, unsigned useNext, unsigned samples,
-                                    unsigned *aliveOut);
+                                    unsigned long long *aliveOut, unsigned long long *verdictHost, unsigned searchNumber);
 hipError_t awfmGpuLaunchMixedLookup(const AwFmGpuIndex *g, hipStream_t s, hipEvent_t start, hipEvent_t stop, const void *lengthTable,
                                     const uint8_t *dChars, const unsigned long long *off, unsigned long long nq, unsigned useNext,
                                     bool superInLds, const unsigned *sampleAlive, unsigned chooseOf, ulonglong2 *rng, unsigned *dCounts,

@@ -297,6 +297,13 @@ __global__ void __launch_bounds__(kListTailThreads)
   __shared__ ulonglong2 sRange[kListTailSlots];
   __shared__ unsigned long long sWave[kListTailThreads / 64], sRed[2][kListTailThreads / 64];
   __shared__ unsigned sMine;
+  /* entries with more than kHuge hits (a random k-mer that falls into a repeat family of a genome-shaped text: 10^5) are
+   * expanded by the whole workgroup, four gathers a thread in flight -- by one wave, 64 hits a trip, such an entry was a
+   * chain of 1500 memory latencies, and 0.2 ms of a 0.57-ms shard step on that text */
+  constexpr unsigned kHugeSlots = 64;
+  constexpr unsigned long long kHuge = 4096;
+  __shared__ unsigned long long sHugeOff[kHugeSlots], sHugeCount[kHugeSlots], sHugeFrom[kHugeSlots];
+  __shared__ unsigned sHugeN;
   const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const unsigned n = *count < cap ? *count : cap;
   const unsigned long long width = (numQueries + gridDim.x - 1ull) / gridDim.x;
@@ -396,6 +403,7 @@ __global__ void __launch_bounds__(kListTailThreads)
         if (lane >= (unsigned)d) incl += up;
       }
       if (lane == 63u) sWave[wave] = incl;
+      if (tid == 0) sHugeN = 0u;
       __syncthreads();
       unsigned long long before = hitBase, chunk = 0;
       for (unsigned v = 0; v < kListTailThreads / 64; v++) {
@@ -411,8 +419,19 @@ __global__ void __launch_bounds__(kListTailThreads)
       /* the hits of the entry: short lists by their own lane, long ones by the wave (as expandHitsKernel) */
       unsigned long long countHere = 0;
       if (positions && off < capacityHits) countHere = off + len <= capacityHits ? len : capacityHits - off;
-      const bool isLong = countHere > 32ull;
-      if (!isLong)
+      bool isHuge = countHere > kHuge;
+      if (isHuge) {
+        const unsigned at = atomicAdd(&sHugeN, 1u);
+        if (at < kHugeSlots) {
+          sHugeOff[at] = off;
+          sHugeCount[at] = countHere;
+          sHugeFrom[at] = range.x;
+        } else {
+          isHuge = false; /* (more than the slots hold in one trip: by its wave, below) */
+        }
+      }
+      const bool isLong = countHere > 32ull && !isHuge;
+      if (!isLong && !isHuge)
         for (unsigned long long h = 0; h < countHere; h++) positions[off + h] = DENSE ? (unsigned long long)dense[range.x + h] : range.x + h;
       unsigned long long longMask = __ballot(isLong);
       while (longMask) {
@@ -423,6 +442,20 @@ __global__ void __launch_bounds__(kListTailThreads)
       }
       hitBase += chunk;
       __syncthreads(); /* sWave is written again */
+      const unsigned huge = sHugeN < kHugeSlots ? sHugeN : kHugeSlots; /* uniform */
+      for (unsigned e = 0; e < huge; e++) {
+        const unsigned long long o = sHugeOff[e], c = sHugeCount[e], p = sHugeFrom[e];
+        unsigned long long h = tid;
+        for (; h + 3ull * kListTailThreads < c; h += 4ull * kListTailThreads) {
+          unsigned long long v[4];
+#pragma unroll
+          for (unsigned u = 0; u < 4u; u++) v[u] = DENSE ? (unsigned long long)dense[p + h + u * kListTailThreads] : p + h + u * kListTailThreads;
+#pragma unroll
+          for (unsigned u = 0; u < 4u; u++) positions[o + h + u * kListTailThreads] = v[u];
+        }
+        for (; h < c; h += kListTailThreads) positions[o + h] = DENSE ? (unsigned long long)dense[p + h] : p + h;
+      }
+      if (huge) __syncthreads(); /* the slots are written again */
     }
     rankBase += m;
   };
@@ -1249,6 +1282,7 @@ static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars,
     /* large batches on an image with its device-only tables: the exact range of every k-mer from one table entry and the
      * few steps behind it (awfm_exact_lookup_kernel.h); no scratch memory for it: the general kernel needs none */
     const int did = awfmGpuExactLookupSearch(g, s, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries, (ulonglong2 *)dRanges, dCounts);
+    g->lastSearchExact = did > 0 ? 1 : 0;
     if (did > 0) return AwFmSuccess;
     if (did < 0 && did != -(int)AwFmAllocationFailure) return (enum AwFmReturnCode)(-did);
   }

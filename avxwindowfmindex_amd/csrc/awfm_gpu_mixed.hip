@@ -14,9 +14,9 @@
 /* awfm_device.h */
 hipError_t awfmGpuLaunchMixedSample(const AwFmGpuIndex *g, hipStream_t s, const void *lengthTable, const uint8_t *dChars,
                                     const unsigned long long *off, unsigned long long nq, unsigned useNext, unsigned samples,
-                                    unsigned *aliveOut) {
+                                    unsigned long long *aliveOut, unsigned long long *verdictHost, unsigned searchNumber) {
   hipLaunchKernelGGL(mixedSampleAliveKernel, dim3((samples + 255u) / 256u), dim3(256), 0, s, g->dev, (const uint2 *)lengthTable, dChars, off, nq,
-                     useNext, samples, aliveOut);
+                     useNext, samples, aliveOut, verdictHost, searchNumber);
   return hipGetLastError();
 }
 

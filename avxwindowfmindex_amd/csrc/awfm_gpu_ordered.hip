@@ -397,6 +397,8 @@ extern "C" int awfmGpuLastLookupFront(AwFmGpuIndex *g) {
   return p.searches == 0u ? -1 : p.lastFront;
 }
 
+extern "C" int awfmGpuLastSearchWasExactLookup(AwFmGpuIndex *g) { return g ? g->lastSearchExact : 0; }
+
 extern "C" int awfmGpuSearchHitsIsOrdered(const AwFmGpuIndex *g, int hasOffsets, uint32_t fixedLength, uint64_t numQueries) {
   if (!g) return 0;
   if (g->amino) return 0;
@@ -968,8 +970,28 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   const bool mixedForced = mixedCapable && (lookupAlways || (mixedEnv && atoi(mixedEnv) == 1));
   const bool mixedWanted = mixedCapable && (mixedEnv ? atoi(mixedEnv) != 0 : nq >= (1ull << 20)) && (mixedForced || nq >= kSamples);
   const uint2 *lengthTable = mixedWanted ? ensureLengthTables(g) : nullptr;
-  const bool lookupOnly = lengthTable && mixedForced, bySample = lengthTable && !mixedForced;
+  const bool bySample = lengthTable && !mixedForced;
   if (lookupAlways && !lengthTable) return 0; /* (no tables after all: the general kernel) */
+  /* round 5, as for fixed lengths (predictFront; a mixed-length batch has length 0 in its tag): the sample is taken on the
+   * device as before and its verdict published to the host, and a batch whose predecessors' verdicts have arrived and agree
+   * launches ONE front end -- the lookup kernel, which then takes whatever the batch is (correct for any batch), or the
+   * 16-byte-record path alone */
+  AwFmGpuIndex::LookupPredict &predict = g->predict;
+  if (bySample && !predict.verdictHost) {
+    if (hipHostMalloc((void **)&predict.verdictHost, 64, hipHostMallocDefault) == hipSuccess) {
+      memset(predict.verdictHost, 0, 64);
+    } else {
+      (void)hipGetLastError();
+      predict.verdictHost = nullptr;
+    }
+  }
+  const int front = bySample ? predictFront(g, 0u, kChooseOf) : kFrontBoth;
+  const bool lookupOnly = lengthTable && (mixedForced || front == kFrontLookupOnly);
+  const bool lookupRuns = lengthTable && front != kFrontOrderedOnly;
+  /* counts only, dense, and nothing but the lookup kernel: it stores every k-mer's count itself, a round's at a time in whole
+   * lines (bit 4 of useNext) -- no pre-fill, no 4-byte stores at k-mer numbers ($AWFM_GPU_MIXED_WHOLE_COUNTS=0: as before) */
+  const char *wholeEnv = getenv("AWFM_GPU_MIXED_WHOLE_COUNTS");
+  const bool wholeCounts = lookupOnly && !sparse && dCounts && !rng && !(wholeEnv && atoi(wholeEnv) == 0);
   const size_t total = leftAt + (lengthTable ? alignUp256(nq * 8u) : 0u);
   /* in the counter block, beyond the ticket counters (which end at 65792): the leftover count, the sample's count, the
    * survivor counters (kFusedCounters words a line apart) */
@@ -995,16 +1017,26 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   QueryRec *recsIn = (QueryRec *)(w + inAt), *recsOut = (QueryRec *)(w + outAt);
   WIDE_TRY(hipMemsetAsync(w, 0, startAt, s));
   WIDE_TRY(fillSparseList(sparse, s));
-  if (!sparse) {
+  if (!sparse && !wholeCounts) {
     hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
                        rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
     WIDE_TRY(hipGetLastError());
   }
   const unsigned *sampleAlive = nullptr;
-  if (lengthTable) {
+  if (bySample) { /* the sample: always taken (the next searches' prediction), consulted on the device when both front ends run */
+    const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
+    const unsigned useNext = (g->dev.deepNext != 0u && !pairOff ? 1u : 0u) | (pairOff ? 2u : 0u);
+    unsigned *sampleWord = (unsigned *)(w + kSampleAt);
+    static_assert(kSamples == kPredictSamples, "the verdict is judged against the sample's size");
+    const unsigned number = predictTag(g, front, 0u);
+    WIDE_TRY(awfmGpuLaunchMixedSample(g, s, lengthTable, dChars, off, nq, useNext, kSamples, (unsigned long long *)sampleWord, predict.verdictHost, number));
+    if (front == kFrontBoth) sampleAlive = sampleWord;
+  }
+  if (lookupRuns) {
     const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
     unsigned useNext = (g->dev.deepNext != 0u && !pairOff ? 1u : 0u) | (pairOff ? 2u : 0u);
     if (getenv("AWFM_GPU_MIXED_DROP_SURVIVORS")) useNext |= 8u; /* MEASUREMENT ONLY (wrong results): the lookup phase alone */
+    if (wholeCounts) useNext |= 16u;
     /* the superblock bases of the pair image are read from memory: 24 KB of them in LDS (a 3.1 Gbp image) would leave room
      * for 3 workgroups per CU where the survivors' slots alone allow 6 (10^8 8..30-mers: 6.36 against 6.74 ms);
      * $AWFM_GPU_LOOKUP_PAIR_SUPER=lds|global: measurement knob */
@@ -1012,11 +1044,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
     const bool superInLds = !pairOff && superEnv && !strcmp(superEnv, "lds");
     unsigned *leftoverCount = (unsigned *)(w + kLeftCountAt), *sampleWord = (unsigned *)(w + kSampleAt), *kept = (unsigned *)(w + kKeptAt);
     unsigned long long *leftover = (unsigned long long *)(w + leftAt);
-    if (bySample) {
-      WIDE_TRY(awfmGpuLaunchMixedSample(g, s, lengthTable, dChars, off, nq, useNext, kSamples, sampleWord));
-      sampleAlive = sampleWord;
-    }
-    g->orderLookup = bySample ? 2 : 1;
+    g->orderLookup = sampleAlive ? 2 : 1;
     g->orderSampleAt = sampleWord;
     g->orderSamples = kChooseOf;
     g->orderLookupFused = true;
@@ -1035,10 +1063,12 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
                        dCounts, (unsigned long long *)nullptr, (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out,
                        (const unsigned *)nullptr, 0u);
     WIDE_TRY(hipGetLastError());
-    if (lookupOnly) { /* forced: the other front end is not launched */
+    if (lookupOnly) { /* forced or predicted: the other front end is not launched */
       WIDE_TRY(slotScope.end());
       return 1;
     }
+  } else if (bySample) { /* predicted: the 16-byte-record path alone */
+    g->orderLookup = 0;
   }
   const unsigned long long encodeTiles = (nq + 255ull) / 256ull;
   const unsigned encodeGrid = (unsigned)(encodeTiles < (unsigned long long)g->numCUs * 8u ? encodeTiles : (unsigned long long)g->numCUs * 8u);

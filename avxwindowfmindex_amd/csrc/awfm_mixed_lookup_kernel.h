@@ -114,6 +114,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
   if (!lookupChosen(sampleAlive, samples, true)) return; /* this batch is the 16-byte-record path's (uniform) */
   const bool PAIR = ix.pairBlocks != nullptr && (useNext & 2u) == 0u;
   const bool LIST = sparse.count != nullptr;
+  /* bit 4 of useNext (counts only, dense, no pre-fill: the host knows that this kernel takes the batch): a round's counts are
+   * stored once, 16 k-mers' worth of whole lines per wave instruction, when the round's survivors are done -- a survivor
+   * leaves its count in its slot -- instead of a pre-filled array and 4-byte stores at k-mer numbers */
+  const bool WHOLE = (useNext & 16u) != 0u && !LIST && !ranges && counts;
   if (threadIdx.x == 0) sWavesDone = 0u;
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   if (threadIdx.x < 17) sLevelAt[threadIdx.x] = threadIdx.x >= 1u ? awfmLengthTableAt(threadIdx.x) : 0ull;
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
         hmask[i] = __ballot(v.hitNow);
         hbefore[i] = htotal;
         htotal += (unsigned)__popcll(hmask[i]);
-      } else if (v.hitNow) {
+      } else if (v.hitNow && !WHOLE) {
         if (ranges) ranges[q] = make_ulonglong2((unsigned long long)entry[i].x, (unsigned long long)entry[i].x + v.length - 1ull);
         if (counts) counts[q] = v.length;
       }
@@ -197,6 +201,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
         sSp[w][rank] = entry[i].x;
         sEp[w][rank] = entry[i].x + v.length - 1u;
       }
+      if (WHOLE) entry[i].x = v.survives && rank < kMixedSlots ? rank : 0xFFFFFFFFu; /* (from here on: the k-mer's slot) */
       const bool left = general[i] || (v.survives && rank >= kMixedSlots);
       const unsigned long long lmask = __ballot(left);
       if (lmask != 0ull) { /* wave-uniform; rare */
@@ -268,7 +273,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
             hitFill = (unsigned)__builtin_amdgcn_readfirstlane((int)(hitFill + hits));
           }
           if (hitFill + kGroups > kHitBuffer) flushHits();
-        } else if (hit) {
+        } else if (hit && !WHOLE) {
           if (ranges) ranges[index] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
           if (counts) counts[index] = (unsigned)(ep - sp + (pos_t)1);
         }
@@ -296,6 +301,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
         const bool gone = live && (sp > ep || pos < stepChars - 1);
         const bool park = gone && sp <= ep && pos == 0; /* PAIR only */
         report(gone && gl == 0 && sp <= ep && pos < 0);
+        if (WHOLE && gone && !park && gl == 0) sLeft[w][mySlot] = sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u; /* (pos < 0 when sp <= ep) */
         const unsigned long long parkMask = __ballot(park && gl == 0);
         if (parkMask != 0ull) { /* wave-uniform */
           if (park && gl == 0) {
@@ -332,9 +338,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
             nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
           }
           report(parked && gl == 0 && sp <= ep);
+          if (WHOLE && parked && gl == 0) sLeft[w][mySlot] = sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u;
         }
       }
       __builtin_amdgcn_wave_barrier(); /* the slots are written again by the next round */
+    }
+    if (WHOLE) { /* uniform */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (unsigned i = 0; i < 4u; i++) {
+        const unsigned long long q = tw + 64ull * i + lane;
+        const unsigned c = entry[i].x != 0xFFFFFFFFu ? sLeft[w][entry[i].x] : entry[i].y;
+        if (q < numQueries) counts[q] = c; /* (k-mers left to the general kernel: 0 until it stores what it finds) */
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   if (lane == 0 && keptHere) atomicAdd(&keptCounters[((blockIdx.x * 4u + w) % kFusedCounters) * 16u], keptHere);
@@ -371,7 +390,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
 __global__ void __launch_bounds__(256)
     mixedSampleAliveKernel(const DevIndex ix, const uint2 *__restrict__ lengthTable, const unsigned char *__restrict__ chars,
                            const unsigned long long *__restrict__ offsets, const unsigned long long numQueries, const unsigned useNext,
-                           const unsigned samples, unsigned *__restrict__ aliveOut) {
+                           const unsigned samples, unsigned long long *__restrict__ aliveOut /* zeroed; the low half is the count */,
+                           unsigned long long *__restrict__ verdictHost, const unsigned searchNumber) {
   __shared__ unsigned long long sLevelAt[17];
   __shared__ unsigned sAlive;
   if (threadIdx.x < 17) sLevelAt[threadIdx.x] = threadIdx.x >= 1u ? awfmLengthTableAt(threadIdx.x) : 0ull;
@@ -394,7 +414,11 @@ __global__ void __launch_bounds__(256)
   const unsigned n = (unsigned)__popcll(__ballot(alive));
   if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&sAlive, n);
   __syncthreads();
-  if (threadIdx.x == 0 && sAlive) atomicAdd(aliveOut, sAlive);
+  if (threadIdx.x == 0) { /* {1, count} in one atomic: the workgroup that sees all the others in publishes the verdict (lookupPrepKernel) */
+    const unsigned long long old = atomicAdd(aliveOut, (1ull << 32) | (unsigned long long)sAlive);
+    if ((unsigned)(old >> 32) == gridDim.x - 1u && verdictHost)
+      *(volatile unsigned long long *)verdictHost = ((unsigned long long)searchNumber << 32) | (unsigned long long)((unsigned)old + sAlive);
+  }
 }
 
 /* ---- what mixedLookupSearchKernel has to read (awfmGpuMixedLookupLineTally) ----

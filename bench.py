@@ -1068,6 +1068,8 @@ def main():
     kernel_log = g.ordered_kernel_log() if ordered else []
     assert not ordered or len(kernel_log) == min(args.steps, 1024), "the library logged another number of searches than were timed"
     lookup_first = bool(ordered and g.last_ordered_kernel_is_lookup())  # the dominant kernel of every step was encodeLookupKernel
+    # (no seed-order path: the hits-only search is awfmGpuSearch, which takes large batches through exactLookupSearchKernel)
+    exact_looked_up = bool(not ordered and g.last_search_was_exact_lookup())
     # which front end(s) the last timed step launched: 0 both (the sample's verdict stays on the device), 1 the lookup kernel
     # only / 2 the ordered kernels only (the verdict of an earlier step had reached the host: awfmGpuLastLookupFront), -1: no sample
     lookup_front = g.last_lookup_front()
@@ -1345,7 +1347,8 @@ def main():
         roofline = {
             "bound": "hbm", "kernel": ("aminoLookupSearchKernel" if amino_looked_up else
                                        "mixedLookupSearchKernel (priced by the general kernel's reads of the same batch: an upper bound)"
-                                       if small_mixed_lookup else "searchKernel") + f" (device-only table of depth {had_deep})",
+                                       if small_mixed_lookup else
+                                       "exactLookupSearchKernel" if exact_looked_up else "searchKernel") + f" (device-only table of depth {had_deep})",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
             "kernel_ms": round(search_ms, 3), "basis": "executed_reads_lower_bound" if amino_looked_up else "executed_reads",

@@ -268,6 +268,10 @@ int awfmGpuLastOrderedKernelIsLookup(AwFmGpuIndex *g);
  * always both).  Either front end alone searches any batch correctly; a verdict that contradicts the mode its own search
  * ran in switches the prediction off for the next 8, 16, ... searches. */
 int awfmGpuLastLookupFront(AwFmGpuIndex *g);
+/* Whether the last awfmGpuSearch on the image (also the one behind a hits-only search that the seed-order path did not take)
+ * went through exactLookupSearchKernel -- the exact ranges from one table entry per k-mer -- (1) or the general kernel (0);
+ * reporting only */
+int awfmGpuLastSearchWasExactLookup(AwFmGpuIndex *g);
 /* with $AWFM_GPU_TIME_ORDERED: orderedSearchKernel's own bracket of the last search, whichever kernel was the dominant one
  * (after encodeLookupKernel it searched only the k-mers that kernel kept); < 0: none */
 double awfmGpuLastOrderedSearchKernelMs(AwFmGpuIndex *g);

@@ -126,10 +126,10 @@ if ordered:
                   "misses of the stores.",
     }, open(os.path.join(dst, f"traffic_{name}.json"), "w"), indent=1)
     print("ordered search call: HBM GB", hbm / 1e9, {k.split("<")[0]: round((v["read_bytes"] + v["write_bytes"]) / 1e9, 2) for k, v in per_kernel.items()})
-search = [k for k in summary if k.startswith(("searchKernel", "aminoLookupSearchKernel")) and "FETCH_SIZE" in summary[k]]
+search = [k for k in summary if k.startswith(("searchKernel", "aminoLookupSearchKernel", "exactLookupSearchKernel")) and "FETCH_SIZE" in summary[k]]
 # large fixed-length amino batches: the timed steps run aminoLookupSearchKernel (the general kernel beside it is the
 # reference-algorithm measurement of bench.py, or returns at once)
-search.sort(key=lambda x: ((0 if (kernel_avg_ns(x) or 0) > 1e5 else 2) if x.startswith("aminoLookupSearchKernel") else 1,
+search.sort(key=lambda x: ((0 if (kernel_avg_ns(x) or 0) > 1e5 else 2) if x.startswith(("aminoLookupSearchKernel", "exactLookupSearchKernel")) else 1,
                            -summary[x]["FETCH_SIZE"]["dispatches"]))
 if search and not ordered:
     k = search[0]
@@ -184,8 +184,16 @@ if dominant:
         if ms is None or not kernel or not str(dominant).startswith(str(kernel).split(" ")[0].split("<")[0]):
             continue  # (the line's roofline is another kernel's: nothing to compare)
         out.setdefault("bench_kernel_ms", {})[label] = ms
-        if abs(ns / 1e6 - ms) > 0.05 * ms:
+        # the profiled run's own line is the same launches measured twice (the library's events, the tracer): 5 % or the set
+        # averages something else.  The un-profiled line is ANOTHER process: the same kernel on the same box differs by up to
+        # 7 % between processes (the exact-range general kernel: 12.2 ms under rocprofv3, 13.1-14.2 without -- DESIGN.md 5),
+        # so between 5 and 10 % the set is kept and says so; beyond 10 % it is refused as well
+        off = abs(ns / 1e6 - ms) / ms
+        if off > (0.05 if label.startswith("the profiled") else 0.10):
             refused.append(f"{label}: kernel_ms {ms:.3f} against {ns / 1e6:.3f} ms in the kernel trace")
+        elif off > 0.05:
+            out["differs_from_the_unprofiled_line"] = {"kernel_ms_unprofiled": ms, "kernel_ms_kernel_trace": round(ns / 1e6, 3), "relative": round(off, 3)}
+            print(f"WARNING counters_{name}: {label}: kernel_ms {ms:.3f} against {ns / 1e6:.3f} ms in the kernel trace (kept, flagged)", file=sys.stderr)
     if refused:
         print(f"REFUSED counters_{name}: " + "; ".join(refused), file=sys.stderr)
         sys.exit(3)

@@ -955,17 +955,22 @@ def test_list_sorted_scanned_and_located_without_a_host_wait(oracle, awfm, requi
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dense_sa", [False, True])
-@pytest.mark.parametrize("shape", ["sparse", "half", "clustered"])
+@pytest.mark.parametrize("shape", ["sparse", "half", "clustered", "repeats"])
 def test_list_tail_in_one_launch(oracle, awfm, require_gpu, shape, dense_sa):
     """awfmGpuSearchHitsCompact -> awfmGpuListLocateOnDevice: the appended list comes out in k-mer order with its hit offsets
     and positions from ONE kernel (each workgroup finds its own prefix: no scan, no scratch), with and without the full suffix
     array, equal to the oracle's and to what the three calls it replaces leave; `clustered`: a stretch of 12 000 consecutive
     k-mers that all occur, i.e. more entries in one workgroup's range than its LDS slots hold (sub-ranges); a position buffer
-    that is too small gets the first `capacity` hits and nothing behind them; offsets only when there is no buffer."""
+    that is too small gets the first `capacity` hits and nothing behind them; offsets only when there is no buffer.  `repeats`:
+    k-mers out of a tandem repeat with 5 * 10^3 hits each (expanded by the whole workgroup) and out of a 40-copy repeat (by a
+    wave) among k-mers with a hit or two (by their lane)."""
     import torch
     n, K = 300000, 15
     Q = 90011 if shape != "clustered" else 3_000_017
     txt = synth.text(n + 3, n, synth.DNA_ALPHABET).copy()
+    if shape == "repeats":
+        txt[100000:110000] = np.frombuffer(b"ac" * 5000, np.uint8)
+        txt[20000:22000] = np.tile(txt[20000:20050], 40)
     ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
     oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
     g = awfm.GpuIndex(ix)
@@ -978,9 +983,13 @@ def test_list_tail_in_one_launch(oracle, awfm, require_gpu, shape, dense_sa):
         q[1_000_000:1_012_000] = synth.planted_queries(22, 12000, K, txt)
         q[Q - 300:] = synth.planted_queries(23, 300, K, txt)  # ... and the very last k-mers of the batch
     else:
-        m = int(Q * (0.02 if shape == "sparse" else 0.6))
+        m = int(Q * (0.02 if shape in ("sparse", "repeats") else 0.6))
         q = np.concatenate([synth.random_queries(21, Q - m, K), synth.planted_queries(22, m, K, txt)])
         q = q[np.random.default_rng(5).permutation(Q)]
+        if shape == "repeats":
+            q[7::9001] = np.frombuffer((b"ac" * 8)[:K], np.uint8)
+            q[4000::20011] = np.frombuffer((b"ca" * 8)[:K], np.uint8)
+            q[11::1501] = txt[20010:20010 + K]
     chars, offsets = synth.fixed_csr(q)
     sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
     has = np.flatnonzero(cnt > 0)
@@ -1603,6 +1612,7 @@ def test_mixed_length_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, aw
     no other front end to choose, the lookup kernel takes both batches."""
     import torch
     monkeypatch.delenv("AWFM_GPU_MIXED_LOOKUP", raising=False)
+    monkeypatch.setenv("AWFM_GPU_LOOKUP_PREDICT", "0")  # every search by its own sample (the prediction: the next test)
     n, Q = 300000, (1 << 20) + 77
     txt = synth.text(n + 43, n, synth.DNA_ALPHABET).copy()
     ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
@@ -1641,6 +1651,86 @@ def test_mixed_length_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, aw
             torch.cuda.synchronize()
             assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt), "general kernel"
             monkeypatch.delenv("AWFM_GPU_MIXED_LOOKUP")
+    g.destroy()
+    ix.dealloc()
+
+
+def test_mixed_length_lookup_prediction_and_whole_line_counts(oracle, awfm, require_gpu, monkeypatch):
+    """Round 5, mixed-length batches: the sample's verdict goes to page-locked host memory as for fixed lengths, and a batch
+    whose predecessors agree launches one front end (awfmGpuLastLookupFront: 1 = mixedLookupSearchKernel alone, which then
+    takes whatever the batch is; 2 = the 16-byte-record path alone).  With the lookup kernel alone a counts-only search is not
+    pre-filled: the kernel stores every k-mer's count itself, a round's at a time in whole lines, survivors' counts out of
+    their slots (and $AWFM_GPU_MIXED_WHOLE_COUNTS=0: pre-filled, 4-byte stores as before).  Counts and list against the oracle
+    whatever was predicted, the batch the prediction is wrong for included."""
+    import torch
+    for name in ("AWFM_GPU_MIXED_LOOKUP", "AWFM_GPU_LOOKUP_PREDICT", "AWFM_GPU_MIXED_WHOLE_COUNTS"):
+        monkeypatch.delenv(name, raising=False)
+    n, Q = 300000, (1 << 20) + 77
+    txt = synth.text(n + 47, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(12)
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(6)
+    lengths = rng.integers(14, 33, Q)  # (longer than the deeper table: drawn from the text they survive their entry)
+    lengths[::7] = rng.integers(0, 36, len(lengths[::7]))  # ... and none, 1..32, too long for the tables
+    offsets = np.zeros(Q + 1, np.uint64)
+    np.cumsum(lengths, out=offsets[1:])
+    total = int(offsets[-1])
+    starts = rng.integers(0, n - 40, Q)
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    batches = {}
+    for name in ("random", "planted"):
+        if name == "random":
+            chars = np.frombuffer(synth.DNA_ALPHABET, np.uint8)[rng.integers(0, 4, total)].copy()
+        else:
+            idx = np.repeat(starts, lengths) + (np.arange(total) - np.repeat(offsets[:-1].astype(np.int64), lengths))
+            chars = txt[idx].copy()
+        chars[::5000] = ord("n")  # some for the general kernel
+        sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+        batches[name] = (torch.from_numpy(np.concatenate([chars, np.zeros(8, np.uint8)])).to(dev), sp, ep, cnt)
+    d_counts = torch.empty(Q, dtype=torch.int32, device=dev)
+    d_kmers = torch.zeros(Q, dtype=torch.int32, device=dev)
+    d_ranges = torch.zeros(Q * 2, dtype=torch.int64, device=dev)
+    d_num = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(name, listed):
+        d_chars, sp, ep, cnt = batches[name]
+        if listed:
+            g.search_hits_compact(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), Q, d_num.data_ptr())
+            torch.cuda.synchronize()
+            m = int(d_num.item())
+            has = np.flatnonzero(cnt > 0)
+            assert m == len(has), (name, m, len(has))
+            ids = d_kmers[:m].cpu().numpy().view(np.uint32)
+            order = np.argsort(ids)
+            r = d_ranges[: 2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)[order]
+            assert np.array_equal(ids[order], has) and np.array_equal(r[:, 0], sp[has]) and np.array_equal(r[:, 1], ep[has]), name
+        else:
+            d_counts.fill_(7)
+            g.search_hits(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, 0, d_counts.data_ptr())
+            torch.cuda.synchronize()
+            got = d_counts.cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, cnt), (name, int(np.flatnonzero(got != cnt)[0]))
+        return g.last_lookup_front()
+
+    fronts = [run("random", False), run("random", True), run("random", False), run("random", True)]
+    assert fronts[0] == 0 and fronts[2:] == [1, 1], fronts
+    monkeypatch.setenv("AWFM_GPU_MIXED_WHOLE_COUNTS", "0")
+    assert run("random", False) == 1
+    monkeypatch.delenv("AWFM_GPU_MIXED_WHOLE_COUNTS")
+    assert run("planted", False) == 1  # predicted from the random batches: the lookup kernel takes the planted one, whole-line counts
+    held = [run("planted", i % 2 == 1) for i in range(9)]
+    assert held[:8] == [0] * 8, held  # the miss switched the prediction off for eight searches
+    later = [run("planted", i % 2 == 0) for i in range(3)]
+    assert later[-1] == 2, (held, later)  # ... and then the 16-byte-record path alone
+    assert not g.last_ordered_kernel_is_lookup()
+    assert run("random", True) == 2  # (wrong the other way round: slower, the same list)
+    assert run("random", False) == 0
+    monkeypatch.setenv("AWFM_GPU_LOOKUP_PREDICT", "0")
+    assert [run("random", False), run("random", True)] == [0, 0]
     g.destroy()
     ix.dealloc()
 
