@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
   extern __shared__ unsigned sPairSuper[];
   __shared__ unsigned long long sLevelAt[17];
   __shared__ unsigned long long sRem[4][kMixedSlots];
-  __shared__ unsigned sNum[4][kMixedSlots], sSp[4][kMixedSlots], sEp[4][kMixedSlots];
+  __shared__ unsigned sSp[4][kMixedSlots], sEp[4][kMixedSlots];
   __shared__ unsigned char sLeft[4][kMixedSlots], sOdd[4][kMixedSlots];
   const bool PAIR = ix.pairBlocks != nullptr && pairOff == 0u;
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
@@ -101,17 +101,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
       }
       const bool looked = len[i] != 0u;
       const bool survives = looked && len[i] > DK && length != 0u;
-      if (looked && !survives) store(q, entry[i].x, entry[i].x + length - 1u); /* the entry is the k-mer's final range */
+      /* (a k-mer that ends at its entry: the entry is its final range.  Nothing is stored yet: a round's results go out
+       * together, in whole lines, when its survivors are done -- the 10^8 k-mers of a batch stored one by one as they
+       * finished were 2.7 x their bytes in partial-line writes) */
       const unsigned long long smask = __ballot(survives);
       const unsigned rank = stotal + (unsigned)__popcll(smask & ((1ull << lane) - 1ull));
       stotal += (unsigned)__popcll(smask);
       if (survives) { /* (a slot for every k-mer of the round) */
         sRem[w][rank] = codes[i] >> (2u * DK);
         sLeft[w][rank] = (unsigned char)(len[i] - DK);
-        sNum[w][rank] = (unsigned)q;
         sSp[w][rank] = entry[i].x;
         sEp[w][rank] = entry[i].x + length - 1u;
       }
+      /* from here on: {sp, length} of a k-mer that ended at its entry ({1, 0}: not looked up -- not in the batch, or the general
+       * kernel's, which stores its own range later), {slot, ~0} of a survivor */
+      entry[i] = survives ? make_uint2(rank, 0xFFFFFFFFu) : looked ? make_uint2(entry[i].x, length) : make_uint2(1u, 0u);
       const unsigned long long lmask = __ballot(general[i]);
       if (lmask != 0ull) { /* wave-uniform; rare */
         unsigned base = 0;
@@ -132,11 +136,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
       bool live = mySlot < stotal;
       pos_t sp = 1, ep = 0;
       unsigned long long rem = 0;
-      unsigned index = 0;
       int pos = -1;
       auto take = [&]() {
         rem = sRem[w][mySlot];
-        index = sNum[w][mySlot];
         sp = sSp[w][mySlot];
         ep = sEp[w][mySlot];
         pos = (int)sLeft[w][mySlot] - 1;
@@ -163,12 +165,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
          * pair steps cannot take (taken through the one-letter image after the loop: a wave iteration issues one kind of read) */
         const bool gone = live && (sp > ep || pos < stepChars - 1);
         const bool park = gone && sp <= ep && pos == 0; /* PAIR only */
-        if (gone && !park && gl == 0) store(index, sp, ep);
+        if (gone && gl == 0) { /* its final range, or where it is parked: back into its slot */
+          sSp[w][mySlot] = sp;
+          sEp[w][mySlot] = ep;
+        }
         const unsigned long long parkMask = __ballot(park && gl == 0);
         if (parkMask != 0ull) { /* wave-uniform */
           if (park && gl == 0) {
-            sSp[w][mySlot] = sp;
-            sEp[w][mySlot] = ep;
             sRem[w][mySlot] = rem;
             sOdd[w][oddCount + (unsigned)__popcll(parkMask & ((1ull << lane) - 1ull))] = (unsigned char)mySlot;
           }
@@ -198,12 +201,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
             mySlot = sOdd[w][k];
             take();
             nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
-            if (gl == 0) store(index, sp, ep);
+            if (gl == 0) {
+              sSp[w][mySlot] = sp;
+              sEp[w][mySlot] = ep;
+            }
           }
         }
       }
-      __builtin_amdgcn_wave_barrier(); /* the slots are written again by the next round */
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+#pragma unroll
+    for (unsigned i = 0; i < 4u; i++) { /* the round's results: 64 consecutive k-mers per wave instruction */
+      const unsigned long long q = tw + 64ull * i + lane;
+      const bool slot = entry[i].y == 0xFFFFFFFFu;
+      const pos_t sp = slot ? sSp[w][entry[i].x] : entry[i].x;
+      const pos_t ep = slot ? sEp[w][entry[i].x] : entry[i].x + entry[i].y - 1u;
+      if (q < numQueries) store(q, sp, ep);
+    }
+    __builtin_amdgcn_wave_barrier(); /* the slots are written again by the next round */
   }
 }
 
