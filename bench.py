@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_GATHER_PEAK_GBS = 17800.0  # MI355X_MICROARCH.md "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCDs' L2s
 RANK_BYTES_DNA, RANK_BYTES_AMINO = 104, 168  # planes + one count of the reference block
-PROFILE_ROUND = "r4"
+PROFILE_ROUND = "r5"
 T_START = time.time()
 WINDOW_HITS = 1 << 28  # hits located per window when a batch's hit list is not kept resident (--workload mixed --mode locate)
 
@@ -461,6 +461,14 @@ def amino_leg(L, api, digest, torch, np, dev, n, Q=50_000_000, K=10, seed_k=5, s
                                            "frac": round(alg_bytes / (plain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": 3}
         roofline["reference_algorithm_frac"] = roofline["reference_algorithm"]["frac"]
         del d_counts
+        # measured HBM bytes of the same kernel on the same batch: rocprofv3 PMC passes of `--alphabet amino [--text-len 2e9]`
+        pname = {200_000_000: "amino", 2_000_000_000: "amino_2e9"}.get(n) if (Q, K, seed_k, sa_ratio) == (50_000_000, 10, 5, 8) else None
+        traffic, tsrc = profile_file("traffic", pname) if pname and looked_up and not any(
+            k.startswith("AWFM_GPU_") and k not in ("AWFM_GPU_TIME_ORDERED", "AWFM_GPU_DEVICE") for k in os.environ) else (None, None)
+        if traffic and str(traffic.get("kernel", "")).startswith("aminoLookupSearchKernel"):
+            roofline["traffic"] = traffic["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = f"{tsrc}: rocprofv3 PMC passes of `bench.py --alphabet amino` on another run of the same code, not measured by this run"
+            roofline["hbm_frac_measured"] = round(roofline["traffic"] / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     else:
         roofline.update(kernel="searchKernel", achieved=round(alg_bytes / (search_ms * 1e-3) / 1e9, 1),
                         frac=round(alg_bytes / (search_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
@@ -1153,6 +1161,9 @@ def main():
     if (args.device_seed_k < 0 and args.device_dense_sa is None and not amino and n == 3_100_000_000 and Q == 100_000_000
             and args.workload == "mixed" and args.seed_k == 12 and args.sa_ratio == 8 and args.mode == "count" and args.text == "uniform"):
         prof_name = "mixed"
+    if (args.device_seed_k < 0 and args.device_dense_sa is None and not amino and n == 3_100_000_000 and Q == 100_000_000
+            and K == 21 and args.seed_k == 12 and args.sa_ratio == 8 and args.text == "repetitive"):
+        prof_name = {("unique", "locate"): "repetitive_unique", ("planted", "count"): "repetitive_planted"}.get((args.workload, args.mode))
     if any(k.startswith("AWFM_GPU_") and k not in ("AWFM_GPU_TIME_ORDERED", "AWFM_GPU_DEVICE") for k in os.environ):
         prof_name = None  # a measurement knob is set: the profiled run was of the default code path
     not_this_run = "rocprofv3 PMC passes of this command line on another run of the same code (scripts/profile_bench.sh), not measured by this run"
