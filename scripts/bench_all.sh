@@ -16,6 +16,8 @@ run planted -- --workload planted
 run planted_dense_results AWFM_BENCH_DENSE_RESULTS=1 -- --workload planted --no-cpu --no-e2e
 run mixed -- --workload mixed
 run mixed_no_lookup AWFM_GPU_MIXED_LOOKUP=0 -- --workload mixed --no-cpu --no-e2e --general-steps 0
+run mixed_round4_stores AWFM_GPU_MIXED_WHOLE_COUNTS=0 -- --workload mixed --no-cpu --no-e2e --general-steps 0
+run mixed_no_prediction AWFM_GPU_LOOKUP_PREDICT=0 -- --workload mixed --no-cpu --no-e2e --general-steps 0
 run mixed_short -- --workload mixed --mixed-lengths 8 15 --no-cpu --no-e2e --general-steps 0 --no-shard-proxy
 run mixed_long -- --workload mixed --mixed-lengths 18 30 --no-cpu --no-e2e --general-steps 0 --no-shard-proxy
 run mixed_locate -- --workload mixed --mode locate --no-e2e --steps 2 --warmup 1
