@@ -1919,6 +1919,7 @@ def main():
         e8 = proxy["shards"]["batch"]["8"]
         config["scaling_proxy_8_efficiency"] = e8["efficiency"]
         config["scaling_proxy_8_ms"] = e8["ms_max"]
+    config["bench_wall_s"] = round(time.time() - T_START, 1)  # this process from its first line to its JSON line (imports, index, every leg)
     out = {
         "metric": "Mkmers/sec located, GRCh38 nucleotide index" if not amino else "Mkmers/sec located, amino index",
         "value": round(value, 2), "unit": "Mkmers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
