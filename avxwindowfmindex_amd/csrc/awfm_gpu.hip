@@ -318,7 +318,8 @@ __global__ void __launch_bounds__(kListTailThreads)
    * length is read and ignored): the pass is a chain of memory latencies, 2 us each -- one entry a trip took 13 us over the
    * 9 * 10^3 entries of a shard's list and would take 100 over the 7 * 10^4 of the whole batch's.  (Measured and dropped: one
    * slot reservation per wave -- a shuffle scan of the threads' counts and a second pass over the keys -- instead of an LDS
-   * atomic per own entry: 20-21 us against 17 for a shard's list; 128 / 64 / 32 workgroups instead of 256: 21 / 23 / 27 us.) */
+   * atomic per own entry: 20-21 us against 17 for a shard's list; and with it 128 / 64 / 32 workgroups instead of 256: 21 / 23 /
+   * 27 us -- fewer workgroups re-read less of the list and are no faster.) */
   unsigned long long below = 0, belowHits = 0;
   constexpr unsigned kPer = 8, kGroups = 2;
   const bool vec = ((unsigned long long)inKmers & 15ull) == 0ull;
