@@ -102,8 +102,20 @@ while time.time() < t_end:
             os.environ["AWFM_GPU_MIXED_LOOKUP"] = mixed
         else:
             os.environ.pop("AWFM_GPU_MIXED_LOOKUP", None)
+        # lookup prediction (one front end launched when earlier verdicts agree) on or off
+        if rng.random() < 0.3:
+            os.environ["AWFM_GPU_LOOKUP_PREDICT"] = "0"
+        else:
+            os.environ.pop("AWFM_GPU_LOOKUP_PREDICT", None)
         g.search_hits(chars_ptr, off_ptr, K, Q, hits.data_ptr(), counts.data_ptr())
         torch.cuda.synchronize()
+        # counts only: the mixed-length lookup kernel then stores a round's counts together, without a pre-fill
+        counts_only = torch.full((Q,), 9, dtype=torch.int32, device=dev)
+        g.search_hits(chars_ptr, off_ptr, K, Q, 0, counts_only.data_ptr())
+        torch.cuda.synchronize()
+        if not torch.equal(counts_only, counts):
+            print(f"COUNTS-ONLY MISMATCH n={n} k={seed_k} deep={deep_k} Q={Q} {desc} lookup_first={lookup!r} mixed_lookup={mixed!r}", flush=True)
+            sys.exit(1)
         listed_ok = True
         if g.search_hits_is_ordered(off_ptr != 0, K, Q) and not fuzz_wide:
             # the list form of the same search, put in k-mer order, sized and located with nothing read back by the host
@@ -118,6 +130,34 @@ while time.time() < t_end:
             want = torch.nonzero(counts).flatten()
             listed_ok = (m == want.numel() and torch.equal(lk[:m].to(torch.int64), want)
                          and torch.equal(lr.view(cap, 2)[:m], hits.view(Q, 2)[want]))
+            lengths = torch.where(lr.view(cap, 2)[:m, 0] <= lr.view(cap, 2)[:m, 1], lr.view(cap, 2)[:m, 1] - lr.view(cap, 2)[:m, 0] + 1,
+                                  torch.zeros(m, dtype=torch.int64, device=dev))
+            total_hits = int(lengths.sum().item())
+            if listed_ok and m > 0 and ix.bwt_length < (1 << 32) and total_hits < 30_000_000:
+                # the list's tail in one launch (lists beyond 2^18 entries: the three calls it replaces) against the list sorted
+                # above, its offsets summed here and the positions of the general locate
+                dense_tail = rng.random() < 0.5
+                if dense_tail:
+                    g.set_dense_sa(True)
+                lk2 = torch.zeros(cap, dtype=torch.int32, device=dev)
+                lr2 = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+                g.search_hits_compact(chars_ptr, off_ptr, K, Q, lk2.data_ptr(), lr2.data_ptr(), cap, ln.data_ptr())
+                sk = torch.zeros(cap, dtype=torch.int32, device=dev)
+                sr = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
+                so = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
+                sp_ = torch.full((total_hits + 8,), -1, dtype=torch.int64, device=dev)
+                g.list_locate_on_device(lk2.data_ptr(), lr2.data_ptr(), cap, ln.data_ptr(), Q, sk.data_ptr(), sr.data_ptr(), so.data_ptr(),
+                                        total_hits, sp_.data_ptr())
+                torch.cuda.synchronize()
+                want_off = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+                torch.cumsum(lengths, 0, out=want_off[1:])
+                ref_pos = torch.zeros(max(total_hits, 1), dtype=torch.int64, device=dev)
+                if dense_tail:
+                    g.set_dense_sa(False)
+                g.locate(lr.data_ptr(), want_off.data_ptr(), m, total_hits, ref_pos.data_ptr())
+                torch.cuda.synchronize()
+                listed_ok = (torch.equal(sk[:m], lk[:m]) and torch.equal(sr[: 2 * m], lr[: 2 * m]) and torch.equal(so[: m + 1], want_off)
+                             and torch.equal(sp_[:total_hits], ref_pos[:total_hits]) and bool((sp_[total_hits:] == -1).all()))
         g.set_wide(False)
         a, b = exact.view(Q, 2), hits.view(Q, 2)
         has = a[:, 0] <= a[:, 1]
