@@ -115,7 +115,10 @@ double awfmGpuIndexDenseSaBuildSeconds(const AwFmGpuIndex *g); /* reporting: wal
  * reference reaches for a k-mer of exactly d characters (ref src/AwFmSearch.c:485-520 below the seed table's length,
  * src/AwFmKmerTable.c:4-51 at it, src/AwFmParallelSearch.c:273-313 above it) -- (4^D - 4) / 3 entries, 11.5 GB for D = 16.
  * Built on the device by the first mixed-length batch (CSR offsets) that takes the lookup-first kernel
- * ($AWFM_GPU_MIXED_LOOKUP=0: never), kept with the image; bytes / wall seconds of that construction (0: none yet). */
+ * ($AWFM_GPU_MIXED_LOOKUP=0: never), kept with the image; bytes / wall seconds of that construction (0: none yet).
+ * THAT ONE CALL IS NOT ASYNCHRONOUS: the tables are built on the null stream and the call waits for the device (0.02 s for
+ * D = 16) before it launches its search on the caller's stream; they are built only when three times their size is free on
+ * the device, and a construction that found no room is tried again 64 mixed-length searches later. */
 uint64_t awfmGpuIndexLengthTableBytes(const AwFmGpuIndex *g);
 double awfmGpuIndexLengthTableBuildSeconds(const AwFmGpuIndex *g);
 /* Nucleotide images carry, beside the one-letter blocks, a pair image: for every BWT position the pair of its two
