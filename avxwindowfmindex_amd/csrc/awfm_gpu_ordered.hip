@@ -835,10 +835,28 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
       }
       /* (lookup only: what the kernel does not search itself goes to the END of the record array, 8 bytes a k-mer number,
        * counted in the general kernel's word -- no code words, no numbers, no histogram) */
-      launchLookupSearchAt<32u>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt, useNext | (pairOff ? 2u : 0u) | (lookupOnly ? 4u : 0u), nq,
+      /* $AWFM_GPU_LOOKUP_TIMELINE=<file> (diagnostic, waits for the device): every wave's start and end on the device's clock,
+       * where it ran and how many trips it made -- scripts/lookup_timeline.py reads the file */
+      const char *timelinePath = getenv("AWFM_GPU_LOOKUP_TIMELINE");
+      unsigned long long *timeline = nullptr;
+      if (timelinePath && hipMalloc((void **)&timeline, (size_t)fusedGrid * 128u) == hipSuccess) {
+        (void)hipMemsetAsync(timeline, 0, (size_t)fusedGrid * 128u, s);
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(gLookupTimeline), &timeline, sizeof(timeline), 0, hipMemcpyHostToDevice, s);
+      }
+      launchLookupSearchAt<32u>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt,
+                                useNext | (pairOff ? 2u : 0u) | (lookupOnly ? 4u : 0u) | (timeline ? 32u : 0u), nq,
                                 (unsigned long long *)(w + codesAt), lookupOnly ? (unsigned *)recs : numbers, lookupOnly ? generalCount : shareCount,
                                 hist, binsPad, sampleAlive, kSamples, rng, dCounts, sparse ? *sparse : SparseOut(),
                                 (unsigned *)(w + kKeptAt), timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr);
+      if (timeline) {
+        std::vector<unsigned long long> host((size_t)fusedGrid * 16u);
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(host.data(), timeline, host.size() * 8u, hipMemcpyDeviceToHost) == hipSuccess)
+          if (FILE *out = fopen(timelinePath, "wb")) {
+            fwrite(host.data(), 8u, host.size(), out);
+            fclose(out);
+          }
+        (void)hipFree(timeline);
+      }
     } else {
       launchEncodeLookupAt<32u>(fixedLength, encodeGrid, bins * 4u, s, g->dev, dChars, fmt, useNext, nq, (unsigned long long *)(w + codesAt), numbers,
                                 shareCount, hist, binsPad, sampleAlive, kSamples, timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr);
