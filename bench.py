@@ -647,9 +647,10 @@ def main():
         args.mode = "count" if args.workload == "mixed" else "locate"
     if args.text == "repetitive" and args.workload == "planted":
         args.mode = "count"  # a 21-mer out of a 300-character family with 10^6 copies has ~10^5 hits: 10^8 of them have 10^12
-    if args.workload == "mixed" and args.mode == "locate" and args.queries == 100_000_000 and not amino:
+    if args.workload == "mixed" and args.mode == "locate" and args.queries == 100_000_000 and not amino and args.mixed_lengths[0] < 14:
         # 8..11-mers have 10^3..10^5 hits each (2.7 * 10^3 per k-mer on average): the hit list of 10^8 mixed k-mers is
         # 2 * 10^11 positions.  The locate form of this workload is 2 M k-mers (5 * 10^9 hits), located in windows.
+        # (--mixed-lengths 14 30 and longer: a hit or a few per k-mer drawn from the text -- the whole 10^8 are located)
         args.queries = 2_000_000
     text_seed = 4 if amino else 2
     query_seed = 104 if amino else {"random": 102, "planted": 103, "mixed": 105, "unique": 106}[args.workload]

@@ -21,6 +21,7 @@ run mixed_no_prediction AWFM_GPU_LOOKUP_PREDICT=0 -- --workload mixed --no-cpu -
 run mixed_short -- --workload mixed --mixed-lengths 8 15 --no-cpu --no-e2e --general-steps 0 --no-shard-proxy
 run mixed_long -- --workload mixed --mixed-lengths 18 30 --no-cpu --no-e2e --general-steps 0 --no-shard-proxy
 run mixed_locate -- --workload mixed --mode locate --no-e2e --steps 2 --warmup 1
+run mixed_locate_16_30 -- --workload mixed --mixed-lengths 16 30 --mode locate --no-e2e --no-secondary --no-dense-form
 run amino -- --alphabet amino
 run amino_2e9 -- --alphabet amino --text-len 2e9 --no-e2e
 run amino_no_lookup AWFM_GPU_AMINO_LOOKUP=0 -- --alphabet amino --no-cpu --no-e2e
