@@ -1009,7 +1009,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   /* counts only, dense, and nothing but the lookup kernel: it stores every k-mer's count itself, a round's at a time in whole
    * lines (bit 4 of useNext) -- no pre-fill, no 4-byte stores at k-mer numbers ($AWFM_GPU_MIXED_WHOLE_COUNTS=0: as before) */
   const char *wholeEnv = getenv("AWFM_GPU_MIXED_WHOLE_COUNTS");
-  const bool wholeCounts = lookupOnly && !sparse && dCounts && !rng && !(wholeEnv && atoi(wholeEnv) == 0);
+  const bool wholeCounts = lookupOnly && !sparse && (dCounts || rng) && !(wholeEnv && atoi(wholeEnv) == 0);
   const size_t total = leftAt + (lengthTable ? alignUp256(nq * 8u) : 0u);
   /* in the counter block, beyond the ticket counters (which end at 65792): the leftover count, the sample's count, the
    * survivor counters (kFusedCounters words a line apart) */

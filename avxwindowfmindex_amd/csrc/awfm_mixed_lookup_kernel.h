@@ -114,10 +114,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
   if (!lookupChosen(sampleAlive, samples, true)) return; /* this batch is the 16-byte-record path's (uniform) */
   const bool PAIR = ix.pairBlocks != nullptr && (useNext & 2u) == 0u;
   const bool LIST = sparse.count != nullptr;
-  /* bit 4 of useNext (counts only, dense, no pre-fill: the host knows that this kernel takes the batch): a round's counts are
-   * stored once, 16 k-mers' worth of whole lines per wave instruction, when the round's survivors are done -- a survivor
-   * leaves its count in its slot -- instead of a pre-filled array and 4-byte stores at k-mer numbers */
-  const bool WHOLE = (useNext & 16u) != 0u && !LIST && !ranges && counts;
+  /* bit 4 of useNext (dense results, no pre-fill: the host knows that this kernel takes the batch): a round's counts and
+   * ranges are stored once, 64 consecutive k-mers -- whole lines -- per wave instruction, when the round's survivors are done
+   * (a survivor leaves its final range in its slot), instead of a pre-filled array and a store at its k-mer number per hit:
+   * every k-mer gets its range -- {1, 0} without hits -- and its count */
+  const bool WHOLE = (useNext & 16u) != 0u && !LIST;
   if (threadIdx.x == 0) sWavesDone = 0u;
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   if (threadIdx.x < 17) sLevelAt[threadIdx.x] = threadIdx.x >= 1u ? awfmLengthTableAt(threadIdx.x) : 0ull;
@@ -201,7 +202,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
         sSp[w][rank] = entry[i].x;
         sEp[w][rank] = entry[i].x + v.length - 1u;
       }
-      if (WHOLE) entry[i].x = v.survives && rank < kMixedSlots ? rank : 0xFFFFFFFFu; /* (from here on: the k-mer's slot) */
+      /* (from here on: {slot, ~0} of a survivor, {first position, count} of a k-mer its entry settled) */
+      if (WHOLE && v.survives && rank < kMixedSlots) entry[i] = make_uint2(rank, 0xFFFFFFFFu);
       const bool left = general[i] || (v.survives && rank >= kMixedSlots);
       const unsigned long long lmask = __ballot(left);
       if (lmask != 0ull) { /* wave-uniform; rare */
@@ -301,7 +303,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
         const bool gone = live && (sp > ep || pos < stepChars - 1);
         const bool park = gone && sp <= ep && pos == 0; /* PAIR only */
         report(gone && gl == 0 && sp <= ep && pos < 0);
-        if (WHOLE && gone && !park && gl == 0) sLeft[w][mySlot] = sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u; /* (pos < 0 when sp <= ep) */
+        if (WHOLE && gone && !park && gl == 0) { /* its final range (empty: it died on the way; else pos < 0) back into its slot */
+          sSp[w][mySlot] = sp;
+          sEp[w][mySlot] = ep;
+        }
         const unsigned long long parkMask = __ballot(park && gl == 0);
         if (parkMask != 0ull) { /* wave-uniform */
           if (park && gl == 0) {
@@ -338,7 +343,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
             nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
           }
           report(parked && gl == 0 && sp <= ep);
-          if (WHOLE && parked && gl == 0) sLeft[w][mySlot] = sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u;
+          if (WHOLE && parked && gl == 0) {
+            sSp[w][mySlot] = sp;
+            sEp[w][mySlot] = ep;
+          }
         }
       }
       __builtin_amdgcn_wave_barrier(); /* the slots are written again by the next round */
@@ -350,8 +358,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
 #pragma unroll
       for (unsigned i = 0; i < 4u; i++) {
         const unsigned long long q = tw + 64ull * i + lane;
-        const unsigned c = entry[i].x != 0xFFFFFFFFu ? sLeft[w][entry[i].x] : entry[i].y;
-        if (q < numQueries) counts[q] = c; /* (k-mers left to the general kernel: 0 until it stores what it finds) */
+        const bool slot = entry[i].y == 0xFFFFFFFFu;
+        const pos_t fsp = slot ? sSp[w][entry[i].x] : entry[i].x, fep = slot ? sEp[w][entry[i].x] : entry[i].x + entry[i].y - 1u;
+        const bool hit = slot ? fsp <= fep : entry[i].y != 0u;
+        if (q < numQueries) { /* (k-mers left to the general kernel: no hit until it stores what it finds) */
+          if (ranges) ranges[q] = hit ? make_ulonglong2((unsigned long long)fsp, (unsigned long long)fep) : make_ulonglong2(1ull, 0ull);
+          if (counts) counts[q] = hit ? (unsigned)(fep - fsp + (pos_t)1) : 0u;
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }

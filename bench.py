@@ -900,6 +900,26 @@ def main():
             g.hit_offsets_on_device(0, ln.ranges.data_ptr(), p.q, ln.hit_off.data_ptr(), ln.scratch.data_ptr(), ln.stream)
         return ln.ranges, ln.hit_off, p.q
 
+    def dense_or_order(p):
+        """a batch most of whose k-mers have hits: results in search order -- unless it is a mixed-length batch, whose dense form
+        is the lookup kernel's when its sample says so (a round's ranges stored in whole lines) and whose search-order form is
+        the 16-byte records': whichever one search call of each, timed here, takes less (the untimed probe chooses the form,
+        the timed steps run it)"""
+        if d_offsets is None:
+            return "order"
+        took = {}
+        for f in ("dense", "order"):
+            for _ in range(3):  # (the lookup prediction settles within two searches)
+                search_part(p, f)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(lanes[0].torch_stream)
+            search_part(p, f)
+            b.record(lanes[0].torch_stream)
+            torch.cuda.synchronize()
+            took[f] = a.elapsed_time(b)
+        p.form_probe_ms = {k: round(v, 3) for k, v in took.items()}
+        return "dense" if took["dense"] <= took["order"] else "order"
+
     def probe(p, force=None):
         """one untimed, synchronous step: which form this piece's results take, how many hits there are, buffers to size"""
         p.form, p.windowed = "dense", False
@@ -915,7 +935,7 @@ def main():
             torch.cuda.synchronize()
             p.listed = int(d_num_hits.item())
             if p.listed > p.cap:  # not a sparse batch after all
-                form = "order" if have_order and p.ordered else "dense"
+                form = dense_or_order(p) if have_order and p.ordered else "dense"
         if form != "list":
             search_part(p, form)
         ranges, offsets, entries = offsets_part(p, form)
@@ -924,7 +944,7 @@ def main():
         if form != "list":
             p.listed = 0
             if force is None and form == "dense" and have_order and p.ordered and p.hits >= p.q // 4:
-                return probe(p, "order")  # most k-mers have hits: results in search order
+                return probe(p, dense_or_order(p))  # most k-mers have hits: results in search order
         p.form = form
         if form == "list" and not os.environ.get("AWFM_BENCH_WIDE_LIST"):
             # the list's capacity for the timed steps: what the probe listed + a quarter (a caller sizes its list by what its
@@ -1882,6 +1902,7 @@ def main():
                                "dense": "awfmGpuSearchHitsSparse" if narrow_counts else "awfmGpuSearchHits"}[whole.form] if locate
                               else "awfmGpuSearchHits") + (", seed order" if ordered else ", mixedLookupSearchKernel" if small_mixed_lookup else ", general kernel"),
               "result_format": form_names[whole.form] if locate else "count under every k-mer number",
+              "result_format_probe_ms": getattr(whole, "form_probe_ms", None),  # mixed-length dense-hit batches: one search call of each form, timed by the probe
               "lookup_front": {0: "both front ends launched, the sample decides on the device", 1: "lookup kernel only (predicted from an earlier step's sample)",
                                2: "ordered kernels only (predicted from an earlier step's sample)"}.get(lookup_front, "no sample"),
               "list_tail": "awfmGpuListLocateOnDevice (one launch)" if locate and whole.form == "list" and list_tail else None}

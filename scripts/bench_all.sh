@@ -5,8 +5,10 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/bench_$TAG
 mkdir -p "$OUT"
 cd "$ROOT"
+# $ONLY="name name ...": those lines only (a kernel changed: its lines again, the others stand)
 run() { # name [ENV=..]... -- bench args
   name=$1; shift
+  if [ -n "${ONLY:-}" ]; then case " $ONLY " in *" $name "*) ;; *) return 0;; esac; fi
   envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
   env "${envs[@]}" python3 bench.py "$@" 2>"$OUT/$name.err" | tail -1 > "$OUT/bench_$name.json"
 }

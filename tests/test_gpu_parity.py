@@ -1658,9 +1658,9 @@ def test_mixed_length_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, aw
 def test_mixed_length_lookup_prediction_and_whole_line_counts(oracle, awfm, require_gpu, monkeypatch):
     """Round 5, mixed-length batches: the sample's verdict goes to page-locked host memory as for fixed lengths, and a batch
     whose predecessors agree launches one front end (awfmGpuLastLookupFront: 1 = mixedLookupSearchKernel alone, which then
-    takes whatever the batch is; 2 = the 16-byte-record path alone).  With the lookup kernel alone a counts-only search is not
-    pre-filled: the kernel stores every k-mer's count itself, a round's at a time in whole lines, survivors' counts out of
-    their slots (and $AWFM_GPU_MIXED_WHOLE_COUNTS=0: pre-filled, 4-byte stores as before).  Counts and list against the oracle
+    takes whatever the batch is; 2 = the 16-byte-record path alone).  With the lookup kernel alone a dense search is not
+    pre-filled: the kernel stores every k-mer's count (and range) itself, a round's at a time in whole lines, survivors' final
+    ranges out of their slots (and $AWFM_GPU_MIXED_WHOLE_COUNTS=0: pre-filled, a store per hit as before).  Counts and list against the oracle
     whatever was predicted, the batch the prediction is wrong for included."""
     import torch
     for name in ("AWFM_GPU_MIXED_LOOKUP", "AWFM_GPU_LOOKUP_PREDICT", "AWFM_GPU_MIXED_WHOLE_COUNTS"):
@@ -1708,6 +1708,15 @@ def test_mixed_length_lookup_prediction_and_whole_line_counts(oracle, awfm, requ
             order = np.argsort(ids)
             r = d_ranges[: 2 * m].cpu().numpy().view(np.uint64).reshape(m, 2)[order]
             assert np.array_equal(ids[order], has) and np.array_equal(r[:, 0], sp[has]) and np.array_equal(r[:, 1], ep[has]), name
+        elif listed == "ranges":  # dense, with ranges (the hits-only contract: the exact range of a k-mer with hits, an empty one otherwise)
+            d_dense = torch.full((2 * Q,), 5, dtype=torch.int64, device=dev)
+            d_counts.fill_(7)
+            g.search_hits(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, d_dense.data_ptr(), d_counts.data_ptr())
+            torch.cuda.synchronize()
+            r = d_dense.cpu().numpy().view(np.uint64).reshape(Q, 2)
+            has = cnt > 0
+            assert np.array_equal(r[has, 0], sp[has]) and np.array_equal(r[has, 1], ep[has]) and np.all(r[~has, 0] > r[~has, 1]), name
+            assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt), name
         else:
             d_counts.fill_(7)
             g.search_hits(d_chars.data_ptr(), d_off.data_ptr(), 0, Q, 0, d_counts.data_ptr())
@@ -1718,11 +1727,12 @@ def test_mixed_length_lookup_prediction_and_whole_line_counts(oracle, awfm, requ
 
     fronts = [run("random", False), run("random", True), run("random", False), run("random", True)]
     assert fronts[0] == 0 and fronts[2:] == [1, 1], fronts
+    assert run("random", "ranges") == 1  # (whole-line ranges)
     monkeypatch.setenv("AWFM_GPU_MIXED_WHOLE_COUNTS", "0")
-    assert run("random", False) == 1
+    assert run("random", False) == 1 and run("random", "ranges") == 1
     monkeypatch.delenv("AWFM_GPU_MIXED_WHOLE_COUNTS")
-    assert run("planted", False) == 1  # predicted from the random batches: the lookup kernel takes the planted one, whole-line counts
-    held = [run("planted", i % 2 == 1) for i in range(9)]
+    assert run("planted", "ranges") == 1  # predicted from the random batches: the lookup kernel takes the planted one, whole-line ranges
+    held = [run("planted", ("ranges", True, False)[i % 3]) for i in range(9)]
     assert held[:8] == [0] * 8, held  # the miss switched the prediction off for eight searches
     later = [run("planted", i % 2 == 0) for i in range(3)]
     assert later[-1] == 2, (held, later)  # ... and then the 16-byte-record path alone
