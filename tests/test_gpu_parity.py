@@ -1891,3 +1891,38 @@ def test_deep_seed_env_knob_through_the_drop_in_api(oracle, awfm, require_gpu, m
     ix = awfm.gpu_create_index(txt, awfm.AwFmAlphabetDna, 8, 6)  # the builder's adopted image gets the table too
     check(ix)
     ix.dealloc()
+
+
+@pytest.mark.gpu
+def test_lookup_timeline_diagnostic(oracle, awfm, require_gpu, monkeypatch, tmp_path):
+    """$AWFM_GPU_LOOKUP_TIMELINE (round 5, diagnostic): lookupSearchKernel leaves every wave's start and end on the device's
+    clock, its HW_ID and the trips it made; the search's results are what they are without it, every wave that ran started
+    before it ended, and the trips of all waves cover the batch (256 k-mers a trip)."""
+    import torch
+    n, K, Q = 300000, 21, (1 << 20) + 5
+    txt = synth.text(n + 51, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(12)
+    q = synth.random_queries(19, Q, K).copy()
+    q[5::64] = synth.planted_queries(20, len(q[5::64]), K, txt)
+    chars, offsets = synth.fixed_csr(q)
+    _, _, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(chars).to(dev)
+    d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+    path = tmp_path / "timeline.bin"
+    monkeypatch.setenv("AWFM_GPU_LOOKUP_FIRST", "1")
+    monkeypatch.setenv("AWFM_GPU_LOOKUP_TIMELINE", str(path))
+    g.search_hits(d_chars.data_ptr(), 0, K, Q, 0, d_counts.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt)
+    t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
+    ran = t[(t[:, 0] != 0) & (t[:, 1] != 0)]
+    assert len(ran) >= 4 and np.all(ran[:, 0] <= ran[:, 1])
+    assert int(ran[:, 3].sum()) == (Q + 255) // 256 or int(ran[:, 3].sum()) >= Q // 256  # (a share's last trip may be a partial one)
+    assert len(np.unique((ran[:, 2] >> 4) & 3)) >= 2  # (HW_ID: waves on more than one SIMD)
+    g.destroy()
+    ix.dealloc()
