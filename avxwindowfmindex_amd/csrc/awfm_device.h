@@ -93,20 +93,30 @@ struct DevIndex {
    * invalid range; NULL when not built */
   const ulonglong2 *deepSeed;
   unsigned int deepK;
-  /* entries of the deeper table: 16 bytes {sp, ep}, or (1) 8 bytes {sp, length} on images below 2^32 positions -- exact:
-   * the stepping stops at the FIRST empty range, and that one is always {sp, sp - 1} (sp = C + Occ(sp' - 1),
-   * ep = C + Occ(ep') - 1 from a valid {sp', ep'}), so a length of 0 says all there is to say; sp >= 1 always */
+  /* entries of the deeper table (deepNarrow): 0 -- 16 bytes {sp, ep}; 1 -- 8 bytes {sp, length} on images below 2^32
+   * positions -- exact: the stepping stops at the FIRST empty range, and that one is always {sp, sp - 1} (sp = C + Occ(sp' - 1),
+   * ep = C + Occ(ep') - 1 from a valid {sp', ep'}), so a length of 0 says all there is to say; sp >= 1 always --; 2 (round 6) --
+   * 8 bytes on images of 2^32 .. 2^36 positions, one 64-bit word sp36 | length12 << 36 | next16 << 48 (ref src/AwFmIndex.h:88-91
+   * is 64-bit throughout; 288 GB of HBM hold no image beyond 2^36 positions with its tables).  The kernels read the format at
+   * run time (uniform), whatever position width they were compiled for. */
   unsigned int deepNarrow;
-  /* (1) the 8-byte entries are {sp, length16 | next16 << 16} (awfmGpuDeepSeedAddNext, built when the image has pair
+  /* (format 1) the 8-byte entries are {sp, length16 | next16 << 16} (awfmGpuDeepSeedAddNext, built when the image has pair
    * blocks): bit c of next16 says whether the range is still non-empty after the pair step with code c (the two
    * characters that precede the deepK-mer in a longer k-mer; awfm_pair.h), so a hits-only search drops a k-mer whose
    * bit is clear without reading a block.  A length of 0xFFFF stands for "0xFFFF or more": the exact one is
    * deepBigBySp[sp >> 15] -- the ranges of two entries are disjoint, so two that are 65535 positions long or longer begin
    * 65535 or more apart and never share a window of 2^15 positions: one read instead of round 4's search in a sorted side
-   * list (9 dependent reads for the 316 such entries of a genome-shaped text, which 2 % of the k-mers drawn from it hit). */
+   * list (9 dependent reads for the 316 such entries of a genome-shaped text, which 2 % of the k-mers drawn from it hit).
+   * Format 2 always has its 16 bits (all set until the pass that computes them has run: deepNext says whether it has), a
+   * 12-bit length whose 0xFFF stands for "4095 or more", and 64-bit exact lengths in deepBigBySp viewed as
+   * unsigned long long [sp >> 11]. */
   unsigned int deepNext;
   unsigned int numDeepBig; /* how many such entries the table has (reporting) */
   const unsigned int *deepBigBySp;
+  /* the tables per k-mer length (awfmGpuBuildLengthTables) of an image whose deeper table has format 2: entries
+   * sp36 | length28 << 36, a length of 2^28 - 1 standing for that or more: the exact one is lengthBig[(d - 1) * 512 + (sp >> 27)]
+   * for level d (ranges of ONE level are disjoint; those of different levels nest) */
+  const unsigned long long *lengthBig;
   /* optional device-only pair image (nucleotide; awfm_pair.h): two backward / LF steps per block read; NULL when
    * not built.  pairSuper32 is the 32-bit copy of the superblock bases the kernels of images below 2^32 positions
    * keep in LDS (kPairSuperStride words per superblock). */
@@ -124,6 +134,32 @@ __host__ __device__ inline unsigned long long awfmLengthTableAt(unsigned d) { re
 constexpr unsigned kDeepBigShift = 15;
 /* exact length of an entry whose 16-bit length field is saturated, from where its range begins */
 __device__ __forceinline__ unsigned deepBigLength(const DevIndex &ix, unsigned sp) { return ix.deepBigBySp[sp >> kDeepBigShift]; }
+/* format 2 (DevIndex::deepNarrow): the second word of an entry is sp's bits 35..32 | length12 << 4 | next16 << 16 */
+constexpr unsigned kDeepWideLengthMask = 0xFFFu, kDeepWideBigShift = 11;
+constexpr unsigned kDeepWideMaxBits = 36; /* positions such an entry can name */
+__host__ __device__ inline uint2 deepWidePack(unsigned long long sp, unsigned long long length, unsigned next16) {
+  const unsigned l12 = length < kDeepWideLengthMask ? (unsigned)length : kDeepWideLengthMask;
+  return make_uint2((unsigned)sp, ((unsigned)(sp >> 32) & 0xFu) | (l12 << 4) | (next16 << 16));
+}
+__device__ __forceinline__ unsigned long long deepWideSp(uint2 e) { return (unsigned long long)e.x | ((unsigned long long)(e.y & 0xFu) << 32); }
+/* the bits of an entry's second word that are zero exactly when its range is empty (every format of 8 bytes; uniform) */
+__device__ __forceinline__ unsigned deepLengthBits(const DevIndex &ix) {
+  return ix.deepNarrow == 2u ? (kDeepWideLengthMask << 4) : (ix.deepNext ? 0xFFFFu : 0xFFFFFFFFu);
+}
+/* the tables per k-mer length of such an image: sp36 | length28 << 36 */
+constexpr unsigned kLengthWideMask = (1u << 28) - 1u, kLengthWideBigShift = 27, kLengthWideBigStride = 512;
+__host__ __device__ inline uint2 lengthWidePack(unsigned long long sp, unsigned long long length) {
+  const unsigned l28 = length < kLengthWideMask ? (unsigned)length : kLengthWideMask;
+  return make_uint2((unsigned)sp, ((unsigned)(sp >> 32) & 0xFu) | (l28 << 4));
+}
+/* {first position, length} of level `d`'s entry `e` (d >= 1) in either format of the length tables */
+__device__ __forceinline__ ulonglong2 lengthEntryOpen(const DevIndex &ix, unsigned d, uint2 e) {
+  if (ix.deepNarrow != 2u) return make_ulonglong2((unsigned long long)e.x, (unsigned long long)e.y);
+  const unsigned long long sp = deepWideSp(e);
+  unsigned long long length = e.y >> 4;
+  if (length == kLengthWideMask) length = ix.lengthBig[(d - 1u) * kLengthWideBigStride + (unsigned)(sp >> kLengthWideBigShift)];
+  return make_ulonglong2(sp, length);
+}
 /* The amino alphabet's entries with next-step bits (round 5) are {sp, length12 | next20 << 12}: bit c of next20 says whether
  * the range is still non-empty after one more step with letter c (0..19) -- a hits-only search drops a k-mer whose bit is
  * clear without reading a block: against 2 * 10^9 residues 79 % of random 7-mers occur and 92 % of those die on the next
@@ -139,14 +175,21 @@ __device__ __forceinline__ unsigned aminoDeepLength(const DevIndex &ix, uint2 e)
 __device__ __forceinline__ bool aminoDeepNextBit(const DevIndex &ix, uint2 e, unsigned letter) {
   return !ix.deepNext || letter >= 20u || ((e.y >> (kAminoDeepLengthBits + letter)) & 1u) != 0u;
 }
-/* {sp, ep} from the two words of a narrow entry; *next16 (may be NULL): the pair steps that keep the range non-empty
- * (all of them when the table has no such bits) */
+/* {sp, ep} from the two words of an 8-byte entry (format 1 or 2); *next16 (may be NULL): the pair steps that keep the range
+ * non-empty (all of them when the table has no such bits) */
 __device__ __forceinline__ ulonglong2 deepSeedOpen(const DevIndex &ix, unsigned long long i, uint2 e, unsigned *next16) {
+  (void)i;
+  if (ix.deepNarrow == 2u) { /* uniform */
+    const unsigned long long sp = deepWideSp(e);
+    unsigned long long length = (e.y >> 4) & kDeepWideLengthMask;
+    if (length == kDeepWideLengthMask) length = ((const unsigned long long *)ix.deepBigBySp)[sp >> kDeepWideBigShift];
+    if (next16) *next16 = e.y >> 16;
+    return make_ulonglong2(sp, sp + length - 1ull);
+  }
   unsigned length = e.y;
   if (ix.deepNext) {
     length = e.y & 0xFFFFu;
     if (length == 0xFFFFu) length = deepBigLength(ix, e.x);
-    (void)i;
     if (next16) *next16 = e.y >> 16;
   } else if (next16) {
     *next16 = 0xFFFFu;
@@ -222,6 +265,42 @@ __device__ __forceinline__ void sparseAppend(const SparseOut &out, bool hit, uns
  * a search never waits for the host to read that word.  sampleAlive == nullptr: no sample was taken, `otherwise` says. */
 __device__ __forceinline__ bool lookupChosen(const unsigned *__restrict__ sampleAlive, const unsigned samples, const bool otherwise) {
   return sampleAlive ? *sampleAlive * 4u < samples : otherwise;
+}
+
+/* The full suffix array of an image (AwFmGpuIndex::dDenseSa) as the kernels see it: 32-bit entries, or -- images of 2^32
+ * positions and more -- 40-bit entries packed 5 bytes apiece (entry i = bytes 5 i .. 5 i + 4, little endian: the two dwords
+ * it lies in are read; one entry in 32 straddles a line).  `wide` is a kernel argument: uniform. */
+struct DenseSa {
+  const unsigned *words;
+  unsigned wide;
+};
+__device__ __forceinline__ unsigned long long denseSaAt(const DenseSa &sa, unsigned long long i) {
+  if (!sa.wide) return (unsigned long long)sa.words[i];
+  const unsigned long long byte = i * 5ull, word = byte >> 2;
+  const unsigned shift = ((unsigned)byte & 3u) * 8u;
+  const unsigned long long both = ((unsigned long long)sa.words[word + 1ull] << 32) | (unsigned long long)sa.words[word];
+  return (both >> shift) & 0xFFFFFFFFFFull;
+}
+inline uint64_t awfmDenseSaBytes(uint64_t n, bool wide) { return wide ? (n + 3ull) / 4ull * 20ull + 16ull : n * 4ull; }
+/* n values (32- or 64-bit, below 2^40) into 40-bit entries: a thread takes four values and writes the five dwords they fill */
+template <class T>
+__global__ void __launch_bounds__(256) packDense40Kernel(const T *__restrict__ in, unsigned long long n, unsigned *__restrict__ out) {
+  const unsigned long long quads = (n + 3ull) / 4ull;
+  for (unsigned long long q = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; q < quads; q += (unsigned long long)gridDim.x * 256ull) {
+    unsigned long long e[4];
+    for (unsigned k = 0; k < 4u; k++) e[k] = 4ull * q + k < n ? (unsigned long long)in[4ull * q + k] & 0xFFFFFFFFFFull : 0ull;
+    unsigned *w = out + 5ull * q;
+    w[0] = (unsigned)e[0];
+    w[1] = (unsigned)(e[0] >> 32) | (unsigned)(e[1] << 8);
+    w[2] = (unsigned)(e[1] >> 24) | (unsigned)(e[2] << 16);
+    w[3] = (unsigned)(e[2] >> 16) | (unsigned)(e[3] << 24);
+    w[4] = (unsigned)(e[3] >> 8);
+  }
+}
+/* and back to 32-bit entries (an image below 2^32 positions that is handed a packed array) */
+__global__ void __launch_bounds__(256) unpackDense40Kernel(const DenseSa in, unsigned long long n, unsigned *__restrict__ out) {
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull)
+    out[i] = (unsigned)denseSaAt(in, i);
 }
 
 /* BWT positions are 32-bit when bwtLength < 2^32 (NARROW): half the integer work of the range arithmetic */
@@ -772,9 +851,11 @@ struct AwFmGpuIndex {
   unsigned lengthDepths = 0; /* levels 1 .. lengthDepths */
   bool lengthTried = false;  /* a construction was attempted and failed, or is done */
   unsigned lengthRetryIn = 0; /* calls since it failed: every 64th tries again */
+  void *dLengthBig = nullptr; /* DevIndex::lengthBig of the tables in the wide format (set before dLengthTable is published) */
   uint64_t lengthTableBytes = 0;
   double lengthTableBuildSeconds = 0.0;
-  void *dDenseSa = nullptr; /* optional full suffix array, 32-bit entries */
+  void *dDenseSa = nullptr; /* optional full suffix array: 32-bit entries, or (denseWide) 40-bit ones packed 5 bytes apiece */
+  bool denseWide = false;
   uint64_t denseSaBytes = 0;
   double denseSaBuildSeconds = 0.0; /* wall time of the automatic construction (reporting) */
   void *dPairBlocks = nullptr, *dPairSuper = nullptr, *dPairSuper32 = nullptr, *dPairC = nullptr; /* pair image */
@@ -976,11 +1057,13 @@ enum AwFmReturnCode awfmGpuScanFlags(AwFmGpuIndex *g, const uint32_t *dCounts, u
 /* peakBytesOut (may be NULL): the most device memory the construction held at once (the table and the level below it) */
 /* allocSecondsOut (may be NULL): wall seconds spent inside the hipMalloc calls of the levels -- on this pool a process's first
  * allocation of tens of GB sometimes takes seconds (memory the driver hands back from, or scrubs after, the process before) */
+/* formatOut / bigOut (may be NULL: the table then has format 0 or 1): the format of the table's entries (DevIndex::deepNarrow)
+ * and, for format 2, the 64-bit lengths of its long ranges ((bwtLength >> 11) + 2 words: DevIndex::deepBigBySp) */
 bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut, uint64_t *peakBytesOut = nullptr,
-                               double *allocSecondsOut = nullptr);
+                               double *allocSecondsOut = nullptr, unsigned *formatOut = nullptr, void **bigOut = nullptr);
 /* one table per k-mer length 1 .. maxDepth (<= 15), 8-byte entries {sp, length}, level d at entry awfmLengthTableAt(d) of one
- * allocation: nucleotide images below 2^32 positions (awfm_gpu_build.hip) */
-bool awfmGpuBuildLengthTables(const AwFmGpuIndex *g, unsigned maxDepth, void **tableOut, uint64_t *bytesOut);
+ * allocation; entries in the deeper table's format, *bigOut: DevIndex::lengthBig of the wide one (awfm_gpu_build.hip) */
+bool awfmGpuBuildLengthTables(const AwFmGpuIndex *g, unsigned maxDepth, void **tableOut, uint64_t *bytesOut, void **bigOut);
 /* awfm_gpu_mixed.hip: the launches of awfm_mixed_lookup_kernel.h (a translation unit of their own) */
 hipError_t awfmGpuLaunchMixedSample(const AwFmGpuIndex *g, hipStream_t s, const void *lengthTable, const uint8_t *dChars,
                                     const unsigned long long *off, unsigned long long nq, unsigned useNext, unsigned samples,
@@ -1007,11 +1090,14 @@ int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
  * next (applyDenseSa takes it; whoever set it frees it when it is still there afterwards) */
 extern thread_local void *awfmGpuDenseSaStash;
 extern thread_local unsigned long long awfmGpuDenseSaStashLength;
+extern thread_local bool awfmGpuDenseSaStashWide; /* 40-bit entries (DenseSa) instead of 32-bit ones */
 /* awfm_gpu_ordered.hip: rewrites the 8-byte entries {sp, length} of a finished table as {sp, length16 | next16 << 16}
  * (DevIndex::deepNext) and returns the lengths that do not fit 16 bits in *bigOut ((bwtLength >> 15) + 1 words, indexed by
  * sp >> 15: DevIndex::deepBigBySp; *numBigOut: how many there are).  Needs the pair image.  1: done; 0: not applicable,
  * nothing was changed; -1: failed, the table is no longer usable. */
-int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **bigOut, unsigned *numBigOut);
+/* format 2 (awfmGpuBuildDeepSeedTable made the table and *big, its long lengths): only the entries' sixteen bits are
+ * rewritten, *big is read and stays as it is, *numBigOut counts the long ranges */
+int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, unsigned format, void **big, unsigned *numBigOut);
 void awfmGpuSetError(const char *what);
 void awfmGpuSetHipError(const char *what, hipError_t e);
 

@@ -14,7 +14,8 @@
  *   single step that emptied it), flagged blocks and the odd last character through the one-letter image;
  *   every k-mer's {sp, ep} and count stored under its number (batch order: whole lines).
  * K-mers with a character that is not a,c,g,t,u, none or more than 32 characters go to a list for the general kernel.
- * Fixed-length batches (offsets == NULL) and CSR ones; images below 2^32 positions with the narrow deeper table.
+ * Fixed-length batches (offsets == NULL) and CSR ones; images with an 8-byte deeper table (DevIndex::deepNarrow 1 or 2),
+ * 32- and 64-bit positions (round 6).
  */
 #ifndef AWFM_EXACT_LOOKUP_KERNEL_H
 #define AWFM_EXACT_LOOKUP_KERNEL_H
@@ -23,6 +24,7 @@
 
 namespace {
 
+template <bool NARROW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
     exactLookupSearchKernel(const DevIndex ix, const uint2 *__restrict__ lengthTable, const unsigned char *__restrict__ chars,
                             const unsigned long long *__restrict__ offsets, const unsigned fixedLength,
@@ -30,22 +32,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
                             unsigned *__restrict__ counts, unsigned long long *__restrict__ leftover,
                             unsigned *__restrict__ leftoverCount) {
   constexpr int G = 4;
-  typedef unsigned pos_t; /* narrow images only (what the 8-byte table entries imply) */
+  /* NARROW: 32-bit positions (awfmImageNarrow); otherwise (round 6) the 64-bit arithmetic of ref src/AwFmIndex.h:88-91; the
+   * entries are read in the format the image built them (DevIndex::deepNarrow) either way */
+  typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
-  __shared__ unsigned long long sSuper[1];
+  __shared__ unsigned long long sSuper[NARROW ? 1 : kMaxNucSuper * 4];
   __shared__ unsigned long long sPairC[16];
   extern __shared__ unsigned sPairSuper[];
   __shared__ unsigned long long sLevelAt[17];
   __shared__ unsigned long long sRem[4][kMixedSlots];
-  __shared__ unsigned sSp[4][kMixedSlots], sEp[4][kMixedSlots];
+  __shared__ pos_t sSp[4][kMixedSlots], sEp[4][kMixedSlots];
   __shared__ unsigned char sLeft[4][kMixedSlots], sOdd[4][kMixedSlots];
   const bool PAIR = ix.pairBlocks != nullptr && pairOff == 0u;
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   if (threadIdx.x < 17) sLevelAt[threadIdx.x] = threadIdx.x >= 1u ? awfmLengthTableAt(threadIdx.x) : 0ull;
   stageMaskTable(sMask);
-  nucStageSuper<true>(ix, sSuper);
-  if (PAIR) pairStageTables<true, 16u>(ix, sPairC, sPairSuper);
+  nucStageSuper<NARROW>(ix, sSuper);
+  if (PAIR) pairStageTables<NARROW, 16u>(ix, sPairC, sPairSuper);
   __syncthreads();
   const unsigned DK = ix.deepK;
   const unsigned long long charsBytes = offsets ? offsets[numQueries] : numQueries * (unsigned long long)fixedLength; /* uniform */
@@ -53,7 +57,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
   const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   auto store = [&](const unsigned long long q, const pos_t sp, const pos_t ep) {
     if (ranges) ranges[q] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
-    if (counts) counts[q] = sp <= ep ? ep - sp + 1u : 0u; /* ref src/AwFmIndexStruct.c:126-130 */
+    if (counts) counts[q] = sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u; /* ref src/AwFmIndexStruct.c:126-130 */
   };
   const unsigned long long waveStride = 1024ull * gridDim.x;
   for (unsigned long long tw = 1024ull * blockIdx.x + 256ull * w; tw < numQueries; tw += waveStride) {
@@ -91,16 +95,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
     for (unsigned i = 0; i < 4u; i++)
       entry[i] = *(len[i] != 0u ? mixedEntryAt(ix, lengthTable, sLevelAt, len[i], codes[i]) : (const uint2 *)ix.deepSeed);
     unsigned stotal = 0;
+    /* a k-mer that ended at its entry: {sp, length} ({1, 0}: not looked up -- not in the batch, or the general kernel's, which
+     * stores its own range later); a survivor: {slot, ~0} */
+    pos_t nowSp[4], nowLen[4];
 #pragma unroll
     for (unsigned i = 0; i < 4u; i++) {
       const unsigned long long q = tw + 64ull * i + lane;
-      unsigned length = entry[i].y;
-      if (len[i] >= DK && ix.deepNext != 0u) { /* {sp, length16 | next16 << 16}: the next-step bits are no use to an exact search */
-        length &= 0xFFFFu;
-        if (length == 0xFFFFu) length = deepBigLength(ix, entry[i].x);
-      }
+      /* (the next-step bits are no use to an exact search: useNext 0) */
+      const MixedVerdict<pos_t> v = mixedRead<pos_t>(ix, 0u, len[i], codes[i], entry[i]);
       const bool looked = len[i] != 0u;
-      const bool survives = looked && len[i] > DK && length != 0u;
+      const bool survives = looked && len[i] > DK && v.length != 0;
       /* (a k-mer that ends at its entry: the entry is its final range.  Nothing is stored yet: a round's results go out
        * together, in whole lines, when its survivors are done -- the 10^8 k-mers of a batch stored one by one as they
        * finished were 2.7 x their bytes in partial-line writes) */
@@ -110,12 +114,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
       if (survives) { /* (a slot for every k-mer of the round) */
         sRem[w][rank] = codes[i] >> (2u * DK);
         sLeft[w][rank] = (unsigned char)(len[i] - DK);
-        sSp[w][rank] = entry[i].x;
-        sEp[w][rank] = entry[i].x + length - 1u;
+        sSp[w][rank] = v.sp;
+        sEp[w][rank] = v.sp + v.length - (pos_t)1;
       }
-      /* from here on: {sp, length} of a k-mer that ended at its entry ({1, 0}: not looked up -- not in the batch, or the general
-       * kernel's, which stores its own range later), {slot, ~0} of a survivor */
-      entry[i] = survives ? make_uint2(rank, 0xFFFFFFFFu) : looked ? make_uint2(entry[i].x, length) : make_uint2(1u, 0u);
+      nowSp[i] = survives ? (pos_t)rank : looked ? v.sp : (pos_t)1;
+      nowLen[i] = survives ? ~(pos_t)0 : looked ? v.length : (pos_t)0;
       const unsigned long long lmask = __ballot(general[i]);
       if (lmask != 0ull) { /* wave-uniform; rare */
         unsigned base = 0;
@@ -150,13 +153,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
           if (PAIR) {
             const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
             /* exact: a k-mer that dies inside the pair ends in the range the letter-by-letter stepping ends in */
-            const PairStep did = pairSearchStep<true, true>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep, sC);
-            if (did == kPairFlagged) nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
-            if (did != kPairStepped && sp <= ep) nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
+            const PairStep did = pairSearchStep<NARROW, true>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep, sC);
+            if (did == kPairFlagged) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
+            if (did != kPairStepped && sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
             pos -= 2;
             rem >>= 4;
           } else {
-            nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+            nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
             pos--;
             rem >>= 2;
           }
@@ -200,7 +203,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
           if (parked) {
             mySlot = sOdd[w][k];
             take();
-            nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+            nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
             if (gl == 0) {
               sSp[w][mySlot] = sp;
               sEp[w][mySlot] = ep;
@@ -215,9 +218,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
 #pragma unroll
     for (unsigned i = 0; i < 4u; i++) { /* the round's results: 64 consecutive k-mers per wave instruction */
       const unsigned long long q = tw + 64ull * i + lane;
-      const bool slot = entry[i].y == 0xFFFFFFFFu;
-      const pos_t sp = slot ? sSp[w][entry[i].x] : entry[i].x;
-      const pos_t ep = slot ? sEp[w][entry[i].x] : entry[i].x + entry[i].y - 1u;
+      const bool slot = nowLen[i] == ~(pos_t)0;
+      const unsigned at = slot ? (unsigned)nowSp[i] : 0u;
+      const pos_t sp = slot ? sSp[w][at] : nowSp[i];
+      const pos_t ep = slot ? sEp[w][at] : nowSp[i] + nowLen[i] - (pos_t)1;
       if (q < numQueries) store(q, sp, ep);
     }
     __builtin_amdgcn_wave_barrier(); /* the slots are written again by the next round */

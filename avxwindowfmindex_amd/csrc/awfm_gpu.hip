@@ -156,7 +156,7 @@ __global__ void narrowKernel(const unsigned long long *in, unsigned long long co
 }
 /* positions[t] = denseSa[positions[t]]: the whole backtrace as one gather (hits of a query are consecutive
  * BWT positions, so the reads are contiguous per query) */
-__global__ void denseSaGatherKernel(const unsigned *__restrict__ dense, unsigned long long totalHits,
+__global__ void denseSaGatherKernel(const DenseSa dense, unsigned long long totalHits,
                                     const unsigned long long *positions, unsigned long long *out,
                                     const unsigned long long *__restrict__ totalOnDevice = nullptr) {
   if (totalOnDevice) { /* the number of hits is still on the device: totalHits is the capacity */
@@ -165,7 +165,7 @@ __global__ void denseSaGatherKernel(const unsigned *__restrict__ dense, unsigned
   }
   const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
   for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < totalHits; t += stride)
-    out[t] = dense[positions[t]];
+    out[t] = denseSaAt(dense, positions[t]);
 }
 
 /* blocks of 256 threads for n elements, at most 2^22 of them */
@@ -185,7 +185,7 @@ template <bool DENSE>
 __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const unsigned long long *__restrict__ hitOffsets,
                                  unsigned long long firstQuery, unsigned long long n, unsigned long long hitBegin,
                                  unsigned long long hitEnd, unsigned long long *__restrict__ positions,
-                                 const unsigned *__restrict__ dense = nullptr) {
+                                 const DenseSa dense = DenseSa()) {
   /* one wave per 64 queries: short lists by their own lane, long lists by the whole wave; the grid is capped (a
    * launch holds fewer than 2^32 threads), workgroups stride over the batch */
   const unsigned lane = threadIdx.x & 63u;
@@ -204,13 +204,13 @@ __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const un
     }
     const bool isLong = count > 32ull;
     if (!isLong)
-      for (unsigned long long h = 0; h < count; h++) positions[start + h] = DENSE ? (unsigned long long)dense[sp + h] : sp + h;
+      for (unsigned long long h = 0; h < count; h++) positions[start + h] = DENSE ? denseSaAt(dense, sp + h) : sp + h;
     unsigned long long longMask = __ballot(isLong);
     while (longMask) {
       const int src = __ffsll((long long)longMask) - 1;
       longMask &= longMask - 1ull;
       const unsigned long long s = __shfl(start, src, 64), c = __shfl(count, src, 64), p = __shfl(sp, src, 64);
-      for (unsigned long long h = lane; h < c; h += 64ull) positions[s + h] = DENSE ? (unsigned long long)dense[p + h] : p + h;
+      for (unsigned long long h = lane; h < c; h += 64ull) positions[s + h] = DENSE ? denseSaAt(dense, p + h) : p + h;
     }
   }
 }
@@ -225,7 +225,7 @@ constexpr unsigned kLongChunk = 16384, kLongStage = 64;
 __global__ void __launch_bounds__(256)
     expandLongKernel(const ulonglong2 *__restrict__ ranges, const unsigned long long *__restrict__ hitOffsets,
                      const unsigned long long firstQuery, const unsigned long long n, const unsigned long long hitBegin,
-                     const unsigned long long hitEnd, unsigned long long *__restrict__ positions, const unsigned *__restrict__ dense) {
+                     const unsigned long long hitEnd, unsigned long long *__restrict__ positions, const DenseSa dense) {
   __shared__ unsigned long long sOff[kLongStage + 1], sSp[kLongStage], sFirst;
   const unsigned tid = threadIdx.x;
   const unsigned long long chunks = (hitEnd - hitBegin + kLongChunk - 1ull) / kLongChunk;
@@ -257,13 +257,14 @@ __global__ void __launch_bounds__(256)
           const unsigned long long src = sSp[i] + (lo - from) - lo; /* dense[src + h] for hit h */
           unsigned long long h = lo + tid;
           for (; h + 768ull < hi; h += 1024ull) { /* four gathers of the thread in flight */
-            const unsigned a = dense[src + h], b = dense[src + h + 256ull], c = dense[src + h + 512ull], d = dense[src + h + 768ull];
+            const unsigned long long a = denseSaAt(dense, src + h), b = denseSaAt(dense, src + h + 256ull), c = denseSaAt(dense, src + h + 512ull),
+                                     d = denseSaAt(dense, src + h + 768ull);
             positions[h - hitBegin] = a;
             positions[h + 256ull - hitBegin] = b;
             positions[h + 512ull - hitBegin] = c;
             positions[h + 768ull - hitBegin] = d;
           }
-          for (; h < hi; h += 256ull) positions[h - hitBegin] = dense[src + h];
+          for (; h < hi; h += 256ull) positions[h - hitBegin] = denseSaAt(dense, src + h);
         }
       }
       if (sOff[kLongStage] >= c1) done = true;
@@ -292,7 +293,7 @@ __global__ void __launch_bounds__(kListTailThreads)
     listTailKernel(const unsigned *__restrict__ inKmers, const ulonglong2 *__restrict__ inRanges, const unsigned *__restrict__ count,
                    const unsigned cap, const unsigned long long numQueries, unsigned *__restrict__ outKmers,
                    ulonglong2 *__restrict__ outRanges, unsigned long long *__restrict__ hitOffsets, const unsigned long long capacityHits,
-                   unsigned long long *__restrict__ positions, const unsigned *__restrict__ dense) {
+                   unsigned long long *__restrict__ positions, const DenseSa dense) {
   __shared__ unsigned sKey[kListTailSlots], sOrder[kListTailSlots];
   __shared__ ulonglong2 sRange[kListTailSlots];
   __shared__ unsigned long long sWave[kListTailThreads / 64], sRed[2][kListTailThreads / 64];
@@ -435,13 +436,13 @@ __global__ void __launch_bounds__(kListTailThreads)
       }
       const bool isLong = countHere > 32ull && !isHuge;
       if (!isLong && !isHuge)
-        for (unsigned long long h = 0; h < countHere; h++) positions[off + h] = DENSE ? (unsigned long long)dense[range.x + h] : range.x + h;
+        for (unsigned long long h = 0; h < countHere; h++) positions[off + h] = DENSE ? denseSaAt(dense, range.x + h) : range.x + h;
       unsigned long long longMask = __ballot(isLong);
       while (longMask) {
         const int src = __ffsll((long long)longMask) - 1;
         longMask &= longMask - 1ull;
         const unsigned long long o = __shfl(off, src, 64), c = __shfl(countHere, src, 64), p = __shfl(range.x, src, 64);
-        for (unsigned long long h = lane; h < c; h += 64ull) positions[o + h] = DENSE ? (unsigned long long)dense[p + h] : p + h;
+        for (unsigned long long h = lane; h < c; h += 64ull) positions[o + h] = DENSE ? denseSaAt(dense, p + h) : p + h;
       }
       hitBase += chunk;
       __syncthreads(); /* sWave is written again */
@@ -452,11 +453,11 @@ __global__ void __launch_bounds__(kListTailThreads)
         for (; h + 3ull * kListTailThreads < c; h += 4ull * kListTailThreads) {
           unsigned long long v[4];
 #pragma unroll
-          for (unsigned u = 0; u < 4u; u++) v[u] = DENSE ? (unsigned long long)dense[p + h + u * kListTailThreads] : p + h + u * kListTailThreads;
+          for (unsigned u = 0; u < 4u; u++) v[u] = DENSE ? denseSaAt(dense, p + h + u * kListTailThreads) : p + h + u * kListTailThreads;
 #pragma unroll
           for (unsigned u = 0; u < 4u; u++) positions[o + h + u * kListTailThreads] = v[u];
         }
-        for (; h < c; h += kListTailThreads) positions[o + h] = DENSE ? (unsigned long long)dense[p + h] : p + h;
+        for (; h < c; h += kListTailThreads) positions[o + h] = DENSE ? denseSaAt(dense, p + h) : p + h;
       }
       if (huge) __syncthreads(); /* the slots are written again */
     }
@@ -542,6 +543,14 @@ enum AwFmReturnCode ensureWork(AwFmGpuIndex *g, size_t bytes) {
 }
 
 inline size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+/* the image's full suffix array as a kernel argument */
+inline DenseSa denseSaOf(const AwFmGpuIndex *g) {
+  DenseSa sa;
+  sa.words = (const unsigned *)g->dDenseSa;
+  sa.wide = g->denseWide ? 1u : 0u;
+  return sa;
+}
 
 }  // namespace
 
@@ -872,6 +881,7 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
       if (g->dDeepBig) (void)hipFree(g->dDeepBig);
       if (g->dDenseSa) (void)hipFree(g->dDenseSa);
       if (g->dLengthTable) (void)hipFree(g->dLengthTable);
+      if (g->dLengthBig) (void)hipFree(g->dLengthBig);
       void *pairOwned[] = {g->dPairBlocks, g->dPairSuper, g->dPairSuper32, g->dPairC};
       for (void *p : pairOwned)
         if (p) (void)hipFree(p);
@@ -941,6 +951,7 @@ static AwFmGpuIndex *makeLane(AwFmGpuIndex *primary) {
   g->dPrefix = primary->dPrefix;
   g->dDeepSeed = primary->dDeepSeed;
   g->dDenseSa = primary->dDenseSa;
+  g->denseWide = primary->denseWide;
   g->numBlocks = primary->numBlocks;
   g->kernel = primary->kernel;
   g->forceWide = primary->forceWide;
@@ -1089,7 +1100,9 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
   { /* the tables of the shorter lengths go with the deeper table they complete; the next mixed-length batch builds them again */
     std::lock_guard<std::mutex> lock(g->lengthMutex);
     if (g->dLengthTable) (void)hipFree(g->dLengthTable);
+    if (g->dLengthBig) (void)hipFree(g->dLengthBig);
     g->dLengthTable = nullptr;
+    g->dLengthBig = nullptr;
     g->lengthDepths = 0;
     g->lengthTableBytes = 0;
     g->lengthTried = false;
@@ -1102,30 +1115,36 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
     uint64_t bytes = 0, peak = 0;
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    if (awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes, &peak, &g->deepSeedAllocSeconds)) {
-      void *big = nullptr;
+    unsigned format = 0;
+    void *big = nullptr;
+    if (awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes, &peak, &g->deepSeedAllocSeconds, &format, &big)) {
       unsigned numBig = 0;
-      const int next = awfmGpuDeepSeedAddNext(g, table, deepK, &big, &numBig); /* images with pair blocks, below 2^32 positions */
+      /* the next-step bits: images with pair blocks (format 1: the long lengths move to `big` with them) */
+      const int next = awfmGpuDeepSeedAddNext(g, table, deepK, format, &big, &numBig);
       (void)hipDeviceSynchronize();
       clock_gettime(CLOCK_MONOTONIC, &t1);
       g->deepSeedBuildSeconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
       g->deepSeedTransientBytes = peak > bytes ? peak - bytes : 0;
       if (next < 0) {
         (void)hipFree(table);
+        if (big) (void)hipFree(big);
         rc = AwFmGeneralFailure;
       } else {
         g->dDeepSeed = table;
         g->dDeepBig = big;
-        g->deepSeedBytes = bytes + (big ? ((g->dev.bwtLength >> (g->amino ? kAminoDeepBigShift : kDeepBigShift)) + 5u) * 4u : 0u);
+        const uint64_t bigBytes = !big ? 0u
+                                  : format == 2u ? ((g->dev.bwtLength >> kDeepWideBigShift) + 2u) * 8u
+                                                 : ((g->dev.bwtLength >> (g->amino ? kAminoDeepBigShift : kDeepBigShift)) + 5u) * 4u;
+        g->deepSeedBytes = bytes + bigBytes;
         g->dev.deepSeed = (const ulonglong2 *)table;
         g->dev.deepK = deepK;
-        g->dev.deepNarrow = g->dev.bwtLength < (1ull << 32) ? 1u : 0u;
+        g->dev.deepNarrow = format;
         g->dev.deepNext = next > 0 ? 1u : 0u;
         g->dev.numDeepBig = numBig;
         g->dev.deepBigBySp = (const unsigned *)big;
         if (getenv("AWFM_VERBOSE"))
-          fprintf(stderr, "[awfm deeper table] depth %u: %.2f GB in %.2f s; next-step bits %s; %u entries with ranges of 65535 and more\n",
-                  deepK, (double)bytes * 1e-9, g->deepSeedBuildSeconds, next > 0 ? "yes" : "no", numBig);
+          fprintf(stderr, "[awfm deeper table] depth %u, entry format %u: %.2f GB in %.2f s; next-step bits %s; %u entries with long ranges\n",
+                  deepK, format, (double)bytes * 1e-9, g->deepSeedBuildSeconds, next > 0 ? "yes" : "no", numBig);
       }
     } else {
       rc = AwFmGeneralFailure;
@@ -1178,7 +1197,7 @@ static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
     size_t freeBytes = 0, totalBytes = 0;
     DeviceGuard guard(g->device);
     if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) {
-      const uint64_t entryBytes = g->dev.bwtLength < (1ull << 32) ? 8u : 16u;
+      const uint64_t entryBytes = g->dev.bwtLength < (1ull << kDeepWideMaxBits) ? 8u : 16u;
       for (unsigned k = kAutoDeepSeedMax; k >= kAutoDeepSeedMin && deepK == 0; k--)
         if ((1ull << (2u * k)) <= 2ull * g->dev.bwtLength && freeBytes / 3u >= (entryBytes << (2u * k))) deepK = (int)k;
       if (deepK == 0 && freeBytes / 4u >= (16ull << (2u * kAutoDeepSeedMin))) deepK = (int)kAutoDeepSeedMin;
@@ -1550,7 +1569,7 @@ enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearch
     hipLaunchKernelGGL(expandHitsKernel<true>, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
                        (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
                        (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
-                       (unsigned long long *)outPositions, (const unsigned *)g->dDenseSa);
+                       (unsigned long long *)outPositions, denseSaOf(g));
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
   }
@@ -1560,7 +1579,7 @@ enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearch
     hipLaunchKernelGGL(expandLongKernel, dim3((unsigned)(chunks < resident ? chunks : resident)), dim3(256), 0, s,
                        (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
                        (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
-                       (unsigned long long *)outPositions, (const unsigned *)g->dDenseSa);
+                       (unsigned long long *)outPositions, denseSaOf(g));
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
   }
@@ -1571,11 +1590,11 @@ enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearch
     hipLaunchKernelGGL(expandHitsKernel<false>, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
                        (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
                        (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
-                       (unsigned long long *)dPositions, (const unsigned *)nullptr);
+                       (unsigned long long *)dPositions, DenseSa());
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     const unsigned long long blocks = (totalHits + 255ull) / 256ull, resident = (unsigned long long)g->numCUs * 16ull;
     hipLaunchKernelGGL(denseSaGatherKernel, dim3((unsigned)(blocks < resident ? blocks : resident)), dim3(256), 0, s,
-                       (const unsigned *)g->dDenseSa, (unsigned long long)totalHits, (const unsigned long long *)dPositions,
+                       denseSaOf(g), (unsigned long long)totalHits, (const unsigned long long *)dPositions,
                        (unsigned long long *)outPositions, (const unsigned long long *)nullptr);
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
@@ -1583,7 +1602,7 @@ enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearch
   hipLaunchKernelGGL(expandHitsKernel<false>, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
                      (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
                      (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
-                     (unsigned long long *)dPositions, (const unsigned *)nullptr);
+                     (unsigned long long *)dPositions, DenseSa());
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   return launchLocate(g, totalHits, (unsigned long long *)dPositions, s, (unsigned long long *)outPositions);
 }
@@ -1619,13 +1638,13 @@ enum AwFmReturnCode awfmGpuLocateOnDevice(AwFmGpuIndex *g, const struct AwFmSear
   if (g->dDenseSa) { /* the full suffix array: expand and gather in one kernel */
     hipLaunchKernelGGL(expandHitsKernel<true>, dim3(cappedGrid(numQueries)), dim3(256), 0, s, (const ulonglong2 *)dRanges,
                        (const unsigned long long *)dHitOffsets, 0ull, (unsigned long long)numQueries, 0ull,
-                       (unsigned long long)capacityHits, (unsigned long long *)dPositions, (const unsigned *)g->dDenseSa);
+                       (unsigned long long)capacityHits, (unsigned long long *)dPositions, denseSaOf(g));
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
   }
   hipLaunchKernelGGL(expandHitsKernel<false>, dim3(cappedGrid(numQueries)), dim3(256), 0, s, (const ulonglong2 *)dRanges,
                      (const unsigned long long *)dHitOffsets, 0ull, (unsigned long long)numQueries, 0ull,
-                     (unsigned long long)capacityHits, (unsigned long long *)dPositions, (const unsigned *)nullptr);
+                     (unsigned long long)capacityHits, (unsigned long long *)dPositions, DenseSa());
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   const unsigned long long *total = (const unsigned long long *)dHitOffsets + numQueries;
   return launchLocate(g, capacityHits, (unsigned long long *)dPositions, s, (unsigned long long *)dPositions, total);
@@ -1659,15 +1678,16 @@ enum AwFmReturnCode awfmGpuListLocateOnDevice(AwFmGpuIndex *g, const uint32_t *d
     AWFM_HIP_TRY(hipMemcpyAsync(dSortedRanges, dHitRanges, (size_t)capacity * 16u, hipMemcpyDeviceToDevice, s), AwFmGeneralFailure);
     enum AwFmReturnCode rc = awfmGpuSortHitsOnDevice(g, dSortedKmers, dSortedRanges, capacity, dNumHits, numQueries, stream);
     if (rc != AwFmSuccess) return rc;
+    /* the scan's scratch is this call's own, allocated and freed in stream order: the image's grow-only work buffer belongs
+     * to the host-buffer entry points, which hold its mutex for their whole synchronous call and may re-allocate it (advisor,
+     * round 5: handing it out beyond that mutex let a concurrent host call overwrite or free the scratch of a scan in flight) */
     void *scratch = nullptr;
-    {
-      std::lock_guard<std::mutex> lock(g->workMutex);
-      rc = ensureWork(g, awfmGpuScanScratchBytes(capacity));
-      scratch = g->dWork;
-    }
-    if (rc != AwFmSuccess) return rc;
+    AWFM_HIP_TRY(hipMallocAsync(&scratch, awfmGpuScanScratchBytes(capacity), s), AwFmAllocationFailure);
     rc = awfmGpuHitOffsetsOnDevice(g, nullptr, dSortedRanges, capacity, dHitOffsets, scratch, stream);
-    if (rc != AwFmSuccess || capacityHits == 0) return rc;
+    const hipError_t freed = hipFreeAsync(scratch, s);
+    if (rc != AwFmSuccess) return rc;
+    AWFM_HIP_TRY(freed, AwFmGeneralFailure);
+    if (capacityHits == 0) return rc;
     return awfmGpuLocateOnDevice(g, dSortedRanges, dHitOffsets, capacity, capacityHits, dPositions, stream);
   }
   /* a workgroup per stretch of the batch; a short list does not need the whole chip */
@@ -1678,12 +1698,12 @@ enum AwFmReturnCode awfmGpuListLocateOnDevice(AwFmGpuIndex *g, const uint32_t *d
     hipLaunchKernelGGL(listTailKernel<true>, dim3(grid), dim3(kListTailThreads), 0, s, (const unsigned *)dHitKmers, (const ulonglong2 *)dHitRanges,
                        (const unsigned *)dNumHits, (unsigned)capacity, (unsigned long long)numQueries, (unsigned *)dSortedKmers,
                        (ulonglong2 *)dSortedRanges, (unsigned long long *)dHitOffsets, (unsigned long long)capacityHits,
-                       (unsigned long long *)dPositions, (const unsigned *)g->dDenseSa);
+                       (unsigned long long *)dPositions, denseSaOf(g));
   else
     hipLaunchKernelGGL(listTailKernel<false>, dim3(grid), dim3(kListTailThreads), 0, s, (const unsigned *)dHitKmers, (const ulonglong2 *)dHitRanges,
                        (const unsigned *)dNumHits, (unsigned)capacity, (unsigned long long)numQueries, (unsigned *)dSortedKmers,
                        (ulonglong2 *)dSortedRanges, (unsigned long long *)dHitOffsets, (unsigned long long)capacityHits,
-                       (unsigned long long *)dPositions, (const unsigned *)nullptr);
+                       (unsigned long long *)dPositions, DenseSa());
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   if (g->dDenseSa || capacityHits == 0) return AwFmSuccess;
   /* no full suffix array: the kernel left the BWT positions; the LF walk and the sample reads take them from there */
@@ -1791,7 +1811,10 @@ enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable) {
   LaneLocks lanes(g);
   std::lock_guard<std::mutex> lock(g->workMutex);
   const enum AwFmReturnCode rc = applyDenseSa(g, enable != 0);
-  for (AwFmGpuIndex *lane : lanes.lanes) lane->dDenseSa = g->dDenseSa;
+  for (AwFmGpuIndex *lane : lanes.lanes) {
+    lane->dDenseSa = g->dDenseSa;
+    lane->denseWide = g->denseWide;
+  }
   return rc;
 }
 
@@ -1808,7 +1831,7 @@ __global__ void __launch_bounds__(256) narrowParkKernel(const unsigned long long
     const unsigned long long v = in[i];
     if (v & kWalkParked) {
       dense[i] = kDenseUnknown;
-      if (park) park[i] = (((v >> 32) & 0x3FFFFFFFull) << 32) | (v & 0xFFFFFFFFull); /* (NULL: the pass that only counts) */
+      if (park) park[i] = (((v >> 40) & 0x3FFFFFull) << 32) | (v & 0xFFFFFFFFull); /* (NULL: the pass that only counts) */
       mine++;
     } else {
       dense[i] = (unsigned)v;
@@ -1867,7 +1890,7 @@ __global__ void __launch_bounds__(256) narrowParkListKernel(const unsigned long 
       const unsigned long long slot = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
       if (slot < capacity) {
         listAt[slot] = (unsigned)(first + i);
-        listEntry[slot] = (((v >> 32) & 0x3FFFFFFFull) << 32) | (v & 0xFFFFFFFFull);
+        listEntry[slot] = (((v >> 40) & 0x3FFFFFull) << 32) | (v & 0xFFFFFFFFull);
         dense[first + i] = (unsigned)slot;
       } else {
         dense[first + i] = kDenseUnknown;
@@ -1906,6 +1929,63 @@ __global__ void __launch_bounds__(256) denseSaJumpListKernel(unsigned *__restric
   for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
   if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(left, mine);
 }
+/* ---- the same construction for images of 2^32 positions and more (round 6; ref src/AwFmSuffixArray.c:12-18 is 64-bit) ----
+ * The array is put together in 64-bit entries and packed to 40 bits at the end (DenseSa).  An entry that is still open holds
+ * bit 63 and the slot of its parked walk in the list -- no value can be mistaken for one --, a list entry is {steps so far,
+ * the position the walk stands at}, and a round reads the entries the round before wrote (two copies of the list), so that a
+ * 16-byte entry is never read while it is rewritten. */
+constexpr unsigned long long kDenseOpen = 1ull << 63;
+__global__ void __launch_bounds__(256) parkWideKernel(const unsigned long long *__restrict__ in, unsigned long long count, unsigned long long first,
+                                                      unsigned long long *__restrict__ dense, unsigned long long *__restrict__ listAt,
+                                                      ulonglong2 *__restrict__ listEntry, unsigned long long capacity,
+                                                      unsigned long long *__restrict__ parked) {
+  const unsigned lane = threadIdx.x & 63u;
+  for (unsigned long long at = (unsigned long long)blockIdx.x * 256ull; at < count; at += (unsigned long long)gridDim.x * 256ull) {
+    const unsigned long long i = at + threadIdx.x;
+    const unsigned long long v = i < count ? in[i] : 0ull;
+    const bool isParked = (v & kWalkParked) != 0ull;
+    const unsigned long long mask = __ballot(isParked);
+    if (mask == 0ull) {
+      if (i < count) dense[first + i] = v;
+      continue;
+    }
+    unsigned long long base = 0;
+    const unsigned leader = (unsigned)__ffsll((long long)mask) - 1u;
+    if (lane == leader) base = atomicAdd(parked, (unsigned long long)__popcll(mask));
+    base = __shfl(base, (int)leader);
+    if (isParked) {
+      const unsigned long long slot = base + (unsigned long long)__popcll(mask & ((1ull << lane) - 1ull));
+      if (slot < capacity) {
+        listAt[slot] = first + i;
+        listEntry[slot] = make_ulonglong2((v >> 40) & 0x3FFFFFull, v & kWalkSampleMask);
+      }
+      dense[first + i] = kDenseOpen | slot; /* (beyond the capacity: the caller sees the count and starts over) */
+    } else if (i < count) {
+      dense[first + i] = v;
+    }
+  }
+}
+__global__ void __launch_bounds__(256) denseSaJumpWideKernel(unsigned long long *__restrict__ dense, const unsigned long long *__restrict__ listAt,
+                                                             const ulonglong2 *__restrict__ entryIn, ulonglong2 *__restrict__ entryOut,
+                                                             unsigned long long listed, unsigned long long n, unsigned long long *__restrict__ left) {
+  unsigned long long mine = 0;
+  for (unsigned long long s = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; s < listed; s += (unsigned long long)gridDim.x * 256ull) {
+    const unsigned long long j = listAt[s];
+    const ulonglong2 e = entryIn[s];
+    entryOut[s] = e;
+    if ((dense[j] & kDenseOpen) == 0ull) continue;
+    const unsigned long long at = ((volatile unsigned long long *)dense)[e.y];
+    if ((at & kDenseOpen) == 0ull) {
+      dense[j] = (at + e.x) % n;
+    } else {
+      const ulonglong2 e2 = entryIn[at & ~kDenseOpen];
+      entryOut[s] = make_ulonglong2(e.x + e2.x, e2.y);
+      mine++;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & 63u) == 0u && mine) atomicAdd(left, mine);
+}
 }  // namespace
 
 /* the full suffix array an index builder of this thread still holds (awfm_gpu_build.hip: 32-bit positions of the text it has
@@ -1913,6 +1993,7 @@ __global__ void __launch_bounds__(256) denseSaJumpListKernel(unsigned *__restric
 extern "C++" {
 thread_local void *awfmGpuDenseSaStash = nullptr;
 thread_local unsigned long long awfmGpuDenseSaStashLength = 0;
+thread_local bool awfmGpuDenseSaStashWide = false;
 }
 
 /* capped (the AUTOMATIC construction): a position that has not reached a sample after 32 x ratio LF steps (a random walk is
@@ -1924,24 +2005,56 @@ thread_local unsigned long long awfmGpuDenseSaStashLength = 0;
  * 8 bytes per position and a second pass.  Without memory for either, or when 64 rounds do not finish, no array is kept and
  * the image locates by walking, as the reference does; a construction that was asked for (awfmGpuIndexSetDenseSa,
  * $AWFM_GPU_DENSE_SA=1) then walks every position to its sample, however long that takes. */
+static enum AwFmReturnCode applyDenseSaWide(AwFmGpuIndex *g, bool capped);
 static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool capped) {
   (void)hipDeviceSynchronize();
   if (g->dDenseSa) (void)hipFree(g->dDenseSa);
   g->dDenseSa = nullptr;
   g->denseSaBytes = 0;
+  g->denseWide = false;
   if (!enable) return AwFmSuccess;
   const unsigned long long n = g->dev.bwtLength;
-  if (n >= (1ull << 32)) {
-    setError("awfmGpuIndexSetDenseSa: 32-bit entries need bwtLength < 2^32");
+  /* 32-bit entries for the images that run 32-bit positions, 40-bit ones (DenseSa) for the others */
+  const bool wide = !awfmImageNarrow(g);
+  if (n >= (1ull << 40)) {
+    setError("awfmGpuIndexSetDenseSa: 40-bit entries need bwtLength < 2^40");
     return AwFmUnsupportedVersionError;
   }
   if (awfmGpuDenseSaStash && awfmGpuDenseSaStashLength == n) { /* this thread's builder hands its array over */
-    g->dDenseSa = awfmGpuDenseSaStash;
-    g->denseSaBytes = n * 4;
+    void *stash = awfmGpuDenseSaStash;
+    const bool stashWide = awfmGpuDenseSaStashWide;
     awfmGpuDenseSaStash = nullptr;
     awfmGpuDenseSaStashLength = 0;
+    if (stashWide != wide) { /* (tests: a small image forced wide, or a small text sorted with 64-bit positions) */
+      void *other = nullptr;
+      if (hipMalloc(&other, awfmDenseSaBytes(n, wide)) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(stash);
+        return AwFmSuccess; /* no array: the image locates by walking */
+      }
+      if (wide) {
+        hipLaunchKernelGGL((packDense40Kernel<unsigned>), dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const unsigned *)stash, n, (unsigned *)other);
+      } else {
+        DenseSa from;
+        from.words = (const unsigned *)stash;
+        from.wide = 1u;
+        hipLaunchKernelGGL(unpackDense40Kernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, from, n, (unsigned *)other);
+      }
+      const bool ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+      (void)hipFree(stash);
+      if (!ok) {
+        (void)hipFree(other);
+        setError("awfmGpuIndexSetDenseSa: converting the builder's suffix array failed");
+        return AwFmGeneralFailure;
+      }
+      stash = other;
+    }
+    g->dDenseSa = stash;
+    g->denseWide = wide;
+    g->denseSaBytes = awfmDenseSaBytes(n, wide);
     return AwFmSuccess;
   }
+  if (wide) return applyDenseSaWide(g, capped);
   unsigned *dense = nullptr;
   unsigned long long *chunkBuf = nullptr, *park = nullptr, *counter = nullptr;
   const unsigned long long chunk = n < (1ull << 28) ? n : (1ull << 28);
@@ -2062,6 +2175,106 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
   return AwFmSuccess;
 }
 
+/* the construction for images that run 64-bit positions (kernels above): capped walks, the parked ones in a list, pointer
+ * jumping, 40-bit entries at the end.  A text that parks more walks than the list holds -- a quarter of its positions, 2^27 at
+ * most -- gets no automatic array; one that was asked for is then walked to the end, however long that takes. */
+static enum AwFmReturnCode applyDenseSaWide(AwFmGpuIndex *g, bool capped) {
+  const unsigned long long n = g->dev.bwtLength;
+  const unsigned long long chunk = n < (1ull << 28) ? n : (1ull << 28);
+  unsigned long long *dense = nullptr, *chunkBuf = nullptr, *listAt = nullptr;
+  ulonglong2 *entry[2] = {nullptr, nullptr};
+  unsigned long long listCapacity = n / 4u + 1024u < (1ull << 27) ? n / 4u + 1024u : (1ull << 27);
+  auto release = [&]() {
+    if (dense) (void)hipFree(dense);
+    if (chunkBuf) (void)hipFree(chunkBuf);
+    if (listAt) (void)hipFree(listAt);
+    if (entry[0]) (void)hipFree(entry[0]);
+    if (entry[1]) (void)hipFree(entry[1]);
+    dense = chunkBuf = listAt = nullptr;
+    entry[0] = entry[1] = nullptr;
+  };
+  if (hipMalloc((void **)&dense, n * 8) != hipSuccess || hipMalloc((void **)&chunkBuf, chunk * 8 + 16) != hipSuccess ||
+      hipMalloc((void **)&listAt, listCapacity * 8) != hipSuccess || hipMalloc((void **)&entry[0], listCapacity * 16) != hipSuccess ||
+      hipMalloc((void **)&entry[1], listCapacity * 16) != hipSuccess) {
+    (void)hipGetLastError();
+    release();
+    setError("awfmGpuIndexSetDenseSa: no device memory for the construction");
+    return capped ? AwFmSuccess : AwFmAllocationFailure;
+  }
+  unsigned long long *counter = chunkBuf + chunk; /* two words behind the chunk: parked entries, entries left */
+  enum AwFmReturnCode rc = AwFmSuccess;
+  unsigned stepCap = 32u * g->dev.saRatio;
+  auto walkAll = [&]() {
+    if (hipMemset(counter, 0, 16) != hipSuccess) rc = AwFmGeneralFailure;
+    for (unsigned long long first = 0; first < n && rc == AwFmSuccess; first += chunk) {
+      const unsigned long long count = n - first < chunk ? n - first : chunk;
+      hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, 0, chunkBuf, first, count);
+      rc = launchLocate(g, count, chunkBuf, (hipStream_t)0, nullptr, nullptr, stepCap);
+      if (stepCap)
+        hipLaunchKernelGGL(parkWideKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const unsigned long long *)chunkBuf, count, first, dense,
+                           listAt, entry[0], listCapacity, counter);
+      else if (hipMemcpyAsync(dense + first, chunkBuf, count * 8, hipMemcpyDeviceToDevice, (hipStream_t)0) != hipSuccess)
+        rc = AwFmGeneralFailure;
+      if (hipGetLastError() != hipSuccess) rc = AwFmGeneralFailure;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) rc = AwFmGeneralFailure;
+  };
+  walkAll();
+  unsigned long long parked = 0, left = 0;
+  if (rc == AwFmSuccess && hipMemcpy(&parked, counter, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
+  if (rc == AwFmSuccess && parked > listCapacity) {
+    if (capped) { /* no automatic array for such a text */
+      release();
+      return AwFmSuccess;
+    }
+    stepCap = 0u; /* asked for: every walk to its sample (exact: finishKernel resumes the ones the walk kernel gives up) */
+    walkAll();
+    parked = 0;
+  }
+  left = parked;
+  unsigned rounds = 0;
+  for (; rc == AwFmSuccess && left != 0 && rounds < 64u; rounds++) {
+    if (hipMemset(counter + 1, 0, 8) != hipSuccess) rc = AwFmGeneralFailure;
+    hipLaunchKernelGGL(denseSaJumpWideKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, dense, (const unsigned long long *)listAt,
+                       (const ulonglong2 *)entry[rounds & 1u], entry[(rounds & 1u) ^ 1u], parked, n, counter + 1);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(&left, counter + 1, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = AwFmGeneralFailure;
+  }
+  if (getenv("AWFM_VERBOSE") && parked)
+    fprintf(stderr, "[awfm full suffix array, 40-bit entries] %llu of %llu walks parked after %u LF steps; %u rounds of pointer jumping, %llu left\n", parked, n,
+            stepCap, rounds, left);
+  if (rc == AwFmSuccess && left != 0) { /* (64 rounds look 2^64 steps ahead: not reached by an index that is one) */
+    release();
+    return AwFmSuccess;
+  }
+  (void)hipFree(chunkBuf);
+  (void)hipFree(listAt);
+  (void)hipFree(entry[0]);
+  (void)hipFree(entry[1]);
+  chunkBuf = listAt = nullptr;
+  entry[0] = entry[1] = nullptr;
+  unsigned *packed = nullptr;
+  if (rc == AwFmSuccess && hipMalloc((void **)&packed, awfmDenseSaBytes(n, true)) != hipSuccess) {
+    (void)hipGetLastError();
+    release();
+    setError("awfmGpuIndexSetDenseSa: no device memory for the array");
+    return capped ? AwFmSuccess : AwFmAllocationFailure;
+  }
+  if (rc == AwFmSuccess) {
+    hipLaunchKernelGGL((packDense40Kernel<unsigned long long>), dim3((unsigned)g->numCUs * 8u), dim3(256), 0, 0, (const unsigned long long *)dense, n, packed);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = AwFmGeneralFailure;
+  }
+  release();
+  if (rc != AwFmSuccess) {
+    if (packed) (void)hipFree(packed);
+    setError("awfmGpuIndexSetDenseSa: construction failed");
+    return rc;
+  }
+  g->dDenseSa = packed;
+  g->denseWide = true;
+  g->denseSaBytes = awfmDenseSaBytes(n, true);
+  return AwFmSuccess;
+}
+
 /* $AWFM_GPU_DENSE_SA=0|1 on an image that was just created or adopted (no lanes, nobody else holds it); unset: automatic.
  * Automatic: an image beyond the caches (>= 2^26 positions, below 2^32: 32-bit entries) whose suffix array is sampled
  * gets the full one when four times its size is free on the device -- 12.4 GB of 288 for a GRCh38-sized image, computed
@@ -2076,17 +2289,19 @@ static enum AwFmReturnCode applyDenseSaFromEnv(AwFmGpuIndex *g) {
     want = automatic = g->dev.saRatio > 1u;
   } else if (env) {
     want = atoi(env) != 0;
-  } else if (g->dev.bwtLength >= (1ull << 26) && g->dev.bwtLength < (1ull << 32) && g->dev.saRatio > 1u) {
+  } else if (g->dev.bwtLength >= (1ull << 26) && g->dev.bwtLength < (1ull << 40) && g->dev.saRatio > 1u) {
     /* (round 5: from 2^26 positions instead of 2^28 -- a Swiss-Prot-sized amino image, 0.8 GB of entries: the LF walk of the
      * few hits of a shard's list was a chain of 130 us, a third of the shard's step) */
     size_t freeBytes = 0, totalBytes = 0;
     DeviceGuard guard(g->device);
-    if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) want = freeBytes / 4u >= g->dev.bwtLength * 4ull + (1ull << 31);
+    /* (32-bit entries; 40-bit ones, put together in 64-bit entries, for the images that run 64-bit positions: round 6) */
+    const uint64_t entryBytes = awfmImageNarrow(g) ? 4u : (awfmGpuDenseSaStash && awfmGpuDenseSaStashLength == g->dev.bwtLength ? 5u : 8u);
+    if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) want = freeBytes / (awfmImageNarrow(g) ? 4u : 2u) >= g->dev.bwtLength * entryBytes + (1ull << 31);
     else (void)hipGetLastError();
     if (!want) g->accelNotes += "full suffix array: not built (less than 4 x its size free); ";
     automatic = true;
   }
-  if (!want || g->dev.bwtLength >= (1ull << 32)) return AwFmSuccess;
+  if (!want || g->dev.bwtLength >= (1ull << 40)) return AwFmSuccess;
   DeviceGuard guard(g->device);
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);

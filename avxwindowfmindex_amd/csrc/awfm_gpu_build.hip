@@ -351,11 +351,25 @@ __global__ void __launch_bounds__(kThreads)
  * so that a round costs one memory latency for U entries (the one-entry-per-round kernel above is bound by that latency:
  * 3.6 s for the two levels from k = 12 to 14 of a 3.1 Gbp index).  Consecutive entries have consecutive parents, whose
  * ranges are neighbours in the BWT: the U steps of a round mostly read the same few lines. */
-/* OUT8: the level is the table itself on an image below 2^32 positions: 8-byte entries {sp, length} (awfm_device.h) */
-template <int U, bool OUT8>
+/* OUT: 0 -- 16-byte entries {sp, ep}; the level is the table itself: 1 -- 8-byte entries {sp, length} (an image below 2^32
+ * positions), 2 -- sp36 | length12 << 36 | all sixteen next-step bits, the lengths of 4095 and more in big[sp >> 11]
+ * (DevIndex::deepNarrow, awfm_device.h) */
+template <int OUT>
+__device__ __forceinline__ void deepSeedStore(ulonglong2 *__restrict__ out, u64 at, u64 sp, u64 ep, u64 *__restrict__ big) {
+  if (OUT == 1) {
+    ((uint2 *)out)[at] = make_uint2((unsigned)sp, (unsigned)(ep + 1ull - sp));
+  } else if (OUT == 2) {
+    const u64 length = ep + 1ull - sp;
+    ((uint2 *)out)[at] = deepWidePack(sp, length, 0xFFFFu);
+    if (length >= kDeepWideLengthMask) big[sp >> kDeepWideBigShift] = length;
+  } else {
+    out[at] = make_ulonglong2(sp, ep);
+  }
+}
+template <int U, int OUT>
 __global__ void __launch_bounds__(kThreads)
     deepSeedLevelKernel(const DevIndex ix, const ulonglong2 *__restrict__ parentLevel, u64 parentLen, u64 outLen,
-                        ulonglong2 *__restrict__ out) {
+                        ulonglong2 *__restrict__ out, u64 *__restrict__ big) {
   constexpr int G = 4;
   __shared__ u64 sC[24];
   __shared__ u64 sSuper[kMaxNucSuper * 4];
@@ -389,10 +403,7 @@ __global__ void __launch_bounds__(kThreads)
     for (int u = 0; u < U; u++) {
       u64 a = sp[u], b = ep[u];
       if (step[u]) nucStepAnyRank<G, false>(ix, sC, sSuper, g, letter[u], &p0[u], &p1[u], a, b);
-      if (g == 0 && base + u < outLen) {
-        if (OUT8) ((uint2 *)out)[base + u] = make_uint2((unsigned)a, (unsigned)(b + 1ull - a));
-        else out[base + u] = make_ulonglong2(a, b);
-      }
+      if (g == 0 && base + u < outLen) deepSeedStore<OUT>(out, base + u, a, b, big);
     }
   }
 }
@@ -402,37 +413,39 @@ __global__ void __launch_bounds__(kThreads)
  * a range that dies inside the pair ends in the empty range the letter-by-letter stepping ends in, as in the general search
  * kernel, whose three lines these are.  The level in between is never written: a depth-16 table is built 12 -> 14 -> 16 and
  * the 17 GB of level 15 -- a quarter of the construction's allocations, which are most of its time -- are not needed.
- * Images below 2^32 positions that have their pair image. */
-template <bool OUT8>
+ * Images that have their pair image; NARROW: 32-bit positions (awfmImageNarrow). */
+template <int OUT, bool NARROW>
 __global__ void __launch_bounds__(kThreads)
     deepSeedPairLevelKernel(const DevIndex ix, const ulonglong2 *__restrict__ parentLevel, u64 parentLen, u64 outLen,
-                            ulonglong2 *__restrict__ out) {
+                            ulonglong2 *__restrict__ out, u64 *__restrict__ big) {
   constexpr int G = 4;
+  typedef typename PositionType<NARROW>::type pos_t;
   __shared__ u64 sC[24];
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
-  __shared__ u64 sSuper[1];
+  __shared__ u64 sSuper[NARROW ? 1 : kMaxNucSuper * 4];
   __shared__ u64 sPairC[16];
   extern __shared__ unsigned sPairSuper[];
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   stageMaskTable(sMask);
-  nucStageSuper<true>(ix, sSuper);
-  pairStageTables<true, 16u>(ix, sPairC, sPairSuper);
+  nucStageSuper<NARROW>(ix, sSuper);
+  pairStageTables<NARROW, 16u>(ix, sPairC, sPairSuper);
   __syncthreads();
   const unsigned gl = threadIdx.x % G;
   const u64 numGroups = (u64)gridDim.x * kSeedGroupsPerBlock;
   for (u64 e = ((u64)blockIdx.x * kThreads + threadIdx.x) / G; e < outLen; e += numGroups) {
     const unsigned code = (unsigned)(e / parentLen);
     const ulonglong2 r = parentLevel[e % parentLen];
-    unsigned sp = (unsigned)r.x, ep = (unsigned)r.y;
+    pos_t sp = (pos_t)r.x, ep = (pos_t)r.y;
     if (r.x <= r.y) { /* a query stops at its first invalid range and keeps it (ref src/AwFmParallelSearch.c:293-294) */
       const unsigned c2 = code & 3u, c1 = code >> 2;
-      const PairStep did = pairSearchStep<true, true>(ix, sPairC, sPairSuper, sMask, gl, code, sp, ep, sC);
-      if (did == kPairFlagged) nucFastStep<G, true>(ix, sC, sSuper, sMask, gl, c2, sp, ep);
-      if (did != kPairStepped && sp <= ep) nucFastStep<G, true>(ix, sC, sSuper, sMask, gl, c1, sp, ep);
+      const PairStep did = pairSearchStep<NARROW, true>(ix, sPairC, sPairSuper, sMask, gl, code, sp, ep, sC);
+      if (did == kPairFlagged) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, gl, c2, sp, ep);
+      if (did != kPairStepped && sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, gl, c1, sp, ep);
     }
     if (gl == 0) {
-      if (OUT8) ((uint2 *)out)[e] = make_uint2(sp, ep + 1u - sp);
-      else out[e] = r.x <= r.y ? make_ulonglong2((u64)sp, (u64)ep) : r; /* (an empty range is {sp, sp - 1}, sp >= 1) */
+      /* (an empty range is {sp, sp - 1}, sp >= 1; a parent that was empty already is passed on as it is) */
+      if (OUT == 0 && r.x > r.y) out[e] = r;
+      else deepSeedStore<OUT>(out, e, r.x <= r.y ? (u64)sp : r.x, r.x <= r.y ? (u64)ep : r.y, big);
     }
   }
 }
@@ -446,38 +459,59 @@ __global__ void __launch_bounds__(kThreads)
  * d + 1 from level d: entry letter * 4^d + p is entry p after one backward step with `letter`; one group of 4 lanes per entry
  * (nucFastStep: the step of the search kernels), consecutive entries have consecutive parents, whose ranges are neighbours
  * in the BWT.  Images below 2^32 positions. */
+/* WIDE (round 6): the image runs 64-bit positions and the entries are sp36 | length28 << 36, the lengths of 2^28 - 1 and more
+ * in big[(d - 1) * 512 + (sp >> 27)] (awfm_device.h: lengthEntryOpen); `level`: the d of the entries written */
+template <bool WIDE>
+__device__ __forceinline__ void lengthStore(uint2 *__restrict__ out, u64 at, u64 sp, u64 length, u64 *__restrict__ big, unsigned level) {
+  if (WIDE) {
+    out[at] = lengthWidePack(sp, length);
+    if (length >= kLengthWideMask) big[(level - 1u) * kLengthWideBigStride + (unsigned)(sp >> kLengthWideBigShift)] = length;
+  } else {
+    out[at] = make_uint2((unsigned)sp, (unsigned)length);
+  }
+}
+template <bool WIDE>
 __global__ void __launch_bounds__(kThreads)
-    lengthLevelKernel(const DevIndex ix, const uint2 *__restrict__ parentLevel, u64 parentLen, u64 outLen, uint2 *__restrict__ out) {
+    lengthLevelKernel(const DevIndex ix, const uint2 *__restrict__ parentLevel, u64 parentLen, u64 outLen, uint2 *__restrict__ out,
+                      u64 *__restrict__ big, unsigned level) {
   constexpr int G = 4;
+  constexpr bool NARROW = !WIDE;
+  typedef typename PositionType<NARROW>::type pos_t;
   __shared__ u64 sC[24];
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
-  __shared__ u64 sSuper[1];
+  __shared__ u64 sSuper[NARROW ? 1 : kMaxNucSuper * 4];
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   stageMaskTable(sMask);
-  nucStageSuper<true>(ix, sSuper);
+  nucStageSuper<NARROW>(ix, sSuper);
   __syncthreads();
   const unsigned gl = threadIdx.x % G;
   const u64 numGroups = (u64)gridDim.x * kSeedGroupsPerBlock;
+  DevIndex view = ix; /* (the parent level is read in the format this construction writes) */
+  view.deepNarrow = WIDE ? 2u : 1u;
+  view.lengthBig = big;
   for (u64 e = ((u64)blockIdx.x * kThreads + threadIdx.x) / G; e < outLen; e += numGroups) {
     const unsigned letter = (unsigned)(e / parentLen);
-    const uint2 r = parentLevel[e % parentLen];
-    unsigned sp = r.x, ep = r.x + r.y - 1u;
-    if (r.y != 0u) nucFastStep<G, true>(ix, sC, sSuper, sMask, gl, letter, sp, ep);
-    if (gl == 0) out[e] = make_uint2(sp, r.y != 0u && sp <= ep ? ep + 1u - sp : 0u);
+    const ulonglong2 r = lengthEntryOpen(view, level - 1u, parentLevel[e % parentLen]);
+    pos_t sp = (pos_t)r.x, ep = (pos_t)(r.x + r.y - 1ull);
+    if (r.y != 0ull) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, gl, letter, sp, ep);
+    if (gl == 0) lengthStore<WIDE>(out, e, (u64)sp, r.y != 0ull && sp <= ep ? (u64)(ep + (pos_t)1 - sp) : 0ull, big, level);
   }
 }
 
 /* level 1: the letter ranges; level seedK: the index's own table in 8-byte form */
-__global__ void lengthLettersKernel(const DevIndex ix, uint2 *__restrict__ out) {
+template <bool WIDE>
+__global__ void lengthLettersKernel(const DevIndex ix, uint2 *__restrict__ out, u64 *__restrict__ big) {
   if (threadIdx.x < 4u) {
     const u64 first = ix.prefixSums[threadIdx.x], next = ix.prefixSums[threadIdx.x + 1u];
-    out[threadIdx.x] = make_uint2((unsigned)first, (unsigned)(next - first));
+    lengthStore<WIDE>(out, threadIdx.x, first, next - first, big, 1u);
   }
 }
-__global__ void __launch_bounds__(256) lengthFromSeedKernel(const ulonglong2 *__restrict__ seed, u64 len, uint2 *__restrict__ out) {
+template <bool WIDE>
+__global__ void __launch_bounds__(256) lengthFromSeedKernel(const ulonglong2 *__restrict__ seed, u64 len, uint2 *__restrict__ out,
+                                                            u64 *__restrict__ big, unsigned level) {
   for (u64 e = (u64)blockIdx.x * 256u + threadIdx.x; e < len; e += (u64)gridDim.x * 256u) {
     const ulonglong2 r = seed[e];
-    out[e] = make_uint2((unsigned)r.x, r.x <= r.y ? (unsigned)(r.y + 1ull - r.x) : 0u);
+    lengthStore<WIDE>(out, e, r.x, r.x <= r.y ? r.y + 1ull - r.x : 0ull, big, level);
   }
 }
 
@@ -533,18 +567,23 @@ __global__ void packSampledSaKernel(const P *__restrict__ sa, u64 samples, unsig
 
 /* ---- rocPRIM wrappers ---- */
 
+/* sorted (keysIn, valsIn) into (keysOut, valsOut); BOTH pairs of buffers are working space (rocPRIM's double-buffer form: no
+ * third copy of the keys and values in the temporary storage, which at 64-bit positions was 16 of the construction's 49
+ * bytes of HBM per text position -- a two-strand human genome did not fit one GPU with it) */
 template <class K, class V>
 bool sortPairs(K *keysIn, K *keysOut, V *valsIn, V *valsOut, u64 n, unsigned endBit, DeviceBuffer &temp,
                size_t &tempBytes) {
+  rocprim::double_buffer<K> keys(keysIn, keysOut);
+  rocprim::double_buffer<V> vals(valsIn, valsOut);
   size_t need = 0;
-  BUILD_TRY(rocprim::radix_sort_pairs(nullptr, need, keysIn, keysOut, valsIn, valsOut, (size_t)n, 0u, endBit,
-                                      (hipStream_t)0));
+  BUILD_TRY(rocprim::radix_sort_pairs(nullptr, need, keys, vals, (size_t)n, 0u, endBit, (hipStream_t)0));
   if (need > tempBytes) {
     if (!temp.alloc(need)) return false;
     tempBytes = need;
   }
-  BUILD_TRY(rocprim::radix_sort_pairs(temp.p, need, keysIn, keysOut, valsIn, valsOut, (size_t)n, 0u, endBit,
-                                      (hipStream_t)0));
+  BUILD_TRY(rocprim::radix_sort_pairs(temp.p, need, keys, vals, (size_t)n, 0u, endBit, (hipStream_t)0));
+  if (keys.current() != keysOut) BUILD_TRY(hipMemcpyAsync(keysOut, keys.current(), n * sizeof(K), hipMemcpyDeviceToDevice, (hipStream_t)0));
+  if (vals.current() != valsOut) BUILD_TRY(hipMemcpyAsync(valsOut, vals.current(), n * sizeof(V), hipMemcpyDeviceToDevice, (hipStream_t)0));
   return true;
 }
 
@@ -742,11 +781,13 @@ bool launchPackSampledSa(const void *dSa, u64 samples, unsigned ratio, unsigned 
 /* Deeper seed table for the device image: level seedK is the index's own table; level L+1 extends
  * every level-L entry by one more (prepended) letter with the search path's stop-at-first-invalid rule. */
 bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tableOut, uint64_t *bytesOut, uint64_t *peakBytesOut,
-                               double *allocSecondsOut) {
+                               double *allocSecondsOut, unsigned *formatOut, void **bigOut) {
   *tableOut = nullptr;
   *bytesOut = 0;
   if (peakBytesOut) *peakBytesOut = 0;
   if (allocSecondsOut) *allocSecondsOut = 0.0;
+  if (formatOut) *formatOut = 0;
+  if (bigOut) *bigOut = nullptr;
   u64 curBytes = 0; /* the level the next one is made from (0: the index's own table) */
   const unsigned K = g->dev.seedK;
   /* nucleotide: up to 16 characters (2^32 entries); amino: up to 7 (20^7 = 1.28 * 10^9 entries, the index a 32-bit sum) */
@@ -758,49 +799,66 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
   DeviceGuard guard(g->device);
   u64 len = 1;
   for (unsigned i = 0; i < K; i++) len *= card;
-  DeviceBuffer cur, nxt;
+  DeviceBuffer cur, nxt, big;
   const ulonglong2 *parent = g->dev.seed;
-  /* two levels per pass through the pair image where the image has one and runs 32-bit positions (deepSeedPairLevelKernel) */
-  const bool pairLevels = !g->amino && g->dev.pairBlocks && awfmImageNarrow(g) && !getenv("AWFM_GPU_DEEP_SINGLE_LEVELS");
-  const bool pairSuperInLds = pairLevels && awfmPairSuperInLds(g);
+  const bool narrow = awfmImageNarrow(g);
+  /* the table's entries (DevIndex::deepNarrow): 8 bytes {sp, length} where the image runs 32-bit positions (every amino
+   * image below 2^32), 8 bytes sp36 | length12 | next16 for the nucleotide images that run 64-bit ones, up to 2^36 positions
+   * (round 6), 16 bytes {sp, ep} for everything else */
+  const unsigned format = g->dev.bwtLength < (1ull << 32) && (narrow || g->amino) ? 1u
+                          : (!g->amino && formatOut && bigOut && g->dev.bwtLength < (1ull << kDeepWideMaxBits) ? 2u : 0u);
+  if (format == 2u) {
+    const size_t bigBytes = ((size_t)(g->dev.bwtLength >> kDeepWideBigShift) + 2u) * 8u;
+    if (!big.alloc(bigBytes)) return false;
+    BUILD_TRY(hipMemset(big.p, 0, bigBytes));
+  }
+  /* two levels per pass through the pair image where the image has one (deepSeedPairLevelKernel) */
+  const bool pairLevels = !g->amino && g->dev.pairBlocks;
+  const bool pairSuperInLds = pairLevels && narrow && awfmPairSuperInLds(g);
   for (unsigned L = K; L < deepK;) {
     const unsigned levels = pairLevels && deepK - L >= 2u ? 2u : 1u;
     u64 outLen = len;
     for (unsigned i = 0; i < levels; i++) outLen *= card;
-    const bool out8 = L + levels == deepK && g->dev.bwtLength < (1ull << 32); /* the table itself, 8-byte entries */
+    const unsigned out = L + levels == deepK ? format : 0u; /* the table itself */
+    const u64 entryBytes = out ? 8u : 16u;
     struct timespec ta, tb, tc;
     clock_gettime(CLOCK_MONOTONIC, &ta);
-    if (!nxt.alloc(outLen * (out8 ? 8 : 16))) return false;
+    if (!nxt.alloc(outLen * entryBytes)) return false;
     clock_gettime(CLOCK_MONOTONIC, &tb);
     if (allocSecondsOut) *allocSecondsOut += (double)(tb.tv_sec - ta.tv_sec) + 1e-9 * (double)(tb.tv_nsec - ta.tv_nsec);
-    if (peakBytesOut && curBytes + outLen * (out8 ? 8 : 16) > *peakBytesOut) *peakBytesOut = curBytes + outLen * (out8 ? 8 : 16);
+    if (peakBytesOut && curBytes + outLen * entryBytes > *peakBytesOut) *peakBytesOut = curBytes + outLen * entryBytes;
     constexpr int kUnroll = 4;
     const u64 blocks = (outLen + kSeedGroupsPerBlock * kUnroll - 1) / (kSeedGroupsPerBlock * kUnroll);
     const u64 resident = (u64)g->numCUs * 8u; /* a persistent grid: what does not fit the chip would only queue */
     const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
+    u64 *bigAt = big.as<u64>();
     if (levels == 2u) {
       DevIndex dev = g->dev;
       dev.pairSuperInLds = pairSuperInLds ? 1u : 0u;
       const size_t lds = pairSuperInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
       const u64 pairBlocks = (outLen + kSeedGroupsPerBlock - 1) / kSeedGroupsPerBlock;
       const unsigned pairGrid = (unsigned)(pairBlocks < resident ? pairBlocks : resident);
-      if (out8)
-        hipLaunchKernelGGL((deepSeedPairLevelKernel<true>), dim3(pairGrid), dim3(kThreads), lds, 0, dev, parent, len, outLen, nxt.as<ulonglong2>());
-      else
-        hipLaunchKernelGGL((deepSeedPairLevelKernel<false>), dim3(pairGrid), dim3(kThreads), lds, 0, dev, parent, len, outLen, nxt.as<ulonglong2>());
+#define AWFM_PAIR_LEVEL(O, NR) \
+  hipLaunchKernelGGL((deepSeedPairLevelKernel<O, NR>), dim3(pairGrid), dim3(kThreads), lds, 0, dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt)
+      if (narrow) {
+        if (out == 1u) AWFM_PAIR_LEVEL(1, true);
+        else AWFM_PAIR_LEVEL(0, true);
+      } else if (out == 2u) AWFM_PAIR_LEVEL(2, false);
+      else AWFM_PAIR_LEVEL(0, false); /* (format 1 is a narrow image's) */
+#undef AWFM_PAIR_LEVEL
     } else if (g->amino) {
       const u64 aminoBlocks = (outLen + kThreads / 4 - 1) / (kThreads / 4);
       const unsigned aminoGrid = (unsigned)(aminoBlocks < resident ? aminoBlocks : resident);
-      if (out8)
+      if (out == 1u)
         hipLaunchKernelGGL((aminoDeepSeedLevelKernel<true>), dim3(aminoGrid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>());
       else
         hipLaunchKernelGGL((aminoDeepSeedLevelKernel<false>), dim3(aminoGrid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>());
-    } else if (out8)
-      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, true>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen,
-                         nxt.as<ulonglong2>());
+    } else if (out == 2u)
+      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, 2>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
+    else if (out == 1u)
+      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, 1>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
     else
-      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, false>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen,
-                         nxt.as<ulonglong2>());
+      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, 0>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
     BUILD_TRY(hipGetLastError());
     BUILD_TRY(hipDeviceSynchronize());
     clock_gettime(CLOCK_MONOTONIC, &tc);
@@ -809,30 +867,42 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
               (double)(tb.tv_sec - ta.tv_sec) + 1e-9 * (double)(tb.tv_nsec - ta.tv_nsec), (double)(tc.tv_sec - tb.tv_sec) + 1e-9 * (double)(tc.tv_nsec - tb.tv_nsec));
     cur.reset();
     cur.p = nxt.release();
-    curBytes = outLen * (out8 ? 8 : 16);
+    curBytes = outLen * entryBytes;
     parent = cur.as<ulonglong2>();
     len = outLen;
     L += levels;
   }
-  *bytesOut = len * (g->dev.bwtLength < (1ull << 32) ? 8 : 16);
+  *bytesOut = len * (format ? 8 : 16);
   *tableOut = cur.release();
+  if (formatOut) *formatOut = format;
+  if (bigOut) *bigOut = big.release();
   return true;
 }
 
 /* awfm_device.h: the tables of the k-mer lengths 1 .. maxDepth in one allocation, level d at entry awfmLengthTableAt(d) */
-bool awfmGpuBuildLengthTables(const AwFmGpuIndex *g, unsigned maxDepth, void **tableOut, uint64_t *bytesOut) {
+bool awfmGpuBuildLengthTables(const AwFmGpuIndex *g, unsigned maxDepth, void **tableOut, uint64_t *bytesOut, void **bigOut) {
   *tableOut = nullptr;
   *bytesOut = 0;
-  if (g->amino || maxDepth < 1u || maxDepth > 15u || g->dev.bwtLength >= (1ull << 32)) {
-    awfmGpuSetError("length tables: nucleotide images below 2^32 positions, k-mer lengths 1..15");
+  *bigOut = nullptr;
+  /* the entries follow the deeper table's format (DevIndex::deepNarrow): {sp, length} beside format 1, sp36 | length28 beside
+   * format 2 */
+  if (g->amino || maxDepth < 1u || maxDepth > 15u || (g->dev.deepNarrow != 1u && g->dev.deepNarrow != 2u)) {
+    awfmGpuSetError("length tables: nucleotide images with an 8-byte deeper table, k-mer lengths 1..15");
     return false;
   }
+  const bool wide = g->dev.deepNarrow == 2u;
   DeviceGuard guard(g->device);
   const u64 entries = awfmLengthTableAt(maxDepth + 1u);
-  DeviceBuffer table;
+  DeviceBuffer table, big;
   if (!table.alloc(entries * sizeof(uint2))) return false;
+  if (wide) {
+    if (!big.alloc(15u * kLengthWideBigStride * 8u)) return false;
+    BUILD_TRY(hipMemset(big.p, 0, 15u * kLengthWideBigStride * 8u));
+  }
   uint2 *base = table.as<uint2>();
-  hipLaunchKernelGGL(lengthLettersKernel, dim3(1), dim3(64), 0, 0, g->dev, base);
+  u64 *bigAt = big.as<u64>();
+  if (wide) hipLaunchKernelGGL(lengthLettersKernel<true>, dim3(1), dim3(64), 0, 0, g->dev, base, bigAt);
+  else hipLaunchKernelGGL(lengthLettersKernel<false>, dim3(1), dim3(64), 0, 0, g->dev, base, bigAt);
   BUILD_TRY(hipGetLastError());
   const u64 resident = (u64)g->numCUs * 8u;
   u64 len = 4;
@@ -841,17 +911,22 @@ bool awfmGpuBuildLengthTables(const AwFmGpuIndex *g, unsigned maxDepth, void **t
     uint2 *out = base + awfmLengthTableAt(d + 1u);
     if (d + 1u == g->dev.seedK && g->dev.seed) {
       const u64 blocks = (outLen + 255u) / 256u;
-      hipLaunchKernelGGL(lengthFromSeedKernel, dim3((unsigned)(blocks < resident ? blocks : resident)), dim3(256), 0, 0, g->dev.seed, outLen, out);
+      const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
+      if (wide) hipLaunchKernelGGL(lengthFromSeedKernel<true>, dim3(grid), dim3(256), 0, 0, g->dev.seed, outLen, out, bigAt, d + 1u);
+      else hipLaunchKernelGGL(lengthFromSeedKernel<false>, dim3(grid), dim3(256), 0, 0, g->dev.seed, outLen, out, bigAt, d + 1u);
     } else {
       const u64 blocks = (outLen + kSeedGroupsPerBlock - 1) / kSeedGroupsPerBlock;
-      hipLaunchKernelGGL(lengthLevelKernel, dim3((unsigned)(blocks < resident ? blocks : resident)), dim3(kThreads), 0, 0, g->dev,
-                         (const uint2 *)(base + awfmLengthTableAt(d)), len, outLen, out);
+      const unsigned grid = (unsigned)(blocks < resident ? blocks : resident);
+      const uint2 *parent = (const uint2 *)(base + awfmLengthTableAt(d));
+      if (wide) hipLaunchKernelGGL(lengthLevelKernel<true>, dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, out, bigAt, d + 1u);
+      else hipLaunchKernelGGL(lengthLevelKernel<false>, dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, out, bigAt, d + 1u);
     }
     BUILD_TRY(hipGetLastError());
   }
   BUILD_TRY(hipDeviceSynchronize());
   *bytesOut = entries * sizeof(uint2);
   *tableOut = table.release();
+  *bigOut = big.release();
   return true;
 }
 
@@ -1065,8 +1140,25 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
               : launchPackSampledSa<u32>(dSa.p, samples, ratio, width, saWords, dPacked.as<u64>()));
   }
   STEP_HIP(hipDeviceSynchronize());
-  /* (32-bit positions: the array is kept for the image this index gets below, which takes it as its full suffix array) */
-  if (wide) dSa.reset();
+  /* the array is kept for the image this index gets below, which takes it as its full suffix array: 32-bit positions as they
+   * are, 64-bit ones as 40-bit entries (round 6: images of 2^32 positions and more locate through the full array too) */
+  bool stashWide = false;
+  if (wide && config->suffixArrayCompressionRatio > 1 && n < (1ull << 40)) {
+    DeviceBuffer dDense40;
+    if (dDense40.alloc(awfmDenseSaBytes(n, true))) {
+      hipLaunchKernelGGL((packDense40Kernel<u64>), dim3(2048), dim3(256), 0, 0, (const u64 *)dSa.p, n, dDense40.as<unsigned>());
+      STEP_HIP(hipGetLastError());
+      STEP_HIP(hipDeviceSynchronize());
+      dSa.reset();
+      dSa.p = dDense40.release();
+      stashWide = true;
+    } else {
+      (void)hipGetLastError();
+      dSa.reset();
+    }
+  } else if (wide) {
+    dSa.reset();
+  }
 
   /* 5. download the reference-layout arrays */
   STEP_HIP(hipMemcpy(ix->bwtBlockList.asNucleotide, dRef.p, numBlocks * refWords * 8, hipMemcpyDeviceToHost));
@@ -1086,6 +1178,7 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
   if (dSa.p && config->suffixArrayCompressionRatio > 1) { /* hand-over: see awfm_device.h */
     awfmGpuDenseSaStash = dSa.release();
     awfmGpuDenseSaStashLength = n;
+    awfmGpuDenseSaStashWide = stashWide;
   } else {
     dSa.reset();
   }

@@ -223,13 +223,41 @@ static bool orderedApplies(const AwFmGpuIndex *g, bool hasOffsets, uint32_t fixe
  * $AWFM_GPU_TIME_ORDERED set (waits for it); negative when there is none */
 /* awfm_device.h.  Two passes over the finished table: the saturated lengths are counted (so that the side list is
  * allocated exactly and the in-place rewrite cannot fail half-way), then deepNextKernel rewrites the entries. */
-int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **bigOut, unsigned *numBigOut) {
-  *bigOut = nullptr;
+int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, unsigned format, void **bigOut, unsigned *numBigOut) {
   *numBigOut = 0;
-  if (!g || !table || g->dev.bwtLength >= (1ull << 32) || deepK == 0) return 0;
+  if (!g || !table || format == 0u || deepK == 0) return 0;
   if (g->amino ? deepK > 7u : (!g->dev.pairBlocks || deepK > 16u)) return 0;
   if (getenv("AWFM_GPU_DEEP_NEXT") && atoi(getenv("AWFM_GPU_DEEP_NEXT")) == 0) return 0; /* comparison runs */
   DeviceGuard guard(g->device);
+  if (format == 2u) { /* (nucleotide: awfmGpuBuildDeepSeedTable) the table is complete but for its bits; *bigOut holds the long lengths */
+    unsigned *dCount = nullptr;
+    if (hipMalloc((void **)&dCount, 16) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    unsigned numBig = 0;
+    bool ok = hipMemset(dCount, 0, 16) == hipSuccess;
+    if (ok) {
+      DevIndex dev = g->dev;
+      dev.deepNarrow = 2u;
+      dev.deepBigBySp = (const unsigned *)*bigOut;
+      dev.pairSuperInLds = 0u;
+      constexpr int threads = orderedThreads(true);
+      const unsigned grid = residentGrid(g, deepNextKernel<false>, 0, threads);
+      hipLaunchKernelGGL(deepNextKernel<false>, dim3(grid ? grid : 1u), dim3(threads), 0, 0, dev, (uint2 *)table, 1ull << (2u * deepK), (unsigned *)nullptr, dCount);
+      ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipMemcpy(&numBig, dCount, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(dCount);
+    if (!ok) {
+      (void)hipGetLastError();
+      awfmGpuSetError("deep seed table: the pass that adds the next-step bits failed");
+      return -1;
+    }
+    *numBigOut = numBig;
+    return 1;
+  }
+  *bigOut = nullptr;
+  if (g->dev.bwtLength >= (1ull << 32)) return 0;
   if (g->amino) { /* {sp, length12 | next20 << 12}, the long lengths by sp >> 11 (awfm_device.h) */
     unsigned long long numEntries = 1;
     for (unsigned k = 0; k < deepK; k++) numEntries *= 20ull;
@@ -274,8 +302,8 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, void **
     DevIndex dev = g->dev;
     dev.pairSuperInLds = superInLds ? 1u : 0u;
     constexpr int threads = orderedThreads(true);
-    unsigned grid = residentGrid(g, deepNextKernel, lds, threads);
-    hipLaunchKernelGGL(deepNextKernel, dim3(grid ? grid : 1u), dim3(threads), lds, 0, dev, (uint2 *)table, numEntries, dBig, dBig + bigWords);
+    unsigned grid = residentGrid(g, deepNextKernel<true>, lds, threads);
+    hipLaunchKernelGGL(deepNextKernel<true>, dim3(grid ? grid : 1u), dim3(threads), lds, 0, dev, (uint2 *)table, numEntries, dBig, dBig + bigWords);
     ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
          hipMemcpy(&numBig, dBig + bigWords, 4, hipMemcpyDeviceToHost) == hipSuccess;
   }
@@ -437,7 +465,10 @@ static hipError_t gateEnter(AwFmGpuIndex::StreamGate &gate, hipStream_t s) {
   if (gate.lastStream == s && s != nullptr && (gateLazy(s) || gate.lastThread == std::this_thread::get_id())) return hipSuccess;
   if (gate.lastStream == s && s == nullptr && gate.lastThread == std::this_thread::get_id()) return hipSuccess;
   if (gate.pending) { /* the last user left no event behind: now one is needed */
-    if (hipEventRecord(gate.done, gate.lastStream) != hipSuccess) {
+    /* (a stream that was synchronised and destroyed without awfmGpuStreamRetire: its handle no longer answers a query, and
+     * everything it was given is over) */
+    const hipError_t alive = hipStreamQuery(gate.lastStream);
+    if ((alive != hipSuccess && alive != hipErrorNotReady) || hipEventRecord(gate.done, gate.lastStream) != hipSuccess) {
       (void)hipGetLastError();
       const hipError_t e = hipDeviceSynchronize(); /* that stream is gone: whatever it was given has to be over */
       gate.pending = gate.recorded = false;
@@ -606,19 +637,19 @@ static void launchEncodeLookupAt(unsigned len, unsigned grid, size_t lds, hipStr
                                  start, stop);
 }
 
-/* lookupSearchKernel<K> for the batch's k-mer length */
-template <unsigned K>
+/* lookupSearchKernel<K, NARROW> for the batch's k-mer length */
+template <unsigned K, bool NARROW>
 static void launchLookupSearchAt(unsigned len, unsigned grid, size_t lds, hipStream_t s, const DevIndex &dev, const uint8_t *dChars,
                                  const BucketFormat &fmt, unsigned useNext, unsigned long long nq, unsigned long long *codes,
                                  unsigned *numbers, unsigned *shareCount, unsigned *hist, unsigned binsPad,
                                  const unsigned *sampleAlive, unsigned samples, ulonglong2 *rng, unsigned *dCounts,
                                  const SparseOut &sparse, unsigned *keptCounters, hipEvent_t start, hipEvent_t stop) {
   if (len == K)
-    AWFM_LAUNCH_WITH_EVENTS((lookupSearchKernel<K>), dim3(grid), dim3(256), (unsigned)lds, s, start, stop, dev, dChars, fmt, useNext, nq, codes,
+    AWFM_LAUNCH_WITH_EVENTS((lookupSearchKernel<K, NARROW>), dim3(grid), dim3(256), (unsigned)lds, s, start, stop, dev, dChars, fmt, useNext, nq, codes,
                           numbers, shareCount, hist, binsPad, sampleAlive, samples, rng, dCounts, sparse, keptCounters);
   else if constexpr (K > 1u)
-    launchLookupSearchAt<K - 1u>(len, grid, lds, s, dev, dChars, fmt, useNext, nq, codes, numbers, shareCount, hist, binsPad, sampleAlive, samples,
-                                 rng, dCounts, sparse, keptCounters, start, stop);
+    launchLookupSearchAt<K - 1u, NARROW>(len, grid, lds, s, dev, dChars, fmt, useNext, nq, codes, numbers, shareCount, hist, binsPad, sampleAlive, samples,
+                                         rng, dCounts, sparse, keptCounters, start, stop);
 }
 
 /* ---- lookup prediction (AwFmGpuIndex::LookupPredict) ---- */
@@ -637,6 +668,10 @@ static int predictFront(AwFmGpuIndex *g, unsigned fixedLength, unsigned chooseOf
   const unsigned tag = (unsigned)(v >> 32), alive = (unsigned)v;
   const unsigned number = tag & kPredictNumberMask, front = (tag >> 22) & 3u, length = (tag >> 24) & 63u;
   if (number == 0u) return kFrontBoth;
+  /* a verdict is judged -- and followed -- only by a call of its own kind (the tag's k-mer length; 0: a mixed-length batch),
+   * whose threshold `chooseOf` is the one its search was launched under: another kind of batch on the same image neither
+   * counts as a miss nor resets the agreement (advisor, round 5) */
+  if (length != fixedLength) return p.holdoff ? (p.holdoff--, kFrontBoth) : kFrontBoth;
   const bool lookup = alive * 4u < chooseOf; /* lookupChosen's rule (chooseOf: the sample's size, or more of it where the lookup kernel pays up to a higher share) */
   if (number != p.lastJudged) {
     p.lastJudged = number;
@@ -653,7 +688,6 @@ static int predictFront(AwFmGpuIndex *g, unsigned fixedLength, unsigned chooseOf
     p.holdoff--;
     return kFrontBoth;
   }
-  if (length != fixedLength) return kFrontBoth;
   return lookup ? kFrontLookupOnly : kFrontOrderedOnly;
 }
 /* the tag of the next sampled search (never 0 in its number: "no verdict yet") */
@@ -679,7 +713,8 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   /* "lookup first" (encodeLookupKernel): ASCII k-mers that start from the narrow deeper table, results dense or as the list of
    * hits (results in search order owe an entry to every k-mer).  Its k-mer numbers: 4 bytes per k-mer behind the records;
    * share counts and the sample's count: in the counter block, beyond the ticket counters. */
-  const bool lookupCapable = !packed && !touch && awfmImageNarrow(g) && table == g->dev.deepSeed && g->dev.deepNarrow != 0u &&
+  const bool narrow = awfmImageNarrow(g);
+  const bool lookupCapable = !packed && !touch && table == g->dev.deepSeed && g->dev.deepNarrow != 0u &&
                              !(sparse && sparse->kmers && !sparse->count);
   const char *lookupEnv = getenv("AWFM_GPU_LOOKUP_FIRST"); /* 0: never, 1: whenever it applies; unset: by a sample of the batch */
   const bool lookupWanted = lookupCapable && (lookupEnv ? atoi(lookupEnv) != 0 : nq >= (1ull << 20));
@@ -808,19 +843,19 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
     /* fused (default): the k-mers still alive after the table are searched by the kernel that looked them up;
      * $AWFM_GPU_LOOKUP_FUSED=0: they are kept, partitioned and searched by orderedSearchKernel (round 3) */
     const char *fusedEnv = getenv("AWFM_GPU_LOOKUP_FUSED");
-    const bool fused = lookupOnly || !(fusedEnv && atoi(fusedEnv) == 0);
+    const bool fused = lookupOnly || !narrow || !(fusedEnv && atoi(fusedEnv) == 0);
     g->orderLookupFused = fused;
     g->orderFusedKeptAt = (const unsigned *)(w + kKeptAt);
     if (fused) {
       const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
       const char *superEnv = getenv("AWFM_GPU_LOOKUP_PAIR_SUPER"); /* measurement knob: lds | global */
-      const bool superInLds = !pairOff && (superEnv ? !strcmp(superEnv, "lds") : awfmPairSuperInLds(g));
+      const bool superInLds = !pairOff && narrow && (superEnv ? !strcmp(superEnv, "lds") : awfmPairSuperInLds(g));
       DevIndex dev = g->dev;
       dev.pairSuperInLds = superInLds ? 1u : 0u;
       const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
       /* persistent grid: what is resident (7 workgroups per CU), a multiple of the 8 shares */
-      unsigned perCU = 7u;
-      if (const char *env = getenv("AWFM_GPU_LOOKUP_BLOCKS_PER_CU")) perCU = (unsigned)atoi(env) >= 1u ? (unsigned)atoi(env) : 7u;
+      unsigned perCU = narrow ? 7u : 6u; /* (the 64-bit instantiation: 80 registers, 6 waves per SIMD) */
+      if (const char *env = getenv("AWFM_GPU_LOOKUP_BLOCKS_PER_CU")) perCU = (unsigned)atoi(env) >= 1u ? (unsigned)atoi(env) : perCU;
       unsigned fusedGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * perCU ? perShare256 * kShares : (unsigned long long)g->numCUs * perCU);
       fusedGrid = (fusedGrid + kShares - 1u) / kShares * kShares;
       /* A workgroup takes its share 1024 k-mers a trip.  A small batch is a few trips per workgroup -- 6.8 for the 1.25 * 10^7
@@ -843,11 +878,15 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
         (void)hipMemsetAsync(timeline, 0, (size_t)fusedGrid * 128u, s);
         (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(gLookupTimeline), &timeline, sizeof(timeline), 0, hipMemcpyHostToDevice, s);
       }
-      launchLookupSearchAt<32u>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt,
-                                useNext | (pairOff ? 2u : 0u) | (lookupOnly ? 4u : 0u) | (timeline ? 32u : 0u), nq,
-                                (unsigned long long *)(w + codesAt), lookupOnly ? (unsigned *)recs : numbers, lookupOnly ? generalCount : shareCount,
-                                hist, binsPad, sampleAlive, kSamples, rng, dCounts, sparse ? *sparse : SparseOut(),
-                                (unsigned *)(w + kKeptAt), timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr);
+#define AWFM_LOOKUP_GO(NR)                                                                                                               \
+  launchLookupSearchAt<32u, NR>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt,                                                        \
+                                useNext | (pairOff ? 2u : 0u) | (lookupOnly ? 4u : 0u) | (timeline ? 32u : 0u), nq,                      \
+                                (unsigned long long *)(w + codesAt), lookupOnly ? (unsigned *)recs : numbers, lookupOnly ? generalCount : shareCount, \
+                                hist, binsPad, sampleAlive, kSamples, rng, dCounts, sparse ? *sparse : SparseOut(),                      \
+                                (unsigned *)(w + kKeptAt), timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr)
+      if (narrow) AWFM_LOOKUP_GO(true);
+      else AWFM_LOOKUP_GO(false);
+#undef AWFM_LOOKUP_GO
       if (timeline) {
         std::vector<unsigned long long> host((size_t)fusedGrid * 16u);
         if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(host.data(), timeline, host.size() * 8u, hipMemcpyDeviceToHost) == hipSuccess)
@@ -870,10 +909,16 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
      * over the tail of the record array -- the last kernel of the search: it carries the event that says the slot is free */
     enum AwFmReturnCode rc = AwFmSuccess;
     if (!packed) {
-      const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, true, true>);
-      AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, false, false, true, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent,
-                            g->dev, dChars, (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
-                            (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u);
+#define AWFM_LEFT_GO(NR)                                                                                                                 \
+  do {                                                                                                                                   \
+    const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, NR, true>);                                               \
+    AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, false, false, NR, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, \
+                            g->dev, dChars, (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr, \
+                            (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u); \
+  } while (0)
+      if (narrow) AWFM_LEFT_GO(true);
+      else AWFM_LEFT_GO(false);
+#undef AWFM_LEFT_GO
       if (hipGetLastError() != hipSuccess) rc = AwFmGeneralFailure;
       g->orderDoneArmed = g->orderDoneEvent != nullptr;
     }
@@ -911,7 +956,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
                      lookupFirst || bySample ? (const unsigned *)numbers : (const unsigned *)nullptr, sampleAlive, kSamples);
   BUCKET_TRY(hipGetLastError());
   const enum AwFmReturnCode rc =
-      awfmImageNarrow(g) ? launchBucketed<true>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse)
+      narrow ? launchBucketed<true>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse)
                          : launchBucketed<false>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse);
   if (rc != AwFmSuccess) return -(int)rc;
   BUCKET_TRY(slotScope.end());
@@ -947,11 +992,14 @@ static const uint2 *ensureLengthTables(AwFmGpuIndex *g) {
   clock_gettime(CLOCK_MONOTONIC, &t0);
   void *table = nullptr;
   uint64_t bytes = 0;
-  if (!awfmGpuBuildLengthTables(p, need, &table, &bytes)) {
+  void *big = nullptr;
+  if (!awfmGpuBuildLengthTables(p, need, &table, &bytes, &big)) {
     (void)hipGetLastError();
     return nullptr;
   }
   clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (p->dLengthBig) (void)hipFree(p->dLengthBig);
+  p->dLengthBig = big; /* (before the table: whoever finds the table under this mutex finds its long lengths) */
   p->dLengthTable = table;
   p->lengthDepths = need;
   p->lengthTableBytes = bytes;
@@ -982,7 +1030,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
    * 18..30-mers: 9.1 against 10.7 ms) */
   constexpr unsigned kSamples = 16384, kChooseOf = 3u * kSamples;
   const char *mixedEnv = getenv("AWFM_GPU_MIXED_LOOKUP");
-  const bool mixedCapable = off && !touch && !g->amino && awfmImageNarrow(g) && g->dev.deepSeed && g->dev.deepNarrow != 0u &&
+  const bool mixedCapable = off && !touch && !g->amino && g->dev.deepSeed && g->dev.deepNarrow != 0u &&
                             g->dev.deepK >= 2u && g->dev.deepK <= 16u && g->dev.seedK < g->dev.deepK &&
                             !(sparse && sparse->kmers && !sparse->count) /* results in search order owe an entry to every k-mer */;
   const bool mixedForced = mixedCapable && (lookupAlways || (mixedEnv && atoi(mixedEnv) == 1));
@@ -1009,7 +1057,9 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   /* counts only, dense, and nothing but the lookup kernel: it stores every k-mer's count itself, a round's at a time in whole
    * lines (bit 4 of useNext) -- no pre-fill, no 4-byte stores at k-mer numbers ($AWFM_GPU_MIXED_WHOLE_COUNTS=0: as before) */
   const char *wholeEnv = getenv("AWFM_GPU_MIXED_WHOLE_COUNTS");
-  const bool wholeCounts = lookupOnly && !sparse && (dCounts || rng) && !(wholeEnv && atoi(wholeEnv) == 0);
+  /* (not for awfmGpuSearchHitsSparse, whose point is that the ranges of the k-mers WITHOUT hits are not written: 16 of the 20
+   * bytes per k-mer; advisor, round 5) */
+  const bool wholeCounts = lookupOnly && !sparse && (dCounts || rng) && !(rangesOfHitsOnly && dCounts && rng) && !(wholeEnv && atoi(wholeEnv) == 0);
   const size_t total = leftAt + (lengthTable ? alignUp256(nq * 8u) : 0u);
   /* in the counter block, beyond the ticket counters (which end at 65792): the leftover count, the sample's count, the
    * survivor counters (kFusedCounters words a line apart) */
@@ -1076,10 +1126,17 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
     g->orderTimedFront = timed;
     if (timed) g->orderLog[(g->orderLogCount - 1u) % AwFmGpuIndex::kOrderLogMax].front = true;
     /* what the lookup kernel left: the last *leftoverCount records of the list */
-    const unsigned tail = residentGrid(g, searchKernel<false, 4, true, false, true, true>);
-    hipLaunchKernelGGL((searchKernel<false, 4, true, false, true, true>), dim3(tail), dim3(kThreads), 0, s, g->dev, dChars, off, fixedLength, nq, rng,
-                       dCounts, (unsigned long long *)nullptr, (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out,
-                       (const unsigned *)nullptr, 0u);
+    if (awfmImageNarrow(g)) {
+      const unsigned tail = residentGrid(g, searchKernel<false, 4, true, false, true, true>);
+      hipLaunchKernelGGL((searchKernel<false, 4, true, false, true, true>), dim3(tail), dim3(kThreads), 0, s, g->dev, dChars, off, fixedLength, nq, rng,
+                         dCounts, (unsigned long long *)nullptr, (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out,
+                         (const unsigned *)nullptr, 0u);
+    } else {
+      const unsigned tail = residentGrid(g, searchKernel<false, 4, true, false, false, true>);
+      hipLaunchKernelGGL((searchKernel<false, 4, true, false, false, true>), dim3(tail), dim3(kThreads), 0, s, g->dev, dChars, off, fixedLength, nq, rng,
+                         dCounts, (unsigned long long *)nullptr, (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out,
+                         (const unsigned *)nullptr, 0u);
+    }
     WIDE_TRY(hipGetLastError());
     if (lookupOnly) { /* forced or predicted: the other front end is not launched */
       WIDE_TRY(slotScope.end());
@@ -1149,7 +1206,7 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
     if (mode < 0)
       if (const char *env = getenv("AWFM_GPU_ORDERED")) mode = atoi(env) != 0;
     const char *mixedEnv = getenv("AWFM_GPU_MIXED_LOOKUP");
-    lookupAlways = off && !touch && mode != 0 && !g->amino && nq < 0xFFFFFFFFull && awfmImageNarrow(g) && g->dev.deepSeed &&
+    lookupAlways = off && !touch && mode != 0 && !g->amino && nq < 0xFFFFFFFFull && g->dev.deepSeed &&
                    g->dev.deepNarrow != 0u && g->dev.deepK >= 2u && g->dev.deepK <= 16u && g->dev.seedK < g->dev.deepK &&
                    !(sparse && sparse->kmers && !sparse->count) && (mixedEnv ? atoi(mixedEnv) != 0 : nq >= (1ull << 20));
     if (!lookupAlways) return 0;
@@ -1437,7 +1494,7 @@ int awfmGpuAminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
  * general kernel's, and the short k-mers of a CSR batch go to it through the list. */
 int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off, uint32_t fixedLength,
                              unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts) {
-  if (g->amino || !awfmImageNarrow(g) || !g->dev.deepSeed || g->dev.deepNarrow == 0u || g->dev.deepK < 2u || g->dev.deepK > 16u ||
+  if (g->amino || !g->dev.deepSeed || g->dev.deepNarrow == 0u || g->dev.deepK < 2u || g->dev.deepK > 16u ||
       g->dev.seedK >= g->dev.deepK || nq >= 0xFFFFFFFFull)
     return 0;
   if (!(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) return 0;
@@ -1453,7 +1510,9 @@ int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
       if (p->dLengthTable && p->lengthDepths >= g->dev.deepK - 1u) lengthTable = (const uint2 *)p->dLengthTable;
     }
     const char *mixedEnv = getenv("AWFM_GPU_MIXED_LOOKUP");
-    if (!lengthTable && (forced || (off && nq >= (1ull << 20))) && !(mixedEnv && atoi(mixedEnv) == 0)) lengthTable = ensureLengthTables(g);
+    /* (awfmGpuSearch allocates nothing by itself: the tables are used when a hits-only mixed-length batch has built them,
+     * or built here when asked for by $AWFM_GPU_EXACT_LOOKUP=1; advisor, round 5) */
+    if (!lengthTable && forced && !(mixedEnv && atoi(mixedEnv) == 0)) lengthTable = ensureLengthTables(g);
     if (!lengthTable && !off) return 0;
   }
   std::lock_guard<std::mutex> lock(g->orderMutex);
@@ -1478,17 +1537,24 @@ int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
   EXACT_TRY(awfmGpuLaunchExactLookup(g, s, nullptr, nullptr, lengthTable, dChars, off, fixedLength, nq, pairOff, rng, dCounts, leftover, leftoverCount));
   /* what the lookup kernel left, letter by letter (exact by construction): the last kernel of the search carries the event
    * that says the scratch slot is free again */
-  if (off) {
-    const unsigned tail = residentGrid(g, searchKernel<false, 4, true, false, true, true>);
-    AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, true, false, true, true>), dim3(tail), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, g->dev, dChars, off,
-                            fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)leftover, 8u, 0u, nq,
-                            (const unsigned *)leftoverCount, SparseOut(), (const unsigned *)nullptr, 0u);
-  } else {
-    const unsigned tail = residentGrid(g, searchKernel<false, 4, false, false, true, true>);
-    AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, false, false, true, true>), dim3(tail), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, g->dev, dChars,
-                            (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
-                            (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, SparseOut(), (const unsigned *)nullptr, 0u);
+#define AWFM_EXACT_TAIL(CSRV, NR)                                                                                                        \
+  do {                                                                                                                                   \
+    const unsigned tail = residentGrid(g, searchKernel<false, 4, CSRV, false, NR, true>);                                                \
+    AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, CSRV, false, NR, true>), dim3(tail), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, g->dev, dChars, \
+                            (const unsigned long long *)off, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)leftover, 8u, \
+                            0u, nq, (const unsigned *)leftoverCount, SparseOut(), (const unsigned *)nullptr, 0u);                        \
+  } while (0)
+  {
+    const bool narrow = awfmImageNarrow(g);
+    if (off) {
+      if (narrow) AWFM_EXACT_TAIL(true, true);
+      else AWFM_EXACT_TAIL(true, false);
+    } else {
+      if (narrow) AWFM_EXACT_TAIL(false, true);
+      else AWFM_EXACT_TAIL(false, false);
+    }
   }
+#undef AWFM_EXACT_TAIL
   EXACT_TRY(hipGetLastError());
   g->orderDoneArmed = g->orderDoneEvent != nullptr;
   EXACT_TRY(slotScope.end());

@@ -28,7 +28,7 @@ namespace {
 
 /* in-place hand-over between the two kernels: bit 63 set, steps in bits 62..40, sample index in 39..0 */
 /* a walk given up after stepCap steps (the construction of the full suffix array): bit 62 set, the steps walked in bits
- * 61..32, the BWT position it stands at in bits 31..0 (images below 2^32 positions) -- untagged for finishKernel, which
+ * 61..40 (a cap is 32 x ratio: 13 bits), the BWT position it stands at in bits 39..0 -- untagged for finishKernel, which
  * passes it on; awfm_gpu.hip completes such entries from each other */
 constexpr unsigned long long kWalkParked = 1ull << 62;
 constexpr unsigned long long kWalkTag = 1ull << 63;
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(walkThreads(PAIR)) __attribute__((amdgpu_num_s
       /* hand the hit over, or park it */
       const unsigned long long sample = POW2 ? (unsigned long long)(p >> ix.saShift) : (unsigned long long)(p / ratio);
       const unsigned long long result = sampled ? (kWalkTag | ((unsigned long long)steps << 40) | (sample & kWalkSampleMask))
-                                                : (stepCap ? (kWalkParked | ((unsigned long long)steps << 32) | (unsigned long long)(unsigned)p)
+                                                : (stepCap ? (kWalkParked | ((unsigned long long)steps << 40) | ((unsigned long long)p & kWalkSampleMask))
                                                            : (kWalkParked | ((unsigned long long)(steps - (unsigned)maxSteps) << 61) | (unsigned long long)p));
       const bool owner = gl == j / kPerLane;
       const unsigned k = j % kPerLane;

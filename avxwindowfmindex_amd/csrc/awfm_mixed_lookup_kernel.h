@@ -18,6 +18,9 @@
  * the general kernel searches afterwards (INDIRECT; a wave has a slot for every k-mer of its round, so no survivor does).  A sample decides, on the
  * device, between this kernel and the 16-byte-record path for the whole batch (lookupChosen).
  *
+ * Round 6: the kernel exists for 32- and for 64-bit positions (NARROW), and the entries of both kinds of table are read in
+ * whichever format the image built them (DevIndex::deepNarrow; lengthEntryOpen, deepSeedOpen).
+ *
  * Results: every k-mer with hits gets the range the reference reaches for it (the tables hold the ranges of the reference's
  * own seed lookup and steps: see awfmGpuBuildLengthTables; ref src/AwFmSearch.c:485-520, src/AwFmKmerTable.c:4-51,
  * src/AwFmParallelSearch.c:273-313); a k-mer without hits has count 0 and an empty range (the hits-only contract of
@@ -58,28 +61,36 @@ __device__ __forceinline__ void decodeKmerWide(const unsigned char *__restrict__
   codes = c >> (2u * (32u - len)); /* character 0 was in bits 63..62: now the last character is in bits 1..0 */
 }
 
-/* what the table entry of a k-mer says (the same reading in the kernel and in its sample) */
+/* what the table entry of a k-mer says (the same reading in the kernel and in its sample); P: the position type of the
+ * kernel that asks (32 bits on images below 2^32 positions, whatever the entries' format: DevIndex::deepNarrow) */
+template <class P>
 struct MixedVerdict {
-  unsigned length; /* of the entry's range */
-  bool hitNow;     /* the entry is the k-mer's range, and it is not empty */
-  bool survives;   /* characters to go from a range that may still hold the k-mer */
+  P sp, length;  /* the entry's range */
+  bool hitNow;   /* the entry is the k-mer's range, and it is not empty */
+  bool survives; /* characters to go from a range that may still hold the k-mer */
 };
-__device__ __forceinline__ MixedVerdict mixedRead(const DevIndex &ix, unsigned useNext, unsigned len, unsigned long long codes, uint2 entry) {
-  MixedVerdict v;
+template <class P>
+__device__ __forceinline__ MixedVerdict<P> mixedRead(const DevIndex &ix, unsigned useNext, unsigned len, unsigned long long codes, uint2 entry) {
+  MixedVerdict<P> v;
   const unsigned DK = ix.deepK;
-  const bool deep = len >= DK;
-  unsigned length = entry.y, next16 = 0xFFFFu;
-  if (deep && ix.deepNext != 0u) {
-    next16 = length >> 16;
-    length &= 0xFFFFu;
-    if (length == 0xFFFFu) length = deepBigLength(ix, entry.x);
+  unsigned next16 = 0xFFFFu;
+  if (len == 0u) { /* not looked up: whatever was read is not an entry of this k-mer */
+    v.sp = (P)1;
+    v.length = (P)0;
+  } else if (len >= DK) { /* the deeper table's entry */
+    const ulonglong2 r = deepSeedOpen(ix, 0ull, entry, &next16);
+    v.sp = (P)r.x;
+    v.length = (P)(r.y + 1ull - r.x);
+  } else { /* the entry of the k-mer's own length */
+    const ulonglong2 r = lengthEntryOpen(ix, len, entry);
+    v.sp = (P)r.x;
+    v.length = (P)r.y;
   }
-  v.length = length;
-  v.hitNow = len != 0u && len <= DK && length != 0u;
+  v.hitNow = len != 0u && len <= DK && v.length != 0;
   /* the first step from the deeper table is a pair step when two or more characters are left and the image has its pair
    * blocks: its next-step bit says whether that step leaves anything (bit 0 of useNext: the bits are there and in use) */
   const bool bit = (useNext & 1u) == 0u || len < DK + 2u || ((next16 >> ((unsigned)(codes >> (2u * DK)) & 15u)) & 1u) != 0u;
-  v.survives = len > DK && length != 0u && bit && (useNext & 8u) == 0u; /* (bit 3: a measurement knob that drops them) */
+  v.survives = len > DK && v.length != 0 && bit && (useNext & 8u) == 0u; /* (bit 3: a measurement knob that drops them) */
   return v;
 }
 /* where the entry of a k-mer of `len` (>= 1) characters is: entry `at` of the deeper table (len >= deepK) or of the length tables */
@@ -89,6 +100,7 @@ __device__ __forceinline__ const uint2 *mixedEntryAt(const DevIndex &ix, const u
   return lengthTable + (sLevelAt[len] + codes);
 }
 
+template <bool NARROW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
     mixedLookupSearchKernel(const DevIndex ix, const uint2 *__restrict__ lengthTable, const unsigned char *__restrict__ chars,
                             const unsigned long long *__restrict__ offsets, const unsigned long long numQueries, const unsigned useNext,
@@ -96,15 +108,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
                             unsigned *__restrict__ counts, const SparseOut sparse, unsigned long long *__restrict__ leftover,
                             unsigned *__restrict__ leftoverCount, unsigned *__restrict__ keptCounters) {
   constexpr int G = 4;
-  typedef unsigned pos_t; /* narrow images only (awfmImageNarrow: what the 8-byte table entries imply) */
+  /* NARROW: 32-bit positions (awfmImageNarrow); otherwise (round 6) the 64-bit arithmetic of ref src/AwFmIndex.h:88-91 */
+  typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
-  __shared__ unsigned long long sSuper[1];
+  __shared__ unsigned long long sSuper[NARROW ? 1 : kMaxNucSuper * 4];
   __shared__ unsigned long long sPairC[16];
   extern __shared__ unsigned sPairSuper[];
   __shared__ unsigned long long sLevelAt[17];
   __shared__ unsigned long long sRem[4][kMixedSlots];
-  __shared__ unsigned sNum[4][kMixedSlots], sSp[4][kMixedSlots], sEp[4][kMixedSlots], sLeft[4][kMixedSlots];
+  __shared__ unsigned sNum[4][kMixedSlots];
+  __shared__ pos_t sSp[4][kMixedSlots], sEp[4][kMixedSlots];
+  __shared__ unsigned char sLeft[4][kMixedSlots]; /* characters to go: at most 32 */
   __shared__ unsigned char sOdd[4][kMixedSlots]; /* the slots whose k-mer has one last single step to take */
   static_assert(kMixedSlots <= 256u, "slot numbers are bytes");
   constexpr unsigned kHitBuffer = 32;
@@ -123,8 +138,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   if (threadIdx.x < 17) sLevelAt[threadIdx.x] = threadIdx.x >= 1u ? awfmLengthTableAt(threadIdx.x) : 0ull;
   stageMaskTable(sMask);
-  nucStageSuper<true>(ix, sSuper);
-  if (PAIR) pairStageTables<true, 16u>(ix, sPairC, sPairSuper);
+  nucStageSuper<NARROW>(ix, sSuper);
+  if (PAIR) pairStageTables<NARROW, 16u>(ix, sPairC, sPairSuper);
   __syncthreads();
   const unsigned DK = ix.deepK;
   const unsigned long long charsBytes = offsets[numQueries]; /* uniform */
@@ -179,31 +194,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
     unsigned stotal = 0, htotal = 0;
     unsigned long long hmask[4];
     unsigned hbefore[4];
+    /* what the entry settled: {first position, count} to report now (count 0: nothing), or -- WHOLE -- {slot, ~0} of a survivor */
+    pos_t nowSp[4], nowLen[4];
 #pragma unroll
     for (unsigned i = 0; i < 4u; i++) {
       const unsigned long long q = tw + 64ull * i + lane;
-      const MixedVerdict v = mixedRead(ix, useNext, len[i], codes[i], entry[i]);
-      entry[i].y = v.hitNow ? v.length : 0u; /* from here on: the count to report now */
+      const MixedVerdict<pos_t> v = mixedRead<pos_t>(ix, useNext, len[i], codes[i], entry[i]);
+      nowSp[i] = v.sp;
+      nowLen[i] = v.hitNow ? v.length : (pos_t)0;
       if (LIST) {
         hmask[i] = __ballot(v.hitNow);
         hbefore[i] = htotal;
         htotal += (unsigned)__popcll(hmask[i]);
       } else if (v.hitNow && !WHOLE) {
-        if (ranges) ranges[q] = make_ulonglong2((unsigned long long)entry[i].x, (unsigned long long)entry[i].x + v.length - 1ull);
-        if (counts) counts[q] = v.length;
+        if (ranges) ranges[q] = make_ulonglong2((unsigned long long)v.sp, (unsigned long long)v.sp + (unsigned long long)v.length - 1ull);
+        if (counts) counts[q] = (unsigned)v.length;
       }
       const unsigned long long smask = __ballot(v.survives);
       const unsigned rank = stotal + (unsigned)__popcll(smask & ((1ull << lane) - 1ull));
       stotal += (unsigned)__popcll(smask);
       if (v.survives && rank < kMixedSlots) {
         sRem[w][rank] = codes[i] >> (2u * DK);
-        sLeft[w][rank] = len[i] - DK;
+        sLeft[w][rank] = (unsigned char)(len[i] - DK);
         sNum[w][rank] = (unsigned)q;
-        sSp[w][rank] = entry[i].x;
-        sEp[w][rank] = entry[i].x + v.length - 1u;
+        sSp[w][rank] = v.sp;
+        sEp[w][rank] = v.sp + v.length - (pos_t)1;
       }
-      /* (from here on: {slot, ~0} of a survivor, {first position, count} of a k-mer its entry settled) */
-      if (WHOLE && v.survives && rank < kMixedSlots) entry[i] = make_uint2(rank, 0xFFFFFFFFu);
+      if (WHOLE && v.survives && rank < kMixedSlots) {
+        nowSp[i] = (pos_t)rank;
+        nowLen[i] = ~(pos_t)0;
+      }
       const bool left = general[i] || (v.survives && rank >= kMixedSlots);
       const unsigned long long lmask = __ballot(left);
       if (lmask != 0ull) { /* wave-uniform; rare */
@@ -220,11 +240,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
       listBase = (unsigned)__builtin_amdgcn_readfirstlane((int)listBase);
 #pragma unroll
       for (unsigned i = 0; i < 4u; i++)
-        if (entry[i].y != 0u) {
+        if (nowLen[i] != 0) { /* (LIST: never a slot marker) */
           const unsigned at = listBase + hbefore[i] + (unsigned)__popcll(hmask[i] & ((1ull << lane) - 1ull));
           if (at < sparse.cap) {
             sparse.kmers[at] = (unsigned)(tw + 64ull * i + lane);
-            sparse.ranges[at] = make_ulonglong2((unsigned long long)entry[i].x, (unsigned long long)entry[i].x + entry[i].y - 1ull);
+            sparse.ranges[at] = make_ulonglong2((unsigned long long)nowSp[i], (unsigned long long)nowSp[i] + (unsigned long long)nowLen[i] - 1ull);
           }
         }
     }
@@ -286,14 +306,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
         if (live && pos >= stepChars - 1) { /* (a k-mer in a group is alive: sp <= ep) */
           if (PAIR) {
             const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
-            if (pairSearchStep<true>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep) == kPairFlagged) {
-              nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
-              if (sp <= ep) nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
+            if (pairSearchStep<NARROW>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep) == kPairFlagged) {
+              nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
+              if (sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
             }
             pos -= 2;
             rem >>= 4;
           } else {
-            nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+            nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
             pos--;
             rem >>= 2;
           }
@@ -340,7 +360,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
           if (parked) {
             mySlot = sOdd[w][k];
             take();
-            nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+            nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
           }
           report(parked && gl == 0 && sp <= ep);
           if (WHOLE && parked && gl == 0) {
@@ -358,9 +378,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
 #pragma unroll
       for (unsigned i = 0; i < 4u; i++) {
         const unsigned long long q = tw + 64ull * i + lane;
-        const bool slot = entry[i].y == 0xFFFFFFFFu;
-        const pos_t fsp = slot ? sSp[w][entry[i].x] : entry[i].x, fep = slot ? sEp[w][entry[i].x] : entry[i].x + entry[i].y - 1u;
-        const bool hit = slot ? fsp <= fep : entry[i].y != 0u;
+        const bool slot = nowLen[i] == ~(pos_t)0;
+        const unsigned at = slot ? (unsigned)nowSp[i] : 0u;
+        const pos_t fsp = slot ? sSp[w][at] : nowSp[i], fep = slot ? sEp[w][at] : nowSp[i] + nowLen[i] - (pos_t)1;
+        const bool hit = slot ? fsp <= fep : nowLen[i] != 0;
         if (q < numQueries) { /* (k-mers left to the general kernel: no hit until it stores what it finds) */
           if (ranges) ranges[q] = hit ? make_ulonglong2((unsigned long long)fsp, (unsigned long long)fep) : make_ulonglong2(1ull, 0ull);
           if (counts) counts[q] = hit ? (unsigned)(fep - fsp + (pos_t)1) : 0u;
@@ -419,7 +440,7 @@ __global__ void __launch_bounds__(256)
       unsigned long long codes;
       unsigned bad;
       decodeKmer(chars, start, (unsigned)l, codes, bad);
-      alive = bad != 0u || mixedRead(ix, useNext, (unsigned)l, codes, *mixedEntryAt(ix, lengthTable, sLevelAt, (unsigned)l, codes)).survives;
+      alive = bad != 0u || mixedRead<unsigned long long>(ix, useNext, (unsigned)l, codes, *mixedEntryAt(ix, lengthTable, sLevelAt, (unsigned)l, codes)).survives;
     } else {
       alive = true;
     }
@@ -489,11 +510,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
     if (len >= DK) mark(touch.deepLines, (unsigned long long)(at - (const uint2 *)ix.deepSeed) >> 4);
     else mark(touch.lengthLines, (unsigned long long)(at - lengthTable) >> 4);
     const uint2 entry = *at;
-    const MixedVerdict v = mixedRead(ix, useNext, len, codes, entry);
+    const MixedVerdict<unsigned> v = mixedRead<unsigned>(ix, useNext, len, codes, entry);
     if (v.hitNow) hits += gl == 0 ? 1u : 0u;
     if (!v.survives) continue;
     alive += gl == 0 ? 1u : 0u;
-    unsigned sp = entry.x, ep = entry.x + v.length - 1u;
+    unsigned sp = v.sp, ep = v.sp + v.length - 1u;
     unsigned long long rem = codes >> (2u * DK);
     const int first = (int)(len - DK) - 1;
     int pos = first;

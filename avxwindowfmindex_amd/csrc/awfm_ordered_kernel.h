@@ -455,6 +455,7 @@ __global__ void __launch_bounds__(256)
   const unsigned long long size = shareSize(numQueries), first = size * share;
   const unsigned long long last = first + size < numQueries ? first + size : numQueries;
   const unsigned long long tableMask = (1ull << (2u * f.depth)) - 1ull;
+  const unsigned lengthBits = deepLengthBits(ix);
   const unsigned lane = threadIdx.x & 63u;
   unsigned blockBase = 0, blockUsed = 0, blockSlots = 0; /* the wave's block of slots in its share's region (wave-uniform) */
   /* wave-uniform trip count: the append below is a wave-wide exchange */
@@ -514,7 +515,7 @@ __global__ void __launch_bounds__(256)
     unsigned before[4], total = 0;
 #pragma unroll
     for (unsigned i = 0; i < 4u; i++) {
-      const unsigned length = ix.deepNext ? (entry[i].y & 0xFFFFu) : entry[i].y;
+      const unsigned length = entry[i].y & lengthBits;
       const bool bit = !useNext || ((entry[i].y >> (16u + ((unsigned)(codes[i] >> (2u * f.depth)) & 15u))) & 1u) != 0u;
       alive[i] = t + i < last && (bad[i] != 0u || (length != 0u && bit));
       mask[i] = __ballot(alive[i]);
@@ -571,8 +572,8 @@ __global__ void __launch_bounds__(256)
 __device__ unsigned long long *gLookupTimeline = nullptr;
 constexpr unsigned kFusedSlots = 64;    /* survivors a wave takes through the steps at a time */
 constexpr unsigned kFusedCounters = 64; /* words (a line apart) the waves count their survivors into: reporting */
-template <unsigned K>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(7, 8)))
+template <unsigned K, bool NARROW = true>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(NARROW ? 7 : 6, 8)))
     lookupSearchKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const BucketFormat f, const unsigned useNext,
                        const unsigned long long numQueries, unsigned long long *__restrict__ codesOut,
                        unsigned *__restrict__ numbersOut, unsigned *__restrict__ shareCount, unsigned *__restrict__ hist,
@@ -580,7 +581,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
                        ulonglong2 *__restrict__ ranges, unsigned *__restrict__ counts, const SparseOut sparse,
                        unsigned *__restrict__ keptCounters) {
   constexpr int G = 4;
-  typedef unsigned pos_t; /* narrow images only (awfmImageNarrow: what the narrow table entries imply) */
+  /* NARROW: 32-bit positions (awfmImageNarrow); otherwise (round 6) the 64-bit arithmetic of ref src/AwFmIndex.h:88-91 -- the
+   * entries' format (DevIndex::deepNarrow: 1 or 2) is read at run time either way */
+  typedef typename PositionType<NARROW>::type pos_t;
   /* kernel arguments, uniform (one instantiation per k-mer length, not four): pair steps when the image has its pair
    * blocks; the hits into the list when there is one */
   const bool PAIR = ix.pairBlocks != nullptr && (useNext & 2u) == 0u;
@@ -589,11 +592,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
   if (timeline && (threadIdx.x & 63u) == 0u) gLookupTimeline[4u * (4u * blockIdx.x + (threadIdx.x >> 6))] = wall_clock64();
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
-  __shared__ unsigned long long sSuper[1];
+  __shared__ unsigned long long sSuper[NARROW ? 1 : kMaxNucSuper * 4];
   __shared__ unsigned long long sPairC[16];
   extern __shared__ unsigned sPairSuper[];
   __shared__ unsigned long long sCodes[4][kFusedSlots];
-  __shared__ unsigned sNum[4][kFusedSlots], sSp[4][kFusedSlots], sEp[4][kFusedSlots];
+  __shared__ unsigned sNum[4][kFusedSlots];
+  __shared__ pos_t sSp[4][kFusedSlots], sEp[4][kFusedSlots];
   constexpr unsigned kHitBuffer = 32;
   __shared__ unsigned sHitKmers[4][kHitBuffer];
   __shared__ unsigned long long sHitRanges[4][kHitBuffer][2];
@@ -602,8 +606,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
   if (threadIdx.x == 0) sWavesDone = 0u;
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   stageMaskTable(sMask);
-  nucStageSuper<true>(ix, sSuper);
-  if (PAIR) pairStageTables<true, 16u>(ix, sPairC, sPairSuper);
+  nucStageSuper<NARROW>(ix, sSuper);
+  if (PAIR) pairStageTables<NARROW, 16u>(ix, sPairC, sPairSuper);
   __syncthreads();
   const unsigned bins = (1u << f.bucketBits) + 1u;
   constexpr unsigned kLoads = (K + 1u + 3u) / 4u;
@@ -613,6 +617,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
   const unsigned long long size = shareSize(numQueries), first = size * share;
   const unsigned long long last = first + size < numQueries ? first + size : numQueries;
   const unsigned long long tableMask = (1ull << (2u * f.depth)) - 1ull;
+  const unsigned lengthBits = deepLengthBits(ix);
   const unsigned lane = threadIdx.x & 63u, gl = threadIdx.x % G, firstSlice = gl;
   const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   unsigned blockBase = 0, blockUsed = 0, blockSlots = 0; /* the wave's block of slots in its share's region: general k-mers */
@@ -708,7 +713,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
     bool append[4];
 #pragma unroll
     for (unsigned i = 0; i < 4u; i++) {
-      const unsigned length = ix.deepNext ? (entry[i].y & 0xFFFFu) : entry[i].y;
+      const unsigned length = entry[i].y & lengthBits;
       const bool bit = (useNext & 1u) == 0u || ((entry[i].y >> (16u + ((unsigned)(codes[i] >> (2u * f.depth)) & 15u))) & 1u) != 0u;
       const bool general = t + i < last && bad[i] != 0u;
       const bool survives = t + i < last && bad[i] == 0u && length != 0u && bit;
@@ -719,8 +724,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
         const ulonglong2 r = deepSeedOpen(ix, codes[i] & tableMask, entry[i], nullptr);
         sCodes[w][rank] = codes[i];
         sNum[w][rank] = (unsigned)(t + i);
-        sSp[w][rank] = (unsigned)r.x;
-        sEp[w][rank] = (unsigned)r.y;
+        sSp[w][rank] = (pos_t)r.x;
+        sEp[w][rank] = (pos_t)r.y;
       }
       append[i] = general || (survives && rank >= kFusedSlots);
       amask[i] = __ballot(append[i]);
@@ -783,20 +788,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
         if (PAIR) {
           while (pos >= 1 && sp <= ep) {
             const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
-            if (pairSearchStep<true>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep) == kPairFlagged) {
-              nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
-              if (sp <= ep) nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
+            if (pairSearchStep<NARROW>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep) == kPairFlagged) {
+              nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c2, sp, ep);
+              if (sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, c1, sp, ep);
             }
             pos -= 2;
             rem >>= 4;
           }
           if (pos == 0 && sp <= ep) {
-            nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+            nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
             pos--;
           }
         } else {
           while (pos >= 0 && sp <= ep) {
-            nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
+            nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, (unsigned)rem & 3u, sp, ep);
             pos--;
             rem >>= 2;
           }
@@ -874,7 +879,7 @@ __global__ void __launch_bounds__(256)
       alive = true;
     } else {
       const uint2 e = ((const uint2 *)ix.deepSeed)[codes & ((1ull << (2u * depth)) - 1ull)];
-      const unsigned length = ix.deepNext ? (e.y & 0xFFFFu) : e.y;
+      const unsigned length = e.y & deepLengthBits(ix);
       alive = length != 0u && (!useNext || ((e.y >> (16u + ((unsigned)(codes >> (2u * depth)) & 15u))) & 1u) != 0u);
     }
   }
@@ -945,7 +950,7 @@ __global__ void __launch_bounds__(256)
         alive = true;
       } else {
         const uint2 e = ((const uint2 *)ix.deepSeed)[codes & ((1ull << (2u * depth)) - 1ull)];
-        const unsigned length = ix.deepNext ? (e.y & 0xFFFFu) : e.y;
+        const unsigned length = e.y & deepLengthBits(ix);
         alive = length != 0u && (!useNext || ((e.y >> (16u + ((unsigned)(codes >> (2u * depth)) & 15u))) & 1u) != 0u);
       }
     }
@@ -1574,7 +1579,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
    * 13.5 GB in 2.34 ms = 5.8 TB/s of random 128-byte lines, 10.7 GB of them table lines: a variant that gave every LANE a
    * record and a table entry -- 64 lookups per wave instruction -- and handed the k-mers still alive to the groups of 4
    * lanes, 16 per round (ds_permute / ds_bpermute), measured 2.44 ms, and 5.99 against 5.22 ms on planted k-mers.) */
-  const bool rawEntries = NARROW && table == ix.deepSeed && ix.deepNarrow != 0u; /* uniform (narrow entries: narrow images) */
+  const bool rawEntries = table == ix.deepSeed && ix.deepNarrow != 0u; /* uniform: 8-byte entries, whose format deepSeedOpen reads */
   const bool dropByNext = PAIR && !VARLEN && rawEntries && ix.deepNext != 0u && len >= depth + 2u;
   auto tableEntry = [&](unsigned long long codes) -> ulonglong2 {
     const unsigned long long at = codes & tableMask;
@@ -1686,7 +1691,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
           ulonglong2 r;
           if (myDepth == ix.seedK) {
             r = ix.seed[at];
-          } else if (NARROW && ix.deepNarrow != 0u) {
+          } else if (ix.deepNarrow != 0u) {
             unsigned next16;
             r = deepSeedOpen(ix, at, ((const uint2 *)ix.deepSeed)[at], &next16);
             /* the first step from the deeper table is a pair step (below): a clear bit ends the k-mer here */
@@ -1816,20 +1821,25 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
  * range -- the same device functions, flagged blocks through the one-letter image as there -- and bit c of next16 set
  * when the range after step c still holds a position.  A length that does not fit 16 bits goes to bigBySp[sp >> 15]
  * (awfm_device.h: deepBigLength).  Persistent grid, chunks of 16 entries per wave at a fixed stride. */
+/* NARROW: the image runs 32-bit positions and the entries are {sp, length} (format 1), rewritten as {sp, length16 | next16 << 16};
+ * otherwise (round 6) they are format 2 -- sp36 | length12 | next16, the long lengths in `big` already, DevIndex::deepBigBySp of
+ * `ix` set by the caller -- and only the sixteen bits are rewritten. */
+template <bool NARROW>
 __global__ void __launch_bounds__(orderedThreads(true)) __attribute__((amdgpu_num_sgpr(80)))
     deepNextKernel(const DevIndex ix, uint2 *__restrict__ table, const unsigned long long numEntries,
                    unsigned *__restrict__ bigBySp, unsigned *__restrict__ numBig) {
   constexpr int G = 4;
   constexpr int S = (int)kSlices / G;
+  typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
-  __shared__ unsigned long long sSuper[1];
+  __shared__ unsigned long long sSuper[NARROW ? 1 : kMaxNucSuper * 4];
   __shared__ unsigned long long sPairC[16];
   extern __shared__ unsigned sPairSuper[];
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   stageMaskTable(sMask);
-  nucStageSuper<true>(ix, sSuper);
-  pairStageTables<true, 16u>(ix, sPairC, sPairSuper);
+  nucStageSuper<NARROW>(ix, sSuper);
+  pairStageTables<NARROW, 16u>(ix, sPairC, sPairSuper);
   __syncthreads();
   const unsigned gl = threadIdx.x % G, lane = threadIdx.x & 63u;
   const unsigned firstSlice = gl * S;
@@ -1841,22 +1851,31 @@ __global__ void __launch_bounds__(orderedThreads(true)) __attribute__((amdgpu_nu
        base += waveStride) {
     const unsigned long long at = base + lane / G;
     const uint2 e = at < numEntries ? table[at] : make_uint2(1u, 0u);
-    if (e.y != 0u) { /* (0: no such deepK-mer, and {sp, 0} is {sp, 0 | 0 << 16} already) whole groups of 4 lanes */
+    const bool some = NARROW ? e.y != 0u : (e.y & (kDeepWideLengthMask << 4)) != 0u;
+    if (some) { /* (empty: no such deepK-mer, and its entry is final as it is) whole groups of 4 lanes */
+      ulonglong2 r;
+      if (NARROW) r = make_ulonglong2((unsigned long long)e.x, (unsigned long long)e.x + e.y - 1ull);
+      else r = deepSeedOpen(ix, at, e, nullptr);
       unsigned next16 = 0;
       for (unsigned code = 0; code < 16u; code++) {
-        PositionType<true>::type sp = e.x, ep = e.x + e.y - 1u;
-        if (pairSearchStep<true>(ix, sPairC, sPairSuper, sMask, gl, code, sp, ep) == kPairFlagged) {
-          nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, code & 3u, sp, ep);
-          if (sp <= ep) nucFastStep<G, true>(ix, sC, sSuper, sMask, firstSlice, code >> 2, sp, ep);
+        pos_t sp = (pos_t)r.x, ep = (pos_t)r.y;
+        if (pairSearchStep<NARROW>(ix, sPairC, sPairSuper, sMask, gl, code, sp, ep) == kPairFlagged) {
+          nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, code & 3u, sp, ep);
+          if (sp <= ep) nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, firstSlice, code >> 2, sp, ep);
         }
         if (sp <= ep) next16 |= 1u << code;
       }
       if (gl == 0) {
-        if (e.y >= 0xFFFFu) { /* (awfm_device.h: deepBigLength) */
-          bigBySp[e.x >> kDeepBigShift] = e.y;
-          atomicAdd(numBig, 1u);
+        if (NARROW) {
+          if (e.y >= 0xFFFFu) { /* (awfm_device.h: deepBigLength) */
+            bigBySp[e.x >> kDeepBigShift] = e.y;
+            atomicAdd(numBig, 1u);
+          }
+          table[at] = make_uint2(e.x, (e.y < 0xFFFFu ? e.y : 0xFFFFu) | next16 << 16);
+        } else {
+          if (((e.y >> 4) & kDeepWideLengthMask) == kDeepWideLengthMask) atomicAdd(numBig, 1u);
+          table[at] = make_uint2(e.x, (e.y & 0xFFFFu) | next16 << 16);
         }
-        table[at] = make_uint2(e.x, (e.y < 0xFFFFu ? e.y : 0xFFFFu) | next16 << 16);
       }
     }
   }

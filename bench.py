@@ -80,6 +80,7 @@ def parse():
     p.add_argument("--no-secondary", action="store_true", help="skip the planted (every k-mer has a hit) line of the default run")
     p.add_argument("--no-amino", action="store_true", help="skip the amino lines (configs[3]) of the default run's secondary")
     p.add_argument("--no-repetitive", action="store_true", help="skip the genome-shaped-text line of the default run's secondary")
+    p.add_argument("--no-wide", action="store_true", help="skip the 6.2 Gbp index (beyond 2^32 positions) of the default run's secondary")
     p.add_argument("--no-shard-proxy", dest="shard_proxy", action="store_false",
                    help="skip the single-GPU strong-scaling proxy (the shards 2, 4 and 8 ranks would hold, each timed alone)")
     p.add_argument("--proxy-steps", type=int, default=5, help="timed steps per shard of the proxy")
@@ -607,6 +608,205 @@ def repetitive_leg(L, api, digest, torch, np, dev, n=3_100_000_000, Q=100_000_00
     L.awfmGpuIndexRelease(ix.ptr)
     ix.dealloc()
     del d_chars, d_planted_at, d_kmers, d_ranges, d_off, d_scratch, d_pos
+    torch.cuda.empty_cache()
+    return out
+
+
+def wide_leg(L, api, digest, synth, torch, np, dev, n=6_200_000_000, Q=100_000_000, K=21, seed_k=12, sa_ratio=8, steps=5, record_digests=None):
+    """Round 6: an index BEYOND 2^32 positions in the driver's own run -- a two-strand human genome's size, 6.2 Gbp of uniform text,
+    indexed on the device (64-bit suffix sort) -- so that the line shows what the 64-bit instantiations of the fast path do (ref
+    src/AwFmIndex.h:88-91, src/AwFmSuffixArray.c:12-18 are 64-bit throughout): the deeper table in its packed 8-byte form
+    (sp36 | length12 | next16), lookupSearchKernel<K, NARROW = false>, the full suffix array in 40-bit entries.  Two batches with
+    the steps the main line runs: Q random K-mers located in the LIST form (awfmGpuSearchHitsCompact + awfmGpuListLocateOnDevice),
+    and Q K-mers drawn from the text located in SEARCH ORDER (awfmGpuSearchHitsInOrder + hit offsets + awfmGpuLocateOnDevice).
+    Checked: the CPU oracle on the first k-mers of each (ranges, counts, positions in BWT order), planted k-mers at the offsets
+    they were taken from, committed digests of both batches."""
+    t0 = time.time()
+    d_text = torch.empty(n, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthText(d_text.data_ptr(), 0, n, 2, 0, None) == 1
+    torch.cuda.synchronize()
+    ix = api.gpu_create_index(d_text.data_ptr(), api.AwFmAlphabetDna, sa_ratio, seed_k, on_device_length=n, device=dev.index)
+    g = api.GpuIndex(ix, acquire=True)
+    build_s = time.time() - t0
+    assert g.is_wide, "an image of 2^32 positions and more runs the 64-bit instantiations"
+    d_chars = torch.empty(Q * K, dtype=torch.uint8, device=dev)
+    d_planted = torch.empty(Q * K, dtype=torch.uint8, device=dev)
+    assert L.awfmGpuSynthRandomQueries(d_chars.data_ptr(), 0, Q, K, 102, 0, None) == 1
+    assert L.awfmGpuSynthPlantedQueries(d_planted.data_ptr(), 0, Q, K, 103, d_text.data_ptr(), n, None) == 1
+    torch.cuda.synchronize()
+    del d_text
+    torch.cuda.empty_cache()
+    assert g.search_hits_is_ordered(False, K, Q), "the batch is not one for the seed-order path"
+    stream_obj = torch.cuda.Stream()
+    stream = stream_obj.cuda_stream
+    timing = os.environ.get("AWFM_GPU_TIME_ORDERED")
+    os.environ["AWFM_GPU_TIME_ORDERED"] = "1"
+    from oracle import oracle as O
+    oi = O.Index.wrap(O.DNA, sa_ratio, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    threads = min(os.cpu_count() or 1, 16)
+    out = {"workload": f"an index of {n / 1e9:g} Gbp ({ix.bwt_length} BWT positions: beyond 2^32), uniform text, SA ratio {sa_ratio}, seed table k={seed_k}, "
+                       "built on the device; 64-bit positions throughout",
+           "index_build_s": round(build_s, 2), "device_image_bytes": g.device_bytes, "device_seed_k": g.deep_seed_k,
+           "device_dense_sa": bool(g.has_dense_sa), "device_image": g.describe()}
+
+    # ---- random k-mers, the list form (the main line's timed step) ----
+    cap = max(Q // 64, 1024)
+    d_hit_kmers = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_hit_ranges = torch.empty(cap * 2, dtype=torch.int64, device=dev)
+    d_sorted_kmers = torch.empty(cap, dtype=torch.int32, device=dev)
+    d_sorted_ranges = torch.empty(cap * 2, dtype=torch.int64, device=dev)
+    d_hit_off_c = torch.empty(cap + 1, dtype=torch.int64, device=dev)
+    d_num_hits = torch.zeros(1, dtype=torch.int32, device=dev)
+    g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), cap, d_num_hits.data_ptr(), stream=stream)
+    g.list_locate_on_device(d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), cap, d_num_hits.data_ptr(), Q, d_sorted_kmers.data_ptr(),
+                            d_sorted_ranges.data_ptr(), d_hit_off_c.data_ptr(), 0, 0, stream)
+    torch.cuda.synchronize()
+    listed, hits = int(d_num_hits.item()), int(d_hit_off_c[cap].item())
+    assert listed <= cap, "more k-mers with hits than the list holds"
+    cap = min(cap, max(1024, -(-(listed * 5 // 4) // 1024) * 1024))
+    d_pos = torch.empty(hits + hits // 8 + 64, dtype=torch.int64, device=dev)
+
+    def list_step():
+        g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), cap, d_num_hits.data_ptr(), stream=stream)
+        g.list_locate_on_device(d_hit_kmers.data_ptr(), d_hit_ranges.data_ptr(), cap, d_num_hits.data_ptr(), Q, d_sorted_kmers.data_ptr(),
+                                d_sorted_ranges.data_ptr(), d_hit_off_c.data_ptr(), d_pos.numel(), d_pos.data_ptr(), stream)
+
+    for _ in range(3):  # (the lookup prediction settles within two searches)
+        list_step()
+    torch.cuda.synchronize()
+    g.ordered_kernel_log()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        list_step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t1) * 1e3 / steps
+    log = g.ordered_kernel_log()
+    fronts = [f for f, _ in log if f >= 0]
+    kernel_ms = float(np.mean(fronts)) if fronts else float(np.mean([k for _, k in log]))
+    looked_up = bool(g.last_ordered_kernel_is_lookup())
+    assert int(d_num_hits.item()) == listed and int(d_hit_off_c[cap].item()) == hits
+    # the oracle on the first k-mers: every listed k-mer's range and positions, and nothing listed that the oracle does not find
+    ms_ = min(Q, 2_000_000)
+    chars = d_chars[: ms_ * K].cpu().numpy()
+    sp, ep, ocnt, _ = oi.batch_search(chars, np.arange(ms_ + 1, dtype=np.uint64) * np.uint64(K), threads=threads)
+    oho, opos, _ = oi.batch_locate(sp, ep, threads=threads)
+    lk = d_sorted_kmers[:listed].cpu().numpy().view(np.uint32).astype(np.int64)
+    lr = d_sorted_ranges[: 2 * listed].view(listed, 2).cpu().numpy().view(np.uint64)
+    lo = d_hit_off_c[: listed + 1].cpu().numpy().view(np.uint64)
+    assert np.all(np.diff(lk) > 0), "the list is not in k-mer order"
+    mine = lk < ms_
+    want = np.flatnonzero(ocnt != 0)
+    assert np.array_equal(lk[mine], want), "the list names other k-mers than the oracle finds"
+    assert np.array_equal(lr[mine, 0], sp[want]) and np.array_equal(lr[mine, 1], ep[want]), "wide index: GPU ranges differ from the oracle"
+    gp = d_pos[: int(lo[int(mine.sum())])].cpu().numpy().view(np.uint64)
+    assert np.array_equal(gp, opos), "wide index: GPU positions differ from the oracle"
+    counts = torch.zeros(Q, dtype=torch.int64, device=dev)
+    counts[d_sorted_kmers[:listed].to(torch.int64)] = d_hit_off_c[1:listed + 1] - d_hit_off_c[:listed]
+    dense_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=dense_off[1:])
+    key = digest.key("dna", "random", "locate", n, str(K), seed_k, sa_ratio, 0, Q)
+    dig = {"counts": f"{digest.counts_digest(0, counts):016x}", "positions": f"{digest.positions_digest(0, dense_off, d_pos[: max(hits, 1)]):016x}"}
+    committed = digest.load_golden().get(key)
+    assert committed is None or committed == dig, f"wide index: digests {dig} differ from the committed {committed}"
+    known = {key: dig}
+    del counts, dense_off
+    table_lines = Q  # (an upper bound that is within 1.5 % of the tally at this size: one 128-B line per k-mer's entry)
+    out["random"] = {"workload": f"{Q / 1e6:g} M random {K}-mers, locate, list form (awfmGpuSearchHitsCompact + awfmGpuListLocateOnDevice)",
+                     "value": round(Q / ms / 1e3, 2), "unit": "Mkmers/s", "ms_per_step": round(ms, 3), "steps": steps, "kmers_with_hits": listed,
+                     "hits_per_step": hits, "lookup_first": looked_up,
+                     "roofline": {"bound": "hbm", "kernel": "lookupSearchKernel<21, NARROW = false>" if looked_up else "orderedSearchKernel", "kernel_ms": round(kernel_ms, 3),
+                                  "basis": "table lines (one 128-B line per k-mer's 8-byte entry) + characters; the survivors' block lines not counted: a lower bound",
+                                  "bytes": int(128 * table_lines + Q * K), "achieved": round((128 * table_lines + Q * K) / (kernel_ms * 1e-3) / 1e9, 1),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((128 * table_lines + Q * K) / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "traffic": None},
+                     "checked": f"the first {ms_} k-mers against the CPU oracle: which ones are listed, their ranges, every position in BWT order",
+                     "digests": dict(dig, status="match" if committed else "unknown")}
+    del d_hit_kmers, d_hit_ranges, d_sorted_kmers, d_sorted_ranges, d_hit_off_c, d_pos, d_chars
+
+    # ---- k-mers drawn from the text, results in search order (the planted secondary's step) ----
+    d_kmers = torch.empty(Q, dtype=torch.int32, device=dev)
+    d_ranges = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+    d_off = torch.empty(Q + 1, dtype=torch.int64, device=dev)
+    d_scratch = torch.empty(api.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
+    g.search_hits_in_order(d_planted.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
+    g.hit_offsets_on_device(0, d_ranges.data_ptr(), Q, d_off.data_ptr(), d_scratch.data_ptr(), stream)
+    torch.cuda.synchronize()
+    phits = int(d_off[Q].item())
+    d_pos = torch.empty(phits + phits // 8 + 64, dtype=torch.int64, device=dev)
+
+    def order_step():
+        g.search_hits_in_order(d_planted.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
+        g.hit_offsets_on_device(0, d_ranges.data_ptr(), Q, d_off.data_ptr(), d_scratch.data_ptr(), stream)
+        g.locate_on_device(d_ranges.data_ptr(), d_off.data_ptr(), Q, d_pos.numel(), d_pos.data_ptr(), stream)
+
+    order_step()
+    torch.cuda.synchronize()
+    g.ordered_kernel_log()
+    psteps = min(steps, 3)
+    t1 = time.perf_counter()
+    for _ in range(psteps):
+        order_step()
+    torch.cuda.synchronize()
+    pms = (time.perf_counter() - t1) * 1e3 / psteps
+    pkernel_ms = float(np.mean([k for _, k in g.ordered_kernel_log()]))
+    assert int(d_off[Q].item()) == phits
+    kmers = d_kmers.to(torch.int64)
+    assert int(torch.bincount(kmers, minlength=Q).max().item()) == 1, "a k-mer is missing from the order or listed twice"
+    lens = d_off[1:] - d_off[:-1]
+    assert int(lens.min().item()) >= 1, "a k-mer drawn from the text was not found"
+    m = min(Q, 1_000_000)
+    slot = torch.empty(Q, dtype=torch.int64, device=dev)
+    slot[kmers] = torch.arange(Q, dtype=torch.int64, device=dev)
+    sl = slot[:m]
+    planted_at = synth.planted_offsets(103, m, K, n, first=0)
+    starts, cnts = d_off[:-1][sl].cpu().numpy(), lens[sl].cpu().numpy()
+    firsts = d_pos[d_off[:-1][sl]].cpu().numpy().view(np.uint64)
+    one = cnts == 1
+    assert np.array_equal(firsts[one], planted_at[one]), "a k-mer drawn from the text was located somewhere else"
+    for i in np.flatnonzero(~one)[:1000]:
+        assert planted_at[i] in d_pos[int(starts[i]): int(starts[i]) + int(cnts[i])].cpu().numpy().view(np.uint64), "a k-mer's own offset is missing from its hit list"
+    mo = min(Q, 200_000)
+    chars = d_planted[: mo * K].cpu().numpy()
+    sp, ep, ocnt, _ = oi.batch_search(chars, np.arange(mo + 1, dtype=np.uint64) * np.uint64(K), threads=threads)
+    oho, opos, _ = oi.batch_locate(sp, ep, threads=threads)
+    gr = d_ranges.view(Q, 2)[slot[:mo]].cpu().numpy().view(np.uint64)
+    assert np.array_equal(gr[:, 0], sp) and np.array_equal(gr[:, 1], ep), "wide index, planted: GPU ranges differ from the oracle"
+    gpos = np.concatenate([d_pos[int(a): int(a) + int(c)].cpu().numpy() for a, c in zip(starts[:2000], cnts[:2000])]).view(np.uint64)
+    assert np.array_equal(gpos, opos[: int(oho[2000])]), "wide index, planted: GPU positions differ from the oracle"
+    counts = torch.zeros(Q, dtype=torch.int64, device=dev)
+    counts[kmers] = lens
+    dense_off = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=dense_off[1:])
+    dense_pos = torch.empty(max(phits, 1), dtype=torch.int64, device=dev)
+    step_q = 1 << 24
+    for b in range(0, Q, step_q):
+        e = min(Q, b + step_q)
+        lo_, hi_ = int(d_off[b].item()), int(d_off[e].item())
+        if hi_ > lo_:
+            shift = torch.repeat_interleave(dense_off[:-1][kmers[b:e]] - d_off[b:e], lens[b:e])
+            dense_pos[shift + torch.arange(lo_, hi_, dtype=torch.int64, device=dev)] = d_pos[lo_:hi_]
+    pkey = digest.key("dna", "planted", "locate", n, str(K), seed_k, sa_ratio, 0, Q)
+    pdig = {"counts": f"{digest.counts_digest(0, counts):016x}", "positions": f"{digest.positions_digest(0, dense_off, dense_pos[: max(phits, 1)]):016x}"}
+    pcommitted = digest.load_golden().get(pkey)
+    assert pcommitted is None or pcommitted == pdig, f"wide index, planted: digests {pdig} differ from the committed {pcommitted}"
+    known[pkey] = pdig
+    out["planted"] = {"workload": f"{Q / 1e6:g} M {K}-mers drawn from the text (every k-mer has >= 1 hit), locate, results in search order",
+                      "value": round(Q / pms / 1e3, 2), "unit": "Mkmers/s", "ms_per_step": round(pms, 3), "steps": psteps, "hits_per_step": phits,
+                      "kernel": "orderedSearchKernel<..., NARROW = false>", "kernel_ms": round(pkernel_ms, 3),
+                      "checked": f"every k-mer once in the order; the first {m} k-mers located where they were taken from; ranges of the first {mo} and "
+                                 "positions of the first 2000 against the CPU oracle",
+                      "digests": dict(pdig, status="match" if pcommitted else "unknown")}
+    out["value"], out["value_present_kmers"], out["unit"] = out["random"]["value"], out["planted"]["value"], "Mkmers/s"
+    if record_digests:
+        have = json.load(open(record_digests)) if os.path.exists(record_digests) else {}
+        have.update(known)
+        json.dump(have, open(record_digests, "w"), indent=1, sort_keys=True)
+    if timing is None:
+        del os.environ["AWFM_GPU_TIME_ORDERED"]
+    g.handle = None
+    L.awfmGpuIndexRelease(ix.ptr)
+    ix.dealloc()
+    del d_planted, d_kmers, d_ranges, d_off, d_scratch, d_pos, counts, dense_off, dense_pos, slot, lens, kmers
     torch.cuda.empty_cache()
     return out
 
@@ -1851,6 +2051,20 @@ def main():
         lst.dealloc()
         g = None
 
+    # ---- round 6: the same steps on an index BEYOND 2^32 positions (6.2 Gbp: a two-strand human genome's size), built here once
+    # this run's own image is gone -- the 64-bit suffix sort takes 33 bytes of HBM per text position at its peak (wide_leg) ----
+    if secondary is not None and not args.no_wide and not amino and world == 1 and time.time() - T_START < 400:
+        if g is not None:
+            g.handle = None
+            g = None
+        L.awfmGpuIndexRelease(ix.ptr)
+        pos_buf["t"] = None
+        for ln in lanes:
+            ln.pos = None
+        torch.cuda.empty_cache()
+        from avxwindowfmindex_amd import synth as _synth
+        secondary["wide"] = wide_leg(L, api, digest, _synth, torch, np, dev, record_digests=args.record_digests)
+
     # the clocks this box runs at (boxes of the pool differ by several per cent on the same code: the line says which one it
     # was).  Read from sysfs -- no child process: a process that has initialised the GPU must not start one.
     clocks = None
@@ -1927,6 +2141,12 @@ def main():
                 config[name + "_value"] = secondary[name]["value"]
                 config[name + "_ms_per_step"] = secondary[name]["ms_per_step"]
                 config[name + "_roofline_frac"] = secondary[name]["roofline"].get("frac")
+        if "wide" in secondary:
+            config["wide_value"] = secondary["wide"]["random"]["value"]
+            config["wide_ms_per_step"] = secondary["wide"]["random"]["ms_per_step"]
+            config["wide_roofline_frac"] = secondary["wide"]["random"]["roofline"]["frac"]
+            config["wide_planted_value"] = secondary["wide"]["planted"]["value"]
+            config["wide_planted_ms_per_step"] = secondary["wide"]["planted"]["ms_per_step"]
     if clocks:
         config["gpu_clocks"] = clocks
         for name in ("sclk", "mclk", "fclk"):

@@ -158,7 +158,9 @@ enum AwFmReturnCode awfmGpuCreateIndex(struct AwFmIndex **index, const struct Aw
  * CSR offsets into dChars) or, with dOffsets == NULL, fixedLength characters
  * per query.  Outputs (each may be NULL): dRanges[numQueries] = final {sp,ep},
  * dCounts[numQueries] = range length truncated to u32
- * (ref src/AwFmIndexStruct.c:126-130).  Asynchronous on `stream`. */
+ * (ref src/AwFmIndexStruct.c:126-130).  Asynchronous on `stream`; allocates no table: large batches read the image's
+ * device-only tables where it has them (the deeper table; the tables per k-mer length once a hits-only mixed-length batch
+ * has built them), and scratch of 8 bytes per k-mer in one of the image's two slots. */
 enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                   uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
                                   uint32_t *dCounts, void *stream);

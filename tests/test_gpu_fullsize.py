@@ -323,7 +323,9 @@ def test_full_suffix_array_of_a_genome_shaped_index_at_full_size(awfm, require_g
     t0 = time.perf_counter()
     g1 = awfm.GpuIndex(ix, acquire=True)
     acquire_s = time.perf_counter() - t0
-    assert g1.has_dense_sa and g1.dense_sa_build_s < 5.0, (g1.has_dense_sa, g1.dense_sa_build_s, acquire_s)
+    # (seconds, not the 566 s of walking every position to the end: 0.9 s of kernels; a fresh box's first large hipMalloc calls
+    # have taken 5 s by themselves -- round 6's first run on the pool: 5.5 s --, hence the margin)
+    assert g1.has_dense_sa and g1.dense_sa_build_s < 15.0, (g1.has_dense_sa, g1.dense_sa_build_s, acquire_s)
     off1, pos1 = locate(g1, total)
     assert torch.equal(off0, off1) and torch.equal(pos0, pos1), "the automatic full suffix array gives other positions than the builder's"
     # no array: the LF walk (the 10^6 k-mers from the unique sequence; a walk from behind a run is as long as the run)
@@ -335,7 +337,7 @@ def test_full_suffix_array_of_a_genome_shaped_index_at_full_size(awfm, require_g
     g1.set_dense_sa(True)
     torch.cuda.synchronize()
     asked_s = time.perf_counter() - t0
-    assert g1.has_dense_sa and asked_s < 10.0, asked_s
+    assert g1.has_dense_sa and asked_s < 15.0, asked_s
     off3, pos3 = locate(g1, total)
     assert torch.equal(off0, off3) and torch.equal(pos0, pos3), "the full suffix array that was asked for gives other positions"
     g1.handle = None

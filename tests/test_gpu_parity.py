@@ -288,7 +288,10 @@ def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, requir
     g.set_deep_seed(deep_k)
     # {sp, length}: 8 bytes per entry below 2^32 positions; with the next-step bits (images with pair blocks) the lengths of
     # 65535 and more have a table of their own, a word per 2^15 positions
-    assert g.device_bytes - before - 8 * 4 ** deep_k in (0, 4 * ((ix.bwt_length >> 15) + 5))
+    # (round 6: an image that runs 64-bit positions has sp36 | length12 | next16 entries and 64-bit lengths of 4095 and more, a
+    # word per 2^11 positions)
+    side = 8 * ((ix.bwt_length >> 11) + 2) if g.is_wide else 4 * ((ix.bwt_length >> 15) + 5)
+    assert g.device_bytes - before - 8 * 4 ** deep_k in ((side,) if g.is_wide else (0, side))
     ranges, ho, p = g.locate_host(chars, offsets)
     assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep)
     assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
@@ -502,7 +505,8 @@ def test_device_dense_sa_keeps_positions_bit_identical(oracle, awfm, require_gpu
     g = awfm.GpuIndex(ix)
     before = g.device_bytes
     g.set_dense_sa(True)
-    assert g.device_bytes == before + 4 * ix.bwt_length
+    # 32-bit entries; 40-bit ones, packed five bytes apiece, for an image that runs 64-bit positions (round 6)
+    assert g.device_bytes == before + ((ix.bwt_length + 3) // 4 * 20 + 16 if g.is_wide else 4 * ix.bwt_length)
     _, ho, p = g.locate_host(chars, offsets)
     assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
     g.set_dense_sa(False)

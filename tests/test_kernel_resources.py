@@ -96,8 +96,11 @@ def test_lookup_search_kernels_resources(kernel_metadata):
     dominant kernel of the headline batch -- must keep 7 waves per SIMD (72 registers; it spills 14 in its decode phase by
     choice: 80 registers and 6 waves left 25 spilled and fewer lookups in flight), aminoLookupSearchKernel<10> spills nothing;
     the first keeps its LDS small enough for 7 workgroups per CU beside the pair image's superblock bases"""
-    k = _one(kernel_metadata, r"lookupSearchKernelILj21EEE")
+    k = _one(kernel_metadata, r"lookupSearchKernelILj21ELb1EEE")
     assert k["vgpr"] <= 72 and k["spill"] <= 16 and k["scratch"] <= 64 and k["lds"] <= 12 * 1024
+    # its 64-bit instantiation (round 6: images of 2^32 positions and more): 6 waves per SIMD, nothing spilled
+    k = _one(kernel_metadata, r"lookupSearchKernelILj21ELb0EEE")
+    assert k["vgpr"] <= 80 and k["spill"] == 0 and k["scratch"] == 0 and k["lds"] <= 16 * 1024
     # (round 5: a slot for every k-mer of a round -- 256 per wave, 25 KB of LDS per workgroup, and groups that refill as they
     # finish: 6 workgroups per CU, 6 waves per SIMD)
     k = _one(kernel_metadata, r"[0-9]aminoLookupSearchKernelILj10EEE")
