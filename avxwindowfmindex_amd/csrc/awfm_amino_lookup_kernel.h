@@ -260,37 +260,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
   }
 }
 
-/* how many of `samples` k-mers at a fixed stride are alive after the deeper table (or are not the table's: a character that
- * is not one of the 20 letters): says beforehand whether the batch is one for aminoLookupSearchKernel */
-__global__ void __launch_bounds__(256)
-    aminoSampleAliveKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const unsigned fixedLen,
-                           const unsigned long long numQueries, const unsigned samples, unsigned *__restrict__ aliveOut) {
-  __shared__ AminoShared sAmino;
-  __shared__ unsigned sAlive;
-  aminoStageTables(sAmino);
-  if (threadIdx.x == 0) sAlive = 0u;
-  __syncthreads();
-  const unsigned j = blockIdx.x * 256u + threadIdx.x;
-  bool alive = false;
-  if (j < samples) {
-    const unsigned char *at = chars + (unsigned long long)j * (numQueries / samples) * fixedLen;
-    unsigned idx = 0;
-    bool bad = false;
-    for (unsigned c = fixedLen - ix.deepK; c < fixedLen; c++) {
-      const unsigned letter = aminoLetterIndex(sAmino, at[c]);
-      idx = idx * 20u + letter;
-      bad |= letter >= 20u;
-    }
-    const uint2 e = ((const uint2 *)ix.deepSeed)[bad ? 0u : idx];
-    const unsigned nextLetter = fixedLen > ix.deepK ? aminoLetterIndex(sAmino, at[fixedLen - ix.deepK - 1u]) : 20u;
-    alive = bad || (aminoDeepLength(ix, e) != 0u && aminoDeepNextBit(ix, e, nextLetter));
-  }
-  const unsigned n = (unsigned)__popcll(__ballot(alive));
-  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&sAlive, n);
-  __syncthreads();
-  if (threadIdx.x == 0 && sAlive) atomicAdd(aliveOut, sAlive);
-}
-
 }  // namespace
 
 #endif

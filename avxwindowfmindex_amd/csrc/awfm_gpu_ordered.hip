@@ -1,9 +1,12 @@
 /*
- * awfm_gpu_ordered.hip -- host side of the ordered hits-only search (awfm_ordered_kernel.h): decides whether a
- * batch takes it, owns its scratch memory in the device image, and launches
- *   fillNoHitKernel -> encodeQueriesKernel -> rocprim::radix_sort_pairs -> orderedSearchKernel -> searchKernel<INDIRECT>
- * on the caller's stream.  Called by awfmGpuSearchHits (awfm_gpu.hip); nothing here synchronises with the host
- * except a scratch (re)allocation.
+ * awfm_gpu_ordered.hip -- host side of the hits-only searches of large batches (awfm_ordered_kernel.h and the lookup kernels):
+ * decides which path a batch takes, owns the scratch memory in the device image (two slots, gated across streams), and
+ * launches, on the caller's stream,
+ *   lookupPrepKernel -> lookupSearchKernel -> searchKernel<INDIRECT>                                   (lookup first, predicted)
+ *   ... -> encodeCodes4Kernel -> bucketScanSharesKernel -> partitionKernel -> orderedSearchKernel -> searchKernel<INDIRECT>
+ * for fixed-length batches (8-byte records), the same passes over 16-byte records or mixedLookupSearchKernel for the others,
+ * aminoLookupSearchKernel for amino batches, exactLookupSearchKernel behind awfmGpuSearch.  Called by awfmGpuSearchHits
+ * (awfm_gpu.hip); nothing here synchronises with the host except a scratch (re)allocation.
  */
 #include <cstring>
 #include <cstdio>
@@ -12,7 +15,7 @@
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-#include <rocprim/rocprim.hpp>
+#include <rocprim/rocprim.hpp> /* awfmGpuSortHits: the list of hits sorted with its length known on the host */
 
 #include "awfm_ordered_kernel.h"
 #include "awfm_amino_lookup_kernel.h"
@@ -40,60 +43,36 @@ inline hipError_t fillSparseList(const SparseOut *sparse, hipStream_t s) {
 constexpr size_t kOrderCounterBytes = 131072; /* 256 B for the count + 8 XCDs x kTicketGroups x 8 waves x 256 B of ticket counters */
 static_assert(256 + 8 * kTicketGroups * 8 * 256 <= kOrderCounterBytes, "ticket counters");
 
-struct OrderScratch {
-  size_t keysIn, keysOut, recsIn, recsOut, generalCount, sortTemp, total;
-};
-
-OrderScratch scratchLayout(uint64_t n, size_t recordBytes, size_t sortTempBytes) {
-  OrderScratch l;
-  size_t at = 0;
-  l.generalCount = at; /* word 0: the count; words 64, 128, ...: the ticket counters (8 XCDs x up to 8 waves) */
-  at += kOrderCounterBytes;
-  l.keysIn = at;
-  at += alignUp256(n * sizeof(unsigned short));
-  l.keysOut = at;
-  at += alignUp256(n * sizeof(unsigned short));
-  l.recsIn = at;
-  at += alignUp256(n * recordBytes);
-  l.recsOut = at;
-  at += alignUp256(n * recordBytes);
-  l.sortTemp = at;
-  at += alignUp256(sortTempBytes ? sortTempBytes : 256);
-  l.total = at;
-  return l;
-}
-
 template <class Kernel>
 unsigned residentGrid(const AwFmGpuIndex *g, Kernel kernel, size_t dynamicLds = 0, int threads = kThreads) {
   int perCU = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, threads, dynamicLds) != hipSuccess || perCU < 1) perCU = 4;
   if (perCU > 8) perCU = 8;
-  if (const char *env = getenv("AWFM_GPU_BLOCKS_PER_CU")) {
-    const int v = atoi(env);
-    if (v >= 1 && v <= 64) perCU = v;
-  }
   return (unsigned)g->numCUs * (unsigned)perCU;
 }
 
-template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false, bool LIST = false>
+/* does the image step two characters per block read?  ($AWFM_GPU_PAIR=0 leaves the pair image out altogether) */
+inline bool pairSteps(const AwFmGpuIndex *g) { return g->dev.pairBlocks != nullptr; }
+
+template <bool NARROW, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false, bool LIST = false>
 enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t len, unsigned depth, const ulonglong2 *table,
-                                        unsigned long long nq, const void *recs, const unsigned short *keys,
-                                        const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts,
-                                        const OrderTouch *touch = nullptr, const unsigned *bucketStart = nullptr,
+                                        unsigned long long nq, const void *recs, const unsigned *generalCount, ulonglong2 *rng,
+                                        uint32_t *dCounts, const OrderTouch *touch = nullptr, const unsigned *bucketStart = nullptr,
                                         const BucketFormat bucketFmt = BucketFormat(), const SparseOut *sparse = nullptr,
                                         const unsigned *skipSampleAlive = nullptr, unsigned skipSamples = 0u) {
+  constexpr int G = 4;
   /* dynamic LDS: the 32-bit superblock bases of the pair image (images below 2^32 positions) */
   const bool superInLds = PAIR && NARROW && awfmPairSuperInLds(g);
   const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u; /* the 16 pair bases of every superblock */
   DevIndex dev = g->dev;
   dev.pairSuperInLds = superInLds ? 1u : 0u;
   constexpr int threads = orderedThreads(PAIR);
-  unsigned grid = residentGrid(g, orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET, LIST>, lds, threads);
+  unsigned grid = residentGrid(g, orderedSearchKernel<G, NARROW, VARLEN, PAIR, TOUCH, BUCKET, LIST>, lds, threads);
   const unsigned long long blocks = (nq + threads / G - 1) / (threads / G);
   if (blocks < grid) grid = (unsigned)blocks;
   if (grid >= 8u) grid &= ~7u; /* a multiple of the 8 XCDs, so that every XCD gets the same number of workgroups */
   /* measurement hook (bench.py): HIP events around the kernel on its launch stream (events [2],[3]; when the call's
-   * dominant kernel was encodeLookupKernel its own events [0],[1] are the ones reported) */
+   * dominant kernel was the lookup kernel its own events [0],[1] are the ones reported) */
   /* (the events ride on the kernel's own dispatch -- hipExtLaunchKernelGGL -- instead of being recorded around it: a
    * recorded event is a packet of its own and left the queue idle for about 5 us each, 24 us per search) */
   const bool timed = g->orderTiming[2] != nullptr; /* this search has an entry in the timing log */
@@ -102,62 +81,54 @@ enum AwFmReturnCode launchOrderedKernel(AwFmGpuIndex *g, hipStream_t s, uint32_t
     skip.sampleAlive = skipSampleAlive;
     skip.samples = skipSamples;
   }
-  AWFM_LAUNCH_WITH_EVENTS((orderedSearchKernel<G, NARROW, COMPACT, VARLEN, PAIR, TOUCH, BUCKET, LIST>), dim3(grid ? grid : 1u), dim3(threads), (unsigned)lds, s,
-                        timed ? g->orderTiming[2] : nullptr, timed ? g->orderTiming[3] : nullptr, dev, recs,
-                        keys, nq, generalCount, len, depth, table, rng, dCounts, (unsigned *)generalCount + 64,
-                        getenv("AWFM_GPU_XCD_MAP") ? atoi(getenv("AWFM_GPU_XCD_MAP")) : 0, touch ? *touch : OrderTouch(), bucketStart,
-                        bucketFmt, sparse ? *sparse : SparseOut(),
+  AWFM_LAUNCH_WITH_EVENTS((orderedSearchKernel<G, NARROW, VARLEN, PAIR, TOUCH, BUCKET, LIST>), dim3(grid ? grid : 1u), dim3(threads), (unsigned)lds, s,
+                        timed ? g->orderTiming[2] : nullptr, timed ? g->orderTiming[3] : nullptr, dev, recs, nq, generalCount, len, depth, table,
+                        rng, dCounts, (unsigned *)generalCount + 64, touch ? *touch : OrderTouch(), bucketStart, bucketFmt,
+                        sparse ? *sparse : SparseOut(),
                         /* chunks a ticket is worth: 10^8 random 21-mers 3.92 (1), 3.49 (2), 3.47 (4), 3.50 (8), 3.65 ms (16); planted
                          * 21-mers (round 4, the batches this kernel still sees whole: the others end in lookupSearchKernel) 5.06 (1),
                          * 5.01 (2), 5.19 (3), 5.18 (4): the records in flight on an XCD span fewer buckets.  Mixed lengths: no gain */
-                        getenv("AWFM_GPU_CHUNKS_PER_TICKET") && atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) >= 1 ? (unsigned)atoi(getenv("AWFM_GPU_CHUNKS_PER_TICKET")) : (BUCKET ? 2u : 1u),
-                        skip);
+                        BUCKET ? 2u : 1u, skip);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   g->orderTimedKernel = timed;
   if (timed) g->orderLog[(g->orderLogCount - 1u) % AwFmGpuIndex::kOrderLogMax].kernel = true;
   return AwFmSuccess;
 }
 
-template <bool NARROW, bool COMPACT, bool VARLEN>
+/* the general kernel over what a hits-only front end left (the last *leftCount of the `numRecs` 8-byte or 16-byte records at
+ * `recs`: k-mers with ambiguity characters, none or more than 32 characters, survivors beyond a round's slots) -- the last
+ * kernel of a search: it carries the event that says the scratch slot is free again */
+template <bool NARROW, bool CSR>
+enum AwFmReturnCode launchLeftover(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off, uint32_t len,
+                                   unsigned long long nq, ulonglong2 *rng, uint32_t *dCounts, const void *recs, unsigned recordBytes,
+                                   unsigned indexAt, const unsigned *leftCount, const SparseOut *sparse, bool last = true) {
+  const unsigned grid = residentGrid(g, searchKernel<false, 4, CSR, false, NARROW, true>);
+  AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, CSR, false, NARROW, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, last ? g->orderDoneEvent : nullptr,
+                          g->dev, dChars, off, len, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)recs, recordBytes,
+                          indexAt, nq, leftCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  if (last) g->orderDoneArmed = g->orderDoneEvent != nullptr;
+  return AwFmSuccess;
+}
+
+/* the search over 16-byte records (partitionRecordsKernel), then the general kernel over the last bin */
+template <bool NARROW, bool VARLEN>
 enum AwFmReturnCode launchOrdered(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, const unsigned long long *off,
                                   uint32_t len, unsigned depth, const ulonglong2 *table, unsigned long long nq,
-                                  const void *recs, const unsigned short *keys, const unsigned *generalCount,
-                                  ulonglong2 *rng, uint32_t *dCounts, bool packed = false, const OrderTouch *touch = nullptr,
-                                  const SparseOut *sparse = nullptr, const unsigned *skipSampleAlive = nullptr, unsigned skipSamples = 0u) {
-  if (touch) { /* instrumented launch: the variant the image would run (4 lanes per k-mer, pair steps when it has the pair image) */
-    if constexpr (COMPACT) { /* the sorted 8-byte records ($AWFM_GPU_ORDERED_SORT=rocprim) are a measurement path: no tally */
-      setError("awfmGpuSearchHitsLineTally: not available with $AWFM_GPU_ORDERED_SORT=rocprim");
-      return AwFmUnsupportedVersionError;
-    } else {
-      if (g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR"))
-        return launchOrderedKernel<4, NARROW, COMPACT, VARLEN, true, true>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, touch);
-      return launchOrderedKernel<4, NARROW, COMPACT, VARLEN, false, true>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, touch);
-    }
-  }
-  {
-    const char *lanes = getenv("AWFM_GPU_ORDERED_LANES"); /* measurement knob: 1 | 2 | 4 lanes per query (default 4) */
-    const int G = lanes ? atoi(lanes) : 4;
-    enum AwFmReturnCode rc;
-    const BucketFormat none = BucketFormat();
-    if (G == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR"))
-      rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN, true>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse, skipSampleAlive, skipSamples);
-    else if (G == 2) rc = launchOrderedKernel<2, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse, skipSampleAlive, skipSamples);
-    else if (G == 1) rc = launchOrderedKernel<1, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse, skipSampleAlive, skipSamples);
-    else rc = launchOrderedKernel<4, NARROW, COMPACT, VARLEN>(g, s, len, depth, table, nq, recs, keys, generalCount, rng, dCounts, nullptr, nullptr, none, sparse, skipSampleAlive, skipSamples);
-    if (rc != AwFmSuccess) return rc;
-  }
-  if (packed) return AwFmSuccess; /* bit-packed k-mers: every one of them is covered */
-  /* the queries the fast path left out (ambiguity characters, empty or longer than 32; normally none): general
-   * kernel over the tail of the order */
-  const unsigned grid = residentGrid(g, searchKernel<false, 4, VARLEN, false, NARROW, true>);
-  /* the last kernel of the search: it carries the event that says the scratch slot is free again */
-  AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, VARLEN, false, NARROW, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent,
-                        g->dev, dChars, off, len, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)recs,
-                        COMPACT ? 8u : (unsigned)sizeof(QueryRec), COMPACT ? 0u : (unsigned)offsetof(QueryRec, index), nq,
-                        generalCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u);
-  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-  g->orderDoneArmed = g->orderDoneEvent != nullptr;
-  return AwFmSuccess;
+                                  const void *recs, const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts,
+                                  const OrderTouch *touch = nullptr, const SparseOut *sparse = nullptr,
+                                  const unsigned *skipSampleAlive = nullptr, unsigned skipSamples = 0u) {
+  enum AwFmReturnCode rc;
+  const BucketFormat none = BucketFormat();
+  if (touch) /* instrumented launch: the variant the image would run */
+    rc = pairSteps(g) ? launchOrderedKernel<NARROW, VARLEN, true, true>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, touch)
+                      : launchOrderedKernel<NARROW, VARLEN, false, true>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, touch);
+  else
+    rc = pairSteps(g) ? launchOrderedKernel<NARROW, VARLEN, true>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, nullptr, nullptr, none, sparse, skipSampleAlive, skipSamples)
+                      : launchOrderedKernel<NARROW, VARLEN, false>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, nullptr, nullptr, none, sparse, skipSampleAlive, skipSamples);
+  if (rc != AwFmSuccess) return rc;
+  return launchLeftover<NARROW, VARLEN>(g, s, dChars, off, len, nq, rng, dCounts, recs, (unsigned)sizeof(QueryRec), (unsigned)offsetof(QueryRec, index),
+                                        generalCount, sparse);
 }
 
 /* the search over bucketed 8-byte records (partitionKernel), then the general kernel over the last bucket */
@@ -166,27 +137,20 @@ enum AwFmReturnCode launchBucketed(AwFmGpuIndex *g, hipStream_t s, const uint8_t
                                    const ulonglong2 *table, unsigned long long nq, const void *recs, const unsigned *bucketStart,
                                    const BucketFormat &fmt, const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts,
                                    bool packed, const OrderTouch *touch, const SparseOut *sparse) {
-  const bool pair = g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR");
+  const bool pair = pairSteps(g);
   enum AwFmReturnCode rc;
   if (touch)
-    rc = pair ? launchOrderedKernel<4, NARROW, true, false, true, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, touch, bucketStart, fmt)
-              : launchOrderedKernel<4, NARROW, true, false, false, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, touch, bucketStart, fmt);
+    rc = pair ? launchOrderedKernel<NARROW, false, true, true, true>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, touch, bucketStart, fmt)
+              : launchOrderedKernel<NARROW, false, false, true, true>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, touch, bucketStart, fmt);
   else if (sparse && sparse->count) /* the list of hits: collected per wave */
-    rc = pair ? launchOrderedKernel<4, NARROW, true, false, true, false, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse)
-              : launchOrderedKernel<4, NARROW, true, false, false, false, true, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse);
+    rc = pair ? launchOrderedKernel<NARROW, false, true, false, true, true>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse)
+              : launchOrderedKernel<NARROW, false, false, false, true, true>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse);
   else
-    rc = pair ? launchOrderedKernel<4, NARROW, true, false, true, false, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse)
-              : launchOrderedKernel<4, NARROW, true, false, false, false, true>(g, s, len, depth, table, nq, recs, nullptr, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse);
+    rc = pair ? launchOrderedKernel<NARROW, false, true, false, true>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse)
+              : launchOrderedKernel<NARROW, false, false, false, true>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse);
   if (rc != AwFmSuccess || packed) return rc; /* bit-packed k-mers: every one of them is covered */
   /* the last bucket: k-mers with ambiguity characters; a record of it is the query number alone */
-  const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, NARROW, true>);
-  /* the last kernel of the search: it carries the event that says the scratch slot is free again */
-  AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, false, false, NARROW, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent,
-                        g->dev, dChars, (const unsigned long long *)nullptr, len, nq, rng, dCounts, (unsigned long long *)nullptr,
-                        (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u);
-  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-  g->orderDoneArmed = g->orderDoneEvent != nullptr;
-  return AwFmSuccess;
+  return launchLeftover<NARROW, false>(g, s, dChars, nullptr, len, nq, rng, dCounts, recs, 8u, 0u, generalCount, sparse);
 }
 
 }  // namespace
@@ -482,7 +446,7 @@ static hipError_t gateEnter(AwFmGpuIndex::StreamGate &gate, hipStream_t s) {
 /* `s` has enqueued its last use; armed: the last kernel was launched with gate.done as its stop event (hipExtLaunchKernelGGL),
  * which costs nothing, where a hipEventRecord is a packet of its own and about 5 us of idle queue */
 static hipError_t gateLeave(AwFmGpuIndex::StreamGate &gate, hipStream_t s, bool armed) {
-  if (gateLazy(s) && !getenv("AWFM_GPU_EAGER_EVENTS")) {
+  if (gateLazy(s)) {
     gate.pending = true;
     gate.recorded = false;
   } else {
@@ -539,8 +503,6 @@ static hipError_t orderBeginSlot(AwFmGpuIndex *g, hipStream_t s) {
     for (int i = 1; i < AwFmGpuIndex::kOrderSlots; i++)
       if (g->orderSlot[i].lastUse < g->orderSlot[pick].lastUse) pick = i;
   }
-  if (const char *env = getenv("AWFM_GPU_ORDER_SLOTS")) /* measurement knob: 1 = one slot, every search queues on it */
-    if (atoi(env) == 1) pick = 0;
   AwFmGpuIndex::OrderSlot &slot = g->orderSlot[pick];
   slot.lastUse = ++g->orderUses;
   g->orderPrevParity = slot.prepParity; /* (a search that keeps the two sample words in step sets it again) */
@@ -550,7 +512,7 @@ static hipError_t orderBeginSlot(AwFmGpuIndex *g, hipStream_t s) {
   g->orderBytes = slot.bytes;
   g->orderDoneArmed = false;
   const hipError_t e = gateEnter(slot.gate, s);
-  g->orderDoneEvent = e == hipSuccess && !(gateLazy(s) && !getenv("AWFM_GPU_EAGER_EVENTS")) ? slot.gate.done : nullptr;
+  g->orderDoneEvent = e == hipSuccess && !gateLazy(s) ? slot.gate.done : nullptr;
   return e;
 }
 static hipError_t orderEndSlot(AwFmGpuIndex *g, hipStream_t s) {
@@ -621,20 +583,6 @@ static void launchEncode4(unsigned len, unsigned grid, size_t lds, hipStream_t s
                           unsigned long long nq, unsigned long long *codes, unsigned *hist, unsigned binsPad,
                           const unsigned *sampleAlive = nullptr, unsigned samples = 0u) {
   launchEncode4At<32u>(len, grid, lds, s, dChars, fmt, nq, codes, hist, binsPad, sampleAlive, samples);
-}
-
-/* encodeLookupKernel<K> for the batch's k-mer length */
-template <unsigned K>
-static void launchEncodeLookupAt(unsigned len, unsigned grid, size_t lds, hipStream_t s, const DevIndex &dev, const uint8_t *dChars,
-                                 const BucketFormat &fmt, unsigned useNext, unsigned long long nq, unsigned long long *codes,
-                                 unsigned *numbers, unsigned *shareCount, unsigned *hist, unsigned binsPad,
-                                 const unsigned *sampleAlive, unsigned samples, hipEvent_t start, hipEvent_t stop) {
-  if (len == K)
-    AWFM_LAUNCH_WITH_EVENTS((encodeLookupKernel<K>), dim3(grid), dim3(256), (unsigned)lds, s, start, stop, dev, dChars, fmt, useNext, nq, codes,
-                          numbers, shareCount, hist, binsPad, sampleAlive, samples);
-  else if constexpr (K > 1u)
-    launchEncodeLookupAt<K - 1u>(len, grid, lds, s, dev, dChars, fmt, useNext, nq, codes, numbers, shareCount, hist, binsPad, sampleAlive, samples,
-                                 start, stop);
 }
 
 /* lookupSearchKernel<K, NARROW> for the batch's k-mer length */
@@ -747,19 +695,18 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   unsigned encodeGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * 8u ? perShare256 * kShares : (unsigned long long)g->numCUs * 8u);
   encodeGrid = (encodeGrid + kShares - 1u) / kShares * kShares;
   unsigned *shareCount = (unsigned *)(w + kShareCountAt), *numbers = (unsigned *)(w + numbersAt);
-  const unsigned useNext = g->dev.deepNext != 0u && g->dev.pairBlocks && !getenv("AWFM_GPU_ORDERED_NO_PAIR") && fixedLength >= depth + 2u ? 1u : 0u;
+  const unsigned useNext = g->dev.deepNext != 0u && pairSteps(g) && fixedLength >= depth + 2u ? 1u : 0u;
   /* lookup first: forced ($AWFM_GPU_LOOKUP_FIRST=1), or left to a sample of the batch -- 16384 k-mers at a fixed stride; the
    * pass pays when fewer than a quarter of them are alive after the table.  The sample's count stays on the device: both
    * front ends are launched and the one it does not choose returns at once (lookupChosen), so the search never waits
-   * for the host -- unless (round 5) the sample of an earlier search of this k-mer length has reached the host by now:
-   * then only the front end it chose is launched (predictFront).  ($AWFM_GPU_LOOKUP_HOST_DECIDES=1: round 3's read-back
-   * of the count, 4 bytes and a stream synchronisation inside the search, for comparison.) */
+   * for the host -- unless the sample of an earlier search of this k-mer length has reached the host by now:
+   * then only the front end it chose is launched (predictFront). */
   constexpr unsigned kSamples = 16384;
   const bool forced = lookupWanted && lookupEnv && atoi(lookupEnv) == 1;
   bool bySample = lookupWanted && !forced;
-  /* the memset, the list's fill and the sample in one launch (lookupPrepKernel); $AWFM_GPU_PREP_FUSED=0: round 4's three */
-  const char *prepEnv = getenv("AWFM_GPU_PREP_FUSED");
-  const bool prepFused = bySample && nq >= kSamples && !getenv("AWFM_GPU_LOOKUP_HOST_DECIDES") && !(prepEnv && atoi(prepEnv) == 0);
+  /* the scratch's counters zeroed, the list's fill and the sample in one launch (lookupPrepKernel); a sampled batch has 2^20
+   * k-mers and more */
+  const bool prepFused = bySample && nq >= kSamples;
   AwFmGpuIndex::LookupPredict &predict = g->predict;
   if (prepFused && !predict.verdictHost) {
     if (hipHostMalloc((void **)&predict.verdictHost, 64, hipHostMallocDefault) == hipSuccess) {
@@ -817,20 +764,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
                          rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
       BUCKET_TRY(hipGetLastError());
     }
-    sampleAlive = bySample ? (const unsigned *)(w + kSampleAt) : nullptr;
-    if (bySample) {
-      hipLaunchKernelGGL(sampleAliveKernel, dim3(kSamples / 256u), dim3(256), 0, s, g->dev, dChars, fixedLength, depth, useNext, nq, kSamples,
-                         (unsigned *)(w + kSampleAt));
-      BUCKET_TRY(hipGetLastError());
-      if (getenv("AWFM_GPU_LOOKUP_HOST_DECIDES")) {
-        unsigned alive = 0;
-        BUCKET_TRY(hipMemcpyAsync(&alive, w + kSampleAt, sizeof alive, hipMemcpyDeviceToHost, s));
-        BUCKET_TRY(hipStreamSynchronize(s));
-        lookupFirst = alive * 4u < kSamples;
-        bySample = false;
-        sampleAlive = nullptr;
-      }
-    }
+    bySample = false; /* (a batch of fewer k-mers than the sample takes: forced, or not looked up first at all) */
     g->orderSampleAt = (const unsigned *)(w + kSampleAt);
   }
   const bool lookupOnly = prepFused && front == kFrontLookupOnly; /* no ordering passes, no ordered kernel behind the lookup kernel */
@@ -840,28 +774,23 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   g->orderTimedFront = false;
   if (lookupFirst || bySample) {
     const bool timed = g->orderTiming[0] != nullptr; /* this search has an entry in the timing log: the events ride on the dispatch */
-    /* fused (default): the k-mers still alive after the table are searched by the kernel that looked them up;
-     * $AWFM_GPU_LOOKUP_FUSED=0: they are kept, partitioned and searched by orderedSearchKernel (round 3) */
-    const char *fusedEnv = getenv("AWFM_GPU_LOOKUP_FUSED");
-    const bool fused = lookupOnly || !narrow || !(fusedEnv && atoi(fusedEnv) == 0);
-    g->orderLookupFused = fused;
+    /* the k-mers still alive after the table are searched by the kernel that looked them up (lookupSearchKernel) */
+    g->orderLookupFused = true;
     g->orderFusedKeptAt = (const unsigned *)(w + kKeptAt);
-    if (fused) {
-      const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
-      const char *superEnv = getenv("AWFM_GPU_LOOKUP_PAIR_SUPER"); /* measurement knob: lds | global */
-      const bool superInLds = !pairOff && narrow && (superEnv ? !strcmp(superEnv, "lds") : awfmPairSuperInLds(g));
+    {
+      const bool pairOff = !pairSteps(g);
+      const bool superInLds = !pairOff && narrow && awfmPairSuperInLds(g);
       DevIndex dev = g->dev;
       dev.pairSuperInLds = superInLds ? 1u : 0u;
       const size_t lds = superInLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
-      /* persistent grid: what is resident (7 workgroups per CU), a multiple of the 8 shares */
-      unsigned perCU = narrow ? 7u : 6u; /* (the 64-bit instantiation: 80 registers, 6 waves per SIMD) */
-      if (const char *env = getenv("AWFM_GPU_LOOKUP_BLOCKS_PER_CU")) perCU = (unsigned)atoi(env) >= 1u ? (unsigned)atoi(env) : perCU;
+      /* persistent grid: what is resident (7 workgroups per CU; the 64-bit instantiation: 80 registers, 6), a multiple of the 8 shares */
+      const unsigned perCU = narrow ? 7u : 6u;
       unsigned fusedGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * perCU ? perShare256 * kShares : (unsigned long long)g->numCUs * perCU);
       fusedGrid = (fusedGrid + kShares - 1u) / kShares * kShares;
       /* A workgroup takes its share 1024 k-mers a trip.  A small batch is a few trips per workgroup -- 6.8 for the 1.25 * 10^7
        * k-mers of a shard of an 8-GPU run on 1792 workgroups: most take 7, and the chip idles while they finish -- so the grid
-       * is trimmed to the workgroups that share the trips evenly (1744 x 7); $AWFM_GPU_LOOKUP_EVEN_TRIPS=0: the resident grid */
-      if (!(getenv("AWFM_GPU_LOOKUP_EVEN_TRIPS") && atoi(getenv("AWFM_GPU_LOOKUP_EVEN_TRIPS")) == 0)) {
+       * is trimmed to the workgroups that share the trips evenly (1744 x 7) */
+      {
         const unsigned long long tripsPerShare = (shareSize(nq) + 1023ull) / 1024ull, groupsPerShare = fusedGrid / kShares;
         if (groupsPerShare > 0u && tripsPerShare > groupsPerShare) {
           const unsigned long long tripsEach = (tripsPerShare + groupsPerShare - 1ull) / groupsPerShare;
@@ -870,35 +799,14 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
       }
       /* (lookup only: what the kernel does not search itself goes to the END of the record array, 8 bytes a k-mer number,
        * counted in the general kernel's word -- no code words, no numbers, no histogram) */
-      /* $AWFM_GPU_LOOKUP_TIMELINE=<file> (diagnostic, waits for the device): every wave's start and end on the device's clock,
-       * where it ran and how many trips it made -- scripts/lookup_timeline.py reads the file */
-      const char *timelinePath = getenv("AWFM_GPU_LOOKUP_TIMELINE");
-      unsigned long long *timeline = nullptr;
-      if (timelinePath && hipMalloc((void **)&timeline, (size_t)fusedGrid * 128u) == hipSuccess) {
-        (void)hipMemsetAsync(timeline, 0, (size_t)fusedGrid * 128u, s);
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(gLookupTimeline), &timeline, sizeof(timeline), 0, hipMemcpyHostToDevice, s);
-      }
 #define AWFM_LOOKUP_GO(NR)                                                                                                               \
-  launchLookupSearchAt<32u, NR>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt,                                                        \
-                                useNext | (pairOff ? 2u : 0u) | (lookupOnly ? 4u : 0u) | (timeline ? 32u : 0u), nq,                      \
+  launchLookupSearchAt<32u, NR>(fixedLength, fusedGrid, lds, s, dev, dChars, fmt, useNext | (pairOff ? 2u : 0u) | (lookupOnly ? 4u : 0u), nq, \
                                 (unsigned long long *)(w + codesAt), lookupOnly ? (unsigned *)recs : numbers, lookupOnly ? generalCount : shareCount, \
                                 hist, binsPad, sampleAlive, kSamples, rng, dCounts, sparse ? *sparse : SparseOut(),                      \
                                 (unsigned *)(w + kKeptAt), timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr)
       if (narrow) AWFM_LOOKUP_GO(true);
       else AWFM_LOOKUP_GO(false);
 #undef AWFM_LOOKUP_GO
-      if (timeline) {
-        std::vector<unsigned long long> host((size_t)fusedGrid * 16u);
-        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(host.data(), timeline, host.size() * 8u, hipMemcpyDeviceToHost) == hipSuccess)
-          if (FILE *out = fopen(timelinePath, "wb")) {
-            fwrite(host.data(), 8u, host.size(), out);
-            fclose(out);
-          }
-        (void)hipFree(timeline);
-      }
-    } else {
-      launchEncodeLookupAt<32u>(fixedLength, encodeGrid, bins * 4u, s, g->dev, dChars, fmt, useNext, nq, (unsigned long long *)(w + codesAt), numbers,
-                                shareCount, hist, binsPad, sampleAlive, kSamples, timed ? g->orderTiming[0] : nullptr, timed ? g->orderTiming[1] : nullptr);
     }
     g->orderTimedFront = timed;
     if (timed) g->orderLog[(g->orderLogCount - 1u) % AwFmGpuIndex::kOrderLogMax].front = true;
@@ -908,20 +816,9 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
     /* what the lookup kernel left (k-mers with ambiguity characters, survivors beyond a round's slots): the general kernel
      * over the tail of the record array -- the last kernel of the search: it carries the event that says the slot is free */
     enum AwFmReturnCode rc = AwFmSuccess;
-    if (!packed) {
-#define AWFM_LEFT_GO(NR)                                                                                                                 \
-  do {                                                                                                                                   \
-    const unsigned grid = residentGrid(g, searchKernel<false, 4, false, false, NR, true>);                                               \
-    AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, false, false, NR, true>), dim3(grid), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, \
-                            g->dev, dChars, (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr, \
-                            (const unsigned char *)recs, 8u, 0u, nq, generalCount, sparse ? *sparse : SparseOut(), (const unsigned *)nullptr, 0u); \
-  } while (0)
-      if (narrow) AWFM_LEFT_GO(true);
-      else AWFM_LEFT_GO(false);
-#undef AWFM_LEFT_GO
-      if (hipGetLastError() != hipSuccess) rc = AwFmGeneralFailure;
-      g->orderDoneArmed = g->orderDoneEvent != nullptr;
-    }
+    if (!packed)
+      rc = narrow ? launchLeftover<true, false>(g, s, dChars, nullptr, fixedLength, nq, rng, dCounts, recs, 8u, 0u, generalCount, sparse)
+                  : launchLeftover<false, false>(g, s, dChars, nullptr, fixedLength, nq, rng, dCounts, recs, 8u, 0u, generalCount, sparse);
     if (rc != AwFmSuccess) return -(int)rc;
     BUCKET_TRY(slotScope.end());
     return 1;
@@ -931,9 +828,6 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   } else if (packed)
     hipLaunchKernelGGL((encodeCodesKernel<true>), dim3(encodeGrid), dim3(256), bins * 4u, s, dChars, fixedLength, fmt, nq,
                        (unsigned long long *)nullptr, hist, binsPad);
-  else if (getenv("AWFM_GPU_ENCODE_ONE")) /* measurement knob: one k-mer per thread (never beside a sample) */
-    hipLaunchKernelGGL((encodeCodesKernel<false>), dim3(encodeGrid), dim3(256), bins * 4u, s, dChars, fixedLength, fmt, nq,
-                       (unsigned long long *)(w + codesAt), hist, binsPad);
   else
     launchEncode4(fixedLength, encodeGrid, bins * 4u, s, dChars, fmt, nq, (unsigned long long *)(w + codesAt), hist, binsPad, sampleAlive, kSamples);
   BUCKET_TRY(hipGetLastError());
@@ -1055,11 +949,10 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   const bool lookupOnly = lengthTable && (mixedForced || front == kFrontLookupOnly);
   const bool lookupRuns = lengthTable && front != kFrontOrderedOnly;
   /* counts only, dense, and nothing but the lookup kernel: it stores every k-mer's count itself, a round's at a time in whole
-   * lines (bit 4 of useNext) -- no pre-fill, no 4-byte stores at k-mer numbers ($AWFM_GPU_MIXED_WHOLE_COUNTS=0: as before) */
-  const char *wholeEnv = getenv("AWFM_GPU_MIXED_WHOLE_COUNTS");
+   * lines (bit 4 of useNext) -- no pre-fill, no 4-byte stores at k-mer numbers */
   /* (not for awfmGpuSearchHitsSparse, whose point is that the ranges of the k-mers WITHOUT hits are not written: 16 of the 20
    * bytes per k-mer; advisor, round 5) */
-  const bool wholeCounts = lookupOnly && !sparse && (dCounts || rng) && !(rangesOfHitsOnly && dCounts && rng) && !(wholeEnv && atoi(wholeEnv) == 0);
+  const bool wholeCounts = lookupOnly && !sparse && (dCounts || rng) && !(rangesOfHitsOnly && dCounts && rng);
   const size_t total = leftAt + (lengthTable ? alignUp256(nq * 8u) : 0u);
   /* in the counter block, beyond the ticket counters (which end at 65792): the leftover count, the sample's count, the
    * survivor counters (kFusedCounters words a line apart) */
@@ -1092,7 +985,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   }
   const unsigned *sampleAlive = nullptr;
   if (bySample) { /* the sample: always taken (the next searches' prediction), consulted on the device when both front ends run */
-    const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
+    const bool pairOff = !pairSteps(g);
     const unsigned useNext = (g->dev.deepNext != 0u && !pairOff ? 1u : 0u) | (pairOff ? 2u : 0u);
     unsigned *sampleWord = (unsigned *)(w + kSampleAt);
     static_assert(kSamples == kPredictSamples, "the verdict is judged against the sample's size");
@@ -1101,15 +994,12 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
     if (front == kFrontBoth) sampleAlive = sampleWord;
   }
   if (lookupRuns) {
-    const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
+    const bool pairOff = !pairSteps(g);
     unsigned useNext = (g->dev.deepNext != 0u && !pairOff ? 1u : 0u) | (pairOff ? 2u : 0u);
-    if (getenv("AWFM_GPU_MIXED_DROP_SURVIVORS")) useNext |= 8u; /* MEASUREMENT ONLY (wrong results): the lookup phase alone */
     if (wholeCounts) useNext |= 16u;
     /* the superblock bases of the pair image are read from memory: 24 KB of them in LDS (a 3.1 Gbp image) would leave room
-     * for 3 workgroups per CU where the survivors' slots alone allow 6 (10^8 8..30-mers: 6.36 against 6.74 ms);
-     * $AWFM_GPU_LOOKUP_PAIR_SUPER=lds|global: measurement knob */
-    const char *superEnv = getenv("AWFM_GPU_LOOKUP_PAIR_SUPER");
-    const bool superInLds = !pairOff && superEnv && !strcmp(superEnv, "lds");
+     * for 3 workgroups per CU where the survivors' slots alone allow 6 (10^8 8..30-mers: 6.36 against 6.74 ms) */
+    const bool superInLds = false;
     unsigned *leftoverCount = (unsigned *)(w + kLeftCountAt), *sampleWord = (unsigned *)(w + kSampleAt), *kept = (unsigned *)(w + kKeptAt);
     unsigned long long *leftover = (unsigned long long *)(w + leftAt);
     g->orderLookup = sampleAlive ? 2 : 1;
@@ -1126,18 +1016,12 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
     g->orderTimedFront = timed;
     if (timed) g->orderLog[(g->orderLogCount - 1u) % AwFmGpuIndex::kOrderLogMax].front = true;
     /* what the lookup kernel left: the last *leftoverCount records of the list */
-    if (awfmImageNarrow(g)) {
-      const unsigned tail = residentGrid(g, searchKernel<false, 4, true, false, true, true>);
-      hipLaunchKernelGGL((searchKernel<false, 4, true, false, true, true>), dim3(tail), dim3(kThreads), 0, s, g->dev, dChars, off, fixedLength, nq, rng,
-                         dCounts, (unsigned long long *)nullptr, (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out,
-                         (const unsigned *)nullptr, 0u);
-    } else {
-      const unsigned tail = residentGrid(g, searchKernel<false, 4, true, false, false, true>);
-      hipLaunchKernelGGL((searchKernel<false, 4, true, false, false, true>), dim3(tail), dim3(kThreads), 0, s, g->dev, dChars, off, fixedLength, nq, rng,
-                         dCounts, (unsigned long long *)nullptr, (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out,
-                         (const unsigned *)nullptr, 0u);
+    {
+      const enum AwFmReturnCode left =
+          awfmImageNarrow(g) ? launchLeftover<true, true>(g, s, dChars, off, fixedLength, nq, rng, dCounts, leftover, 8u, 0u, leftoverCount, sparse, lookupOnly)
+                             : launchLeftover<false, true>(g, s, dChars, off, fixedLength, nq, rng, dCounts, leftover, 8u, 0u, leftoverCount, sparse, lookupOnly);
+      if (left != AwFmSuccess) return -(int)left; /* (not lookup only: more kernels follow, and the last one carries the slot's event) */
     }
-    WIDE_TRY(hipGetLastError());
     if (lookupOnly) { /* forced or predicted: the other front end is not launched */
       WIDE_TRY(slotScope.end());
       return 1;
@@ -1177,9 +1061,8 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
   WIDE_TRY(hipGetLastError());
   const bool narrow = awfmImageNarrow(g);
   enum AwFmReturnCode rc;
-  const unsigned short *noKeys = nullptr;
 #define WIDE_GO(NR, VL) \
-  launchOrdered<NR, false, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, noKeys, generalCount, rng, dCounts, false, touch, sparse, sampleAlive, kChooseOf)
+  launchOrdered<NR, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, generalCount, rng, dCounts, touch, sparse, sampleAlive, kChooseOf)
   if (off) rc = narrow ? WIDE_GO(true, true) : WIDE_GO(false, true);
   else rc = narrow ? WIDE_GO(true, false) : WIDE_GO(false, false);
 #undef WIDE_GO
@@ -1237,111 +1120,17 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
     if (recordBytesOut) *recordBytesOut = 0u;
     return wideBucketedSearch(g, s, dChars, off, fixedLength, 0u, nullptr, nq, rng, dCounts, rangesOfHitsOnly, nullptr, sparse, true);
   }
-  /* 8-byte records: fixed-length batches of short enough k-mers */
-  /* fixed-length batches whose records fit 8 bytes: counted and partitioned by the kernels of awfm_ordered_kernel.h
-   * ($AWFM_GPU_ORDERED_SORT=rocprim: the earlier encode + radix sort of (16-bit key, record) pairs, for comparison) */
+  /* fixed-length batches whose records fit 8 bytes: counted and partitioned by the kernels of awfm_ordered_kernel.h */
   const BucketFormat bucketFmt = bucketFormat(depth, nq);
-  const char *sortEnv = getenv("AWFM_GPU_ORDERED_SORT");
-  const bool bucketed = !off && bucketFits(fixedLength, bucketFmt) && !(sortEnv && !strcmp(sortEnv, "rocprim")) &&
-                        !getenv("AWFM_GPU_ORDERED_WIDE");
-  if (bucketed) {
+  if (!off && bucketFits(fixedLength, bucketFmt)) {
     if (recordBytesOut) *recordBytesOut = 8u;
     return bucketedSearch(g, s, dChars, fixedLength, depth, table, nq, rng, dCounts, packed, rangesOfHitsOnly, touch, bucketFmt, sparse);
   }
   /* everything else the path covers -- mixed-length batches, fixed-length k-mers whose record does not fit 8 bytes --
-   * through the same two passes over 16-byte records */
-  if (!(sortEnv && !strcmp(sortEnv, "rocprim")) && !getenv("AWFM_GPU_ORDER_KEY_BITS") && !packed) {
-    if (recordBytesOut) *recordBytesOut = sizeof(QueryRec);
-    return wideBucketedSearch(g, s, dChars, off, fixedLength, depth, table, nq, rng, dCounts, rangesOfHitsOnly, touch, sparse);
-  }
-  const bool compact = !off && orderCompact(fixedLength, depth) && !getenv("AWFM_GPU_ORDERED_WIDE");
-  if (recordBytesOut) *recordBytesOut = compact ? 8u + 2u : sizeof(QueryRec); /* what the search reads per k-mer: record (+ key) */
-  unsigned short *nullKeys = nullptr;
-  size_t sortTemp = 0;
-  hipError_t sized;
-  if (compact) {
-    unsigned long long *nullRecs = nullptr;
-    sized = rocprim::radix_sort_pairs(nullptr, sortTemp, nullKeys, nullKeys, nullRecs, nullRecs, (size_t)nq, 0u, kOrderKeyBits, s);
-  } else {
-    QueryRec *nullRecs = nullptr;
-    sized = rocprim::radix_sort_pairs(nullptr, sortTemp, nullKeys, nullKeys, nullRecs, nullRecs, (size_t)nq, 0u, kOrderKeyBits, s);
-  }
-  if (sized != hipSuccess) {
-    setError("awfmGpuSearchHits: radix sort sizing failed");
-    return -(int)AwFmGeneralFailure;
-  }
-  const OrderScratch l = scratchLayout(nq, compact ? 8 : sizeof(QueryRec), sortTemp);
-  if (orderBeginSlot(g, s) != hipSuccess) {
-    setError("seed-order search: could not order the use of its scratch across streams");
-    return -(int)AwFmGeneralFailure;
-  }
-  OrderSlotScope slotScope(g, s);
-  if (!ensureOrderScratch(g, l.total)) return kOrderNoScratch; /* no room for the scratch: the general kernel needs none */
-  uint8_t *w = (uint8_t *)g->dOrder;
-  unsigned *generalCount = (unsigned *)(w + l.generalCount);
-  unsigned short *keysIn = (unsigned short *)(w + l.keysIn), *keysOut = (unsigned short *)(w + l.keysOut);
-  void *recsIn = w + l.recsIn, *recsOut = w + l.recsOut;
-#define ORDER_TRY(call)                     \
-  do {                                      \
-    hipError_t e__ = (call);                \
-    if (e__ != hipSuccess) {                \
-      setError(#call, e__);                 \
-      return -(int)AwFmGeneralFailure;      \
-    }                                       \
-  } while (0)
-  ORDER_TRY(hipMemsetAsync(generalCount, 0, kOrderCounterBytes, s)); /* the count and the ticket counters */
-  ORDER_TRY(fillSparseList(sparse, s));
-  /* rangesOfHitsOnly (awfmGpuSearchHitsSparse): the counts say which k-mers have hits, so only the counts are
-   * pre-filled and the ranges of the others stay as the caller left them -- 16 of the 20 bytes per k-mer not written */
-  if (!sparse) {
-    hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
-                       rangesOfHitsOnly && dCounts ? (ulonglong2 *)nullptr : rng, dCounts, nq);
-    ORDER_TRY(hipGetLastError());
-  }
-  const unsigned encodeGrid = (unsigned)((nq + 255) / 256);
-  const unsigned seedK = g->dev.seedK, deepK = g->dev.deepK;
-  unsigned keyMask = 0xFFFFu;
-  if (const char *env = getenv("AWFM_GPU_ORDER_KEY_BITS")) { /* measurement knob: order by the leading n of the 15 key bits */
-    const int n = atoi(env);
-    if (n >= 1 && n < 15) keyMask = (0x7FFFu << (15 - n)) & 0x7FFFu;
-  }
-  size_t tempBytes = sortTemp;
-  if (compact) {
-    if (packed)
-      hipLaunchKernelGGL((encodeQueriesKernel<true, false, true>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength,
-                         depth, seedK, deepK, nq, keysIn, recsIn, generalCount);
-    else
-      hipLaunchKernelGGL((encodeQueriesKernel<true, false>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
-                         seedK, deepK, nq, keysIn, recsIn, generalCount);
-    ORDER_TRY(hipGetLastError());
-    ORDER_TRY(rocprim::radix_sort_pairs(w + l.sortTemp, tempBytes, keysIn, keysOut, (unsigned long long *)recsIn,
-                                        (unsigned long long *)recsOut, (size_t)nq, 0u, kOrderKeyBits, s));
-  } else {
-    if (off)
-      hipLaunchKernelGGL((encodeQueriesKernel<false, true>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
-                         seedK, deepK, nq, keysIn, recsIn, generalCount, keyMask);
-    else if (packed)
-      hipLaunchKernelGGL((encodeQueriesKernel<false, false, true>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength,
-                         depth, seedK, deepK, nq, keysIn, recsIn, generalCount, keyMask);
-    else
-      hipLaunchKernelGGL((encodeQueriesKernel<false, false>), dim3(encodeGrid), dim3(256), 0, s, dChars, off, fixedLength, depth,
-                         seedK, deepK, nq, keysIn, recsIn, generalCount, keyMask);
-    ORDER_TRY(hipGetLastError());
-    ORDER_TRY(rocprim::radix_sort_pairs(w + l.sortTemp, tempBytes, keysIn, keysOut, (QueryRec *)recsIn, (QueryRec *)recsOut,
-                                        (size_t)nq, 0u, kOrderKeyBits, s));
-  }
-  const bool narrow = awfmImageNarrow(g);
-  enum AwFmReturnCode rc;
-#define ORDER_GO(NR, CP, VL) \
-  launchOrdered<NR, CP, VL>(g, s, dChars, off, fixedLength, depth, table, nq, recsOut, keysOut, generalCount, rng, dCounts, packed, touch, sparse)
-  if (off) rc = narrow ? ORDER_GO(true, false, true) : ORDER_GO(false, false, true);
-  else if (compact) rc = narrow ? ORDER_GO(true, true, false) : ORDER_GO(false, true, false);
-  else rc = narrow ? ORDER_GO(true, false, false) : ORDER_GO(false, false, false);
-#undef ORDER_GO
-  if (rc != AwFmSuccess) return -(int)rc;
-  ORDER_TRY(slotScope.end());
-#undef ORDER_TRY
-  return 1;
+   * through the same two passes over 16-byte records (bit-packed k-mers of more than 24 characters: the caller unpacks them) */
+  if (packed) return 0;
+  if (recordBytesOut) *recordBytesOut = sizeof(QueryRec);
+  return wideBucketedSearch(g, s, dChars, off, fixedLength, depth, table, nq, rng, dCounts, rangesOfHitsOnly, touch, sparse);
 }
 
 
@@ -1393,8 +1182,7 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
   /* round 5, as the nucleotide bucketed search: the counters zeroed, the list pre-filled and the sample taken by ONE launch
    * (lookupPrepKernel<true>; the sample's two words at bytes 0 and 128 of the counter block), and only the kernel an earlier
    * search's sample named when its verdict has reached the host (predictFront: 1 = this kernel, 2 = the general kernel) */
-  const char *prepEnv = getenv("AWFM_GPU_PREP_FUSED");
-  const bool prepFused = !forced && !(prepEnv && atoi(prepEnv) == 0);
+  const bool prepFused = !forced;
   AwFmGpuIndex::LookupPredict &predict = g->predict;
   if (prepFused && !predict.verdictHost) {
     if (hipHostMalloc((void **)&predict.verdictHost, 64, hipHostMallocDefault) == hipSuccess) {
@@ -1407,10 +1195,8 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
   /* the lookup kernel has a slot for every k-mer of a round (round 5): it is chosen while fewer than `percent` of the sample
    * are still alive after their entry (lookupChosen compares 4 x alive with the number it is given) -- the general kernel
    * keeps twice the chains in flight per wave, which wins when nearly every k-mer goes on for several steps (k-mers drawn
-   * from the text); $AWFM_GPU_AMINO_CHOOSE_PERCENT: measurement knob */
-  unsigned percent = 90u;
-  if (const char *e = getenv("AWFM_GPU_AMINO_CHOOSE_PERCENT"))
-    if (atoi(e) >= 1 && atoi(e) <= 100) percent = (unsigned)atoi(e);
+   * from the text) */
+  constexpr unsigned percent = 90u;
   const unsigned chooseOf = (unsigned)((unsigned long long)kSamples * 4ull * percent / 100ull);
   const int front = prepFused ? predictFront(g, fixedLength, chooseOf) : kFrontBoth;
   const unsigned *sampleAlive = nullptr;
@@ -1432,14 +1218,9 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
     g->orderSlot[g->orderCur].prepParity = 1 - parity;
     sampleWord = (unsigned *)aliveOut;
     if (front == kFrontBoth) sampleAlive = sampleWord;
-  } else {
+  } else { /* forced: no sample */
     AMINO_TRY(hipMemsetAsync(w, 0, kCounterBytes, s));
     AMINO_TRY(fillSparseList(sparse, s));
-    if (!forced) {
-      hipLaunchKernelGGL(aminoSampleAliveKernel, dim3(kSamples / 256u), dim3(256), 0, s, g->dev, dChars, fixedLength, nq, kSamples, sampleWord);
-      AMINO_TRY(hipGetLastError());
-      sampleAlive = sampleWord;
-    }
   }
   if (!sparse) {
     hipLaunchKernelGGL(fillNoHitKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, s,
@@ -1533,30 +1314,20 @@ int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
   unsigned *leftoverCount = (unsigned *)w;
   unsigned long long *leftover = (unsigned long long *)(w + listAt);
   EXACT_TRY(hipMemsetAsync(w, 0, 256, s));
-  const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_GENERAL_NO_PAIR");
+  const bool pairOff = !pairSteps(g);
   EXACT_TRY(awfmGpuLaunchExactLookup(g, s, nullptr, nullptr, lengthTable, dChars, off, fixedLength, nq, pairOff, rng, dCounts, leftover, leftoverCount));
   /* what the lookup kernel left, letter by letter (exact by construction): the last kernel of the search carries the event
    * that says the scratch slot is free again */
-#define AWFM_EXACT_TAIL(CSRV, NR)                                                                                                        \
-  do {                                                                                                                                   \
-    const unsigned tail = residentGrid(g, searchKernel<false, 4, CSRV, false, NR, true>);                                                \
-    AWFM_LAUNCH_WITH_EVENTS((searchKernel<false, 4, CSRV, false, NR, true>), dim3(tail), dim3(kThreads), 0u, s, nullptr, g->orderDoneEvent, g->dev, dChars, \
-                            (const unsigned long long *)off, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr, (const unsigned char *)leftover, 8u, \
-                            0u, nq, (const unsigned *)leftoverCount, SparseOut(), (const unsigned *)nullptr, 0u);                        \
-  } while (0)
   {
     const bool narrow = awfmImageNarrow(g);
-    if (off) {
-      if (narrow) AWFM_EXACT_TAIL(true, true);
-      else AWFM_EXACT_TAIL(true, false);
-    } else {
-      if (narrow) AWFM_EXACT_TAIL(false, true);
-      else AWFM_EXACT_TAIL(false, false);
-    }
+    const unsigned long long *csr = (const unsigned long long *)off;
+    enum AwFmReturnCode left;
+    if (off) left = narrow ? launchLeftover<true, true>(g, s, dChars, csr, fixedLength, nq, rng, dCounts, leftover, 8u, 0u, leftoverCount, nullptr)
+                           : launchLeftover<false, true>(g, s, dChars, csr, fixedLength, nq, rng, dCounts, leftover, 8u, 0u, leftoverCount, nullptr);
+    else left = narrow ? launchLeftover<true, false>(g, s, dChars, nullptr, fixedLength, nq, rng, dCounts, leftover, 8u, 0u, leftoverCount, nullptr)
+                       : launchLeftover<false, false>(g, s, dChars, nullptr, fixedLength, nq, rng, dCounts, leftover, 8u, 0u, leftoverCount, nullptr);
+    if (left != AwFmSuccess) return -(int)left;
   }
-#undef AWFM_EXACT_TAIL
-  EXACT_TRY(hipGetLastError());
-  g->orderDoneArmed = g->orderDoneEvent != nullptr;
   EXACT_TRY(slotScope.end());
 #undef EXACT_TRY
   return 1;
@@ -1605,7 +1376,7 @@ extern "C" enum AwFmReturnCode awfmGpuMixedLookupLineTally(AwFmGpuIndex *g, cons
   hipStream_t s = nullptr;
   unsigned long long *pairLines = bits + lengthWords + deepWords, *nucLines = pairLines + (uint64_t)levels * pairWords;
   unsigned long long *sums = nucLines + (uint64_t)levels * nucWords; /* [0..2] the kernel's counts, [3..6] the four line totals */
-  const bool pairOff = !g->dev.pairBlocks || getenv("AWFM_GPU_ORDERED_NO_PAIR");
+  const bool pairOff = !pairSteps(g);
   const unsigned useNext = (g->dev.deepNext != 0u && !pairOff ? 1u : 0u) | (pairOff ? 2u : 0u);
   hipError_t e = hipMemsetAsync(bits, 0, words * 8u, s);
   unsigned long long host[8] = {0};
@@ -1981,7 +1752,7 @@ extern "C" enum AwFmReturnCode awfmGpuSortHitsOnDevice(AwFmGpuIndex *g, uint32_t
   hipLaunchKernelGGL(rankBlockScanKernel, dim3(1), dim3(1024), 0, s, blockCount, numBlocks);
   AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
   /* the last kernel carries the gate's event as its stop event */
-  const bool eager = !(gateLazy(s) && !getenv("AWFM_GPU_EAGER_EVENTS"));
+  const bool eager = !gateLazy(s);
   AWFM_LAUNCH_WITH_EVENTS(rankPlaceKernel, dim3(listGrid), dim3(256), 0, s, nullptr, eager ? g->sparseGate.done : nullptr, (const unsigned *)tmpKmers,
                         (const ulonglong2 *)tmpRanges, (const unsigned *)dNumHits, (unsigned)capacity, (unsigned long long)numQueries,
                         (const unsigned long long *)bitmap, (const unsigned *)blockCount, (unsigned *)dHitKmers, (ulonglong2 *)dHitRanges);

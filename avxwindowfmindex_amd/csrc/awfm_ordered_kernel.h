@@ -7,18 +7,19 @@
  * whatever the kernel does.  The order of the queries inside a batch is not part of the
  * result, so this path picks the order that makes those reads local:
  *
- *   1. encodeQueriesKernel: one thread per query packs the k-mer into 2-bit codes (a 16-byte record, or 8 bytes
- *      for fixed-length k-mers of up to 23 characters) and derives a 16-bit key = the leading bits of the string
- *      its search starts from (its table index; the k-mer itself when it is shorter than the seed).  Queries with
- *      ambiguity characters, no characters or more than 32 get key 0x8000 and are searched by the general kernel
- *      afterwards (searchKernel<INDIRECT>).
- *   2. rocPRIM radix sort of (key, record): two 8-bit passes.
+ *   1. a counting pass (encodeCodes4Kernel / encodeRecordsKernel): the k-mers as 2-bit codes and a histogram of the 2048
+ *      buckets the leading bits of the string their search starts from fall into (its table index; the k-mer itself when it is
+ *      shorter than the seed).  K-mers with ambiguity characters, no characters or more than 32 go to a last bin and are
+ *      searched by the general kernel afterwards (searchKernel<INDIRECT>).
+ *   2. a partition pass (partitionKernel / partitionRecordsKernel): records in bucket order, any order inside a bucket.
  *   3. orderedSearchKernel: the same table lookup and the same backward steps as searchKernel (nucFastStep) over
- *      the records in key order.  Neighbours in that order start in neighbouring table entries and, step after
+ *      the records in that order.  Neighbours in it start in neighbouring table entries and, step after
  *      step, land in neighbouring blocks (the range of cP lies in the c-section of the BWT in the order of P),
  *      so most block reads hit the L2.  Each XCD has its own L2: workgroup b runs on XCD b % 8, every XCD walks
  *      one contiguous eighth of the order, and its waves take consecutive chunks from ticket counters so that
  *      what is in flight stays within what the L2 holds.
+ *   Batches most of whose k-mers end at the deeper table skip the ordering: lookupSearchKernel (below) looks every k-mer's
+ *   entry up in input order and searches the few that are still alive itself.
  *
  * Putting results back under the original query numbers is a scatter of one partial line per query, which costs
  * as much as the ordering saves -- unless it is sparse.  This path therefore reports HITS: the
@@ -36,9 +37,6 @@
 #include "awfm_pair.h"
 
 namespace {
-
-constexpr unsigned kOrderKeyBits = 16;        /* sort key width */
-constexpr unsigned kOrderGeneralKey = 0x8000; /* key of the queries left to the general kernel */
 
 /* 4 characters -> 4 two-bit codes (first character in bits 7..6) and 4 "not a,c,g,t,u" flags (bit i = character i);
  * same SWAR decode as the window decode of searchKernel */
@@ -68,41 +66,6 @@ __device__ __forceinline__ void decodeWordAny(unsigned word, unsigned countMask,
   const unsigned expect = __builtin_amdgcn_perm(0u, 0x74676361u, t); /* byte i = "acgt"[code i] */
   diffs |= ((word | 0x20202020u) ^ expect) & ~b01 & countMask;
   packed = ((t & 3u) << 6) | ((t >> 4) & 0x30u) | ((t >> 14) & 0x0Cu) | (t >> 24);
-}
-
-/*
- * Sort key and record.  The key is the leading keyBits = min(15, 2*depth) bits of the table index (the low
- * 2*depth bits of the code string), left-aligned in 15 bits.  A 16-byte QueryRec carries the whole code string.
- * When the rest of the code string -- everything but those key bits, 2*len - keyBits bits -- fits 32 bits
- * (k-mers of up to 23 characters), the record is 8 bytes instead: rest in the high word, query number in the
- * low word; the sort then moves 10 bytes per query instead of 18, and the search rebuilds the codes from the
- * sorted key and the rest.
- */
-struct OrderFormat {
-  unsigned depth;    /* characters the table lookup consumes */
-  unsigned keyBits;  /* min(15, 2*depth) */
-  unsigned lowBits;  /* 2*depth - keyBits: table-index bits below the key */
-};
-__host__ __device__ inline OrderFormat orderFormat(unsigned depth) {
-  OrderFormat f;
-  f.depth = depth;
-  f.keyBits = 2u * depth < 15u ? 2u * depth : 15u;
-  f.lowBits = 2u * depth - f.keyBits;
-  return f;
-}
-__host__ __device__ inline bool orderCompact(unsigned len, unsigned depth) { return 2u * len - orderFormat(depth).keyBits <= 32u; }
-__device__ __forceinline__ unsigned orderKey(const OrderFormat &f, unsigned long long codes) {
-  const unsigned long long index = codes & ((1ull << (2u * f.depth)) - 1ull);
-  return (unsigned)(index >> f.lowBits) << (15u - f.keyBits);
-}
-__device__ __forceinline__ unsigned orderRest(const OrderFormat &f, unsigned long long codes) {
-  const unsigned long long low = codes & ((1ull << f.lowBits) - 1ull);
-  return (unsigned)(((codes >> (2u * f.depth)) << f.lowBits) | low);
-}
-__device__ __forceinline__ unsigned long long orderCodes(const OrderFormat &f, unsigned key, unsigned rest) {
-  const unsigned long long low = (unsigned long long)rest & ((1ull << f.lowBits) - 1ull);
-  const unsigned long long index = ((unsigned long long)(key >> (15u - f.keyBits)) << f.lowBits) | low;
-  return ((unsigned long long)(rest >> f.lowBits) << (2u * f.depth)) | index;
 }
 
 /* 2-bit codes (last character in bits 1..0) and ambiguity mask (bit i = character i is not a,c,g,t,u) of the `len`
@@ -156,81 +119,6 @@ __host__ __device__ inline unsigned orderStartDepth(unsigned len, unsigned seedK
   return len >= seedK ? seedK : 0u;
 }
 
-/* Record + key per query.  Fixed-length batch (VARLEN false): every k-mer has fixedLen characters and starts at
- * table depth fixedDepth; recs is QueryRec[numQueries], or unsigned long long[numQueries] when COMPACT.  CSR batch
- * (VARLEN): lengths from the offsets, the start depth per k-mer (orderStartDepth), 16-byte records; the key of a
- * k-mer that starts below a table is the leading bits of the k-mer itself, which is where its letter-range
- * search ends up in the BWT.  K-mers the ordered kernel does not cover (ambiguity characters, no characters,
- * more than 32) get the general key. */
-/* (Staging a workgroup's 256 * fixedLen contiguous bytes through LDS with coalesced dword loads, with or without the
- * "no hit" fill folded in, was measured slower than these per-thread unaligned-stride reads: search call 6.87-6.93
- * against 6.54-6.70 ms per 10^8 21-mers in a same-box A/B -- the L1 already serves the overlapping dwords.) */
-/* PACKED: `chars` is one 64-bit word per k-mer (2-bit codes, last character in bits 1..0: the record's own format;
- * include/awfm_gpu.h), fixed length: nothing to decode, and no k-mer is left to the general kernel */
-template <bool COMPACT, bool VARLEN, bool PACKED = false>
-__global__ void __launch_bounds__(256)
-    encodeQueriesKernel(const unsigned char *__restrict__ chars, const unsigned long long *__restrict__ offsets,
-                        const unsigned fixedLen, const unsigned fixedDepth, const unsigned seedK, const unsigned deepK,
-                        const unsigned long long numQueries, unsigned short *__restrict__ keys,
-                        void *__restrict__ recs, unsigned *__restrict__ generalCount, const unsigned keyMask = 0xFFFFu) {
-  const unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
-  const bool live = t < numQueries;
-  unsigned long long codes = 0, start = 0;
-  unsigned bad = 0, len = fixedLen;
-  if (live) {
-    if (VARLEN) {
-      start = offsets[t];
-      const unsigned long long l = offsets[t + 1] - start;
-      len = l > 33ull ? 33u : (unsigned)l;
-    } else {
-      start = t * fixedLen;
-    }
-  }
-  const bool inRange = live && len >= 1u && len <= 32u;
-  if (PACKED) {
-    if (inRange) {
-      const unsigned long long word = ((const unsigned long long *)chars)[t];
-      codes = len >= 32u ? word : (word & ((1ull << (2u * len)) - 1ull));
-    }
-  } else if (inRange) {
-    decodeKmer(chars, start, len, codes, bad);
-  }
-  const bool fast = inRange && bad == 0u;
-  if (live) {
-    unsigned key = kOrderGeneralKey;
-    if (fast) {
-      if (VARLEN) {
-        /* leading 15 bits of the string the search starts from: the last `depth` characters, or the whole
-         * k-mer when it starts from a letter range */
-        key = startKey15(codes, len, orderStartDepth(len, seedK, deepK));
-      } else {
-        key = orderKey(orderFormat(fixedDepth), codes);
-      }
-    }
-    /* measurement knob ($AWFM_GPU_ORDER_KEY_BITS, 16-byte records only: an 8-byte record relies on its key for the bits
-     * the record leaves out): a coarser order */
-    if (!COMPACT && fast) key &= keyMask;
-    keys[t] = (unsigned short)key;
-    if (COMPACT) {
-      ((unsigned long long *)recs)[t] =
-          ((unsigned long long)(fast ? orderRest(orderFormat(fixedDepth), codes) : 0u) << 32) | (unsigned)t;
-    } else {
-      QueryRec r;
-      r.codes = codes;
-      r.index = (unsigned)t;
-      r.length = fast ? len : 0xFFFFFFFFu;
-      ((QueryRec *)recs)[t] = r;
-    }
-  }
-  const unsigned long long general = __ballot(live && !fast);
-  if ((threadIdx.x & 63u) == 0u && general != 0ull) atomicAdd(generalCount, (unsigned)__popcll(general));
-}
-
-/*
- * Backward search over the ordered records.  Group/lane layout and the step are those of searchKernel; a query
- * comes from a 16-byte record (read one iteration ahead) and only a non-empty final range is stored, under the
- * original query number.
- */
 /*
  * ---- the hand-written ordering of fixed-length batches: one counting pass + one partition pass ----
  *
@@ -423,132 +311,6 @@ __global__ void __launch_bounds__(256)
       (void)ldsCountRank(sHist, bad[i] ? bins - 1u : bucketOf(f, codes[i]), t + i < last);
     }
   }
-  __syncthreads();
-  for (unsigned e = threadIdx.x; e < bins; e += 256u)
-    if (sHist[e]) atomicAdd(&hist[share * binsPad + e], sHist[e]);
-}
-
-/* ---- looking the table entry up in the encode pass ("lookup first") ----
- * In a batch most of whose k-mers do not occur, nearly every k-mer ends at its entry of the deeper table (no such
- * deepK-mer, or a clear next-step bit: 95.6 % of 10^8 random 21-mers against 3.1 Gbp), and ordering the batch first means
- * writing, reading and partitioning 10^8 code words so that a kernel can then read one table line per k-mer in a nicer
- * order.  This pass decodes as encodeCodes4Kernel does, looks the entry up right away (four lookups per thread in flight),
- * and keeps only the k-mers that are still alive: their code words and numbers are appended to the share's region of the
- * code array (one atomic per wave and round), and only they are counted, partitioned and searched -- by the same kernels,
- * which look a survivor's entry up again.  Results are the same: a k-mer dropped here has no hit.
- * alive = ambiguity characters (the general kernel's) | length != 0 and, with next-step bits and a pair step to come, its bit. */
-template <unsigned K>
-__global__ void __launch_bounds__(256)
-    encodeLookupKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const BucketFormat f, const unsigned useNext,
-                       const unsigned long long numQueries, unsigned long long *__restrict__ codesOut,
-                       unsigned *__restrict__ numbersOut, unsigned *__restrict__ shareCount, unsigned *__restrict__ hist,
-                       const unsigned binsPad, const unsigned *__restrict__ sampleAlive = nullptr, const unsigned samples = 0u) {
-  extern __shared__ unsigned sHist[]; /* 2^bucketBits + 1 */
-  if (!lookupChosen(sampleAlive, samples, true)) return; /* this batch is encodeCodes4Kernel's (uniform) */
-  const unsigned bins = (1u << f.bucketBits) + 1u;
-  for (unsigned e = threadIdx.x; e < bins; e += 256u) sHist[e] = 0u;
-  __syncthreads();
-  constexpr unsigned kLoads = (K + 1u + 3u) / 4u;
-  const unsigned shift = (unsigned)((unsigned long long)chars & 3ull);
-  typedef const Dwords4 __attribute__((address_space(1))) *GlobalDwords4;
-  const unsigned share = blockIdx.x % kShares, localBlock = blockIdx.x / kShares, localGrid = gridDim.x / kShares;
-  const unsigned long long size = shareSize(numQueries), first = size * share;
-  const unsigned long long last = first + size < numQueries ? first + size : numQueries;
-  const unsigned long long tableMask = (1ull << (2u * f.depth)) - 1ull;
-  const unsigned lengthBits = deepLengthBits(ix);
-  const unsigned lane = threadIdx.x & 63u;
-  unsigned blockBase = 0, blockUsed = 0, blockSlots = 0; /* the wave's block of slots in its share's region (wave-uniform) */
-  /* wave-uniform trip count: the append below is a wave-wide exchange */
-  const unsigned long long waveFirst = first + 4ull * ((unsigned long long)localBlock * 256ull + (threadIdx.x & ~63u));
-  for (unsigned long long tw = waveFirst; tw < last; tw += 4ull * localGrid * 256ull) {
-    const unsigned long long t = tw + 4ull * lane;
-    unsigned long long codes[4];
-    unsigned bad[4];
-    if (t * K + 16ull * kLoads <= numQueries * K) { /* the 16-byte loads from the aligned-down start stay inside the batch */
-      const GlobalDwords4 from = (GlobalDwords4)(((unsigned long long)chars + t * K) & ~3ull);
-      unsigned dw[kLoads * 4u + 1u];
-#pragma unroll
-      for (unsigned j = 0; j < kLoads; j++) {
-        const Dwords4 q = from[j];
-        dw[4u * j] = q.x;
-        dw[4u * j + 1u] = q.y;
-        dw[4u * j + 2u] = q.z;
-        dw[4u * j + 3u] = q.w;
-      }
-      dw[kLoads * 4u] = 0u;
-      unsigned al[K + 1u];
-#pragma unroll
-      for (unsigned j = 0; j < K; j++) al[j] = __builtin_amdgcn_alignbyte(dw[j + 1u], dw[j], shift);
-      al[K] = 0u;
-#pragma unroll
-      for (unsigned i = 0; i < 4u; i++) {
-        constexpr unsigned kWords = (K + 3u) / 4u;
-        const unsigned at = i * K;
-        unsigned long long c = 0;
-        unsigned b = 0;
-#pragma unroll
-        for (unsigned w = 0; w < 8u; w++) {
-          unsigned packed = 0;
-          if (w < kWords) {
-            const unsigned lo = al[(at >> 2) + w], hi = (at >> 2) + w + 1u <= K ? al[(at >> 2) + w + 1u] : 0u;
-            const unsigned inKmer = K - 4u * w >= 4u ? 4u : K - 4u * w;
-            decodeWordAny(__builtin_amdgcn_alignbyte(hi, lo, at & 3u), inKmer >= 4u ? ~0u : (1u << (8u * inKmer)) - 1u, packed, b);
-          }
-          c = (c << 8) | packed;
-        }
-        codes[i] = c >> (2u * (32u - K));
-        bad[i] = b;
-      }
-    } else {
-#pragma unroll
-      for (unsigned i = 0; i < 4u; i++) {
-        codes[i] = 0;
-        bad[i] = 0;
-        if (t + i < numQueries) decodeKmer(chars, (t + i) * K, K, codes[i], bad[i]);
-      }
-    }
-    uint2 entry[4];
-#pragma unroll
-    for (unsigned i = 0; i < 4u; i++) entry[i] = ((const uint2 *)ix.deepSeed)[t + i < last && !bad[i] ? (codes[i] & tableMask) : 0ull];
-    bool alive[4];
-    unsigned long long mask[4];
-    unsigned before[4], total = 0;
-#pragma unroll
-    for (unsigned i = 0; i < 4u; i++) {
-      const unsigned length = entry[i].y & lengthBits;
-      const bool bit = !useNext || ((entry[i].y >> (16u + ((unsigned)(codes[i] >> (2u * f.depth)) & 15u))) & 1u) != 0u;
-      alive[i] = t + i < last && (bad[i] != 0u || (length != 0u && bit));
-      mask[i] = __ballot(alive[i]);
-      before[i] = total;
-      total += (unsigned)__popcll(mask[i]);
-    }
-    if (total != 0u) { /* wave-uniform */
-      if (blockUsed + total > blockSlots) {
-        /* a new block of slots (the counters of the shares are a line apart: returning atomics on one line serialise, and
-         * one per wave and round -- 4 * 10^5 of them -- took longer than the whole pass); what is left of the old one holds no k-mer */
-        if (blockUsed + lane < blockSlots) codesOut[first + blockBase + blockUsed + lane] = kCodeNone;
-        /* (never rounded up in the round that reaches the end of the share: the share's region holds as many slots as the
-         * share has k-mers, and a round of fewer than 64 k-mers that took 64 would run past it -- into the next region,
-         * or, in the last share, past the code array) */
-        blockSlots = total > kLookupBlock || tw + 256ull > last ? total : kLookupBlock;
-        unsigned base = 0;
-        if (lane == 0) base = atomicAdd(&shareCount[share * kShareCountStride], blockSlots);
-        blockBase = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-        blockUsed = 0;
-      }
-#pragma unroll
-      for (unsigned i = 0; i < 4u; i++) {
-        if (alive[i]) {
-          const unsigned long long slot = first + blockBase + blockUsed + before[i] + (unsigned)__popcll(mask[i] & ((1ull << lane) - 1ull));
-          codesOut[slot] = bad[i] ? kCodeGeneral : codes[i];
-          numbersOut[slot] = (unsigned)(t + i);
-        }
-        (void)ldsCountRank(sHist, bad[i] ? bins - 1u : bucketOf(f, codes[i]), alive[i]);
-      }
-      blockUsed += total;
-    }
-  }
-  for (unsigned at = blockUsed + lane; at < blockSlots; at += 64u) codesOut[first + blockBase + at] = kCodeNone;
   __syncthreads();
   for (unsigned e = threadIdx.x; e < bins; e += 256u)
     if (sHist[e]) atomicAdd(&hist[share * binsPad + e], sHist[e]);
@@ -863,36 +625,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
   }
 }
 
-/* how many of `samples` k-mers taken at a fixed stride over the batch are alive in the sense above: says beforehand
- * whether the batch is one for encodeLookupKernel */
-__global__ void __launch_bounds__(256)
-    sampleAliveKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const unsigned fixedLen, const unsigned depth,
-                      const unsigned useNext, const unsigned long long numQueries, const unsigned samples, unsigned *__restrict__ aliveOut) {
-  const unsigned j = blockIdx.x * 256u + threadIdx.x;
-  bool alive = false;
-  if (j < samples) {
-    const unsigned long long t = (unsigned long long)j * (numQueries / samples);
-    unsigned long long codes = 0;
-    unsigned bad = 0;
-    decodeKmer(chars, t * fixedLen, fixedLen, codes, bad);
-    if (bad) {
-      alive = true;
-    } else {
-      const uint2 e = ((const uint2 *)ix.deepSeed)[codes & ((1ull << (2u * depth)) - 1ull)];
-      const unsigned length = e.y & deepLengthBits(ix);
-      alive = length != 0u && (!useNext || ((e.y >> (16u + ((unsigned)(codes >> (2u * depth)) & 15u))) & 1u) != 0u);
-    }
-  }
-  /* one atomic per workgroup: a thousand waves each adding to the one word were 12 of this kernel's 17 us */
-  __shared__ unsigned sAlive;
-  if (threadIdx.x == 0) sAlive = 0u;
-  __syncthreads();
-  const unsigned n = (unsigned)__popcll(__ballot(alive));
-  if ((threadIdx.x & 63u) == 0 && n) atomicAdd(&sAlive, n);
-  __syncthreads();
-  if (threadIdx.x == 0 && sAlive) atomicAdd(aliveOut, sAlive);
-}
-
 /* Everything a bucketed search needs before its front end, in ONE launch (round 5; they were a memset, a fill kernel and
  * sampleAliveKernel: 17 of the 470 us a 1.25 * 10^7-k-mer shard takes): the scratch counters zeroed (two regions of 16-byte
  * pieces), the caller's list of hits pre-filled, and the sample taken.  The sample's word is not zeroed by the launch that
@@ -930,7 +662,7 @@ __global__ void __launch_bounds__(256)
   bool alive = false;
   if (gid < samples) {
     const unsigned long long t = (unsigned long long)gid * (numQueries / samples);
-    if (AMINO) { /* aminoSampleAliveKernel's test (awfm_amino_lookup_kernel.h): the entry over the last `depth` characters */
+    if (AMINO) { /* aminoLookupSearchKernel's test (awfm_amino_lookup_kernel.h): the entry over the last `depth` characters */
       const unsigned char *at = chars + t * fixedLen;
       unsigned idx = 0;
       bool bad = false;
@@ -1379,7 +1111,7 @@ struct OrderSkip<true> {
 };
 
 constexpr unsigned kTicketGroups = 4; /* ticket counters per XCD and wave slot */
-template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false,
+template <int G, bool NARROW, bool VARLEN, bool PAIR = false, bool TOUCH = false, bool BUCKET = false,
           bool LIST = false /* bucketed records + the list of hits: a wave collects its hits (below) */>
 /* registers: 8 waves per SIMD (64 VGPRs) for the one-step variants; the mixed-length, the pair and the bucketed variants get
  * 72 (7 waves) -- the bucketed pair variant, which carries the next chunk's codes, query number and table entry as well,
@@ -1387,15 +1119,14 @@ template <int G, bool NARROW, bool COMPACT, bool VARLEN, bool PAIR = false, bool
  * table (10^8 random 21-mers 2.31-2.38 against 2.57-2.59 ms with 80 registers and 6 waves; planted 5.17 against 5.25) --;
  * the 64-bit pair variants, the instrumented variant and the wide two-lane measurement variant get 80 (6 waves). */
 __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(G >= 2 ? ((PAIR && !NARROW) || TOUCH || (G == 2 && !NARROW) ? 6 : (VARLEN || PAIR || BUCKET ? 7 : 8)) : 2, 8)))
-    orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned short *__restrict__ keys,
-                        const unsigned long long numRecs,
+    orderedSearchKernel(const DevIndex ix, const void *__restrict__ recs, const unsigned long long numRecs,
                         const unsigned *__restrict__ generalCount, const unsigned len, const unsigned depth,
                         const ulonglong2 *__restrict__ table, ulonglong2 *__restrict__ ranges,
-                        unsigned *__restrict__ counts, unsigned *__restrict__ tickets, const int xcdMap = 0,
+                        unsigned *__restrict__ counts, unsigned *__restrict__ tickets,
                         const OrderTouch touch = OrderTouch(), const unsigned *__restrict__ bucketStart = nullptr,
                         const BucketFormat bucketFmt = BucketFormat(), const SparseOut sparse = SparseOut(),
                         const unsigned chunksPerTicket = 1u, const OrderSkip<VARLEN> skip = OrderSkip<VARLEN>()) {
-  static_assert(!BUCKET || (COMPACT && !VARLEN), "bucketed records are the 8-byte records of fixed-length batches");
+  static_assert(!BUCKET || !VARLEN, "bucketed records are the 8-byte records of fixed-length batches");
   /* a mixed-length batch that the sample gave to mixedLookupSearchKernel: no records were written (uniform) */
   if (skip.chosen()) return;
   constexpr bool AHEAD = BUCKET; /* the next chunk's table entry is requested a chunk ahead */
@@ -1430,19 +1161,15 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   if (PAIR) pairStageTables<NARROW, 16u>(ix, sPairC, sPairSuper);
   __syncthreads();
 
-  const OrderFormat format = orderFormat(depth);
-  /* A record as loaded: {codes, query number | length << 32} (16 bytes), or COMPACT the 8-byte record plus the
-   * aligned dword that holds its sorted 16-bit key.  Every loaded value lands in the register it is later read
-   * from (no widening, no copy: either would be waited for right after the load) and is taken apart one
-   * iteration later. */
+  /* A record as loaded: {codes, query number | length << 32} (16 bytes), or BUCKET the 8-byte record.  Every loaded value
+   * lands in the register it is later read from (no widening, no copy: either would be waited for right after the load)
+   * and is taken apart one iteration later. */
   struct Raw {
-    unsigned long long a, b; /* wide: the two words; COMPACT: a = record */
-    unsigned keyWord;        /* COMPACT */
+    unsigned long long a, b; /* 16-byte records: the two words; BUCKET: a = record */
   };
   auto readRecord = [&](unsigned long long at, Raw &r) {
-    if (COMPACT) {
+    if (BUCKET) {
       r.a = ((const unsigned long long *)recs)[at];
-      if (!BUCKET) r.keyWord = ((const unsigned *)keys)[at >> 1];
     } else {
       const ulonglong2 w = *(const ulonglong2 *)((const QueryRec *)recs + at);
       r.a = w.x;
@@ -1473,10 +1200,9 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   /* (bucketed records: what lies before the last bin -- the batch without the k-mers of the general kernel, or the k-mers
    * encodeLookupKernel kept) */
   const unsigned long long covered = BUCKET ? (unsigned long long)bucketStart[1u << bucketFmt.bucketBits] : numRecs - (unsigned long long)*generalCount;
-  const unsigned xcds = (gridDim.x & 7u) == 0u && xcdMap != 2 ? 8u : 1u;
-  const unsigned perXcd = gridDim.x / xcds;
-  const unsigned xcd = xcds == 8u ? (xcdMap == 1 ? blockIdx.x / perXcd : (blockIdx.x & 7u)) : 0u;
-  const unsigned blockInXcd = xcds == 8u ? (xcdMap == 1 ? blockIdx.x % perXcd : (blockIdx.x >> 3)) : blockIdx.x;
+  const unsigned xcds = (gridDim.x & 7u) == 0u ? 8u : 1u; /* (workgroup b runs on XCD b % 8 under round-robin dispatch) */
+  const unsigned xcd = xcds == 8u ? (blockIdx.x & 7u) : 0u;
+  const unsigned blockInXcd = xcds == 8u ? (blockIdx.x >> 3) : blockIdx.x;
   const unsigned long long share = (covered + xcds - 1ull) / xcds;
   const unsigned long long begin = share * xcd;
   const unsigned long long end = begin + share < covered ? begin + share : covered;
@@ -1541,7 +1267,7 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   unsigned long long baseNext = nextChunk();
 
   const unsigned long long tableMask = (1ull << (2u * depth)) - 1ull;
-  Raw raw = {0ull, 0ull, 0u}; /* the prefetched record */
+  Raw raw = {0ull, 0ull}; /* the prefetched record */
   if (base + lane / G < end) readRecord(base + lane / G, raw);
   /* BUCKET: a record does not hold the bits its bucket stands for; the bucket of a position is where bucketStart says.
    * The wave keeps the bucket of the chunk it looked at last (its chunks come in increasing order): wave-uniform, scalar
@@ -1653,12 +1379,9 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
     } else {
     /* the record fetched an iteration ago is taken apart BEFORE anything new is issued: a wait placed after the
      * atomic below would also wait for that atomic */
-    asm volatile("" : "+v"(raw.a), "+v"(raw.b), "+v"(raw.keyWord)::"memory");
-    const unsigned key = (raw.keyWord >> (16u * (unsigned)(q & 1ull))) & 0xFFFFu;
-    codes = BUCKET    ? bucketCodes(bucketFmt, laneBucket(base), raw.a >> bucketFmt.indexBits)
-            : COMPACT ? orderCodes(format, key, (unsigned)(raw.a >> 32))
-                      : raw.a;
-    index = BUCKET ? (unsigned)(raw.a & ((1ull << bucketFmt.indexBits) - 1ull)) : COMPACT ? (unsigned)raw.a : (unsigned)raw.b;
+    asm volatile("" : "+v"(raw.a), "+v"(raw.b)::"memory");
+    codes = BUCKET ? bucketCodes(bucketFmt, laneBucket(base), raw.a >> bucketFmt.indexBits) : raw.a;
+    index = BUCKET ? (unsigned)(raw.a & ((1ull << bucketFmt.indexBits) - 1ull)) : (unsigned)raw.b;
     }
     const unsigned myLen = VARLEN ? (unsigned)(raw.b >> 32) : len; /* before `raw` is overwritten by the prefetch */
     /* ---- seed (ref src/AwFmKmerTable.c:4-51): the index table, or the deeper device-only one ---- */

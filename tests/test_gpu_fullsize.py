@@ -249,6 +249,63 @@ def test_an_index_beyond_2_pow_32_positions_built_searched_and_located_on_the_gp
     assert float(single.float().mean()) > 0.99
     assert torch.equal(d_pos[d_off[:half][single]], planted[single])
     assert n < (1 << 32) or bool((beyond & single).any())
+    if not amino and n >= (1 << 32):
+        # round 6: the FAST path of an image beyond 2^32 positions, nothing forced -- the deeper table in its packed 8-byte form
+        # with next-step bits, the full suffix array in 40-bit entries, and, for a batch of random 21-mers in the list form
+        # (bench.py's timed step), lookupSearchKernel's 64-bit instantiation: it must be the kernel that ran, and its list,
+        # offsets and positions must be those of the exact general search and of the LF walk
+        assert g.is_wide and g.deep_seed_k == 16 and g.has_dense_sa and "next-step bits" in g.describe(), g.describe()
+        Kr, Qr = 21, Q
+        d_rand = torch.empty(Qr * Kr + 8, dtype=torch.uint8, device=dev)
+        assert L.awfmGpuSynthRandomQueries(d_rand.data_ptr(), 0, Qr, Kr, 205, 0, None) == 1
+        cap = Qr // 64
+        lk = torch.empty(cap, dtype=torch.int32, device=dev)
+        lr = torch.empty(cap * 2, dtype=torch.int64, device=dev)
+        sk = torch.empty(cap, dtype=torch.int32, device=dev)
+        sr = torch.empty(cap * 2, dtype=torch.int64, device=dev)
+        lo_ = torch.empty(cap + 1, dtype=torch.int64, device=dev)
+        num = torch.zeros(1, dtype=torch.int32, device=dev)
+        lpos = torch.empty(Qr // 16, dtype=torch.int64, device=dev)
+        st = torch.cuda.Stream()
+        for _ in range(3):  # (the third call is predicted: the lookup kernel alone)
+            g.search_hits_compact(d_rand.data_ptr(), 0, Kr, Qr, lk.data_ptr(), lr.data_ptr(), cap, num.data_ptr(), stream=st.cuda_stream)
+            g.list_locate_on_device(lk.data_ptr(), lr.data_ptr(), cap, num.data_ptr(), Qr, sk.data_ptr(), sr.data_ptr(), lo_.data_ptr(),
+                                    lpos.numel(), lpos.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize()
+        assert g.last_ordered_kernel_is_lookup(), "the lookup kernel did not take a batch of random 21-mers on an image beyond 2^32 positions"
+        assert g.last_lookup_front() == 1
+        m_ = int(num.item())
+        ex = torch.empty(Qr * 2, dtype=torch.int64, device=dev)
+        g.search(d_rand.data_ptr(), 0, Kr, Qr, ex.data_ptr(), 0)  # exact ranges
+        torch.cuda.synchronize()
+        ex2 = ex.view(Qr, 2)
+        want = torch.nonzero(ex2[:, 0] <= ex2[:, 1]).flatten()
+        assert m_ == want.numel() and m_ > 1000 and torch.equal(sk[:m_].to(torch.int64), want)
+        assert torch.equal(sr.view(cap, 2)[:m_], ex2[want])
+        tot = int(lo_[cap].item())
+        assert tot == int((ex2[want, 1] - ex2[want, 0] + 1).sum()) and tot <= lpos.numel()
+        g.set_dense_sa(False)  # the same list through the LF walk and the sampled array (the reference's backtrace)
+        walked = torch.empty(tot, dtype=torch.int64, device=dev)
+        g.locate(sr.data_ptr(), lo_.data_ptr(), m_, tot, walked.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(walked, lpos[:tot]), "the 40-bit full suffix array and the LF walk disagree"
+        own = torch.repeat_interleave(want, ex2[want, 1] - ex2[want, 0] + 1)
+        r2d = d_rand[: Qr * Kr].view(Qr, Kr)
+        for c in range(Kr):
+            assert torch.equal(d_text[walked + c], r2d[own, c]), f"a random k-mer's hit does not spell it at character {c}"
+        # ... and the array once more, this time put together from the sampled one (what an index read from a file gets: capped
+        # walks, parked ones completed by pointer jumping, 64-bit entries packed to 40 bits): the same positions again
+        t1 = time.time()
+        g.set_dense_sa(True)
+        torch.cuda.synchronize()
+        print(f"[wide full suffix array from the sampled one] {time.time() - t1:.1f} s")
+        assert g.has_dense_sa
+        lpos.fill_(-1)
+        g.list_locate_on_device(lk.data_ptr(), lr.data_ptr(), cap, num.data_ptr(), Qr, sk.data_ptr(), sr.data_ptr(), lo_.data_ptr(),
+                                lpos.numel(), lpos.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize()
+        assert torch.equal(walked, lpos[:tot]), "the full suffix array built from the sampled one gives other positions"
+        del d_rand, ex, walked, lpos
     # oracle over the downloaded (reference-layout) arrays on a sample from both halves of the batch
     oi = oracle.Index.wrap(oracle.AMINO if amino else oracle.DNA, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(),
                            ix.seed_table(), ix.packed_sa())

@@ -165,13 +165,15 @@ def test_long_hit_lists_located_in_windows_through_the_full_suffix_array(oracle,
     ix.dealloc()
 
 
-def test_full_suffix_array_of_a_text_with_long_runs(oracle, awfm, require_gpu, monkeypatch):
+def test_full_suffix_array_of_a_text_with_long_runs(oracle, awfm, require_gpu, monkeypatch, wide):
     """A text with R long runs of one letter, R a multiple of the sampling ratio (a genome's runs of N): the suffixes inside
     the runs move R places per LF step and never meet a sample until a run ends.  The AUTOMATIC construction of the full
     suffix array parks such walks after 32 x ratio steps and completes the parked entries from each other (pointer
     jumping); a construction that was asked for walks to the end; an index built on the GPU hands its own suffix array to
     its image and walks nothing; without the array the locate walks, as the reference does.  Positions against the oracle
-    in all four cases -- k-mers right behind a run (their walks enter it) and k-mers of N (hits INSIDE the runs) included."""
+    in all four cases -- k-mers right behind a run (their walks enter it) and k-mers of N (hits INSIDE the runs) included.
+    Round 6: with 64-bit positions (`wide`) the array has 40-bit entries and its own construction (64-bit entries, the parked
+    walks in a list read from the round before)."""
     import torch
     n, runs, run_len, ratio = 160000, 8, 3000, 8
     txt = synth.text(n + 71, n, synth.DNA_ALPHABET).copy()
