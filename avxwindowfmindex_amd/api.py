@@ -236,6 +236,10 @@ def pack_kmers(kmers, alphabet=AwFmAlphabetDna):
     return out
 
 
+# enum AwFmGpuKernel (include/awfm_gpu.h)
+AWFM_GPU_KERNEL_AUTO, AWFM_GPU_KERNEL_GROUP8, AWFM_GPU_KERNEL_GROUP4, AWFM_GPU_KERNEL_GROUP2, AWFM_GPU_KERNEL_GROUP1 = range(5)
+
+
 class GpuIndex:
     """AwFmGpuIndex* owner: the device image plus the flat batch API of include/awfm_gpu.h"""
 
@@ -315,6 +319,9 @@ class GpuIndex:
         return bool(_lib.lib().awfmGpuIndexHasPairImage(self.handle))
 
     def set_kernel(self, kernel):
+        """enum AwFmGpuKernel (include/awfm_gpu.h): AWFM_GPU_KERNEL_AUTO, or a fixed number of lanes per k-mer for the general
+        kernel and the walk -- anything but AUTO / GROUP4 keeps a search away from the pair image and the device-only tables,
+        i.e. runs the reference's letter-by-letter algorithm (what the differential fuzz compares everything else with)"""
         _lib.lib().awfmGpuIndexSetKernel(self.handle, kernel)
 
     def set_wide(self, wide=True):

@@ -207,7 +207,7 @@ struct locateCtx {
   /* the window being scattered */
   uint64_t queryBegin, hitBegin, hitEnd;
   const uint64_t *positions;
-  double waitMs, scatterMs; /* $AWFM_GPU_AOS_TRACE */
+  double waitMs, scatterMs; /* $AWFM_GPU_DIAG aos_trace */
 };
 
 /* ref src/AwFmParallelSearch.c:327-328, :367-387 (setPositionListCount): count is set, the list grows by realloc to
@@ -291,7 +291,7 @@ static void invalidateCounts(struct AwFmKmerSearchData *data, uint64_t n) {
  * download) alternate, so a list is cut into chunks that the lanes -- one host thread per device image, three images
  * on the default device -- take in turn: while one lane waits for the device, another packs or scatters with ALL the
  * caller's threads.  The host stages take turns (hostStage); a lane never waits for the device while it holds the
- * turn.  $AWFM_GPU_AOS_CHUNK: k-mers per chunk; $AWFM_GPU_AOS_TRACE: one line per chunk on stderr. */
+ * turn.  $AWFM_GPU_AOS_CHUNK: k-mers per chunk; $AWFM_GPU_DIAG aos_trace=1: one line per chunk on stderr. */
 #define AWFM_AOS_CHUNK_DEFAULT (1u << 20) /* 10^7 random 21-mers, locate, 32 threads: 8.5 ms at 2^20 or 2^21, 13.7 ms at 4*10^6 */
 static pthread_mutex_t hostStage = PTHREAD_MUTEX_INITIALIZER;
 
@@ -459,7 +459,7 @@ static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKm
   bool spawned[AWFM_MAX_IMAGES] = {false};
   for (int i = 0; i < numImages; i++)
     jobs[i] = (struct laneJob){images[i], list->kmerSearchData, n, chunk, (unsigned)i, (unsigned)numImages, numThreads > 0 ? numThreads : 1,
-                               locate, getenv("AWFM_GPU_AOS_TRACE") != NULL, AwFmSuccess, {0}};
+                               locate, getenv("AWFM_GPU_DIAG") != NULL && strstr(getenv("AWFM_GPU_DIAG"), "aos_trace") != NULL, AwFmSuccess, {0}};
   for (int i = 1; i < numImages; i++) spawned[i] = pthread_create(&threads[i], NULL, runLane, &jobs[i]) == 0;
   runLane(&jobs[0]);
   int firstFailed = jobs[0].rc != AwFmSuccess ? 0 : -1;

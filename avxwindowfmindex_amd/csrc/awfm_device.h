@@ -962,16 +962,38 @@ struct AwFmGpuIndex {
   struct AwFmGpuStreamState *streamState = nullptr;
 };
 
+/* Test and diagnostics hooks -- none of them selects a faster path --, all behind ONE environment variable:
+ * $AWFM_GPU_DIAG = "key=value,key=value,..." (include/awfm_gpu.h lists the keys).  Returns the value of `key` (up to 31
+ * characters, in a buffer of the calling thread), or NULL. */
+inline const char *awfmGpuDiag(const char *key) {
+  const char *env = getenv("AWFM_GPU_DIAG");
+  if (!env) return nullptr;
+  static thread_local char value[32];
+  const size_t keyLen = strlen(key);
+  for (const char *at = env; *at;) {
+    const char *end = strchr(at, ',');
+    const size_t len = end ? (size_t)(end - at) : strlen(at);
+    if (len > keyLen && !strncmp(at, key, keyLen) && at[keyLen] == '=') {
+      const size_t n = len - keyLen - 1 < sizeof(value) - 1 ? len - keyLen - 1 : sizeof(value) - 1;
+      memcpy(value, at + keyLen + 1, n);
+      value[n] = 0;
+      return value;
+    }
+    at += len + (end ? 1 : 0);
+  }
+  return nullptr;
+}
+
 /* sizes of the device block array and of the superblock table of an index */
 inline uint64_t awfmDeviceBlocks(uint64_t bwtLength) { return 2 * awfmNumBlocks(bwtLength); }
 inline uint64_t awfmDeviceBlockBytes(bool amino) { return amino ? 128 : 64; }
-/* log2 of the positions per superblock.  Nucleotide: 32.  $AWFM_GPU_NUC_SUPER_SHIFT = 13..31, or "auto" (the
+/* log2 of the positions per superblock.  Nucleotide: 32.  $AWFM_GPU_DIAG nuc_super_shift = 13..31, or "auto" (the
  * smallest shift >= 13 that gives at most 48 superblocks), makes them smaller so that the parity tests reach the
  * several-superblock arithmetic an index of 2^32 or more positions runs -- such an image always uses the 64-bit
  * kernels, the only ones that read the superblock bases. */
 inline unsigned awfmSuperShift(bool amino, uint64_t bwtLength) {
   if (amino) return kAminoSuperShift;
-  if (const char *env = getenv("AWFM_GPU_NUC_SUPER_SHIFT")) {
+  if (const char *env = awfmGpuDiag("nuc_super_shift")) {
     if (!strcmp(env, "auto")) {
       unsigned shift = 13;
       while (((bwtLength - 1) >> shift) + 1 > 48) shift++;
@@ -997,9 +1019,8 @@ inline bool awfmImageNarrow(const AwFmGpuIndex *g) {
 }
 
 /* where the kernels that use the pair image keep its 32-bit superblock bases (64 B per 2^23 positions): in dynamic LDS,
- * or read from memory beside the blocks.  $AWFM_GPU_PAIR_SUPER=lds|global (measurement knob) */
+ * or read from memory beside the blocks */
 inline bool awfmPairSuperInLds(const AwFmGpuIndex *g) {
-  if (const char *env = getenv("AWFM_GPU_PAIR_SUPER")) return !strcmp(env, "lds");
   return g->dev.numPairSuper * (kPairSuperStride * 4u) <= 32768u; /* measured: 4.46 ms from LDS against 4.91 ms from memory (10^8 random 21-mers) */
 }
 

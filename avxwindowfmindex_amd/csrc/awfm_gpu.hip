@@ -154,20 +154,6 @@ __global__ void narrowKernel(const unsigned long long *in, unsigned long long co
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) out[i] = (unsigned)in[i];
 }
-/* positions[t] = denseSa[positions[t]]: the whole backtrace as one gather (hits of a query are consecutive
- * BWT positions, so the reads are contiguous per query) */
-__global__ void denseSaGatherKernel(const DenseSa dense, unsigned long long totalHits,
-                                    const unsigned long long *positions, unsigned long long *out,
-                                    const unsigned long long *__restrict__ totalOnDevice = nullptr) {
-  if (totalOnDevice) { /* the number of hits is still on the device: totalHits is the capacity */
-    const unsigned long long t = *totalOnDevice;
-    totalHits = t < totalHits ? t : totalHits;
-  }
-  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < totalHits; t += stride)
-    out[t] = denseSaAt(dense, positions[t]);
-}
-
 /* blocks of 256 threads for n elements, at most 2^22 of them */
 inline unsigned cappedGrid(unsigned long long n) {
   const unsigned long long blocks = (n + 255ull) / 256ull;
@@ -219,8 +205,8 @@ __global__ void expandHitsKernel(const ulonglong2 *__restrict__ ranges, const un
  * (one binary search over the hit offsets per chunk), and walks the k-mers from there, their offsets and first positions
  * staged 64 at a time: every k-mer's part of the chunk is copied by all 256 threads, positions[h - hitBegin] =
  * dense[sp + h - from].  expandHitsKernel<true> gives a k-mer to a wave, which walks a long list one memory latency at a
- * time (2 * 10^6 mixed 8..30-mers, 5.5 * 10^9 hits: 72 ms); expandHitsKernel<false> + denseSaGatherKernel are parallel where
- * it matters but move every position three times (154 GB: 32 ms); this kernel reads 4 and writes 8 bytes per hit. */
+ * time (2 * 10^6 mixed 8..30-mers, 5.5 * 10^9 hits: 72 ms); an expansion parallel over the k-mers followed by a gather parallel
+ * over the hits moved every position three times (154 GB: 32 ms); this kernel reads 4 (5) and writes 8 bytes per hit. */
 constexpr unsigned kLongChunk = 16384, kLongStage = 64;
 __global__ void __launch_bounds__(256)
     expandLongKernel(const ulonglong2 *__restrict__ ranges, const unsigned long long *__restrict__ hitOffsets,
@@ -515,17 +501,13 @@ std::vector<ImageEntry> imageTable;
 
 /* Persistent grid: the kernels stride over the work, so the grid is exactly what is resident
  * (blocksPerCU from the occupancy query for that kernel); a larger grid would run as a second,
- * under-filled round.  AWFM_GPU_BLOCKS_PER_CU overrides (measurement knob). */
+ * under-filled round. */
 template <class Kernel>
 unsigned gridFor(uint64_t groups, const AwFmGpuIndex *g, Kernel kernel, unsigned groupsPerBlock, size_t dynamicLds = 0,
                  int threads = kThreads) {
   int perCU = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, threads, dynamicLds) != hipSuccess || perCU < 1) perCU = 4;
   if (perCU > 8) perCU = 8;
-  if (const char *env = getenv("AWFM_GPU_BLOCKS_PER_CU")) {
-    const int v = atoi(env);
-    if (v >= 1 && v <= 64) perCU = v;
-  }
   const uint64_t blocks = (groups + groupsPerBlock - 1) / groupsPerBlock;
   const uint64_t cap = (uint64_t)g->numCUs * (uint64_t)perCU;
   return (unsigned)(blocks < cap ? (blocks ? blocks : 1) : cap);
@@ -591,7 +573,7 @@ namespace {
 enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions,
                                  hipStream_t s, unsigned long long *out = nullptr, const unsigned long long *totalOnDevice = nullptr,
                                  unsigned stepCap = 0u);
-/* lanes that cooperate on one query: image setting, else $AWFM_GPU_KERNEL (g4|g2|g1), else the default.  A device
+/* lanes that cooperate on one query: image setting, else $AWFM_GPU_DIAG kernel=g4|g2|g1, else the default.  A device
  * block has 4 slices, so 4 lanes is the widest group (GROUP8 of the enum maps to it); amino slices are 32 B, 2 lanes
  * per query already hold 64 registers of block data */
 int lanesPerQuery(const AwFmGpuIndex *g) {
@@ -607,7 +589,7 @@ int lanesPerQuery(const AwFmGpuIndex *g) {
        * chip delivers random granules; g4 keeps 8 waves per SIMD without spilling); 5*10^7 amino 10-mers: g4 3.91 ms,
        * g2 3.72 */
       lanes = g->amino ? 2 : 4;
-      if (const char *env = getenv("AWFM_GPU_KERNEL")) { /* measurement knob */
+      if (const char *env = awfmGpuDiag("kernel")) { /* lanes per k-mer of the general kernel: g4 | g2 | g1 */
         if (!strcmp(env, "g8") || !strcmp(env, "g4")) lanes = 4;
         else if (!strcmp(env, "g2")) lanes = 2;
         else if (!strcmp(env, "g1")) lanes = 1;
@@ -1283,8 +1265,7 @@ enum AwFmReturnCode awfmGpuSearch(AwFmGpuIndex *g, const uint8_t *dChars, const 
 }
 
 /* the general kernel: exact ranges (the reference's final range for k-mers without hits too).  Nucleotide images with
- * pair blocks take two characters per block read (exact as well, awfm_pair.h; $AWFM_GPU_GENERAL_NO_PAIR: one-letter
- * steps only). */
+ * pair blocks take two characters per block read (exact as well, awfm_pair.h). */
 static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                          uint32_t fixedLength, uint64_t numQueries, struct AwFmSearchRange *dRanges,
                                          uint32_t *dCounts, void *stream) {
@@ -1308,7 +1289,7 @@ static enum AwFmReturnCode searchGeneral(AwFmGpuIndex *g, const uint8_t *dChars,
     if (did > 0) return AwFmSuccess;
     if (did < 0 && did != -(int)AwFmAllocationFailure) return (enum AwFmReturnCode)(-did);
   }
-  if (!g->amino && lanes == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_GENERAL_NO_PAIR")) {
+  if (!g->amino && lanes == 4 && g->dev.pairBlocks) {
     const unsigned long long *off = (const unsigned long long *)dOffsets;
     const bool narrow = awfmImageNarrow(g);
 #define AWFM_PAIR_GO(CSRV, NR) \
@@ -1398,7 +1379,7 @@ enum AwFmReturnCode awfmGpuSearchTally(AwFmGpuIndex *g, const uint8_t *dChars, c
      * the image view without the device-only deeper table; the image itself is not touched (other threads may
      * be searching through it) */
     DevIndex plain = g->dev;
-    if (!getenv("AWFM_GPU_TALLY_WITH_DEEP")) { /* (measurement knob: what the kernel executes behind the deeper table) */
+    if (!awfmGpuDiag("tally_with_deep")) { /* (diagnostics: what the kernel executes behind the deeper table) */
       plain.deepSeed = nullptr;
       plain.deepK = 0;
     }
@@ -1433,7 +1414,7 @@ template <int SOURCE>
 enum AwFmReturnCode scanRecursive(const void *in, uint64_t n, unsigned long long *out, unsigned long long *scratch,
                                   hipStream_t s) {
   const uint64_t tiles = (n + kScanTile - 1) / kScanTile;
-  if (tiles > 1 && n <= (uint64_t)kScanSmall && !getenv("AWFM_GPU_SCAN_TILED")) {
+  if (tiles > 1 && n <= (uint64_t)kScanSmall) {
     hipLaunchKernelGGL(scanSmallKernel<SOURCE>, dim3(1), dim3(kScanSmallThreads), 0, s, in, (unsigned long long)n, out);
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
@@ -1573,29 +1554,15 @@ enum AwFmReturnCode awfmGpuLocateWindow(AwFmGpuIndex *g, const struct AwFmSearch
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
   }
-  if (g->dDenseSa && !getenv("AWFM_GPU_LONG_LISTS_TWO_KERNELS")) {
-    /* long hit lists (64 hits per k-mer and more on average): parallel over the hits (expandLongKernel) */
+  if (g->dDenseSa) {
+    /* long hit lists (64 hits per k-mer and more on average): parallel over the hits (expandLongKernel; the expansion parallel
+     * over the k-mers followed by a gather parallel over the hits moved every position three times: 32 against 15 ms for
+     * 2 * 10^6 mixed 8..30-mers with 5.5 * 10^9 hits) */
     const unsigned long long chunks = (totalHits + kLongChunk - 1ull) / kLongChunk, resident = (unsigned long long)g->numCUs * 8ull;
     hipLaunchKernelGGL(expandLongKernel, dim3((unsigned)(chunks < resident ? chunks : resident)), dim3(256), 0, s,
                        (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
                        (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
                        (unsigned long long *)outPositions, denseSaOf(g));
-    AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-    return AwFmSuccess;
-  }
-  if (g->dDenseSa) {
-    /* ($AWFM_GPU_LONG_LISTS_TWO_KERNELS: the expansion parallel over the k-mers, then the gather parallel over the hits --
-     * every position moved three times; 2 * 10^6 mixed 8..30-mers with 5.5 * 10^9 hits: 32 ms; with the gather inside the
-     * k-mer-parallel expansion a wave walks its lists one memory latency at a time: 72 ms) */
-    hipLaunchKernelGGL(expandHitsKernel<false>, dim3(cappedGrid(numQueries)), dim3(256), 0, s,
-                       (const ulonglong2 *)dRanges, (const unsigned long long *)dHitOffsets, (unsigned long long)queryBegin,
-                       (unsigned long long)numQueries, (unsigned long long)hitBegin, (unsigned long long)hitEnd,
-                       (unsigned long long *)dPositions, DenseSa());
-    AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
-    const unsigned long long blocks = (totalHits + 255ull) / 256ull, resident = (unsigned long long)g->numCUs * 16ull;
-    hipLaunchKernelGGL(denseSaGatherKernel, dim3((unsigned)(blocks < resident ? blocks : resident)), dim3(256), 0, s,
-                       denseSaOf(g), (unsigned long long)totalHits, (const unsigned long long *)dPositions,
-                       (unsigned long long *)outPositions, (const unsigned long long *)nullptr);
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     return AwFmSuccess;
   }
@@ -1671,8 +1638,7 @@ enum AwFmReturnCode awfmGpuListLocateOnDevice(AwFmGpuIndex *g, const uint32_t *d
   DeviceGuard guard(g->device);
   hipStream_t s = (hipStream_t)stream;
   if (!dPositions) capacityHits = 0;
-  const char *env = getenv("AWFM_GPU_LIST_TAIL"); /* 0: the three calls this one replaces (measurement knob) */
-  if (capacity > kListTailMaxEntries || (env && atoi(env) == 0)) {
+  if (capacity > kListTailMaxEntries) {
     /* a long list: copy, rank in a bitmap of the batch, scan, expand (what a caller did before this entry point existed) */
     AWFM_HIP_TRY(hipMemcpyAsync(dSortedKmers, dHitKmers, (size_t)capacity * 4u, hipMemcpyDeviceToDevice, s), AwFmGeneralFailure);
     AWFM_HIP_TRY(hipMemcpyAsync(dSortedRanges, dHitRanges, (size_t)capacity * 16u, hipMemcpyDeviceToDevice, s), AwFmGeneralFailure);
@@ -1719,12 +1685,6 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     /* the walk runs at the rate the chip delivers random granules whatever the group width (17.2 / 17.5 / 18.3 ms
      * for g4 / g2 / g1 on 1.0007*10^8 hits); four lanes keep the fewest instructions per step */
     int lanes = g->kernel == AWFM_GPU_KERNEL_AUTO ? 4 : lanesPerQuery(g);
-    if (const char *env = getenv("AWFM_GPU_LOCATE_KERNEL")) { /* measurement knob: g4 | g2 | g1 */
-      if (!strcmp(env, "g8")) lanes = 4;
-      else if (!strcmp(env, "g4")) lanes = 4;
-      else if (!strcmp(env, "g2")) lanes = 2;
-      else if (!strcmp(env, "g1")) lanes = 1;
-    }
     if (lanes > 4) lanes = 4;
     if (g->amino && lanes < 2) lanes = 2;
     unsigned long long *pos = dPositions;
@@ -1737,15 +1697,15 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     const bool narrow = awfmImageNarrow(g);
     /* two LF steps per block read where the image has its pair blocks (awfm_pair.h); their 32-bit superblock bases are
      * dynamic LDS */
-    const bool pair = !g->amino && lanes == 4 && g->dev.pairBlocks && !getenv("AWFM_GPU_LOCATE_NO_PAIR");
+    const bool pair = !g->amino && lanes == 4 && g->dev.pairBlocks;
     const bool superInLds = pair && narrow && awfmPairSuperInLds(g);
     const size_t pairLds = superInLds ? (size_t)g->dev.numPairSuper * (kPairSuperStride * 4u) : 0u;
     DevIndex pairDev = g->dev;
     pairDev.pairSuperInLds = superInLds ? 1u : 0u;
     /* steps after which an uncapped walk is parked for finishKernel to walk on (the hand-over holds 23 bits of steps);
-     * $AWFM_GPU_WALK_GIVE_UP: a small number, so that the tests reach that path on ordinary texts */
+     * $AWFM_GPU_DIAG walk_give_up: a small number, so that the tests reach that path on ordinary texts */
     unsigned giveUp = (1u << kWalkStepBits) - 1u;
-    if (const char *env = getenv("AWFM_GPU_WALK_GIVE_UP")) {
+    if (const char *env = awfmGpuDiag("walk_give_up")) {
       const long v = atol(env);
       if (v >= 1 && v < (long)giveUp) giveUp = (unsigned)v;
     }
@@ -1787,7 +1747,7 @@ enum AwFmReturnCode launchLocate(AwFmGpuIndex *g, unsigned long long totalHits, 
     AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
     /* out-of-place: the final positions go to `out` (page-locked host memory in the pipeline): a smaller grid, so that
      * a kernel paced by the PCIe writes leaves the chip to whatever runs beside it */
-    const unsigned finishGrid = out && out != pos ? (unsigned)g->numCUs * (getenv("AWFM_GPU_FINISH_BLOCKS") ? (unsigned)atoi(getenv("AWFM_GPU_FINISH_BLOCKS")) : 2u) : (unsigned)g->numCUs * 8u;
+    const unsigned finishGrid = out && out != pos ? (unsigned)g->numCUs * 2u : (unsigned)g->numCUs * 8u;
     hipLaunchKernelGGL(finishKernel, dim3(finishGrid), dim3(256), 0, s, g->dev, th, (const unsigned long long *)pos, out ? out : pos, totalOnDevice,
                        stepCap ? 0u : (g->amino ? 2u : 1u), giveUp);
   }
@@ -2073,12 +2033,12 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
   const bool explicitBuild = !capped;
   unsigned stepCap = 32u * g->dev.saRatio;
   /* the parked walks of the first pass go into a list (narrowParkListKernel) of at most a quarter of the positions, 2^26 at
-   * most (0.8 GB; $AWFM_GPU_DENSE_SA_PARK_LIST = entries, 0 = none): a text that parks more -- one that is mostly runs -- takes
+   * most (0.8 GB; $AWFM_GPU_DIAG park_list = entries, 0 = none: tests): a text that parks more -- one that is mostly runs -- takes
    * the array over all positions and a second pass, as round 4 did for every text that parked anything */
   unsigned *listAt = nullptr;
   unsigned long long *listEntry = nullptr;
   unsigned long long listCapacity = n / 4u + 1024u < (1ull << 26) ? n / 4u + 1024u : (1ull << 26);
-  if (const char *env = getenv("AWFM_GPU_DENSE_SA_PARK_LIST")) listCapacity = strtoull(env, nullptr, 10);
+  if (const char *env = awfmGpuDiag("park_list")) listCapacity = strtoull(env, nullptr, 10);
   if (listCapacity > n) listCapacity = n;
   if (listCapacity != 0 && (hipMalloc((void **)&listAt, listCapacity * 4) != hipSuccess ||
                             hipMalloc((void **)&listEntry, listCapacity * 8) != hipSuccess)) {

@@ -971,8 +971,8 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
   }
   const bool verbose = getenv("AWFM_VERBOSE") != nullptr;
   const bool amino = config->alphabetType == AwFmAlphabetAmino;
-  /* 32-bit suffix positions and ranks while they fit ($AWFM_GPU_BUILD_WIDE=1: 64-bit ones on any text, for tests) */
-  const char *wideEnv = getenv("AWFM_GPU_BUILD_WIDE");
+  /* 32-bit suffix positions and ranks while they fit ($AWFM_GPU_DIAG build_wide=1: 64-bit ones on any text, for tests) */
+  const char *wideEnv = awfmGpuDiag("build_wide");
   const bool wide = n > 0xFFFFFFFEull || (wideEnv && *wideEnv && *wideEnv != '0');
   const u64 numBlocks = awfmNumBlocks(n);
   const unsigned refWords = amino ? 44 : 20;

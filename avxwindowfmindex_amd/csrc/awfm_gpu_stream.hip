@@ -483,8 +483,7 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
   /* $AWFM_GPU_STREAM_MODE=split: one upload stream, one kernel stream, download streams; default: everything of a
    * chunk on its slot's own stream (measured, 10^8 planted 21-mers located: 43-58 ms against 60 ms; random ones 23-25
    * against 22.8 ms) */
-  const char *modeEnv = getenv("AWFM_GPU_STREAM_MODE");
-  const bool perSlot = !(modeEnv && !strcmp(modeEnv, "split"));
+  const bool perSlot = true; /* (round 6: the split mode is no longer selectable) */
   const size_t inBytesPerKmer = packed ? 8 : kmerLength;
   const bool stage = !isPinned(input);
   const bool narrowCounts = g->dev.bwtLength < (1ull << 32);
@@ -517,7 +516,7 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
     }                          \
   } while (0)
 
-  const bool trace = getenv("AWFM_GPU_STREAM_TRACE") != nullptr; /* host-side timeline of the loop on stderr */
+  const bool trace = awfmGpuDiag("stream_trace") != nullptr; /* host-side timeline of the loop on stderr */
   struct timespec ts0;
   clock_gettime(CLOCK_MONOTONIC, &ts0);
   auto now = [&]() {
@@ -644,13 +643,12 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
           STEP_RC(ensurePositions(s, s.total));
           /* $AWFM_GPU_STREAM_DIRECT: the finish kernel stores into the page-locked staging itself (awfmGpuLocateTo) instead
            * of a copy afterwards; measured the same (10^8 planted 21-mers: 46-54 ms either way) */
-          direct = getenv("AWFM_GPU_STREAM_DIRECT") != nullptr;
+          direct = false;
           STEP_RC(awfmGpuLocateTo(g, (const struct AwFmSearchRange *)s.dRanges, (const uint64_t *)s.dHitOffsets, s.n, s.total,
                                   (uint64_t *)s.dPositions, direct ? (uint64_t *)s.hPositions : (uint64_t *)s.dPositions, comp));
         }
         STEP_TRY(hipEventRecord(s.located, comp));
-        if (getenv("AWFM_GPU_STREAM_HOSTWAIT")) STEP_TRY(hipEventSynchronize(s.located));
-        else STEP_TRY(hipStreamWaitEvent(out, s.located, 0));
+        STEP_TRY(hipStreamWaitEvent(out, s.located, 0));
         split = !perSlot && s.total >= (1ull << 20) && !s.windowed;
         const u64 lower = direct || s.windowed ? 0 : (split ? s.total / 2 : s.total);
         if (direct) split = false;

@@ -328,10 +328,6 @@ __global__ void __launch_bounds__(256)
  * general kernel by way of the share's region, the scan and the partition (all but empty now).
  * Results: every k-mer with hits gets the range the reference's stepping gives it (same entry, same steps); a k-mer dropped at
  * the table or emptied on the way has no hit. */
-/* $AWFM_GPU_LOOKUP_TIMELINE (diagnostic; bit 5 of useNext): every wave leaves the device's 100-MHz clock at its start and at
- * its end here, [4 * (4 * workgroup + wave)] and [... + 1], its HW_ID register and the trips it made in [... + 2] and [... + 3]:
- * where a launch's time goes beside its trips (scripts/lookup_timeline.py) */
-__device__ unsigned long long *gLookupTimeline = nullptr;
 constexpr unsigned kFusedSlots = 64;    /* survivors a wave takes through the steps at a time */
 constexpr unsigned kFusedCounters = 64; /* words (a line apart) the waves count their survivors into: reporting */
 template <unsigned K, bool NARROW = true>
@@ -350,8 +346,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
    * blocks; the hits into the list when there is one */
   const bool PAIR = ix.pairBlocks != nullptr && (useNext & 2u) == 0u;
   const bool LIST = sparse.count != nullptr;
-  const bool timeline = (useNext & 32u) != 0u;
-  if (timeline && (threadIdx.x & 63u) == 0u) gLookupTimeline[4u * (4u * blockIdx.x + (threadIdx.x >> 6))] = wall_clock64();
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
   __shared__ unsigned long long sSuper[NARROW ? 1 : kMaxNucSuper * 4];
@@ -402,7 +396,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
   /* (Round 5 tried dealing the 256-k-mer trips to the waves from a counter per share, the next ticket drawn a trip ahead, so
    * that the waves with long trips do not keep the chip waiting at the end: 0.39 instead of 0.36 ms per 1.25 * 10^7 k-mers, 2.89
    * instead of 2.68 per 10^8, and an 81st register: the fixed stride stays, with the grid trimmed to even trips.)
-   * Then the waves' own clocks were looked at ($AWFM_GPU_LOOKUP_TIMELINE, scripts/lookup_timeline.py): every wave makes the
+   * Then the waves' own clocks were looked at (round 5's timeline build: profiles/r5/lookup_timeline): every wave makes the
    * same number of trips, and the waves of a launch end anywhere between 0.45 and 1.0 of its span, in the order of their SLOT
    * on the SIMD (slot 0: 23-25 us a trip, slot 6: 48) -- whatever serves the waves' memory requests serves the older slots
    * first, and rotating the issue priority (s_setprio by trip and slot) changes nothing about it.  Dealing the trips out again,
@@ -414,9 +408,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
    * costs more than all of it: 6 ms).  With equal shares the early slots finish, the later ones move up, and the launch as a
    * whole runs at the memory system's rate: the spread of the ends is how the hardware shares, not time that is lost. */
   const unsigned long long waveFirst = first + 4ull * ((unsigned long long)localBlock * 256ull + (threadIdx.x & ~63u));
-  unsigned tripsMade = 0; /* wave-uniform (the timeline's) */
   for (unsigned long long tw = waveFirst; tw < last; tw += 4ull * localGrid * 256ull) {
-    tripsMade++;
     const unsigned long long t = tw + 4ull * lane;
     unsigned long long codes[4];
     unsigned bad[4];
@@ -592,11 +584,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
   }
   for (unsigned at = blockUsed + lane; at < blockSlots; at += 64u) codesOut[first + blockBase + at] = kCodeNone;
   if (lane == 0 && keptHere) atomicAdd(&keptCounters[((blockIdx.x * 4u + w) % kFusedCounters) * 16u], keptHere);
-  if (timeline && lane == 0u) {
-    gLookupTimeline[4u * (4u * blockIdx.x + w) + 1u] = wall_clock64();
-    gLookupTimeline[4u * (4u * blockIdx.x + w) + 2u] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | ((32 - 1) << 11)); /* HW_ID */
-    gLookupTimeline[4u * (4u * blockIdx.x + w) + 3u] = (unsigned long long)tripsMade;
-  }
   if (LIST) { /* the waves' leftovers in one reservation, as in orderedSearchKernel */
     if (lane == 0) sHitLeft[w] = hitFill;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -429,9 +429,12 @@ def amino_leg(L, api, digest, torch, np, dev, n, Q=50_000_000, K=10, seed_k=5, s
     roofline = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel_ms": round(search_ms, 3)}
     deep_k = g.deep_seed_k
     if deep_k:
-        os.environ["AWFM_GPU_TALLY_WITH_DEEP"] = "1"
+        _diag_before = os.environ.get("AWFM_GPU_DIAG")
+        os.environ["AWFM_GPU_DIAG"] = "tally_with_deep=1"  # the library's variable of test and diagnostics hooks
         executed = g.search_tally(d_chars.data_ptr(), 0, K, Q)
-        del os.environ["AWFM_GPU_TALLY_WITH_DEEP"]
+        os.environ.pop("AWFM_GPU_DIAG")
+        if _diag_before is not None:
+            os.environ["AWFM_GPU_DIAG"] = _diag_before
         lookups = Q - executed["seeded"] if K >= deep_k else 0
         exec_bytes = executed["chars"] + 128 * lookups + 16 * executed["seeded"] + RANK_BYTES_AMINO * executed["blocks"] + 16 * Q
         basis = "executed_reads"
@@ -1073,9 +1076,7 @@ def main():
         else:
             g.search_hits(p.chars_ptr, p.off_ptr, K, p.q, ln.ranges.data_ptr(), 0, ln.stream)
 
-    # AWFM_BENCH_LIST_TAIL=0: round 4's tail of a list step (rank the list in a bitmap of the batch, scan, expand: three calls,
-    # seven launches) instead of awfmGpuListLocateOnDevice's one
-    list_tail = os.environ.get("AWFM_BENCH_LIST_TAIL", "1") != "0"
+    list_tail = True  # the tail of a list step in one launch (awfmGpuListLocateOnDevice)
 
     def sorted_list(ln):
         """(k-mer numbers, ranges) of a lane's list in k-mer order"""
@@ -1408,7 +1409,7 @@ def main():
         what = ("distinct (search level, 128-B line) pairs the kernel reads, tallied on the device by an "
                 "instrumented launch of the same kernel on the same sorted batch (awfmGpuSearchHitsLineTally), "
                 "x 128 B, + sorted records and keys read + results stored")
-        fused = lookup_first and (mixed_lookup or os.environ.get("AWFM_GPU_LOOKUP_FUSED", "1") != "0")
+        fused = lookup_first  # (the k-mers still alive are searched by the kernel that looked them up)
         if mixed_lookup:
             # A mixed-length batch that took "lookup first" (DESIGN.md 4c): ONE table entry per k-mer -- from the table of its
             # own length (k-mers shorter than the deeper table's) or from the deeper table --, then the steps of the k-mers
@@ -1451,7 +1452,7 @@ def main():
         # NEEDED bytes: what the kernel consumes -- a table lookup is an 8-byte entry (16 from 2^32 positions), not the 128-B
         # line it arrives in; the block reads of the search levels stay at their distinct lines.  traffic / needed says how
         # much of what the kernel moves is the rest of a line nobody asked for.
-        entry_bytes = 8 if narrow_counts else 16
+        entry_bytes = 8 if ix.bwt_length < (1 << 36) else 16  # (round 6: the packed entries of images of 2^32 .. 2^36 positions are 8 bytes too)
         if mixed_lookup:
             needed = streamed + 8 * lines["ordered_kmers"] + 128 * (lines["pair_level_lines"] + lines["nuc_level_lines"]) + stored
         elif lookup_first and fused:
@@ -1542,9 +1543,12 @@ def main():
         # launch of the same kernel with the table on: a 128-B line per table lookup, 168 B per distinct block of the steps
         # behind it -- and `reference_algorithm` is the same kernel without the table (the reference's steps),
         # timed on the same batch, whose ranges must equal the timed steps'.
-        os.environ["AWFM_GPU_TALLY_WITH_DEEP"] = "1"
+        _diag_before = os.environ.get("AWFM_GPU_DIAG")
+        os.environ["AWFM_GPU_DIAG"] = "tally_with_deep=1"  # the library's variable of test and diagnostics hooks
         executed = g.search_tally(d_chars.data_ptr(), off_ptr, K, Q)
-        del os.environ["AWFM_GPU_TALLY_WITH_DEEP"]
+        os.environ.pop("AWFM_GPU_DIAG")
+        if _diag_before is not None:
+            os.environ["AWFM_GPU_DIAG"] = _diag_before
         deep_lookups = Q - executed["seeded"] if K >= g.deep_seed_k else 0  # fixed-length k-mers without ambiguity letters start at the deeper table
         exec_bytes = executed["chars"] + 128 * deep_lookups + 16 * executed["seeded"] + rank_bytes * executed["blocks"] + 16 * Q
         if amino_looked_up:
@@ -2053,7 +2057,7 @@ def main():
 
     # ---- round 6: the same steps on an index BEYOND 2^32 positions (6.2 Gbp: a two-strand human genome's size), built here once
     # this run's own image is gone -- the 64-bit suffix sort takes 33 bytes of HBM per text position at its peak (wide_leg) ----
-    if secondary is not None and not args.no_wide and not amino and world == 1 and time.time() - T_START < 400:
+    if secondary is not None and not args.no_wide and not amino and world == 1 and n < (1 << 32) and time.time() - T_START < 400:
         if g is not None:
             g.handle = None
             g = None

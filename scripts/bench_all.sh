@@ -1,6 +1,6 @@
 #!/bin/bash
 # every bench.py configuration quoted in DESIGN.md, one JSON line each -> gpurun_out/bench_<tag>/bench_<name>.json
-TAG=${1:-r5}
+TAG=${1:-r6}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/bench_$TAG
 mkdir -p "$OUT"
@@ -18,7 +18,6 @@ run planted -- --workload planted
 run planted_dense_results AWFM_BENCH_DENSE_RESULTS=1 -- --workload planted --no-cpu --no-e2e
 run mixed -- --workload mixed
 run mixed_no_lookup AWFM_GPU_MIXED_LOOKUP=0 -- --workload mixed --no-cpu --no-e2e --general-steps 0
-run mixed_round4_stores AWFM_GPU_MIXED_WHOLE_COUNTS=0 -- --workload mixed --no-cpu --no-e2e --general-steps 0
 run mixed_no_prediction AWFM_GPU_LOOKUP_PREDICT=0 -- --workload mixed --no-cpu --no-e2e --general-steps 0
 run mixed_short -- --workload mixed --mixed-lengths 8 15 --no-cpu --no-e2e --general-steps 0 --no-shard-proxy
 run mixed_long -- --workload mixed --mixed-lengths 18 30 --no-cpu --no-e2e --general-steps 0 --no-shard-proxy
@@ -29,19 +28,13 @@ run amino_2e9 -- --alphabet amino --text-len 2e9 --no-e2e
 run amino_no_lookup AWFM_GPU_AMINO_LOOKUP=0 -- --alphabet amino --no-cpu --no-e2e
 run amino_no_deep_table AWFM_GPU_AMINO_DEEP_SEED_K=0 -- --alphabet amino --no-cpu --no-e2e
 run weak -- --scaling weak --no-cpu --no-e2e --no-secondary --general-steps 0 --no-shard-proxy
-run no_fused_lookup AWFM_GPU_LOOKUP_FUSED=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
-run lookup_host_decides AWFM_GPU_LOOKUP_HOST_DECIDES=1 -- --no-cpu --no-e2e --no-secondary --general-steps 0
-run eager_events AWFM_GPU_EAGER_EVENTS=1 -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run general AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 -- --mode count --no-cpu --no-e2e
-run general_letters AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 AWFM_GPU_GENERAL_NO_PAIR=1 -- --mode count --no-cpu --no-e2e
 run dense_results AWFM_BENCH_DENSE_RESULTS=1 -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run no_deep_table -- --device-seed-k 0 --no-cpu --no-e2e --no-secondary --general-steps 0
 run deep_table_14 -- --device-seed-k 14 --no-cpu --no-e2e --no-secondary --general-steps 0
 run no_next_bits AWFM_GPU_DEEP_NEXT=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run no_lookup_first AWFM_GPU_LOOKUP_FIRST=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run no_lookup_first_count AWFM_GPU_LOOKUP_FIRST=0 -- --mode count --no-cpu --no-e2e --no-secondary --general-steps 0
-run rocprim_sort AWFM_GPU_ORDERED_SORT=rocprim -- --no-cpu --no-e2e --no-secondary --general-steps 0
-run mixed_rocprim_sort AWFM_GPU_ORDERED_SORT=rocprim -- --workload mixed --no-cpu --no-e2e --general-steps 0
 run nopair_default AWFM_GPU_PAIR=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run planted_lf_walk -- --workload planted --no-device-dense-sa --no-cpu --no-e2e
 run lf_walk -- --no-device-dense-sa --no-cpu --no-e2e --no-secondary --general-steps 0
@@ -50,14 +43,15 @@ run repetitive_planted -- --text repetitive --workload planted --no-cpu --no-e2e
 run repetitive_unique -- --text repetitive --workload unique --no-cpu --no-e2e --general-steps 0
 # round 5
 run no_prediction AWFM_GPU_LOOKUP_PREDICT=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
-run no_fused_prologue AWFM_GPU_PREP_FUSED=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
-run no_list_tail AWFM_BENCH_LIST_TAIL=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
-run round4_step AWFM_GPU_LOOKUP_PREDICT=0 AWFM_GPU_PREP_FUSED=0 AWFM_BENCH_LIST_TAIL=0 -- --no-cpu --no-e2e --no-secondary --general-steps 0
 run exact_tables AWFM_GPU_ORDERED=0 -- --mode count --no-cpu --no-e2e --no-secondary
 run exact_tables_off AWFM_GPU_ORDERED=0 AWFM_GPU_EXACT_LOOKUP=0 -- --mode count --no-cpu --no-e2e --no-secondary
 run amino_no_next_bits AWFM_GPU_DEEP_NEXT=0 -- --alphabet amino --no-cpu --no-e2e
 run amino_2e9_no_next_bits AWFM_GPU_DEEP_NEXT=0 -- --alphabet amino --text-len 2e9 --no-cpu --no-e2e
 run amino_planted -- --alphabet amino --workload planted --no-cpu --no-e2e
+# round 6: an index beyond 2^32 positions as the main line (the 64-bit instantiations), random and planted
+run wide -- --text-len 6.2e9 --no-e2e --no-amino --no-repetitive --no-wide
+run wide_planted -- --text-len 6.2e9 --workload planted --no-cpu --no-e2e --no-wide
+run wide_mixed -- --text-len 6.2e9 --workload mixed --no-cpu --no-e2e --general-steps 0 --no-wide
 python3 - "$OUT" <<'PY'
 import glob, json, os, sys
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Here, after scripts/refresh_profiles.sh ran on a GPU box: condense every profiled set into profiles/<round>/ (a set whose
 # kernel-trace average is not its bench line's kernel_ms is refused and named), copy the bench lines and the shard timelines.
-R=${1:-r5}
+R=${1:-r6}
 D=profiles/$R
 mkdir -p "$D"
 B=gpurun_out/bench_$R
@@ -9,6 +9,8 @@ collect() { # set, workload text, un-profiled bench line
   python3 scripts/collect_profiles.py "gpurun_out/prof_$1" "$D" "$1" "$2" "$B/bench_$3.json" || echo "== set $1 NOT collected"
 }
 collect default "100 M random 21-mers, locate, 3.1 Gbp" default
+collect wide "100 M random 21-mers, locate, 6.2 Gbp (an index beyond 2^32 positions: 64-bit instantiations)" wide
+collect wide_planted "100 M planted 21-mers, locate, 6.2 Gbp" wide_planted
 collect ordered_only "100 M random 21-mers, locate, 3.1 Gbp, AWFM_GPU_LOOKUP_FIRST=0" no_lookup_first
 collect planted "100 M planted 21-mers, locate, 3.1 Gbp" planted
 collect general_pair "100 M random 21-mers, count, 3.1 Gbp, AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 (exact-range general kernel)" general

@@ -76,10 +76,10 @@ while time.time() < t_end:
         exact = torch.zeros(Q * 2, dtype=torch.int64, device=dev)
         hits = torch.full((Q * 2,), 9, dtype=torch.int64, device=dev)
         counts = torch.full((Q,), 9, dtype=torch.int32, device=dev)
-        os.environ["AWFM_GPU_GENERAL_NO_PAIR"] = "1"  # the reference side: one letter per step
+        g.set_kernel(api.AWFM_GPU_KERNEL_GROUP2)  # the reference side: the general kernel, two lanes per k-mer, one letter per step, no table beyond the index's
         g.search(chars_ptr, off_ptr, K, Q, exact.data_ptr(), 0)
         torch.cuda.synchronize()
-        del os.environ["AWFM_GPU_GENERAL_NO_PAIR"]
+        g.set_kernel(api.AWFM_GPU_KERNEL_AUTO)
         g.set_wide(fuzz_wide)
         # the exact search with pair steps: every range, the empty ones of k-mers without hits included
         exact_pair = torch.full((Q * 2,), 5, dtype=torch.int64, device=dev)
@@ -183,10 +183,10 @@ while time.time() < t_end:
                 total_b = g.hit_offsets(hits.data_ptr(), Q, off_b.data_ptr(), scratch.data_ptr())
             pos_a = torch.zeros(max(total_a, 1), dtype=torch.int64, device=dev)
             pos_b = torch.zeros(max(total_b, 1), dtype=torch.int64, device=dev)
-            os.environ["AWFM_GPU_LOCATE_NO_PAIR"] = "1"  # side A: one LF step per block read
+            g.set_kernel(api.AWFM_GPU_KERNEL_GROUP2)  # side A: one LF step per block read
             g.locate(exact.data_ptr(), off_a.data_ptr(), Q, total_a, pos_a.data_ptr())
             torch.cuda.synchronize()
-            del os.environ["AWFM_GPU_LOCATE_NO_PAIR"]
+            g.set_kernel(api.AWFM_GPU_KERNEL_AUTO)
             g.set_wide(fuzz_wide)
             dense_sa = ix.bwt_length < (1 << 32) and rng.random() < 0.3  # side B through the full suffix array now and then
             if dense_sa:

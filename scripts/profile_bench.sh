@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 echo "${AWFM_COMMIT:-unknown}" > "$OUT/commit.txt"   # the commit of the tree this box was given (there is no .git here)
 cd /tmp && export TMPDIR=/tmp
 KERNELS="earchKernel|lookupSearch|lookupPrep|listTail|exactLookup|SampleAlive|mixedLookupTally|encodeLookup|encodeRecords|partitionRecords|rankMark|rankBlock|rankPlace|sampleAlive|bucketScanShares|walkKernel|finishKernel|fillNoHitKernel|fillSparseKernel|encodeQueriesKernel|encodeCodes|partitionKernel|bucketScanKernel|segmentSumsKernel|tileOffsetsKernel|radix_sort|onesweep|expandHitsKernel|scanTileKernel|scanReduceKernel|sortKeysKernel|bucketKernel"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-secondary --no-shard-proxy --no-dense-form "$@" > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-secondary --no-shard-proxy --no-dense-form --no-wide "$@" > "$OUT/bench_trace.log" 2>&1
 declare -A PASS
 PASS[fetch]="FETCH_SIZE"
 PASS[write]="WRITE_SIZE"
@@ -25,7 +25,7 @@ PASS[busy]="TCC_BUSY_avr GRBM_TA_BUSY GRBM_TC_BUSY GRBM_EA_BUSY"
 # sat in its finalisation until the call's limit: name it (or `busy`) in $PROFILE_PASSES only under a short `timeout`
 for N in ${PROFILE_PASSES:-fetch write l2 sq sq2 ea tcp}; do
   [ "$N" = "-" ] && continue  # PROFILE_PASSES=-: the kernel trace only
-  rocprofv3 --pmc ${PASS[$N]} --kernel-include-regex "$KERNELS" --output-format csv -d "$OUT/pmc_$N" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-secondary --no-shard-proxy --no-dense-form --general-steps 0 --steps 2 --warmup 1 "$@" > "$OUT/bench_pmc_$N.log" 2>&1
+  rocprofv3 --pmc ${PASS[$N]} --kernel-include-regex "$KERNELS" --output-format csv -d "$OUT/pmc_$N" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-secondary --no-shard-proxy --no-dense-form --no-wide --general-steps 0 --steps 2 --warmup 1 "$@" > "$OUT/bench_pmc_$N.log" 2>&1
   rc=$?
   echo "pass $N: $(find "$OUT/pmc_$N" -name '*counter_collection.csv' | wc -l) csv, rc $rc"
 done

@@ -38,26 +38,37 @@ def require_gpu(awfm):
     return n
 
 
+def set_diag(monkeypatch, **keys):
+    """adds key=value pairs to $AWFM_GPU_DIAG (the library's one variable of test and diagnostics hooks: include/awfm_gpu.h);
+    a value of None takes the key out"""
+    have = dict(kv.split("=", 1) for kv in os.environ.get("AWFM_GPU_DIAG", "").split(",") if "=" in kv)
+    for key, value in keys.items():
+        if value is None:
+            have.pop(key, None)
+        else:
+            have[key] = str(value)
+    if have:
+        monkeypatch.setenv("AWFM_GPU_DIAG", ",".join(f"{k}={v}" for k, v in have.items()))
+    else:
+        monkeypatch.delenv("AWFM_GPU_DIAG", raising=False)
+
+
+@pytest.fixture
+def diag(monkeypatch):
+    """diag(key=value, ...): see set_diag"""
+    return lambda **keys: set_diag(monkeypatch, **keys)
+
+
 @pytest.fixture(params=["narrow", "wide", "wide-superblocks"])
 def wide(request, monkeypatch):
     """runs a GPU test three times: with 32-bit BWT positions in the kernels (what an index below 2^32 positions
     gets); with the 64-bit instantiations forced on the same small index ($AWFM_GPU_FORCE_WIDE is read when a device
     image is created); and with nucleotide superblocks of a few thousand positions instead of 2^32 on top of that
-    ($AWFM_GPU_NUC_SUPER_SHIFT=auto: up to 48 superblocks), i.e. the code and the base-count arithmetic an index of
+    ($AWFM_GPU_DIAG nuc_super_shift=auto: up to 48 superblocks), i.e. the code and the base-count arithmetic an index of
     2^32 or more positions runs (ref src/AwFmIndex.h:88-91 is 64-bit throughout)"""
     monkeypatch.setenv("AWFM_GPU_FORCE_WIDE", "0" if request.param == "narrow" else "1")
     if request.param == "wide-superblocks":
-        monkeypatch.setenv("AWFM_GPU_NUC_SUPER_SHIFT", "auto")
+        set_diag(monkeypatch, nuc_super_shift="auto")
     return request.param != "narrow"
 
 
-@pytest.fixture(params=["partition", "rocprim"])
-def order_sort(request, monkeypatch):
-    """how the seed-order path of awfmGpuSearchHits orders a fixed-length batch: the hand-written count + partition
-    kernels (2048 buckets, 8-byte records without their bucket's bits; the default), or the earlier encode + rocPRIM radix
-    sort of (16-bit key, record) pairs ($AWFM_GPU_ORDERED_SORT=rocprim, kept for comparison)"""
-    if request.param == "rocprim":
-        monkeypatch.setenv("AWFM_GPU_ORDERED_SORT", "rocprim")
-    else:
-        monkeypatch.delenv("AWFM_GPU_ORDERED_SORT", raising=False)
-    return request.param

@@ -14,13 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(params=[False, True], ids=["pos32", "pos64"])
-def build_wide(request, monkeypatch):
+def build_wide(request, diag):
     """the suffix sort of the GPU builder with 32-bit and with 64-bit positions and ranks (the latter is what texts of
-    2^32 - 1 characters and more get; $AWFM_GPU_BUILD_WIDE=1 selects it on any text)"""
-    if request.param:
-        monkeypatch.setenv("AWFM_GPU_BUILD_WIDE", "1")
-    else:
-        monkeypatch.delenv("AWFM_GPU_BUILD_WIDE", raising=False)
+    2^32 - 1 characters and more get; $AWFM_GPU_DIAG build_wide=1 selects it on any text)"""
+    diag(build_wide="1" if request.param else None)
     return request.param
 
 

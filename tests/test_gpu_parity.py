@@ -113,15 +113,12 @@ def test_repetitive_text_many_hits(oracle, awfm, require_gpu, wide):
         ix.dealloc()
 
 
-@pytest.mark.parametrize("two_kernels", [False, True])
-def test_long_hit_lists_located_in_windows_through_the_full_suffix_array(oracle, awfm, require_gpu, monkeypatch, two_kernels):
+def test_long_hit_lists_located_in_windows_through_the_full_suffix_array(oracle, awfm, require_gpu, wide):
     """windows of LONG hit lists (64 hits per k-mer and more) on an image with the full suffix array: expandLongKernel, parallel
     over the hits -- chunks of 16384 hits that begin and end inside a list, lists of a few hits and k-mers without hits
     between lists of 10^4, windows that begin and end inside a list or hold a single hit, the whole list as one window --
-    against the oracle's positions (and the two-kernel way, $AWFM_GPU_LONG_LISTS_TWO_KERNELS, against the same)"""
+    against the oracle's positions; 32-bit entries, and the 40-bit ones of an image that runs 64-bit positions (`wide`)"""
     import torch
-    if two_kernels:
-        monkeypatch.setenv("AWFM_GPU_LONG_LISTS_TWO_KERNELS", "1")
     rng = np.random.default_rng(11)
     unit = rng.integers(0, 4, 700)
     body = np.frombuffer(b"acgt", np.uint8)[np.concatenate([unit] * 120 + [rng.integers(0, 4, 30000)])]
@@ -165,7 +162,7 @@ def test_long_hit_lists_located_in_windows_through_the_full_suffix_array(oracle,
     ix.dealloc()
 
 
-def test_full_suffix_array_of_a_text_with_long_runs(oracle, awfm, require_gpu, monkeypatch, wide):
+def test_full_suffix_array_of_a_text_with_long_runs(oracle, awfm, require_gpu, monkeypatch, wide, diag):
     """A text with R long runs of one letter, R a multiple of the sampling ratio (a genome's runs of N): the suffixes inside
     the runs move R places per LF step and never meet a sample until a run ends.  The AUTOMATIC construction of the full
     suffix array parks such walks after 32 x ratio steps and completes the parked entries from each other (pointer
@@ -198,11 +195,11 @@ def test_full_suffix_array_of_a_text_with_long_runs(oracle, awfm, require_gpu, m
     monkeypatch.setenv("AWFM_GPU_DENSE_SA", "auto")
     for park_list in (None, "0", "1000"):  # the parked walks in a list (round 5) / an entry per position / a list that overflows
         if park_list is not None:
-            monkeypatch.setenv("AWFM_GPU_DENSE_SA_PARK_LIST", park_list)
+            diag(park_list=park_list)
         ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, 6)
         check(ix, True)  # 7/8 of the positions inside the runs parked, then completed
         ix.dealloc()
-    monkeypatch.delenv("AWFM_GPU_DENSE_SA_PARK_LIST")
+    diag(park_list=None)
     monkeypatch.setenv("AWFM_GPU_DENSE_SA", "0")
     ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, ratio, 6)
     check(ix, False)  # the walk at query time
@@ -305,13 +302,13 @@ def test_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, requir
 
 
 @pytest.mark.parametrize("seed_k,deep_k,lanes", [(2, 4, None), (3, 5, None), (1, 3, "g4"), (2, 5, "g4")])
-def test_amino_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, require_gpu, wide, monkeypatch, seed_k, deep_k, lanes):
+def test_amino_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, require_gpu, wide, monkeypatch, diag, seed_k, deep_k, lanes):
     """the same for the amino alphabet (20^deep_k entries, the index of ref src/AwFmKmerTable.c:37-51 over the last deep_k
     characters): exact ranges -- the first empty range of an absent k-mer included --, counts and positions, for k-mers
     shorter than the table, ambiguity letters (z, x, b) inside and outside its characters, upper case; two and four
     lanes per k-mer"""
     if lanes:
-        monkeypatch.setenv("AWFM_GPU_KERNEL", lanes)
+        diag(kernel=lanes)
     n = 120000
     txt = synth.text(700 + deep_k, n, synth.AMINO_ALPHABET).copy()
     txt[500:503] = ord("x")
@@ -519,13 +516,13 @@ def test_device_dense_sa_keeps_positions_bit_identical(oracle, awfm, require_gpu
 
 
 @pytest.mark.parametrize("alphabet_name,ratio,pair", [("dna", 16, "1"), ("dna", 13, "0"), ("amino", 16, "1")])
-def test_a_walk_the_walk_kernel_gives_up_is_walked_on_exactly(oracle, awfm, require_gpu, wide, monkeypatch, alphabet_name, ratio, pair):
+def test_a_walk_the_walk_kernel_gives_up_is_walked_on_exactly(oracle, awfm, require_gpu, wide, monkeypatch, diag, alphabet_name, ratio, pair):
     """The hand-over between walkKernel and finishKernel holds 23 bits of LF steps.  A walk that has not met a sample by then --
     a hit right behind a long run of one letter: a valid index -- used to be finished as if it stood on one (advisor, round
-    4); now it is parked and finishKernel walks it on, one thread, to its sample.  $AWFM_GPU_WALK_GIVE_UP=3 moves the limit
+    4); now it is parked and finishKernel walks it on, one thread, to its sample.  $AWFM_GPU_DIAG walk_give_up=3 moves the limit
     to three steps, so that most walks of an ordinary text (ratio 13 / 16) take that path: positions must be the oracle's,
     through the pair image and without, amino, 32- and 64-bit positions."""
-    monkeypatch.setenv("AWFM_GPU_WALK_GIVE_UP", "3")
+    diag(walk_give_up=3)
     monkeypatch.setenv("AWFM_GPU_PAIR", pair)
     amino = alphabet_name == "amino"
     letters = synth.AMINO_ALPHABET if amino else synth.DNA_ALPHABET
@@ -1046,7 +1043,7 @@ def test_list_tail_in_one_launch(oracle, awfm, require_gpu, shape, dense_sa):
 
 @pytest.mark.gpu
 def test_list_tail_of_a_long_list_takes_the_three_calls(oracle, awfm, require_gpu, monkeypatch):
-    """a list of more than 2^18 entries (and any list with $AWFM_GPU_LIST_TAIL=0) goes through copy + awfmGpuSortHitsOnDevice +
+    """a list of more than 2^18 entries goes through copy + awfmGpuSortHitsOnDevice +
     awfmGpuHitOffsetsOnDevice + awfmGpuLocateOnDevice inside awfmGpuListLocateOnDevice: the same arrays come out"""
     import torch
     n, K, Q = 300000, 14, 700_001
@@ -1064,9 +1061,7 @@ def test_list_tail_of_a_long_list_takes_the_three_calls(oracle, awfm, require_gp
     oho, opos, _ = oi.batch_locate(sp[has], ep[has], threads=4)
     dev = torch.device("cuda")
     d_chars = torch.from_numpy(chars).to(dev)
-    for cap, knob in ((len(has) + 1000, None), (len(has) + 1000, "0")):
-        if knob is not None:
-            monkeypatch.setenv("AWFM_GPU_LIST_TAIL", knob)
+    for cap in (len(has) + 1000,):
         d_kmers = torch.zeros(cap, dtype=torch.int32, device=dev)
         d_ranges = torch.zeros(cap * 2, dtype=torch.int64, device=dev)
         d_num = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -1095,7 +1090,7 @@ def test_lookup_prediction_launches_one_front_end_and_keeps_the_results(oracle, 
     alone must give every batch the oracle's counts and list -- the batch the prediction is wrong for included (k-mers drawn
     from the text right behind random ones and the other way round) -- and a wrong prediction must switch it off for a while."""
     import torch
-    for name in ("AWFM_GPU_LOOKUP_FIRST", "AWFM_GPU_LOOKUP_PREDICT", "AWFM_GPU_PREP_FUSED"):
+    for name in ("AWFM_GPU_LOOKUP_FIRST", "AWFM_GPU_LOOKUP_PREDICT"):
         monkeypatch.delenv(name, raising=False)
     n, K, Q = 300000, 21, (1 << 20) + 5
     txt = synth.text(n + 41, n, synth.DNA_ALPHABET).copy()
@@ -1200,7 +1195,7 @@ def _check_hits_contract(ranges, counts, sp, ep, cnt):
 @pytest.mark.parametrize("n,ratio,seed_k,deep_k,K", [(300000, 8, 8, 0, 21), (300000, 5, 8, 0, 8), (200000, 8, 6, 9, 32),
                                                      (200000, 8, 6, 9, 7), (4096, 3, 4, 0, 13), (100000, 8, 1, 0, 5),
                                                      (150000, 8, 10, 11, 11), (300000, 8, 12, 16, 21)])
-def test_ordered_hits_only_search_is_exact_on_hits(oracle, awfm, require_gpu, wide, order_sort, n, ratio, seed_k, deep_k, K):
+def test_ordered_hits_only_search_is_exact_on_hits(oracle, awfm, require_gpu, wide, n, ratio, seed_k, deep_k, K):
     """awfmGpuSearchHits with the ordered path forced on (fixed-length DNA batches): ambiguity characters and upper
     case included, query buffer at every byte alignment, ranges only / counts only / both, then the locate
     pipeline on top of the hits-only ranges"""
@@ -1666,10 +1661,10 @@ def test_mixed_length_lookup_prediction_and_whole_line_counts(oracle, awfm, requ
     whose predecessors agree launches one front end (awfmGpuLastLookupFront: 1 = mixedLookupSearchKernel alone, which then
     takes whatever the batch is; 2 = the 16-byte-record path alone).  With the lookup kernel alone a dense search is not
     pre-filled: the kernel stores every k-mer's count (and range) itself, a round's at a time in whole lines, survivors' final
-    ranges out of their slots (and $AWFM_GPU_MIXED_WHOLE_COUNTS=0: pre-filled, a store per hit as before).  Counts and list against the oracle
+    ranges out of their slots.  Counts and list against the oracle
     whatever was predicted, the batch the prediction is wrong for included."""
     import torch
-    for name in ("AWFM_GPU_MIXED_LOOKUP", "AWFM_GPU_LOOKUP_PREDICT", "AWFM_GPU_MIXED_WHOLE_COUNTS"):
+    for name in ("AWFM_GPU_MIXED_LOOKUP", "AWFM_GPU_LOOKUP_PREDICT"):
         monkeypatch.delenv(name, raising=False)
     n, Q = 300000, (1 << 20) + 77
     txt = synth.text(n + 47, n, synth.DNA_ALPHABET).copy()
@@ -1734,9 +1729,6 @@ def test_mixed_length_lookup_prediction_and_whole_line_counts(oracle, awfm, requ
     fronts = [run("random", False), run("random", True), run("random", False), run("random", True)]
     assert fronts[0] == 0 and fronts[2:] == [1, 1], fronts
     assert run("random", "ranges") == 1  # (whole-line ranges)
-    monkeypatch.setenv("AWFM_GPU_MIXED_WHOLE_COUNTS", "0")
-    assert run("random", False) == 1 and run("random", "ranges") == 1
-    monkeypatch.delenv("AWFM_GPU_MIXED_WHOLE_COUNTS")
     assert run("planted", "ranges") == 1  # predicted from the random batches: the lookup kernel takes the planted one, whole-line ranges
     held = [run("planted", ("ranges", True, False)[i % 3]) for i in range(9)]
     assert held[:8] == [0] * 8, held  # the miss switched the prediction off for eight searches
@@ -1896,39 +1888,4 @@ def test_deep_seed_env_knob_through_the_drop_in_api(oracle, awfm, require_gpu, m
     monkeypatch.delenv("AWFM_GPU_DEVICES")
     ix = awfm.gpu_create_index(txt, awfm.AwFmAlphabetDna, 8, 6)  # the builder's adopted image gets the table too
     check(ix)
-    ix.dealloc()
-
-
-@pytest.mark.gpu
-def test_lookup_timeline_diagnostic(oracle, awfm, require_gpu, monkeypatch, tmp_path):
-    """$AWFM_GPU_LOOKUP_TIMELINE (round 5, diagnostic): lookupSearchKernel leaves every wave's start and end on the device's
-    clock, its HW_ID and the trips it made; the search's results are what they are without it, every wave that ran started
-    before it ended, and the trips of all waves cover the batch (256 k-mers a trip)."""
-    import torch
-    n, K, Q = 300000, 21, (1 << 20) + 5
-    txt = synth.text(n + 51, n, synth.DNA_ALPHABET).copy()
-    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
-    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
-    g = awfm.GpuIndex(ix)
-    g.set_ordered(1)
-    g.set_deep_seed(12)
-    q = synth.random_queries(19, Q, K).copy()
-    q[5::64] = synth.planted_queries(20, len(q[5::64]), K, txt)
-    chars, offsets = synth.fixed_csr(q)
-    _, _, cnt, _ = oi.batch_search(chars, offsets, threads=4)
-    dev = torch.device("cuda")
-    d_chars = torch.from_numpy(chars).to(dev)
-    d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
-    path = tmp_path / "timeline.bin"
-    monkeypatch.setenv("AWFM_GPU_LOOKUP_FIRST", "1")
-    monkeypatch.setenv("AWFM_GPU_LOOKUP_TIMELINE", str(path))
-    g.search_hits(d_chars.data_ptr(), 0, K, Q, 0, d_counts.data_ptr())
-    torch.cuda.synchronize()
-    assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt)
-    t = np.fromfile(path, dtype=np.uint64).reshape(-1, 4)
-    ran = t[(t[:, 0] != 0) & (t[:, 1] != 0)]
-    assert len(ran) >= 4 and np.all(ran[:, 0] <= ran[:, 1])
-    assert int(ran[:, 3].sum()) == (Q + 255) // 256 or int(ran[:, 3].sum()) >= Q // 256  # (a share's last trip may be a partial one)
-    assert len(np.unique((ran[:, 2] >> 4) & 3)) >= 2  # (HW_ID: waves on more than one SIMD)
-    g.destroy()
     ix.dealloc()

@@ -185,7 +185,7 @@ def test_device_resident_packed_search(oracle, awfm, require_gpu, wide, ordered)
 
 def test_locate_into_page_locked_host_memory(oracle, awfm, require_gpu, monkeypatch):
     """awfmGpuLocateTo: the kernel that produces the positions stores them where the caller reads them (page-locked host
-    memory), the walk's work array stays on the device; and the pipeline's variant of it ($AWFM_GPU_STREAM_DIRECT)"""
+    memory), the walk's work array stays on the device"""
     import torch
     from avxwindowfmindex_amd import _lib
     L = _lib.lib()
@@ -211,9 +211,6 @@ def test_locate_into_page_locked_host_memory(oracle, awfm, require_gpu, monkeypa
     got = np.ctypeslib.as_array(C.cast(address, C.POINTER(C.c_uint64)), shape=(total,)).copy()
     assert np.array_equal(got, pos)
     L.awfmGpuHostFree(address)
-    monkeypatch.setenv("AWFM_GPU_STREAM_DIRECT", "1")
-    counts, positions = g.stream(awfm.pack_kmers(kmers), K, locate=True, chunk=2000)
-    assert np.array_equal(counts, cnt) and np.array_equal(positions, pos)
     g.destroy()
     ix.dealloc()
 
