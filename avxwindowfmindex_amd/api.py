@@ -492,6 +492,30 @@ class GpuIndex:
             self.handle, d_chars, d_offsets or None, fixed_length, n, int(bool(packed)), d_hit_kmers, d_hit_ranges, capacity,
             d_num_hits, stream or None))
 
+    # seed-bucket sharding (include/awfm_gpu.h) ---------------------------
+    def order_buckets(self, fixed_length, total_queries):
+        """buckets of the seed order of such a batch on this image (0: not a batch for 8-byte records)"""
+        return int(_lib.lib().awfmGpuOrderBuckets(self.handle, fixed_length, total_queries))
+
+    def order_kmers(self, d_chars, fixed_length, n, first_number, total_queries, d_records, d_bucket_start, stream=0):
+        """awfmGpuOrderKmers: the shard's records {rest of the code string, number in the whole batch} in bucket order"""
+        _check("awfmGpuOrderKmers", _lib.lib().awfmGpuOrderKmers(self.handle, d_chars, fixed_length, n, first_number, total_queries,
+                                                               d_records, d_bucket_start, stream or None))
+
+    def search_ordered_records(self, d_records, d_bucket_start, first_bucket, end_bucket, fixed_length, total_queries, d_order_kmers,
+                               d_order_ranges, stream=0):
+        """awfmGpuSearchOrderedRecords: the buckets [first, end) of a record array, results in that order"""
+        _check("awfmGpuSearchOrderedRecords", _lib.lib().awfmGpuSearchOrderedRecords(
+            self.handle, d_records, d_bucket_start, first_bucket, end_bucket, fixed_length, total_queries, d_order_kmers, d_order_ranges,
+            stream or None))
+
+    def search_general_records(self, d_chars, fixed_length, n, first_number, total_queries, d_records, d_bucket_start, d_order_kmers,
+                               d_order_ranges, stream=0):
+        """awfmGpuSearchGeneralRecords: the tail of a shard's own records (k-mers with ambiguity characters) through the general kernel"""
+        _check("awfmGpuSearchGeneralRecords", _lib.lib().awfmGpuSearchGeneralRecords(
+            self.handle, d_chars, fixed_length, n, first_number, total_queries, d_records, d_bucket_start, d_order_kmers, d_order_ranges,
+            stream or None))
+
     def search_hits_in_order(self, d_chars, d_offsets, fixed_length, n, d_order_kmers, d_order_ranges, packed=False, stream=0):
         """awfmGpuSearchHitsInOrder: {k-mer number, range} for every k-mer, in the order the seed-order search took them"""
         _check("awfmGpuSearchHitsInOrder", _lib.lib().awfmGpuSearchHitsInOrder(

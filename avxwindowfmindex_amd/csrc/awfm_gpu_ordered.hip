@@ -1564,6 +1564,184 @@ extern "C" enum AwFmReturnCode awfmGpuSearchHitsInOrder(AwFmGpuIndex *g, const u
   return AwFmSuccess;
 }
 
+/* ------------------------------------------------------------------ seed-bucket sharding (round 6; include/awfm_gpu.h) */
+
+/* the table a fixed-length batch of `totalQueries` k-mers starts from on this image, and the format of its 8-byte records;
+ * false: such a batch is not one for bucketed records */
+static bool shardedFormat(const AwFmGpuIndex *g, uint32_t fixedLength, uint64_t totalQueries, unsigned *depthOut, const ulonglong2 **tableOut,
+                          BucketFormat *fmtOut) {
+  if (g->amino || !(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) return false;
+  if (totalQueries == 0 || totalQueries >= 0xFFFFFFFFull || g->dev.seedK == 0 || g->dev.seedK >= 32 || g->dev.deepK >= 32) return false;
+  if (fixedLength == 0 || fixedLength > 32) return false;
+  const bool deep = g->dev.deepK != 0 && fixedLength >= g->dev.deepK;
+  const unsigned depth = deep ? g->dev.deepK : g->dev.seedK;
+  if (fixedLength < depth) return false;
+  const BucketFormat fmt = bucketFormat(depth, totalQueries);
+  if (!bucketFits(fixedLength, fmt)) return false;
+  *depthOut = depth;
+  *tableOut = deep ? g->dev.deepSeed : g->dev.seed;
+  *fmtOut = fmt;
+  return true;
+}
+
+extern "C" uint32_t awfmGpuOrderBuckets(const AwFmGpuIndex *g, uint32_t fixedLength, uint64_t totalQueries) {
+  unsigned depth = 0;
+  const ulonglong2 *table = nullptr;
+  BucketFormat fmt;
+  if (!g || !shardedFormat(g, fixedLength, totalQueries, &depth, &table, &fmt)) return 0;
+  return 1u << fmt.bucketBits;
+}
+
+extern "C" enum AwFmReturnCode awfmGpuOrderKmers(AwFmGpuIndex *g, const uint8_t *dChars, uint32_t fixedLength, uint64_t numQueries,
+                                                 uint64_t firstNumber, uint64_t totalQueries, uint64_t *dRecords, uint32_t *dBucketStart,
+                                                 void *stream) {
+  if (!g || !dChars || !dRecords || !dBucketStart) {
+    setError("awfmGpuOrderKmers: null argument");
+    return AwFmNullPtrError;
+  }
+  unsigned depth = 0;
+  const ulonglong2 *table = nullptr;
+  BucketFormat fmt;
+  if (numQueries == 0 || firstNumber + numQueries > totalQueries || !shardedFormat(g, fixedLength, totalQueries, &depth, &table, &fmt)) {
+    setError("awfmGpuOrderKmers: a shard [first, first + n) of a fixed-length nucleotide batch whose 8-byte records fit (awfmGpuOrderBuckets)");
+    return AwFmIllegalPositionError;
+  }
+  DeviceGuard guard(g->device);
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  const unsigned long long nq = numQueries;
+  const unsigned bins = (1u << fmt.bucketBits) + 1u, binsPad = (bins + 3u) & ~3u;
+  /* [counters 128 KB][hist -> sub-run starts: 8 shares x binsPad][cursors: 8 x binsPad][codes: nq x 8] of the image's scratch */
+  const size_t histAt = kOrderCounterBytes, cursorsAt = histAt + alignUp256((size_t)kShares * binsPad * 4u);
+  const size_t codesAt = cursorsAt + alignUp256((size_t)kShares * binsPad * 4u), total = codesAt + alignUp256(nq * 8u);
+#define SHARD_TRY(call)                     \
+  do {                                      \
+    hipError_t e__ = (call);                \
+    if (e__ != hipSuccess) {                \
+      setError(#call, e__);                 \
+      return AwFmGeneralFailure;            \
+    }                                       \
+  } while (0)
+  SHARD_TRY(orderBeginSlot(g, s));
+  OrderSlotScope slotScope(g, s);
+  if (!ensureOrderScratch(g, total)) return AwFmAllocationFailure;
+  uint8_t *w = (uint8_t *)g->dOrder;
+  unsigned *generalCount = (unsigned *)w, *hist = (unsigned *)(w + histAt), *cursors = (unsigned *)(w + cursorsAt);
+  unsigned long long *codes = (unsigned long long *)(w + codesAt);
+  SHARD_TRY(hipMemsetAsync(w, 0, codesAt, s));
+  const unsigned long long perShare256 = (shareSize(nq) + 255ull) / 256ull;
+  unsigned encodeGrid = (unsigned)(perShare256 * kShares < (unsigned long long)g->numCUs * 8u ? perShare256 * kShares : (unsigned long long)g->numCUs * 8u);
+  encodeGrid = (encodeGrid + kShares - 1u) / kShares * kShares;
+  launchEncode4(fixedLength, encodeGrid, bins * 4u, s, dChars, fmt, nq, codes, hist, binsPad);
+  SHARD_TRY(hipGetLastError());
+  hipLaunchKernelGGL(bucketScanSharesKernel, dim3(1), dim3(1024), 0, s, hist, bins, binsPad, (unsigned *)dBucketStart, generalCount, (unsigned)nq);
+  SHARD_TRY(hipGetLastError());
+  const size_t partitionLds = (size_t)kPartitionTile * 8u + 3u * binsPad * 4u;
+  SHARD_TRY(hipFuncSetAttribute((const void *)partitionKernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(kPartitionTile * 8u + 3u * (((1u << kBucketBitsMax) + 4u) & ~3u) * 4u)));
+  const unsigned long long tilesPerShare = shareSize(nq) / kPartitionTile;
+  unsigned partitionGrid = (unsigned)(tilesPerShare * kShares < (unsigned long long)g->numCUs ? tilesPerShare * kShares : (unsigned long long)g->numCUs);
+  partitionGrid = (partitionGrid + kShares - 1u) / kShares * kShares;
+  /* (the records carry the k-mers' numbers in the WHOLE batch: firstNumber + the number in this shard) */
+  hipLaunchKernelGGL(partitionKernel, dim3(partitionGrid), dim3(kPartitionThreads), partitionLds, s, (const unsigned long long *)codes, fixedLength, fmt, nq,
+                     (const unsigned *)hist, cursors, (unsigned long long *)dRecords, 1u, (const unsigned *)nullptr, (const unsigned *)nullptr,
+                     (const unsigned *)nullptr, 0u, (unsigned long long)firstNumber);
+  SHARD_TRY(hipGetLastError());
+  /* (the size of the last bin -- the k-mers awfmGpuSearchGeneralRecords takes -- behind the bucket starts) */
+  SHARD_TRY(hipMemcpyAsync(dBucketStart + bins + 1u, generalCount, 4, hipMemcpyDeviceToDevice, s));
+  SHARD_TRY(slotScope.end());
+  return AwFmSuccess;
+}
+
+extern "C" enum AwFmReturnCode awfmGpuSearchOrderedRecords(AwFmGpuIndex *g, const uint64_t *dRecords, const uint32_t *dBucketStart, uint32_t firstBucket,
+                                                           uint32_t endBucket, uint32_t fixedLength, uint64_t totalQueries, uint32_t *dOrderKmers,
+                                                           struct AwFmSearchRange *dOrderRanges, void *stream) {
+  if (!g || !dRecords || !dBucketStart || !dOrderKmers || !dOrderRanges) {
+    setError("awfmGpuSearchOrderedRecords: null argument");
+    return AwFmNullPtrError;
+  }
+  unsigned depth = 0;
+  const ulonglong2 *table = nullptr;
+  BucketFormat fmt;
+  if (!shardedFormat(g, fixedLength, totalQueries, &depth, &table, &fmt) || firstBucket >= endBucket || endBucket > (1u << fmt.bucketBits)) {
+    setError("awfmGpuSearchOrderedRecords: buckets [first, end) of the records awfmGpuOrderKmers makes for this image and batch");
+    return AwFmIllegalPositionError;
+  }
+  DeviceGuard guard(g->device);
+  hipStream_t s = (hipStream_t)stream;
+  std::lock_guard<std::mutex> lock(g->orderMutex);
+  fmt.firstBucket = firstBucket;
+  fmt.endBucket = endBucket;
+  /* the ticket counters of the search kernel: the counter block of the image's scratch */
+  if (orderBeginSlot(g, s) != hipSuccess) {
+    setError("seed-order search: could not order the use of its scratch across streams");
+    return AwFmGeneralFailure;
+  }
+  OrderSlotScope slotScope(g, s);
+  if (!ensureOrderScratch(g, kOrderCounterBytes)) return AwFmAllocationFailure;
+  unsigned *generalCount = (unsigned *)g->dOrder;
+  AWFM_HIP_TRY(hipMemsetAsync(generalCount, 0, kOrderCounterBytes, s), AwFmGeneralFailure);
+  for (int i = 0; i < 4; i++) g->orderTiming[i] = nullptr;
+  SparseOut out;
+  out.count = nullptr;
+  out.cap = 0;
+  out.kmers = (unsigned *)dOrderKmers;
+  out.ranges = (ulonglong2 *)dOrderRanges;
+  const bool pair = pairSteps(g);
+  enum AwFmReturnCode rc;
+#define SHARD_GO(NR, PR) \
+  launchOrderedKernel<NR, false, PR, false, true>(g, s, fixedLength, depth, table, totalQueries, dRecords, generalCount, nullptr, nullptr, nullptr, (const unsigned *)dBucketStart, fmt, &out)
+  if (awfmImageNarrow(g)) rc = pair ? SHARD_GO(true, true) : SHARD_GO(true, false);
+  else rc = pair ? SHARD_GO(false, true) : SHARD_GO(false, false);
+#undef SHARD_GO
+  if (rc != AwFmSuccess) return rc;
+  AWFM_HIP_TRY(slotScope.end(), AwFmGeneralFailure);
+  return AwFmSuccess;
+}
+
+extern "C" enum AwFmReturnCode awfmGpuSearchGeneralRecords(AwFmGpuIndex *g, const uint8_t *dChars, uint32_t fixedLength, uint64_t numQueries,
+                                                           uint64_t firstNumber, uint64_t totalQueries, const uint64_t *dRecords,
+                                                           const uint32_t *dBucketStart, uint32_t *dOrderKmers, struct AwFmSearchRange *dOrderRanges,
+                                                           void *stream) {
+  if (!g || !dChars || !dRecords || !dBucketStart || !dOrderKmers || !dOrderRanges) {
+    setError("awfmGpuSearchGeneralRecords: null argument");
+    return AwFmNullPtrError;
+  }
+  unsigned depth = 0;
+  const ulonglong2 *table = nullptr;
+  BucketFormat fmt;
+  if (numQueries == 0 || firstNumber + numQueries > totalQueries || !shardedFormat(g, fixedLength, totalQueries, &depth, &table, &fmt)) {
+    setError("awfmGpuSearchGeneralRecords: the shard awfmGpuOrderKmers was given");
+    return AwFmIllegalPositionError;
+  }
+  DeviceGuard guard(g->device);
+  hipStream_t s = (hipStream_t)stream;
+  /* the last bin of the shard's records: the k-mers with ambiguity characters, a record each = its number in the whole batch.
+   * The general kernel reads the k-mer under that number: the character array as if it began at the batch's first k-mer.
+   * Entries [dBucketStart[buckets], numQueries) of the order arrays get {number, range}. */
+  const unsigned bins = (1u << fmt.bucketBits) + 1u;
+  const unsigned *leftCount = (const unsigned *)dBucketStart + bins + 1u; /* bucketScanSharesKernel leaves the last bin's size there */
+  SparseOut out;
+  out.count = nullptr;
+  out.cap = 0;
+  out.kmers = (unsigned *)dOrderKmers;
+  out.ranges = (ulonglong2 *)dOrderRanges;
+  const uint8_t *base = dChars - (size_t)firstNumber * fixedLength;
+  const bool narrow = awfmImageNarrow(g);
+  const unsigned grid = narrow ? residentGrid(g, searchKernel<false, 4, false, false, true, true>) : residentGrid(g, searchKernel<false, 4, false, false, false, true>);
+  if (narrow)
+    hipLaunchKernelGGL((searchKernel<false, 4, false, false, true, true>), dim3(grid), dim3(kThreads), 0, s, g->dev, base, (const unsigned long long *)nullptr, fixedLength,
+                       (unsigned long long)(firstNumber + numQueries), (ulonglong2 *)nullptr, (unsigned *)nullptr, (unsigned long long *)nullptr,
+                       (const unsigned char *)dRecords, 8u, 0u, (unsigned long long)numQueries, leftCount, out, (const unsigned *)nullptr, 0u);
+  else
+    hipLaunchKernelGGL((searchKernel<false, 4, false, false, false, true>), dim3(grid), dim3(kThreads), 0, s, g->dev, base, (const unsigned long long *)nullptr, fixedLength,
+                       (unsigned long long)(firstNumber + numQueries), (ulonglong2 *)nullptr, (unsigned *)nullptr, (unsigned long long *)nullptr,
+                       (const unsigned char *)dRecords, 8u, 0u, (unsigned long long)numQueries, leftCount, out, (const unsigned *)nullptr, 0u);
+  AWFM_HIP_TRY(hipGetLastError(), AwFmGeneralFailure);
+  return AwFmSuccess;
+}
+#undef SHARD_TRY
+
 extern "C" enum AwFmReturnCode awfmGpuCompactHits(AwFmGpuIndex *g, const uint32_t *dCounts, const struct AwFmSearchRange *dRanges,
                                                   uint64_t numQueries, uint64_t *dFlagOffsets, void *dScratch, uint32_t *dHitKmers,
                                                   struct AwFmSearchRange *dHitRanges, uint32_t capacity, uint32_t *dNumHits,

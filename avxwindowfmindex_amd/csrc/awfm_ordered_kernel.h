@@ -176,6 +176,9 @@ struct BucketFormat {
   unsigned bucketBits; /* min(kBucketBitsMax, 2 * depth): leading bits of the table index */
   unsigned lowBits;    /* 2 * depth - bucketBits: table-index bits below the bucket's */
   unsigned indexBits;  /* bits of a query number */
+  /* round 6 (seed-bucket sharding, awfmGpuSearchOrderedRecords): the search takes the records of the buckets
+   * [firstBucket, endBucket) only -- a rank's dense share of the order; endBucket 0: all of them */
+  unsigned firstBucket, endBucket;
 };
 __host__ __device__ inline BucketFormat bucketFormat(unsigned depth, unsigned long long numQueries) {
   BucketFormat f;
@@ -184,6 +187,7 @@ __host__ __device__ inline BucketFormat bucketFormat(unsigned depth, unsigned lo
   f.lowBits = 2u * depth - f.bucketBits;
   f.indexBits = 1;
   while (f.indexBits < 32u && (numQueries - 1ull) >> f.indexBits) f.indexBits++;
+  f.firstBucket = f.endBucket = 0u;
   return f;
 }
 /* does a record of a k-mer of `len` characters fit 8 bytes? */
@@ -766,7 +770,8 @@ __global__ void __launch_bounds__(kPartitionThreads)
                     unsigned *__restrict__ cursors, unsigned long long *__restrict__ recs, const unsigned honourGeneral,
                     const unsigned *__restrict__ shareCountIn = nullptr /* after encodeLookupKernel: code words in the share's region */,
                     const unsigned *__restrict__ numbersIn = nullptr /* ... and the k-mer numbers beside them */,
-                    const unsigned *__restrict__ sampleAlive = nullptr, const unsigned samples = 0u /* lookupChosen: was it that kernel? */) {
+                    const unsigned *__restrict__ sampleAlive = nullptr, const unsigned samples = 0u /* lookupChosen: was it that kernel? */,
+                    const unsigned long long numberBase = 0ull /* a shard of a larger batch (awfmGpuOrderKmers): its first k-mer's number there */) {
   const bool afterLookup = shareCountIn != nullptr && lookupChosen(sampleAlive, samples, true);
   const unsigned *__restrict__ shareCount = afterLookup ? shareCountIn : nullptr;
   const unsigned *__restrict__ numbers = afterLookup ? numbersIn : nullptr;
@@ -823,7 +828,7 @@ __global__ void __launch_bounds__(kPartitionThreads)
       const unsigned rank = ldsCountRank(sCnt, b, valid);
       if (valid) {
         where[j] = (b << 16) | rank;
-        rec[j] = (general ? 0ull : bucketRest(f, c) << f.indexBits) | (numbers ? (unsigned long long)numbers[idx] : idx);
+        rec[j] = (general ? 0ull : bucketRest(f, c) << f.indexBits) | ((numbers ? (unsigned long long)numbers[idx] : idx) + numberBase);
       }
     }
     __syncthreads();
@@ -1135,8 +1140,12 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   __shared__ unsigned sHitKmers[LIST ? orderedThreads(PAIR) / 64 : 1][kHitBuffer];
   __shared__ unsigned long long sHitRanges[LIST ? orderedThreads(PAIR) / 64 : 1][kHitBuffer][2];
   unsigned hitFill = 0; /* wave-uniform */
+  /* the records this launch covers: the whole order, or the buckets [firstBucket, endBucket) of it */
+  const unsigned long long coveredFirst = BUCKET && bucketFmt.endBucket != 0u ? (unsigned long long)bucketStart[bucketFmt.firstBucket] : 0ull;
+  const unsigned long long coveredEnd = BUCKET ? (unsigned long long)bucketStart[bucketFmt.endBucket != 0u ? bucketFmt.endBucket : 1u << bucketFmt.bucketBits]
+                                               : numRecs - (unsigned long long)*generalCount;
   /* nothing to search (the batch ended in lookupSearchKernel): not even the tables are staged */
-  if (BUCKET && bucketStart[1u << bucketFmt.bucketBits] == 0u) return;
+  if (BUCKET && coveredEnd == coveredFirst) return;
   /* ... and what the waves of a workgroup still hold when they are done goes out in ONE reservation, made by the wave that
    * finishes last: the waves of the grid end together, and 7168 of them each taking a returning atomic on the list's counter
    * were a tail of 60-80 us on a kernel that searched 5 * 10^5 k-mers (a word takes 88 atomics per microsecond) */
@@ -1186,13 +1195,13 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   /* the records the fast path covers come first in the order; each XCD takes a contiguous eighth of them */
   /* (bucketed records: what lies before the last bin -- the batch without the k-mers of the general kernel, or the k-mers
    * encodeLookupKernel kept) */
-  const unsigned long long covered = BUCKET ? (unsigned long long)bucketStart[1u << bucketFmt.bucketBits] : numRecs - (unsigned long long)*generalCount;
+  const unsigned long long covered = coveredEnd - coveredFirst;
   const unsigned xcds = (gridDim.x & 7u) == 0u ? 8u : 1u; /* (workgroup b runs on XCD b % 8 under round-robin dispatch) */
   const unsigned xcd = xcds == 8u ? (blockIdx.x & 7u) : 0u;
   const unsigned blockInXcd = xcds == 8u ? (blockIdx.x >> 3) : blockIdx.x;
   const unsigned long long share = (covered + xcds - 1ull) / xcds;
-  const unsigned long long begin = share * xcd;
-  const unsigned long long end = begin + share < covered ? begin + share : covered;
+  const unsigned long long begin = coveredFirst + share * xcd;
+  const unsigned long long end = begin + share < coveredEnd ? begin + share : coveredEnd;
   /* The waves of an XCD take chunks of 64/G consecutive records from ticket counters instead of a fixed stride:
    * free-running waves drift apart, and with a fixed stride the records in flight on an XCD would then span
    * many more buckets than its L2 holds the blocks of (8.7 ms with the stride, 5.8 ms with tickets).  Wave w of
@@ -1479,8 +1488,8 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
         }
       } else if (sparse.kmers) { /* results in search order: entry `at`, whatever the outcome */
         if (mine) {
-          sparse.kmers[at] = index;
-          sparse.ranges[at] = sp <= ep ? make_ulonglong2((unsigned long long)sp, (unsigned long long)ep) : make_ulonglong2(1ull, 0ull);
+          sparse.kmers[at - coveredFirst] = index; /* (a share of the order: its entries from 0) */
+          sparse.ranges[at - coveredFirst] = sp <= ep ? make_ulonglong2((unsigned long long)sp, (unsigned long long)ep) : make_ulonglong2(1ull, 0ull);
         }
       } else if (mine && sp <= ep) {
         if (ranges) ranges[index] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);

@@ -66,6 +66,39 @@ def positions_digest(first, hit_offsets, positions):
     return total & MASK
 
 
+def counts_digest_keyed(ids, counts):
+    """the same sum over k-mers that are named one by one (ids: their numbers in the whole batch, any order) -- what a rank of
+    a seed-bucket-sharded run holds: a share of the ORDER, not a stretch of the batch"""
+    import torch
+    total = 0
+    step = 1 << 24
+    for b in range(0, ids.numel(), step):
+        c = counts[b:b + step].to(torch.int64) & 0xFFFFFFFF
+        total += int(_mix(ids[b:b + step].to(torch.int64) * _s64(_A) + c * _s64(_B)).sum().item())
+    return total & MASK
+
+
+def positions_digest_keyed(ids, hit_offsets, positions):
+    """positions_digest for entries named one by one: entry e is k-mer ids[e], its hits positions[hit_offsets[e]:hit_offsets[e + 1]]"""
+    import torch
+    n = hit_offsets.numel() - 1
+    total = 0
+    step = 1 << 23
+    for b in range(0, n, step):
+        e = min(n, b + step)
+        off = hit_offsets[b:e + 1]
+        lo, hi = int(off[0].item()), int(off[-1].item())
+        if hi == lo:
+            continue
+        lens = off[1:] - off[:-1]
+        q = torch.repeat_interleave(ids[b:e].to(torch.int64), lens)
+        starts = torch.repeat_interleave(off[:-1], lens)
+        rank = torch.arange(lo, hi, dtype=torch.int64, device=off.device) - starts
+        p = positions[lo:hi].to(torch.int64)
+        total += int(_mix(q * _s64(_A) + rank * _s64(_C) + p * _s64(_D)).sum().item())
+    return total & MASK
+
+
 def key(alphabet, workload, mode, text_len, kmer, seed_k, sa_ratio, first, count):
     """the name of a committed digest: the synthetic inputs are functions of these and of fixed seeds (bench.py)"""
     return f"{alphabet}:{workload}:{mode}:n{text_len}:k{kmer}:seed{seed_k}:ratio{sa_ratio}:first{first}:count{count}"

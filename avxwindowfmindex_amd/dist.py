@@ -1,4 +1,5 @@
-"""Query sharding across ranks (one process per GPU, index replicated, no data-path collective).
+"""Query sharding across ranks (one process per GPU, index replicated; no data-path collective -- but for the seed-bucket
+sharding of dense-hit batches, whose one exchange of records is below: bucket_exchange).
 
 The reference's only parallel axis is OpenMP over independent 8-query blocks
 (ref src/AwFmParallelSearch.c:103-129); across GPUs the same independence lets every rank take a
@@ -134,3 +135,80 @@ def gather_counts(local, world):
     parts = [None] * world
     dist.all_gather_object(parts, local)
     return np.concatenate(parts)
+
+
+# ---- seed-bucket sharding (round 6; include/awfm_gpu.h: awfmGpuOrderKmers / awfmGpuSearchOrderedRecords) ----
+
+def bucket_cuts(buckets, world):
+    """bucket ranges of the ranks: rank r takes [cuts[r], cuts[r + 1])"""
+    return [(buckets * r) // world for r in range(world + 1)]
+
+
+def merge_bucket_slices(slices, starts, first_bucket, end_bucket):
+    """What a rank holds after the exchange, put in bucket order.  slices[j]: the records rank j sent (its buckets
+    [first_bucket, end_bucket), bucket by bucket); starts[j]: rank j's bucket starts over those buckets, relative to the slice
+    (end_bucket - first_bucket + 1 numbers).  Returns (records, bucket starts of the merged array, absolute bucket numbers): the
+    runs of one bucket from all ranks end up next to each other, rank by rank -- any order inside a bucket will do
+    (awfm_ordered_kernel.h).  torch tensors (any device) or numpy arrays."""
+    import torch
+    nb = end_bucket - first_bucket
+    starts = [torch.as_tensor(s, dtype=torch.int64) for s in starts]
+    counts = torch.stack([s[1:] - s[:-1] for s in starts])  # [rank][bucket]
+    per_bucket = counts.sum(0)
+    merged_start = torch.zeros(nb + 1, dtype=torch.int64)
+    merged_start[1:] = torch.cumsum(per_bucket, 0)
+    before = torch.cumsum(counts, 0) - counts  # records of the bucket from the ranks before j
+    device = slices[0].device if hasattr(slices[0], "device") else "cpu"
+    out = torch.empty(int(merged_start[-1]), dtype=torch.int64, device=device)
+    for j, sl in enumerate(slices):
+        sl = torch.as_tensor(sl)
+        if sl.numel() == 0:
+            continue
+        # destination of record p of slice j: merged_start[b] + before[j][b] + (p - starts[j][b]), b its bucket
+        shift = (merged_start[:-1] + before[j] - starts[j][:-1]).to(device)
+        reps = counts[j].to(device)
+        dest = torch.arange(sl.numel(), dtype=torch.int64, device=device) + torch.repeat_interleave(shift, reps)
+        out[dest] = sl.view(torch.int64) if sl.dtype != torch.int64 else sl
+    return out, merged_start
+
+
+def bucket_exchange(records, bucket_start, buckets, world, rank, group=None):
+    """The one exchange of the seed-bucket sharding: every rank sends rank j the records of its buckets
+    [cuts[j], cuts[j + 1]) -- a contiguous slice of its bucket-ordered array -- and puts what it receives in bucket order
+    (merge_bucket_slices).  `records`: int64 tensor (device or host), `bucket_start`: the buckets + 1 first words
+    awfmGpuOrderKmers left (records before every bucket).  Returns (records of this rank's buckets in bucket order, their
+    bucket starts relative to that array).  The transport is torch.distributed's all_to_all_single on the tensors' device
+    (RCCL over xGMI for device tensors under the nccl backend; gloo moves host tensors -- the tests' way)."""
+    import torch
+    import torch.distributed as dist
+    cuts = bucket_cuts(buckets, world)
+    bs = torch.as_tensor(bucket_start, dtype=torch.int64).cpu()
+    send_at = [int(bs[c]) for c in cuts]
+    send_sizes = [send_at[j + 1] - send_at[j] for j in range(world)]
+    rel = [(bs[cuts[j]: cuts[j + 1] + 1] - bs[cuts[j]]).tolist() for j in range(world)]  # my starts inside the slice for rank j
+    if world == 1:
+        return records[send_at[0]: send_at[1]], torch.tensor(rel[0], dtype=torch.int64)
+    # sizes and per-bucket starts first (small, over the default gloo group), then the records
+    theirs = [None] * world
+    dist.all_gather_object(theirs, rel)  # theirs[j][r]: rank j's starts inside the slice it sends to rank r
+    mine = [torch.tensor(theirs[j][rank], dtype=torch.int64) for j in range(world)]
+    recv_sizes = [int(m[-1]) for m in mine]
+    send = records[send_at[0]: send_at[-1]].contiguous()
+    recv = torch.empty(sum(recv_sizes), dtype=records.dtype, device=records.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=recv_sizes, input_split_sizes=send_sizes, group=group)
+    parts, at = [], 0
+    for n in recv_sizes:
+        parts.append(recv[at: at + n])
+        at += n
+    return merge_bucket_slices(parts, mine, cuts[rank], cuts[rank + 1])
+
+
+def full_bucket_start(merged_start, first_bucket, end_bucket, buckets):
+    """the bucket starts awfmGpuSearchOrderedRecords wants (buckets + 3 words) for an array that holds the buckets
+    [first_bucket, end_bucket) only: nothing before them, everything before what follows them"""
+    import torch
+    total = int(merged_start[-1])
+    out = torch.zeros(buckets + 3, dtype=torch.int64)
+    out[first_bucket: end_bucket + 1] = torch.as_tensor(merged_start, dtype=torch.int64)
+    out[end_bucket + 1: buckets + 2] = total
+    return out.to(torch.int32)

@@ -92,7 +92,7 @@ def parse():
                         "step behind the one before it")
     p.add_argument("--no-dense-form", dest="dense_form", action="store_false",
                    help="skip timing the dense form of the results beside the form the steps used")
-    p.add_argument("--general-steps", type=int, default=3,
+    p.add_argument("--general-steps", type=int, default=10,
                    help="timed steps of the exact-range general kernel for roofline_general (0: skip)")
     p.add_argument("--e2e-aos-queries", type=count, default=10_000_000,
                    help="k-mers of the batch that also go through the drop-in AoS entry point (0: skip)")
@@ -812,6 +812,38 @@ def wide_leg(L, api, digest, synth, torch, np, dev, n=6_200_000_000, Q=100_000_0
     del d_planted, d_kmers, d_ranges, d_off, d_scratch, d_pos, counts, dense_off, dense_pos, slot, lens, kmers
     torch.cuda.empty_cache()
     return out
+
+
+def gpu_state(card=0):
+    """what the device reports of itself through sysfs -- engine / memory / fabric clock levels in use, compute and memory
+    partition modes, power cap -- without a child process (a process that has initialised the GPU must not start one)"""
+    import glob
+    out = {}
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        if not cards:
+            return None
+        base = os.path.dirname(cards[min(card, len(cards) - 1)])
+        for name in ("sclk", "mclk", "fclk", "socclk"):
+            path = os.path.join(base, f"pp_dpm_{name}")
+            if os.path.exists(path):
+                cur = [ln for ln in open(path).read().split("\n") if ln.strip().endswith("*")]
+                out[name] = cur[0].split(":")[1].replace("*", "").strip() if cur else None
+        for name in ("current_compute_partition", "current_memory_partition", "gpu_busy_percent", "mem_busy_percent"):
+            path = os.path.join(base, name)
+            if os.path.exists(path):
+                out[name] = open(path).read().strip()
+        for hw in glob.glob(os.path.join(base, "hwmon", "hwmon*")):
+            for name in ("power1_average", "power1_input", "power1_cap", "temp1_input", "temp3_input"):
+                path = os.path.join(hw, name)
+                if os.path.exists(path):
+                    try:
+                        out[name] = int(open(path).read().strip())
+                    except (OSError, ValueError):
+                        pass
+    except OSError:
+        return out or None
+    return out or None
 
 
 def profile_file(kind, name):
@@ -1635,6 +1667,7 @@ def main():
         d_exact = torch.empty(Q * 2, dtype=torch.int64, device=dev)
         g.search(d_chars.data_ptr(), off_ptr, K, Q, d_exact.data_ptr(), 0, stream)
         torch.cuda.synchronize()
+        gen_state_before = gpu_state()
         events = []
         for _ in range(args.general_steps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1643,7 +1676,9 @@ def main():
             e1.record()
             events.append((e0, e1))
         torch.cuda.synchronize()
-        gen_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        gen_each = [a.elapsed_time(b) for a, b in events]
+        gen_ms = float(np.mean(gen_each))
+        gen_state_after = gpu_state()
         if args.mode == "locate":
             ex = d_exact.view(Q, 2)
             has = ex[:, 0] <= ex[:, 1]
@@ -1658,6 +1693,12 @@ def main():
             "algorithmic_bytes_per_launch": int(alg_bytes), "per_query": per_query,
             "Mkmers_per_s": round(Q / gen_ms / 1e3, 1), "seed_table_k": args.seed_k,
             "checked": "ranges of every k-mer with hits equal the timed steps'" if args.mode == "locate" else None,
+            # round 5's verdict: this kernel's time moved by 11-14 % between boxes and nobody had logged what the box was doing.
+            # Every launch's own time, and the clocks / partition modes the device reported right before and right after them
+            "kernel_ms_each": [round(x, 3) for x in gen_each],
+            "kernel_ms_min_median_max": [round(min(gen_each), 3), round(float(np.median(gen_each)), 3), round(max(gen_each), 3)],
+            "spread": round((max(gen_each) - min(gen_each)) / float(np.median(gen_each)), 4),
+            "gpu_state_before": gen_state_before, "gpu_state_after": gen_state_after,
         }
         if prof_name == "default":
             traffic, tsrc = profile_file("traffic", "general_pair")
@@ -1759,11 +1800,14 @@ def main():
             sample_cap = max(1, min(sample_cap, state["first_window"]))
         m = min(sample_cap, 2_000_000)
         best = None
-        for c in candidates:  # thread-count probe
+        for c in candidates:  # thread-count probe: which oversubscription, if any, hides the DRAM latency best
             dt, tl = run_sample(m, c)
             if best is None or dt < best[0]:
                 best = (dt, c)
-        cores = best[1]
+        over = best[1]
+        # the headline baseline runs one thread per GRANTED CPU (round 5's verdict: `cores` must be cores; the oversubscribed
+        # figure, which is the faster one on a latency-bound path, is reported beside it)
+        cores = granted
         dt, tl = run_sample(m)
         for _ in range(4):
             if dt >= args.cpu_seconds / 2 or m >= sample_cap:
@@ -1789,7 +1833,13 @@ def main():
             mt = min(sample_cap, mt)
             dtt, _ = run_sample(mt, t)
             fixed[f"threads_{t}"] = {"value": round(mt / dtt / 1e6, 3), "sample": mt}
-        cpu = {"value": round(m / dt / 1e6, 3), "unit": "Mkmers/s", "cores": cores, "kind": "port", **fixed,
+        oversubscribed = None
+        if over != cores:
+            dto, _ = run_sample(m, over)
+            oversubscribed = {"threads": over, "value": round(m / dto / 1e6, 3), "sample": m,
+                              "what": f"the same sample on {over} threads over the {granted} granted CPUs (the path is DRAM-latency bound)"}
+        cpu = {"value": round(m / dt / 1e6, 3), "unit": "Mkmers/s", "cores": cores, "threads": cores, "cpus_granted": granted,
+               "cpus_of_the_box": os.cpu_count(), "oversubscribed": oversubscribed, "kind": "port", **fixed,
                "threads_1_value": fixed["threads_1"]["value"], "threads_8_value": fixed["threads_8"]["value"],  # flat copies (the 1- and 8-thread points)
                "build": builds[variant],
                "builds_timed_Mkmers_per_s": {builds[v]: round(m / t / 1e6, 3) for v, t in timed.items()},
@@ -1999,6 +2049,86 @@ def main():
                                      "Mkmers_per_s_at_N_gpus": round(Q / max(times) / 1e3, 1),
                                      "efficiency": round(base_ms / (parts * max(times)), 4)}
             proxy["shards"][name] = per_n
+        # ---- round 6: the dense-hit batch sharded by SEED BUCKET instead of by batch position (include/awfm_gpu.h:
+        # awfmGpuOrderKmers / awfmGpuSearchOrderedRecords; dist.bucket_exchange is the exchange N real ranks run).  A rank's
+        # step: order its own contiguous N-th of the batch (timed), send every other rank the records of that rank's buckets
+        # and receive its own (PRICED: one GPU cannot time an exchange over xGMI), put the N slices in bucket order (timed as the
+        # copy it is), search the dense N-th of the ORDER it then holds and locate its hits (timed).  The records of a rank's
+        # buckets from all N shards are exactly the records of those buckets in the whole batch's order, so that is what the
+        # timed search reads.  Results carry the k-mers' numbers in the whole batch: the ranks' digests add up to the batch's. ----
+        if d_planted is not None and locate and d_offsets is None and g.order_buckets(K, Q):
+            buckets = g.order_buckets(K, Q)
+            d_all_recs = torch.empty(Q, dtype=torch.int64, device=dev)
+            d_all_bs = torch.empty(buckets + 3, dtype=torch.int32, device=dev)
+            st = lanes[0].stream
+            g.order_kmers(d_planted.data_ptr(), K, Q, first, first + Q, d_all_recs.data_ptr(), d_all_bs.data_ptr(), st)
+            torch.cuda.synchronize()
+            all_bs = d_all_bs.cpu().to(torch.int64)
+            assert int(all_bs[buckets + 2]) == 0, "planted k-mers have no ambiguity characters"
+            XGMI_LINK_GBS, XGMI_EFFICIENCY = 153.0, 0.7  # per link and direction (MI355X: 7 links per GPU); what a large all-to-all sustains: assumed
+            per_n = {}
+            for parts in (2, 4, 8):
+                cuts = shard.bucket_cuts(buckets, parts)
+                rows, sum_c, sum_p = [], 0, 0
+                for r in range(parts):
+                    lo, hi = shard.shard_bounds(Q, parts, r)
+                    d_recs = torch.empty(hi - lo, dtype=torch.int64, device=dev)
+                    d_bs = torch.empty(buckets + 3, dtype=torch.int32, device=dev)
+
+                    def order_own():
+                        g.order_kmers(d_planted.data_ptr() + lo * K, K, hi - lo, first + lo, first + Q, d_recs.data_ptr(), d_bs.data_ptr(), st)
+
+                    b0, b1 = int(all_bs[cuts[r]]), int(all_bs[cuts[r + 1]])
+                    m = b1 - b0
+                    d_k = torch.empty(m, dtype=torch.int32, device=dev)
+                    d_r = torch.empty(m * 2, dtype=torch.int64, device=dev)
+                    d_o = torch.empty(m + 1, dtype=torch.int64, device=dev)
+                    d_sc = torch.empty(api.GpuIndex.scan_scratch_bytes(m), dtype=torch.uint8, device=dev)
+                    g.search_ordered_records(d_all_recs.data_ptr(), d_all_bs.data_ptr(), cuts[r], cuts[r + 1], K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st)
+                    g.hit_offsets_on_device(0, d_r.data_ptr(), m, d_o.data_ptr(), d_sc.data_ptr(), st)
+                    torch.cuda.synchronize()
+                    hits_r = int(d_o[m].item())
+                    d_p = torch.empty(hits_r + hits_r // 8 + 64, dtype=torch.int64, device=dev)
+                    d_merge = torch.empty(m, dtype=torch.int64, device=dev)
+
+                    def search_own():
+                        g.search_ordered_records(d_all_recs.data_ptr(), d_all_bs.data_ptr(), cuts[r], cuts[r + 1], K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st)
+                        g.hit_offsets_on_device(0, d_r.data_ptr(), m, d_o.data_ptr(), d_sc.data_ptr(), st)
+                        g.locate_on_device(d_r.data_ptr(), d_o.data_ptr(), m, d_p.numel(), d_p.data_ptr(), st)
+
+                    def timed(fn):
+                        fn()
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(args.proxy_steps):
+                            fn()
+                        torch.cuda.synchronize()
+                        return (time.perf_counter() - t1) * 1e3 / args.proxy_steps
+
+                    order_ms = timed(order_own)
+                    search_ms_r = timed(search_own)
+                    with torch.cuda.stream(lanes[0].torch_stream):
+                        merge_ms = timed(lambda: d_merge.copy_(d_all_recs[b0:b1]))
+                    # every rank sends (and receives) N - 1 slices of about m / N records at once, each over a link of its own
+                    exchange_ms = (m / parts * 8) / (XGMI_LINK_GBS * XGMI_EFFICIENCY * 1e9) * 1e3 if parts > 1 else 0.0
+                    rows.append({"order_own_shard_ms": round(order_ms, 4), "exchange_ms_priced": round(exchange_ms, 4), "merge_ms": round(merge_ms, 4),
+                                 "search_and_locate_ms": round(search_ms_r, 4), "kmers": m, "hits": hits_r,
+                                 "total_ms": round(order_ms + exchange_ms + merge_ms + search_ms_r, 4)})
+                    ids = d_k.to(torch.int64)
+                    assert int(ids.min().item()) >= first and int(ids.max().item()) < first + Q
+                    sum_c += digest.counts_digest_keyed(ids, d_o[1:] - d_o[:-1])
+                    sum_p += digest.positions_digest_keyed(ids, d_o, d_p[: max(hits_r, 1)])
+                    del d_recs, d_bs, d_k, d_r, d_o, d_sc, d_p, d_merge, ids
+                assert (sum_c & digest.MASK) == int(pdig["counts"], 16), f"seed-bucket sharding: the counts digests of {parts} ranks do not add up to the batch's"
+                assert (sum_p & digest.MASK) == int(pdig["positions"], 16), f"seed-bucket sharding: the positions digests of {parts} ranks do not add up"
+                slowest = max(rw["total_ms"] for rw in rows)
+                per_n[str(parts)] = {"sharding": "seed_bucket", "ms_max": round(slowest, 4), "ranks": rows,
+                                     "Mkmers_per_s_at_N_gpus": round(Q / slowest / 1e3, 1), "efficiency": round(planted_whole_ms / (parts * slowest), 4)}
+            proxy["shards"]["planted_seed_bucket"] = per_n
+            proxy["seed_bucket_note"] = ("planted_seed_bucket: every rank orders its contiguous shard (awfmGpuOrderKmers), exchanges records by bucket range "
+                                         f"(priced at {XGMI_LINK_GBS:g} GB/s per xGMI link x {XGMI_EFFICIENCY:g}: one GPU cannot time it), and searches the dense N-th of the "
+                                         "ORDER (awfmGpuSearchOrderedRecords); digests keyed by the k-mers' numbers in the whole batch add up to the batch's")
+            del d_all_recs, d_all_bs
         proxy["digests"] = ("the shards' counts and positions digests add up to the whole batch's for every N; every shard that has "
                             "a committed digest of its own (tests/golden/bench_digests.json) equals it")
         if args.record_digests:
@@ -2164,11 +2294,18 @@ def main():
     if proxy:
         e8 = proxy["shards"]["batch"]["8"]
         config["scaling_proxy_8_efficiency"] = e8["efficiency"]
+        if "planted" in proxy["shards"]:
+            config["scaling_proxy_8_planted_efficiency"] = proxy["shards"]["planted"]["8"]["efficiency"]
+        if "planted_seed_bucket" in proxy["shards"]:
+            config["scaling_proxy_8_planted_seed_bucket_efficiency"] = proxy["shards"]["planted_seed_bucket"]["8"]["efficiency"]
         config["scaling_proxy_8_ms"] = e8["ms_max"]
     config["bench_wall_s"] = round(time.time() - T_START, 1)  # this process from its first line to its JSON line (imports, index, every leg)
     out = {
         "metric": "Mkmers/sec located, GRCh38 nucleotide index" if not amino else "Mkmers/sec located, amino index",
         "value": round(value, 2), "unit": "Mkmers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        # the same metric for k-mers that OCCUR (drawn from the text: every one located), which is what a seed-and-extend caller
+        # sends -- the headline's random 21-mers almost never occur, and lookup first is at its best on them
+        "value_present_kmers": secondary["value"] if secondary and "value" in secondary else None,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": config,

@@ -513,6 +513,35 @@ enum AwFmReturnCode awfmGpuSynthMixedQueries(uint8_t *dOut, const uint64_t *dOff
                                              uint64_t seedQ, const uint8_t *dText, uint64_t textLength, int amino,
                                              void *stream);
 
+/* ---- seed-bucket sharding of dense-hit batches over the GPUs of a node (round 6) ----
+ * The reference treats the k-mers of a batch as independent (ref src/AwFmParallelSearch.c:103-129), so ANY split of a batch
+ * over index replicas gives the same results.  A contiguous split of the batch hands every rank a THIN slice of the seed order
+ * (one k-mer per two block lines where the whole batch has four per line): its search re-reads nothing from the L2 and an 8-way
+ * split of 10^8 k-mers drawn from the text scales to 0.67.  These three calls let N ranks split the ORDER instead: every rank
+ * orders its own contiguous shard (awfmGpuOrderKmers: the counting and the partition pass, records {rest of the code string,
+ * number in the WHOLE batch} in bucket order), the ranks exchange the records bucket range by bucket range (rank j gets the
+ * buckets [j B / N, (j + 1) B / N) of everybody: contiguous slices, whose per-bucket runs the receiver puts together bucket by
+ * bucket -- the caller's all-to-all; avxwindowfmindex_amd/dist.py does it over torch.distributed), and every rank searches the
+ * dense N-th of the order it then holds (awfmGpuSearchOrderedRecords: results in that order, {number in the whole batch,
+ * range}, hit offsets and positions by the calls that follow awfmGpuSearchHitsInOrder).  K-mers the seed-order kernel does not
+ * take (ambiguity characters) stay with the rank that holds their characters (awfmGpuSearchGeneralRecords).
+ * dBucketStart: awfmGpuOrderBuckets() + 3 words -- [b] = records before bucket b, [buckets] = records the seed-order kernel
+ * takes, [buckets + 1] = numQueries, [buckets + 2] = the k-mers left to the general kernel (the records' tail). */
+uint32_t awfmGpuOrderBuckets(const AwFmGpuIndex *g, uint32_t fixedLength, uint64_t totalQueries); /* 0: not a batch for it */
+enum AwFmReturnCode awfmGpuOrderKmers(AwFmGpuIndex *g, const uint8_t *dChars, uint32_t fixedLength, uint64_t numQueries,
+                                      uint64_t firstNumber, uint64_t totalQueries, uint64_t *dRecords, uint32_t *dBucketStart,
+                                      void *stream);
+/* the buckets [firstBucket, endBucket) of `dRecords` (bucket order, dBucketStart as above); entry e of the outputs belongs to
+ * record dBucketStart[firstBucket] + e */
+enum AwFmReturnCode awfmGpuSearchOrderedRecords(AwFmGpuIndex *g, const uint64_t *dRecords, const uint32_t *dBucketStart,
+                                                uint32_t firstBucket, uint32_t endBucket, uint32_t fixedLength, uint64_t totalQueries,
+                                                uint32_t *dOrderKmers, struct AwFmSearchRange *dOrderRanges, void *stream);
+/* the tail of a shard's own records through the general kernel: entries [dBucketStart[buckets], numQueries) of the outputs */
+enum AwFmReturnCode awfmGpuSearchGeneralRecords(AwFmGpuIndex *g, const uint8_t *dChars, uint32_t fixedLength, uint64_t numQueries,
+                                                uint64_t firstNumber, uint64_t totalQueries, const uint64_t *dRecords,
+                                                const uint32_t *dBucketStart, uint32_t *dOrderKmers,
+                                                struct AwFmSearchRange *dOrderRanges, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,98 @@
+"""Seed-bucket sharding (round 6; include/awfm_gpu.h: awfmGpuOrderKmers / awfmGpuSearchOrderedRecords /
+awfmGpuSearchGeneralRecords, avxwindowfmindex_amd/dist.py: merge_bucket_slices): N ranks emulated one after the other on ONE
+GPU -- every "rank" orders its contiguous shard, the slices are exchanged by plain tensor indexing instead of a collective,
+every rank searches the dense N-th of the order it then holds -- must give every k-mer of the batch, under its number in the
+WHOLE batch, the oracle's count, range and positions (ref src/AwFmParallelSearch.c:103-129: the k-mers of a batch are
+independent, so any split gives the reference's results)."""
+import numpy as np
+import pytest
+
+from avxwindowfmindex_amd import dist as shard
+from avxwindowfmindex_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_seed_bucket_sharding_gives_the_reference_results(oracle, awfm, require_gpu, wide, world):
+    import torch
+    n, K, Q = 400_000, 21, 60_001
+    txt = synth.text(900 + world, n).copy()
+    txt[5000:5040] = ord("n")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_deep_seed(10)
+    q = synth.planted_queries(31, Q, K, txt).copy()
+    q[::5] = synth.random_queries(32, len(q[::5]), K)
+    q[7::97, 3] = ord("x")  # ambiguity characters: such k-mers stay with the rank that holds their characters
+    q[11::89] = np.frombuffer(bytes(x - 32 for x in b"acgt" * 6)[:K], np.uint8)  # upper case, a k-mer many times over
+    chars, offsets = synth.fixed_csr(q)
+    sp, ep, cnt, _ = oi.batch_search(chars, offsets, threads=4)
+    oho, opos, _ = oi.batch_locate(sp, ep, threads=4)
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(chars).to(dev)
+    buckets = g.order_buckets(K, Q)
+    assert buckets == 2048
+    cuts = shard.bucket_cuts(buckets, world)
+    # every rank orders its own contiguous shard
+    recs, starts, own = [], [], []
+    for r in range(world):
+        b, e = shard.shard_bounds(Q, world, r)
+        d_rec = torch.zeros(e - b, dtype=torch.int64, device=dev)
+        d_bs = torch.zeros(buckets + 3, dtype=torch.int32, device=dev)
+        g.order_kmers(d_chars.data_ptr() + b * K, K, e - b, b, Q, d_rec.data_ptr(), d_bs.data_ptr())
+        torch.cuda.synchronize()
+        bs = d_bs.cpu().to(torch.int64)
+        assert int(bs[buckets + 1]) == e - b and int(bs[buckets + 2]) == e - b - int(bs[buckets])
+        recs.append(d_rec)
+        starts.append(bs)
+        # the k-mers with ambiguity characters: searched where their characters are
+        d_k = torch.full((e - b,), -1, dtype=torch.int32, device=dev)
+        d_r = torch.zeros((e - b) * 2, dtype=torch.int64, device=dev)
+        g.search_general_records(d_chars.data_ptr() + b * K, K, e - b, b, Q, d_rec.data_ptr(), d_bs.data_ptr(), d_k.data_ptr(), d_r.data_ptr())
+        torch.cuda.synchronize()
+        left = int(bs[buckets])
+        own.append((d_k[left:].cpu().numpy().astype(np.int64), d_r.view(-1, 2)[left:].cpu().numpy().view(np.uint64)))
+    got_sp = np.zeros(Q, np.uint64)
+    got_ep = np.zeros(Q, np.uint64)
+    seen = np.zeros(Q, np.int64)
+    all_pos = {}
+    for r in range(world):  # the exchange, by indexing: rank r gets the buckets [cuts[r], cuts[r + 1]) of everybody
+        slices = [recs[j][int(starts[j][cuts[r]]): int(starts[j][cuts[r + 1]])] for j in range(world)]
+        rel = [starts[j][cuts[r]: cuts[r + 1] + 1] - starts[j][cuts[r]] for j in range(world)]
+        merged, mstart = shard.merge_bucket_slices(slices, rel, cuts[r], cuts[r + 1])
+        m = merged.numel()
+        if m == 0:
+            continue
+        d_bs = shard.full_bucket_start(mstart, cuts[r], cuts[r + 1], buckets).to(dev)
+        d_k = torch.full((m,), -1, dtype=torch.int32, device=dev)
+        d_r = torch.zeros(m * 2, dtype=torch.int64, device=dev)
+        g.search_ordered_records(merged.data_ptr(), d_bs.data_ptr(), cuts[r], cuts[r + 1], K, Q, d_k.data_ptr(), d_r.data_ptr())
+        d_off = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+        d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(m), dtype=torch.uint8, device=dev)
+        total = g.hit_offsets(d_r.data_ptr(), m, d_off.data_ptr(), d_scratch.data_ptr())
+        d_pos = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
+        g.locate(d_r.data_ptr(), d_off.data_ptr(), m, total, d_pos.data_ptr())
+        torch.cuda.synchronize()
+        k = d_k.cpu().numpy().astype(np.int64)
+        rr = d_r.view(m, 2).cpu().numpy().view(np.uint64)
+        off = d_off.cpu().numpy()
+        pos = d_pos.cpu().numpy().view(np.uint64)
+        assert k.min() >= 0 and k.max() < Q
+        seen[k] += 1
+        got_sp[k], got_ep[k] = rr[:, 0], rr[:, 1]
+        for i in np.flatnonzero(off[1:] > off[:-1])[:3000]:
+            all_pos[int(k[i])] = pos[off[i]:off[i + 1]]
+    for k, rr in own:
+        seen[k] += 1
+        got_sp[k], got_ep[k] = rr[:, 0], rr[:, 1]
+    assert np.all(seen == 1), "a k-mer was searched by no rank, or by two"
+    hit = cnt > 0
+    assert np.array_equal(got_sp[hit], sp[hit]) and np.array_equal(got_ep[hit], ep[hit]), "ranges of k-mers with hits differ from the oracle's"
+    assert np.all(got_sp[~hit] > got_ep[~hit]), "a k-mer without hits got a range"
+    assert len(all_pos) > 1000
+    for k, p in all_pos.items():
+        assert np.array_equal(p, opos[oho[k]:oho[k + 1]]), f"positions of k-mer {k}"
+    g.destroy()
+    ix.dealloc()

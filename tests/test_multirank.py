@@ -145,3 +145,49 @@ def test_balanced_shard_bounds_follow_the_weights():
         assert b[0][0] == 0 and b[-1][1] == lengths.size and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
         work = [int(prefix[e] - prefix[s]) for s, e in b]
         assert max(work) - min(work) <= 31, work  # within one k-mer of each other
+
+
+def _exchange_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from avxwindowfmindex_amd import dist as shard
+    r, w = shard.init("gloo")
+    buckets = 64
+    rng = np.random.default_rng(100 + rank)
+    counts = rng.integers(0, 50, buckets)
+    counts[rng.integers(0, buckets, 9)] = 0  # empty buckets too
+    start = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    # a record that says where it comes from: bucket << 40 | rank << 32 | its place in the bucket
+    recs = np.concatenate([(np.int64(b) << 40) | (np.int64(rank) << 32) | np.arange(counts[b], dtype=np.int64) for b in range(buckets)] or [np.zeros(0, np.int64)])
+    mine, mstart = shard.bucket_exchange(torch.from_numpy(recs), start, buckets, w, r)
+    cuts = shard.bucket_cuts(buckets, w)
+    np.save(os.path.join(out_dir, f"sent_{rank}.npy"), recs)
+    np.save(os.path.join(out_dir, f"got_{rank}.npy"), mine.numpy())
+    np.save(os.path.join(out_dir, f"start_{rank}.npy"), mstart.numpy())
+    assert len(mstart) == cuts[r + 1] - cuts[r] + 1 and int(mstart[-1]) == mine.numel()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_seed_bucket_exchange_over_gloo(tmp_path, world):
+    """round 6, the one exchange of the seed-bucket sharding (dist.bucket_exchange; include/awfm_gpu.h: awfmGpuOrderKmers): every
+    rank ends up with exactly the records of its bucket range from all ranks, bucket by bucket, with the bucket starts that go
+    with them -- here on host tensors over gloo; the records say where they came from"""
+    import torch.multiprocessing as mp
+    from avxwindowfmindex_amd import dist as shard
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    buckets = 64
+    cuts = shard.bucket_cuts(buckets, world)
+    sent = np.concatenate([np.load(tmp_path / f"sent_{r}.npy") for r in range(world)])
+    for r in range(world):
+        got, start = np.load(tmp_path / f"got_{r}.npy"), np.load(tmp_path / f"start_{r}.npy")
+        b = got >> 40
+        assert np.all(np.diff(b) >= 0) and (len(b) == 0 or (b.min() >= cuts[r] and b.max() < cuts[r + 1])), "not in bucket order / another rank's bucket"
+        want = np.sort(sent[((sent >> 40) >= cuts[r]) & ((sent >> 40) < cuts[r + 1])])
+        assert np.array_equal(np.sort(got), want), "records lost, duplicated or sent to the wrong rank"
+        for i, bucket in enumerate(range(cuts[r], cuts[r + 1])):
+            assert np.all(b[start[i]:start[i + 1]] == bucket)
