@@ -30,6 +30,11 @@ def timing_backend():
     return _TIMING_BACKEND
 
 
+def timing_group():
+    """the process group device tensors travel on (the RCCL group when it could be set up; None: the default gloo group)"""
+    return _TIMING_GROUP
+
+
 def init(backend):
     """initialise torch.distributed when launched with WORLD_SIZE > 1; returns (rank, world).
 

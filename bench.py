@@ -64,6 +64,10 @@ def parse():
                    help="strong (default; configs[2]: ONE batch of --queries k-mers, sharded over the --gpus ranks) | "
                         "weak: --queries k-mers per GPU")
     count = lambda v: int(float(v))  # noqa: E731  ("3e6" is accepted)
+    p.add_argument("--sharding", choices=["contiguous", "seed_bucket"], default="contiguous",
+                   help="how a batch is cut over the ranks: contiguous stretches of the batch (no exchange; the default), or -- dense-hit "
+                        "fixed-length nucleotide batches, locate -- by seed bucket: every rank orders its stretch, the ranks exchange the records "
+                        "bucket range by bucket range (one all-to-all), every rank searches a dense N-th of the ORDER (round 6)")
     p.add_argument("--text-len", type=count, default=None, help="default 3.1e9 (dna) / 2e8 (amino)")
     p.add_argument("--queries", type=count, default=None, help="k-mers per GPU per step (strong: in total); default 1e8 (dna) / 5e7 (amino)")
     p.add_argument("--query-offset", type=count, default=0,
@@ -851,6 +855,123 @@ def profile_file(kind, name):
     return (json.load(open(path)), f"profiles/{PROFILE_ROUND}/{kind}_{name}.json") if os.path.exists(path) else (None, None)
 
 
+def seed_bucket_run(args, L, api, digest, shard, torch, np, dev, g, ix, d_chars, Q, first, batch_total, K, n, rank, world, build_s):
+    """--sharding seed_bucket: the timed step of a rank is  order my contiguous stretch (awfmGpuOrderKmers)  ->  one all-to-all of
+    the records by bucket range (dist.bucket_exchange: RCCL over xGMI under the nccl backend; through host memory under gloo, the
+    tests' way)  ->  search the dense N-th of the order I then hold, in search order (awfmGpuSearchOrderedRecords)  ->  hit offsets
+    ->  positions; the k-mers with ambiguity characters stay with the rank that holds their characters
+    (awfmGpuSearchGeneralRecords).  One host wait per step: the slice sizes of the exchange.  Results carry the k-mers' numbers in
+    the WHOLE batch; the ranks' keyed digests add up to the digest of the batch however it was cut."""
+    import torch.distributed as dist
+    buckets = g.order_buckets(K, batch_total)
+    assert buckets, "--sharding seed_bucket: fixed-length nucleotide batches whose 8-byte records fit"
+    cuts = shard.bucket_cuts(buckets, world)
+    via_host = world > 1 and shard.timing_backend() != "nccl"
+    stream_obj = torch.cuda.Stream()
+    st = stream_obj.cuda_stream
+    d_recs = torch.empty(Q, dtype=torch.int64, device=dev)
+    d_bs = torch.empty(buckets + 3, dtype=torch.int32, device=dev)
+    d_gk = torch.empty(Q, dtype=torch.int32, device=dev)  # my own stretch's order: its tail are the general kernel's k-mers
+    d_gr = torch.empty(Q * 2, dtype=torch.int64, device=dev)
+    state = {}
+
+    def step():
+        g.order_kmers(d_chars.data_ptr(), K, Q, first, args.query_offset + batch_total, d_recs.data_ptr(), d_bs.data_ptr(), st)
+        g.search_general_records(d_chars.data_ptr(), K, Q, first, args.query_offset + batch_total, d_recs.data_ptr(), d_bs.data_ptr(), d_gk.data_ptr(),
+                                 d_gr.data_ptr(), st)
+        stream_obj.synchronize()
+        bs = d_bs.cpu().to(torch.int64)
+        with torch.cuda.stream(stream_obj):
+            if via_host:
+                mine, mstart = shard.bucket_exchange(d_recs.cpu(), bs[: buckets + 1], buckets, world, rank)
+                mine = mine.to(dev)
+            else:
+                mine, mstart = shard.bucket_exchange(d_recs, bs[: buckets + 1], buckets, world, rank, group=shard.timing_group())
+            m = mine.numel()
+            full = shard.full_bucket_start(mstart, cuts[rank], cuts[rank + 1], buckets).to(dev)
+            if state.get("m") != m:
+                state.update(m=m, k=torch.empty(max(m, 1), dtype=torch.int32, device=dev), r=torch.empty(max(m, 1) * 2, dtype=torch.int64, device=dev),
+                             o=torch.zeros(max(m, 1) + 1, dtype=torch.int64, device=dev),
+                             sc=torch.empty(api.GpuIndex.scan_scratch_bytes(max(m, 1)), dtype=torch.uint8, device=dev), p=None)
+        stream_obj.synchronize()
+        if m:
+            g.search_ordered_records(mine.data_ptr(), full.data_ptr(), cuts[rank], cuts[rank + 1], K, args.query_offset + batch_total,
+                                     state["k"].data_ptr(), state["r"].data_ptr(), st)
+            g.hit_offsets_on_device(0, state["r"].data_ptr(), m, state["o"].data_ptr(), state["sc"].data_ptr(), st)
+            if state["p"] is None:
+                stream_obj.synchronize()
+                hits = int(state["o"][m].item())
+                state["p"] = torch.empty(hits + hits // 8 + 64, dtype=torch.int64, device=dev)
+            g.locate_on_device(state["r"].data_ptr(), state["o"].data_ptr(), m, state["p"].numel(), state["p"].data_ptr(), st)
+        state["left"] = int(bs[buckets])  # entries [left, Q) of d_gk / d_gr: my general k-mers
+        state["keep"] = (mine, full)
+
+    def barrier():
+        shard.barrier(world, torch.cuda.synchronize)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = shard.max_over_ranks((time.perf_counter() - t0) / args.steps, world, dev)
+    # digests keyed by the k-mers' numbers in the whole batch: my share of the order + my own general k-mers
+    m, left = state["m"], state["left"]
+    dc = dp = 0
+    hits = 0
+    if m:
+        ids = state["k"][:m].to(torch.int64)
+        lens = state["o"][1:m + 1] - state["o"][:m]
+        hits = int(state["o"][m].item())
+        dc += digest.counts_digest_keyed(ids, lens)
+        dp += digest.positions_digest_keyed(ids, state["o"][: m + 1], state["p"][: max(hits, 1)])
+    if left < Q:  # (located here too: ranges -> offsets -> positions over the tail)
+        gm = Q - left
+        gr = d_gr[2 * left:].contiguous()
+        go = torch.zeros(gm + 1, dtype=torch.int64, device=dev)
+        gsc = torch.empty(api.GpuIndex.scan_scratch_bytes(gm), dtype=torch.uint8, device=dev)
+        total = g.hit_offsets(gr.data_ptr(), gm, go.data_ptr(), gsc.data_ptr())
+        gp = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+        g.locate(gr.data_ptr(), go.data_ptr(), gm, total, gp.data_ptr())
+        torch.cuda.synchronize()
+        gids = d_gk[left:].to(torch.int64)
+        dc += digest.counts_digest_keyed(gids, go[1:] - go[:-1])
+        dp += digest.positions_digest_keyed(gids, go, gp)
+        hits += total
+    parts = shard.gather_objects((rank, m + (Q - left), hits, dc & digest.MASK, dp & digest.MASK), world)
+    if rank == 0:
+        total_c = sum(p[3] for p in parts) & digest.MASK
+        total_p = sum(p[4] for p in parts) & digest.MASK
+        assert sum(p[1] for p in parts) == batch_total, "the ranks' shares of the order do not add up to the batch"
+        key = digest.key(args.alphabet, args.workload, args.mode, n, str(K), args.seed_k, args.sa_ratio, args.query_offset, batch_total)
+        dig = {"counts": f"{total_c:016x}", "positions": f"{total_p:016x}"}
+        committed = digest.load_golden().get(key)
+        assert committed is None or committed == dig, f"seed-bucket sharding: digests {dig} differ from the committed {committed}"
+        if args.record_digests:
+            known = json.load(open(args.record_digests)) if os.path.exists(args.record_digests) else {}
+            known[key] = dig
+            json.dump(known, open(args.record_digests, "w"), indent=1, sort_keys=True)
+        out = {"metric": "Mkmers/sec located, GRCh38 nucleotide index", "value": round(batch_total / dt / 1e6, 2), "unit": "Mkmers/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+               "config": {"workload": f"{batch_total / 1e6:g} M {args.workload} {K}-mers in total, locate, {n / 1e9:g} Gbp uniform synthetic dna text, SA ratio {args.sa_ratio}, "
+                                      f"seed table k={args.seed_k}",
+                          "sharding": "seed_bucket", "parallelism": f"index replica per GPU; every rank orders its stretch of the batch, ONE all-to-all of the records by "
+                                                                    f"bucket range ({'through host memory over gloo' if via_host else 'RCCL' if world > 1 else 'one rank: no exchange'}), "
+                                                                    "every rank searches a dense N-th of the seed order",
+                          "batch_kmers": batch_total, "buckets": buckets, "index_build_s": round(build_s, 2), "timing_collective": shard.timing_backend() or "none (one rank)",
+                          "host_waits_per_step": 3},
+               "roofline": None, "cpu_baseline": None,
+               "digests": dict(dig, status="match" if committed else "unknown", shards=world,
+                               per_rank=[{"rank": p[0], "kmers": p[1], "hits": p[2]} for p in parts])}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -965,6 +1086,10 @@ def main():
         plant = L.awfmGpuSynthPlantedQueriesClean if args.text == "repetitive" else L.awfmGpuSynthPlantedQueries
         assert plant(d_chars.data_ptr(), first, Q, K, query_seed, d_text.data_ptr(), n, None) == 1
     torch.cuda.synchronize()
+    if args.sharding == "seed_bucket":
+        assert not amino and d_offsets is None and args.mode == "locate" and args.scaling == "strong", \
+            "--sharding seed_bucket: fixed-length nucleotide batches, located, one batch cut over the ranks"
+        return seed_bucket_run(args, L, api, digest, shard, torch, np, dev, g, ix, d_chars, Q, first, batch_total, K, n, rank, world, build_s)
     off_ptr = d_offsets.data_ptr() if d_offsets is not None else 0
     # the default run also reports the dense-hit case (every k-mer located, ~7 LF steps per hit) beside the headline:
     # its k-mers are drawn from the text now, searched after everything else
@@ -1675,6 +1800,8 @@ def main():
             g.search(d_chars.data_ptr(), off_ptr, K, Q, d_exact.data_ptr(), 0, stream)
             e1.record()
             events.append((e0, e1))
+        time.sleep(0.03)  # (the launches are in flight: what the device reports of itself now is what it runs them at)
+        gen_state_during = gpu_state()
         torch.cuda.synchronize()
         gen_each = [a.elapsed_time(b) for a, b in events]
         gen_ms = float(np.mean(gen_each))
@@ -1698,7 +1825,7 @@ def main():
             "kernel_ms_each": [round(x, 3) for x in gen_each],
             "kernel_ms_min_median_max": [round(min(gen_each), 3), round(float(np.median(gen_each)), 3), round(max(gen_each), 3)],
             "spread": round((max(gen_each) - min(gen_each)) / float(np.median(gen_each)), 4),
-            "gpu_state_before": gen_state_before, "gpu_state_after": gen_state_after,
+            "gpu_state_before": gen_state_before, "gpu_state_during": gen_state_during, "gpu_state_after": gen_state_after,
         }
         if prof_name == "default":
             traffic, tsrc = profile_file("traffic", "general_pair")

@@ -122,6 +122,30 @@ def test_n_rank_digests_equal_the_one_rank_run(require_gpu, tmp_path, workload, 
 
 
 @pytest.mark.gpu
+def test_seed_bucket_sharding_digests_equal_the_contiguous_one_rank_run(require_gpu, tmp_path):
+    """round 6: --sharding seed_bucket -- every rank orders its stretch of the batch, the ranks exchange the records by bucket
+    range (here: two ranks on one GPU, the all-to-all through host memory over gloo), every rank searches a dense half of the
+    seed order.  The results carry the k-mers' numbers in the whole batch, so the two ranks' keyed digests must add up to the
+    digest the ordinary 1-rank run of the same batch recorded; and so must the 1-rank run of the new mode itself."""
+    golden = str(tmp_path / "digests.json")
+    common = ["--text-len", "3e6", "--queries", "1e6", "--kmer", "21", "--seed-k", "8", "--workload", "planted", "--mode", "locate",
+              "--no-cpu", "--no-e2e", "--no-secondary", "--general-steps", "0", "--steps", "1", "--warmup", "1", "--scaling", "strong"]
+    one = _line(_run_bench(common + ["--gpus", "1", "--record-digests", golden]))
+    os.environ["AWFM_BENCH_DIGESTS"] = golden
+    try:
+        two = _line(_run_bench(common + ["--gpus", "2", "--force-device", "0", "--dist-backend", "gloo", "--sharding", "seed_bucket"]))
+        alone = _line(_run_bench(common + ["--gpus", "1", "--sharding", "seed_bucket"]))
+    finally:
+        os.environ.pop("AWFM_BENCH_DIGESTS")
+    for line in (two, alone):
+        assert line["config"]["sharding"] == "seed_bucket" and line["digests"]["status"] == "match", line["digests"]
+        assert line["digests"]["counts"] == one["digests"]["counts"] and line["digests"]["positions"] == one["digests"]["positions"]
+    assert two["n_gpus"] == 2 and len(two["digests"]["per_rank"]) == 2
+    kmers = [p["kmers"] for p in two["digests"]["per_rank"]]
+    assert sum(kmers) == 1_000_000 and min(kmers) > 300_000  # two dense halves of the order, not two halves of the batch
+
+
+@pytest.mark.gpu
 def test_two_ranks_on_two_distinct_gpus_over_rccl(require_gpu, tmp_path):
     """--gpus 2 the way the driver runs it at N > 1: one rank per device, barrier and MAX reduction over RCCL"""
     from avxwindowfmindex_amd import _lib
