@@ -1037,6 +1037,65 @@ struct DeviceGuard {
   }
 };
 
+/* ---- shared by the translation units of the shim (awfm_gpu*.hip) ---- */
+/* The stream the image-construction code of the CALLING THREAD launches on: the null stream (everything an image is made of is
+ * then complete when the call that makes it returns), or -- the thread that builds an image's deeper table and full suffix
+ * array BEHIND the first searches (round 6: awfm_gpu_image.hip, awfmGpuIndexCreate) -- a non-blocking stream of its own, so
+ * that its kernels neither wait for the searches' streams nor make them wait. */
+extern thread_local hipStream_t awfmGpuSetupStream;
+inline hipError_t awfmGpuSetupSync() { return awfmGpuSetupStream ? hipStreamSynchronize(awfmGpuSetupStream) : hipDeviceSynchronize(); }
+inline hipError_t awfmGpuSetupMemset(void *p, int value, size_t bytes) { return hipMemsetAsync(p, value, bytes, awfmGpuSetupStream); }
+inline hipError_t awfmGpuSetupToHost(void *dst, const void *src, size_t bytes) {
+  const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, awfmGpuSetupStream);
+  return e != hipSuccess ? e : hipStreamSynchronize(awfmGpuSetupStream);
+}
+/* Persistent grid: the kernels stride over the work, so the grid is exactly what is resident (blocksPerCU from the occupancy
+ * query for that kernel); a larger grid would run as a second, under-filled round. */
+template <class Kernel>
+unsigned gridFor(uint64_t groups, const AwFmGpuIndex *g, Kernel kernel, unsigned groupsPerBlock, size_t dynamicLds = 0, int threads = kThreads) {
+  int perCU = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, threads, dynamicLds) != hipSuccess || perCU < 1) perCU = 4;
+  if (perCU > 8) perCU = 8;
+  const uint64_t blocks = (groups + groupsPerBlock - 1) / groupsPerBlock;
+  const uint64_t cap = (uint64_t)g->numCUs * (uint64_t)perCU;
+  return (unsigned)(blocks < cap ? (blocks ? blocks : 1) : cap);
+}
+inline size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+/* the image's full suffix array as a kernel argument */
+inline DenseSa denseSaOf(const AwFmGpuIndex *g) {
+  DenseSa sa;
+  sa.words = (const unsigned *)g->dDenseSa;
+  sa.wide = g->denseWide ? 1u : 0u;
+  return sa;
+}
+/* awfm_gpu_image.hip: the image's grow-only work buffer (the caller holds workMutex); lanes that cooperate on one k-mer in the
+ * general kernel and the walk; the lanes of a primary image */
+enum AwFmReturnCode awfmGpuEnsureWork(AwFmGpuIndex *g, size_t bytes);
+int awfmGpuLanesPerQuery(const AwFmGpuIndex *g);
+std::vector<AwFmGpuIndex *> awfmGpuLanesOf(const AwFmGpuIndex *primary);
+/* holds the work and AoS locks of every lane of a primary image for the lifetime of the object */
+struct AwFmGpuLaneLocks {
+  std::vector<AwFmGpuIndex *> lanes;
+  explicit AwFmGpuLaneLocks(const AwFmGpuIndex *primary) : lanes(awfmGpuLanesOf(primary)) {
+    for (AwFmGpuIndex *lane : lanes) {
+      lane->aosMutex.lock();
+      lane->workMutex.lock();
+    }
+  }
+  ~AwFmGpuLaneLocks() {
+    for (AwFmGpuIndex *lane : lanes) {
+      lane->workMutex.unlock();
+      lane->aosMutex.unlock();
+    }
+  }
+};
+/* awfm_gpu_locate.hip: LF-walk + sampled-SA kernels over `totalHits` BWT positions stored in dPositions (in place, or to `out`);
+ * stepCap != 0: the construction of the full suffix array (walks given up after so many steps are parked) */
+enum AwFmReturnCode awfmGpuLaunchLocate(AwFmGpuIndex *g, unsigned long long totalHits, unsigned long long *dPositions, hipStream_t s,
+                                        unsigned long long *out = nullptr, const unsigned long long *totalOnDevice = nullptr, unsigned stepCap = 0u);
+/* awfm_gpu_dense_sa.hip: the full suffix array of an image that was just created or adopted ($AWFM_GPU_DENSE_SA, else by its size) */
+enum AwFmReturnCode awfmGpuApplyDenseSaAuto(AwFmGpuIndex *g);
+
 /* blocks + superblock table of the device image from reference-layout blocks already on the device (current device,
  * null stream).  dBlocks / dSuper are allocated by the caller: awfmDeviceBlocks x awfmDeviceBlockBytes, awfmSuperBytes.
  * Synchronous; false with awfmGpuLastError set on failure. */

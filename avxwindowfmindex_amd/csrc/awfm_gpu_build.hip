@@ -810,7 +810,7 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
   if (format == 2u) {
     const size_t bigBytes = ((size_t)(g->dev.bwtLength >> kDeepWideBigShift) + 2u) * 8u;
     if (!big.alloc(bigBytes)) return false;
-    BUILD_TRY(hipMemset(big.p, 0, bigBytes));
+    BUILD_TRY(awfmGpuSetupMemset(big.p, 0, bigBytes));
   }
   /* two levels per pass through the pair image where the image has one (deepSeedPairLevelKernel) */
   const bool pairLevels = !g->amino && g->dev.pairBlocks;
@@ -839,7 +839,7 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
       const u64 pairBlocks = (outLen + kSeedGroupsPerBlock - 1) / kSeedGroupsPerBlock;
       const unsigned pairGrid = (unsigned)(pairBlocks < resident ? pairBlocks : resident);
 #define AWFM_PAIR_LEVEL(O, NR) \
-  hipLaunchKernelGGL((deepSeedPairLevelKernel<O, NR>), dim3(pairGrid), dim3(kThreads), lds, 0, dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt)
+  hipLaunchKernelGGL((deepSeedPairLevelKernel<O, NR>), dim3(pairGrid), dim3(kThreads), lds, awfmGpuSetupStream, dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt)
       if (narrow) {
         if (out == 1u) AWFM_PAIR_LEVEL(1, true);
         else AWFM_PAIR_LEVEL(0, true);
@@ -850,17 +850,17 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
       const u64 aminoBlocks = (outLen + kThreads / 4 - 1) / (kThreads / 4);
       const unsigned aminoGrid = (unsigned)(aminoBlocks < resident ? aminoBlocks : resident);
       if (out == 1u)
-        hipLaunchKernelGGL((aminoDeepSeedLevelKernel<true>), dim3(aminoGrid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>());
+        hipLaunchKernelGGL((aminoDeepSeedLevelKernel<true>), dim3(aminoGrid), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, parent, len, outLen, nxt.as<ulonglong2>());
       else
-        hipLaunchKernelGGL((aminoDeepSeedLevelKernel<false>), dim3(aminoGrid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>());
+        hipLaunchKernelGGL((aminoDeepSeedLevelKernel<false>), dim3(aminoGrid), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, parent, len, outLen, nxt.as<ulonglong2>());
     } else if (out == 2u)
-      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, 2>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
+      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, 2>), dim3(grid), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
     else if (out == 1u)
-      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, 1>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
+      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, 1>), dim3(grid), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
     else
-      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, 0>), dim3(grid), dim3(kThreads), 0, 0, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
+      hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, 0>), dim3(grid), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
     BUILD_TRY(hipGetLastError());
-    BUILD_TRY(hipDeviceSynchronize());
+    BUILD_TRY(awfmGpuSetupSync());
     clock_gettime(CLOCK_MONOTONIC, &tc);
     if (getenv("AWFM_VERBOSE"))
       fprintf(stderr, "[awfm deep seed] level %u -> %u: %llu entries, allocation %.3f s, kernel %.3f s\n", L, L + levels, (unsigned long long)outLen,

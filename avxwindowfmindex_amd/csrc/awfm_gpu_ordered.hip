@@ -200,7 +200,7 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, unsigne
       return 0;
     }
     unsigned numBig = 0;
-    bool ok = hipMemset(dCount, 0, 16) == hipSuccess;
+    bool ok = awfmGpuSetupMemset(dCount, 0, 16) == hipSuccess;
     if (ok) {
       DevIndex dev = g->dev;
       dev.deepNarrow = 2u;
@@ -208,8 +208,8 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, unsigne
       dev.pairSuperInLds = 0u;
       constexpr int threads = orderedThreads(true);
       const unsigned grid = residentGrid(g, deepNextKernel<false>, 0, threads);
-      hipLaunchKernelGGL(deepNextKernel<false>, dim3(grid ? grid : 1u), dim3(threads), 0, 0, dev, (uint2 *)table, 1ull << (2u * deepK), (unsigned *)nullptr, dCount);
-      ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess && hipMemcpy(&numBig, dCount, 4, hipMemcpyDeviceToHost) == hipSuccess;
+      hipLaunchKernelGGL(deepNextKernel<false>, dim3(grid ? grid : 1u), dim3(threads), 0, awfmGpuSetupStream, dev, (uint2 *)table, 1ull << (2u * deepK), (unsigned *)nullptr, dCount);
+      ok = hipGetLastError() == hipSuccess && awfmGpuSetupSync() == hipSuccess && awfmGpuSetupToHost(&numBig, dCount, 4) == hipSuccess;
     }
     (void)hipFree(dCount);
     if (!ok) {
@@ -232,12 +232,12 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, unsigne
       return 0;
     }
     unsigned numBig = 0;
-    bool ok = hipMemset(dBig, 0, (bigWords + 4u) * 4u) == hipSuccess;
+    bool ok = awfmGpuSetupMemset(dBig, 0, (bigWords + 4u) * 4u) == hipSuccess;
     if (ok) {
       const unsigned grid = residentGrid(g, aminoDeepNextKernel, 0, kThreads);
-      hipLaunchKernelGGL(aminoDeepNextKernel, dim3(grid ? grid : 1u), dim3(kThreads), 0, 0, g->dev, (uint2 *)table, numEntries, dBig, dBig + bigWords);
-      ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
-           hipMemcpy(&numBig, dBig + bigWords, 4, hipMemcpyDeviceToHost) == hipSuccess;
+      hipLaunchKernelGGL(aminoDeepNextKernel, dim3(grid ? grid : 1u), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, (uint2 *)table, numEntries, dBig, dBig + bigWords);
+      ok = hipGetLastError() == hipSuccess && awfmGpuSetupSync() == hipSuccess &&
+           awfmGpuSetupToHost(&numBig, dBig + bigWords, 4) == hipSuccess;
     }
     if (!ok) {
       (void)hipGetLastError();
@@ -258,7 +258,7 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, unsigne
     (void)hipGetLastError();
     return 0;
   }
-  bool ok = hipMemset(dBig, 0, (bigWords + 4u) * 4u) == hipSuccess;
+  bool ok = awfmGpuSetupMemset(dBig, 0, (bigWords + 4u) * 4u) == hipSuccess;
   unsigned numBig = 0;
   if (ok) {
     const bool superInLds = awfmPairSuperInLds(g);
@@ -267,9 +267,9 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, unsigne
     dev.pairSuperInLds = superInLds ? 1u : 0u;
     constexpr int threads = orderedThreads(true);
     unsigned grid = residentGrid(g, deepNextKernel<true>, lds, threads);
-    hipLaunchKernelGGL(deepNextKernel<true>, dim3(grid ? grid : 1u), dim3(threads), lds, 0, dev, (uint2 *)table, numEntries, dBig, dBig + bigWords);
-    ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
-         hipMemcpy(&numBig, dBig + bigWords, 4, hipMemcpyDeviceToHost) == hipSuccess;
+    hipLaunchKernelGGL(deepNextKernel<true>, dim3(grid ? grid : 1u), dim3(threads), lds, awfmGpuSetupStream, dev, (uint2 *)table, numEntries, dBig, dBig + bigWords);
+    ok = hipGetLastError() == hipSuccess && awfmGpuSetupSync() == hipSuccess &&
+         awfmGpuSetupToHost(&numBig, dBig + bigWords, 4) == hipSuccess;
   }
   if (!ok) {
     /* the table may have been rewritten in part: the caller must not use it */

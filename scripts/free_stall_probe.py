@@ -55,3 +55,20 @@ for gb in [40]:
     r, dt_next, _ = malloc(34 << 30)
     hip.hipFree(r)
     print(f"again {gb} GB: hipMalloc {dt_alloc:.3f} s, hipFree {dt_free:.3f} s, sync {dt_sync:.3f} s, then hipMalloc(1 MB) {dt_small:.3f} s, hipMalloc(34 GB) {dt_next:.3f} s")
+# near the device's capacity, in pieces (what the index builder's sort does): 8 x 26 GB, used, freed, then the image's allocations
+ps = []
+for i in range(8):
+    p, dt, rc = malloc(26 << 30)
+    assert rc == 0, rc
+    hip.hipMemset(p, 1, 26 << 30)
+    ps.append(p)
+hip.hipDeviceSynchronize()
+t0 = time.perf_counter()
+for p in ps:
+    hip.hipFree(p)
+dt_free = time.perf_counter() - t0
+q, dt1, _ = malloc(4 << 30)
+r, dt2, _ = malloc(34 << 30)
+dt_set, _ = timed(hip.hipMemset, r, 1, 34 << 30)
+dt_sync, _ = timed(hip.hipDeviceSynchronize)
+print(f"8 x 26 GB used and freed ({dt_free:.3f} s): hipMalloc(4 GB) {dt1:.3f} s, hipMalloc(34 GB) {dt2:.3f} s, first touch of it {dt_set + dt_sync:.3f} s")

@@ -18,7 +18,7 @@ def kernel_metadata(tmp_path_factory):
     if not os.path.exists(HIPCC):
         pytest.skip("hipcc not installed")
     text = ""
-    for source in ("awfm_gpu.hip", "awfm_gpu_ordered.hip", "awfm_gpu_mixed.hip"):
+    for source in ("awfm_gpu.hip", "awfm_gpu_locate.hip", "awfm_gpu_ordered.hip", "awfm_gpu_mixed.hip"):
         out = tmp_path_factory.mktemp("isa") / (source + ".s")
         subprocess.check_call([HIPCC, "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
                                "-I" + CSRC, "-Wno-unused-function", "-S", "--cuda-device-only", "-o", str(out),
