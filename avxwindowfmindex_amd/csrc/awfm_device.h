@@ -30,6 +30,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -953,6 +954,25 @@ struct AwFmGpuIndex {
     unsigned agreed = 0;
   } predict;
   int lastSearchExact = 0; /* awfmGpuLastSearchWasExactLookup */
+  /* Accelerators built BEHIND the first searches (round 6).  An image made by awfmGpuIndexAcquireAll -- the drop-in entry
+   * points' way -- is usable as soon as its blocks, seed table, sampled array and pair image are on the device (the reference's
+   * index is usable the moment awFmReadIndexFromFile returns, ref src/AwFmFile.c:195-449); its deeper table and full suffix array
+   * are made by a thread of their own on a stream of their own and installed between two calls (awfmGpuAdoptAccelerators).
+   * Searches give the reference's results with or without them.  accelState: 0 nothing pending, 1 being built, 2 built and
+   * waiting to be installed. */
+  std::thread accelThread;
+  std::atomic<int> accelState{0};
+  struct PendingAccel {
+    void *deepTable = nullptr, *deepBig = nullptr;
+    uint64_t deepBytes = 0, deepBigBytes = 0, deepTransient = 0;
+    unsigned deepK = 0, deepFormat = 0, deepNext = 0, numDeepBig = 0;
+    double deepSeconds = 0.0, deepAllocSeconds = 0.0;
+    void *dense = nullptr;
+    bool denseWide = false;
+    uint64_t denseBytes = 0;
+    double denseSeconds = 0.0;
+    std::string notes;
+  } pendingAccel;
   std::mutex aosMutex;       /* serialises the AoS entry points (they share the pinned buffers) */
   void *pinned[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t pinnedBytes[4] = {0, 0, 0, 0};
@@ -1095,6 +1115,14 @@ enum AwFmReturnCode awfmGpuLaunchLocate(AwFmGpuIndex *g, unsigned long long tota
                                         unsigned long long *out = nullptr, const unsigned long long *totalOnDevice = nullptr, unsigned stepCap = 0u);
 /* awfm_gpu_dense_sa.hip: the full suffix array of an image that was just created or adopted ($AWFM_GPU_DENSE_SA, else by its size) */
 enum AwFmReturnCode awfmGpuApplyDenseSaAuto(AwFmGpuIndex *g);
+/* ... the same decision and construction without touching the image (the thread that builds behind the first searches): the
+ * array, its entry width and size, the seconds it took; notes: what was not built and why */
+enum AwFmReturnCode awfmGpuBuildDenseSaAuto(const AwFmGpuIndex *g, void **arrayOut, bool *wideOut, uint64_t *bytesOut, double *secondsOut,
+                                            std::string *notes);
+/* awfm_gpu_image.hip: installs what an image's builder thread has finished.  wait: join the thread first (the explicit
+ * entry points); otherwise only when it is done and the image's locks are free right now.  lanes: the image's lanes, listed by
+ * a caller that holds the registry's lock (NULL: looked up here) */
+void awfmGpuAdoptAccelerators(AwFmGpuIndex *g, bool wait, const std::vector<AwFmGpuIndex *> *lanes = nullptr);
 
 /* blocks + superblock table of the device image from reference-layout blocks already on the device (current device,
  * null stream).  dBlocks / dSuper are allocated by the caller: awfmDeviceBlocks x awfmDeviceBlockBytes, awfmSuperBytes.

@@ -42,6 +42,7 @@ enum AwFmReturnCode awfmGpuIndexSetDenseSa(AwFmGpuIndex *g, int enable) {
     setError("awfmGpuIndexSetDenseSa: set it on the primary image, not on a lane");
     return AwFmIllegalPositionError;
   }
+  awfmGpuAdoptAccelerators(g, true); /* (whatever is still being built behind the first searches) */
   DeviceGuard guard(g->device);
   AwFmGpuLaneLocks lanes(g);
   std::lock_guard<std::mutex> lock(g->workMutex);
@@ -240,7 +241,13 @@ thread_local bool awfmGpuDenseSaStashWide = false;
  * 8 bytes per position and a second pass.  Without memory for either, or when 64 rounds do not finish, no array is kept and
  * the image locates by walking, as the reference does; a construction that was asked for (awfmGpuIndexSetDenseSa,
  * $AWFM_GPU_DENSE_SA=1) then walks every position to its sample, however long that takes. */
-static enum AwFmReturnCode applyDenseSaWide(AwFmGpuIndex *g, bool capped);
+struct DenseBuilt {
+  void *dDenseSa = nullptr;
+  bool denseWide = false;
+  uint64_t denseSaBytes = 0;
+};
+static enum AwFmReturnCode buildDenseSaWide(AwFmGpuIndex *image, bool capped, DenseBuilt *g);
+static enum AwFmReturnCode buildDenseSa(AwFmGpuIndex *image, bool capped, DenseBuilt *g);
 static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool capped) {
   (void)awfmGpuSetupSync();
   if (g->dDenseSa) (void)hipFree(g->dDenseSa);
@@ -248,9 +255,18 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
   g->denseSaBytes = 0;
   g->denseWide = false;
   if (!enable) return AwFmSuccess;
-  const unsigned long long n = g->dev.bwtLength;
+  DenseBuilt built;
+  const enum AwFmReturnCode rc = buildDenseSa(g, capped, &built);
+  g->dDenseSa = built.dDenseSa;
+  g->denseWide = built.denseWide;
+  g->denseSaBytes = built.denseSaBytes;
+  return rc;
+}
+/* the construction itself: reads the image (its blocks, its sampled array), writes `g` (what was built) */
+static enum AwFmReturnCode buildDenseSa(AwFmGpuIndex *image, bool capped, DenseBuilt *g) {
+  const unsigned long long n = image->dev.bwtLength;
   /* 32-bit entries for the images that run 32-bit positions, 40-bit ones (DenseSa) for the others */
-  const bool wide = !awfmImageNarrow(g);
+  const bool wide = !awfmImageNarrow(image);
   if (n >= (1ull << 40)) {
     setError("awfmGpuIndexSetDenseSa: 40-bit entries need bwtLength < 2^40");
     return AwFmUnsupportedVersionError;
@@ -268,12 +284,12 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
         return AwFmSuccess; /* no array: the image locates by walking */
       }
       if (wide) {
-        hipLaunchKernelGGL((packDense40Kernel<unsigned>), dim3((unsigned)g->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, (const unsigned *)stash, n, (unsigned *)other);
+        hipLaunchKernelGGL((packDense40Kernel<unsigned>), dim3((unsigned)image->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, (const unsigned *)stash, n, (unsigned *)other);
       } else {
         DenseSa from;
         from.words = (const unsigned *)stash;
         from.wide = 1u;
-        hipLaunchKernelGGL(unpackDense40Kernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, from, n, (unsigned *)other);
+        hipLaunchKernelGGL(unpackDense40Kernel, dim3((unsigned)image->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, from, n, (unsigned *)other);
       }
       const bool ok = hipGetLastError() == hipSuccess && awfmGpuSetupSync() == hipSuccess;
       (void)hipFree(stash);
@@ -289,7 +305,7 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
     g->denseSaBytes = awfmDenseSaBytes(n, wide);
     return AwFmSuccess;
   }
-  if (wide) return applyDenseSaWide(g, capped);
+  if (wide) return buildDenseSaWide(image, capped, g);
   unsigned *dense = nullptr;
   unsigned long long *chunkBuf = nullptr, *park = nullptr, *counter = nullptr;
   const unsigned long long chunk = n < (1ull << 28) ? n : (1ull << 28);
@@ -306,7 +322,7 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
    * runs); `capped` = false now only says what happens when the parked walks cannot be kept: the array that was asked for
    * is then built by walking to the end, the automatic one is dropped */
   const bool explicitBuild = !capped;
-  unsigned stepCap = 32u * g->dev.saRatio;
+  unsigned stepCap = 32u * image->dev.saRatio;
   /* the parked walks of the first pass go into a list (narrowParkListKernel) of at most a quarter of the positions, 2^26 at
    * most (0.8 GB; $AWFM_GPU_DIAG park_list = entries, 0 = none: tests): a text that parks more -- one that is mostly runs -- takes
    * the array over all positions and a second pass, as round 4 did for every text that parked anything */
@@ -329,12 +345,12 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
     for (unsigned long long first = 0; first < n && rc == AwFmSuccess; first += chunk) {
       const unsigned long long count = n - first < chunk ? n - first : chunk;
       hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, awfmGpuSetupStream, chunkBuf, first, count);
-      rc = awfmGpuLaunchLocate(g, count, chunkBuf, awfmGpuSetupStream, nullptr, nullptr, stepCap);
+      rc = awfmGpuLaunchLocate(image, count, chunkBuf, awfmGpuSetupStream, nullptr, nullptr, stepCap);
       if (stepCap && listing)
-        hipLaunchKernelGGL(narrowParkListKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, (const unsigned long long *)chunkBuf,
+        hipLaunchKernelGGL(narrowParkListKernel, dim3((unsigned)image->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, (const unsigned long long *)chunkBuf,
                            count, first, dense, listAt, listEntry, listCapacity, counter);
       else if (stepCap)
-        hipLaunchKernelGGL(narrowParkKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, (const unsigned long long *)chunkBuf, count,
+        hipLaunchKernelGGL(narrowParkKernel, dim3((unsigned)image->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, (const unsigned long long *)chunkBuf, count,
                            dense + first, park ? park + first : (unsigned long long *)nullptr, counter);
       else
         hipLaunchKernelGGL(narrowKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, awfmGpuSetupStream, chunkBuf, count, dense + first);
@@ -378,10 +394,10 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
     for (; rc == AwFmSuccess && left != 0 && rounds < 64u; rounds++) {
       if (awfmGpuSetupMemset(counter + 1, 0, 8) != hipSuccess) rc = AwFmGeneralFailure;
       if (listed)
-        hipLaunchKernelGGL(denseSaJumpListKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, dense, (const unsigned *)listAt, listEntry,
+        hipLaunchKernelGGL(denseSaJumpListKernel, dim3((unsigned)image->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, dense, (const unsigned *)listAt, listEntry,
                            parked, n, counter + 1);
       else
-        hipLaunchKernelGGL(denseSaJumpKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, dense, park, n, counter + 1);
+        hipLaunchKernelGGL(denseSaJumpKernel, dim3((unsigned)image->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, dense, park, n, counter + 1);
       if (hipGetLastError() != hipSuccess || awfmGpuSetupToHost(&left, counter + 1, 8) != hipSuccess) rc = AwFmGeneralFailure;
     }
     if (getenv("AWFM_VERBOSE") && parked)
@@ -413,8 +429,8 @@ static enum AwFmReturnCode applyDenseSa(AwFmGpuIndex *g, bool enable, bool cappe
 /* the construction for images that run 64-bit positions (kernels above): capped walks, the parked ones in a list, pointer
  * jumping, 40-bit entries at the end.  A text that parks more walks than the list holds -- a quarter of its positions, 2^27 at
  * most -- gets no automatic array; one that was asked for is then walked to the end, however long that takes. */
-static enum AwFmReturnCode applyDenseSaWide(AwFmGpuIndex *g, bool capped) {
-  const unsigned long long n = g->dev.bwtLength;
+static enum AwFmReturnCode buildDenseSaWide(AwFmGpuIndex *image, bool capped, DenseBuilt *g) {
+  const unsigned long long n = image->dev.bwtLength;
   const unsigned long long chunk = n < (1ull << 28) ? n : (1ull << 28);
   unsigned long long *dense = nullptr, *chunkBuf = nullptr, *listAt = nullptr;
   ulonglong2 *entry[2] = {nullptr, nullptr};
@@ -438,15 +454,15 @@ static enum AwFmReturnCode applyDenseSaWide(AwFmGpuIndex *g, bool capped) {
   }
   unsigned long long *counter = chunkBuf + chunk; /* two words behind the chunk: parked entries, entries left */
   enum AwFmReturnCode rc = AwFmSuccess;
-  unsigned stepCap = 32u * g->dev.saRatio;
+  unsigned stepCap = 32u * image->dev.saRatio;
   auto walkAll = [&]() {
     if (awfmGpuSetupMemset(counter, 0, 16) != hipSuccess) rc = AwFmGeneralFailure;
     for (unsigned long long first = 0; first < n && rc == AwFmSuccess; first += chunk) {
       const unsigned long long count = n - first < chunk ? n - first : chunk;
       hipLaunchKernelGGL(iotaKernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, awfmGpuSetupStream, chunkBuf, first, count);
-      rc = awfmGpuLaunchLocate(g, count, chunkBuf, awfmGpuSetupStream, nullptr, nullptr, stepCap);
+      rc = awfmGpuLaunchLocate(image, count, chunkBuf, awfmGpuSetupStream, nullptr, nullptr, stepCap);
       if (stepCap)
-        hipLaunchKernelGGL(parkWideKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, (const unsigned long long *)chunkBuf, count, first, dense,
+        hipLaunchKernelGGL(parkWideKernel, dim3((unsigned)image->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, (const unsigned long long *)chunkBuf, count, first, dense,
                            listAt, entry[0], listCapacity, counter);
       else if (hipMemcpyAsync(dense + first, chunkBuf, count * 8, hipMemcpyDeviceToDevice, awfmGpuSetupStream) != hipSuccess)
         rc = AwFmGeneralFailure;
@@ -470,7 +486,7 @@ static enum AwFmReturnCode applyDenseSaWide(AwFmGpuIndex *g, bool capped) {
   unsigned rounds = 0;
   for (; rc == AwFmSuccess && left != 0 && rounds < 64u; rounds++) {
     if (awfmGpuSetupMemset(counter + 1, 0, 8) != hipSuccess) rc = AwFmGeneralFailure;
-    hipLaunchKernelGGL(denseSaJumpWideKernel, dim3((unsigned)g->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, dense, (const unsigned long long *)listAt,
+    hipLaunchKernelGGL(denseSaJumpWideKernel, dim3((unsigned)image->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, dense, (const unsigned long long *)listAt,
                        (const ulonglong2 *)entry[rounds & 1u], entry[(rounds & 1u) ^ 1u], parked, n, counter + 1);
     if (hipGetLastError() != hipSuccess || awfmGpuSetupToHost(&left, counter + 1, 8) != hipSuccess) rc = AwFmGeneralFailure;
   }
@@ -495,7 +511,7 @@ static enum AwFmReturnCode applyDenseSaWide(AwFmGpuIndex *g, bool capped) {
     return capped ? AwFmSuccess : AwFmAllocationFailure;
   }
   if (rc == AwFmSuccess) {
-    hipLaunchKernelGGL((packDense40Kernel<unsigned long long>), dim3((unsigned)g->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, (const unsigned long long *)dense, n, packed);
+    hipLaunchKernelGGL((packDense40Kernel<unsigned long long>), dim3((unsigned)image->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, (const unsigned long long *)dense, n, packed);
     if (hipGetLastError() != hipSuccess || awfmGpuSetupSync() != hipSuccess) rc = AwFmGeneralFailure;
   }
   release();
@@ -518,7 +534,12 @@ static enum AwFmReturnCode applyDenseSaWide(AwFmGpuIndex *g, bool capped) {
  * a small batch (60 us) is gone.  Positions are those of the walk (it wrote them); the host index, its sampled array
  * and the .awfmi file are untouched. */
 }  // extern "C"
-enum AwFmReturnCode awfmGpuApplyDenseSaAuto(AwFmGpuIndex *g) {
+enum AwFmReturnCode awfmGpuBuildDenseSaAuto(const AwFmGpuIndex *g, void **arrayOut, bool *wideOut, uint64_t *bytesOut, double *secondsOut,
+                                            std::string *notes) {
+  *arrayOut = nullptr;
+  *wideOut = false;
+  *bytesOut = 0;
+  *secondsOut = 0.0;
   bool want = false, automatic = false;
   const char *env = getenv("AWFM_GPU_DENSE_SA");
   if (env && !strcmp(env, "auto")) { /* the automatic construction whatever the image's size (tests) */
@@ -534,17 +555,36 @@ enum AwFmReturnCode awfmGpuApplyDenseSaAuto(AwFmGpuIndex *g) {
     const uint64_t entryBytes = awfmImageNarrow(g) ? 4u : (awfmGpuDenseSaStash && awfmGpuDenseSaStashLength == g->dev.bwtLength ? 5u : 8u);
     if (hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) want = freeBytes / (awfmImageNarrow(g) ? 4u : 2u) >= g->dev.bwtLength * entryBytes + (1ull << 31);
     else (void)hipGetLastError();
-    if (!want) g->accelNotes += "full suffix array: not built (less than 4 x its size free); ";
+    if (!want) *notes += "full suffix array: not built (less than 4 x its size free); ";
     automatic = true;
   }
   if (!want || g->dev.bwtLength >= (1ull << 40)) return AwFmSuccess;
   DeviceGuard guard(g->device);
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);
-  const enum AwFmReturnCode rc = applyDenseSa(g, true, automatic);
-  if (!g->dDenseSa) g->accelNotes += "full suffix array: not built (no device memory, or walks that could not be completed); ";
+  DenseBuilt built;
+  const enum AwFmReturnCode rc = buildDenseSa(const_cast<AwFmGpuIndex *>(g), automatic, &built); /* (reads the image only) */
+  if (!built.dDenseSa) *notes += "full suffix array: not built (no device memory, or walks that could not be completed); ";
   clock_gettime(CLOCK_MONOTONIC, &t1);
-  g->denseSaBuildSeconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  *arrayOut = built.dDenseSa;
+  *wideOut = built.denseWide;
+  *bytesOut = built.denseSaBytes;
+  *secondsOut = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  return rc;
+}
+enum AwFmReturnCode awfmGpuApplyDenseSaAuto(AwFmGpuIndex *g) {
+  void *array = nullptr;
+  bool wide = false;
+  uint64_t bytes = 0;
+  double seconds = 0.0;
+  const enum AwFmReturnCode rc = awfmGpuBuildDenseSaAuto(g, &array, &wide, &bytes, &seconds, &g->accelNotes);
+  if (array) {
+    if (g->dDenseSa) (void)hipFree(g->dDenseSa);
+    g->dDenseSa = array;
+    g->denseWide = wide;
+    g->denseSaBytes = bytes;
+    g->denseSaBuildSeconds = seconds;
+  }
   return rc;
 }
 extern "C" {

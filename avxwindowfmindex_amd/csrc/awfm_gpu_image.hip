@@ -16,6 +16,7 @@
 #include "awfm_search_kernel.h"
 #include "awfm_locate_kernel.h"
 
+thread_local hipStream_t awfmGpuSetupStream = nullptr; /* awfm_device.h */
 static thread_local std::string tlsError;
 void awfmGpuSetError(const char *what) { tlsError = what; }
 void awfmGpuSetHipError(const char *what, hipError_t e) { tlsError = std::string(what) + ": " + hipGetErrorString(e); }
@@ -183,7 +184,15 @@ int awfmGpuDeviceCount(void) {
 
 const char *awfmGpuLastError(void) { return tlsError.c_str(); }
 
+static enum AwFmReturnCode createImage(const struct AwFmIndex *index, int device, AwFmGpuIndex **out, bool deferAccelerators);
 enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device, AwFmGpuIndex **out) {
+  return createImage(index, device, out, false);
+}
+static void accelBuilder(AwFmGpuIndex *g);
+static unsigned chooseDeepSeedK(const AwFmGpuIndex *g, std::string &notes);
+static enum AwFmReturnCode buildDeepSeed(AwFmGpuIndex *g, unsigned deepK, AwFmGpuIndex::PendingAccel *to);
+static void installDeepSeed(AwFmGpuIndex *g, AwFmGpuIndex::PendingAccel *from, const std::vector<AwFmGpuIndex *> &laneList);
+static enum AwFmReturnCode createImage(const struct AwFmIndex *index, int device, AwFmGpuIndex **out, bool deferAccelerators) {
   if (!index || !out) {
     setError("awfmGpuIndexCreate: null argument");
     return AwFmNullPtrError;
@@ -290,16 +299,92 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
   fillDevIndex(g, index, superShift, sentinelPos);
   if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
   (void)applyPairFromEnv(g); /* without it (no memory left) searches simply take one step per read */
-  if (applyDeepSeedFromEnv(g) != AwFmSuccess) return fail(AwFmGeneralFailure);
-  (void)awfmGpuApplyDenseSaAuto(g); /* optional accelerator: without it (no memory left) a locate walks */
+  if (deferAccelerators) {
+    /* the image is usable now (general kernel from the index's own table, pair steps, LF walk); the deeper table and the full
+     * suffix array are built by a thread of their own, on a stream of their own, and installed between two calls */
+    g->accelState.store(1);
+    g->accelThread = std::thread(accelBuilder, g);
+  } else {
+    if (applyDeepSeedFromEnv(g) != AwFmSuccess) return fail(AwFmGeneralFailure);
+    (void)awfmGpuApplyDenseSaAuto(g); /* optional accelerator: without it (no memory left) a locate walks */
+  }
   *out = g;
   return AwFmSuccess;
 }
 
+/* the thread that builds an image's deeper table and full suffix array behind its first searches: the choices the
+ * synchronous construction makes (by the image's size and the free memory), on a non-blocking stream of the thread's own */
+static void accelBuilder(AwFmGpuIndex *g) {
+  DeviceGuard guard(g->device);
+  hipStream_t own = nullptr;
+  if (hipStreamCreateWithFlags(&own, hipStreamNonBlocking) != hipSuccess) own = nullptr; /* (the null stream then: correct, not hidden) */
+  awfmGpuSetupStream = own;
+  AwFmGpuIndex::PendingAccel &to = g->pendingAccel;
+  const unsigned deepK = chooseDeepSeedK(g, to.notes);
+  if (deepK != 0 && buildDeepSeed(g, deepK, &to) != AwFmSuccess) to.notes += "deeper table: construction failed; ";
+  (void)awfmGpuBuildDenseSaAuto(g, &to.dense, &to.denseWide, &to.denseBytes, &to.denseSeconds, &to.notes);
+  (void)awfmGpuSetupSync();
+  awfmGpuSetupStream = nullptr;
+  if (own) (void)hipStreamDestroy(own);
+  (void)hipGetLastError();
+  g->accelState.store(2);
+}
+
+}  // extern "C"
+void awfmGpuAdoptAccelerators(AwFmGpuIndex *g, bool wait, const std::vector<AwFmGpuIndex *> *lanesIn) {
+  if (!g || g->shares) return;
+  if (g->accelState.load() == 0) return;
+  if (wait) {
+    if (g->accelThread.joinable()) g->accelThread.join();
+  } else if (g->accelState.load() != 2) {
+    return;
+  }
+  if (g->accelState.load() != 2) return;
+  std::vector<AwFmGpuIndex *> lanes = lanesIn ? *lanesIn : awfmGpuLanesOf(g);
+  /* nobody is enqueuing a search through the image or one of its lanes while its view changes: all their locks, or (not
+   * waiting) none and another time */
+  std::vector<std::mutex *> want = {&g->aosMutex, &g->workMutex, &g->orderMutex};
+  for (AwFmGpuIndex *lane : lanes) {
+    want.push_back(&lane->aosMutex);
+    want.push_back(&lane->workMutex);
+    want.push_back(&lane->orderMutex);
+  }
+  size_t held = 0;
+  for (; held < want.size(); held++) {
+    if (wait) want[held]->lock();
+    else if (!want[held]->try_lock()) break;
+  }
+  if (held == want.size() && g->accelState.load() == 2) {
+    if (g->accelThread.joinable()) g->accelThread.join();
+    AwFmGpuIndex::PendingAccel &from = g->pendingAccel;
+    if (from.deepTable) installDeepSeed(g, &from, lanes);
+    if (from.dense) {
+      g->dDenseSa = from.dense;
+      g->denseWide = from.denseWide;
+      g->denseSaBytes = from.denseBytes;
+      g->denseSaBuildSeconds = from.denseSeconds;
+      from.dense = nullptr;
+      for (AwFmGpuIndex *lane : lanes) {
+        lane->dDenseSa = g->dDenseSa;
+        lane->denseWide = g->denseWide;
+      }
+    }
+    g->accelNotes += from.notes;
+    from.notes.clear();
+    g->accelState.store(0);
+  }
+  while (held > 0) want[--held]->unlock();
+}
+extern "C" {
+
 void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
   if (!g) return;
+  if (g->accelThread.joinable()) g->accelThread.join();
   {
     DeviceGuard guard(g->device);
+    if (g->pendingAccel.deepTable) (void)hipFree(g->pendingAccel.deepTable); /* (built, never installed) */
+    if (g->pendingAccel.deepBig) (void)hipFree(g->pendingAccel.deepBig);
+    if (g->pendingAccel.dense) (void)hipFree(g->pendingAccel.dense);
     awfmGpuStreamStateFree(g);
     if (!g->shares) { /* a lane owns only its staging */
       if (g->dBlocks) (void)hipFree(g->dBlocks);
@@ -417,19 +502,32 @@ int awfmGpuIndexAcquireAll(const struct AwFmIndex *index, AwFmGpuIndex **out, in
         AwFmGpuIndex *primary = find(devs[slot], 0);
         if (!primary) return n;
         g = makeLane(primary);
-      } else if (awfmGpuIndexCreate(index, devs[slot], &g) != AwFmSuccess) {
+      } else if (createImage(index, devs[slot], &g, true) != AwFmSuccess) {
         return n;
       }
       imageTable.push_back({index, devs[slot], lane, g});
     }
     out[n++] = g;
   }
+  /* what the images' builder threads have finished since the last call is installed now, if nobody is inside a search */
+  for (int i = 0; i < n; i++) {
+    AwFmGpuIndex *primary = out[i]->shares ? out[i]->shares : out[i];
+    if (primary->accelState.load() == 2) {
+      std::vector<AwFmGpuIndex *> lanes;
+      for (auto &e : imageTable)
+        if (e.image->shares == primary) lanes.push_back(e.image);
+      awfmGpuAdoptAccelerators(primary, false, &lanes);
+    }
+  }
   return n;
 }
 
+/* the explicit way to an index's image: complete -- whatever is built behind the first searches is waited for and installed */
 AwFmGpuIndex *awfmGpuIndexAcquire(const struct AwFmIndex *index) {
   AwFmGpuIndex *g = nullptr;
-  return awfmGpuIndexAcquireAll(index, &g, 1) == 1 ? g : nullptr;
+  if (awfmGpuIndexAcquireAll(index, &g, 1) != 1) return nullptr;
+  awfmGpuAdoptAccelerators(g->shares ? g->shares : g, true);
+  return g;
 }
 
 void awfmGpuIndexRelease(const struct AwFmIndex *index) {
@@ -492,25 +590,78 @@ enum AwFmReturnCode awfmGpuIndexSetDeepSeed(AwFmGpuIndex *g, unsigned deepK) {
     setError("awfmGpuIndexSetDeepSeed: set it on the primary image, not on a lane");
     return AwFmIllegalPositionError;
   }
+  awfmGpuAdoptAccelerators(g, true);
   DeviceGuard guard(g->device);
   AwFmGpuLaneLocks lanes(g); /* nobody searches through a lane while the table is replaced */
   std::lock_guard<std::mutex> lock(g->workMutex);
   return applyDeepSeed(g, deepK, lanes.lanes);
 }
 
+/* the deeper table of depth deepK with its next-step bits, built from the image as it is (nothing of the image is written):
+ * into `to` */
+static enum AwFmReturnCode buildDeepSeed(AwFmGpuIndex *g, unsigned deepK, AwFmGpuIndex::PendingAccel *to) {
+  void *table = nullptr, *big = nullptr;
+  uint64_t bytes = 0, peak = 0;
+  unsigned format = 0, numBig = 0;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  if (!awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes, &peak, &to->deepAllocSeconds, &format, &big)) return AwFmGeneralFailure;
+  /* the next-step bits: images with pair blocks (format 1: the long lengths move to `big` with them) */
+  const int next = awfmGpuDeepSeedAddNext(g, table, deepK, format, &big, &numBig);
+  (void)awfmGpuSetupSync();
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (next < 0) {
+    (void)hipFree(table);
+    if (big) (void)hipFree(big);
+    return AwFmGeneralFailure;
+  }
+  to->deepTable = table;
+  to->deepBig = big;
+  to->deepBytes = bytes;
+  to->deepBigBytes = !big ? 0u
+                     : format == 2u ? ((g->dev.bwtLength >> kDeepWideBigShift) + 2u) * 8u
+                                    : ((g->dev.bwtLength >> (g->amino ? kAminoDeepBigShift : kDeepBigShift)) + 5u) * 4u;
+  to->deepTransient = peak > bytes ? peak - bytes : 0;
+  to->deepK = deepK;
+  to->deepFormat = format;
+  to->deepNext = next > 0 ? 1u : 0u;
+  to->numDeepBig = numBig;
+  to->deepSeconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  if (getenv("AWFM_VERBOSE"))
+    fprintf(stderr, "[awfm deeper table] depth %u, entry format %u: %.2f GB in %.2f s; next-step bits %s; %u entries with long ranges\n", deepK, format,
+            (double)bytes * 1e-9, to->deepSeconds, next > 0 ? "yes" : "no", numBig);
+  return AwFmSuccess;
+}
+/* a built table becomes the image's (and its lanes'); the caller holds whatever locks the image needs */
+static void installDeepSeed(AwFmGpuIndex *g, AwFmGpuIndex::PendingAccel *from, const std::vector<AwFmGpuIndex *> &laneList) {
+  g->dDeepSeed = from->deepTable;
+  g->dDeepBig = from->deepBig;
+  g->deepSeedBytes = from->deepBytes + from->deepBigBytes;
+  g->deepSeedBuildSeconds = from->deepSeconds;
+  g->deepSeedAllocSeconds = from->deepAllocSeconds;
+  g->deepSeedTransientBytes = from->deepTransient;
+  g->dev.deepSeed = (const ulonglong2 *)from->deepTable;
+  g->dev.deepNarrow = from->deepFormat;
+  g->dev.deepNext = from->deepNext;
+  g->dev.numDeepBig = from->numDeepBig;
+  g->dev.deepBigBySp = (const unsigned *)from->deepBig;
+  g->dev.deepK = from->deepTable ? from->deepK : 0u;
+  from->deepTable = from->deepBig = nullptr;
+  for (AwFmGpuIndex *lane : laneList) {
+    lane->dDeepSeed = g->dDeepSeed;
+    lane->dev.deepSeed = g->dev.deepSeed;
+    lane->dev.deepNarrow = g->dev.deepNarrow;
+    lane->dev.deepK = g->dev.deepK;
+    lane->dev.deepNext = g->dev.deepNext;
+    lane->dev.numDeepBig = g->dev.numDeepBig;
+    lane->dev.deepBigBySp = g->dev.deepBigBySp;
+  }
+}
+
 static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const std::vector<AwFmGpuIndex *> &laneList) {
   (void)hipDeviceSynchronize();
   if (g->dDeepSeed) (void)hipFree(g->dDeepSeed);
   if (g->dDeepBig) (void)hipFree(g->dDeepBig);
-  g->dDeepSeed = nullptr;
-  g->dDeepBig = nullptr;
-  g->deepSeedBytes = 0;
-  g->dev.deepSeed = nullptr;
-  g->dev.deepK = 0;
-  g->dev.deepNarrow = 0;
-  g->dev.deepNext = 0;
-  g->dev.numDeepBig = 0;
-  g->dev.deepBigBySp = nullptr;
   { /* the tables of the shorter lengths go with the deeper table they complete; the next mixed-length batch builds them again */
     std::lock_guard<std::mutex> lock(g->lengthMutex);
     if (g->dLengthTable) (void)hipFree(g->dLengthTable);
@@ -521,65 +672,31 @@ static enum AwFmReturnCode applyDeepSeed(AwFmGpuIndex *g, unsigned deepK, const 
     g->lengthTableBytes = 0;
     g->lengthTried = false;
   }
+  AwFmGpuIndex::PendingAccel built; /* (nothing: the image without a deeper table) */
   enum AwFmReturnCode rc = AwFmSuccess;
-  g->deepSeedBuildSeconds = 0.0;
-  g->deepSeedTransientBytes = 0;
   if (deepK != 0) {
-    void *table = nullptr;
-    uint64_t bytes = 0, peak = 0;
-    struct timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
-    unsigned format = 0;
-    void *big = nullptr;
-    if (awfmGpuBuildDeepSeedTable(g, deepK, &table, &bytes, &peak, &g->deepSeedAllocSeconds, &format, &big)) {
-      unsigned numBig = 0;
-      /* the next-step bits: images with pair blocks (format 1: the long lengths move to `big` with them) */
-      const int next = awfmGpuDeepSeedAddNext(g, table, deepK, format, &big, &numBig);
-      (void)hipDeviceSynchronize();
-      clock_gettime(CLOCK_MONOTONIC, &t1);
-      g->deepSeedBuildSeconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-      g->deepSeedTransientBytes = peak > bytes ? peak - bytes : 0;
-      if (next < 0) {
-        (void)hipFree(table);
-        if (big) (void)hipFree(big);
-        rc = AwFmGeneralFailure;
-      } else {
-        g->dDeepSeed = table;
-        g->dDeepBig = big;
-        const uint64_t bigBytes = !big ? 0u
-                                  : format == 2u ? ((g->dev.bwtLength >> kDeepWideBigShift) + 2u) * 8u
-                                                 : ((g->dev.bwtLength >> (g->amino ? kAminoDeepBigShift : kDeepBigShift)) + 5u) * 4u;
-        g->deepSeedBytes = bytes + bigBytes;
-        g->dev.deepSeed = (const ulonglong2 *)table;
-        g->dev.deepK = deepK;
-        g->dev.deepNarrow = format;
-        g->dev.deepNext = next > 0 ? 1u : 0u;
-        g->dev.numDeepBig = numBig;
-        g->dev.deepBigBySp = (const unsigned *)big;
-        if (getenv("AWFM_VERBOSE"))
-          fprintf(stderr, "[awfm deeper table] depth %u, entry format %u: %.2f GB in %.2f s; next-step bits %s; %u entries with long ranges\n",
-                  deepK, format, (double)bytes * 1e-9, g->deepSeedBuildSeconds, next > 0 ? "yes" : "no", numBig);
-      }
-    } else {
-      rc = AwFmGeneralFailure;
-    }
+    /* (the construction reads the image's view: without the table that is being replaced) */
+    g->dev.deepSeed = nullptr;
+    g->dev.deepK = 0;
+    rc = buildDeepSeed(g, deepK, &built);
   }
-  for (AwFmGpuIndex *lane : laneList) {
-    lane->dDeepSeed = g->dDeepSeed;
-    lane->dev.deepSeed = g->dev.deepSeed;
-    lane->dev.deepNarrow = g->dev.deepNarrow;
-    lane->dev.deepK = g->dev.deepK;
-    lane->dev.deepNext = g->dev.deepNext;
-    lane->dev.numDeepBig = g->dev.numDeepBig;
-    lane->dev.deepBigBySp = g->dev.deepBigBySp;
-  }
+  installDeepSeed(g, &built, laneList);
   return rc;
 }
 
 /* $AWFM_GPU_DEEP_SEED_K on an image that was just created or adopted: nobody else holds it and it has no lanes,
  * so no lock is taken -- awfmGpuIndexAcquireAll creates images while it holds the table lock, and the public
  * setter would ask for that lock again through lanesOf() */
+static unsigned chooseDeepSeedK(const AwFmGpuIndex *g, std::string &notes);
 static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
+  const unsigned deepK = chooseDeepSeedK(g, g->accelNotes);
+  if (deepK == 0) return AwFmSuccess;
+  DeviceGuard guard(g->device);
+  return applyDeepSeed(g, deepK, {});
+}
+/* the depth of the device-only table an image gets by itself ($AWFM_GPU_DEEP_SEED_K / $AWFM_GPU_AMINO_DEEP_SEED_K, else by its size
+ * and the memory that is free); 0: none */
+static unsigned chooseDeepSeedK(const AwFmGpuIndex *g, std::string &notes) {
   int deepK = 0;
   if (const char *env = getenv(g->amino ? "AWFM_GPU_AMINO_DEEP_SEED_K" : "AWFM_GPU_DEEP_SEED_K")) {
     deepK = atoi(env); /* 0: none */
@@ -595,7 +712,7 @@ static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
       for (unsigned k = 1; k <= 7u; k++) {
         entries *= 20ull;
         if (k > g->dev.seedK && entries <= 8ull * g->dev.bwtLength && freeBytes / 3u >= entries * 8ull) deepK = (int)k;
-        else if (k > g->dev.seedK && entries <= 8ull * g->dev.bwtLength && k > (unsigned)deepK) g->accelNotes += "deeper table: depth " + std::to_string(k) + " not built (less than 3 x its size free); ";
+        else if (k > g->dev.seedK && entries <= 8ull * g->dev.bwtLength && k > (unsigned)deepK) notes += "deeper table: depth " + std::to_string(k) + " not built (less than 3 x its size free); ";
       }
     } else {
       (void)hipGetLastError();
@@ -619,15 +736,13 @@ static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
       for (unsigned k = kAutoDeepSeedMax; k >= kAutoDeepSeedMin && wanted == 0; k--)
         if ((1ull << (2u * k)) <= 2ull * g->dev.bwtLength) wanted = k;
       if ((unsigned)deepK < wanted)
-        g->accelNotes += "deeper table: depth " + std::to_string(wanted) + " not built (less than 3 x its size free)" +
+        notes += "deeper table: depth " + std::to_string(wanted) + " not built (less than 3 x its size free)" +
                          (deepK ? ", depth " + std::to_string(deepK) + " instead; " : "; ");
     } else {
       (void)hipGetLastError();
     }
   }
-  if (deepK <= 0 || (unsigned)deepK <= g->dev.seedK) return AwFmSuccess; /* nothing deeper than the index's own table */
-  DeviceGuard guard(g->device);
-  return applyDeepSeed(g, (unsigned)deepK, {});
+  return deepK <= 0 || (unsigned)deepK <= g->dev.seedK ? 0u : (unsigned)deepK; /* (nothing deeper than the index's own table) */
 }
 /* Pair image (awfm_pair.h) of a nucleotide image that was just created or adopted (nobody else holds it, no lanes, so
  * no lock): built unless $AWFM_GPU_PAIR=0.  It doubles the block bytes of the image (128 B per 128 positions beside
@@ -654,6 +769,7 @@ enum AwFmReturnCode awfmGpuIndexSetPairImage(AwFmGpuIndex *g, int enable) {
     setError("awfmGpuIndexSetPairImage: set it on the primary image, not on a lane");
     return AwFmIllegalPositionError;
   }
+  awfmGpuAdoptAccelerators(g, true);
   DeviceGuard guard(g->device);
   AwFmGpuLaneLocks lanes(g); /* nobody searches through a lane while the image changes */
   std::lock_guard<std::mutex> lock(g->workMutex);
