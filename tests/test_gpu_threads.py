@@ -252,3 +252,61 @@ def test_a_stream_is_retired_before_it_is_destroyed(oracle, awfm, require_gpu):
         torch.cuda.synchronize()
     g.destroy()
     ix.dealloc()
+
+
+def test_accelerators_built_behind_the_first_searches(oracle, awfm, require_gpu, monkeypatch):
+    """Round 6: the image awFmParallelSearch* makes for an index is usable as soon as its blocks, tables and pair image are on the
+    device; its deeper table and its full suffix array are built by a thread of their own and installed between two calls
+    (awfm_gpu_image.hip).  Three host threads search the index from the first moment on, with their own lists, round after round:
+    every round of every caller -- before, while and after the accelerators arrive -- must give the oracle's counts and position
+    lists (the reference's index answers the moment it is loaded, ref src/AwFmFile.c:195-449); and the explicit way to the image
+    (awfmGpuIndexAcquire) hands it over complete."""
+    monkeypatch.setenv("AWFM_GPU_DEEP_SEED_K", "11")  # (a small text gets neither by itself)
+    monkeypatch.setenv("AWFM_GPU_DENSE_SA", "auto")
+    txt = synth.text(451, 900_000).copy()
+    txt[1000:1100] = ord("n")
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)  # the host builder's index: no device image yet
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    n, jobs = 30011, []
+    for t in range(3):
+        q = np.concatenate([synth.random_queries(460 + t, n // 2, 19), synth.planted_queries(470 + t, n - n // 2, 19, txt)])
+        kmers = [bytes(r) for r in q]
+        sp, ep, cnt, _ = oi.search_list(kmers)
+        hit_off, pos, _ = oi.batch_locate(sp, ep)
+        lst = awfm.KmerSearchList(n)
+        lst.fill(kmers)
+        jobs.append({"cnt": cnt, "hit_off": hit_off, "pos": pos, "list": lst, "errors": [], "rounds": 0})
+
+    def work(job):
+        try:
+            for _ in range(25):
+                rc = awfm.parallel_search_locate(ix, job["list"], 2)
+                if rc != awfm.AwFmSuccess:
+                    raise AssertionError(f"awFmParallelSearchLocate returned {rc}")
+                if not np.array_equal(job["list"].counts(), job["cnt"]):
+                    raise AssertionError(f"round {job['rounds']}: counts differ from the oracle")
+                for i in range(0, n, 37):
+                    if not np.array_equal(job["list"].positions(i), job["pos"][int(job["hit_off"][i]):int(job["hit_off"][i + 1])]):
+                        raise AssertionError(f"round {job['rounds']}: positions of k-mer {i} differ from the oracle")
+                job["rounds"] += 1
+        except Exception as e:  # noqa: BLE001  (reported by the main thread)
+            job["errors"].append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(job,)) for job in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not any(t.is_alive() for t in threads), "a caller did not come back"
+    for i, job in enumerate(jobs):
+        assert not job["errors"] and job["rounds"] == 25, f"caller {i}: {job['errors']}"
+    g = awfm.GpuIndex(ix, acquire=True)  # the explicit way: complete
+    assert g.deep_seed_k == 11 and g.has_dense_sa, g.describe()
+    awfm.parallel_search_locate(ix, jobs[0]["list"], 2)  # ... and the drop-in call through the complete image
+    assert np.array_equal(jobs[0]["list"].counts(), jobs[0]["cnt"])
+    for i in range(0, n, 37):
+        assert np.array_equal(jobs[0]["list"].positions(i), jobs[0]["pos"][int(jobs[0]["hit_off"][i]):int(jobs[0]["hit_off"][i + 1])])
+    g.handle = None
+    for job in jobs:
+        job["list"].dealloc()
+    ix.dealloc()
