@@ -442,7 +442,7 @@ static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKm
   pthread_mutex_unlock(&stageLock);
   AwFmGpuIndex *images[AWFM_MAX_IMAGES];
   /* without an explicit device list a small batch is one chunk on one lane: splitting it would only add launches */
-  const char *deviceList = getenv("AWFM_GPU_DEVICES");
+  const char *deviceList = awfmKnob(AWFM_KNOB_DEVICES);
   const bool oneShard = !(deviceList && *deviceList) && n < AWFM_MIN_SHARDED_LIST;
   const int numImages = awfmGpuIndexAcquireAll(index, images, oneShard ? 1 : AWFM_MAX_IMAGES);
   if (numImages <= 0) {
@@ -451,7 +451,7 @@ static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKm
     return AwFmGeneralFailure;
   }
   uint64_t chunk = AWFM_AOS_CHUNK_DEFAULT;
-  if (getenv("AWFM_GPU_AOS_CHUNK") && strtoull(getenv("AWFM_GPU_AOS_CHUNK"), NULL, 10) > 0) chunk = strtoull(getenv("AWFM_GPU_AOS_CHUNK"), NULL, 10);
+  if (awfmKnob(AWFM_KNOB_AOS_CHUNK) && strtoull(awfmKnob(AWFM_KNOB_AOS_CHUNK), NULL, 10) > 0) chunk = strtoull(awfmKnob(AWFM_KNOB_AOS_CHUNK), NULL, 10);
   const uint64_t even = (n + (uint64_t)numImages - 1) / (uint64_t)numImages; /* a list of less than a chunk per image: even shares */
   if (chunk > even) chunk = even;
   struct laneJob jobs[AWFM_MAX_IMAGES];
@@ -459,7 +459,7 @@ static enum AwFmReturnCode runBatch(const struct AwFmIndex *index, struct AwFmKm
   bool spawned[AWFM_MAX_IMAGES] = {false};
   for (int i = 0; i < numImages; i++)
     jobs[i] = (struct laneJob){images[i], list->kmerSearchData, n, chunk, (unsigned)i, (unsigned)numImages, numThreads > 0 ? numThreads : 1,
-                               locate, getenv("AWFM_GPU_DIAG") != NULL && strstr(getenv("AWFM_GPU_DIAG"), "aos_trace") != NULL, AwFmSuccess, {0}};
+                               locate, awfmKnob(AWFM_KNOB_DIAG) != NULL && strstr(awfmKnob(AWFM_KNOB_DIAG), "aos_trace") != NULL, AwFmSuccess, {0}};
   for (int i = 1; i < numImages; i++) spawned[i] = pthread_create(&threads[i], NULL, runLane, &jobs[i]) == 0;
   runLane(&jobs[0]);
   int firstFailed = jobs[0].rc != AwFmSuccess ? 0 : -1;

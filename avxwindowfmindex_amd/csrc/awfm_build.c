@@ -121,7 +121,7 @@ enum AwFmReturnCode awfmCreateIndexWithFasta(struct AwFmIndex **index, const str
    * build (no device, not enough device memory: about 25 bytes per position, 37 from 2^32-1 positions on, where
    * suffix positions and ranks are 64-bit). */
   if (sequenceLength >= AWFM_GPU_BUILD_MIN_LENGTH && config->suffixArrayCompressionRatio != 0) {
-    const char *hostOnly = getenv("AWFM_HOST_BUILD");
+    const char *hostOnly = awfmKnob(AWFM_KNOB_HOST_BUILD);
     if (!(hostOnly && *hostOnly && *hostOnly != '0') && awfmGpuDeviceCount() > 0) {
       const enum AwFmReturnCode rc =
           awfmGpuCreateIndexWithFasta(index, config, sequence, sequenceLength, 0, fileSrc, -1, fastaVector);

@@ -60,7 +60,7 @@ inline void setError(const char *what) { awfmGpuSetError(what); }
 constexpr unsigned kBlockShift = 7;       /* 128 positions per device block */
 constexpr unsigned kBlockMask = 127;
 constexpr unsigned kSlices = 4;           /* 32-position slices per device block */
-constexpr unsigned kNucSuperShift = 32;   /* positions per nucleotide superblock: 2^32 ($AWFM_GPU_NUC_SUPER_SHIFT: tests) */
+constexpr unsigned kNucSuperShift = 32;   /* positions per nucleotide superblock: 2^32 ($AWFM_GPU_DIAG nuc_super_shift: tests) */
 constexpr unsigned kMaxNucSuper = 64;     /* nucleotide images of up to 2^38 positions */
 constexpr unsigned kAminoSuperShift = 16; /* positions per amino superblock: 2^16 */
 constexpr unsigned kAminoSuperStride = 24;
@@ -986,7 +986,7 @@ struct AwFmGpuIndex {
  * $AWFM_GPU_DIAG = "key=value,key=value,..." (include/awfm_gpu.h lists the keys).  Returns the value of `key` (up to 31
  * characters, in a buffer of the calling thread), or NULL. */
 inline const char *awfmGpuDiag(const char *key) {
-  const char *env = getenv("AWFM_GPU_DIAG");
+  const char *env = awfmKnob(AWFM_KNOB_DIAG);
   if (!env) return nullptr;
   static thread_local char value[32];
   const size_t keyLen = strlen(key);

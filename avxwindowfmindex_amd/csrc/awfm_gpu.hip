@@ -45,7 +45,7 @@ void launchPairSearchKernel(const AwFmGpuIndex *g, const DevIndex &dev, hipStrea
                             const unsigned long long *off, uint32_t fixedLength, unsigned long long nq, ulonglong2 *rng,
                             uint32_t *dCounts) {
   /* the 16 pair bases of every superblock in dynamic LDS, as in the ordered kernel (same box, 10^8 random 21-mers:
-   * 11.4-11.7 ms against 12.8-12.9 ms with the bases read from memory; $AWFM_GPU_PAIR_SUPER=lds|global) */
+   * 11.4-11.7 ms against 12.8-12.9 ms with the bases read from memory) */
   const bool inLds = NARROW && awfmPairSuperInLds(g);
   const size_t lds = inLds ? (size_t)g->dev.numPairSuper * 64u : 0u;
   DevIndex view = dev;
@@ -295,7 +295,7 @@ enum AwFmReturnCode awfmGpuCountHost(AwFmGpuIndex *g, const uint8_t *chars, cons
 /* How many hits' positions may be resident on the device at once: $AWFM_GPU_HIT_BUDGET_BYTES / 8, else a quarter of
  * the free device memory (what this image's own position buffer holds counted as free), between 2^25 and 2^31 hits. */
 uint64_t awfmGpuHitBudget(const AwFmGpuIndex *g) {
-  if (const char *env = getenv("AWFM_GPU_HIT_BUDGET_BYTES")) {
+  if (const char *env = awfmKnob(AWFM_KNOB_HIT_BUDGET_BYTES)) {
     const unsigned long long bytes = strtoull(env, nullptr, 10);
     if (bytes) return bytes / 8 > 1024 ? bytes / 8 : 1024;
   }

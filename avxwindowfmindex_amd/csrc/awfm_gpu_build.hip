@@ -19,7 +19,7 @@
  *      device image is kept and registered for awFmParallelSearch*.
  * Suffix positions and ranks are 32-bit on the device while bwtLength <= 2^32 - 2 and 64-bit beyond (every kernel
  * of the suffix sort is a template over the position type; the doubling keys are then 128-bit, sorted over the bits
- * in use); $AWFM_GPU_BUILD_WIDE=1 selects the 64-bit instantiation on any text (tests).
+ * in use); $AWFM_GPU_DIAG build_wide=1 selects the 64-bit instantiation on any text (tests).
  */
 #include <cstdio>
 #include <cstdlib>
@@ -862,7 +862,7 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
     BUILD_TRY(hipGetLastError());
     BUILD_TRY(awfmGpuSetupSync());
     clock_gettime(CLOCK_MONOTONIC, &tc);
-    if (getenv("AWFM_VERBOSE"))
+    if (awfmKnob(AWFM_KNOB_VERBOSE))
       fprintf(stderr, "[awfm deep seed] level %u -> %u: %llu entries, allocation %.3f s, kernel %.3f s\n", L, L + levels, (unsigned long long)outLen,
               (double)(tb.tv_sec - ta.tv_sec) + 1e-9 * (double)(tb.tv_nsec - ta.tv_nsec), (double)(tc.tv_sec - tb.tv_sec) + 1e-9 * (double)(tc.tv_nsec - tb.tv_nsec));
     cur.reset();
@@ -958,7 +958,7 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
     return AwFmGeneralFailure;
   }
   if (device < 0) {
-    const char *env = getenv("AWFM_GPU_DEVICE");
+    const char *env = awfmKnob(AWFM_KNOB_DEVICE);
     if (env && *env)
       device = atoi(env);
     else if (hipGetDevice(&device) != hipSuccess)
@@ -969,7 +969,7 @@ extern "C" enum AwFmReturnCode awfmGpuCreateIndexWithFasta(struct AwFmIndex **in
     awfmGpuSetError("awfmGpuCreateIndex: hipSetDevice failed");
     return AwFmGeneralFailure;
   }
-  const bool verbose = getenv("AWFM_VERBOSE") != nullptr;
+  const bool verbose = awfmKnob(AWFM_KNOB_VERBOSE) != nullptr;
   const bool amino = config->alphabetType == AwFmAlphabetAmino;
   /* 32-bit suffix positions and ranks while they fit ($AWFM_GPU_DIAG build_wide=1: 64-bit ones on any text, for tests) */
   const char *wideEnv = awfmGpuDiag("build_wide");

@@ -400,7 +400,7 @@ static enum AwFmReturnCode buildDenseSa(AwFmGpuIndex *image, bool capped, DenseB
         hipLaunchKernelGGL(denseSaJumpKernel, dim3((unsigned)image->numCUs * 8u), dim3(256), 0, awfmGpuSetupStream, dense, park, n, counter + 1);
       if (hipGetLastError() != hipSuccess || awfmGpuSetupToHost(&left, counter + 1, 8) != hipSuccess) rc = AwFmGeneralFailure;
     }
-    if (getenv("AWFM_VERBOSE") && parked)
+    if (awfmKnob(AWFM_KNOB_VERBOSE) && parked)
       fprintf(stderr, "[awfm full suffix array] %llu of %llu walks parked after %u LF steps (%s); %u rounds of pointer jumping, %llu left\n",
               parked, n, stepCap, listed ? "in a list" : "an entry per position, walked twice", rounds, left);
     if (rc == AwFmSuccess && left != 0) { /* (64 rounds look 2^64 steps ahead: not reached by an index that is one) */
@@ -490,7 +490,7 @@ static enum AwFmReturnCode buildDenseSaWide(AwFmGpuIndex *image, bool capped, De
                        (const ulonglong2 *)entry[rounds & 1u], entry[(rounds & 1u) ^ 1u], parked, n, counter + 1);
     if (hipGetLastError() != hipSuccess || awfmGpuSetupToHost(&left, counter + 1, 8) != hipSuccess) rc = AwFmGeneralFailure;
   }
-  if (getenv("AWFM_VERBOSE") && parked)
+  if (awfmKnob(AWFM_KNOB_VERBOSE) && parked)
     fprintf(stderr, "[awfm full suffix array, 40-bit entries] %llu of %llu walks parked after %u LF steps; %u rounds of pointer jumping, %llu left\n", parked, n,
             stepCap, rounds, left);
   if (rc == AwFmSuccess && left != 0) { /* (64 rounds look 2^64 steps ahead: not reached by an index that is one) */
@@ -541,7 +541,7 @@ enum AwFmReturnCode awfmGpuBuildDenseSaAuto(const AwFmGpuIndex *g, void **arrayO
   *bytesOut = 0;
   *secondsOut = 0.0;
   bool want = false, automatic = false;
-  const char *env = getenv("AWFM_GPU_DENSE_SA");
+  const char *env = awfmKnob(AWFM_KNOB_DENSE_SA);
   if (env && !strcmp(env, "auto")) { /* the automatic construction whatever the image's size (tests) */
     want = automatic = g->dev.saRatio > 1u;
   } else if (env) {

@@ -130,7 +130,7 @@ AwFmGpuIndex *awfmGpuIndexAdopt(const struct AwFmIndex *index, int device, void 
   g->dPrefix = dPrefix;
   g->deviceBytes = deviceBytes;
   fillDevIndex(g, index, superShift, sentinelPos);
-  if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
+  if (const char *env = awfmKnob(AWFM_KNOB_FORCE_WIDE)) g->forceWide = atoi(env) != 0;
   (void)applyPairFromEnv(g);     /* first: the deeper table's next-step bits are computed through the pair image */
   (void)applyDeepSeedFromEnv(g); /* optional accelerator: on failure the image simply has no deeper table */
   (void)awfmGpuApplyDenseSaAuto(g);  /* the same: without it a locate walks */
@@ -203,7 +203,7 @@ static enum AwFmReturnCode createImage(const struct AwFmIndex *index, int device
     return AwFmGeneralFailure;
   }
   if (device < 0) {
-    const char *env = getenv("AWFM_GPU_DEVICE");
+    const char *env = awfmKnob(AWFM_KNOB_DEVICE);
     if (env && *env) {
       device = atoi(env);
     } else if (hipGetDevice(&device) != hipSuccess) {
@@ -297,7 +297,7 @@ static enum AwFmReturnCode createImage(const struct AwFmIndex *index, int device
 #undef TRY_OR_FAIL
 
   fillDevIndex(g, index, superShift, sentinelPos);
-  if (const char *env = getenv("AWFM_GPU_FORCE_WIDE")) g->forceWide = atoi(env) != 0;
+  if (const char *env = awfmKnob(AWFM_KNOB_FORCE_WIDE)) g->forceWide = atoi(env) != 0;
   (void)applyPairFromEnv(g); /* without it (no memory left) searches simply take one step per read */
   if (deferAccelerators) {
     /* the image is usable now (general kernel from the index's own table, pair steps, LF walk); the deeper table and the full
@@ -426,7 +426,7 @@ void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
  * list is packed / scattered on the host while others are on the PCIe bus or in the kernels (awfm_batch.c) */
 static int aosDevices(int *devs, int maxOut) {
   int n = 0;
-  const char *env = getenv("AWFM_GPU_DEVICES");
+  const char *env = awfmKnob(AWFM_KNOB_DEVICES);
   if (env && !strcmp(env, "all")) {
     const int count = awfmGpuDeviceCount();
     for (int d = 0; d < count && n < maxOut; d++) devs[n++] = d;
@@ -482,7 +482,7 @@ int awfmGpuIndexAcquireAll(const struct AwFmIndex *index, AwFmGpuIndex **out, in
   /* -1 = the default device: $AWFM_GPU_DEVICE, else the calling thread's current device.  Entries are keyed by
    * the resolved ordinal, so a list that changes between calls never hands out another device's image. */
   int fallback = 0;
-  if (const char *env = getenv("AWFM_GPU_DEVICE"); env && *env) fallback = atoi(env);
+  if (const char *env = awfmKnob(AWFM_KNOB_DEVICE); env && *env) fallback = atoi(env);
   else if (hipGetDevice(&fallback) != hipSuccess) fallback = 0;
   for (int i = 0; i < numDevs; i++)
     if (devs[i] < 0) devs[i] = fallback;
@@ -627,7 +627,7 @@ static enum AwFmReturnCode buildDeepSeed(AwFmGpuIndex *g, unsigned deepK, AwFmGp
   to->deepNext = next > 0 ? 1u : 0u;
   to->numDeepBig = numBig;
   to->deepSeconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-  if (getenv("AWFM_VERBOSE"))
+  if (awfmKnob(AWFM_KNOB_VERBOSE))
     fprintf(stderr, "[awfm deeper table] depth %u, entry format %u: %.2f GB in %.2f s; next-step bits %s; %u entries with long ranges\n", deepK, format,
             (double)bytes * 1e-9, to->deepSeconds, next > 0 ? "yes" : "no", numBig);
   return AwFmSuccess;
@@ -698,7 +698,7 @@ static enum AwFmReturnCode applyDeepSeedFromEnv(AwFmGpuIndex *g) {
  * and the memory that is free); 0: none */
 static unsigned chooseDeepSeedK(const AwFmGpuIndex *g, std::string &notes) {
   int deepK = 0;
-  if (const char *env = getenv(g->amino ? "AWFM_GPU_AMINO_DEEP_SEED_K" : "AWFM_GPU_DEEP_SEED_K")) {
+  if (const char *env = awfmKnob(g->amino ? AWFM_KNOB_AMINO_DEEP_SEED_K : AWFM_KNOB_DEEP_SEED_K)) {
     deepK = atoi(env); /* 0: none */
   } else if (g->amino) {
     /* Automatic, amino: an image of >= 2^26 positions whose own table is shallower gets the deepest table of up to 7
@@ -749,7 +749,7 @@ static unsigned chooseDeepSeedK(const AwFmGpuIndex *g, std::string &notes) {
  * the 64 B of the one-letter blocks) and halves the dependent block reads of hits-only searches and of the LF walk. */
 static enum AwFmReturnCode applyPairFromEnv(AwFmGpuIndex *g) {
   if (g->amino) return AwFmSuccess;
-  if (const char *env = getenv("AWFM_GPU_PAIR"))
+  if (const char *env = awfmKnob(AWFM_KNOB_PAIR))
     if (atoi(env) == 0) return AwFmSuccess;
   DeviceGuard guard(g->device);
   const enum AwFmReturnCode rc = awfmGpuApplyPairImage(g, true);

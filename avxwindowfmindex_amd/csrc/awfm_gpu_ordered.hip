@@ -171,7 +171,7 @@ static bool orderedApplies(const AwFmGpuIndex *g, bool hasOffsets, uint32_t fixe
   }
   int mode = g->orderMode; /* -1 auto, 0 off, 1 on */
   if (mode < 0) {
-    if (const char *env = getenv("AWFM_GPU_ORDERED")) mode = atoi(env) != 0;
+    if (const char *env = awfmKnob(AWFM_KNOB_ORDERED)) mode = atoi(env) != 0;
   }
   if (mode < 0) {
     /* worth its sort and its extra launches only when the batch is large and the image far exceeds the L2s.  Against
@@ -191,7 +191,7 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, unsigne
   *numBigOut = 0;
   if (!g || !table || format == 0u || deepK == 0) return 0;
   if (g->amino ? deepK > 7u : (!g->dev.pairBlocks || deepK > 16u)) return 0;
-  if (getenv("AWFM_GPU_DEEP_NEXT") && atoi(getenv("AWFM_GPU_DEEP_NEXT")) == 0) return 0; /* comparison runs */
+  if (awfmKnob(AWFM_KNOB_DEEP_NEXT) && atoi(awfmKnob(AWFM_KNOB_DEEP_NEXT)) == 0) return 0; /* comparison runs */
   DeviceGuard guard(g->device);
   if (format == 2u) { /* (nucleotide: awfmGpuBuildDeepSeedTable) the table is complete but for its bits; *bigOut holds the long lengths */
     unsigned *dCount = nullptr;
@@ -607,7 +607,7 @@ constexpr unsigned kPredictHoldoff = 8, kPredictSamples = 16384, kPredictNumberM
  * (nothing waits for one); the caller holds orderMutex.  $AWFM_GPU_LOOKUP_PREDICT=0: always both (round 4). */
 static int predictFront(AwFmGpuIndex *g, unsigned fixedLength, unsigned chooseOf = kPredictSamples) {
   AwFmGpuIndex::LookupPredict &p = g->predict;
-  if (const char *env = getenv("AWFM_GPU_LOOKUP_PREDICT"))
+  if (const char *env = awfmKnob(AWFM_KNOB_LOOKUP_PREDICT))
     if (atoi(env) == 0) return kFrontBoth;
   if (!p.verdictHost) return kFrontBoth;
   /* the newest verdict: {tag of its search, k-mers of its sample alive}; the tag says what the host needs to know about that
@@ -664,7 +664,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   const bool narrow = awfmImageNarrow(g);
   const bool lookupCapable = !packed && !touch && table == g->dev.deepSeed && g->dev.deepNarrow != 0u &&
                              !(sparse && sparse->kmers && !sparse->count);
-  const char *lookupEnv = getenv("AWFM_GPU_LOOKUP_FIRST"); /* 0: never, 1: whenever it applies; unset: by a sample of the batch */
+  const char *lookupEnv = awfmKnob(AWFM_KNOB_LOOKUP_FIRST); /* 0: never, 1: whenever it applies; unset: by a sample of the batch */
   const bool lookupWanted = lookupCapable && (lookupEnv ? atoi(lookupEnv) != 0 : nq >= (1ull << 20));
   const size_t numbersAt = recsAt + alignUp256(nq * 8u);
   const size_t total = numbersAt + (lookupWanted ? alignUp256(nq * 4u) : 0u);
@@ -898,7 +898,7 @@ static const uint2 *ensureLengthTables(AwFmGpuIndex *g) {
   p->lengthDepths = need;
   p->lengthTableBytes = bytes;
   p->lengthTableBuildSeconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-  if (getenv("AWFM_VERBOSE"))
+  if (awfmKnob(AWFM_KNOB_VERBOSE))
     fprintf(stderr, "[awfm length tables] lengths 1..%u: %.2f GB in %.3f s\n", need, (double)bytes * 1e-9, p->lengthTableBuildSeconds);
   return (const uint2 *)table;
 }
@@ -923,7 +923,7 @@ static int wideBucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCh
    * kernel is the slower one even when half the k-mers survive (8..30-mers, half drawn from the text: 6.4 against 9.8 ms;
    * 18..30-mers: 9.1 against 10.7 ms) */
   constexpr unsigned kSamples = 16384, kChooseOf = 3u * kSamples;
-  const char *mixedEnv = getenv("AWFM_GPU_MIXED_LOOKUP");
+  const char *mixedEnv = awfmKnob(AWFM_KNOB_MIXED_LOOKUP);
   const bool mixedCapable = off && !touch && !g->amino && g->dev.deepSeed && g->dev.deepNarrow != 0u &&
                             g->dev.deepK >= 2u && g->dev.deepK <= 16u && g->dev.seedK < g->dev.deepK &&
                             !(sparse && sparse->kmers && !sparse->count) /* results in search order owe an entry to every k-mer */;
@@ -1087,8 +1087,8 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
      * $AWFM_GPU_MIXED_LOOKUP=0 and a seed-order path that is switched off keep the general kernel. */
     int mode = g->orderMode;
     if (mode < 0)
-      if (const char *env = getenv("AWFM_GPU_ORDERED")) mode = atoi(env) != 0;
-    const char *mixedEnv = getenv("AWFM_GPU_MIXED_LOOKUP");
+      if (const char *env = awfmKnob(AWFM_KNOB_ORDERED)) mode = atoi(env) != 0;
+    const char *mixedEnv = awfmKnob(AWFM_KNOB_MIXED_LOOKUP);
     lookupAlways = off && !touch && mode != 0 && !g->amino && nq < 0xFFFFFFFFull && g->dev.deepSeed &&
                    g->dev.deepNarrow != 0u && g->dev.deepK >= 2u && g->dev.deepK <= 16u && g->dev.seedK < g->dev.deepK &&
                    !(sparse && sparse->kmers && !sparse->count) && (mixedEnv ? atoi(mixedEnv) != 0 : nq >= (1ull << 20));
@@ -1100,7 +1100,7 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
   g->orderTimedFront = false;
   g->orderTimedKernel = false;
   for (int i = 0; i < 4; i++) g->orderTiming[i] = nullptr;
-  if (getenv("AWFM_GPU_TIME_ORDERED")) { /* measurement hook: this search's entry of the timing log */
+  if (awfmKnob(AWFM_KNOB_TIME_ORDERED)) { /* measurement hook: this search's entry of the timing log */
     DeviceGuard guard(g->device);
     const unsigned at = (unsigned)(g->orderLogCount % AwFmGpuIndex::kOrderLogMax);
     if (at >= g->orderLog.size()) g->orderLog.resize(at + 1u);
@@ -1156,7 +1156,7 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
   if (!g->amino || !awfmImageNarrow(g) || g->dev.deepK == 0u || g->dev.deepNarrow == 0u || g->dev.deepSeed == nullptr) return 0;
   if (fixedLength < g->dev.deepK || fixedLength > kMaxLength || fixedLength - g->dev.deepK > 12u || nq >= 0xFFFFFFFFull) return 0;
   if (!(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP2)) return 0;
-  const char *env = getenv("AWFM_GPU_AMINO_LOOKUP");
+  const char *env = awfmKnob(AWFM_KNOB_AMINO_LOOKUP);
   if (env ? atoi(env) == 0 : nq < (1ull << 20)) return 0;
   const bool forced = env && atoi(env) == 1;
   constexpr unsigned kSamples = 16384;
@@ -1280,7 +1280,7 @@ int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
     return 0;
   if (!(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP4)) return 0;
   if (!off && (fixedLength == 0u || fixedLength > 32u)) return 0;
-  const char *env = getenv("AWFM_GPU_EXACT_LOOKUP");
+  const char *env = awfmKnob(AWFM_KNOB_EXACT_LOOKUP);
   if (env ? atoi(env) == 0 : nq < (1ull << 18)) return 0;
   const bool forced = env && atoi(env) == 1;
   const uint2 *lengthTable = nullptr;
@@ -1290,7 +1290,7 @@ int awfmGpuExactLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
       std::lock_guard<std::mutex> lock(p->lengthMutex);
       if (p->dLengthTable && p->lengthDepths >= g->dev.deepK - 1u) lengthTable = (const uint2 *)p->dLengthTable;
     }
-    const char *mixedEnv = getenv("AWFM_GPU_MIXED_LOOKUP");
+    const char *mixedEnv = awfmKnob(AWFM_KNOB_MIXED_LOOKUP);
     /* (awfmGpuSearch allocates nothing by itself: the tables are used when a hits-only mixed-length batch has built them,
      * or built here when asked for by $AWFM_GPU_EXACT_LOOKUP=1; advisor, round 5) */
     if (!lengthTable && forced && !(mixedEnv && atoi(mixedEnv) == 0)) lengthTable = ensureLengthTables(g);

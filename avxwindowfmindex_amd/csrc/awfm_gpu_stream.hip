@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256)
 }
 
 struct StreamSlot {
-  hipEvent_t uploaded = nullptr, searched = nullptr, located = nullptr, done = nullptr, doneB = nullptr;
+  hipEvent_t uploaded = nullptr, searched = nullptr, located = nullptr, done = nullptr;
   /* device */
   void *dIn = nullptr;       /* packed words or ASCII as uploaded */
   void *dChars = nullptr;    /* ASCII the search reads (packed input only) */
@@ -123,11 +123,10 @@ struct StreamSlot {
 constexpr int kStreamSlots = 3; /* chunk t uploads and searches, t-1 walks and downloads, t-2 is with the caller */
 
 struct AwFmGpuStreamState {
-  /* downloads: one stream per slot and a second one for the upper half of a large copy -- a single stream moves
-   * device-to-host bytes at well under half the rate the link gives several (measured: 10^8 planted 21-mers, 1.2 GB
-   * back, 69 ms through one download stream against 36 ms) */
-  hipStream_t copyIn = nullptr, compute = nullptr, copyOut[kStreamSlots] = {}, copyOutB = nullptr;
-  hipStream_t slotStream[kStreamSlots] = {}; /* $AWFM_GPU_STREAM_MODE=slots: everything of a chunk on its slot's stream */
+  /* one stream per slot: three chunks' copies and kernels are in flight at a time, so the downloads of neighbouring chunks
+   * overlap (a single download stream moved device-to-host bytes at well under half the rate the link gives several:
+   * 10^8 planted 21-mers, 1.2 GB back, 69 ms against 36 ms) */
+  hipStream_t slotStream[kStreamSlots] = {}; /* everything of a chunk -- upload, kernels, download -- on its slot's stream */
   bool streamsReady = false;
   StreamSlot slot[kStreamSlots];
 };
@@ -142,7 +141,7 @@ void freeSlot(StreamSlot &s) {
   void *host[] = {s.hIn, s.hCounts, s.hTotal, s.hPositions, s.hOffsets, s.hHitKmers, s.hListOffsets};
   for (void *p : host)
     if (p) (void)hipHostFree(p);
-  hipEvent_t events[] = {s.uploaded, s.searched, s.located, s.done, s.doneB};
+  hipEvent_t events[] = {s.uploaded, s.searched, s.located, s.done};
   for (hipEvent_t e : events)
     if (e) (void)hipEventDestroy(e);
   s = StreamSlot();
@@ -162,7 +161,7 @@ enum AwFmReturnCode ensureSlot(StreamSlot &s, size_t kmers, size_t inBytesPerKme
                                bool stageInput) {
   if (!s.ready) {
     /* published only when every create succeeded: a slot half set up is torn down, not run on null events */
-    hipEvent_t *events[] = {&s.uploaded, &s.searched, &s.located, &s.done, &s.doneB};
+    hipEvent_t *events[] = {&s.uploaded, &s.searched, &s.located, &s.done};
     hipError_t e = hipSuccess;
     for (hipEvent_t *ev : events)
       if (e == hipSuccess && !*ev) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
@@ -297,8 +296,7 @@ bool isPinned(const void *p) {
 void awfmGpuStreamStateFree(AwFmGpuIndex *g) {
   if (!g || !g->streamState) return;
   AwFmGpuStreamState &state = *g->streamState;
-  hipStream_t streams[] = {state.copyIn, state.compute, state.copyOut[0], state.copyOut[1], state.copyOut[2], state.copyOutB,
-                           state.slotStream[0], state.slotStream[1], state.slotStream[2]};
+  hipStream_t streams[] = {state.slotStream[0], state.slotStream[1], state.slotStream[2]};
   for (hipStream_t s : streams)
     if (s) {
       (void)hipStreamSynchronize(s);
@@ -464,9 +462,8 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
   AwFmGpuStreamState &st = *g->streamState;
   StreamSlot *slots = st.slot;
   if (!st.streamsReady) {
-    /* all nine streams or none: a later failure must not leave a guard satisfied with null streams behind it */
-    hipStream_t *streams[] = {&st.copyIn, &st.compute, &st.copyOut[0], &st.copyOut[1], &st.copyOut[2], &st.copyOutB,
-                              &st.slotStream[0], &st.slotStream[1], &st.slotStream[2]};
+    /* all three streams or none: a later failure must not leave a guard satisfied with null streams behind it */
+    hipStream_t *streams[] = {&st.slotStream[0], &st.slotStream[1], &st.slotStream[2]};
     hipError_t e = hipSuccess;
     for (hipStream_t *p : streams)
       if (e == hipSuccess && !*p) e = hipStreamCreateWithFlags(p, hipStreamNonBlocking);
@@ -480,10 +477,9 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
     }
     st.streamsReady = true;
   }
-  /* $AWFM_GPU_STREAM_MODE=split: one upload stream, one kernel stream, download streams; default: everything of a
-   * chunk on its slot's own stream (measured, 10^8 planted 21-mers located: 43-58 ms against 60 ms; random ones 23-25
-   * against 22.8 ms) */
-  const bool perSlot = true; /* (round 6: the split mode is no longer selectable) */
+  /* Everything of a chunk runs on its slot's own stream (rounds 3-5 also carried a mode with one upload stream, one kernel
+   * stream and download streams: 10^8 planted 21-mers located in 60 ms against 43-58 ms this way, random ones 22.8 against
+   * 23-25; retired in round 6) */
   const size_t inBytesPerKmer = packed ? 8 : kmerLength;
   const bool stage = !isPinned(input);
   const bool narrowCounts = g->dev.bwtLength < (1ull << 32);
@@ -492,10 +488,6 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
   const u64 numChunks = (numKmers + chunkKmers - 1) / chunkKmers;
   enum AwFmReturnCode rc = AwFmSuccess;
   auto drain = [&]() {
-    (void)hipStreamSynchronize(st.copyIn);
-    (void)hipStreamSynchronize(st.compute);
-    for (int i = 0; i < kStreamSlots; i++) (void)hipStreamSynchronize(st.copyOut[i]);
-    (void)hipStreamSynchronize(st.copyOutB);
     for (int i = 0; i < kStreamSlots; i++) (void)hipStreamSynchronize(st.slotStream[i]);
   };
 #define STEP_TRY(call)                    \
@@ -540,7 +532,7 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
         awfmParallelFor(hostThreads, bytes, copyRange, &ctx);
         src = (const uint8_t *)s.hIn;
       }
-      hipStream_t in = perSlot ? st.slotStream[t % kStreamSlots] : st.copyIn, comp = perSlot ? st.slotStream[t % kStreamSlots] : st.compute;
+      hipStream_t in = st.slotStream[t % kStreamSlots], comp = in;
       STEP_TRY(hipMemcpyAsync(s.dIn, src, bytes, hipMemcpyHostToDevice, in));
       STEP_TRY(hipEventRecord(s.uploaded, in));
       STEP_TRY(hipStreamWaitEvent(comp, s.uploaded, 0));
@@ -591,9 +583,7 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
     }
     if (t >= 1 && t - 1 < numChunks) { /* ---- B(t-1): locate; download ---- */
       StreamSlot &s = slots[(t - 1) % kStreamSlots];
-      hipStream_t out = perSlot ? st.slotStream[(t - 1) % kStreamSlots] : st.copyOut[(t - 1) % kStreamSlots];
-      hipStream_t comp = perSlot ? st.slotStream[(t - 1) % kStreamSlots] : st.compute;
-      bool split = false, direct = false;
+      hipStream_t out = st.slotStream[(t - 1) % kStreamSlots], comp = out;
       if (sparse) {
         STEP_TRY(hipEventSynchronize(s.searched));
         u64 listed = *(const uint32_t *)(s.hTotal + 1);
@@ -641,25 +631,14 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
         s.windowed = s.total > hitBudget;
         if (s.total && !s.windowed) {
           STEP_RC(ensurePositions(s, s.total));
-          /* $AWFM_GPU_STREAM_DIRECT: the finish kernel stores into the page-locked staging itself (awfmGpuLocateTo) instead
-           * of a copy afterwards; measured the same (10^8 planted 21-mers: 46-54 ms either way) */
-          direct = false;
+          /* (the finish kernel storing into the page-locked staging itself instead of a copy afterwards measured the same:
+           * 10^8 planted 21-mers, 46-54 ms either way) */
           STEP_RC(awfmGpuLocateTo(g, (const struct AwFmSearchRange *)s.dRanges, (const uint64_t *)s.dHitOffsets, s.n, s.total,
-                                  (uint64_t *)s.dPositions, direct ? (uint64_t *)s.hPositions : (uint64_t *)s.dPositions, comp));
+                                  (uint64_t *)s.dPositions, (uint64_t *)s.dPositions, comp));
         }
         STEP_TRY(hipEventRecord(s.located, comp));
         STEP_TRY(hipStreamWaitEvent(out, s.located, 0));
-        split = !perSlot && s.total >= (1ull << 20) && !s.windowed;
-        const u64 lower = direct || s.windowed ? 0 : (split ? s.total / 2 : s.total);
-        if (direct) split = false;
-        if (lower) STEP_TRY(hipMemcpyAsync(s.hPositions, s.dPositions, lower * 8, hipMemcpyDeviceToHost, out));
-        if (split) {
-          STEP_TRY(hipStreamWaitEvent(st.copyOutB, s.located, 0));
-          STEP_TRY(hipMemcpyAsync(s.hPositions + lower, (const u64 *)s.dPositions + lower, (s.total - lower) * 8,
-                                  hipMemcpyDeviceToHost, st.copyOutB));
-          STEP_TRY(hipEventRecord(s.doneB, st.copyOutB));
-          STEP_TRY(hipStreamWaitEvent(out, s.doneB, 0)); /* `done` covers both halves */
-        }
+        if (s.total && !s.windowed) STEP_TRY(hipMemcpyAsync(s.hPositions, s.dPositions, s.total * 8, hipMemcpyDeviceToHost, out));
       } else {
         STEP_TRY(hipStreamWaitEvent(out, s.searched, 0));
       }
@@ -679,7 +658,7 @@ static enum AwFmReturnCode streamBatch(AwFmGpuIndex *g, const void *input, int p
         /* Hit-budgeted hand-over: the chunk's k-mers go to the sink in consecutive groups whose hit lists fit one window
          * (half the budget); a k-mer whose own list is longer goes alone, slice by slice (same firstKmer, numKmers = 1,
          * counts[0] its full count every time). */
-        hipStream_t ws = perSlot ? st.slotStream[(t - lag) % kStreamSlots] : st.compute;
+        hipStream_t ws = st.slotStream[(t - lag) % kStreamSlots];
         if ((s.n + 1) * 8 > s.hCapOffsets) {
           if (s.hOffsets) (void)hipHostFree(s.hOffsets);
           s.hOffsets = nullptr;

@@ -8,6 +8,7 @@
 
 #include "AwFmIndex.h"
 #include "awfm_gpu.h"
+#include "awfm_knobs.h"
 
 #define AWFM_VERSION_NUMBER 8u          /* ref src/AwFmIndexStruct.h:9 */
 #define AWFM_FEATURE_BIT_FASTA_VECTOR 0 /* ref src/AwFmIndexStruct.h:10 */

@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      /* (Round 5 measured what bounds these steps: with the survivors dropped -- $AWFM_GPU_MIXED_DROP_SURVIVORS, wrong results --
+      /* (Round 5 measured what bounds these steps: with the survivors dropped (a diagnostic build, wrong results)
        * the kernel takes 2.8 of its 6.7 ms per 10^8 8..30-mers, so the steps of 3.3 * 10^7 survivors take 3.9: 1.2 * 10^8 block
        * lines at 3.1 * 10^7 a second.  TWO k-mers per group of 4 lanes, the loads of both requested before either is ranked --
        * 32 chains a wave, at 4 and at 5 waves per SIMD -- took 6.74 and 6.60 ms: the same.  The chains in flight are not the

@@ -124,7 +124,7 @@ __host__ __device__ inline unsigned orderStartDepth(unsigned len, unsigned seedK
  *
  * The order the search needs is coarse: what is in flight on an XCD must stay within what its L2 holds, and with the k-mers
  * partitioned by the leading 11 bits of their table index (2048 buckets, any order inside a bucket) orderedSearchKernel
- * takes 4.59 instead of 4.41 ms per 10^8 random 21-mers (12 bits 4.54, 10 bits 4.83: $AWFM_GPU_ORDER_KEY_BITS on the
+ * takes 4.59 instead of 4.41 ms per 10^8 random 21-mers (12 bits 4.54, 10 bits 4.83, measured on round 3's
  * sorted path).  A 2048-way partition is ONE pass whose stores still leave a workgroup as runs of 64 bytes, where the
  * 15-bit order took two radix-sort passes over (key, record) pairs after an encoding pass:
  *   encodeCodesKernel   k-mer characters -> 2-bit codes (8 B per k-mer, original order) + bucket histogram (skipped for

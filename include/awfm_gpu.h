@@ -148,7 +148,7 @@ int awfmGpuIndexIsWide(const AwFmGpuIndex *g); /* 1 when searches on this image 
  * resident and is the one awFmParallelSearch* will use.  Suffix positions and ranks are 32-bit on the device while
  * bwtLength <= 2^32-2 (about 25 bytes of HBM per position at the peak) and 64-bit beyond (about 37 bytes per
  * position: a 4.4 Gbp text builds in 12 s, a two-strand human genome of 6.2 Gbp fits one MI355X);
- * $AWFM_GPU_BUILD_WIDE=1 selects the 64-bit suffix sort on any text (tests). */
+ * $AWFM_GPU_DIAG build_wide=1 selects the 64-bit suffix sort on any text (tests). */
 enum AwFmReturnCode awfmGpuCreateIndex(struct AwFmIndex **index, const struct AwFmIndexConfiguration *config,
                                        const uint8_t *sequence, uint64_t sequenceLength, int sequenceOnDevice,
                                        const char *fileSrc, int device);
