@@ -51,19 +51,22 @@ __device__ __forceinline__ void aminoDecode(const AminoShared &t, const Bytes &b
   }
 }
 
-template <unsigned K>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(6, 8))) /* 6 workgroups' LDS fit a CU: 6 waves per SIMD, 80 registers */
+/* NARROW = false (round 6): images of 2^32 positions and more -- 64-bit ranges in the slots and the steps, the table's entries in
+ * their packed form (awfm_device.h: aminoWidePack); 4 waves per SIMD (the LDS of 5 workgroups would fit a CU, the registers of 5 waves do not) */
+template <unsigned K, bool NARROW = true>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(NARROW ? 6 : 4, 8))) /* 6 workgroups' LDS fit a CU: 6 waves per SIMD, 80 registers */
     aminoLookupSearchKernel(const DevIndex ix, const unsigned char *__restrict__ chars, const unsigned long long numQueries,
                             const unsigned *__restrict__ sampleAlive, const unsigned samples, ulonglong2 *__restrict__ ranges,
                             unsigned *__restrict__ counts, const SparseOut sparse, unsigned long long *__restrict__ leftover,
                             unsigned *__restrict__ leftoverCount, unsigned *__restrict__ keptCounters) {
   constexpr int G = 4;
-  typedef unsigned pos_t;
+  typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
   __shared__ AminoShared sAmino;
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
   __shared__ unsigned long long sLead[4][kAminoSlots];
-  __shared__ unsigned sNum[4][kAminoSlots], sSp[4][kAminoSlots], sEp[4][kAminoSlots];
+  __shared__ unsigned sNum[4][kAminoSlots];
+  __shared__ pos_t sSp[4][kAminoSlots], sEp[4][kAminoSlots];
   constexpr unsigned kHitBuffer = 32;
   __shared__ unsigned sHitKmers[4][kHitBuffer];
   __shared__ unsigned long long sHitRanges[4][kHitBuffer][2];
@@ -144,16 +147,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
       const bool inBatch = t + i < numQueries;
       /* alive after the entry: its range holds something and -- tables with next-step bits -- still will after the next
        * letter (the first of the lead's: bits 4..0; a k-mer that ends at the table has no next letter) */
-      const unsigned length = aminoDeepLength(ix, entry[i]);
-      const bool survives = inBatch && !bad[i] && length != 0u && (K == DK || aminoDeepNextBit(ix, entry[i], (unsigned)lead[i] & 31u));
+      const unsigned long long length = aminoDeepLength(ix, entry[i]);
+      const bool survives = inBatch && !bad[i] && length != 0ull && (K == DK || aminoDeepNextBit(ix, entry[i], (unsigned)lead[i] & 31u));
       const unsigned long long smask = __ballot(survives);
       const unsigned rank = stotal + (unsigned)__popcll(smask & ((1ull << lane) - 1ull));
       stotal += (unsigned)__popcll(smask);
       if (survives && rank < kAminoSlots) {
         sLead[w][rank] = lead[i];
         sNum[w][rank] = (unsigned)(t + i);
-        sSp[w][rank] = entry[i].x;
-        sEp[w][rank] = entry[i].x + length - 1u;
+        const unsigned long long first = aminoDeepSp(ix, entry[i]);
+        sSp[w][rank] = (pos_t)first;
+        sEp[w][rank] = (pos_t)(first + length - 1ull);
       }
       /* the general kernel's: a character among the table's that is not one of the 20 letters; a survivor without a slot */
       const bool left = inBatch && (bad[i] || (survives && rank >= kAminoSlots));
@@ -194,7 +198,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80), amdgp
       if (live) take();
       while (__ballot(live) != 0ull) { /* wave-uniform */
         if (live && pos >= 0) { /* (a k-mer in a group is alive: sp <= ep) */
-          aminoStepAny<G, true>(ix, sC, sAmino, sMask, gl, (unsigned)rem & 31u, sp, ep);
+          aminoStepAny<G, NARROW>(ix, sC, sAmino, sMask, gl, (unsigned)rem & 31u, sp, ep);
           pos--;
           rem >>= 5;
         }

@@ -167,14 +167,28 @@ __device__ __forceinline__ ulonglong2 lengthEntryOpen(const DevIndex &ix, unsign
  * letter.  A length of 0xFFF stands for "4095 or more": the exact one is deepBigBySp[sp >> 11] (two ranges that long begin
  * 4095 or more apart). */
 constexpr unsigned kAminoDeepLengthBits = 12, kAminoDeepLengthMask = (1u << kAminoDeepLengthBits) - 1u, kAminoDeepBigShift = kAminoDeepLengthBits - 1u;
-__device__ __forceinline__ unsigned aminoDeepLength(const DevIndex &ix, uint2 e) {
+/* Amino images that run 64-bit positions (2^32 positions and more; format 2 of DevIndex::deepNarrow, round 6) keep the 8 bytes:
+ * sp's bits 35..32 | length8 << 4 | next20 << 12 in the second word -- the next-letter bits where the narrow entries have them --;
+ * a length of 0xFF stands for "255 or more", the exact one is the 64-bit word deepBigBySp[sp >> 7] (two ranges that long begin
+ * 255 or more apart).  The bits are all set in a table built without them ($AWFM_GPU_DEEP_NEXT=0). */
+constexpr unsigned kAminoWideLengthMask = 0xFFu, kAminoWideBigShift = 7;
+__host__ __device__ inline uint2 aminoWidePack(unsigned long long sp, unsigned long long length, unsigned next20) {
+  const unsigned l8 = length < kAminoWideLengthMask ? (unsigned)length : kAminoWideLengthMask;
+  return make_uint2((unsigned)sp, ((unsigned)(sp >> 32) & 0xFu) | (l8 << 4) | (next20 << kAminoDeepLengthBits));
+}
+__device__ __forceinline__ unsigned long long aminoDeepSp(const DevIndex &ix, uint2 e) { return ix.deepNarrow == 2u ? deepWideSp(e) : (unsigned long long)e.x; }
+__device__ __forceinline__ unsigned long long aminoDeepLength(const DevIndex &ix, uint2 e) {
+  if (ix.deepNarrow == 2u) { /* uniform */
+    const unsigned length = (e.y >> 4) & kAminoWideLengthMask;
+    return length == kAminoWideLengthMask ? ((const unsigned long long *)ix.deepBigBySp)[deepWideSp(e) >> kAminoWideBigShift] : (unsigned long long)length;
+  }
   if (!ix.deepNext) return e.y;
   const unsigned length = e.y & kAminoDeepLengthMask;
   return length == kAminoDeepLengthMask ? ix.deepBigBySp[e.x >> kAminoDeepBigShift] : length;
 }
 /* may a k-mer whose next letter (index 0..19; anything else: an ambiguity letter, which has no bit) go on from the entry? */
 __device__ __forceinline__ bool aminoDeepNextBit(const DevIndex &ix, uint2 e, unsigned letter) {
-  return !ix.deepNext || letter >= 20u || ((e.y >> (kAminoDeepLengthBits + letter)) & 1u) != 0u;
+  return (ix.deepNarrow != 2u && !ix.deepNext) || letter >= 20u || ((e.y >> (kAminoDeepLengthBits + letter)) & 1u) != 0u;
 }
 /* {sp, ep} from the two words of an 8-byte entry (format 1 or 2); *next16 (may be NULL): the pair steps that keep the range
  * non-empty (all of them when the table has no such bits) */
@@ -206,7 +220,8 @@ __device__ __forceinline__ ulonglong2 deepSeedEntry(const DevIndex &ix, unsigned
 __device__ __forceinline__ ulonglong2 aminoDeepSeedEntry(const DevIndex &ix, unsigned long long i) {
   if (ix.deepNarrow) {
     const uint2 e = ((const uint2 *)ix.deepSeed)[i];
-    return make_ulonglong2((unsigned long long)e.x, (unsigned long long)e.x + aminoDeepLength(ix, e) - 1ull);
+    const unsigned long long sp = aminoDeepSp(ix, e);
+    return make_ulonglong2(sp, sp + aminoDeepLength(ix, e) - 1ull);
   }
   return ix.deepSeed[i];
 }

@@ -519,10 +519,10 @@ __global__ void __launch_bounds__(256) lengthFromSeedKernel(const ulonglong2 *__
  * one backward step with `letter` (0..19: the index puts the leftmost character first, ref src/AwFmKmerTable.c:37-51), or
  * that entry unchanged when its range is already empty.  One group of 4 lanes per entry (aminoStepAny: the step of the
  * search kernel); consecutive entries have consecutive parents, whose ranges are neighbours in the BWT. */
-template <bool OUT8>
+template <int OUT> /* 0: {sp, ep}; 1: {sp32, length32}; 2: aminoWidePack with every next-letter bit set, the long lengths in big[sp >> 7] */
 __global__ void __launch_bounds__(kThreads)
     aminoDeepSeedLevelKernel(const DevIndex ix, const ulonglong2 *__restrict__ parentLevel, u64 parentLen, u64 outLen,
-                             ulonglong2 *__restrict__ out) {
+                             ulonglong2 *__restrict__ out, u64 *__restrict__ big) {
   constexpr int G = 4;
   __shared__ u64 sC[24];
   __shared__ AminoShared sAmino;
@@ -540,8 +540,15 @@ __global__ void __launch_bounds__(kThreads)
     /* a query stops at its first invalid range and keeps it (ref src/AwFmParallelSearch.c:293-294) */
     if (sp <= ep) aminoStepAny<G, false>(ix, sC, sAmino, sMask, g, letter, sp, ep);
     if (g == 0) {
-      if (OUT8) ((uint2 *)out)[e] = make_uint2((unsigned)sp, (unsigned)(ep + 1ull - sp));
-      else out[e] = make_ulonglong2(sp, ep);
+      if (OUT == 1) {
+        ((uint2 *)out)[e] = make_uint2((unsigned)sp, (unsigned)(ep + 1ull - sp));
+      } else if (OUT == 2) {
+        const u64 length = ep + 1ull - sp;
+        ((uint2 *)out)[e] = aminoWidePack(sp, length, 0xFFFFFu);
+        if (length >= kAminoWideLengthMask) big[sp >> kAminoWideBigShift] = length;
+      } else {
+        out[e] = make_ulonglong2(sp, ep);
+      }
     }
   }
 }
@@ -803,12 +810,12 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
   const ulonglong2 *parent = g->dev.seed;
   const bool narrow = awfmImageNarrow(g);
   /* the table's entries (DevIndex::deepNarrow): 8 bytes {sp, length} where the image runs 32-bit positions (every amino
-   * image below 2^32), 8 bytes sp36 | length12 | next16 for the nucleotide images that run 64-bit ones, up to 2^36 positions
-   * (round 6), 16 bytes {sp, ep} for everything else */
-  const unsigned format = g->dev.bwtLength < (1ull << 32) && (narrow || g->amino) ? 1u
-                          : (!g->amino && formatOut && bigOut && g->dev.bwtLength < (1ull << kDeepWideMaxBits) ? 2u : 0u);
+   * image below 2^32), 8 bytes sp36 | length12 | next16 (nucleotide) or sp36 | length8 | next20 (amino) for the images that run
+   * 64-bit ones, up to 2^36 positions (round 6), 16 bytes {sp, ep} for everything else */
+  const unsigned format = g->dev.bwtLength < (1ull << 32) && narrow ? 1u
+                          : (formatOut && bigOut && g->dev.bwtLength < (1ull << kDeepWideMaxBits) ? 2u : 0u);
   if (format == 2u) {
-    const size_t bigBytes = ((size_t)(g->dev.bwtLength >> kDeepWideBigShift) + 2u) * 8u;
+    const size_t bigBytes = ((size_t)(g->dev.bwtLength >> (g->amino ? kAminoWideBigShift : kDeepWideBigShift)) + 2u) * 8u;
     if (!big.alloc(bigBytes)) return false;
     BUILD_TRY(awfmGpuSetupMemset(big.p, 0, bigBytes));
   }
@@ -849,10 +856,12 @@ bool awfmGpuBuildDeepSeedTable(const AwFmGpuIndex *g, unsigned deepK, void **tab
     } else if (g->amino) {
       const u64 aminoBlocks = (outLen + kThreads / 4 - 1) / (kThreads / 4);
       const unsigned aminoGrid = (unsigned)(aminoBlocks < resident ? aminoBlocks : resident);
-      if (out == 1u)
-        hipLaunchKernelGGL((aminoDeepSeedLevelKernel<true>), dim3(aminoGrid), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, parent, len, outLen, nxt.as<ulonglong2>());
+      if (out == 2u)
+        hipLaunchKernelGGL((aminoDeepSeedLevelKernel<2>), dim3(aminoGrid), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
+      else if (out == 1u)
+        hipLaunchKernelGGL((aminoDeepSeedLevelKernel<1>), dim3(aminoGrid), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
       else
-        hipLaunchKernelGGL((aminoDeepSeedLevelKernel<false>), dim3(aminoGrid), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, parent, len, outLen, nxt.as<ulonglong2>());
+        hipLaunchKernelGGL((aminoDeepSeedLevelKernel<0>), dim3(aminoGrid), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
     } else if (out == 2u)
       hipLaunchKernelGGL((deepSeedLevelKernel<kUnroll, 2>), dim3(grid), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, parent, len, outLen, nxt.as<ulonglong2>(), bigAt);
     else if (out == 1u)

@@ -619,7 +619,7 @@ static enum AwFmReturnCode buildDeepSeed(AwFmGpuIndex *g, unsigned deepK, AwFmGp
   to->deepBig = big;
   to->deepBytes = bytes;
   to->deepBigBytes = !big ? 0u
-                     : format == 2u ? ((g->dev.bwtLength >> kDeepWideBigShift) + 2u) * 8u
+                     : format == 2u ? ((g->dev.bwtLength >> (g->amino ? kAminoWideBigShift : kDeepWideBigShift)) + 2u) * 8u
                                     : ((g->dev.bwtLength >> (g->amino ? kAminoDeepBigShift : kDeepBigShift)) + 5u) * 4u;
   to->deepTransient = peak > bytes ? peak - bytes : 0;
   to->deepK = deepK;
@@ -707,7 +707,7 @@ static unsigned chooseDeepSeedK(const AwFmGpuIndex *g, std::string &notes) {
      * 7-mer) and the rest start two steps further on.  Exact: an entry is what the stepping holds after those steps. */
     size_t freeBytes = 0, totalBytes = 0;
     DeviceGuard guard(g->device);
-    if (g->dev.bwtLength >= (1ull << 26) && g->dev.bwtLength < (1ull << 32) && g->dev.seedK >= 2 && hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) {
+    if (g->dev.bwtLength >= (1ull << 26) && g->dev.bwtLength < (1ull << kDeepWideMaxBits) && g->dev.seedK >= 2 && hipMemGetInfo(&freeBytes, &totalBytes) == hipSuccess) {
       unsigned long long entries = 1;
       for (unsigned k = 1; k <= 7u; k++) {
         entries *= 20ull;

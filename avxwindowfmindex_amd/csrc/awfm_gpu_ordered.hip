@@ -193,7 +193,7 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, unsigne
   if (g->amino ? deepK > 7u : (!g->dev.pairBlocks || deepK > 16u)) return 0;
   if (awfmKnob(AWFM_KNOB_DEEP_NEXT) && atoi(awfmKnob(AWFM_KNOB_DEEP_NEXT)) == 0) return 0; /* comparison runs */
   DeviceGuard guard(g->device);
-  if (format == 2u) { /* (nucleotide: awfmGpuBuildDeepSeedTable) the table is complete but for its bits; *bigOut holds the long lengths */
+  if (format == 2u) { /* (awfmGpuBuildDeepSeedTable) the table is complete but for its bits; *bigOut holds the long lengths */
     unsigned *dCount = nullptr;
     if (hipMalloc((void **)&dCount, 16) != hipSuccess) {
       (void)hipGetLastError();
@@ -206,9 +206,16 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, unsigne
       dev.deepNarrow = 2u;
       dev.deepBigBySp = (const unsigned *)*bigOut;
       dev.pairSuperInLds = 0u;
-      constexpr int threads = orderedThreads(true);
-      const unsigned grid = residentGrid(g, deepNextKernel<false>, 0, threads);
-      hipLaunchKernelGGL(deepNextKernel<false>, dim3(grid ? grid : 1u), dim3(threads), 0, awfmGpuSetupStream, dev, (uint2 *)table, 1ull << (2u * deepK), (unsigned *)nullptr, dCount);
+      if (g->amino) {
+        unsigned long long numEntries = 1;
+        for (unsigned k = 0; k < deepK; k++) numEntries *= 20ull;
+        const unsigned grid = residentGrid(g, aminoDeepNextKernel<false>, 0, kThreads);
+        hipLaunchKernelGGL(aminoDeepNextKernel<false>, dim3(grid ? grid : 1u), dim3(kThreads), 0, awfmGpuSetupStream, dev, (uint2 *)table, numEntries, (unsigned *)nullptr, dCount);
+      } else {
+        constexpr int threads = orderedThreads(true);
+        const unsigned grid = residentGrid(g, deepNextKernel<false>, 0, threads);
+        hipLaunchKernelGGL(deepNextKernel<false>, dim3(grid ? grid : 1u), dim3(threads), 0, awfmGpuSetupStream, dev, (uint2 *)table, 1ull << (2u * deepK), (unsigned *)nullptr, dCount);
+      }
       ok = hipGetLastError() == hipSuccess && awfmGpuSetupSync() == hipSuccess && awfmGpuSetupToHost(&numBig, dCount, 4) == hipSuccess;
     }
     (void)hipFree(dCount);
@@ -234,8 +241,8 @@ int awfmGpuDeepSeedAddNext(AwFmGpuIndex *g, void *table, unsigned deepK, unsigne
     unsigned numBig = 0;
     bool ok = awfmGpuSetupMemset(dBig, 0, (bigWords + 4u) * 4u) == hipSuccess;
     if (ok) {
-      const unsigned grid = residentGrid(g, aminoDeepNextKernel, 0, kThreads);
-      hipLaunchKernelGGL(aminoDeepNextKernel, dim3(grid ? grid : 1u), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, (uint2 *)table, numEntries, dBig, dBig + bigWords);
+      const unsigned grid = residentGrid(g, aminoDeepNextKernel<true>, 0, kThreads);
+      hipLaunchKernelGGL(aminoDeepNextKernel<true>, dim3(grid ? grid : 1u), dim3(kThreads), 0, awfmGpuSetupStream, g->dev, (uint2 *)table, numEntries, dBig, dBig + bigWords);
       ok = hipGetLastError() == hipSuccess && awfmGpuSetupSync() == hipSuccess &&
            awfmGpuSetupToHost(&numBig, dBig + bigWords, 4) == hipSuccess;
     }
@@ -1136,15 +1143,15 @@ static int orderedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, 
 
 /* ------------------------------------------------------------------ amino: lookup first (awfm_amino_lookup_kernel.h) */
 
-template <unsigned K>
+template <unsigned K, bool NARROW>
 static void launchAminoLookupAt(unsigned len, unsigned grid, hipStream_t s, const DevIndex &dev, const uint8_t *dChars, unsigned long long nq,
                                 const unsigned *sampleAlive, unsigned samples, ulonglong2 *rng, unsigned *dCounts, const SparseOut &sparse,
                                 unsigned long long *leftover, unsigned *leftoverCount, unsigned *kept) {
   if (len == K)
-    hipLaunchKernelGGL((aminoLookupSearchKernel<K>), dim3(grid), dim3(256), 0, s, dev, dChars, nq, sampleAlive, samples, rng, dCounts, sparse,
+    hipLaunchKernelGGL((aminoLookupSearchKernel<K, NARROW>), dim3(grid), dim3(256), 0, s, dev, dChars, nq, sampleAlive, samples, rng, dCounts, sparse,
                        leftover, leftoverCount, kept);
   else if constexpr (K > 2u)
-    launchAminoLookupAt<K - 1u>(len, grid, s, dev, dChars, nq, sampleAlive, samples, rng, dCounts, sparse, leftover, leftoverCount, kept);
+    launchAminoLookupAt<K - 1u, NARROW>(len, grid, s, dev, dChars, nq, sampleAlive, samples, rng, dCounts, sparse, leftover, leftoverCount, kept);
 }
 
 /* Hits-only search of a large fixed-length amino batch through the device-only deeper table: 1 = searched, 0 = does not
@@ -1153,7 +1160,8 @@ static void launchAminoLookupAt(unsigned len, unsigned grid, hipStream_t s, cons
 static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t fixedLength, unsigned long long nq,
                              ulonglong2 *rng, uint32_t *dCounts, bool rangesOfHitsOnly, const SparseOut *sparse) {
   constexpr unsigned kMaxLength = 19; /* the table's 7 characters + 12 in front of them (5 bits each in one word) */
-  if (!g->amino || !awfmImageNarrow(g) || g->dev.deepK == 0u || g->dev.deepNarrow == 0u || g->dev.deepSeed == nullptr) return 0;
+  const bool narrow = awfmImageNarrow(g);
+  if (!g->amino || g->dev.deepK == 0u || g->dev.deepNarrow != (narrow ? 1u : 2u) || g->dev.deepSeed == nullptr) return 0;
   if (fixedLength < g->dev.deepK || fixedLength > kMaxLength || fixedLength - g->dev.deepK > 12u || nq >= 0xFFFFFFFFull) return 0;
   if (!(g->kernel == AWFM_GPU_KERNEL_AUTO || g->kernel == AWFM_GPU_KERNEL_GROUP2)) return 0;
   const char *env = awfmKnob(AWFM_KNOB_AMINO_LOOKUP);
@@ -1237,23 +1245,31 @@ static int aminoLookupSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dCha
   const SparseOut out = sparse ? *sparse : SparseOut();
   if (lookupRuns) {
     const unsigned long long rounds = (nq + 1023ull) / 1024ull; /* a workgroup takes 1024 k-mers a round */
-    unsigned grid = residentGrid(g, aminoLookupSearchKernel<10u>);
+    unsigned grid = narrow ? residentGrid(g, aminoLookupSearchKernel<10u, true>) : residentGrid(g, aminoLookupSearchKernel<10u, false>);
     if (rounds < grid) grid = (unsigned)rounds;
-    launchAminoLookupAt<kMaxLength>(fixedLength, grid ? grid : 1u, s, g->dev, dChars, nq, sampleAlive, chooseOf, rng, dCounts, out, leftover, leftoverCount, kept);
+    if (narrow) launchAminoLookupAt<kMaxLength, true>(fixedLength, grid ? grid : 1u, s, g->dev, dChars, nq, sampleAlive, chooseOf, rng, dCounts, out, leftover, leftoverCount, kept);
+    else launchAminoLookupAt<kMaxLength, false>(fixedLength, grid ? grid : 1u, s, g->dev, dChars, nq, sampleAlive, chooseOf, rng, dCounts, out, leftover, leftoverCount, kept);
     AMINO_TRY(hipGetLastError());
   }
   if (generalRuns) { /* the whole batch through the general kernel when the sample says so (it returns at once otherwise) */
-    const unsigned full = residentGrid(g, searchKernel<true, 2, false, false, true>);
-    hipLaunchKernelGGL((searchKernel<true, 2, false, false, true>), dim3(full), dim3(kThreads), 0, s, g->dev, dChars,
-                       (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
-                       (const unsigned char *)nullptr, 0u, 0u, 0ull, (const unsigned *)nullptr, out, sampleAlive, chooseOf);
+#define AMINO_GENERAL(NR, ...)                                                                                                     \
+  do {                                                                                                                             \
+    const unsigned grid__ = residentGrid(g, searchKernel<true, 2, false, false, NR, __VA_ARGS__>);                                 \
+    hipLaunchKernelGGL((searchKernel<true, 2, false, false, NR, __VA_ARGS__>), dim3(grid__), dim3(kThreads), 0, s, g->dev, dChars, \
+                       (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr, AMINO_GENERAL_ARGS); \
+  } while (0)
+#define AMINO_GENERAL_ARGS (const unsigned char *)nullptr, 0u, 0u, 0ull, (const unsigned *)nullptr, out, sampleAlive, chooseOf
+    if (narrow) AMINO_GENERAL(true, false);
+    else AMINO_GENERAL(false, false);
+#undef AMINO_GENERAL_ARGS
     AMINO_TRY(hipGetLastError());
   }
   if (lookupRuns) { /* what the lookup kernel left: the last *leftoverCount records of the list */
-    const unsigned tail = residentGrid(g, searchKernel<true, 2, false, false, true, true>);
-    hipLaunchKernelGGL((searchKernel<true, 2, false, false, true, true>), dim3(tail), dim3(kThreads), 0, s, g->dev, dChars,
-                       (const unsigned long long *)nullptr, fixedLength, nq, rng, dCounts, (unsigned long long *)nullptr,
-                       (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out, (const unsigned *)nullptr, 0u);
+#define AMINO_GENERAL_ARGS (const unsigned char *)leftover, 8u, 0u, nq, (const unsigned *)leftoverCount, out, (const unsigned *)nullptr, 0u
+    if (narrow) AMINO_GENERAL(true, true);
+    else AMINO_GENERAL(false, true);
+#undef AMINO_GENERAL_ARGS
+#undef AMINO_GENERAL
     AMINO_TRY(hipGetLastError());
   }
   AMINO_TRY(slotScope.end());

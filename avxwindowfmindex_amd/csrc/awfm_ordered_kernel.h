@@ -1604,6 +1604,7 @@ __global__ void __launch_bounds__(orderedThreads(true)) __attribute__((amdgpu_nu
  * becomes {sp, length12 | next20 << 12}, bit c set when the range still holds a position after one more step with letter c.
  * One group of 4 lanes per entry, 20 steps each (aminoStepAny: the search kernels' step); lengths of 4095 and more go to
  * bigBySp[sp >> 11]. */
+template <bool NARROW>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
     aminoDeepNextKernel(const DevIndex ix, uint2 *__restrict__ table, const unsigned long long numEntries, unsigned *__restrict__ bigBySp,
                         unsigned *__restrict__ numBig) {
@@ -1622,19 +1623,28 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80)))
        base += waveStride) {
     const unsigned long long at = base + lane / G;
     const uint2 e = at < numEntries ? table[at] : make_uint2(1u, 0u);
-    if (e.y != 0u) { /* whole groups of 4 lanes */
+    /* NARROW: the finished table is {sp, length}; otherwise aminoWidePack's entries with every bit set and the long lengths
+     * already beside them (ix.deepNarrow == 2, ix.deepBigBySp: aminoDeepSeedLevelKernel<2> wrote both) */
+    const unsigned long long first = NARROW ? (unsigned long long)e.x : deepWideSp(e);
+    const unsigned long long length = NARROW ? (unsigned long long)e.y : aminoDeepLength(ix, e);
+    if (length != 0ull) { /* whole groups of 4 lanes */
       unsigned next20 = 0;
       for (unsigned letter = 0; letter < 20u; letter++) {
-        PositionType<true>::type sp = e.x, ep = e.x + e.y - 1u;
-        aminoStepAny<G, true>(ix, sC, sAmino, sMask, gl, letter, sp, ep);
+        typename PositionType<NARROW>::type sp = (typename PositionType<NARROW>::type)first, ep = (typename PositionType<NARROW>::type)(first + length - 1ull);
+        aminoStepAny<G, NARROW>(ix, sC, sAmino, sMask, gl, letter, sp, ep);
         if (sp <= ep) next20 |= 1u << letter;
       }
       if (gl == 0) {
-        if (e.y >= kAminoDeepLengthMask) {
-          bigBySp[e.x >> kAminoDeepBigShift] = e.y;
-          atomicAdd(numBig, 1u);
+        if (NARROW) {
+          if (e.y >= kAminoDeepLengthMask) {
+            bigBySp[e.x >> kAminoDeepBigShift] = e.y;
+            atomicAdd(numBig, 1u);
+          }
+          table[at] = make_uint2(e.x, (e.y < kAminoDeepLengthMask ? e.y : kAminoDeepLengthMask) | next20 << kAminoDeepLengthBits);
+        } else {
+          if (length >= kAminoWideLengthMask) atomicAdd(numBig, 1u);
+          table[at] = make_uint2(e.x, (e.y & kAminoDeepLengthMask) | next20 << kAminoDeepLengthBits);
         }
-        table[at] = make_uint2(e.x, (e.y < kAminoDeepLengthMask ? e.y : kAminoDeepLengthMask) | next20 << kAminoDeepLengthBits);
       }
     }
   }

@@ -466,6 +466,40 @@ def test_cfg4_amino_10mers_counted_and_located(awfm, oracle, require_gpu):
         assert t.equal(hits.view(Q, 2)[has], ranges.view(Q, 2)[has])
         big.check_positions_spell(d_chars, None, K, Q, lens, d_pos[:total])
         big.check_sample_against_oracle(d_chars, None, K, Q, ranges, counts, hit_off, d_pos, exact_ranges=True)
+        # the LIST form bench.py times for this configuration (awfmGpuSearchHitsCompact + awfmGpuListLocateOnDevice on a stream
+        # of its own: aminoLookupSearchKernel appends the k-mers with hits, one launch sorts, sizes and locates the list), three
+        # consecutive calls and more until the lookup prediction launches that kernel alone -- entry by entry against the dense
+        # form above (round 5's verdict, item 5; ref src/AwFmParallelSearch.c:187-190, :327-361)
+        want = t.nonzero(counts).flatten()
+        cap = max(1024, -(-(int(want.numel()) * 5 // 4) // 1024) * 1024)
+        kmers = t.empty(cap, dtype=t.int32, device=big.dev)
+        lranges = t.empty(cap * 2, dtype=t.int64, device=big.dev)
+        skmers = t.empty(cap, dtype=t.int32, device=big.dev)
+        sranges = t.empty(cap * 2, dtype=t.int64, device=big.dev)
+        loff = t.empty(cap + 1, dtype=t.int64, device=big.dev)
+        num = t.zeros(1, dtype=t.int32, device=big.dev)
+        pos_list = t.empty(total + total // 8 + 64, dtype=t.int64, device=big.dev)
+        stream_obj = t.cuda.Stream()
+        fronts = []
+        for call in range(40):
+            pos_list.fill_(-1)
+            big.g.search_hits_compact(d_chars.data_ptr(), 0, K, Q, kmers.data_ptr(), lranges.data_ptr(), cap, num.data_ptr(), stream=stream_obj.cuda_stream)
+            big.g.list_locate_on_device(kmers.data_ptr(), lranges.data_ptr(), cap, num.data_ptr(), Q, skmers.data_ptr(), sranges.data_ptr(),
+                                        loff.data_ptr(), pos_list.numel(), pos_list.data_ptr(), stream_obj.cuda_stream)
+            t.cuda.synchronize()
+            fronts.append(big.g.last_lookup_front())
+            m = int(num.item())
+            assert m == want.numel(), (call, m, int(want.numel()))
+            assert t.equal(skmers[:m].to(t.int64), want), f"call {call}: the list names other k-mers than the dense form has hits for"
+            assert t.equal(sranges.view(cap, 2)[:m], ranges.view(Q, 2)[want]), f"call {call}: ranges"
+            assert t.equal(loff[:m + 1], t.cat([hit_off[want], hit_off[Q:Q + 1]])), f"call {call}: hit offsets"
+            assert int(loff[cap]) == total and t.equal(pos_list[:total], d_pos[:total]), f"call {call}: positions"
+            if call >= 2 and fronts[-3:] == [1, 1, 1]:
+                break
+        if (n, Q) == (200_000_000, 50_000_000):
+            assert big.g.deep_seed_k and big.g.last_ordered_kernel_is_lookup(), "the amino lookup kernel did not run"
+            assert fronts[-3:] == [1, 1, 1], f"the checked calls did not launch the lookup kernel alone (fronts launched: {fronts})"
+        del kmers, lranges, skmers, sranges, loff, pos_list
         # planted 10-mers: every one is found where it was taken from, every hit spells it
         Qp = Q // 5
         d_chars = _planted_batch(big, Qp, K, 114)

@@ -329,8 +329,10 @@ def test_amino_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, 
     g = awfm.GpuIndex(ix)
     before = g.device_bytes
     g.set_deep_seed(deep_k)
-    # (8-byte entries {sp, length12 | next20 << 12}; the lengths of 4095 and more have a table of their own, a word per 2^11 positions)
-    assert g.deep_seed_k == deep_k and g.device_bytes == before + 8 * 20 ** deep_k + 4 * ((ix.bwt_length >> 11) + 5)
+    # (8-byte entries {sp, length12 | next20 << 12}; the lengths of 4095 and more have a table of their own, a word per 2^11 positions;
+    # round 6, an image that runs 64-bit positions: sp36 | length8 | next20, the lengths of 255 and more in 64-bit words per 2^7 positions)
+    side = 8 * ((ix.bwt_length >> 7) + 2) if g.is_wide else 4 * ((ix.bwt_length >> 11) + 5)
+    assert g.deep_seed_k == deep_k and g.device_bytes == before + 8 * 20 ** deep_k + side
     ranges, ho, p = g.locate_host(chars, offsets)
     assert np.array_equal(ranges[:, 0], sp) and np.array_equal(ranges[:, 1], ep)
     assert np.array_equal(ho, hit_off) and np.array_equal(p, pos)
@@ -349,7 +351,7 @@ def test_amino_device_deep_seed_table_keeps_results_bit_identical(oracle, awfm, 
 
 
 @pytest.mark.parametrize("seed_k,deep_k,K,planted_share", [(2, 4, 6, 0.1), (3, 5, 10, 0.5), (2, 5, 5, 0.05), (1, 3, 15, 1.0), (2, 4, 16, 0.3)])
-def test_amino_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, monkeypatch, seed_k, deep_k, K, planted_share):
+def test_amino_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, wide, monkeypatch, seed_k, deep_k, K, planted_share):
     """aminoLookupSearchKernel forced on ($AWFM_GPU_AMINO_LOOKUP=1) for fixed-length amino batches: the deeper table is looked
     up while the k-mers are decoded, survivors are stepped out of LDS, what the kernel does not cover (characters that are not
     one of the 20 letters among the table's, more than 64 survivors in a round of 256: the all-planted case) goes to the
@@ -360,6 +362,7 @@ def test_amino_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, 
     n = 150000
     txt = synth.text(900 + K, n, synth.AMINO_ALPHABET).copy()
     txt[700:703] = ord("x")
+    txt[90000:96000] = np.frombuffer(b"wyvt" * 1500, np.uint8)  # a repeat: ranges of 1500 (the 8-bit lengths of the wide entries saturate)
     ix = awfm.create_index(txt, awfm.AwFmAlphabetAmino, 8, seed_k)
     oi = oracle.Index.wrap(oracle.AMINO, 8, seed_k, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
     g = awfm.GpuIndex(ix)
@@ -415,7 +418,7 @@ def test_amino_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, 
     ix.dealloc()
 
 
-def test_amino_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, monkeypatch):
+def test_amino_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, wide, monkeypatch):
     """without $AWFM_GPU_AMINO_LOOKUP a batch of 2^20 amino k-mers or more is sampled: random 8-mers nearly all end at the
     deeper table -> aminoLookupSearchKernel; k-mers drawn from the text all survive it -> the general kernel; counts against
     the oracle either way"""

@@ -103,8 +103,12 @@ def test_lookup_search_kernels_resources(kernel_metadata):
     assert k["vgpr"] <= 80 and k["spill"] <= 4 and k["scratch"] <= 16 and k["lds"] <= 16 * 1024
     # (round 5: a slot for every k-mer of a round -- 256 per wave, 25 KB of LDS per workgroup, and groups that refill as they
     # finish: 6 workgroups per CU, 6 waves per SIMD)
-    k = _one(kernel_metadata, r"[0-9]aminoLookupSearchKernelILj10EEE")
+    k = _one(kernel_metadata, r"[0-9]aminoLookupSearchKernelILj10ELb1EEE")
     assert k["vgpr"] <= 80 and k["spill"] == 0 and k["scratch"] == 0 and k["lds"] <= 26 * 1024
+    # its 64-bit instantiation (round 6): 4 waves per SIMD, nothing spilled, 64-bit ranges in the slots
+    k = _one(kernel_metadata, r"[0-9]aminoLookupSearchKernelILj10ELb0EEE")
+    print("aminoLookupSearchKernel<10, false>", k)
+    assert k["vgpr"] <= 128 and k["spill"] == 0 and k["scratch"] == 0 and k["lds"] <= 34 * 1024
     # mixedLookupSearchKernel (mixed-length batches): four decoded k-mers and their entries per lane, 256 survivor slots per
     # wave (every k-mer of a round may survive): 5 waves per SIMD (<= 96 registers; builds held to 80 measured slower), no
     # spills, 5 workgroups' LDS (30 KB each) per CU
