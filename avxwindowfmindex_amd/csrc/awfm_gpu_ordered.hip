@@ -19,6 +19,7 @@
 
 #include "awfm_ordered_kernel.h"
 #include "awfm_amino_lookup_kernel.h"
+#include "awfm_count_order_kernel.h"
 
 namespace {
 
@@ -136,7 +137,9 @@ template <bool NARROW>
 enum AwFmReturnCode launchBucketed(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars, uint32_t len, unsigned depth,
                                    const ulonglong2 *table, unsigned long long nq, const void *recs, const unsigned *bucketStart,
                                    const BucketFormat &fmt, const unsigned *generalCount, ulonglong2 *rng, uint32_t *dCounts,
-                                   bool packed, const OrderTouch *touch, const SparseOut *sparse) {
+                                   bool packed, const OrderTouch *touch, const SparseOut *sparse, bool countRecords = false) {
+  /* countRecords: `sparse` names the array of {k-mer number, count} the ordered kernel fills in search order; the caller takes
+   * them home and launches the general kernel over the last bucket itself (the last kernel of a search) */
   const bool pair = pairSteps(g);
   enum AwFmReturnCode rc;
   if (touch)
@@ -148,7 +151,7 @@ enum AwFmReturnCode launchBucketed(AwFmGpuIndex *g, hipStream_t s, const uint8_t
   else
     rc = pair ? launchOrderedKernel<NARROW, false, true, false, true>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse)
               : launchOrderedKernel<NARROW, false, false, false, true>(g, s, len, depth, table, nq, recs, generalCount, rng, dCounts, nullptr, bucketStart, fmt, sparse);
-  if (rc != AwFmSuccess || packed) return rc; /* bit-packed k-mers: every one of them is covered */
+  if (rc != AwFmSuccess || packed || countRecords) return rc; /* bit-packed k-mers: every one of them is covered */
   /* the last bucket: k-mers with ambiguity characters; a record of it is the query number alone */
   return launchLeftover<NARROW, false>(g, s, dChars, nullptr, len, nq, rng, dCounts, recs, 8u, 0u, generalCount, sparse);
 }
@@ -674,7 +677,13 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   const char *lookupEnv = awfmKnob(AWFM_KNOB_LOOKUP_FIRST); /* 0: never, 1: whenever it applies; unset: by a sample of the batch */
   const bool lookupWanted = lookupCapable && (lookupEnv ? atoi(lookupEnv) != 0 : nq >= (1ull << 20));
   const size_t numbersAt = recsAt + alignUp256(nq * 8u);
-  const size_t total = numbersAt + (lookupWanted ? alignUp256(nq * 4u) : 0u);
+  /* counts only, dense (awfm_count_order_kernel.h): the ordered kernel's {number, count} records in search order, and the
+   * same records by the leading bits of their numbers */
+  const bool countRecords = !sparse && !touch && dCounts && !rng;
+  const unsigned countShift = countOrderShift(nq), countBuckets = (unsigned)(((nq - 1ull) >> countShift) + 1ull);
+  const size_t countInAt = numbersAt + (lookupWanted ? alignUp256(nq * 4u) : 0u);
+  const size_t countOutAt = countInAt + (countRecords ? alignUp256(nq * 8u) : 0u);
+  const size_t total = countOutAt + (countRecords ? alignUp256(((size_t)countBuckets << countShift) * 8u) : 0u);
   if (orderBeginSlot(g, s) != hipSuccess) {
     setError("seed-order search: could not order the use of its scratch across streams");
     return -(int)AwFmGeneralFailure;
@@ -683,6 +692,8 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   if (!ensureOrderScratch(g, total)) return kOrderNoScratch;
   constexpr size_t kShareCountAt = 98304, kSampleAt = kShareCountAt + kShares * kShareCountStride * 4u; /* bytes into the counter block (tickets end at 65792) */
   constexpr size_t kKeptAt = 102400; /* lookupSearchKernel's survivor counters: kFusedCounters words a line apart */
+  constexpr size_t kCountCursorsAt = 66048; /* countScatterKernel's cursors (zeroed with the counters) */
+  static_assert(256 + 8 * kTicketGroups * 8 * 256 <= kCountCursorsAt && kCountCursorsAt + kCountBucketsMax * 4u <= kShareCountAt, "counter block");
   static_assert(256 + 8 * kTicketGroups * 8 * 256 <= kShareCountAt && kSampleAt + 4 <= kKeptAt && kKeptAt + kFusedCounters * 64u <= kOrderCounterBytes, "counter block");
 #define BUCKET_TRY(call)                    \
   do {                                      \
@@ -856,10 +867,29 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
                      lookupFirst || bySample ? (const unsigned *)shareCount : (const unsigned *)nullptr,
                      lookupFirst || bySample ? (const unsigned *)numbers : (const unsigned *)nullptr, sampleAlive, kSamples);
   BUCKET_TRY(hipGetLastError());
+  const SparseOut countOut{nullptr, 0u, (unsigned *)(w + countInAt), nullptr};
+  const SparseOut *results = countRecords ? &countOut : sparse;
   const enum AwFmReturnCode rc =
-      narrow ? launchBucketed<true>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse)
-                         : launchBucketed<false>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, sparse);
+      narrow ? launchBucketed<true>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, results, countRecords)
+                         : launchBucketed<false>(g, s, dChars, fixedLength, depth, table, nq, recs, bucketStart, fmt, generalCount, rng, dCounts, packed, touch, results, countRecords);
   if (rc != AwFmSuccess) return -(int)rc;
+  if (countRecords) { /* the counts home from search order (the number of records: where the general kernel's bucket begins) */
+    const unsigned *ordered = bucketStart + (1u << fmt.bucketBits);
+    unsigned *countCursors = (unsigned *)(w + kCountCursorsAt);
+    const unsigned long long tiles = (nq + kCountScatterTile - 1ull) / kCountScatterTile;
+    const unsigned scatterGrid = (unsigned)(tiles < (unsigned long long)g->numCUs * 4u ? tiles : (unsigned long long)g->numCUs * 4u);
+    hipLaunchKernelGGL(countScatterKernel, dim3(scatterGrid ? scatterGrid : 1u), dim3(kCountScatterThreads), 0, s, (const uint2 *)(w + countInAt), ordered,
+                       countShift, countBuckets, (uint2 *)(w + countOutAt), countCursors);
+    BUCKET_TRY(hipGetLastError());
+    hipLaunchKernelGGL(countPlaceKernel, dim3((countBuckets + 7u) / 8u * kCountPlaceParts * 8u), dim3(256), 0, s, (const uint2 *)(w + countOutAt),
+                       (const unsigned *)countCursors, countShift, countBuckets, dCounts);
+    BUCKET_TRY(hipGetLastError());
+    if (!packed) { /* the k-mers the order does not hold: stored at counts[number] */
+      const enum AwFmReturnCode left = narrow ? launchLeftover<true, false>(g, s, dChars, nullptr, fixedLength, nq, rng, dCounts, recs, 8u, 0u, generalCount, nullptr)
+                                              : launchLeftover<false, false>(g, s, dChars, nullptr, fixedLength, nq, rng, dCounts, recs, 8u, 0u, generalCount, nullptr);
+      if (left != AwFmSuccess) return -(int)left;
+    }
+  }
   BUCKET_TRY(slotScope.end());
 #undef BUCKET_TRY
   return 1;

@@ -1487,9 +1487,11 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
           hitFill = (unsigned)__builtin_amdgcn_readfirstlane((int)(hitFill + hits));
         }
       } else if (sparse.kmers) { /* results in search order: entry `at`, whatever the outcome */
-        if (mine) {
+        if (mine && sparse.ranges) {
           sparse.kmers[at - coveredFirst] = index; /* (a share of the order: its entries from 0) */
           sparse.ranges[at - coveredFirst] = sp <= ep ? make_ulonglong2((unsigned long long)sp, (unsigned long long)ep) : make_ulonglong2(1ull, 0ull);
+        } else if (mine) { /* counts only (awfm_count_order_kernel.h): {k-mer number, count}, taken home by two passes */
+          ((uint2 *)sparse.kmers)[at - coveredFirst] = make_uint2(index, sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u);
         }
       } else if (mine && sp <= ep) {
         if (ranges) ranges[index] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);

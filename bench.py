@@ -64,6 +64,8 @@ def parse():
                    help="strong (default; configs[2]: ONE batch of --queries k-mers, sharded over the --gpus ranks) | "
                         "weak: --queries k-mers per GPU")
     count = lambda v: int(float(v))  # noqa: E731  ("3e6" is accepted)
+    p.add_argument("--seed-bucket-pipeline", type=int, default=1,
+                   help="--sharding seed_bucket: 1 = two batches in flight (the exchange of one behind the search of the one before), 0 = one")
     p.add_argument("--sharding", choices=["contiguous", "seed_bucket"], default="contiguous",
                    help="how a batch is cut over the ranks: contiguous stretches of the batch (no exchange; the default), or -- dense-hit "
                         "fixed-length nucleotide batches, locate -- by seed bucket: every rank orders its stretch, the ranks exchange the records "
@@ -877,54 +879,83 @@ def seed_bucket_run(args, L, api, digest, shard, torch, np, dev, g, ix, d_chars,
     assert buckets, "--sharding seed_bucket: fixed-length nucleotide batches whose 8-byte records fit"
     cuts = shard.bucket_cuts(buckets, world)
     via_host = world > 1 and shard.timing_backend() != "nccl"
-    stream_obj = torch.cuda.Stream()
-    st = stream_obj.cuda_stream
-    d_recs = torch.empty(Q, dtype=torch.int64, device=dev)
-    d_bs = torch.empty(buckets + 3, dtype=torch.int32, device=dev)
-    d_gk = torch.empty(Q, dtype=torch.int32, device=dev)  # my own stretch's order: its tail are the general kernel's k-mers
-    d_gr = torch.empty(Q * 2, dtype=torch.int64, device=dev)
-    state = {}
+    # Two batches in flight (round 6): the FRONT of batch i + 1 -- order, the host's wait for the slice sizes, the exchange -- is
+    # issued behind the BACK of batch i -- search, hit offsets, positions -- on a stream of its own, so that the all-to-all (RCCL
+    # moves it with copy engines and a few CUs) runs while the search kernels have the chip.  --seed-bucket-pipeline 0: one batch
+    # at a time (front, then back, then the next front).
+    pipelined = bool(args.seed_bucket_pipeline)
+    front_obj, back_obj = torch.cuda.Stream(), torch.cuda.Stream()
+    sf, sb = front_obj.cuda_stream, back_obj.cuda_stream
 
-    def step():
-        g.order_kmers(d_chars.data_ptr(), K, Q, first, args.query_offset + batch_total, d_recs.data_ptr(), d_bs.data_ptr(), st)
-        g.search_general_records(d_chars.data_ptr(), K, Q, first, args.query_offset + batch_total, d_recs.data_ptr(), d_bs.data_ptr(), d_gk.data_ptr(),
-                                 d_gr.data_ptr(), st)
-        stream_obj.synchronize()
-        bs = d_bs.cpu().to(torch.int64)
-        with torch.cuda.stream(stream_obj):
+    def new_slot():
+        return {"recs": torch.empty(Q, dtype=torch.int64, device=dev), "bs": torch.empty(buckets + 3, dtype=torch.int32, device=dev),
+                "gk": torch.empty(Q, dtype=torch.int32, device=dev),  # my own stretch's order: its tail are the general kernel's k-mers
+                "gr": torch.empty(Q * 2, dtype=torch.int64, device=dev), "m": None, "p": None, "front_done": torch.cuda.Event(), "back_done": None}
+
+    slots = [new_slot() for _ in range(2 if pipelined else 1)]
+
+    def front(s):
+        if s["back_done"] is not None:
+            front_obj.wait_event(s["back_done"])  # the slot's arrays are still being searched by the batch before last
+        g.order_kmers(d_chars.data_ptr(), K, Q, first, args.query_offset + batch_total, s["recs"].data_ptr(), s["bs"].data_ptr(), sf)
+        g.search_general_records(d_chars.data_ptr(), K, Q, first, args.query_offset + batch_total, s["recs"].data_ptr(), s["bs"].data_ptr(),
+                                 s["gk"].data_ptr(), s["gr"].data_ptr(), sf)
+        front_obj.synchronize()  # the host wait of a step: the slice sizes of the exchange
+        bs = s["bs"].cpu().to(torch.int64)
+        with torch.cuda.stream(front_obj):
             if via_host:
-                mine, mstart = shard.bucket_exchange(d_recs.cpu(), bs[: buckets + 1], buckets, world, rank)
+                mine, mstart = shard.bucket_exchange(s["recs"].cpu(), bs[: buckets + 1], buckets, world, rank)
                 mine = mine.to(dev)
             else:
-                mine, mstart = shard.bucket_exchange(d_recs, bs[: buckets + 1], buckets, world, rank, group=shard.timing_group())
+                mine, mstart = shard.bucket_exchange(s["recs"], bs[: buckets + 1], buckets, world, rank, group=shard.timing_group())
             m = mine.numel()
             full = shard.full_bucket_start(mstart, cuts[rank], cuts[rank + 1], buckets).to(dev)
-            if state.get("m") != m:
-                state.update(m=m, k=torch.empty(max(m, 1), dtype=torch.int32, device=dev), r=torch.empty(max(m, 1) * 2, dtype=torch.int64, device=dev),
-                             o=torch.zeros(max(m, 1) + 1, dtype=torch.int64, device=dev),
-                             sc=torch.empty(api.GpuIndex.scan_scratch_bytes(max(m, 1)), dtype=torch.uint8, device=dev), p=None)
-        stream_obj.synchronize()
+            if s["m"] != m:
+                s.update(m=m, k=torch.empty(max(m, 1), dtype=torch.int32, device=dev), r=torch.empty(max(m, 1) * 2, dtype=torch.int64, device=dev),
+                         o=torch.zeros(max(m, 1) + 1, dtype=torch.int64, device=dev),
+                         sc=torch.empty(api.GpuIndex.scan_scratch_bytes(max(m, 1)), dtype=torch.uint8, device=dev), p=None)
+                front_obj.synchronize()  # (the allocator's: these arrays are first used on the other stream)
+        s["front_done"].record(front_obj)
+        s["left"] = int(bs[buckets])  # entries [left, Q) of gk / gr: my general k-mers
+        s["keep"] = (mine, full)
+
+    def back(s):
+        back_obj.wait_event(s["front_done"])
+        mine, full = s["keep"]
+        m = s["m"]
         if m:
             g.search_ordered_records(mine.data_ptr(), full.data_ptr(), cuts[rank], cuts[rank + 1], K, args.query_offset + batch_total,
-                                     state["k"].data_ptr(), state["r"].data_ptr(), st)
-            g.hit_offsets_on_device(0, state["r"].data_ptr(), m, state["o"].data_ptr(), state["sc"].data_ptr(), st)
-            if state["p"] is None:
-                stream_obj.synchronize()
-                hits = int(state["o"][m].item())
-                state["p"] = torch.empty(hits + hits // 8 + 64, dtype=torch.int64, device=dev)
-            g.locate_on_device(state["r"].data_ptr(), state["o"].data_ptr(), m, state["p"].numel(), state["p"].data_ptr(), st)
-        state["left"] = int(bs[buckets])  # entries [left, Q) of d_gk / d_gr: my general k-mers
-        state["keep"] = (mine, full)
+                                     s["k"].data_ptr(), s["r"].data_ptr(), sb)
+            g.hit_offsets_on_device(0, s["r"].data_ptr(), m, s["o"].data_ptr(), s["sc"].data_ptr(), sb)
+            if s["p"] is None:
+                back_obj.synchronize()
+                hits = int(s["o"][m].item())
+                s["p"] = torch.empty(hits + hits // 8 + 64, dtype=torch.int64, device=dev)
+            g.locate_on_device(s["r"].data_ptr(), s["o"].data_ptr(), m, s["p"].numel(), s["p"].data_ptr(), sb)
+        s["back_done"] = torch.cuda.Event()
+        s["back_done"].record(back_obj)
+
+    def run(steps):
+        """`steps` batches through the two stages; returns the slot of the last one"""
+        if not pipelined:
+            for _ in range(steps):
+                front(slots[0])
+                back(slots[0])
+            return slots[0]
+        front(slots[0])
+        for i in range(steps):
+            back(slots[i % 2])
+            if i + 1 < steps:
+                front(slots[(i + 1) % 2])
+        return slots[(steps - 1) % 2]
 
     def barrier():
         shard.barrier(world, torch.cuda.synchronize)
 
-    for _ in range(max(args.warmup, 1)):
-        step()
+    run(max(args.warmup, 2))
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    state = run(args.steps)
     barrier()
     dt = shard.max_over_ranks((time.perf_counter() - t0) / args.steps, world, dev)
     # digests keyed by the k-mers' numbers in the whole batch: my share of the order + my own general k-mers
@@ -939,14 +970,14 @@ def seed_bucket_run(args, L, api, digest, shard, torch, np, dev, g, ix, d_chars,
         dp += digest.positions_digest_keyed(ids, state["o"][: m + 1], state["p"][: max(hits, 1)])
     if left < Q:  # (located here too: ranges -> offsets -> positions over the tail)
         gm = Q - left
-        gr = d_gr[2 * left:].contiguous()
+        gr = state["gr"][2 * left:].contiguous()
         go = torch.zeros(gm + 1, dtype=torch.int64, device=dev)
         gsc = torch.empty(api.GpuIndex.scan_scratch_bytes(gm), dtype=torch.uint8, device=dev)
         total = g.hit_offsets(gr.data_ptr(), gm, go.data_ptr(), gsc.data_ptr())
         gp = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
         g.locate(gr.data_ptr(), go.data_ptr(), gm, total, gp.data_ptr())
         torch.cuda.synchronize()
-        gids = d_gk[left:].to(torch.int64)
+        gids = state["gk"][left:].to(torch.int64)
         dc += digest.counts_digest_keyed(gids, go[1:] - go[:-1])
         dp += digest.positions_digest_keyed(gids, go, gp)
         hits += total
@@ -972,7 +1003,7 @@ def seed_bucket_run(args, L, api, digest, shard, torch, np, dev, g, ix, d_chars,
                                                                     f"bucket range ({'through host memory over gloo' if via_host else 'RCCL' if world > 1 else 'one rank: no exchange'}), "
                                                                     "every rank searches a dense N-th of the seed order",
                           "batch_kmers": batch_total, "buckets": buckets, "index_build_s": round(build_s, 2), "timing_collective": shard.timing_backend() or "none (one rank)",
-                          "host_waits_per_step": 3},
+                          "batches_in_flight": 2 if pipelined else 1, "host_waits_per_step": 1},
                "roofline": None, "cpu_baseline": None,
                "digests": dict(dig, status="match" if committed else "unknown", shards=world,
                                per_rank=[{"rank": p[0], "kmers": p[1], "hits": p[2]} for p in parts])}
@@ -2253,7 +2284,10 @@ def main():
                     exchange_ms = (m / parts * 8) / (XGMI_LINK_GBS * XGMI_EFFICIENCY * 1e9) * 1e3 if parts > 1 else 0.0
                     rows.append({"order_own_shard_ms": round(order_ms, 4), "exchange_ms_priced": round(exchange_ms, 4), "merge_ms": round(merge_ms, 4),
                                  "search_and_locate_ms": round(search_ms_r, 4), "kmers": m, "hits": hits_r,
-                                 "total_ms": round(order_ms + exchange_ms + merge_ms + search_ms_r, 4)})
+                                 "total_ms": round(order_ms + exchange_ms + merge_ms + search_ms_r, 4),
+                                 # two batches in flight (bench.py --sharding seed_bucket runs that way): the exchange of batch i + 1 is
+                                 # in the links while batch i is searched, so a step costs what the GPU does, or the exchange if longer
+                                 "pipelined_ms": round(max(order_ms + merge_ms + search_ms_r, exchange_ms), 4)})
                     ids = d_k.to(torch.int64)
                     assert int(ids.min().item()) >= first and int(ids.max().item()) < first + Q
                     sum_c += digest.counts_digest_keyed(ids, d_o[1:] - d_o[:-1])
@@ -2262,12 +2296,18 @@ def main():
                 assert (sum_c & digest.MASK) == int(pdig["counts"], 16), f"seed-bucket sharding: the counts digests of {parts} ranks do not add up to the batch's"
                 assert (sum_p & digest.MASK) == int(pdig["positions"], 16), f"seed-bucket sharding: the positions digests of {parts} ranks do not add up"
                 slowest = max(rw["total_ms"] for rw in rows)
+                slowest_pipelined = max(rw["pipelined_ms"] for rw in rows)
                 per_n[str(parts)] = {"sharding": "seed_bucket", "ms_max": round(slowest, 4), "ranks": rows,
-                                     "Mkmers_per_s_at_N_gpus": round(Q / slowest / 1e3, 1), "efficiency": round(planted_whole_ms / (parts * slowest), 4)}
+                                     "Mkmers_per_s_at_N_gpus": round(Q / slowest / 1e3, 1), "efficiency": round(planted_whole_ms / (parts * slowest), 4),
+                                     "ms_max_two_batches_in_flight": round(slowest_pipelined, 4),
+                                     "efficiency_two_batches_in_flight": round(planted_whole_ms / (parts * slowest_pipelined), 4)}
             proxy["shards"]["planted_seed_bucket"] = per_n
             proxy["seed_bucket_note"] = ("planted_seed_bucket: every rank orders its contiguous shard (awfmGpuOrderKmers), exchanges records by bucket range "
                                          f"(priced at {XGMI_LINK_GBS:g} GB/s per xGMI link x {XGMI_EFFICIENCY:g}: one GPU cannot time it), and searches the dense N-th of the "
-                                         "ORDER (awfmGpuSearchOrderedRecords); digests keyed by the k-mers' numbers in the whole batch add up to the batch's")
+                                         "ORDER (awfmGpuSearchOrderedRecords); digests keyed by the k-mers' numbers in the whole batch add up to the batch's.  "
+                                         "`efficiency`: one batch at a time, the exchange exposed; `efficiency_two_batches_in_flight`: the throughput of a stream of "
+                                         "batches the way `--sharding seed_bucket` runs them (the exchange of batch i + 1 behind the search of batch i, on its own "
+                                         "stream) -- a MODEL on one GPU: it assumes the all-to-all costs the kernels nothing")
             del d_all_recs, d_all_bs
         proxy["digests"] = ("the shards' counts and positions digests add up to the whole batch's for every N; every shard that has "
                             "a committed digest of its own (tests/golden/bench_digests.json) equals it")
@@ -2444,6 +2484,7 @@ def main():
             config["scaling_proxy_8_planted_efficiency"] = proxy["shards"]["planted"]["8"]["efficiency"]
         if "planted_seed_bucket" in proxy["shards"]:
             config["scaling_proxy_8_planted_seed_bucket_efficiency"] = proxy["shards"]["planted_seed_bucket"]["8"]["efficiency"]
+            config["scaling_proxy_8_planted_seed_bucket_efficiency_two_batches_in_flight"] = proxy["shards"]["planted_seed_bucket"]["8"]["efficiency_two_batches_in_flight"]
         config["scaling_proxy_8_ms"] = e8["ms_max"]
     config["bench_wall_s"] = round(time.time() - T_START, 1)  # this process from its first line to its JSON line (imports, index, every leg)
     out = {

@@ -52,6 +52,9 @@ run amino_planted -- --alphabet amino --workload planted --no-cpu --no-e2e
 run wide -- --text-len 6.2e9 --no-e2e --no-amino --no-repetitive --no-wide
 run wide_planted -- --text-len 6.2e9 --workload planted --no-cpu --no-e2e --no-wide
 run wide_mixed -- --text-len 6.2e9 --workload mixed --no-cpu --no-e2e --general-steps 0 --no-wide
+run amino_wide -- --alphabet amino --text-len 4.4e9 --no-cpu --no-e2e --no-secondary --no-shard-proxy
+# counts only of a dense-hit batch: the counts come home from search order in whole lines (awfm_count_order_kernel.h)
+run planted_count -- --workload planted --mode count --no-cpu --no-e2e --no-secondary --general-steps 0 --no-shard-proxy
 python3 - "$OUT" <<'PY'
 import glob, json, os, sys
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "bench_*.json"))):

@@ -133,13 +133,16 @@ def test_seed_bucket_sharding_digests_equal_the_contiguous_one_rank_run(require_
     one = _line(_run_bench(common + ["--gpus", "1", "--record-digests", golden]))
     os.environ["AWFM_BENCH_DIGESTS"] = golden
     try:
-        two = _line(_run_bench(common + ["--gpus", "2", "--force-device", "0", "--dist-backend", "gloo", "--sharding", "seed_bucket"]))
-        alone = _line(_run_bench(common + ["--gpus", "1", "--sharding", "seed_bucket"]))
+        # (two batches in flight, the default: three timed steps so that both slots of the pipeline are used again; and one
+        # batch at a time)
+        two = _line(_run_bench(common + ["--gpus", "2", "--force-device", "0", "--dist-backend", "gloo", "--sharding", "seed_bucket", "--steps", "3"]))
+        alone = _line(_run_bench(common + ["--gpus", "1", "--sharding", "seed_bucket", "--seed-bucket-pipeline", "0"]))
     finally:
         os.environ.pop("AWFM_BENCH_DIGESTS")
     for line in (two, alone):
         assert line["config"]["sharding"] == "seed_bucket" and line["digests"]["status"] == "match", line["digests"]
         assert line["digests"]["counts"] == one["digests"]["counts"] and line["digests"]["positions"] == one["digests"]["positions"]
+    assert two["config"]["batches_in_flight"] == 2 and alone["config"]["batches_in_flight"] == 1
     assert two["n_gpus"] == 2 and len(two["digests"]["per_rank"]) == 2
     kmers = [p["kmers"] for p in two["digests"]["per_rank"]]
     assert sum(kmers) == 1_000_000 and min(kmers) > 300_000  # two dense halves of the order, not two halves of the batch

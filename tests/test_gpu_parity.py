@@ -1195,6 +1195,46 @@ def _check_hits_contract(ranges, counts, sp, ep, cnt):
     assert np.all(ranges[~hit, 0] > ranges[~hit, 1]), "a query without hits must have an empty range"
 
 
+def test_counts_of_a_dense_hit_batch_come_home_from_search_order(oracle, awfm, require_gpu, wide):
+    """counts only through the seed-order search (round 6, awfm_count_order_kernel.h): orderedSearchKernel leaves {k-mer number,
+    count} in search order, countScatterKernel / countPlaceKernel take them to counts[number] -- 700 001 k-mers are three
+    buckets of k-mer numbers (2^18 each), the last one partly filled; k-mers with ambiguity characters are the general
+    kernel's; absent k-mers get their 0 from the same passes.  Against the oracle, from ASCII and from packed k-mers."""
+    import torch
+    n, K, Q = 400000, 21, 700001
+    txt = synth.text(4242, n, synth.DNA_ALPHABET).copy()
+    ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
+    oi = oracle.Index.wrap(oracle.DNA, 8, 8, ix.bwt_length, ix.blocks(), ix.prefix_sums(), ix.seed_table(), ix.packed_sa())
+    g = awfm.GpuIndex(ix)
+    g.set_ordered(1)
+    g.set_deep_seed(10)
+    q = np.concatenate([synth.planted_queries(61, Q - Q // 8, K, txt), synth.random_queries(62, Q // 8, K)]).copy()
+    rng = np.random.default_rng(7)
+    q = q[rng.permutation(Q)]
+    flat = q.reshape(-1)
+    flat[rng.random(flat.size) < 0.0005] = ord("n")
+    chars, offsets = synth.fixed_csr(q)
+    _, _, cnt, _ = oi.batch_search(chars, offsets, threads=os.cpu_count() or 1)
+    assert (cnt > 0).sum() > Q // 2 and (cnt == 0).sum() > Q // 16
+    dev = torch.device("cuda")
+    d_chars = torch.from_numpy(chars).to(dev)
+    for _ in range(2):  # (the second search finds the scratch and its counters as the first left them)
+        d_counts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+        g.search_hits(d_chars.data_ptr(), 0, K, Q, 0, d_counts.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt)
+    clean = ~(q == ord("n")).any(axis=1)
+    packed = awfm.pack_kmers(np.ascontiguousarray(q[clean]), awfm.AwFmAlphabetDna)
+    d_packed = torch.from_numpy(packed.view(np.int64)).to(dev)
+    m = int(clean.sum())
+    d_counts = torch.full((m,), 7, dtype=torch.int32, device=dev)
+    g.search_hits_packed(d_packed.data_ptr(), K, m, 0, d_counts.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_counts.cpu().numpy().view(np.uint32), cnt[clean])
+    g.destroy()
+    ix.dealloc()
+
+
 @pytest.mark.parametrize("n,ratio,seed_k,deep_k,K", [(300000, 8, 8, 0, 21), (300000, 5, 8, 0, 8), (200000, 8, 6, 9, 32),
                                                      (200000, 8, 6, 9, 7), (4096, 3, 4, 0, 13), (100000, 8, 1, 0, 5),
                                                      (150000, 8, 10, 11, 11), (300000, 8, 12, 16, 21)])
