@@ -7,15 +7,16 @@
  * counts, 2.2 of the kernel's 7.2 ms on a genome-shaped text (round 5).  Instead the kernel leaves {k-mer number, count}
  * at the k-mer's place in the ORDER (8-byte stores that fill lines as the order is walked), and two passes take the records
  * home:
- *   countScatterKernel  the records into the bucket of their k-mer number's leading bits (each bucket a fixed stretch of the
- *                       output: a bucket of 2^shift numbers never holds more records), a tile of 16384 records at a time: the
- *                       tile's histogram in LDS, one reservation per bucket and tile, then the records again (out of the L2)
- *                       into runs of ~40 -- whole lines but for a run's two ends;
- *   countPlaceKernel    a bucket's records to counts[number]: the bucket's counts are 1 MB, the workgroups of a bucket run on
- *                       ONE XCD (blockIdx % 8: the dispatch order this library's other kernels rely on), two buckets at a time,
- *                       so the 4-byte stores meet in that XCD's L2 and leave it as whole lines.
+ *   countScatterKernel  the records into the bucket of their k-mer number's leading bits -- 2^15 numbers a bucket, each bucket a
+ *                       fixed stretch of the output (it never holds more records than numbers) --, a tile of 16384 records at a
+ *                       time: the tile's histogram in LDS, one reservation per bucket and tile, then the records again (out of the
+ *                       L2) to their places; the few thousand lines being filled stay in the L2s until they are whole;
+ *   countPlaceKernel    one workgroup per bucket: the bucket's 2^15 counts (128 KB) are put together in LDS and stored as whole
+ *                       lines.  (First built with buckets of 2^18 numbers and the 4-byte stores meeting in one XCD's L2: 0.94 ms
+ *                       per 10^8 against 0.65 for the scatter -- a store per record is a request per record whatever the L2 merges.)
  * Every k-mer of the order gets its count written, 0 included; the k-mers the order does not hold (ambiguity characters) are
- * the general kernel's, which stores at counts[number] as before.
+ * the general kernel's, which runs after these passes and stores at counts[number] as before.  Batches of up to 2^27 k-mers
+ * (4096 buckets); larger ones keep the direct stores.
  */
 #ifndef AWFM_COUNT_ORDER_KERNEL_H
 #define AWFM_COUNT_ORDER_KERNEL_H
@@ -25,19 +26,17 @@
 namespace {
 
 constexpr unsigned kCountScatterThreads = 256, kCountScatterPerThread = 64, kCountScatterTile = kCountScatterThreads * kCountScatterPerThread;
-constexpr unsigned kCountBucketsMax = 512;
-constexpr unsigned kCountPlaceParts = 128; /* workgroups per bucket in countPlaceKernel */
+constexpr unsigned kCountShift = 15, kCountBucketsMax = 4096, kCountPlaceThreads = 1024;
 
-/* the shift that leaves at most kCountBucketsMax buckets of k-mer numbers below n, and windows of counts an L2 holds twice */
-inline unsigned countOrderShift(unsigned long long n) {
-  unsigned shift = 18; /* 2^18 numbers: 1 MB of counts */
-  while (((n - 1ull) >> shift) + 1ull > kCountBucketsMax) shift++;
-  return shift;
+/* buckets of k-mer numbers below n; 0: more than the passes take */
+inline unsigned countOrderBuckets(unsigned long long n) {
+  const unsigned long long buckets = ((n - 1ull) >> kCountShift) + 1ull;
+  return n != 0ull && buckets <= kCountBucketsMax ? (unsigned)buckets : 0u;
 }
 
 __global__ void __launch_bounds__(kCountScatterThreads)
-    countScatterKernel(const uint2 *__restrict__ in, const unsigned *__restrict__ total, const unsigned shift, const unsigned buckets,
-                       uint2 *__restrict__ out, unsigned *__restrict__ cursors) {
+    countScatterKernel(const uint2 *__restrict__ in, const unsigned *__restrict__ total, const unsigned buckets, uint2 *__restrict__ out,
+                       unsigned *__restrict__ cursors) {
   __shared__ unsigned sHist[kCountBucketsMax], sBase[kCountBucketsMax];
   const unsigned long long n = *total;
   const unsigned long long tiles = (n + kCountScatterTile - 1ull) / kCountScatterTile;
@@ -48,7 +47,7 @@ __global__ void __launch_bounds__(kCountScatterThreads)
 #pragma unroll 8
     for (unsigned j = 0; j < kCountScatterPerThread; j++) {
       const unsigned long long at = first + (unsigned long long)j * kCountScatterThreads + threadIdx.x;
-      if (at < n) atomicAdd(&sHist[in[at].x >> shift], 1u);
+      if (at < n) atomicAdd(&sHist[in[at].x >> kCountShift], 1u);
     }
     __syncthreads();
     for (unsigned b = threadIdx.x; b < buckets; b += kCountScatterThreads) {
@@ -62,29 +61,42 @@ __global__ void __launch_bounds__(kCountScatterThreads)
       const unsigned long long at = first + (unsigned long long)j * kCountScatterThreads + threadIdx.x;
       if (at < n) {
         const uint2 rec = in[at];
-        const unsigned b = rec.x >> shift;
-        out[((unsigned long long)b << shift) + sBase[b] + atomicAdd(&sHist[b], 1u)] = rec;
+        const unsigned b = rec.x >> kCountShift;
+        out[((unsigned long long)b << kCountShift) + sBase[b] + atomicAdd(&sHist[b], 1u)] = rec;
       }
     }
     __syncthreads();
   }
 }
 
-/* workgroup id -> (bucket, part): the 8 buckets of a group of buckets side by side (bucket % 8 = blockIdx % 8 = the XCD), the
- * parts of a bucket one after the other on that XCD */
-__global__ void __launch_bounds__(256)
-    countPlaceKernel(const uint2 *__restrict__ recs, const unsigned *__restrict__ cursors, const unsigned shift, const unsigned buckets,
+/* one workgroup per bucket: its records (any order) -> the window of its counts in LDS -> counts[] in whole lines; a number
+ * without a record (a k-mer the order does not hold) gets 0 here and its count from the general kernel afterwards */
+__global__ void __launch_bounds__(kCountPlaceThreads)
+    countPlaceKernel(const uint2 *__restrict__ recs, const unsigned *__restrict__ cursors, const unsigned long long numQueries,
                      unsigned *__restrict__ counts) {
-  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const unsigned bucket = (slot / kCountPlaceParts) * 8u + xcd, part = slot % kCountPlaceParts;
-  if (bucket >= buckets) return;
+  extern __shared__ unsigned sWindow[]; /* 2^kCountShift words */
+  constexpr unsigned kWindow = 1u << kCountShift;
+  const unsigned bucket = blockIdx.x;
+  const unsigned long long firstNumber = (unsigned long long)bucket << kCountShift;
+  for (unsigned i = threadIdx.x; i < kWindow; i += kCountPlaceThreads) sWindow[i] = 0u;
+  __syncthreads();
   const unsigned have = cursors[bucket];
-  const unsigned per = (have + kCountPlaceParts - 1u) / kCountPlaceParts;
-  const unsigned from = part * per, to = from + per < have ? from + per : have;
-  const uint2 *mine = recs + ((unsigned long long)bucket << shift);
-  for (unsigned i = from + threadIdx.x; i < to; i += 256u) {
+  const uint2 *mine = recs + firstNumber;
+  for (unsigned i = threadIdx.x; i < have; i += kCountPlaceThreads) {
     const uint2 rec = mine[i];
-    counts[rec.x] = rec.y;
+    sWindow[rec.x & (kWindow - 1u)] = rec.y;
+  }
+  __syncthreads();
+  const unsigned long long left = numQueries - firstNumber;
+  const unsigned valid = left < kWindow ? (unsigned)left : kWindow;
+  unsigned *to = counts + firstNumber; /* (16-byte aligned when counts is: a window is 128 KB) */
+  if (((unsigned long long)to & 15ull) == 0ull) {
+    const unsigned vecs = valid / 4u;
+    for (unsigned i = threadIdx.x; i < vecs; i += kCountPlaceThreads)
+      ((uint4 *)to)[i] = make_uint4(sWindow[4u * i], sWindow[4u * i + 1u], sWindow[4u * i + 2u], sWindow[4u * i + 3u]);
+    for (unsigned i = vecs * 4u + threadIdx.x; i < valid; i += kCountPlaceThreads) to[i] = sWindow[i];
+  } else {
+    for (unsigned i = threadIdx.x; i < valid; i += kCountPlaceThreads) to[i] = sWindow[i];
   }
 }
 

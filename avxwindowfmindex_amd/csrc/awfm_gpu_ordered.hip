@@ -679,8 +679,9 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
   const size_t numbersAt = recsAt + alignUp256(nq * 8u);
   /* counts only, dense (awfm_count_order_kernel.h): the ordered kernel's {number, count} records in search order, and the
    * same records by the leading bits of their numbers */
-  const bool countRecords = !sparse && !touch && dCounts && !rng;
-  const unsigned countShift = countOrderShift(nq), countBuckets = (unsigned)(((nq - 1ull) >> countShift) + 1ull);
+  const unsigned countBuckets = countOrderBuckets(nq);
+  const bool countRecords = !sparse && !touch && dCounts && !rng && countBuckets != 0u;
+  constexpr unsigned countShift = kCountShift;
   const size_t countInAt = numbersAt + (lookupWanted ? alignUp256(nq * 4u) : 0u);
   const size_t countOutAt = countInAt + (countRecords ? alignUp256(nq * 8u) : 0u);
   const size_t total = countOutAt + (countRecords ? alignUp256(((size_t)countBuckets << countShift) * 8u) : 0u);
@@ -879,10 +880,16 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
     const unsigned long long tiles = (nq + kCountScatterTile - 1ull) / kCountScatterTile;
     const unsigned scatterGrid = (unsigned)(tiles < (unsigned long long)g->numCUs * 4u ? tiles : (unsigned long long)g->numCUs * 4u);
     hipLaunchKernelGGL(countScatterKernel, dim3(scatterGrid ? scatterGrid : 1u), dim3(kCountScatterThreads), 0, s, (const uint2 *)(w + countInAt), ordered,
-                       countShift, countBuckets, (uint2 *)(w + countOutAt), countCursors);
+                       countBuckets, (uint2 *)(w + countOutAt), countCursors);
     BUCKET_TRY(hipGetLastError());
-    hipLaunchKernelGGL(countPlaceKernel, dim3((countBuckets + 7u) / 8u * kCountPlaceParts * 8u), dim3(256), 0, s, (const uint2 *)(w + countOutAt),
-                       (const unsigned *)countCursors, countShift, countBuckets, dCounts);
+    static std::once_flag placeOnce;
+    static hipError_t placeError = hipSuccess;
+    std::call_once(placeOnce, [] {
+      placeError = hipFuncSetAttribute((const void *)countPlaceKernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((1u << kCountShift) * 4u));
+    });
+    BUCKET_TRY(placeError);
+    hipLaunchKernelGGL(countPlaceKernel, dim3(countBuckets), dim3(kCountPlaceThreads), (size_t)(1u << kCountShift) * 4u, s, (const uint2 *)(w + countOutAt),
+                       (const unsigned *)countCursors, nq, dCounts);
     BUCKET_TRY(hipGetLastError());
     if (!packed) { /* the k-mers the order does not hold: stored at counts[number] */
       const enum AwFmReturnCode left = narrow ? launchLeftover<true, false>(g, s, dChars, nullptr, fixedLength, nq, rng, dCounts, recs, 8u, 0u, generalCount, nullptr)

@@ -1197,8 +1197,8 @@ def _check_hits_contract(ranges, counts, sp, ep, cnt):
 
 def test_counts_of_a_dense_hit_batch_come_home_from_search_order(oracle, awfm, require_gpu, wide):
     """counts only through the seed-order search (round 6, awfm_count_order_kernel.h): orderedSearchKernel leaves {k-mer number,
-    count} in search order, countScatterKernel / countPlaceKernel take them to counts[number] -- 700 001 k-mers are three
-    buckets of k-mer numbers (2^18 each), the last one partly filled; k-mers with ambiguity characters are the general
+    count} in search order, countScatterKernel / countPlaceKernel take them to counts[number] -- 700 001 k-mers are 22
+    buckets of k-mer numbers (2^15 each), the last one partly filled; k-mers with ambiguity characters are the general
     kernel's; absent k-mers get their 0 from the same passes.  Against the oracle, from ASCII and from packed k-mers."""
     import torch
     n, K, Q = 400000, 21, 700001
