@@ -472,7 +472,7 @@ def amino_leg(L, api, digest, torch, np, dev, n, Q=50_000_000, K=10, seed_k=5, s
         roofline["reference_algorithm_frac"] = roofline["reference_algorithm"]["frac"]
         del d_counts
         # measured HBM bytes of the same kernel on the same batch: rocprofv3 PMC passes of `--alphabet amino [--text-len 2e9]`
-        pname = {200_000_000: "amino", 2_000_000_000: "amino_2e9"}.get(n) if (Q, K, seed_k, sa_ratio) == (50_000_000, 10, 5, 8) else None
+        pname = {200_000_000: "amino", 2_000_000_000: "amino_2e9", 4_400_000_000: "amino_wide"}.get(n) if (Q, K, seed_k, sa_ratio) == (50_000_000, 10, 5, 8) else None
         traffic, tsrc = profile_file("traffic", pname) if pname and looked_up and not any(
             k.startswith("AWFM_GPU_") and k not in ("AWFM_GPU_TIME_ORDERED", "AWFM_GPU_DEVICE") for k in os.environ) else (None, None)
         if traffic and str(traffic.get("kernel", "")).startswith("aminoLookupSearchKernel"):
@@ -1578,6 +1578,9 @@ def main():
     if (args.device_seed_k < 0 and args.device_dense_sa is None and not amino and n == 3_100_000_000 and Q == 100_000_000
             and K == 21 and args.seed_k == 12 and args.sa_ratio == 8 and args.mode == "locate" and args.text == "uniform"):
         prof_name = {"random": "default", "planted": "planted"}.get(args.workload)
+    if (args.device_seed_k < 0 and args.device_dense_sa is None and not amino and n == 3_100_000_000 and Q == 100_000_000
+            and K == 21 and args.seed_k == 12 and args.sa_ratio == 8 and args.mode == "count" and args.text == "uniform" and args.workload == "planted"):
+        prof_name = "planted_count"
     if (args.device_seed_k < 0 and args.device_dense_sa is None and not amino and n == 6_200_000_000 and Q == 100_000_000
             and K == 21 and args.seed_k == 12 and args.sa_ratio == 8 and args.mode == "locate" and args.text == "uniform"):
         prof_name = {"random": "wide", "planted": "wide_planted"}.get(args.workload)

@@ -13,11 +13,13 @@ collect wide "100 M random 21-mers, locate, 6.2 Gbp (an index beyond 2^32 positi
 collect wide_planted "100 M planted 21-mers, locate, 6.2 Gbp" wide_planted
 collect ordered_only "100 M random 21-mers, locate, 3.1 Gbp, AWFM_GPU_LOOKUP_FIRST=0" no_lookup_first
 collect planted "100 M planted 21-mers, locate, 3.1 Gbp" planted
+collect planted_count "100 M planted 21-mers, count, 3.1 Gbp (counts home from search order: countScatterKernel, countPlaceKernel)" planted_count
 collect general_pair "100 M random 21-mers, count, 3.1 Gbp, AWFM_GPU_ORDERED=0 AWFM_GPU_DEEP_SEED_K=0 (exact-range general kernel)" general
 collect exact_tables "100 M random 21-mers, count, 3.1 Gbp, AWFM_GPU_ORDERED=0 (awfmGpuSearch through the tables: exactLookupSearchKernel)" exact_tables
 collect mixed "100 M mixed 8..30-mers, count, 3.1 Gbp" mixed
 collect amino "50 M random 10-mers, locate, 200 M residues" amino
 collect amino_2e9 "50 M random 10-mers, locate, 2 G residues" amino_2e9
+collect amino_wide "50 M random 10-mers, locate, 4.4 G residues (64-bit instantiations)" amino_wide
 collect repetitive_unique "100 M 21-mers from the unique sequence of a genome-shaped 3.1 Gbp text, locate" repetitive_unique
 collect repetitive_planted "100 M planted 21-mers, count, genome-shaped 3.1 Gbp text" repetitive_planted
 cp "$B"/bench_*.json "$D"/ 2>/dev/null

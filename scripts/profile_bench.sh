@@ -8,7 +8,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 echo "${AWFM_COMMIT:-unknown}" > "$OUT/commit.txt"   # the commit of the tree this box was given (there is no .git here)
 cd /tmp && export TMPDIR=/tmp
-KERNELS="earchKernel|lookupSearch|lookupPrep|listTail|exactLookup|SampleAlive|mixedLookupTally|encodeLookup|encodeRecords|partitionRecords|rankMark|rankBlock|rankPlace|sampleAlive|bucketScanShares|walkKernel|finishKernel|fillNoHitKernel|fillSparseKernel|encodeQueriesKernel|encodeCodes|partitionKernel|bucketScanKernel|segmentSumsKernel|tileOffsetsKernel|radix_sort|onesweep|expandHitsKernel|scanTileKernel|scanReduceKernel|sortKeysKernel|bucketKernel"
+KERNELS="earchKernel|countScatter|countPlace|lookupSearch|lookupPrep|listTail|exactLookup|SampleAlive|mixedLookupTally|encodeLookup|encodeRecords|partitionRecords|rankMark|rankBlock|rankPlace|sampleAlive|bucketScanShares|walkKernel|finishKernel|fillNoHitKernel|fillSparseKernel|encodeQueriesKernel|encodeCodes|partitionKernel|bucketScanKernel|segmentSumsKernel|tileOffsetsKernel|radix_sort|onesweep|expandHitsKernel|scanTileKernel|scanReduceKernel|sortKeysKernel|bucketKernel"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" --no-cpu --no-e2e --no-secondary --no-shard-proxy --no-dense-form --no-wide "$@" > "$OUT/bench_trace.log" 2>&1
 declare -A PASS
 PASS[fetch]="FETCH_SIZE"
