@@ -14,8 +14,9 @@
  *   countPlaceKernel    one workgroup per bucket: the bucket's 2^15 counts (128 KB) are put together in LDS and stored as whole
  *                       lines.  (First built with buckets of 2^18 numbers and the 4-byte stores meeting in one XCD's L2: 0.94 ms
  *                       per 10^8 against 0.65 for the scatter -- a store per record is a request per record whatever the L2 merges.)
- * Every k-mer of the order gets its count written, 0 included; the k-mers the order does not hold (ambiguity characters) are
- * the general kernel's, which runs after these passes and stores at counts[number] as before.  Batches of up to 2^27 k-mers
+ * Every k-mer of the order gets its count written, 0 included; what the order does not hold keeps what it has: the pre-fill's 0,
+ * the counts a lookup kernel in front of the ordered search stored for the k-mers it searched itself, and -- stored after
+ * these passes -- the general kernel's for the k-mers with ambiguity characters.  Batches of up to 2^27 k-mers
  * (4096 buckets); larger ones keep the direct stores.
  */
 #ifndef AWFM_COUNT_ORDER_KERNEL_H
@@ -69,35 +70,41 @@ __global__ void __launch_bounds__(kCountScatterThreads)
   }
 }
 
-/* one workgroup per bucket: its records (any order) -> the window of its counts in LDS -> counts[] in whole lines; a number
- * without a record (a k-mer the order does not hold) gets 0 here and its count from the general kernel afterwards */
+/* one workgroup per bucket: the window of its counts as they stand (the pre-fill's zeros, and whatever a lookup kernel in front
+ * of the ordered search has stored for the k-mers it searched itself) -> the bucket's records laid over it in LDS -> back in
+ * whole lines.  A bucket without records (the batch went to the lookup kernel alone) is left as it is. */
 __global__ void __launch_bounds__(kCountPlaceThreads)
     countPlaceKernel(const uint2 *__restrict__ recs, const unsigned *__restrict__ cursors, const unsigned long long numQueries,
                      unsigned *__restrict__ counts) {
   extern __shared__ unsigned sWindow[]; /* 2^kCountShift words */
   constexpr unsigned kWindow = 1u << kCountShift;
   const unsigned bucket = blockIdx.x;
-  const unsigned long long firstNumber = (unsigned long long)bucket << kCountShift;
-  for (unsigned i = threadIdx.x; i < kWindow; i += kCountPlaceThreads) sWindow[i] = 0u;
-  __syncthreads();
   const unsigned have = cursors[bucket];
+  if (have == 0u) return; /* uniform */
+  const unsigned long long firstNumber = (unsigned long long)bucket << kCountShift;
+  const unsigned long long left = numQueries - firstNumber;
+  const unsigned valid = left < kWindow ? (unsigned)left : kWindow;
+  unsigned *to = counts + firstNumber;
+  const bool aligned = ((unsigned long long)to & 15ull) == 0ull; /* (a window is 128 KB: aligned whenever counts is) */
+  const unsigned vecs = aligned ? valid / 4u : 0u;
+  for (unsigned i = threadIdx.x; i < vecs; i += kCountPlaceThreads) {
+    const uint4 v = ((const uint4 *)to)[i];
+    sWindow[4u * i] = v.x;
+    sWindow[4u * i + 1u] = v.y;
+    sWindow[4u * i + 2u] = v.z;
+    sWindow[4u * i + 3u] = v.w;
+  }
+  for (unsigned i = vecs * 4u + threadIdx.x; i < valid; i += kCountPlaceThreads) sWindow[i] = to[i];
+  __syncthreads();
   const uint2 *mine = recs + firstNumber;
   for (unsigned i = threadIdx.x; i < have; i += kCountPlaceThreads) {
     const uint2 rec = mine[i];
     sWindow[rec.x & (kWindow - 1u)] = rec.y;
   }
   __syncthreads();
-  const unsigned long long left = numQueries - firstNumber;
-  const unsigned valid = left < kWindow ? (unsigned)left : kWindow;
-  unsigned *to = counts + firstNumber; /* (16-byte aligned when counts is: a window is 128 KB) */
-  if (((unsigned long long)to & 15ull) == 0ull) {
-    const unsigned vecs = valid / 4u;
-    for (unsigned i = threadIdx.x; i < vecs; i += kCountPlaceThreads)
-      ((uint4 *)to)[i] = make_uint4(sWindow[4u * i], sWindow[4u * i + 1u], sWindow[4u * i + 2u], sWindow[4u * i + 3u]);
-    for (unsigned i = vecs * 4u + threadIdx.x; i < valid; i += kCountPlaceThreads) to[i] = sWindow[i];
-  } else {
-    for (unsigned i = threadIdx.x; i < valid; i += kCountPlaceThreads) to[i] = sWindow[i];
-  }
+  for (unsigned i = threadIdx.x; i < vecs; i += kCountPlaceThreads)
+    ((uint4 *)to)[i] = make_uint4(sWindow[4u * i], sWindow[4u * i + 1u], sWindow[4u * i + 2u], sWindow[4u * i + 3u]);
+  for (unsigned i = vecs * 4u + threadIdx.x; i < valid; i += kCountPlaceThreads) to[i] = sWindow[i];
 }
 
 }  // namespace

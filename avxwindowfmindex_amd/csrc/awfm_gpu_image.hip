@@ -189,6 +189,27 @@ enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device
   return createImage(index, device, out, false);
 }
 static void accelBuilder(AwFmGpuIndex *g);
+/* images whose builder thread has not been joined yet */
+static std::mutex buildingMutex;
+static std::vector<AwFmGpuIndex *> building;
+static void forgetBuilder(AwFmGpuIndex *g) {
+  std::lock_guard<std::mutex> lock(buildingMutex);
+  for (size_t i = 0; i < building.size(); i++)
+    if (building[i] == g) {
+      building[i] = building.back();
+      building.pop_back();
+      break;
+    }
+}
+static void settleBuildersAtExit() {
+  std::vector<AwFmGpuIndex *> left;
+  {
+    std::lock_guard<std::mutex> lock(buildingMutex);
+    left.swap(building);
+  }
+  for (AwFmGpuIndex *g : left)
+    if (g->accelThread.joinable()) g->accelThread.join();
+}
 static unsigned chooseDeepSeedK(const AwFmGpuIndex *g, std::string &notes);
 static enum AwFmReturnCode buildDeepSeed(AwFmGpuIndex *g, unsigned deepK, AwFmGpuIndex::PendingAccel *to);
 static void installDeepSeed(AwFmGpuIndex *g, AwFmGpuIndex::PendingAccel *from, const std::vector<AwFmGpuIndex *> &laneList);
@@ -304,6 +325,12 @@ static enum AwFmReturnCode createImage(const struct AwFmIndex *index, int device
      * suffix array are built by a thread of their own, on a stream of their own, and installed between two calls */
     g->accelState.store(1);
     g->accelThread = std::thread(accelBuilder, g);
+    { /* a program that exits while a builder is at work (no awFmDeallocIndex) must not tear the runtime down under it */
+      std::lock_guard<std::mutex> lock(buildingMutex);
+      static bool hooked = false;
+      if (!hooked) hooked = atexit(settleBuildersAtExit) == 0;
+      building.push_back(g);
+    }
   } else {
     if (applyDeepSeedFromEnv(g) != AwFmSuccess) return fail(AwFmGeneralFailure);
     (void)awfmGpuApplyDenseSaAuto(g); /* optional accelerator: without it (no memory left) a locate walks */
@@ -335,7 +362,10 @@ void awfmGpuAdoptAccelerators(AwFmGpuIndex *g, bool wait, const std::vector<AwFm
   if (!g || g->shares) return;
   if (g->accelState.load() == 0) return;
   if (wait) {
-    if (g->accelThread.joinable()) g->accelThread.join();
+    if (g->accelThread.joinable()) {
+      g->accelThread.join();
+      forgetBuilder(g);
+    }
   } else if (g->accelState.load() != 2) {
     return;
   }
@@ -355,7 +385,10 @@ void awfmGpuAdoptAccelerators(AwFmGpuIndex *g, bool wait, const std::vector<AwFm
     else if (!want[held]->try_lock()) break;
   }
   if (held == want.size() && g->accelState.load() == 2) {
-    if (g->accelThread.joinable()) g->accelThread.join();
+    if (g->accelThread.joinable()) {
+      g->accelThread.join();
+      forgetBuilder(g);
+    }
     AwFmGpuIndex::PendingAccel &from = g->pendingAccel;
     if (from.deepTable) installDeepSeed(g, &from, lanes);
     if (from.dense) {
@@ -380,6 +413,7 @@ extern "C" {
 void awfmGpuIndexDestroy(AwFmGpuIndex *g) {
   if (!g) return;
   if (g->accelThread.joinable()) g->accelThread.join();
+  forgetBuilder(g);
   {
     DeviceGuard guard(g->device);
     if (g->pendingAccel.deepTable) (void)hipFree(g->pendingAccel.deepTable); /* (built, never installed) */

@@ -1195,12 +1195,19 @@ def _check_hits_contract(ranges, counts, sp, ep, cnt):
     assert np.all(ranges[~hit, 0] > ranges[~hit, 1]), "a query without hits must have an empty range"
 
 
-def test_counts_of_a_dense_hit_batch_come_home_from_search_order(oracle, awfm, require_gpu, wide):
+@pytest.mark.parametrize("lookup_first", [None, "0", "1"])
+def test_counts_of_a_dense_hit_batch_come_home_from_search_order(oracle, awfm, require_gpu, wide, monkeypatch, lookup_first):
     """counts only through the seed-order search (round 6, awfm_count_order_kernel.h): orderedSearchKernel leaves {k-mer number,
     count} in search order, countScatterKernel / countPlaceKernel take them to counts[number] -- 700 001 k-mers are 22
     buckets of k-mer numbers (2^15 each), the last one partly filled; k-mers with ambiguity characters are the general
-    kernel's; absent k-mers get their 0 from the same passes.  Against the oracle, from ASCII and from packed k-mers."""
+    kernel's; absent k-mers get their 0 from the same passes.  With the lookup kernel in front ($AWFM_GPU_LOOKUP_FIRST=1) most
+    k-mers' counts are stored by THAT kernel and only what it leaves goes through the order: the passes must lay their records
+    over what is there.  Against the oracle, from ASCII and from packed k-mers."""
     import torch
+    if lookup_first is None:
+        monkeypatch.delenv("AWFM_GPU_LOOKUP_FIRST", raising=False)
+    else:
+        monkeypatch.setenv("AWFM_GPU_LOOKUP_FIRST", lookup_first)
     n, K, Q = 400000, 21, 700001
     txt = synth.text(4242, n, synth.DNA_ALPHABET).copy()
     ix = awfm.create_index(txt, awfm.AwFmAlphabetDna, 8, 8)
