@@ -38,23 +38,22 @@ inline unsigned countOrderBuckets(unsigned long long n) {
 __global__ void __launch_bounds__(kCountScatterThreads)
     countScatterKernel(const uint2 *__restrict__ in, const unsigned *__restrict__ total, const unsigned buckets, uint2 *__restrict__ out,
                        unsigned *__restrict__ cursors) {
-  __shared__ unsigned sHist[kCountBucketsMax], sBase[kCountBucketsMax];
+  __shared__ unsigned sNext[kCountBucketsMax]; /* a tile's records per bucket, then where the bucket's next record goes */
   const unsigned long long n = *total;
   const unsigned long long tiles = (n + kCountScatterTile - 1ull) / kCountScatterTile;
   for (unsigned long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const unsigned long long first = tile * kCountScatterTile;
-    for (unsigned b = threadIdx.x; b < buckets; b += kCountScatterThreads) sHist[b] = 0u;
+    for (unsigned b = threadIdx.x; b < buckets; b += kCountScatterThreads) sNext[b] = 0u;
     __syncthreads();
 #pragma unroll 8
     for (unsigned j = 0; j < kCountScatterPerThread; j++) {
       const unsigned long long at = first + (unsigned long long)j * kCountScatterThreads + threadIdx.x;
-      if (at < n) atomicAdd(&sHist[in[at].x >> kCountShift], 1u);
+      if (at < n) atomicAdd(&sNext[in[at].x >> kCountShift], 1u);
     }
     __syncthreads();
     for (unsigned b = threadIdx.x; b < buckets; b += kCountScatterThreads) {
-      const unsigned mine = sHist[b];
-      sBase[b] = mine ? atomicAdd(&cursors[b], mine) : 0u;
-      sHist[b] = 0u;
+      const unsigned mine = sNext[b];
+      if (mine) sNext[b] = atomicAdd(&cursors[b], mine); /* one reservation per bucket and tile */
     }
     __syncthreads();
 #pragma unroll 8
@@ -63,7 +62,7 @@ __global__ void __launch_bounds__(kCountScatterThreads)
       if (at < n) {
         const uint2 rec = in[at];
         const unsigned b = rec.x >> kCountShift;
-        out[((unsigned long long)b << kCountShift) + sBase[b] + atomicAdd(&sHist[b], 1u)] = rec;
+        out[((unsigned long long)b << kCountShift) + atomicAdd(&sNext[b], 1u)] = rec;
       }
     }
     __syncthreads();

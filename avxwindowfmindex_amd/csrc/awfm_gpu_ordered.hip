@@ -878,7 +878,7 @@ static int bucketedSearch(AwFmGpuIndex *g, hipStream_t s, const uint8_t *dChars,
     const unsigned *ordered = bucketStart + (1u << fmt.bucketBits);
     unsigned *countCursors = (unsigned *)(w + kCountCursorsAt);
     const unsigned long long tiles = (nq + kCountScatterTile - 1ull) / kCountScatterTile;
-    const unsigned scatterGrid = (unsigned)(tiles < (unsigned long long)g->numCUs * 4u ? tiles : (unsigned long long)g->numCUs * 4u);
+    const unsigned scatterGrid = (unsigned)(tiles < (unsigned long long)g->numCUs * 8u ? tiles : (unsigned long long)g->numCUs * 8u); /* (16 KB of LDS each) */
     hipLaunchKernelGGL(countScatterKernel, dim3(scatterGrid ? scatterGrid : 1u), dim3(kCountScatterThreads), 0, s, (const uint2 *)(w + countInAt), ordered,
                        countBuckets, (uint2 *)(w + countOutAt), countCursors);
     BUCKET_TRY(hipGetLastError());
