@@ -80,8 +80,12 @@ hipError_t awfmGpuLaunchMixedTally(const AwFmGpuIndex *g, hipStream_t s, const v
   touch.sums = touch.nucLines + (unsigned long long)kMixedTouchLevels * nucWords;
   DevIndex dev = viewOf(g);
   dev.pairSuperInLds = 0u;
-  hipLaunchKernelGGL(mixedLookupTallyKernel, dim3((unsigned)g->numCUs * 4u), dim3(256), 0, s, dev, (const uint2 *)lengthTable, dChars, off, nq,
-                     useNext, touch);
+  if (awfmImageNarrow(g))
+    hipLaunchKernelGGL(mixedLookupTallyKernel<true>, dim3((unsigned)g->numCUs * 4u), dim3(256), 0, s, dev, (const uint2 *)lengthTable, dChars, off, nq,
+                       useNext, touch);
+  else
+    hipLaunchKernelGGL(mixedLookupTallyKernel<false>, dim3((unsigned)g->numCUs * 4u), dim3(256), 0, s, dev, (const uint2 *)lengthTable, dChars, off, nq,
+                       useNext, touch);
   return hipGetLastError();
 }
 unsigned awfmGpuMixedTouchLevels(void) { return kMixedTouchLevels; }

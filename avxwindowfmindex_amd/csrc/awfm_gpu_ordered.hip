@@ -1407,12 +1407,12 @@ extern "C" enum AwFmReturnCode awfmGpuMixedLookupLineTally(AwFmGpuIndex *g, cons
     return AwFmNullPtrError;
   }
   for (int i = 0; i < 8; i++) tallyOut[i] = 0;
-  const bool capable = !g->amino && awfmImageNarrow(g) && g->dev.deepSeed && g->dev.deepNarrow != 0u && g->dev.deepK >= 2u &&
+  const bool capable = !g->amino && g->dev.deepSeed && g->dev.deepNarrow == (awfmImageNarrow(g) ? 1u : 2u) && g->dev.deepK >= 2u &&
                        g->dev.deepK <= 16u && g->dev.seedK < g->dev.deepK;
   DeviceGuard guard(g->device);
   const uint2 *lengthTable = capable ? ensureLengthTables(g) : nullptr;
   if (!lengthTable) {
-    setError("awfmGpuMixedLookupLineTally: this image has no tables per k-mer length (a nucleotide image below 2^32 positions with its narrow deeper table)");
+    setError("awfmGpuMixedLookupLineTally: this image has no tables per k-mer length (a nucleotide image with its deeper table in 8-byte entries)");
     return AwFmUnsupportedVersionError;
   }
   const uint64_t lengthWords = (awfmLengthTableAt(g->dev.deepK) * 8u / 128u + 64u) / 64u;

@@ -470,14 +470,16 @@ struct MixedTouch {
 };
 constexpr unsigned kMixedTouchLevels = 17; /* characters a k-mer of up to 32 can have to go beyond a table */
 
+template <bool NARROW>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
     mixedLookupTallyKernel(const DevIndex ix, const uint2 *__restrict__ lengthTable, const unsigned char *__restrict__ chars,
                            const unsigned long long *__restrict__ offsets, const unsigned long long numQueries, const unsigned useNext,
                            const MixedTouch touch) {
   constexpr int G = 4;
+  typedef typename PositionType<NARROW>::type pos_t;
   __shared__ unsigned long long sC[24];
   __shared__ unsigned sMask[(kBlockMask + 1) * kSlices];
-  __shared__ unsigned long long sSuper[1];
+  __shared__ unsigned long long sSuper[!NARROW ? kMaxNucSuper * 4 : 1];
   __shared__ unsigned long long sPairC[16];
   extern __shared__ unsigned sPairSuper[];
   __shared__ unsigned long long sLevelAt[17];
@@ -485,8 +487,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
   if (threadIdx.x < 24) sC[threadIdx.x] = ix.prefixSums[threadIdx.x];
   if (threadIdx.x < 17) sLevelAt[threadIdx.x] = threadIdx.x >= 1u ? awfmLengthTableAt(threadIdx.x) : 0ull;
   stageMaskTable(sMask);
-  nucStageSuper<true>(ix, sSuper);
-  if (PAIR) pairStageTables<true, 16u>(ix, sPairC, sPairSuper);
+  nucStageSuper<NARROW>(ix, sSuper);
+  if (PAIR) pairStageTables<NARROW, 16u>(ix, sPairC, sPairSuper);
   __syncthreads();
   const unsigned DK = ix.deepK;
   const unsigned gl = threadIdx.x % G;
@@ -510,36 +512,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
     if (len >= DK) mark(touch.deepLines, (unsigned long long)(at - (const uint2 *)ix.deepSeed) >> 4);
     else mark(touch.lengthLines, (unsigned long long)(at - lengthTable) >> 4);
     const uint2 entry = *at;
-    const MixedVerdict<unsigned> v = mixedRead<unsigned>(ix, useNext, len, codes, entry);
+    const MixedVerdict<pos_t> v = mixedRead<pos_t>(ix, useNext, len, codes, entry);
     if (v.hitNow) hits += gl == 0 ? 1u : 0u;
     if (!v.survives) continue;
     alive += gl == 0 ? 1u : 0u;
-    unsigned sp = v.sp, ep = v.sp + v.length - 1u;
+    pos_t sp = v.sp, ep = v.sp + v.length - (pos_t)1;
     unsigned long long rem = codes >> (2u * DK);
     const int first = (int)(len - DK) - 1;
     int pos = first;
     auto touchPair = [&](unsigned level) {
       unsigned long long *bits = touch.pairLines + (level < kMixedTouchLevels ? level : kMixedTouchLevels - 1u) * touch.pairWords;
-      mark(bits, (unsigned long long)(sp - 1u) >> kBlockShift);
+      mark(bits, (unsigned long long)(sp - (pos_t)1) >> kBlockShift);
       mark(bits, (unsigned long long)ep >> kBlockShift);
-      reads += gl == 0 ? (((sp - 1u) >> kBlockShift) != (ep >> kBlockShift) ? 2u : 1u) : 0u;
+      reads += gl == 0 ? (((sp - (pos_t)1) >> kBlockShift) != (ep >> kBlockShift) ? 2u : 1u) : 0u;
     };
     auto touchNuc = [&](unsigned level) {
       unsigned long long *bits = touch.nucLines + (level < kMixedTouchLevels ? level : kMixedTouchLevels - 1u) * touch.nucWords;
-      mark(bits, ((unsigned long long)(sp - 1u) >> kBlockShift) >> 1);
+      mark(bits, ((unsigned long long)(sp - (pos_t)1) >> kBlockShift) >> 1);
       mark(bits, ((unsigned long long)ep >> kBlockShift) >> 1);
-      reads += gl == 0 ? (((sp - 1u) >> kBlockShift) != (ep >> kBlockShift) ? 2u : 1u) : 0u;
+      reads += gl == 0 ? (((sp - (pos_t)1) >> kBlockShift) != (ep >> kBlockShift) ? 2u : 1u) : 0u;
     };
     if (PAIR) {
       while (pos >= 1 && sp <= ep) {
         const unsigned c2 = (unsigned)rem & 3u, c1 = (unsigned)(rem >> 2) & 3u;
         touchPair((unsigned)(first - pos));
-        if (pairSearchStep<true>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep) == kPairFlagged) {
+        if (pairSearchStep<NARROW>(ix, sPairC, sPairSuper, sMask, gl, c1 * 4u + c2, sp, ep) == kPairFlagged) {
           touchNuc((unsigned)(first - pos));
-          nucFastStep<G, true>(ix, sC, sSuper, sMask, gl, c2, sp, ep);
+          nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, gl, c2, sp, ep);
           if (sp <= ep) {
             touchNuc((unsigned)(first - pos) + 1u);
-            nucFastStep<G, true>(ix, sC, sSuper, sMask, gl, c1, sp, ep);
+            nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, gl, c1, sp, ep);
           }
         }
         pos -= 2;
@@ -547,13 +549,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
       }
       if (pos == 0 && sp <= ep) {
         touchNuc((unsigned)first);
-        nucFastStep<G, true>(ix, sC, sSuper, sMask, gl, (unsigned)rem & 3u, sp, ep);
+        nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, gl, (unsigned)rem & 3u, sp, ep);
         pos--;
       }
     } else {
       while (pos >= 0 && sp <= ep) {
         touchNuc((unsigned)(first - pos));
-        nucFastStep<G, true>(ix, sC, sSuper, sMask, gl, (unsigned)rem & 3u, sp, ep);
+        nucFastStep<G, NARROW>(ix, sC, sSuper, sMask, gl, (unsigned)rem & 3u, sp, ep);
         pos--;
         rem >>= 2;
       }

@@ -449,7 +449,7 @@ def test_amino_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, req
 
 
 @pytest.mark.parametrize("pair", ["1", "0"])
-def test_deep_seed_table_next_step_bits_and_long_ranges(oracle, awfm, require_gpu, monkeypatch, pair):
+def test_deep_seed_table_next_step_bits_and_long_ranges(oracle, awfm, require_gpu, wide, monkeypatch, pair):
     """On images with pair blocks the 8-byte entries of the deeper table are {sp, length16 | next16 << 16}: the lengths
     that do not fit (a tandem repeat: six 5-mers with 120 000 occurrences each) come from deepBigBySp[sp >> 15], and the seed-order
     search drops k-mers by the next-step bits.  General kernels (exact ranges), the seed-order search (hits) and the
@@ -468,7 +468,10 @@ def test_deep_seed_table_next_step_bits_and_long_ranges(oracle, awfm, require_gp
     g.set_deep_seed(deep_k)
     # (with the next-step bits, i.e. pair blocks: the table of the lengths of 65535 and more -- the six 5-mers of the repeat --,
     # a word per 2^15 positions)
-    assert g.device_bytes == before + 8 * 4 ** deep_k + (4 * ((ix.bwt_length >> 15) + 5) if pair == "1" else 0)
+    # (an image that runs 64-bit positions: sp36 | length12 | next16 entries, the lengths of 4095 and more in 64-bit words per
+    # 2^11 positions, with or without pair blocks)
+    side = 8 * ((ix.bwt_length >> 11) + 2) if g.is_wide else (4 * ((ix.bwt_length >> 15) + 5) if pair == "1" else 0)
+    assert g.device_bytes == before + 8 * 4 ** deep_k + side
     # mixed lengths through the general kernels: exact ranges, k-mers shorter than the table included
     chars, offsets = _mixed_queries(502, 4000, txt, synth.DNA_ALPHABET, 1, 30, ambiguity=ord("x"), upper=True)
     sp, ep, cnt, _ = oi.batch_search(chars, offsets)
@@ -552,7 +555,7 @@ def test_a_walk_the_walk_kernel_gives_up_is_walked_on_exactly(oracle, awfm, requ
 
 
 @pytest.mark.parametrize("pair", ["1", "0"])
-def test_exact_ranges_through_the_tables(oracle, awfm, require_gpu, monkeypatch, pair):
+def test_exact_ranges_through_the_tables(oracle, awfm, require_gpu, wide, monkeypatch, pair):
     """awfmGpuSearch through exactLookupSearchKernel (round 5; forced here, large batches take it by themselves): every k-mer's
     final range -- for a k-mer without hits the reference's first empty range, not just some empty one -- from ONE table entry
     (the deeper table's, or the table of the k-mer's own length) and exact pair steps behind it.  Fixed lengths at, around and far
@@ -808,7 +811,7 @@ def test_drop_in_aos_api_default_lanes(oracle, awfm, require_gpu, monkeypatch):
 
 @pytest.mark.parametrize("n,seed_k,deep_k,K,pair", [(300000, 8, 12, 21, "1"), (300000, 8, 12, 13, "1"), (200000, 6, 9, 9, "1"),
                                                     (300000, 8, 12, 21, "0"), (250000, 12, 16, 24, "1"), (150000, 6, 9, 26, "1")])
-def test_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, monkeypatch, n, seed_k, deep_k, K, pair):
+def test_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, wide, monkeypatch, n, seed_k, deep_k, K, pair):
     """"Lookup first" (encodeLookupKernel): the table entry of every k-mer is read while the batch is encoded, and only the
     k-mers that are still alive after it -- and the ones with ambiguity characters, which go to the general kernel -- are
     ordered and searched.  Forced on and off over the same batches (random + planted k-mers, ambiguity characters, upper
@@ -870,7 +873,7 @@ def test_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, monkey
 
 @pytest.mark.parametrize("tail", [1, 31, 32, 63, 64, 255])
 @pytest.mark.parametrize("K", [21, 12])
-def test_lookup_first_all_hits_batch_whose_last_round_is_short(oracle, awfm, require_gpu, monkeypatch, tail, K):
+def test_lookup_first_all_hits_batch_whose_last_round_is_short(oracle, awfm, require_gpu, wide, monkeypatch, tail, K):
     """encodeLookupKernel reserves slots in blocks of 64 per wave; in the last partial round of the last share (nq % 256 in
     1..63) a block of 64 would reach past the share's region -- past the code array -- when every earlier k-mer was kept.
     Forced lookup first on batches in which EVERY k-mer has hits (nothing is dropped, no slack anywhere), with
@@ -907,7 +910,7 @@ def test_lookup_first_all_hits_batch_whose_last_round_is_short(oracle, awfm, req
 
 
 @pytest.mark.parametrize("planted_share", [0.02, 0.6])
-def test_list_sorted_scanned_and_located_without_a_host_wait(oracle, awfm, require_gpu, planted_share):
+def test_list_sorted_scanned_and_located_without_a_host_wait(oracle, awfm, require_gpu, wide, planted_share):
     """awfmGpuSearchHitsCompact -> awfmGpuSortHitsOnDevice -> awfmGpuHitOffsetsOnDevice -> awfmGpuLocateOnDevice: the list's
     length and the number of hits are read on the device only.  The sorted list, its offsets and the positions must be what
     the host-counted calls (awfmGpuSortHits / awfmGpuHitOffsets / awfmGpuLocate) and the oracle give; a position buffer that
@@ -962,7 +965,7 @@ def test_list_sorted_scanned_and_located_without_a_host_wait(oracle, awfm, requi
 @pytest.mark.gpu
 @pytest.mark.parametrize("dense_sa", [False, True])
 @pytest.mark.parametrize("shape", ["sparse", "half", "clustered", "repeats"])
-def test_list_tail_in_one_launch(oracle, awfm, require_gpu, shape, dense_sa):
+def test_list_tail_in_one_launch(oracle, awfm, require_gpu, wide, shape, dense_sa):
     """awfmGpuSearchHitsCompact -> awfmGpuListLocateOnDevice: the appended list comes out in k-mer order with its hit offsets
     and positions from ONE kernel (each workgroup finds its own prefix: no scan, no scratch), with and without the full suffix
     array, equal to the oracle's and to what the three calls it replaces leave; `clustered`: a stretch of 12 000 consecutive
@@ -1045,7 +1048,7 @@ def test_list_tail_in_one_launch(oracle, awfm, require_gpu, shape, dense_sa):
 
 
 @pytest.mark.gpu
-def test_list_tail_of_a_long_list_takes_the_three_calls(oracle, awfm, require_gpu, monkeypatch):
+def test_list_tail_of_a_long_list_takes_the_three_calls(oracle, awfm, require_gpu, wide, monkeypatch):
     """a list of more than 2^18 entries goes through copy + awfmGpuSortHitsOnDevice +
     awfmGpuHitOffsetsOnDevice + awfmGpuLocateOnDevice inside awfmGpuListLocateOnDevice: the same arrays come out"""
     import torch
@@ -1086,7 +1089,7 @@ def test_list_tail_of_a_long_list_takes_the_three_calls(oracle, awfm, require_gp
 
 
 @pytest.mark.gpu
-def test_lookup_prediction_launches_one_front_end_and_keeps_the_results(oracle, awfm, require_gpu, monkeypatch):
+def test_lookup_prediction_launches_one_front_end_and_keeps_the_results(oracle, awfm, require_gpu, wide, monkeypatch):
     """Round 5: a sampled search publishes its sample's verdict in page-locked host memory, and a later search of the same
     k-mer length launches only the front end that verdict names (awfmGpuLastLookupFront: 0 both, 1 the lookup kernel alone
     with what it cannot finish left to the general kernel, 2 the ordering passes + ordered kernel alone).  Either front end
@@ -1154,7 +1157,7 @@ def test_lookup_prediction_launches_one_front_end_and_keeps_the_results(oracle, 
     ix.dealloc()
 
 
-def test_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, monkeypatch):
+def test_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, wide, monkeypatch):
     """Without $AWFM_GPU_LOOKUP_FIRST a batch of 2^20 k-mers or more is sampled (16384 k-mers at a fixed stride): random
     21-mers against a small text nearly all end at the deeper table -> encodeLookupKernel; k-mers drawn from the text all
     survive it -> the count + partition passes as before.  Counts against the oracle either way."""
@@ -1588,7 +1591,7 @@ def test_ordered_hits_only_search_of_mixed_length_batches(oracle, awfm, require_
 
 @pytest.mark.parametrize("n,seed_k,deep_k,pair,lo,hi", [(300000, 8, 12, "1", 0, 40), (300000, 8, 12, "0", 1, 32), (200000, 6, 9, "1", 0, 36),
                                                         (4096, 3, 5, "1", 0, 20), (250000, 12, 16, "1", 8, 30), (150000, 1, 2, "1", 0, 12)])
-def test_mixed_length_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, monkeypatch, n, seed_k, deep_k, pair, lo, hi):
+def test_mixed_length_lookup_first_keeps_hits_bit_identical(oracle, awfm, require_gpu, wide, monkeypatch, n, seed_k, deep_k, pair, lo, hi):
     """"Lookup first" for mixed-length batches (mixedLookupSearchKernel): one table entry per k-mer -- the table of its own
     length when it is shorter than the deeper table's k-mers, the deeper table otherwise --, the survivors stepped by the
     kernel that looked them up, what it does not cover (ambiguity characters, no characters, more than 32) left to the
@@ -1655,7 +1658,7 @@ def test_mixed_length_lookup_first_keeps_hits_bit_identical(oracle, awfm, requir
 
 
 @pytest.mark.parametrize("seed_order", [True, False])
-def test_mixed_length_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, monkeypatch, seed_order):
+def test_mixed_length_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, awfm, require_gpu, wide, monkeypatch, seed_order):
     """Without $AWFM_GPU_MIXED_LOOKUP a mixed-length batch of 2^20 k-mers or more is sampled: random 8..30-mers against a
     small text mostly end at their table entry -> mixedLookupSearchKernel; k-mers drawn from the text, most of them longer
     than the deeper table's, survive it -> the 16-byte-record path as before.  Counts against the oracle either way.
@@ -1706,7 +1709,7 @@ def test_mixed_length_lookup_first_is_chosen_by_a_sample_of_the_batch(oracle, aw
     ix.dealloc()
 
 
-def test_mixed_length_lookup_prediction_and_whole_line_counts(oracle, awfm, require_gpu, monkeypatch):
+def test_mixed_length_lookup_prediction_and_whole_line_counts(oracle, awfm, require_gpu, wide, monkeypatch):
     """Round 5, mixed-length batches: the sample's verdict goes to page-locked host memory as for fixed lengths, and a batch
     whose predecessors agree launches one front end (awfmGpuLastLookupFront: 1 = mixedLookupSearchKernel alone, which then
     takes whatever the batch is; 2 = the 16-byte-record path alone).  With the lookup kernel alone a dense search is not
