@@ -95,10 +95,14 @@ ordered = [k for k in summary if k.startswith("orderedSearchKernel") and "FETCH_
 # the instantiation the timed steps run (the instrumented one of the line tally is launched once)
 ordered.sort(key=lambda k: -summary[k]["FETCH_SIZE"]["dispatches"])
 if ordered:
-    calls = summary[ordered[0]]["FETCH_SIZE"]["dispatches"]
+    # search calls of the run = dispatches of the kernel that every call launches: with lookup prediction a call launches the
+    # lookup kernel OR the ordered kernels, so the most-dispatched of the search kernels counts the calls (round 6: counting by
+    # the ordered kernel alone made a predicted lookup kernel look like four launches per call)
+    front = [k for k in summary if k.startswith(("lookupSearchKernel", "mixedLookupSearchKernel")) and "FETCH_SIZE" in summary[k]]
+    calls = max(summary[k]["FETCH_SIZE"]["dispatches"] for k in [ordered[0]] + front)
     parts = [k for k in summary if "FETCH_SIZE" in summary[k] and (
              k == ordered[0] or k.startswith(("fillNoHitKernel", "fillSparseKernel", "encodeQueriesKernel", "encodeCodes", "encodeLookup", "lookupSearch", "mixedLookupSearch", "mixedSampleAlive", "encodeRecords", "partitionRecords",
-                                              "sampleAlive", "partitionKernel", "bucketScan", "segmentSumsKernel", "tileOffsetsKernel"))
+                                              "sampleAlive", "partitionKernel", "bucketScan", "segmentSumsKernel", "tileOffsetsKernel", "countScatterKernel", "countPlaceKernel", "lookupPrepKernel"))
              or ("radix_sort" in k and "unsigned short" in k) or (k.startswith("searchKernel") and k.rstrip(">").endswith("true, false")))]
     # kernels that ran fewer times than the dominant one belong to the one instrumented tally call, not to a timed call
     parts = [k for k in parts if summary[k]["FETCH_SIZE"]["dispatches"] * 2 >= calls]
