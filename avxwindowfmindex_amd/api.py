@@ -509,6 +509,14 @@ class GpuIndex:
             self.handle, d_records, d_bucket_start, first_bucket, end_bucket, fixed_length, total_queries, d_order_kmers, d_order_ranges,
             stream or None))
 
+    def merge_bucket_runs(self, d_received, d_slice_at, d_slice_starts, num_slices, first_bucket, end_bucket, buckets, d_records,
+                          d_bucket_start, stream=0):
+        """awfmGpuMergeBucketRuns: the slices a rank received in the exchange of the seed-bucket sharding, put in bucket order
+        (one launch), with the bucket starts search_ordered_records wants"""
+        _check("awfmGpuMergeBucketRuns", _lib.lib().awfmGpuMergeBucketRuns(
+            self.handle, d_received, d_slice_at, d_slice_starts, num_slices, first_bucket, end_bucket, buckets, d_records, d_bucket_start,
+            stream or None))
+
     def search_general_records(self, d_chars, fixed_length, n, first_number, total_queries, d_records, d_bucket_start, d_order_kmers,
                                d_order_ranges, stream=0):
         """awfmGpuSearchGeneralRecords: the tail of a shard's own records (k-mers with ambiguity characters) through the general kernel"""

@@ -1706,6 +1706,70 @@ extern "C" enum AwFmReturnCode awfmGpuOrderKmers(AwFmGpuIndex *g, const uint8_t 
   return AwFmSuccess;
 }
 
+/* ---- what a rank holds after the exchange, put in bucket order (include/awfm_gpu.h) ---- */
+namespace {
+constexpr unsigned kMergeParts = 16; /* workgroups per bucket */
+/* Workgroup (b, part): the part-th share of every slice's run of bucket b, copied to where the bucket's runs lie next to each
+ * other, slice by slice.  Where that is needs no pass of its own: the records before bucket b are the sum over the slices of
+ * THEIR records before b (starts[j][b], a slice's starts being relative to the slice).  The workgroups behind the last bucket
+ * write the bucket starts awfmGpuSearchOrderedRecords wants. */
+__global__ void __launch_bounds__(256)
+    mergeBucketRunsKernel(const unsigned long long *__restrict__ received, const unsigned long long *__restrict__ sliceAt,
+                          const unsigned *__restrict__ starts, const unsigned numSlices, const unsigned firstBucket, const unsigned endBucket,
+                          const unsigned buckets, unsigned long long *__restrict__ out, unsigned *__restrict__ bucketStartOut) {
+  const unsigned nb = endBucket - firstBucket, stride = nb + 1u;
+  const unsigned b = blockIdx.x / kMergeParts, part = blockIdx.x % kMergeParts;
+  if (b >= nb) { /* the last workgroups: the array of bucket starts (buckets + 3 words) */
+    const unsigned worker = (blockIdx.x - nb * kMergeParts) * 256u + threadIdx.x, workers = (gridDim.x - nb * kMergeParts) * 256u;
+    unsigned long long total = 0;
+    for (unsigned j = 0; j < numSlices; j++) total += starts[j * stride + nb];
+    for (unsigned e = worker; e < buckets + 3u; e += workers) {
+      unsigned long long v = 0;
+      if (e >= firstBucket && e <= endBucket) {
+        for (unsigned j = 0; j < numSlices; j++) v += starts[j * stride + (e - firstBucket)];
+      } else if (e > endBucket && e < buckets + 2u) {
+        v = total; /* nothing behind this rank's buckets; [buckets], [buckets + 1]: the records held */
+      }
+      bucketStartOut[e] = (unsigned)v;
+    }
+    return;
+  }
+  unsigned long long to = 0;
+  for (unsigned j = 0; j < numSlices; j++) to += starts[j * stride + b];
+  for (unsigned j = 0; j < numSlices; j++) {
+    const unsigned first = starts[j * stride + b], count = starts[j * stride + b + 1u] - first;
+    const unsigned share = (count + kMergeParts - 1u) / kMergeParts;
+    const unsigned lo = part * share < count ? part * share : count, hi = lo + share < count ? lo + share : count;
+    const unsigned long long *from = received + sliceAt[j] + first;
+    for (unsigned i = lo + threadIdx.x; i < hi; i += 256u) out[to + i] = from[i];
+    to += count;
+  }
+}
+}  // namespace
+
+extern "C" enum AwFmReturnCode awfmGpuMergeBucketRuns(AwFmGpuIndex *g, const uint64_t *dReceived, const uint64_t *dSliceAt, const uint32_t *dSliceStarts,
+                                                      uint32_t numSlices, uint32_t firstBucket, uint32_t endBucket, uint32_t buckets, uint64_t *dRecords,
+                                                      uint32_t *dBucketStart, void *stream) {
+  if (!g || !dReceived || !dSliceAt || !dSliceStarts || !dRecords || !dBucketStart) {
+    setError("awfmGpuMergeBucketRuns: null argument");
+    return AwFmNullPtrError;
+  }
+  if (numSlices == 0u || firstBucket >= endBucket || endBucket > buckets) {
+    setError("awfmGpuMergeBucketRuns: slices of the buckets [first, end) of `buckets` (awfmGpuOrderBuckets)");
+    return AwFmIllegalPositionError;
+  }
+  DeviceGuard guard(g->device);
+  const unsigned nb = endBucket - firstBucket;
+  hipLaunchKernelGGL(mergeBucketRunsKernel, dim3(nb * kMergeParts + 4u), dim3(256), 0, (hipStream_t)stream, (const unsigned long long *)dReceived,
+                     (const unsigned long long *)dSliceAt, dSliceStarts, numSlices, firstBucket, endBucket, buckets, (unsigned long long *)dRecords, dBucketStart);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    setError("awfmGpuMergeBucketRuns", e);
+    return AwFmGeneralFailure;
+  }
+  return AwFmSuccess;
+}
+
 extern "C" enum AwFmReturnCode awfmGpuSearchOrderedRecords(AwFmGpuIndex *g, const uint64_t *dRecords, const uint32_t *dBucketStart, uint32_t firstBucket,
                                                            uint32_t endBucket, uint32_t fixedLength, uint64_t totalQueries, uint32_t *dOrderKmers,
                                                            struct AwFmSearchRange *dOrderRanges, void *stream) {

@@ -208,6 +208,38 @@ def bucket_exchange(records, bucket_start, buckets, world, rank, group=None):
     return merge_bucket_slices(parts, mine, cuts[rank], cuts[rank + 1])
 
 
+def bucket_exchange_on_device(g, records, bucket_start, buckets, world, rank, group=None, stream=0):
+    """bucket_exchange for records that live on the device of the image `g` (api.GpuIndex): the same all-to-all, and the
+    slices put in bucket order by ONE kernel (awfmGpuMergeBucketRuns) instead of torch's index arithmetic.  Returns (records of
+    this rank's buckets in bucket order, the buckets + 3 bucket starts awfmGpuSearchOrderedRecords wants, on the device)."""
+    import torch
+    import torch.distributed as dist
+    cuts = bucket_cuts(buckets, world)
+    bs = torch.as_tensor(bucket_start, dtype=torch.int64).cpu()
+    send_at = [int(bs[c]) for c in cuts]
+    send_sizes = [send_at[j + 1] - send_at[j] for j in range(world)]
+    rel = [(bs[cuts[j]: cuts[j + 1] + 1] - bs[cuts[j]]).tolist() for j in range(world)]
+    if world == 1:
+        theirs_for_me, recv, recv_sizes = [rel[0]], records[send_at[0]: send_at[1]], [send_sizes[0]]
+    else:
+        theirs = [None] * world
+        dist.all_gather_object(theirs, rel)  # theirs[j][r]: rank j's starts inside the slice it sends to rank r
+        theirs_for_me = [theirs[j][rank] for j in range(world)]
+        recv_sizes = [int(t[-1]) for t in theirs_for_me]
+        send = records[send_at[0]: send_at[-1]].contiguous()
+        recv = torch.empty(sum(recv_sizes), dtype=records.dtype, device=records.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=recv_sizes, input_split_sizes=send_sizes, group=group)
+    slice_at = torch.tensor([sum(recv_sizes[:j]) for j in range(len(recv_sizes))], dtype=torch.int64)
+    starts = torch.tensor(theirs_for_me, dtype=torch.int32)  # [slice][bucket of mine + 1]
+    d_slice_at, d_starts = slice_at.to(records.device, non_blocking=True), starts.to(records.device, non_blocking=True)
+    out = torch.empty(max(int(sum(recv_sizes)), 1), dtype=torch.int64, device=records.device)
+    d_full = torch.empty(buckets + 3, dtype=torch.int32, device=records.device)
+    g.merge_bucket_runs(recv.data_ptr(), d_slice_at.data_ptr(), d_starts.data_ptr(), len(recv_sizes), cuts[rank], cuts[rank + 1], buckets,
+                        out.data_ptr(), d_full.data_ptr(), stream)
+    keep = (recv, d_slice_at, d_starts)  # (alive until the kernel has run: the caller keeps the tuple)
+    return out[: int(sum(recv_sizes))], d_full, keep
+
+
 def full_bucket_start(merged_start, first_bucket, end_bucket, buckets):
     """the bucket starts awfmGpuSearchOrderedRecords wants (buckets + 3 words) for an array that holds the buckets
     [first_bucket, end_bucket) only: nothing before them, everything before what follows them"""

@@ -903,13 +903,14 @@ def seed_bucket_run(args, L, api, digest, shard, torch, np, dev, g, ix, d_chars,
         front_obj.synchronize()  # the host wait of a step: the slice sizes of the exchange
         bs = s["bs"].cpu().to(torch.int64)
         with torch.cuda.stream(front_obj):
-            if via_host:
+            if via_host:  # (the tests' way: gloo moves host tensors; the slices are put in bucket order by torch on the host)
                 mine, mstart = shard.bucket_exchange(s["recs"].cpu(), bs[: buckets + 1], buckets, world, rank)
                 mine = mine.to(dev)
-            else:
-                mine, mstart = shard.bucket_exchange(s["recs"], bs[: buckets + 1], buckets, world, rank, group=shard.timing_group())
+                full = shard.full_bucket_start(mstart, cuts[rank], cuts[rank + 1], buckets).to(dev)
+            else:  # records stay on the device: all-to-all over RCCL (one rank: none), awfmGpuMergeBucketRuns puts the slices together
+                mine, full, s["exchange_keep"] = shard.bucket_exchange_on_device(g, s["recs"], bs[: buckets + 1], buckets, world, rank,
+                                                                                 group=shard.timing_group(), stream=sf)
             m = mine.numel()
-            full = shard.full_bucket_start(mstart, cuts[rank], cuts[rank + 1], buckets).to(dev)
             if s["m"] != m:
                 s.update(m=m, k=torch.empty(max(m, 1), dtype=torch.int32, device=dev), r=torch.empty(max(m, 1) * 2, dtype=torch.int64, device=dev),
                          o=torch.zeros(max(m, 1) + 1, dtype=torch.int64, device=dev),
@@ -2226,10 +2227,9 @@ def main():
         # ---- round 6: the dense-hit batch sharded by SEED BUCKET instead of by batch position (include/awfm_gpu.h:
         # awfmGpuOrderKmers / awfmGpuSearchOrderedRecords; dist.bucket_exchange is the exchange N real ranks run).  A rank's
         # step: order its own contiguous N-th of the batch (timed), send every other rank the records of that rank's buckets
-        # and receive its own (PRICED: one GPU cannot time an exchange over xGMI), put the N slices in bucket order (timed as the
-        # copy it is), search the dense N-th of the ORDER it then holds and locate its hits (timed).  The records of a rank's
-        # buckets from all N shards are exactly the records of those buckets in the whole batch's order, so that is what the
-        # timed search reads.  Results carry the k-mers' numbers in the whole batch: the ranks' digests add up to the batch's. ----
+        # and receive its own (PRICED: one GPU cannot time an exchange over xGMI), put the N slices it received in bucket order
+        # (awfmGpuMergeBucketRuns, timed, on the slices the N shards' own orders give), search the dense N-th of the ORDER it
+        # then holds and locate its hits (timed, on those merged records).  Results carry the k-mers' numbers in the whole batch: the ranks' digests add up to the batch's. ----
         if d_planted is not None and locate and d_offsets is None and g.order_buckets(K, Q):
             buckets = g.order_buckets(K, Q)
             d_all_recs = torch.empty(Q, dtype=torch.int64, device=dev)
@@ -2243,6 +2243,17 @@ def main():
             per_n = {}
             for parts in (2, 4, 8):
                 cuts = shard.bucket_cuts(buckets, parts)
+                # the orders of all N contiguous shards (what the N ranks would hold before the exchange), made once
+                shard_recs, shard_bs = [], []
+                for j in range(parts):
+                    lo, hi = shard.shard_bounds(Q, parts, j)
+                    recs_j = torch.empty(hi - lo, dtype=torch.int64, device=dev)
+                    bs_j = torch.empty(buckets + 3, dtype=torch.int32, device=dev)
+                    g.order_kmers(d_planted.data_ptr() + lo * K, K, hi - lo, first + lo, first + Q, recs_j.data_ptr(), bs_j.data_ptr(), st)
+                    shard_recs.append(recs_j)
+                    shard_bs.append(bs_j)
+                torch.cuda.synchronize()
+                bs_host = [b.cpu().to(torch.int64) for b in shard_bs]
                 rows, sum_c, sum_p = [], 0, 0
                 for r in range(parts):
                     lo, hi = shard.shard_bounds(Q, parts, r)
@@ -2252,21 +2263,34 @@ def main():
                     def order_own():
                         g.order_kmers(d_planted.data_ptr() + lo * K, K, hi - lo, first + lo, first + Q, d_recs.data_ptr(), d_bs.data_ptr(), st)
 
-                    b0, b1 = int(all_bs[cuts[r]]), int(all_bs[cuts[r + 1]])
-                    m = b1 - b0
+                    # what rank r receives: slice j = the records of r's buckets in shard j's order, with the starts of its buckets
+                    c0, c1 = cuts[r], cuts[r + 1]
+                    sizes = [int(bs_host[j][c1] - bs_host[j][c0]) for j in range(parts)]
+                    d_received = torch.cat([shard_recs[j][int(bs_host[j][c0]): int(bs_host[j][c1])] for j in range(parts)])
+                    d_slice_at = torch.tensor([sum(sizes[:j]) for j in range(parts)], dtype=torch.int64).to(dev)
+                    d_starts = torch.stack([(bs_host[j][c0: c1 + 1] - bs_host[j][c0]).to(torch.int32) for j in range(parts)]).to(dev)
+                    m = int(sum(sizes))
+                    assert m == int(all_bs[c1]) - int(all_bs[c0]), "the slices of a rank's buckets do not add up to those buckets of the whole order"
+                    d_mine = torch.empty(m, dtype=torch.int64, device=dev)
+                    d_full = torch.empty(buckets + 3, dtype=torch.int32, device=dev)
+
+                    def merge_own():
+                        g.merge_bucket_runs(d_received.data_ptr(), d_slice_at.data_ptr(), d_starts.data_ptr(), parts, c0, c1, buckets,
+                                            d_mine.data_ptr(), d_full.data_ptr(), st)
+
+                    merge_own()
                     d_k = torch.empty(m, dtype=torch.int32, device=dev)
                     d_r = torch.empty(m * 2, dtype=torch.int64, device=dev)
                     d_o = torch.empty(m + 1, dtype=torch.int64, device=dev)
                     d_sc = torch.empty(api.GpuIndex.scan_scratch_bytes(m), dtype=torch.uint8, device=dev)
-                    g.search_ordered_records(d_all_recs.data_ptr(), d_all_bs.data_ptr(), cuts[r], cuts[r + 1], K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st)
+                    g.search_ordered_records(d_mine.data_ptr(), d_full.data_ptr(), c0, c1, K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st)
                     g.hit_offsets_on_device(0, d_r.data_ptr(), m, d_o.data_ptr(), d_sc.data_ptr(), st)
                     torch.cuda.synchronize()
                     hits_r = int(d_o[m].item())
                     d_p = torch.empty(hits_r + hits_r // 8 + 64, dtype=torch.int64, device=dev)
-                    d_merge = torch.empty(m, dtype=torch.int64, device=dev)
 
                     def search_own():
-                        g.search_ordered_records(d_all_recs.data_ptr(), d_all_bs.data_ptr(), cuts[r], cuts[r + 1], K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st)
+                        g.search_ordered_records(d_mine.data_ptr(), d_full.data_ptr(), c0, c1, K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st)
                         g.hit_offsets_on_device(0, d_r.data_ptr(), m, d_o.data_ptr(), d_sc.data_ptr(), st)
                         g.locate_on_device(d_r.data_ptr(), d_o.data_ptr(), m, d_p.numel(), d_p.data_ptr(), st)
 
@@ -2280,9 +2304,8 @@ def main():
                         return (time.perf_counter() - t1) * 1e3 / args.proxy_steps
 
                     order_ms = timed(order_own)
+                    merge_ms = timed(merge_own)
                     search_ms_r = timed(search_own)
-                    with torch.cuda.stream(lanes[0].torch_stream):
-                        merge_ms = timed(lambda: d_merge.copy_(d_all_recs[b0:b1]))
                     # every rank sends (and receives) N - 1 slices of about m / N records at once, each over a link of its own
                     exchange_ms = (m / parts * 8) / (XGMI_LINK_GBS * XGMI_EFFICIENCY * 1e9) * 1e3 if parts > 1 else 0.0
                     rows.append({"order_own_shard_ms": round(order_ms, 4), "exchange_ms_priced": round(exchange_ms, 4), "merge_ms": round(merge_ms, 4),
@@ -2295,7 +2318,8 @@ def main():
                     assert int(ids.min().item()) >= first and int(ids.max().item()) < first + Q
                     sum_c += digest.counts_digest_keyed(ids, d_o[1:] - d_o[:-1])
                     sum_p += digest.positions_digest_keyed(ids, d_o, d_p[: max(hits_r, 1)])
-                    del d_recs, d_bs, d_k, d_r, d_o, d_sc, d_p, d_merge, ids
+                    del d_recs, d_bs, d_k, d_r, d_o, d_sc, d_p, d_mine, d_full, d_received, ids
+                del shard_recs, shard_bs
                 assert (sum_c & digest.MASK) == int(pdig["counts"], 16), f"seed-bucket sharding: the counts digests of {parts} ranks do not add up to the batch's"
                 assert (sum_p & digest.MASK) == int(pdig["positions"], 16), f"seed-bucket sharding: the positions digests of {parts} ranks do not add up"
                 slowest = max(rw["total_ms"] for rw in rows)

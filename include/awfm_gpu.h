@@ -517,7 +517,7 @@ enum AwFmReturnCode awfmGpuSynthMixedQueries(uint8_t *dOut, const uint64_t *dOff
  * The reference treats the k-mers of a batch as independent (ref src/AwFmParallelSearch.c:103-129), so ANY split of a batch
  * over index replicas gives the same results.  A contiguous split of the batch hands every rank a THIN slice of the seed order
  * (one k-mer per two block lines where the whole batch has four per line): its search re-reads nothing from the L2 and an 8-way
- * split of 10^8 k-mers drawn from the text scales to 0.67.  These three calls let N ranks split the ORDER instead: every rank
+ * split of 10^8 k-mers drawn from the text scales to 0.67.  These calls let N ranks split the ORDER instead: every rank
  * orders its own contiguous shard (awfmGpuOrderKmers: the counting and the partition pass, records {rest of the code string,
  * number in the WHOLE batch} in bucket order), the ranks exchange the records bucket range by bucket range (rank j gets the
  * buckets [j B / N, (j + 1) B / N) of everybody: contiguous slices, whose per-bucket runs the receiver puts together bucket by
@@ -531,6 +531,15 @@ uint32_t awfmGpuOrderBuckets(const AwFmGpuIndex *g, uint32_t fixedLength, uint64
 enum AwFmReturnCode awfmGpuOrderKmers(AwFmGpuIndex *g, const uint8_t *dChars, uint32_t fixedLength, uint64_t numQueries,
                                       uint64_t firstNumber, uint64_t totalQueries, uint64_t *dRecords, uint32_t *dBucketStart,
                                       void *stream);
+/* What a rank holds after the exchange, put in bucket order, in one launch: `dReceived` = the numSlices slices the ranks sent
+ * (slice j begins at record dSliceAt[j]; each holds the sender's records of the buckets [firstBucket, endBucket), bucket by
+ * bucket), dSliceStarts[j * (endBucket - firstBucket + 1) + b] = records of slice j before its bucket firstBucket + b (the
+ * last one: the slice's length).  dRecords gets the runs of a bucket from all slices next to each other, slice by slice (any
+ * order inside a bucket will do), dBucketStart the buckets + 3 words awfmGpuSearchOrderedRecords wants for an array that holds
+ * those buckets only. */
+enum AwFmReturnCode awfmGpuMergeBucketRuns(AwFmGpuIndex *g, const uint64_t *dReceived, const uint64_t *dSliceAt, const uint32_t *dSliceStarts,
+                                           uint32_t numSlices, uint32_t firstBucket, uint32_t endBucket, uint32_t buckets, uint64_t *dRecords,
+                                           uint32_t *dBucketStart, void *stream);
 /* the buckets [firstBucket, endBucket) of `dRecords` (bucket order, dBucketStart as above); entry e of the outputs belongs to
  * record dBucketStart[firstBucket] + e */
 enum AwFmReturnCode awfmGpuSearchOrderedRecords(AwFmGpuIndex *g, const uint64_t *dRecords, const uint32_t *dBucketStart,

@@ -66,6 +66,17 @@ def test_seed_bucket_sharding_gives_the_reference_results(oracle, awfm, require_
         if m == 0:
             continue
         d_bs = shard.full_bucket_start(mstart, cuts[r], cuts[r + 1], buckets).to(dev)
+        # the same in one launch (awfmGpuMergeBucketRuns: what the ranks of a real run call on what they received)
+        d_received = torch.cat(slices)
+        sizes = [int(sl.numel()) for sl in slices]
+        d_slice_at = torch.tensor([sum(sizes[:j]) for j in range(world)], dtype=torch.int64).to(dev)
+        d_starts = torch.stack([t.to(torch.int32) for t in rel]).to(dev)
+        d_merged2 = torch.full((m,), -1, dtype=torch.int64, device=dev)
+        d_bs2 = torch.full((buckets + 3,), -1, dtype=torch.int32, device=dev)
+        g.merge_bucket_runs(d_received.data_ptr(), d_slice_at.data_ptr(), d_starts.data_ptr(), world, cuts[r], cuts[r + 1], buckets,
+                            d_merged2.data_ptr(), d_bs2.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(d_merged2, merged.to(dev)) and torch.equal(d_bs2, d_bs), "the merge kernel and torch's index arithmetic disagree"
         d_k = torch.full((m,), -1, dtype=torch.int32, device=dev)
         d_r = torch.zeros(m * 2, dtype=torch.int64, device=dev)
         g.search_ordered_records(merged.data_ptr(), d_bs.data_ptr(), cuts[r], cuts[r + 1], K, Q, d_k.data_ptr(), d_r.data_ptr())
