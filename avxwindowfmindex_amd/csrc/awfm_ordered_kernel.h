@@ -1268,7 +1268,10 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
   /* BUCKET: a record does not hold the bits its bucket stands for; the bucket of a position is where bucketStart says.
    * The wave keeps the bucket of the chunk it looked at last (its chunks come in increasing order): wave-uniform, scalar
    * loads. */
-  const unsigned numBuckets = BUCKET ? 1u << bucketFmt.bucketBits : 0u;
+  /* (the buckets this launch covers end at endBucket: behind it an array that holds a share of the order only has every start
+   * equal to its length, and a wave looking for the bucket of the share's last chunk walked through all of them -- 1792 dependent
+   * scalar loads, 0.18 ms behind a 0.67-ms search of an eighth of the order) */
+  const unsigned numBuckets = BUCKET ? (bucketFmt.endBucket != 0u ? bucketFmt.endBucket : 1u << bucketFmt.bucketBits) : 0u;
   unsigned waveBucket = 0, waveNext = 0;
   if (BUCKET && base < end) {
     unsigned lo = 0, hi = numBuckets - 1u; /* the last bucket that starts at or before `base` */

@@ -2306,6 +2306,25 @@ def main():
                     order_ms = timed(order_own)
                     merge_ms = timed(merge_own)
                     search_ms_r = timed(search_own)
+                    if os.environ.get("AWFM_BENCH_SEED_BUCKET_PROBE") and r == 0:  # where a rank's step goes, and the same on the whole batch's order
+                        probe = {"search": timed(lambda: g.search_ordered_records(d_mine.data_ptr(), d_full.data_ptr(), c0, c1, K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st)),
+                                 "offsets": timed(lambda: g.hit_offsets_on_device(0, d_r.data_ptr(), m, d_o.data_ptr(), d_sc.data_ptr(), st)),
+                                 "locate": timed(lambda: g.locate_on_device(d_r.data_ptr(), d_o.data_ptr(), m, d_p.numel(), d_p.data_ptr(), st)),
+                                 "search_whole_order": timed(lambda: g.search_ordered_records(d_all_recs.data_ptr(), d_all_bs.data_ptr(), c0, c1, K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st))}
+                        d_copy = d_all_recs[int(all_bs[c0]): int(all_bs[c1])].clone()
+                        probe["search_copy_of_whole_order_with_own_starts"] = timed(lambda: g.search_ordered_records(d_copy.data_ptr(), d_full.data_ptr(), c0, c1, K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st))
+                        # the merged array with every bucket's records put in k-mer-number order (what the whole order nearly has)
+                        bstart = d_full[c0: c1 + 1].to(torch.int64)
+                        bucket_of = torch.repeat_interleave(torch.arange(c1 - c0, device=dev), bstart[1:] - bstart[:-1])
+                        key = (bucket_of << 32) | (d_mine & ((1 << 27) - 1))
+                        d_sorted = d_mine[torch.argsort(key)]
+                        probe["search_merged_sorted_by_number_inside_buckets"] = timed(lambda: g.search_ordered_records(d_sorted.data_ptr(), d_full.data_ptr(), c0, c1, K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st))
+                        g.search_ordered_records(d_all_recs.data_ptr(), d_all_bs.data_ptr(), c0, c1, K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st)
+                        g.hit_offsets_on_device(0, d_r.data_ptr(), m, d_o.data_ptr(), d_sc.data_ptr(), st)
+                        probe["locate_whole_order"] = timed(lambda: g.locate_on_device(d_r.data_ptr(), d_o.data_ptr(), m, d_p.numel(), d_p.data_ptr(), st))
+                        sys.stderr.write(f"[seed-bucket probe] N={parts}: {probe}\n")
+                        search_own()
+                        torch.cuda.synchronize()
                     # every rank sends (and receives) N - 1 slices of about m / N records at once, each over a link of its own
                     exchange_ms = (m / parts * 8) / (XGMI_LINK_GBS * XGMI_EFFICIENCY * 1e9) * 1e3 if parts > 1 else 0.0
                     rows.append({"order_own_shard_ms": round(order_ms, 4), "exchange_ms_priced": round(exchange_ms, 4), "merge_ms": round(merge_ms, 4),
