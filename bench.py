@@ -2336,8 +2336,16 @@ def main():
                                  "pipelined_ms": round(max(order_ms + merge_ms + search_ms_r, exchange_ms), 4)})
                     ids = d_k.to(torch.int64)
                     assert int(ids.min().item()) >= first and int(ids.max().item()) < first + Q
-                    sum_c += digest.counts_digest_keyed(ids, d_o[1:] - d_o[:-1])
-                    sum_p += digest.positions_digest_keyed(ids, d_o, d_p[: max(hits_r, 1)])
+                    dc_r = digest.counts_digest_keyed(ids, d_o[1:] - d_o[:-1]) & digest.MASK
+                    dp_r = digest.positions_digest_keyed(ids, d_o, d_p[: max(hits_r, 1)]) & digest.MASK
+                    sum_c += dc_r
+                    sum_p += dp_r
+                    # the rank's own committed digest (what rank r of N must produce when the batch is cut by seed bucket)
+                    rkey = digest.key(args.alphabet, f"planted_seed_bucket_rank{r}_of_{parts}", args.mode, n, kmer_name, args.seed_k, args.sa_ratio, first, Q)
+                    rdig = {"counts": f"{dc_r:016x}", "positions": f"{dp_r:016x}", "kmers": m}
+                    committed_rank = digest.load_golden().get(rkey)
+                    assert committed_rank is None or committed_rank == rdig, f"seed-bucket rank digest {rdig} differs from the committed {committed_rank} ({rkey})"
+                    shard_digests[rkey] = rdig
                     del d_recs, d_bs, d_k, d_r, d_o, d_sc, d_p, d_mine, d_full, d_received, ids
                 del shard_recs, shard_bs
                 assert (sum_c & digest.MASK) == int(pdig["counts"], 16), f"seed-bucket sharding: the counts digests of {parts} ranks do not add up to the batch's"
