@@ -1614,7 +1614,6 @@ def main():
         what = ("distinct (search level, 128-B line) pairs the kernel reads, tallied on the device by an "
                 "instrumented launch of the same kernel on the same sorted batch (awfmGpuSearchHitsLineTally), "
                 "x 128 B, + sorted records and keys read + results stored")
-        fused = lookup_first  # (the k-mers still alive are searched by the kernel that looked them up)
         if mixed_lookup:
             # A mixed-length batch that took "lookup first" (DESIGN.md 4c): ONE table entry per k-mer -- from the table of its
             # own length (k-mers shorter than the deeper table's) or from the deeper table --, then the steps of the k-mers
@@ -1630,7 +1629,7 @@ def main():
             what = ("the k-mers' characters and offsets + 128 B x (the distinct lines of the length tables and of the deeper table the "
                     "batch's k-mers need + the distinct (search level, line) pairs of the block reads of the k-mers still alive after "
                     "their entry), tallied on the device by awfmGpuMixedLookupLineTally, + the results stored")
-        elif lookup_first and fused:
+        elif lookup_first:
             # The batch was one for "lookup first"  and the kernel that looks the table entries up also searches
             # the few k-mers that are still alive after them (lookupSearchKernel).  Its compulsory bytes: the characters +
             # every distinct table line once (the tally's deep_table_lines: the same entries, whatever the order) + every
@@ -1642,17 +1641,6 @@ def main():
             what = ("the k-mers' characters + 128 B x (the distinct lines of the deeper table the batch's k-mers need + the distinct "
                     "(search level, line) pairs of the block reads of the k-mers still alive after the table), tallied on the "
                     "device by awfmGpuSearchHitsLineTally, + the results stored")
-        elif lookup_first:
-            # $AWFM_GPU_LOOKUP_FUSED=0: the dominant kernel is encodeLookupKernel, which reads the k-mers' characters and one
-            # table entry per k-mer and keeps the few that are still alive; the kernels after it (partition,
-            # orderedSearchKernel over what was kept) are priced in `call`.  Its compulsory bytes: the characters + every
-            # distinct table line once + what it appends per k-mer kept (code word 8 B + number 4 B).
-            dom_name = "encodeLookupKernel"
-            compulsory = Q * K + 128 * lines["deep_table_lines"] + 12 * lookup_kept
-            lines = dict(lines, kmers_kept=int(lookup_kept), characters_read=int(Q * K))
-            what = ("the k-mers' characters + 128 B x the distinct lines of the deeper table the batch's k-mers need (tallied on the "
-                    "device by awfmGpuSearchHitsLineTally: deep_table_lines) + 12 B per k-mer kept; pair_level_lines / "
-                    "nuc_level_lines are the lines the kernels AFTER it read for the k-mers kept")
         achieved = compulsory / (dom_ms * 1e-3) / 1e9
         # NEEDED bytes: what the kernel consumes -- a table lookup is an 8-byte entry (16 from 2^32 positions), not the 128-B
         # line it arrives in; the block reads of the search levels stay at their distinct lines.  traffic / needed says how
@@ -1660,10 +1648,8 @@ def main():
         entry_bytes = 8 if ix.bwt_length < (1 << 36) else 16  # (round 6: the packed entries of images of 2^32 .. 2^36 positions are 8 bytes too)
         if mixed_lookup:
             needed = streamed + 8 * lines["ordered_kmers"] + 128 * (lines["pair_level_lines"] + lines["nuc_level_lines"]) + stored
-        elif lookup_first and fused:
-            needed = Q * K + entry_bytes * Q + 128 * (lines["pair_level_lines"] + lines["nuc_level_lines"]) + stored
         elif lookup_first:
-            needed = Q * K + entry_bytes * Q + 12 * lookup_kept
+            needed = Q * K + entry_bytes * Q + 128 * (lines["pair_level_lines"] + lines["nuc_level_lines"]) + stored
         else:
             needed = (entry_bytes * lines["ordered_kmers"] + 128 * (lines["pair_level_lines"] + lines["nuc_level_lines"])
                       + lines["record_bytes_per_kmer"] * lines["ordered_kmers"] + stored)
@@ -1713,8 +1699,6 @@ def main():
                               "source": f"{csrc}: TCC_REQ_sum x 128 B over this run's kernel time; peak = the guide's chip-wide rate "
                                         "for rows gathered out of the XCDs' L2s (16.8-18.8 TB/s)"}
         dominant = {"name": dom_name, "ms": round(dom_ms, 3)}
-        if after_lookup_ms is not None and not fused:
-            dominant["orderedSearchKernel_over_the_kmers_kept_ms"] = round(after_lookup_ms, 3)
         if counters:
             for key in ("l2_hit_rate", "valu_issue_frac", "wave_wait_frac", "clock_ghz_under_profiler"):
                 if key in counters:
@@ -1727,10 +1711,8 @@ def main():
         roofline["call"] = {
             "kernels": ("awfmGpuSearchHits*: fill / memset + mixedSampleAliveKernel + mixedLookupSearchKernel + the general kernel over "
                         "what it left (+ the kernels of the 16-byte-record path, which return at once)" if mixed_lookup else
-                        "awfmGpuSearchHits*: fill / memset + sampleAliveKernel + lookupSearchKernel (+ the kernels of the other front "
-                        "end, which return at once)" if lookup_first and fused else
-                        "awfmGpuSearchHits*: fill / memset + sampleAliveKernel + encodeLookupKernel + bucketScanSharesKernel + "
-                        "partitionKernel + orderedSearchKernel over the k-mers kept" if lookup_first else
+                        "awfmGpuSearchHits*: lookupPrepKernel + lookupSearchKernel (+ the kernels of the other front end while no "
+                        "prediction holds, which return at once) + the general kernel over what it left" if lookup_first else
                         "awfmGpuSearchHits*: fill / memset + encodeCodes4Kernel (count) + bucketScanSharesKernel + partitionKernel + "
                         "orderedSearchKernel (fixed lengths with 8-byte records; 16-byte records: encodeRecordsKernel + "
                         "partitionRecordsKernel)"),
