@@ -60,13 +60,31 @@ const char *awfmGpuLastError(void);     /* thread-local text of the last failure
  * stderr, and leaves its code here. */
 enum AwFmReturnCode awfmGpuLastBatchStatus(void);
 
+/* ---- environment ----
+ * The library reads 20 variables, all through csrc/awfm_knobs.h (INTEGRATION.md section 7 explains each); none changes a
+ * result.  $AWFM_GPU_DIAG = "key=value,key=value,..." holds the test and diagnostics hooks, none of which selects a faster path:
+ *   walk_give_up=N      LF steps after which an ordinary locate's walk is parked for finishKernel to walk on
+ *   park_list=N         capacity of the full-suffix-array builder's list of parked walks (0: an entry per position)
+ *   build_wide=1        the GPU builder's 64-bit suffix sort on any text
+ *   kernel=g1|g2|g4     lanes per k-mer of the general kernel (awfmGpuIndexSetKernel does the same per image)
+ *   tally_with_deep=1   awfmGpuSearchTally starts from the deeper table (default: the index's own, the reference's bytes)
+ *   nuc_super_shift=13..31|auto   nucleotide superblocks of 2^shift positions: the arithmetic of images of 2^32 positions
+ *                       and more on small ones
+ *   stream_trace=1, aos_trace=1   host timelines of the chunked pipelines / the AoS lanes on stderr */
+
 /* ---- device image ---- */
 /* Builds the device image of `index` on GPU `device` (-1: current device or
  * $AWFM_GPU_DEVICE).  When the index has no in-memory sampled SA
- * (keepSuffixArrayInMemory == false) it is staged from index->fileDescriptor. */
+ * (keepSuffixArrayInMemory == false) it is staged from index->fileDescriptor.  The image is complete when the call returns:
+ * its device-only accelerators (deeper seed table, full suffix array: below) are built before it does. */
 enum AwFmReturnCode awfmGpuIndexCreate(const struct AwFmIndex *index, int device, AwFmGpuIndex **out);
 void awfmGpuIndexDestroy(AwFmGpuIndex *g);
-/* Side table used by awFmParallelSearch*: image for a host index, created on first use. */
+/* Side table used by awFmParallelSearch*: image for a host index, created on first use.  Round 6: the image the drop-in entry
+ * points make (awfmGpuIndexAcquireAll) is usable as soon as its blocks, pair image and copied tables are on the device; its
+ * deeper table and full suffix array are built by a thread of their own, on a stream of their own, and installed between two
+ * calls of the entry points -- the first awFmParallelSearchLocate on a GRCh38-sized index returns after 0.2 s instead of 0.9-7 s,
+ * and searches issued meanwhile run on what is there (same results).  awfmGpuIndexAcquire hands over the COMPLETE image: it
+ * waits for that thread. */
 AwFmGpuIndex *awfmGpuIndexAcquire(const struct AwFmIndex *index);
 /* Handles on the device images of a host index for every entry of $AWFM_GPU_DEVICES ("all" or a comma list of
  * ordinals), created on first use; awFmParallelSearch* deal the chunks of a list to them, one host thread each.  A device
