@@ -35,7 +35,7 @@ GPU_SYMBOLS = [
     "awfmPackKmers", "awfmGpuPackKmers", "awfmGpuUnpackKmers", "awfmGpuHostAlloc", "awfmGpuHostFree", "awfmGpuStreamPacked",
     "awfmGpuStreamChars", "awfmGpuCountPackedHost", "awfmGpuLocatePackedHost", "awfmGpuIndexSetPairImage", "awfmGpuIndexHasPairImage",
     "awfmGpuSearchHitsPacked", "awfmGpuLocateTo", "awfmGpuSearchHitsLineTally", "awfmGpuIndexDeepSeedK", "awfmGpuSearchHitsCompact", "awfmGpuCompactHits", "awfmGpuSortHits",
-    "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse", "awfmGpuSearchHitsInOrder",
+    "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse", "awfmGpuSearchHitsInOrder", "awfmGpuSearchHitsInOrderCounts",
     "awfmGpuSortHitsOnDevice", "awfmGpuHitOffsetsOnDevice", "awfmGpuLocateOnDevice", "awfmGpuLastOrderedSearchKernelMs", "awfmGpuOrderedKernelLog", "awfmGpuIndexDeepSeedBuildSeconds", "awfmGpuIndexDeepSeedTransientBytes", "awfmGpuIndexHasDenseSa", "awfmGpuIndexDenseSaBuildSeconds", "awfmGpuIndexLengthTableBytes", "awfmGpuIndexLengthTableBuildSeconds", "awfmGpuMixedLookupLineTally",
     "awfmGpuListLocateOnDevice", "awfmGpuLastLookupFront", "awfmGpuLastSearchWasExactLookup", "awfmGpuSynthPlantedQueriesUnique", "awfmGpuStreamRetire", "awfmGpuIndexDescribe", "awfmGpuIndexDeepSeedAllocSeconds", "awfmGpuAosLastStages", "awfmHostCopyGBs",
     "awfmGpuOrderBuckets", "awfmGpuOrderKmers", "awfmGpuSearchOrderedRecords", "awfmGpuSearchGeneralRecords", "awfmGpuMergeBucketRuns",
@@ -171,6 +171,7 @@ def lib():
         "awfmGpuSearchHitsCompact": (C.c_int, [vp, vp, vp, C.c_uint32, u64, C.c_int, vp, vp, C.c_uint32, vp, vp]),
         "awfmGpuCompactHits": (C.c_int, [vp, vp, vp, u64, vp, vp, vp, vp, C.c_uint32, vp, vp]),
         "awfmGpuSearchHitsInOrder": (C.c_int, [vp, vp, vp, C.c_uint32, u64, C.c_int, vp, vp, vp]),
+        "awfmGpuSearchHitsInOrderCounts": (C.c_int, [vp, vp, vp, C.c_uint32, u64, C.c_int, vp, vp, vp, vp]),
         "awfmGpuOrderBuckets": (C.c_uint32, [vp, C.c_uint32, u64]),
         "awfmGpuOrderKmers": (C.c_int, [vp, vp, C.c_uint32, u64, u64, u64, vp, vp, vp]),
         "awfmGpuSearchOrderedRecords": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, u64, vp, vp, vp]),

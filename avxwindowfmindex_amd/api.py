@@ -524,10 +524,13 @@ class GpuIndex:
             self.handle, d_chars, fixed_length, n, first_number, total_queries, d_records, d_bucket_start, d_order_kmers, d_order_ranges,
             stream or None))
 
-    def search_hits_in_order(self, d_chars, d_offsets, fixed_length, n, d_order_kmers, d_order_ranges, packed=False, stream=0):
-        """awfmGpuSearchHitsInOrder: {k-mer number, range} for every k-mer, in the order the seed-order search took them"""
-        _check("awfmGpuSearchHitsInOrder", _lib.lib().awfmGpuSearchHitsInOrder(
-            self.handle, d_chars, d_offsets or None, fixed_length, n, int(bool(packed)), d_order_kmers, d_order_ranges, stream or None))
+    def search_hits_in_order(self, d_chars, d_offsets, fixed_length, n, d_order_kmers, d_order_ranges, packed=False, stream=0,
+                             d_order_counts=0):
+        """awfmGpuSearchHitsInOrder[Counts]: {k-mer number, range} for every k-mer, in the order the seed-order search took them;
+        d_order_counts: the 32-bit counts in that order as well"""
+        _check("awfmGpuSearchHitsInOrderCounts", _lib.lib().awfmGpuSearchHitsInOrderCounts(
+            self.handle, d_chars, d_offsets or None, fixed_length, n, int(bool(packed)), d_order_kmers, d_order_ranges,
+            d_order_counts or None, stream or None))
 
     def compact_hits(self, d_counts, d_ranges, n, d_flag_offsets, d_scratch, d_hit_kmers, d_hit_ranges, capacity, d_num_hits,
                      stream=0):

@@ -1593,6 +1593,12 @@ extern "C" enum AwFmReturnCode awfmGpuSearchHitsCompact(AwFmGpuIndex *g, const u
 extern "C" enum AwFmReturnCode awfmGpuSearchHitsInOrder(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
                                                         uint32_t fixedLength, uint64_t numQueries, int packed, uint32_t *dOrderKmers,
                                                         struct AwFmSearchRange *dOrderRanges, void *stream) {
+  return awfmGpuSearchHitsInOrderCounts(g, dChars, dOffsets, fixedLength, numQueries, packed, dOrderKmers, dOrderRanges, nullptr, stream);
+}
+
+extern "C" enum AwFmReturnCode awfmGpuSearchHitsInOrderCounts(AwFmGpuIndex *g, const uint8_t *dChars, const uint64_t *dOffsets,
+                                                              uint32_t fixedLength, uint64_t numQueries, int packed, uint32_t *dOrderKmers,
+                                                              struct AwFmSearchRange *dOrderRanges, uint32_t *dOrderCounts, void *stream) {
   if (!g || !dChars || !dOrderKmers || !dOrderRanges) {
     setError("awfmGpuSearchHitsInOrder: null argument");
     return AwFmNullPtrError;
@@ -1608,7 +1614,7 @@ extern "C" enum AwFmReturnCode awfmGpuSearchHitsInOrder(AwFmGpuIndex *g, const u
   out.kmers = (unsigned *)dOrderKmers;
   out.ranges = (ulonglong2 *)dOrderRanges;
   const int did = orderedSearch(g, (hipStream_t)stream, dChars, (const unsigned long long *)dOffsets, fixedLength, numQueries, nullptr,
-                                nullptr, packed != 0, false, nullptr, nullptr, &out);
+                                dOrderCounts, packed != 0, false, nullptr, nullptr, &out);
   if (did < 0) return (enum AwFmReturnCode)(-did);
   if (did == 0) {
     setError("awfmGpuSearchHitsInOrder: this batch does not take the seed-order path on this image");

@@ -1493,6 +1493,9 @@ __global__ void __launch_bounds__(orderedThreads(PAIR)) __attribute__((amdgpu_nu
         if (mine && sparse.ranges) {
           sparse.kmers[at - coveredFirst] = index; /* (a share of the order: its entries from 0) */
           sparse.ranges[at - coveredFirst] = sp <= ep ? make_ulonglong2((unsigned long long)sp, (unsigned long long)ep) : make_ulonglong2(1ull, 0ull);
+          /* the counts in the same order when they are asked for (awfmGpuSearchHitsInOrderCounts): the scan that follows reads
+           * 4 instead of 16 bytes per k-mer */
+          if (counts) counts[at - coveredFirst] = sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u;
         } else if (mine) { /* counts only (awfm_count_order_kernel.h): {k-mer number, count}, taken home by two passes */
           ((uint2 *)sparse.kmers)[at - coveredFirst] = make_uint2(index, sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u);
         }

@@ -353,6 +353,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80), 
         const unsigned long long slot = subsetTotal - listed + q;
         sparse.kmers[slot] = (unsigned)queryNumber(q);
         sparse.ranges[slot] = make_ulonglong2((unsigned long long)sp, (unsigned long long)ep);
+        if (counts) counts[slot] = sp <= ep ? (unsigned)(ep - sp + (pos_t)1) : 0u; /* (counts in search order too) */
       }
     } else if (gl == 0) {
       const unsigned long long out = queryNumber(q);

@@ -523,15 +523,16 @@ def repetitive_leg(L, api, digest, torch, np, dev, n=3_100_000_000, Q=100_000_00
     stream_obj = torch.cuda.Stream()
     stream = stream_obj.cuda_stream
     torch.cuda.synchronize()
-    g.search_hits_in_order(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
-    g.hit_offsets_on_device(0, d_ranges.data_ptr(), Q, d_off.data_ptr(), d_scratch.data_ptr(), stream)
+    d_ocounts = torch.empty(Q, dtype=torch.int32, device=dev)  # (the counts in search order: the scan reads them, not the ranges)
+    g.search_hits_in_order(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream, d_order_counts=d_ocounts.data_ptr())
+    g.hit_offsets_on_device(d_ocounts.data_ptr(), 0, Q, d_off.data_ptr(), d_scratch.data_ptr(), stream)
     torch.cuda.synchronize()
     hits = int(d_off[Q].item())
     d_pos = torch.empty(hits + hits // 8 + 64, dtype=torch.int64, device=dev)
 
     def step():
-        g.search_hits_in_order(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream)
-        g.hit_offsets_on_device(0, d_ranges.data_ptr(), Q, d_off.data_ptr(), d_scratch.data_ptr(), stream)
+        g.search_hits_in_order(d_chars.data_ptr(), 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(), stream=stream, d_order_counts=d_ocounts.data_ptr())
+        g.hit_offsets_on_device(d_ocounts.data_ptr(), 0, Q, d_off.data_ptr(), d_scratch.data_ptr(), stream)
         g.locate_on_device(d_ranges.data_ptr(), d_off.data_ptr(), Q, d_pos.numel(), d_pos.data_ptr(), stream)
 
     timing = os.environ.get("AWFM_GPU_TIME_ORDERED")
@@ -1267,7 +1268,10 @@ def main():
             g.search_hits_compact(p.chars_ptr, p.off_ptr, K, p.q, ln.hit_kmers.data_ptr(), ln.hit_ranges.data_ptr(), p.cap,
                                   ln.num_hits.data_ptr(), stream=ln.stream)
         elif form == "order":
-            g.search_hits_in_order(p.chars_ptr, p.off_ptr, K, p.q, ln.order_kmers.data_ptr(), ln.ranges.data_ptr(), stream=ln.stream)
+            # (round 6: with the 32-bit counts in search order beside the ranges where they are exact -- images below 2^32
+            # positions --, so that the scan that follows reads 4 instead of 16 bytes per k-mer)
+            g.search_hits_in_order(p.chars_ptr, p.off_ptr, K, p.q, ln.order_kmers.data_ptr(), ln.ranges.data_ptr(), stream=ln.stream,
+                                   d_order_counts=ln.counts.data_ptr() if narrow_counts else 0)
         elif narrow_counts:
             # the hit offsets are scanned from the counts and the locate reads the range of a k-mer only when it has hits: the
             # ranges of the others need not be written
@@ -1294,7 +1298,7 @@ def main():
             g.sort_hits_on_device(ln.hit_kmers.data_ptr(), ln.hit_ranges.data_ptr(), p.cap, ln.num_hits.data_ptr(), p.q, ln.stream)
             g.hit_offsets_on_device(0, ln.hit_ranges.data_ptr(), p.cap, ln.hit_off_c.data_ptr(), ln.scratch.data_ptr(), ln.stream)
             return ln.hit_ranges, ln.hit_off_c, p.cap
-        if form == "dense" and narrow_counts:
+        if form in ("dense", "order") and narrow_counts:
             g.hit_offsets_on_device(ln.counts.data_ptr(), 0, p.q, ln.hit_off.data_ptr(), ln.scratch.data_ptr(), ln.stream)
         else:
             g.hit_offsets_on_device(0, ln.ranges.data_ptr(), p.q, ln.hit_off.data_ptr(), ln.scratch.data_ptr(), ln.stream)

@@ -1445,10 +1445,17 @@ def test_results_in_search_order_are_a_permutation_with_exact_ranges(oracle, awf
     d_off = torch.from_numpy(offsets.view(np.int64).copy()).to(dev) if csr else None
     d_kmers = torch.full((Q,), -1, dtype=torch.int32, device=dev)
     d_ranges = torch.full((Q * 2,), 7, dtype=torch.int64, device=dev)
-    g.search_hits_in_order(d_chars.data_ptr(), d_off.data_ptr() if csr else 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr())
+    # (round 6: with the 32-bit counts in the same order -- awfmGpuSearchHitsInOrderCounts --, from which the hit offsets scan)
+    d_ocounts = torch.full((Q,), 7, dtype=torch.int32, device=dev)
+    g.search_hits_in_order(d_chars.data_ptr(), d_off.data_ptr() if csr else 0, K, Q, d_kmers.data_ptr(), d_ranges.data_ptr(),
+                           d_order_counts=d_ocounts.data_ptr())
     d_hoff = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
     d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(Q), dtype=torch.uint8, device=dev)
     total = g.hit_offsets(d_ranges.data_ptr(), Q, d_hoff.data_ptr(), d_scratch.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(d_ocounts.cpu().numpy().view(np.uint32), cnt[d_kmers.cpu().numpy().astype(np.int64)]), "counts in search order"
+    d_hoff2 = torch.zeros(Q + 1, dtype=torch.int64, device=dev)
+    assert g.hit_offsets_from_counts(d_ocounts.data_ptr(), Q, d_hoff2.data_ptr(), d_scratch.data_ptr()) == total and torch.equal(d_hoff2, d_hoff)
     d_pos = torch.zeros(max(total, 1), dtype=torch.int64, device=dev)
     g.locate(d_ranges.data_ptr(), d_hoff.data_ptr(), Q, total, d_pos.data_ptr())
     torch.cuda.synchronize()
