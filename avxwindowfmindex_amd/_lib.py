@@ -38,7 +38,7 @@ GPU_SYMBOLS = [
     "awfmGpuStreamPackedSparse", "awfmGpuStreamCharsSparse", "awfmGpuSearchHitsInOrder", "awfmGpuSearchHitsInOrderCounts",
     "awfmGpuSortHitsOnDevice", "awfmGpuHitOffsetsOnDevice", "awfmGpuLocateOnDevice", "awfmGpuLastOrderedSearchKernelMs", "awfmGpuOrderedKernelLog", "awfmGpuIndexDeepSeedBuildSeconds", "awfmGpuIndexDeepSeedTransientBytes", "awfmGpuIndexHasDenseSa", "awfmGpuIndexDenseSaBuildSeconds", "awfmGpuIndexLengthTableBytes", "awfmGpuIndexLengthTableBuildSeconds", "awfmGpuMixedLookupLineTally",
     "awfmGpuListLocateOnDevice", "awfmGpuLastLookupFront", "awfmGpuLastSearchWasExactLookup", "awfmGpuSynthPlantedQueriesUnique", "awfmGpuStreamRetire", "awfmGpuIndexDescribe", "awfmGpuIndexDeepSeedAllocSeconds", "awfmGpuAosLastStages", "awfmHostCopyGBs",
-    "awfmGpuOrderBuckets", "awfmGpuOrderKmers", "awfmGpuSearchOrderedRecords", "awfmGpuSearchGeneralRecords", "awfmGpuMergeBucketRuns",
+    "awfmGpuOrderBuckets", "awfmGpuOrderKmers", "awfmGpuSearchOrderedRecords", "awfmGpuSearchOrderedRecordsCounts", "awfmGpuSearchGeneralRecords", "awfmGpuMergeBucketRuns",
 ]
 # int sink(void *user, uint64 firstKmer, uint64 numKmers, const uint32 *counts, const uint64 *positions, uint64 numPositions)
 CHUNK_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.c_uint64)
@@ -175,6 +175,7 @@ def lib():
         "awfmGpuOrderBuckets": (C.c_uint32, [vp, C.c_uint32, u64]),
         "awfmGpuOrderKmers": (C.c_int, [vp, vp, C.c_uint32, u64, u64, u64, vp, vp, vp]),
         "awfmGpuSearchOrderedRecords": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, u64, vp, vp, vp]),
+        "awfmGpuSearchOrderedRecordsCounts": (C.c_int, [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, u64, vp, vp, vp, vp]),
         "awfmGpuMergeBucketRuns": (C.c_int, [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]),
         "awfmGpuSearchGeneralRecords": (C.c_int, [vp, vp, C.c_uint32, u64, u64, u64, vp, vp, vp, vp, vp]),
         "awfmGpuSortHits": (C.c_int, [vp, vp, vp, C.c_uint32, vp]),

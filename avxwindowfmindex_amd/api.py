@@ -503,11 +503,12 @@ class GpuIndex:
                                                                d_records, d_bucket_start, stream or None))
 
     def search_ordered_records(self, d_records, d_bucket_start, first_bucket, end_bucket, fixed_length, total_queries, d_order_kmers,
-                               d_order_ranges, stream=0):
-        """awfmGpuSearchOrderedRecords: the buckets [first, end) of a record array, results in that order"""
-        _check("awfmGpuSearchOrderedRecords", _lib.lib().awfmGpuSearchOrderedRecords(
+                               d_order_ranges, stream=0, d_order_counts=0):
+        """awfmGpuSearchOrderedRecords[Counts]: the buckets [first, end) of a record array, results in that order (d_order_counts:
+        the 32-bit counts in that order as well)"""
+        _check("awfmGpuSearchOrderedRecordsCounts", _lib.lib().awfmGpuSearchOrderedRecordsCounts(
             self.handle, d_records, d_bucket_start, first_bucket, end_bucket, fixed_length, total_queries, d_order_kmers, d_order_ranges,
-            stream or None))
+            d_order_counts or None, stream or None))
 
     def merge_bucket_runs(self, d_received, d_slice_at, d_slice_starts, num_slices, first_bucket, end_bucket, buckets, d_records,
                           d_bucket_start, stream=0):

@@ -1779,6 +1779,14 @@ extern "C" enum AwFmReturnCode awfmGpuMergeBucketRuns(AwFmGpuIndex *g, const uin
 extern "C" enum AwFmReturnCode awfmGpuSearchOrderedRecords(AwFmGpuIndex *g, const uint64_t *dRecords, const uint32_t *dBucketStart, uint32_t firstBucket,
                                                            uint32_t endBucket, uint32_t fixedLength, uint64_t totalQueries, uint32_t *dOrderKmers,
                                                            struct AwFmSearchRange *dOrderRanges, void *stream) {
+  return awfmGpuSearchOrderedRecordsCounts(g, dRecords, dBucketStart, firstBucket, endBucket, fixedLength, totalQueries, dOrderKmers, dOrderRanges, nullptr,
+                                           stream);
+}
+
+extern "C" enum AwFmReturnCode awfmGpuSearchOrderedRecordsCounts(AwFmGpuIndex *g, const uint64_t *dRecords, const uint32_t *dBucketStart,
+                                                                 uint32_t firstBucket, uint32_t endBucket, uint32_t fixedLength, uint64_t totalQueries,
+                                                                 uint32_t *dOrderKmers, struct AwFmSearchRange *dOrderRanges, uint32_t *dOrderCounts,
+                                                                 void *stream) {
   if (!g || !dRecords || !dBucketStart || !dOrderKmers || !dOrderRanges) {
     setError("awfmGpuSearchOrderedRecords: null argument");
     return AwFmNullPtrError;
@@ -1813,7 +1821,7 @@ extern "C" enum AwFmReturnCode awfmGpuSearchOrderedRecords(AwFmGpuIndex *g, cons
   const bool pair = pairSteps(g);
   enum AwFmReturnCode rc;
 #define SHARD_GO(NR, PR) \
-  launchOrderedKernel<NR, false, PR, false, true>(g, s, fixedLength, depth, table, totalQueries, dRecords, generalCount, nullptr, nullptr, nullptr, (const unsigned *)dBucketStart, fmt, &out)
+  launchOrderedKernel<NR, false, PR, false, true>(g, s, fixedLength, depth, table, totalQueries, dRecords, generalCount, nullptr, dOrderCounts, nullptr, (const unsigned *)dBucketStart, fmt, &out)
   if (awfmImageNarrow(g)) rc = pair ? SHARD_GO(true, true) : SHARD_GO(true, false);
   else rc = pair ? SHARD_GO(false, true) : SHARD_GO(false, false);
 #undef SHARD_GO

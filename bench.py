@@ -926,9 +926,15 @@ def seed_bucket_run(args, L, api, digest, shard, torch, np, dev, g, ix, d_chars,
         mine, full = s["keep"]
         m = s["m"]
         if m:
+            narrow = ix.bwt_length < (1 << 32)  # (32-bit counts are exact: the scan reads them instead of the ranges)
+            if narrow and s.get("c") is None or (narrow and s["c"].numel() < m):
+                s["c"] = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
             g.search_ordered_records(mine.data_ptr(), full.data_ptr(), cuts[rank], cuts[rank + 1], K, args.query_offset + batch_total,
-                                     s["k"].data_ptr(), s["r"].data_ptr(), sb)
-            g.hit_offsets_on_device(0, s["r"].data_ptr(), m, s["o"].data_ptr(), s["sc"].data_ptr(), sb)
+                                     s["k"].data_ptr(), s["r"].data_ptr(), sb, d_order_counts=s["c"].data_ptr() if narrow else 0)
+            if narrow:
+                g.hit_offsets_on_device(s["c"].data_ptr(), 0, m, s["o"].data_ptr(), s["sc"].data_ptr(), sb)
+            else:
+                g.hit_offsets_on_device(0, s["r"].data_ptr(), m, s["o"].data_ptr(), s["sc"].data_ptr(), sb)
             if s["p"] is None:
                 back_obj.synchronize()
                 hits = int(s["o"][m].item())
@@ -2280,9 +2286,15 @@ def main():
                     hits_r = int(d_o[m].item())
                     d_p = torch.empty(hits_r + hits_r // 8 + 64, dtype=torch.int64, device=dev)
 
+                    d_c = torch.empty(m, dtype=torch.int32, device=dev) if narrow_counts else None  # (counts in search order: what the scan reads)
+
                     def search_own():
-                        g.search_ordered_records(d_mine.data_ptr(), d_full.data_ptr(), c0, c1, K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st)
-                        g.hit_offsets_on_device(0, d_r.data_ptr(), m, d_o.data_ptr(), d_sc.data_ptr(), st)
+                        g.search_ordered_records(d_mine.data_ptr(), d_full.data_ptr(), c0, c1, K, first + Q, d_k.data_ptr(), d_r.data_ptr(), st,
+                                                 d_order_counts=d_c.data_ptr() if narrow_counts else 0)
+                        if narrow_counts:
+                            g.hit_offsets_on_device(d_c.data_ptr(), 0, m, d_o.data_ptr(), d_sc.data_ptr(), st)
+                        else:
+                            g.hit_offsets_on_device(0, d_r.data_ptr(), m, d_o.data_ptr(), d_sc.data_ptr(), st)
                         g.locate_on_device(d_r.data_ptr(), d_o.data_ptr(), m, d_p.numel(), d_p.data_ptr(), st)
 
                     def timed(fn):  # (the smaller of two timed loops, as time_piece)

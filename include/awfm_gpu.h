@@ -569,6 +569,11 @@ enum AwFmReturnCode awfmGpuMergeBucketRuns(AwFmGpuIndex *g, const uint64_t *dRec
 enum AwFmReturnCode awfmGpuSearchOrderedRecords(AwFmGpuIndex *g, const uint64_t *dRecords, const uint32_t *dBucketStart,
                                                 uint32_t firstBucket, uint32_t endBucket, uint32_t fixedLength, uint64_t totalQueries,
                                                 uint32_t *dOrderKmers, struct AwFmSearchRange *dOrderRanges, void *stream);
+/* ... with the 32-bit counts in that order as well (dOrderCounts may be NULL), as awfmGpuSearchHitsInOrderCounts */
+enum AwFmReturnCode awfmGpuSearchOrderedRecordsCounts(AwFmGpuIndex *g, const uint64_t *dRecords, const uint32_t *dBucketStart,
+                                                      uint32_t firstBucket, uint32_t endBucket, uint32_t fixedLength, uint64_t totalQueries,
+                                                      uint32_t *dOrderKmers, struct AwFmSearchRange *dOrderRanges, uint32_t *dOrderCounts,
+                                                      void *stream);
 /* the tail of a shard's own records through the general kernel: entries [dBucketStart[buckets], numQueries) of the outputs */
 enum AwFmReturnCode awfmGpuSearchGeneralRecords(AwFmGpuIndex *g, const uint8_t *dChars, uint32_t fixedLength, uint64_t numQueries,
                                                 uint64_t firstNumber, uint64_t totalQueries, const uint64_t *dRecords,

@@ -79,7 +79,12 @@ def test_seed_bucket_sharding_gives_the_reference_results(oracle, awfm, require_
         assert torch.equal(d_merged2, merged.to(dev)) and torch.equal(d_bs2, d_bs), "the merge kernel and torch's index arithmetic disagree"
         d_k = torch.full((m,), -1, dtype=torch.int32, device=dev)
         d_r = torch.zeros(m * 2, dtype=torch.int64, device=dev)
-        g.search_ordered_records(merged.data_ptr(), d_bs.data_ptr(), cuts[r], cuts[r + 1], K, Q, d_k.data_ptr(), d_r.data_ptr())
+        d_c = torch.full((m,), 7, dtype=torch.int32, device=dev)  # (the counts in the same order: awfmGpuSearchOrderedRecordsCounts)
+        g.search_ordered_records(merged.data_ptr(), d_bs.data_ptr(), cuts[r], cuts[r + 1], K, Q, d_k.data_ptr(), d_r.data_ptr(),
+                                 d_order_counts=d_c.data_ptr())
+        torch.cuda.synchronize()
+        rr_ = d_r.view(m, 2)
+        assert torch.equal(d_c.to(torch.int64), torch.where(rr_[:, 0] <= rr_[:, 1], rr_[:, 1] - rr_[:, 0] + 1, torch.zeros_like(rr_[:, 0])))
         d_off = torch.zeros(m + 1, dtype=torch.int64, device=dev)
         d_scratch = torch.zeros(awfm.GpuIndex.scan_scratch_bytes(m), dtype=torch.uint8, device=dev)
         total = g.hit_offsets(d_r.data_ptr(), m, d_off.data_ptr(), d_scratch.data_ptr())
