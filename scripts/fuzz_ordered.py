@@ -116,6 +116,21 @@ while time.time() < t_end:
         if not torch.equal(counts_only, counts):
             print(f"COUNTS-ONLY MISMATCH n={n} k={seed_k} deep={deep_k} Q={Q} {desc} lookup_first={lookup!r} mixed_lookup={mixed!r}", flush=True)
             sys.exit(1)
+        if g.search_hits_is_ordered(off_ptr != 0, K, Q):
+            # results in search order, with the counts in that order: a permutation of the batch whose entries are the dense
+            # results' (ranges of the k-mers with hits, every count)
+            ok_ = torch.full((Q,), -1, dtype=torch.int32, device=dev)
+            or_ = torch.full((Q * 2,), 9, dtype=torch.int64, device=dev)
+            oc_ = torch.full((Q,), 9, dtype=torch.int32, device=dev)
+            g.search_hits_in_order(chars_ptr, off_ptr, K, Q, ok_.data_ptr(), or_.data_ptr(), d_order_counts=oc_.data_ptr())
+            torch.cuda.synchronize()
+            ids = ok_.to(torch.int64)
+            hit_ = counts[ids] != 0
+            if not (int(torch.bincount(ids.clamp(0, Q - 1), minlength=Q).max().item()) == 1 and torch.equal(oc_, counts[ids])
+                    and torch.equal(or_.view(Q, 2)[hit_], hits.view(Q, 2)[ids][hit_])
+                    and bool((or_.view(Q, 2)[~hit_][:, 0] > or_.view(Q, 2)[~hit_][:, 1]).all())):
+                print(f"SEARCH-ORDER MISMATCH n={n} k={seed_k} deep={deep_k} Q={Q} {desc} lookup_first={lookup!r} mixed_lookup={mixed!r}", flush=True)
+                sys.exit(1)
         listed_ok = True
         if g.search_hits_is_ordered(off_ptr != 0, K, Q) and not fuzz_wide:
             # the list form of the same search, put in k-mer order, sized and located with nothing read back by the host
